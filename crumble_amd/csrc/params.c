@@ -1,0 +1,164 @@
+/*
+ * params.c -- host-side parameter block of the engine: defaults, presets,
+ * -y technology profiles, -k/-K quality lists, init_bins and BED collapsing.
+ * Mirrors the option handling of the reference's main()
+ * (/root/reference/snp_score.c:2144-2542) and bed.c:20-40 so that a caller who
+ * switches from crumble's getopt loop to this ABI gets identical settings.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+#include "../../include/crumble_hip.h"
+
+/* main()'s initialiser, snp_score.c:2152-2192 (== preset -9) */
+void crumble_params_default(crumble_params *p)
+{
+    memset(p, 0, sizeof(*p));
+    p->reduce_qual   = 1;      /* REDUCE_QUAL  snp:103 */
+    p->binary_qual   = 0;      /* BINARY_QUAL  snp:104 */
+    p->iSTR_mul      = 1.0;    /* I_STR_MUL    snp:128 */
+    p->iSTR_add      = 2;      /* I_STR_ADD    snp:129 */
+    p->sSTR_mul      = 0.0;    /* S_STR_MUL    snp:125 */
+    p->sSTR_add      = 0;      /* S_STR_ADD    snp:126 */
+    p->qlow          = 5;      /* QL           snp:94  */
+    p->qcutoff       = 25;     /* QM           snp:95  */
+    p->qhigh         = 40;     /* QH           snp:96  */
+    p->qcap          = 60;     /* QCAP         snp:97  */
+    p->min_mqual     = 0;      /* MIN_MQUAL    snp:100 */
+    p->min_qual_A    = 0;      /* MIN_QUAL_A   snp:110 */
+    p->min_indel_A   = 50;     /* MIN_INDEL_A  snp:111 */
+    p->min_discrep_A = 2.0;    /* MIN_DISCREP_A snp:112 */
+    p->min_qual_B    = 70;     /* MIN_QUAL_B   snp:115 */
+    p->min_indel_B   = 125;    /* MIN_INDEL_B  snp:116 */
+    p->min_discrep_B = 1.5;    /* MIN_DISCREP_B snp:117 */
+    p->indel_fract   = 0.0;    /* INDEL_FRACT  snp:107 */
+    p->clip_perc     = 0.2;    /* CLIP_PERC    snp:139 */
+    p->low_mqual_perc= 1.0;    /* LOW_MQUAL_PERC snp:133 */
+    p->ins_len_perc  = 1.0;    /* INS_LEN_PERC snp:136 */
+    p->over_depth    = 999.0;  /* OVER_DEPTH   snp:142 */
+    p->indel_ov_perc = 0.0;    /* INDEL_OVERLAP_PERC snp:145 */
+    p->pblock        = 8;      /* PBLOCK       snp:147 */
+    p->softclip      = 0;
+    p->perfect_col   = 0;
+}
+
+/* The 13 fields every preset overwrites (snp_score.c:2380-2482); columns are
+ * p Q D X M Z V P s_mul s_add i_mul i_add m. */
+int crumble_params_preset(crumble_params *p, int level)
+{
+    struct row { int lvl, pb, Q, D; double X, M, Z, V, P, smul; int sadd; double imul; int iadd, m; };
+    static const struct row rows[] = {
+        {9, 8, 70, 125, 1.5, 1.0, 1.0, 0.0, 999.0, 0.0, 0, 1.0, 2, 0},
+        {8, 0, 70, 125, 1.5, 1.0, 1.0, 0.0, 999.0, 0.0, 0, 1.0, 2, 0},
+        {7, 0, 75, 150, 1.0, 1.0, 1.0, 0.0, 999.0, 0.0, 0, 1.1, 2, 0},
+        {5, 0, 75, 150, 1.0, 0.5, 0.1, 0.5,   3.0, 0.0, 0, 1.1, 2, 0},
+        {3, 0, 75, 150, 1.0, 0.5, 0.1, 0.5,   3.0, 1.0, 0, 1.1, 2, 0},
+        {1, 0, 75, 150, 1.0, 0.5, 0.1, 0.5,   3.0, 1.0, 5, 2.0, 1, 5},
+    };
+    size_t i;
+    for (i = 0; i < sizeof(rows) / sizeof(rows[0]); i++) {
+        const struct row *r = &rows[i];
+        if (r->lvl != level) continue;
+        p->pblock = r->pb;  p->min_qual_B = r->Q;  p->min_indel_B = r->D;
+        p->min_discrep_B = r->X;  p->low_mqual_perc = r->M;  p->ins_len_perc = r->Z;
+        p->indel_ov_perc = r->V;  p->over_depth = r->P;
+        p->sSTR_mul = r->smul;  p->sSTR_add = r->sadd;
+        p->iSTR_mul = r->imul;  p->iSTR_add = r->iadd;  p->min_mqual = r->m;
+        return CRUMBLE_OK;
+    }
+    return CRUMBLE_EINVAL;   /* -2 -4 -6 do not exist (getopt string snp:2199) */
+}
+
+/* -y (snp_score.c:2316-2328).  The code, not the man page, is authoritative:
+ * pbccs sets qcutoff (not min_mqual) to 40. */
+int crumble_params_tech(crumble_params *p, const char *tech)
+{
+    if (!tech) return CRUMBLE_EINVAL;
+    if (strcasecmp(tech, "illumina") == 0) return CRUMBLE_OK;
+    if (strcasecmp(tech, "pbccs") == 0) {
+        p->indel_fract = 0.1;
+        p->min_discrep_B = 0.8;
+        p->qcutoff = 40;
+        p->qhigh = 60;
+        p->pblock = 16;
+        p->perfect_col = 1;
+        p->preserve_qual[93] = 1;
+        return CRUMBLE_OK;
+    }
+    return CRUMBLE_OK;       /* unknown names are silently ignored, as upstream */
+}
+
+/* -k / -K  "q1[-q2][,...]" (snp_score.c:2362-2375) */
+int crumble_params_keep_quals(crumble_params *p, const char *list, int really)
+{
+    char *endp;
+    if (!list) return CRUMBLE_EINVAL;
+    endp = (char *)list;
+    do {
+        long q1 = strtol(endp, &endp, 10), q2 = q1;
+        if (*endp == '-') q2 = strtol(endp + 1, &endp, 10);
+        do {
+            long q = q1 < 0 ? 0 : (q1 > 255 ? 255 : q1);
+            p->preserve_qual[q] = 1 + (really != 0);
+        } while (++q1 <= q2);
+    } while (*endp++ == ',');
+    return CRUMBLE_OK;
+}
+
+/* init_bins (snp_score.c:234-247) */
+void crumble_init_bins(const crumble_params *p, uint8_t bin2[256])
+{
+    int i;
+    for (i = 0; i < p->qcutoff && i < 256; i++) bin2[i] = (uint8_t)p->qlow;
+    for (; i < 256; i++) bin2[i] = (uint8_t)p->qhigh;
+    for (i = 0; i < 256; i++)
+        if (p->preserve_qual[i] > 1) bin2[i] = (uint8_t)i;
+}
+
+/* bed_collapse (bed.c:20-40): sort by (tid,start); a region starts a new entry
+ * when it begins beyond the end of the PREVIOUS INPUT region (not of the merged
+ * one) -- reproduced literally, because the monotone cursor of the column loop
+ * (snp_score.c:1443-1463) observes the difference.  The reference then copies
+ * one element past the input as an extra region (uninitialised memory,
+ * SURVEY.md Q15); that phantom entry is not reproduced. */
+typedef struct { int32_t tid, start, end; } bed3;
+static int bed3_cmp(const void *a, const void *b)
+{
+    const bed3 *x = a, *y = b;
+    if (x->tid != y->tid) return x->tid - y->tid;
+    return x->start - y->start;
+}
+int crumble_bed_collapse(int32_t *tid, int32_t *start, int32_t *end, int n)
+{
+    bed3 *r;
+    int i, j, last_tid = -1, last_end = -1;
+    if (n <= 0) return 0;
+    r = malloc(n * sizeof(*r));
+    if (!r) return CRUMBLE_ENOMEM;
+    for (i = 0; i < n; i++) { r[i].tid = tid[i]; r[i].start = start[i]; r[i].end = end[i]; }
+    qsort(r, n, sizeof(*r), bed3_cmp);
+    for (i = j = 0; i < n; i++) {
+        if (r[i].tid > last_tid || r[i].start > last_end) r[j++] = r[i];
+        else if (r[i].end > r[j - 1].end) r[j - 1].end = r[i].end;
+        last_tid = r[i].tid;
+        last_end = r[i].end;
+    }
+    for (i = 0; i < j; i++) { tid[i] = r[i].tid; start[i] = r[i].start; end[i] = r[i].end; }
+    free(r);
+    return j;
+}
+
+const char *crumble_hip_strerror(int err)
+{
+    switch (err) {
+    case CRUMBLE_OK:        return "ok";
+    case CRUMBLE_EINVAL:    return "invalid argument or unsupported parameter";
+    case CRUMBLE_ENOMEM:    return "out of memory";
+    case CRUMBLE_EHIP:      return "HIP runtime error";
+    case CRUMBLE_EUNSORTED: return "reads are not coordinate sorted";
+    case CRUMBLE_EOVERFLOW: return "internal work list overflow";
+    case CRUMBLE_ENODEVICE: return "no usable HIP device (there is no CPU fallback)";
+    case CRUMBLE_ERCCL:     return "RCCL error";
+    default:                return "unknown error";
+    }
+}

@@ -1,0 +1,221 @@
+"""Loader + object wrapper for libcrumble_hip.so (the C ABI of include/crumble_hip.h).
+
+There is deliberately no fallback here: if the HIP library or a GPU is missing
+the calls raise.  The CPU oracle lives in oracle/ and is only imported by tests,
+smoke() and bench.py's cpu_baseline leg.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .capi import (Params, Batch, Column, HostBatch, COLUMN_DTYPE, ST_N, ROOT, HERE)
+
+LIB_PATH = os.path.join(HERE, "libcrumble_hip.so")
+_lib = None
+
+
+class CrumbleError(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = code
+        msg = lib().crumble_hip_strerror(code).decode()
+        try:
+            detail = lib().crumble_hip_last_error().decode()
+        except Exception:
+            detail = ""
+        super().__init__(f"{where}: {msg} ({code}) {detail}".strip())
+
+
+def build_library(verbose=False):
+    """make -C crumble_amd/csrc (hipcc --offload-arch=gfx950; works without a GPU)."""
+    r = subprocess.run(["make", "-C", os.path.join(HERE, "csrc")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or r.returncode:
+        print(r.stdout)
+    if r.returncode:
+        raise RuntimeError("building libcrumble_hip.so failed")
+    return LIB_PATH
+
+
+def load_library(path=None):
+    global _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)")
+    L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    PP = C.POINTER(Params)
+    sig = {
+        "crumble_params_default": (None, [PP]),
+        "crumble_params_preset": (C.c_int, [PP, C.c_int]),
+        "crumble_params_tech": (C.c_int, [PP, C.c_char_p]),
+        "crumble_params_keep_quals": (C.c_int, [PP, C.c_char_p, C.c_int]),
+        "crumble_init_bins": (None, [PP, vp]),
+        "crumble_bed_collapse": (C.c_int, [vp, vp, vp, C.c_int]),
+        "crumble_hip_create": (vp, [PP, C.c_int, C.POINTER(C.c_int)]),
+        "crumble_hip_destroy": (None, [vp]),
+        "crumble_hip_contig": (C.c_int, [vp, C.POINTER(Batch), vp, vp, vp]),
+        "crumble_hip_upload": (C.c_int, [vp, C.POINTER(Batch)]),
+        "crumble_hip_run": (C.c_int, [vp]),
+        "crumble_hip_download": (C.c_int, [vp, vp, vp, vp]),
+        "crumble_hip_kernel_times": (C.c_int, [vp, vp, vp, vp, C.c_int]),
+        "crumble_hip_stats_devptr": (vp, [vp]),
+        "crumble_hip_stats_reset": (C.c_int, [vp]),
+        "crumble_hip_stats_read": (C.c_int, [vp, vp]),
+        "crumble_hip_stats_allreduce": (C.c_int, [vp, vp]),
+        "crumble_hip_columns": (i64, [vp, vp, i64]),
+        "crumble_hip_mask_lc": (C.c_int, [vp, i64, vp, vp, vp, vp, vp]),
+        "crumble_hip_pblock": (C.c_int, [vp, i64, vp, vp]),
+        "crumble_hip_strerror": (C.c_char_p, [C.c_int]),
+        "crumble_hip_last_error": (C.c_char_p, []),
+    }
+    for name, (res, args) in sig.items():
+        try:
+            f = getattr(L, name)
+        except AttributeError:        # tests/test_abi.py checks completeness
+            continue
+        f.restype, f.argtypes = res, args
+    _lib = L
+    return L
+
+
+def lib():
+    return _lib if _lib is not None else load_library()
+
+
+EXPORTED = [
+    "crumble_params_default", "crumble_params_preset", "crumble_params_tech",
+    "crumble_params_keep_quals", "crumble_init_bins", "crumble_bed_collapse",
+    "crumble_hip_create", "crumble_hip_destroy", "crumble_hip_contig",
+    "crumble_hip_upload", "crumble_hip_run", "crumble_hip_download",
+    "crumble_hip_kernel_times", "crumble_hip_stats_devptr", "crumble_hip_stats_reset",
+    "crumble_hip_stats_read", "crumble_hip_stats_allreduce", "crumble_hip_columns",
+    "crumble_hip_mask_lc", "crumble_hip_pblock", "crumble_hip_strerror",
+    "crumble_hip_last_error",
+]
+
+
+def default_params():
+    p = Params()
+    lib().crumble_params_default(C.byref(p))
+    return p
+
+
+def preset_params(level=9, tech=None, keep=None, really_keep=None, **over):
+    """crumble -<level> [-y tech] [-k list] [-K list] plus field overrides."""
+    p = default_params()
+    if level is not None:
+        rc = lib().crumble_params_preset(C.byref(p), int(level))
+        if rc:
+            raise CrumbleError(rc, f"preset -{level}")
+    if tech:
+        lib().crumble_params_tech(C.byref(p), tech.encode())
+    if keep:
+        lib().crumble_params_keep_quals(C.byref(p), str(keep).encode(), 0)
+    if really_keep:
+        lib().crumble_params_keep_quals(C.byref(p), str(really_keep).encode(), 1)
+    for k, v in over.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def _vp(a):
+    return a.ctypes.data if a is not None else None
+
+
+class Engine:
+    """One crumble_hip handle (one GPU, one stream)."""
+
+    def __init__(self, params, device=0):
+        err = C.c_int(0)
+        self._p = params
+        self.h = lib().crumble_hip_create(C.byref(params), int(device), C.byref(err))
+        if not self.h:
+            raise CrumbleError(err.value, "crumble_hip_create")
+        self._batch = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().crumble_hip_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, rc, where):
+        if rc:
+            raise CrumbleError(rc, where)
+
+    def upload(self, hb: HostBatch):
+        self._batch = hb
+        self._bstruct = hb.struct()
+        self._chk(lib().crumble_hip_upload(self.h, C.byref(self._bstruct)), "upload")
+
+    def run(self):
+        self._chk(lib().crumble_hip_run(self.h), "run")
+
+    def download(self, want_flags=True, want_stats=True):
+        hb = self._batch
+        q = np.empty(max(hb.n_bases, 1), np.uint8)
+        f = np.zeros(max(hb.n_reads, 1), np.uint8) if want_flags else None
+        s = np.zeros(ST_N, np.int64) if want_stats else None
+        self._chk(lib().crumble_hip_download(self.h, _vp(q), _vp(f), _vp(s)), "download")
+        return q[:hb.n_bases], (f[:hb.n_reads] if f is not None else None), s
+
+    def contig(self, hb: HostBatch):
+        """crumble_hip_contig: qualities, per-read flags, stats."""
+        b = hb.struct()
+        q = np.empty(max(hb.n_bases, 1), np.uint8)
+        f = np.zeros(max(hb.n_reads, 1), np.uint8)
+        s = np.zeros(ST_N, np.int64)
+        self._batch = hb
+        self._chk(lib().crumble_hip_contig(self.h, C.byref(b), _vp(q), _vp(f), _vp(s)),
+                  "contig")
+        return q[:hb.n_bases], f[:hb.n_reads], s
+
+    def columns(self):
+        n = lib().crumble_hip_columns(self.h, None, 0)
+        if n < 0:
+            raise CrumbleError(int(n), "columns")
+        cols = np.zeros(max(n, 1), COLUMN_DTYPE)
+        lib().crumble_hip_columns(self.h, _vp(cols), n)
+        return cols[:n]
+
+    def kernel_times(self, maxk=64):
+        names = (C.c_char_p * maxk)()
+        ms = np.zeros(maxk, np.float32)
+        by = np.zeros(maxk, np.float64)
+        n = lib().crumble_hip_kernel_times(self.h, C.cast(names, C.c_void_p), _vp(ms),
+                                           _vp(by), maxk)
+        return [(names[i].decode(), float(ms[i]), float(by[i])) for i in range(n)]
+
+    def mask_lc(self, read_idx, qpos1, is_indel):
+        r = np.ascontiguousarray(read_idx, np.int64)
+        q = np.ascontiguousarray(qpos1, np.int32)
+        k = np.ascontiguousarray(is_indel, np.uint8)
+        lo = np.zeros(len(r), np.int32)
+        hi = np.zeros(len(r), np.int32)
+        self._chk(lib().crumble_hip_mask_lc(self.h, len(r), _vp(r), _vp(q), _vp(k),
+                                            _vp(lo), _vp(hi)), "mask_lc")
+        return lo, hi
+
+    def pblock(self, seq_off, quals):
+        so = np.ascontiguousarray(seq_off, np.int64)
+        q = np.ascontiguousarray(quals, np.uint8).copy()
+        self._chk(lib().crumble_hip_pblock(self.h, len(so) - 1, _vp(so), _vp(q)), "pblock")
+        return q
+
+    def stats_devptr(self):
+        return lib().crumble_hip_stats_devptr(self.h)
+
+    def stats_reset(self):
+        self._chk(lib().crumble_hip_stats_reset(self.h), "stats_reset")
+
+    def stats_read(self):
+        s = np.zeros(ST_N, np.int64)
+        self._chk(lib().crumble_hip_stats_read(self.h, _vp(s)), "stats_read")
+        return s

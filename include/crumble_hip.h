@@ -1,0 +1,219 @@
+/*
+ * crumble_hip.h -- C ABI of the MI355X-native quality-quantisation engine.
+ *
+ * This is the drop-in boundary for crumble's column engine: everything that
+ * reference crumble does inside the body of transcode()'s pileup loop
+ * (/root/reference/snp_score.c:1437-1983) plus the per-read epilogue of
+ * flush_bam_list() (snp_score.c:1090-1100: strip 0x80, P-block) is done by
+ * crumble_hip_contig() on one GPU for one reference contig at a time.
+ * File I/O (htslib sam_read1/sam_write1), aux-tag purging and the CLI stay on
+ * the host; see INTEGRATION.md for the binding a crumble maintainer would add.
+ *
+ * Plain C, plain pointers and sizes; no HIP or torch types cross this ABI.
+ * The caller owns every host buffer; the library owns every device buffer.
+ * All entry points return 0 on success or a negative CRUMBLE_E* code and never
+ * abort (the reference asserts / aborts instead: snp_score.c:1075,1830,1842).
+ */
+#ifndef CRUMBLE_HIP_H
+#define CRUMBLE_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ errors */
+#define CRUMBLE_OK            0
+#define CRUMBLE_EINVAL       -1   /* bad argument / unsupported parameter     */
+#define CRUMBLE_ENOMEM       -2   /* host or device allocation failed         */
+#define CRUMBLE_EHIP         -3   /* HIP runtime error (see strerror)         */
+#define CRUMBLE_EUNSORTED    -4   /* reads not coordinate sorted (snp:1075)   */
+#define CRUMBLE_EOVERFLOW    -5   /* internal work-list capacity exceeded     */
+#define CRUMBLE_ENODEVICE    -6   /* no usable GPU: the product never falls   */
+                                  /* back to a CPU path                       */
+#define CRUMBLE_ERCCL        -7   /* RCCL failure in the stats all-reduce     */
+
+/* --------------------------------------------------------------- parameters */
+/*
+ * POD restatement of the hot-path fields of cram_lossy_params
+ * (snp_score.c:185-226) plus the file-scope preserve_qual[] table
+ * (snp_score.c:232, filled by -k/-K snp_score.c:2362-2375 and -y pbccs
+ * snp_score.c:2326).  Fields that only drive host plumbing (region, bed_fn,
+ * aux white/black lists, BD/BI binning, verbose, noPG, bed_fp) are not here.
+ */
+typedef struct crumble_params {
+    int32_t reduce_qual;      /* -L  snp:103  */
+    int32_t binary_qual;      /* -B  snp:104  */
+    int32_t iSTR_add;         /* -i  snp:129  */
+    int32_t sSTR_add;         /* -s  snp:126  */
+    double  iSTR_mul;         /* -i  snp:128  */
+    double  sSTR_mul;         /* -s  snp:125  */
+    int32_t qlow;             /* -l  snp:94   */
+    int32_t qcutoff;          /* -c  snp:95   */
+    int32_t qhigh;            /* -u  snp:96   */
+    int32_t qcap;             /* -U  snp:97   */
+    int32_t min_mqual;        /* -m  snp:100  */
+    int32_t min_qual_A;       /* -q  snp:110  */
+    int32_t min_indel_A;      /* -d  snp:111  */
+    int32_t min_qual_B;       /* -Q  snp:115  */
+    int32_t min_indel_B;      /* -D  snp:116  */
+    int32_t pblock;           /* -p  snp:147  */
+    int32_t softclip;         /* -S           */
+    int32_t perfect_col;      /* -N           */
+    double  indel_fract;      /* -Y  snp:107  */
+    double  min_discrep_A;    /* -x  snp:112  */
+    double  min_discrep_B;    /* -X  snp:117  */
+    double  low_mqual_perc;   /* -M  snp:133  */
+    double  clip_perc;        /* -C  snp:139  */
+    double  ins_len_perc;     /* -Z  snp:136  */
+    double  over_depth;       /* -P  snp:142  */
+    double  indel_ov_perc;    /* -V  snp:145  */
+    uint8_t preserve_qual[256]; /* 0 none, 1 = -k, 2 = -K */
+} crumble_params;
+
+/* Defaults of main() (snp_score.c:2152-2192) == level 9. */
+void crumble_params_default(crumble_params *p);
+/* Presets -1 -3 -5 -7 -8 -9 (snp_score.c:2380-2482); others -> CRUMBLE_EINVAL. */
+int  crumble_params_preset(crumble_params *p, int level);
+/* -y illumina | pbccs (snp_score.c:2316-2328). */
+int  crumble_params_tech(crumble_params *p, const char *tech);
+/* -k / -K quality list "93" or "2-5,40" (snp_score.c:2362-2375); really=1 for -K. */
+int  crumble_params_keep_quals(crumble_params *p, const char *list, int really);
+/* init_bins() (snp_score.c:234-247). */
+void crumble_init_bins(const crumble_params *p, uint8_t bin2[256]);
+
+/* ------------------------------------------------------------------ batches */
+/*
+ * One reference contig worth of reads in SoA form, coordinate sorted exactly
+ * as the BAM was (file order == (pos, arrival) order, snp_score.c:863-872).
+ * This replaces the bam1_t stream that pileup_callback() (snp_score.c:1113)
+ * pulls from htslib.  Reads that htslib's pileup never shows crumble
+ * (BAM_FUNMAP, or no reference-consuming CIGAR op: snp_score.c:1130-1149) may
+ * be present: they are passed through like the reference's b_hist entries
+ * (only the P-block epilogue touches them).  Reads carrying
+ * SECONDARY/QCFAIL/DUP are handled the same way (extension; the reference
+ * asserts on them).  tid == -1 marks the trailing
+ * unmapped block (snp_score.c:1998-2012): every read is passed through.
+ */
+typedef struct crumble_batch {
+    int32_t  tid;
+    int64_t  n_reads;
+    const int32_t  *pos;      /* [n_reads] 0-based leftmost coordinate          */
+    const uint8_t  *mapq;     /* [n_reads]                                      */
+    const uint16_t *flag;     /* [n_reads] BAM flag                             */
+    const int64_t  *seq_off;  /* [n_reads+1] first base of read i in bases/quals*/
+    const int64_t  *cig_off;  /* [n_reads+1] first op of read i in cigar        */
+    const uint32_t *cigar;    /* BAM encoding: len<<4 | op (MIDNSHP=X)          */
+    const uint8_t  *bases;    /* one nt16 code (0..15, "=ACMGRSVTWYHKDBN") per  */
+                              /* base; l_qseq(i) = seq_off[i+1]-seq_off[i]      */
+    const uint8_t  *quals;    /* phred, one byte per base (must be < 128)       */
+    int32_t  n_bed;           /* keep-regions of THIS contig, after             */
+    const int32_t *bed_start; /* crumble_bed_collapse() (bed.c:20-40)           */
+    const int32_t *bed_end;
+} crumble_batch;
+
+/* per-read output flags */
+#define CRUMBLE_RF_KEEP     1   /* bam_sorted_item.keep_qual was set (snp:1847) */
+#define CRUMBLE_RF_NOPBLOCK 2   /* flag bit 15 was set (snp:1890-1892)          */
+#define CRUMBLE_RF_PASSTHRU 4   /* read never entered the pileup                */
+
+/* ------------------------------------------------------------------- stats  */
+/* int64 vector: the reference's counters (snp_score.c:1292-1311), read/base
+ * totals and a 256-bin histogram of the output qualities (new: this is what
+ * the multi-GPU all-reduce sums). */
+enum {
+    CRUMBLE_ST_COLUMNS = 0,
+    CRUMBLE_ST_HET_A, CRUMBLE_ST_HET_QUAL_A, CRUMBLE_ST_HOM_A, CRUMBLE_ST_HOM_QUAL_A,
+    CRUMBLE_ST_DISCREP_A,
+    CRUMBLE_ST_HET_B, CRUMBLE_ST_HET_QUAL_B, CRUMBLE_ST_HOM_B, CRUMBLE_ST_HOM_QUAL_B,
+    CRUMBLE_ST_DISCREP_B,
+    CRUMBLE_ST_DIFF, CRUMBLE_ST_INDEL, CRUMBLE_ST_INDEL_QUAL,
+    CRUMBLE_ST_LOW_MQUAL_PERC, CRUMBLE_ST_CLIP_PERC, CRUMBLE_ST_INS_LEN_PERC,
+    CRUMBLE_ST_INDEL_OV_PERC, CRUMBLE_ST_OVER_DEPTH,
+    CRUMBLE_ST_READS, CRUMBLE_ST_BASES, CRUMBLE_ST_BASES_CHANGED,
+    CRUMBLE_ST_TRIGGERS, CRUMBLE_ST_TOO_DEEP,
+    CRUMBLE_ST_HIST0 = 32,          /* [32..287] output quality histogram */
+    CRUMBLE_ST_N = 288
+};
+
+/* ----------------------------------------------------------- BED (bed.c)   */
+/* Sort + merge exactly like bed_collapse() (bed.c:20-40) minus its phantom
+ * trailing entry.  In place; returns the new count. */
+int crumble_bed_collapse(int32_t *tid, int32_t *start, int32_t *end, int n);
+
+/* ------------------------------------------------------------ the engine   */
+typedef struct crumble_hip crumble_hip;
+
+/* Creates an engine bound to HIP device `device`. Builds the log-probability
+ * tables of consensus_init() (snp_score.c:378-489) on the host with libm and
+ * uploads them. *err receives the error code when NULL is returned. */
+crumble_hip *crumble_hip_create(const crumble_params *p, int device, int *err);
+void         crumble_hip_destroy(crumble_hip *h);
+
+/* Replaces one contig's worth of transcode() loop iterations + flush:
+ *   qual_out[seq_off[n_reads]]  final quality bytes (0x80 stripped, P-blocked)
+ *   read_flags_out[n_reads]     CRUMBLE_RF_* (may be NULL)
+ *   stats[CRUMBLE_ST_N]         ADDED to (caller zeroes) (may be NULL)
+ * = crumble_hip_upload + crumble_hip_run + crumble_hip_download. */
+int crumble_hip_contig(crumble_hip *h, const crumble_batch *b,
+                       uint8_t *qual_out, uint8_t *read_flags_out, int64_t *stats);
+
+/* The three stages separately, so callers (and bench.py) can keep a batch
+ * resident in HBM and time only the kernels. */
+int crumble_hip_upload(crumble_hip *h, const crumble_batch *b);
+int crumble_hip_run(crumble_hip *h);      /* asynchronous launches + one sync */
+int crumble_hip_download(crumble_hip *h, uint8_t *qual_out,
+                         uint8_t *read_flags_out, int64_t *stats);
+
+/* HIP-event timings of the last crumble_hip_run(): names[i] / ms[i] for up to
+ * `max` kernels (returns the number filled).  bytes[i] (may be NULL) receives
+ * the algorithmic bytes that launch is charged with. */
+int crumble_hip_kernel_times(crumble_hip *h, const char **names, float *ms,
+                             double *bytes, int max);
+
+/* Accumulated device-side stats vector (int64[CRUMBLE_ST_N]) of this engine:
+ * a raw device pointer so torch.distributed / RCCL can all-reduce it in place. */
+void *crumble_hip_stats_devptr(crumble_hip *h);
+int   crumble_hip_stats_reset(crumble_hip *h);
+int   crumble_hip_stats_read(crumble_hip *h, int64_t *stats);
+/* Sums the stats vector over all ranks of an RCCL communicator (ncclComm_t
+ * passed as void*). The only collective on the path. */
+int   crumble_hip_stats_allreduce(crumble_hip *h, void *nccl_comm);
+
+/* Operator-level seams (used by the parity tests; same maths as the engine):
+ *  calculate_consensus_pileup (snp:533) over every column of a batch ->
+ *  per-position records; find_STR/mask_LC_regions (str_finder.c:135, snp:1230)
+ *  over explicit (read, qpos+1, is_indel) queries; pblock (snp:803) per read. */
+typedef struct crumble_column {        /* one pileup column, after step 18 of  */
+    int32_t pos;                       /* SURVEY.md App. A.2                   */
+    int32_t n_plp;
+    int32_t score;                     /* sB (or sA)  snp:1575-1591            */
+    uint8_t call1, call2;              /* allele index 0..5 (A C G T * N)      */
+    uint8_t preserve;                  /* 0..3 (bit1 = BED)                    */
+    uint8_t perfect;
+    uint8_t keep_qual;
+    uint8_t trigger;                   /* `indel` != 0  snp:1870               */
+    uint8_t window;                    /* min_pos != INT_MAX  snp:1880         */
+    uint8_t skipped;                   /* 1 all-refskip, 2 too deep            */
+    int32_t min_pos2;                  /* valid when trigger                   */
+} crumble_column;
+/* Fills cols[0..max) with the columns of the uploaded batch in position order
+ * after crumble_hip_run(); returns the number of columns (may exceed max). */
+int64_t crumble_hip_columns(crumble_hip *h, crumble_column *cols, int64_t max);
+
+int crumble_hip_mask_lc(crumble_hip *h, int64_t n, const int64_t *read_idx,
+                        const int32_t *qpos1, const uint8_t *is_indel,
+                        int32_t *lo, int32_t *hi);
+int crumble_hip_pblock(crumble_hip *h, int64_t n_reads, const int64_t *seq_off,
+                       uint8_t *quals /* in/out, host */);
+
+const char *crumble_hip_strerror(int err);
+/* Text of the last HIP/RCCL runtime error seen by this thread. */
+const char *crumble_hip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRUMBLE_HIP_H */
