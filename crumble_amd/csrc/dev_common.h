@@ -1,0 +1,123 @@
+/*
+ * dev_common.h -- structures shared by the HIP kernels and the host layer.
+ */
+#ifndef CRUMBLE_DEV_COMMON_H
+#define CRUMBLE_DEV_COMMON_H
+
+#include <stdint.h>
+#include <limits.h>
+#include <string.h>
+
+#ifndef CRUMBLE_EMU
+#include <hip/hip_runtime.h>
+#define CRUMBLE_LAUNCH(kern, grid, block, stream, ...) \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
+/* kernels whose lanes never communicate (the CPU test emulator may run their
+ * lanes sequentially); on the GPU both forms are the same launch */
+#define CRUMBLE_LAUNCH_INDEP CRUMBLE_LAUNCH
+#endif
+
+#define HD __host__ __device__ __forceinline__
+
+/* Device copy of crumble_params plus derived values. */
+struct DParams {
+    int32_t reduce_qual, binary_qual, iSTR_add, sSTR_add;
+    double  iSTR_mul, sSTR_mul;
+    int32_t qlow, qcutoff, qhigh, qcap, min_mqual;
+    int32_t min_qual_A, min_indel_A, min_qual_B, min_indel_B;
+    int32_t pblock, softclip, perfect_col;
+    double  indel_fract, min_discrep_A, min_discrep_B, low_mqual_perc;
+    double  clip_perc, ins_len_perc, over_depth, indel_ov_perc;
+    int32_t str_snp;        /* sSTR_add || sSTR_mul          snp:1345 */
+    int32_t any_preserve;   /* any preserve_qual[] non-zero            */
+    uint8_t preserve_qual[256];
+    uint8_t bin2[256];      /* init_bins                     snp:234  */
+};
+
+/* Host-built (libm) tables: consensus_init snp:378-489 + statics snp:560-575. */
+struct DTables {
+    double MMd[101];        /* pMM[q] - p__[q]   snp:645 */
+    double _Md[101];        /* p_M[q] - p__[q]   snp:646 */
+    double omq[101];        /* 1 - q2p[q]        snp:651 */
+    double lprior15[15];
+    double e_tab[1001];     /* exp(i),    i = -500..500  (index +500) */
+    double e_tab2[1001];    /* exp(i/10), i = -500..500  (index +500) */
+    uint8_t adj[65536];     /* [mapq][qual] -> adjusted quality, snp:632-638 */
+};
+
+/* One reference-consuming CIGAR op (M,=,X / D / N) of a read, with what
+ * htslib's resolve_cigar2 would report on its last column. */
+#define SEG_M 0u
+#define SEG_D 1u
+#define SEG_N 2u
+struct Seg {
+    int32_t  roff;          /* reference offset from the read's pos          */
+    int32_t  qstart;        /* query index of its first base (M) or of the   */
+                            /* next base (D/N)                               */
+    uint32_t len_type;      /* len | type << 30                              */
+    int32_t  indel_after;   /* bam_pileup1_t.indel on the op's last column   */
+};
+HD int32_t  seg_len(const Seg &s)  { return (int32_t)(s.len_type & 0x3fffffffu); }
+HD uint32_t seg_type(const Seg &s) { return s.len_type >> 30; }
+
+/* Device-resident batch. Positions are stored relative to p0. */
+struct DBatch {
+    int64_t n_reads, n_bases;
+    int32_t p0;             /* first pileup position                         */
+    int32_t L;              /* number of positions covered: [p0, p0+L)       */
+    int32_t n_tiles;        /* ceil(L/64)                                    */
+    int32_t n_bed;
+    const int32_t *pos, *end;       /* end = pos + reflen; == pos if passthru */
+    const uint8_t *mapq, *inplp;
+    const int64_t *seq_off, *cig_off, *seg_off;
+    const uint32_t *cigar;
+    const Seg *segs;
+    const uint8_t *bases, *quals;
+    const int32_t *tile_lo, *tile_hi;
+    const int32_t *bed_start, *bed_end, *bed_pmax;
+};
+
+/* per-position column record */
+#define CR_A1(r)        ((r) & 7u)
+#define CR_A2(r)        (((r) >> 3) & 7u)
+#define CR_PRESERVE(r)  (((r) >> 6) & 3u)
+#define CR_PERFECT      (1u << 8)
+#define CR_KEEP         (1u << 9)
+#define CR_TRIG         (1u << 10)
+#define CR_WIN          (1u << 11)
+#define CR_COUNTED      (1u << 12)   /* column went through the full engine  */
+#define CR_ALLREFSKIP   (1u << 13)
+#define CR_TOODEEP      (1u << 14)
+#define CR_HASINS       (1u << 15)   /* indel_sz > 0: needs the histogram    */
+#define CR_EXISTS       (1u << 16)   /* n_plp > 0                            */
+#define CR_SCAN         (1u << 17)   /* indel_cnt >= n_plp*indel_fract       */
+#define CR_SKIP         (CR_ALLREFSKIP | CR_TOODEEP)
+
+/* one STR/indel trigger (snp:1718-1756) */
+struct TrigItem {
+    int32_t read;
+    int32_t qpos1_kind;     /* (qpos+1) | is_indel << 30                     */
+    int32_t lo, hi;         /* mask_LC_regions result (INT_MAX,0 = none)     */
+};
+
+struct ScanVal {            /* per-position quantities that need prefix sums */
+    int64_t depth;          /* sum of n_plp over counted columns             */
+    int32_t cols;           /* counted columns                               */
+    int32_t trigcols;       /* columns with >= 1 trigger                     */
+    int32_t items;          /* triggers                                      */
+    int32_t ins;            /* columns needing the indel-size histogram      */
+};
+
+struct Epoch {              /* running-average state of snp:1490-1491,1684   */
+    int64_t ord_start;      /* ordinal of the first counted column           */
+    int64_t tc_start;       /* total_col before that column                  */
+    int64_t td_start;       /* total_depth before that column                */
+    int64_t dpre_start;     /* exclusive depth prefix at that column         */
+};
+#define MAX_EPOCHS 8192
+
+#define MAX_DEPTH_COL 20000     /* MAX_DEPTH snp:92   */
+#define MASK_WIN_DEV  250       /* MASK_WIN  snp:1229 */
+#define STR_CAP       640       /* live repeats per window   */
+
+#endif

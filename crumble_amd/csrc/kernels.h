@@ -1,0 +1,968 @@
+/*
+ * kernels.h -- the HIP kernels of the column engine (gfx950 / CDNA4).
+ *
+ * Re-decomposition of transcode()'s sequential loop body
+ * (/root/reference/snp_score.c:1437-1983) into data-parallel passes that give
+ * bit-identical results (DESIGN.md "Kernels"):
+ *
+ *   k_columns      one lane per pileup column: consensus (snp:533-797) with the
+ *                  per-genotype FP64 sums taken in file order, column decisions
+ *                  (snp:1575-1649) and the O(depth) heuristics (snp:1658-1773)
+ *   scan_*         prefix sums over positions (running depth, work-list offsets)
+ *   k_epochs/k_overdepth   running-average over-depth test (snp:1490,1673-1687)
+ *   k_inshist      indel-length histogram test (snp:1708-1713,1777-1819)
+ *   k_emit         ordered list of STR triggers per column (snp:1718-1730)
+ *   k_str          find_STR/mask_LC_regions per trigger (str_finder.c:34-189,
+ *                  snp:1230-1290)
+ *   k_fold_*       min_pos/max_pos window state across columns (snp:1508-1511,
+ *                  1741-1755), parallel over provably independent chains
+ *   k_replay       per-read replay of the per-base loop (snp:1822-1920) and the
+ *                  retirement/flush epilogue (snp:1939, 1093-1096)
+ *   k_pblock       P-block (snp:803-834)
+ *   k_stats        output-quality histogram
+ *
+ * All floating point here must round exactly like the reference's separate C
+ * double operations: the translation unit is compiled with -ffp-contract=off
+ * and without fast-math.
+ */
+#ifndef CRUMBLE_KERNELS_H
+#define CRUMBLE_KERNELS_H
+
+#include "dev_common.h"
+#include <float.h>
+#include <math.h>
+
+#ifdef CRUMBLE_EMU
+#define UNIFORM(x) (x)
+#else
+#define UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+
+typedef unsigned long long u64;
+
+/* stats indices (mirror of the enum in include/crumble_hip.h) */
+#define ST_COLUMNS 0
+#define ST_HET_A 1
+#define ST_HET_QUAL_A 2
+#define ST_HOM_A 3
+#define ST_HOM_QUAL_A 4
+#define ST_DISCREP_A 5
+#define ST_HET_B 6
+#define ST_HET_QUAL_B 7
+#define ST_HOM_B 8
+#define ST_HOM_QUAL_B 9
+#define ST_DISCREP_B 10
+#define ST_DIFF 11
+#define ST_INDEL 12
+#define ST_INDEL_QUAL 13
+#define ST_LOW_MQUAL_PERC 14
+#define ST_CLIP_PERC 15
+#define ST_INS_LEN_PERC 16
+#define ST_INDEL_OV_PERC 17
+#define ST_OVER_DEPTH 18
+#define ST_READS 19
+#define ST_BASES 20
+#define ST_BASES_CHANGED 21
+#define ST_TRIGGERS 22
+#define ST_TOO_DEEP 23
+#define ST_HIST0 32
+
+__device__ __forceinline__ void stat_inc(u64 *stats, int which, bool cond)
+{
+    /* per-lane +1 under a predicate: hipcc folds these into one wave-level add */
+    if (cond) atomicAdd(&stats[which], (u64)1);
+}
+
+/* ------------------------------------------------------------------------ */
+/* fast_log2 / fast_exp (snp:491-518) */
+__device__ __forceinline__ double dev_fast_log2(double val)
+{
+    int64_t x;
+    memcpy(&x, &val, 8);
+    const int log_2 = (int)((x >> 52) & 2047) - 1024;
+    x &= ~(2047LL << 52);
+    x += 1023LL << 52;
+    memcpy(&val, &x, 8);
+    val = ((-1.0f / 3) * val + 2) * val - 2.0f / 3;
+    return val + log_2;
+}
+#define DEV_TENLOG2OVERLOG10 3.0103
+__device__ __forceinline__ double dev_ph_log(double x) { return -DEV_TENLOG2OVERLOG10 * dev_fast_log2(x); }
+
+__device__ __forceinline__ double dev_fast_exp(const DTables *T, double y)
+{
+    if (y >= -50 && y <= 50) return T->e_tab2[(int)(y * 10) + 500];
+    if (y < -500) y = -500;
+    if (y > 500) y = 500;
+    return T->e_tab[(int)y + 500];
+}
+
+/* ------------------------------------------------------------------------ */
+/* One pileup entry (the bam_pileup1_t fields crumble reads). */
+struct Entry { int qpos, indel, is_del, is_refskip, is_head, is_tail; };
+
+__device__ __forceinline__ int seg_find(const Seg *s, int n, int off)
+{
+    if (n <= 1) return 0;
+    if (n <= 6) {
+        int i = 0;
+        while (i < n - 1 && off >= s[i].roff + seg_len(s[i])) i++;
+        return i;
+    }
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (off >= s[mid].roff + seg_len(s[mid])) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ void entry_from_seg(const Seg &sg, int off, int reflen, Entry &e)
+{
+    const int len = seg_len(sg);
+    const unsigned t = seg_type(sg);
+    const int o = off - sg.roff;
+    e.is_del = (t != SEG_M);
+    e.is_refskip = (t == SEG_N);
+    e.qpos = (t == SEG_M) ? sg.qstart + o : sg.qstart;
+    e.indel = (o == len - 1) ? sg.indel_after : 0;
+    e.is_head = (off == 0);
+    e.is_tail = (off == reflen - 1);
+}
+
+__device__ __forceinline__ void resolve_entry(const DBatch &B, int r, int apos, Entry &e)
+{
+    const int rp = B.pos[r];
+    const int64_t sgo = B.seg_off[r];
+    const int ns = (int)(B.seg_off[r + 1] - sgo);
+    const int off = apos - rp;
+    const int si = seg_find(B.segs + sgo, ns, off);
+    entry_from_seg(B.segs[sgo + si], off, B.end[r] - rp, e);
+}
+
+__device__ __forceinline__ uint8_t cap_q(const DParams *P, uint8_t q)
+{   /* cap_quality snp:1325-1332 */
+    return (q > P->qcap && !P->preserve_qual[q]) ? (uint8_t)P->qcap : q;
+}
+
+/* keep-BED test (snp:1443-1463): the monotone cursor stops at the first region
+ * (in bed_collapse order) whose end >= pos; that is the first index whose
+ * prefix-max of `end` is >= pos. */
+__device__ __forceinline__ int bed_preserve(const DBatch &B, int apos)
+{
+    if (!B.n_bed) return 0;
+    int lo = 0, hi = B.n_bed;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (B.bed_pmax[mid] < apos) lo = mid + 1; else hi = mid;
+    }
+    if (lo < B.n_bed && B.bed_start[lo] <= apos && B.bed_end[lo] > apos) return 2;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+struct ConsOut { int call, het_call, het_phred, phred; float discrep; };
+
+/* The "speculate" half of calculate_consensus_pileup (snp:689-794). */
+__device__ __forceinline__ void cons_finalize(const DTables *T, double *S, const double *sC,
+                                              int depth, int nN, ConsOut &o)
+{
+    const int map_sing[15] = {0,5,5,5,5, 1,5,5,5, 2,5,5, 3,5, 4};
+    const int map_het[15]  = {0,1,2,3,4, 6,7,8,9, 12,13,14, 18,19, 24};
+    const double min_e_exp = -706.6895275309849;     /* DBL_MIN_EXP*log(2)+1, host-checked */
+    double shift = -DBL_MAX, max = -DBL_MAX, max_het = -DBL_MAX, norm[15];
+    int call = 0, het_call = 0, ph, j;
+    double tot1, tot2;
+
+    for (j = 0; j < 15; j++) {
+        S[j] += T->lprior15[j];
+        if (shift < S[j]) shift = S[j];
+        if (j != 0 && j != 5 && j != 9 && j != 12 && j != 14) {
+            if (max_het < S[j]) { max_het = S[j]; het_call = j; }
+            continue;
+        }
+        if (max < S[j]) { max = S[j]; call = j; }
+    }
+    for (j = 0; j < 15; j++) {
+        S[j] -= shift;
+        double e = dev_fast_exp(T, S[j]);
+        S[j] = (S[j] > min_e_exp) ? e : DBL_MIN;
+        norm[j] = 0;
+    }
+    tot1 = tot2 = 0;
+    for (j = 0; j < 15; j++) {
+        norm[j]      += tot1;
+        norm[14 - j] += tot2;
+        tot1 += S[j];
+        tot2 += S[14 - j];
+    }
+    if (depth && depth != nN) {
+        double nc = norm[call], nh = norm[het_call];
+        o.call = map_sing[call];
+        if (nc == 0) nc = DBL_MIN;
+        ph = (int)(dev_ph_log(nc) + .5);
+        o.phred = ph > 255 ? 255 : (ph < 0 ? 0 : ph);
+        o.het_call = map_het[het_call];
+        if (nh == 0) nh = DBL_MIN;
+        ph = (int)(DEV_TENLOG2OVERLOG10 * (dev_fast_log2(S[het_call]) - dev_fast_log2(nh)) + .5);
+        o.het_phred = ph;
+        {
+            double m = sC[0] + sC[1] + sC[2] + sC[3] + sC[4], c;
+            if (o.het_phred > 0) c = sC[o.het_call % 5] + sC[o.het_call / 5];
+            else                 c = sC[o.call];
+            o.discrep = (float)((m - c) / sqrt(m));
+        }
+    } else {
+        o.call = 5; o.het_call = 0; o.het_phred = 0; o.phred = 0; o.discrep = 0;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* k_columns: one lane per reference position; a wave owns 64 consecutive
+ * positions and walks the candidate reads of its tile in file order, so each
+ * lane adds its column's contributions in exactly the reference's order.
+ * MQ selects CONS_MQUAL (mode B, snp:1535) vs plain (mode A, snp:1524). */
+template <bool MQ>
+__global__ void __launch_bounds__(256)
+k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T,
+          uint32_t *__restrict__ colrec, int32_t *__restrict__ nplp_out,
+          int32_t *__restrict__ score_out, int32_t *__restrict__ trigcnt, u64 *stats)
+{
+    __shared__ double sMM[101], s_M[101], sOmq[101];
+    for (int i = threadIdx.x; i < 101; i += blockDim.x) {
+        sMM[i] = T->MMd[i]; s_M[i] = T->_Md[i]; sOmq[i] = T->omq[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int tile = UNIFORM((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (tile >= B.n_tiles) return;
+    const int c = tile * 64 + lane;
+    const int apos = B.p0 + c;
+    const bool inr = c < B.L;
+    const int c0 = B.p0 + tile * 64;
+    const int lo = UNIFORM(B.tile_lo[tile]), hi = UNIFORM(B.tile_hi[tile]);
+    const bool use_cons = MQ ? (P->min_qual_B != 0) : (P->min_qual_A != 0);
+    const int qcap = P->qcap, min_mqual = P->min_mqual, any_pres = P->any_preserve;
+
+    double S[15], sC[5];
+    #pragma unroll
+    for (int j = 0; j < 15; j++) S[j] = 0;
+    #pragma unroll
+    for (int j = 0; j < 5; j++) sC[j] = 0;
+    int depth = 0, nN = 0, n_plp = 0, nref = 0, low_mq = 0, indel_cnt = 0;
+    int clipped = 0, n_overlap = 0, n_isindel = 0, has_ins = 0;
+    unsigned cp = 0;
+
+    for (int r = lo; r < hi; r++) {
+        const int rp = B.pos[r], re = B.end[r];
+        if (re <= c0) continue;                       /* wave-uniform */
+        if (!(inr && apos >= rp && apos < re)) continue;
+        const int64_t so = B.seq_off[r];
+        const int lq = (int)(B.seq_off[r + 1] - so);
+        const int64_t sgo = B.seg_off[r];
+        const int ns = (int)(B.seg_off[r + 1] - sgo);
+        const int mq = B.mapq[r];
+        const int off = apos - rp;
+        const int si = seg_find(B.segs + sgo, ns, off);
+        Entry e;
+        entry_from_seg(B.segs[sgo + si], off, re - rp, e);
+
+        /* --- column heuristics inputs (snp:1662-1713) --- */
+        n_plp++;
+        low_mq += (mq <= min_mqual);
+        if (e.indel || e.is_del) indel_cnt++;
+        if (e.is_refskip) { nref++; continue; }       /* snp:589, snp:1696 */
+        n_isindel += (e.indel || e.is_del) ? 1 : 0;
+        if ((e.is_head && e.qpos > 0) || (e.is_tail && e.qpos + 1 < lq)) clipped++;
+        if (!e.is_tail && !e.is_head) { n_overlap++; if (e.indel > 0) has_ins = 1; }
+
+        /* --- consensus accumulation (snp:594-685) --- */
+        if (!lq || !use_cons) continue;
+        int b;
+        uint8_t q = 0;
+        if (e.qpos < lq) {
+            const int code = B.bases[so + e.qpos] & 15;
+            b = (code == 1) ? 0 : (code == 2) ? 1 : (code == 4) ? 2 : (code == 8) ? 3 : 5;
+            q = B.quals[so + e.qpos];
+            q = (q > qcap && !P->preserve_qual[q]) ? (uint8_t)qcap : q;
+        } else b = 5;                                  /* fence: read ends in D/N */
+        if (e.is_del) b = 4;
+        if (any_pres) {                                /* snp:611-623 */
+            const uint8_t pv = P->preserve_qual[q];
+            if (pv) cp |= 1u << b;
+            if (pv > 1) cp |= (1u << b) << 8;
+            if (e.indel > 0)
+                for (int ins = 0; ins < e.indel; ins++) {
+                    const int qi = e.qpos + 1 + ins;
+                    if (qi < lq && P->preserve_qual[cap_q(P, B.quals[so + qi])]) cp |= 1u << 4;
+                }
+        }
+        int aq = MQ ? T->adj[mq * 256 + q] : q;        /* snp:632-638 */
+        if (aq < 1) aq = 1;                            /* snp:641 */
+        if (aq > 100) aq = 100;                        /* fence */
+        const double MM = sMM[aq], _M = s_M[aq], om = sOmq[aq];
+        depth++;
+        if (b == 5) {                                  /* N: snp:677-682 */
+            nN++;
+            S[0] += MM; S[1] += MM; S[2] += MM; S[3] += MM; S[4] += _M;
+            S[5] += MM; S[6] += MM; S[7] += MM; S[8] += _M;
+            S[9] += MM; S[10] += MM; S[11] += _M;
+            S[12] += MM; S[13] += _M;
+            continue;
+        }
+        const bool b0 = b == 0, b1 = b == 1, b2 = b == 2, b3 = b == 3, b4 = b == 4;
+        sC[0] += b0 ? om : 0.0; sC[1] += b1 ? om : 0.0; sC[2] += b2 ? om : 0.0;
+        sC[3] += b3 ? om : 0.0; sC[4] += b4 ? om : 0.0;
+        /* adding +0.0 is exact, so every genotype sees its own subsequence of
+         * addends in file order (snp:656-675) */
+        S[0]  += b0 ? MM : 0.0;
+        S[1]  += (b0 || b1) ? _M : 0.0;
+        S[2]  += (b0 || b2) ? _M : 0.0;
+        S[3]  += (b0 || b3) ? _M : 0.0;
+        S[4]  += (b0 || b4) ? _M : 0.0;
+        S[5]  += b1 ? MM : 0.0;
+        S[6]  += (b1 || b2) ? _M : 0.0;
+        S[7]  += (b1 || b3) ? _M : 0.0;
+        S[8]  += (b1 || b4) ? _M : 0.0;
+        S[9]  += b2 ? MM : 0.0;
+        S[10] += (b2 || b3) ? _M : 0.0;
+        S[11] += (b2 || b4) ? _M : 0.0;
+        S[12] += b3 ? MM : 0.0;
+        S[13] += (b3 || b4) ? _M : 0.0;
+        S[14] += b4 ? MM : 0.0;
+    }
+
+    if (!inr) return;
+    if (n_plp == 0) { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; return; }
+
+    uint32_t rec = CR_EXISTS;
+    int preserve = bed_preserve(B, apos);              /* snp:1443-1463 */
+    int perfect = 1, score = 0, tcnt = 0;
+    nplp_out[c] = n_plp;
+    if (nref == n_plp) {                               /* snp:1466-1472 */
+        colrec[c] = rec | CR_ALLREFSKIP; score_out[c] = 0; trigcnt[c] = 0;
+        return;
+    }
+    rec |= CR_COUNTED;
+    stat_inc(stats, ST_COLUMNS, true);
+    if (n_plp > MAX_DEPTH_COL) {                       /* snp:1493-1500 */
+        stat_inc(stats, ST_TOO_DEEP, true);
+        colrec[c] = rec | CR_TOODEEP; score_out[c] = 0; trigcnt[c] = 0;
+        return;
+    }
+
+    int a1 = 6, a2 = 6;                                /* call1 = call2 = 0 */
+    bool cond_score = false;
+    if (use_cons) {
+        ConsOut co;
+        cons_finalize(T, S, sC, depth, nN, co);
+        const bool het = co.het_phred > 0;
+        if (het) { a1 = co.het_call / 5; a2 = co.het_call % 5; }     /* snp:1537-1542 */
+        else     { a1 = a2 = co.call; }
+        score = het ? co.het_phred : co.phred;                        /* snp:1588-1590 */
+        const int min_qual = MQ ? P->min_qual_B : P->min_qual_A;
+        const int min_indel = MQ ? P->min_indel_B : P->min_indel_A;
+        const double min_discrep = MQ ? P->min_discrep_B : P->min_discrep_A;
+        const bool lowq = score < min_qual;
+        const bool disc = co.discrep >= min_discrep;                  /* float vs double */
+        stat_inc(stats, MQ ? ST_HET_B : ST_HET_A, het);
+        stat_inc(stats, MQ ? ST_HET_QUAL_B : ST_HET_QUAL_A, het && lowq);
+        stat_inc(stats, MQ ? ST_HOM_B : ST_HOM_A, !het);
+        stat_inc(stats, MQ ? ST_HOM_QUAL_B : ST_HOM_QUAL_A, !het && lowq);
+        stat_inc(stats, MQ ? ST_DISCREP_B : ST_DISCREP_A, disc);
+        if (!MQ && (int)cp != (1 << co.call)) perfect = 0;            /* snp:1606 */
+        preserve |= (lowq ? 1 : 0);                                   /* snp:1624-1628 */
+        preserve |= (disc ? 1 : 0);
+        if (!preserve) {                                              /* snp:1633-1645 */
+            const int bit2call[32] = {99,0,1,99,2,99,99,99,3,99,99,99,99,99,99,99,
+                                      4,99,99,99,99,99,99,99,99,99,99,99,99,99,99,99};
+            if ((co.het_phred <= 0 && bit2call[cp & 31] != co.call) || (cp >> 8)) perfect = 0;
+        }
+        cond_score = score < min_indel;                               /* snp:1719-1720 */
+    }
+    if (P->perfect_col && !perfect) preserve = 1;                     /* snp:1648 */
+
+    bool keep = (double)low_mq > P->low_mqual_perc * (n_plp + .01);   /* snp:1668 */
+    stat_inc(stats, ST_LOW_MQUAL_PERC, keep);
+    if ((clipped - 1.0) >= P->clip_perc * n_overlap) {                /* snp:1764 */
+        keep = true;
+        stat_inc(stats, ST_CLIP_PERC, true);
+    }
+    if (cond_score)                                                   /* snp:1718 */
+        tcnt = (P->str_snp && preserve) ? (n_plp - nref) : n_isindel;
+    stat_inc(stats, ST_INDEL, indel_cnt > 0);                         /* snp:1761 */
+    stat_inc(stats, ST_INDEL_QUAL, cond_score && n_isindel > 0);      /* snp:1762 */
+    if (tcnt) atomicAdd(&stats[ST_TRIGGERS], (u64)tcnt);
+
+    rec |= (uint32_t)a1 | ((uint32_t)a2 << 3) | ((uint32_t)preserve << 6);
+    if (perfect) rec |= CR_PERFECT;
+    if (keep) rec |= CR_KEEP;
+    if (tcnt) rec |= CR_TRIG | CR_WIN;
+    if (has_ins) rec |= CR_HASINS;
+    if ((double)indel_cnt >= n_plp * P->indel_fract) rec |= CR_SCAN;  /* snp:1732 */
+    colrec[c] = rec; score_out[c] = score; trigcnt[c] = tcnt;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Chunked device-wide exclusive scan of ScanVal over positions.            */
+#define SCAN_CHUNK 2048
+
+__device__ __forceinline__ void scanval_of(uint32_t rec, int32_t nplp, int32_t tc, ScanVal &v)
+{
+    const bool counted = (rec & CR_COUNTED) != 0;
+    v.depth = counted ? nplp : 0;
+    v.cols = counted ? 1 : 0;
+    v.trigcols = (rec & CR_TRIG) ? 1 : 0;
+    v.items = tc;
+    v.ins = (rec & CR_HASINS) ? 1 : 0;
+}
+__device__ __forceinline__ void scanval_add(ScanVal &a, const ScanVal &b)
+{ a.depth += b.depth; a.cols += b.cols; a.trigcols += b.trigcols; a.items += b.items; a.ins += b.ins; }
+
+__global__ void k_scan_reduce(int L, const uint32_t *colrec, const int32_t *nplp,
+                              const int32_t *trigcnt, ScanVal *partial, int nchunks)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    ScanVal acc = {0, 0, 0, 0, 0}, v;
+    const int b = t * SCAN_CHUNK, e = (b + SCAN_CHUNK < L) ? b + SCAN_CHUNK : L;
+    for (int i = b; i < e; i++) { scanval_of(colrec[i], nplp[i], trigcnt[i], v); scanval_add(acc, v); }
+    partial[t] = acc;
+}
+
+/* single thread: exclusive scan of the chunk partials; totals -> partial[nchunks] */
+__global__ void k_scan_partials(ScanVal *partial, int nchunks)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    ScanVal run = {0, 0, 0, 0, 0};
+    for (int i = 0; i < nchunks; i++) { ScanVal v = partial[i]; partial[i] = run; scanval_add(run, v); }
+    partial[nchunks] = run;
+}
+
+__global__ void k_scan_apply(int L, const uint32_t *colrec, const int32_t *nplp,
+                             const int32_t *trigcnt, const ScanVal *partial, int nchunks,
+                             int64_t *dpre, int32_t *col_ord, int32_t *trig_ord,
+                             int32_t *item_off, int32_t *ins_ord)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    ScanVal run = partial[t], v;
+    const int b = t * SCAN_CHUNK, e = (b + SCAN_CHUNK < L) ? b + SCAN_CHUNK : L;
+    for (int i = b; i < e; i++) {
+        dpre[i] = run.depth; col_ord[i] = run.cols; trig_ord[i] = run.trigcols;
+        item_off[i] = run.items; ins_ord[i] = run.ins;
+        scanval_of(colrec[i], nplp[i], trigcnt[i], v);
+        scanval_add(run, v);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Running depth average (snp:1490-1491, 1684-1687): total_col grows by one per
+ * counted column and both sums are halved after the test of the first column
+ * (not a too-deep one) that finds total_col > 2^20.  One thread walks the few
+ * hundred halving points; every column then evaluates its own test. */
+__device__ __forceinline__ int ord_to_pos(const int32_t *col_ord, const uint32_t *colrec, int L, int64_t ord)
+{   /* position of the counted column with ordinal `ord` */
+    int lo = 0, hi = L;                 /* first i with col_ord[i+1-ish] > ord */
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        /* inclusive count at mid */
+        int64_t inc = col_ord[mid] + ((colrec[mid] & CR_COUNTED) ? 1 : 0);
+        if (inc <= ord) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void k_epochs(int L, const uint32_t *colrec, const int32_t *nplp, const int32_t *col_ord,
+                         const int64_t *dpre, const ScanVal *totals, Epoch *ep, int *n_ep)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    const int64_t ncols = totals->cols;
+    int64_t tc = 0, td = 0, ord = 0;
+    int n = 0;
+    while (ord < ncols && n < MAX_EPOCHS - 1) {
+        int p0 = ord_to_pos(col_ord, colrec, L, ord);
+        ep[n].ord_start = ord; ep[n].tc_start = tc; ep[n].td_start = td; ep[n].dpre_start = dpre[p0];
+        n++;
+        int64_t j = ord + ((tc + 1 > 1048576) ? 0 : (1048576 - tc));   /* first ordinal with tc' > 2^20 */
+        if (j >= ncols) break;
+        int pj = ord_to_pos(col_ord, colrec, L, j);
+        while (j < ncols && (colrec[pj] & CR_TOODEEP)) {               /* too deep: no halving (goto) */
+            j++;
+            if (j < ncols) pj = ord_to_pos(col_ord, colrec, L, j);
+        }
+        if (j >= ncols) break;
+        const int64_t tcj = tc + (j - ord + 1);
+        const int64_t tdj = td + (dpre[pj] + nplp[pj] - ep[n - 1].dpre_start);
+        tc = tcj >> 1; td = tdj >> 1; ord = j + 1;
+    }
+    *n_ep = n;
+}
+
+/* over-depth test per column (snp:1673-1681) + compaction of the trigger and
+ * histogram columns. */
+__global__ void k_overdepth(int L, uint32_t *colrec, const int32_t *nplp, const int32_t *col_ord,
+                            const int64_t *dpre, const int32_t *trig_ord, const int32_t *item_off,
+                            const int32_t *ins_ord, const Epoch *ep, const int *n_ep,
+                            const DParams *P, int32_t *trigcol_pos, int32_t *trigcol_off,
+                            int32_t *inscol_pos, u64 *stats)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    uint32_t rec = colrec[i];
+    if (!(rec & CR_COUNTED) || (rec & CR_TOODEEP)) return;
+    const int64_t ord = col_ord[i];
+    int lo = 0, hi = *n_ep - 1;                  /* last epoch with ord_start <= ord */
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (ep[mid].ord_start <= ord) lo = mid; else hi = mid - 1;
+    }
+    const Epoch e = ep[lo];
+    const int n = nplp[i];
+    const int64_t total_col = e.tc_start + (ord - e.ord_start + 1);
+    const int64_t total_depth = e.td_start + (dpre[i] + n - e.dpre_start);
+    if ((double)((int64_t)n * (total_col + 1)) > P->over_depth * (double)(total_depth + 1)) {
+        rec |= CR_KEEP;
+        colrec[i] = rec;
+        stat_inc(stats, ST_OVER_DEPTH, true);
+    }
+    if (rec & CR_TRIG) { trigcol_pos[trig_ord[i]] = i; trigcol_off[trig_ord[i]] = item_off[i]; }
+    if (rec & CR_HASINS) inscol_pos[ins_ord[i]] = i;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Indel-length histogram test (snp:1708-1713, 1777-1819), columns with an
+ * insertion only.  One thread per such column. */
+__global__ void k_inshist(DBatch B, const DParams *P, int n_ins, const int32_t *inscol_pos,
+                          uint32_t *colrec, const int32_t *nplp, u64 *stats)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_ins) return;
+    const int c = inscol_pos[t], apos = B.p0 + c, tile = c >> 6;
+    const int lo = B.tile_lo[tile], hi = B.tile_hi[tile];
+    int hist[100];
+    for (int i = 0; i < 100; i++) hist[i] = 0;
+    int indel_sz = 0;
+    for (int r = lo; r < hi; r++) {
+        if (!(apos >= B.pos[r] && apos < B.end[r])) continue;
+        Entry e;
+        resolve_entry(B, r, apos, e);
+        if (e.is_refskip || e.is_head || e.is_tail) continue;
+        if (e.indel > indel_sz) indel_sz = e.indel;
+        if (e.indel >= 0) hist[e.indel < 99 ? e.indel : 99]++;
+    }
+    if (indel_sz > 100) indel_sz = 100;
+    if (!indel_sz) return;
+    int qd1 = 0, qd2 = 0, ov = 0;
+    for (int i = 0; i <= indel_sz && i < 100; i++) {
+        if (!hist[i]) continue;
+        ov += hist[i];
+        if (qd1 < hist[i]) { qd2 = qd1; qd1 = hist[i]; }
+        else if (qd2 < hist[i]) qd2 = hist[i];
+    }
+    bool keep = false;
+    if ((double)(ov - qd1 - qd2) > P->ins_len_perc * (ov + .1)) { keep = true; stat_inc(stats, ST_INS_LEN_PERC, true); }
+    if ((double)ov < P->indel_ov_perc * nplp[c]) { keep = true; stat_inc(stats, ST_INDEL_OV_PERC, true); }
+    if (keep) colrec[c] |= CR_KEEP;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Ordered trigger list of each trigger column (snp:1695-1730). */
+__global__ void k_emit(DBatch B, const DParams *P, int n_trig, const int32_t *trigcol_pos,
+                       const int32_t *trigcol_off, const uint32_t *colrec, TrigItem *items)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_trig) return;
+    const int c = trigcol_pos[t], apos = B.p0 + c, tile = c >> 6;
+    const int lo = B.tile_lo[tile], hi = B.tile_hi[tile];
+    const uint32_t rec = colrec[c];
+    const bool snp_kind = P->str_snp && CR_PRESERVE(rec);
+    int o = trigcol_off[t];
+    for (int r = lo; r < hi; r++) {
+        if (!(apos >= B.pos[r] && apos < B.end[r])) continue;
+        Entry e;
+        resolve_entry(B, r, apos, e);
+        if (e.is_refskip) continue;
+        const int is_indel = (e.indel || e.is_del) ? 1 : 0;
+        if (!(is_indel || snp_kind)) continue;
+        TrigItem it;
+        it.read = r; it.qpos1_kind = (e.qpos + 1) | (is_indel << 30);
+        it.lo = INT_MAX; it.hi = 0;
+        items[o++] = it;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* find_STR / add_rep (str_finder.c:34-189) on the 2-bit codes of a read
+ * window, and mask_LC_regions (snp:1230-1290).  One thread per trigger.      */
+struct StrWin {
+    const uint8_t *bases;   /* read's nt16 codes */
+    int lq, start;          /* window start in the read */
+    int tail_code;          /* code of index lq */
+};
+__device__ __forceinline__ int str_code(const StrWin &w, int i)
+{   /* str_finder.c:15-32 via seq_nt16_str: C=1 G=2 T=3, all else 0 */
+    const int qi = w.start + i;
+    int c16 = (qi < w.lq) ? (w.bases[qi] & 15) : w.tail_code;
+    return (c16 == 2) ? 1 : (c16 == 4) ? 2 : (c16 == 8) ? 3 : 0;
+}
+
+__device__ inline int dev_find_STR(const StrWin &w, int len, short *st, short *en, int *overflow)
+{
+    int n = 0;
+    uint32_t word = 0;
+    for (int i = 0; i < len; i++) {
+        word = (word << 2) | (uint32_t)str_code(w, i);
+        /* candidate periods for this position (str_finder.c:140-186) */
+        int first, last;
+        if (i < 15) { first = 1; last = 7; }           /* every fitting period */
+        else        { first = 8; last = 1; }           /* largest matching only */
+        for (int step = 0; step < 8; step++) {
+            int rlen = (i < 15) ? first + step : first - step;
+            if (i < 15) { if (rlen > last) break; if (i < 2 * rlen - 1) continue; }
+            else if (rlen < last) break;
+            const uint32_t mask = (rlen == 8) ? 0xffffu : ((1u << (2 * rlen)) - 1);
+            if ((word & mask) != ((word >> (2 * rlen)) & mask)) continue;
+
+            /* ---- add_rep(pos = i, rlen) ---- */
+            bool handled = false;
+            if (n) {
+                if (st[n - 1] <= i - rlen * 2 + 1 && en[n - 1] >= i) handled = true;
+            }
+            if (!handled) {
+                int cp1 = i + 1 - rlen, cp2 = i + 1;
+                while (cp2 < len && str_code(w, cp1) == str_code(w, cp2)) { cp1++; cp2++; }
+                const int el_end = cp2 - 1, el_start = i + 1 - 2 * rlen;
+                if (n) {                                /* str_finder.c:106-122 */
+                    int cur = n - 1;
+                    for (;;) {
+                        const bool was_head = (cur == 0);
+                        int prev = was_head ? n - 1 : cur - 1;
+                        bool deleted = false;
+                        if (en[cur] < el_start) break;
+                        if (st[cur] >= el_start) {
+                            for (int k = cur; k < n - 1; k++) { st[k] = st[k + 1]; en[k] = en[k + 1]; }
+                            n--; deleted = true;
+                        }
+                        if (was_head && !deleted) break;
+                        if (!n) break;
+                        if (was_head) prev = n - 1;
+                        cur = prev;
+                    }
+                }
+                if (n < STR_CAP) { st[n] = (short)el_start; en[n] = (short)el_end; n++; }
+                else *overflow = 1;
+            }
+            if (i >= 15) break;                         /* else-if chain */
+        }
+    }
+    return n;
+}
+
+/* bam_qpos2rpos (snp:1205-1219) on the raw CIGAR */
+__device__ __forceinline__ int dev_qpos2rpos(const uint32_t *cig, int nc, int rpos0, int qpos)
+{
+    int rpos = rpos0, aqpos = 0;
+    for (int k = 0; k < nc && aqpos < qpos; k++) {
+        const int op = cig[k] & 15, l = (int)(cig[k] >> 4);
+        const int ty = (0x3C1A7 >> (op << 1)) & 3;
+        if (ty & 2) rpos += (l <= qpos - aqpos) ? l : (qpos - aqpos);
+        if (ty & 1) aqpos += l;
+    }
+    return rpos;
+}
+/* ref2query_pos (snp:1156-1179) */
+__device__ __forceinline__ int dev_ref2query_pos(const uint32_t *cig, int nc, int rpos0, int pos)
+{
+    int p = rpos0, q = 0;
+    for (int i = 0; i < nc; i++) {
+        const int op = cig[i] & 15, l = (int)(cig[i] >> 4);
+        const int ty = (0x3C1A7 >> (op << 1)) & 3;
+        if (p + ((ty & 2) ? l : 0) < pos) {
+            if (ty & 1) q += l;
+            if (ty & 2) p += l;
+            continue;
+        }
+        if (ty & 1) q += (pos - p);
+        return q >= 0 ? q : 0;
+    }
+    return q;
+}
+
+__device__ inline void dev_mask_lc(const DBatch &B, const DParams *P, int r, int rpos, int is_indel,
+                                   int *min_pos, int *max_pos, int *overflow)
+{
+    short st[STR_CAP], en[STR_CAP];
+    const int64_t so = B.seq_off[r];
+    const int lq = (int)(B.seq_off[r + 1] - so);
+    StrWin w;
+    w.bases = B.bases + so; w.lq = lq;
+    w.start = rpos - MASK_WIN_DEV > 0 ? rpos - MASK_WIN_DEV : 0;
+    const int end = rpos + MASK_WIN_DEV < lq ? rpos + MASK_WIN_DEV : lq;
+    const int len = end - w.start + 1;
+    w.tail_code = (lq & 1) || !lq ? 0 : (cap_q(P, B.quals[so]) >> 4);
+    const int n = dev_find_STR(w, len, st, en, overflow);
+    const int add = is_indel ? P->iSTR_add : P->sSTR_add;
+    const uint32_t *cig = B.cigar + B.cig_off[r];
+    const int nc = (int)(B.cig_off[r + 1] - B.cig_off[r]);
+    for (int i = 0; i < n; i++) {
+        int s = st[i] + w.start, e = en[i] + w.start;
+        if (!(rpos + add >= s && rpos - add <= e)) continue;
+        s = dev_qpos2rpos(cig, nc, B.pos[r], s);
+        e = dev_qpos2rpos(cig, nc, B.pos[r], e);
+        if (*min_pos > s) *min_pos = s;
+        if (*max_pos < e) *max_pos = e;
+    }
+}
+
+__global__ void k_str(DBatch B, const DParams *P, int n_items, TrigItem *items,
+                      const int32_t *item_col /* may be NULL */, const uint32_t *colrec, int *overflow)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_items) return;
+    TrigItem it = items[t];
+    if (item_col && !(colrec[item_col[t]] & CR_SCAN)) return;   /* snp:1732 */
+    int lo = INT_MAX, hi = 0;
+    dev_mask_lc(B, P, it.read, it.qpos1_kind & 0x3fffffff, (it.qpos1_kind >> 30) & 1, &lo, &hi, overflow);
+    items[t].lo = lo; items[t].hi = hi;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Window state across columns (snp:1508-1511, 1741-1755).
+ * A chain is a run of trigger columns not separated by a reset
+ * (pos > max_pos2).  ubound[k] is a sound upper bound of max_pos2 after
+ * column k under ANY incoming state, so pos[k+1] > ubound[k] proves a reset:
+ * those are independent segments, folded sequentially by one thread each. */
+__global__ void k_fold_bounds(DBatch B, const DParams *P, int n_trig, const int32_t *trigcol_pos,
+                              const int32_t *trigcol_off, const int32_t *trigcnt,
+                              const TrigItem *items, int32_t *colhi)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_trig) return;
+    const int c = trigcol_pos[k], pos = B.p0 + c;
+    const int o = trigcol_off[k], n = trigcnt[c];
+    int h = pos;
+    for (int i = 0; i < n; i++) if (items[o + i].hi > h) h = items[o + i].hi;
+    colhi[k] = h;
+}
+
+/* generic chunked inclusive prefix-max over int32 */
+__global__ void k_pmax_reduce(int n, const int32_t *v, int32_t *partial, int nchunks, int chunk)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    int m = INT_MIN;
+    const int b = t * chunk, e = b + chunk < n ? b + chunk : n;
+    for (int i = b; i < e; i++) if (v[i] > m) m = v[i];
+    partial[t] = m;
+}
+__global__ void k_pmax_partials(int32_t *partial, int nchunks)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    int run = INT_MIN;
+    for (int i = 0; i < nchunks; i++) { int v = partial[i]; partial[i] = run; if (v > run) run = v; }
+}
+__global__ void k_pmax_apply(int n, int32_t *v, const int32_t *partial, int nchunks, int chunk)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    int run = partial[t];
+    const int b = t * chunk, e = b + chunk < n ? b + chunk : n;
+    for (int i = b; i < e; i++) { if (v[i] > run) run = v[i]; v[i] = run; }
+}
+
+/* colhi (already prefix-maxed = bound on max_pos) -> per-column bound on max_pos2 */
+__global__ void k_fold_ub(DBatch B, const DParams *P, int n_trig, const int32_t *trigcol_pos,
+                          const int32_t *colhi, int32_t *ub)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_trig) return;
+    const double pos = B.p0 + trigcol_pos[k], h = colhi[k];
+    double a = pos + (h - pos) * P->iSTR_mul + P->iSTR_add;
+    double b = pos + (h - pos) * P->sSTR_mul + P->sSTR_add;
+    double m = a > b ? a : b;
+    if (m < pos) m = pos;
+    m += 2;                                         /* slack over the truncations */
+    ub[k] = m > 2147483000.0 ? 2147483000 : (int)m;
+}
+
+__global__ void k_fold(DBatch B, const DParams *P, int n_trig, const int32_t *trigcol_pos,
+                       const int32_t *trigcol_off, const int32_t *trigcnt, const TrigItem *items,
+                       const int32_t *ubmax /* inclusive prefix max of ub */,
+                       uint32_t *colrec, int32_t *pos_mn2, int32_t *trig_mx2)
+{
+    const int k0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k0 >= n_trig) return;
+    if (k0 > 0 && !(B.p0 + trigcol_pos[k0] > ubmax[k0 - 1])) return;   /* not a segment start */
+    int min_pos = INT_MAX, max_pos = 0, min_pos2 = INT_MAX, max_pos2 = 0;
+    const double imul = P->iSTR_mul, smul = P->sSTR_mul;
+    const int iadd = P->iSTR_add, sadd = P->sSTR_add;
+    for (int k = k0; k < n_trig; k++) {
+        const int c = trigcol_pos[k], pos = B.p0 + c;
+        if (k > k0 && pos > ubmax[k - 1]) break;                         /* next segment */
+        if (pos > max_pos2) {                                            /* snp:1508-1511 */
+            min_pos2 = min_pos = INT_MAX;
+            max_pos2 = max_pos = 0;
+        }
+        const int o = trigcol_off[k], n = trigcnt[c];
+        for (int i = 0; i < n; i++) {
+            const TrigItem it = items[o + i];
+            if (min_pos > it.lo) min_pos = it.lo;                        /* mask_LC_regions */
+            if (max_pos < it.hi) max_pos = it.hi;
+            if (min_pos > pos) min_pos = pos;                            /* snp:1741-1742 */
+            if (max_pos < pos) max_pos = pos;
+            const bool ind = (it.qpos1_kind >> 30) & 1;
+            const double mul = ind ? imul : smul;
+            const int add = ind ? iadd : sadd;
+            const double e1 = pos - (pos - min_pos) * mul - add;         /* snp:1746-1754 */
+            const double e2 = pos + (max_pos - pos) * mul + add;
+            min_pos2 = ((double)min_pos2 < e1) ? min_pos2 : (int)e1;
+            max_pos2 = ((double)max_pos2 > e2) ? max_pos2 : (int)e2;
+        }
+        pos_mn2[c] = min_pos2;
+        trig_mx2[k] = max_pos2;
+    }
+}
+
+/* columns after a trigger column stay "in window" while pos <= max_pos2 (snp:1880) */
+__global__ void k_window(DBatch B, int n_trig, const int32_t *trigcol_pos, const int32_t *trig_mx2,
+                         uint32_t *colrec)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_trig) return;
+    const int c = trigcol_pos[k];
+    int64_t last = (int64_t)trig_mx2[k] - B.p0;
+    const int next = (k + 1 < n_trig) ? trigcol_pos[k + 1] : B.L;
+    if (last > next - 1) last = next - 1;
+    for (int64_t i = c + 1; i <= last; i++) colrec[i] |= CR_WIN;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Per-read replay of the per-base loop (snp:1822-1920), the keep_qual
+ * retirement copy (snp:1939) and the 0x80 strip of flush_bam_list
+ * (snp:1093-1096).  One thread per read, columns in order. */
+__global__ void k_replay(DBatch B, const DParams *P, const uint32_t *colrec, const int32_t *pos_mn2,
+                         uint8_t *out, uint8_t *rflags)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B.n_reads) return;
+    const int64_t so = B.seq_off[r];
+    const int lq = (int)(B.seq_off[r + 1] - so);
+    uint8_t *q2 = out + so;
+    const uint8_t *qin = B.quals + so;
+    if (!B.inplp[r]) {
+        for (int x = 0; x < lq; x++) q2[x] = qin[x] & 0x7f;
+        rflags[r] = 4;
+        return;
+    }
+    const int rp = B.pos[r], re = B.end[r], mq = B.mapq[r];
+    const Seg *segs = B.segs + B.seg_off[r];
+    const int ns = (int)(B.seg_off[r + 1] - B.seg_off[r]);
+    const uint32_t *cig = B.cigar + B.cig_off[r];
+    const int nc = (int)(B.cig_off[r + 1] - B.cig_off[r]);
+    const int qhigh = P->qhigh, qlow = P->qlow;
+    int keep = 0, b15 = 0, si = 0;
+    for (int x = 0; x < lq; x++) q2[x] = qin[x];
+
+    for (int apos = rp; apos < re; apos++) {
+        const int off = apos - rp;
+        while (si < ns - 1 && off >= segs[si].roff + seg_len(segs[si])) si++;
+        const uint32_t rec = colrec[apos - B.p0];
+        if (rec & CR_SKIP) continue;                  /* `continue` / goto too_deep */
+        Entry e;
+        entry_from_seg(segs[si], off, re - rp, e);
+        if (rec & CR_KEEP) keep = 1;                  /* snp:1847 */
+        if (e.is_head && mq <= P->min_mqual)          /* snp:1852-1859 */
+            for (int x = 0; x < lq; x++) q2[x] |= 0x80;
+        if (!lq || e.qpos >= lq) continue;
+        const int preserve = CR_PRESERVE(rec);
+        const int perfect = (rec & CR_PERFECT) ? 1 : 0;
+        if (rec & CR_TRIG) {                          /* snp:1870-1879 */
+            for (int x = dev_ref2query_pos(cig, nc, rp, pos_mn2[apos - B.p0]); x <= e.qpos; x++)
+                q2[x] = cap_q(P, qin[x]) | 0x80;
+        }
+        uint8_t v = q2[e.qpos];
+        if (rec & CR_WIN) v = cap_q(P, qin[e.qpos]) | 0x80;                  /* snp:1880-1883 */
+        if (preserve || P->preserve_qual[v & 0x7f] >= 1 + perfect) v |= 0x80; /* snp:1885 */
+        if (preserve > 1) b15 = 1;                                           /* snp:1890 */
+        q2[e.qpos] = v;
+        if (!(rec & CR_KEEP) && P->softclip) {                               /* snp:1894-1904 */
+            if (e.is_head) { for (int x = 1; x <= e.qpos; x++) q2[e.qpos - x] = P->bin2[q2[e.qpos - x]]; }
+            else if (e.is_tail) { for (int x = lq - e.qpos - 1; x > 0; x--) q2[e.qpos + x] = P->bin2[q2[e.qpos + x]]; }
+        }
+        if (!(v & 0x80)) {                                                   /* snp:1906-1919 */
+            const int base = B.bases[so + e.qpos] & 15;
+            const int c1 = 1 << CR_A1(rec), c2 = 1 << CR_A2(rec);
+            if (base == c1 || base == c2) v = (uint8_t)qhigh;
+            else if (P->reduce_qual) v = P->binary_qual ? P->bin2[v] : (uint8_t)qlow;
+            q2[e.qpos] = v;
+        }
+    }
+    if (keep) for (int x = 0; x < lq; x++) q2[x] = cap_q(P, qin[x]);         /* snp:1939 */
+    for (int x = 0; x < lq; x++) q2[x] &= 0x7f;                              /* snp:1093 */
+    rflags[r] = (uint8_t)((keep ? 1 : 0) | (b15 ? 2 : 0));
+}
+
+/* ------------------------------------------------------------------------ */
+/* P-block (snp:803-834), one thread per read, in place. */
+__device__ inline void dev_pblock(uint8_t *qual, int len, int level, int qcap, const uint8_t *pq)
+{
+    int i, j, qmin = INT_MAX, qmax = INT_MIN, last_qmin = 0, last_qmax = 0, mid;
+    level *= 2;
+    for (i = j = 0; i < len; i++) {
+        const int q = qual[i];
+        if (qmin > q) qmin = q;
+        if (qmax < q) qmax = q;
+        if (qmax - qmin > level || pq[q]) {
+            mid = (last_qmin + last_qmax) / 2;
+            if (mid > qcap) mid = qcap;
+            for (int k = j; k < i; k++) qual[k] = (uint8_t)mid;
+            while (i < len && pq[qual[i]]) i++;
+            if (i < len) qmin = qmax = qual[i]; else qmin = qmax = 0;
+            j = i;
+        }
+        last_qmin = qmin; last_qmax = qmax;
+    }
+    mid = (last_qmin + last_qmax) / 2;
+    const int e = i < len ? i : len;
+    for (int k = j; k < e; k++) qual[k] = (uint8_t)mid;
+}
+
+__global__ void k_pblock(int64_t n_reads, const int64_t *seq_off, uint8_t *out,
+                         const uint8_t *rflags, const DParams *P)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    if (rflags && (rflags[r] & 2)) return;            /* flag bit 15: snp:1098 */
+    dev_pblock(out + seq_off[r], (int)(seq_off[r + 1] - seq_off[r]), P->pblock, P->qcap, P->preserve_qual);
+}
+
+/* ------------------------------------------------------------------------ */
+/* Output-quality histogram + changed-byte count (feeds the RCCL all-reduce). */
+__global__ void __launch_bounds__(256)
+k_stats(int64_t n_bases, int64_t n_reads, const uint8_t *out, const uint8_t *in, u64 *stats)
+{
+    __shared__ unsigned int h[257];
+    for (int i = threadIdx.x; i < 257; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned int changed = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_bases; i += stride) {
+        const uint8_t o = out[i];
+        atomicAdd(&h[o], 1u);
+        changed += (o != in[i]);
+    }
+    if (changed) atomicAdd(&h[256], changed);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 257; i += blockDim.x) {
+        const unsigned int v = h[i];
+        if (v) atomicAdd(&stats[i < 256 ? ST_HIST0 + i : ST_BASES_CHANGED], (u64)v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&stats[ST_READS], (u64)n_reads);
+        atomicAdd(&stats[ST_BASES], (u64)n_bases);
+    }
+}
+
+#endif /* CRUMBLE_KERNELS_H */
