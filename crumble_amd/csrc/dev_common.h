@@ -42,6 +42,7 @@ struct DTables {
     double lprior15[15];
     double e_tab[1001];     /* exp(i),    i = -500..500  (index +500) */
     double e_tab2[1001];    /* exp(i/10), i = -500..500  (index +500) */
+    double min_e_exp;       /* DBL_MIN_EXP*log(2)+1  snp:540 */
     uint8_t adj[65536];     /* [mapq][qual] -> adjusted quality, snp:632-638 */
 };
 
@@ -96,7 +97,7 @@ struct DBatch {
 /* one STR/indel trigger (snp:1718-1756) */
 struct TrigItem {
     int32_t read;
-    int32_t qpos1_kind;     /* (qpos+1) | is_indel << 30                     */
+    int32_t qpos1_kind;     /* (qpos+1) | is_indel << 30 | noscan << 29      */
     int32_t lo, hi;         /* mask_LC_regions result (INT_MAX,0 = none)     */
 };
 

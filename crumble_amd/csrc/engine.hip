@@ -1,0 +1,668 @@
+/*
+ * engine.hip -- host layer of the engine + the C ABI of include/crumble_hip.h.
+ *
+ * Replaces the body of transcode()'s pileup loop and flush_bam_list()'s
+ * per-read epilogue (/root/reference/snp_score.c:1437-1983, 1090-1100) for one
+ * contig: the batch is expanded on the host (P0: CIGAR -> reference-op segment
+ * tables, read ends, per-tile candidate ranges), made resident in HBM, and run
+ * through the kernels of kernels.h on one HIP stream.  No CPU fallback exists:
+ * without a HIP device crumble_hip_create() fails with CRUMBLE_ENODEVICE.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <float.h>
+#include <vector>
+#include <string>
+#ifndef CRUMBLE_EMU
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#endif
+
+#include "../../include/crumble_hip.h"
+#include "dev_common.h"
+#include "kernels.h"
+
+static thread_local std::string g_last_error;
+extern "C" const char *crumble_hip_last_error(void) { return g_last_error.c_str(); }
+
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    char buf_[512]; snprintf(buf_, sizeof buf_, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+    g_last_error = buf_; return CRUMBLE_EHIP; } } while (0)
+
+/* grow-only device buffer */
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap && p) return CRUMBLE_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 8 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; g_last_error = "hipMalloc failed"; return CRUMBLE_ENOMEM; }
+        cap = want;
+        return CRUMBLE_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+#define MAX_STAGES 16
+struct crumble_hip {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    crumble_params params;
+    DParams hparams;
+    DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc;
+    /* batch (inputs) */
+    DevBuf d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
+           d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax;
+    /* per position */
+    DevBuf d_colrec, d_nplp, d_score, d_trigcnt, d_dpre, d_col_ord, d_trig_ord, d_item_off,
+           d_ins_ord, d_pos_mn2, d_partial, d_epochs;
+    /* work lists */
+    DevBuf d_trigcol_pos, d_trigcol_off, d_inscol_pos, d_items, d_colhi, d_ub, d_pmax_partial, d_trig_mx2;
+    /* outputs */
+    DevBuf d_out, d_rflags;
+    DBatch B;
+    bool have_batch = false, have_run = false;
+    int64_t n_reads = 0, n_bases = 0, n_cigar = 0;
+    ScanVal totals;
+    /* timing */
+    hipEvent_t ev[MAX_STAGES + 1];
+    const char *stage_name[MAX_STAGES];
+    double stage_bytes[MAX_STAGES];
+    float stage_ms[MAX_STAGES];
+    int n_stages = 0;
+    bool events_ok = false;
+};
+
+/* ---------------------------------------------------------------- tables */
+static void build_tables(DTables *t)
+{
+    /* consensus_init(P_HET = 1e-6) for STECH_SOLEXA (snp:378-489) and the
+     * function statics of calculate_consensus_pileup (snp:560-575), evaluated
+     * with the host libm exactly as the reference does. */
+    double pMM[101], p__[101], p_M[101], prior[25], q2p[101], mqual_pow[256];
+    const double p_het = 1e-6;
+    int i;
+    for (i = -500; i <= 500; i++) t->e_tab[i + 500] = exp(i);
+    for (i = -500; i <= 500; i++) t->e_tab2[i + 500] = exp(i / 10.);
+    for (i = 0; i < 25; i++) prior[i] = p_het / 20;
+    prior[0] = prior[6] = prior[12] = prior[18] = prior[24] = (1 - p_het) / 5;
+    {
+        static const int idx[15] = {0,1,2,3,4, 6,7,8,9, 12,13,14, 18,19, 24};
+        static const int dbl[15] = {0,1,1,1,1, 0,1,1,1, 0,1,1, 0,1, 0};
+        for (i = 0; i < 15; i++) t->lprior15[i] = dbl[i] ? log(prior[idx[i]] * 2) : log(prior[idx[i]]);
+    }
+    for (i = 1; i < 101; i++) {
+        double prob = 1 - pow(10, -i / 10.0);
+        pMM[i] = log(prob / 5);
+        p__[i] = log((1 - prob) / 20);
+        p_M[i] = log((exp(pMM[i]) + exp(p__[i])) / 2);
+    }
+    pMM[0] = pMM[1]; p__[0] = p__[1]; p_M[0] = p_M[1];
+    for (i = 0; i <= 100; i++) q2p[i] = pow(10, -i / 10.0);
+    for (i = 0; i < 255; i++) mqual_pow[i] = 1 - pow(10, -(i / 2 + .05) / 10.0);
+    mqual_pow[255] = mqual_pow[10];
+    for (i = 0; i <= 100; i++) {
+        t->MMd[i] = pMM[i] - p__[i];          /* snp:645 */
+        t->_Md[i] = p_M[i] - p__[i];          /* snp:646 */
+        t->omq[i] = 1 - q2p[i];               /* snp:651 */
+    }
+    t->min_e_exp = DBL_MIN_EXP * log(2) + 1;  /* snp:540 */
+    for (int m = 0; m < 256; m++)
+        for (int q = 0; q < 256; q++) {       /* snp:632-638, ph_log on the host */
+            double _p = mqual_pow[q], _m = mqual_pow[m];
+            double x = 1 - (_m * _p + (1 - _m) / 4);
+            int64_t bits; memcpy(&bits, &x, 8);
+            int log_2 = (int)((bits >> 52) & 2047) - 1024;
+            bits &= ~(2047LL << 52); bits += 1023LL << 52;
+            double val; memcpy(&val, &bits, 8);
+            val = ((-1.0f / 3) * val + 2) * val - 2.0f / 3;
+            double ph = -3.0103 * (val + log_2);
+            t->adj[m * 256 + q] = (uint8_t)ph;
+        }
+}
+
+static int fill_dparams(const crumble_params *p, DParams *d)
+{
+    memset(d, 0, sizeof(*d));
+    d->reduce_qual = p->reduce_qual; d->binary_qual = p->binary_qual;
+    d->iSTR_add = p->iSTR_add; d->sSTR_add = p->sSTR_add;
+    d->iSTR_mul = p->iSTR_mul; d->sSTR_mul = p->sSTR_mul;
+    d->qlow = p->qlow; d->qcutoff = p->qcutoff; d->qhigh = p->qhigh; d->qcap = p->qcap;
+    d->min_mqual = p->min_mqual;
+    d->min_qual_A = p->min_qual_A; d->min_indel_A = p->min_indel_A;
+    d->min_qual_B = p->min_qual_B; d->min_indel_B = p->min_indel_B;
+    d->pblock = p->pblock; d->softclip = p->softclip; d->perfect_col = p->perfect_col;
+    d->indel_fract = p->indel_fract; d->min_discrep_A = p->min_discrep_A;
+    d->min_discrep_B = p->min_discrep_B; d->low_mqual_perc = p->low_mqual_perc;
+    d->clip_perc = p->clip_perc; d->ins_len_perc = p->ins_len_perc;
+    d->over_depth = p->over_depth; d->indel_ov_perc = p->indel_ov_perc;
+    d->str_snp = (p->sSTR_add || p->sSTR_mul) ? 1 : 0;
+    for (int i = 0; i < 256; i++) {
+        d->preserve_qual[i] = p->preserve_qual[i];
+        if (p->preserve_qual[i]) d->any_preserve = 1;
+    }
+    crumble_init_bins(p, d->bin2);
+    /* fences */
+    if (p->min_qual_A != 0 && p->min_qual_B != 0) {
+        g_last_error = "running consensus modes A (-q) and B (-Q) together is not supported yet";
+        return CRUMBLE_EINVAL;
+    }
+    if (p->qcap < 0 || p->qcap > 100 || p->qlow < 0 || p->qlow > 127 || p->qhigh < 0 || p->qhigh > 127) {
+        g_last_error = "qcap must be in 0..100 and qlow/qhigh in 0..127 (SURVEY.md Q5/Q13)";
+        return CRUMBLE_EINVAL;
+    }
+    for (int i = 101; i < 256; i++)
+        if (p->preserve_qual[i]) { g_last_error = "preserved qualities must be <= 100 (SURVEY.md Q5)"; return CRUMBLE_EINVAL; }
+    return CRUMBLE_OK;
+}
+
+/* ---------------------------------------------------------------- create */
+extern "C" crumble_hip *crumble_hip_create(const crumble_params *p, int device, int *err)
+{
+    int e = CRUMBLE_OK, ndev = 0;
+    crumble_hip *h = nullptr;
+    DTables *tab = nullptr;
+    auto fail = [&](int code) -> crumble_hip * {
+        if (err) *err = code;
+        if (h) crumble_hip_destroy(h);
+        free(tab);
+        return nullptr;
+    };
+    if (!p) return fail(CRUMBLE_EINVAL);
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_last_error = "no HIP device visible";
+        return fail(CRUMBLE_ENODEVICE);
+    }
+    if (device < 0 || device >= ndev) { g_last_error = "device index out of range"; return fail(CRUMBLE_EINVAL); }
+    h = new crumble_hip();
+    h->device = device;
+    h->params = *p;
+    if ((e = fill_dparams(p, &h->hparams)) != CRUMBLE_OK) return fail(e);
+    if (hipSetDevice(device) != hipSuccess) { g_last_error = "hipSetDevice failed"; return fail(CRUMBLE_EHIP); }
+    if (hipStreamCreate(&h->stream) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(CRUMBLE_EHIP); }
+    for (int i = 0; i <= MAX_STAGES; i++)
+        if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(CRUMBLE_EHIP); }
+    h->events_ok = true;
+    tab = (DTables *)calloc(1, sizeof(DTables));
+    if (!tab) return fail(CRUMBLE_ENOMEM);
+    build_tables(tab);
+    if ((e = h->d_params.reserve(sizeof(DParams))) || (e = h->d_tables.reserve(sizeof(DTables))) ||
+        (e = h->d_stats.reserve(CRUMBLE_ST_N * 8)) || (e = h->d_batch_stats.reserve(CRUMBLE_ST_N * 8)) ||
+        (e = h->d_misc.reserve(256)))
+        return fail(e);
+    if (hipMemcpy(h->d_params.p, &h->hparams, sizeof(DParams), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->d_tables.p, tab, sizeof(DTables), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(h->d_stats.p, 0, CRUMBLE_ST_N * 8) != hipSuccess ||
+        hipMemset(h->d_batch_stats.p, 0, CRUMBLE_ST_N * 8) != hipSuccess) {
+        g_last_error = "uploading tables failed";
+        return fail(CRUMBLE_EHIP);
+    }
+    free(tab);
+    if (err) *err = CRUMBLE_OK;
+    return h;
+}
+
+extern "C" void crumble_hip_destroy(crumble_hip *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    DevBuf *all[] = { &h->d_params, &h->d_tables, &h->d_stats, &h->d_batch_stats, &h->d_misc,
+        &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
+        &h->d_cigar, &h->d_segs, &h->d_bases, &h->d_quals, &h->d_tile_lo, &h->d_tile_hi,
+        &h->d_bed_start, &h->d_bed_end, &h->d_bed_pmax, &h->d_colrec, &h->d_nplp, &h->d_score,
+        &h->d_trigcnt, &h->d_dpre, &h->d_col_ord, &h->d_trig_ord, &h->d_item_off, &h->d_ins_ord,
+        &h->d_pos_mn2, &h->d_partial, &h->d_epochs, &h->d_trigcol_pos, &h->d_trigcol_off,
+        &h->d_inscol_pos, &h->d_items, &h->d_colhi, &h->d_ub, &h->d_pmax_partial, &h->d_trig_mx2,
+        &h->d_out, &h->d_rflags };
+    for (DevBuf *b : all) b->release();
+    if (h->events_ok) for (int i = 0; i <= MAX_STAGES; i++) (void)hipEventDestroy(h->ev[i]);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+/* ------------------------------------------------------------- P0 expand */
+static inline int cig_type(int op) { return (0x3C1A7 >> (op << 1)) & 3; }
+static inline bool is_mdnx(int op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
+
+/* bam_pileup1_t.indel on the last column of ref-op k (htslib resolve_cigar2's
+ * peek at the next op) */
+static int indel_after(const uint32_t *cig, int n, int k)
+{
+    if (k + 1 >= n) return 0;
+    int op = cig[k] & 15, op2 = cig[k + 1] & 15, l2 = (int)(cig[k + 1] >> 4), indel = 0, j;
+    if (op2 == 2 && op != 2) {
+        indel = -l2;
+        for (j = k + 2; j < n; j++) { if ((cig[j] & 15) == 2) indel -= (int)(cig[j] >> 4); else break; }
+    } else if (op2 == 1) {
+        indel = l2;
+        for (j = k + 2; j < n; j++) {
+            int o = cig[j] & 15;
+            if (o == 1) indel += (int)(cig[j] >> 4); else if (o != 6) break;
+        }
+    } else if (op2 == 6 && k + 2 < n) {
+        int l3 = 0;
+        for (j = k + 2; j < n; j++) {
+            int o = cig[j] & 15;
+            if (o == 1) l3 += (int)(cig[j] >> 4);
+            else if (o == 2 || o == 0 || o == 3 || o == 7 || o == 8) break;
+        }
+        if (l3 > 0) indel = l3;
+    }
+    return indel;
+}
+
+template <class T>
+static int up(crumble_hip *h, DevBuf &d, const T *src, size_t n)
+{
+    int e = d.reserve((n ? n : 1) * sizeof(T));
+    if (e) return e;
+    if (n) HIPCHK(hipMemcpyAsync(d.p, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    return CRUMBLE_OK;
+}
+
+extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
+{
+    if (!h || !b || b->n_reads < 0) return CRUMBLE_EINVAL;
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t n = b->n_reads;
+    const int64_t nb = n ? b->seq_off[n] : 0, nc = n ? b->cig_off[n] : 0;
+    if (n >= (int64_t)INT_MAX - 64) { g_last_error = "more than 2^31 reads in one batch"; return CRUMBLE_EINVAL; }
+    h->have_batch = false; h->have_run = false;
+
+    std::vector<int32_t> end(n + 1);
+    std::vector<uint8_t> inplp(n + 1);
+    std::vector<int64_t> seg_off(n + 1);
+    std::vector<Seg> segs;
+    segs.reserve((size_t)(n + n / 4 + 16));
+    int64_t first = -1;
+    int32_t last_pos = INT_MIN, max_end = INT_MIN, p0 = 0;
+    for (int64_t r = 0; r < n; r++) {
+        const uint32_t *cig = b->cigar + b->cig_off[r];
+        const int ncg = (int)(b->cig_off[r + 1] - b->cig_off[r]);
+        const int64_t lq = b->seq_off[r + 1] - b->seq_off[r];
+        seg_off[r] = (int64_t)segs.size();
+        end[r] = b->pos[r];
+        inplp[r] = 0;
+        if (lq < 0 || ncg < 0) { g_last_error = "negative read or cigar length"; return CRUMBLE_EINVAL; }
+        /* pileup_callback routing (snp:1130-1149) + htslib's default filter */
+        if (b->tid < 0 || (b->flag[r] & (4 | 256 | 512 | 1024))) continue;
+        int x = 0, y = 0; bool any = false;
+        for (int k = 0; k < ncg; k++) {
+            const int op = cig[k] & 15, l = (int)(cig[k] >> 4);
+            if (is_mdnx(op)) {
+                Seg s;
+                s.roff = x; s.qstart = y;
+                s.len_type = (uint32_t)l | ((op == 2 ? SEG_D : op == 3 ? SEG_N : SEG_M) << 30);
+                s.indel_after = indel_after(cig, ncg, k);
+                if (l > 0) { segs.push_back(s); any = true; }
+                x += l;
+                if (op != 2 && op != 3) y += l;
+            } else if (op == 1 || op == 4) y += l;
+        }
+        if (!any || x <= 0) { segs.resize((size_t)seg_off[r]); continue; }
+        if (y != lq && lq != 0) { g_last_error = "CIGAR query length differs from l_qseq"; return CRUMBLE_EINVAL; }
+        if (b->pos[r] < last_pos) return CRUMBLE_EUNSORTED;       /* snp:1075 */
+        if (b->pos[r] < 0 || (int64_t)b->pos[r] + x >= (int64_t)INT_MAX - 64) { g_last_error = "coordinate out of range"; return CRUMBLE_EINVAL; }
+        last_pos = b->pos[r];
+        inplp[r] = 1;
+        end[r] = b->pos[r] + x;
+        if (first < 0) { first = r; p0 = b->pos[r]; }
+        if (end[r] > max_end) max_end = end[r];
+    }
+    seg_off[n] = (int64_t)segs.size();
+    for (int64_t i = 0; i < nb; i++)
+        if (b->quals[i] & 0x80) { g_last_error = "input quality >= 128 (SURVEY.md Q13)"; return CRUMBLE_EINVAL; }
+
+    DBatch &B = h->B;
+    memset(&B, 0, sizeof(B));
+    B.n_reads = n; B.n_bases = nb;
+    B.p0 = p0;
+    B.L = (first >= 0) ? (max_end - p0) : 0;
+    B.n_tiles = (B.L + 63) / 64;
+    /* candidate read range per 64-column tile (reads are sorted by pos) */
+    std::vector<int32_t> tile_lo(B.n_tiles + 1), tile_hi(B.n_tiles + 1);
+    {
+        int64_t lo = 0, hi = 0;
+        for (int t = 0; t < B.n_tiles; t++) {
+            const int64_t c0 = (int64_t)p0 + (int64_t)t * 64, c1 = c0 + 63;
+            while (hi < n && (!inplp[hi] || b->pos[hi] <= c1)) hi++;
+            while (lo < hi && (!inplp[lo] || end[lo] <= c0)) lo++;
+            tile_lo[t] = (int32_t)lo; tile_hi[t] = (int32_t)hi;
+        }
+    }
+    /* keep-regions: prefix max of `end` drives the cursor emulation */
+    std::vector<int32_t> pmax(b->n_bed > 0 ? b->n_bed : 1);
+    for (int i = 0; i < b->n_bed; i++) pmax[i] = (i && pmax[i - 1] > b->bed_end[i]) ? pmax[i - 1] : b->bed_end[i];
+    B.n_bed = b->n_bed > 0 ? b->n_bed : 0;
+
+    int e;
+    if ((e = up(h, h->d_pos, b->pos, n)) || (e = up(h, h->d_end, end.data(), n)) ||
+        (e = up(h, h->d_mapq, b->mapq, n)) || (e = up(h, h->d_inplp, inplp.data(), n)) ||
+        (e = up(h, h->d_seq_off, b->seq_off, n + 1)) || (e = up(h, h->d_cig_off, b->cig_off, n + 1)) ||
+        (e = up(h, h->d_seg_off, seg_off.data(), n + 1)) || (e = up(h, h->d_cigar, b->cigar, nc)) ||
+        (e = up(h, h->d_segs, segs.data(), segs.size())) || (e = up(h, h->d_bases, b->bases, nb)) ||
+        (e = up(h, h->d_quals, b->quals, nb)) || (e = up(h, h->d_tile_lo, tile_lo.data(), B.n_tiles)) ||
+        (e = up(h, h->d_tile_hi, tile_hi.data(), B.n_tiles)) ||
+        (e = up(h, h->d_bed_start, b->bed_start, B.n_bed)) || (e = up(h, h->d_bed_end, b->bed_end, B.n_bed)) ||
+        (e = up(h, h->d_bed_pmax, pmax.data(), B.n_bed)))
+        return e;
+    HIPCHK(hipStreamSynchronize(h->stream));    /* host vectors die here */
+    B.pos = h->d_pos.as<int32_t>(); B.end = h->d_end.as<int32_t>();
+    B.mapq = h->d_mapq.as<uint8_t>(); B.inplp = h->d_inplp.as<uint8_t>();
+    B.seq_off = h->d_seq_off.as<int64_t>(); B.cig_off = h->d_cig_off.as<int64_t>();
+    B.seg_off = h->d_seg_off.as<int64_t>(); B.cigar = h->d_cigar.as<uint32_t>();
+    B.segs = h->d_segs.as<Seg>(); B.bases = h->d_bases.as<uint8_t>(); B.quals = h->d_quals.as<uint8_t>();
+    B.tile_lo = h->d_tile_lo.as<int32_t>(); B.tile_hi = h->d_tile_hi.as<int32_t>();
+    B.bed_start = h->d_bed_start.as<int32_t>(); B.bed_end = h->d_bed_end.as<int32_t>();
+    B.bed_pmax = h->d_bed_pmax.as<int32_t>();
+    h->n_reads = n; h->n_bases = nb; h->n_cigar = nc;
+
+    const size_t L = (size_t)(B.L > 0 ? B.L : 1);
+    const int nchunks = (int)((L + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    if ((e = h->d_colrec.reserve(L * 4)) || (e = h->d_nplp.reserve(L * 4)) || (e = h->d_score.reserve(L * 4)) ||
+        (e = h->d_trigcnt.reserve(L * 4)) || (e = h->d_dpre.reserve(L * 8)) || (e = h->d_col_ord.reserve(L * 4)) ||
+        (e = h->d_trig_ord.reserve(L * 4)) || (e = h->d_item_off.reserve(L * 4)) || (e = h->d_ins_ord.reserve(L * 4)) ||
+        (e = h->d_pos_mn2.reserve(L * 4)) || (e = h->d_partial.reserve((size_t)(nchunks + 2) * sizeof(ScanVal))) ||
+        (e = h->d_epochs.reserve(MAX_EPOCHS * sizeof(Epoch))) ||
+        (e = h->d_out.reserve((size_t)(nb ? nb : 1))) || (e = h->d_rflags.reserve((size_t)(n ? n : 1))))
+        return e;
+    h->have_batch = true;
+    return CRUMBLE_OK;
+}
+
+/* -------------------------------------------------------------------- run */
+static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b > 0 ? (n + b - 1) / b : 1); }
+
+#define STAGE(name_, bytes_) do { if (h->n_stages < MAX_STAGES) { \
+    HIPCHK(hipEventRecord(h->ev[h->n_stages], st)); \
+    h->stage_name[h->n_stages] = name_; h->stage_bytes[h->n_stages] = (double)(bytes_); h->n_stages++; } } while (0)
+
+extern "C" int crumble_hip_run(crumble_hip *h)
+{
+    if (!h || !h->have_batch) { g_last_error = "no batch uploaded"; return CRUMBLE_EINVAL; }
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const DBatch &B = h->B;
+    const DParams *P = h->d_params.as<DParams>();
+    const DTables *T = h->d_tables.as<DTables>();
+    u64 *stats = h->d_batch_stats.as<u64>();
+    int *d_overflow = h->d_misc.as<int>();        /* [0] overflow flag, [1] n_epochs */
+    int *d_nep = d_overflow + 1;
+    const int L = B.L;
+    const int64_t n = B.n_reads, nb = B.n_bases;
+    uint32_t *colrec = h->d_colrec.as<uint32_t>();
+    int32_t *nplp = h->d_nplp.as<int32_t>(), *score = h->d_score.as<int32_t>();
+    int32_t *trigcnt = h->d_trigcnt.as<int32_t>();
+    /* algorithmic bytes of the whole pass: 3 B/base + 32 B/read + 8 B/cigar op */
+    const double algo_bytes = 3.0 * nb + 32.0 * n + 8.0 * h->n_cigar;
+
+    h->n_stages = 0; h->have_run = false;
+    memset(&h->totals, 0, sizeof(h->totals));
+    HIPCHK(hipMemsetAsync(stats, 0, CRUMBLE_ST_N * 8, st));
+    HIPCHK(hipMemsetAsync(d_overflow, 0, 8, st));
+
+    if (L > 0) {
+        STAGE("k_columns", 2.0 * nb + 32.0 * n + 8.0 * h->n_cigar);
+        const bool modeB = h->hparams.min_qual_B != 0;
+        const unsigned grid = nblk(B.n_tiles, 4);
+        if (modeB) CRUMBLE_LAUNCH(k_columns<true>, grid, 256, st, B, P, T, colrec, nplp, score, trigcnt, stats);
+        else       CRUMBLE_LAUNCH(k_columns<false>, grid, 256, st, B, P, T, colrec, nplp, score, trigcnt, stats);
+
+        STAGE("scan", 0);
+        const int nchunks = (L + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        ScanVal *partial = h->d_partial.as<ScanVal>();
+        CRUMBLE_LAUNCH_INDEP(k_scan_reduce, nblk(nchunks, 64), 64, st, L, colrec, nplp, trigcnt, partial, nchunks);
+        CRUMBLE_LAUNCH_INDEP(k_scan_partials, 1, 1, st, partial, nchunks);
+        CRUMBLE_LAUNCH_INDEP(k_scan_apply, nblk(nchunks, 64), 64, st, L, colrec, nplp, trigcnt, partial, nchunks,
+                             h->d_dpre.as<int64_t>(), h->d_col_ord.as<int32_t>(), h->d_trig_ord.as<int32_t>(),
+                             h->d_item_off.as<int32_t>(), h->d_ins_ord.as<int32_t>());
+        CRUMBLE_LAUNCH_INDEP(k_epochs, 1, 1, st, L, colrec, nplp, h->d_col_ord.as<int32_t>(), h->d_dpre.as<int64_t>(),
+                             partial + nchunks, h->d_epochs.as<Epoch>(), d_nep);
+        HIPCHK(hipMemcpyAsync(&h->totals, partial + nchunks, sizeof(ScanVal), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));           /* sizes of the work lists */
+        const int n_trig = h->totals.trigcols, n_items = h->totals.items, n_ins = h->totals.ins;
+        int e;
+        if ((e = h->d_trigcol_pos.reserve((size_t)(n_trig + 1) * 4)) || (e = h->d_trigcol_off.reserve((size_t)(n_trig + 1) * 4)) ||
+            (e = h->d_inscol_pos.reserve((size_t)(n_ins + 1) * 4)) || (e = h->d_items.reserve((size_t)(n_items + 1) * sizeof(TrigItem))) ||
+            (e = h->d_colhi.reserve((size_t)(n_trig + 1) * 4)) || (e = h->d_ub.reserve((size_t)(n_trig + 1) * 4)) ||
+            (e = h->d_trig_mx2.reserve((size_t)(n_trig + 1) * 4)) || (e = h->d_pmax_partial.reserve((size_t)(n_trig / 256 + 2) * 4)))
+            return e;
+        int32_t *trigcol_pos = h->d_trigcol_pos.as<int32_t>(), *trigcol_off = h->d_trigcol_off.as<int32_t>();
+        int32_t *inscol_pos = h->d_inscol_pos.as<int32_t>();
+        TrigItem *items = h->d_items.as<TrigItem>();
+
+        STAGE("k_overdepth", 0);
+        CRUMBLE_LAUNCH_INDEP(k_overdepth, nblk(L, 256), 256, st, L, colrec, nplp, h->d_col_ord.as<int32_t>(),
+                             h->d_dpre.as<int64_t>(), h->d_trig_ord.as<int32_t>(), h->d_item_off.as<int32_t>(),
+                             h->d_ins_ord.as<int32_t>(), h->d_epochs.as<Epoch>(), d_nep, P,
+                             trigcol_pos, trigcol_off, inscol_pos, stats);
+        if (n_ins > 0) {
+            STAGE("k_inshist", 0);
+            CRUMBLE_LAUNCH_INDEP(k_inshist, nblk(n_ins, 64), 64, st, B, P, n_ins, inscol_pos, colrec, nplp, stats);
+        }
+        if (n_trig > 0) {
+            STAGE("k_emit", 0);
+            CRUMBLE_LAUNCH_INDEP(k_emit, nblk(n_trig, 64), 64, st, B, P, n_trig, trigcol_pos, trigcol_off, colrec, items);
+            STAGE("k_str", 0);
+            CRUMBLE_LAUNCH_INDEP(k_str, nblk(n_items, 64), 64, st, B, P, n_items, items, d_overflow);
+            STAGE("k_fold", 0);
+            int32_t *colhi = h->d_colhi.as<int32_t>(), *ub = h->d_ub.as<int32_t>();
+            int32_t *pp = h->d_pmax_partial.as<int32_t>();
+            const int chunk = 256, nch = (n_trig + chunk - 1) / chunk;
+            CRUMBLE_LAUNCH_INDEP(k_fold_bounds, nblk(n_trig, 64), 64, st, B, P, n_trig, trigcol_pos, trigcol_off, trigcnt, items, colhi);
+            CRUMBLE_LAUNCH_INDEP(k_pmax_reduce, nblk(nch, 64), 64, st, n_trig, colhi, pp, nch, chunk);
+            CRUMBLE_LAUNCH_INDEP(k_pmax_partials, 1, 1, st, pp, nch);
+            CRUMBLE_LAUNCH_INDEP(k_pmax_apply, nblk(nch, 64), 64, st, n_trig, colhi, pp, nch, chunk);
+            CRUMBLE_LAUNCH_INDEP(k_fold_ub, nblk(n_trig, 64), 64, st, B, P, n_trig, trigcol_pos, colhi, ub);
+            CRUMBLE_LAUNCH_INDEP(k_pmax_reduce, nblk(nch, 64), 64, st, n_trig, ub, pp, nch, chunk);
+            CRUMBLE_LAUNCH_INDEP(k_pmax_partials, 1, 1, st, pp, nch);
+            CRUMBLE_LAUNCH_INDEP(k_pmax_apply, nblk(nch, 64), 64, st, n_trig, ub, pp, nch, chunk);
+            CRUMBLE_LAUNCH_INDEP(k_fold, nblk(n_trig, 64), 64, st, B, P, n_trig, trigcol_pos, trigcol_off, trigcnt, items, ub,
+                                 colrec, h->d_pos_mn2.as<int32_t>(), h->d_trig_mx2.as<int32_t>());
+            CRUMBLE_LAUNCH_INDEP(k_window, nblk(n_trig, 64), 64, st, B, n_trig, trigcol_pos, h->d_trig_mx2.as<int32_t>(), colrec);
+        }
+    }
+    if (n > 0) {
+        STAGE("k_replay", 3.0 * nb);
+        CRUMBLE_LAUNCH_INDEP(k_replay, nblk(n, 64), 64, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
+                             h->d_out.as<uint8_t>(), h->d_rflags.as<uint8_t>());
+        if (h->hparams.pblock) {
+            STAGE("k_pblock", 2.0 * nb);
+            CRUMBLE_LAUNCH_INDEP(k_pblock, nblk(n, 64), 64, st, n, B.seq_off, h->d_out.as<uint8_t>(),
+                                 h->d_rflags.as<uint8_t>(), P);
+        }
+        STAGE("k_stats", 2.0 * nb);
+        CRUMBLE_LAUNCH(k_stats, 1024, 256, st, nb, n, h->d_out.as<uint8_t>(), B.quals, stats);
+    }
+    HIPCHK(hipEventRecord(h->ev[h->n_stages], st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    for (int i = 0; i < h->n_stages; i++)
+        HIPCHK(hipEventElapsedTime(&h->stage_ms[i], h->ev[i], h->ev[i + 1]));
+    (void)algo_bytes;
+    int ovf[2] = {0, 0};
+    HIPCHK(hipMemcpy(ovf, d_overflow, 8, hipMemcpyDeviceToHost));
+    if (ovf[0]) { g_last_error = "STR repeat list overflow"; return CRUMBLE_EOVERFLOW; }
+    /* fold this batch's counters into the engine's accumulated stats vector (device side) */
+    {
+        std::vector<int64_t> a(CRUMBLE_ST_N), bsum(CRUMBLE_ST_N);
+        HIPCHK(hipMemcpy(a.data(), h->d_stats.p, CRUMBLE_ST_N * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(bsum.data(), h->d_batch_stats.p, CRUMBLE_ST_N * 8, hipMemcpyDeviceToHost));
+        for (int i = 0; i < CRUMBLE_ST_N; i++) a[i] += bsum[i];
+        HIPCHK(hipMemcpy(h->d_stats.p, a.data(), CRUMBLE_ST_N * 8, hipMemcpyHostToDevice));
+    }
+    h->have_run = true;
+    return CRUMBLE_OK;
+}
+
+extern "C" int crumble_hip_download(crumble_hip *h, uint8_t *qual_out, uint8_t *read_flags_out, int64_t *stats)
+{
+    if (!h || !h->have_run) { g_last_error = "nothing to download: call crumble_hip_run first"; return CRUMBLE_EINVAL; }
+    HIPCHK(hipSetDevice(h->device));
+    if (qual_out && h->n_bases) HIPCHK(hipMemcpy(qual_out, h->d_out.p, (size_t)h->n_bases, hipMemcpyDeviceToHost));
+    if (read_flags_out && h->n_reads) HIPCHK(hipMemcpy(read_flags_out, h->d_rflags.p, (size_t)h->n_reads, hipMemcpyDeviceToHost));
+    if (stats) {
+        int64_t s[CRUMBLE_ST_N];
+        HIPCHK(hipMemcpy(s, h->d_batch_stats.p, sizeof s, hipMemcpyDeviceToHost));
+        for (int i = 0; i < CRUMBLE_ST_N; i++) stats[i] += s[i];
+    }
+    return CRUMBLE_OK;
+}
+
+extern "C" int crumble_hip_contig(crumble_hip *h, const crumble_batch *b, uint8_t *qual_out,
+                                  uint8_t *read_flags_out, int64_t *stats)
+{
+    int e;
+    if ((e = crumble_hip_upload(h, b))) return e;
+    if ((e = crumble_hip_run(h))) return e;
+    return crumble_hip_download(h, qual_out, read_flags_out, stats);
+}
+
+extern "C" int crumble_hip_kernel_times(crumble_hip *h, const char **names, float *ms, double *bytes, int max)
+{
+    if (!h || !h->have_run) return 0;
+    int n = h->n_stages < max ? h->n_stages : max;
+    for (int i = 0; i < n; i++) {
+        if (names) names[i] = h->stage_name[i];
+        if (ms) ms[i] = h->stage_ms[i];
+        if (bytes) bytes[i] = h->stage_bytes[i];
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------ stats */
+extern "C" void *crumble_hip_stats_devptr(crumble_hip *h) { return h ? h->d_stats.p : nullptr; }
+extern "C" int crumble_hip_stats_reset(crumble_hip *h)
+{
+    if (!h) return CRUMBLE_EINVAL;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemset(h->d_stats.p, 0, CRUMBLE_ST_N * 8));
+    return CRUMBLE_OK;
+}
+extern "C" int crumble_hip_stats_read(crumble_hip *h, int64_t *stats)
+{
+    if (!h || !stats) return CRUMBLE_EINVAL;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpy(stats, h->d_stats.p, CRUMBLE_ST_N * 8, hipMemcpyDeviceToHost));
+    return CRUMBLE_OK;
+}
+
+/* The single collective of the path: sum the int64 stats vector over ranks
+ * (RCCL over xGMI).  librccl is resolved at run time so that the library loads
+ * on hosts without it. */
+extern "C" int crumble_hip_stats_allreduce(crumble_hip *h, void *nccl_comm)
+{
+#ifdef CRUMBLE_EMU
+    (void)h; (void)nccl_comm;
+    return CRUMBLE_ERCCL;
+#else
+    typedef int (*allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    static allreduce_fn fn = nullptr;
+    if (!h || !nccl_comm) return CRUMBLE_EINVAL;
+    if (!fn) {
+        void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) { g_last_error = "librccl.so not found"; return CRUMBLE_ERCCL; }
+        fn = (allreduce_fn)dlsym(lib, "ncclAllReduce");
+        if (!fn) { g_last_error = "ncclAllReduce not found"; return CRUMBLE_ERCCL; }
+    }
+    HIPCHK(hipSetDevice(h->device));
+    /* ncclInt64 = 4, ncclSum = 0 */
+    int rc = fn(h->d_stats.p, h->d_stats.p, CRUMBLE_ST_N, 4, 0, nccl_comm, h->stream);
+    if (rc != 0) { g_last_error = "ncclAllReduce failed"; return CRUMBLE_ERCCL; }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CRUMBLE_OK;
+#endif
+}
+
+/* ---------------------------------------------------- operator-level seams */
+extern "C" int64_t crumble_hip_columns(crumble_hip *h, crumble_column *cols, int64_t max)
+{
+    if (!h || !h->have_run) return CRUMBLE_EINVAL;
+    if (hipSetDevice(h->device) != hipSuccess) return CRUMBLE_EHIP;
+    const int L = h->B.L;
+    std::vector<uint32_t> rec(L > 0 ? L : 1);
+    std::vector<int32_t> np(L > 0 ? L : 1), sc(L > 0 ? L : 1), mn2(L > 0 ? L : 1);
+    if (L > 0) {
+        if (hipMemcpy(rec.data(), h->d_colrec.p, (size_t)L * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(np.data(), h->d_nplp.p, (size_t)L * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(sc.data(), h->d_score.p, (size_t)L * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(mn2.data(), h->d_pos_mn2.p, (size_t)L * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return CRUMBLE_EHIP;
+    }
+    int64_t k = 0;
+    for (int i = 0; i < L; i++) {
+        const uint32_t r = rec[i];
+        if (!(r & CR_EXISTS)) continue;
+        if (cols && k < max) {
+            crumble_column *c = &cols[k];
+            memset(c, 0, sizeof(*c));
+            c->pos = h->B.p0 + i; c->n_plp = np[i];
+            c->skipped = (r & CR_ALLREFSKIP) ? 1 : (r & CR_TOODEEP) ? 2 : 0;
+            if (!c->skipped) {
+                c->score = sc[i];
+                c->call1 = CR_A1(r); c->call2 = CR_A2(r);
+                c->preserve = CR_PRESERVE(r); c->perfect = (r & CR_PERFECT) ? 1 : 0;
+                c->keep_qual = (r & CR_KEEP) ? 1 : 0;
+                c->trigger = (r & CR_TRIG) ? 1 : 0; c->window = (r & CR_WIN) ? 1 : 0;
+                c->min_pos2 = (r & CR_TRIG) ? mn2[i] : 0;
+            }
+        }
+        k++;
+    }
+    return k;
+}
+
+extern "C" int crumble_hip_mask_lc(crumble_hip *h, int64_t nq, const int64_t *read_idx, const int32_t *qpos1,
+                                   const uint8_t *is_indel, int32_t *lo, int32_t *hi)
+{
+    if (!h || !h->have_batch || nq < 0) return CRUMBLE_EINVAL;
+    if (nq == 0) return CRUMBLE_OK;
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<TrigItem> it((size_t)nq);
+    for (int64_t i = 0; i < nq; i++) {
+        if (read_idx[i] < 0 || read_idx[i] >= h->n_reads || qpos1[i] < 0) return CRUMBLE_EINVAL;
+        it[i].read = (int32_t)read_idx[i];
+        it[i].qpos1_kind = qpos1[i] | ((is_indel[i] ? 1 : 0) << 30);
+        it[i].lo = INT_MAX; it[i].hi = 0;
+    }
+    DevBuf d;
+    int e = d.reserve((size_t)nq * sizeof(TrigItem));
+    if (e) return e;
+    int *d_overflow = h->d_misc.as<int>();
+    HIPCHK(hipMemset(d_overflow, 0, 4));
+    HIPCHK(hipMemcpy(d.p, it.data(), (size_t)nq * sizeof(TrigItem), hipMemcpyHostToDevice));
+    CRUMBLE_LAUNCH_INDEP(k_str, nblk(nq, 64), 64, h->stream, h->B, h->d_params.as<DParams>(), (int)nq, d.as<TrigItem>(), d_overflow);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(it.data(), d.p, (size_t)nq * sizeof(TrigItem), hipMemcpyDeviceToHost));
+    int ovf = 0;
+    HIPCHK(hipMemcpy(&ovf, d_overflow, 4, hipMemcpyDeviceToHost));
+    d.release();
+    if (ovf) return CRUMBLE_EOVERFLOW;
+    for (int64_t i = 0; i < nq; i++) { lo[i] = it[i].lo; hi[i] = it[i].hi; }
+    return CRUMBLE_OK;
+}
+
+extern "C" int crumble_hip_pblock(crumble_hip *h, int64_t n_reads, const int64_t *seq_off, uint8_t *quals)
+{
+    if (!h || n_reads < 0 || !seq_off) return CRUMBLE_EINVAL;
+    if (n_reads == 0) return CRUMBLE_OK;
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t nb = seq_off[n_reads];
+    DevBuf dq, ds;
+    int e;
+    if ((e = dq.reserve((size_t)(nb ? nb : 1))) || (e = ds.reserve((size_t)(n_reads + 1) * 8))) return e;
+    if (nb) HIPCHK(hipMemcpy(dq.p, quals, (size_t)nb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ds.p, seq_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice));
+    if (h->hparams.pblock)
+        CRUMBLE_LAUNCH_INDEP(k_pblock, nblk(n_reads, 64), 64, h->stream, n_reads, ds.as<int64_t>(), dq.as<uint8_t>(),
+                             (const uint8_t *)nullptr, h->d_params.as<DParams>());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (nb) HIPCHK(hipMemcpy(quals, dq.p, (size_t)nb, hipMemcpyDeviceToHost));
+    dq.release(); ds.release();
+    return CRUMBLE_OK;
+}

@@ -169,7 +169,7 @@ __device__ __forceinline__ void cons_finalize(const DTables *T, double *S, const
 {
     const int map_sing[15] = {0,5,5,5,5, 1,5,5,5, 2,5,5, 3,5, 4};
     const int map_het[15]  = {0,1,2,3,4, 6,7,8,9, 12,13,14, 18,19, 24};
-    const double min_e_exp = -706.6895275309849;     /* DBL_MIN_EXP*log(2)+1, host-checked */
+    const double min_e_exp = T->min_e_exp;            /* DBL_MIN_EXP*log(2)+1 (snp:540), host libm */
     double shift = -DBL_MAX, max = -DBL_MAX, max_het = -DBL_MAX, norm[15];
     int call = 0, het_call = 0, ph, j;
     double tot1, tot2;
@@ -587,7 +587,7 @@ __global__ void k_emit(DBatch B, const DParams *P, int n_trig, const int32_t *tr
         const int is_indel = (e.indel || e.is_del) ? 1 : 0;
         if (!(is_indel || snp_kind)) continue;
         TrigItem it;
-        it.read = r; it.qpos1_kind = (e.qpos + 1) | (is_indel << 30);
+        it.read = r; it.qpos1_kind = (e.qpos + 1) | (is_indel << 30) | ((rec & CR_SCAN) ? 0 : (1 << 29));
         it.lo = INT_MAX; it.hi = 0;
         items[o++] = it;
     }
@@ -608,53 +608,58 @@ __device__ __forceinline__ int str_code(const StrWin &w, int i)
     return (c16 == 2) ? 1 : (c16 == 4) ? 2 : (c16 == 8) ? 3 : 0;
 }
 
+/* add_rep (str_finder.c:34-127) without pads; the utlist list is an ordered array */
+__device__ inline int dev_add_rep(const StrWin &w, int len, int pos, int rlen,
+                                  short *st, short *en, int n, int *overflow)
+{
+    if (n && st[n - 1] <= pos - rlen * 2 + 1 && en[n - 1] >= pos) return n;   /* :41-45 */
+    int cp1 = pos + 1 - rlen, cp2 = pos + 1;
+    while (cp2 < len && str_code(w, cp1) == str_code(w, cp2)) { cp1++; cp2++; }  /* :62-75 */
+    const int el_end = cp2 - 1, el_start = pos + 1 - 2 * rlen;
+    if (n) {                                            /* :106-122 */
+        int cur = n - 1;
+        for (;;) {
+            const bool was_head = (cur == 0);
+            int prev = was_head ? n - 1 : cur - 1;      /* head->prev is the tail */
+            bool deleted = false;
+            if (en[cur] < el_start) break;
+            if (st[cur] >= el_start) {
+                for (int k = cur; k < n - 1; k++) { st[k] = st[k + 1]; en[k] = en[k + 1]; }
+                n--; deleted = true;
+            }
+            if (was_head && !deleted) break;
+            if (!n) break;
+            if (was_head) prev = n - 1;
+            cur = prev;
+        }
+    }
+    if (n < STR_CAP) { st[n] = (short)el_start; en[n] = (short)el_end; n++; }
+    else *overflow = 1;
+    return n;
+}
+
+/* find_STR (str_finder.c:135-189) */
 __device__ inline int dev_find_STR(const StrWin &w, int len, short *st, short *en, int *overflow)
 {
     int n = 0;
     uint32_t word = 0;
     for (int i = 0; i < len; i++) {
         word = (word << 2) | (uint32_t)str_code(w, i);
-        /* candidate periods for this position (str_finder.c:140-186) */
-        int first, last;
-        if (i < 15) { first = 1; last = 7; }           /* every fitting period */
-        else        { first = 8; last = 1; }           /* largest matching only */
-        for (int step = 0; step < 8; step++) {
-            int rlen = (i < 15) ? first + step : first - step;
-            if (i < 15) { if (rlen > last) break; if (i < 2 * rlen - 1) continue; }
-            else if (rlen < last) break;
-            const uint32_t mask = (rlen == 8) ? 0xffffu : ((1u << (2 * rlen)) - 1);
-            if ((word & mask) != ((word >> (2 * rlen)) & mask)) continue;
-
-            /* ---- add_rep(pos = i, rlen) ---- */
-            bool handled = false;
-            if (n) {
-                if (st[n - 1] <= i - rlen * 2 + 1 && en[n - 1] >= i) handled = true;
+        if (i < 15) {                                   /* every period that fits */
+            for (int rlen = 1; rlen <= 7; rlen++) {
+                if (i < 2 * rlen - 1) break;
+                const uint32_t mask = (1u << (2 * rlen)) - 1;
+                if ((word & mask) == ((word >> (2 * rlen)) & mask))
+                    n = dev_add_rep(w, len, i, rlen, st, en, n, overflow);
             }
-            if (!handled) {
-                int cp1 = i + 1 - rlen, cp2 = i + 1;
-                while (cp2 < len && str_code(w, cp1) == str_code(w, cp2)) { cp1++; cp2++; }
-                const int el_end = cp2 - 1, el_start = i + 1 - 2 * rlen;
-                if (n) {                                /* str_finder.c:106-122 */
-                    int cur = n - 1;
-                    for (;;) {
-                        const bool was_head = (cur == 0);
-                        int prev = was_head ? n - 1 : cur - 1;
-                        bool deleted = false;
-                        if (en[cur] < el_start) break;
-                        if (st[cur] >= el_start) {
-                            for (int k = cur; k < n - 1; k++) { st[k] = st[k + 1]; en[k] = en[k + 1]; }
-                            n--; deleted = true;
-                        }
-                        if (was_head && !deleted) break;
-                        if (!n) break;
-                        if (was_head) prev = n - 1;
-                        cur = prev;
-                    }
+        } else {                                        /* largest matching period only */
+            for (int rlen = 8; rlen >= 1; rlen--) {
+                const uint32_t mask = (rlen == 8) ? 0xffffu : ((1u << (2 * rlen)) - 1);
+                if ((word & mask) == ((word >> (2 * rlen)) & mask)) {
+                    n = dev_add_rep(w, len, i, rlen, st, en, n, overflow);
+                    break;
                 }
-                if (n < STR_CAP) { st[n] = (short)el_start; en[n] = (short)el_end; n++; }
-                else *overflow = 1;
             }
-            if (i >= 15) break;                         /* else-if chain */
         }
     }
     return n;
@@ -716,15 +721,14 @@ __device__ inline void dev_mask_lc(const DBatch &B, const DParams *P, int r, int
     }
 }
 
-__global__ void k_str(DBatch B, const DParams *P, int n_items, TrigItem *items,
-                      const int32_t *item_col /* may be NULL */, const uint32_t *colrec, int *overflow)
+__global__ void k_str(DBatch B, const DParams *P, int n_items, TrigItem *items, int *overflow)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_items) return;
-    TrigItem it = items[t];
-    if (item_col && !(colrec[item_col[t]] & CR_SCAN)) return;   /* snp:1732 */
+    const TrigItem it = items[t];
+    if (it.qpos1_kind & (1 << 29)) return;            /* indel_cnt < n_plp*indel_fract: snp:1732 */
     int lo = INT_MAX, hi = 0;
-    dev_mask_lc(B, P, it.read, it.qpos1_kind & 0x3fffffff, (it.qpos1_kind >> 30) & 1, &lo, &hi, overflow);
+    dev_mask_lc(B, P, it.read, it.qpos1_kind & 0x1fffffff, (it.qpos1_kind >> 30) & 1, &lo, &hi, overflow);
     items[t].lo = lo; items[t].hi = hi;
 }
 

@@ -17,11 +17,12 @@ _lib = None
 
 
 class CrumbleError(RuntimeError):
-    def __init__(self, code, where=""):
+    def __init__(self, code, where="", library=None):
         self.code = code
-        msg = lib().crumble_hip_strerror(code).decode()
+        L = library if library is not None else lib()
+        msg = L.crumble_hip_strerror(code).decode()
         try:
-            detail = lib().crumble_hip_last_error().decode()
+            detail = L.crumble_hip_last_error().decode()
         except Exception:
             detail = ""
         super().__init__(f"{where}: {msg} ({code}) {detail}".strip())
@@ -38,14 +39,14 @@ def build_library(verbose=False):
     return LIB_PATH
 
 
-def load_library(path=None):
+def load_library(path=None, make_default=True):
     global _lib
     path = path or LIB_PATH
     if not os.path.exists(path):
         raise FileNotFoundError(
             f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback)")
-    L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    L = C.CDLL(path, mode=C.RTLD_LOCAL)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     PP = C.POINTER(Params)
     sig = {
@@ -78,7 +79,8 @@ def load_library(path=None):
         except AttributeError:        # tests/test_abi.py checks completeness
             continue
         f.restype, f.argtypes = res, args
-    _lib = L
+    if make_default:
+        _lib = L
     return L
 
 
@@ -131,39 +133,40 @@ def _vp(a):
 class Engine:
     """One crumble_hip handle (one GPU, one stream)."""
 
-    def __init__(self, params, device=0):
+    def __init__(self, params, device=0, library=None):
         err = C.c_int(0)
         self._p = params
-        self.h = lib().crumble_hip_create(C.byref(params), int(device), C.byref(err))
+        self.L = library if library is not None else lib()
+        self.h = self.L.crumble_hip_create(C.byref(params), int(device), C.byref(err))
         if not self.h:
-            raise CrumbleError(err.value, "crumble_hip_create")
+            raise CrumbleError(err.value, "crumble_hip_create", self.L)
         self._batch = None
 
     def close(self):
         if getattr(self, "h", None):
-            lib().crumble_hip_destroy(self.h)
+            self.L.crumble_hip_destroy(self.h)
             self.h = None
 
     __del__ = close
 
     def _chk(self, rc, where):
         if rc:
-            raise CrumbleError(rc, where)
+            raise CrumbleError(rc, where, self.L)
 
     def upload(self, hb: HostBatch):
         self._batch = hb
         self._bstruct = hb.struct()
-        self._chk(lib().crumble_hip_upload(self.h, C.byref(self._bstruct)), "upload")
+        self._chk(self.L.crumble_hip_upload(self.h, C.byref(self._bstruct)), "upload")
 
     def run(self):
-        self._chk(lib().crumble_hip_run(self.h), "run")
+        self._chk(self.L.crumble_hip_run(self.h), "run")
 
     def download(self, want_flags=True, want_stats=True):
         hb = self._batch
         q = np.empty(max(hb.n_bases, 1), np.uint8)
         f = np.zeros(max(hb.n_reads, 1), np.uint8) if want_flags else None
         s = np.zeros(ST_N, np.int64) if want_stats else None
-        self._chk(lib().crumble_hip_download(self.h, _vp(q), _vp(f), _vp(s)), "download")
+        self._chk(self.L.crumble_hip_download(self.h, _vp(q), _vp(f), _vp(s)), "download")
         return q[:hb.n_bases], (f[:hb.n_reads] if f is not None else None), s
 
     def contig(self, hb: HostBatch):
@@ -173,23 +176,23 @@ class Engine:
         f = np.zeros(max(hb.n_reads, 1), np.uint8)
         s = np.zeros(ST_N, np.int64)
         self._batch = hb
-        self._chk(lib().crumble_hip_contig(self.h, C.byref(b), _vp(q), _vp(f), _vp(s)),
+        self._chk(self.L.crumble_hip_contig(self.h, C.byref(b), _vp(q), _vp(f), _vp(s)),
                   "contig")
         return q[:hb.n_bases], f[:hb.n_reads], s
 
     def columns(self):
-        n = lib().crumble_hip_columns(self.h, None, 0)
+        n = self.L.crumble_hip_columns(self.h, None, 0)
         if n < 0:
             raise CrumbleError(int(n), "columns")
         cols = np.zeros(max(n, 1), COLUMN_DTYPE)
-        lib().crumble_hip_columns(self.h, _vp(cols), n)
+        self.L.crumble_hip_columns(self.h, _vp(cols), n)
         return cols[:n]
 
     def kernel_times(self, maxk=64):
         names = (C.c_char_p * maxk)()
         ms = np.zeros(maxk, np.float32)
         by = np.zeros(maxk, np.float64)
-        n = lib().crumble_hip_kernel_times(self.h, C.cast(names, C.c_void_p), _vp(ms),
+        n = self.L.crumble_hip_kernel_times(self.h, C.cast(names, C.c_void_p), _vp(ms),
                                            _vp(by), maxk)
         return [(names[i].decode(), float(ms[i]), float(by[i])) for i in range(n)]
 
@@ -199,23 +202,23 @@ class Engine:
         k = np.ascontiguousarray(is_indel, np.uint8)
         lo = np.zeros(len(r), np.int32)
         hi = np.zeros(len(r), np.int32)
-        self._chk(lib().crumble_hip_mask_lc(self.h, len(r), _vp(r), _vp(q), _vp(k),
+        self._chk(self.L.crumble_hip_mask_lc(self.h, len(r), _vp(r), _vp(q), _vp(k),
                                             _vp(lo), _vp(hi)), "mask_lc")
         return lo, hi
 
     def pblock(self, seq_off, quals):
         so = np.ascontiguousarray(seq_off, np.int64)
         q = np.ascontiguousarray(quals, np.uint8).copy()
-        self._chk(lib().crumble_hip_pblock(self.h, len(so) - 1, _vp(so), _vp(q)), "pblock")
+        self._chk(self.L.crumble_hip_pblock(self.h, len(so) - 1, _vp(so), _vp(q)), "pblock")
         return q
 
     def stats_devptr(self):
-        return lib().crumble_hip_stats_devptr(self.h)
+        return self.L.crumble_hip_stats_devptr(self.h)
 
     def stats_reset(self):
-        self._chk(lib().crumble_hip_stats_reset(self.h), "stats_reset")
+        self._chk(self.L.crumble_hip_stats_reset(self.h), "stats_reset")
 
     def stats_read(self):
         s = np.zeros(ST_N, np.int64)
-        self._chk(lib().crumble_hip_stats_read(self.h, _vp(s)), "stats_read")
+        self._chk(self.L.crumble_hip_stats_read(self.h, _vp(s)), "stats_read")
         return s

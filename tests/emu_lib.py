@@ -1,0 +1,28 @@
+"""Loads tests/emu/libcrumble_emu.so: the engine's literal kernel sources compiled
+for the CPU through tests/emu/hip_emu.h.  TEST INFRASTRUCTURE ONLY -- lets the
+no-GPU test tier exercise kernel logic; the -m gpu tier runs the real HIP build."""
+import os
+import subprocess
+
+import crumble_amd
+from crumble_amd.capi import ROOT
+
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+EMU_LIB = os.path.join(EMU_DIR, "libcrumble_emu.so")
+_L = None
+
+
+def load():
+    global _L
+    if _L is None:
+        r = subprocess.run(["make", "-C", EMU_DIR], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True)
+        if r.returncode:
+            print(r.stdout)
+            raise RuntimeError("building the emulated engine failed")
+        _L = crumble_amd.load_library(EMU_LIB, make_default=False)
+    return _L
+
+
+def engine(params):
+    return crumble_amd.Engine(params, 0, library=load())
