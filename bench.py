@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- Gbases/s quality-quantized on a chr20-shaped 30x synthetic BAM (-5 preset).
+
+One "step" = one full pass of the hot path (all kernels of crumble_hip_run) over
+one contig batch that is already resident in HBM.  N>1: one process per GPU
+(torch.distributed, backend nccl == RCCL), every rank owns its own contig
+(contigs are the independent unit of the path) -> weak scaling, no
+data-path collective; the only collective is the final all-reduce of the
+quality-histogram/statistics vector.
+
+Prints ONE JSON line on rank 0 (see the task contract); adds
+  "roofline":     dominant kernel, algorithmic bytes / HIP-event time vs 8 TB/s
+  "cpu_baseline": the CPU oracle ("port") timed on a bounded prefix of the same
+                  workload on this host, 1 core (reference crumble is single-threaded)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def prefix_batch(hb, n_reads):
+    """First n_reads reads of a HostBatch (same data, bounded CPU-baseline sample)."""
+    from crumble_amd import HostBatch
+    n = min(n_reads, hb.n_reads)
+    nb, nc = int(hb.seq_off[n]), int(hb.cig_off[n])
+    return HostBatch(hb.tid, hb.pos[:n], hb.mapq[:n], hb.flag[:n], hb.seq_off[:n + 1],
+                     hb.cig_off[:n + 1], hb.cigar[:nc], hb.bases[:nb], hb.quals[:nb])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="chr20")
+    ap.add_argument("--scale", type=float, default=1.0, help="contig length scale (1.0 = BASELINE config)")
+    ap.add_argument("--preset", type=int, default=5)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import crumble_amd as ca
+    from crumble_amd import synth
+    if not os.path.exists(ca.LIB_PATH):
+        ca.build_library()
+
+    # ---- synthetic input (no NA12878 BAM offline): one contig per rank ----
+    t0 = time.time()
+    cfg = synth.config(args.workload, scale=args.scale)
+    cfg.seed = cfg.seed + 1000 * rank           # rank r owns "contig r"
+    cfg.tid = rank
+    hb = synth.generate(cfg)
+    t_gen = time.time() - t0
+    params = ca.preset_params(args.preset)
+
+    eng = ca.Engine(params, local_rank)         # raises if no GPU (no CPU fallback)
+    t0 = time.time()
+    eng.upload(hb)
+    t_up = time.time() - t0
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.run()
+    eng.stats_reset()
+    sync_all()
+    t0 = time.perf_counter()
+    ktimes = {}
+    for _ in range(args.steps):
+        eng.run()                                # launches every kernel + stream sync
+        for name, ms, by in eng.kernel_times():
+            a = ktimes.setdefault(name, [0.0, 0.0, 0])
+            a[0] += ms; a[1] = by; a[2] += 1
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- the one collective of the path: statistics / quality histogram ----
+    stats = eng.stats_read()
+    bases_local = hb.n_bases
+    if dist is not None:
+        st = torch.from_numpy(stats.copy()).to("cuda")
+        dist.all_reduce(st, op=dist.ReduceOp.SUM)
+        stats = st.cpu().numpy()
+        tb = torch.tensor([bases_local], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        total_bases = int(tb.item())
+    else:
+        total_bases = bases_local
+    assert int(stats[ca.capi.ST_NAMES.index("bases")]) == total_bases * args.steps, "stats all-reduce mismatch"
+
+    value = total_bases * args.steps / elapsed / 1e9
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- roofline of the dominant kernel (HIP events on the engine's stream) ----
+    dom = max(ktimes.items(), key=lambda kv: kv[1][0])
+    dom_ms = dom[1][0] / dom[1][2]
+    dom_bytes = dom[1][1]
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    n_cig = int(hb.cig_off[-1])
+    algo_total = 3.0 * hb.n_bases + 32.0 * hb.n_reads + 8.0 * n_cig
+    kernel_ms_total = sum(v[0] / v[2] for v in ktimes.values())
+    roofline = {
+        "bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "kernel_ms": round(dom_ms, 3),
+        "pipeline_achieved": round(algo_total / (kernel_ms_total * 1e-3) / 1e9, 2),
+        "pipeline_frac": round(algo_total / (kernel_ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+        "kernels_ms": {k: round(v[0] / v[2], 3) for k, v in ktimes.items()},
+    }
+
+    out = {
+        "metric": "Gbases/s quality-quantized, 30x WGS; bit-exact vs reference crumble",
+        "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64", "data": "synthetic",
+        "config": {"workload": f"{args.workload}-30x synthetic contig ({cfg.contig_len} bp, "
+                               f"{hb.n_reads} reads, {hb.n_bases} bases per GPU), preset -{args.preset}",
+                   "preset": args.preset, "scale": args.scale, "contigs": world,
+                   "gen_s": round(t_gen, 1), "upload_s": round(t_up, 2)},
+        "roofline": roofline,
+    }
+
+    if rank == 0:
+        # ---- parity spot check + CPU baseline on a bounded prefix of the same workload ----
+        import oracle_lib as O
+        ns_per_base = 60e-9
+        n_sample_bases = args.cpu_seconds / ns_per_base
+        n_sample = int(min(hb.n_reads, max(1000, n_sample_bases / max(1, hb.n_bases / max(1, hb.n_reads)))))
+        sample = prefix_batch(hb, n_sample)
+        if not args.no_cpu:
+            O.load()
+            t0 = time.perf_counter()
+            wq, wf, ws = O.contig(params, sample)
+            t_cpu = time.perf_counter() - t0
+            out["cpu_baseline"] = {
+                "value": round(sample.n_bases / t_cpu / 1e9, 5), "unit": "Gbases/s", "cores": 1,
+                "kind": "port",
+                "sample": f"first {sample.n_reads} reads / {sample.n_bases} bases of the same contig, "
+                          f"{t_cpu:.1f} s, CPU restatement (oracle/) single thread like reference crumble",
+            }
+            if not args.no_verify:
+                e2 = ca.Engine(params, local_rank)
+                gq, gf, gs = e2.contig(sample)
+                e2.close()
+                out["config"]["verified_bit_exact_on_sample"] = bool(
+                    np.array_equal(gq, wq) and np.array_equal(gf, wf) and np.array_equal(gs, ws))
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,73 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/*.h declares."""
+import ctypes as C
+import os
+import re
+
+import crumble_amd
+from crumble_amd.capi import ROOT
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(crumble_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_exports_every_declared_symbol(product):
+    L = C.CDLL(crumble_amd.LIB_PATH)
+    names = _declared("crumble_hip.h") + _declared("crumble_synth.h")
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/ but not exported"
+
+
+def test_presets_match_reference_table(product):
+    """SURVEY.md App. E / snp_score.c:2380-2482."""
+    want = {
+        9: (8, 70, 125, 1.5, 1.0, 1.0, 0.0, 999.0, 0.0, 0, 1.0, 2, 0),
+        8: (0, 70, 125, 1.5, 1.0, 1.0, 0.0, 999.0, 0.0, 0, 1.0, 2, 0),
+        7: (0, 75, 150, 1.0, 1.0, 1.0, 0.0, 999.0, 0.0, 0, 1.1, 2, 0),
+        5: (0, 75, 150, 1.0, 0.5, 0.1, 0.5, 3.0, 0.0, 0, 1.1, 2, 0),
+        3: (0, 75, 150, 1.0, 0.5, 0.1, 0.5, 3.0, 1.0, 0, 1.1, 2, 0),
+        1: (0, 75, 150, 1.0, 0.5, 0.1, 0.5, 3.0, 1.0, 5, 2.0, 1, 5),
+    }
+    for lvl, w in want.items():
+        p = crumble_amd.preset_params(lvl)
+        got = (p.pblock, p.min_qual_B, p.min_indel_B, p.min_discrep_B, p.low_mqual_perc,
+               p.ins_len_perc, p.indel_ov_perc, p.over_depth, p.sSTR_mul, p.sSTR_add,
+               p.iSTR_mul, p.iSTR_add, p.min_mqual)
+        assert got == w, lvl
+        assert (p.qlow, p.qcutoff, p.qhigh, p.qcap, p.min_qual_A) == (5, 25, 40, 60, 0)
+    for bad in (2, 4, 6, 0):
+        p = crumble_amd.default_params()
+        assert crumble_amd.lib().crumble_params_preset(C.byref(p), bad) != 0
+    p = crumble_amd.preset_params(None, tech="pbccs")
+    assert (p.indel_fract, p.min_discrep_B, p.qcutoff, p.qhigh, p.pblock, p.perfect_col,
+            p.preserve_qual[93]) == (0.1, 0.8, 40, 60, 16, 1, 1)
+    p = crumble_amd.preset_params(9, keep="2-4,40", really_keep="93")
+    assert [p.preserve_qual[i] for i in (1, 2, 3, 4, 5, 40, 93)] == [0, 1, 1, 1, 0, 1, 2]
+
+
+def test_create_fails_loudly_without_gpu(product):
+    """No CPU fallback: without a HIP device the engine refuses to exist."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    try:
+        crumble_amd.Engine(crumble_amd.preset_params(9))
+    except crumble_amd.CrumbleError as e:
+        assert e.code in (-6, -3)
+    else:
+        raise AssertionError("engine was created without a GPU")
+
+
+def test_bed_collapse_semantics(product):
+    import numpy as np
+    L = crumble_amd.lib()
+    tid = np.array([0, 0, 0, 1], np.int32)
+    st = np.array([25, 0, 10, 5], np.int32)
+    en = np.array([50, 30, 20, 9], np.int32)
+    n = L.crumble_bed_collapse(tid.ctypes.data, st.ctypes.data, en.ctypes.data, 4)
+    # bed.c:20-40 compares with the previous INPUT region's end: [25,50] is not merged into [0,30]
+    assert n == 3
+    assert list(zip(tid[:n], st[:n], en[:n])) == [(0, 0, 30), (0, 25, 50), (1, 5, 9)]

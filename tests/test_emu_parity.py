@@ -1,0 +1,32 @@
+"""Kernel logic vs the oracle WITHOUT a GPU: the literal kernel sources of
+crumble_amd/csrc compiled for the CPU through tests/emu/hip_emu.h.  This is a
+development aid for the no-GPU tier; the parity claim itself rests on the
+-m gpu tests (tests/test_gpu_parity.py) that run the real HIP build."""
+import numpy as np
+import pytest
+
+import crumble_amd as ca
+from crumble_amd import HostBatch
+import emu_lib
+from parity_util import assert_parity, synth_batch
+
+
+@pytest.mark.parametrize("level", [1, 5, 9])
+def test_emu_chr20_small(product, level):
+    hb = synth_batch("chr20", 0.0004)
+    assert_parity(emu_lib.engine, ca.preset_params(level), hb)
+
+
+def test_emu_ce(product):
+    hb = synth_batch("ce", 0.3)
+    assert_parity(emu_lib.engine, ca.preset_params(1), hb)
+
+
+def test_emu_empty_and_passthrough(product):
+    p = ca.preset_params(9)
+    hb = HostBatch.from_reads([])
+    assert_parity(emu_lib.engine, p, hb)
+    reads = [dict(pos=10, cigar="*", seq="ACGTACGTAC", qual=[30, 31, 33, 36, 40, 12, 12, 13, 30, 30], flag=4),
+             dict(pos=10, cigar="5S5I", seq="ACGTACGTAC", qual=35)]
+    assert_parity(emu_lib.engine, p, HostBatch.from_reads(reads))
+    assert_parity(emu_lib.engine, p, HostBatch.from_reads(reads, tid=-1))

@@ -1,0 +1,83 @@
+"""Parity tests proper: the real HIP build on a real MI355X, through the C ABI,
+bit-exact against the CPU oracle (quality bytes, per-read flags, per-column
+records, statistics)."""
+import numpy as np
+import pytest
+
+import crumble_amd as ca
+from crumble_amd import HostBatch
+import oracle_lib as O
+from parity_util import assert_parity, synth_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_engine(params):
+    return ca.Engine(params, 0)
+
+
+@pytest.mark.parametrize("level", [1, 3, 5, 7, 8, 9])
+def test_chr20_presets(product, level):
+    hb = synth_batch("chr20", 0.01)
+    assert_parity(gpu_engine, ca.preset_params(level), hb)
+
+
+def test_ce_like(product):
+    assert_parity(gpu_engine, ca.preset_params(1), synth_batch("ce", 1.0))
+
+
+def test_panel_300x(product):
+    assert_parity(gpu_engine, ca.preset_params(9), synth_batch("panel", 0.005))
+
+
+def test_hifi_pbccs(product):
+    hb = synth_batch("hifi", 0.002)
+    hb.bed_start = np.arange(20000, 400000, 50000, dtype=np.int32)
+    hb.bed_end = hb.bed_start + 2000
+    assert_parity(gpu_engine, ca.preset_params(None, tech="pbccs"), hb)
+    assert_parity(gpu_engine, ca.preset_params(5), hb)
+
+
+def test_empty_and_passthrough(product):
+    p = ca.preset_params(9)
+    assert_parity(gpu_engine, p, HostBatch.from_reads([]))
+    reads = [dict(pos=10, cigar="*", seq="ACGTACGTAC", qual=[30, 31, 33, 36, 40, 12, 12, 13, 30, 30], flag=4),
+             dict(pos=10, cigar="5S5I", seq="ACGTACGTAC", qual=35)]
+    assert_parity(gpu_engine, p, HostBatch.from_reads(reads))
+    assert_parity(gpu_engine, p, HostBatch.from_reads(reads, tid=-1))
+
+
+def test_mode_a_and_options(product):
+    hb = synth_batch("chr20", 0.002)
+    assert_parity(gpu_engine, ca.preset_params(5, min_qual_A=30, min_qual_B=0), hb)
+    assert_parity(gpu_engine, ca.preset_params(5, binary_qual=1, softclip=1), hb)
+    assert_parity(gpu_engine, ca.preset_params(9, keep="37", perfect_col=1), hb)
+    assert_parity(gpu_engine, ca.preset_params(3, really_keep="2", indel_fract=0.2), hb)
+
+
+def test_mask_lc_and_pblock_seams(product):
+    hb = synth_batch("chr20", 0.002)
+    p = ca.preset_params(9)
+    eng = gpu_engine(p)
+    eng.upload(hb)
+    rng = np.random.default_rng(1)
+    idx = rng.integers(0, hb.n_reads, 300)
+    idx = idx[(hb.flag[idx] & 4) == 0]
+    lq = (hb.seq_off[idx + 1] - hb.seq_off[idx]).astype(np.int64)
+    qpos1 = (rng.random(len(idx)) * lq).astype(np.int32) + 1
+    kind = rng.integers(0, 2, len(idx)).astype(np.uint8)
+    lo, hi = eng.mask_lc(idx, qpos1, kind)
+    for i in range(len(idx)):
+        assert O.mask_lc(p, hb, int(idx[i]), int(kind[i]), int(qpos1[i])) == (lo[i], hi[i])
+    out = eng.pblock(hb.seq_off, hb.quals)
+    for r in range(0, hb.n_reads, 37):
+        a, b = hb.seq_off[r], hb.seq_off[r + 1]
+        assert np.array_equal(out[a:b], O.pblock(hb.quals[a:b], p.pblock, p.qcap))
+    eng.close()
+
+
+def test_fp64_sqrt_div_match_host(product):
+    """discrep = (m-c)/sqrt(m) must be the correctly rounded FP64 result."""
+    hb = synth_batch("chr20", 0.002)
+    p = ca.preset_params(5, min_discrep_B=0.05)     # make the comparison bite often
+    assert_parity(gpu_engine, p, hb)
