@@ -468,8 +468,8 @@ extern "C" int crumble_hip_run(crumble_hip *h)
     }
     if (n > 0) {
         STAGE("k_replay", 3.0 * nb);
-        CRUMBLE_LAUNCH_INDEP(k_replay, nblk(n, 64), 64, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
-                             h->d_out.as<uint8_t>(), h->d_rflags.as<uint8_t>());
+        CRUMBLE_LAUNCH(k_replay_wave, nblk(n, 4), 256, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
+                       h->d_out.as<uint8_t>(), h->d_rflags.as<uint8_t>());
         if (h->hparams.pblock) {
             STAGE("k_pblock", 2.0 * nb);
             CRUMBLE_LAUNCH_INDEP(k_pblock, nblk(n, 64), 64, st, n, B.seq_off, h->d_out.as<uint8_t>(),

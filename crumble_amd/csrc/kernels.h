@@ -909,6 +909,151 @@ __global__ void k_replay(DBatch B, const DParams *P, const uint32_t *colrec, con
 }
 
 /* ------------------------------------------------------------------------ */
+/* k_replay_wave: the same replay with one wavefront per read and one lane per
+ * base (coalesced byte traffic).  Exact because the final value of quality
+ * byte x only depends on (DESIGN.md "replay"):
+ *   - the is_head low-mapq mark (snp:1852),
+ *   - the columns whose pileup entry has qpos == x, in order: the D/N columns
+ *     just before x (htslib reports the NEXT base for them) and x's own column,
+ *   - whether any LATER column of the read is a trigger column whose back-fill
+ *     range [ref2query_pos(min_pos2), qpos] reaches down to x (snp:1875): a
+ *     suffix-min over the read, taken with wave shuffles,
+ *   - the OR of keep_qual over all the read's columns (snp:1847,1939). */
+struct ColOp { uint8_t v; int T; int keep, b15; };
+
+__device__ __forceinline__ void apply_col(const DParams *P, const DBatch &B, uint32_t rec, int mn2,
+                                          const uint32_t *cig, int nc, int rp, int x, uint8_t capq,
+                                          int base, ColOp &o)
+{
+    if (rec & CR_SKIP) return;
+    if (rec & CR_KEEP) o.keep = 1;
+    const int preserve = CR_PRESERVE(rec);
+    if (rec & CR_TRIG) {                                   /* snp:1870-1879 */
+        const int start = dev_ref2query_pos(cig, nc, rp, mn2);
+        if (start < o.T) o.T = start;
+        if (start <= x) o.v = capq | 0x80;
+    }
+    if (rec & CR_WIN) o.v = capq | 0x80;                   /* snp:1880-1883 */
+    if (preserve || P->preserve_qual[o.v & 0x7f] >= 1 + ((rec & CR_PERFECT) ? 1 : 0)) o.v |= 0x80;
+    if (preserve > 1) o.b15 = 1;
+    if (!(o.v & 0x80)) {                                   /* snp:1906-1919 */
+        const int c1 = 1 << CR_A1(rec), c2 = 1 << CR_A2(rec);
+        if (base == c1 || base == c2) o.v = (uint8_t)P->qhigh;
+        else if (P->reduce_qual) o.v = P->binary_qual ? P->bin2[o.v] : (uint8_t)P->qlow;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_replay_wave(DBatch B, const DParams *__restrict__ P, const uint32_t *__restrict__ colrec,
+              const int32_t *__restrict__ pos_mn2, uint8_t *__restrict__ out, uint8_t *__restrict__ rflags)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = UNIFORM((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (r >= B.n_reads) return;
+    const int64_t so = B.seq_off[r];
+    const int lq = (int)(B.seq_off[r + 1] - so);
+    uint8_t *q2 = out + so;
+    const uint8_t *qin = B.quals + so;
+    if (!B.inplp[r]) {
+        for (int x = lane; x < lq; x += 64) q2[x] = qin[x] & 0x7f;
+        if (lane == 0) rflags[r] = 4;
+        return;
+    }
+    const int rp = B.pos[r], re = B.end[r], mq = B.mapq[r];
+    const Seg *segs = B.segs + B.seg_off[r];
+    const int ns = (int)(B.seg_off[r + 1] - B.seg_off[r]);
+    const uint32_t *cig = B.cigar + B.cig_off[r];
+    const int nc = (int)(B.cig_off[r + 1] - B.cig_off[r]);
+    const uint32_t headrec = colrec[rp - B.p0], tailrec = colrec[re - 1 - B.p0];
+    const Seg s0 = segs[0], sl = segs[ns - 1];
+    const int qpos_head = s0.qstart;
+    const int qpos_tail = (seg_type(sl) == SEG_M) ? sl.qstart + seg_len(sl) - 1 : sl.qstart;
+    const bool headmark = (mq <= P->min_mqual) && !(headrec & CR_SKIP);               /* snp:1852 */
+    const bool sc_head = P->softclip && !(headrec & (CR_SKIP | CR_KEEP));             /* snp:1894 */
+    const bool sc_tail = P->softclip && (re - 1 != rp) && !(tailrec & (CR_SKIP | CR_KEEP));
+    int keep = 0, b15 = 0, carry = INT_MAX;
+
+    for (int ch = (lq + 63) / 64 - 1; ch >= 0; ch--) {
+        const int x = ch * 64 + lane;
+        const bool active = x < lq;
+        ColOp o; o.v = 0; o.T = INT_MAX; o.keep = 0; o.b15 = 0;
+        uint8_t capq = 0;
+        if (active) {
+            const uint8_t q0 = qin[x];
+            capq = cap_q(P, q0);
+            const int base = B.bases[so + x] & 15;
+            o.v = headmark ? (q0 | 0x80) : q0;
+            if (sc_head && x < qpos_head) o.v = P->bin2[o.v];
+            /* first segment with qstart >= x */
+            int i;
+            if (ns == 1) i = (s0.qstart >= x) ? 0 : 1;
+            else {
+                int lo = 0, hi = ns;
+                while (lo < hi) { int mid = (lo + hi) >> 1; if (segs[mid].qstart < x) lo = mid + 1; else hi = mid; }
+                i = lo;
+            }
+            bool own_done = false;
+            while (i < ns && segs[i].qstart == x) {        /* D/N runs that report x, then maybe x's own M op */
+                const Seg sg = segs[i];
+                const int len = seg_len(sg);
+                if (seg_type(sg) == SEG_M) {
+                    const int c = rp + sg.roff - B.p0;
+                    apply_col(P, B, colrec[c], pos_mn2[c], cig, nc, rp, x, capq, base, o);
+                    own_done = true;
+                    break;
+                }
+                for (int k = 0; k < len; k++) {
+                    const int c = rp + sg.roff + k - B.p0;
+                    apply_col(P, B, colrec[c], pos_mn2[c], cig, nc, rp, x, capq, base, o);
+                }
+                i++;
+            }
+            if (!own_done && i > 0 && i <= ns) {           /* x strictly inside the previous M op? */
+                const Seg sg = segs[i - 1];
+                if (seg_type(sg) == SEG_M && sg.qstart < x && x < sg.qstart + seg_len(sg)) {
+                    const int c = rp + sg.roff + (x - sg.qstart) - B.p0;
+                    apply_col(P, B, colrec[c], pos_mn2[c], cig, nc, rp, x, capq, base, o);
+                }
+            }
+            if (sc_tail && x > qpos_tail) o.v = P->bin2[o.v];
+        }
+        /* exclusive suffix-min of the back-fill starts over lanes, then over later chunks */
+        int incl = o.T;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int other = __shfl_down(incl, d);
+            if (lane + d < 64 && other < incl) incl = other;
+        }
+        int excl = __shfl_down(incl, 1);
+        if (lane == 63) excl = INT_MAX;
+        if (carry < excl) excl = carry;
+        if (active) {
+            if (excl <= x) o.v = capq | 0x80;
+            q2[x] = o.v & 0x7f;                            /* snp:1093 */
+        }
+        const int first = __shfl(incl, 0);
+        if (first < carry) carry = first;
+        keep |= o.keep; b15 |= o.b15;
+    }
+    /* columns that no base owns: D/N ops at the very end of the query (fenced), or l_qseq == 0 */
+    if (lane == 0) {
+        if (lq == 0) {
+            for (int c = rp; c < re; c++) { const uint32_t rec = colrec[c - B.p0]; if (!(rec & CR_SKIP) && (rec & CR_KEEP)) keep = 1; }
+        } else {
+            for (int i = ns - 1; i >= 0 && segs[i].qstart >= lq; i--) {
+                const Seg sg = segs[i];
+                for (int k = 0; k < seg_len(sg); k++) {
+                    const uint32_t rec = colrec[rp + sg.roff + k - B.p0];
+                    if (!(rec & CR_SKIP) && (rec & CR_KEEP)) keep = 1;
+                }
+            }
+        }
+    }
+    keep = __any(keep); b15 = __any(b15);
+    if (keep) for (int x = lane; x < lq; x += 64) q2[x] = cap_q(P, qin[x]) & 0x7f;   /* snp:1939 */
+    if (lane == 0) rflags[r] = (uint8_t)((keep ? 1 : 0) | (b15 ? 2 : 0));
+}
+
+/* ------------------------------------------------------------------------ */
 /* P-block (snp:803-834), one thread per read, in place. */
 __device__ inline void dev_pblock(uint8_t *qual, int len, int level, int qcap, const uint8_t *pq)
 {

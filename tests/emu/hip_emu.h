@@ -8,8 +8,8 @@
  * The product library never contains or links this file, has no CPU fallback,
  * and the -m gpu parity tests always run the real HIP build.
  *
- * Model: blocks run one after another; the threads of a block are real OS
- * threads (so __syncthreads(), LDS atomics and wave shuffles behave), unless a
+ * Model: blocks are spread over host threads; the threads of a block are fibers
+ * of one host thread (so __syncthreads(), LDS atomics and wave shuffles behave), unless a
  * launch is declared lane-independent (CRUMBLE_LAUNCH_INDEP), in which case
  * lanes run sequentially and blocks are spread over host threads.
  */
@@ -34,7 +34,7 @@
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
-#define __shared__ static
+#define __shared__ static thread_local
 #ifndef __restrict__
 #define __restrict__
 #endif
