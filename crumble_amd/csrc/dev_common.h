@@ -61,6 +61,17 @@ struct Seg {
 HD int32_t  seg_len(const Seg &s)  { return (int32_t)(s.len_type & 0x3fffffffu); }
 HD uint32_t seg_type(const Seg &s) { return s.len_type >> 30; }
 
+/* Compact per-read record for the column kernel (one 32-byte load per read). */
+#define RR_SIMPLE 0x100u    /* one M/=/X op covers the whole alignment, no indel flag, l_qseq > 0 */
+struct ReadRec {
+    int32_t  pos, end;      /* end = pos + reference length; == pos if not in the pileup */
+    int64_t  so;            /* seq_off */
+    int32_t  lq;            /* l_qseq */
+    int32_t  q0;            /* query index of the first aligned base */
+    uint32_t info;          /* mapq | RR_SIMPLE */
+    uint32_t pad;
+};
+
 /* Device-resident batch. Positions are stored relative to p0. */
 struct DBatch {
     int64_t n_reads, n_bases;
@@ -73,6 +84,7 @@ struct DBatch {
     const int64_t *seq_off, *cig_off, *seg_off;
     const uint32_t *cigar;
     const Seg *segs;
+    const ReadRec *rr;
     const uint8_t *bases, *quals;
     const int32_t *tile_lo, *tile_hi;
     const int32_t *bed_start, *bed_end, *bed_pmax;

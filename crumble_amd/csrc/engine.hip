@@ -55,7 +55,7 @@ struct crumble_hip {
     DParams hparams;
     DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc;
     /* batch (inputs) */
-    DevBuf d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
+    DevBuf d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
            d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax;
     /* per position */
     DevBuf d_colrec, d_nplp, d_score, d_trigcnt, d_dpre, d_col_ord, d_trig_ord, d_item_off,
@@ -66,6 +66,7 @@ struct crumble_hip {
     DevBuf d_out, d_rflags;
     DBatch B;
     bool have_batch = false, have_run = false;
+    unsigned persistent_blocks = 1024;
     int64_t n_reads = 0, n_bases = 0, n_cigar = 0;
     ScanVal totals;
     /* timing */
@@ -187,6 +188,15 @@ extern "C" crumble_hip *crumble_hip_create(const crumble_params *p, int device, 
     for (int i = 0; i <= MAX_STAGES; i++)
         if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(CRUMBLE_EHIP); }
     h->events_ok = true;
+#ifndef CRUMBLE_EMU
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+            h->persistent_blocks = (unsigned)cus * 4;          /* 4 x 256 threads per CU: 4 waves per SIMD */
+    }
+#else
+    h->persistent_blocks = 3;
+#endif
     tab = (DTables *)calloc(1, sizeof(DTables));
     if (!tab) return fail(CRUMBLE_ENOMEM);
     build_tables(tab);
@@ -211,7 +221,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     DevBuf *all[] = { &h->d_params, &h->d_tables, &h->d_stats, &h->d_batch_stats, &h->d_misc,
-        &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
+        &h->d_rr, &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
         &h->d_cigar, &h->d_segs, &h->d_bases, &h->d_quals, &h->d_tile_lo, &h->d_tile_hi,
         &h->d_bed_start, &h->d_bed_end, &h->d_bed_pmax, &h->d_colrec, &h->d_nplp, &h->d_score,
         &h->d_trigcnt, &h->d_dpre, &h->d_col_ord, &h->d_trig_ord, &h->d_item_off, &h->d_ins_ord,
@@ -314,6 +324,20 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
         if (end[r] > max_end) max_end = end[r];
     }
     seg_off[n] = (int64_t)segs.size();
+    std::vector<ReadRec> rr((size_t)n + 1);
+    for (int64_t r = 0; r < n; r++) {
+        ReadRec &x = rr[r];
+        const int64_t ns = seg_off[r + 1] - seg_off[r];
+        x.pos = b->pos[r]; x.end = end[r]; x.so = b->seq_off[r];
+        x.lq = (int32_t)(b->seq_off[r + 1] - b->seq_off[r]);
+        x.q0 = ns ? segs[(size_t)seg_off[r]].qstart : 0;
+        x.info = b->mapq[r];
+        x.pad = 0;
+        if (inplp[r] && ns == 1 && x.lq > 0) {
+            const Seg &s0 = segs[(size_t)seg_off[r]];
+            if (seg_type(s0) == SEG_M && s0.indel_after == 0) x.info |= RR_SIMPLE;
+        }
+    }
     for (int64_t i = 0; i < nb; i++)
         if (b->quals[i] & 0x80) { g_last_error = "input quality >= 128 (SURVEY.md Q13)"; return CRUMBLE_EINVAL; }
 
@@ -340,7 +364,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     B.n_bed = b->n_bed > 0 ? b->n_bed : 0;
 
     int e;
-    if ((e = up(h, h->d_pos, b->pos, n)) || (e = up(h, h->d_end, end.data(), n)) ||
+    if ((e = up(h, h->d_rr, rr.data(), n)) || (e = up(h, h->d_pos, b->pos, n)) || (e = up(h, h->d_end, end.data(), n)) ||
         (e = up(h, h->d_mapq, b->mapq, n)) || (e = up(h, h->d_inplp, inplp.data(), n)) ||
         (e = up(h, h->d_seq_off, b->seq_off, n + 1)) || (e = up(h, h->d_cig_off, b->cig_off, n + 1)) ||
         (e = up(h, h->d_seg_off, seg_off.data(), n + 1)) || (e = up(h, h->d_cigar, b->cigar, nc)) ||
@@ -355,7 +379,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     B.mapq = h->d_mapq.as<uint8_t>(); B.inplp = h->d_inplp.as<uint8_t>();
     B.seq_off = h->d_seq_off.as<int64_t>(); B.cig_off = h->d_cig_off.as<int64_t>();
     B.seg_off = h->d_seg_off.as<int64_t>(); B.cigar = h->d_cigar.as<uint32_t>();
-    B.segs = h->d_segs.as<Seg>(); B.bases = h->d_bases.as<uint8_t>(); B.quals = h->d_quals.as<uint8_t>();
+    B.segs = h->d_segs.as<Seg>(); B.rr = h->d_rr.as<ReadRec>(); B.bases = h->d_bases.as<uint8_t>(); B.quals = h->d_quals.as<uint8_t>();
     B.tile_lo = h->d_tile_lo.as<int32_t>(); B.tile_hi = h->d_tile_hi.as<int32_t>();
     B.bed_start = h->d_bed_start.as<int32_t>(); B.bed_end = h->d_bed_end.as<int32_t>();
     B.bed_pmax = h->d_bed_pmax.as<int32_t>();
@@ -408,7 +432,8 @@ extern "C" int crumble_hip_run(crumble_hip *h)
     if (L > 0) {
         STAGE("k_columns", 2.0 * nb + 32.0 * n + 8.0 * h->n_cigar);
         const bool modeB = h->hparams.min_qual_B != 0;
-        const unsigned grid = nblk(B.n_tiles, 4);
+        unsigned grid = nblk(B.n_tiles, 4);
+        if (grid > h->persistent_blocks) grid = h->persistent_blocks;   /* grid-stride over tiles */
         if (modeB) CRUMBLE_LAUNCH(k_columns<true>, grid, 256, st, B, P, T, colrec, nplp, score, trigcnt, stats);
         else       CRUMBLE_LAUNCH(k_columns<false>, grid, 256, st, B, P, T, colrec, nplp, score, trigcnt, stats);
 

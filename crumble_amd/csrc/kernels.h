@@ -163,53 +163,70 @@ __device__ __forceinline__ int bed_preserve(const DBatch &B, int apos)
 /* ------------------------------------------------------------------------ */
 struct ConsOut { int call, het_call, het_phred, phred; float discrep; };
 
-/* The "speculate" half of calculate_consensus_pileup (snp:689-794). */
+/* The "speculate" half of calculate_consensus_pileup (snp:689-794).
+ * Written without dynamically indexed arrays so that the 15 genotype sums stay
+ * in registers: the reference's norm[j] (sum of all S[i], i != j, built from a
+ * prefix and a suffix pass, snp:743-749) is prefix[j] + suffix[j] exactly,
+ * because each norm[j] receives exactly those two addends starting from 0. */
 __device__ __forceinline__ void cons_finalize(const DTables *T, double *S, const double *sC,
                                               int depth, int nN, ConsOut &o)
 {
-    const int map_sing[15] = {0,5,5,5,5, 1,5,5,5, 2,5,5, 3,5, 4};
-    const int map_het[15]  = {0,1,2,3,4, 6,7,8,9, 12,13,14, 18,19, 24};
     const double min_e_exp = T->min_e_exp;            /* DBL_MIN_EXP*log(2)+1 (snp:540), host libm */
-    double shift = -DBL_MAX, max = -DBL_MAX, max_het = -DBL_MAX, norm[15];
-    int call = 0, het_call = 0, ph, j;
-    double tot1, tot2;
+    double shift = -DBL_MAX, max = -DBL_MAX, max_het = -DBL_MAX;
+    int call = 0, het_call = 0, ph;
 
-    for (j = 0; j < 15; j++) {
+    #pragma unroll
+    for (int j = 0; j < 15; j++) {                     /* snp:707-725 */
         S[j] += T->lprior15[j];
         if (shift < S[j]) shift = S[j];
         if (j != 0 && j != 5 && j != 9 && j != 12 && j != 14) {
             if (max_het < S[j]) { max_het = S[j]; het_call = j; }
-            continue;
+        } else {
+            if (max < S[j]) { max = S[j]; call = j; }
         }
-        if (max < S[j]) { max = S[j]; call = j; }
     }
-    for (j = 0; j < 15; j++) {
+    #pragma unroll
+    for (int j = 0; j < 15; j++) {                     /* snp:736-741 */
         S[j] -= shift;
-        double e = dev_fast_exp(T, S[j]);
+        const double e = dev_fast_exp(T, S[j]);
         S[j] = (S[j] > min_e_exp) ? e : DBL_MIN;
-        norm[j] = 0;
     }
-    tot1 = tot2 = 0;
-    for (j = 0; j < 15; j++) {
-        norm[j]      += tot1;
-        norm[14 - j] += tot2;
-        tot1 += S[j];
-        tot2 += S[14 - j];
+    double pre[15], suf[15], tot1 = 0, tot2 = 0;       /* snp:743-749 */
+    #pragma unroll
+    for (int j = 0; j < 15; j++) {
+        pre[j] = tot1; suf[14 - j] = tot2;
+        tot1 += S[j]; tot2 += S[14 - j];
+    }
+    double nc = 0, nh = 0, s_het = 0;
+    #pragma unroll
+    for (int j = 0; j < 15; j++) {
+        const double nj = (0.0 + pre[j]) + suf[j];
+        if (j == call) nc = nj;
+        if (j == het_call) { nh = nj; s_het = S[j]; }
     }
     if (depth && depth != nN) {
-        double nc = norm[call], nh = norm[het_call];
-        o.call = map_sing[call];
+        /* map_sing / map_het (snp:547-558) */
+        o.call = (call == 0) ? 0 : (call == 5) ? 1 : (call == 9) ? 2 : (call == 12) ? 3 : 4;
         if (nc == 0) nc = DBL_MIN;
         ph = (int)(dev_ph_log(nc) + .5);
         o.phred = ph > 255 ? 255 : (ph < 0 ? 0 : ph);
-        o.het_call = map_het[het_call];
+        o.het_call = (het_call < 5) ? het_call : (het_call < 9) ? het_call + 1 :
+                     (het_call < 12) ? het_call + 3 : (het_call < 14) ? het_call + 6 : 24;
         if (nh == 0) nh = DBL_MIN;
-        ph = (int)(DEV_TENLOG2OVERLOG10 * (dev_fast_log2(S[het_call]) - dev_fast_log2(nh)) + .5);
+        ph = (int)(DEV_TENLOG2OVERLOG10 * (dev_fast_log2(s_het) - dev_fast_log2(nh)) + .5);
         o.het_phred = ph;
         {
-            double m = sC[0] + sC[1] + sC[2] + sC[3] + sC[4], c;
-            if (o.het_phred > 0) c = sC[o.het_call % 5] + sC[o.het_call / 5];
-            else                 c = sC[o.call];
+            const double m = sC[0] + sC[1] + sC[2] + sC[3] + sC[4];
+            double c;
+            if (o.het_phred > 0) {
+                const int x = o.het_call % 5, y = o.het_call / 5;
+                const double cx = (x == 0) ? sC[0] : (x == 1) ? sC[1] : (x == 2) ? sC[2] : (x == 3) ? sC[3] : sC[4];
+                const double cy = (y == 0) ? sC[0] : (y == 1) ? sC[1] : (y == 2) ? sC[2] : (y == 3) ? sC[3] : sC[4];
+                c = cx + cy;
+            } else {
+                const int x = o.call;
+                c = (x == 0) ? sC[0] : (x == 1) ? sC[1] : (x == 2) ? sC[2] : (x == 3) ? sC[3] : sC[4];
+            }
             o.discrep = (float)((m - c) / sqrt(m));
         }
     } else {
@@ -219,128 +236,113 @@ __device__ __forceinline__ void cons_finalize(const DTables *T, double *S, const
 
 /* ------------------------------------------------------------------------ */
 /* k_columns: one lane per reference position; a wave owns 64 consecutive
- * positions and walks the candidate reads of its tile in file order, so each
- * lane adds its column's contributions in exactly the reference's order.
- * MQ selects CONS_MQUAL (mode B, snp:1535) vs plain (mode A, snp:1524). */
-template <bool MQ>
-__global__ void __launch_bounds__(256)
-k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T,
-          uint32_t *__restrict__ colrec, int32_t *__restrict__ nplp_out,
-          int32_t *__restrict__ score_out, int32_t *__restrict__ trigcnt, u64 *stats)
-{
-    __shared__ double sMM[101], s_M[101], sOmq[101];
-    for (int i = threadIdx.x; i < 101; i += blockDim.x) {
-        sMM[i] = T->MMd[i]; s_M[i] = T->_Md[i]; sOmq[i] = T->omq[i];
-    }
-    __syncthreads();
+ * positions (a tile) and walks the candidate reads of its tile in file order,
+ * so each lane adds its column's contributions in exactly the reference's
+ * order.  MQ selects CONS_MQUAL (mode B, snp:1535) vs plain (mode A, snp:1524).
+ *
+ * Memory behaviour: the per-read records of up to 64 candidate reads are
+ * fetched with one coalesced load (lane i <- read i) and broadcast with
+ * v_readlane; reads whose alignment is one match op ("simple", ~97 %) are
+ * processed four at a time so their base/quality byte loads are in flight
+ * together; the (mapq, qual) -> adjusted-quality table and the log-probability
+ * tables live in LDS; workgroups are persistent (grid-stride over tiles) so the
+ * 34 KB of LDS tables are staged once per workgroup. */
+#ifdef CRUMBLE_EMU
+#define READLANE(v, l) __shfl((int)(v), (int)(l))
+#else
+#define READLANE(v, l) __builtin_amdgcn_readlane((int)(v), (int)(l))
+#endif
 
-    const int lane = threadIdx.x & 63;
-    const int tile = UNIFORM((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    if (tile >= B.n_tiles) return;
-    const int c = tile * 64 + lane;
-    const int apos = B.p0 + c;
-    const bool inr = c < B.L;
-    const int c0 = B.p0 + tile * 64;
-    const int lo = UNIFORM(B.tile_lo[tile]), hi = UNIFORM(B.tile_hi[tile]);
-    const bool use_cons = MQ ? (P->min_qual_B != 0) : (P->min_qual_A != 0);
-    const int qcap = P->qcap, min_mqual = P->min_mqual, any_pres = P->any_preserve;
-
+struct ColState {
     double S[15], sC[5];
-    #pragma unroll
-    for (int j = 0; j < 15; j++) S[j] = 0;
-    #pragma unroll
-    for (int j = 0; j < 5; j++) sC[j] = 0;
-    int depth = 0, nN = 0, n_plp = 0, nref = 0, low_mq = 0, indel_cnt = 0;
-    int clipped = 0, n_overlap = 0, n_isindel = 0, has_ins = 0;
-    unsigned cp = 0;
+    int depth, nN, n_plp, nref, low_mq, indel_cnt, clipped, n_overlap, n_isindel, has_ins;
+    unsigned cp;
+};
 
-    for (int r = lo; r < hi; r++) {
-        const int rp = B.pos[r], re = B.end[r];
-        if (re <= c0) continue;                       /* wave-uniform */
-        if (!(inr && apos >= rp && apos < re)) continue;
-        const int64_t so = B.seq_off[r];
-        const int lq = (int)(B.seq_off[r + 1] - so);
-        const int64_t sgo = B.seg_off[r];
-        const int ns = (int)(B.seg_off[r + 1] - sgo);
-        const int mq = B.mapq[r];
-        const int off = apos - rp;
-        const int si = seg_find(B.segs + sgo, ns, off);
-        Entry e;
-        entry_from_seg(B.segs[sgo + si], off, re - rp, e);
+template <bool MQ>
+__device__ __forceinline__ void col_accumulate(ColState &st, const Entry &e, int code, uint8_t q, int lq, int mq,
+                                               const uint8_t *rq /* read's quals */, const DParams *__restrict__ P,
+                                               const double *sMM, const double *s_M, const double *sOmq,
+                                               const uint8_t *sAdj, bool use_cons, int qcap, int min_mqual, int any_pres)
+{
+    /* --- column heuristics inputs (snp:1662-1713) --- */
+    st.n_plp++;
+    st.low_mq += (mq <= min_mqual);
+    if (e.indel || e.is_del) st.indel_cnt++;
+    if (e.is_refskip) { st.nref++; return; }           /* snp:589, snp:1696 */
+    st.n_isindel += (e.indel || e.is_del) ? 1 : 0;
+    if ((e.is_head && e.qpos > 0) || (e.is_tail && e.qpos + 1 < lq)) st.clipped++;
+    if (!e.is_tail && !e.is_head) { st.n_overlap++; if (e.indel > 0) st.has_ins = 1; }
 
-        /* --- column heuristics inputs (snp:1662-1713) --- */
-        n_plp++;
-        low_mq += (mq <= min_mqual);
-        if (e.indel || e.is_del) indel_cnt++;
-        if (e.is_refskip) { nref++; continue; }       /* snp:589, snp:1696 */
-        n_isindel += (e.indel || e.is_del) ? 1 : 0;
-        if ((e.is_head && e.qpos > 0) || (e.is_tail && e.qpos + 1 < lq)) clipped++;
-        if (!e.is_tail && !e.is_head) { n_overlap++; if (e.indel > 0) has_ins = 1; }
-
-        /* --- consensus accumulation (snp:594-685) --- */
-        if (!lq || !use_cons) continue;
-        int b;
-        uint8_t q = 0;
-        if (e.qpos < lq) {
-            const int code = B.bases[so + e.qpos] & 15;
-            b = (code == 1) ? 0 : (code == 2) ? 1 : (code == 4) ? 2 : (code == 8) ? 3 : 5;
-            q = B.quals[so + e.qpos];
-            q = (q > qcap && !P->preserve_qual[q]) ? (uint8_t)qcap : q;
-        } else b = 5;                                  /* fence: read ends in D/N */
-        if (e.is_del) b = 4;
-        if (any_pres) {                                /* snp:611-623 */
-            const uint8_t pv = P->preserve_qual[q];
-            if (pv) cp |= 1u << b;
-            if (pv > 1) cp |= (1u << b) << 8;
-            if (e.indel > 0)
-                for (int ins = 0; ins < e.indel; ins++) {
-                    const int qi = e.qpos + 1 + ins;
-                    if (qi < lq && P->preserve_qual[cap_q(P, B.quals[so + qi])]) cp |= 1u << 4;
-                }
-        }
-        int aq = MQ ? T->adj[mq * 256 + q] : q;        /* snp:632-638 */
-        if (aq < 1) aq = 1;                            /* snp:641 */
-        if (aq > 100) aq = 100;                        /* fence */
-        const double MM = sMM[aq], _M = s_M[aq], om = sOmq[aq];
-        depth++;
-        if (b == 5) {                                  /* N: snp:677-682 */
-            nN++;
-            S[0] += MM; S[1] += MM; S[2] += MM; S[3] += MM; S[4] += _M;
-            S[5] += MM; S[6] += MM; S[7] += MM; S[8] += _M;
-            S[9] += MM; S[10] += MM; S[11] += _M;
-            S[12] += MM; S[13] += _M;
-            continue;
-        }
-        const bool b0 = b == 0, b1 = b == 1, b2 = b == 2, b3 = b == 3, b4 = b == 4;
-        sC[0] += b0 ? om : 0.0; sC[1] += b1 ? om : 0.0; sC[2] += b2 ? om : 0.0;
-        sC[3] += b3 ? om : 0.0; sC[4] += b4 ? om : 0.0;
-        /* adding +0.0 is exact, so every genotype sees its own subsequence of
-         * addends in file order (snp:656-675) */
-        S[0]  += b0 ? MM : 0.0;
-        S[1]  += (b0 || b1) ? _M : 0.0;
-        S[2]  += (b0 || b2) ? _M : 0.0;
-        S[3]  += (b0 || b3) ? _M : 0.0;
-        S[4]  += (b0 || b4) ? _M : 0.0;
-        S[5]  += b1 ? MM : 0.0;
-        S[6]  += (b1 || b2) ? _M : 0.0;
-        S[7]  += (b1 || b3) ? _M : 0.0;
-        S[8]  += (b1 || b4) ? _M : 0.0;
-        S[9]  += b2 ? MM : 0.0;
-        S[10] += (b2 || b3) ? _M : 0.0;
-        S[11] += (b2 || b4) ? _M : 0.0;
-        S[12] += b3 ? MM : 0.0;
-        S[13] += (b3 || b4) ? _M : 0.0;
-        S[14] += b4 ? MM : 0.0;
+    /* --- consensus accumulation (snp:594-685) --- */
+    if (!lq || !use_cons) return;
+    int b;
+    if (e.qpos < lq) {
+        b = (code == 1) ? 0 : (code == 2) ? 1 : (code == 4) ? 2 : (code == 8) ? 3 : 5;
+        q = (q > qcap && !P->preserve_qual[q]) ? (uint8_t)qcap : q;
+    } else { b = 5; q = 0; }                           /* fence: read ends in D/N */
+    if (e.is_del) b = 4;
+    if (any_pres) {                                    /* snp:611-623 */
+        const uint8_t pv = P->preserve_qual[q];
+        if (pv) st.cp |= 1u << b;
+        if (pv > 1) st.cp |= (1u << b) << 8;
+        if (e.indel > 0)
+            for (int ins = 0; ins < e.indel; ins++) {
+                const int qi = e.qpos + 1 + ins;
+                if (qi < lq && P->preserve_qual[cap_q(P, rq[qi])]) st.cp |= 1u << 4;
+            }
     }
+    int aq = MQ ? sAdj[mq * 128 + (q & 127)] : q;      /* snp:632-638 */
+    if (aq < 1) aq = 1;                                /* snp:641 */
+    if (aq > 100) aq = 100;                            /* fence */
+    const double MM = sMM[aq], _M = s_M[aq], om = sOmq[aq];
+    st.depth++;
+    double *S = st.S, *sC = st.sC;
+    if (b == 5) {                                      /* N: snp:677-682 */
+        st.nN++;
+        S[0] += MM; S[1] += MM; S[2] += MM; S[3] += MM; S[4] += _M;
+        S[5] += MM; S[6] += MM; S[7] += MM; S[8] += _M;
+        S[9] += MM; S[10] += MM; S[11] += _M;
+        S[12] += MM; S[13] += _M;
+        return;
+    }
+    const bool b0 = b == 0, b1 = b == 1, b2 = b == 2, b3 = b == 3, b4 = b == 4;
+    sC[0] += b0 ? om : 0.0; sC[1] += b1 ? om : 0.0; sC[2] += b2 ? om : 0.0;
+    sC[3] += b3 ? om : 0.0; sC[4] += b4 ? om : 0.0;
+    /* adding +0.0 is exact, so every genotype sees its own subsequence of
+     * addends in file order (snp:656-675) */
+    S[0]  += b0 ? MM : 0.0;
+    S[1]  += (b0 || b1) ? _M : 0.0;
+    S[2]  += (b0 || b2) ? _M : 0.0;
+    S[3]  += (b0 || b3) ? _M : 0.0;
+    S[4]  += (b0 || b4) ? _M : 0.0;
+    S[5]  += b1 ? MM : 0.0;
+    S[6]  += (b1 || b2) ? _M : 0.0;
+    S[7]  += (b1 || b3) ? _M : 0.0;
+    S[8]  += (b1 || b4) ? _M : 0.0;
+    S[9]  += b2 ? MM : 0.0;
+    S[10] += (b2 || b3) ? _M : 0.0;
+    S[11] += (b2 || b4) ? _M : 0.0;
+    S[12] += b3 ? MM : 0.0;
+    S[13] += (b3 || b4) ? _M : 0.0;
+    S[14] += b4 ? MM : 0.0;
+}
 
-    if (!inr) return;
+/* column decisions: snp:1438-1773 minus the passes that need cross-column state */
+template <bool MQ>
+__device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const DParams *__restrict__ P,
+                                           const DTables *__restrict__ T, int c, int apos, bool use_cons,
+                                           uint32_t *__restrict__ colrec, int32_t *__restrict__ nplp_out,
+                                           int32_t *__restrict__ score_out, int32_t *__restrict__ trigcnt, u64 *stats)
+{
+    const int n_plp = st.n_plp;
     if (n_plp == 0) { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; return; }
 
     uint32_t rec = CR_EXISTS;
     int preserve = bed_preserve(B, apos);              /* snp:1443-1463 */
     int perfect = 1, score = 0, tcnt = 0;
     nplp_out[c] = n_plp;
-    if (nref == n_plp) {                               /* snp:1466-1472 */
+    if (st.nref == n_plp) {                            /* snp:1466-1472 */
         colrec[c] = rec | CR_ALLREFSKIP; score_out[c] = 0; trigcnt[c] = 0;
         return;
     }
@@ -356,7 +358,8 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
     bool cond_score = false;
     if (use_cons) {
         ConsOut co;
-        cons_finalize(T, S, sC, depth, nN, co);
+        cons_finalize(T, st.S, st.sC, st.depth, st.nN, co);
+        const unsigned cp = st.cp;
         const bool het = co.het_phred > 0;
         if (het) { a1 = co.het_call / 5; a2 = co.het_call % 5; }     /* snp:1537-1542 */
         else     { a1 = a2 = co.call; }
@@ -375,33 +378,134 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
         preserve |= (lowq ? 1 : 0);                                   /* snp:1624-1628 */
         preserve |= (disc ? 1 : 0);
         if (!preserve) {                                              /* snp:1633-1645 */
-            const int bit2call[32] = {99,0,1,99,2,99,99,99,3,99,99,99,99,99,99,99,
-                                      4,99,99,99,99,99,99,99,99,99,99,99,99,99,99,99};
-            if ((co.het_phred <= 0 && bit2call[cp & 31] != co.call) || (cp >> 8)) perfect = 0;
+            /* bit2call (snp:1384): one-hot ACGT* -> 0..4, everything else 99 */
+            const unsigned lowb = cp & 31;
+            const int b2c = (lowb == 1) ? 0 : (lowb == 2) ? 1 : (lowb == 4) ? 2 : (lowb == 8) ? 3 : (lowb == 16) ? 4 : 99;
+            if ((co.het_phred <= 0 && b2c != co.call) || (cp >> 8)) perfect = 0;
         }
         cond_score = score < min_indel;                               /* snp:1719-1720 */
     }
     if (P->perfect_col && !perfect) preserve = 1;                     /* snp:1648 */
 
-    bool keep = (double)low_mq > P->low_mqual_perc * (n_plp + .01);   /* snp:1668 */
+    bool keep = (double)st.low_mq > P->low_mqual_perc * (n_plp + .01);   /* snp:1668 */
     stat_inc(stats, ST_LOW_MQUAL_PERC, keep);
-    if ((clipped - 1.0) >= P->clip_perc * n_overlap) {                /* snp:1764 */
+    if ((st.clipped - 1.0) >= P->clip_perc * st.n_overlap) {          /* snp:1764 */
         keep = true;
         stat_inc(stats, ST_CLIP_PERC, true);
     }
     if (cond_score)                                                   /* snp:1718 */
-        tcnt = (P->str_snp && preserve) ? (n_plp - nref) : n_isindel;
-    stat_inc(stats, ST_INDEL, indel_cnt > 0);                         /* snp:1761 */
-    stat_inc(stats, ST_INDEL_QUAL, cond_score && n_isindel > 0);      /* snp:1762 */
+        tcnt = (P->str_snp && preserve) ? (n_plp - st.nref) : st.n_isindel;
+    stat_inc(stats, ST_INDEL, st.indel_cnt > 0);                      /* snp:1761 */
+    stat_inc(stats, ST_INDEL_QUAL, cond_score && st.n_isindel > 0);   /* snp:1762 */
     if (tcnt) atomicAdd(&stats[ST_TRIGGERS], (u64)tcnt);
 
     rec |= (uint32_t)a1 | ((uint32_t)a2 << 3) | ((uint32_t)preserve << 6);
     if (perfect) rec |= CR_PERFECT;
     if (keep) rec |= CR_KEEP;
     if (tcnt) rec |= CR_TRIG | CR_WIN;
-    if (has_ins) rec |= CR_HASINS;
-    if ((double)indel_cnt >= n_plp * P->indel_fract) rec |= CR_SCAN;  /* snp:1732 */
+    if (st.has_ins) rec |= CR_HASINS;
+    if ((double)st.indel_cnt >= n_plp * P->indel_fract) rec |= CR_SCAN;  /* snp:1732 */
     colrec[c] = rec; score_out[c] = score; trigcnt[c] = tcnt;
+}
+
+template <bool MQ>
+__global__ void __launch_bounds__(256, 4)
+k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T,
+          uint32_t *__restrict__ colrec, int32_t *__restrict__ nplp_out,
+          int32_t *__restrict__ score_out, int32_t *__restrict__ trigcnt, u64 *stats)
+{
+    __shared__ double sMM[101], s_M[101], sOmq[101];
+    __shared__ uint8_t sAdj[MQ ? 256 * 128 : 16];
+    for (int i = threadIdx.x; i < 101; i += blockDim.x) {
+        sMM[i] = T->MMd[i]; s_M[i] = T->_Md[i]; sOmq[i] = T->omq[i];
+    }
+    if (MQ) {
+        /* adj[mapq][qual] for qual < 128 (input and capped qualities are < 128) */
+        for (int i = threadIdx.x; i < 256 * 128 / 4; i += blockDim.x) {
+            const int m = i >> 5, q4 = (i & 31) * 4;
+            *(uint32_t *)&sAdj[m * 128 + q4] = *(const uint32_t *)&T->adj[m * 256 + q4];
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave0 = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    const bool use_cons = MQ ? (P->min_qual_B != 0) : (P->min_qual_A != 0);
+    const int qcap = P->qcap, min_mqual = P->min_mqual, any_pres = P->any_preserve;
+
+    for (int tile = UNIFORM(wave0); tile < B.n_tiles; tile += nwaves) {
+        const int c = tile * 64 + lane;
+        const int apos = B.p0 + c;
+        const bool inr = c < B.L;
+        const int lo = UNIFORM(B.tile_lo[tile]), hi = UNIFORM(B.tile_hi[tile]);
+
+        ColState st;
+        #pragma unroll
+        for (int j = 0; j < 15; j++) st.S[j] = 0;
+        #pragma unroll
+        for (int j = 0; j < 5; j++) st.sC[j] = 0;
+        st.depth = st.nN = st.n_plp = st.nref = st.low_mq = st.indel_cnt = 0;
+        st.clipped = st.n_overlap = st.n_isindel = st.has_ins = 0;
+        st.cp = 0;
+
+        for (int b0 = lo; b0 < hi; b0 += 64) {
+            const int cnt = (hi - b0 < 64) ? hi - b0 : 64;
+            /* lane i holds the record of candidate read b0+i */
+            int m_pos = 0, m_end = INT_MIN, m_solo = 0, m_sohi = 0, m_lq = 0, m_q0 = 0, m_info = 0;
+            if (lane < cnt) {
+                const ReadRec rr = B.rr[b0 + lane];
+                m_pos = rr.pos; m_end = rr.end; m_solo = (int)(uint32_t)(rr.so & 0xffffffff);
+                m_sohi = (int)(rr.so >> 32); m_lq = rr.lq; m_q0 = rr.q0; m_info = (int)rr.info;
+            }
+            for (int j = 0; j < cnt; j += 4) {
+                /* phase A: the byte loads of up to four simple reads go out together
+                 * (uncovered lanes read byte 0: no branch between the loads) */
+                uint8_t cc[4], qq[4];
+                #pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int l = (j + u < cnt) ? j + u : j;
+                    const int rp = READLANE(m_pos, l), re = READLANE(m_end, l);
+                    const int q0 = READLANE(m_q0, l), info = READLANE(m_info, l);
+                    const int64_t so = (int64_t)(((uint64_t)(uint32_t)READLANE(m_sohi, l) << 32) | (uint32_t)READLANE(m_solo, l));
+                    const bool cv = (info & RR_SIMPLE) && inr && apos >= rp && apos < re;
+                    const int64_t a = cv ? so + q0 + (apos - rp) : 0;
+                    cc[u] = B.bases[a]; qq[u] = B.quals[a];
+                }
+                const uint32_t pkc = (uint32_t)(cc[0] & 15) | ((uint32_t)(cc[1] & 15) << 8) | ((uint32_t)(cc[2] & 15) << 16) | ((uint32_t)(cc[3] & 15) << 24);
+                const uint32_t pkq = (uint32_t)qq[0] | ((uint32_t)qq[1] << 8) | ((uint32_t)qq[2] << 16) | ((uint32_t)qq[3] << 24);
+                /* phase B: accumulate in file order */
+                #pragma unroll 1
+                for (int u = 0; u < 4; u++) {
+                    const int l = j + u;
+                    if (l >= cnt) break;
+                    const int rp = READLANE(m_pos, l), re = READLANE(m_end, l), lq = READLANE(m_lq, l);
+                    const int q0 = READLANE(m_q0, l), info = READLANE(m_info, l);
+                    const int64_t so = (int64_t)(((uint64_t)(uint32_t)READLANE(m_sohi, l) << 32) | (uint32_t)READLANE(m_solo, l));
+                    if (!(inr && apos >= rp && apos < re)) continue;
+                    Entry e;
+                    int code; uint8_t q;
+                    if (info & RR_SIMPLE) {
+                        e.qpos = q0 + (apos - rp); e.indel = 0; e.is_del = 0; e.is_refskip = 0;
+                        e.is_head = (apos == rp); e.is_tail = (apos == re - 1);
+                        code = (int)((pkc >> (8 * u)) & 15); q = (uint8_t)((pkq >> (8 * u)) & 255);
+                    } else {                                        /* general CIGARs */
+                        const int r = b0 + l;
+                        const int64_t sgo = B.seg_off[r];
+                        const int ns = (int)(B.seg_off[r + 1] - sgo);
+                        const int off = apos - rp;
+                        const int si = seg_find(B.segs + sgo, ns, off);
+                        entry_from_seg(B.segs[sgo + si], off, re - rp, e);
+                        code = 0; q = 0;
+                        if (e.qpos < lq && !e.is_refskip) { code = B.bases[so + e.qpos] & 15; q = B.quals[so + e.qpos]; }
+                    }
+                    col_accumulate<MQ>(st, e, code, q, lq, info & 255, B.quals + so, P,
+                                       sMM, s_M, sOmq, sAdj, use_cons, qcap, min_mqual, any_pres);
+                }
+            }
+        }
+        if (inr) col_decide<MQ>(st, B, P, T, c, apos, use_cons, colrec, nplp_out, score_out, trigcnt, stats);
+    }
 }
 
 /* ------------------------------------------------------------------------ */
