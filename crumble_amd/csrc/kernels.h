@@ -73,6 +73,14 @@ __device__ __forceinline__ void stat_inc(u64 *stats, int which, bool cond)
     if (cond) atomicAdd(&stats[which], (u64)1);
 }
 
+/* Same, into a workgroup's LDS counters: one hot global word saturates at ~90
+ * atomics/us (MI355X_MICROARCH.md "dequeue"), which a counter bumped once per
+ * 64-column tile would hit; LDS counters are flushed once per workgroup. */
+__device__ __forceinline__ void lds_inc(unsigned *cnt, int which, bool cond)
+{
+    if (cond) atomicAdd(&cnt[which], 1u);
+}
+
 /* ------------------------------------------------------------------------ */
 /* fast_log2 / fast_exp (snp:491-518) */
 __device__ __forceinline__ double dev_fast_log2(double val)
@@ -259,81 +267,12 @@ struct ColState {
     unsigned cp;
 };
 
-template <bool MQ>
-__device__ __forceinline__ void col_accumulate(ColState &st, const Entry &e, int code, uint8_t q, int lq, int mq,
-                                               const uint8_t *rq /* read's quals */, const DParams *__restrict__ P,
-                                               const double *sMM, const double *s_M, const double *sOmq,
-                                               const uint8_t *sAdj, bool use_cons, int qcap, int min_mqual, int any_pres)
-{
-    /* --- column heuristics inputs (snp:1662-1713) --- */
-    st.n_plp++;
-    st.low_mq += (mq <= min_mqual);
-    if (e.indel || e.is_del) st.indel_cnt++;
-    if (e.is_refskip) { st.nref++; return; }           /* snp:589, snp:1696 */
-    st.n_isindel += (e.indel || e.is_del) ? 1 : 0;
-    if ((e.is_head && e.qpos > 0) || (e.is_tail && e.qpos + 1 < lq)) st.clipped++;
-    if (!e.is_tail && !e.is_head) { st.n_overlap++; if (e.indel > 0) st.has_ins = 1; }
-
-    /* --- consensus accumulation (snp:594-685) --- */
-    if (!lq || !use_cons) return;
-    int b;
-    if (e.qpos < lq) {
-        b = (code == 1) ? 0 : (code == 2) ? 1 : (code == 4) ? 2 : (code == 8) ? 3 : 5;
-        q = (q > qcap && !P->preserve_qual[q]) ? (uint8_t)qcap : q;
-    } else { b = 5; q = 0; }                           /* fence: read ends in D/N */
-    if (e.is_del) b = 4;
-    if (any_pres) {                                    /* snp:611-623 */
-        const uint8_t pv = P->preserve_qual[q];
-        if (pv) st.cp |= 1u << b;
-        if (pv > 1) st.cp |= (1u << b) << 8;
-        if (e.indel > 0)
-            for (int ins = 0; ins < e.indel; ins++) {
-                const int qi = e.qpos + 1 + ins;
-                if (qi < lq && P->preserve_qual[cap_q(P, rq[qi])]) st.cp |= 1u << 4;
-            }
-    }
-    int aq = MQ ? sAdj[mq * 128 + (q & 127)] : q;      /* snp:632-638 */
-    if (aq < 1) aq = 1;                                /* snp:641 */
-    if (aq > 100) aq = 100;                            /* fence */
-    const double MM = sMM[aq], _M = s_M[aq], om = sOmq[aq];
-    st.depth++;
-    double *S = st.S, *sC = st.sC;
-    if (b == 5) {                                      /* N: snp:677-682 */
-        st.nN++;
-        S[0] += MM; S[1] += MM; S[2] += MM; S[3] += MM; S[4] += _M;
-        S[5] += MM; S[6] += MM; S[7] += MM; S[8] += _M;
-        S[9] += MM; S[10] += MM; S[11] += _M;
-        S[12] += MM; S[13] += _M;
-        return;
-    }
-    const bool b0 = b == 0, b1 = b == 1, b2 = b == 2, b3 = b == 3, b4 = b == 4;
-    sC[0] += b0 ? om : 0.0; sC[1] += b1 ? om : 0.0; sC[2] += b2 ? om : 0.0;
-    sC[3] += b3 ? om : 0.0; sC[4] += b4 ? om : 0.0;
-    /* adding +0.0 is exact, so every genotype sees its own subsequence of
-     * addends in file order (snp:656-675) */
-    S[0]  += b0 ? MM : 0.0;
-    S[1]  += (b0 || b1) ? _M : 0.0;
-    S[2]  += (b0 || b2) ? _M : 0.0;
-    S[3]  += (b0 || b3) ? _M : 0.0;
-    S[4]  += (b0 || b4) ? _M : 0.0;
-    S[5]  += b1 ? MM : 0.0;
-    S[6]  += (b1 || b2) ? _M : 0.0;
-    S[7]  += (b1 || b3) ? _M : 0.0;
-    S[8]  += (b1 || b4) ? _M : 0.0;
-    S[9]  += b2 ? MM : 0.0;
-    S[10] += (b2 || b3) ? _M : 0.0;
-    S[11] += (b2 || b4) ? _M : 0.0;
-    S[12] += b3 ? MM : 0.0;
-    S[13] += (b3 || b4) ? _M : 0.0;
-    S[14] += b4 ? MM : 0.0;
-}
-
 /* column decisions: snp:1438-1773 minus the passes that need cross-column state */
 template <bool MQ>
 __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const DParams *__restrict__ P,
                                            const DTables *__restrict__ T, int c, int apos, bool use_cons,
                                            uint32_t *__restrict__ colrec, int32_t *__restrict__ nplp_out,
-                                           int32_t *__restrict__ score_out, int32_t *__restrict__ trigcnt, u64 *stats)
+                                           int32_t *__restrict__ score_out, int32_t *__restrict__ trigcnt, unsigned *stats)
 {
     const int n_plp = st.n_plp;
     if (n_plp == 0) { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; return; }
@@ -347,9 +286,9 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
         return;
     }
     rec |= CR_COUNTED;
-    stat_inc(stats, ST_COLUMNS, true);
+    lds_inc(stats, ST_COLUMNS, true);
     if (n_plp > MAX_DEPTH_COL) {                       /* snp:1493-1500 */
-        stat_inc(stats, ST_TOO_DEEP, true);
+        lds_inc(stats, ST_TOO_DEEP, true);
         colrec[c] = rec | CR_TOODEEP; score_out[c] = 0; trigcnt[c] = 0;
         return;
     }
@@ -369,11 +308,11 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
         const double min_discrep = MQ ? P->min_discrep_B : P->min_discrep_A;
         const bool lowq = score < min_qual;
         const bool disc = co.discrep >= min_discrep;                  /* float vs double */
-        stat_inc(stats, MQ ? ST_HET_B : ST_HET_A, het);
-        stat_inc(stats, MQ ? ST_HET_QUAL_B : ST_HET_QUAL_A, het && lowq);
-        stat_inc(stats, MQ ? ST_HOM_B : ST_HOM_A, !het);
-        stat_inc(stats, MQ ? ST_HOM_QUAL_B : ST_HOM_QUAL_A, !het && lowq);
-        stat_inc(stats, MQ ? ST_DISCREP_B : ST_DISCREP_A, disc);
+        lds_inc(stats, MQ ? ST_HET_B : ST_HET_A, het);
+        lds_inc(stats, MQ ? ST_HET_QUAL_B : ST_HET_QUAL_A, het && lowq);
+        lds_inc(stats, MQ ? ST_HOM_B : ST_HOM_A, !het);
+        lds_inc(stats, MQ ? ST_HOM_QUAL_B : ST_HOM_QUAL_A, !het && lowq);
+        lds_inc(stats, MQ ? ST_DISCREP_B : ST_DISCREP_A, disc);
         if (!MQ && (int)cp != (1 << co.call)) perfect = 0;            /* snp:1606 */
         preserve |= (lowq ? 1 : 0);                                   /* snp:1624-1628 */
         preserve |= (disc ? 1 : 0);
@@ -388,16 +327,16 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
     if (P->perfect_col && !perfect) preserve = 1;                     /* snp:1648 */
 
     bool keep = (double)st.low_mq > P->low_mqual_perc * (n_plp + .01);   /* snp:1668 */
-    stat_inc(stats, ST_LOW_MQUAL_PERC, keep);
+    lds_inc(stats, ST_LOW_MQUAL_PERC, keep);
     if ((st.clipped - 1.0) >= P->clip_perc * st.n_overlap) {          /* snp:1764 */
         keep = true;
-        stat_inc(stats, ST_CLIP_PERC, true);
+        lds_inc(stats, ST_CLIP_PERC, true);
     }
     if (cond_score)                                                   /* snp:1718 */
         tcnt = (P->str_snp && preserve) ? (n_plp - st.nref) : st.n_isindel;
-    stat_inc(stats, ST_INDEL, st.indel_cnt > 0);                      /* snp:1761 */
-    stat_inc(stats, ST_INDEL_QUAL, cond_score && st.n_isindel > 0);   /* snp:1762 */
-    if (tcnt) atomicAdd(&stats[ST_TRIGGERS], (u64)tcnt);
+    lds_inc(stats, ST_INDEL, st.indel_cnt > 0);                      /* snp:1761 */
+    lds_inc(stats, ST_INDEL_QUAL, cond_score && st.n_isindel > 0);   /* snp:1762 */
+    if (tcnt) atomicAdd(&stats[ST_TRIGGERS], (unsigned)tcnt);
 
     rec |= (uint32_t)a1 | ((uint32_t)a2 << 3) | ((uint32_t)preserve << 6);
     if (perfect) rec |= CR_PERFECT;
@@ -416,6 +355,8 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
 {
     __shared__ double sMM[101], s_M[101], sOmq[101];
     __shared__ uint8_t sAdj[MQ ? 256 * 128 : 16];
+    __shared__ unsigned sStat[32];
+    if (threadIdx.x < 32) sStat[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < 101; i += blockDim.x) {
         sMM[i] = T->MMd[i]; s_M[i] = T->_Md[i]; sOmq[i] = T->omq[i];
     }
@@ -482,30 +423,93 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                     const int rp = READLANE(m_pos, l), re = READLANE(m_end, l), lq = READLANE(m_lq, l);
                     const int q0 = READLANE(m_q0, l), info = READLANE(m_info, l);
                     const int64_t so = (int64_t)(((uint64_t)(uint32_t)READLANE(m_sohi, l) << 32) | (uint32_t)READLANE(m_solo, l));
-                    if (!(inr && apos >= rp && apos < re)) continue;
-                    Entry e;
-                    int code; uint8_t q;
-                    if (info & RR_SIMPLE) {
-                        e.qpos = q0 + (apos - rp); e.indel = 0; e.is_del = 0; e.is_refskip = 0;
-                        e.is_head = (apos == rp); e.is_tail = (apos == re - 1);
-                        code = (int)((pkc >> (8 * u)) & 15); q = (uint8_t)((pkq >> (8 * u)) & 255);
-                    } else {                                        /* general CIGARs */
-                        const int r = b0 + l;
-                        const int64_t sgo = B.seg_off[r];
-                        const int ns = (int)(B.seg_off[r + 1] - sgo);
-                        const int off = apos - rp;
-                        const int si = seg_find(B.segs + sgo, ns, off);
-                        entry_from_seg(B.segs[sgo + si], off, re - rp, e);
+                    const bool cov = inr && apos >= rp && apos < re;
+                    const int mq = info & 255;
+                    /* the pileup entry of this read on this column (bam_pileup1_t fields) */
+                    int e_qpos = q0 + (apos - rp), e_indel = 0;
+                    bool e_del = false, e_refskip = false;
+                    int code = (int)((pkc >> (8 * u)) & 15);
+                    int q = (int)((pkq >> (8 * u)) & 255);
+                    if (!(info & RR_SIMPLE)) {                      /* general CIGARs (wave-uniform branch) */
                         code = 0; q = 0;
-                        if (e.qpos < lq && !e.is_refskip) { code = B.bases[so + e.qpos] & 15; q = B.quals[so + e.qpos]; }
+                        if (cov) {
+                            const int r = b0 + l;
+                            const int64_t sgo = B.seg_off[r];
+                            const int ns = (int)(B.seg_off[r + 1] - sgo);
+                            const int off = apos - rp;
+                            const int si = seg_find(B.segs + sgo, ns, off);
+                            Entry e;
+                            entry_from_seg(B.segs[sgo + si], off, re - rp, e);
+                            e_qpos = e.qpos; e_indel = e.indel; e_del = e.is_del; e_refskip = e.is_refskip;
+                            if (e.qpos < lq && !e.is_refskip) { code = B.bases[so + e.qpos] & 15; q = B.quals[so + e.qpos]; }
+                        }
                     }
-                    col_accumulate<MQ>(st, e, code, q, lq, info & 255, B.quals + so, P,
-                                       sMM, s_M, sOmq, sAdj, use_cons, qcap, min_mqual, any_pres);
+                    /* One branch-free accumulate for every kind of entry: lanes that the read
+                     * does not cover (or that must not count) add +0.0, which is exact, so each
+                     * genotype sum sees its own addends in file order (snp:656-683) and the 20
+                     * running sums never leave their registers. */
+                    const bool head = (apos == rp), tail = (apos == re - 1);
+                    const bool isind = (e_indel != 0) || e_del;
+                    const bool act = cov && !e_refskip;             /* snp:589, snp:1696 */
+                    st.n_plp += cov ? 1 : 0;
+                    st.low_mq += (cov && mq <= min_mqual) ? 1 : 0;  /* snp:1663 */
+                    st.indel_cnt += (cov && isind) ? 1 : 0;         /* snp:1664 */
+                    st.nref += (cov && e_refskip) ? 1 : 0;
+                    st.n_isindel += (act && isind) ? 1 : 0;
+                    st.clipped += (act && ((head && e_qpos > 0) || (tail && e_qpos + 1 < lq))) ? 1 : 0;   /* snp:1701 */
+                    st.n_overlap += (act && !head && !tail) ? 1 : 0;                                      /* snp:1705 */
+                    st.has_ins |= (act && !head && !tail && e_indel > 0) ? 1 : 0;                         /* snp:1708 */
+                    const bool cons = act && lq > 0 && use_cons;    /* snp:594 */
+                    const bool inq = e_qpos < lq;                   /* fence: read ends in D/N */
+                    q = inq ? q : 0;
+                    if (any_pres) q = (q > qcap && !P->preserve_qual[q]) ? qcap : q;   /* cap_quality snp:1325 */
+                    else          q = q > qcap ? qcap : q;
+                    int b = (code == 1) ? 0 : (code == 2) ? 1 : (code == 4) ? 2 : (code == 8) ? 3 : 5;   /* snp:603 */
+                    b = inq ? b : 5;
+                    b = e_del ? 4 : b;                              /* snp:609 */
+                    if (any_pres && cons) {                         /* snp:611-623 */
+                        const uint8_t pv = P->preserve_qual[q];
+                        if (pv) st.cp |= 1u << b;
+                        if (pv > 1) st.cp |= (1u << b) << 8;
+                        if (e_indel > 0)
+                            for (int ins = 0; ins < e_indel; ins++) {
+                                const int qi = e_qpos + 1 + ins;
+                                if (qi < lq && P->preserve_qual[cap_q(P, B.quals[so + qi])]) st.cp |= 1u << 4;
+                            }
+                    }
+                    int aq = MQ ? sAdj[mq * 128 + (q & 127)] : q;   /* snp:632-638 */
+                    aq = aq < 1 ? 1 : (aq > 100 ? 100 : aq);        /* snp:641; fence Q5 */
+                    const double MM = sMM[aq], _M = s_M[aq], om = sOmq[aq];
+                    const bool cA = cons && b == 0, cC = cons && b == 1, cG = cons && b == 2, cT = cons && b == 3;
+                    const bool cS = cons && b == 4, cN = cons && b == 5;
+                    const double Mn = cN ? MM : _M;                 /* an N gives MM to the '*'-free hets (snp:677) */
+                    double *S = st.S, *sC = st.sC;
+                    st.depth += cons ? 1 : 0;
+                    st.nN += cN ? 1 : 0;
+                    sC[0] += cA ? om : 0.0; sC[1] += cC ? om : 0.0; sC[2] += cG ? om : 0.0;
+                    sC[3] += cT ? om : 0.0; sC[4] += cS ? om : 0.0;
+                    S[0]  += (cA || cN) ? MM : 0.0;
+                    S[1]  += (cA || cC || cN) ? Mn : 0.0;
+                    S[2]  += (cA || cG || cN) ? Mn : 0.0;
+                    S[3]  += (cA || cT || cN) ? Mn : 0.0;
+                    S[4]  += (cA || cS || cN) ? _M : 0.0;
+                    S[5]  += (cC || cN) ? MM : 0.0;
+                    S[6]  += (cC || cG || cN) ? Mn : 0.0;
+                    S[7]  += (cC || cT || cN) ? Mn : 0.0;
+                    S[8]  += (cC || cS || cN) ? _M : 0.0;
+                    S[9]  += (cG || cN) ? MM : 0.0;
+                    S[10] += (cG || cT || cN) ? Mn : 0.0;
+                    S[11] += (cG || cS || cN) ? _M : 0.0;
+                    S[12] += (cT || cN) ? MM : 0.0;
+                    S[13] += (cT || cS || cN) ? _M : 0.0;
+                    S[14] += cS ? MM : 0.0;
                 }
             }
         }
-        if (inr) col_decide<MQ>(st, B, P, T, c, apos, use_cons, colrec, nplp_out, score_out, trigcnt, stats);
+        if (inr) col_decide<MQ>(st, B, P, T, c, apos, use_cons, colrec, nplp_out, score_out, trigcnt, sStat);
     }
+    __syncthreads();
+    if (threadIdx.x < 32 && sStat[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (u64)sStat[threadIdx.x]);
 }
 
 /* ------------------------------------------------------------------------ */
