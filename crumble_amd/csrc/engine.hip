@@ -440,9 +440,9 @@ extern "C" int crumble_hip_run(crumble_hip *h)
         STAGE("scan", 0);
         const int nchunks = (L + SCAN_CHUNK - 1) / SCAN_CHUNK;
         ScanVal *partial = h->d_partial.as<ScanVal>();
-        CRUMBLE_LAUNCH_INDEP(k_scan_reduce, nblk(nchunks, 64), 64, st, L, colrec, nplp, trigcnt, partial, nchunks);
-        CRUMBLE_LAUNCH_INDEP(k_scan_partials, 1, 1, st, partial, nchunks);
-        CRUMBLE_LAUNCH_INDEP(k_scan_apply, nblk(nchunks, 64), 64, st, L, colrec, nplp, trigcnt, partial, nchunks,
+        CRUMBLE_LAUNCH(k_scan_reduce, nchunks, 256, st, L, colrec, nplp, trigcnt, partial, nchunks);
+        CRUMBLE_LAUNCH(k_scan_partials, 1, 256, st, partial, nchunks);
+        CRUMBLE_LAUNCH(k_scan_apply, nchunks, 256, st, L, colrec, nplp, trigcnt, partial, nchunks,
                              h->d_dpre.as<int64_t>(), h->d_col_ord.as<int32_t>(), h->d_trig_ord.as<int32_t>(),
                              h->d_item_off.as<int32_t>(), h->d_ins_ord.as<int32_t>());
         CRUMBLE_LAUNCH_INDEP(k_epochs, 1, 1, st, L, colrec, nplp, h->d_col_ord.as<int32_t>(), h->d_dpre.as<int64_t>(),

@@ -528,40 +528,90 @@ __device__ __forceinline__ void scanval_of(uint32_t rec, int32_t nplp, int32_t t
 __device__ __forceinline__ void scanval_add(ScanVal &a, const ScanVal &b)
 { a.depth += b.depth; a.cols += b.cols; a.trigcols += b.trigcols; a.items += b.items; a.ins += b.ins; }
 
-__global__ void k_scan_reduce(int L, const uint32_t *colrec, const int32_t *nplp,
-                              const int32_t *trigcnt, ScanVal *partial, int nchunks)
+/* wave-level inclusive scan of a ScanVal (shuffles), then block-level via LDS */
+__device__ __forceinline__ ScanVal scanval_wave_incl(ScanVal v, int lane)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nchunks) return;
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        ScanVal o;
+        o.depth = __shfl_up(v.depth, d); o.cols = __shfl_up(v.cols, d); o.trigcols = __shfl_up(v.trigcols, d);
+        o.items = __shfl_up(v.items, d); o.ins = __shfl_up(v.ins, d);
+        if (lane >= d) scanval_add(v, o);
+    }
+    return v;
+}
+
+/* one workgroup reduces one chunk of SCAN_CHUNK consecutive positions (coalesced) */
+__global__ void __launch_bounds__(256)
+k_scan_reduce(int L, const uint32_t *colrec, const int32_t *nplp,
+              const int32_t *trigcnt, ScanVal *partial, int nchunks)
+{
+    __shared__ ScanVal ws[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int base = blockIdx.x * SCAN_CHUNK;
     ScanVal acc = {0, 0, 0, 0, 0}, v;
-    const int b = t * SCAN_CHUNK, e = (b + SCAN_CHUNK < L) ? b + SCAN_CHUNK : L;
-    for (int i = b; i < e; i++) { scanval_of(colrec[i], nplp[i], trigcnt[i], v); scanval_add(acc, v); }
-    partial[t] = acc;
+    for (int k = 0; k < SCAN_CHUNK / 256; k++) {
+        const int i = base + k * 256 + (int)threadIdx.x;
+        if (i < L) { scanval_of(colrec[i], nplp[i], trigcnt[i], v); scanval_add(acc, v); }
+    }
+    acc = scanval_wave_incl(acc, lane);
+    if (lane == 63) ws[w] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ScanVal t = ws[0];
+        for (int j = 1; j < (int)(blockDim.x >> 6); j++) scanval_add(t, ws[j]);
+        partial[blockIdx.x] = t;
+    }
 }
 
-/* single thread: exclusive scan of the chunk partials; totals -> partial[nchunks] */
-__global__ void k_scan_partials(ScanVal *partial, int nchunks)
+/* one workgroup: exclusive scan of the chunk partials; totals -> partial[nchunks] */
+__global__ void __launch_bounds__(256)
+k_scan_partials(ScanVal *partial, int nchunks)
 {
-    if (blockIdx.x || threadIdx.x) return;
+    __shared__ ScanVal ws[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nt = blockDim.x;
+    const int per = (nchunks + nt - 1) / nt;
+    const int b = (int)threadIdx.x * per, e = (b + per < nchunks) ? b + per : nchunks;
+    ScanVal acc = {0, 0, 0, 0, 0};
+    for (int i = b; i < e; i++) scanval_add(acc, partial[i]);
+    ScanVal inc = scanval_wave_incl(acc, lane);
+    if (lane == 63) ws[w] = inc;
+    __syncthreads();
     ScanVal run = {0, 0, 0, 0, 0};
-    for (int i = 0; i < nchunks; i++) { ScanVal v = partial[i]; partial[i] = run; scanval_add(run, v); }
-    partial[nchunks] = run;
+    for (int j = 0; j < w; j++) scanval_add(run, ws[j]);
+    /* exclusive prefix of this thread = run + inc - acc */
+    run.depth += inc.depth - acc.depth; run.cols += inc.cols - acc.cols; run.trigcols += inc.trigcols - acc.trigcols;
+    run.items += inc.items - acc.items; run.ins += inc.ins - acc.ins;
+    for (int i = b; i < e; i++) { ScanVal v = partial[i]; partial[i] = run; scanval_add(run, v); }
+    if ((int)threadIdx.x == nt - 1) partial[nchunks] = run;   /* last thread ends with the grand total */
 }
 
-__global__ void k_scan_apply(int L, const uint32_t *colrec, const int32_t *nplp,
-                             const int32_t *trigcnt, const ScanVal *partial, int nchunks,
-                             int64_t *dpre, int32_t *col_ord, int32_t *trig_ord,
-                             int32_t *item_off, int32_t *ins_ord)
+__global__ void __launch_bounds__(256)
+k_scan_apply(int L, const uint32_t *colrec, const int32_t *nplp,
+             const int32_t *trigcnt, const ScanVal *partial, int nchunks,
+             int64_t *dpre, int32_t *col_ord, int32_t *trig_ord,
+             int32_t *item_off, int32_t *ins_ord)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nchunks) return;
-    ScanVal run = partial[t], v;
-    const int b = t * SCAN_CHUNK, e = (b + SCAN_CHUNK < L) ? b + SCAN_CHUNK : L;
-    for (int i = b; i < e; i++) {
-        dpre[i] = run.depth; col_ord[i] = run.cols; trig_ord[i] = run.trigcols;
-        item_off[i] = run.items; ins_ord[i] = run.ins;
-        scanval_of(colrec[i], nplp[i], trigcnt[i], v);
-        scanval_add(run, v);
+    __shared__ ScanVal ws[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int base = blockIdx.x * SCAN_CHUNK;
+    ScanVal carry = partial[blockIdx.x];
+    for (int k = 0; k < SCAN_CHUNK / 256; k++) {
+        const int i = base + k * 256 + (int)threadIdx.x;
+        ScanVal v = {0, 0, 0, 0, 0};
+        if (i < L) scanval_of(colrec[i], nplp[i], trigcnt[i], v);
+        ScanVal inc = scanval_wave_incl(v, lane);
+        __syncthreads();                               /* ws reuse */
+        if (lane == 63) ws[w] = inc;
+        __syncthreads();
+        ScanVal run = carry;
+        for (int j = 0; j < w; j++) scanval_add(run, ws[j]);
+        if (i < L) {
+            dpre[i] = run.depth + inc.depth - v.depth; col_ord[i] = run.cols + inc.cols - v.cols;
+            trig_ord[i] = run.trigcols + inc.trigcols - v.trigcols;
+            item_off[i] = run.items + inc.items - v.items; ins_ord[i] = run.ins + inc.ins - v.ins;
+        }
+        for (int j = 0; j < (int)(blockDim.x >> 6); j++) scanval_add(carry, ws[j]);
     }
 }
 
@@ -705,15 +755,17 @@ __global__ void k_emit(DBatch B, const DParams *P, int n_trig, const int32_t *tr
 /* find_STR / add_rep (str_finder.c:34-189) on the 2-bit codes of a read
  * window, and mask_LC_regions (snp:1230-1290).  One thread per trigger.      */
 struct StrWin {
-    const uint8_t *bases;   /* read's nt16 codes */
-    int lq, start;          /* window start in the read */
-    int tail_code;          /* code of index lq */
+    const unsigned *w;      /* this lane's packed 2-bit codes in LDS: word k at w[k*64] */
 };
-__device__ __forceinline__ int str_code(const StrWin &w, int i)
-{   /* str_finder.c:15-32 via seq_nt16_str: C=1 G=2 T=3, all else 0 */
-    const int qi = w.start + i;
-    int c16 = (qi < w.lq) ? (w.bases[qi] & 15) : w.tail_code;
-    return (c16 == 2) ? 1 : (c16 == 4) ? 2 : (c16 == 8) ? 3 : 0;
+#define STR_WORDS 32        /* 512 codes >= 2*MASK_WIN+1 */
+__device__ __forceinline__ int str_code(const StrWin &sw, int i)
+{
+    return (int)((sw.w[(i >> 4) * 64] >> ((i & 15) * 2)) & 3u);
+}
+/* str_finder.c:15-32 via seq_nt16_str: C=1 G=2 T=3, all else (A, N, '=', IUPAC) 0 */
+__device__ __forceinline__ unsigned nt16_to_str2(unsigned c16)
+{
+    return (c16 == 2) ? 1u : (c16 == 4) ? 2u : (c16 == 8) ? 3u : 0u;
 }
 
 /* add_rep (str_finder.c:34-127) without pads; the utlist list is an ordered array */
@@ -804,23 +856,36 @@ __device__ __forceinline__ int dev_ref2query_pos(const uint32_t *cig, int nc, in
 }
 
 __device__ inline void dev_mask_lc(const DBatch &B, const DParams *P, int r, int rpos, int is_indel,
-                                   int *min_pos, int *max_pos, int *overflow)
+                                   int *min_pos, int *max_pos, int *overflow, unsigned *lds_lane)
 {
     short st[STR_CAP], en[STR_CAP];
     const int64_t so = B.seq_off[r];
     const int lq = (int)(B.seq_off[r + 1] - so);
-    StrWin w;
-    w.bases = B.bases + so; w.lq = lq;
-    w.start = rpos - MASK_WIN_DEV > 0 ? rpos - MASK_WIN_DEV : 0;
+    const uint8_t *bases = B.bases + so;
+    const int start = rpos - MASK_WIN_DEV > 0 ? rpos - MASK_WIN_DEV : 0;
     const int end = rpos + MASK_WIN_DEV < lq ? rpos + MASK_WIN_DEV : lq;
-    const int len = end - w.start + 1;
-    w.tail_code = (lq & 1) || !lq ? 0 : (cap_q(P, B.quals[so]) >> 4);
+    const int len = end - start + 1;                       /* inclusive (snp:1235,1241) */
+    /* index l_qseq is read too: pad nibble, or high nibble of the capped qual[0] */
+    const unsigned tail_code = ((lq & 1) || !lq) ? 0u : (unsigned)(cap_q(P, B.quals[so]) >> 4);
+    /* stage the window as packed 2-bit codes in LDS (16 independent byte loads per word) */
+    for (int k = 0; k * 16 < len; k++) {
+        unsigned word = 0;
+        #pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int i = k * 16 + j, qi = start + i;
+            unsigned c16 = 0;
+            if (i < len) c16 = (qi < lq) ? (unsigned)(bases[qi] & 15) : tail_code;
+            word |= nt16_to_str2(c16) << (2 * j);
+        }
+        lds_lane[k * 64] = word;
+    }
+    StrWin w; w.w = lds_lane;
     const int n = dev_find_STR(w, len, st, en, overflow);
     const int add = is_indel ? P->iSTR_add : P->sSTR_add;
     const uint32_t *cig = B.cigar + B.cig_off[r];
     const int nc = (int)(B.cig_off[r + 1] - B.cig_off[r]);
     for (int i = 0; i < n; i++) {
-        int s = st[i] + w.start, e = en[i] + w.start;
+        int s = st[i] + start, e = en[i] + start;
         if (!(rpos + add >= s && rpos - add <= e)) continue;
         s = dev_qpos2rpos(cig, nc, B.pos[r], s);
         e = dev_qpos2rpos(cig, nc, B.pos[r], e);
@@ -829,14 +894,17 @@ __device__ inline void dev_mask_lc(const DBatch &B, const DParams *P, int r, int
     }
 }
 
-__global__ void k_str(DBatch B, const DParams *P, int n_items, TrigItem *items, int *overflow)
+__global__ void __launch_bounds__(64)
+k_str(DBatch B, const DParams *P, int n_items, TrigItem *items, int *overflow)
 {
+    __shared__ unsigned win[STR_WORDS * 64];           /* lane t owns win[k*64 + t] */
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_items) return;
     const TrigItem it = items[t];
     if (it.qpos1_kind & (1 << 29)) return;            /* indel_cnt < n_plp*indel_fract: snp:1732 */
     int lo = INT_MAX, hi = 0;
-    dev_mask_lc(B, P, it.read, it.qpos1_kind & 0x1fffffff, (it.qpos1_kind >> 30) & 1, &lo, &hi, overflow);
+    dev_mask_lc(B, P, it.read, it.qpos1_kind & 0x1fffffff, (it.qpos1_kind >> 30) & 1, &lo, &hi, overflow,
+                &win[threadIdx.x & 63]);
     items[t].lo = lo; items[t].hi = hi;
 }
 
@@ -1029,15 +1097,18 @@ __global__ void k_replay(DBatch B, const DParams *P, const uint32_t *colrec, con
  *   - the OR of keep_qual over all the read's columns (snp:1847,1939). */
 struct ColOp { uint8_t v; int T; int keep, b15; };
 
-__device__ __forceinline__ void apply_col(const DParams *P, const DBatch &B, uint32_t rec, int mn2,
-                                          const uint32_t *cig, int nc, int rp, int x, uint8_t capq,
-                                          int base, ColOp &o)
+/* the per-base loop body (snp:1870-1919) for the entry (column c, query index x) */
+__device__ __forceinline__ void apply_col(const DParams *__restrict__ P, const DBatch &B, uint32_t rec, int c,
+                                          const int32_t *__restrict__ pos_mn2, int64_t r, int rp, int x,
+                                          uint8_t capq, int base, ColOp &o)
 {
     if (rec & CR_SKIP) return;
     if (rec & CR_KEEP) o.keep = 1;
     const int preserve = CR_PRESERVE(rec);
-    if (rec & CR_TRIG) {                                   /* snp:1870-1879 */
-        const int start = dev_ref2query_pos(cig, nc, rp, mn2);
+    if (rec & CR_TRIG) {                                   /* snp:1870-1879 (rare) */
+        const uint32_t *cig = B.cigar + B.cig_off[r];
+        const int nc = (int)(B.cig_off[r + 1] - B.cig_off[r]);
+        const int start = dev_ref2query_pos(cig, nc, rp, pos_mn2[c]);
         if (start < o.T) o.T = start;
         if (start <= x) o.v = capq | 0x80;
     }
@@ -1058,27 +1129,38 @@ k_replay_wave(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
     const int lane = threadIdx.x & 63;
     const int64_t r = UNIFORM((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (r >= B.n_reads) return;
-    const int64_t so = B.seq_off[r];
-    const int lq = (int)(B.seq_off[r + 1] - so);
+    const ReadRec rr = B.rr[r];                            /* one 32-byte record per read */
+    const int64_t so = rr.so;
+    const int lq = rr.lq;
     uint8_t *q2 = out + so;
     const uint8_t *qin = B.quals + so;
-    if (!B.inplp[r]) {
+    if (rr.end <= rr.pos) {                                /* never entered the pileup */
         for (int x = lane; x < lq; x += 64) q2[x] = qin[x] & 0x7f;
         if (lane == 0) rflags[r] = 4;
         return;
     }
-    const int rp = B.pos[r], re = B.end[r], mq = B.mapq[r];
-    const Seg *segs = B.segs + B.seg_off[r];
-    const int ns = (int)(B.seg_off[r + 1] - B.seg_off[r]);
-    const uint32_t *cig = B.cigar + B.cig_off[r];
-    const int nc = (int)(B.cig_off[r + 1] - B.cig_off[r]);
-    const uint32_t headrec = colrec[rp - B.p0], tailrec = colrec[re - 1 - B.p0];
-    const Seg s0 = segs[0], sl = segs[ns - 1];
+    const int rp = rr.pos, re = rr.end, mq = (int)(rr.info & 255);
+    const bool simple = (rr.info & RR_SIMPLE) != 0;
+    const bool softclip = P->softclip != 0;
+    const bool lowmq = mq <= P->min_mqual;
+    /* general alignments need the segment table */
+    const Seg *segs = B.segs;
+    int ns = 1;
+    Seg s0, sl;
+    s0.roff = 0; s0.qstart = rr.q0; s0.len_type = (uint32_t)(re - rp); s0.indel_after = 0;
+    sl = s0;
+    if (!simple) {
+        segs = B.segs + B.seg_off[r];
+        ns = (int)(B.seg_off[r + 1] - B.seg_off[r]);
+        s0 = segs[0]; sl = segs[ns - 1];
+    }
+    uint32_t headrec = 0, tailrec = 0;
+    if (lowmq || softclip) { headrec = colrec[rp - B.p0]; tailrec = colrec[re - 1 - B.p0]; }
     const int qpos_head = s0.qstart;
     const int qpos_tail = (seg_type(sl) == SEG_M) ? sl.qstart + seg_len(sl) - 1 : sl.qstart;
-    const bool headmark = (mq <= P->min_mqual) && !(headrec & CR_SKIP);               /* snp:1852 */
-    const bool sc_head = P->softclip && !(headrec & (CR_SKIP | CR_KEEP));             /* snp:1894 */
-    const bool sc_tail = P->softclip && (re - 1 != rp) && !(tailrec & (CR_SKIP | CR_KEEP));
+    const bool headmark = lowmq && !(headrec & CR_SKIP);                               /* snp:1852 */
+    const bool sc_head = softclip && !(headrec & (CR_SKIP | CR_KEEP));                 /* snp:1894 */
+    const bool sc_tail = softclip && (re - 1 != rp) && !(tailrec & (CR_SKIP | CR_KEEP));
     int keep = 0, b15 = 0, carry = INT_MAX;
 
     for (int ch = (lq + 63) / 64 - 1; ch >= 0; ch--) {
@@ -1092,58 +1174,66 @@ k_replay_wave(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
             const int base = B.bases[so + x] & 15;
             o.v = headmark ? (q0 | 0x80) : q0;
             if (sc_head && x < qpos_head) o.v = P->bin2[o.v];
-            /* first segment with qstart >= x */
-            int i;
-            if (ns == 1) i = (s0.qstart >= x) ? 0 : 1;
-            else {
+            if (simple) {
+                const int off = x - rr.q0;
+                if (off >= 0 && off < re - rp) {
+                    const int c = rp + off - B.p0;
+                    apply_col(P, B, colrec[c], c, pos_mn2, r, rp, x, capq, base, o);
+                }
+            } else {
+                /* first segment with qstart >= x */
                 int lo = 0, hi = ns;
                 while (lo < hi) { int mid = (lo + hi) >> 1; if (segs[mid].qstart < x) lo = mid + 1; else hi = mid; }
-                i = lo;
-            }
-            bool own_done = false;
-            while (i < ns && segs[i].qstart == x) {        /* D/N runs that report x, then maybe x's own M op */
-                const Seg sg = segs[i];
-                const int len = seg_len(sg);
-                if (seg_type(sg) == SEG_M) {
-                    const int c = rp + sg.roff - B.p0;
-                    apply_col(P, B, colrec[c], pos_mn2[c], cig, nc, rp, x, capq, base, o);
-                    own_done = true;
-                    break;
+                int i = lo;
+                bool own_done = false;
+                while (i < ns && segs[i].qstart == x) {    /* D/N runs that report x, then maybe x's own M op */
+                    const Seg sg = segs[i];
+                    const int len = seg_len(sg);
+                    if (seg_type(sg) == SEG_M) {
+                        const int c = rp + sg.roff - B.p0;
+                        apply_col(P, B, colrec[c], c, pos_mn2, r, rp, x, capq, base, o);
+                        own_done = true;
+                        break;
+                    }
+                    for (int k = 0; k < len; k++) {
+                        const int c = rp + sg.roff + k - B.p0;
+                        apply_col(P, B, colrec[c], c, pos_mn2, r, rp, x, capq, base, o);
+                    }
+                    i++;
                 }
-                for (int k = 0; k < len; k++) {
-                    const int c = rp + sg.roff + k - B.p0;
-                    apply_col(P, B, colrec[c], pos_mn2[c], cig, nc, rp, x, capq, base, o);
-                }
-                i++;
-            }
-            if (!own_done && i > 0 && i <= ns) {           /* x strictly inside the previous M op? */
-                const Seg sg = segs[i - 1];
-                if (seg_type(sg) == SEG_M && sg.qstart < x && x < sg.qstart + seg_len(sg)) {
-                    const int c = rp + sg.roff + (x - sg.qstart) - B.p0;
-                    apply_col(P, B, colrec[c], pos_mn2[c], cig, nc, rp, x, capq, base, o);
+                if (!own_done && i > 0 && i <= ns) {       /* x strictly inside the previous M op? */
+                    const Seg sg = segs[i - 1];
+                    if (seg_type(sg) == SEG_M && sg.qstart < x && x < sg.qstart + seg_len(sg)) {
+                        const int c = rp + sg.roff + (x - sg.qstart) - B.p0;
+                        apply_col(P, B, colrec[c], c, pos_mn2, r, rp, x, capq, base, o);
+                    }
                 }
             }
             if (sc_tail && x > qpos_tail) o.v = P->bin2[o.v];
         }
-        /* exclusive suffix-min of the back-fill starts over lanes, then over later chunks */
-        int incl = o.T;
-        for (int d = 1; d < 64; d <<= 1) {
-            const int other = __shfl_down(incl, d);
-            if (lane + d < 64 && other < incl) incl = other;
+        /* exclusive suffix-min of the back-fill starts over lanes, then over later chunks;
+         * skipped (wave-uniformly) when this read has met no trigger column so far */
+        int excl = INT_MAX;
+        if (__any(o.T != INT_MAX) || carry != INT_MAX) {
+            int incl = o.T;
+            for (int d = 1; d < 64; d <<= 1) {
+                const int other = __shfl_down(incl, d);
+                if (lane + d < 64 && other < incl) incl = other;
+            }
+            excl = __shfl_down(incl, 1);
+            if (lane == 63) excl = INT_MAX;
+            if (carry < excl) excl = carry;
+            const int first = __shfl(incl, 0);
+            if (first < carry) carry = first;
         }
-        int excl = __shfl_down(incl, 1);
-        if (lane == 63) excl = INT_MAX;
-        if (carry < excl) excl = carry;
         if (active) {
             if (excl <= x) o.v = capq | 0x80;
             q2[x] = o.v & 0x7f;                            /* snp:1093 */
         }
-        const int first = __shfl(incl, 0);
-        if (first < carry) carry = first;
         keep |= o.keep; b15 |= o.b15;
     }
     /* columns that no base owns: D/N ops at the very end of the query (fenced), or l_qseq == 0 */
-    if (lane == 0) {
+    if (lane == 0 && (lq == 0 || !simple)) {
         if (lq == 0) {
             for (int c = rp; c < re; c++) { const uint32_t rec = colrec[c - B.p0]; if (!(rec & CR_SKIP) && (rec & CR_KEEP)) keep = 1; }
         } else {
@@ -1196,29 +1286,58 @@ __global__ void k_pblock(int64_t n_reads, const int64_t *seq_off, uint8_t *out,
 }
 
 /* ------------------------------------------------------------------------ */
-/* Output-quality histogram + changed-byte count (feeds the RCCL all-reduce). */
+/* Output-quality histogram + changed-byte count (feeds the RCCL all-reduce).
+ * 16 bytes per lane per load; the LDS histogram is replicated 32x with the copy
+ * index in the bank bits, so the dominant output values (qhigh, qlow) do not
+ * serialise the LDS atomics. */
+#define HIST_COPIES 32
 __global__ void __launch_bounds__(256)
 k_stats(int64_t n_bases, int64_t n_reads, const uint8_t *out, const uint8_t *in, u64 *stats)
 {
-    __shared__ unsigned int h[257];
-    for (int i = threadIdx.x; i < 257; i += blockDim.x) h[i] = 0;
+    __shared__ unsigned int h[256 * HIST_COPIES];
+    __shared__ unsigned int hchg;
+    for (int i = threadIdx.x; i < 256 * HIST_COPIES; i += blockDim.x) h[i] = 0;
+    if (threadIdx.x == 0) hchg = 0;
     __syncthreads();
+    const int copy = threadIdx.x & (HIST_COPIES - 1);
+    const int64_t nvec = n_bases >> 4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     unsigned int changed = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_bases; i += stride) {
-        const uint8_t o = out[i];
-        atomicAdd(&h[o], 1u);
-        changed += (o != in[i]);
+    const uint4 *o4 = (const uint4 *)out, *i4 = (const uint4 *)in;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const uint4 a = o4[i], b = i4[i];
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            #pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned o = (aw[k] >> (8 * j)) & 255, q = (bw[k] >> (8 * j)) & 255;
+                atomicAdd(&h[o * HIST_COPIES + copy], 1u);
+                changed += (o != q);
+            }
+        }
     }
-    if (changed) atomicAdd(&h[256], changed);
+    /* tail bytes */
+    if (blockIdx.x == 0) {
+        for (int64_t i = (nvec << 4) + threadIdx.x; i < n_bases; i += blockDim.x) {
+            const unsigned o = out[i];
+            atomicAdd(&h[o * HIST_COPIES + copy], 1u);
+            changed += (o != in[i]);
+        }
+    }
+    if (changed) atomicAdd(&hchg, changed);
     __syncthreads();
-    for (int i = threadIdx.x; i < 257; i += blockDim.x) {
-        const unsigned int v = h[i];
-        if (v) atomicAdd(&stats[i < 256 ? ST_HIST0 + i : ST_BASES_CHANGED], (u64)v);
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        unsigned int v = 0;
+        for (int c = 0; c < HIST_COPIES; c++) v += h[i * HIST_COPIES + c];
+        if (v) atomicAdd(&stats[ST_HIST0 + i], (u64)v);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        atomicAdd(&stats[ST_READS], (u64)n_reads);
-        atomicAdd(&stats[ST_BASES], (u64)n_bases);
+    if (threadIdx.x == 0) {
+        if (hchg) atomicAdd(&stats[ST_BASES_CHANGED], (u64)hchg);
+        if (blockIdx.x == 0) {
+            atomicAdd(&stats[ST_READS], (u64)n_reads);
+            atomicAdd(&stats[ST_BASES], (u64)n_bases);
+        }
     }
 }
 

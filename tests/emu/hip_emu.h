@@ -43,6 +43,8 @@ struct dim3 {
     unsigned x, y, z;
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
+struct uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };
 extern thread_local dim3 threadIdx, blockIdx;
 extern dim3 blockDim, gridDim;
 static const int warpSize = 64;
