@@ -1019,74 +1019,10 @@ __global__ void k_window(DBatch B, int n_trig, const int32_t *trigcol_pos, const
 }
 
 /* ------------------------------------------------------------------------ */
-/* Per-read replay of the per-base loop (snp:1822-1920), the keep_qual
- * retirement copy (snp:1939) and the 0x80 strip of flush_bam_list
- * (snp:1093-1096).  One thread per read, columns in order. */
-__global__ void k_replay(DBatch B, const DParams *P, const uint32_t *colrec, const int32_t *pos_mn2,
-                         uint8_t *out, uint8_t *rflags)
-{
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= B.n_reads) return;
-    const int64_t so = B.seq_off[r];
-    const int lq = (int)(B.seq_off[r + 1] - so);
-    uint8_t *q2 = out + so;
-    const uint8_t *qin = B.quals + so;
-    if (!B.inplp[r]) {
-        for (int x = 0; x < lq; x++) q2[x] = qin[x] & 0x7f;
-        rflags[r] = 4;
-        return;
-    }
-    const int rp = B.pos[r], re = B.end[r], mq = B.mapq[r];
-    const Seg *segs = B.segs + B.seg_off[r];
-    const int ns = (int)(B.seg_off[r + 1] - B.seg_off[r]);
-    const uint32_t *cig = B.cigar + B.cig_off[r];
-    const int nc = (int)(B.cig_off[r + 1] - B.cig_off[r]);
-    const int qhigh = P->qhigh, qlow = P->qlow;
-    int keep = 0, b15 = 0, si = 0;
-    for (int x = 0; x < lq; x++) q2[x] = qin[x];
-
-    for (int apos = rp; apos < re; apos++) {
-        const int off = apos - rp;
-        while (si < ns - 1 && off >= segs[si].roff + seg_len(segs[si])) si++;
-        const uint32_t rec = colrec[apos - B.p0];
-        if (rec & CR_SKIP) continue;                  /* `continue` / goto too_deep */
-        Entry e;
-        entry_from_seg(segs[si], off, re - rp, e);
-        if (rec & CR_KEEP) keep = 1;                  /* snp:1847 */
-        if (e.is_head && mq <= P->min_mqual)          /* snp:1852-1859 */
-            for (int x = 0; x < lq; x++) q2[x] |= 0x80;
-        if (!lq || e.qpos >= lq) continue;
-        const int preserve = CR_PRESERVE(rec);
-        const int perfect = (rec & CR_PERFECT) ? 1 : 0;
-        if (rec & CR_TRIG) {                          /* snp:1870-1879 */
-            for (int x = dev_ref2query_pos(cig, nc, rp, pos_mn2[apos - B.p0]); x <= e.qpos; x++)
-                q2[x] = cap_q(P, qin[x]) | 0x80;
-        }
-        uint8_t v = q2[e.qpos];
-        if (rec & CR_WIN) v = cap_q(P, qin[e.qpos]) | 0x80;                  /* snp:1880-1883 */
-        if (preserve || P->preserve_qual[v & 0x7f] >= 1 + perfect) v |= 0x80; /* snp:1885 */
-        if (preserve > 1) b15 = 1;                                           /* snp:1890 */
-        q2[e.qpos] = v;
-        if (!(rec & CR_KEEP) && P->softclip) {                               /* snp:1894-1904 */
-            if (e.is_head) { for (int x = 1; x <= e.qpos; x++) q2[e.qpos - x] = P->bin2[q2[e.qpos - x]]; }
-            else if (e.is_tail) { for (int x = lq - e.qpos - 1; x > 0; x--) q2[e.qpos + x] = P->bin2[q2[e.qpos + x]]; }
-        }
-        if (!(v & 0x80)) {                                                   /* snp:1906-1919 */
-            const int base = B.bases[so + e.qpos] & 15;
-            const int c1 = 1 << CR_A1(rec), c2 = 1 << CR_A2(rec);
-            if (base == c1 || base == c2) v = (uint8_t)qhigh;
-            else if (P->reduce_qual) v = P->binary_qual ? P->bin2[v] : (uint8_t)qlow;
-            q2[e.qpos] = v;
-        }
-    }
-    if (keep) for (int x = 0; x < lq; x++) q2[x] = cap_q(P, qin[x]);         /* snp:1939 */
-    for (int x = 0; x < lq; x++) q2[x] &= 0x7f;                              /* snp:1093 */
-    rflags[r] = (uint8_t)((keep ? 1 : 0) | (b15 ? 2 : 0));
-}
-
-/* ------------------------------------------------------------------------ */
-/* k_replay_wave: the same replay with one wavefront per read and one lane per
- * base (coalesced byte traffic).  Exact because the final value of quality
+/* k_replay_wave: per-read replay of the per-base loop (snp:1822-1920), the
+ * keep_qual retirement copy (snp:1939) and the 0x80 strip of flush_bam_list
+ * (snp:1093-1096), with one wavefront per read and one lane per base
+ * (coalesced byte traffic).  Exact because the final value of quality
  * byte x only depends on (DESIGN.md "replay"):
  *   - the is_head low-mapq mark (snp:1852),
  *   - the columns whose pileup entry has qpos == x, in order: the D/N columns
@@ -1100,7 +1036,7 @@ struct ColOp { uint8_t v; int T; int keep, b15; };
 /* the per-base loop body (snp:1870-1919) for the entry (column c, query index x) */
 __device__ __forceinline__ void apply_col(const DParams *__restrict__ P, const DBatch &B, uint32_t rec, int c,
                                           const int32_t *__restrict__ pos_mn2, int64_t r, int rp, int x,
-                                          uint8_t capq, int base, ColOp &o)
+                                          uint8_t capq, int base, ColOp &o, bool head_apart)
 {
     if (rec & CR_SKIP) return;
     if (rec & CR_KEEP) o.keep = 1;
@@ -1109,7 +1045,9 @@ __device__ __forceinline__ void apply_col(const DParams *__restrict__ P, const D
         const uint32_t *cig = B.cigar + B.cig_off[r];
         const int nc = (int)(B.cig_off[r + 1] - B.cig_off[r]);
         const int start = dev_ref2query_pos(cig, nc, rp, pos_mn2[c]);
-        if (start < o.T) o.T = start;
+        /* with -S the head column's back-fill precedes its soft-clip binning (snp:1875 then
+         * 1895), so it is applied apart from the suffix-min of the later columns */
+        if (start < o.T && !(head_apart && c == rp - B.p0)) o.T = start;
         if (start <= x) o.v = capq | 0x80;
     }
     if (rec & CR_WIN) o.v = capq | 0x80;                   /* snp:1880-1883 */
@@ -1161,7 +1099,11 @@ k_replay_wave(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
     const bool headmark = lowmq && !(headrec & CR_SKIP);                               /* snp:1852 */
     const bool sc_head = softclip && !(headrec & (CR_SKIP | CR_KEEP));                 /* snp:1894 */
     const bool sc_tail = softclip && (re - 1 != rp) && !(tailrec & (CR_SKIP | CR_KEEP));
-    int keep = 0, b15 = 0, carry = INT_MAX;
+    int keep = 0, b15 = 0, carry = INT_MAX, headT = INT_MAX;
+    if (softclip && (headrec & CR_TRIG) && !(headrec & CR_SKIP)) {
+        const uint32_t *cig = B.cigar + B.cig_off[r];
+        headT = dev_ref2query_pos(cig, (int)(B.cig_off[r + 1] - B.cig_off[r]), rp, pos_mn2[rp - B.p0]);
+    }
 
     for (int ch = (lq + 63) / 64 - 1; ch >= 0; ch--) {
         const int x = ch * 64 + lane;
@@ -1173,12 +1115,15 @@ k_replay_wave(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
             capq = cap_q(P, q0);
             const int base = B.bases[so + x] & 15;
             o.v = headmark ? (q0 | 0x80) : q0;
-            if (sc_head && x < qpos_head) o.v = P->bin2[o.v];
+            if (x < qpos_head) {                           /* head column: back-fill, then -S binning */
+                if (headT <= x) o.v = capq | 0x80;
+                if (sc_head) o.v = P->bin2[o.v];
+            }
             if (simple) {
                 const int off = x - rr.q0;
                 if (off >= 0 && off < re - rp) {
                     const int c = rp + off - B.p0;
-                    apply_col(P, B, colrec[c], c, pos_mn2, r, rp, x, capq, base, o);
+                    apply_col(P, B, colrec[c], c, pos_mn2, r, rp, x, capq, base, o, softclip);
                 }
             } else {
                 /* first segment with qstart >= x */
@@ -1191,13 +1136,13 @@ k_replay_wave(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
                     const int len = seg_len(sg);
                     if (seg_type(sg) == SEG_M) {
                         const int c = rp + sg.roff - B.p0;
-                        apply_col(P, B, colrec[c], c, pos_mn2, r, rp, x, capq, base, o);
+                        apply_col(P, B, colrec[c], c, pos_mn2, r, rp, x, capq, base, o, softclip);
                         own_done = true;
                         break;
                     }
                     for (int k = 0; k < len; k++) {
                         const int c = rp + sg.roff + k - B.p0;
-                        apply_col(P, B, colrec[c], c, pos_mn2, r, rp, x, capq, base, o);
+                        apply_col(P, B, colrec[c], c, pos_mn2, r, rp, x, capq, base, o, softclip);
                     }
                     i++;
                 }
@@ -1205,7 +1150,7 @@ k_replay_wave(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
                     const Seg sg = segs[i - 1];
                     if (seg_type(sg) == SEG_M && sg.qstart < x && x < sg.qstart + seg_len(sg)) {
                         const int c = rp + sg.roff + (x - sg.qstart) - B.p0;
-                        apply_col(P, B, colrec[c], c, pos_mn2, r, rp, x, capq, base, o);
+                        apply_col(P, B, colrec[c], c, pos_mn2, r, rp, x, capq, base, o, softclip);
                     }
                 }
             }

@@ -36,3 +36,24 @@ def assert_parity(make_engine, params, hb, check_columns=True):
     finally:
         eng.close()
     return q, f, s
+
+
+def cigar_zoo(cases, reps=60, seed=7):
+    """Overlapping reads over a zoo of CIGAR shapes, random mapq/flags/quals, keep-BED."""
+    from crumble_amd import HostBatch
+    rng = np.random.default_rng(seed)
+    reads = []
+    pos = 1000
+    for rep in range(reps):
+        for cg in cases:
+            ops = ca.parse_cigar(cg)
+            lq = int(sum(int(o >> 4) for o in ops if (int(o) & 15) in (0, 1, 4, 7, 8)))
+            seq = "".join("ACGTN"[i] for i in rng.choice(5, lq, p=[.3, .2, .2, .28, .02]))
+            reads.append(dict(pos=pos, cigar=cg, seq=seq, qual=rng.integers(2, 42, lq).astype(np.uint8),
+                              mapq=int(rng.choice([0, 3, 20, 60, 255])),
+                              flag=int(rng.choice([0, 16, 1024, 4], p=[.6, .3, .05, .05]))))
+            pos += int(rng.integers(0, 3))
+    # zero-length SEQ read and a read ending in a deletion (fenced paths)
+    reads.append(dict(pos=pos, cigar="10M", seq="", qual=np.zeros(0, np.uint8)))
+    reads.append(dict(pos=pos, cigar="6M2D", seq="ACGTAC", qual=30))
+    return HostBatch.from_reads(reads, bed=[(1010, 1030), (1100, 1101)])

@@ -7,7 +7,7 @@ import pytest
 import crumble_amd as ca
 from crumble_amd import HostBatch
 import oracle_lib as O
-from parity_util import assert_parity, synth_batch
+from parity_util import assert_parity, synth_batch, cigar_zoo
 
 pytestmark = pytest.mark.gpu
 
@@ -81,3 +81,33 @@ def test_fp64_sqrt_div_match_host(product):
     hb = synth_batch("chr20", 0.002)
     p = ca.preset_params(5, min_discrep_B=0.05)     # make the comparison bite often
     assert_parity(gpu_engine, p, hb)
+
+
+@pytest.mark.parametrize("level", [1, 5, 9])
+def test_cigar_zoo(product, level):
+    from test_pileup_cases import CASES
+    hb = cigar_zoo(CASES)
+    assert_parity(gpu_engine, ca.preset_params(level), hb)
+    assert_parity(gpu_engine, ca.preset_params(level, keep="30-33", softclip=1), hb)
+    assert_parity(gpu_engine, ca.preset_params(level, softclip=1, min_mqual=20, indel_fract=0.1), hb)
+
+
+def test_large_properties(product):
+    """Size-independent properties at a larger size than the oracle comparison:
+    idempotent re-run, histogram total == bases, passthrough reads untouched at -5,
+    every output quality is one of {qlow, qhigh} or an (optionally capped) input value."""
+    hb = synth_batch("chr20", 0.1)
+    p = ca.preset_params(5)
+    eng = gpu_engine(p)
+    q, f, s = eng.contig(hb)
+    q2, f2, s2 = eng.contig(hb)
+    assert np.array_equal(q, q2) and np.array_equal(f, f2) and np.array_equal(s, s2)
+    assert s[ca.ST_HIST0:].sum() == hb.n_bases == s[ca.ST_NAMES.index("bases")]
+    changed = q != hb.quals
+    assert np.isin(q[changed], [p.qlow, p.qhigh, p.qcap]).all()
+    pt = np.nonzero(f & ca.RF_PASSTHRU)[0]
+    assert len(pt) > 0
+    for r in pt[:200]:
+        a, b = hb.seq_off[r], hb.seq_off[r + 1]
+        assert np.array_equal(q[a:b], hb.quals[a:b])
+    eng.close()
