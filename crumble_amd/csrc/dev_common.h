@@ -69,7 +69,24 @@ struct ReadRec {
     int32_t  lq;            /* l_qseq */
     int32_t  q0;            /* query index of the first aligned base */
     uint32_t info;          /* mapq | RR_SIMPLE */
-    uint32_t pad;
+    uint32_t cix;           /* general CIGARs: first entry of this read in the base->column table */
+};
+
+/* One reference-consuming CIGAR op of one read, self-contained, in file order: the unit
+ * the column kernel iterates over (a read with k such ops contributes k consecutive
+ * records, so every record is "one op covering [pos,end)" and the kernel has one path). */
+#define SR_TYPE(i)     (((i) >> 8) & 3u)     /* SEG_M / SEG_D / SEG_N            */
+#define SR_FIRST       (1u << 10)            /* contains the read's first column */
+#define SR_LAST        (1u << 11)            /* contains the read's last column  */
+#define SR_HEADCLIP    (1u << 12)            /* qpos > 0 on the head column      (snp:1701) */
+#define SR_TAILCLIP    (1u << 13)            /* qpos+1 < l_qseq on the tail column (snp:1702) */
+struct SegRec {
+    int32_t  pos, end;      /* reference span of this op                                   */
+    int64_t  so;            /* seq_off of the read                                         */
+    int32_t  lq;            /* l_qseq                                                      */
+    int32_t  qoff;          /* M: qpos = qoff + apos;  D/N: qpos = qoff (the next base)    */
+    int32_t  indel_after;   /* bam_pileup1_t.indel on the op's last column                 */
+    uint32_t info;          /* mapq | type << 8 | SR_* flags                               */
 };
 
 /* Device-resident batch. Positions are stored relative to p0. */
@@ -85,6 +102,9 @@ struct DBatch {
     const uint32_t *cigar;
     const Seg *segs;
     const ReadRec *rr;
+    const int32_t *cix;     /* per base of every non-simple read: column (pos-p0), -1 none, -2 general routine */
+    const SegRec *sr;
+    const int32_t *stile_lo, *stile_hi;   /* candidate SegRec range per 64-column tile */
     const uint8_t *bases, *quals;
     const int32_t *tile_lo, *tile_hi;
     const int32_t *bed_start, *bed_end, *bed_pmax;

@@ -55,7 +55,7 @@ struct crumble_hip {
     DParams hparams;
     DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc;
     /* batch (inputs) */
-    DevBuf d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
+    DevBuf d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
            d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax;
     /* per position */
     DevBuf d_colrec, d_nplp, d_score, d_trigcnt, d_dpre, d_col_ord, d_trig_ord, d_item_off,
@@ -63,11 +63,11 @@ struct crumble_hip {
     /* work lists */
     DevBuf d_trigcol_pos, d_trigcol_off, d_inscol_pos, d_items, d_colhi, d_ub, d_pmax_partial, d_trig_mx2;
     /* outputs */
-    DevBuf d_out, d_rflags;
+    DevBuf d_out, d_rflags, d_keepf, d_b15f, d_blk_read;
     DBatch B;
     bool have_batch = false, have_run = false;
     unsigned persistent_blocks = 1024;
-    int64_t n_reads = 0, n_bases = 0, n_cigar = 0;
+    int64_t n_reads = 0, n_bases = 0, n_cigar = 0, n_slow = 0;
     ScanVal totals;
     /* timing */
     hipEvent_t ev[MAX_STAGES + 1];
@@ -221,13 +221,13 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     DevBuf *all[] = { &h->d_params, &h->d_tables, &h->d_stats, &h->d_batch_stats, &h->d_misc,
-        &h->d_rr, &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
+        &h->d_slow_g, &h->d_slow_r, &h->d_cix, &h->d_sr, &h->d_stile_lo, &h->d_stile_hi, &h->d_rr, &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
         &h->d_cigar, &h->d_segs, &h->d_bases, &h->d_quals, &h->d_tile_lo, &h->d_tile_hi,
         &h->d_bed_start, &h->d_bed_end, &h->d_bed_pmax, &h->d_colrec, &h->d_nplp, &h->d_score,
         &h->d_trigcnt, &h->d_dpre, &h->d_col_ord, &h->d_trig_ord, &h->d_item_off, &h->d_ins_ord,
         &h->d_pos_mn2, &h->d_partial, &h->d_epochs, &h->d_trigcol_pos, &h->d_trigcol_off,
         &h->d_inscol_pos, &h->d_items, &h->d_colhi, &h->d_ub, &h->d_pmax_partial, &h->d_trig_mx2,
-        &h->d_out, &h->d_rflags };
+        &h->d_out, &h->d_rflags, &h->d_keepf, &h->d_b15f, &h->d_blk_read };
     for (DevBuf *b : all) b->release();
     if (h->events_ok) for (int i = 0; i <= MAX_STAGES; i++) (void)hipEventDestroy(h->ev[i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -332,7 +332,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
         x.lq = (int32_t)(b->seq_off[r + 1] - b->seq_off[r]);
         x.q0 = ns ? segs[(size_t)seg_off[r]].qstart : 0;
         x.info = b->mapq[r];
-        x.pad = 0;
+        x.cix = 0;
         if (inplp[r] && ns == 1 && x.lq > 0) {
             const Seg &s0 = segs[(size_t)seg_off[r]];
             if (seg_type(s0) == SEG_M && s0.indel_after == 0) x.info |= RR_SIMPLE;
@@ -358,13 +358,87 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
             tile_lo[t] = (int32_t)lo; tile_hi[t] = (int32_t)hi;
         }
     }
+    /* SegRec list (file order) and its candidate range per tile */
+    std::vector<SegRec> sr;
+    std::vector<int32_t> sr_ppos, sr_pend;            /* parent read's span, for the ranges */
+    sr.reserve(segs.size() + 1); sr_ppos.reserve(segs.size() + 1); sr_pend.reserve(segs.size() + 1);
+    for (int64_t r = 0; r < n; r++) {
+        if (!inplp[r]) continue;
+        const int64_t s0i = seg_off[r], s1i = seg_off[r + 1];
+        const int32_t lq = (int32_t)(b->seq_off[r + 1] - b->seq_off[r]);
+        for (int64_t k = s0i; k < s1i; k++) {
+            const Seg &sg = segs[(size_t)k];
+            SegRec x;
+            const uint32_t ty = seg_type(sg);
+            x.pos = b->pos[r] + sg.roff; x.end = x.pos + seg_len(sg);
+            x.so = b->seq_off[r]; x.lq = lq;
+            x.qoff = (ty == SEG_M) ? sg.qstart - x.pos : sg.qstart;
+            x.indel_after = sg.indel_after;
+            x.info = (uint32_t)b->mapq[r] | (ty << 8);
+            if (k == s0i) { x.info |= SR_FIRST; if (sg.qstart > 0) x.info |= SR_HEADCLIP; }
+            if (k == s1i - 1) {
+                const int qt = (ty == SEG_M) ? sg.qstart + seg_len(sg) - 1 : sg.qstart;
+                x.info |= SR_LAST;
+                if (qt + 1 < lq) x.info |= SR_TAILCLIP;
+            }
+            sr.push_back(x); sr_ppos.push_back(b->pos[r]); sr_pend.push_back(end[r]);
+        }
+    }
+    /* base -> column table for reads with general CIGARs (the replay's lane-per-base pass) */
+    std::vector<int32_t> cix;
+    std::vector<int64_t> slow_g;
+    std::vector<int32_t> slow_r;
+    for (int64_t r = 0; r < n; r++) {
+        if (!inplp[r] || (rr[r].info & RR_SIMPLE)) continue;
+        if (cix.size() + (size_t)rr[r].lq >= 0xfffffff0u) { g_last_error = "base->column table too large"; return CRUMBLE_EINVAL; }
+        rr[r].cix = (uint32_t)cix.size();
+        const size_t base0 = cix.size();
+        cix.resize(base0 + (size_t)rr[r].lq, -1);
+        for (int64_t k = seg_off[r]; k < seg_off[r + 1]; k++) {
+            const Seg &sg = segs[(size_t)k];
+            if (seg_type(sg) != SEG_M) continue;
+            for (int o = 0; o < seg_len(sg) && sg.qstart + o < rr[r].lq; o++)
+                cix[base0 + (size_t)(sg.qstart + o)] = (b->pos[r] + sg.roff + o) - p0;
+        }
+        for (int64_t k = seg_off[r]; k < seg_off[r + 1]; k++) {     /* bases that D/N columns report */
+            const Seg &sg = segs[(size_t)k];
+            if (seg_type(sg) != SEG_M && sg.qstart < rr[r].lq && cix[base0 + (size_t)sg.qstart] != -2) {
+                cix[base0 + (size_t)sg.qstart] = -2;
+                slow_g.push_back(b->seq_off[r] + sg.qstart); slow_r.push_back((int32_t)r);
+            }
+        }
+    }
+    /* first read whose bases reach into each 64-base block of the flat base array */
+    std::vector<int32_t> blk_read((size_t)(nb / 64 + 2));
+    {
+        int64_t r = 0;
+        for (int64_t blk = 0; blk * 64 < nb; blk++) {
+            const int64_t g0 = blk * 64;
+            while (r + 1 < n && b->seq_off[r + 1] <= g0) r++;
+            blk_read[(size_t)blk] = (int32_t)r;
+        }
+    }
+    if (sr.size() >= (size_t)INT_MAX - 64) { g_last_error = "too many CIGAR segments in one batch"; return CRUMBLE_EINVAL; }
+    std::vector<int32_t> stile_lo(B.n_tiles + 1), stile_hi(B.n_tiles + 1);
+    {
+        size_t lo = 0, hi = 0, ns = sr.size();
+        for (int t = 0; t < B.n_tiles; t++) {
+            const int64_t c0 = (int64_t)p0 + (int64_t)t * 64, c1 = c0 + 63;
+            while (hi < ns && sr_ppos[hi] <= c1) hi++;
+            while (lo < hi && sr_pend[lo] <= c0) lo++;
+            stile_lo[t] = (int32_t)lo; stile_hi[t] = (int32_t)hi;
+        }
+    }
     /* keep-regions: prefix max of `end` drives the cursor emulation */
     std::vector<int32_t> pmax(b->n_bed > 0 ? b->n_bed : 1);
     for (int i = 0; i < b->n_bed; i++) pmax[i] = (i && pmax[i - 1] > b->bed_end[i]) ? pmax[i - 1] : b->bed_end[i];
     B.n_bed = b->n_bed > 0 ? b->n_bed : 0;
 
     int e;
-    if ((e = up(h, h->d_rr, rr.data(), n)) || (e = up(h, h->d_pos, b->pos, n)) || (e = up(h, h->d_end, end.data(), n)) ||
+    h->n_slow = (int64_t)slow_g.size();
+    if ((e = up(h, h->d_slow_g, slow_g.data(), slow_g.size())) || (e = up(h, h->d_slow_r, slow_r.data(), slow_r.size())) ||
+        (e = up(h, h->d_cix, cix.data(), cix.size())) || (e = up(h, h->d_blk_read, blk_read.data(), (size_t)(nb / 64 + 1))) || (e = up(h, h->d_sr, sr.data(), sr.size())) || (e = up(h, h->d_stile_lo, stile_lo.data(), B.n_tiles)) ||
+        (e = up(h, h->d_stile_hi, stile_hi.data(), B.n_tiles)) || (e = up(h, h->d_rr, rr.data(), n)) || (e = up(h, h->d_pos, b->pos, n)) || (e = up(h, h->d_end, end.data(), n)) ||
         (e = up(h, h->d_mapq, b->mapq, n)) || (e = up(h, h->d_inplp, inplp.data(), n)) ||
         (e = up(h, h->d_seq_off, b->seq_off, n + 1)) || (e = up(h, h->d_cig_off, b->cig_off, n + 1)) ||
         (e = up(h, h->d_seg_off, seg_off.data(), n + 1)) || (e = up(h, h->d_cigar, b->cigar, nc)) ||
@@ -379,7 +453,8 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     B.mapq = h->d_mapq.as<uint8_t>(); B.inplp = h->d_inplp.as<uint8_t>();
     B.seq_off = h->d_seq_off.as<int64_t>(); B.cig_off = h->d_cig_off.as<int64_t>();
     B.seg_off = h->d_seg_off.as<int64_t>(); B.cigar = h->d_cigar.as<uint32_t>();
-    B.segs = h->d_segs.as<Seg>(); B.rr = h->d_rr.as<ReadRec>(); B.bases = h->d_bases.as<uint8_t>(); B.quals = h->d_quals.as<uint8_t>();
+    B.segs = h->d_segs.as<Seg>(); B.rr = h->d_rr.as<ReadRec>(); B.cix = h->d_cix.as<int32_t>();
+    B.sr = h->d_sr.as<SegRec>(); B.stile_lo = h->d_stile_lo.as<int32_t>(); B.stile_hi = h->d_stile_hi.as<int32_t>(); B.bases = h->d_bases.as<uint8_t>(); B.quals = h->d_quals.as<uint8_t>();
     B.tile_lo = h->d_tile_lo.as<int32_t>(); B.tile_hi = h->d_tile_hi.as<int32_t>();
     B.bed_start = h->d_bed_start.as<int32_t>(); B.bed_end = h->d_bed_end.as<int32_t>();
     B.bed_pmax = h->d_bed_pmax.as<int32_t>();
@@ -392,7 +467,8 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
         (e = h->d_trig_ord.reserve(L * 4)) || (e = h->d_item_off.reserve(L * 4)) || (e = h->d_ins_ord.reserve(L * 4)) ||
         (e = h->d_pos_mn2.reserve(L * 4)) || (e = h->d_partial.reserve((size_t)(nchunks + 2) * sizeof(ScanVal))) ||
         (e = h->d_epochs.reserve(MAX_EPOCHS * sizeof(Epoch))) ||
-        (e = h->d_out.reserve((size_t)(nb ? nb : 1))) || (e = h->d_rflags.reserve((size_t)(n ? n : 1))))
+        (e = h->d_out.reserve((size_t)(nb ? nb : 1))) || (e = h->d_rflags.reserve((size_t)(n ? n : 1))) ||
+        (e = h->d_keepf.reserve((size_t)(n ? n : 1))) || (e = h->d_b15f.reserve((size_t)(n ? n : 1))))
         return e;
     h->have_batch = true;
     return CRUMBLE_OK;
@@ -493,8 +569,26 @@ extern "C" int crumble_hip_run(crumble_hip *h)
     }
     if (n > 0) {
         STAGE("k_replay", 3.0 * nb);
-        CRUMBLE_LAUNCH(k_replay_wave, nblk(n, 4), 256, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
-                       h->d_out.as<uint8_t>(), h->d_rflags.as<uint8_t>());
+        HIPCHK(hipMemsetAsync(h->d_keepf.p, 0, (size_t)n, st));
+        HIPCHK(hipMemsetAsync(h->d_b15f.p, 0, (size_t)n, st));
+        if (nb > 0 && h->hparams.softclip)
+            CRUMBLE_LAUNCH_INDEP(k_replay_general, nblk(nb, 256), 256, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
+                                 h->d_blk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(),
+                                 h->d_b15f.as<uint8_t>());
+        else if (nb > 0) {
+            CRUMBLE_LAUNCH_INDEP(k_replay_flat, nblk((nb + 7) / 8, 256), 256, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
+                                 h->d_blk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(),
+                                 h->d_b15f.as<uint8_t>());
+            if (h->n_slow > 0)
+                CRUMBLE_LAUNCH_INDEP(k_replay_slow, nblk(h->n_slow, 64), 64, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
+                                     h->n_slow, h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(),
+                                     h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(), h->d_b15f.as<uint8_t>());
+        }
+        if (L > 0 && h->totals.trigcols > 0)
+            CRUMBLE_LAUNCH_INDEP(k_restore, nblk(h->totals.trigcols, 64), 64, st, B, P, h->totals.trigcols,
+                                 h->d_trigcol_pos.as<int32_t>(), h->d_pos_mn2.as<int32_t>(), h->d_out.as<uint8_t>());
+        CRUMBLE_LAUNCH_INDEP(k_readfix, nblk(n, 256), 256, st, B, P, colrec, h->d_keepf.as<uint8_t>(),
+                             h->d_b15f.as<uint8_t>(), h->d_out.as<uint8_t>(), h->d_rflags.as<uint8_t>());
         if (h->hparams.pblock) {
             STAGE("k_pblock", 2.0 * nb);
             CRUMBLE_LAUNCH_INDEP(k_pblock, nblk(n, 64), 64, st, n, B.seq_off, h->d_out.as<uint8_t>(),

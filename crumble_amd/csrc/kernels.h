@@ -32,6 +32,9 @@
 #include <float.h>
 #include <math.h>
 
+#ifndef CRUMBLE_ABL
+#define CRUMBLE_ABL 0
+#endif
 #ifdef CRUMBLE_EMU
 #define UNIFORM(x) (x)
 #else
@@ -379,7 +382,7 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
         const int c = tile * 64 + lane;
         const int apos = B.p0 + c;
         const bool inr = c < B.L;
-        const int lo = UNIFORM(B.tile_lo[tile]), hi = UNIFORM(B.tile_hi[tile]);
+        const int lo = UNIFORM(B.stile_lo[tile]), hi = UNIFORM(B.stile_hi[tile]);
 
         ColState st;
         #pragma unroll
@@ -390,122 +393,113 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
         st.clipped = st.n_overlap = st.n_isindel = st.has_ins = 0;
         st.cp = 0;
 
-        for (int b0 = lo; b0 < hi; b0 += 64) {
-            const int cnt = (hi - b0 < 64) ? hi - b0 : 64;
-            /* lane i holds the record of candidate read b0+i */
-            int m_pos = 0, m_end = INT_MIN, m_solo = 0, m_sohi = 0, m_lq = 0, m_q0 = 0, m_info = 0;
-            if (lane < cnt) {
-                const ReadRec rr = B.rr[b0 + lane];
-                m_pos = rr.pos; m_end = rr.end; m_solo = (int)(uint32_t)(rr.so & 0xffffffff);
-                m_sohi = (int)(rr.so >> 32); m_lq = rr.lq; m_q0 = rr.q0; m_info = (int)rr.info;
+        const int c0 = B.p0 + tile * 64, c1 = c0 + 63;
+        int n_ht = 0;                                    /* entries that are is_head or is_tail */
+        for (int j = lo; j < hi; j += 4) {
+            /* four candidate records (one reference-consuming CIGAR op of one read each);
+             * the index is wave-uniform, so these are scalar loads (s_load_dwordx8) */
+            SegRec R[4];
+            #pragma unroll
+            for (int u = 0; u < 4; u++) R[u] = B.sr[(j + u < hi) ? j + u : j];
+            /* phase A: the byte loads of the four records go out together
+             * (lanes that need no byte read byte 0: no branch between the loads) */
+            uint8_t cc[4], qq[4];
+            #pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const unsigned ty = SR_TYPE(R[u].info);
+                const int qp = (ty == SEG_M) ? R[u].qoff + apos : R[u].qoff;
+                const bool cv = inr && apos >= R[u].pos && apos < R[u].end && qp < R[u].lq && ty != SEG_N;
+                const int64_t a = cv ? R[u].so + qp : 0;
+                cc[u] = B.bases[a]; qq[u] = B.quals[a];
             }
-            for (int j = 0; j < cnt; j += 4) {
-                /* phase A: the byte loads of up to four simple reads go out together
-                 * (uncovered lanes read byte 0: no branch between the loads) */
-                uint8_t cc[4], qq[4];
-                #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int l = (j + u < cnt) ? j + u : j;
-                    const int rp = READLANE(m_pos, l), re = READLANE(m_end, l);
-                    const int q0 = READLANE(m_q0, l), info = READLANE(m_info, l);
-                    const int64_t so = (int64_t)(((uint64_t)(uint32_t)READLANE(m_sohi, l) << 32) | (uint32_t)READLANE(m_solo, l));
-                    const bool cv = (info & RR_SIMPLE) && inr && apos >= rp && apos < re;
-                    const int64_t a = cv ? so + q0 + (apos - rp) : 0;
-                    cc[u] = B.bases[a]; qq[u] = B.quals[a];
+            /* phase B: accumulate in file order.  Everything that depends only on the record
+             * is wave-uniform (scalar), so the rare cases cost a scalar branch, not vector work. */
+            #pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (j + u >= hi) break;
+                const int rp = R[u].pos, re = R[u].end, lq = R[u].lq;
+                const unsigned info = R[u].info, ty = SR_TYPE(info);
+                const int mq = (int)(info & 255);
+                const bool cov = inr && apos >= rp && apos < re;
+                const bool isM = ty == SEG_M, isN = ty == SEG_N;               /* uniform */
+                st.n_plp += cov ? 1 : 0;
+                if (mq <= min_mqual) st.low_mq += cov ? 1 : 0;                 /* snp:1663 */
+                if (!isM || R[u].indel_after != 0) {                           /* indel bookkeeping: rare ops */
+                    const int e_indel = (apos == re - 1) ? R[u].indel_after : 0;
+                    const bool isind = (e_indel != 0) || !isM;
+                    const bool head = (info & SR_FIRST) && apos == rp, tail = (info & SR_LAST) && apos == re - 1;
+                    st.indel_cnt += (cov && isind) ? 1 : 0;                    /* snp:1664 */
+                    st.nref += (cov && isN) ? 1 : 0;                           /* snp:1468 */
+                    st.n_isindel += (cov && !isN && isind) ? 1 : 0;
+                    st.has_ins |= (cov && !isN && !head && !tail && e_indel > 0) ? 1 : 0;   /* snp:1708 */
                 }
-                const uint32_t pkc = (uint32_t)(cc[0] & 15) | ((uint32_t)(cc[1] & 15) << 8) | ((uint32_t)(cc[2] & 15) << 16) | ((uint32_t)(cc[3] & 15) << 24);
-                const uint32_t pkq = (uint32_t)qq[0] | ((uint32_t)qq[1] << 8) | ((uint32_t)qq[2] << 16) | ((uint32_t)qq[3] << 24);
-                /* phase B: accumulate in file order */
-                #pragma unroll 1
-                for (int u = 0; u < 4; u++) {
-                    const int l = j + u;
-                    if (l >= cnt) break;
-                    const int rp = READLANE(m_pos, l), re = READLANE(m_end, l), lq = READLANE(m_lq, l);
-                    const int q0 = READLANE(m_q0, l), info = READLANE(m_info, l);
-                    const int64_t so = (int64_t)(((uint64_t)(uint32_t)READLANE(m_sohi, l) << 32) | (uint32_t)READLANE(m_solo, l));
-                    const bool cov = inr && apos >= rp && apos < re;
-                    const int mq = info & 255;
-                    /* the pileup entry of this read on this column (bam_pileup1_t fields) */
-                    int e_qpos = q0 + (apos - rp), e_indel = 0;
-                    bool e_del = false, e_refskip = false;
-                    int code = (int)((pkc >> (8 * u)) & 15);
-                    int q = (int)((pkq >> (8 * u)) & 255);
-                    if (!(info & RR_SIMPLE)) {                      /* general CIGARs (wave-uniform branch) */
-                        code = 0; q = 0;
-                        if (cov) {
-                            const int r = b0 + l;
-                            const int64_t sgo = B.seg_off[r];
-                            const int ns = (int)(B.seg_off[r + 1] - sgo);
-                            const int off = apos - rp;
-                            const int si = seg_find(B.segs + sgo, ns, off);
-                            Entry e;
-                            entry_from_seg(B.segs[sgo + si], off, re - rp, e);
-                            e_qpos = e.qpos; e_indel = e.indel; e_del = e.is_del; e_refskip = e.is_refskip;
-                            if (e.qpos < lq && !e.is_refskip) { code = B.bases[so + e.qpos] & 15; q = B.quals[so + e.qpos]; }
+                if (((info & SR_FIRST) && rp >= c0) || ((info & SR_LAST) && re - 1 <= c1)) {   /* head/tail in this tile */
+                    const bool head = (info & SR_FIRST) && apos == rp, tail = (info & SR_LAST) && apos == re - 1;
+                    const bool act = cov && !isN;
+                    n_ht += (act && (head || tail)) ? 1 : 0;                   /* snp:1705 */
+                    st.clipped += (act && ((head && (info & SR_HEADCLIP)) || (tail && (info & SR_TAILCLIP)))) ? 1 : 0;   /* snp:1701 */
+                }
+                if (isN || lq == 0 || !use_cons) continue;                     /* snp:589,594 (uniform) */
+                /* consensus accumulation: branch-free over lanes; lanes that the record does not
+                 * cover add +0.0, which is exact, so each genotype sum sees its own addends in
+                 * file order (snp:656-683) and the 20 running sums never leave their registers */
+                const int e_qpos = isM ? R[u].qoff + apos : R[u].qoff;
+                const bool inq = e_qpos < lq;                                  /* fence: read ends in D/N */
+                int q = inq ? (int)qq[u] : 0;
+                if (any_pres) q = (q > qcap && !P->preserve_qual[q]) ? qcap : q;   /* cap_quality snp:1325 */
+                else          q = q > qcap ? qcap : q;
+                const int code = inq ? (cc[u] & 15) : 15;
+                if (any_pres && cov) {                                         /* snp:611-623 */
+                    const int b = !isM ? 4 : (code == 1) ? 0 : (code == 2) ? 1 : (code == 4) ? 2 : (code == 8) ? 3 : 5;
+                    const int e_indel = (apos == re - 1) ? R[u].indel_after : 0;
+                    const uint8_t pv = P->preserve_qual[q];
+                    if (pv) st.cp |= 1u << b;
+                    if (pv > 1) st.cp |= (1u << b) << 8;
+                    if (e_indel > 0)
+                        for (int ins = 0; ins < e_indel; ins++) {
+                            const int qi = e_qpos + 1 + ins;
+                            if (qi < lq && P->preserve_qual[cap_q(P, B.quals[R[u].so + qi])]) st.cp |= 1u << 4;
                         }
-                    }
-                    /* One branch-free accumulate for every kind of entry: lanes that the read
-                     * does not cover (or that must not count) add +0.0, which is exact, so each
-                     * genotype sum sees its own addends in file order (snp:656-683) and the 20
-                     * running sums never leave their registers. */
-                    const bool head = (apos == rp), tail = (apos == re - 1);
-                    const bool isind = (e_indel != 0) || e_del;
-                    const bool act = cov && !e_refskip;             /* snp:589, snp:1696 */
-                    st.n_plp += cov ? 1 : 0;
-                    st.low_mq += (cov && mq <= min_mqual) ? 1 : 0;  /* snp:1663 */
-                    st.indel_cnt += (cov && isind) ? 1 : 0;         /* snp:1664 */
-                    st.nref += (cov && e_refskip) ? 1 : 0;
-                    st.n_isindel += (act && isind) ? 1 : 0;
-                    st.clipped += (act && ((head && e_qpos > 0) || (tail && e_qpos + 1 < lq))) ? 1 : 0;   /* snp:1701 */
-                    st.n_overlap += (act && !head && !tail) ? 1 : 0;                                      /* snp:1705 */
-                    st.has_ins |= (act && !head && !tail && e_indel > 0) ? 1 : 0;                         /* snp:1708 */
-                    const bool cons = act && lq > 0 && use_cons;    /* snp:594 */
-                    const bool inq = e_qpos < lq;                   /* fence: read ends in D/N */
-                    q = inq ? q : 0;
-                    if (any_pres) q = (q > qcap && !P->preserve_qual[q]) ? qcap : q;   /* cap_quality snp:1325 */
-                    else          q = q > qcap ? qcap : q;
-                    int b = (code == 1) ? 0 : (code == 2) ? 1 : (code == 4) ? 2 : (code == 8) ? 3 : 5;   /* snp:603 */
-                    b = inq ? b : 5;
-                    b = e_del ? 4 : b;                              /* snp:609 */
-                    if (any_pres && cons) {                         /* snp:611-623 */
-                        const uint8_t pv = P->preserve_qual[q];
-                        if (pv) st.cp |= 1u << b;
-                        if (pv > 1) st.cp |= (1u << b) << 8;
-                        if (e_indel > 0)
-                            for (int ins = 0; ins < e_indel; ins++) {
-                                const int qi = e_qpos + 1 + ins;
-                                if (qi < lq && P->preserve_qual[cap_q(P, B.quals[so + qi])]) st.cp |= 1u << 4;
-                            }
-                    }
-                    int aq = MQ ? sAdj[mq * 128 + (q & 127)] : q;   /* snp:632-638 */
-                    aq = aq < 1 ? 1 : (aq > 100 ? 100 : aq);        /* snp:641; fence Q5 */
-                    const double MM = sMM[aq], _M = s_M[aq], om = sOmq[aq];
-                    const bool cA = cons && b == 0, cC = cons && b == 1, cG = cons && b == 2, cT = cons && b == 3;
-                    const bool cS = cons && b == 4, cN = cons && b == 5;
-                    const double Mn = cN ? MM : _M;                 /* an N gives MM to the '*'-free hets (snp:677) */
-                    double *S = st.S, *sC = st.sC;
-                    st.depth += cons ? 1 : 0;
-                    st.nN += cN ? 1 : 0;
-                    sC[0] += cA ? om : 0.0; sC[1] += cC ? om : 0.0; sC[2] += cG ? om : 0.0;
-                    sC[3] += cT ? om : 0.0; sC[4] += cS ? om : 0.0;
-                    S[0]  += (cA || cN) ? MM : 0.0;
-                    S[1]  += (cA || cC || cN) ? Mn : 0.0;
-                    S[2]  += (cA || cG || cN) ? Mn : 0.0;
-                    S[3]  += (cA || cT || cN) ? Mn : 0.0;
-                    S[4]  += (cA || cS || cN) ? _M : 0.0;
-                    S[5]  += (cC || cN) ? MM : 0.0;
-                    S[6]  += (cC || cG || cN) ? Mn : 0.0;
-                    S[7]  += (cC || cT || cN) ? Mn : 0.0;
-                    S[8]  += (cC || cS || cN) ? _M : 0.0;
-                    S[9]  += (cG || cN) ? MM : 0.0;
-                    S[10] += (cG || cT || cN) ? Mn : 0.0;
-                    S[11] += (cG || cS || cN) ? _M : 0.0;
-                    S[12] += (cT || cN) ? MM : 0.0;
-                    S[13] += (cT || cS || cN) ? _M : 0.0;
-                    S[14] += cS ? MM : 0.0;
                 }
+#if CRUMBLE_ABL == 2
+                int aq = q; const double MM = 1.5 + aq, _M = 0.5 + aq, om = 0.25;
+#else
+                int aq = MQ ? sAdj[mq * 128 + (q & 127)] : q;                  /* snp:632-638 */
+                aq = aq < 1 ? 1 : (aq > 100 ? 100 : aq);                       /* snp:641; fence Q5 */
+                const double MM = sMM[aq], _M = s_M[aq], om = sOmq[aq];
+#endif
+                const bool cm = cov && isM;                                    /* a base call (snp:603) */
+                const bool cA = cm && code == 1, cC = cm && code == 2, cG = cm && code == 4, cT = cm && code == 8;
+                const bool cS = cov && !isM;                                   /* deletion: '*' (snp:609) */
+                const bool cN = cm && !(code == 1 || code == 2 || code == 4 || code == 8);
+                const double Mn = cN ? MM : _M;                 /* an N gives MM to the '*'-free hets (snp:677) */
+                double *S = st.S, *sC = st.sC;
+                st.depth += cov ? 1 : 0;
+                st.nN += cN ? 1 : 0;
+#if CRUMBLE_ABL == 1
+                S[0] += (cA||cC||cG||cT||cS||cN) ? MM + _M + om + Mn : 0.0;
+#else
+                sC[0] += cA ? om : 0.0; sC[1] += cC ? om : 0.0; sC[2] += cG ? om : 0.0;
+                sC[3] += cT ? om : 0.0; sC[4] += cS ? om : 0.0;
+                S[0]  += (cA || cN) ? MM : 0.0;
+                S[1]  += (cA || cC || cN) ? Mn : 0.0;
+                S[2]  += (cA || cG || cN) ? Mn : 0.0;
+                S[3]  += (cA || cT || cN) ? Mn : 0.0;
+                S[4]  += (cA || cS || cN) ? _M : 0.0;
+                S[5]  += (cC || cN) ? MM : 0.0;
+                S[6]  += (cC || cG || cN) ? Mn : 0.0;
+                S[7]  += (cC || cT || cN) ? Mn : 0.0;
+                S[8]  += (cC || cS || cN) ? _M : 0.0;
+                S[9]  += (cG || cN) ? MM : 0.0;
+                S[10] += (cG || cT || cN) ? Mn : 0.0;
+                S[11] += (cG || cS || cN) ? _M : 0.0;
+                S[12] += (cT || cN) ? MM : 0.0;
+                S[13] += (cT || cS || cN) ? _M : 0.0;
+                S[14] += cS ? MM : 0.0;
+#endif
             }
         }
+        st.n_overlap = st.n_plp - st.nref - n_ht;
         if (inr) col_decide<MQ>(st, B, P, T, c, apos, use_cons, colrec, nplp_out, score_out, trigcnt, sStat);
     }
     __syncthreads();
@@ -1019,39 +1013,45 @@ __global__ void k_window(DBatch B, int n_trig, const int32_t *trigcol_pos, const
 }
 
 /* ------------------------------------------------------------------------ */
-/* k_replay_wave: per-read replay of the per-base loop (snp:1822-1920), the
- * keep_qual retirement copy (snp:1939) and the 0x80 strip of flush_bam_list
- * (snp:1093-1096), with one wavefront per read and one lane per base
- * (coalesced byte traffic).  Exact because the final value of quality
- * byte x only depends on (DESIGN.md "replay"):
- *   - the is_head low-mapq mark (snp:1852),
- *   - the columns whose pileup entry has qpos == x, in order: the D/N columns
- *     just before x (htslib reports the NEXT base for them) and x's own column,
- *   - whether any LATER column of the read is a trigger column whose back-fill
- *     range [ref2query_pos(min_pos2), qpos] reaches down to x (snp:1875): a
- *     suffix-min over the read, taken with wave shuffles,
- *   - the OR of keep_qual over all the read's columns (snp:1847,1939). */
-struct ColOp { uint8_t v; int T; int keep, b15; };
+/* Replay of the per-base loop (snp:1822-1920), the keep_qual retirement copy
+ * (snp:1939) and the 0x80 strip of flush_bam_list (snp:1093-1096).
+ *
+ * The reference mutates each read's output copy column by column.  The final
+ * value of quality byte x of a read only depends on (DESIGN.md "replay"):
+ *   (a) the is_head low-mapq mark (snp:1852) and -S binning (snp:1894),
+ *   (b) the columns whose pileup entry has qpos == x, in order: the D/N columns
+ *       just before x (htslib reports the NEXT base for them) and x's own column,
+ *   (c) whether any LATER column of the read is a trigger column whose back-fill
+ *       range [ref2query_pos(min_pos2), qpos] reaches down to x (snp:1875):
+ *       the byte is then the capped original,
+ *   (d) the OR of keep_qual over the read's columns (snp:1847,1939): capped original.
+ * (a)+(b) are one lane per base over the flat base array (k_replay_flat, fully
+ * coalesced, no cross-lane traffic); (c) is a scatter from the few trigger
+ * columns (k_restore); (d) and the per-read flags are k_readfix.  (c) and (d)
+ * write the same value, so their order does not matter. */
+struct ColOp { uint8_t v; int keep, b15; };
+
+__device__ __forceinline__ uint8_t cap_q2(const DParams *__restrict__ P, int qcap, bool any_pres, uint8_t q)
+{   /* cap_quality snp:1325-1332; the preserve_qual table is only consulted when -k/-K/-y set it */
+    if (q > qcap && !(any_pres && P->preserve_qual[q])) return (uint8_t)qcap;
+    return q;
+}
 
 /* the per-base loop body (snp:1870-1919) for the entry (column c, query index x) */
 __device__ __forceinline__ void apply_col(const DParams *__restrict__ P, const DBatch &B, uint32_t rec, int c,
                                           const int32_t *__restrict__ pos_mn2, int64_t r, int rp, int x,
-                                          uint8_t capq, int base, ColOp &o, bool head_apart)
+                                          uint8_t capq, int base, ColOp &o, bool any_pres)
 {
     if (rec & CR_SKIP) return;
     if (rec & CR_KEEP) o.keep = 1;
     const int preserve = CR_PRESERVE(rec);
-    if (rec & CR_TRIG) {                                   /* snp:1870-1879 (rare) */
+    if (rec & CR_TRIG) {                                   /* snp:1870-1879 (rare): x == qpos here */
         const uint32_t *cig = B.cigar + B.cig_off[r];
         const int nc = (int)(B.cig_off[r + 1] - B.cig_off[r]);
-        const int start = dev_ref2query_pos(cig, nc, rp, pos_mn2[c]);
-        /* with -S the head column's back-fill precedes its soft-clip binning (snp:1875 then
-         * 1895), so it is applied apart from the suffix-min of the later columns */
-        if (start < o.T && !(head_apart && c == rp - B.p0)) o.T = start;
-        if (start <= x) o.v = capq | 0x80;
+        if (dev_ref2query_pos(cig, nc, rp, pos_mn2[c]) <= x) o.v = capq | 0x80;
     }
     if (rec & CR_WIN) o.v = capq | 0x80;                   /* snp:1880-1883 */
-    if (preserve || P->preserve_qual[o.v & 0x7f] >= 1 + ((rec & CR_PERFECT) ? 1 : 0)) o.v |= 0x80;
+    if (preserve || (any_pres && P->preserve_qual[o.v & 0x7f] >= 1 + ((rec & CR_PERFECT) ? 1 : 0))) o.v |= 0x80;
     if (preserve > 1) o.b15 = 1;
     if (!(o.v & 0x80)) {                                   /* snp:1906-1919 */
         const int c1 = 1 << CR_A1(rec), c2 = 1 << CR_A2(rec);
@@ -1060,140 +1060,275 @@ __device__ __forceinline__ void apply_col(const DParams *__restrict__ P, const D
     }
 }
 
-__global__ void __launch_bounds__(256)
-k_replay_wave(DBatch B, const DParams *__restrict__ P, const uint32_t *__restrict__ colrec,
-              const int32_t *__restrict__ pos_mn2, uint8_t *__restrict__ out, uint8_t *__restrict__ rflags)
+/* one base through the general path (any CIGAR, -S, -k/-K ...) */
+__device__ __forceinline__ uint8_t replay_base(const DBatch &B, const DParams *__restrict__ P,
+                                            const uint32_t *__restrict__ colrec, const int32_t *__restrict__ pos_mn2,
+                                            int64_t g, int64_t r,
+                                            uint8_t *__restrict__ keepf, uint8_t *__restrict__ b15f)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = UNIFORM((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    if (r >= B.n_reads) return;
-    const ReadRec rr = B.rr[r];                            /* one 32-byte record per read */
-    const int64_t so = rr.so;
-    const int lq = rr.lq;
-    uint8_t *q2 = out + so;
-    const uint8_t *qin = B.quals + so;
-    if (rr.end <= rr.pos) {                                /* never entered the pileup */
-        for (int x = lane; x < lq; x += 64) q2[x] = qin[x] & 0x7f;
-        if (lane == 0) rflags[r] = 4;
-        return;
-    }
-    const int rp = rr.pos, re = rr.end, mq = (int)(rr.info & 255);
+    const ReadRec rr = B.rr[r];
+    const int x = (int)(g - rr.so);
+    const uint8_t q0 = B.quals[g];
+    if (rr.end <= rr.pos) return q0 & 0x7f;                /* never entered the pileup */
+    const int qcap = P->qcap;
+    const bool any_pres = P->any_preserve != 0, softclip = P->softclip != 0;
+    const int rp = rr.pos, re = rr.end;
     const bool simple = (rr.info & RR_SIMPLE) != 0;
-    const bool softclip = P->softclip != 0;
-    const bool lowmq = mq <= P->min_mqual;
-    /* general alignments need the segment table */
+    const bool lowmq = (int)(rr.info & 255) <= P->min_mqual;
+    const uint8_t capq = cap_q2(P, qcap, any_pres, q0);
+    const int base = B.bases[g] & 15;
     const Seg *segs = B.segs;
     int ns = 1;
-    Seg s0, sl;
-    s0.roff = 0; s0.qstart = rr.q0; s0.len_type = (uint32_t)(re - rp); s0.indel_after = 0;
-    sl = s0;
-    if (!simple) {
-        segs = B.segs + B.seg_off[r];
-        ns = (int)(B.seg_off[r + 1] - B.seg_off[r]);
-        s0 = segs[0]; sl = segs[ns - 1];
+    if (!simple) { segs = B.segs + B.seg_off[r]; ns = (int)(B.seg_off[r + 1] - B.seg_off[r]); }
+    ColOp o; o.v = q0; o.keep = 0; o.b15 = 0;
+    bool sc_tail = false;
+    if (lowmq || softclip) {
+        const uint32_t headrec = colrec[rp - B.p0], tailrec = colrec[re - 1 - B.p0];
+        if (lowmq && !(headrec & CR_SKIP)) o.v |= 0x80;                                /* snp:1852 */
+        if (softclip) {
+            int qpos_head = rr.q0, qpos_tail = rr.q0 + (re - rp) - 1;
+            if (!simple) {
+                const Seg sl = segs[ns - 1];
+                qpos_head = segs[0].qstart;
+                qpos_tail = (seg_type(sl) == SEG_M) ? sl.qstart + seg_len(sl) - 1 : sl.qstart;
+            }
+            if (x < qpos_head) {
+                /* head column: its back-fill (snp:1875) precedes its -S binning (snp:1895) */
+                if ((headrec & CR_TRIG) && !(headrec & CR_SKIP)) {
+                    const uint32_t *cig = B.cigar + B.cig_off[r];
+                    if (dev_ref2query_pos(cig, (int)(B.cig_off[r + 1] - B.cig_off[r]), rp, pos_mn2[rp - B.p0]) <= x)
+                        o.v = capq | 0x80;
+                }
+                if (!(headrec & (CR_SKIP | CR_KEEP))) o.v = P->bin2[o.v];
+            }
+            sc_tail = (re - 1 != rp) && !(tailrec & (CR_SKIP | CR_KEEP)) && x > qpos_tail;
+        }
     }
-    uint32_t headrec = 0, tailrec = 0;
-    if (lowmq || softclip) { headrec = colrec[rp - B.p0]; tailrec = colrec[re - 1 - B.p0]; }
-    const int qpos_head = s0.qstart;
-    const int qpos_tail = (seg_type(sl) == SEG_M) ? sl.qstart + seg_len(sl) - 1 : sl.qstart;
-    const bool headmark = lowmq && !(headrec & CR_SKIP);                               /* snp:1852 */
-    const bool sc_head = softclip && !(headrec & (CR_SKIP | CR_KEEP));                 /* snp:1894 */
-    const bool sc_tail = softclip && (re - 1 != rp) && !(tailrec & (CR_SKIP | CR_KEEP));
-    int keep = 0, b15 = 0, carry = INT_MAX, headT = INT_MAX;
-    if (softclip && (headrec & CR_TRIG) && !(headrec & CR_SKIP)) {
-        const uint32_t *cig = B.cigar + B.cig_off[r];
-        headT = dev_ref2query_pos(cig, (int)(B.cig_off[r + 1] - B.cig_off[r]), rp, pos_mn2[rp - B.p0]);
+    if (simple) {
+        const int off = x - rr.q0;
+        if (off >= 0 && off < re - rp) {
+            const int c = rp + off - B.p0;
+            apply_col(P, B, colrec[c], c, pos_mn2, r, rp, x, capq, base, o, any_pres);
+        }
+    } else {
+        /* first segment with qstart >= x */
+        int lo = 0, hi = ns;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (segs[mid].qstart < x) lo = mid + 1; else hi = mid; }
+        int i = lo;
+        bool own_done = false;
+        while (i < ns && segs[i].qstart == x) {            /* D/N runs that report x, then maybe x's own M op */
+            const Seg sg = segs[i];
+            const int len = seg_len(sg);
+            if (seg_type(sg) == SEG_M) {
+                const int c = rp + sg.roff - B.p0;
+                apply_col(P, B, colrec[c], c, pos_mn2, r, rp, x, capq, base, o, any_pres);
+                own_done = true;
+                break;
+            }
+            for (int kk = 0; kk < len; kk++) {
+                const int c = rp + sg.roff + kk - B.p0;
+                apply_col(P, B, colrec[c], c, pos_mn2, r, rp, x, capq, base, o, any_pres);
+            }
+            i++;
+        }
+        if (!own_done && i > 0 && i <= ns) {               /* x strictly inside the previous M op? */
+            const Seg sg = segs[i - 1];
+            if (seg_type(sg) == SEG_M && sg.qstart < x && x < sg.qstart + seg_len(sg)) {
+                const int c = rp + sg.roff + (x - sg.qstart) - B.p0;
+                apply_col(P, B, colrec[c], c, pos_mn2, r, rp, x, capq, base, o, any_pres);
+            }
+        }
     }
+    if (sc_tail) o.v = P->bin2[o.v];
+    if (o.keep) keepf[r] = 1;                              /* same value from every lane: benign */
+    if (o.b15) b15f[r] = 1;
+    return o.v & 0x7f;                                     /* snp:1093 */
+}
 
-    for (int ch = (lq + 63) / 64 - 1; ch >= 0; ch--) {
-        const int x = ch * 64 + lane;
-        const bool active = x < lq;
-        ColOp o; o.v = 0; o.T = INT_MAX; o.keep = 0; o.b15 = 0;
-        uint8_t capq = 0;
-        if (active) {
-            const uint8_t q0 = qin[x];
-            capq = cap_q(P, q0);
-            const int base = B.bases[so + x] & 15;
-            o.v = headmark ? (q0 | 0x80) : q0;
-            if (x < qpos_head) {                           /* head column: back-fill, then -S binning */
-                if (headT <= x) o.v = capq | 0x80;
-                if (sc_head) o.v = P->bin2[o.v];
+/* Eight consecutive bases per lane.  For a base of a read whose alignment is one match
+ * op (and no rarely-used option is on) the byte is produced with a handful of selects:
+ *   window/back-fill (snp:1880)            -> capped original
+ *   preserve, or low-mapq read (snp:1852)  -> original
+ *   no column (clip, insertion), skipped   -> original
+ *   else (snp:1906-1919)                   -> qhigh if the base is a called allele, else qlow/bin2
+ * everything else goes through replay_base(). */
+__global__ void __launch_bounds__(256)
+k_replay_flat(DBatch B, const DParams *__restrict__ P, const uint32_t *__restrict__ colrec,
+              const int32_t *__restrict__ pos_mn2, const int32_t *__restrict__ blk_read,
+              uint8_t *__restrict__ out, uint8_t *__restrict__ keepf, uint8_t *__restrict__ b15f)
+{
+    const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (g0 >= B.n_bases) return;
+    const int n8 = (B.n_bases - g0 < 8) ? (int)(B.n_bases - g0) : 8;
+    const bool any_pres = P->any_preserve != 0;
+    const int min_mqual = P->min_mqual;
+    /* phase 1: owning read and column of each of the eight bases (reads are laid out back
+     * to back in file order; at most a few read changes inside eight bases) */
+    int64_t r = blk_read[g0 >> 6];
+    while (B.seq_off[r + 1] <= g0) r++;
+    const int64_t r0 = r;
+    ReadRec rr = B.rr[r];
+    bool hm = false;                                       /* is_head low-mapq mark of the current read */
+    if (rr.end > rr.pos && (int)(rr.info & 255) <= min_mqual) hm = !(colrec[rr.pos - B.p0] & CR_SKIP);
+    int cidx[8];
+    unsigned slow = 0, hmm = 0, rdelta = 0;                /* bit k / 3 bits per k */
+    #pragma unroll
+    for (int k = 0; k < 8; k++) {
+        cidx[k] = -1;
+        if (k < n8) {
+            const int64_t g = g0 + k;
+            while (g >= rr.so + rr.lq) {                   /* next read (no load unless the read changes) */
+                r++; rr = B.rr[r];
+                hm = false;
+                if (rr.end > rr.pos && (int)(rr.info & 255) <= min_mqual) hm = !(colrec[rr.pos - B.p0] & CR_SKIP);
             }
-            if (simple) {
-                const int off = x - rr.q0;
-                if (off >= 0 && off < re - rp) {
-                    const int c = rp + off - B.p0;
-                    apply_col(P, B, colrec[c], c, pos_mn2, r, rp, x, capq, base, o, softclip);
-                }
-            } else {
-                /* first segment with qstart >= x */
-                int lo = 0, hi = ns;
-                while (lo < hi) { int mid = (lo + hi) >> 1; if (segs[mid].qstart < x) lo = mid + 1; else hi = mid; }
-                int i = lo;
-                bool own_done = false;
-                while (i < ns && segs[i].qstart == x) {    /* D/N runs that report x, then maybe x's own M op */
-                    const Seg sg = segs[i];
-                    const int len = seg_len(sg);
-                    if (seg_type(sg) == SEG_M) {
-                        const int c = rp + sg.roff - B.p0;
-                        apply_col(P, B, colrec[c], c, pos_mn2, r, rp, x, capq, base, o, softclip);
-                        own_done = true;
-                        break;
-                    }
-                    for (int k = 0; k < len; k++) {
-                        const int c = rp + sg.roff + k - B.p0;
-                        apply_col(P, B, colrec[c], c, pos_mn2, r, rp, x, capq, base, o, softclip);
-                    }
-                    i++;
-                }
-                if (!own_done && i > 0 && i <= ns) {       /* x strictly inside the previous M op? */
-                    const Seg sg = segs[i - 1];
-                    if (seg_type(sg) == SEG_M && sg.qstart < x && x < sg.qstart + seg_len(sg)) {
-                        const int c = rp + sg.roff + (x - sg.qstart) - B.p0;
-                        apply_col(P, B, colrec[c], c, pos_mn2, r, rp, x, capq, base, o, softclip);
-                    }
+            rdelta |= (unsigned)(r - r0) << (3 * k);
+            if (rr.end > rr.pos) {                         /* in the pileup */
+                if (rr.info & RR_SIMPLE) {
+                    const int off = (int)(g - rr.so) - rr.q0;
+                    if (off >= 0 && off < rr.end - rr.pos) cidx[k] = rr.pos + off - B.p0;
+                    if (hm) hmm |= 1u << k;
+                } else {                                   /* general CIGAR: host-built base -> column table */
+                    const int c = B.cix[(size_t)rr.cix + (size_t)(g - rr.so)];
+                    if (c == -2) slow |= 1u << k;          /* D/N columns report this base: sequence matters */
+                    else { cidx[k] = c; if (hm) hmm |= 1u << k; }
                 }
             }
-            if (sc_tail && x > qpos_tail) o.v = P->bin2[o.v];
         }
-        /* exclusive suffix-min of the back-fill starts over lanes, then over later chunks;
-         * skipped (wave-uniformly) when this read has met no trigger column so far */
-        int excl = INT_MAX;
-        if (__any(o.T != INT_MAX) || carry != INT_MAX) {
-            int incl = o.T;
-            for (int d = 1; d < 64; d <<= 1) {
-                const int other = __shfl_down(incl, d);
-                if (lane + d < 64 && other < incl) incl = other;
-            }
-            excl = __shfl_down(incl, 1);
-            if (lane == 63) excl = INT_MAX;
-            if (carry < excl) excl = carry;
-            const int first = __shfl(incl, 0);
-            if (first < carry) carry = first;
-        }
-        if (active) {
-            if (excl <= x) o.v = capq | 0x80;
-            q2[x] = o.v & 0x7f;                            /* snp:1093 */
-        }
-        keep |= o.keep; b15 |= o.b15;
     }
-    /* columns that no base owns: D/N ops at the very end of the query (fenced), or l_qseq == 0 */
-    if (lane == 0 && (lq == 0 || !simple)) {
-        if (lq == 0) {
-            for (int c = rp; c < re; c++) { const uint32_t rec = colrec[c - B.p0]; if (!(rec & CR_SKIP) && (rec & CR_KEEP)) keep = 1; }
+    /* phase 2: the eight column records (consecutive words for the common case) */
+    uint32_t rec[8];
+    if (cidx[0] >= 0 && cidx[7] == cidx[0] + 7) {          /* one read, inside its match op: 32 consecutive bytes */
+        const uint32_t *rc = colrec + cidx[0];
+        #pragma unroll
+        for (int k = 0; k < 8; k++) rec[k] = rc[k];
+    } else {
+        #pragma unroll
+        for (int k = 0; k < 8; k++) { const uint32_t v = colrec[cidx[k] >= 0 ? cidx[k] : 0]; rec[k] = cidx[k] >= 0 ? v : CR_ALLREFSKIP; }
+    }
+    uint32_t qw[2] = {0, 0}, bw[2] = {0, 0};
+    if (n8 == 8) {
+        const uint2 q2 = *(const uint2 *)(B.quals + g0), b2 = *(const uint2 *)(B.bases + g0);
+        qw[0] = q2.x; qw[1] = q2.y; bw[0] = b2.x; bw[1] = b2.y;
+    } else {
+        for (int k = 0; k < n8; k++) { qw[k >> 2] |= (uint32_t)B.quals[g0 + k] << (8 * (k & 3)); bw[k >> 2] |= (uint32_t)B.bases[g0 + k] << (8 * (k & 3)); }
+    }
+    /* phase 3 */
+    const int qcap = P->qcap, qhigh = P->qhigh, qlow = P->qlow;
+    const bool reduce = P->reduce_qual != 0, binary = P->binary_qual != 0;
+    uint32_t ow[2] = {0, 0};
+    #pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t q0 = (qw[k >> 2] >> (8 * (k & 3))) & 255;
+        const int base = (bw[k >> 2] >> (8 * (k & 3))) & 15;
+        const uint32_t rcd = rec[k];
+        const bool skip = (rcd & CR_SKIP) != 0;
+        const int64_t rk = r0 + ((rdelta >> (3 * k)) & 7);
+        uint32_t v;
+        /* a trigger column is always a window column (k_columns sets both), so its own byte is
+         * the capped original whatever the back-fill start: no special case needed here */
+        if ((slow >> k) & 1) {                             /* rare: rewritten by k_replay_slow */
+            v = q0;
         } else {
-            for (int i = ns - 1; i >= 0 && segs[i].qstart >= lq; i--) {
-                const Seg sg = segs[i];
-                for (int k = 0; k < seg_len(sg); k++) {
-                    const uint32_t rec = colrec[rp + sg.roff + k - B.p0];
-                    if (!(rec & CR_SKIP) && (rec & CR_KEEP)) keep = 1;
-                }
+            const uint32_t capq = any_pres ? (uint32_t)cap_q2(P, qcap, true, (uint8_t)q0) : (q0 > (uint32_t)qcap ? (uint32_t)qcap : q0);
+            const int pres = CR_PRESERVE(rcd);
+            bool keepv = ((hmm >> k) & 1) || skip || pres;                   /* value untouched */
+            if (any_pres) keepv = keepv || P->preserve_qual[q0 & 0x7f] >= 1 + ((rcd & CR_PERFECT) ? 1 : 0);   /* snp:1885 */
+            const bool match = base == (1 << CR_A1(rcd)) || base == (1 << CR_A2(rcd));
+            const uint32_t qz = match ? (uint32_t)qhigh : (reduce ? (binary ? (uint32_t)P->bin2[q0] : (uint32_t)qlow) : q0);
+            v = (!skip && (rcd & CR_WIN)) ? capq : (keepv ? q0 : qz);
+            if (!skip && (rcd & CR_KEEP)) keepf[rk] = 1;
+            if (!skip && pres > 1) b15f[rk] = 1;
+        }
+        ow[k >> 2] |= (v & 0x7f) << (8 * (k & 3));
+    }
+    if (n8 == 8) { uint2 o2; o2.x = ow[0]; o2.y = ow[1]; *(uint2 *)(out + g0) = o2; }
+    else for (int k = 0; k < n8; k++) out[g0 + k] = (uint8_t)((ow[k >> 2] >> (8 * (k & 3))) & 255);
+}
+
+/* the bases that D/N columns report (host-built list), after k_replay_flat */
+__global__ void k_replay_slow(DBatch B, const DParams *__restrict__ P, const uint32_t *__restrict__ colrec,
+                              const int32_t *__restrict__ pos_mn2, int64_t n_slow, const int64_t *__restrict__ slow_g,
+                              const int32_t *__restrict__ slow_r, uint8_t *__restrict__ out,
+                              uint8_t *__restrict__ keepf, uint8_t *__restrict__ b15f)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_slow) return;
+    out[slow_g[t]] = replay_base(B, P, colrec, pos_mn2, slow_g[t], slow_r[t], keepf, b15f);
+}
+
+/* every base through the general routine (used when -S is on) */
+__global__ void k_replay_general(DBatch B, const DParams *__restrict__ P, const uint32_t *__restrict__ colrec,
+                                 const int32_t *__restrict__ pos_mn2, const int32_t *__restrict__ blk_read,
+                                 uint8_t *__restrict__ out, uint8_t *__restrict__ keepf, uint8_t *__restrict__ b15f)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= B.n_bases) return;
+    int64_t r = blk_read[g >> 6];
+    while (B.seq_off[r + 1] <= g) r++;
+    out[g] = replay_base(B, P, colrec, pos_mn2, g, r, keepf, b15f);
+}
+
+/* (c): back-fill of every read under a trigger column (snp:1870-1879), bases before
+ * the entry's own qpos (the entry's own byte is handled by apply_col). */
+__global__ void k_restore(DBatch B, const DParams *__restrict__ P, int n_trig, const int32_t *trigcol_pos,
+                          const int32_t *__restrict__ pos_mn2, uint8_t *__restrict__ out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_trig) return;
+    const int c = trigcol_pos[t], apos = B.p0 + c, tile = c >> 6;
+    const int lo = B.tile_lo[tile], hi = B.tile_hi[tile];
+    const int mn2 = pos_mn2[c], qcap = P->qcap;
+    const bool any_pres = P->any_preserve != 0, softclip = P->softclip != 0;
+    for (int r = lo; r < hi; r++) {
+        const int rp = B.pos[r];
+        if (!(apos >= rp && apos < B.end[r])) continue;
+        if (softclip && apos == rp) continue;              /* done in k_replay_flat, before the binning */
+        Entry e;
+        resolve_entry(B, r, apos, e);
+        const int64_t so = B.seq_off[r];
+        const int lq = (int)(B.seq_off[r + 1] - so);
+        if (!lq || e.qpos >= lq) continue;                 /* snp:1861 / fence */
+        const uint32_t *cig = B.cigar + B.cig_off[r];
+        const int start = dev_ref2query_pos(cig, (int)(B.cig_off[r + 1] - B.cig_off[r]), rp, mn2);
+        for (int x = start; x < e.qpos; x++)
+            out[so + x] = cap_q2(P, qcap, any_pres, B.quals[so + x]) & 0x7f;
+    }
+}
+
+/* (d) + per-read flags: one thread per read */
+__global__ void k_readfix(DBatch B, const DParams *__restrict__ P, const uint32_t *__restrict__ colrec,
+                          const uint8_t *__restrict__ keepf, const uint8_t *__restrict__ b15f,
+                          uint8_t *__restrict__ out, uint8_t *__restrict__ rflags)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B.n_reads) return;
+    const ReadRec rr = B.rr[r];
+    if (rr.end <= rr.pos) { rflags[r] = 4; return; }
+    int keep = keepf[r];
+    const int lq = rr.lq, rp = rr.pos, re = rr.end;
+    /* columns that no base owns: l_qseq == 0, or D/N ops at the very end of the query (fenced) */
+    if (lq == 0) {
+        for (int c = rp; c < re; c++) { const uint32_t rec = colrec[c - B.p0]; if (!(rec & CR_SKIP) && (rec & CR_KEEP)) keep = 1; }
+    } else if (!(rr.info & RR_SIMPLE)) {
+        const Seg *segs = B.segs + B.seg_off[r];
+        const int ns = (int)(B.seg_off[r + 1] - B.seg_off[r]);
+        for (int i = ns - 1; i >= 0 && segs[i].qstart >= lq; i--) {
+            const Seg sg = segs[i];
+            for (int kk = 0; kk < seg_len(sg); kk++) {
+                const uint32_t rec = colrec[rp + sg.roff + kk - B.p0];
+                if (!(rec & CR_SKIP) && (rec & CR_KEEP)) keep = 1;
             }
         }
     }
-    keep = __any(keep); b15 = __any(b15);
-    if (keep) for (int x = lane; x < lq; x += 64) q2[x] = cap_q(P, qin[x]) & 0x7f;   /* snp:1939 */
-    if (lane == 0) rflags[r] = (uint8_t)((keep ? 1 : 0) | (b15 ? 2 : 0));
+    if (keep) {                                            /* snp:1939: memcpy of the capped copy */
+        const int qcap = P->qcap;
+        const bool any_pres = P->any_preserve != 0;
+        const uint8_t *qin = B.quals + rr.so;
+        uint8_t *q2 = out + rr.so;
+        for (int x = 0; x < lq; x++) q2[x] = cap_q2(P, qcap, any_pres, qin[x]) & 0x7f;
+    }
+    rflags[r] = (uint8_t)((keep ? 1 : 0) | (b15f[r] ? 2 : 0));
 }
 
 /* ------------------------------------------------------------------------ */

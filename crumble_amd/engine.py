@@ -12,7 +12,7 @@ import numpy as np
 
 from .capi import (Params, Batch, Column, HostBatch, COLUMN_DTYPE, ST_N, ROOT, HERE)
 
-LIB_PATH = os.path.join(HERE, "libcrumble_hip.so")
+LIB_PATH = os.environ.get("CRUMBLE_HIP_LIB", os.path.join(HERE, "libcrumble_hip.so"))
 _lib = None
 
 
