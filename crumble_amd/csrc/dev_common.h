@@ -139,6 +139,8 @@ struct ScanVal {            /* per-position quantities that need prefix sums */
     int32_t trigcols;       /* columns with >= 1 trigger                     */
     int32_t items;          /* triggers                                      */
     int32_t ins;            /* columns needing the indel-size histogram      */
+    int32_t toodeep;        /* columns deeper than MAX_DEPTH                 */
+    int32_t pad;
 };
 
 struct Epoch {              /* running-average state of snp:1490-1491,1684   */

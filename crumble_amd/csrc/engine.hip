@@ -63,7 +63,7 @@ struct crumble_hip {
     /* work lists */
     DevBuf d_trigcol_pos, d_trigcol_off, d_inscol_pos, d_items, d_colhi, d_ub, d_pmax_partial, d_trig_mx2;
     /* outputs */
-    DevBuf d_out, d_rflags, d_keepf, d_b15f, d_blk_read;
+    DevBuf d_out, d_rflags, d_keepf, d_b15f, d_blk_read, d_kept;
     DBatch B;
     bool have_batch = false, have_run = false;
     unsigned persistent_blocks = 1024;
@@ -227,7 +227,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
         &h->d_trigcnt, &h->d_dpre, &h->d_col_ord, &h->d_trig_ord, &h->d_item_off, &h->d_ins_ord,
         &h->d_pos_mn2, &h->d_partial, &h->d_epochs, &h->d_trigcol_pos, &h->d_trigcol_off,
         &h->d_inscol_pos, &h->d_items, &h->d_colhi, &h->d_ub, &h->d_pmax_partial, &h->d_trig_mx2,
-        &h->d_out, &h->d_rflags, &h->d_keepf, &h->d_b15f, &h->d_blk_read };
+        &h->d_out, &h->d_rflags, &h->d_keepf, &h->d_b15f, &h->d_blk_read, &h->d_kept };
     for (DevBuf *b : all) b->release();
     if (h->events_ok) for (int i = 0; i <= MAX_STAGES; i++) (void)hipEventDestroy(h->ev[i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -468,7 +468,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
         (e = h->d_pos_mn2.reserve(L * 4)) || (e = h->d_partial.reserve((size_t)(nchunks + 2) * sizeof(ScanVal))) ||
         (e = h->d_epochs.reserve(MAX_EPOCHS * sizeof(Epoch))) ||
         (e = h->d_out.reserve((size_t)(nb ? nb : 1))) || (e = h->d_rflags.reserve((size_t)(n ? n : 1))) ||
-        (e = h->d_keepf.reserve((size_t)(n ? n : 1))) || (e = h->d_b15f.reserve((size_t)(n ? n : 1))))
+        (e = h->d_keepf.reserve((size_t)(n ? n : 1))) || (e = h->d_kept.reserve((size_t)(n ? n : 1) * 4)) || (e = h->d_b15f.reserve((size_t)(n ? n : 1))))
         return e;
     h->have_batch = true;
     return CRUMBLE_OK;
@@ -503,7 +503,7 @@ extern "C" int crumble_hip_run(crumble_hip *h)
     h->n_stages = 0; h->have_run = false;
     memset(&h->totals, 0, sizeof(h->totals));
     HIPCHK(hipMemsetAsync(stats, 0, CRUMBLE_ST_N * 8, st));
-    HIPCHK(hipMemsetAsync(d_overflow, 0, 8, st));
+    HIPCHK(hipMemsetAsync(d_overflow, 0, 16, st));      /* [0] overflow, [1] n_epochs, [2] n_kept */
 
     if (L > 0) {
         STAGE("k_columns", 2.0 * nb + 32.0 * n + 8.0 * h->n_cigar);
@@ -521,11 +521,15 @@ extern "C" int crumble_hip_run(crumble_hip *h)
         CRUMBLE_LAUNCH(k_scan_apply, nchunks, 256, st, L, colrec, nplp, trigcnt, partial, nchunks,
                              h->d_dpre.as<int64_t>(), h->d_col_ord.as<int32_t>(), h->d_trig_ord.as<int32_t>(),
                              h->d_item_off.as<int32_t>(), h->d_ins_ord.as<int32_t>());
-        CRUMBLE_LAUNCH_INDEP(k_epochs, 1, 1, st, L, colrec, nplp, h->d_col_ord.as<int32_t>(), h->d_dpre.as<int64_t>(),
-                             partial + nchunks, h->d_epochs.as<Epoch>(), d_nep);
         HIPCHK(hipMemcpyAsync(&h->totals, partial + nchunks, sizeof(ScanVal), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));           /* sizes of the work lists */
         const int n_trig = h->totals.trigcols, n_items = h->totals.items, n_ins = h->totals.ins;
+        if (h->totals.toodeep == 0)
+            CRUMBLE_LAUNCH(k_epochs_par, 1, 256, st, L, colrec, h->d_col_ord.as<int32_t>(), h->d_dpre.as<int64_t>(),
+                           partial + nchunks, h->d_epochs.as<Epoch>(), d_nep);
+        else
+            CRUMBLE_LAUNCH_INDEP(k_epochs, 1, 1, st, L, colrec, nplp, h->d_col_ord.as<int32_t>(), h->d_dpre.as<int64_t>(),
+                                 partial + nchunks, h->d_epochs.as<Epoch>(), d_nep);
         int e;
         if ((e = h->d_trigcol_pos.reserve((size_t)(n_trig + 1) * 4)) || (e = h->d_trigcol_off.reserve((size_t)(n_trig + 1) * 4)) ||
             (e = h->d_inscol_pos.reserve((size_t)(n_ins + 1) * 4)) || (e = h->d_items.reserve((size_t)(n_items + 1) * sizeof(TrigItem))) ||
@@ -585,10 +589,12 @@ extern "C" int crumble_hip_run(crumble_hip *h)
                                      h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(), h->d_b15f.as<uint8_t>());
         }
         if (L > 0 && h->totals.trigcols > 0)
-            CRUMBLE_LAUNCH_INDEP(k_restore, nblk(h->totals.trigcols, 64), 64, st, B, P, h->totals.trigcols,
+            CRUMBLE_LAUNCH_INDEP(k_restore, h->totals.trigcols, 64, st, B, P, h->totals.trigcols,
                                  h->d_trigcol_pos.as<int32_t>(), h->d_pos_mn2.as<int32_t>(), h->d_out.as<uint8_t>());
-        CRUMBLE_LAUNCH_INDEP(k_readfix, nblk(n, 256), 256, st, B, P, colrec, h->d_keepf.as<uint8_t>(),
-                             h->d_b15f.as<uint8_t>(), h->d_out.as<uint8_t>(), h->d_rflags.as<uint8_t>());
+        CRUMBLE_LAUNCH_INDEP(k_readfix, nblk(n, 256), 256, st, B, colrec, h->d_keepf.as<uint8_t>(),
+                             h->d_b15f.as<uint8_t>(), h->d_rflags.as<uint8_t>(), h->d_kept.as<int32_t>(), d_overflow + 2);
+        CRUMBLE_LAUNCH_INDEP(k_keepfix, (nblk(n, 4) < 512u ? nblk(n, 4) : 512u), 256, st, B, P, h->d_kept.as<int32_t>(),
+                             d_overflow + 2, h->d_out.as<uint8_t>());
         if (h->hparams.pblock) {
             STAGE("k_pblock", 2.0 * nb);
             CRUMBLE_LAUNCH_INDEP(k_pblock, nblk(n, 64), 64, st, n, B.seq_off, h->d_out.as<uint8_t>(),

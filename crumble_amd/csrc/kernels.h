@@ -440,9 +440,10 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                     st.clipped += (act && ((head && (info & SR_HEADCLIP)) || (tail && (info & SR_TAILCLIP)))) ? 1 : 0;   /* snp:1701 */
                 }
                 if (isN || lq == 0 || !use_cons) continue;                     /* snp:589,594 (uniform) */
-                /* consensus accumulation: branch-free over lanes; lanes that the record does not
-                 * cover add +0.0, which is exact, so each genotype sum sees its own addends in
-                 * file order (snp:656-683) and the 20 running sums never leave their registers */
+                /* consensus accumulation (snp:594-685).  Each base class is an exec-masked block of
+                 * in-place FP64 adds (only the lanes that the record covers with that class take part;
+                 * the block is skipped when there is none), so every genotype sum sees exactly its own
+                 * addends, in file order, and the 20 running sums never leave their registers. */
                 const int e_qpos = isM ? R[u].qoff + apos : R[u].qoff;
                 const bool inq = e_qpos < lq;                                  /* fence: read ends in D/N */
                 int q = inq ? (int)qq[u] : 0;
@@ -461,42 +462,27 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                             if (qi < lq && P->preserve_qual[cap_q(P, B.quals[R[u].so + qi])]) st.cp |= 1u << 4;
                         }
                 }
-#if CRUMBLE_ABL == 2
-                int aq = q; const double MM = 1.5 + aq, _M = 0.5 + aq, om = 0.25;
-#else
                 int aq = MQ ? sAdj[mq * 128 + (q & 127)] : q;                  /* snp:632-638 */
                 aq = aq < 1 ? 1 : (aq > 100 ? 100 : aq);                       /* snp:641; fence Q5 */
                 const double MM = sMM[aq], _M = s_M[aq], om = sOmq[aq];
-#endif
                 const bool cm = cov && isM;                                    /* a base call (snp:603) */
                 const bool cA = cm && code == 1, cC = cm && code == 2, cG = cm && code == 4, cT = cm && code == 8;
                 const bool cS = cov && !isM;                                   /* deletion: '*' (snp:609) */
                 const bool cN = cm && !(code == 1 || code == 2 || code == 4 || code == 8);
-                const double Mn = cN ? MM : _M;                 /* an N gives MM to the '*'-free hets (snp:677) */
                 double *S = st.S, *sC = st.sC;
                 st.depth += cov ? 1 : 0;
                 st.nN += cN ? 1 : 0;
-#if CRUMBLE_ABL == 1
-                S[0] += (cA||cC||cG||cT||cS||cN) ? MM + _M + om + Mn : 0.0;
-#else
-                sC[0] += cA ? om : 0.0; sC[1] += cC ? om : 0.0; sC[2] += cG ? om : 0.0;
-                sC[3] += cT ? om : 0.0; sC[4] += cS ? om : 0.0;
-                S[0]  += (cA || cN) ? MM : 0.0;
-                S[1]  += (cA || cC || cN) ? Mn : 0.0;
-                S[2]  += (cA || cG || cN) ? Mn : 0.0;
-                S[3]  += (cA || cT || cN) ? Mn : 0.0;
-                S[4]  += (cA || cS || cN) ? _M : 0.0;
-                S[5]  += (cC || cN) ? MM : 0.0;
-                S[6]  += (cC || cG || cN) ? Mn : 0.0;
-                S[7]  += (cC || cT || cN) ? Mn : 0.0;
-                S[8]  += (cC || cS || cN) ? _M : 0.0;
-                S[9]  += (cG || cN) ? MM : 0.0;
-                S[10] += (cG || cT || cN) ? Mn : 0.0;
-                S[11] += (cG || cS || cN) ? _M : 0.0;
-                S[12] += (cT || cN) ? MM : 0.0;
-                S[13] += (cT || cS || cN) ? _M : 0.0;
-                S[14] += cS ? MM : 0.0;
-#endif
+                if (cA) { sC[0] += om; S[0] += MM; S[1] += _M; S[2] += _M; S[3] += _M; S[4] += _M; }
+                if (cC) { sC[1] += om; S[1] += _M; S[5] += MM; S[6] += _M; S[7] += _M; S[8] += _M; }
+                if (cG) { sC[2] += om; S[2] += _M; S[6] += _M; S[9] += MM; S[10] += _M; S[11] += _M; }
+                if (cT) { sC[3] += om; S[3] += _M; S[7] += _M; S[10] += _M; S[12] += MM; S[13] += _M; }
+                if (cS) { sC[4] += om; S[4] += _M; S[8] += _M; S[11] += _M; S[13] += _M; S[14] += MM; }
+                if (cN) {                                                      /* snp:677-682 */
+                    S[0] += MM; S[1] += MM; S[2] += MM; S[3] += MM; S[4] += _M;
+                    S[5] += MM; S[6] += MM; S[7] += MM; S[8] += _M;
+                    S[9] += MM; S[10] += MM; S[11] += _M;
+                    S[12] += MM; S[13] += _M;
+                }
             }
         }
         st.n_overlap = st.n_plp - st.nref - n_ht;
@@ -518,9 +504,11 @@ __device__ __forceinline__ void scanval_of(uint32_t rec, int32_t nplp, int32_t t
     v.trigcols = (rec & CR_TRIG) ? 1 : 0;
     v.items = tc;
     v.ins = (rec & CR_HASINS) ? 1 : 0;
+    v.toodeep = (rec & CR_TOODEEP) ? 1 : 0;
+    v.pad = 0;
 }
 __device__ __forceinline__ void scanval_add(ScanVal &a, const ScanVal &b)
-{ a.depth += b.depth; a.cols += b.cols; a.trigcols += b.trigcols; a.items += b.items; a.ins += b.ins; }
+{ a.depth += b.depth; a.cols += b.cols; a.trigcols += b.trigcols; a.items += b.items; a.ins += b.ins; a.toodeep += b.toodeep; }
 
 /* wave-level inclusive scan of a ScanVal (shuffles), then block-level via LDS */
 __device__ __forceinline__ ScanVal scanval_wave_incl(ScanVal v, int lane)
@@ -529,7 +517,7 @@ __device__ __forceinline__ ScanVal scanval_wave_incl(ScanVal v, int lane)
     for (int d = 1; d < 64; d <<= 1) {
         ScanVal o;
         o.depth = __shfl_up(v.depth, d); o.cols = __shfl_up(v.cols, d); o.trigcols = __shfl_up(v.trigcols, d);
-        o.items = __shfl_up(v.items, d); o.ins = __shfl_up(v.ins, d);
+        o.items = __shfl_up(v.items, d); o.ins = __shfl_up(v.ins, d); o.toodeep = __shfl_up(v.toodeep, d); o.pad = 0;
         if (lane >= d) scanval_add(v, o);
     }
     return v;
@@ -543,7 +531,7 @@ k_scan_reduce(int L, const uint32_t *colrec, const int32_t *nplp,
     __shared__ ScanVal ws[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int base = blockIdx.x * SCAN_CHUNK;
-    ScanVal acc = {0, 0, 0, 0, 0}, v;
+    ScanVal acc = {0, 0, 0, 0, 0, 0, 0}, v;
     for (int k = 0; k < SCAN_CHUNK / 256; k++) {
         const int i = base + k * 256 + (int)threadIdx.x;
         if (i < L) { scanval_of(colrec[i], nplp[i], trigcnt[i], v); scanval_add(acc, v); }
@@ -566,16 +554,16 @@ k_scan_partials(ScanVal *partial, int nchunks)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nt = blockDim.x;
     const int per = (nchunks + nt - 1) / nt;
     const int b = (int)threadIdx.x * per, e = (b + per < nchunks) ? b + per : nchunks;
-    ScanVal acc = {0, 0, 0, 0, 0};
+    ScanVal acc = {0, 0, 0, 0, 0, 0, 0};
     for (int i = b; i < e; i++) scanval_add(acc, partial[i]);
     ScanVal inc = scanval_wave_incl(acc, lane);
     if (lane == 63) ws[w] = inc;
     __syncthreads();
-    ScanVal run = {0, 0, 0, 0, 0};
+    ScanVal run = {0, 0, 0, 0, 0, 0, 0};
     for (int j = 0; j < w; j++) scanval_add(run, ws[j]);
     /* exclusive prefix of this thread = run + inc - acc */
     run.depth += inc.depth - acc.depth; run.cols += inc.cols - acc.cols; run.trigcols += inc.trigcols - acc.trigcols;
-    run.items += inc.items - acc.items; run.ins += inc.ins - acc.ins;
+    run.items += inc.items - acc.items; run.ins += inc.ins - acc.ins; run.toodeep += inc.toodeep - acc.toodeep;
     for (int i = b; i < e; i++) { ScanVal v = partial[i]; partial[i] = run; scanval_add(run, v); }
     if ((int)threadIdx.x == nt - 1) partial[nchunks] = run;   /* last thread ends with the grand total */
 }
@@ -592,7 +580,7 @@ k_scan_apply(int L, const uint32_t *colrec, const int32_t *nplp,
     ScanVal carry = partial[blockIdx.x];
     for (int k = 0; k < SCAN_CHUNK / 256; k++) {
         const int i = base + k * 256 + (int)threadIdx.x;
-        ScanVal v = {0, 0, 0, 0, 0};
+        ScanVal v = {0, 0, 0, 0, 0, 0, 0};
         if (i < L) scanval_of(colrec[i], nplp[i], trigcnt[i], v);
         ScanVal inc = scanval_wave_incl(v, lane);
         __syncthreads();                               /* ws reuse */
@@ -650,6 +638,33 @@ __global__ void k_epochs(int L, const uint32_t *colrec, const int32_t *nplp, con
         tc = tcj >> 1; td = tdj >> 1; ord = j + 1;
     }
     *n_ep = n;
+}
+
+/* Same result when no column is deeper than MAX_DEPTH (the usual case): the halving
+ * points are then at fixed ordinals (2^20, then every 2^19+1 columns), so each epoch's
+ * prefix lookup is independent; only the tiny td recurrence is sequential. */
+__global__ void __launch_bounds__(256)
+k_epochs_par(int L, const uint32_t *colrec, const int32_t *col_ord, const int64_t *dpre,
+             const ScanVal *totals, Epoch *ep, int *n_ep)
+{
+    const int64_t ncols = totals->cols;
+    int n = 0;
+    if (ncols > 0) n = 1 + (int)((ncols > 1048577) ? (ncols - 1048577 + 524288) / 524289 : 0);
+    if (n > MAX_EPOCHS - 1) n = MAX_EPOCHS - 1;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const int64_t ord = (k == 0) ? 0 : 1048577 + (int64_t)(k - 1) * 524289;
+        const int p = ord_to_pos(col_ord, colrec, L, ord);
+        ep[k].ord_start = ord; ep[k].tc_start = (k == 0) ? 0 : 524288; ep[k].dpre_start = dpre[p]; ep[k].td_start = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t td = 0;
+        for (int k = 0; k + 1 < n; k++) {
+            td = (td + ep[k + 1].dpre_start - ep[k].dpre_start) >> 1;
+            ep[k + 1].td_start = td;
+        }
+        *n_ep = n;
+    }
 }
 
 /* over-depth test per column (snp:1673-1681) + compaction of the trigger and
@@ -1271,19 +1286,21 @@ __global__ void k_replay_general(DBatch B, const DParams *__restrict__ P, const 
 
 /* (c): back-fill of every read under a trigger column (snp:1870-1879), bases before
  * the entry's own qpos (the entry's own byte is handled by apply_col). */
-__global__ void k_restore(DBatch B, const DParams *__restrict__ P, int n_trig, const int32_t *trigcol_pos,
-                          const int32_t *__restrict__ pos_mn2, uint8_t *__restrict__ out)
+__global__ void __launch_bounds__(64)
+k_restore(DBatch B, const DParams *__restrict__ P, int n_trig, const int32_t *trigcol_pos,
+          const int32_t *__restrict__ pos_mn2, uint8_t *__restrict__ out)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    /* one 64-lane workgroup per trigger column, lanes over its candidate reads */
+    const int t = blockIdx.x;
     if (t >= n_trig) return;
     const int c = trigcol_pos[t], apos = B.p0 + c, tile = c >> 6;
     const int lo = B.tile_lo[tile], hi = B.tile_hi[tile];
     const int mn2 = pos_mn2[c], qcap = P->qcap;
     const bool any_pres = P->any_preserve != 0, softclip = P->softclip != 0;
-    for (int r = lo; r < hi; r++) {
+    for (int r = lo + (int)threadIdx.x; r < hi; r += blockDim.x) {
         const int rp = B.pos[r];
         if (!(apos >= rp && apos < B.end[r])) continue;
-        if (softclip && apos == rp) continue;              /* done in k_replay_flat, before the binning */
+        if (softclip && apos == rp) continue;              /* done by the replay pass, before the binning */
         Entry e;
         resolve_entry(B, r, apos, e);
         const int64_t so = B.seq_off[r];
@@ -1296,10 +1313,10 @@ __global__ void k_restore(DBatch B, const DParams *__restrict__ P, int n_trig, c
     }
 }
 
-/* (d) + per-read flags: one thread per read */
-__global__ void k_readfix(DBatch B, const DParams *__restrict__ P, const uint32_t *__restrict__ colrec,
+/* (d) + per-read flags: one thread per read; reads whose keep_qual is set are queued */
+__global__ void k_readfix(DBatch B, const uint32_t *__restrict__ colrec,
                           const uint8_t *__restrict__ keepf, const uint8_t *__restrict__ b15f,
-                          uint8_t *__restrict__ out, uint8_t *__restrict__ rflags)
+                          uint8_t *__restrict__ rflags, int32_t *__restrict__ kept, int *__restrict__ n_kept)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= B.n_reads) return;
@@ -1321,14 +1338,25 @@ __global__ void k_readfix(DBatch B, const DParams *__restrict__ P, const uint32_
             }
         }
     }
-    if (keep) {                                            /* snp:1939: memcpy of the capped copy */
-        const int qcap = P->qcap;
-        const bool any_pres = P->any_preserve != 0;
+    if (keep && lq > 0) kept[atomicAdd(n_kept, 1)] = (int32_t)r;
+    rflags[r] = (uint8_t)((keep ? 1 : 0) | (b15f[r] ? 2 : 0));
+}
+
+/* snp:1939: a kept read gets the (capped) pileup copy back; one wave per queued read */
+__global__ void __launch_bounds__(256)
+k_keepfix(DBatch B, const DParams *__restrict__ P, const int32_t *__restrict__ kept,
+          const int *__restrict__ n_kept, uint8_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int nw = (int)(gridDim.x * (blockDim.x >> 6));
+    const int n = *n_kept, qcap = P->qcap;
+    const bool any_pres = P->any_preserve != 0;
+    for (int i = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); i < n; i += nw) {
+        const ReadRec rr = B.rr[kept[i]];
         const uint8_t *qin = B.quals + rr.so;
         uint8_t *q2 = out + rr.so;
-        for (int x = 0; x < lq; x++) q2[x] = cap_q2(P, qcap, any_pres, qin[x]) & 0x7f;
+        for (int x = lane; x < rr.lq; x += 64) q2[x] = cap_q2(P, qcap, any_pres, qin[x]) & 0x7f;
     }
-    rflags[r] = (uint8_t)((keep ? 1 : 0) | (b15f[r] ? 2 : 0));
 }
 
 /* ------------------------------------------------------------------------ */

@@ -22,6 +22,14 @@ def test_chr20_presets(product, level):
     assert_parity(gpu_engine, ca.preset_params(level), hb)
 
 
+@pytest.mark.parametrize("level", [1, 5])
+def test_chr20_running_depth_epochs(product, level):
+    """> 2^20 columns: the running depth average is halved (snp:1684-1687) inside the contig."""
+    hb = synth_batch("chr20", 0.04)
+    assert_parity(gpu_engine, ca.preset_params(level), hb)
+    assert_parity(gpu_engine, ca.preset_params(level, over_depth=1.05), hb, check_columns=False)
+
+
 def test_ce_like(product):
     assert_parity(gpu_engine, ca.preset_params(1), synth_batch("ce", 1.0))
 
