@@ -128,9 +128,22 @@ def main():
     n_cig = int(hb.cig_off[-1])
     algo_total = 3.0 * hb.n_bases + 32.0 * hb.n_reads + 8.0 * n_cig
     kernel_ms_total = sum(v[0] / v[2] for v in ktimes.values())
+    # HBM traffic of that kernel from rocprofv3 PMC counters (FETCH_SIZE + WRITE_SIZE, separate
+    # passes, same command, committed under profiles/): per launch, bytes; None when not measured
+    traffic = None
+    try:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1:]:
+            kk = json.load(open(f))["kernels"]
+            key = [k for k in kk if k.split("<")[0] == dom[0]]
+            if key and args.workload == "chr20" and args.scale == 1.0:
+                t = kk[key[0]]
+                traffic = round((t["FETCH_SIZE_KB_per_launch"] + t["WRITE_SIZE_KB_per_launch"]) * 1024)
+    except Exception:
+        traffic = None
     roofline = {
         "bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
         "kernel_ms": round(dom_ms, 3),
         "pipeline_achieved": round(algo_total / (kernel_ms_total * 1e-3) / 1e9, 2),
         "pipeline_frac": round(algo_total / (kernel_ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
