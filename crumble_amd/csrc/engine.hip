@@ -148,10 +148,6 @@ static int fill_dparams(const crumble_params *p, DParams *d)
     }
     crumble_init_bins(p, d->bin2);
     /* fences */
-    if (p->min_qual_A != 0 && p->min_qual_B != 0) {
-        g_last_error = "running consensus modes A (-q) and B (-Q) together is not supported yet";
-        return CRUMBLE_EINVAL;
-    }
     if (p->qcap < 0 || p->qcap > 100 || p->qlow < 0 || p->qlow > 127 || p->qhigh < 0 || p->qhigh > 127) {
         g_last_error = "qcap must be in 0..100 and qlow/qhigh in 0..127 (SURVEY.md Q5/Q13)";
         return CRUMBLE_EINVAL;
@@ -510,8 +506,10 @@ extern "C" int crumble_hip_run(crumble_hip *h)
         const bool modeB = h->hparams.min_qual_B != 0;
         unsigned grid = nblk(B.n_tiles, 4);
         if (grid > h->persistent_blocks) grid = h->persistent_blocks;   /* grid-stride over tiles */
-        if (modeB) CRUMBLE_LAUNCH(k_columns<true>, grid, 256, st, B, P, T, colrec, nplp, score, trigcnt, stats);
-        else       CRUMBLE_LAUNCH(k_columns<false>, grid, 256, st, B, P, T, colrec, nplp, score, trigcnt, stats);
+        const bool modeA = h->hparams.min_qual_A != 0;
+        if (modeA && modeB) CRUMBLE_LAUNCH(k_columns<2>, grid, 256, st, B, P, T, colrec, nplp, score, trigcnt, stats);
+        else if (modeB)     CRUMBLE_LAUNCH(k_columns<1>, grid, 256, st, B, P, T, colrec, nplp, score, trigcnt, stats);
+        else                CRUMBLE_LAUNCH(k_columns<0>, grid, 256, st, B, P, T, colrec, nplp, score, trigcnt, stats);
 
         STAGE("scan", 0);
         const int nchunks = (L + SCAN_CHUNK - 1) / SCAN_CHUNK;

@@ -265,13 +265,16 @@ __device__ __forceinline__ void cons_finalize(const DTables *T, double *S, const
 #endif
 
 struct ColState {
-    double S[15], sC[5];
+    double S[15], sC[5];        /* the active consensus (mode B when enabled, else mode A)      */
+    double S2[15], sC2[5];      /* mode A sums when both modes run (MODE 2); unused otherwise   */
     int depth, nN, n_plp, nref, low_mq, indel_cnt, clipped, n_overlap, n_isindel, has_ins;
     unsigned cp;
 };
 
 /* column decisions: snp:1438-1773 minus the passes that need cross-column state */
-template <bool MQ>
+/* MODE 0: consensus A only (snp:1523, plain qualities); 1: B only (snp:1534, mapq-adjusted);
+ * 2: both.  No preset enables A; -q does. */
+template <int MODE>
 __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const DParams *__restrict__ P,
                                            const DTables *__restrict__ T, int c, int apos, bool use_cons,
                                            uint32_t *__restrict__ colrec, int32_t *__restrict__ nplp_out,
@@ -299,33 +302,44 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
     int a1 = 6, a2 = 6;                                /* call1 = call2 = 0 */
     bool cond_score = false;
     if (use_cons) {
-        ConsOut co;
-        cons_finalize(T, st.S, st.sC, st.depth, st.nN, co);
         const unsigned cp = st.cp;
-        const bool het = co.het_phred > 0;
-        if (het) { a1 = co.het_call / 5; a2 = co.het_call % 5; }     /* snp:1537-1542 */
-        else     { a1 = a2 = co.call; }
-        score = het ? co.het_phred : co.phred;                        /* snp:1588-1590 */
-        const int min_qual = MQ ? P->min_qual_B : P->min_qual_A;
-        const int min_indel = MQ ? P->min_indel_B : P->min_indel_A;
-        const double min_discrep = MQ ? P->min_discrep_B : P->min_discrep_A;
-        const bool lowq = score < min_qual;
-        const bool disc = co.discrep >= min_discrep;                  /* float vs double */
-        lds_inc(stats, MQ ? ST_HET_B : ST_HET_A, het);
-        lds_inc(stats, MQ ? ST_HET_QUAL_B : ST_HET_QUAL_A, het && lowq);
-        lds_inc(stats, MQ ? ST_HOM_B : ST_HOM_A, !het);
-        lds_inc(stats, MQ ? ST_HOM_QUAL_B : ST_HOM_QUAL_A, !het && lowq);
-        lds_inc(stats, MQ ? ST_DISCREP_B : ST_DISCREP_A, disc);
-        if (!MQ && (int)cp != (1 << co.call)) perfect = 0;            /* snp:1606 */
-        preserve |= (lowq ? 1 : 0);                                   /* snp:1624-1628 */
-        preserve |= (disc ? 1 : 0);
-        if (!preserve) {                                              /* snp:1633-1645 */
-            /* bit2call (snp:1384): one-hot ACGT* -> 0..4, everything else 99 */
-            const unsigned lowb = cp & 31;
-            const int b2c = (lowb == 1) ? 0 : (lowb == 2) ? 1 : (lowb == 4) ? 2 : (lowb == 8) ? 3 : (lowb == 16) ? 4 : 99;
-            if ((co.het_phred <= 0 && b2c != co.call) || (cp >> 8)) perfect = 0;
+        const unsigned lowb = cp & 31;                 /* bit2call (snp:1384): one-hot ACGT* -> 0..4, else 99 */
+        const int b2c = (lowb == 1) ? 0 : (lowb == 2) ? 1 : (lowb == 4) ? 2 : (lowb == 8) ? 3 : (lowb == 16) ? 4 : 99;
+        ConsOut coA, coB;
+        int hA = 0, sA = 0, hB = 0, sB = 0;
+        const bool useA = MODE != 1, useB = MODE != 0;
+        if (useA) {                                    /* snp:1523-1532, 1576-1583, 1594-1609 */
+            cons_finalize(T, MODE == 2 ? st.S2 : st.S, MODE == 2 ? st.sC2 : st.sC, st.depth, st.nN, coA);
+            const bool het = coA.het_phred > 0;
+            if (het) { a1 = coA.het_call / 5; a2 = coA.het_call % 5; } else { a1 = a2 = coA.call; }
+            hA = het ? coA.het_call : coA.call * 5 + coA.call;
+            sA = het ? coA.het_phred : coA.phred;
+            lds_inc(stats, ST_HET_A, het); lds_inc(stats, ST_HET_QUAL_A, het && sA < P->min_qual_A);
+            lds_inc(stats, ST_HOM_A, !het); lds_inc(stats, ST_HOM_QUAL_A, !het && sA < P->min_qual_A);
+            lds_inc(stats, ST_DISCREP_A, coA.discrep >= P->min_discrep_A);
+            if ((int)cp != (1 << coA.call)) perfect = 0;                 /* snp:1606 */
         }
-        cond_score = score < min_indel;                               /* snp:1719-1720 */
+        if (useB) {                                    /* snp:1534-1543, 1584-1591, 1610-1622 */
+            cons_finalize(T, st.S, st.sC, st.depth, st.nN, coB);
+            const bool het = coB.het_phred > 0;
+            if (het) { a1 = coB.het_call / 5; a2 = coB.het_call % 5; } else { a1 = a2 = coB.call; }
+            hB = het ? coB.het_call : coB.call * 5 + coB.call;
+            sB = het ? coB.het_phred : coB.phred;
+            lds_inc(stats, ST_HET_B, het); lds_inc(stats, ST_HET_QUAL_B, het && sB < P->min_qual_B);
+            lds_inc(stats, ST_HOM_B, !het); lds_inc(stats, ST_HOM_QUAL_B, !het && sB < P->min_qual_B);
+            lds_inc(stats, ST_DISCREP_B, coB.discrep >= P->min_discrep_B);
+        }
+        if (MODE == 2) lds_inc(stats, ST_DIFF, hA != hB);                /* snp:1593 */
+        preserve |= ((MODE == 2 && hA != hB) || (useA && sA < P->min_qual_A) || (useB && sB < P->min_qual_B)) ? 1 : 0;   /* snp:1624 */
+        preserve |= ((useA && coA.discrep >= P->min_discrep_A) || (useB && coB.discrep >= P->min_discrep_B)) ? 1 : 0;   /* float vs double */
+        if (useA && !preserve) {                                         /* snp:1633-1638 */
+            if ((coA.het_phred <= 0 && b2c != coA.call) || (cp >> 8)) perfect = 0;
+        }
+        if (useB && !preserve) {                                         /* snp:1640-1645 */
+            if ((coB.het_phred <= 0 && b2c != coB.call) || (cp >> 8)) perfect = 0;
+        }
+        cond_score = (useA && sA < P->min_indel_A) || (useB && sB < P->min_indel_B);   /* snp:1719-1720 */
+        score = useB ? sB : sA;
     }
     if (P->perfect_col && !perfect) preserve = 1;                     /* snp:1648 */
 
@@ -350,13 +364,14 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
     colrec[c] = rec; score_out[c] = score; trigcnt[c] = tcnt;
 }
 
-template <bool MQ>
-__global__ void __launch_bounds__(256, 4)
+template <int MODE>
+__global__ void __launch_bounds__(256, MODE == 2 ? 3 : 4)
 k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T,
           uint32_t *__restrict__ colrec, int32_t *__restrict__ nplp_out,
           int32_t *__restrict__ score_out, int32_t *__restrict__ trigcnt, u64 *stats)
 {
     __shared__ double sMM[101], s_M[101], sOmq[101];
+    constexpr bool MQ = MODE != 0;                          /* the active consensus uses CONS_MQUAL */
     __shared__ uint8_t sAdj[MQ ? 256 * 128 : 16];
     __shared__ unsigned sStat[32];
     if (threadIdx.x < 32) sStat[threadIdx.x] = 0;
@@ -375,7 +390,7 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
     const int lane = threadIdx.x & 63;
     const int wave0 = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
-    const bool use_cons = MQ ? (P->min_qual_B != 0) : (P->min_qual_A != 0);
+    const bool use_cons = MODE == 0 ? (P->min_qual_A != 0) : (P->min_qual_B != 0);
     const int qcap = P->qcap, min_mqual = P->min_mqual, any_pres = P->any_preserve;
 
     for (int tile = UNIFORM(wave0); tile < B.n_tiles; tile += nwaves) {
@@ -389,6 +404,12 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
         for (int j = 0; j < 15; j++) st.S[j] = 0;
         #pragma unroll
         for (int j = 0; j < 5; j++) st.sC[j] = 0;
+        if (MODE == 2) {
+            #pragma unroll
+            for (int j = 0; j < 15; j++) st.S2[j] = 0;
+            #pragma unroll
+            for (int j = 0; j < 5; j++) st.sC2[j] = 0;
+        }
         st.depth = st.nN = st.n_plp = st.nref = st.low_mq = st.indel_cnt = 0;
         st.clipped = st.n_overlap = st.n_isindel = st.has_ins = 0;
         st.cp = 0;
@@ -465,28 +486,42 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                 int aq = MQ ? sAdj[mq * 128 + (q & 127)] : q;                  /* snp:632-638 */
                 aq = aq < 1 ? 1 : (aq > 100 ? 100 : aq);                       /* snp:641; fence Q5 */
                 const double MM = sMM[aq], _M = s_M[aq], om = sOmq[aq];
+                /* mode A next to mode B (MODE 2): the same entry with the plain (capped) quality */
+                const int aq2 = q < 1 ? 1 : (q > 100 ? 100 : q);
+                const double MM2 = MODE == 2 ? sMM[aq2] : 0.0, _M2 = MODE == 2 ? s_M[aq2] : 0.0, om2 = MODE == 2 ? sOmq[aq2] : 0.0;
                 const bool cm = cov && isM;                                    /* a base call (snp:603) */
                 const bool cA = cm && code == 1, cC = cm && code == 2, cG = cm && code == 4, cT = cm && code == 8;
                 const bool cS = cov && !isM;                                   /* deletion: '*' (snp:609) */
                 const bool cN = cm && !(code == 1 || code == 2 || code == 4 || code == 8);
-                double *S = st.S, *sC = st.sC;
+                double *S = st.S, *sC = st.sC, *S2 = st.S2, *sC2 = st.sC2;
                 st.depth += cov ? 1 : 0;
                 st.nN += cN ? 1 : 0;
-                if (cA) { sC[0] += om; S[0] += MM; S[1] += _M; S[2] += _M; S[3] += _M; S[4] += _M; }
-                if (cC) { sC[1] += om; S[1] += _M; S[5] += MM; S[6] += _M; S[7] += _M; S[8] += _M; }
-                if (cG) { sC[2] += om; S[2] += _M; S[6] += _M; S[9] += MM; S[10] += _M; S[11] += _M; }
-                if (cT) { sC[3] += om; S[3] += _M; S[7] += _M; S[10] += _M; S[12] += MM; S[13] += _M; }
-                if (cS) { sC[4] += om; S[4] += _M; S[8] += _M; S[11] += _M; S[13] += _M; S[14] += MM; }
+                if (cA) { sC[0] += om; S[0] += MM; S[1] += _M; S[2] += _M; S[3] += _M; S[4] += _M;
+                          if (MODE == 2) { sC2[0] += om2; S2[0] += MM2; S2[1] += _M2; S2[2] += _M2; S2[3] += _M2; S2[4] += _M2; } }
+                if (cC) { sC[1] += om; S[1] += _M; S[5] += MM; S[6] += _M; S[7] += _M; S[8] += _M;
+                          if (MODE == 2) { sC2[1] += om2; S2[1] += _M2; S2[5] += MM2; S2[6] += _M2; S2[7] += _M2; S2[8] += _M2; } }
+                if (cG) { sC[2] += om; S[2] += _M; S[6] += _M; S[9] += MM; S[10] += _M; S[11] += _M;
+                          if (MODE == 2) { sC2[2] += om2; S2[2] += _M2; S2[6] += _M2; S2[9] += MM2; S2[10] += _M2; S2[11] += _M2; } }
+                if (cT) { sC[3] += om; S[3] += _M; S[7] += _M; S[10] += _M; S[12] += MM; S[13] += _M;
+                          if (MODE == 2) { sC2[3] += om2; S2[3] += _M2; S2[7] += _M2; S2[10] += _M2; S2[12] += MM2; S2[13] += _M2; } }
+                if (cS) { sC[4] += om; S[4] += _M; S[8] += _M; S[11] += _M; S[13] += _M; S[14] += MM;
+                          if (MODE == 2) { sC2[4] += om2; S2[4] += _M2; S2[8] += _M2; S2[11] += _M2; S2[13] += _M2; S2[14] += MM2; } }
                 if (cN) {                                                      /* snp:677-682 */
                     S[0] += MM; S[1] += MM; S[2] += MM; S[3] += MM; S[4] += _M;
                     S[5] += MM; S[6] += MM; S[7] += MM; S[8] += _M;
                     S[9] += MM; S[10] += MM; S[11] += _M;
                     S[12] += MM; S[13] += _M;
+                    if (MODE == 2) {
+                        S2[0] += MM2; S2[1] += MM2; S2[2] += MM2; S2[3] += MM2; S2[4] += _M2;
+                        S2[5] += MM2; S2[6] += MM2; S2[7] += MM2; S2[8] += _M2;
+                        S2[9] += MM2; S2[10] += MM2; S2[11] += _M2;
+                        S2[12] += MM2; S2[13] += _M2;
+                    }
                 }
             }
         }
         st.n_overlap = st.n_plp - st.nref - n_ht;
-        if (inr) col_decide<MQ>(st, B, P, T, c, apos, use_cons, colrec, nplp_out, score_out, trigcnt, sStat);
+        if (inr) col_decide<MODE>(st, B, P, T, c, apos, use_cons, colrec, nplp_out, score_out, trigcnt, sStat);
     }
     __syncthreads();
     if (threadIdx.x < 32 && sStat[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (u64)sStat[threadIdx.x]);

@@ -30,3 +30,12 @@ def test_emu_empty_and_passthrough(product):
              dict(pos=10, cigar="5S5I", seq="ACGTACGTAC", qual=35)]
     assert_parity(emu_lib.engine, p, HostBatch.from_reads(reads))
     assert_parity(emu_lib.engine, p, HostBatch.from_reads(reads, tid=-1))
+
+
+def test_emu_consensus_modes(product):
+    """-q (mode A), -Q (mode B) and both together (snp:1523-1543, 1593, 1624)."""
+    hb = synth_batch("chr20", 0.0004)
+    assert_parity(emu_lib.engine, ca.preset_params(5, min_qual_A=30, min_qual_B=0), hb)
+    assert_parity(emu_lib.engine, ca.preset_params(5, min_qual_A=30, min_indel_A=60), hb)
+    assert_parity(emu_lib.engine, ca.preset_params(9, min_qual_A=75, min_discrep_A=1.0, keep="25"), hb)
+    assert_parity(emu_lib.engine, ca.preset_params(5, min_qual_A=0, min_qual_B=0), hb)

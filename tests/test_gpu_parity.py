@@ -58,6 +58,9 @@ def test_empty_and_passthrough(product):
 def test_mode_a_and_options(product):
     hb = synth_batch("chr20", 0.002)
     assert_parity(gpu_engine, ca.preset_params(5, min_qual_A=30, min_qual_B=0), hb)
+    assert_parity(gpu_engine, ca.preset_params(5, min_qual_A=30, min_indel_A=60), hb)          # A and B together
+    assert_parity(gpu_engine, ca.preset_params(9, min_qual_A=75, min_discrep_A=1.0, keep="25"), hb)
+    assert_parity(gpu_engine, ca.preset_params(5, min_qual_A=0, min_qual_B=0), hb)            # no consensus at all
     assert_parity(gpu_engine, ca.preset_params(5, binary_qual=1, softclip=1), hb)
     assert_parity(gpu_engine, ca.preset_params(9, keep="37", perfect_col=1), hb)
     assert_parity(gpu_engine, ca.preset_params(3, really_keep="2", indel_fract=0.2), hb)
@@ -118,4 +121,34 @@ def test_large_properties(product):
     for r in pt[:200]:
         a, b = hb.seq_off[r], hb.seq_off[r + 1]
         assert np.array_equal(q[a:b], hb.quals[a:b])
+    eng.close()
+
+
+def test_rccl_stats_allreduce_single_rank(product):
+    """crumble_hip_stats_allreduce: the one collective of the path, through RCCL (world size 1 here;
+    the N>1 semantics are covered by tests/test_shard_gloo.py and bench.py --gpus N)."""
+    import ctypes as C
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    try:
+        rccl = C.CDLL("librccl.so")
+    except OSError:
+        pytest.skip("librccl.so not found")
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    hb = synth_batch("chr20", 0.002)
+    eng = gpu_engine(ca.preset_params(5))
+    _, _, s = eng.contig(hb)
+    before = eng.stats_read()
+    assert np.array_equal(before, s)
+    rc = eng.L.crumble_hip_stats_allreduce(eng.h, comm)
+    assert rc == 0, eng.L.crumble_hip_last_error()
+    assert np.array_equal(eng.stats_read(), before)
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
     eng.close()
