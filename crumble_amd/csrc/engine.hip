@@ -789,3 +789,17 @@ extern "C" int crumble_hip_pblock(crumble_hip *h, int64_t n_reads, const int64_t
     dq.release(); ds.release();
     return CRUMBLE_OK;
 }
+
+extern "C" int crumble_hip_indel_only(crumble_hip *h, int dist, int q, uint8_t *qual_out)
+{
+    if (!h || !h->have_batch || dist < 0 || q < 0 || q > 127 || !qual_out) return CRUMBLE_EINVAL;
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t nb = h->n_bases;
+    if (nb == 0) return CRUMBLE_OK;
+    CRUMBLE_LAUNCH_INDEP(k_indel_only, nblk(nb, 256), 256, h->stream, h->B, h->d_blk_read.as<int32_t>(), dist, q,
+                         h->d_out.as<uint8_t>());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(qual_out, h->d_out.p, (size_t)nb, hipMemcpyDeviceToHost));
+    h->have_run = false;                 /* d_out no longer holds crumble_hip_run's result */
+    return CRUMBLE_OK;
+}

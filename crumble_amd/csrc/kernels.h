@@ -1395,6 +1395,40 @@ k_keepfix(DBatch B, const DParams *__restrict__ P, const int32_t *__restrict__ k
 }
 
 /* ------------------------------------------------------------------------ */
+/* indel_only.c:83-122 as a second mode of the masking pass: a base keeps its quality iff it lies
+ * within +-D query bases of (qpos + 1) of an entry with indel != 0 (the last column of an op that
+ * is followed by I/D) or is_del (every D/N column: qpos is the next base).  One lane per base. */
+__global__ void k_indel_only(DBatch B, const int32_t *__restrict__ blk_read, int D, int Q, uint8_t *__restrict__ out)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= B.n_bases) return;
+    int64_t r = blk_read[g >> 6];
+    while (B.seq_off[r + 1] <= g) r++;
+    const ReadRec rr = B.rr[r];
+    const uint8_t q0 = B.quals[g];
+    if (rr.end <= rr.pos) { out[g] = q0; return; }         /* never reaches a column */
+    const int x = (int)(g - rr.so), lq = rr.lq;
+    bool keep = false;
+    if (!(rr.info & RR_SIMPLE)) {
+        const Seg *segs = B.segs + B.seg_off[r];
+        const int ns = (int)(B.seg_off[r + 1] - B.seg_off[r]);
+        for (int i = 0; i < ns && !keep; i++) {
+            const Seg sg = segs[i];
+            int c = -1;                                    /* qpos of a marking entry */
+            if (seg_type(sg) != SEG_M) c = sg.qstart;
+            else if (sg.indel_after != 0) c = sg.qstart + seg_len(sg) - 1;
+            if (c < 0) continue;
+            int xs = c + 1 - D, xe = c + 1 + D;
+            if (xs < 0) xs = 0;
+            if (xe >= lq) xe = lq - 1;
+            keep = x >= xs && x <= xe;
+            /* an M op followed by an indel may ALSO be preceded by D/N columns: handled by those segs */
+        }
+    }
+    out[g] = keep ? q0 : (uint8_t)Q;
+}
+
+/* ------------------------------------------------------------------------ */
 /* P-block (snp:803-834), one thread per read, in place. */
 __device__ inline void dev_pblock(uint8_t *qual, int len, int level, int qcap, const uint8_t *pq)
 {

@@ -70,6 +70,7 @@ def load_library(path=None, make_default=True):
         "crumble_hip_columns": (i64, [vp, vp, i64]),
         "crumble_hip_mask_lc": (C.c_int, [vp, i64, vp, vp, vp, vp, vp]),
         "crumble_hip_pblock": (C.c_int, [vp, i64, vp, vp]),
+        "crumble_hip_indel_only": (C.c_int, [vp, C.c_int, C.c_int, vp]),
         "crumble_hip_strerror": (C.c_char_p, [C.c_int]),
         "crumble_hip_last_error": (C.c_char_p, []),
     }
@@ -95,7 +96,7 @@ EXPORTED = [
     "crumble_hip_upload", "crumble_hip_run", "crumble_hip_download",
     "crumble_hip_kernel_times", "crumble_hip_stats_devptr", "crumble_hip_stats_reset",
     "crumble_hip_stats_read", "crumble_hip_stats_allreduce", "crumble_hip_columns",
-    "crumble_hip_mask_lc", "crumble_hip_pblock", "crumble_hip_strerror",
+    "crumble_hip_mask_lc", "crumble_hip_pblock", "crumble_hip_indel_only", "crumble_hip_strerror",
     "crumble_hip_last_error",
 ]
 
@@ -211,6 +212,13 @@ class Engine:
         q = np.ascontiguousarray(quals, np.uint8).copy()
         self._chk(self.L.crumble_hip_pblock(self.h, len(so) - 1, _vp(so), _vp(q)), "pblock")
         return q
+
+    def indel_only(self, hb, dist=20, q=37):
+        """indel_only.c: keep +-dist bases around indels, everything else -> q."""
+        self.upload(hb)
+        out = np.empty(max(hb.n_bases, 1), np.uint8)
+        self._chk(self.L.crumble_hip_indel_only(self.h, int(dist), int(q), _vp(out)), "indel_only")
+        return out[:hb.n_bases]
 
     def stats_devptr(self):
         return self.L.crumble_hip_stats_devptr(self.h)

@@ -209,6 +209,12 @@ int crumble_hip_mask_lc(crumble_hip *h, int64_t n, const int64_t *read_idx,
 int crumble_hip_pblock(crumble_hip *h, int64_t n_reads, const int64_t *seq_off,
                        uint8_t *quals /* in/out, host */);
 
+/* indel_only.c (the reference's stand-alone toy, indel_only.c:83-122): keep the qualities
+ * within +-dist query bases of every pileup entry with indel != 0 or is_del (reference:
+ * D = 20), set all other qualities of reads that reach a pileup column to q (reference:
+ * Q = 37).  Uses the batch of the last crumble_hip_upload(). */
+int crumble_hip_indel_only(crumble_hip *h, int dist, int q, uint8_t *qual_out);
+
 const char *crumble_hip_strerror(int err);
 /* Text of the last HIP/RCCL runtime error seen by this thread. */
 const char *crumble_hip_last_error(void);

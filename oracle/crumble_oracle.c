@@ -1043,3 +1043,52 @@ int64_t crumble_oracle_pileup(const crumble_batch *b, int64_t max,
     free(act);
     return out;
 }
+
+/* indel_only.c:83-122: keep qualities within +-D query bases of any pileup entry that has
+ * indel != 0 or is_del, set everything else to Q.  (The tool writes reads in tail order and
+ * silently drops reads that never reach a column; here those are returned unchanged.) */
+int crumble_oracle_indel_only(const crumble_batch *b, int D, int Q, uint8_t *qual_out)
+{
+    int64_t n = b->n_reads, nb = n ? b->seq_off[n] : 0, next = 0, r;
+    oact_t *act = calloc(n + 1, sizeof(*act));
+    uint8_t *mark = calloc(nb + 1, 1);
+    int n_act = 0, pos = 0, i, a, x;
+    if (!act || !mark) { free(act); free(mark); return CRUMBLE_ENOMEM; }
+    memcpy(qual_out, b->quals, nb);
+    for (;;) {
+        while (next < n && !crumble_oracle_in_pileup(b, next)) next++;
+        if (n_act == 0) { if (next >= n) break; if (pos < b->pos[next]) pos = b->pos[next]; }
+        while (next < n && (!crumble_oracle_in_pileup(b, next) || b->pos[next] <= pos)) {
+            if (crumble_oracle_in_pileup(b, next)) {
+                act[n_act].r = next; act[n_act].beg = b->pos[next];
+                act[n_act].end = b->pos[next] + o_reflen(b, next);
+                act[n_act].k = -1; act[n_act].x = act[n_act].y = 0; n_act++;
+            }
+            next++;
+        }
+        for (a = i = 0; i < n_act; i++) if (act[i].end > pos) act[a++] = act[i];
+        n_act = a;
+        if (!n_act) continue;
+        for (i = 0; i < n_act; i++) {
+            plp_t p;
+            int lq;
+            if (act[i].beg > pos) continue;
+            o_resolve_cigar(b, &act[i], pos, &p);
+            lq = o_lqseq(b, p.r);
+            if (p.indel || p.is_del) {                     /* indel_only.c:95-103 */
+                int x_s = p.qpos + 1 - D, x_e = p.qpos + 1 + D;
+                if (x_s < 0) x_s = 0;
+                if (x_e >= lq) x_e = lq - 1;
+                for (x = x_s; x <= x_e; x++) mark[b->seq_off[p.r] + x] = 1;
+            }
+        }
+        pos++;
+    }
+    for (r = 0; r < n; r++) {                              /* indel_only.c:106-121 */
+        if (!crumble_oracle_in_pileup(b, r)) continue;
+        for (x = 0; x < o_lqseq(b, r); x++)
+            if (!mark[b->seq_off[r] + x]) qual_out[b->seq_off[r] + x] = (uint8_t)Q;
+    }
+    free(act); free(mark);
+    return CRUMBLE_OK;
+}

@@ -44,6 +44,8 @@ int crumble_oracle_in_pileup(const crumble_batch *b, int64_t r);
 int64_t crumble_oracle_pileup(const crumble_batch *b, int64_t max,
                               int32_t *col_pos, int64_t *read, int32_t *qpos,
                               int32_t *indel, uint8_t *bits);
+/* indel_only.c:83-122 */
+int crumble_oracle_indel_only(const crumble_batch *b, int D, int Q, uint8_t *qual_out);
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,8 @@ def load():
                                          C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.crumble_oracle_adjust_lut.restype = None
     L.crumble_oracle_adjust_lut.argtypes = [vp]
+    L.crumble_oracle_indel_only.restype = C.c_int
+    L.crumble_oracle_indel_only.argtypes = [C.POINTER(Batch), C.c_int, C.c_int, vp]
     L.crumble_oracle_pileup.restype = i64
     L.crumble_oracle_pileup.argtypes = [C.POINTER(Batch), i64, vp, vp, vp, vp, vp]
     _o = L
@@ -188,3 +190,11 @@ def pileup(hb, maxn=1 << 20):
     return [dict(pos=int(cp[i]), read=int(rd[i]), qpos=int(qp[i]), indel=int(ind[i]),
                  is_del=bits[i] & 1, is_head=(bits[i] >> 1) & 1, is_tail=(bits[i] >> 2) & 1,
                  is_refskip=(bits[i] >> 3) & 1) for i in range(n)]
+
+
+def indel_only(hb, dist=20, q=37):
+    b = hb.struct()
+    out = np.empty(max(hb.n_bases, 1), np.uint8)
+    rc = load().crumble_oracle_indel_only(C.byref(b), dist, q, out.ctypes.data)
+    assert rc == 0
+    return out[:hb.n_bases]

@@ -39,3 +39,17 @@ def test_emu_consensus_modes(product):
     assert_parity(emu_lib.engine, ca.preset_params(5, min_qual_A=30, min_indel_A=60), hb)
     assert_parity(emu_lib.engine, ca.preset_params(9, min_qual_A=75, min_discrep_A=1.0, keep="25"), hb)
     assert_parity(emu_lib.engine, ca.preset_params(5, min_qual_A=0, min_qual_B=0), hb)
+
+
+def test_emu_indel_only(product):
+    """indel_only.c:83-122 (D=20, Q=37) as a mode of the masking pass."""
+    import oracle_lib as O
+    from parity_util import cigar_zoo
+    from test_pileup_cases import CASES
+    for hb in (cigar_zoo(CASES, reps=10), synth_batch("chr20", 0.0004)):
+        eng = emu_lib.engine(ca.preset_params(9))
+        for d, q in ((20, 37), (3, 11)):
+            got = eng.indel_only(hb, d, q)
+            want = O.indel_only(hb, d, q)
+            assert np.array_equal(got, want), (d, q, np.nonzero(got != want)[0][:10])
+        eng.close()

@@ -152,3 +152,13 @@ def test_rccl_stats_allreduce_single_rank(product):
     rccl.ncclCommDestroy.argtypes = [C.c_void_p]
     rccl.ncclCommDestroy(comm)
     eng.close()
+
+
+def test_indel_only_mode(product):
+    """indel_only.c:83-122 on the GPU vs the oracle."""
+    from test_pileup_cases import CASES
+    for hb in (cigar_zoo(CASES, reps=20), synth_batch("chr20", 0.01), synth_batch("hifi", 0.002)):
+        eng = gpu_engine(ca.preset_params(9))
+        for d, q in ((20, 37), (5, 2)):
+            assert np.array_equal(eng.indel_only(hb, d, q), O.indel_only(hb, d, q))
+        eng.close()
