@@ -65,18 +65,40 @@ def main():
     if not os.path.exists(ca.LIB_PATH):
         ca.build_library()
 
-    # ---- synthetic input (no NA12878 BAM offline): one contig per rank ----
+    # ---- synthetic input (no NA12878 BAM offline) ----
+    #  chr20 (default, BASELINE config 2): one chr20-shaped contig per rank -> weak scaling
+    #  wgs   (BASELINE config 5): 24 contigs with GRCh38 lengths x scale, LPT-packed onto the
+    #        ranks (crumble_amd/shard.py) -> strong scaling; no data-path collective either way
+    from crumble_amd import shard
     t0 = time.time()
-    cfg = synth.config(args.workload, scale=args.scale)
-    cfg.seed = cfg.seed + 1000 * rank           # rank r owns "contig r"
-    cfg.tid = rank
-    hb = synth.generate(cfg)
+    batches = []
+    if args.workload == "wgs":
+        sizes = [int(l * args.scale) for l in shard.GRCH38]
+        assign, _ = shard.lpt_pack(sizes, world)
+        for tid in assign[rank]:
+            cfg = synth.config("chr20", scale=1.0)
+            cfg.contig_len = max(sizes[tid], 4 * cfg.read_len + 4096)
+            cfg.seed = 5000 + tid
+            cfg.tid = tid
+            batches.append(synth.generate(cfg))
+        scaling = "strong"
+    else:
+        cfg = synth.config(args.workload, scale=args.scale)
+        cfg.seed = cfg.seed + 1000 * rank       # rank r owns "contig r"
+        cfg.tid = rank
+        batches.append(synth.generate(cfg))
+        scaling = "weak"
     t_gen = time.time() - t0
+    hb = batches[0]
     params = ca.preset_params(args.preset)
 
-    eng = ca.Engine(params, local_rank)         # raises if no GPU (no CPU fallback)
     t0 = time.time()
-    eng.upload(hb)
+    engines = []
+    for b_ in batches:
+        e_ = ca.Engine(params, local_rank)      # raises if no GPU (no CPU fallback)
+        e_.upload(b_)                           # contigs stay resident in HBM
+        engines.append(e_)
+    eng = engines[0]
     t_up = time.time() - t0
 
     def sync_all():
@@ -86,16 +108,19 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        eng.run()
-    eng.stats_reset()
+        for e_ in engines:
+            e_.run()
+    for e_ in engines:
+        e_.stats_reset()
     sync_all()
     t0 = time.perf_counter()
     ktimes = {}
     for _ in range(args.steps):
-        eng.run()                                # launches every kernel + stream sync
-        for name, ms, by in eng.kernel_times():
-            a = ktimes.setdefault(name, [0.0, 0.0, 0])
-            a[0] += ms; a[1] = by; a[2] += 1
+        for e_ in engines:
+            e_.run()                             # launches every kernel + stream sync
+            for name, ms, by in e_.kernel_times():
+                a = ktimes.setdefault(name, [0.0, 0.0, 0])
+                a[0] += ms; a[1] += by; a[2] += 1
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -104,8 +129,8 @@ def main():
         elapsed = float(t.item())
 
     # ---- the one collective of the path: statistics / quality histogram ----
-    stats = eng.stats_read()
-    bases_local = hb.n_bases
+    stats = sum(e_.stats_read() for e_ in engines)
+    bases_local = sum(b_.n_bases for b_ in batches)
     if dist is not None:
         st = torch.from_numpy(stats.copy()).to("cuda")
         dist.all_reduce(st, op=dist.ReduceOp.SUM)
@@ -123,11 +148,10 @@ def main():
     # ---- roofline of the dominant kernel (HIP events on the engine's stream) ----
     dom = max(ktimes.items(), key=lambda kv: kv[1][0])
     dom_ms = dom[1][0] / dom[1][2]
-    dom_bytes = dom[1][1]
+    dom_bytes = dom[1][1] / dom[1][2]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    n_cig = int(hb.cig_off[-1])
-    algo_total = 3.0 * hb.n_bases + 32.0 * hb.n_reads + 8.0 * n_cig
-    kernel_ms_total = sum(v[0] / v[2] for v in ktimes.values())
+    algo_total = sum(3.0 * b_.n_bases + 32.0 * b_.n_reads + 8.0 * int(b_.cig_off[-1]) for b_ in batches)
+    kernel_ms_total = sum(v[0] for v in ktimes.values()) / args.steps
     # HBM traffic of that kernel from rocprofv3 PMC counters (FETCH_SIZE + WRITE_SIZE, separate
     # passes, same command, committed under profiles/): per launch, bytes; None when not measured
     traffic = None
@@ -154,10 +178,14 @@ def main():
         "metric": "Gbases/s quality-quantized, 30x WGS; bit-exact vs reference crumble",
         "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64", "data": "synthetic",
-        "config": {"workload": f"{args.workload}-30x synthetic contig ({cfg.contig_len} bp, "
-                               f"{hb.n_reads} reads, {hb.n_bases} bases per GPU), preset -{args.preset}",
-                   "preset": args.preset, "scale": args.scale, "contigs": world,
+        "scaling": scaling, "vs_baseline": None, "dtype": "u8/f64", "data": "synthetic",
+        "config": {"workload": (f"{args.workload}-30x synthetic contig ({cfg.contig_len} bp, "
+                                f"{hb.n_reads} reads, {hb.n_bases} bases per GPU), preset -{args.preset}"
+                                if args.workload != "wgs" else
+                                f"wgs-30x: 24 synthetic contigs (GRCh38 lengths x {args.scale}), {total_bases} bases "
+                                f"LPT-packed on {world} GPU(s), preset -{args.preset}"),
+                   "preset": args.preset, "scale": args.scale,
+                   "contigs": world if args.workload != "wgs" else 24,
                    "gen_s": round(t_gen, 1), "upload_s": round(t_up, 2)},
         "roofline": roofline,
     }
@@ -187,7 +215,8 @@ def main():
                 out["config"]["verified_bit_exact_on_sample"] = bool(
                     np.array_equal(gq, wq) and np.array_equal(gf, wf) and np.array_equal(gs, ws))
         print(json.dumps(out))
-    eng.close()
+    for e_ in engines:
+        e_.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
