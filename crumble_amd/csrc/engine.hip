@@ -578,7 +578,7 @@ extern "C" int crumble_hip_run(crumble_hip *h)
                                  h->d_blk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(),
                                  h->d_b15f.as<uint8_t>());
         else if (nb > 0) {
-            CRUMBLE_LAUNCH_INDEP(k_replay_flat, nblk((nb + 7) / 8, 256), 256, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
+            CRUMBLE_LAUNCH_INDEP(k_replay_flat, nblk((nb + RPL_NB - 1) / RPL_NB, 256), 256, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
                                  h->d_blk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(),
                                  h->d_b15f.as<uint8_t>());
             if (h->n_slow > 0)

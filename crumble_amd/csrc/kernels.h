@@ -812,15 +812,17 @@ __device__ __forceinline__ unsigned nt16_to_str2(unsigned c16)
     return (c16 == 2) ? 1u : (c16 == 4) ? 2u : (c16 == 8) ? 3u : 0u;
 }
 
-/* add_rep (str_finder.c:34-127) without pads; the utlist list is an ordered array */
-__device__ inline int dev_add_rep(const StrWin &w, int len, int pos, int rlen,
-                                  short *st, short *en, int n, int *overflow)
+/* add_rep (str_finder.c:34-127) without pads; the utlist list is an ordered array whose
+ * tail element is mirrored in registers (ts, te): most calls end at the "already covered by
+ * the tail" test or append without touching older elements */
+__device__ __forceinline__ int dev_add_rep(const StrWin &w, int len, int pos, int rlen,
+                                           short *st, short *en, int n, int &ts, int &te, int *overflow)
 {
-    if (n && st[n - 1] <= pos - rlen * 2 + 1 && en[n - 1] >= pos) return n;   /* :41-45 */
+    if (n && ts <= pos - rlen * 2 + 1 && te >= pos) return n;                /* :41-45 */
     int cp1 = pos + 1 - rlen, cp2 = pos + 1;
     while (cp2 < len && str_code(w, cp1) == str_code(w, cp2)) { cp1++; cp2++; }  /* :62-75 */
     const int el_end = cp2 - 1, el_start = pos + 1 - 2 * rlen;
-    if (n) {                                            /* :106-122 */
+    if (n && te >= el_start) {                          /* :106-122 (the walk stops at once otherwise) */
         int cur = n - 1;
         for (;;) {
             const bool was_head = (cur == 0);
@@ -837,15 +839,15 @@ __device__ inline int dev_add_rep(const StrWin &w, int len, int pos, int rlen,
             cur = prev;
         }
     }
-    if (n < STR_CAP) { st[n] = (short)el_start; en[n] = (short)el_end; n++; }
+    if (n < STR_CAP) { st[n] = (short)el_start; en[n] = (short)el_end; n++; ts = el_start; te = el_end; }
     else *overflow = 1;
     return n;
 }
 
 /* find_STR (str_finder.c:135-189) */
-__device__ inline int dev_find_STR(const StrWin &w, int len, short *st, short *en, int *overflow)
+__device__ __forceinline__ int dev_find_STR(const StrWin &w, int len, short *st, short *en, int *overflow)
 {
-    int n = 0;
+    int n = 0, ts = 0, te = -1;
     uint32_t word = 0;
     for (int i = 0; i < len; i++) {
         word = (word << 2) | (uint32_t)str_code(w, i);
@@ -854,16 +856,19 @@ __device__ inline int dev_find_STR(const StrWin &w, int len, short *st, short *e
                 if (i < 2 * rlen - 1) break;
                 const uint32_t mask = (1u << (2 * rlen)) - 1;
                 if ((word & mask) == ((word >> (2 * rlen)) & mask))
-                    n = dev_add_rep(w, len, i, rlen, st, en, n, overflow);
+                    n = dev_add_rep(w, len, i, rlen, st, en, n, ts, te, overflow);
             }
         } else {                                        /* largest matching period only */
-            for (int rlen = 8; rlen >= 1; rlen--) {
-                const uint32_t mask = (rlen == 8) ? 0xffffu : ((1u << (2 * rlen)) - 1);
-                if ((word & mask) == ((word >> (2 * rlen)) & mask)) {
-                    n = dev_add_rep(w, len, i, rlen, st, en, n, overflow);
-                    break;
-                }
-            }
+            int rl = 0;
+            if      ((word & 0xffffu) == ((word >> 16) & 0xffffu)) rl = 8;
+            else if ((word & 0x3fffu) == ((word >> 14) & 0x3fffu)) rl = 7;
+            else if ((word & 0x0fffu) == ((word >> 12) & 0x0fffu)) rl = 6;
+            else if ((word & 0x03ffu) == ((word >> 10) & 0x03ffu)) rl = 5;
+            else if ((word & 0x00ffu) == ((word >>  8) & 0x00ffu)) rl = 4;
+            else if ((word & 0x003fu) == ((word >>  6) & 0x003fu)) rl = 3;
+            else if ((word & 0x000fu) == ((word >>  4) & 0x000fu)) rl = 2;
+            else if ((word & 0x0003u) == ((word >>  2) & 0x0003u)) rl = 1;
+            if (rl) n = dev_add_rep(w, len, i, rl, st, en, n, ts, te, overflow);
         }
     }
     return n;
@@ -1195,44 +1200,46 @@ __device__ __forceinline__ uint8_t replay_base(const DBatch &B, const DParams *_
     return o.v & 0x7f;                                     /* snp:1093 */
 }
 
-/* Eight consecutive bases per lane.  For a base of a read whose alignment is one match
+/* RPL_NB consecutive bases per lane.  For a base of a read whose alignment is one match
  * op (and no rarely-used option is on) the byte is produced with a handful of selects:
  *   window/back-fill (snp:1880)            -> capped original
  *   preserve, or low-mapq read (snp:1852)  -> original
  *   no column (clip, insertion), skipped   -> original
  *   else (snp:1906-1919)                   -> qhigh if the base is a called allele, else qlow/bin2
  * everything else goes through replay_base(). */
+#define RPL_NB 16        /* consecutive bases per lane */
 __global__ void __launch_bounds__(256)
 k_replay_flat(DBatch B, const DParams *__restrict__ P, const uint32_t *__restrict__ colrec,
               const int32_t *__restrict__ pos_mn2, const int32_t *__restrict__ blk_read,
               uint8_t *__restrict__ out, uint8_t *__restrict__ keepf, uint8_t *__restrict__ b15f)
 {
-    const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * RPL_NB;
     if (g0 >= B.n_bases) return;
-    const int n8 = (B.n_bases - g0 < 8) ? (int)(B.n_bases - g0) : 8;
+    const int nn = (B.n_bases - g0 < RPL_NB) ? (int)(B.n_bases - g0) : RPL_NB;
     const bool any_pres = P->any_preserve != 0;
     const int min_mqual = P->min_mqual;
-    /* phase 1: owning read and column of each of the eight bases (reads are laid out back
-     * to back in file order; at most a few read changes inside eight bases) */
+    /* phase 1: owning read and column of each base (reads are laid out back to back in file
+     * order; at most a few read changes inside RPL_NB bases) */
     int64_t r = blk_read[g0 >> 6];
     while (B.seq_off[r + 1] <= g0) r++;
     const int64_t r0 = r;
     ReadRec rr = B.rr[r];
     bool hm = false;                                       /* is_head low-mapq mark of the current read */
     if (rr.end > rr.pos && (int)(rr.info & 255) <= min_mqual) hm = !(colrec[rr.pos - B.p0] & CR_SKIP);
-    int cidx[8];
-    unsigned slow = 0, hmm = 0, rdelta = 0;                /* bit k / 3 bits per k */
+    int cidx[RPL_NB];
+    unsigned slow = 0, hmm = 0;                            /* bit k */
+    uint64_t rdelta = 0;                                   /* 4 bits per k */
     #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < RPL_NB; k++) {
         cidx[k] = -1;
-        if (k < n8) {
+        if (k < nn) {
             const int64_t g = g0 + k;
             while (g >= rr.so + rr.lq) {                   /* next read (no load unless the read changes) */
                 r++; rr = B.rr[r];
                 hm = false;
                 if (rr.end > rr.pos && (int)(rr.info & 255) <= min_mqual) hm = !(colrec[rr.pos - B.p0] & CR_SKIP);
             }
-            rdelta |= (unsigned)(r - r0) << (3 * k);
+            rdelta |= (uint64_t)(r - r0) << (4 * k);
             if (rr.end > rr.pos) {                         /* in the pileup */
                 if (rr.info & RR_SIMPLE) {
                     const int off = (int)(g - rr.so) - rr.q0;
@@ -1246,34 +1253,42 @@ k_replay_flat(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
             }
         }
     }
-    /* phase 2: the eight column records (consecutive words for the common case) */
-    uint32_t rec[8];
-    if (cidx[0] >= 0 && cidx[7] == cidx[0] + 7) {          /* one read, inside its match op: 32 consecutive bytes */
+    /* phase 2: the column records (consecutive words for the common case) */
+    uint32_t rec[RPL_NB];
+    bool consec = cidx[0] >= 0;
+    #pragma unroll
+    for (int k = 1; k < RPL_NB; k++) consec = consec && cidx[k] == cidx[k - 1] + 1;
+    if (consec) {                                          /* consecutive columns: RPL_NB consecutive words */
         const uint32_t *rc = colrec + cidx[0];
         #pragma unroll
-        for (int k = 0; k < 8; k++) rec[k] = rc[k];
+        for (int k = 0; k < RPL_NB; k++) rec[k] = rc[k];
     } else {
         #pragma unroll
-        for (int k = 0; k < 8; k++) { const uint32_t v = colrec[cidx[k] >= 0 ? cidx[k] : 0]; rec[k] = cidx[k] >= 0 ? v : CR_ALLREFSKIP; }
+        for (int k = 0; k < RPL_NB; k++) { const uint32_t v = colrec[cidx[k] >= 0 ? cidx[k] : 0]; rec[k] = cidx[k] >= 0 ? v : CR_ALLREFSKIP; }
     }
-    uint32_t qw[2] = {0, 0}, bw[2] = {0, 0};
-    if (n8 == 8) {
-        const uint2 q2 = *(const uint2 *)(B.quals + g0), b2 = *(const uint2 *)(B.bases + g0);
-        qw[0] = q2.x; qw[1] = q2.y; bw[0] = b2.x; bw[1] = b2.y;
+    uint32_t qw[RPL_NB / 4], bw[RPL_NB / 4];
+    if (nn == RPL_NB) {
+        const uint4 q4 = *(const uint4 *)(B.quals + g0), b4 = *(const uint4 *)(B.bases + g0);
+        qw[0] = q4.x; qw[1] = q4.y; qw[2] = q4.z; qw[3] = q4.w;
+        bw[0] = b4.x; bw[1] = b4.y; bw[2] = b4.z; bw[3] = b4.w;
     } else {
-        for (int k = 0; k < n8; k++) { qw[k >> 2] |= (uint32_t)B.quals[g0 + k] << (8 * (k & 3)); bw[k >> 2] |= (uint32_t)B.bases[g0 + k] << (8 * (k & 3)); }
+        #pragma unroll
+        for (int k = 0; k < RPL_NB / 4; k++) { qw[k] = 0; bw[k] = 0; }
+        for (int k = 0; k < nn; k++) { qw[k >> 2] |= (uint32_t)B.quals[g0 + k] << (8 * (k & 3)); bw[k >> 2] |= (uint32_t)B.bases[g0 + k] << (8 * (k & 3)); }
     }
     /* phase 3 */
     const int qcap = P->qcap, qhigh = P->qhigh, qlow = P->qlow;
     const bool reduce = P->reduce_qual != 0, binary = P->binary_qual != 0;
-    uint32_t ow[2] = {0, 0};
+    uint32_t ow[RPL_NB / 4];
     #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < RPL_NB / 4; k++) ow[k] = 0;
+    #pragma unroll
+    for (int k = 0; k < RPL_NB; k++) {
         const uint32_t q0 = (qw[k >> 2] >> (8 * (k & 3))) & 255;
         const int base = (bw[k >> 2] >> (8 * (k & 3))) & 15;
         const uint32_t rcd = rec[k];
         const bool skip = (rcd & CR_SKIP) != 0;
-        const int64_t rk = r0 + ((rdelta >> (3 * k)) & 7);
+        const int64_t rk = r0 + (int64_t)((rdelta >> (4 * k)) & 15);
         uint32_t v;
         /* a trigger column is always a window column (k_columns sets both), so its own byte is
          * the capped original whatever the back-fill start: no special case needed here */
@@ -1292,8 +1307,8 @@ k_replay_flat(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
         }
         ow[k >> 2] |= (v & 0x7f) << (8 * (k & 3));
     }
-    if (n8 == 8) { uint2 o2; o2.x = ow[0]; o2.y = ow[1]; *(uint2 *)(out + g0) = o2; }
-    else for (int k = 0; k < n8; k++) out[g0 + k] = (uint8_t)((ow[k >> 2] >> (8 * (k & 3))) & 255);
+    if (nn == RPL_NB) { uint4 o4; o4.x = ow[0]; o4.y = ow[1]; o4.z = ow[2]; o4.w = ow[3]; *(uint4 *)(out + g0) = o4; }
+    else for (int k = 0; k < nn; k++) out[g0 + k] = (uint8_t)((ow[k >> 2] >> (8 * (k & 3))) & 255);
 }
 
 /* the bases that D/N columns report (host-built list), after k_replay_flat */
