@@ -504,12 +504,14 @@ extern "C" int crumble_hip_run(crumble_hip *h)
     if (L > 0) {
         STAGE("k_columns", 2.0 * nb + 32.0 * n + 8.0 * h->n_cigar);
         const bool modeB = h->hparams.min_qual_B != 0;
-        unsigned grid = nblk(B.n_tiles, 4);
-        if (grid > h->persistent_blocks) grid = h->persistent_blocks;   /* grid-stride over tiles */
+        const unsigned kw = KCOL_THREADS / 64;
+        unsigned grid = nblk(B.n_tiles, kw);
+        const unsigned pgrid = (h->persistent_blocks * 4 * (modeB && h->hparams.min_qual_A ? 3 : KCOL_WAVES) / 4 + kw - 1) / kw;
+        if (grid > pgrid) grid = pgrid;                 /* persistent: grid-stride over tiles */
         const bool modeA = h->hparams.min_qual_A != 0;
-        if (modeA && modeB) CRUMBLE_LAUNCH(k_columns<2>, grid, 256, st, B, P, T, colrec, nplp, score, trigcnt, stats);
-        else if (modeB)     CRUMBLE_LAUNCH(k_columns<1>, grid, 256, st, B, P, T, colrec, nplp, score, trigcnt, stats);
-        else                CRUMBLE_LAUNCH(k_columns<0>, grid, 256, st, B, P, T, colrec, nplp, score, trigcnt, stats);
+        if (modeA && modeB) CRUMBLE_LAUNCH(k_columns<2>, grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, stats);
+        else if (modeB)     CRUMBLE_LAUNCH(k_columns<1>, grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, stats);
+        else                CRUMBLE_LAUNCH(k_columns<0>, grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, stats);
 
         STAGE("scan", 0);
         const int nchunks = (L + SCAN_CHUNK - 1) / SCAN_CHUNK;

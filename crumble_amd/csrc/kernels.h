@@ -364,8 +364,12 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
     colrec[c] = rec; score_out[c] = score; trigcnt[c] = tcnt;
 }
 
+#ifndef KCOL_THREADS
+#define KCOL_THREADS 256
+#define KCOL_WAVES 4
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(256, MODE == 2 ? 3 : 4)
+__global__ void __launch_bounds__(KCOL_THREADS, MODE == 2 ? 3 : KCOL_WAVES)
 k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T,
           uint32_t *__restrict__ colrec, int32_t *__restrict__ nplp_out,
           int32_t *__restrict__ score_out, int32_t *__restrict__ trigcnt, u64 *stats)
