@@ -67,7 +67,7 @@ struct crumble_hip {
     DBatch B;
     bool have_batch = false, have_run = false;
     unsigned persistent_blocks = 1024;
-    int64_t n_reads = 0, n_bases = 0, n_cigar = 0, n_slow = 0;
+    int64_t n_reads = 0, n_bases = 0, n_cigar = 0, n_slow = 0, n_segrec = 0;
     ScanVal totals;
     /* timing */
     hipEvent_t ev[MAX_STAGES + 1];
@@ -431,7 +431,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     B.n_bed = b->n_bed > 0 ? b->n_bed : 0;
 
     int e;
-    h->n_slow = (int64_t)slow_g.size();
+    h->n_slow = (int64_t)slow_g.size(); h->n_segrec = (int64_t)sr.size();
     if ((e = up(h, h->d_slow_g, slow_g.data(), slow_g.size())) || (e = up(h, h->d_slow_r, slow_r.data(), slow_r.size())) ||
         (e = up(h, h->d_cix, cix.data(), cix.size())) || (e = up(h, h->d_blk_read, blk_read.data(), (size_t)(nb / 64 + 1))) || (e = up(h, h->d_sr, sr.data(), sr.size())) || (e = up(h, h->d_stile_lo, stile_lo.data(), B.n_tiles)) ||
         (e = up(h, h->d_stile_hi, stile_hi.data(), B.n_tiles)) || (e = up(h, h->d_rr, rr.data(), n)) || (e = up(h, h->d_pos, b->pos, n)) || (e = up(h, h->d_end, end.data(), n)) ||
@@ -509,9 +509,13 @@ extern "C" int crumble_hip_run(crumble_hip *h)
         const unsigned pgrid = (h->persistent_blocks * 4 * (modeB && h->hparams.min_qual_A ? 3 : KCOL_WAVES) / 4 + kw - 1) / kw;
         if (grid > pgrid) grid = pgrid;                 /* persistent: grid-stride over tiles */
         const bool modeA = h->hparams.min_qual_A != 0;
-        if (modeA && modeB) CRUMBLE_LAUNCH(k_columns<2>, grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, stats);
-        else if (modeB)     CRUMBLE_LAUNCH(k_columns<1>, grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, stats);
-        else                CRUMBLE_LAUNCH(k_columns<0>, grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, stats);
+        const bool multi = h->n_segrec > h->n_reads + h->n_reads / 2;     /* long reads: many ops per read */
+#define KCOL_LAUNCH(M) do { if (multi) CRUMBLE_LAUNCH((k_columns<M, true>), grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, stats); \
+                            else       CRUMBLE_LAUNCH((k_columns<M, false>), grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, stats); } while (0)
+        if (modeA && modeB) KCOL_LAUNCH(2);
+        else if (modeB)     KCOL_LAUNCH(1);
+        else                KCOL_LAUNCH(0);
+#undef KCOL_LAUNCH
 
         STAGE("scan", 0);
         const int nchunks = (L + SCAN_CHUNK - 1) / SCAN_CHUNK;
@@ -547,7 +551,7 @@ extern "C" int crumble_hip_run(crumble_hip *h)
                              trigcol_pos, trigcol_off, inscol_pos, stats);
         if (n_ins > 0) {
             STAGE("k_inshist", 0);
-            CRUMBLE_LAUNCH_INDEP(k_inshist, nblk(n_ins, 64), 64, st, B, P, n_ins, inscol_pos, colrec, nplp, stats);
+            CRUMBLE_LAUNCH(k_inshist, n_ins, 64, st, B, P, n_ins, inscol_pos, colrec, nplp, stats);
         }
         if (n_trig > 0) {
             STAGE("k_emit", 0);

@@ -368,7 +368,8 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
 #define KCOL_THREADS 256
 #define KCOL_WAVES 4
 #endif
-template <int MODE>
+/* MULTI: the batch has many multi-op reads (long reads): skip a read's other ops cheaply */
+template <int MODE, bool MULTI>
 __global__ void __launch_bounds__(KCOL_THREADS, MODE == 2 ? 3 : KCOL_WAVES)
 k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T,
           uint32_t *__restrict__ colrec, int32_t *__restrict__ nplp_out,
@@ -444,6 +445,8 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                 if (j + u >= hi) break;
                 const int rp = R[u].pos, re = R[u].end, lq = R[u].lq;
                 const unsigned info = R[u].info, ty = SR_TYPE(info);
+                if (MULTI && (re <= c0 || rp > c1))
+                    continue;                             /* another op of a multi-op read that overlaps the tile (uniform) */
                 const int mq = (int)(info & 255);
                 const bool cov = inr && apos >= rp && apos < re;
                 const bool isM = ty == SEG_M, isN = ty == SEG_N;               /* uniform */
@@ -740,24 +743,30 @@ __global__ void k_overdepth(int L, uint32_t *colrec, const int32_t *nplp, const 
 /* ------------------------------------------------------------------------ */
 /* Indel-length histogram test (snp:1708-1713, 1777-1819), columns with an
  * insertion only.  One thread per such column. */
-__global__ void k_inshist(DBatch B, const DParams *P, int n_ins, const int32_t *inscol_pos,
-                          uint32_t *colrec, const int32_t *nplp, u64 *stats)
+__global__ void __launch_bounds__(64)
+k_inshist(DBatch B, const DParams *P, int n_ins, const int32_t *inscol_pos,
+          uint32_t *colrec, const int32_t *nplp, u64 *stats)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_ins) return;
+    /* one 64-lane workgroup per column, lanes over its candidate reads */
+    __shared__ int hist[100];
+    __shared__ int s_sz;
+    const int t = blockIdx.x;
+    for (int i = threadIdx.x; i < 100; i += blockDim.x) hist[i] = 0;
+    if (threadIdx.x == 0) s_sz = 0;
+    __syncthreads();
     const int c = inscol_pos[t], apos = B.p0 + c, tile = c >> 6;
     const int lo = B.tile_lo[tile], hi = B.tile_hi[tile];
-    int hist[100];
-    for (int i = 0; i < 100; i++) hist[i] = 0;
-    int indel_sz = 0;
-    for (int r = lo; r < hi; r++) {
+    for (int r = lo + (int)threadIdx.x; r < hi; r += blockDim.x) {
         if (!(apos >= B.pos[r] && apos < B.end[r])) continue;
         Entry e;
         resolve_entry(B, r, apos, e);
         if (e.is_refskip || e.is_head || e.is_tail) continue;
-        if (e.indel > indel_sz) indel_sz = e.indel;
-        if (e.indel >= 0) hist[e.indel < 99 ? e.indel : 99]++;
+        if (e.indel > 0) atomicMax(&s_sz, e.indel);
+        if (e.indel >= 0) atomicAdd(&hist[e.indel < 99 ? e.indel : 99], 1);
     }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    int indel_sz = s_sz;
     if (indel_sz > 100) indel_sz = 100;
     if (!indel_sz) return;
     int qd1 = 0, qd2 = 0, ov = 0;
@@ -1449,27 +1458,54 @@ __global__ void k_indel_only(DBatch B, const int32_t *__restrict__ blk_read, int
 
 /* ------------------------------------------------------------------------ */
 /* P-block (snp:803-834), one thread per read, in place. */
-__device__ inline void dev_pblock(uint8_t *qual, int len, int level, int qcap, const uint8_t *pq)
+/* pblock (snp:803-834) as a streaming state machine: the bytes are read 16 at a time (one
+ * load per 16 steps instead of a dependent byte load per step); a run's value is only known
+ * when it ends, so the run is written back then (the reference's memset). */
+__device__ __forceinline__ void pb_fill(uint8_t *qual, int j, int i, int v)
 {
-    int i, j, qmin = INT_MAX, qmax = INT_MIN, last_qmin = 0, last_qmax = 0, mid;
+    for (int k = j; k < i; k++) qual[k] = (uint8_t)v;
+}
+__device__ inline void dev_pblock(uint8_t *qual, int len, int level, int qcap, const uint8_t *pq, bool any_pres)
+{
+    int j = 0, qmin = INT_MAX, qmax = INT_MIN, last_qmin = 0, last_qmax = 0;
+    bool skipping = false;                 /* inside the `while (preserve_qual[qual[i]]) i++` of snp:823 */
     level *= 2;
-    for (i = j = 0; i < len; i++) {
-        const int q = qual[i];
-        if (qmin > q) qmin = q;
-        if (qmax < q) qmax = q;
-        if (qmax - qmin > level || pq[q]) {
-            mid = (last_qmin + last_qmax) / 2;
-            if (mid > qcap) mid = qcap;
-            for (int k = j; k < i; k++) qual[k] = (uint8_t)mid;
-            while (i < len && pq[qual[i]]) i++;
-            if (i < len) qmin = qmax = qual[i]; else qmin = qmax = 0;
-            j = i;
+    int i = 0;
+    while (i < len) {
+        /* fetch up to 16 bytes: bytes up to the next 16-byte boundary, then whole aligned vectors */
+        uint32_t w[4] = {0, 0, 0, 0};
+        int nbuf;
+        const uintptr_t addr = (uintptr_t)(qual + i);
+        if ((addr & 15) == 0 && i + 16 <= len) {
+            const uint4 v = *(const uint4 *)(qual + i);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; nbuf = 16;
+        } else {
+            nbuf = 16 - (int)(addr & 15);
+            if (nbuf > len - i) nbuf = len - i;
+            for (int k = 0; k < nbuf; k++) w[k >> 2] |= (uint32_t)qual[i + k] << (8 * (k & 3));
         }
-        last_qmin = qmin; last_qmax = qmax;
+        for (int k = 0; k < nbuf; k++, i++) {
+            const int q = (int)((w[k >> 2] >> (8 * (k & 3))) & 255);
+            const bool pres = any_pres && pq[q];
+            if (skipping) {
+                if (pres) continue;                     /* still skipping preserved values */
+                qmin = qmax = q; j = i; skipping = false;
+                last_qmin = qmin; last_qmax = qmax;
+                continue;
+            }
+            if (qmin > q) qmin = q;
+            if (qmax < q) qmax = q;
+            if (qmax - qmin > level || pres) {
+                int mid = (last_qmin + last_qmax) / 2;
+                if (mid > qcap) mid = qcap;
+                pb_fill(qual, j, i, mid);
+                if (pres) { skipping = true; j = i; continue; }
+                qmin = qmax = q; j = i;
+            }
+            last_qmin = qmin; last_qmax = qmax;
+        }
     }
-    mid = (last_qmin + last_qmax) / 2;
-    const int e = i < len ? i : len;
-    for (int k = j; k < e; k++) qual[k] = (uint8_t)mid;
+    if (!skipping) pb_fill(qual, j, len, (last_qmin + last_qmax) / 2);   /* final run: not capped (snp:832) */
 }
 
 __global__ void k_pblock(int64_t n_reads, const int64_t *seq_off, uint8_t *out,
@@ -1478,7 +1514,8 @@ __global__ void k_pblock(int64_t n_reads, const int64_t *seq_off, uint8_t *out,
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     if (rflags && (rflags[r] & 2)) return;            /* flag bit 15: snp:1098 */
-    dev_pblock(out + seq_off[r], (int)(seq_off[r + 1] - seq_off[r]), P->pblock, P->qcap, P->preserve_qual);
+    dev_pblock(out + seq_off[r], (int)(seq_off[r + 1] - seq_off[r]), P->pblock, P->qcap, P->preserve_qual,
+               P->any_preserve != 0);
 }
 
 /* ------------------------------------------------------------------------ */

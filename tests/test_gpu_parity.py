@@ -162,3 +162,24 @@ def test_indel_only_mode(product):
         for d, q in ((20, 37), (5, 2)):
             assert np.array_equal(eng.indel_only(hb, d, q), O.indel_only(hb, d, q))
         eng.close()
+
+
+def test_too_deep_columns(product):
+    """> MAX_DEPTH (20000) entries on a column: `goto too_deep` (snp:1493-1500) -- no consensus, no
+    per-base work, no halving of the running depth average on that column (sequential k_epochs path)."""
+    rng = np.random.default_rng(3)
+    reads = []
+    seqs = ["".join("ACGT"[i] for i in rng.integers(0, 4, 40)) for _ in range(8)]
+    for i in range(300):                       # ordinary coverage before the pile
+        reads.append(dict(pos=1000 + i, cigar="40M", seq=seqs[i % 8], qual=rng.integers(5, 41, 40).astype(np.uint8)))
+    for i in range(20500):                     # the pile: every read covers 1400..1409
+        p0 = 1380 + (i * 21) // 20500
+        reads.append(dict(pos=p0, cigar="30M", seq=seqs[i % 8][:30], qual=(np.arange(30) % 30 + 8).astype(np.uint8),
+                          mapq=int(rng.choice([0, 60]))))
+    for i in range(300):
+        reads.append(dict(pos=1401 + i, cigar="40M", seq=seqs[i % 8], qual=rng.integers(5, 41, 40).astype(np.uint8)))
+    reads.sort(key=lambda r: r["pos"])
+    hb = HostBatch.from_reads(reads)
+    for level in (5, 9):
+        q, f, s = assert_parity(gpu_engine, ca.preset_params(level), hb)
+        assert s[ca.ST_NAMES.index("too_deep")] > 0
