@@ -59,7 +59,7 @@ struct crumble_hip {
            d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax;
     /* per position */
     DevBuf d_colrec, d_nplp, d_score, d_trigcnt, d_dpre, d_col_ord, d_trig_ord, d_item_off,
-           d_ins_ord, d_pos_mn2, d_partial, d_epochs;
+           d_ins_ord, d_pos_mn2, d_partial, d_epochs, d_ht;
     /* work lists */
     DevBuf d_trigcol_pos, d_trigcol_off, d_inscol_pos, d_items, d_colhi, d_ub, d_pmax_partial, d_trig_mx2;
     /* outputs */
@@ -221,7 +221,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
         &h->d_cigar, &h->d_segs, &h->d_bases, &h->d_quals, &h->d_tile_lo, &h->d_tile_hi,
         &h->d_bed_start, &h->d_bed_end, &h->d_bed_pmax, &h->d_colrec, &h->d_nplp, &h->d_score,
         &h->d_trigcnt, &h->d_dpre, &h->d_col_ord, &h->d_trig_ord, &h->d_item_off, &h->d_ins_ord,
-        &h->d_pos_mn2, &h->d_partial, &h->d_epochs, &h->d_trigcol_pos, &h->d_trigcol_off,
+        &h->d_pos_mn2, &h->d_partial, &h->d_epochs, &h->d_ht, &h->d_trigcol_pos, &h->d_trigcol_off,
         &h->d_inscol_pos, &h->d_items, &h->d_colhi, &h->d_ub, &h->d_pmax_partial, &h->d_trig_mx2,
         &h->d_out, &h->d_rflags, &h->d_keepf, &h->d_b15f, &h->d_blk_read, &h->d_kept };
     for (DevBuf *b : all) b->release();
@@ -461,7 +461,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     if ((e = h->d_colrec.reserve(L * 4)) || (e = h->d_nplp.reserve(L * 4)) || (e = h->d_score.reserve(L * 4)) ||
         (e = h->d_trigcnt.reserve(L * 4)) || (e = h->d_dpre.reserve(L * 8)) || (e = h->d_col_ord.reserve(L * 4)) ||
         (e = h->d_trig_ord.reserve(L * 4)) || (e = h->d_item_off.reserve(L * 4)) || (e = h->d_ins_ord.reserve(L * 4)) ||
-        (e = h->d_pos_mn2.reserve(L * 4)) || (e = h->d_partial.reserve((size_t)(nchunks + 2) * sizeof(ScanVal))) ||
+        (e = h->d_pos_mn2.reserve(L * 4)) || (e = h->d_ht.reserve(L * 4)) || (e = h->d_partial.reserve((size_t)(nchunks + 2) * sizeof(ScanVal))) ||
         (e = h->d_epochs.reserve(MAX_EPOCHS * sizeof(Epoch))) ||
         (e = h->d_out.reserve((size_t)(nb ? nb : 1))) || (e = h->d_rflags.reserve((size_t)(n ? n : 1))) ||
         (e = h->d_keepf.reserve((size_t)(n ? n : 1))) || (e = h->d_kept.reserve((size_t)(n ? n : 1) * 4)) || (e = h->d_b15f.reserve((size_t)(n ? n : 1))))
@@ -503,6 +503,9 @@ extern "C" int crumble_hip_run(crumble_hip *h)
 
     if (L > 0) {
         STAGE("k_columns", 2.0 * nb + 32.0 * n + 8.0 * h->n_cigar);
+        uint32_t *ht = h->d_ht.as<uint32_t>();
+        HIPCHK(hipMemsetAsync(ht, 0, (size_t)L * 4, st));
+        CRUMBLE_LAUNCH_INDEP(k_headtail, nblk(n, 256), 256, st, B, ht);
         const bool modeB = h->hparams.min_qual_B != 0;
         const unsigned kw = KCOL_THREADS / 64;
         unsigned grid = nblk(B.n_tiles, kw);
@@ -510,8 +513,8 @@ extern "C" int crumble_hip_run(crumble_hip *h)
         if (grid > pgrid) grid = pgrid;                 /* persistent: grid-stride over tiles */
         const bool modeA = h->hparams.min_qual_A != 0;
         const bool multi = h->n_segrec > h->n_reads + h->n_reads / 2;     /* long reads: many ops per read */
-#define KCOL_LAUNCH(M) do { if (multi) CRUMBLE_LAUNCH((k_columns<M, true>), grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, stats); \
-                            else       CRUMBLE_LAUNCH((k_columns<M, false>), grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, stats); } while (0)
+#define KCOL_LAUNCH(M) do { if (multi) CRUMBLE_LAUNCH((k_columns<M, true>), grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, ht, stats); \
+                            else       CRUMBLE_LAUNCH((k_columns<M, false>), grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, ht, stats); } while (0)
         if (modeA && modeB) KCOL_LAUNCH(2);
         else if (modeB)     KCOL_LAUNCH(1);
         else                KCOL_LAUNCH(0);

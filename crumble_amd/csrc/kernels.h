@@ -364,6 +364,34 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
     colrec[c] = rec; score_out[c] = score; trigcnt[c] = tcnt;
 }
 
+/* is_head / is_tail bookkeeping (snp:1701-1706) is two columns per read, not a per-(column,
+ * read) job: one thread per read adds them into a packed per-position word
+ * (low 16 bits: entries that are head or tail; high 16 bits: "clipped" entries), which
+ * col_decide() reads back.  Counts only matter on columns of depth <= MAX_DEPTH. */
+__global__ void k_headtail(DBatch B, uint32_t *__restrict__ ht)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B.n_reads) return;
+    const ReadRec rr = B.rr[r];
+    if (rr.end <= rr.pos) return;
+    int q_head = rr.q0, q_tail = rr.q0 + (rr.end - rr.pos) - 1;
+    bool head_act = true, tail_act = true;                 /* a ref-skip entry is not counted (snp:1696) */
+    if (!(rr.info & RR_SIMPLE)) {
+        const Seg *segs = B.segs + B.seg_off[r];
+        const int ns = (int)(B.seg_off[r + 1] - B.seg_off[r]);
+        const Seg s0 = segs[0], sl = segs[ns - 1];
+        q_head = s0.qstart; head_act = seg_type(s0) != SEG_N;
+        q_tail = (seg_type(sl) == SEG_M) ? sl.qstart + seg_len(sl) - 1 : sl.qstart; tail_act = seg_type(sl) != SEG_N;
+    }
+    const bool hc = q_head > 0, tc = q_tail + 1 < rr.lq;
+    if (rr.end - rr.pos == 1) {                            /* head and tail on the same column */
+        if (head_act) atomicAdd(&ht[rr.pos - B.p0], 1u + ((hc || tc) ? 0x10000u : 0u));
+    } else {
+        if (head_act) atomicAdd(&ht[rr.pos - B.p0], 1u + (hc ? 0x10000u : 0u));
+        if (tail_act) atomicAdd(&ht[rr.end - 1 - B.p0], 1u + (tc ? 0x10000u : 0u));
+    }
+}
+
 #ifndef KCOL_THREADS
 #define KCOL_THREADS 256
 #define KCOL_WAVES 4
@@ -373,15 +401,16 @@ template <int MODE, bool MULTI>
 __global__ void __launch_bounds__(KCOL_THREADS, MODE == 2 ? 3 : KCOL_WAVES)
 k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T,
           uint32_t *__restrict__ colrec, int32_t *__restrict__ nplp_out,
-          int32_t *__restrict__ score_out, int32_t *__restrict__ trigcnt, u64 *stats)
+          int32_t *__restrict__ score_out, int32_t *__restrict__ trigcnt, const uint32_t *__restrict__ ht,
+          u64 *stats)
 {
-    __shared__ double sMM[101], s_M[101], sOmq[101];
+    __shared__ double sTab[101 * 4];                       /* [aq] -> {MM, _M, 1 - q2p, -} : one 32-byte LDS row */
     constexpr bool MQ = MODE != 0;                          /* the active consensus uses CONS_MQUAL */
     __shared__ uint8_t sAdj[MQ ? 256 * 128 : 16];
     __shared__ unsigned sStat[32];
     if (threadIdx.x < 32) sStat[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < 101; i += blockDim.x) {
-        sMM[i] = T->MMd[i]; s_M[i] = T->_Md[i]; sOmq[i] = T->omq[i];
+        sTab[i * 4] = T->MMd[i]; sTab[i * 4 + 1] = T->_Md[i]; sTab[i * 4 + 2] = T->omq[i]; sTab[i * 4 + 3] = 0;
     }
     if (MQ) {
         /* adj[mapq][qual] for qual < 128 (input and capped qualities are < 128) */
@@ -420,7 +449,7 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
         st.cp = 0;
 
         const int c0 = B.p0 + tile * 64, c1 = c0 + 63;
-        int n_ht = 0;                                    /* entries that are is_head or is_tail */
+        int n_lq0 = 0;                                   /* covered entries of reads without SEQ */
         for (int j = lo; j < hi; j += 4) {
             /* four candidate records (one reference-consuming CIGAR op of one read each);
              * the index is wave-uniform, so these are scalar loads (s_load_dwordx8) */
@@ -434,12 +463,13 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
             for (int u = 0; u < 4; u++) {
                 const unsigned ty = SR_TYPE(R[u].info);
                 const int qp = (ty == SEG_M) ? R[u].qoff + apos : R[u].qoff;
-                const bool cv = inr && apos >= R[u].pos && apos < R[u].end && qp < R[u].lq && ty != SEG_N;
+                const bool cv = inr && (unsigned)(apos - R[u].pos) < (unsigned)(R[u].end - R[u].pos) && qp < R[u].lq;
                 const int64_t a = cv ? R[u].so + qp : 0;
                 cc[u] = B.bases[a]; qq[u] = B.quals[a];
             }
-            /* phase B: accumulate in file order.  Everything that depends only on the record
-             * is wave-uniform (scalar), so the rare cases cost a scalar branch, not vector work. */
+            /* phase B: accumulate in file order.  Everything that depends only on the record is
+             * wave-uniform (scalar), so the rare cases cost a scalar branch, not vector work; the
+             * is_head/is_tail bookkeeping is not here at all (k_headtail). */
             #pragma unroll
             for (int u = 0; u < 4; u++) {
                 if (j + u >= hi) break;
@@ -448,7 +478,7 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                 if (MULTI && (re <= c0 || rp > c1))
                     continue;                             /* another op of a multi-op read that overlaps the tile (uniform) */
                 const int mq = (int)(info & 255);
-                const bool cov = inr && apos >= rp && apos < re;
+                const bool cov = inr && (unsigned)(apos - rp) < (unsigned)(re - rp);
                 const bool isM = ty == SEG_M, isN = ty == SEG_N;               /* uniform */
                 st.n_plp += cov ? 1 : 0;
                 if (mq <= min_mqual) st.low_mq += cov ? 1 : 0;                 /* snp:1663 */
@@ -461,12 +491,7 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                     st.n_isindel += (cov && !isN && isind) ? 1 : 0;
                     st.has_ins |= (cov && !isN && !head && !tail && e_indel > 0) ? 1 : 0;   /* snp:1708 */
                 }
-                if (((info & SR_FIRST) && rp >= c0) || ((info & SR_LAST) && re - 1 <= c1)) {   /* head/tail in this tile */
-                    const bool head = (info & SR_FIRST) && apos == rp, tail = (info & SR_LAST) && apos == re - 1;
-                    const bool act = cov && !isN;
-                    n_ht += (act && (head || tail)) ? 1 : 0;                   /* snp:1705 */
-                    st.clipped += (act && ((head && (info & SR_HEADCLIP)) || (tail && (info & SR_TAILCLIP)))) ? 1 : 0;   /* snp:1701 */
-                }
+                if (lq == 0) n_lq0 += cov ? 1 : 0;
                 if (isN || lq == 0 || !use_cons) continue;                     /* snp:589,594 (uniform) */
                 /* consensus accumulation (snp:594-685).  Each base class is an exec-masked block of
                  * in-place FP64 adds (only the lanes that the record covers with that class take part;
@@ -492,16 +517,15 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                 }
                 int aq = MQ ? sAdj[mq * 128 + (q & 127)] : q;                  /* snp:632-638 */
                 aq = aq < 1 ? 1 : (aq > 100 ? 100 : aq);                       /* snp:641; fence Q5 */
-                const double MM = sMM[aq], _M = s_M[aq], om = sOmq[aq];
+                const double MM = sTab[aq * 4], _M = sTab[aq * 4 + 1], om = sTab[aq * 4 + 2];
                 /* mode A next to mode B (MODE 2): the same entry with the plain (capped) quality */
                 const int aq2 = q < 1 ? 1 : (q > 100 ? 100 : q);
-                const double MM2 = MODE == 2 ? sMM[aq2] : 0.0, _M2 = MODE == 2 ? s_M[aq2] : 0.0, om2 = MODE == 2 ? sOmq[aq2] : 0.0;
+                const double MM2 = MODE == 2 ? sTab[aq2 * 4] : 0.0, _M2 = MODE == 2 ? sTab[aq2 * 4 + 1] : 0.0, om2 = MODE == 2 ? sTab[aq2 * 4 + 2] : 0.0;
                 const bool cm = cov && isM;                                    /* a base call (snp:603) */
                 const bool cA = cm && code == 1, cC = cm && code == 2, cG = cm && code == 4, cT = cm && code == 8;
                 const bool cS = cov && !isM;                                   /* deletion: '*' (snp:609) */
                 const bool cN = cm && !(code == 1 || code == 2 || code == 4 || code == 8);
                 double *S = st.S, *sC = st.sC, *S2 = st.S2, *sC2 = st.sC2;
-                st.depth += cov ? 1 : 0;
                 st.nN += cN ? 1 : 0;
                 if (cA) { sC[0] += om; S[0] += MM; S[1] += _M; S[2] += _M; S[3] += _M; S[4] += _M;
                           if (MODE == 2) { sC2[0] += om2; S2[0] += MM2; S2[1] += _M2; S2[2] += _M2; S2[3] += _M2; S2[4] += _M2; } }
@@ -527,7 +551,12 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                 }
             }
         }
-        st.n_overlap = st.n_plp - st.nref - n_ht;
+        if (inr) {
+            const uint32_t h = ht[c];
+            st.depth = st.n_plp - st.nref - n_lq0;       /* entries that reached the sums (snp:685) */
+            st.clipped = (int)(h >> 16);
+            st.n_overlap = st.n_plp - st.nref - (int)(h & 0xffff);
+        }
         if (inr) col_decide<MODE>(st, B, P, T, c, apos, use_cons, colrec, nplp_out, score_out, trigcnt, sStat);
     }
     __syncthreads();
