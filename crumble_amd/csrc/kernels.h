@@ -416,7 +416,14 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
         /* adj[mapq][qual] for qual < 128 (input and capped qualities are < 128) */
         for (int i = threadIdx.x; i < 256 * 128 / 4; i += blockDim.x) {
             const int m = i >> 5, q4 = (i & 31) * 4;
-            *(uint32_t *)&sAdj[m * 128 + q4] = *(const uint32_t *)&T->adj[m * 256 + q4];
+            uint32_t w = *(const uint32_t *)&T->adj[m * 256 + q4], o = 0;
+            #pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t v = (w >> (8 * k)) & 255;
+                v = v < 1 ? 1 : (v > 100 ? 100 : v);
+                o |= v << (8 * k);
+            }
+            *(uint32_t *)&sAdj[m * 128 + q4] = o;
         }
     }
     __syncthreads();
@@ -464,8 +471,9 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                 const unsigned ty = SR_TYPE(R[u].info);
                 const int qp = (ty == SEG_M) ? R[u].qoff + apos : R[u].qoff;
                 const bool cv = inr && (unsigned)(apos - R[u].pos) < (unsigned)(R[u].end - R[u].pos) && qp < R[u].lq;
-                const int64_t a = cv ? R[u].so + qp : 0;
-                cc[u] = B.bases[a]; qq[u] = B.quals[a];
+                const uint8_t *bp = B.bases + R[u].so, *qp8 = B.quals + R[u].so;   /* wave-uniform bases */
+                const unsigned a = cv ? (unsigned)qp : 0u;                          /* 32-bit lane offset */
+                cc[u] = bp[a]; qq[u] = qp8[a];
             }
             /* phase B: accumulate in file order.  Everything that depends only on the record is
              * wave-uniform (scalar), so the rare cases cost a scalar branch, not vector work; the
@@ -498,7 +506,7 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                  * the block is skipped when there is none), so every genotype sum sees exactly its own
                  * addends, in file order, and the 20 running sums never leave their registers. */
                 const int e_qpos = isM ? R[u].qoff + apos : R[u].qoff;
-                const bool inq = e_qpos < lq;                                  /* fence: read ends in D/N */
+                const bool inq = isM || e_qpos < lq;                           /* fence: read ends in D/N (uniform for M) */
                 int q = inq ? (int)qq[u] : 0;
                 if (any_pres) q = (q > qcap && !P->preserve_qual[q]) ? qcap : q;   /* cap_quality snp:1325 */
                 else          q = q > qcap ? qcap : q;
@@ -515,8 +523,8 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                             if (qi < lq && P->preserve_qual[cap_q(P, B.quals[R[u].so + qi])]) st.cp |= 1u << 4;
                         }
                 }
-                int aq = MQ ? sAdj[mq * 128 + (q & 127)] : q;                  /* snp:632-638 */
-                aq = aq < 1 ? 1 : (aq > 100 ? 100 : aq);                       /* snp:641; fence Q5 */
+                /* snp:632-638; sAdj is stored already clamped to 1..100 (snp:641; fence Q5) */
+                int aq = MQ ? (int)sAdj[mq * 128 + (q & 127)] : (q < 1 ? 1 : (q > 100 ? 100 : q));
                 const double MM = sTab[aq * 4], _M = sTab[aq * 4 + 1], om = sTab[aq * 4 + 2];
                 /* mode A next to mode B (MODE 2): the same entry with the plain (capped) quality */
                 const int aq2 = q < 1 ? 1 : (q > 100 ? 100 : q);
@@ -526,7 +534,6 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                 const bool cS = cov && !isM;                                   /* deletion: '*' (snp:609) */
                 const bool cN = cm && !(code == 1 || code == 2 || code == 4 || code == 8);
                 double *S = st.S, *sC = st.sC, *S2 = st.S2, *sC2 = st.sC2;
-                st.nN += cN ? 1 : 0;
                 if (cA) { sC[0] += om; S[0] += MM; S[1] += _M; S[2] += _M; S[3] += _M; S[4] += _M;
                           if (MODE == 2) { sC2[0] += om2; S2[0] += MM2; S2[1] += _M2; S2[2] += _M2; S2[3] += _M2; S2[4] += _M2; } }
                 if (cC) { sC[1] += om; S[1] += _M; S[5] += MM; S[6] += _M; S[7] += _M; S[8] += _M;
@@ -538,6 +545,7 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                 if (cS) { sC[4] += om; S[4] += _M; S[8] += _M; S[11] += _M; S[13] += _M; S[14] += MM;
                           if (MODE == 2) { sC2[4] += om2; S2[4] += _M2; S2[8] += _M2; S2[11] += _M2; S2[13] += _M2; S2[14] += MM2; } }
                 if (cN) {                                                      /* snp:677-682 */
+                    st.nN++;
                     S[0] += MM; S[1] += MM; S[2] += MM; S[3] += MM; S[4] += _M;
                     S[5] += MM; S[6] += MM; S[7] += MM; S[8] += _M;
                     S[9] += MM; S[10] += MM; S[11] += _M;
