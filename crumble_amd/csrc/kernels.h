@@ -1271,9 +1271,9 @@ k_replay_flat(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
     /* phase 1: owning read and column of each base (reads are laid out back to back in file
      * order; at most a few read changes inside RPL_NB bases) */
     int64_t r = blk_read[g0 >> 6];
-    while (B.seq_off[r + 1] <= g0) r++;
-    const int64_t r0 = r;
     ReadRec rr = B.rr[r];
+    while (g0 >= rr.so + rr.lq) { r++; rr = B.rr[r]; }    /* at most a few steps inside a 64-base block */
+    const int64_t r0 = r;
     bool hm = false;                                       /* is_head low-mapq mark of the current read */
     if (rr.end > rr.pos && (int)(rr.info & 255) <= min_mqual) hm = !(colrec[rr.pos - B.p0] & CR_SKIP);
     int cidx[RPL_NB];
