@@ -502,10 +502,11 @@ extern "C" int crumble_hip_run(crumble_hip *h)
     HIPCHK(hipMemsetAsync(d_overflow, 0, 16, st));      /* [0] overflow, [1] n_epochs, [2] n_kept */
 
     if (L > 0) {
-        STAGE("k_columns", 2.0 * nb + 32.0 * n + 8.0 * h->n_cigar);
+        STAGE("k_headtail", 0);
         uint32_t *ht = h->d_ht.as<uint32_t>();
         HIPCHK(hipMemsetAsync(ht, 0, (size_t)L * 4, st));
         CRUMBLE_LAUNCH_INDEP(k_headtail, nblk(n, 256), 256, st, B, ht);
+        STAGE("k_columns", 2.0 * nb + 32.0 * n + 8.0 * h->n_cigar);
         const bool modeB = h->hparams.min_qual_B != 0;
         const unsigned kw = KCOL_THREADS / 64;
         unsigned grid = nblk(B.n_tiles, kw);
