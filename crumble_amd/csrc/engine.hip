@@ -23,6 +23,7 @@
 #include "../../include/crumble_hip.h"
 #include "dev_common.h"
 #include "kernels.h"
+#include "p0_kernels.h"
 
 static thread_local std::string g_last_error;
 extern "C" const char *crumble_hip_last_error(void) { return g_last_error.c_str(); }
@@ -55,7 +56,7 @@ struct crumble_hip {
     DParams hparams;
     DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc;
     /* batch (inputs) */
-    DevBuf d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
+    DevBuf d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
            d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax;
     /* per position */
     DevBuf d_colrec, d_nplp, d_score, d_trigcnt, d_dpre, d_col_ord, d_trig_ord, d_item_off,
@@ -217,6 +218,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     DevBuf *all[] = { &h->d_params, &h->d_tables, &h->d_stats, &h->d_batch_stats, &h->d_misc,
+        &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
         &h->d_slow_g, &h->d_slow_r, &h->d_cix, &h->d_sr, &h->d_stile_lo, &h->d_stile_hi, &h->d_rr, &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
         &h->d_cigar, &h->d_segs, &h->d_bases, &h->d_quals, &h->d_tile_lo, &h->d_tile_hi,
         &h->d_bed_start, &h->d_bed_end, &h->d_bed_pmax, &h->d_colrec, &h->d_nplp, &h->d_score,
@@ -231,35 +233,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
 }
 
 /* ------------------------------------------------------------- P0 expand */
-static inline int cig_type(int op) { return (0x3C1A7 >> (op << 1)) & 3; }
-static inline bool is_mdnx(int op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
-
-/* bam_pileup1_t.indel on the last column of ref-op k (htslib resolve_cigar2's
- * peek at the next op) */
-static int indel_after(const uint32_t *cig, int n, int k)
-{
-    if (k + 1 >= n) return 0;
-    int op = cig[k] & 15, op2 = cig[k + 1] & 15, l2 = (int)(cig[k + 1] >> 4), indel = 0, j;
-    if (op2 == 2 && op != 2) {
-        indel = -l2;
-        for (j = k + 2; j < n; j++) { if ((cig[j] & 15) == 2) indel -= (int)(cig[j] >> 4); else break; }
-    } else if (op2 == 1) {
-        indel = l2;
-        for (j = k + 2; j < n; j++) {
-            int o = cig[j] & 15;
-            if (o == 1) indel += (int)(cig[j] >> 4); else if (o != 6) break;
-        }
-    } else if (op2 == 6 && k + 2 < n) {
-        int l3 = 0;
-        for (j = k + 2; j < n; j++) {
-            int o = cig[j] & 15;
-            if (o == 1) l3 += (int)(cig[j] >> 4);
-            else if (o == 2 || o == 0 || o == 3 || o == 7 || o == 8) break;
-        }
-        if (l3 > 0) indel = l3;
-    }
-    return indel;
-}
+static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b > 0 ? (n + b - 1) / b : 1); }
 
 template <class T>
 static int up(crumble_hip *h, DevBuf &d, const T *src, size_t n)
@@ -270,208 +244,159 @@ static int up(crumble_hip *h, DevBuf &d, const T *src, size_t n)
     return CRUMBLE_OK;
 }
 
+/* in-place inclusive prefix max of an int32 device array (chunked; used for the search keys) */
+static int prefix_max(crumble_hip *h, int32_t *v, int64_t n)
+{
+    if (n <= 0) return CRUMBLE_OK;
+    const int chunk = 2048, nch = (int)((n + chunk - 1) / chunk);
+    int e = h->d_pmax_partial.reserve((size_t)(nch + 2) * 4);
+    if (e) return e;
+    int32_t *pp = h->d_pmax_partial.as<int32_t>();
+    CRUMBLE_LAUNCH_INDEP(k_pmax_reduce, nblk(nch, 64), 64, h->stream, (int)n, v, pp, nch, chunk);
+    CRUMBLE_LAUNCH_INDEP(k_pmax_partials, 1, 1, h->stream, pp, nch);
+    CRUMBLE_LAUNCH_INDEP(k_pmax_apply, nblk(nch, 64), 64, h->stream, (int)n, v, pp, nch, chunk);
+    return CRUMBLE_OK;
+}
+
+/* Copies the raw batch to the device and expands it there (p0_kernels.h): no per-read host work. */
 extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
 {
     if (!h || !b || b->n_reads < 0) return CRUMBLE_EINVAL;
     HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
     const int64_t n = b->n_reads;
     const int64_t nb = n ? b->seq_off[n] : 0, nc = n ? b->cig_off[n] : 0;
     if (n >= (int64_t)INT_MAX - 64) { g_last_error = "more than 2^31 reads in one batch"; return CRUMBLE_EINVAL; }
+    if (nb < 0 || nc < 0) { g_last_error = "negative total length"; return CRUMBLE_EINVAL; }
     h->have_batch = false; h->have_run = false;
+    int e;
 
-    std::vector<int32_t> end(n + 1);
-    std::vector<uint8_t> inplp(n + 1);
-    std::vector<int64_t> seg_off(n + 1);
-    std::vector<Seg> segs;
-    segs.reserve((size_t)(n + n / 4 + 16));
-    int64_t first = -1;
-    int32_t last_pos = INT_MIN, max_end = INT_MIN, p0 = 0;
-    for (int64_t r = 0; r < n; r++) {
-        const uint32_t *cig = b->cigar + b->cig_off[r];
-        const int ncg = (int)(b->cig_off[r + 1] - b->cig_off[r]);
-        const int64_t lq = b->seq_off[r + 1] - b->seq_off[r];
-        seg_off[r] = (int64_t)segs.size();
-        end[r] = b->pos[r];
-        inplp[r] = 0;
-        if (lq < 0 || ncg < 0) { g_last_error = "negative read or cigar length"; return CRUMBLE_EINVAL; }
-        /* pileup_callback routing (snp:1130-1149) + htslib's default filter */
-        if (b->tid < 0 || (b->flag[r] & (4 | 256 | 512 | 1024))) continue;
-        int x = 0, y = 0; bool any = false;
-        for (int k = 0; k < ncg; k++) {
-            const int op = cig[k] & 15, l = (int)(cig[k] >> 4);
-            if (is_mdnx(op)) {
-                Seg s;
-                s.roff = x; s.qstart = y;
-                s.len_type = (uint32_t)l | ((op == 2 ? SEG_D : op == 3 ? SEG_N : SEG_M) << 30);
-                s.indel_after = indel_after(cig, ncg, k);
-                if (l > 0) { segs.push_back(s); any = true; }
-                x += l;
-                if (op != 2 && op != 3) y += l;
-            } else if (op == 1 || op == 4) y += l;
-        }
-        if (!any || x <= 0) { segs.resize((size_t)seg_off[r]); continue; }
-        if (y != lq && lq != 0) { g_last_error = "CIGAR query length differs from l_qseq"; return CRUMBLE_EINVAL; }
-        if (b->pos[r] < last_pos) return CRUMBLE_EUNSORTED;       /* snp:1075 */
-        if (b->pos[r] < 0 || (int64_t)b->pos[r] + x >= (int64_t)INT_MAX - 64) { g_last_error = "coordinate out of range"; return CRUMBLE_EINVAL; }
-        last_pos = b->pos[r];
-        inplp[r] = 1;
-        end[r] = b->pos[r] + x;
-        if (first < 0) { first = r; p0 = b->pos[r]; }
-        if (end[r] > max_end) max_end = end[r];
+    /* 1. raw arrays */
+    if ((e = up(h, h->d_pos, b->pos, n)) || (e = up(h, h->d_mapq, b->mapq, n)) || (e = up(h, h->d_flag, b->flag, n)) ||
+        (e = up(h, h->d_seq_off, b->seq_off, n + 1)) || (e = up(h, h->d_cig_off, b->cig_off, n + 1)) ||
+        (e = up(h, h->d_cigar, b->cigar, nc)) || (e = up(h, h->d_bases, b->bases, nb)) || (e = up(h, h->d_quals, b->quals, nb)))
+        return e;
+    if (n == 0) {                                   /* seq_off[0] may not exist on the host side */
+        const int64_t z = 0;
+        if ((e = up(h, h->d_seq_off, &z, 1)) || (e = up(h, h->d_cig_off, &z, 1))) return e;
     }
-    seg_off[n] = (int64_t)segs.size();
-    std::vector<ReadRec> rr((size_t)n + 1);
-    for (int64_t r = 0; r < n; r++) {
-        ReadRec &x = rr[r];
-        const int64_t ns = seg_off[r + 1] - seg_off[r];
-        x.pos = b->pos[r]; x.end = end[r]; x.so = b->seq_off[r];
-        x.lq = (int32_t)(b->seq_off[r + 1] - b->seq_off[r]);
-        x.q0 = ns ? segs[(size_t)seg_off[r]].qstart : 0;
-        x.info = b->mapq[r];
-        x.cix = 0;
-        if (inplp[r] && ns == 1 && x.lq > 0) {
-            const Seg &s0 = segs[(size_t)seg_off[r]];
-            if (seg_type(s0) == SEG_M && s0.indel_after == 0) x.info |= RR_SIMPLE;
-        }
+    /* keep-regions: the prefix max of `end` drives the cursor emulation (bed_preserve) */
+    const int n_bed = b->n_bed > 0 ? b->n_bed : 0;
+    std::vector<int32_t> pmax(n_bed ? n_bed : 1);
+    for (int i = 0; i < n_bed; i++) pmax[i] = (i && pmax[i - 1] > b->bed_end[i]) ? pmax[i - 1] : b->bed_end[i];
+    if ((e = up(h, h->d_bed_start, b->bed_start, n_bed)) || (e = up(h, h->d_bed_end, b->bed_end, n_bed)) ||
+        (e = up(h, h->d_bed_pmax, pmax.data(), n_bed)))
+        return e;
+
+    /* 2. classify + validate + count */
+    const int nchunks = (int)((n + P0_CHUNK - 1) / P0_CHUNK);
+    if ((e = h->d_inplp.reserve((size_t)(n + 1))) || (e = h->d_end.reserve((size_t)(n + 1) * 4)) ||
+        (e = h->d_p0cnt.reserve((size_t)(n + 1) * sizeof(P0Cnt))) ||
+        (e = h->d_p0part.reserve((size_t)(nchunks + 2) * sizeof(P0Cnt))) || (e = h->d_misc.reserve(256)))
+        return e;
+    int *d_err = h->d_misc.as<int>() + 8, *d_minmax = d_err + 1, *d_nslow = d_err + 3;
+    const int init[4] = {0, INT_MAX, INT_MIN, 0};
+    HIPCHK(hipMemcpyAsync(d_err, init, sizeof init, hipMemcpyHostToDevice, st));
+    P0Cnt *cnt = h->d_p0cnt.as<P0Cnt>(), *part = h->d_p0part.as<P0Cnt>();
+    P0Cnt tot = {0, 0, 0};
+    int res[4] = {0, INT_MAX, INT_MIN, 0};
+    if (n > 0) {
+        CRUMBLE_LAUNCH_INDEP(k_p0_classify, nblk(n, 256), 256, st, n, (int)b->tid, h->d_pos.as<int32_t>(),
+                             h->d_flag.as<uint16_t>(), h->d_seq_off.as<int64_t>(), h->d_cig_off.as<int64_t>(),
+                             h->d_cigar.as<uint32_t>(), h->d_inplp.as<uint8_t>(), h->d_end.as<int32_t>(), cnt, d_err, d_minmax);
+        CRUMBLE_LAUNCH_INDEP(k_p0_sorted, nblk(n, 256), 256, st, n, h->d_pos.as<int32_t>(), h->d_inplp.as<uint8_t>(), d_err);
+        if (nb > 0) CRUMBLE_LAUNCH_INDEP(k_p0_quals, nblk((nb + 15) / 16, 256), 256, st, nb, h->d_quals.as<uint8_t>(), d_err);
+        CRUMBLE_LAUNCH_INDEP(k_p0scan_reduce, nblk(nchunks, 64), 64, st, n, cnt, part, nchunks);
+        CRUMBLE_LAUNCH_INDEP(k_p0scan_partials, 1, 1, st, part, nchunks);
+        CRUMBLE_LAUNCH_INDEP(k_p0scan_apply, nblk(nchunks, 64), 64, st, n, cnt, part, nchunks);
+        HIPCHK(hipMemcpyAsync(&tot, part + nchunks, sizeof tot, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(res, d_err, sizeof res, hipMemcpyDeviceToHost, st));
     }
-    for (int64_t i = 0; i < nb; i++)
-        if (b->quals[i] & 0x80) { g_last_error = "input quality >= 128 (SURVEY.md Q13)"; return CRUMBLE_EINVAL; }
+    HIPCHK(hipStreamSynchronize(st));               /* sizes of the expanded tables */
+    switch (res[0]) {
+    case 0: break;
+    case P0_ERR_UNSORTED: return CRUMBLE_EUNSORTED;                      /* snp:1075 */
+    case P0_ERR_QUAL:  g_last_error = "input quality >= 128 (SURVEY.md Q13)"; return CRUMBLE_EINVAL;
+    case P0_ERR_QLEN:  g_last_error = "CIGAR query length differs from l_qseq"; return CRUMBLE_EINVAL;
+    case P0_ERR_COORD: g_last_error = "coordinate out of range"; return CRUMBLE_EINVAL;
+    default:           g_last_error = "negative or oversized read / cigar length"; return CRUMBLE_EINVAL;
+    }
+    if (tot.nseg >= (int64_t)INT_MAX - 64) { g_last_error = "too many CIGAR segments in one batch"; return CRUMBLE_EINVAL; }
+    if (tot.ncix >= (int64_t)0xfffffff0u) { g_last_error = "base->column table too large"; return CRUMBLE_EINVAL; }
 
     DBatch &B = h->B;
     memset(&B, 0, sizeof(B));
-    B.n_reads = n; B.n_bases = nb;
-    B.p0 = p0;
-    B.L = (first >= 0) ? (max_end - p0) : 0;
+    const bool any = res[1] != INT_MAX;
+    B.n_reads = n; B.n_bases = nb; B.n_bed = n_bed;
+    B.p0 = any ? res[1] : 0;
+    B.L = any ? res[2] - res[1] : 0;
     B.n_tiles = (B.L + 63) / 64;
-    /* candidate read range per 64-column tile (reads are sorted by pos) */
-    std::vector<int32_t> tile_lo(B.n_tiles + 1), tile_hi(B.n_tiles + 1);
-    {
-        int64_t lo = 0, hi = 0;
-        for (int t = 0; t < B.n_tiles; t++) {
-            const int64_t c0 = (int64_t)p0 + (int64_t)t * 64, c1 = c0 + 63;
-            while (hi < n && (!inplp[hi] || b->pos[hi] <= c1)) hi++;
-            while (lo < hi && (!inplp[lo] || end[lo] <= c0)) lo++;
-            tile_lo[t] = (int32_t)lo; tile_hi[t] = (int32_t)hi;
-        }
-    }
-    /* SegRec list (file order) and its candidate range per tile */
-    std::vector<SegRec> sr;
-    std::vector<int32_t> sr_ppos, sr_pend;            /* parent read's span, for the ranges */
-    sr.reserve(segs.size() + 1); sr_ppos.reserve(segs.size() + 1); sr_pend.reserve(segs.size() + 1);
-    for (int64_t r = 0; r < n; r++) {
-        if (!inplp[r]) continue;
-        const int64_t s0i = seg_off[r], s1i = seg_off[r + 1];
-        const int32_t lq = (int32_t)(b->seq_off[r + 1] - b->seq_off[r]);
-        for (int64_t k = s0i; k < s1i; k++) {
-            const Seg &sg = segs[(size_t)k];
-            SegRec x;
-            const uint32_t ty = seg_type(sg);
-            x.pos = b->pos[r] + sg.roff; x.end = x.pos + seg_len(sg);
-            x.so = b->seq_off[r]; x.lq = lq;
-            x.qoff = (ty == SEG_M) ? sg.qstart - x.pos : sg.qstart;
-            x.indel_after = sg.indel_after;
-            x.info = (uint32_t)b->mapq[r] | (ty << 8);
-            if (k == s0i) { x.info |= SR_FIRST; if (sg.qstart > 0) x.info |= SR_HEADCLIP; }
-            if (k == s1i - 1) {
-                const int qt = (ty == SEG_M) ? sg.qstart + seg_len(sg) - 1 : sg.qstart;
-                x.info |= SR_LAST;
-                if (qt + 1 < lq) x.info |= SR_TAILCLIP;
-            }
-            sr.push_back(x); sr_ppos.push_back(b->pos[r]); sr_pend.push_back(end[r]);
-        }
-    }
-    /* base -> column table for reads with general CIGARs (the replay's lane-per-base pass) */
-    std::vector<int32_t> cix;
-    std::vector<int64_t> slow_g;
-    std::vector<int32_t> slow_r;
-    for (int64_t r = 0; r < n; r++) {
-        if (!inplp[r] || (rr[r].info & RR_SIMPLE)) continue;
-        if (cix.size() + (size_t)rr[r].lq >= 0xfffffff0u) { g_last_error = "base->column table too large"; return CRUMBLE_EINVAL; }
-        rr[r].cix = (uint32_t)cix.size();
-        const size_t base0 = cix.size();
-        cix.resize(base0 + (size_t)rr[r].lq, -1);
-        for (int64_t k = seg_off[r]; k < seg_off[r + 1]; k++) {
-            const Seg &sg = segs[(size_t)k];
-            if (seg_type(sg) != SEG_M) continue;
-            for (int o = 0; o < seg_len(sg) && sg.qstart + o < rr[r].lq; o++)
-                cix[base0 + (size_t)(sg.qstart + o)] = (b->pos[r] + sg.roff + o) - p0;
-        }
-        for (int64_t k = seg_off[r]; k < seg_off[r + 1]; k++) {     /* bases that D/N columns report */
-            const Seg &sg = segs[(size_t)k];
-            if (seg_type(sg) != SEG_M && sg.qstart < rr[r].lq && cix[base0 + (size_t)sg.qstart] != -2) {
-                cix[base0 + (size_t)sg.qstart] = -2;
-                slow_g.push_back(b->seq_off[r] + sg.qstart); slow_r.push_back((int32_t)r);
-            }
-        }
-    }
-    /* first read whose bases reach into each 64-base block of the flat base array */
-    std::vector<int32_t> blk_read((size_t)(nb / 64 + 2));
-    {
-        int64_t r = 0;
-        for (int64_t blk = 0; blk * 64 < nb; blk++) {
-            const int64_t g0 = blk * 64;
-            while (r + 1 < n && b->seq_off[r + 1] <= g0) r++;
-            blk_read[(size_t)blk] = (int32_t)r;
-        }
-    }
-    if (sr.size() >= (size_t)INT_MAX - 64) { g_last_error = "too many CIGAR segments in one batch"; return CRUMBLE_EINVAL; }
-    std::vector<int32_t> stile_lo(B.n_tiles + 1), stile_hi(B.n_tiles + 1);
-    {
-        size_t lo = 0, hi = 0, ns = sr.size();
-        for (int t = 0; t < B.n_tiles; t++) {
-            const int64_t c0 = (int64_t)p0 + (int64_t)t * 64, c1 = c0 + 63;
-            while (hi < ns && sr_ppos[hi] <= c1) hi++;
-            while (lo < hi && sr_pend[lo] <= c0) lo++;
-            stile_lo[t] = (int32_t)lo; stile_hi[t] = (int32_t)hi;
-        }
-    }
-    /* keep-regions: prefix max of `end` drives the cursor emulation */
-    std::vector<int32_t> pmax(b->n_bed > 0 ? b->n_bed : 1);
-    for (int i = 0; i < b->n_bed; i++) pmax[i] = (i && pmax[i - 1] > b->bed_end[i]) ? pmax[i - 1] : b->bed_end[i];
-    B.n_bed = b->n_bed > 0 ? b->n_bed : 0;
+    h->n_reads = n; h->n_bases = nb; h->n_cigar = nc;
+    h->n_segrec = tot.nseg; h->n_slow = tot.nslow;  /* upper bound; the exact count is d_nslow */
 
-    int e;
-    h->n_slow = (int64_t)slow_g.size(); h->n_segrec = (int64_t)sr.size();
-    if ((e = up(h, h->d_slow_g, slow_g.data(), slow_g.size())) || (e = up(h, h->d_slow_r, slow_r.data(), slow_r.size())) ||
-        (e = up(h, h->d_cix, cix.data(), cix.size())) || (e = up(h, h->d_blk_read, blk_read.data(), (size_t)(nb / 64 + 1))) || (e = up(h, h->d_sr, sr.data(), sr.size())) || (e = up(h, h->d_stile_lo, stile_lo.data(), B.n_tiles)) ||
-        (e = up(h, h->d_stile_hi, stile_hi.data(), B.n_tiles)) || (e = up(h, h->d_rr, rr.data(), n)) || (e = up(h, h->d_pos, b->pos, n)) || (e = up(h, h->d_end, end.data(), n)) ||
-        (e = up(h, h->d_mapq, b->mapq, n)) || (e = up(h, h->d_inplp, inplp.data(), n)) ||
-        (e = up(h, h->d_seq_off, b->seq_off, n + 1)) || (e = up(h, h->d_cig_off, b->cig_off, n + 1)) ||
-        (e = up(h, h->d_seg_off, seg_off.data(), n + 1)) || (e = up(h, h->d_cigar, b->cigar, nc)) ||
-        (e = up(h, h->d_segs, segs.data(), segs.size())) || (e = up(h, h->d_bases, b->bases, nb)) ||
-        (e = up(h, h->d_quals, b->quals, nb)) || (e = up(h, h->d_tile_lo, tile_lo.data(), B.n_tiles)) ||
-        (e = up(h, h->d_tile_hi, tile_hi.data(), B.n_tiles)) ||
-        (e = up(h, h->d_bed_start, b->bed_start, B.n_bed)) || (e = up(h, h->d_bed_end, b->bed_end, B.n_bed)) ||
-        (e = up(h, h->d_bed_pmax, pmax.data(), B.n_bed)))
+    /* 3. expanded tables */
+    const size_t ns = (size_t)tot.nseg;
+    const size_t nblkb = (size_t)(nb / 64 + 1);
+    if ((e = h->d_segs.reserve((ns + 1) * sizeof(Seg))) || (e = h->d_sr.reserve((ns + 1) * sizeof(SegRec))) ||
+        (e = h->d_sr_ppos.reserve((ns + 1) * 4)) || (e = h->d_sr_pend.reserve((ns + 1) * 4)) ||
+        (e = h->d_rr.reserve((size_t)(n + 1) * sizeof(ReadRec))) || (e = h->d_seg_off.reserve((size_t)(n + 2) * 8)) ||
+        (e = h->d_cix.reserve(((size_t)tot.ncix + 1) * 4)) || (e = h->d_slow_g.reserve(((size_t)tot.nslow + 1) * 8)) ||
+        (e = h->d_slow_r.reserve(((size_t)tot.nslow + 1) * 4)) || (e = h->d_kpos.reserve((size_t)(n + 1) * 4)) ||
+        (e = h->d_kend.reserve((size_t)(n + 1) * 4)) || (e = h->d_tile_lo.reserve((size_t)(B.n_tiles + 1) * 4)) ||
+        (e = h->d_tile_hi.reserve((size_t)(B.n_tiles + 1) * 4)) || (e = h->d_stile_lo.reserve((size_t)(B.n_tiles + 1) * 4)) ||
+        (e = h->d_stile_hi.reserve((size_t)(B.n_tiles + 1) * 4)) || (e = h->d_blk_read.reserve((nblkb + 1) * 4)))
         return e;
-    HIPCHK(hipStreamSynchronize(h->stream));    /* host vectors die here */
+    if (n == 0) HIPCHK(hipMemsetAsync(h->d_seg_off.p, 0, 16, st));
+    if (n > 0) {
+        CRUMBLE_LAUNCH_INDEP(k_p0_fill, nblk(n, 256), 256, st, n, B.p0, h->d_pos.as<int32_t>(), h->d_mapq.as<uint8_t>(),
+                             h->d_seq_off.as<int64_t>(), h->d_cig_off.as<int64_t>(), h->d_cigar.as<uint32_t>(),
+                             h->d_inplp.as<uint8_t>(), h->d_end.as<int32_t>(), cnt, part + nchunks,
+                             h->d_segs.as<Seg>(), h->d_sr.as<SegRec>(), h->d_sr_ppos.as<int32_t>(), h->d_sr_pend.as<int32_t>(),
+                             h->d_rr.as<ReadRec>(), h->d_seg_off.as<int64_t>(), h->d_cix.as<int32_t>(),
+                             h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(), d_nslow);
+        CRUMBLE_LAUNCH_INDEP(k_p0_keys, nblk(n, 256), 256, st, n, h->d_pos.as<int32_t>(), h->d_end.as<int32_t>(),
+                             h->d_inplp.as<uint8_t>(), h->d_kpos.as<int32_t>(), h->d_kend.as<int32_t>());
+        if ((e = prefix_max(h, h->d_kpos.as<int32_t>(), n)) || (e = prefix_max(h, h->d_kend.as<int32_t>(), n)) ||
+            (e = prefix_max(h, h->d_sr_pend.as<int32_t>(), (int64_t)ns)))
+            return e;
+        if (B.n_tiles > 0) {
+            CRUMBLE_LAUNCH_INDEP(k_p0_tiles, nblk(B.n_tiles, 256), 256, st, B.n_tiles, B.p0, n, h->d_kpos.as<int32_t>(),
+                                 h->d_kend.as<int32_t>(), h->d_tile_lo.as<int32_t>(), h->d_tile_hi.as<int32_t>());
+            CRUMBLE_LAUNCH_INDEP(k_p0_tiles, nblk(B.n_tiles, 256), 256, st, B.n_tiles, B.p0, (int64_t)ns, h->d_sr_ppos.as<int32_t>(),
+                                 h->d_sr_pend.as<int32_t>(), h->d_stile_lo.as<int32_t>(), h->d_stile_hi.as<int32_t>());
+        }
+        if (nb > 0)
+            CRUMBLE_LAUNCH_INDEP(k_p0_blkread, nblk((int64_t)nblkb, 256), 256, st, (int64_t)((nb + 63) / 64), n,
+                                 h->d_seq_off.as<int64_t>(), h->d_blk_read.as<int32_t>());
+    }
     B.pos = h->d_pos.as<int32_t>(); B.end = h->d_end.as<int32_t>();
     B.mapq = h->d_mapq.as<uint8_t>(); B.inplp = h->d_inplp.as<uint8_t>();
     B.seq_off = h->d_seq_off.as<int64_t>(); B.cig_off = h->d_cig_off.as<int64_t>();
     B.seg_off = h->d_seg_off.as<int64_t>(); B.cigar = h->d_cigar.as<uint32_t>();
     B.segs = h->d_segs.as<Seg>(); B.rr = h->d_rr.as<ReadRec>(); B.cix = h->d_cix.as<int32_t>();
-    B.sr = h->d_sr.as<SegRec>(); B.stile_lo = h->d_stile_lo.as<int32_t>(); B.stile_hi = h->d_stile_hi.as<int32_t>(); B.bases = h->d_bases.as<uint8_t>(); B.quals = h->d_quals.as<uint8_t>();
+    B.sr = h->d_sr.as<SegRec>(); B.stile_lo = h->d_stile_lo.as<int32_t>(); B.stile_hi = h->d_stile_hi.as<int32_t>();
+    B.bases = h->d_bases.as<uint8_t>(); B.quals = h->d_quals.as<uint8_t>();
     B.tile_lo = h->d_tile_lo.as<int32_t>(); B.tile_hi = h->d_tile_hi.as<int32_t>();
     B.bed_start = h->d_bed_start.as<int32_t>(); B.bed_end = h->d_bed_end.as<int32_t>();
     B.bed_pmax = h->d_bed_pmax.as<int32_t>();
-    h->n_reads = n; h->n_bases = nb; h->n_cigar = nc;
 
     const size_t L = (size_t)(B.L > 0 ? B.L : 1);
-    const int nchunks = (int)((L + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    const int nsc = (int)((L + SCAN_CHUNK - 1) / SCAN_CHUNK);
     if ((e = h->d_colrec.reserve(L * 4)) || (e = h->d_nplp.reserve(L * 4)) || (e = h->d_score.reserve(L * 4)) ||
         (e = h->d_trigcnt.reserve(L * 4)) || (e = h->d_dpre.reserve(L * 8)) || (e = h->d_col_ord.reserve(L * 4)) ||
         (e = h->d_trig_ord.reserve(L * 4)) || (e = h->d_item_off.reserve(L * 4)) || (e = h->d_ins_ord.reserve(L * 4)) ||
-        (e = h->d_pos_mn2.reserve(L * 4)) || (e = h->d_ht.reserve(L * 4)) || (e = h->d_partial.reserve((size_t)(nchunks + 2) * sizeof(ScanVal))) ||
+        (e = h->d_pos_mn2.reserve(L * 4)) || (e = h->d_ht.reserve(L * 4)) || (e = h->d_partial.reserve((size_t)(nsc + 2) * sizeof(ScanVal))) ||
         (e = h->d_epochs.reserve(MAX_EPOCHS * sizeof(Epoch))) ||
         (e = h->d_out.reserve((size_t)(nb ? nb : 1))) || (e = h->d_rflags.reserve((size_t)(n ? n : 1))) ||
         (e = h->d_keepf.reserve((size_t)(n ? n : 1))) || (e = h->d_kept.reserve((size_t)(n ? n : 1) * 4)) || (e = h->d_b15f.reserve((size_t)(n ? n : 1))))
         return e;
+    HIPCHK(hipStreamSynchronize(st));               /* the caller may free its host buffers */
+    HIPCHK(hipGetLastError());
     h->have_batch = true;
     return CRUMBLE_OK;
 }
 
 /* -------------------------------------------------------------------- run */
-static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b > 0 ? (n + b - 1) / b : 1); }
 
 #define STAGE(name_, bytes_) do { if (h->n_stages < MAX_STAGES) { \
     HIPCHK(hipEventRecord(h->ev[h->n_stages], st)); \
@@ -499,7 +424,7 @@ extern "C" int crumble_hip_run(crumble_hip *h)
     h->n_stages = 0; h->have_run = false;
     memset(&h->totals, 0, sizeof(h->totals));
     HIPCHK(hipMemsetAsync(stats, 0, CRUMBLE_ST_N * 8, st));
-    HIPCHK(hipMemsetAsync(d_overflow, 0, 16, st));      /* [0] overflow, [1] n_epochs, [2] n_kept */
+    HIPCHK(hipMemsetAsync(d_overflow, 0, 16, st));      /* [0] overflow, [1] n_epochs, [2] n_kept; [8..11] belong to upload */
 
     if (L > 0) {
         STAGE("k_headtail", 0);
@@ -593,7 +518,7 @@ extern "C" int crumble_hip_run(crumble_hip *h)
                                  h->d_b15f.as<uint8_t>());
             if (h->n_slow > 0)
                 CRUMBLE_LAUNCH_INDEP(k_replay_slow, nblk(h->n_slow, 64), 64, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
-                                     h->n_slow, h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(),
+                                     h->d_misc.as<int>() + 11, h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(),
                                      h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(), h->d_b15f.as<uint8_t>());
         }
         if (L > 0 && h->totals.trigcols > 0)

@@ -1363,12 +1363,12 @@ k_replay_flat(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
 
 /* the bases that D/N columns report (host-built list), after k_replay_flat */
 __global__ void k_replay_slow(DBatch B, const DParams *__restrict__ P, const uint32_t *__restrict__ colrec,
-                              const int32_t *__restrict__ pos_mn2, int64_t n_slow, const int64_t *__restrict__ slow_g,
+                              const int32_t *__restrict__ pos_mn2, const int *__restrict__ n_slow, const int64_t *__restrict__ slow_g,
                               const int32_t *__restrict__ slow_r, uint8_t *__restrict__ out,
                               uint8_t *__restrict__ keepf, uint8_t *__restrict__ b15f)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_slow) return;
+    if (t >= *n_slow) return;
     out[slow_g[t]] = replay_base(B, P, colrec, pos_mn2, slow_g[t], slow_r[t], keepf, b15f);
 }
 

@@ -1,0 +1,268 @@
+/*
+ * p0_kernels.h -- "P0 expand" on the device: everything the column engine needs beyond the raw
+ * BAM-shaped arrays of a crumble_batch is derived here, so crumble_hip_upload() is a set of
+ * host->device copies plus a few launches (no per-read host loops).
+ *
+ *   k_p0_classify   per read: pileup_callback's routing (snp_score.c:1130-1149) + htslib's default
+ *                   flag filter, reference length / end, number of reference-consuming CIGAR ops,
+ *                   input validation (the reference asserts instead: snp_score.c:1075)
+ *   k_p0_quals      input qualities must be < 128
+ *   k_p0_sorted     coordinate order of the reads that enter the pileup (snp_score.c:1075)
+ *   k_p0scan_*      exclusive prefix sums -> offsets of each read's ops / base->column entries
+ *   k_p0_fill       per read: Seg + SegRec tables with htslib's resolve_cigar2 `indel` peek
+ *                   (SURVEY.md App. C), ReadRec, base->column table and the list of bases that
+ *                   D/N columns report (replay)
+ *   k_p0_keys, k_pmax_*, k_p0_tiles   candidate ranges per 64-column tile (reads and ops)
+ *   k_p0_blkread    owning read of every 64-base block of the flat base array
+ */
+#ifndef CRUMBLE_P0_KERNELS_H
+#define CRUMBLE_P0_KERNELS_H
+
+#include "dev_common.h"
+
+struct P0Cnt { int64_t nseg, ncix, nslow; };
+
+#define P0_ERR_NEG      1
+#define P0_ERR_QLEN     2
+#define P0_ERR_COORD    3
+#define P0_ERR_UNSORTED 4
+#define P0_ERR_QUAL     5
+
+__device__ __forceinline__ bool p0_is_mdnx(int op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
+
+/* bam_pileup1_t.indel on the last column of ref-op k (htslib resolve_cigar2's peek at the
+ * next op) */
+__device__ __forceinline__ int p0_indel_after(const uint32_t *cig, int n, int k)
+{
+    if (k + 1 >= n) return 0;
+    const int op = cig[k] & 15, op2 = cig[k + 1] & 15, l2 = (int)(cig[k + 1] >> 4);
+    int indel = 0;
+    if (op2 == 2 && op != 2) {
+        indel = -l2;
+        for (int j = k + 2; j < n; j++) { if ((cig[j] & 15) == 2) indel -= (int)(cig[j] >> 4); else break; }
+    } else if (op2 == 1) {
+        indel = l2;
+        for (int j = k + 2; j < n; j++) {
+            const int o = cig[j] & 15;
+            if (o == 1) indel += (int)(cig[j] >> 4); else if (o != 6) break;
+        }
+    } else if (op2 == 6 && k + 2 < n) {
+        int l3 = 0;
+        for (int j = k + 2; j < n; j++) {
+            const int o = cig[j] & 15;
+            if (o == 1) l3 += (int)(cig[j] >> 4);
+            else if (o == 2 || o == 0 || o == 3 || o == 7 || o == 8) break;
+        }
+        if (l3 > 0) indel = l3;
+    }
+    return indel;
+}
+
+__global__ void k_p0_classify(int64_t n, int tid, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
+                              const int64_t *__restrict__ seq_off, const int64_t *__restrict__ cig_off,
+                              const uint32_t *__restrict__ cigar, uint8_t *__restrict__ inplp,
+                              int32_t *__restrict__ end, P0Cnt *__restrict__ cnt, int *err, int *minmax)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t *cig = cigar + cig_off[r];
+    const int64_t ncg64 = cig_off[r + 1] - cig_off[r], lq = seq_off[r + 1] - seq_off[r];
+    P0Cnt c = {0, 0, 0};
+    inplp[r] = 0; end[r] = pos[r];
+    if (lq < 0 || ncg64 < 0 || lq > 0x3fffffff) { atomicMax(err, P0_ERR_NEG); cnt[r] = c; return; }
+    const int ncg = (int)ncg64;
+    /* pileup_callback routing (snp:1130-1149) + htslib's default filter */
+    if (tid < 0 || (flag[r] & (4 | 256 | 512 | 1024))) { cnt[r] = c; return; }
+    int64_t x = 0, y = 0;
+    int nseg = 0, ndn = 0, first_type = -1, first_ia = 0;
+    for (int k = 0; k < ncg; k++) {
+        const int op = cig[k] & 15, l = (int)(cig[k] >> 4);
+        if (p0_is_mdnx(op)) {
+            if (l > 0) {
+                if (!nseg) { first_type = (op == 2) ? 1 : (op == 3) ? 2 : 0; first_ia = p0_indel_after(cig, ncg, k); }
+                nseg++;
+                if ((op == 2 || op == 3) && y < lq) ndn++;
+            }
+            x += l;
+            if (op != 2 && op != 3) y += l;
+        } else if (op == 1 || op == 4) y += l;
+    }
+    if (!nseg || x <= 0) { cnt[r] = c; return; }                      /* no reference-consuming op */
+    if (y != lq && lq != 0) { atomicMax(err, P0_ERR_QLEN); cnt[r] = c; return; }
+    if (pos[r] < 0 || (int64_t)pos[r] + x >= (int64_t)INT_MAX - 64) { atomicMax(err, P0_ERR_COORD); cnt[r] = c; return; }
+    inplp[r] = 1;
+    end[r] = pos[r] + (int32_t)x;
+    const bool simple = nseg == 1 && first_type == 0 && first_ia == 0 && lq > 0;
+    c.nseg = nseg; c.ncix = simple ? 0 : lq; c.nslow = simple ? 0 : ndn;
+    cnt[r] = c;
+    atomicMin(&minmax[0], pos[r]);
+    atomicMax(&minmax[1], end[r]);
+}
+
+__global__ void k_p0_sorted(int64_t n, const int32_t *__restrict__ pos, const uint8_t *__restrict__ inplp, int *err)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n || !inplp[r]) return;
+    int64_t q = r - 1;
+    while (q >= 0 && !inplp[q]) q--;
+    if (q >= 0 && pos[r] < pos[q]) atomicMax(err, P0_ERR_UNSORTED);   /* snp:1075 */
+}
+
+__global__ void k_p0_quals(int64_t nb, const uint8_t *__restrict__ quals, int *err)
+{
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i >= nb) return;
+    bool bad = false;
+    if (i + 16 <= nb) {
+        const uint4 v = *(const uint4 *)(quals + i);
+        bad = ((v.x | v.y | v.z | v.w) & 0x80808080u) != 0;
+    } else {
+        for (int64_t k = i; k < nb; k++) bad = bad || (quals[k] & 0x80);
+    }
+    if (bad) atomicMax(err, P0_ERR_QUAL);
+}
+
+/* chunked exclusive scan of P0Cnt over reads; totals -> partial[nchunks] */
+#define P0_CHUNK 1024
+__device__ __forceinline__ void p0cnt_add(P0Cnt &a, const P0Cnt &b) { a.nseg += b.nseg; a.ncix += b.ncix; a.nslow += b.nslow; }
+__global__ void k_p0scan_reduce(int64_t n, const P0Cnt *__restrict__ cnt, P0Cnt *__restrict__ partial, int nchunks)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    P0Cnt acc = {0, 0, 0};
+    const int64_t b = (int64_t)t * P0_CHUNK, e = b + P0_CHUNK < n ? b + P0_CHUNK : n;
+    for (int64_t i = b; i < e; i++) p0cnt_add(acc, cnt[i]);
+    partial[t] = acc;
+}
+__global__ void k_p0scan_partials(P0Cnt *partial, int nchunks)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    P0Cnt run = {0, 0, 0};
+    for (int i = 0; i < nchunks; i++) { const P0Cnt v = partial[i]; partial[i] = run; p0cnt_add(run, v); }
+    partial[nchunks] = run;
+}
+__global__ void k_p0scan_apply(int64_t n, P0Cnt *__restrict__ cnt, const P0Cnt *__restrict__ partial, int nchunks)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    P0Cnt run = partial[t];
+    const int64_t b = (int64_t)t * P0_CHUNK, e = b + P0_CHUNK < n ? b + P0_CHUNK : n;
+    for (int64_t i = b; i < e; i++) { const P0Cnt v = cnt[i]; cnt[i] = run; p0cnt_add(run, v); }
+}
+
+__global__ void k_p0_fill(int64_t n, int p0, const int32_t *__restrict__ pos, const uint8_t *__restrict__ mapq,
+                          const int64_t *__restrict__ seq_off, const int64_t *__restrict__ cig_off,
+                          const uint32_t *__restrict__ cigar, const uint8_t *__restrict__ inplp,
+                          const int32_t *__restrict__ end, const P0Cnt *__restrict__ off, const P0Cnt *__restrict__ total,
+                          Seg *__restrict__ segs, SegRec *__restrict__ sr, int32_t *__restrict__ sr_ppos,
+                          int32_t *__restrict__ sr_pend, ReadRec *__restrict__ rr, int64_t *__restrict__ seg_off,
+                          int32_t *__restrict__ cix, int64_t *__restrict__ slow_g, int32_t *__restrict__ slow_r,
+                          int *n_slow)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const P0Cnt o = off[r];
+    seg_off[r] = o.nseg;
+    if (r == n - 1) seg_off[n] = total->nseg;
+    const int64_t so = seq_off[r];
+    const int lq = (int)(seq_off[r + 1] - so);
+    ReadRec x;
+    x.pos = pos[r]; x.end = end[r]; x.so = so; x.lq = lq; x.q0 = 0; x.info = mapq[r]; x.cix = 0;
+    if (!inplp[r]) { rr[r] = x; return; }
+    const uint32_t *cig = cigar + cig_off[r];
+    const int ncg = (int)(cig_off[r + 1] - cig_off[r]);
+    /* pass 1: the op table (Seg) and the self-contained records (SegRec) */
+    int64_t si = o.nseg;
+    const int64_t s_first = si;
+    int xr = 0, y = 0, nseg = 0;
+    for (int k = 0; k < ncg; k++) {
+        const int op = cig[k] & 15, l = (int)(cig[k] >> 4);
+        if (p0_is_mdnx(op)) {
+            if (l > 0) {
+                const uint32_t ty = (op == 2) ? SEG_D : (op == 3) ? SEG_N : SEG_M;
+                Seg s;
+                s.roff = xr; s.qstart = y; s.len_type = (uint32_t)l | (ty << 30);
+                s.indel_after = p0_indel_after(cig, ncg, k);
+                segs[si] = s;
+                SegRec q;
+                q.pos = x.pos + xr; q.end = q.pos + l; q.so = so; q.lq = lq;
+                q.qoff = (ty == SEG_M) ? y - q.pos : y;
+                q.indel_after = s.indel_after;
+                q.info = (uint32_t)mapq[r] | (ty << 8);
+                if (si == s_first) { q.info |= SR_FIRST; if (y > 0) q.info |= SR_HEADCLIP; x.q0 = y; }
+                sr[si] = q; sr_ppos[si] = x.pos; sr_pend[si] = x.end;
+                si++; nseg++;
+            }
+            xr += l;
+            if (op != 2 && op != 3) y += l;
+        } else if (op == 1 || op == 4) y += l;
+    }
+    {   /* the last op carries the tail flags */
+        SegRec q = sr[si - 1];
+        const Seg sl = segs[si - 1];
+        const int qt = (seg_type(sl) == SEG_M) ? sl.qstart + seg_len(sl) - 1 : sl.qstart;
+        q.info |= SR_LAST;
+        if (qt + 1 < lq) q.info |= SR_TAILCLIP;
+        sr[si - 1] = q;
+    }
+    const Seg s0 = segs[s_first];
+    const bool simple = nseg == 1 && seg_type(s0) == SEG_M && s0.indel_after == 0 && lq > 0;
+    if (simple) { x.info |= RR_SIMPLE; rr[r] = x; return; }
+    /* pass 2: base -> column table of a general CIGAR (replay) */
+    x.cix = (uint32_t)o.ncix;
+    rr[r] = x;
+    int32_t *cx = cix + o.ncix;
+    for (int i = 0; i < lq; i++) cx[i] = -1;
+    for (int64_t k = s_first; k < si; k++) {
+        const Seg sg = segs[k];
+        if (seg_type(sg) != SEG_M) continue;
+        for (int i = 0; i < seg_len(sg) && sg.qstart + i < lq; i++) cx[sg.qstart + i] = (x.pos + sg.roff + i) - p0;
+    }
+    for (int64_t k = s_first; k < si; k++) {               /* bases that D/N columns report */
+        const Seg sg = segs[k];
+        if (seg_type(sg) != SEG_M && sg.qstart < lq && cx[sg.qstart] != -2) {
+            cx[sg.qstart] = -2;
+            const int w = atomicAdd(n_slow, 1);
+            slow_g[w] = so + sg.qstart; slow_r[w] = (int32_t)r;
+        }
+    }
+}
+
+/* monotone search keys for the per-tile candidate ranges of reads */
+__global__ void k_p0_keys(int64_t n, const int32_t *__restrict__ pos, const int32_t *__restrict__ end,
+                          const uint8_t *__restrict__ inplp, int32_t *__restrict__ kpos, int32_t *__restrict__ kend)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    kpos[r] = inplp[r] ? pos[r] : INT_MIN;
+    kend[r] = inplp[r] ? end[r] : INT_MIN;
+}
+
+/* For tile t = columns [c0, c0+63]: hi = first index whose (prefix-max) start key > c0+63,
+ * lo = min(hi, first index whose (prefix-max) end key > c0): exactly the two-pointer walk over
+ * position-sorted reads (entries between lo and hi that ended earlier are skipped by the kernels). */
+__global__ void k_p0_tiles(int n_tiles, int p0, int64_t n, const int32_t *__restrict__ kpos,
+                           const int32_t *__restrict__ kend, int32_t *__restrict__ tlo, int32_t *__restrict__ thi)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const int64_t c0 = (int64_t)p0 + (int64_t)t * 64, c1 = c0 + 63;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)kpos[mid] <= c1) lo = mid + 1; else hi = mid; }
+    const int64_t h = lo;
+    lo = 0; hi = h;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)kend[mid] <= c0) lo = mid + 1; else hi = mid; }
+    tlo[t] = (int32_t)lo; thi[t] = (int32_t)h;
+}
+
+__global__ void k_p0_blkread(int64_t nblocks, int64_t n, const int64_t *__restrict__ seq_off, int32_t *__restrict__ blk_read)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const int64_t g0 = b * 64;
+    int64_t lo = 0, hi = n;                                /* first r with seq_off[r + 1] > g0 */
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (seq_off[mid + 1] <= g0) lo = mid + 1; else hi = mid; }
+    blk_read[b] = (int32_t)(lo < n ? lo : n - 1);
+}
+
+#endif

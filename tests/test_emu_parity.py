@@ -53,3 +53,23 @@ def test_emu_indel_only(product):
             want = O.indel_only(hb, d, q)
             assert np.array_equal(got, want), (d, q, np.nonzero(got != want)[0][:10])
         eng.close()
+
+
+def test_emu_upload_validation(product):
+    """Errors are return codes, not asserts (the reference asserts at snp_score.c:1075)."""
+    p = ca.preset_params(9)
+    eng = emu_lib.engine(p)
+    ok = [dict(pos=100, cigar="10M", seq="ACGTACGTAC", qual=30), dict(pos=105, cigar="10M", seq="ACGTACGTAC", qual=30)]
+    eng.contig(HostBatch.from_reads(ok))
+    with pytest.raises(ca.CrumbleError) as ei:      # unsorted
+        eng.contig(HostBatch.from_reads(ok[::-1]))
+    assert ei.value.code == -4
+    with pytest.raises(ca.CrumbleError) as ei:      # quality >= 128
+        eng.contig(HostBatch.from_reads([dict(pos=1, cigar="4M", seq="ACGT", qual=[1, 2, 200, 3])]))
+    assert ei.value.code == -1
+    with pytest.raises(ca.CrumbleError) as ei:      # CIGAR does not match l_qseq
+        eng.contig(HostBatch.from_reads([dict(pos=1, cigar="5M", seq="ACGT", qual=9)]))
+    assert ei.value.code == -1
+    # an unsorted read that never enters the pileup is fine (FUNMAP mate)
+    eng.contig(HostBatch.from_reads([ok[1], dict(pos=3, cigar="*", seq="ACGT", qual=9, flag=4)]))
+    eng.close()

@@ -183,3 +183,18 @@ def test_too_deep_columns(product):
     for level in (5, 9):
         q, f, s = assert_parity(gpu_engine, ca.preset_params(level), hb)
         assert s[ca.ST_NAMES.index("too_deep")] > 0
+
+
+def test_upload_validation_errors(product):
+    """Device-side input validation (p0_kernels.h): return codes instead of the reference's asserts."""
+    eng = gpu_engine(ca.preset_params(9))
+    ok = [dict(pos=100, cigar="10M", seq="ACGTACGTAC", qual=30), dict(pos=105, cigar="10M", seq="ACGTACGTAC", qual=30)]
+    eng.contig(HostBatch.from_reads(ok))
+    for reads, code in ((ok[::-1], -4),
+                        ([dict(pos=1, cigar="4M", seq="ACGT", qual=[1, 2, 200, 3])], -1),
+                        ([dict(pos=1, cigar="5M", seq="ACGT", qual=9)], -1)):
+        with pytest.raises(ca.CrumbleError) as ei:
+            eng.contig(HostBatch.from_reads(reads))
+        assert ei.value.code == code
+    eng.contig(HostBatch.from_reads(ok))            # the engine is still usable
+    eng.close()
