@@ -1,0 +1,158 @@
+"""ctypes mirror of include/crumble_bamio.h (BGZF + BAM ingest / egress).
+
+Test / benchmark driver only; the product is ``csrc/bamio.c`` behind its C ABI and the
+``crumble-hip`` command line program.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .capi import Batch, HostBatch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+class BamError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"crumble_bamio error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(HERE, "libcrumble_bamio.so")
+        if not os.path.exists(path):
+            raise BamError(0, f"{path} missing: run `make -C crumble_amd/csrc`")
+        L = C.CDLL(path, mode=getattr(os, "RTLD_LOCAL", 0))
+        L.crumble_bam_open.restype = C.c_void_p
+        L.crumble_bam_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+        L.crumble_bam_close.argtypes = [C.c_void_p]
+        L.crumble_bam_n_ref.argtypes = [C.c_void_p]
+        L.crumble_bam_ref_name.restype = C.c_char_p
+        L.crumble_bam_ref_name.argtypes = [C.c_void_p, C.c_int32]
+        L.crumble_bam_ref_len.restype = C.c_int64
+        L.crumble_bam_ref_len.argtypes = [C.c_void_p, C.c_int32]
+        L.crumble_bam_header_text.restype = C.c_char_p
+        L.crumble_bam_header_text.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.crumble_bam_next_contig.argtypes = [C.c_void_p, C.POINTER(Batch)]
+        L.crumble_bam_create.restype = C.c_void_p
+        L.crumble_bam_create.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.crumble_bam_write_group.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.crumble_bam_writer_close.argtypes = [C.c_void_p]
+        L.crumble_bam_write_batches.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
+                                                C.c_int32, C.POINTER(Batch), C.c_int, C.c_int]
+        L.crumble_bam_load_bed.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                           C.POINTER(C.c_void_p)]
+        L.crumble_bam_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _err(code):
+    return BamError(code, lib().crumble_bam_last_error().decode(errors="replace"))
+
+
+def write_batches(path, refs, batches, level=1, threads=0):
+    """refs: [(name, length)], batches: [HostBatch] in header order."""
+    L = lib()
+    names = (C.c_char_p * len(refs))(*[n.encode() for n, _ in refs])
+    lens = (C.c_int64 * len(refs))(*[int(l) for _, l in refs])
+    arr = (Batch * max(1, len(batches)))(*[b.struct() for b in batches])
+    rc = L.crumble_bam_write_batches(os.fsencode(path), len(refs), names, lens, len(batches), arr, level, threads)
+    if rc:
+        raise _err(rc)
+
+
+def _view(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype)
+    buf = (C.c_uint8 * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+class Reader:
+    def __init__(self, path, threads=0):
+        e = C.c_int(0)
+        self.h = lib().crumble_bam_open(os.fsencode(path), threads, C.byref(e))
+        if not self.h:
+            raise _err(e.value)
+
+    @property
+    def refs(self):
+        L = lib()
+        return [(L.crumble_bam_ref_name(self.h, i).decode(), int(L.crumble_bam_ref_len(self.h, i)))
+                for i in range(L.crumble_bam_n_ref(self.h))]
+
+    @property
+    def header_text(self):
+        n = C.c_int64(0)
+        t = lib().crumble_bam_header_text(self.h, C.byref(n))
+        return t.decode() if t else ""
+
+    def next_contig(self):
+        """Returns a HostBatch (copies of the reader's views) or None at end of file."""
+        b = Batch()
+        rc = lib().crumble_bam_next_contig(self.h, C.byref(b))
+        if rc < 0:
+            raise _err(rc)
+        if rc == 0:
+            return None
+        n = b.n_reads
+        so = _view(b.seq_off, n + 1, np.int64)
+        co = _view(b.cig_off, n + 1, np.int64)
+        return HostBatch(b.tid, _view(b.pos, n, np.int32), _view(b.mapq, n, np.uint8), _view(b.flag, n, np.uint16),
+                         so, co, _view(b.cigar, int(co[-1]), np.uint32), _view(b.bases, int(so[-1]), np.uint8),
+                         _view(b.quals, int(so[-1]), np.uint8))
+
+    def __iter__(self):
+        while True:
+            hb = self.next_contig()
+            if hb is None:
+                return
+            yield hb
+
+    def load_bed(self, path):
+        t, s, e = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n = lib().crumble_bam_load_bed(self.h, os.fsencode(path), C.byref(t), C.byref(s), C.byref(e))
+        if n < 0:
+            raise _err(n)
+        out = np.stack([_view(t.value, n, np.int32), _view(s.value, n, np.int32), _view(e.value, n, np.int32)], 1) \
+            if n else np.zeros((0, 3), np.int32)
+        libc = C.CDLL(None)
+        libc.free.argtypes = [C.c_void_p]
+        for p in (t, s, e):
+            libc.free(p)
+        return out
+
+    def close(self):
+        if self.h:
+            lib().crumble_bam_close(self.h)
+            self.h = None
+
+
+class Writer:
+    def __init__(self, path, reader, pg_line=None, level=1, threads=0):
+        e = C.c_int(0)
+        self.h = lib().crumble_bam_create(os.fsencode(path), reader.h, pg_line.encode() if pg_line else None, level,
+                                          threads, C.byref(e))
+        if not self.h:
+            raise _err(e.value)
+        self.reader = reader
+
+    def write_group(self, qual_out=None):
+        q = None
+        if qual_out is not None:
+            q = np.ascontiguousarray(qual_out, np.uint8)
+        rc = lib().crumble_bam_write_group(self.h, self.reader.h, q.ctypes.data if q is not None and q.size else None)
+        if rc:
+            raise _err(rc)
+
+    def close(self):
+        if self.h:
+            rc = lib().crumble_bam_writer_close(self.h)
+            self.h = None
+            if rc:
+                raise _err(rc)

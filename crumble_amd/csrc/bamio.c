@@ -1,0 +1,550 @@
+/*
+ * bamio.c -- BGZF + BAM ingest / egress for the column engine (include/crumble_bamio.h).
+ *
+ * Written from the SAMv1 specification (section 4: BGZF 4.1, BAM 4.2); replaces what reference
+ * crumble gets from htslib's sam_read1 / sam_write1 (snp_score.c:1116-1117, 1101).
+ *
+ * Layout decisions (host side of an HBM-resident engine):
+ *  - a contig's records are inflated straight into ONE growing byte buffer (`raw`), never copied
+ *    again: the SoA views handed to the engine are built from it by an OpenMP team, the engine's
+ *    quality bytes are scattered back into it, and the same buffer is deflated for output;
+ *  - BGZF blocks are independent deflate streams, so both directions are a parallel-for over blocks
+ *    with a prefix sum over the (known) block sizes; file reads/writes stay sequential.
+ */
+#define _GNU_SOURCE
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <errno.h>
+#include <stdarg.h>
+#include <zlib.h>
+#include <omp.h>
+#include "../../include/crumble_bamio.h"
+
+static __thread char g_err[512];
+const char *crumble_bam_last_error(void) { return g_err; }
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+static inline uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | p[1] << 8); }
+static inline void put32(uint8_t *p, uint32_t v) { p[0] = v; p[1] = v >> 8; p[2] = v >> 16; p[3] = v >> 24; }
+static inline void put16(uint8_t *p, uint16_t v) { p[0] = v; p[1] = v >> 8; }
+
+/* ------------------------------------------------------------------ BGZF in */
+#define CHUNK_IN   (32u << 20)      /* compressed bytes read per refill           */
+#define MAX_BLOCKS 16384            /* per refill (>= CHUNK_IN / smallest sane block, grown on demand) */
+
+struct crumble_bam_reader {
+    FILE *fp;
+    int threads;
+    uint8_t *cbuf; size_t clen, ccap;        /* compressed bytes not yet inflated  */
+    int eof_file;
+    /* the uncompressed stream window: [0, raw_len) valid, scan = parse position     */
+    uint8_t *raw; size_t raw_len, raw_cap, scan;
+    size_t group_end;                         /* end of the current group inside raw */
+    /* header */
+    char *text; int64_t l_text;
+    int32_t n_ref; char **ref_name; int64_t *ref_len;
+    /* current group */
+    int64_t n, cap_n;
+    size_t *rec_off;                          /* [n] offset of block_size field      */
+    int32_t tid;
+    int32_t *pos; uint8_t *mapq; uint16_t *flag; int64_t *seq_off, *cig_off;
+    uint32_t *cigar; uint8_t *bases, *quals;
+    size_t cap_reads, cap_bases, cap_cig;
+};
+
+typedef struct { size_t coff, clen, uoff, ulen; uint32_t crc; } blk_t;
+
+static int raw_reserve(crumble_bam_reader *r, size_t need)
+{
+    if (need <= r->raw_cap) return 0;
+    size_t nc = r->raw_cap ? r->raw_cap : (64u << 20);
+    while (nc < need) nc += nc / 2 + (16u << 20);
+    uint8_t *p = realloc(r->raw, nc);
+    if (!p) return fail(CRUMBLE_BAM_ENOMEM, "out of memory growing record buffer to %zu bytes", nc);
+    r->raw = p; r->raw_cap = nc;
+    return 0;
+}
+
+/* Appends more uncompressed bytes to raw.  Returns 1 if bytes were added, 0 at EOF, < 0 on error. */
+static int refill(crumble_bam_reader *r)
+{
+    for (;;) {
+        if (!r->eof_file) {
+            if (r->ccap < r->clen + CHUNK_IN) {
+                uint8_t *p = realloc(r->cbuf, r->clen + CHUNK_IN);
+                if (!p) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+                r->cbuf = p; r->ccap = r->clen + CHUNK_IN;
+            }
+            size_t got = fread(r->cbuf + r->clen, 1, CHUNK_IN, r->fp);
+            if (got < CHUNK_IN) {
+                if (ferror(r->fp)) return fail(CRUMBLE_BAM_EIO, "read error: %s", strerror(errno));
+                r->eof_file = 1;
+            }
+            r->clen += got;
+        }
+        if (r->clen == 0) return 0;
+        /* delimit whole blocks */
+        blk_t *blk = NULL; size_t nb = 0, capb = 0, off = 0, utot = 0;
+        while (off + 18 <= r->clen) {
+            const uint8_t *h = r->cbuf + off;
+            if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { free(blk); return fail(CRUMBLE_BAM_EFORMAT, "not a BGZF block (bad gzip header)"); }
+            const unsigned xlen = le16(h + 10);
+            if (off + 12 + xlen > r->clen) break;
+            int bsize = -1;
+            for (unsigned x = 0; x + 4 <= xlen; ) {
+                const uint8_t *sf = h + 12 + x;
+                const unsigned slen = le16(sf + 2);
+                if (sf[0] == 'B' && sf[1] == 'C' && slen == 2) bsize = le16(sf + 4);
+                x += 4 + slen;
+            }
+            if (bsize < 0) { free(blk); return fail(CRUMBLE_BAM_EFORMAT, "gzip member without BGZF BC field"); }
+            const size_t total = (size_t)bsize + 1;
+            if (total < 12 + xlen + 8) { free(blk); return fail(CRUMBLE_BAM_EFORMAT, "corrupt BGZF block size"); }
+            if (off + total > r->clen) break;
+            if (nb == capb) { capb = capb ? capb * 2 : 1024; blk = realloc(blk, capb * sizeof *blk); if (!blk) return fail(CRUMBLE_BAM_ENOMEM, "out of memory"); }
+            blk[nb].coff = off + 12 + xlen;
+            blk[nb].clen = total - 12 - xlen - 8;
+            blk[nb].ulen = le32(h + total - 4);
+            blk[nb].crc  = le32(h + total - 8);
+            blk[nb].uoff = utot;
+            if (blk[nb].ulen > 65536) { free(blk); return fail(CRUMBLE_BAM_EFORMAT, "BGZF ISIZE > 64 KiB"); }
+            utot += blk[nb].ulen;
+            nb++;
+            off += total;
+        }
+        if (nb == 0) {
+            free(blk);
+            if (r->eof_file) return fail(CRUMBLE_BAM_EFORMAT, "truncated BGZF block at end of file");
+            continue;                                       /* need more compressed bytes */
+        }
+        int rc = raw_reserve(r, r->raw_len + utot);
+        if (rc) { free(blk); return rc; }
+        uint8_t *dst = r->raw + r->raw_len;
+        int bad = 0;
+        #pragma omp parallel for schedule(dynamic, 16) num_threads(r->threads) reduction(|:bad)
+        for (size_t i = 0; i < nb; i++) {
+            if (blk[i].ulen == 0) continue;
+            z_stream zs; memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) { bad |= 1; continue; }
+            zs.next_in = r->cbuf + blk[i].coff; zs.avail_in = (uInt)blk[i].clen;
+            zs.next_out = dst + blk[i].uoff;    zs.avail_out = (uInt)blk[i].ulen;
+            const int zr = inflate(&zs, Z_FINISH);
+            if (zr != Z_STREAM_END || zs.avail_out != 0) bad |= 2;
+            inflateEnd(&zs);
+            if (crc32(crc32(0L, Z_NULL, 0), dst + blk[i].uoff, (uInt)blk[i].ulen) != blk[i].crc) bad |= 4;
+        }
+        free(blk);
+        if (bad) return fail(CRUMBLE_BAM_EFORMAT, "BGZF inflate/CRC failure (mask %d)", bad);
+        memmove(r->cbuf, r->cbuf + off, r->clen - off);
+        r->clen -= off;
+        r->raw_len += utot;
+        if (utot) return 1;
+        if (r->eof_file && r->clen == 0) return 0;          /* only empty (EOF marker) blocks */
+    }
+}
+
+/* makes sure [scan, scan+need) is in raw; returns 1 ok, 0 clean EOF before any byte, < 0 error */
+static int need_bytes(crumble_bam_reader *r, size_t need)
+{
+    while (r->raw_len - r->scan < need) {
+        const int rc = refill(r);
+        if (rc < 0) return rc;
+        if (rc == 0) {
+            if (r->raw_len == r->scan) return 0;
+            return fail(CRUMBLE_BAM_EFORMAT, "truncated BAM record at end of file");
+        }
+    }
+    return 1;
+}
+
+crumble_bam_reader *crumble_bam_open(const char *path, int threads, int *err)
+{
+    int e = 0;
+    crumble_bam_reader *r = calloc(1, sizeof *r);
+    if (!r) { e = fail(CRUMBLE_BAM_ENOMEM, "out of memory"); goto bad; }
+    r->threads = threads > 0 ? threads : omp_get_max_threads();
+    r->fp = fopen(path, "rb");
+    if (!r->fp) { e = fail(CRUMBLE_BAM_EIO, "%s: %s", path, strerror(errno)); goto bad; }
+    int rc;
+    if ((rc = need_bytes(r, 12)) <= 0) { e = rc ? rc : fail(CRUMBLE_BAM_EFORMAT, "%s: empty file", path); goto bad; }
+    if (memcmp(r->raw, "BAM\1", 4)) { e = fail(CRUMBLE_BAM_EFORMAT, "%s: no BAM magic", path); goto bad; }
+    r->l_text = (int32_t)le32(r->raw + 4);
+    if (r->l_text < 0) { e = fail(CRUMBLE_BAM_EFORMAT, "negative l_text"); goto bad; }
+    r->scan = 8;
+    if ((rc = need_bytes(r, (size_t)r->l_text + 4)) <= 0) { e = rc ? rc : fail(CRUMBLE_BAM_EFORMAT, "truncated header"); goto bad; }
+    r->text = malloc((size_t)r->l_text + 1);
+    if (!r->text) { e = fail(CRUMBLE_BAM_ENOMEM, "out of memory"); goto bad; }
+    memcpy(r->text, r->raw + r->scan, (size_t)r->l_text); r->text[r->l_text] = 0;
+    r->l_text = (int64_t)strlen(r->text);                   /* header text may be NUL padded */
+    r->scan += (size_t)le32(r->raw + 4);
+    r->n_ref = (int32_t)le32(r->raw + r->scan); r->scan += 4;
+    if (r->n_ref < 0) { e = fail(CRUMBLE_BAM_EFORMAT, "negative n_ref"); goto bad; }
+    r->ref_name = calloc((size_t)r->n_ref + 1, sizeof *r->ref_name);
+    r->ref_len = calloc((size_t)r->n_ref + 1, sizeof *r->ref_len);
+    if (!r->ref_name || !r->ref_len) { e = fail(CRUMBLE_BAM_ENOMEM, "out of memory"); goto bad; }
+    for (int32_t i = 0; i < r->n_ref; i++) {
+        if ((rc = need_bytes(r, 4)) <= 0) { e = rc ? rc : fail(CRUMBLE_BAM_EFORMAT, "truncated reference list"); goto bad; }
+        const int32_t ln = (int32_t)le32(r->raw + r->scan);
+        if (ln <= 0) { e = fail(CRUMBLE_BAM_EFORMAT, "bad reference name length"); goto bad; }
+        if ((rc = need_bytes(r, (size_t)ln + 8)) <= 0) { e = rc ? rc : fail(CRUMBLE_BAM_EFORMAT, "truncated reference list"); goto bad; }
+        r->ref_name[i] = malloc((size_t)ln + 1);
+        if (!r->ref_name[i]) { e = fail(CRUMBLE_BAM_ENOMEM, "out of memory"); goto bad; }
+        memcpy(r->ref_name[i], r->raw + r->scan + 4, (size_t)ln); r->ref_name[i][ln] = 0;
+        r->ref_len[i] = (int32_t)le32(r->raw + r->scan + 4 + ln);
+        r->scan += (size_t)ln + 8;
+    }
+    r->group_end = r->scan;                                 /* header bytes are dropped on the first call */
+    if (err) *err = 0;
+    return r;
+bad:
+    if (err) *err = e;
+    crumble_bam_close(r);
+    return NULL;
+}
+
+void crumble_bam_close(crumble_bam_reader *r)
+{
+    if (!r) return;
+    if (r->fp) fclose(r->fp);
+    free(r->cbuf); free(r->raw); free(r->text);
+    if (r->ref_name) for (int32_t i = 0; i < r->n_ref; i++) free(r->ref_name[i]);
+    free(r->ref_name); free(r->ref_len); free(r->rec_off);
+    free(r->pos); free(r->mapq); free(r->flag); free(r->seq_off); free(r->cig_off);
+    free(r->cigar); free(r->bases); free(r->quals);
+    free(r);
+}
+
+int32_t crumble_bam_n_ref(const crumble_bam_reader *r) { return r->n_ref; }
+const char *crumble_bam_ref_name(const crumble_bam_reader *r, int32_t tid) { return tid >= 0 && tid < r->n_ref ? r->ref_name[tid] : "*"; }
+int64_t crumble_bam_ref_len(const crumble_bam_reader *r, int32_t tid) { return tid >= 0 && tid < r->n_ref ? r->ref_len[tid] : 0; }
+const char *crumble_bam_header_text(const crumble_bam_reader *r, int64_t *len) { if (len) *len = r->l_text; return r->text; }
+
+/* fixed part of a BAM alignment record, offsets from the block_size field */
+enum { F_REFID = 4, F_POS = 8, F_LNAME = 12, F_MAPQ = 13, F_NCIG = 16, F_FLAG = 18, F_LSEQ = 20, F_FIXED = 36 };
+
+int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
+{
+    /* drop the previous group (or the header) from the window */
+    if (r->group_end) {
+        memmove(r->raw, r->raw + r->group_end, r->raw_len - r->group_end);
+        r->raw_len -= r->group_end; r->scan -= r->group_end; r->group_end = 0;
+    }
+    r->n = 0;
+    int have_tid = 0;
+    for (;;) {
+        int rc = need_bytes(r, 4);
+        if (rc < 0) return rc;
+        if (rc == 0) break;
+        const uint32_t bs = le32(r->raw + r->scan);
+        if (bs < 32 || bs > (1u << 30)) return fail(CRUMBLE_BAM_EFORMAT, "implausible BAM record size %u", bs);
+        if ((rc = need_bytes(r, 4 + (size_t)bs)) <= 0) return rc ? rc : fail(CRUMBLE_BAM_EFORMAT, "truncated BAM record");
+        const uint8_t *p = r->raw + r->scan;
+        const int32_t tid = (int32_t)le32(p + F_REFID);
+        if (!have_tid) { r->tid = tid; have_tid = 1; }
+        else if (tid != r->tid) break;
+        const uint32_t lname = p[F_LNAME], ncig = le16(p + F_NCIG);
+        const int32_t lseq = (int32_t)le32(p + F_LSEQ);
+        if (lseq < 0 || (size_t)F_FIXED - 4 + lname + 4u * ncig + ((size_t)lseq + 1) / 2 + (size_t)lseq > bs)
+            return fail(CRUMBLE_BAM_EFORMAT, "BAM record fields exceed block_size");
+        if (r->n == r->cap_n) {
+            const int64_t nc = r->cap_n ? r->cap_n * 2 : (1 << 20);
+            size_t *q = realloc(r->rec_off, (size_t)nc * sizeof *q);
+            if (!q) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+            r->rec_off = q; r->cap_n = nc;
+        }
+        r->rec_off[r->n++] = r->scan;
+        r->scan += 4 + (size_t)bs;
+    }
+    r->group_end = r->scan;
+    if (r->n == 0) return 0;
+
+    const int64_t n = r->n;
+    if (r->cap_reads < (size_t)n + 1) {
+        const size_t c = (size_t)n + (size_t)n / 4 + 64;
+        free(r->pos); free(r->mapq); free(r->flag); free(r->seq_off); free(r->cig_off);
+        r->pos = malloc(c * sizeof *r->pos); r->mapq = malloc(c); r->flag = malloc(c * sizeof *r->flag);
+        r->seq_off = malloc(c * sizeof *r->seq_off); r->cig_off = malloc(c * sizeof *r->cig_off);
+        r->cap_reads = (r->pos && r->mapq && r->flag && r->seq_off && r->cig_off) ? c : 0;
+        if (!r->cap_reads) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+    }
+    int64_t nb = 0, nc = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const uint8_t *p = r->raw + r->rec_off[i];
+        r->seq_off[i] = nb; r->cig_off[i] = nc;
+        nb += (int32_t)le32(p + F_LSEQ); nc += le16(p + F_NCIG);
+    }
+    r->seq_off[n] = nb; r->cig_off[n] = nc;
+    if (r->cap_bases < (size_t)nb + 16) {
+        const size_t c = (size_t)nb + (size_t)nb / 8 + 64;
+        free(r->bases); free(r->quals);
+        r->bases = malloc(c); r->quals = malloc(c);
+        r->cap_bases = (r->bases && r->quals) ? c : 0;
+        if (!r->cap_bases) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+    }
+    if (r->cap_cig < (size_t)nc + 1) {
+        const size_t c = (size_t)nc + (size_t)nc / 8 + 64;
+        free(r->cigar);
+        r->cigar = malloc(c * sizeof *r->cigar);
+        r->cap_cig = r->cigar ? c : 0;
+        if (!r->cap_cig) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+    }
+    int unsupported = 0;
+    #pragma omp parallel for schedule(static) num_threads(r->threads) reduction(|:unsupported)
+    for (int64_t i = 0; i < n; i++) {
+        const uint8_t *p = r->raw + r->rec_off[i];
+        const uint32_t lname = p[F_LNAME], ncig = le16(p + F_NCIG);
+        const int32_t lseq = (int32_t)le32(p + F_LSEQ);
+        r->pos[i] = (int32_t)le32(p + F_POS);
+        r->mapq[i] = p[F_MAPQ];
+        r->flag[i] = le16(p + F_FLAG);
+        const uint8_t *cg = p + F_FIXED + lname;
+        uint32_t *co = r->cigar + r->cig_off[i];
+        for (uint32_t k = 0; k < ncig; k++) co[k] = le32(cg + 4 * k);
+        /* a 2-op "<lseq>S<reflen>N" placeholder means the real CIGAR sits in the CG tag (SAMv1 4.2.2) */
+        if (ncig == 2 && (co[0] & 15) == 4 && (co[0] >> 4) == (uint32_t)lseq && (co[1] & 15) == 3 && lseq > 0) unsupported |= 1;
+        const uint8_t *sq = cg + 4 * (size_t)ncig;
+        uint8_t *bo = r->bases + r->seq_off[i];
+        for (int32_t k = 0; k + 1 < lseq; k += 2) { const uint8_t v = sq[k >> 1]; bo[k] = v >> 4; bo[k + 1] = v & 15; }
+        if (lseq & 1) bo[lseq - 1] = sq[lseq >> 1] >> 4;
+        const uint8_t *ql = sq + ((size_t)lseq + 1) / 2;
+        uint8_t *qo = r->quals + r->seq_off[i];
+        if (lseq > 0 && ql[0] == 0xff) memset(qo, 0, (size_t)lseq);     /* absent qualities */
+        else memcpy(qo, ql, (size_t)lseq);
+    }
+    if (unsupported) return fail(CRUMBLE_BAM_EUNSUPP, "record with its CIGAR in the CG tag (>65535 ops) is not supported");
+    memset(b, 0, sizeof *b);
+    b->tid = r->tid; b->n_reads = n;
+    b->pos = r->pos; b->mapq = r->mapq; b->flag = r->flag;
+    b->seq_off = r->seq_off; b->cig_off = r->cig_off; b->cigar = r->cigar;
+    b->bases = r->bases; b->quals = r->quals;
+    return 1;
+}
+
+/* ----------------------------------------------------------------- BGZF out */
+#define BLK_IN 0xff00u                       /* uncompressed bytes per block (htslib's choice too) */
+struct crumble_bam_writer { FILE *fp; int level, threads; uint8_t *obuf; size_t ocap; };
+
+static const uint8_t BGZF_EOF[28] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+
+/* deflates data[0..len) as consecutive BGZF blocks and writes them */
+static int bgzf_write(crumble_bam_writer *w, const uint8_t *data, size_t len)
+{
+    const size_t SLOT = 65536, BATCH = 4096;                 /* 256 MiB of input per round */
+    if (w->ocap < SLOT * BATCH) {
+        uint8_t *p = realloc(w->obuf, SLOT * BATCH);
+        if (!p) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+        w->obuf = p; w->ocap = SLOT * BATCH;
+    }
+    size_t *osz = malloc(BATCH * sizeof *osz);
+    if (!osz) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+    const size_t nblk = (len + BLK_IN - 1) / BLK_IN;
+    for (size_t b0 = 0; b0 < nblk; b0 += BATCH) {
+        const size_t nb = nblk - b0 < BATCH ? nblk - b0 : BATCH;
+        int bad = 0;
+        #pragma omp parallel for schedule(dynamic, 8) num_threads(w->threads) reduction(|:bad)
+        for (size_t i = 0; i < nb; i++) {
+            const size_t off = (b0 + i) * BLK_IN, ul = len - off < BLK_IN ? len - off : BLK_IN;
+            uint8_t *o = w->obuf + i * SLOT;
+            z_stream zs; memset(&zs, 0, sizeof zs);
+            if (deflateInit2(&zs, w->level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = 1; continue; }
+            zs.next_in = (Bytef *)(data + off); zs.avail_in = (uInt)ul;
+            zs.next_out = o + 18; zs.avail_out = (uInt)(SLOT - 18 - 8);
+            if (deflate(&zs, Z_FINISH) != Z_STREAM_END) bad = 1;
+            const size_t cl = zs.total_out;
+            deflateEnd(&zs);
+            static const uint8_t hdr[16] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0 };
+            memcpy(o, hdr, 16);
+            put16(o + 16, (uint16_t)(18 + cl + 8 - 1));
+            put32(o + 18 + cl, (uint32_t)crc32(crc32(0L, Z_NULL, 0), data + off, (uInt)ul));
+            put32(o + 18 + cl + 4, (uint32_t)ul);
+            osz[i] = 18 + cl + 8;
+        }
+        if (bad) { free(osz); return fail(CRUMBLE_BAM_EIO, "deflate failed"); }
+        /* compact the slots so the file sees one write per round */
+        size_t tot = osz[0];
+        for (size_t i = 1; i < nb; i++) { memmove(w->obuf + tot, w->obuf + i * SLOT, osz[i]); tot += osz[i]; }
+        if (fwrite(w->obuf, 1, tot, w->fp) != tot) { free(osz); return fail(CRUMBLE_BAM_EIO, "write error: %s", strerror(errno)); }
+    }
+    free(osz);
+    return 0;
+}
+
+static int write_header(crumble_bam_writer *w, const char *text, int64_t l_text, const char *pg_line,
+                        int32_t n_ref, const char *const *names, const int64_t *lens)
+{
+    size_t extra = pg_line ? strlen(pg_line) + 1 : 0, need = 12 + (size_t)l_text + extra + 1;
+    for (int32_t i = 0; i < n_ref; i++) need += 8 + strlen(names[i]) + 1;
+    uint8_t *h = malloc(need), *p = h;
+    if (!h) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+    memcpy(p, "BAM\1", 4); p += 4;
+    const int addnl = l_text > 0 && text[l_text - 1] != '\n';
+    put32(p, (uint32_t)((size_t)l_text + addnl + extra)); p += 4;
+    memcpy(p, text, (size_t)l_text); p += l_text;
+    if (addnl) *p++ = '\n';
+    if (pg_line) { memcpy(p, pg_line, extra - 1); p += extra - 1; *p++ = '\n'; }
+    put32(p, (uint32_t)n_ref); p += 4;
+    for (int32_t i = 0; i < n_ref; i++) {
+        const size_t ln = strlen(names[i]) + 1;
+        put32(p, (uint32_t)ln); p += 4;
+        memcpy(p, names[i], ln); p += ln;
+        put32(p, (uint32_t)lens[i]); p += 4;
+    }
+    const int rc = bgzf_write(w, h, (size_t)(p - h));
+    free(h);
+    return rc;
+}
+
+static crumble_bam_writer *writer_open(const char *path, int level, int threads, int *err)
+{
+    crumble_bam_writer *w = calloc(1, sizeof *w);
+    if (!w) { if (err) *err = fail(CRUMBLE_BAM_ENOMEM, "out of memory"); return NULL; }
+    w->level = level < 0 ? Z_DEFAULT_COMPRESSION : (level > 9 ? 9 : level);
+    w->threads = threads > 0 ? threads : omp_get_max_threads();
+    w->fp = fopen(path, "wb");
+    if (!w->fp) { if (err) *err = fail(CRUMBLE_BAM_EIO, "%s: %s", path, strerror(errno)); free(w); return NULL; }
+    return w;
+}
+
+crumble_bam_writer *crumble_bam_create(const char *path, const crumble_bam_reader *r, const char *pg_line,
+                                       int level, int threads, int *err)
+{
+    crumble_bam_writer *w = writer_open(path, level, threads, err);
+    if (!w) return NULL;
+    const int rc = write_header(w, r->text, r->l_text, pg_line, r->n_ref, (const char *const *)r->ref_name, r->ref_len);
+    if (rc) { if (err) *err = rc; fclose(w->fp); free(w->obuf); free(w); return NULL; }
+    if (err) *err = 0;
+    return w;
+}
+
+int crumble_bam_write_group(crumble_bam_writer *w, crumble_bam_reader *r, const uint8_t *qual_out)
+{
+    if (r->n == 0) return 0;
+    if (qual_out) {
+        #pragma omp parallel for schedule(static) num_threads(w->threads)
+        for (int64_t i = 0; i < r->n; i++) {
+            uint8_t *p = r->raw + r->rec_off[i];
+            const int32_t lseq = (int32_t)le32(p + F_LSEQ);
+            uint8_t *ql = p + F_FIXED + p[F_LNAME] + 4 * (size_t)le16(p + F_NCIG) + ((size_t)lseq + 1) / 2;
+            if (lseq > 0 && ql[0] != 0xff) memcpy(ql, qual_out + r->seq_off[i], (size_t)lseq);
+        }
+    }
+    const size_t first = r->rec_off[0];
+    return bgzf_write(w, r->raw + first, r->group_end - first);
+}
+
+int crumble_bam_writer_close(crumble_bam_writer *w)
+{
+    if (!w) return 0;
+    int rc = 0;
+    if (fwrite(BGZF_EOF, 1, 28, w->fp) != 28) rc = fail(CRUMBLE_BAM_EIO, "write error: %s", strerror(errno));
+    if (fclose(w->fp) != 0 && !rc) rc = fail(CRUMBLE_BAM_EIO, "close: %s", strerror(errno));
+    free(w->obuf); free(w);
+    return rc;
+}
+
+/* --------------------------------------------------- SoA -> BAM (test helper) */
+static int reg2bin(int64_t beg, int64_t end)
+{   /* SAMv1 5.3 */
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+int crumble_bam_write_batches(const char *path, int32_t n_ref, const char *const *names, const int64_t *lens,
+                              int32_t n_batches, const crumble_batch *batches, int level, int threads)
+{
+    int err = 0;
+    crumble_bam_writer *w = writer_open(path, level, threads, &err);
+    if (!w) return err;
+    static const char text[] = "@HD\tVN:1.6\tSO:coordinate\n";
+    int rc = write_header(w, text, (int64_t)strlen(text), NULL, n_ref, names, lens);
+    int64_t serial = 0;
+    for (int32_t bi = 0; bi < n_batches && !rc; bi++) {
+        const crumble_batch *b = &batches[bi];
+        const int64_t n = b->n_reads;
+        size_t *off = malloc(((size_t)n + 1) * sizeof *off);
+        if (!off) { rc = fail(CRUMBLE_BAM_ENOMEM, "out of memory"); break; }
+        size_t tot = 0;
+        for (int64_t i = 0; i < n; i++) {
+            char nm[32];
+            const int ln = snprintf(nm, sizeof nm, "r%lld", (long long)(serial + i)) + 1;
+            const int64_t lq = b->seq_off[i + 1] - b->seq_off[i], ncg = b->cig_off[i + 1] - b->cig_off[i];
+            off[i] = tot;
+            tot += (size_t)F_FIXED + (size_t)ln + 4 * (size_t)ncg + ((size_t)lq + 1) / 2 + (size_t)lq;
+        }
+        off[n] = tot;
+        uint8_t *buf = malloc(tot + 1);
+        if (!buf) { free(off); rc = fail(CRUMBLE_BAM_ENOMEM, "out of memory"); break; }
+        #pragma omp parallel for schedule(static) num_threads(w->threads)
+        for (int64_t i = 0; i < n; i++) {
+            uint8_t *p = buf + off[i];
+            char nm[32];
+            const int ln = snprintf(nm, sizeof nm, "r%lld", (long long)(serial + i)) + 1;
+            const int64_t lq = b->seq_off[i + 1] - b->seq_off[i], ncg = b->cig_off[i + 1] - b->cig_off[i];
+            const uint32_t *cg = b->cigar + b->cig_off[i];
+            int64_t rlen = 0;
+            for (int64_t k = 0; k < ncg; k++) { const unsigned op = cg[k] & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += cg[k] >> 4; }
+            put32(p, (uint32_t)(off[i + 1] - off[i] - 4));
+            put32(p + F_REFID, (uint32_t)b->tid);
+            put32(p + F_POS, (uint32_t)b->pos[i]);
+            p[F_LNAME] = (uint8_t)ln; p[F_MAPQ] = b->mapq[i];
+            put16(p + 14, (uint16_t)reg2bin(b->pos[i] < 0 ? 0 : b->pos[i], (b->pos[i] < 0 ? 0 : b->pos[i]) + (rlen ? rlen : 1)));
+            put16(p + F_NCIG, (uint16_t)ncg); put16(p + F_FLAG, b->flag[i]);
+            put32(p + F_LSEQ, (uint32_t)lq);
+            put32(p + 24, (uint32_t)-1); put32(p + 28, (uint32_t)-1); put32(p + 32, 0);
+            uint8_t *q = p + F_FIXED;
+            memcpy(q, nm, (size_t)ln); q += ln;
+            for (int64_t k = 0; k < ncg; k++) { put32(q, cg[k]); q += 4; }
+            const uint8_t *bs = b->bases + b->seq_off[i];
+            for (int64_t k = 0; k + 1 < lq; k += 2) *q++ = (uint8_t)((bs[k] & 15) << 4 | (bs[k + 1] & 15));
+            if (lq & 1) *q++ = (uint8_t)((bs[lq - 1] & 15) << 4);
+            memcpy(q, b->quals + b->seq_off[i], (size_t)lq);
+        }
+        rc = bgzf_write(w, buf, tot);
+        serial += n;
+        free(buf); free(off);
+    }
+    const int rc2 = crumble_bam_writer_close(w);
+    return rc ? rc : rc2;
+}
+
+/* ------------------------------------------------------------------- -R BED */
+int crumble_bam_load_bed(const crumble_bam_reader *r, const char *path, int32_t **tid, int32_t **start, int32_t **end)
+{
+    FILE *fp = fopen(path, "r");
+    if (!fp) return fail(CRUMBLE_BAM_EIO, "%s: %s", path, strerror(errno));
+    char line[8192], chr[8192];
+    int n = 0, cap = 0, s, e;
+    int32_t *t = NULL, *st = NULL, *en = NULL;
+    while (fgets(line, sizeof line, fp)) {
+        /* same line filter and field scan as bed_load (bed.c:55-64) */
+        if (line[0] == '#' || !strncmp(line, "track", 5) || !strncmp(line, "browser", 7) || line[0] == '\n') continue;
+        if (sscanf(line, "%8191s %d %d", chr, &s, &e) != 3) { fclose(fp); free(t); free(st); free(en); return fail(CRUMBLE_BAM_EFORMAT, "malformed bed line: %s", line); }
+        int id = -1;
+        for (int32_t i = 0; i < r->n_ref; i++) if (!strcmp(r->ref_name[i], chr)) { id = i; break; }
+        if (id < 0) { fclose(fp); free(t); free(st); free(en); return fail(CRUMBLE_BAM_EFORMAT, "unknown reference name: %s", chr); }
+        if (n == cap) {
+            cap = cap ? cap * 2 : 1024;
+            t = realloc(t, cap * sizeof *t); st = realloc(st, cap * sizeof *st); en = realloc(en, cap * sizeof *en);
+            if (!t || !st || !en) { fclose(fp); return fail(CRUMBLE_BAM_ENOMEM, "out of memory"); }
+        }
+        t[n] = id; st[n] = s; en[n] = e; n++;
+    }
+    fclose(fp);
+    if (n) n = crumble_bed_collapse(t, st, en, n);
+    *tid = t; *start = st; *end = en;
+    return n;
+}

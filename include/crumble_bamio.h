@@ -1,0 +1,77 @@
+/*
+ * crumble_bamio.h -- host ingest / egress either side of the column engine.
+ *
+ * Reference crumble reads and writes through htslib: sam_read1() inside pileup_callback()
+ * (snp_score.c:1116-1117) and sam_write1() inside flush_bam_list() (snp_score.c:1101).  htslib is
+ * not part of /root/reference, so this is a from-the-spec BGZF + BAM (SAMv1 section 4) reader and
+ * writer that produces exactly the SoA `crumble_batch` the engine consumes and writes the records
+ * back with the engine's quality bytes.  BGZF blocks are inflated / deflated by an OpenMP team
+ * (zlib per block), record fields are unpacked per read in parallel.
+ *
+ * Plain C ABI, no HIP.  Lives in libcrumble_bamio.so so that hosts which already have htslib need
+ * not link it.  Not supported (documented, fenced with an error): CRAM/SAM text, >65535-op CIGARs
+ * stored in the CG tag, BAM index output.
+ */
+#ifndef CRUMBLE_BAMIO_H
+#define CRUMBLE_BAMIO_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include "crumble_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRUMBLE_BAM_EIO      -20   /* open/read/write failed                      */
+#define CRUMBLE_BAM_EFORMAT  -21   /* not BGZF / not BAM / truncated / corrupt    */
+#define CRUMBLE_BAM_ENOMEM   -22
+#define CRUMBLE_BAM_EUNSUPP  -23   /* valid BAM feature this reader does not take */
+
+typedef struct crumble_bam_reader crumble_bam_reader;
+typedef struct crumble_bam_writer crumble_bam_writer;
+
+/* Opens a BAM file and parses its header.  threads <= 0: omp_get_max_threads(). */
+crumble_bam_reader *crumble_bam_open(const char *path, int threads, int *err);
+void        crumble_bam_close(crumble_bam_reader *r);
+int32_t     crumble_bam_n_ref(const crumble_bam_reader *r);
+const char *crumble_bam_ref_name(const crumble_bam_reader *r, int32_t tid);
+int64_t     crumble_bam_ref_len(const crumble_bam_reader *r, int32_t tid);
+const char *crumble_bam_header_text(const crumble_bam_reader *r, int64_t *len);
+
+/* Reads the next run of records sharing one refID (a contig, or the trailing tid -1 block: the
+ * unit transcode() resets its state on, snp_score.c:1478-1488) and fills *b with SoA views owned
+ * by the reader, valid until the next call.  b->n_bed is 0 (the caller attaches keep regions).
+ * Missing qualities (0xff, SAMv1 4.2.3) are presented as 0 and written back untouched.
+ * Returns 1 when a group was produced, 0 at end of file, < 0 on error. */
+int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b);
+
+/* Creates an output BAM with the reader's header; pg_line (may be NULL) is a complete "@PG\t..."
+ * line without newline that is appended to the header text (the reference adds its @PG through
+ * sam_hdr_add_pg, snp_score.c:2588-2609).  level: zlib 0..9 (-1 default). */
+crumble_bam_writer *crumble_bam_create(const char *path, const crumble_bam_reader *hdr_from,
+                                       const char *pg_line, int level, int threads, int *err);
+/* Writes the reader's current group with qual_out (same layout as crumble_hip_contig's output;
+ * NULL = qualities unchanged) replacing the quality bytes: flush_bam_list(), snp_score.c:1081-1105. */
+int crumble_bam_write_group(crumble_bam_writer *w, crumble_bam_reader *r, const uint8_t *qual_out);
+/* Writes the BGZF EOF block and closes. */
+int crumble_bam_writer_close(crumble_bam_writer *w);
+
+/* Test / bench helper: writes SoA batches as a BAM (read names "r<n>", no aux tags, mate fields
+ * empty).  Batches must be in header order. */
+int crumble_bam_write_batches(const char *path, int32_t n_ref, const char *const *names,
+                              const int64_t *lens, int32_t n_batches, const crumble_batch *batches,
+                              int level, int threads);
+
+/* "chrom<TAB>start<TAB>end" keep regions (-R, bed.c:42-105 bed_load) resolved against the
+ * reader's reference names and collapsed per contig with crumble_bed_collapse().  Returns the
+ * number of regions (arrays malloc'ed, sorted by tid then start; caller frees) or < 0. */
+int crumble_bam_load_bed(const crumble_bam_reader *r, const char *path,
+                         int32_t **tid, int32_t **start, int32_t **end);
+
+const char *crumble_bam_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

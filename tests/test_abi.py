@@ -21,6 +21,14 @@ def test_exports_every_declared_symbol(product):
         assert hasattr(L, n), f"{n} declared in include/ but not exported"
 
 
+def test_bamio_exports_every_declared_symbol(product):
+    L = C.CDLL(os.path.join(ROOT, "crumble_amd", "libcrumble_bamio.so"))
+    names = [n for n in _declared("crumble_bamio.h") if n.startswith("crumble_bam_")]
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/crumble_bamio.h but not exported"
+
+
 def test_presets_match_reference_table(product):
     """SURVEY.md App. E / snp_score.c:2380-2482."""
     want = {

@@ -1,0 +1,290 @@
+"""Host ingest / egress: BGZF + BAM reader and writer, and the crumble-hip
+file -> file driver.  The checker for the reader is an independent pure-Python BGZF/BAM
+encoder in this file (struct + zlib from the SAMv1 text); the checker for the writer is
+Python's own gzip decoder plus a pure-Python record walker."""
+import gzip
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import crumble_amd as ca
+from crumble_amd import bamio, synth
+from crumble_amd.capi import ROOT, HostBatch
+
+import oracle_lib as O
+
+BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+# ---------------------------------------------------------------- independent encoder / walker
+def py_bgzf(data, block=30000, empty_every=0):
+    out = bytearray()
+    k = 0
+    for off in range(0, len(data), block):
+        chunk = data[off:off + block]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = c.compress(chunk) + c.flush()
+        out += struct.pack("<4BI2BH2BHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(comp) + 25)
+        out += comp + struct.pack("<II", zlib.crc32(chunk), len(chunk))
+        k += 1
+        if empty_every and k % empty_every == 0:
+            out += BGZF_EOF                                   # empty blocks may appear anywhere
+    return bytes(out) + BGZF_EOF
+
+
+def py_bam(refs, reads, text="@HD\tVN:1.6\tSO:coordinate\n"):
+    """reads: dicts(tid,pos,mapq,flag,cigar(list of u32),seq(nt16 codes),qual(bytes or None),name,aux)."""
+    out = bytearray(b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(refs)))
+    for n, l in refs:
+        out += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", l)
+    for r in reads:
+        name = r.get("name", "q").encode() + b"\0"
+        seq = [int(x) for x in r["seq"]]
+        packed = bytes(((seq[i] << 4) | (seq[i + 1] if i + 1 < len(seq) else 0)) for i in range(0, len(seq), 2))
+        qual = bytes(np.asarray(r["qual"], np.uint8)) if r.get("qual") is not None else b"\xff" * len(seq)
+        aux = r.get("aux", b"")
+        body = struct.pack("<iiBBHHHiiii", r["tid"], r["pos"], len(name), r.get("mapq", 60), 4680, len(r["cigar"]),
+                           r.get("flag", 0), len(seq), -1, -1, 0)
+        body += name + b"".join(struct.pack("<I", c) for c in r["cigar"]) + packed + qual + aux
+        out += struct.pack("<i", len(body)) + body
+    return bytes(out)
+
+
+def walk_bam(path):
+    """-> (header text, refs, [record dicts]) using only gzip + struct."""
+    d = gzip.decompress(open(path, "rb").read())              # checks every member's CRC32 and ISIZE
+    assert d[:4] == b"BAM\1"
+    lt, = struct.unpack_from("<i", d, 4)
+    text = d[8:8 + lt].decode()
+    p = 8 + lt
+    nref, = struct.unpack_from("<i", d, p); p += 4
+    refs = []
+    for _ in range(nref):
+        ln, = struct.unpack_from("<i", d, p); p += 4
+        nm = d[p:p + ln - 1].decode(); p += ln
+        l, = struct.unpack_from("<i", d, p); p += 4
+        refs.append((nm, l))
+    recs = []
+    while p < len(d):
+        bs, = struct.unpack_from("<i", d, p); p += 4
+        tid, pos, lname, mapq, _bin, ncig, flag, lseq, _nt, _np, _tl = struct.unpack_from("<iiBBHHHiiii", d, p)
+        q = p + 32
+        name = d[q:q + lname - 1]; q += lname
+        cig = list(struct.unpack_from(f"<{ncig}I", d, q)); q += 4 * ncig
+        sq = d[q:q + (lseq + 1) // 2]; q += (lseq + 1) // 2
+        qual = d[q:q + lseq]; q += lseq
+        recs.append(dict(tid=tid, pos=pos, mapq=mapq, flag=flag, cigar=cig, seqpacked=sq, qual=qual, name=name,
+                         aux=d[q:p + bs]))
+        p += bs
+    return text, refs, recs
+
+
+def batches_equal(a, b):
+    for nm in ("pos", "mapq", "flag", "seq_off", "cig_off", "cigar", "bases", "quals"):
+        assert np.array_equal(getattr(a, nm), getattr(b, nm)), nm
+    assert a.tid == b.tid
+
+
+def three_groups():
+    b0 = synth.generate(synth.config("ce", scale=0.5))
+    b1 = synth.generate(synth.config("ce", scale=0.2, seed=77, tid=1))
+    rng = np.random.default_rng(3)
+    n, L = 30, 100
+    un = HostBatch(-1, np.full(n, -1), np.zeros(n), np.full(n, 4), np.arange(n + 1) * L, np.zeros(n + 1),
+                   np.zeros(0, np.uint32), rng.choice([1, 2, 4, 8, 15], n * L), rng.integers(2, 42, n * L))
+    return [("chrI", 60000), ("chrII", 25000)], [b0, b1, un]
+
+
+# ------------------------------------------------------------------------------- tests
+def test_write_batches_then_read_back(tmp_path):
+    refs, bs = three_groups()
+    path = tmp_path / "t.bam"
+    bamio.write_batches(path, refs, bs, level=6)
+    text, wrefs, recs = walk_bam(path)                        # valid gzip members, valid BAM
+    assert wrefs == refs and "SO:coordinate" in text
+    assert len(recs) == sum(b.n_reads for b in bs)
+    assert open(path, "rb").read()[-28:] == BGZF_EOF
+    assert [r["pos"] for r in recs[:bs[0].n_reads]] == list(bs[0].pos)
+    rd = bamio.Reader(path, threads=3)
+    assert rd.refs == refs
+    got = list(rd)
+    rd.close()
+    assert len(got) == 3
+    for a, b in zip(got, bs):
+        batches_equal(a, b)
+
+
+def test_reader_against_python_encoder(tmp_path):
+    rng = np.random.default_rng(11)
+    refs = [("a", 5000), ("b", 9000), ("c", 100)]
+    reads = []
+    for tid, n in ((0, 400), (2, 7)):                         # contig b has no reads; group order = header order
+        pos = np.sort(rng.integers(0, 3000 if tid == 0 else 50, n))
+        for i in range(n):
+            L = int(rng.integers(0, 180))                     # includes l_seq == 0 and odd lengths
+            cig = [(L << 4) | 0] if L else []
+            if L > 20 and rng.random() < 0.3:
+                cig = [(5 << 4) | 4, ((L - 12) << 4) | 0, (3 << 4) | 2, (7 << 4) | 0]
+            reads.append(dict(tid=tid, pos=int(pos[i]), mapq=int(rng.integers(0, 61)), flag=int(rng.choice([0, 16, 99, 147])),
+                              cigar=cig, seq=rng.choice([1, 2, 4, 8, 15], L), qual=None if i % 50 == 7 else rng.integers(0, 94, L),
+                              name=f"read{i}", aux=b"NMC\x03XSZhello\0" if i % 3 == 0 else b""))
+    reads.append(dict(tid=-1, pos=-1, flag=4, cigar=[], seq=[1, 2, 4], qual=[30, 31, 32], name="un"))
+    raw = py_bam(refs, reads)
+    path = tmp_path / "p.bam"
+    path.write_bytes(py_bgzf(raw, block=777, empty_every=5))  # records and header fields straddle blocks
+    rd = bamio.Reader(path, threads=2)
+    assert rd.refs == refs
+    groups = list(rd)
+    assert [g.tid for g in groups] == [0, 2, -1]
+    k = 0
+    for g in groups:
+        for i in range(g.n_reads):
+            r = reads[k]; k += 1
+            assert (g.pos[i], g.mapq[i], g.flag[i]) == (r["pos"], r.get("mapq", 60), r.get("flag", 0))
+            assert list(g.cigar[g.cig_off[i]:g.cig_off[i + 1]]) == r["cigar"]
+            assert list(g.bases[g.seq_off[i]:g.seq_off[i + 1]]) == list(r["seq"])
+            want = np.zeros(len(r["seq"]), np.uint8) if r.get("qual") is None else np.asarray(r["qual"], np.uint8)
+            assert np.array_equal(g.quals[g.seq_off[i]:g.seq_off[i + 1]], want)
+    assert k == len(reads)
+    rd.close()
+
+    # writer: names, aux, cigars and absent qualities survive; other qualities are replaced
+    rd = bamio.Reader(path)
+    wr = bamio.Writer(tmp_path / "o.bam", rd, pg_line="@PG\tID:test\tPN:test", level=1, threads=2)
+    while True:
+        g = rd.next_contig()
+        if g is None:
+            break
+        wr.write_group((g.quals ^ 1) if g.tid != 2 else None)
+    wr.close(); rd.close()
+    text, wrefs, recs = walk_bam(tmp_path / "o.bam")
+    assert wrefs == refs and text.endswith("@PG\tID:test\tPN:test\n")
+    assert len(recs) == len(reads)
+    for r, o in zip(reads, recs):
+        assert o["name"] == r["name"].encode() and o["aux"] == r.get("aux", b"") and o["cigar"] == r["cigar"]
+        if r.get("qual") is None:
+            assert o["qual"] == b"\xff" * len(r["seq"])
+        elif r["tid"] == 2:
+            assert o["qual"] == bytes(np.asarray(r["qual"], np.uint8))
+        else:
+            assert o["qual"] == bytes(np.asarray(r["qual"], np.uint8) ^ 1)
+
+
+def test_reader_rejects_bad_input(tmp_path):
+    raw = py_bam([("a", 100)], [dict(tid=0, pos=1, cigar=[(3 << 4)], seq=[1, 2, 4], qual=[1, 2, 3])])
+    good = py_bgzf(raw)
+    cases = {
+        "plain gzip": gzip.compress(raw),
+        "not bam": py_bgzf(b"BAX\1" + raw[4:]),
+        "truncated block": good[:len(good) - 40],
+        "truncated record": py_bgzf(raw[:-2]),
+        "crc": good[:30] + bytes([good[30] ^ 0x55]) + good[31:],
+        "empty": b"",
+    }
+    for name, data in cases.items():
+        p = tmp_path / "bad.bam"
+        p.write_bytes(data)
+        with pytest.raises(bamio.BamError):
+            rd = bamio.Reader(p)
+            list(rd)
+    with pytest.raises(bamio.BamError):
+        bamio.Reader(tmp_path / "missing.bam")
+    # CG-tag placeholder CIGAR (kSmN) is refused, not misread
+    raw = py_bam([("a", 100)], [dict(tid=0, pos=1, cigar=[(3 << 4) | 4, (50 << 4) | 3], seq=[1, 2, 4], qual=[1, 2, 3])])
+    (tmp_path / "cg.bam").write_bytes(py_bgzf(raw))
+    with pytest.raises(bamio.BamError) as e:
+        list(bamio.Reader(tmp_path / "cg.bam"))
+    assert e.value.code == -23
+
+
+def test_load_bed_matches_bed_collapse(tmp_path):
+    refs = [("chrI", 60000), ("chrII", 25000)]
+    bamio.write_batches(tmp_path / "h.bam", refs, [])
+    (tmp_path / "k.bed").write_text("# c\ntrack x\nbrowser y\n\nchrII\t10\t20\nchrI 500 900\nchrI\t100\t600\textra\nchrI\t2000\t2100\n")
+    rd = bamio.Reader(tmp_path / "h.bam")
+    got = rd.load_bed(tmp_path / "k.bed")
+    assert got.tolist() == [[0, 100, 900], [0, 2000, 2100], [1, 10, 20]]
+    (tmp_path / "bad.bed").write_text("chrIII\t1\t2\n")
+    with pytest.raises(bamio.BamError):
+        rd.load_bed(tmp_path / "bad.bed")
+    rd.close()
+
+
+def _oracle_file(params, path, bed=None):
+    """What crumble-hip must write: per group, the oracle's bytes (the checker)."""
+    O.load()
+    rd = bamio.Reader(path)
+    out = []
+    for g in rd:
+        if bed is not None and g.tid >= 0:
+            sel = bed[bed[:, 0] == g.tid][:, 1:]
+            g = HostBatch(g.tid, g.pos, g.mapq, g.flag, g.seq_off, g.cig_off, g.cigar, g.bases, g.quals, sel)
+        out.append(O.contig(params, g)[0])
+    rd.close()
+    return np.concatenate(out)
+
+
+def _file_quals(path):
+    return np.frombuffer(b"".join(r["qual"] for r in walk_bam(path)[2]), np.uint8)
+
+
+def test_cli_end_to_end_emulated(tmp_path):
+    """crumble-hip (csrc/cli.c) linked against the CPU-emulated kernels: file in, file out, bytes == oracle."""
+    import emu_lib
+    emu_lib.load()
+    exe = os.path.join(ROOT, "tests", "emu", "crumble-hip-emu")
+    refs, bs = three_groups()
+    bamio.write_batches(tmp_path / "in.bam", refs, bs)
+    (tmp_path / "keep.bed").write_text("chrI\t1000\t3000\nchrII\t500\t800\n")
+    for args, params, bed in (
+            (["-5"], ca.preset_params(5), None),
+            (["-1", "-u", "35", "-K", "2-3", "-R", str(tmp_path / "keep.bed")], ca.preset_params(1, really_keep="2-3", qhigh=35), True),
+            (["-9", "-y", "pbccs", "-S"], ca.preset_params(9, tech="pbccs", softclip=1), None)):
+        r = subprocess.run([exe, "-v", *args, str(tmp_path / "in.bam"), str(tmp_path / "out.bam")],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        assert "Gbases/s file to file" in r.stderr
+        bedarr = None
+        if bed:
+            rd = bamio.Reader(tmp_path / "in.bam"); bedarr = rd.load_bed(tmp_path / "keep.bed"); rd.close()
+        want = _oracle_file(params, tmp_path / "in.bam", bedarr)
+        got = _file_quals(tmp_path / "out.bam")
+        assert np.array_equal(got, want), np.nonzero(got != want)[0][:10]
+        text, wrefs, recs = walk_bam(tmp_path / "out.bam")
+        assert wrefs == refs and "@PG\tID:crumble-hip" in text and len(recs) == sum(b.n_reads for b in bs)
+    # options that were not rebuilt are refused loudly
+    r = subprocess.run([exe, "-r", "chrI", str(tmp_path / "in.bam"), str(tmp_path / "o2.bam")], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "does not provide" in r.stderr
+
+
+def test_cli_has_no_cpu_path(tmp_path):
+    """Without a GPU the shipped binary stops with ENODEVICE (exit 2); it never computes on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    exe = os.path.join(ROOT, "crumble_amd", "crumble-hip")
+    refs, bs = three_groups()
+    bamio.write_batches(tmp_path / "in.bam", refs, bs[:1])
+    r = subprocess.run([exe, "-5", str(tmp_path / "in.bam"), str(tmp_path / "out.bam")], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 2 and "no usable HIP device" in r.stderr
+    assert not os.path.exists(tmp_path / "out.bam")
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_gpu(tmp_path):
+    exe = os.path.join(ROOT, "crumble_amd", "crumble-hip")
+    b0 = synth.generate(synth.config("chr20", scale=0.004))
+    b1 = synth.generate(synth.config("panel", scale=0.01, tid=1))
+    refs = [("chr20", 63025520), ("panel", 20000000)]
+    bamio.write_batches(tmp_path / "in.bam", refs, [b0, b1])
+    for args, params in ((["-5"], ca.preset_params(5)), (["-9", "-p", "4"], ca.preset_params(9, pblock=4))):
+        r = subprocess.run([exe, "-v", *args, str(tmp_path / "in.bam"), str(tmp_path / "out.bam")],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr
+        want = _oracle_file(params, tmp_path / "in.bam")
+        got = _file_quals(tmp_path / "out.bam")
+        assert np.array_equal(got, want)
