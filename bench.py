@@ -37,6 +37,37 @@ def prefix_batch(hb, n_reads):
                      hb.cig_off[:n + 1], hb.cigar[:nc], hb.bases[:nb], hb.quals[:nb])
 
 
+def file_to_file(hb, args, device):
+    """Metric (ii): the same contig as a BAM file through the crumble-hip driver (BGZF inflate + BAM parse +
+    H2D + kernels + D2H + BGZF deflate), wall clock of the whole process."""
+    import re
+    import subprocess
+    import tempfile
+    from crumble_amd import bamio
+    tmp = tempfile.mkdtemp(prefix="crumble_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
+    src, dst = os.path.join(tmp, "in.bam"), os.path.join(tmp, "out.bam")
+    try:
+        bamio.write_batches(src, [("chr20", 64444167)], [hb], level=1)
+        env = dict(os.environ, CRUMBLE_HIP_DEVICE=str(device), CRUMBLE_BAM_LEVEL="1")
+        t0 = time.perf_counter()
+        r = subprocess.run([os.path.join(ROOT, "crumble_amd", "crumble-hip"), "-v", f"-{args.preset}", src, dst],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        wall = time.perf_counter() - t0
+        if r.returncode:
+            return {"error": r.stderr[-300:]}
+        m = re.search(r"end-to-end ([0-9.]+) s \(read\+parse ([0-9.]+), upload\+kernels\+download ([0-9.]+), write ([0-9.]+)\)", r.stderr)
+        st = [float(x) for x in m.groups()] if m else [None] * 4
+        return {"value": round(hb.n_bases / wall / 1e9, 4), "unit": "Gbases/s", "process_wall_s": round(wall, 2),
+                "loop_s": st[0], "read_parse_s": st[1], "gpu_incl_pcie_s": st[2], "deflate_write_s": st[3],
+                "host_threads": os.cpu_count(), "in_bytes": os.path.getsize(src), "out_bytes": os.path.getsize(dst),
+                "note": "BAM (zlib level 1) -> crumble-hip -> BAM; includes process start, hipInit and engine creation"}
+    finally:
+        for f in (src, dst):
+            if os.path.exists(f):
+                os.remove(f)
+        os.rmdir(tmp)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -48,6 +79,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--e2e", action="store_true",
+                    help="also time metric (ii): BAM file -> crumble-hip -> BAM file (SURVEY.md 8d), reported "
+                         "as an extra 'end_to_end' object; never part of 'value'")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -214,6 +248,8 @@ def main():
                 e2.close()
                 out["config"]["verified_bit_exact_on_sample"] = bool(
                     np.array_equal(gq, wq) and np.array_equal(gf, wf) and np.array_equal(gs, ws))
+        if args.e2e:
+            out["end_to_end"] = file_to_file(hb, args, local_rank)
         print(json.dumps(out))
     for e_ in engines:
         e_.close()
