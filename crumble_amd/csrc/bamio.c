@@ -19,6 +19,7 @@
 #include <stdarg.h>
 #include <zlib.h>
 #include <omp.h>
+#include <sys/mman.h>
 #include "../../include/crumble_bamio.h"
 
 static __thread char g_err[512];
@@ -32,10 +33,66 @@ static int fail(int code, const char *fmt, ...)
     return code;
 }
 
+/* coarse phase timers (seconds), reported by crumble_bam_timing(): where host time goes */
+#include <time.h>
+static double T_fread, T_inflate, T_scan, T_prefix, T_unpack, T_scatter, T_deflate, T_fwrite;
+static inline double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+int crumble_bam_timing(char *buf, size_t len)
+{
+    return snprintf(buf, len, "bamio: fread %.3f inflate %.3f record-scan %.3f prefix %.3f unpack %.3f | scatter %.3f deflate %.3f fwrite %.3f s",
+                    T_fread, T_inflate, T_scan, T_prefix, T_unpack, T_scatter, T_deflate, T_fwrite);
+}
+
 static inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
 static inline uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | p[1] << 8); }
 static inline void put32(uint8_t *p, uint32_t v) { p[0] = v; p[1] = v >> 8; p[2] = v >> 16; p[3] = v >> 24; }
 static inline void put16(uint8_t *p, uint16_t v) { p[0] = v; p[1] = v >> 8; }
+
+/* Multi-GB buffers come straight from mmap with MADV_HUGEPAGE: first touch of 4 KiB pages by a
+ * large OpenMP team is otherwise the dominant host cost (one page fault per 4 KiB, serialised on
+ * the address-space lock).  Growing keeps the contents through mremap (no copy). */
+static void *big_alloc(size_t n)
+{
+    void *p = mmap(NULL, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) return NULL;
+    madvise(p, n, MADV_HUGEPAGE);
+    return p;
+}
+static void big_free(void *p, size_t n) { if (p && n) munmap(p, n); }
+static void *big_grow(void *p, size_t old, size_t n)
+{
+    if (!p || !old) return big_alloc(n);
+    void *q = mremap(p, old, n, MREMAP_MAYMOVE);
+    if (q == MAP_FAILED) return NULL;
+    madvise(q, n, MADV_HUGEPAGE);
+    return q;
+}
+void *crumble_bam_big_alloc(size_t n) { return big_alloc(n); }
+void  crumble_bam_big_free(void *p, size_t n) { big_free(p, n); }
+
+/* Default team size: the CPUs this process may actually use (affinity mask and cgroup v2 quota),
+ * at most 64 -- beyond that the per-block zlib work no longer scales and an over-subscribed
+ * container (more visible CPUs than quota) collapses. */
+#include <sched.h>
+static int default_threads(void)
+{
+    int n = omp_get_max_threads();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0 && c < n) n = c; }
+    FILE *fp = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (fp) {
+        long long quota = 0, period = 0;
+        char q[32];
+        if (fscanf(fp, "%31s %lld", q, &period) == 2 && strcmp(q, "max") && period > 0) {
+            quota = atoll(q);
+            const int c = (int)((quota + period - 1) / period);
+            if (c > 0 && c < n) n = c;
+        }
+        fclose(fp);
+    }
+    if (n > 64) n = 64;
+    return n < 1 ? 1 : n;
+}
 
 /* ------------------------------------------------------------------ BGZF in */
 #define CHUNK_IN   (32u << 20)      /* compressed bytes read per refill           */
@@ -68,7 +125,8 @@ static int raw_reserve(crumble_bam_reader *r, size_t need)
     if (need <= r->raw_cap) return 0;
     size_t nc = r->raw_cap ? r->raw_cap : (64u << 20);
     while (nc < need) nc += nc / 2 + (16u << 20);
-    uint8_t *p = realloc(r->raw, nc);
+    nc = (nc + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    uint8_t *p = big_grow(r->raw, r->raw_cap, nc);
     if (!p) return fail(CRUMBLE_BAM_ENOMEM, "out of memory growing record buffer to %zu bytes", nc);
     r->raw = p; r->raw_cap = nc;
     return 0;
@@ -84,7 +142,9 @@ static int refill(crumble_bam_reader *r)
                 if (!p) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
                 r->cbuf = p; r->ccap = r->clen + CHUNK_IN;
             }
+            const double tf = now_s();
             size_t got = fread(r->cbuf + r->clen, 1, CHUNK_IN, r->fp);
+            T_fread += now_s() - tf;
             if (got < CHUNK_IN) {
                 if (ferror(r->fp)) return fail(CRUMBLE_BAM_EIO, "read error: %s", strerror(errno));
                 r->eof_file = 1;
@@ -130,19 +190,25 @@ static int refill(crumble_bam_reader *r)
         if (rc) { free(blk); return rc; }
         uint8_t *dst = r->raw + r->raw_len;
         int bad = 0;
-        #pragma omp parallel for schedule(dynamic, 16) num_threads(r->threads) reduction(|:bad)
-        for (size_t i = 0; i < nb; i++) {
-            if (blk[i].ulen == 0) continue;
-            z_stream zs; memset(&zs, 0, sizeof zs);
-            if (inflateInit2(&zs, -15) != Z_OK) { bad |= 1; continue; }
-            zs.next_in = r->cbuf + blk[i].coff; zs.avail_in = (uInt)blk[i].clen;
-            zs.next_out = dst + blk[i].uoff;    zs.avail_out = (uInt)blk[i].ulen;
-            const int zr = inflate(&zs, Z_FINISH);
-            if (zr != Z_STREAM_END || zs.avail_out != 0) bad |= 2;
-            inflateEnd(&zs);
-            if (crc32(crc32(0L, Z_NULL, 0), dst + blk[i].uoff, (uInt)blk[i].ulen) != blk[i].crc) bad |= 4;
+        const double ti = now_s();
+        #pragma omp parallel num_threads(r->threads) reduction(|:bad)
+        {
+            z_stream zs; memset(&zs, 0, sizeof zs);            /* one inflate state per thread, reset per block */
+            const int zok = inflateInit2(&zs, -15) == Z_OK;
+            #pragma omp for schedule(dynamic, 4)
+            for (size_t i = 0; i < nb; i++) {
+                if (blk[i].ulen == 0) continue;
+                if (!zok || inflateReset(&zs) != Z_OK) { bad |= 1; continue; }
+                zs.next_in = r->cbuf + blk[i].coff; zs.avail_in = (uInt)blk[i].clen;
+                zs.next_out = dst + blk[i].uoff;    zs.avail_out = (uInt)blk[i].ulen;
+                const int zr = inflate(&zs, Z_FINISH);
+                if (zr != Z_STREAM_END || zs.avail_out != 0) bad |= 2;
+                if (crc32(crc32(0L, Z_NULL, 0), dst + blk[i].uoff, (uInt)blk[i].ulen) != blk[i].crc) bad |= 4;
+            }
+            if (zok) inflateEnd(&zs);
         }
         free(blk);
+        T_inflate += now_s() - ti;
         if (bad) return fail(CRUMBLE_BAM_EFORMAT, "BGZF inflate/CRC failure (mask %d)", bad);
         memmove(r->cbuf, r->cbuf + off, r->clen - off);
         r->clen -= off;
@@ -171,7 +237,7 @@ crumble_bam_reader *crumble_bam_open(const char *path, int threads, int *err)
     int e = 0;
     crumble_bam_reader *r = calloc(1, sizeof *r);
     if (!r) { e = fail(CRUMBLE_BAM_ENOMEM, "out of memory"); goto bad; }
-    r->threads = threads > 0 ? threads : omp_get_max_threads();
+    r->threads = threads > 0 ? threads : default_threads();
     r->fp = fopen(path, "rb");
     if (!r->fp) { e = fail(CRUMBLE_BAM_EIO, "%s: %s", path, strerror(errno)); goto bad; }
     int rc;
@@ -215,11 +281,11 @@ void crumble_bam_close(crumble_bam_reader *r)
 {
     if (!r) return;
     if (r->fp) fclose(r->fp);
-    free(r->cbuf); free(r->raw); free(r->text);
+    free(r->cbuf); big_free(r->raw, r->raw_cap); free(r->text);
     if (r->ref_name) for (int32_t i = 0; i < r->n_ref; i++) free(r->ref_name[i]);
     free(r->ref_name); free(r->ref_len); free(r->rec_off);
     free(r->pos); free(r->mapq); free(r->flag); free(r->seq_off); free(r->cig_off);
-    free(r->cigar); free(r->bases); free(r->quals);
+    free(r->cigar); big_free(r->bases, r->cap_bases); big_free(r->quals, r->cap_bases);
     free(r);
 }
 
@@ -240,6 +306,7 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
     }
     r->n = 0;
     int have_tid = 0;
+    const double ts0 = now_s(), tin0 = T_inflate + T_fread;
     for (;;) {
         int rc = need_bytes(r, 4);
         if (rc < 0) return rc;
@@ -265,7 +332,9 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
         r->scan += 4 + (size_t)bs;
     }
     r->group_end = r->scan;
+    T_scan += (now_s() - ts0) - (T_inflate + T_fread - tin0);
     if (r->n == 0) return 0;
+    const double tp0 = now_s();
 
     const int64_t n = r->n;
     if (r->cap_reads < (size_t)n + 1) {
@@ -284,9 +353,10 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
     }
     r->seq_off[n] = nb; r->cig_off[n] = nc;
     if (r->cap_bases < (size_t)nb + 16) {
-        const size_t c = (size_t)nb + (size_t)nb / 8 + 64;
-        free(r->bases); free(r->quals);
-        r->bases = malloc(c); r->quals = malloc(c);
+        const size_t c = ((size_t)nb + (size_t)nb / 8 + ((size_t)2 << 20)) & ~(((size_t)2 << 20) - 1);
+        big_free(r->bases, r->cap_bases); big_free(r->quals, r->cap_bases);
+        r->bases = big_alloc(c); r->quals = big_alloc(c);
+        if (!r->bases || !r->quals) { big_free(r->bases, c); big_free(r->quals, c); r->bases = r->quals = NULL; }
         r->cap_bases = (r->bases && r->quals) ? c : 0;
         if (!r->cap_bases) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
     }
@@ -298,6 +368,8 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
         if (!r->cap_cig) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
     }
     int unsupported = 0;
+    const double tu0 = now_s();
+    T_prefix += tu0 - tp0;
     #pragma omp parallel for schedule(static) num_threads(r->threads) reduction(|:unsupported)
     for (int64_t i = 0; i < n; i++) {
         const uint8_t *p = r->raw + r->rec_off[i];
@@ -320,6 +392,7 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
         if (lseq > 0 && ql[0] == 0xff) memset(qo, 0, (size_t)lseq);     /* absent qualities */
         else memcpy(qo, ql, (size_t)lseq);
     }
+    T_unpack += now_s() - tu0;
     if (unsupported) return fail(CRUMBLE_BAM_EUNSUPP, "record with its CIGAR in the CG tag (>65535 ops) is not supported");
     memset(b, 0, sizeof *b);
     b->tid = r->tid; b->n_reads = n;
@@ -340,8 +413,9 @@ static int bgzf_write(crumble_bam_writer *w, const uint8_t *data, size_t len)
 {
     const size_t SLOT = 65536, BATCH = 4096;                 /* 256 MiB of input per round */
     if (w->ocap < SLOT * BATCH) {
-        uint8_t *p = realloc(w->obuf, SLOT * BATCH);
-        if (!p) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+        big_free(w->obuf, w->ocap);
+        uint8_t *p = big_alloc(SLOT * BATCH);
+        if (!p) { w->obuf = NULL; w->ocap = 0; return fail(CRUMBLE_BAM_ENOMEM, "out of memory"); }
         w->obuf = p; w->ocap = SLOT * BATCH;
     }
     size_t *osz = malloc(BATCH * sizeof *osz);
@@ -350,29 +424,38 @@ static int bgzf_write(crumble_bam_writer *w, const uint8_t *data, size_t len)
     for (size_t b0 = 0; b0 < nblk; b0 += BATCH) {
         const size_t nb = nblk - b0 < BATCH ? nblk - b0 : BATCH;
         int bad = 0;
-        #pragma omp parallel for schedule(dynamic, 8) num_threads(w->threads) reduction(|:bad)
-        for (size_t i = 0; i < nb; i++) {
-            const size_t off = (b0 + i) * BLK_IN, ul = len - off < BLK_IN ? len - off : BLK_IN;
-            uint8_t *o = w->obuf + i * SLOT;
-            z_stream zs; memset(&zs, 0, sizeof zs);
-            if (deflateInit2(&zs, w->level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = 1; continue; }
-            zs.next_in = (Bytef *)(data + off); zs.avail_in = (uInt)ul;
-            zs.next_out = o + 18; zs.avail_out = (uInt)(SLOT - 18 - 8);
-            if (deflate(&zs, Z_FINISH) != Z_STREAM_END) bad = 1;
-            const size_t cl = zs.total_out;
-            deflateEnd(&zs);
-            static const uint8_t hdr[16] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0 };
-            memcpy(o, hdr, 16);
-            put16(o + 16, (uint16_t)(18 + cl + 8 - 1));
-            put32(o + 18 + cl, (uint32_t)crc32(crc32(0L, Z_NULL, 0), data + off, (uInt)ul));
-            put32(o + 18 + cl + 4, (uint32_t)ul);
-            osz[i] = 18 + cl + 8;
+        const double td = now_s();
+        #pragma omp parallel num_threads(w->threads) reduction(|:bad)
+        {
+            z_stream zs; memset(&zs, 0, sizeof zs);            /* one deflate state per thread, reset per block */
+            const int zok = deflateInit2(&zs, w->level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK;
+            #pragma omp for schedule(dynamic, 4)
+            for (size_t i = 0; i < nb; i++) {
+                const size_t off = (b0 + i) * BLK_IN, ul = len - off < BLK_IN ? len - off : BLK_IN;
+                uint8_t *o = w->obuf + i * SLOT;
+                osz[i] = 0;
+                if (!zok || deflateReset(&zs) != Z_OK) { bad = 1; continue; }
+                zs.next_in = (Bytef *)(data + off); zs.avail_in = (uInt)ul;
+                zs.next_out = o + 18; zs.avail_out = (uInt)(SLOT - 18 - 8);
+                if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { bad = 1; continue; }
+                const size_t cl = zs.total_out;
+                static const uint8_t hdr[16] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0 };
+                memcpy(o, hdr, 16);
+                put16(o + 16, (uint16_t)(18 + cl + 8 - 1));
+                put32(o + 18 + cl, (uint32_t)crc32(crc32(0L, Z_NULL, 0), data + off, (uInt)ul));
+                put32(o + 18 + cl + 4, (uint32_t)ul);
+                osz[i] = 18 + cl + 8;
+            }
+            if (zok) deflateEnd(&zs);
         }
+        T_deflate += now_s() - td;
         if (bad) { free(osz); return fail(CRUMBLE_BAM_EIO, "deflate failed"); }
+        const double tw = now_s();
         /* compact the slots so the file sees one write per round */
         size_t tot = osz[0];
         for (size_t i = 1; i < nb; i++) { memmove(w->obuf + tot, w->obuf + i * SLOT, osz[i]); tot += osz[i]; }
         if (fwrite(w->obuf, 1, tot, w->fp) != tot) { free(osz); return fail(CRUMBLE_BAM_EIO, "write error: %s", strerror(errno)); }
+        T_fwrite += now_s() - tw;
     }
     free(osz);
     return 0;
@@ -408,7 +491,7 @@ static crumble_bam_writer *writer_open(const char *path, int level, int threads,
     crumble_bam_writer *w = calloc(1, sizeof *w);
     if (!w) { if (err) *err = fail(CRUMBLE_BAM_ENOMEM, "out of memory"); return NULL; }
     w->level = level < 0 ? Z_DEFAULT_COMPRESSION : (level > 9 ? 9 : level);
-    w->threads = threads > 0 ? threads : omp_get_max_threads();
+    w->threads = threads > 0 ? threads : default_threads();
     w->fp = fopen(path, "wb");
     if (!w->fp) { if (err) *err = fail(CRUMBLE_BAM_EIO, "%s: %s", path, strerror(errno)); free(w); return NULL; }
     return w;
@@ -420,7 +503,7 @@ crumble_bam_writer *crumble_bam_create(const char *path, const crumble_bam_reade
     crumble_bam_writer *w = writer_open(path, level, threads, err);
     if (!w) return NULL;
     const int rc = write_header(w, r->text, r->l_text, pg_line, r->n_ref, (const char *const *)r->ref_name, r->ref_len);
-    if (rc) { if (err) *err = rc; fclose(w->fp); free(w->obuf); free(w); return NULL; }
+    if (rc) { if (err) *err = rc; fclose(w->fp); big_free(w->obuf, w->ocap); free(w); return NULL; }
     if (err) *err = 0;
     return w;
 }
@@ -428,6 +511,7 @@ crumble_bam_writer *crumble_bam_create(const char *path, const crumble_bam_reade
 int crumble_bam_write_group(crumble_bam_writer *w, crumble_bam_reader *r, const uint8_t *qual_out)
 {
     if (r->n == 0) return 0;
+    const double tsc = now_s();
     if (qual_out) {
         #pragma omp parallel for schedule(static) num_threads(w->threads)
         for (int64_t i = 0; i < r->n; i++) {
@@ -437,6 +521,7 @@ int crumble_bam_write_group(crumble_bam_writer *w, crumble_bam_reader *r, const 
             if (lseq > 0 && ql[0] != 0xff) memcpy(ql, qual_out + r->seq_off[i], (size_t)lseq);
         }
     }
+    T_scatter += now_s() - tsc;
     const size_t first = r->rec_off[0];
     return bgzf_write(w, r->raw + first, r->group_end - first);
 }
@@ -447,7 +532,7 @@ int crumble_bam_writer_close(crumble_bam_writer *w)
     int rc = 0;
     if (fwrite(BGZF_EOF, 1, 28, w->fp) != 28) rc = fail(CRUMBLE_BAM_EIO, "write error: %s", strerror(errno));
     if (fclose(w->fp) != 0 && !rc) rc = fail(CRUMBLE_BAM_EIO, "close: %s", strerror(errno));
-    free(w->obuf); free(w);
+    big_free(w->obuf, w->ocap); free(w);
     return rc;
 }
 

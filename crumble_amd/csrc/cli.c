@@ -139,7 +139,11 @@ int main(int argc, char **argv)
         while (j < nbed && bt[j] == B.tid) j++;
         if (B.tid >= 0 && j > bed_i) { B.n_bed = j - bed_i; B.bed_start = bs + bed_i; B.bed_end = be + bed_i; }
         const size_t nb = (size_t)B.seq_off[B.n_reads];
-        if (qcap < nb + 16) { free(qout); qcap = nb + nb / 8 + 64; qout = malloc(qcap); if (!qout) { fprintf(stderr, "crumble-hip: out of memory\n"); return 1; } }
+        if (qcap < nb + 16) {
+            crumble_bam_big_free(qout, qcap);
+            qcap = nb + nb / 8 + 64; qout = crumble_bam_big_alloc(qcap);
+            if (!qout) { fprintf(stderr, "crumble-hip: out of memory\n"); return 1; }
+        }
         t0 = now();
         const int e = crumble_hip_contig(eng, &B, qout, NULL, stats);
         t_gpu += now() - t0;
@@ -156,9 +160,12 @@ int main(int argc, char **argv)
         const double gb = stats[CRUMBLE_ST_BASES] / 1e9;
         fprintf(stderr, "end-to-end %.3f s (read+parse %.3f, upload+kernels+download %.3f, write %.3f): %.4f Gbases/s file to file\n",
                 wall, t_read, t_gpu, t_write, wall > 0 ? gb / wall : 0.0);
+        char tb[512];
+        crumble_bam_timing(tb, sizeof tb);
+        fprintf(stderr, "%s\n", tb);
     }
     crumble_bam_close(rd);
     crumble_hip_destroy(eng);
-    free(qout); free(bt); free(bs); free(be); free(pg);
+    crumble_bam_big_free(qout, qcap); free(bt); free(bs); free(be); free(pg);
     return 0;
 }

@@ -96,6 +96,8 @@ struct DBatch {
     int32_t L;              /* number of positions covered: [p0, p0+L)       */
     int32_t n_tiles;        /* ceil(L/64)                                    */
     int32_t n_bed;
+    int32_t hot_mq;         /* most frequent mapq of the batch (sampled): a performance hint only */
+    int32_t pad0_;
     const int32_t *pos, *end;       /* end = pos + reflen; == pos if passthru */
     const uint8_t *mapq, *inplp;
     const int64_t *seq_off, *cig_off, *seg_off;

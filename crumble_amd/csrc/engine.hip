@@ -331,6 +331,13 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     B.p0 = any ? res[1] : 0;
     B.L = any ? res[2] - res[1] : 0;
     B.n_tiles = (B.L + 63) / 64;
+    {   /* the mapq most reads carry: k_columns keeps a composed quality table for it in LDS */
+        int hist[256] = {0}, best = 0;
+        const int64_t step = n > 4096 ? n / 4096 : 1;
+        for (int64_t i = 0; i < n; i += step) hist[b->mapq[i]]++;
+        for (int i = 1; i < 256; i++) if (hist[i] > hist[best]) best = i;
+        B.hot_mq = best;
+    }
     h->n_reads = n; h->n_bases = nb; h->n_cigar = nc;
     h->n_segrec = tot.nseg; h->n_slow = tot.nslow;  /* upper bound; the exact count is d_nslow */
 

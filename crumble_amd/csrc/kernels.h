@@ -408,6 +408,10 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
     constexpr bool MQ = MODE != 0;                          /* the active consensus uses CONS_MQUAL */
     __shared__ uint8_t sAdj[MQ ? 256 * 128 : 16];
     __shared__ unsigned sStat[32];
+    /* composed row table of the batch's dominant mapq: sHot[q] = sTab[adj[hot_mq][q]], so that most
+     * records need one dependent LDS round trip instead of two */
+    __shared__ double sHot[MQ ? 128 * 4 : 4];
+    const int hot_mq = MQ ? B.hot_mq : -1;
     if (threadIdx.x < 32) sStat[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < 101; i += blockDim.x) {
         sTab[i * 4] = T->MMd[i]; sTab[i * 4 + 1] = T->_Md[i]; sTab[i * 4 + 2] = T->omq[i]; sTab[i * 4 + 3] = 0;
@@ -424,6 +428,11 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                 o |= v << (8 * k);
             }
             *(uint32_t *)&sAdj[m * 128 + q4] = o;
+        }
+        for (int q = threadIdx.x; q < 128; q += blockDim.x) {
+            int a = T->adj[hot_mq * 256 + q];
+            a = a < 1 ? 1 : (a > 100 ? 100 : a);
+            sHot[q * 4] = T->MMd[a]; sHot[q * 4 + 1] = T->_Md[a]; sHot[q * 4 + 2] = T->omq[a]; sHot[q * 4 + 3] = 0;
         }
     }
     __syncthreads();
@@ -524,15 +533,21 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                         }
                 }
                 /* snp:632-638; sAdj is stored already clamped to 1..100 (snp:641; fence Q5) */
-                int aq = MQ ? (int)sAdj[mq * 128 + (q & 127)] : (q < 1 ? 1 : (q > 100 ? 100 : q));
-                const double MM = sTab[aq * 4], _M = sTab[aq * 4 + 1], om = sTab[aq * 4 + 2];
+                double MM, _M, om;
+                if (MQ && mq == hot_mq) {                                      /* uniform: one lookup */
+                    const double *row = &sHot[(q & 127) * 4];
+                    MM = row[0]; _M = row[1]; om = row[2];
+                } else {
+                    const int aq = MQ ? (int)sAdj[mq * 128 + (q & 127)] : (q < 1 ? 1 : (q > 100 ? 100 : q));
+                    MM = sTab[aq * 4]; _M = sTab[aq * 4 + 1]; om = sTab[aq * 4 + 2];
+                }
                 /* mode A next to mode B (MODE 2): the same entry with the plain (capped) quality */
                 const int aq2 = q < 1 ? 1 : (q > 100 ? 100 : q);
                 const double MM2 = MODE == 2 ? sTab[aq2 * 4] : 0.0, _M2 = MODE == 2 ? sTab[aq2 * 4 + 1] : 0.0, om2 = MODE == 2 ? sTab[aq2 * 4 + 2] : 0.0;
                 const bool cm = cov && isM;                                    /* a base call (snp:603) */
                 const bool cA = cm && code == 1, cC = cm && code == 2, cG = cm && code == 4, cT = cm && code == 8;
                 const bool cS = cov && !isM;                                   /* deletion: '*' (snp:609) */
-                const bool cN = cm && !(code == 1 || code == 2 || code == 4 || code == 8);
+                const bool cN = cm && !((0x0116u >> code) & 1u);               /* not one of A C G T */
                 double *S = st.S, *sC = st.sC, *S2 = st.S2, *sC2 = st.sC2;
                 if (cA) { sC[0] += om; S[0] += MM; S[1] += _M; S[2] += _M; S[3] += _M; S[4] += _M;
                           if (MODE == 2) { sC2[0] += om2; S2[0] += MM2; S2[1] += _M2; S2[2] += _M2; S2[3] += _M2; S2[4] += _M2; } }

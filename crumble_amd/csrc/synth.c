@@ -160,7 +160,8 @@ static void gen_read(const genome_t *g, win_t *w, rng_t *r, int64_t s)
         /* sum of uniforms ~ normal; log-normal length */
         double z = (rndu(r) + rndu(r) + rndu(r) + rndu(r) - 2.0) * 1.7320508;
         double f = exp(z * c->read_len_sigma / 100.0);
-        if (f < 0.5) f = 0.5; if (f > 2.0) f = 2.0;
+        if (f < 0.5) f = 0.5;
+        if (f > 2.0) f = 2.0;
         L = (int)(L * f);
     }
     if (L < 30) L = 30;

@@ -31,7 +31,7 @@ extern "C" {
 typedef struct crumble_bam_reader crumble_bam_reader;
 typedef struct crumble_bam_writer crumble_bam_writer;
 
-/* Opens a BAM file and parses its header.  threads <= 0: omp_get_max_threads(). */
+/* Opens a BAM file and parses its header.  threads <= 0: the CPUs the process may use (affinity, cgroup quota), at most 64. */
 crumble_bam_reader *crumble_bam_open(const char *path, int threads, int *err);
 void        crumble_bam_close(crumble_bam_reader *r);
 int32_t     crumble_bam_n_ref(const crumble_bam_reader *r);
@@ -68,6 +68,14 @@ int crumble_bam_write_batches(const char *path, int32_t n_ref, const char *const
  * number of regions (arrays malloc'ed, sorted by tid then start; caller frees) or < 0. */
 int crumble_bam_load_bed(const crumble_bam_reader *r, const char *path,
                          int32_t **tid, int32_t **start, int32_t **end);
+
+/* Huge-page backed host buffers for multi-GB arrays (e.g. the caller's qual_out): mmap +
+ * MADV_HUGEPAGE; release with the same size. */
+void *crumble_bam_big_alloc(size_t n);
+void  crumble_bam_big_free(void *p, size_t n);
+
+/* Where the host time went so far (process-wide phase timers), as one line of text. */
+int crumble_bam_timing(char *buf, size_t len);
 
 const char *crumble_bam_last_error(void);
 
