@@ -56,7 +56,7 @@ struct crumble_hip {
     DParams hparams;
     DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc;
     /* batch (inputs) */
-    DevBuf d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
+    DevBuf d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
            d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax;
     /* per position */
     DevBuf d_colrec, d_nplp, d_score, d_trigcnt, d_dpre, d_col_ord, d_trig_ord, d_item_off,
@@ -218,7 +218,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     DevBuf *all[] = { &h->d_params, &h->d_tables, &h->d_stats, &h->d_batch_stats, &h->d_misc,
-        &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
+        &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
         &h->d_slow_g, &h->d_slow_r, &h->d_cix, &h->d_sr, &h->d_stile_lo, &h->d_stile_hi, &h->d_rr, &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
         &h->d_cigar, &h->d_segs, &h->d_bases, &h->d_quals, &h->d_tile_lo, &h->d_tile_hi,
         &h->d_bed_start, &h->d_bed_end, &h->d_bed_pmax, &h->d_colrec, &h->d_nplp, &h->d_score,
@@ -394,7 +394,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
         (e = h->d_trig_ord.reserve(L * 4)) || (e = h->d_item_off.reserve(L * 4)) || (e = h->d_ins_ord.reserve(L * 4)) ||
         (e = h->d_pos_mn2.reserve(L * 4)) || (e = h->d_ht.reserve(L * 4)) || (e = h->d_partial.reserve((size_t)(nsc + 2) * sizeof(ScanVal))) ||
         (e = h->d_epochs.reserve(MAX_EPOCHS * sizeof(Epoch))) ||
-        (e = h->d_out.reserve((size_t)(nb ? nb : 1))) || (e = h->d_rflags.reserve((size_t)(n ? n : 1))) ||
+        (e = h->d_out.reserve((size_t)nb + 64)) || (e = h->d_rflags.reserve((size_t)(n ? n : 1))) ||
         (e = h->d_keepf.reserve((size_t)(n ? n : 1))) || (e = h->d_kept.reserve((size_t)(n ? n : 1) * 4)) || (e = h->d_b15f.reserve((size_t)(n ? n : 1))))
         return e;
     HIPCHK(hipStreamSynchronize(st));               /* the caller may free its host buffers */
@@ -408,6 +408,35 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
 #define STAGE(name_, bytes_) do { if (h->n_stages < MAX_STAGES) { \
     HIPCHK(hipEventRecord(h->ev[h->n_stages], st)); \
     h->stage_name[h->n_stages] = name_; h->stage_bytes[h->n_stages] = (double)(bytes_); h->n_stages++; } } while (0)
+
+/* P-block over a flat quality array (snp:803-834): stop masks, then one lane per 64-base word
+ * replays the segments that start in its word (kernels.h). */
+static int launch_pblock(crumble_hip *h, hipStream_t st, int64_t n_reads, int64_t nb, const int64_t *seq_off,
+                         uint8_t *out, const uint8_t *rflags, const int32_t *blk_read)
+{
+    if (nb <= 0 || n_reads <= 0) return CRUMBLE_OK;
+    const DParams *P = h->d_params.as<DParams>();
+    /* short reads: one lane per read keeps the lanes of a wave evenly loaded; long reads: segment-parallel.
+     * CRUMBLE_HIP_PBLOCK=reads|segments overrides the choice (tuning / tests). */
+    const char *force = getenv("CRUMBLE_HIP_PBLOCK");
+    const bool per_read = force ? !strcmp(force, "reads") : nb < 1024 * n_reads;
+    if (per_read) {
+        CRUMBLE_LAUNCH_INDEP(k_pblock, nblk(n_reads, 64), 64, st, n_reads, seq_off, out, rflags, P);
+        return CRUMBLE_OK;
+    }
+    const int64_t nwords = (nb + 63) / 64;
+    int e;
+    if ((e = h->d_pbstop.reserve((size_t)(nwords + 1) * 8)) || (e = h->d_pbrs.reserve((size_t)(nwords + 1) * 8)) ||
+        (e = h->d_pbruns.reserve((size_t)(nwords + 1) * 8)) || (e = h->d_pbval.reserve((size_t)nb + 64)))
+        return e;
+    u64 *stop = h->d_pbstop.as<u64>(), *rs = h->d_pbrs.as<u64>(), *runs = h->d_pbruns.as<u64>();
+    uint8_t *val = h->d_pbval.as<uint8_t>();
+    CRUMBLE_LAUNCH_INDEP(k_pb_marks, nblk(nwords, 256), 256, st, nb, out, P, stop, rs, runs);
+    CRUMBLE_LAUNCH_INDEP(k_pb_readstarts, nblk(n_reads, 256), 256, st, n_reads, seq_off, stop, rs);
+    CRUMBLE_LAUNCH_INDEP(k_pb_segments, nblk(nwords, 256), 256, st, nb, n_reads, seq_off, out, rflags, blk_read, stop, rs, runs, val, P);
+    CRUMBLE_LAUNCH_INDEP(k_pb_fill, nblk((nb + 15) / 16, 256), 256, st, nb, out, stop, runs, val);
+    return CRUMBLE_OK;
+}
 
 extern "C" int crumble_hip_run(crumble_hip *h)
 {
@@ -537,8 +566,9 @@ extern "C" int crumble_hip_run(crumble_hip *h)
                              d_overflow + 2, h->d_out.as<uint8_t>());
         if (h->hparams.pblock) {
             STAGE("k_pblock", 2.0 * nb);
-            CRUMBLE_LAUNCH_INDEP(k_pblock, nblk(n, 64), 64, st, n, B.seq_off, h->d_out.as<uint8_t>(),
-                                 h->d_rflags.as<uint8_t>(), P);
+            const int pe = launch_pblock(h, st, n, nb, B.seq_off, h->d_out.as<uint8_t>(), h->d_rflags.as<uint8_t>(),
+                                         h->d_blk_read.as<int32_t>());
+            if (pe) return pe;
         }
         STAGE("k_stats", 2.0 * nb);
         CRUMBLE_LAUNCH(k_stats, 1024, 256, st, nb, n, h->d_out.as<uint8_t>(), B.quals, stats);
@@ -718,14 +748,15 @@ extern "C" int crumble_hip_pblock(crumble_hip *h, int64_t n_reads, const int64_t
     if (n_reads == 0) return CRUMBLE_OK;
     HIPCHK(hipSetDevice(h->device));
     const int64_t nb = seq_off[n_reads];
+    for (int64_t i = 0; i < nb; i++)
+        if (quals[i] >= 128) { g_last_error = "quality >= 128 (SURVEY.md Q13)"; return CRUMBLE_EINVAL; }
     DevBuf dq, ds;
     int e;
-    if ((e = dq.reserve((size_t)(nb ? nb : 1))) || (e = ds.reserve((size_t)(n_reads + 1) * 8))) return e;
+    if ((e = dq.reserve((size_t)nb + 64)) || (e = ds.reserve((size_t)(n_reads + 1) * 8))) return e;
     if (nb) HIPCHK(hipMemcpy(dq.p, quals, (size_t)nb, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ds.p, seq_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice));
-    if (h->hparams.pblock)
-        CRUMBLE_LAUNCH_INDEP(k_pblock, nblk(n_reads, 64), 64, h->stream, n_reads, ds.as<int64_t>(), dq.as<uint8_t>(),
-                             (const uint8_t *)nullptr, h->d_params.as<DParams>());
+    if (h->hparams.pblock && nb > 0 && (e = launch_pblock(h, h->stream, n_reads, nb, ds.as<int64_t>(), dq.as<uint8_t>(), nullptr, nullptr)))
+        return e;
     HIPCHK(hipStreamSynchronize(h->stream));
     if (nb) HIPCHK(hipMemcpy(quals, dq.p, (size_t)nb, hipMemcpyDeviceToHost));
     dq.release(); ds.release();

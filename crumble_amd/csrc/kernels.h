@@ -466,12 +466,41 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
 
         const int c0 = B.p0 + tile * 64, c1 = c0 + 63;
         int n_lq0 = 0;                                   /* covered entries of reads without SEQ */
-        for (int j = lo; j < hi; j += 4) {
+        /* Record feed.  Short-read batches: the candidate range [lo, hi) is walked four records at a
+         * time.  MULTI (long reads, many ops per read): the range holds every op of every read that
+         * touches the tile, most of which lie elsewhere -- 64 candidates at a time are tested by the
+         * lanes (one 8-byte load each), and only the ballot's set bits are walked, still in file order. */
+        int j = lo;
+        unsigned long long cand = 0;                     /* MULTI: untested-yet overlapping records of the chunk */
+        int cbase = lo;
+        for (;;) {
+            int id[4]; bool valid[4];
+            if (!MULTI) {
+                if (j >= hi) break;
+                #pragma unroll
+                for (int u = 0; u < 4; u++) { valid[u] = j + u < hi; id[u] = valid[u] ? j + u : j; }
+                j += 4;
+            } else {
+                while (cand == 0 && j < hi) {
+                    const int idx = j + lane;
+                    bool ov = false;
+                    if (idx < hi) { const int2 pe = *(const int2 *)&B.sr[idx]; ov = pe.y > c0 && pe.x <= c1; }
+                    cand = __ballot(ov);
+                    cbase = j; j += 64;
+                }
+                if (cand == 0) break;
+                #pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    valid[u] = cand != 0;
+                    if (valid[u]) { id[u] = cbase + __builtin_ctzll(cand); cand &= cand - 1; }
+                    else id[u] = id[0];
+                }
+            }
             /* four candidate records (one reference-consuming CIGAR op of one read each);
              * the index is wave-uniform, so these are scalar loads (s_load_dwordx8) */
             SegRec R[4];
             #pragma unroll
-            for (int u = 0; u < 4; u++) R[u] = B.sr[(j + u < hi) ? j + u : j];
+            for (int u = 0; u < 4; u++) R[u] = B.sr[MULTI ? UNIFORM(id[u]) : id[u]];
             /* phase A: the byte loads of the four records go out together
              * (lanes that need no byte read byte 0: no branch between the loads) */
             uint8_t cc[4], qq[4];
@@ -489,11 +518,9 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
              * is_head/is_tail bookkeeping is not here at all (k_headtail). */
             #pragma unroll
             for (int u = 0; u < 4; u++) {
-                if (j + u >= hi) break;
+                if (!valid[u]) break;
                 const int rp = R[u].pos, re = R[u].end, lq = R[u].lq;
                 const unsigned info = R[u].info, ty = SR_TYPE(info);
-                if (MULTI && (re <= c0 || rp > c1))
-                    continue;                             /* another op of a multi-op read that overlaps the tile (uniform) */
                 const int mq = (int)(info & 255);
                 const bool cov = inr && (unsigned)(apos - rp) < (unsigned)(re - rp);
                 const bool isM = ty == SEG_M, isN = ty == SEG_N;               /* uniform */
@@ -1568,6 +1595,223 @@ __global__ void k_pblock(int64_t n_reads, const int64_t *seq_off, uint8_t *out,
     if (rflags && (rflags[r] & 2)) return;            /* flag bit 15: snp:1098 */
     dev_pblock(out + seq_off[r], (int)(seq_off[r + 1] - seq_off[r]), P->pblock, P->qcap, P->preserve_qual,
                P->any_preserve != 0);
+}
+
+/* ------------------------------------------------------------------------ */
+/* P-block, segment-parallel.  pblock() is a greedy left-to-right segmentation, but some run
+ * boundaries do not depend on where the current run started:
+ *   - position i with |q[i] - q[i-1]| > 2*level: any run holding both would exceed the range test
+ *     of snp:817, so the run holding i-1 ends at i and a new one starts there with qmin = qmax = q[i];
+ *   - a preserved value (snp:817,822-823): the run ends, preserved bytes are skipped untouched, and
+ *     the first byte after them starts a fresh run;
+ *   - the first base of a read.
+ * Between two such "stops" the bytes form a segment whose result depends on nothing outside it.
+ *   k_pb_marks       the stops of all bases at once (one 64-bit word per 64 bases)
+ *   k_pb_readstarts  adds the read starts
+ *   k_pb_segments    every segment goes to the lane that owns the 64-base word of its first byte;
+ *                    the lane replays the reference's state machine over the segment, 16 bytes per
+ *                    load, and only RECORDS the runs: a bit at each run start and the run's value
+ *                    (the capped mid-point of its min and max) in a side byte array
+ *   k_pb_fill        one lane per 16 bytes: each byte takes the value of the run that holds it
+ *                    (coalesced 16-byte loads and stores; no divergent byte loops anywhere)
+ * Long reads (a 15 kb HiFi read is ~10^3 segments) no longer serialise on one thread. */
+#define PB_KEEP 0xffu            /* run value: leave the bytes as they are (preserved, or flag bit 15) */
+
+__global__ void __launch_bounds__(256)
+k_pb_marks(int64_t n_bases, const uint8_t *__restrict__ q, const DParams *__restrict__ P,
+           u64 *__restrict__ stop, u64 *__restrict__ rstart, u64 *__restrict__ runs)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t g0 = w * 64;
+    if (g0 >= n_bases) return;
+    const int level2 = P->pblock * 2;
+    const bool any_pres = P->any_preserve != 0;
+    const int nn = (n_bases - g0 < 64) ? (int)(n_bases - g0) : 64;
+    int prev = g0 > 0 ? (int)q[g0 - 1] : -1000;
+    bool prev_pres = g0 > 0 && any_pres && P->preserve_qual[prev];
+    u64 m = 0;
+    for (int k0 = 0; k0 < nn; k0 += 16) {
+        uint32_t wd[4] = {0, 0, 0, 0};
+        if (k0 + 16 <= nn) { const uint4 v = *(const uint4 *)(q + g0 + k0); wd[0] = v.x; wd[1] = v.y; wd[2] = v.z; wd[3] = v.w; }
+        else for (int k = k0; k < nn; k++) wd[(k - k0) >> 2] |= (uint32_t)q[g0 + k] << (8 * (k & 3));
+        #pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int v = (int)((wd[k >> 2] >> (8 * (k & 3))) & 255);
+            const bool pres = any_pres && P->preserve_qual[v];
+            int d = v - prev; d = d < 0 ? -d : d;
+            if (k0 + k < nn && (pres || prev_pres || d > level2)) m |= 1ull << (k0 + k);
+            prev = v; prev_pres = pres;
+        }
+    }
+    stop[w] = m;
+    rstart[w] = 0;
+    runs[w] = 0;
+}
+
+__global__ void k_pb_readstarts(int64_t n_reads, const int64_t *__restrict__ seq_off,
+                                u64 *__restrict__ stop, u64 *__restrict__ rstart)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const int64_t g = seq_off[r];
+    if (seq_off[r + 1] == g) return;
+    atomicOr((unsigned long long *)&stop[g >> 6], 1ull << (g & 63));
+    atomicOr((unsigned long long *)&rstart[g >> 6], 1ull << (g & 63));
+}
+
+__global__ void __launch_bounds__(256)
+k_pb_segments(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_off, const uint8_t *__restrict__ out,
+              const uint8_t *__restrict__ rflags, const int32_t *__restrict__ blk_read,
+              const u64 *__restrict__ stop, const u64 *__restrict__ rstart, u64 *__restrict__ runs,
+              uint8_t *__restrict__ runval, const DParams *__restrict__ P)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nwords = (n_bases + 63) >> 6;
+    if (w >= nwords) return;
+    u64 starts = stop[w];
+    if (!starts) return;
+    const int level2 = P->pblock * 2, qcap = P->qcap;
+    const bool any_pres = P->any_preserve != 0;
+    int64_t r = rflags ? blk_read[w] : 0;
+    /* One flat loop: every trip either opens the lane's next segment or consumes up to 16 bytes (one
+     * aligned 16-byte load) of the open one, so a wave takes as long as its busiest lane has work. */
+    bool open = false, at_read_end = false;
+    int64_t j = 0, i = 0, e = 0;
+    int qmin = 0, qmax = 0, last_qmin = 0, last_qmax = 0;
+    for (;;) {
+        if (!open) {
+            if (!starts) break;
+            const int b = __builtin_ctzll(starts);
+            starts &= starts - 1;
+            const int64_t g = w * 64 + b;
+            bool keep = any_pres && P->preserve_qual[out[g]];   /* a stop, but not a start */
+            if (!keep && rflags) {
+                while (seq_off[r + 1] <= g) r++;
+                keep = (rflags[r] & 2) != 0;                    /* flag bit 15: snp:1098 */
+            }
+            if (keep) { runval[g] = (uint8_t)PB_KEEP; continue; }
+            /* fresh state of snp:807 at g; the next stop ends the segment */
+            j = g; i = g;
+            qmin = INT_MAX; qmax = INT_MIN; last_qmin = last_qmax = 0;
+            int64_t ww = w;
+            u64 rest = stop[ww] & ~((2ull << b) - 1);
+            while (!rest && ++ww < nwords) rest = stop[ww];
+            if (ww >= nwords) { e = n_bases; at_read_end = true; }
+            else { const int bb = __builtin_ctzll(rest); e = ww * 64 + bb; at_read_end = (rstart[ww] >> bb) & 1; }
+            open = true;
+        } else if (i < e) {
+            const int64_t base = i & ~(int64_t)15;
+            const uint4 v = *(const uint4 *)(out + base);       /* the buffer has >= 16 bytes of slack */
+            const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+            /* fast path: min and max of the chunk's bytes inside [i, e) with packed byte arithmetic
+             * (values are < 128, so bit 7 of every byte is free as a borrow guard); if the run's
+             * range test still holds with them, no run ends in this chunk */
+            {
+                const int lo = (int)(i - base), hi = (e - base < 16) ? (int)(e - base) : 16;
+                const unsigned vb = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+                uint32_t mn[4], mx[4];
+                #pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const uint32_t M = ((((vb >> (4 * t)) & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;
+                    mn[t] = (wd[t] & M) | (~M & 0x7f7f7f7fu);
+                    mx[t] = wd[t] & M;
+                }
+                #define PB_GE(a, b) (((((a) | 0x80808080u) - (b)) & 0x80808080u) >> 7) * 0xffu
+                #define PB_MIN(a, b, m) (((b) & (m)) | ((a) & ~(m)))       /* m = bytes where a >= b */
+                #define PB_MAX(a, b, m) (((a) & (m)) | ((b) & ~(m)))
+                uint32_t g01 = PB_GE(mn[0], mn[1]), g23 = PB_GE(mn[2], mn[3]);
+                uint32_t a = PB_MIN(mn[0], mn[1], g01), b2 = PB_MIN(mn[2], mn[3], g23);
+                uint32_t gab = PB_GE(a, b2);
+                const uint32_t m4 = PB_MIN(a, b2, gab);
+                g01 = PB_GE(mx[0], mx[1]); g23 = PB_GE(mx[2], mx[3]);
+                a = PB_MAX(mx[0], mx[1], g01); b2 = PB_MAX(mx[2], mx[3], g23);
+                gab = PB_GE(a, b2);
+                const uint32_t x4 = PB_MAX(a, b2, gab);
+                #undef PB_GE
+                #undef PB_MIN
+                #undef PB_MAX
+                int cmin = (int)(m4 & 255), cmax = (int)(x4 & 255);
+                #pragma unroll
+                for (int t = 1; t < 4; t++) {
+                    const int u0 = (int)((m4 >> (8 * t)) & 255), u1 = (int)((x4 >> (8 * t)) & 255);
+                    cmin = u0 < cmin ? u0 : cmin; cmax = u1 > cmax ? u1 : cmax;
+                }
+                const int nmin = cmin < qmin ? cmin : qmin, nmax = cmax > qmax ? cmax : qmax;
+                if (nmax - nmin <= level2) {
+                    qmin = last_qmin = nmin; qmax = last_qmax = nmax;
+                    i = base + hi;
+                    continue;
+                }
+            }
+            bool hit = false;
+            int hitk = 0, hitq = 0;
+            #pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int64_t pos = base + k;
+                if (!hit && pos >= i && pos < e) {
+                    const int q = (int)((wd[k >> 2] >> (8 * (k & 3))) & 255);
+                    if (qmin > q) qmin = q;
+                    if (qmax < q) qmax = q;
+                    if (qmax - qmin > level2) { hit = true; hitk = k; hitq = q; }
+                    else { last_qmin = qmin; last_qmax = qmax; }
+                }
+            }
+            if (hit) {                                          /* a run ends inside the segment (snp:817-826) */
+                const int64_t pos = base + hitk;
+                int mid = (last_qmin + last_qmax) / 2;
+                if (mid > qcap) mid = qcap;
+                runval[j] = (uint8_t)mid;
+                atomicOr((unsigned long long *)&runs[pos >> 6], 1ull << (pos & 63));   /* the next run starts at pos */
+                qmin = qmax = last_qmin = last_qmax = hitq; j = pos; i = pos + 1;
+            } else i = (base + 16 < e) ? base + 16 : e;
+        } else {
+            int mid = (last_qmin + last_qmax) / 2;
+            if (!at_read_end && mid > qcap) mid = qcap;         /* the read's final run is not capped (snp:832) */
+            runval[j] = (uint8_t)mid;
+            open = false;
+        }
+    }
+}
+
+/* every byte takes the value of the run that holds it */
+__global__ void __launch_bounds__(256)
+k_pb_fill(int64_t n_bases, uint8_t *__restrict__ out, const u64 *__restrict__ stop, const u64 *__restrict__ runs,
+          const uint8_t *__restrict__ runval)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t g0 = t * 16;
+    if (g0 >= n_bases) return;
+    const int64_t w = g0 >> 6;
+    const int sh = (int)(g0 & 63);
+    const u64 m = stop[w] | runs[w];
+    /* run start governing the first byte: the last set bit at or before g0 */
+    int64_t s;
+    {
+        u64 below = m & ((2ull << sh) - 1);
+        int64_t ww = w;
+        while (!below && ww > 0) { ww--; below = stop[ww] | runs[ww]; }
+        s = below ? ww * 64 + (63 - __builtin_clzll(below)) : 0;
+    }
+    uint32_t val = runval[s];
+    const uint4 v = *(const uint4 *)(out + g0);
+    const uint4 rv4 = *(const uint4 *)(runval + g0);        /* only the bytes at run starts are meaningful */
+    uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t rv[4] = {rv4.x, rv4.y, rv4.z, rv4.w};
+    const unsigned bits = (unsigned)((m >> sh) & 0xffffu);
+    bool changed = false;
+    #pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (k > 0 && ((bits >> k) & 1)) val = (rv[k >> 2] >> (8 * (k & 3))) & 255;
+        const uint32_t old = (wd[k >> 2] >> (8 * (k & 3))) & 255;
+        if (val != PB_KEEP && old != val && g0 + k < n_bases) {
+            wd[k >> 2] = (wd[k >> 2] & ~(255u << (8 * (k & 3)))) | (val << (8 * (k & 3)));
+            changed = true;
+        }
+    }
+    if (changed) {
+        if (g0 + 16 <= n_bases) { uint4 o; o.x = wd[0]; o.y = wd[1]; o.z = wd[2]; o.w = wd[3]; *(uint4 *)(out + g0) = o; }
+        else for (int k = 0; g0 + k < n_bases; k++) out[g0 + k] = (uint8_t)((wd[k >> 2] >> (8 * (k & 3))) & 255);
+    }
 }
 
 /* ------------------------------------------------------------------------ */

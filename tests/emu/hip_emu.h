@@ -46,6 +46,7 @@ struct dim3 {
 };
 struct uint4 { unsigned x, y, z, w; };
 struct uint2 { unsigned x, y; };
+struct int2 { int x, y; };
 extern thread_local dim3 threadIdx, blockIdx;
 extern dim3 blockDim, gridDim;
 static const int warpSize = 64;

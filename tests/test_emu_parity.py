@@ -22,6 +22,24 @@ def test_emu_ce(product):
     assert_parity(emu_lib.engine, ca.preset_params(1), hb)
 
 
+def test_emu_hifi_long_reads(product):
+    """Long multi-op reads: the ballot-compacted record feed of k_columns<.,MULTI> and -y pbccs."""
+    hb = synth_batch("hifi", 0.0002, read_len=3000)
+    assert hb.cig_off[-1] > 3 * hb.n_reads
+    assert_parity(emu_lib.engine, ca.preset_params(9, tech="pbccs"), hb)
+    assert_parity(emu_lib.engine, ca.preset_params(5), hb)
+
+
+@pytest.mark.parametrize("path", ["reads", "segments"])
+def test_emu_pblock_paths(product, path, monkeypatch):
+    """Both P-block implementations (one lane per read / segment-parallel) on short and long reads."""
+    monkeypatch.setenv("CRUMBLE_HIP_PBLOCK", path)
+    for hb, p in ((synth_batch("chr20", 0.0004), ca.preset_params(9)),
+                  (synth_batch("panel", 0.001), ca.preset_params(9, pblock=3, keep="30-31")),
+                  (synth_batch("hifi", 0.0002, read_len=3000), ca.preset_params(9, tech="pbccs"))):
+        assert_parity(emu_lib.engine, p, hb, check_columns=False)
+
+
 def test_emu_empty_and_passthrough(product):
     p = ca.preset_params(9)
     hb = HostBatch.from_reads([])

@@ -46,6 +46,17 @@ def test_hifi_pbccs(product):
     assert_parity(gpu_engine, ca.preset_params(5), hb)
 
 
+@pytest.mark.parametrize("path", ["reads", "segments"])
+def test_pblock_paths(product, path, monkeypatch):
+    """Both P-block implementations (one lane per read / segment-parallel) on short and long reads."""
+    monkeypatch.setenv("CRUMBLE_HIP_PBLOCK", path)
+    for hb, p in ((synth_batch("chr20", 0.01), ca.preset_params(9)),
+                  (synth_batch("panel", 0.005), ca.preset_params(9, pblock=3, keep="30-31")),
+                  (synth_batch("hifi", 0.002), ca.preset_params(9, tech="pbccs")),
+                  (synth_batch("hifi", 0.002), ca.preset_params(9, pblock=2))):
+        assert_parity(gpu_engine, p, hb, check_columns=False)
+
+
 def test_empty_and_passthrough(product):
     p = ca.preset_params(9)
     assert_parity(gpu_engine, p, HostBatch.from_reads([]))
