@@ -470,23 +470,20 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
          * time.  MULTI (long reads, many ops per read): the range holds every op of every read that
          * touches the tile, most of which lie elsewhere -- 64 candidates at a time are tested by the
          * lanes (one 8-byte load each), and only the ballot's set bits are walked, still in file order. */
-        int j = lo;
         unsigned long long cand = 0;                     /* MULTI: untested-yet overlapping records of the chunk */
-        int cbase = lo;
-        for (;;) {
+        int cbase = lo, jm = lo;
+        for (int j = lo; MULTI || j < hi; j += MULTI ? 0 : 4) {
             int id[4]; bool valid[4];
             if (!MULTI) {
-                if (j >= hi) break;
                 #pragma unroll
-                for (int u = 0; u < 4; u++) { valid[u] = j + u < hi; id[u] = valid[u] ? j + u : j; }
-                j += 4;
+                for (int u = 0; u < 4; u++) { valid[u] = true; id[u] = (j + u < hi) ? j + u : j; }
             } else {
-                while (cand == 0 && j < hi) {
-                    const int idx = j + lane;
+                while (cand == 0 && jm < hi) {
+                    const int idx = jm + lane;
                     bool ov = false;
                     if (idx < hi) { const int2 pe = *(const int2 *)&B.sr[idx]; ov = pe.y > c0 && pe.x <= c1; }
                     cand = __ballot(ov);
-                    cbase = j; j += 64;
+                    cbase = jm; jm += 64;
                 }
                 if (cand == 0) break;
                 #pragma unroll
@@ -518,7 +515,7 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
              * is_head/is_tail bookkeeping is not here at all (k_headtail). */
             #pragma unroll
             for (int u = 0; u < 4; u++) {
-                if (!valid[u]) break;
+                if (MULTI ? !valid[u] : (j + u >= hi)) break;
                 const int rp = R[u].pos, re = R[u].end, lq = R[u].lq;
                 const unsigned info = R[u].info, ty = SR_TYPE(info);
                 const int mq = (int)(info & 255);
