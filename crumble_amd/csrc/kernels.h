@@ -501,11 +501,14 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
             /* phase A: the byte loads of the four records go out together
              * (lanes that need no byte read byte 0: no branch between the loads) */
             uint8_t cc[4], qq[4];
+            bool cvr[4];                                  /* lane's column lies inside the record's span */
             #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const unsigned ty = SR_TYPE(R[u].info);
-                const int qp = (ty == SEG_M) ? R[u].qoff + apos : R[u].qoff;
-                const bool cv = inr && (unsigned)(apos - R[u].pos) < (unsigned)(R[u].end - R[u].pos) && qp < R[u].lq;
+                /* branch-free on purpose (bitwise &, selects): control flow here costs more than it saves */
+                const unsigned isMm = (SR_TYPE(R[u].info) == SEG_M) ? 0xffffffffu : 0u;   /* uniform */
+                const int qp = R[u].qoff + (int)((unsigned)apos & isMm);
+                cvr[u] = inr & ((unsigned)(apos - R[u].pos) < (unsigned)(R[u].end - R[u].pos));
+                const bool cv = cvr[u] & (qp < R[u].lq);
                 const uint8_t *bp = B.bases + R[u].so, *qp8 = B.quals + R[u].so;   /* wave-uniform bases */
                 const unsigned a = cv ? (unsigned)qp : 0u;                          /* 32-bit lane offset */
                 cc[u] = bp[a]; qq[u] = qp8[a];
@@ -519,7 +522,7 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                 const int rp = R[u].pos, re = R[u].end, lq = R[u].lq;
                 const unsigned info = R[u].info, ty = SR_TYPE(info);
                 const int mq = (int)(info & 255);
-                const bool cov = inr && (unsigned)(apos - rp) < (unsigned)(re - rp);
+                const bool cov = cvr[u];
                 const bool isM = ty == SEG_M, isN = ty == SEG_N;               /* uniform */
                 st.n_plp += cov ? 1 : 0;
                 if (mq <= min_mqual) st.low_mq += cov ? 1 : 0;                 /* snp:1663 */
