@@ -396,6 +396,9 @@ __global__ void k_headtail(DBatch B, uint32_t *__restrict__ ht)
 #define KCOL_THREADS 256
 #define KCOL_WAVES 4
 #endif
+/* keeps a wave-uniform rare branch a real (scalar) branch: without it the compiler if-converts the
+ * body into selects that every record pays for */
+#define RARE_PATH() asm volatile("")
 /* MULTI: the batch has many multi-op reads (long reads): skip a read's other ops cheaply */
 template <int MODE, bool MULTI>
 __global__ void __launch_bounds__(KCOL_THREADS, MODE == 2 ? 3 : KCOL_WAVES)
@@ -525,7 +528,7 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                 const bool cov = cvr[u];
                 const bool isM = ty == SEG_M, isN = ty == SEG_N;               /* uniform */
                 st.n_plp += cov ? 1 : 0;
-                if (mq <= min_mqual) st.low_mq += cov ? 1 : 0;                 /* snp:1663 */
+                if (mq <= min_mqual) { RARE_PATH(); st.low_mq += cov ? 1 : 0; }   /* snp:1663 (uniform) */
                 if (!isM || R[u].indel_after != 0) {                           /* indel bookkeeping: rare ops */
                     const int e_indel = (apos == re - 1) ? R[u].indel_after : 0;
                     const bool isind = (e_indel != 0) || !isM;
@@ -535,18 +538,17 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                     st.n_isindel += (cov && !isN && isind) ? 1 : 0;
                     st.has_ins |= (cov && !isN && !head && !tail && e_indel > 0) ? 1 : 0;   /* snp:1708 */
                 }
-                if (lq == 0) n_lq0 += cov ? 1 : 0;
+                if (lq == 0) { RARE_PATH(); n_lq0 += cov ? 1 : 0; }
                 if (isN || lq == 0 || !use_cons) continue;                     /* snp:589,594 (uniform) */
                 /* consensus accumulation (snp:594-685).  Each base class is an exec-masked block of
                  * in-place FP64 adds (only the lanes that the record covers with that class take part;
                  * the block is skipped when there is none), so every genotype sum sees exactly its own
                  * addends, in file order, and the 20 running sums never leave their registers. */
                 const int e_qpos = isM ? R[u].qoff + apos : R[u].qoff;
-                const bool inq = isM || e_qpos < lq;                           /* fence: read ends in D/N (uniform for M) */
-                int q = inq ? (int)qq[u] : 0;
+                int q = (int)qq[u], code = cc[u] & 15;
+                if (!isM && e_qpos >= lq) { q = 0; code = 15; }                /* fence: read ends in D/N (uniform) */
                 if (any_pres) q = (q > qcap && !P->preserve_qual[q]) ? qcap : q;   /* cap_quality snp:1325 */
                 else          q = q > qcap ? qcap : q;
-                const int code = inq ? (cc[u] & 15) : 15;
                 if (any_pres && cov) {                                         /* snp:611-623 */
                     const int b = !isM ? 4 : (code == 1) ? 0 : (code == 2) ? 1 : (code == 4) ? 2 : (code == 8) ? 3 : 5;
                     const int e_indel = (apos == re - 1) ? R[u].indel_after : 0;
