@@ -42,6 +42,7 @@ def lib():
         L.crumble_bam_create.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.crumble_bam_write_group.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.crumble_bam_writer_close.argtypes = [C.c_void_p]
+        L.crumble_bam_set_aux_filter.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.crumble_bam_write_batches.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
                                                 C.c_int32, C.POINTER(Batch), C.c_int, C.c_int]
         L.crumble_bam_load_bed.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
@@ -141,6 +142,15 @@ class Writer:
         if not self.h:
             raise _err(e.value)
         self.reader = reader
+
+    def set_aux_filter(self, whitelist=None, blacklist=None, bd=None, bi=None):
+        """purge_tags: -t / -T lists and BD / BI (low, mid, high) character values."""
+        a = (C.c_int * 3)(*bd) if bd else None
+        b = (C.c_int * 3)(*bi) if bi else None
+        rc = lib().crumble_bam_set_aux_filter(self.h, whitelist.encode() if whitelist else None,
+                                              blacklist.encode() if blacklist else None, a, b)
+        if rc:
+            raise _err(rc)
 
     def write_group(self, qual_out=None):
         q = None

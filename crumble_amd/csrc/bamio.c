@@ -404,7 +404,15 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
 
 /* ----------------------------------------------------------------- BGZF out */
 #define BLK_IN 0xff00u                       /* uncompressed bytes per block (htslib's choice too) */
-struct crumble_bam_writer { FILE *fp; int level, threads; uint8_t *obuf; size_t ocap; };
+struct crumble_bam_writer {
+    FILE *fp; int level, threads; uint8_t *obuf; size_t ocap;
+    /* purge_tags (snp_score.c:989-1054) */
+    int aux_mode;                      /* 0 none, 1 whitelist (-t), 2 blacklist (-T) */
+    uint8_t *aux_set;                  /* 65536-bit set of two-character tags */
+    int bd[3], bi[3];                  /* BD / BI low, mid, high (already +33); all 0 = off */
+    uint8_t *raw2; size_t raw2_cap;    /* compacted records when tags are dropped */
+    size_t *noff; size_t noff_cap;
+};
 
 static const uint8_t BGZF_EOF[28] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 
@@ -508,6 +516,85 @@ crumble_bam_writer *crumble_bam_create(const char *path, const crumble_bam_reade
     return w;
 }
 
+/* -t / -T lists: "XX,YY,ZZ" exactly as parse_aux_list (snp_score.c:2031-2054) reads them */
+static int parse_aux_list(uint8_t *set, const char *arg)
+{
+    while (strlen(arg) >= 2) {
+        const unsigned x = (unsigned)(uint8_t)arg[0] << 8 | (uint8_t)arg[1];
+        set[x >> 3] |= (uint8_t)(1u << (x & 7));
+        arg += 2;
+        if (*arg == ',') arg++;
+        else if (*arg != 0) break;
+    }
+    return strlen(arg) ? -1 : 0;
+}
+
+int crumble_bam_set_aux_filter(crumble_bam_writer *w, const char *whitelist, const char *blacklist,
+                               const int bd[3], const int bi[3])
+{
+    w->aux_mode = 0;
+    if (whitelist || blacklist) {
+        if (!w->aux_set && !(w->aux_set = calloc(8192, 1))) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+        memset(w->aux_set, 0, 8192);
+        /* a white list wins over a black list (the else-if of snp_score.c:990,1007) */
+        if (parse_aux_list(w->aux_set, whitelist ? whitelist : blacklist))
+            return fail(CRUMBLE_EINVAL, "auxiliary tags should be exactly two characters long");
+        w->aux_mode = whitelist ? 1 : 2;
+    }
+    for (int k = 0; k < 3; k++) { w->bd[k] = bd ? bd[k] : 0; w->bi[k] = bi ? bi[k] : 0; }
+    /* the reference would write NUL bytes into the tag (and then abort in skip_aux) when a bin
+     * value is left at 0: refuse instead */
+    if ((w->bd[0] || w->bd[1] || w->bd[2]) && (!w->bd[0] || !w->bd[2])) return fail(CRUMBLE_EINVAL, "BD binning needs both -e and -g");
+    if ((w->bi[0] || w->bi[1] || w->bi[2]) && (!w->bi[0] || !w->bi[2])) return fail(CRUMBLE_EINVAL, "BI binning needs both -E and -G");
+    for (int k = 0; k < 3; k++)
+        if (w->bd[k] < 0 || w->bd[k] > 255 || w->bi[k] < 0 || w->bi[k] > 255) return fail(CRUMBLE_EINVAL, "BD/BI bin value out of range");
+    return 0;
+}
+
+/* end of the aux field that starts at s (after its two tag characters), or NULL when malformed */
+static const uint8_t *aux_end(const uint8_t *s, const uint8_t *lim)
+{
+    if (s >= lim) return NULL;
+    const int t = *s++;
+    size_t sz;
+    switch (t) {
+    case 'A': case 'c': case 'C': sz = 1; break;
+    case 's': case 'S': sz = 2; break;
+    case 'i': case 'I': case 'f': sz = 4; break;
+    case 'd': sz = 8; break;
+    case 'Z': case 'H':
+        while (s < lim && *s) s++;
+        return s < lim ? s + 1 : NULL;
+    case 'B': {
+        if (s + 5 > lim) return NULL;
+        const int st = *s++;
+        const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : (st == 'i' || st == 'I' || st == 'f') ? 4 : 0;
+        if (!es) return NULL;
+        const uint32_t n = le32(s); s += 4;
+        return ((size_t)(lim - s) >= es * (size_t)n) ? s + es * (size_t)n : NULL;
+    }
+    default: return NULL;
+    }
+    return ((size_t)(lim - s) >= sz) ? s + sz : NULL;
+}
+
+static inline int aux_keep(const crumble_bam_writer *w, const uint8_t *t)
+{
+    if (!w->aux_mode) return 1;
+    const unsigned x = (unsigned)t[0] << 8 | t[1];
+    const int in = (w->aux_set[x >> 3] >> (x & 7)) & 1;
+    return w->aux_mode == 1 ? in : !in;
+}
+
+/* BD / BI quantisation of one kept Z tag in place (snp_score.c:1025-1052) */
+static inline void aux_bin(const crumble_bam_writer *w, uint8_t *t)
+{
+    const int *b = (t[0] == 'B' && t[1] == 'D' && (w->bd[0] | w->bd[1] | w->bd[2])) ? w->bd
+                 : (t[0] == 'B' && t[1] == 'I' && (w->bi[0] | w->bi[1] | w->bi[2])) ? w->bi : NULL;
+    if (!b || t[2] != 'Z') return;
+    for (uint8_t *c = t + 3; *c; c++) *c = (uint8_t)((*c >= b[1]) ? b[2] : b[0]);
+}
+
 int crumble_bam_write_group(crumble_bam_writer *w, crumble_bam_reader *r, const uint8_t *qual_out)
 {
     if (r->n == 0) return 0;
@@ -521,9 +608,67 @@ int crumble_bam_write_group(crumble_bam_writer *w, crumble_bam_reader *r, const 
             if (lseq > 0 && ql[0] != 0xff) memcpy(ql, qual_out + r->seq_off[i], (size_t)lseq);
         }
     }
-    T_scatter += now_s() - tsc;
     const size_t first = r->rec_off[0];
-    return bgzf_write(w, r->raw + first, r->group_end - first);
+    const int binning = w->bd[0] | w->bd[1] | w->bd[2] | w->bi[0] | w->bi[1] | w->bi[2];
+    if (!w->aux_mode && !binning) {
+        T_scatter += now_s() - tsc;
+        return bgzf_write(w, r->raw + first, r->group_end - first);
+    }
+    /* purge_tags: records shrink, so they are re-packed into a second buffer (sizes first, then a
+     * prefix sum, then every record is copied by its own thread) */
+    const int64_t n = r->n;
+    if (w->noff_cap < (size_t)n + 1) {
+        free(w->noff);
+        w->noff = malloc(((size_t)n + 1) * sizeof *w->noff);
+        w->noff_cap = w->noff ? (size_t)n + 1 : 0;
+        if (!w->noff) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+    }
+    int bad = 0;
+    #pragma omp parallel for schedule(static) num_threads(w->threads) reduction(|:bad)
+    for (int64_t i = 0; i < n; i++) {
+        const uint8_t *p = r->raw + r->rec_off[i];
+        const uint32_t bs = le32(p);
+        const int32_t lseq = (int32_t)le32(p + F_LSEQ);
+        const uint8_t *aux = p + F_FIXED + p[F_LNAME] + 4 * (size_t)le16(p + F_NCIG) + ((size_t)lseq + 1) / 2 + (size_t)lseq;
+        const uint8_t *lim = p + 4 + bs;
+        size_t keep = (size_t)(aux - p);
+        for (const uint8_t *t = aux; t < lim; ) {
+            const uint8_t *e = (t + 3 <= lim) ? aux_end(t + 2, lim) : NULL;
+            if (!e) { bad = 1; break; }
+            if (aux_keep(w, t)) keep += (size_t)(e - t);
+            t = e;
+        }
+        w->noff[i] = keep;
+    }
+    if (bad) return fail(CRUMBLE_BAM_EFORMAT, "malformed auxiliary field");
+    size_t tot = 0;
+    for (int64_t i = 0; i < n; i++) { const size_t k = w->noff[i]; w->noff[i] = tot; tot += k; }
+    w->noff[n] = tot;
+    if (w->raw2_cap < tot + 64) {
+        big_free(w->raw2, w->raw2_cap);
+        const size_t c = (tot + tot / 8 + ((size_t)2 << 20)) & ~(((size_t)2 << 20) - 1);
+        w->raw2 = big_alloc(c);
+        w->raw2_cap = w->raw2 ? c : 0;
+        if (!w->raw2) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+    }
+    #pragma omp parallel for schedule(static) num_threads(w->threads)
+    for (int64_t i = 0; i < n; i++) {
+        const uint8_t *p = r->raw + r->rec_off[i];
+        const uint32_t bs = le32(p);
+        const int32_t lseq = (int32_t)le32(p + F_LSEQ);
+        const uint8_t *aux = p + F_FIXED + p[F_LNAME] + 4 * (size_t)le16(p + F_NCIG) + ((size_t)lseq + 1) / 2 + (size_t)lseq;
+        const uint8_t *lim = p + 4 + bs;
+        uint8_t *o = w->raw2 + w->noff[i], *q = o;
+        memcpy(q, p, (size_t)(aux - p)); q += aux - p;
+        for (const uint8_t *t = aux; t < lim; ) {
+            const uint8_t *e = aux_end(t + 2, lim);
+            if (aux_keep(w, t)) { memcpy(q, t, (size_t)(e - t)); if (binning) aux_bin(w, q); q += e - t; }
+            t = e;
+        }
+        put32(o, (uint32_t)(q - o - 4));
+    }
+    T_scatter += now_s() - tsc;
+    return bgzf_write(w, w->raw2, tot);
 }
 
 int crumble_bam_writer_close(crumble_bam_writer *w)
@@ -532,7 +677,7 @@ int crumble_bam_writer_close(crumble_bam_writer *w)
     int rc = 0;
     if (fwrite(BGZF_EOF, 1, 28, w->fp) != 28) rc = fail(CRUMBLE_BAM_EIO, "write error: %s", strerror(errno));
     if (fclose(w->fp) != 0 && !rc) rc = fail(CRUMBLE_BAM_EIO, "close: %s", strerror(errno));
-    big_free(w->obuf, w->ocap); free(w);
+    big_free(w->obuf, w->ocap); big_free(w->raw2, w->raw2_cap); free(w->noff); free(w->aux_set); free(w);
     return rc;
 }
 

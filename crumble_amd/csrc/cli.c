@@ -6,7 +6,7 @@
  * getopt string (snp_score.c:2199) in argv order (presets overwrite, later options refine), records
  * are gathered per contig (the unit the reference resets its state on, snp_score.c:1478-1488), the
  * engine rewrites the qualities, records go out in input order.  BAM only (no htslib here): options
- * that belong to htslib / host plumbing that was not rebuilt (-I -O -r -t -T -e..-G -b) are refused
+ * that belong to htslib / host plumbing that was not rebuilt (-I -O -r -b) are refused
  * rather than silently ignored.  There is no CPU path: without a GPU the program stops with
  * CRUMBLE_ENODEVICE.
  */
@@ -37,6 +37,8 @@ static void usage(FILE *fp)
         "  -p N   -S   -N          P-block, soft-clip quantisation, perfect columns\n"
         "  -k list  -K list        qualities to preserve (-K: always)\n"
         "  -R keep.bed             regions whose qualities are kept\n"
+        "  -t list  -T list        auxiliary tags to keep (white list) / to drop (black list)\n"
+        "  -e -f -g / -E -F -G n   BD / BI tag low, cutoff, high values\n"
         "  -z                      no @PG header line\n"
         "  -v                      statistics and timings on stderr\n"
         "  -@ N                    host threads for BGZF/BAM work\n"
@@ -53,7 +55,8 @@ int main(int argc, char **argv)
     crumble_params P;
     crumble_params_default(&P);
     int opt, verbose = 0, threads = 0, no_pg = 0;
-    const char *bed_fn = NULL;
+    const char *bed_fn = NULL, *wl = NULL, *bl = NULL;
+    int bd[3] = {0, 0, 0}, bi[3] = {0, 0, 0};
     while ((opt = getopt(argc, argv, "I:O:q:d:x:Q:D:X:m:l:u:U:c:i:L:Bs:t:T:hr:b:vC:M:Z:P:V:p:e:f:g:E:F:G:S135789zR:Y:y:k:K:N@:")) != -1) {
         switch (opt) {
         case 'q': P.min_qual_A = atoi(optarg); break;
@@ -89,9 +92,16 @@ int main(int argc, char **argv)
         case 'v': verbose++; break;
         case '@': threads = atoi(optarg); break;
         case 'h': usage(stdout); return 0;
-        case 'I': case 'O': case 'r': case 't': case 'T': case 'b':
-        case 'e': case 'f': case 'g': case 'E': case 'F': case 'G':
-            fprintf(stderr, "crumble-hip: option -%c (htslib formats / regions / aux-tag editing / bed output) is host "
+        case 't': wl = optarg; break;
+        case 'T': bl = optarg; break;
+        case 'e': bd[0] = atoi(optarg) + 33; break;
+        case 'f': bd[1] = atoi(optarg) + 33; break;
+        case 'g': bd[2] = atoi(optarg) + 33; break;
+        case 'E': bi[0] = atoi(optarg) + 33; break;
+        case 'F': bi[1] = atoi(optarg) + 33; break;
+        case 'G': bi[2] = atoi(optarg) + 33; break;
+        case 'I': case 'O': case 'r': case 'b':
+            fprintf(stderr, "crumble-hip: option -%c (htslib formats / regions / bed output) is host "
                             "plumbing that this build does not provide\n", opt);
             return 1;
         default: usage(stderr); return 1;
@@ -121,6 +131,7 @@ int main(int argc, char **argv)
     }
     crumble_bam_writer *wr = crumble_bam_create(out_fn, rd, pg, level, threads, &err);
     if (!wr) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
+    if (crumble_bam_set_aux_filter(wr, wl, bl, bd, bi)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
 
     int64_t stats[CRUMBLE_ST_N] = {0};
     uint8_t *qout = NULL; size_t qcap = 0;

@@ -51,6 +51,12 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b);
  * sam_hdr_add_pg, snp_score.c:2588-2609).  level: zlib 0..9 (-1 default). */
 crumble_bam_writer *crumble_bam_create(const char *path, const crumble_bam_reader *hdr_from,
                                        const char *pg_line, int level, int threads, int *err);
+/* purge_tags() of the reference (snp_score.c:989-1054), applied to every record written:
+ * whitelist (-t) or blacklist (-T) of two-character tags in the reference's "XX,YY,ZZ"
+ * list syntax (a white list wins), and BD / BI quantisation (-e -f -g / -E -F -G): bd[] / bi[] =
+ * {low, mid, high} as character values (the option value + 33), all 0 = off.  NULL = none. */
+int crumble_bam_set_aux_filter(crumble_bam_writer *w, const char *whitelist, const char *blacklist,
+                               const int bd[3], const int bi[3]);
 /* Writes the reader's current group with qual_out (same layout as crumble_hip_contig's output;
  * NULL = qualities unchanged) replacing the quality bytes: flush_bam_list(), snp_score.c:1081-1105. */
 int crumble_bam_write_group(crumble_bam_writer *w, crumble_bam_reader *r, const uint8_t *qual_out);

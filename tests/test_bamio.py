@@ -214,6 +214,84 @@ def test_load_bed_matches_bed_collapse(tmp_path):
     rd.close()
 
 
+# ------------------------------------------------------------------------ purge_tags (f3)
+def py_aux_split(aux):
+    """[(tag, whole field bytes)] with the SAMv1 4.2.4 type sizes."""
+    out, p = [], 0
+    fixed = {b"A": 1, b"c": 1, b"C": 1, b"s": 2, b"S": 2, b"i": 4, b"I": 4, b"f": 4, b"d": 8}
+    while p < len(aux):
+        t = aux[p + 2:p + 3]
+        if t in fixed:
+            e = p + 3 + fixed[t]
+        elif t in (b"Z", b"H"):
+            e = aux.index(b"\0", p + 3) + 1
+        else:
+            assert t == b"B"
+            n, = struct.unpack_from("<I", aux, p + 4)
+            e = p + 8 + n * fixed[aux[p + 3:p + 4]]
+        out.append((aux[p:p + 2], aux[p:e]))
+        p = e
+    return out
+
+
+def py_purge(aux, white=None, black=None, bd=None, bi=None):
+    """purge_tags, snp_score.c:989-1054, restated."""
+    keep = []
+    for tag, field in py_aux_split(aux):
+        if white is not None:
+            if tag not in white:
+                continue
+        elif black is not None and tag in black:
+            continue
+        for name, b in ((b"BD", bd), (b"BI", bi)):
+            if b and tag == name and field[2:3] == b"Z":
+                field = field[:3] + bytes((b[2] if c >= b[1] else b[0]) for c in field[3:-1]) + b"\0"
+        keep.append(field)
+    return b"".join(keep)
+
+
+def test_purge_tags(tmp_path):
+    rng = np.random.default_rng(5)
+    refs = [("a", 100000)]
+    fields = [b"NMC\x05", b"XSZhello world\0", b"BDZ" + bytes(rng.integers(33, 90, 40).astype(np.uint8)) + b"\0",
+              b"BIZ" + bytes(rng.integers(33, 90, 40).astype(np.uint8)) + b"\0", b"ASi" + struct.pack("<i", -7),
+              b"XFf" + struct.pack("<f", 1.5), b"ZBBS" + struct.pack("<I3H", 3, 1, 2, 3), b"MDZ10A5\0", b"RGZgrp\0",
+              b"XHH1AE3\0", b"XAA!", b"xds" + struct.pack("<h", -2), b"BDZ\0"]
+    reads = []
+    for i in range(300):
+        L = int(rng.integers(1, 80))
+        k = rng.permutation(len(fields))[:int(rng.integers(0, len(fields)))]
+        reads.append(dict(tid=0, pos=10 * i, cigar=[(L << 4)], seq=rng.choice([1, 2, 4, 8], L), qual=rng.integers(2, 41, L),
+                          name=f"r{i}", aux=b"".join(fields[j] for j in k)))
+    (tmp_path / "a.bam").write_bytes(py_bgzf(py_bam(refs, reads), block=5000))
+    cases = [dict(whitelist="NM,RG,BD"), dict(blacklist="XS,BD,ZB"), dict(whitelist="NM", blacklist="NM"),
+             dict(bd=(40 + 33, 20 + 33, 50 + 33)), dict(blacklist="XS,MD", bd=(35, 60, 80), bi=(36, 50, 70)), dict()]
+    for kw in cases:
+        rd = bamio.Reader(tmp_path / "a.bam")
+        wr = bamio.Writer(tmp_path / "o.bam", rd, level=1, threads=3)
+        wr.set_aux_filter(**kw)
+        while rd.next_contig() is not None:
+            wr.write_group(None)
+        wr.close(); rd.close()
+        _, _, recs = walk_bam(tmp_path / "o.bam")
+        assert len(recs) == len(reads)
+        def split(l):
+            if l is None:
+                return None
+            l = l.replace(",", "")
+            return {l[i:i + 2].encode() for i in range(0, len(l), 2)}
+        for r, o in zip(reads, recs):
+            want = py_purge(r["aux"], split(kw.get("whitelist")), split(kw.get("blacklist")), kw.get("bd"), kw.get("bi"))
+            assert o["aux"] == want, (kw, r["aux"], o["aux"], want)
+            assert o["name"] == r["name"].encode() and o["qual"] == bytes(np.asarray(r["qual"], np.uint8))
+    rd = bamio.Reader(tmp_path / "a.bam")
+    wr = bamio.Writer(tmp_path / "o.bam", rd)
+    for bad in (dict(whitelist="NMX"), dict(bd=(40, 0, 0)), dict(bi=(0, 50, 0))):
+        with pytest.raises(bamio.BamError):
+            wr.set_aux_filter(**bad)
+    wr.close(); rd.close()
+
+
 def _oracle_file(params, path, bed=None):
     """What crumble-hip must write: per group, the oracle's bytes (the checker)."""
     O.load()
@@ -256,6 +334,15 @@ def test_cli_end_to_end_emulated(tmp_path):
         assert np.array_equal(got, want), np.nonzero(got != want)[0][:10]
         text, wrefs, recs = walk_bam(tmp_path / "out.bam")
         assert wrefs == refs and "@PG\tID:crumble-hip" in text and len(recs) == sum(b.n_reads for b in bs)
+    # purge_tags through the command line (-T drops, -e/-f/-g bins BD) leaves names and qualities alone
+    raw = py_bam(refs, [dict(tid=0, pos=100 + i, cigar=[(50 << 4)], seq=[1] * 50, qual=[30] * 50, name=f"t{i}",
+                             aux=b"NMC\x01BDZ" + bytes([40 + i, 70]) + b"\0XSZab\0") for i in range(5)])
+    (tmp_path / "tags.bam").write_bytes(py_bgzf(raw))
+    r = subprocess.run([exe, "-9", "-T", "XS", "-e", "2", "-f", "20", "-g", "40", str(tmp_path / "tags.bam"), str(tmp_path / "t2.bam")],
+                       stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    recs = walk_bam(tmp_path / "t2.bam")[2]
+    assert [x["aux"] for x in recs] == [b"NMC\x01BDZ" + bytes([35 if 40 + i < 53 else 73, 73]) + b"\0" for i in range(5)]
     # options that were not rebuilt are refused loudly
     r = subprocess.run([exe, "-r", "chrI", str(tmp_path / "in.bam"), str(tmp_path / "o2.bam")], stderr=subprocess.PIPE, text=True)
     assert r.returncode == 1 and "does not provide" in r.stderr
