@@ -6,7 +6,7 @@
  * getopt string (snp_score.c:2199) in argv order (presets overwrite, later options refine), records
  * are gathered per contig (the unit the reference resets its state on, snp_score.c:1478-1488), the
  * engine rewrites the qualities, records go out in input order.  BAM only (no htslib here): options
- * that belong to htslib / host plumbing that was not rebuilt (-I -O -r -b) are refused
+ * that belong to htslib / host plumbing that was not rebuilt (-I -O -r) are refused
  * rather than silently ignored.  There is no CPU path: without a GPU the program stops with
  * CRUMBLE_ENODEVICE.
  */
@@ -37,6 +37,7 @@ static void usage(FILE *fp)
         "  -p N   -S   -N          P-block, soft-clip quantisation, perfect columns\n"
         "  -k list  -K list        qualities to preserve (-K: always)\n"
         "  -R keep.bed             regions whose qualities are kept\n"
+        "  -b out.bed              write the suspicious regions (DEEP, CLIP, INDEL_LEN, ...) as BED\n"
         "  -t list  -T list        auxiliary tags to keep (white list) / to drop (black list)\n"
         "  -e -f -g / -E -F -G n   BD / BI tag low, cutoff, high values\n"
         "  -z                      no @PG header line\n"
@@ -57,6 +58,7 @@ int main(int argc, char **argv)
     int opt, verbose = 0, threads = 0, no_pg = 0;
     const char *bed_fn = NULL, *wl = NULL, *bl = NULL;
     int bd[3] = {0, 0, 0}, bi[3] = {0, 0, 0};
+    FILE *bed_fp = NULL;
     while ((opt = getopt(argc, argv, "I:O:q:d:x:Q:D:X:m:l:u:U:c:i:L:Bs:t:T:hr:b:vC:M:Z:P:V:p:e:f:g:E:F:G:S135789zR:Y:y:k:K:N@:")) != -1) {
         switch (opt) {
         case 'q': P.min_qual_A = atoi(optarg); break;
@@ -100,8 +102,9 @@ int main(int argc, char **argv)
         case 'E': bi[0] = atoi(optarg) + 33; break;
         case 'F': bi[1] = atoi(optarg) + 33; break;
         case 'G': bi[2] = atoi(optarg) + 33; break;
-        case 'I': case 'O': case 'r': case 'b':
-            fprintf(stderr, "crumble-hip: option -%c (htslib formats / regions / bed output) is host "
+        case 'b': if (!(bed_fp = fopen(optarg, "w"))) { perror(optarg); return 1; } break;
+        case 'I': case 'O': case 'r':
+            fprintf(stderr, "crumble-hip: option -%c (htslib formats / regions) is host "
                             "plumbing that this build does not provide\n", opt);
             return 1;
         default: usage(stderr); return 1;
@@ -159,11 +162,26 @@ int main(int argc, char **argv)
         const int e = crumble_hip_contig(eng, &B, qout, NULL, stats);
         t_gpu += now() - t0;
         if (e) { fprintf(stderr, "crumble-hip: contig %s: %s (%s)\n", crumble_bam_ref_name(rd, B.tid), crumble_hip_strerror(e), crumble_hip_last_error()); return 2; }
+        if (bed_fp && B.tid >= 0) {                             /* -b: snp_score.c:1496,1676,1768,1802,1810 */
+            const int64_t ns = crumble_hip_suspect(eng, NULL, NULL, 0);
+            if (ns < 0) { fprintf(stderr, "crumble-hip: %s\n", crumble_hip_strerror((int)ns)); return 2; }
+            int32_t *sp = malloc((size_t)(ns + 1) * 4); uint8_t *sw = malloc((size_t)ns + 1);
+            if (!sp || !sw || crumble_hip_suspect(eng, sp, sw, ns) != ns) { fprintf(stderr, "crumble-hip: -b failed\n"); return 2; }
+            static const struct { int bit; const char *name; } why[] = {
+                { CRUMBLE_WHY_VDEEP, "VDEEP" }, { CRUMBLE_WHY_DEEP, "DEEP" }, { CRUMBLE_WHY_CLIP, "CLIP" },
+                { CRUMBLE_WHY_INDEL_LEN, "INDEL_LEN" }, { CRUMBLE_WHY_INDEL_COVERAGE, "INDEL_COVERAGE" } };
+            for (int64_t k = 0; k < ns; k++)
+                for (int y = 0; y < 5; y++)
+                    if (sw[k] & why[y].bit)
+                        fprintf(bed_fp, "%s\t%d\t%d\t%s\n", crumble_bam_ref_name(rd, B.tid), sp[k] > 50 ? sp[k] - 50 : 0, sp[k] + 50, why[y].name);
+            free(sp); free(sw);
+        }
         t0 = now();
         if (crumble_bam_write_group(wr, rd, qout)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
         t_write += now() - t0;
         if (verbose > 1) fprintf(stderr, "  %s: %lld reads, %zu bases\n", crumble_bam_ref_name(rd, B.tid), (long long)B.n_reads, nb);
     }
+    if (bed_fp && fclose(bed_fp)) { perror("-b"); return 1; }
     if (crumble_bam_writer_close(wr)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
     const double wall = now() - t_all;
     if (verbose) {

@@ -126,6 +126,11 @@ struct DBatch {
 #define CR_HASINS       (1u << 15)   /* indel_sz > 0: needs the histogram    */
 #define CR_EXISTS       (1u << 16)   /* n_plp > 0                            */
 #define CR_SCAN         (1u << 17)   /* indel_cnt >= n_plp*indel_fract       */
+/* why keep_qual was forced on (the reference's -b reasons, snp:1676,1768,1802,1810) */
+#define CR_R_DEEP       (1u << 18)
+#define CR_R_CLIP       (1u << 19)
+#define CR_R_INSLEN     (1u << 20)
+#define CR_R_INDELOV    (1u << 21)
 #define CR_SKIP         (CR_ALLREFSKIP | CR_TOODEEP)
 
 /* one STR/indel trigger (snp:1718-1756) */

@@ -699,6 +699,8 @@ extern "C" int64_t crumble_hip_columns(crumble_hip *h, crumble_column *cols, int
             c->pos = h->B.p0 + i; c->n_plp = np[i];
             c->skipped = (r & CR_ALLREFSKIP) ? 1 : (r & CR_TOODEEP) ? 2 : 0;
             if (!c->skipped) {
+                c->skipped = (uint8_t)(((r & CR_R_DEEP) ? CRUMBLE_WHY_DEEP : 0) | ((r & CR_R_CLIP) ? CRUMBLE_WHY_CLIP : 0) |
+                                       ((r & CR_R_INSLEN) ? CRUMBLE_WHY_INDEL_LEN : 0) | ((r & CR_R_INDELOV) ? CRUMBLE_WHY_INDEL_COVERAGE : 0));
                 c->score = sc[i];
                 c->call1 = CR_A1(r); c->call2 = CR_A2(r);
                 c->preserve = CR_PRESERVE(r); c->perfect = (r & CR_PERFECT) ? 1 : 0;
@@ -707,6 +709,29 @@ extern "C" int64_t crumble_hip_columns(crumble_hip *h, crumble_column *cols, int
                 c->min_pos2 = (r & CR_TRIG) ? mn2[i] : 0;
             }
         }
+        k++;
+    }
+    return k;
+}
+
+/* The columns the reference reports with -b (snp_score.c:1496,1676,1768,1802,1810), in position order. */
+extern "C" int64_t crumble_hip_suspect(crumble_hip *h, int32_t *pos, uint8_t *why, int64_t max)
+{
+    if (!h || !h->have_run) return CRUMBLE_EINVAL;
+    if (hipSetDevice(h->device) != hipSuccess) return CRUMBLE_EHIP;
+    const int L = h->B.L;
+    if (L <= 0) return 0;
+    std::vector<uint32_t> rec((size_t)L);
+    if (hipMemcpy(rec.data(), h->d_colrec.p, (size_t)L * 4, hipMemcpyDeviceToHost) != hipSuccess) return CRUMBLE_EHIP;
+    int64_t k = 0;
+    for (int i = 0; i < L; i++) {
+        const uint32_t r = rec[i];
+        if (!(r & CR_EXISTS) || (r & CR_ALLREFSKIP)) continue;
+        const unsigned w = (r & CR_TOODEEP) ? CRUMBLE_WHY_VDEEP
+                         : (((r & CR_R_DEEP) ? CRUMBLE_WHY_DEEP : 0) | ((r & CR_R_CLIP) ? CRUMBLE_WHY_CLIP : 0) |
+                            ((r & CR_R_INSLEN) ? CRUMBLE_WHY_INDEL_LEN : 0) | ((r & CR_R_INDELOV) ? CRUMBLE_WHY_INDEL_COVERAGE : 0));
+        if (!w) continue;
+        if (k < max) { if (pos) pos[k] = h->B.p0 + i; if (why) why[k] = (uint8_t)w; }
         k++;
     }
     return k;

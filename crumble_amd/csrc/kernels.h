@@ -343,10 +343,12 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
     }
     if (P->perfect_col && !perfect) preserve = 1;                     /* snp:1648 */
 
+    bool why_clip = false;
     bool keep = (double)st.low_mq > P->low_mqual_perc * (n_plp + .01);   /* snp:1668 */
     lds_inc(stats, ST_LOW_MQUAL_PERC, keep);
     if ((st.clipped - 1.0) >= P->clip_perc * st.n_overlap) {          /* snp:1764 */
         keep = true;
+        why_clip = true;
         lds_inc(stats, ST_CLIP_PERC, true);
     }
     if (cond_score)                                                   /* snp:1718 */
@@ -358,6 +360,7 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
     rec |= (uint32_t)a1 | ((uint32_t)a2 << 3) | ((uint32_t)preserve << 6);
     if (perfect) rec |= CR_PERFECT;
     if (keep) rec |= CR_KEEP;
+    if (why_clip) rec |= CR_R_CLIP;
     if (tcnt) rec |= CR_TRIG | CR_WIN;
     if (st.has_ins) rec |= CR_HASINS;
     if ((double)st.indel_cnt >= n_plp * P->indel_fract) rec |= CR_SCAN;  /* snp:1732 */
@@ -813,7 +816,7 @@ __global__ void k_overdepth(int L, uint32_t *colrec, const int32_t *nplp, const 
     const int64_t total_col = e.tc_start + (ord - e.ord_start + 1);
     const int64_t total_depth = e.td_start + (dpre[i] + n - e.dpre_start);
     if ((double)((int64_t)n * (total_col + 1)) > P->over_depth * (double)(total_depth + 1)) {
-        rec |= CR_KEEP;
+        rec |= CR_KEEP | CR_R_DEEP;
         colrec[i] = rec;
         stat_inc(stats, ST_OVER_DEPTH, true);
     }
@@ -857,10 +860,10 @@ k_inshist(DBatch B, const DParams *P, int n_ins, const int32_t *inscol_pos,
         if (qd1 < hist[i]) { qd2 = qd1; qd1 = hist[i]; }
         else if (qd2 < hist[i]) qd2 = hist[i];
     }
-    bool keep = false;
-    if ((double)(ov - qd1 - qd2) > P->ins_len_perc * (ov + .1)) { keep = true; stat_inc(stats, ST_INS_LEN_PERC, true); }
-    if ((double)ov < P->indel_ov_perc * nplp[c]) { keep = true; stat_inc(stats, ST_INDEL_OV_PERC, true); }
-    if (keep) colrec[c] |= CR_KEEP;
+    uint32_t why = 0;
+    if ((double)(ov - qd1 - qd2) > P->ins_len_perc * (ov + .1)) { why |= CR_KEEP | CR_R_INSLEN; stat_inc(stats, ST_INS_LEN_PERC, true); }
+    if ((double)ov < P->indel_ov_perc * nplp[c]) { why |= CR_KEEP | CR_R_INDELOV; stat_inc(stats, ST_INDEL_OV_PERC, true); }
+    if (why) colrec[c] |= why;
 }
 
 /* ------------------------------------------------------------------------ */

@@ -186,6 +186,15 @@ int   crumble_hip_stats_allreduce(crumble_hip *h, void *nccl_comm);
  *  calculate_consensus_pileup (snp:533) over every column of a batch ->
  *  per-position records; find_STR/mask_LC_regions (str_finder.c:135, snp:1230)
  *  over explicit (read, qpos+1, is_indel) queries; pblock (snp:803) per read. */
+/* why a column forced keep_qual: the reasons reference crumble writes to its -b BED file
+ * (snp_score.c:1676 DEEP, 1768 CLIP, 1802 INDEL_LEN, 1810 INDEL_COVERAGE; 1496 VDEEP is skipped == 2).
+ * One line "chrom  max(pos-50,0)  pos+50  REASON" per set bit, in this order, per column. */
+#define CRUMBLE_WHY_VDEEP           0x08   /* only from crumble_hip_suspect(): n_plp > 20000 */
+#define CRUMBLE_WHY_DEEP            0x10
+#define CRUMBLE_WHY_CLIP            0x20
+#define CRUMBLE_WHY_INDEL_LEN       0x40
+#define CRUMBLE_WHY_INDEL_COVERAGE  0x80
+
 typedef struct crumble_column {        /* one pileup column, after step 18 of  */
     int32_t pos;                       /* SURVEY.md App. A.2                   */
     int32_t n_plp;
@@ -196,12 +205,17 @@ typedef struct crumble_column {        /* one pileup column, after step 18 of  *
     uint8_t keep_qual;
     uint8_t trigger;                   /* `indel` != 0  snp:1870               */
     uint8_t window;                    /* min_pos != INT_MAX  snp:1880         */
-    uint8_t skipped;                   /* 1 all-refskip, 2 too deep            */
+    uint8_t skipped;                   /* 1 all-refskip, 2 too deep (= the -b  */
+                                       /* reason VDEEP); else CRUMBLE_WHY_* bits */
     int32_t min_pos2;                  /* valid when trigger                   */
 } crumble_column;
 /* Fills cols[0..max) with the columns of the uploaded batch in position order
  * after crumble_hip_run(); returns the number of columns (may exceed max). */
 int64_t crumble_hip_columns(crumble_hip *h, crumble_column *cols, int64_t max);
+
+/* The suspicious columns of the last crumble_hip_run() in position order: pos[k], why[k] =
+ * CRUMBLE_WHY_* bits; returns their number (may exceed max).  This is what crumble -b prints. */
+int64_t crumble_hip_suspect(crumble_hip *h, int32_t *pos, uint8_t *why, int64_t max);
 
 int crumble_hip_mask_lc(crumble_hip *h, int64_t n, const int64_t *read_idx,
                         const int32_t *qpos1, const uint8_t *is_indel,

@@ -690,7 +690,7 @@ int crumble_oracle_contig(const crumble_params *p, const crumble_batch *b,
         int hA = 0, sA = 0, hB = 0, sB = 0;
         int had_indel = 0, had_indel_Q = 0, low_mq_count = 0, keep_qual = 0, indel_cnt = 0;
         int indel_sz = 0, indel_depth[101], clipped = 0, n_overlap = 0;
-        int skipped = 0;
+        int skipped = 0, why = 0;
 
         /* skip reads that never enter the pileup */
         while (next_read < n && !inplp[next_read]) next_read++;
@@ -797,7 +797,7 @@ int crumble_oracle_contig(const crumble_params *p, const crumble_batch *b,
         keep_qual = low_mq_count > p->low_mqual_perc * (n_plp + .01);   /* snp:1668 */
         st[CRUMBLE_ST_LOW_MQUAL_PERC] += keep_qual;
         if (n_plp * (total_col + 1) > p->over_depth * (total_depth + 1)) {  /* snp:1673 */
-            keep_qual = 1; st[CRUMBLE_ST_OVER_DEPTH]++;
+            keep_qual = 1; st[CRUMBLE_ST_OVER_DEPTH]++; why |= CRUMBLE_WHY_DEEP;        /* -b DEEP snp:1676 */
         }
         if (total_col > 1024 * 1024) { total_col >>= 1; total_depth >>= 1; }  /* snp:1684 */
 
@@ -842,7 +842,7 @@ int crumble_oracle_contig(const crumble_params *p, const crumble_batch *b,
         if (had_indel_Q) st[CRUMBLE_ST_INDEL_QUAL]++;
 
         if ((clipped - 1.0) >= p->clip_perc * n_overlap) { /* snp:1764 */
-            keep_qual = 1; st[CRUMBLE_ST_CLIP_PERC]++;
+            keep_qual = 1; st[CRUMBLE_ST_CLIP_PERC]++; why |= CRUMBLE_WHY_CLIP;         /* -b CLIP snp:1768 */
         }
         if (indel_sz) {                                    /* snp:1777-1819 */
             int qd1 = 0, qd2 = 0, indel_overlap = 0;
@@ -853,10 +853,10 @@ int crumble_oracle_contig(const crumble_params *p, const crumble_batch *b,
                 else if (qd2 < indel_depth[i]) qd2 = indel_depth[i];
             }
             if ((indel_overlap - qd1 - qd2) > p->ins_len_perc * (indel_overlap + .1)) {
-                keep_qual = 1; st[CRUMBLE_ST_INS_LEN_PERC]++;
+                keep_qual = 1; st[CRUMBLE_ST_INS_LEN_PERC]++; why |= CRUMBLE_WHY_INDEL_LEN;         /* snp:1802 */
             }
             if ((double)indel_overlap < p->indel_ov_perc * n_plp) {
-                keep_qual = 1; st[CRUMBLE_ST_INDEL_OV_PERC]++;
+                keep_qual = 1; st[CRUMBLE_ST_INDEL_OV_PERC]++; why |= CRUMBLE_WHY_INDEL_COVERAGE;   /* snp:1810 */
             }
         }
 
@@ -907,6 +907,7 @@ int crumble_oracle_contig(const crumble_params *p, const crumble_batch *b,
             memset(t, 0, sizeof(*t));
             t->pos = pos; t->n_plp = n_plp; t->skipped = skipped;
             if (!skipped) {
+                t->skipped = (uint8_t)why;
                 int a1 = 0, a2 = 0;
                 while ((1 << a1) != call1 && a1 < 6) a1++;
                 while ((1 << a2) != call2 && a2 < 6) a2++;

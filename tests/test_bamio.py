@@ -348,6 +348,43 @@ def test_cli_end_to_end_emulated(tmp_path):
     assert r.returncode == 1 and "does not provide" in r.stderr
 
 
+def _oracle_bed(params, path):
+    """The -b lines the reference would print (snp_score.c:1496,1676,1768,1802,1810), from the oracle's trace."""
+    O.load()
+    rd = bamio.Reader(path)
+    names = [n for n, _ in rd.refs]
+    lines = []
+    for g in rd:
+        if g.tid < 0:
+            continue
+        cols = O.contig(params, g, trace=True)[3]
+        for c in cols:
+            why = ["VDEEP"] if c["skipped"] == 2 else [] if c["skipped"] == 1 else \
+                [nm for bit, nm in ((0x10, "DEEP"), (0x20, "CLIP"), (0x40, "INDEL_LEN"), (0x80, "INDEL_COVERAGE")) if c["skipped"] & bit]
+            for w in why:
+                lines.append(f"{names[g.tid]}\t{max(int(c['pos']) - 50, 0)}\t{int(c['pos']) + 50}\t{w}\n")
+    rd.close()
+    return lines
+
+
+def test_cli_suspect_bed_emulated(tmp_path):
+    """-b: the suspicious-region BED equals what the oracle's column trace implies, line for line."""
+    import emu_lib
+    emu_lib.load()
+    exe = os.path.join(ROOT, "tests", "emu", "crumble-hip-emu")
+    refs, bs = three_groups()
+    bamio.write_batches(tmp_path / "in.bam", refs, bs)
+    args = ["-5", "-P", "1.3", "-C", "0.02", "-Z", "0.05", "-V", "0.6"]
+    params = ca.preset_params(5, over_depth=1.3, clip_perc=0.02, ins_len_perc=0.05, indel_ov_perc=0.6)
+    r = subprocess.run([exe, *args, "-b", str(tmp_path / "s.bed"), str(tmp_path / "in.bam"), str(tmp_path / "out.bam")],
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    got = open(tmp_path / "s.bed").readlines()
+    want = _oracle_bed(params, tmp_path / "in.bam")
+    assert len(want) > 20 and {l.split("\t")[3] for l in want} >= {"DEEP\n", "CLIP\n"}
+    assert got == want
+
+
 def test_cli_has_no_cpu_path(tmp_path):
     """Without a GPU the shipped binary stops with ENODEVICE (exit 2); it never computes on the host."""
     import torch
