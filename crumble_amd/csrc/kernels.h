@@ -1437,26 +1437,45 @@ __global__ void __launch_bounds__(64)
 k_restore(DBatch B, const DParams *__restrict__ P, int n_trig, const int32_t *trigcol_pos,
           const int32_t *__restrict__ pos_mn2, uint8_t *__restrict__ out)
 {
-    /* one 64-lane workgroup per trigger column, lanes over its candidate reads */
+    /* one wave per trigger column.  Step 1: every lane resolves one candidate read (entry, start of
+     * the back-fill in query coordinates).  Step 2: the wave writes the ranges one read at a time,
+     * lanes along the bytes, so a range is one or two coalesced stores instead of a byte loop per
+     * lane that touches 64 different cache lines per step. */
     const int t = blockIdx.x;
     if (t >= n_trig) return;
+    const int lane = threadIdx.x;
     const int c = trigcol_pos[t], apos = B.p0 + c, tile = c >> 6;
     const int lo = B.tile_lo[tile], hi = B.tile_hi[tile];
     const int mn2 = pos_mn2[c], qcap = P->qcap;
     const bool any_pres = P->any_preserve != 0, softclip = P->softclip != 0;
-    for (int r = lo + (int)threadIdx.x; r < hi; r += blockDim.x) {
-        const int rp = B.pos[r];
-        if (!(apos >= rp && apos < B.end[r])) continue;
-        if (softclip && apos == rp) continue;              /* done by the replay pass, before the binning */
-        Entry e;
-        resolve_entry(B, r, apos, e);
-        const int64_t so = B.seq_off[r];
-        const int lq = (int)(B.seq_off[r + 1] - so);
-        if (!lq || e.qpos >= lq) continue;                 /* snp:1861 / fence */
-        const uint32_t *cig = B.cigar + B.cig_off[r];
-        const int start = dev_ref2query_pos(cig, (int)(B.cig_off[r + 1] - B.cig_off[r]), rp, mn2);
-        for (int x = start; x < e.qpos; x++)
-            out[so + x] = cap_q2(P, qcap, any_pres, B.quals[so + x]) & 0x7f;
+    for (int r0 = lo; r0 < hi; r0 += 64) {
+        const int r = r0 + lane;
+        int start = 0, stop = 0;
+        unsigned so_lo = 0, so_hi = 0;
+        if (r < hi) {
+            const int rp = B.pos[r];
+            if (apos >= rp && apos < B.end[r] && !(softclip && apos == rp)) {   /* head column with -S: done by the replay pass */
+                Entry e;
+                resolve_entry(B, r, apos, e);
+                const int64_t so = B.seq_off[r];
+                const int lq = (int)(B.seq_off[r + 1] - so);
+                if (lq && e.qpos < lq) {                       /* snp:1861 / fence */
+                    const uint32_t *cig = B.cigar + B.cig_off[r];
+                    start = dev_ref2query_pos(cig, (int)(B.cig_off[r + 1] - B.cig_off[r]), rp, mn2);
+                    stop = e.qpos;
+                    so_lo = (unsigned)(uint64_t)so; so_hi = (unsigned)((uint64_t)so >> 32);
+                }
+            }
+        }
+        unsigned long long todo = __ballot(start < stop);
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int s = READLANE(start, src), e = READLANE(stop, src);
+            const int64_t so = (int64_t)(((uint64_t)(unsigned)READLANE(so_hi, src) << 32) | (unsigned)READLANE(so_lo, src));
+            for (int x = s + lane; x < e; x += 64)
+                out[so + x] = cap_q2(P, qcap, any_pres, B.quals[so + x]) & 0x7f;
+        }
     }
 }
 
