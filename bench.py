@@ -91,8 +91,17 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        # RCCL ("nccl") over xGMI is the real path; CRUMBLE_BENCH_BACKEND=gloo + CRUMBLE_BENCH_DEVICE=0 let the
+        # N>1 control flow be exercised on a one-GPU box (tests/test_gpu_parity.py::test_bench_two_ranks)
+        backend = os.environ.get("CRUMBLE_BENCH_BACKEND", "nccl")
+        if "CRUMBLE_BENCH_DEVICE" in os.environ:
+            local_rank = int(os.environ["CRUMBLE_BENCH_DEVICE"])
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    red_dev = "cuda" if os.environ.get("CRUMBLE_BENCH_BACKEND", "nccl") == "nccl" else "cpu"
 
     import crumble_amd as ca
     from crumble_amd import synth
@@ -158,7 +167,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -166,10 +175,10 @@ def main():
     stats = sum(e_.stats_read() for e_ in engines)
     bases_local = sum(b_.n_bases for b_ in batches)
     if dist is not None:
-        st = torch.from_numpy(stats.copy()).to("cuda")
+        st = torch.from_numpy(stats.copy()).to(red_dev)
         dist.all_reduce(st, op=dist.ReduceOp.SUM)
         stats = st.cpu().numpy()
-        tb = torch.tensor([bases_local], dtype=torch.int64, device="cuda")
+        tb = torch.tensor([bases_local], dtype=torch.int64, device=red_dev)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         total_bases = int(tb.item())
     else:
@@ -231,7 +240,7 @@ def main():
         n_sample_bases = args.cpu_seconds / ns_per_base
         n_sample = int(min(hb.n_reads, max(1000, n_sample_bases / max(1, hb.n_bases / max(1, hb.n_reads)))))
         sample = prefix_batch(hb, n_sample)
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:          # CPU baseline: rank 0 at N=1 only
             O.load()
             t0 = time.perf_counter()
             wq, wf, ws = O.contig(params, sample)

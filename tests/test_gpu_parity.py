@@ -209,3 +209,23 @@ def test_upload_validation_errors(product):
         assert ei.value.code == code
     eng.contig(HostBatch.from_reads(ok))            # the engine is still usable
     eng.close()
+
+
+@pytest.mark.parametrize("workload", ["chr20", "wgs"])
+def test_bench_two_ranks(product, workload):
+    """bench.py's N>1 control flow (barriers, max-over-ranks timing, stats / base-count all-reduce, one JSON
+    line from rank 0) with two processes sharing this box's one GPU; gloo stands in for RCCL here."""
+    import json, os, subprocess, sys
+    from crumble_amd.capi import ROOT
+    env = dict(os.environ, CRUMBLE_BENCH_BACKEND="gloo", CRUMBLE_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    scale = "0.01" if workload == "chr20" else "0.0005"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload, "--scale", scale],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == ("weak" if workload == "chr20" else "strong")
+    assert "roofline" in d and "cpu_baseline" not in d
