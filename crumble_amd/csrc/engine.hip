@@ -56,7 +56,7 @@ struct crumble_hip {
     DParams hparams;
     DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc;
     /* batch (inputs) */
-    DevBuf d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
+    DevBuf d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
            d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax;
     /* per position */
     DevBuf d_colrec, d_nplp, d_score, d_trigcnt, d_dpre, d_col_ord, d_trig_ord, d_item_off,
@@ -218,7 +218,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     DevBuf *all[] = { &h->d_params, &h->d_tables, &h->d_stats, &h->d_batch_stats, &h->d_misc,
-        &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
+        &h->d_act, &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
         &h->d_slow_g, &h->d_slow_r, &h->d_cix, &h->d_sr, &h->d_stile_lo, &h->d_stile_hi, &h->d_rr, &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
         &h->d_cigar, &h->d_segs, &h->d_bases, &h->d_quals, &h->d_tile_lo, &h->d_tile_hi,
         &h->d_bed_start, &h->d_bed_end, &h->d_bed_pmax, &h->d_colrec, &h->d_nplp, &h->d_score,
@@ -238,7 +238,7 @@ static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / 
 template <class T>
 static int up(crumble_hip *h, DevBuf &d, const T *src, size_t n)
 {
-    int e = d.reserve((n ? n : 1) * sizeof(T));
+    int e = d.reserve((n ? n : 1) * sizeof(T) + 64);      /* slack: kernels read whole 16-byte vectors */
     if (e) return e;
     if (n) HIPCHK(hipMemcpyAsync(d.p, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
     return CRUMBLE_OK;
@@ -548,7 +548,23 @@ extern "C" int crumble_hip_run(crumble_hip *h)
             CRUMBLE_LAUNCH_INDEP(k_replay_general, nblk(nb, 256), 256, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
                                  h->d_blk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(),
                                  h->d_b15f.as<uint8_t>());
-        else if (nb > 0) {
+        else if (nb > 0 && !(h->n_segrec > h->n_reads + h->n_reads / 2) && !h->hparams.any_preserve && h->hparams.qcutoff >= 0 && h->hparams.qcutoff < 128 &&
+                 h->hparams.qcap < 128 && !getenv("CRUMBLE_HIP_REPLAY_FLAT")) {
+            /* short reads, no -k/-K/-S: action bytes + packed 16-base chunks + per-read edges (kernels.h) */
+            int ea;
+            if ((ea = h->d_act.reserve((size_t)L + 2 * ACT_PAD))) return ea;
+            uint8_t *act = h->d_act.as<uint8_t>() + ACT_PAD;
+            if (L > 0) CRUMBLE_LAUNCH_INDEP(k_actions, nblk(L, 256), 256, st, L, colrec, act);
+            CRUMBLE_LAUNCH_INDEP(k_replay_fast, nblk((nb + 15) / 16, 256), 256, st, B, P, colrec, act,
+                                 h->d_blk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(),
+                                 h->d_b15f.as<uint8_t>());
+            CRUMBLE_LAUNCH(k_replay_reads, nblk(n, 256), 256, st, B, P, colrec,
+                           h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(), h->d_b15f.as<uint8_t>());
+            if (h->n_slow > 0)
+                CRUMBLE_LAUNCH_INDEP(k_replay_slow, nblk(h->n_slow, 64), 64, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
+                                     h->d_misc.as<int>() + 11, h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(),
+                                     h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(), h->d_b15f.as<uint8_t>());
+        } else if (nb > 0) {
             CRUMBLE_LAUNCH_INDEP(k_replay_flat, nblk((nb + RPL_NB - 1) / RPL_NB, 256), 256, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
                                  h->d_blk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(),
                                  h->d_b15f.as<uint8_t>());

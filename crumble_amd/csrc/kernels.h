@@ -1408,6 +1408,171 @@ k_replay_flat(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
     else for (int k = 0; k < nn; k++) out[g0 + k] = (uint8_t)((ow[k >> 2] >> (8 * (k & 3))) & 255);
 }
 
+/* ------------------------------------------------------------------------ */
+/* Short-read batches: the replay in packed form instead of one general per-base routine.
+ *   k_actions       one byte per column: everything a base needs to know about its column
+ *                     bits 0-3  nt16 mask of the called alleles ((1<<A1 | 1<<A2) & 15)
+ *                     bit  4    value stays (skipped column, or preserve != 0)
+ *                     bit  5    window column: capped original (snp:1880)
+ *                     bit  6    the column sets a per-read flag (keep_qual / bit 15): rare follow-up
+ *   k_replay_fast   one lane per 16-byte chunk of the flat base array.  For every single-match read
+ *                   that overlaps the chunk, 16 qualities, 16 bases and the 16 action bytes of the
+ *                   columns they would sit on are combined with packed byte arithmetic (values < 128
+ *                   leave bit 7 free as a guard), ~9 VALU per base instead of ~80, and the bytes of
+ *                   that read's aligned part are taken from the result; clips, reads outside the
+ *                   pileup and (for now) reads with a general CIGAR keep the input byte.  All loads
+ *                   and the store are 16 bytes wide and coalesced.
+ *   k_replay_reads  the reads with a general CIGAR (a few %): the wave takes them one at a time,
+ *                   one lane per base, through replay_base(). */
+__global__ void k_actions(int L, const uint32_t *__restrict__ colrec, uint8_t *__restrict__ act)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= L) return;
+    const uint32_t r = colrec[c];
+    const bool skip = (r & CR_SKIP) != 0;
+    const unsigned pres = CR_PRESERVE(r);
+    unsigned a = ((1u << CR_A1(r)) | (1u << CR_A2(r))) & 15u;
+    if (skip || pres) a |= 16u;
+    if (!skip && (r & CR_WIN)) a |= 32u;
+    if (!skip && ((r & CR_KEEP) || pres > 1)) a |= 64u;
+    act[c] = (uint8_t)a;
+}
+
+#define PB4(x)       ((uint32_t)(x) * 0x01010101u)
+#define PB_GE(a, b)  ((((((a) | 0x80808080u) - (b)) & 0x80808080u) >> 7) * 0xffu)    /* bytes where a >= b (a, b < 128) */
+#define PB_NZ(x)     (((((x) + 0x7f7f7f7fu) & 0x80808080u) >> 7) * 0xffu)             /* bytes where x != 0 (x < 128)    */
+#define ACT_PAD 64   /* bytes in front of act[0]: a chunk may start up to 15 columns before the read */
+
+__global__ void __launch_bounds__(256)
+k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restrict__ colrec,
+              const uint8_t *__restrict__ act, const int32_t *__restrict__ blk_read,
+              uint8_t *__restrict__ out, uint8_t *__restrict__ keepf, uint8_t *__restrict__ b15f)
+{
+    const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (g0 >= B.n_bases) return;
+    const int64_t gend = (g0 + 16 < B.n_bases) ? g0 + 16 : B.n_bases;
+    const uint4 q4 = *(const uint4 *)(B.quals + g0), b4 = *(const uint4 *)(B.bases + g0);   /* buffers carry slack */
+    const uint32_t qw[4] = {q4.x, q4.y, q4.z, q4.w}, bw[4] = {b4.x, b4.y, b4.z, b4.w};
+    uint32_t ow[4] = {qw[0] & 0x7f7f7f7fu, qw[1] & 0x7f7f7f7fu, qw[2] & 0x7f7f7f7fu, qw[3] & 0x7f7f7f7fu};
+    const uint32_t QC = PB4(P->qcap), QH = PB4(P->qhigh), QL = PB4(P->qlow), CUT = PB4(P->qcutoff);
+    const bool reduce = P->reduce_qual != 0, binary = P->binary_qual != 0;
+    const int min_mqual = P->min_mqual;
+    int64_t r = blk_read[g0 >> 6];
+    ReadRec rr = B.rr[r];
+    while (g0 >= rr.so + rr.lq) { r++; rr = B.rr[r]; }
+    for (;;) {
+        if ((rr.info & RR_SIMPLE) && rr.end > rr.pos) {
+            /* bytes of this chunk that are aligned bases of this read */
+            const int64_t a0 = rr.so + rr.q0, a1 = a0 + (rr.end - rr.pos);
+            const int lo = (a0 > g0) ? (int)(a0 - g0) : 0, hi = (a1 < gend) ? (int)(a1 - g0) : (int)(gend - g0);
+            if (lo < hi) {
+                const unsigned vb = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+                const int c0 = rr.pos + (int)(g0 - a0) - B.p0;     /* column of byte 0 (may be < 0: padded) */
+                uint32_t hm = 0;                                   /* low-mapq read whose head column is live: snp:1852 */
+                if ((int)(rr.info & 255) <= min_mqual && !(colrec[rr.pos - B.p0] & CR_SKIP)) hm = 0xffffffffu;
+                uint32_t a[4];
+                {   /* 16 action bytes from an arbitrary byte address: aligned dwords + byte funnel */
+                    const uint8_t *ap = act + c0;
+                    const unsigned sh = (unsigned)((uintptr_t)ap & 3u);
+                    const uint32_t *aw = (const uint32_t *)(ap - sh);
+                    const uint32_t w0 = aw[0], w1 = aw[1], w2 = aw[2], w3 = aw[3], w4 = aw[4];
+                    const unsigned s8 = sh * 8u;
+                    a[0] = sh ? (w0 >> s8) | (w1 << (32u - s8)) : w0;
+                    a[1] = sh ? (w1 >> s8) | (w2 << (32u - s8)) : w1;
+                    a[2] = sh ? (w2 >> s8) | (w3 << (32u - s8)) : w2;
+                    a[3] = sh ? (w3 >> s8) | (w4 << (32u - s8)) : w3;
+                }
+                uint32_t se = 0;
+                #pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t q = qw[k], b = bw[k], ac = a[k];
+                    const uint32_t V = ((((vb >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;   /* this read's bytes */
+                    const uint32_t geq = PB_GE(q, QC);
+                    const uint32_t capq = (QC & geq) | (q & ~geq);                       /* cap_quality snp:1325 */
+                    const uint32_t hit = b & ac & 0x0f0f0f0fu;                          /* base shares a bit with a called allele */
+                    const uint32_t many = b & ((b | 0x80808080u) - 0x01010101u) & 0x0f0f0f0fu;   /* >= 2 bits: never equals a call */
+                    const uint32_t M = PB_NZ(hit) & ~PB_NZ(many);                       /* base == call1 || base == call2 (snp:1908) */
+                    uint32_t nm = q;
+                    if (reduce) {
+                        if (binary) { const uint32_t gc = PB_GE(q, CUT); nm = (QH & gc) | (QL & ~gc); }   /* bin2[], no -K here */
+                        else nm = QL;
+                    }
+                    const uint32_t qz = (QH & M) | (nm & ~M);
+                    const uint32_t U = (((ac >> 4) & 0x01010101u) * 0xffu) | hm;
+                    const uint32_t W = ((ac >> 5) & 0x01010101u) * 0xffu;
+                    const uint32_t v = ((capq & W) | (~W & ((q & U) | (qz & ~U)))) & 0x7f7f7f7fu;
+                    ow[k] = (v & V) | (ow[k] & ~V);
+                    se |= ac & V & 0x40404040u;
+                }
+                if (se) {                                          /* rare: a column raises a per-read flag */
+                    for (int k = lo; k < hi; k++) {
+                        const uint32_t rc = colrec[c0 + k];
+                        if (rc & CR_SKIP) continue;
+                        if (rc & CR_KEEP) keepf[r] = 1;
+                        if (CR_PRESERVE(rc) > 1) b15f[r] = 1;
+                    }
+                }
+            }
+        }
+        if (rr.so + rr.lq >= gend || r + 1 >= B.n_reads) break;
+        r++; rr = B.rr[r];
+    }
+    if (gend - g0 == 16) { uint4 o4; o4.x = ow[0]; o4.y = ow[1]; o4.z = ow[2]; o4.w = ow[3]; *(uint4 *)(out + g0) = o4; }
+    else for (int k = 0; k < (int)(gend - g0); k++) out[g0 + k] = (uint8_t)((ow[k >> 2] >> (8 * (k & 3))) & 255);
+}
+
+__global__ void __launch_bounds__(256)
+k_replay_reads(DBatch B, const DParams *__restrict__ P, const uint32_t *__restrict__ colrec,
+               uint8_t *__restrict__ out, uint8_t *__restrict__ keepf, uint8_t *__restrict__ b15f)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int lq = 0, hm = 0;
+    unsigned cix = 0;
+    int64_t so = 0;
+    bool general = false;
+    if (r < B.n_reads) {
+        const ReadRec rr = B.rr[r];
+        lq = rr.lq; so = rr.so; cix = rr.cix;
+        general = rr.lq > 0 && rr.end > rr.pos && !(rr.info & RR_SIMPLE);
+        if (general) hm = (int)(rr.info & 255) <= P->min_mqual && !(colrec[rr.pos - B.p0] & CR_SKIP);
+    }
+    const int qcap = P->qcap, qhigh = P->qhigh, qlow = P->qlow;
+    const bool reduce = P->reduce_qual != 0, binary = P->binary_qual != 0;
+    unsigned long long todo = __ballot(general);
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int64_t rs = r - lane + src;
+        const int n = READLANE(lq, src), hms = READLANE(hm, src);
+        const unsigned cx = (unsigned)READLANE((int)cix, src);
+        const int64_t s0 = (int64_t)(((uint64_t)(unsigned)READLANE((int)((uint64_t)so >> 32), src) << 32) |
+                                     (unsigned)READLANE((int)(uint64_t)so, src));
+        for (int x = lane; x < n; x += 64) {
+            /* base -> column table of the read (built with the batch): -1 no column, -2 a D/N column
+             * reports this base (k_replay_slow, afterwards) */
+            const int c = B.cix[(size_t)cx + (size_t)x];
+            const uint32_t q0 = B.quals[s0 + x];
+            uint32_t v = q0;
+            if (c >= 0) {
+                const uint32_t rcd = colrec[c];
+                const bool skip = (rcd & CR_SKIP) != 0;
+                const int pres = CR_PRESERVE(rcd), base = B.bases[s0 + x] & 15;
+                const bool match = base == (1 << CR_A1(rcd)) || base == (1 << CR_A2(rcd));
+                const uint32_t capq = q0 > (uint32_t)qcap ? (uint32_t)qcap : q0;
+                const uint32_t qz = match ? (uint32_t)qhigh : (reduce ? (binary ? (uint32_t)P->bin2[q0] : (uint32_t)qlow) : q0);
+                v = (!skip && (rcd & CR_WIN)) ? capq : ((hms || skip || pres) ? q0 : qz);
+                if (!skip && (rcd & CR_KEEP)) keepf[rs] = 1;
+                if (!skip && pres > 1) b15f[rs] = 1;
+            }
+            out[s0 + x] = (uint8_t)(v & 0x7f);
+        }
+    }
+}
+#undef PB4
+#undef PB_GE
+#undef PB_NZ
+
 /* the bases that D/N columns report (host-built list), after k_replay_flat */
 __global__ void k_replay_slow(DBatch B, const DParams *__restrict__ P, const uint32_t *__restrict__ colrec,
                               const int32_t *__restrict__ pos_mn2, const int *__restrict__ n_slow, const int64_t *__restrict__ slow_g,
