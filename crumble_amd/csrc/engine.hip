@@ -578,7 +578,7 @@ extern "C" int crumble_hip_run(crumble_hip *h)
                                  h->d_trigcol_pos.as<int32_t>(), h->d_pos_mn2.as<int32_t>(), h->d_out.as<uint8_t>());
         CRUMBLE_LAUNCH_INDEP(k_readfix, nblk(n, 256), 256, st, B, colrec, h->d_keepf.as<uint8_t>(),
                              h->d_b15f.as<uint8_t>(), h->d_rflags.as<uint8_t>(), h->d_kept.as<int32_t>(), d_overflow + 2);
-        CRUMBLE_LAUNCH_INDEP(k_keepfix, (nblk(n, 4) < 512u ? nblk(n, 4) : 512u), 256, st, B, P, h->d_kept.as<int32_t>(),
+        CRUMBLE_LAUNCH_INDEP(k_keepfix, (nblk(n, 4) < 4096u ? nblk(n, 4) : 4096u), 256, st, B, P, h->d_kept.as<int32_t>(),
                              d_overflow + 2, h->d_out.as<uint8_t>());
         if (h->hparams.pblock) {
             STAGE("k_pblock", 2.0 * nb);

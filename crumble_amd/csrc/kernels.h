@@ -806,11 +806,13 @@ __global__ void k_overdepth(int L, uint32_t *colrec, const int32_t *nplp, const 
     uint32_t rec = colrec[i];
     if (!(rec & CR_COUNTED) || (rec & CR_TOODEEP)) return;
     const int64_t ord = col_ord[i];
-    int lo = 0, hi = *n_ep - 1;                  /* last epoch with ord_start <= ord */
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (ep[mid].ord_start <= ord) lo = mid; else hi = mid - 1;
-    }
+    /* last epoch with ord_start <= ord.  Epochs are ~2^20 columns first and ~2^19 afterwards, so an
+     * arithmetic guess is right or off by one: two probes instead of a dependent binary search */
+    const int nep = *n_ep;
+    int lo = ord < (1 << 20) ? 0 : 1 + (int)((ord - (1 << 20)) >> 19);
+    if (lo > nep - 1) lo = nep - 1;
+    while (lo + 1 < nep && ep[lo + 1].ord_start <= ord) lo++;
+    while (lo > 0 && ep[lo].ord_start > ord) lo--;
     const Epoch e = ep[lo];
     const int n = nplp[i];
     const int64_t total_col = e.tc_start + (ord - e.ord_start + 1);
