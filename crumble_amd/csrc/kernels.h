@@ -399,9 +399,8 @@ __global__ void k_headtail(DBatch B, uint32_t *__restrict__ ht)
 #define KCOL_THREADS 256
 #define KCOL_WAVES 4
 #endif
-/* keeps a wave-uniform rare branch a real (scalar) branch: without it the compiler if-converts the
- * body into selects that every record pays for */
-#define RARE_PATH() asm volatile("")
+/* (an `asm volatile` anywhere in this kernel makes the compiler treat memory as clobbered and turns the
+ * scalar s_load_dwordx8 record loads into vector loads + readfirstlane: do not add one) */
 /* MULTI: the batch has many multi-op reads (long reads): skip a read's other ops cheaply */
 template <int MODE, bool MULTI>
 __global__ void __launch_bounds__(KCOL_THREADS, MODE == 2 ? 3 : KCOL_WAVES)
@@ -531,7 +530,7 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                 const bool cov = cvr[u];
                 const bool isM = ty == SEG_M, isN = ty == SEG_N;               /* uniform */
                 st.n_plp += cov ? 1 : 0;
-                if (mq <= min_mqual) { RARE_PATH(); st.low_mq += cov ? 1 : 0; }   /* snp:1663 (uniform) */
+                if (mq <= min_mqual) st.low_mq += cov ? 1 : 0;                 /* snp:1663 */
                 if (!isM || R[u].indel_after != 0) {                           /* indel bookkeeping: rare ops */
                     const int e_indel = (apos == re - 1) ? R[u].indel_after : 0;
                     const bool isind = (e_indel != 0) || !isM;
@@ -541,7 +540,7 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
                     st.n_isindel += (cov && !isN && isind) ? 1 : 0;
                     st.has_ins |= (cov && !isN && !head && !tail && e_indel > 0) ? 1 : 0;   /* snp:1708 */
                 }
-                if (lq == 0) { RARE_PATH(); n_lq0 += cov ? 1 : 0; }
+                if (lq == 0) n_lq0 += cov ? 1 : 0;
                 if (isN || lq == 0 || !use_cons) continue;                     /* snp:589,594 (uniform) */
                 /* consensus accumulation (snp:594-685).  Each base class is an exec-masked block of
                  * in-place FP64 adds (only the lanes that the record covers with that class take part;
