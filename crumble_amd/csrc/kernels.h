@@ -897,12 +897,15 @@ __global__ void k_emit(DBatch B, const DParams *P, int n_trig, const int32_t *tr
 /* find_STR / add_rep (str_finder.c:34-189) on the 2-bit codes of a read
  * window, and mask_LC_regions (snp:1230-1290).  One thread per trigger.      */
 struct StrWin {
-    const unsigned *w;      /* this lane's packed 2-bit codes in LDS: word k at w[k*64] */
+    const unsigned *w;      /* this lane's window in LDS as two bit planes of the 2-bit codes, 32 positions
+                             * per word: low bits at w[k*64], high bits at w[(STR_PW + k)*64] */
 };
-#define STR_WORDS 32        /* 512 codes >= 2*MASK_WIN+1 */
+#define STR_PW    16        /* words per plane: 512 positions >= 2*MASK_WIN+1 */
+#define STR_WORDS (2 * STR_PW)
 __device__ __forceinline__ int str_code(const StrWin &sw, int i)
 {
-    return (int)((sw.w[(i >> 4) * 64] >> ((i & 15) * 2)) & 3u);
+    const unsigned lo = sw.w[(i >> 5) * 64] >> (i & 31), hi = sw.w[(STR_PW + (i >> 5)) * 64] >> (i & 31);
+    return (int)((lo & 1u) | ((hi & 1u) << 1));
 }
 /* str_finder.c:15-32 via seq_nt16_str: C=1 G=2 T=3, all else (A, N, '=', IUPAC) 0 */
 __device__ __forceinline__ unsigned nt16_to_str2(unsigned c16)
@@ -942,31 +945,63 @@ __device__ __forceinline__ int dev_add_rep(const StrWin &w, int len, int pos, in
     return n;
 }
 
-/* find_STR (str_finder.c:135-189) */
+/* find_STR (str_finder.c:135-189).  From position 15 on, the reference asks at every position i for
+ * the LARGEST period rl in 1..8 whose last rl codes equal the rl codes before them, i.e. whether
+ * D_rl[i-k] = (x[i-k] == x[i-k-rl]) holds for k = 0..rl-1.  That is computed for 32 positions at a
+ * time on the two bit planes (funnel shifts across the word boundary, run-ANDs by doubling); the
+ * positions with a hit are then visited in order, and only those reach add_rep().  The first 15
+ * positions (every period that fits, ascending) keep the reference's rolling word. */
 __device__ __forceinline__ int dev_find_STR(const StrWin &w, int len, short *st, short *en, int *overflow)
 {
     int n = 0, ts = 0, te = -1;
     uint32_t word = 0;
-    for (int i = 0; i < len; i++) {
+    for (int i = 0; i < len && i < 15; i++) {
         word = (word << 2) | (uint32_t)str_code(w, i);
-        if (i < 15) {                                   /* every period that fits */
-            for (int rlen = 1; rlen <= 7; rlen++) {
-                if (i < 2 * rlen - 1) break;
-                const uint32_t mask = (1u << (2 * rlen)) - 1;
-                if ((word & mask) == ((word >> (2 * rlen)) & mask))
-                    n = dev_add_rep(w, len, i, rlen, st, en, n, ts, te, overflow);
-            }
-        } else {                                        /* largest matching period only */
-            int rl = 0;
-            if      ((word & 0xffffu) == ((word >> 16) & 0xffffu)) rl = 8;
-            else if ((word & 0x3fffu) == ((word >> 14) & 0x3fffu)) rl = 7;
-            else if ((word & 0x0fffu) == ((word >> 12) & 0x0fffu)) rl = 6;
-            else if ((word & 0x03ffu) == ((word >> 10) & 0x03ffu)) rl = 5;
-            else if ((word & 0x00ffu) == ((word >>  8) & 0x00ffu)) rl = 4;
-            else if ((word & 0x003fu) == ((word >>  6) & 0x003fu)) rl = 3;
-            else if ((word & 0x000fu) == ((word >>  4) & 0x000fu)) rl = 2;
-            else if ((word & 0x0003u) == ((word >>  2) & 0x0003u)) rl = 1;
-            if (rl) n = dev_add_rep(w, len, i, rl, st, en, n, ts, te, overflow);
+        for (int rlen = 1; rlen <= 7; rlen++) {             /* every period that fits */
+            if (i < 2 * rlen - 1) break;
+            const uint32_t mask = (1u << (2 * rlen)) - 1;
+            if ((word & mask) == ((word >> (2 * rlen)) & mask))
+                n = dev_add_rep(w, len, i, rlen, st, en, n, ts, te, overflow);
+        }
+    }
+    /* D[p-1]: equality with the code p positions back, for the previous word (needed for runs that
+     * cross the word boundary) */
+    uint32_t Dp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t x0p = 0, x1p = 0;                              /* planes of the previous word */
+    const int nw = (len + 31) >> 5;
+    for (int wi = 0; wi < nw; wi++) {
+        const uint32_t x0 = w.w[wi * 64], x1 = w.w[(STR_PW + wi) * 64];
+        uint32_t E[8];
+        #pragma unroll
+        for (int p = 1; p <= 8; p++) {
+            /* codes p positions back, aligned with this word's positions */
+            const uint32_t s0 = (x0 << p) | (x0p >> (32 - p)), s1 = (x1 << p) | (x1p >> (32 - p));
+            const uint32_t D = ~((x0 ^ s0) | (x1 ^ s1)), Dq = Dp[p - 1];
+            /* run of p consecutive ones ending at each position (previous word supplies the carry-in) */
+            uint32_t r = D, rq = Dq;                        /* runs of length 1 */
+            if (p >= 2) { const uint32_t t = r & ((r << 1) | (rq >> 31)), tq = rq & (rq << 1); r = t; rq = tq; }          /* 2 */
+            if (p >= 4) { const uint32_t t = r & ((r << 2) | (rq >> 30)), tq = rq & (rq << 2); r = t; rq = tq; }          /* 4 */
+            if (p == 8) { r = r & ((r << 4) | (rq >> 28)); }                                                             /* 8 */
+            if (p == 3) { r = r & ((D << 2) | (Dq >> 30)); }                                                             /* 2 + 1 */
+            if (p == 5) { r = r & ((D << 4) | (Dq >> 28)); }                                                             /* 4 + 1 */
+            if (p == 6) { const uint32_t d2 = D & ((D << 1) | (Dq >> 31)), d2q = Dq & (Dq << 1);
+                          r = r & ((d2 << 4) | (d2q >> 28)); }                                                           /* 4 + 2 */
+            if (p == 7) { const uint32_t d2 = D & ((D << 1) | (Dq >> 31)), d2q = Dq & (Dq << 1);
+                          r = r & ((d2 << 4) | (d2q >> 28)) & ((D << 6) | (Dq >> 26)); }                                 /* 4 + 2 + 1 */
+            E[p - 1] = r;
+            Dp[p - 1] = D;
+        }
+        x0p = x0; x1p = x1;
+        uint32_t any = E[0] | E[1] | E[2] | E[3] | E[4] | E[5] | E[6] | E[7];
+        if (wi == 0) any &= ~0x7fffu;                       /* positions 0..14 were handled above */
+        if (wi == nw - 1 && (len & 31)) any &= (1u << (len & 31)) - 1u;
+        while (any) {
+            const int b = __builtin_ctz(any);
+            any &= any - 1;
+            const uint32_t bit = 1u << b;
+            const int rl = (E[7] & bit) ? 8 : (E[6] & bit) ? 7 : (E[5] & bit) ? 6 : (E[4] & bit) ? 5
+                         : (E[3] & bit) ? 4 : (E[2] & bit) ? 3 : (E[1] & bit) ? 2 : 1;
+            n = dev_add_rep(w, len, wi * 32 + b, rl, st, en, n, ts, te, overflow);
         }
     }
     return n;
@@ -1014,17 +1049,19 @@ __device__ inline void dev_mask_lc(const DBatch &B, const DParams *P, int r, int
     const int len = end - start + 1;                       /* inclusive (snp:1235,1241) */
     /* index l_qseq is read too: pad nibble, or high nibble of the capped qual[0] */
     const unsigned tail_code = ((lq & 1) || !lq) ? 0u : (unsigned)(cap_q(P, B.quals[so]) >> 4);
-    /* stage the window as packed 2-bit codes in LDS (16 independent byte loads per word) */
-    for (int k = 0; k * 16 < len; k++) {
-        unsigned word = 0;
+    /* stage the window in LDS as two bit planes of the 2-bit codes (C=1 G=2 T=3, else 0), 32 positions
+     * per word */
+    for (int k = 0; k * 32 < len; k++) {
+        unsigned p0 = 0, p1 = 0;
         #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int i = k * 16 + j, qi = start + i;
+        for (int j = 0; j < 32; j++) {
+            const int i = k * 32 + j, qi = start + i;
             unsigned c16 = 0;
             if (i < len) c16 = (qi < lq) ? (unsigned)(bases[qi] & 15) : tail_code;
-            word |= nt16_to_str2(c16) << (2 * j);
+            const unsigned c = nt16_to_str2(c16);
+            p0 |= (c & 1u) << j; p1 |= (c >> 1) << j;
         }
-        lds_lane[k * 64] = word;
+        lds_lane[k * 64] = p0; lds_lane[(STR_PW + k) * 64] = p1;
     }
     StrWin w; w.w = lds_lane;
     const int n = dev_find_STR(w, len, st, en, overflow);

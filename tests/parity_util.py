@@ -2,7 +2,7 @@
 import numpy as np
 
 import crumble_amd as ca
-from crumble_amd import synth
+from crumble_amd import synth, HostBatch
 import oracle_lib as O
 
 _cache = {}
@@ -57,3 +57,31 @@ def cigar_zoo(cases, reps=60, seed=7):
     reads.append(dict(pos=pos, cigar="10M", seq="", qual=np.zeros(0, np.uint8)))
     reads.append(dict(pos=pos, cigar="6M2D", seq="ACGTAC", qual=30))
     return HostBatch.from_reads(reads, bed=[(1010, 1030), (1100, 1101)])
+
+
+def str_stress_batch(n_reads=400, seed=9):
+    """Reads made of tandem repeats, homopolymers, near-repeats and random stretches (lengths 1..700):
+    every branch of find_STR / add_rep (str_finder.c:34-189) gets exercised through the mask_LC seam."""
+    rng = np.random.default_rng(seed)
+    reads, pos = [], 100
+    for i in range(n_reads):
+        L = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 64, 150, 251, 499, 501, 520, 700]))
+        seq = []
+        while len(seq) < L:
+            kind = rng.integers(0, 5)
+            if kind == 0:
+                seq += list(rng.choice(list("ACGT"), int(rng.integers(1, 40))))
+            elif kind == 1:
+                seq += [str(rng.choice(list("ACGTN")))] * int(rng.integers(2, 60))
+            else:
+                unit = list(rng.choice(list("ACGT"), int(rng.integers(1, 10))))
+                rep = unit * int(rng.integers(2, 20))
+                if kind == 3 and len(rep) > 4:                  # imperfect copy
+                    rep[int(rng.integers(0, len(rep)))] = str(rng.choice(list("ACGT")))
+                if kind == 4:                                   # partial last copy
+                    rep = rep[:len(rep) - int(rng.integers(0, len(unit)))]
+                seq += rep
+        seq = "".join(seq[:L])
+        reads.append(dict(pos=pos, cigar=f"{L}M", seq=seq, qual=rng.integers(2, 60, L), mapq=60))
+        pos += int(rng.integers(0, 30))
+    return HostBatch.from_reads(reads)

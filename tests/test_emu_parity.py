@@ -91,3 +91,23 @@ def test_emu_upload_validation(product):
     # an unsorted read that never enters the pileup is fine (FUNMAP mate)
     eng.contig(HostBatch.from_reads([ok[1], dict(pos=3, cigar="*", seq="ACGT", qual=9, flag=4)]))
     eng.close()
+
+
+def test_emu_find_str_stress(product):
+    """mask_LC_regions / find_STR seam on repeat-rich reads of many lengths vs the oracle (whose find_STR is
+    pinned against the real reference str_finder.c)."""
+    import oracle_lib as O
+    from parity_util import str_stress_batch
+    hb = str_stress_batch()
+    p = ca.preset_params(1)
+    eng = emu_lib.engine(p)
+    eng.upload(hb)
+    rng = np.random.default_rng(2)
+    idx = rng.integers(0, hb.n_reads, 1500)
+    lq = (hb.seq_off[idx + 1] - hb.seq_off[idx]).astype(np.int64)
+    qpos1 = np.minimum((rng.random(len(idx)) * (lq + 1)).astype(np.int32) + 1, lq.astype(np.int32))
+    kind = rng.integers(0, 2, len(idx)).astype(np.uint8)
+    lo, hi = eng.mask_lc(idx, qpos1, kind)
+    for i in range(len(idx)):
+        assert O.mask_lc(p, hb, int(idx[i]), int(kind[i]), int(qpos1[i])) == (lo[i], hi[i]), (i, idx[i], qpos1[i])
+    eng.close()

@@ -229,3 +229,21 @@ def test_bench_two_ranks(product, workload):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == ("weak" if workload == "chr20" else "strong")
     assert "roofline" in d and "cpu_baseline" not in d
+
+
+def test_find_str_stress(product):
+    """mask_LC_regions / find_STR seam on repeat-rich reads of many lengths (see tests/test_emu_parity.py)."""
+    from parity_util import str_stress_batch
+    hb = str_stress_batch(n_reads=1500, seed=10)
+    p = ca.preset_params(1)
+    eng = gpu_engine(p)
+    eng.upload(hb)
+    rng = np.random.default_rng(3)
+    idx = rng.integers(0, hb.n_reads, 20000)
+    lq = (hb.seq_off[idx + 1] - hb.seq_off[idx]).astype(np.int64)
+    qpos1 = np.minimum((rng.random(len(idx)) * (lq + 1)).astype(np.int32) + 1, lq.astype(np.int32))
+    kind = rng.integers(0, 2, len(idx)).astype(np.uint8)
+    lo, hi = eng.mask_lc(idx, qpos1, kind)
+    for i in range(len(idx)):
+        assert O.mask_lc(p, hb, int(idx[i]), int(kind[i]), int(qpos1[i])) == (lo[i], hi[i]), (i, idx[i], qpos1[i])
+    eng.close()
