@@ -22,7 +22,7 @@
 #include <sys/mman.h>
 #include "../../include/crumble_bamio.h"
 
-static __thread char g_err[512];
+static char g_err[512];          /* process-wide: the record scan may run on any thread of the team */
 const char *crumble_bam_last_error(void) { return g_err; }
 static int fail(int code, const char *fmt, ...)
 {
@@ -116,6 +116,9 @@ struct crumble_bam_reader {
     int32_t *pos; uint8_t *mapq; uint16_t *flag; int64_t *seq_off, *cig_off;
     uint32_t *cigar; uint8_t *bases, *quals;
     size_t cap_reads, cap_bases, cap_cig;
+    /* record scan (runs beside the inflate team) */
+    int have_tid, group_done, scan_err;
+    int64_t acc_nb, acc_nc;
 };
 
 typedef struct { size_t coff, clen, uoff, ulen; uint32_t crc; } blk_t;
@@ -133,7 +136,10 @@ static int raw_reserve(crumble_bam_reader *r, size_t need)
 }
 
 /* Appends more uncompressed bytes to raw.  Returns 1 if bytes were added, 0 at EOF, < 0 on error. */
-static int refill(crumble_bam_reader *r)
+static void scan_records(crumble_bam_reader *r);
+
+/* `side`: run scan_records() on the bytes that are already there while the team inflates the new chunk */
+static int refill(crumble_bam_reader *r, int side)
 {
     for (;;) {
         if (!r->eof_file) {
@@ -151,7 +157,7 @@ static int refill(crumble_bam_reader *r)
             }
             r->clen += got;
         }
-        if (r->clen == 0) return 0;
+        if (r->clen == 0) { if (side) scan_records(r); return 0; }
         /* delimit whole blocks */
         blk_t *blk = NULL; size_t nb = 0, capb = 0, off = 0, utot = 0;
         while (off + 18 <= r->clen) {
@@ -195,6 +201,12 @@ static int refill(crumble_bam_reader *r)
         {
             z_stream zs; memset(&zs, 0, sizeof zs);            /* one inflate state per thread, reset per block */
             const int zok = inflateInit2(&zs, -15) == Z_OK;
+            if (side) {
+                /* the sequential walk over the records inflated so far costs about as much as one
+                 * round of inflate: one thread does it while the others start on the blocks */
+                #pragma omp single nowait
+                scan_records(r);
+            }
             #pragma omp for schedule(dynamic, 4)
             for (size_t i = 0; i < nb; i++) {
                 if (blk[i].ulen == 0) continue;
@@ -213,6 +225,7 @@ static int refill(crumble_bam_reader *r)
         memmove(r->cbuf, r->cbuf + off, r->clen - off);
         r->clen -= off;
         r->raw_len += utot;
+        side = 0;                                           /* at most once per call */
         if (utot) return 1;
         if (r->eof_file && r->clen == 0) return 0;          /* only empty (EOF marker) blocks */
     }
@@ -222,7 +235,7 @@ static int refill(crumble_bam_reader *r)
 static int need_bytes(crumble_bam_reader *r, size_t need)
 {
     while (r->raw_len - r->scan < need) {
-        const int rc = refill(r);
+        const int rc = refill(r, 0);
         if (rc < 0) return rc;
         if (rc == 0) {
             if (r->raw_len == r->scan) return 0;
@@ -297,6 +310,45 @@ const char *crumble_bam_header_text(const crumble_bam_reader *r, int64_t *len) {
 /* fixed part of a BAM alignment record, offsets from the block_size field */
 enum { F_REFID = 4, F_POS = 8, F_LNAME = 12, F_MAPQ = 13, F_NCIG = 16, F_FLAG = 18, F_LSEQ = 20, F_FIXED = 36 };
 
+/* Walks the complete records in [scan, raw_len): group membership, offsets of the record and of its
+ * bases / CIGAR words in the SoA arrays.  Stops at the first record of another refID (group_done)
+ * or at the first incomplete record.  Errors are left in scan_err / g_err. */
+static void scan_records(crumble_bam_reader *r)
+{
+    const double t0 = now_s();
+    while (!r->group_done && !r->scan_err) {
+        if (r->raw_len - r->scan < 4) break;
+        const uint32_t bs = le32(r->raw + r->scan);
+        if (bs < 32 || bs > (1u << 30)) { r->scan_err = fail(CRUMBLE_BAM_EFORMAT, "implausible BAM record size %u", bs); break; }
+        if (r->raw_len - r->scan < 4 + (size_t)bs) break;
+        const uint8_t *p = r->raw + r->scan;
+        const int32_t tid = (int32_t)le32(p + F_REFID);
+        if (!r->have_tid) { r->tid = tid; r->have_tid = 1; }
+        else if (tid != r->tid) { r->group_done = 1; break; }
+        const uint32_t lname = p[F_LNAME], ncig = le16(p + F_NCIG);
+        const int32_t lseq = (int32_t)le32(p + F_LSEQ);
+        if (lseq < 0 || (size_t)F_FIXED - 4 + lname + 4u * ncig + ((size_t)lseq + 1) / 2 + (size_t)lseq > bs) {
+            r->scan_err = fail(CRUMBLE_BAM_EFORMAT, "BAM record fields exceed block_size"); break;
+        }
+        if (r->n + 1 >= r->cap_n) {
+            const int64_t nc = r->cap_n ? r->cap_n * 2 : (1 << 20);
+            size_t *q = realloc(r->rec_off, (size_t)nc * sizeof *q);
+            int64_t *so = realloc(r->seq_off, (size_t)nc * sizeof *so), *co = realloc(r->cig_off, (size_t)nc * sizeof *co);
+            if (q) r->rec_off = q;
+            if (so) r->seq_off = so;
+            if (co) r->cig_off = co;
+            if (!q || !so || !co) { r->scan_err = fail(CRUMBLE_BAM_ENOMEM, "out of memory"); break; }
+            r->cap_n = nc;
+        }
+        r->rec_off[r->n] = r->scan;
+        r->seq_off[r->n] = r->acc_nb; r->cig_off[r->n] = r->acc_nc;
+        r->acc_nb += lseq; r->acc_nc += ncig;
+        r->n++;
+        r->scan += 4 + (size_t)bs;
+    }
+    T_scan += now_s() - t0;
+}
+
 int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
 {
     /* drop the previous group (or the header) from the window */
@@ -304,53 +356,33 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
         memmove(r->raw, r->raw + r->group_end, r->raw_len - r->group_end);
         r->raw_len -= r->group_end; r->scan -= r->group_end; r->group_end = 0;
     }
-    r->n = 0;
-    int have_tid = 0;
-    const double ts0 = now_s(), tin0 = T_inflate + T_fread;
+    r->n = 0; r->have_tid = 0; r->group_done = 0; r->scan_err = 0; r->acc_nb = r->acc_nc = 0;
     for (;;) {
-        int rc = need_bytes(r, 4);
+        /* inflate the next chunk while one thread walks the records that are already there */
+        const int rc = refill(r, 1);
         if (rc < 0) return rc;
-        if (rc == 0) break;
-        const uint32_t bs = le32(r->raw + r->scan);
-        if (bs < 32 || bs > (1u << 30)) return fail(CRUMBLE_BAM_EFORMAT, "implausible BAM record size %u", bs);
-        if ((rc = need_bytes(r, 4 + (size_t)bs)) <= 0) return rc ? rc : fail(CRUMBLE_BAM_EFORMAT, "truncated BAM record");
-        const uint8_t *p = r->raw + r->scan;
-        const int32_t tid = (int32_t)le32(p + F_REFID);
-        if (!have_tid) { r->tid = tid; have_tid = 1; }
-        else if (tid != r->tid) break;
-        const uint32_t lname = p[F_LNAME], ncig = le16(p + F_NCIG);
-        const int32_t lseq = (int32_t)le32(p + F_LSEQ);
-        if (lseq < 0 || (size_t)F_FIXED - 4 + lname + 4u * ncig + ((size_t)lseq + 1) / 2 + (size_t)lseq > bs)
-            return fail(CRUMBLE_BAM_EFORMAT, "BAM record fields exceed block_size");
-        if (r->n == r->cap_n) {
-            const int64_t nc = r->cap_n ? r->cap_n * 2 : (1 << 20);
-            size_t *q = realloc(r->rec_off, (size_t)nc * sizeof *q);
-            if (!q) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
-            r->rec_off = q; r->cap_n = nc;
+        if (r->scan_err) return r->scan_err;
+        if (r->group_done) break;
+        if (rc == 0) {                                      /* end of file: everything left has been walked */
+            scan_records(r);                                /* (bytes of the last round, if any) */
+            if (r->scan_err) return r->scan_err;
+            if (!r->group_done && r->raw_len != r->scan) return fail(CRUMBLE_BAM_EFORMAT, "truncated BAM record at end of file");
+            break;
         }
-        r->rec_off[r->n++] = r->scan;
-        r->scan += 4 + (size_t)bs;
     }
     r->group_end = r->scan;
-    T_scan += (now_s() - ts0) - (T_inflate + T_fread - tin0);
     if (r->n == 0) return 0;
     const double tp0 = now_s();
 
     const int64_t n = r->n;
     if (r->cap_reads < (size_t)n + 1) {
         const size_t c = (size_t)n + (size_t)n / 4 + 64;
-        free(r->pos); free(r->mapq); free(r->flag); free(r->seq_off); free(r->cig_off);
+        free(r->pos); free(r->mapq); free(r->flag);
         r->pos = malloc(c * sizeof *r->pos); r->mapq = malloc(c); r->flag = malloc(c * sizeof *r->flag);
-        r->seq_off = malloc(c * sizeof *r->seq_off); r->cig_off = malloc(c * sizeof *r->cig_off);
-        r->cap_reads = (r->pos && r->mapq && r->flag && r->seq_off && r->cig_off) ? c : 0;
+        r->cap_reads = (r->pos && r->mapq && r->flag) ? c : 0;
         if (!r->cap_reads) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
     }
-    int64_t nb = 0, nc = 0;
-    for (int64_t i = 0; i < n; i++) {
-        const uint8_t *p = r->raw + r->rec_off[i];
-        r->seq_off[i] = nb; r->cig_off[i] = nc;
-        nb += (int32_t)le32(p + F_LSEQ); nc += le16(p + F_NCIG);
-    }
+    const int64_t nb = r->acc_nb, nc = r->acc_nc;
     r->seq_off[n] = nb; r->cig_off[n] = nc;
     if (r->cap_bases < (size_t)nb + 16) {
         const size_t c = ((size_t)nb + (size_t)nb / 8 + ((size_t)2 << 20)) & ~(((size_t)2 << 20) - 1);
