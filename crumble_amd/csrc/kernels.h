@@ -1638,7 +1638,7 @@ __global__ void k_replay_general(DBatch B, const DParams *__restrict__ P, const 
  * the entry's own qpos (the entry's own byte is handled by apply_col). */
 __global__ void __launch_bounds__(64)
 k_restore(DBatch B, const DParams *__restrict__ P, int n_trig, const int32_t *trigcol_pos,
-          const int32_t *__restrict__ pos_mn2, uint8_t *__restrict__ out)
+          const int32_t *__restrict__ pos_mn2, uint8_t *__restrict__ out, int coop)
 {
     /* one wave per trigger column.  Step 1: every lane resolves one candidate read (entry, start of
      * the back-fill in query coordinates).  Step 2: the wave writes the ranges one read at a time,
@@ -1669,6 +1669,12 @@ k_restore(DBatch B, const DParams *__restrict__ P, int n_trig, const int32_t *tr
                     so_lo = (unsigned)(uint64_t)so; so_hi = (unsigned)((uint64_t)so >> 32);
                 }
             }
+        }
+        if (!coop) {                                       /* long reads: few candidates per column, a lane each */
+            const int64_t so = (int64_t)(((uint64_t)so_hi << 32) | so_lo);
+            for (int x = start; x < stop; x++)
+                out[so + x] = cap_q2(P, qcap, any_pres, B.quals[so + x]) & 0x7f;
+            continue;
         }
         unsigned long long todo = __ballot(start < stop);
         while (todo) {
@@ -1846,7 +1852,7 @@ __global__ void k_pblock(int64_t n_reads, const int64_t *seq_off, uint8_t *out,
 
 __global__ void __launch_bounds__(256)
 k_pb_marks(int64_t n_bases, const uint8_t *__restrict__ q, const DParams *__restrict__ P,
-           u64 *__restrict__ stop, u64 *__restrict__ rstart, u64 *__restrict__ runs)
+           u64 *__restrict__ stop, u64 *__restrict__ rstart, u64 *__restrict__ runs, uint16_t *__restrict__ wmm)
 {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t g0 = w * 64;
@@ -1857,6 +1863,7 @@ k_pb_marks(int64_t n_bases, const uint8_t *__restrict__ q, const DParams *__rest
     int prev = g0 > 0 ? (int)q[g0 - 1] : -1000;
     bool prev_pres = g0 > 0 && any_pres && P->preserve_qual[prev];
     u64 m = 0;
+    int wmin = 255, wmax = 0;                            /* of the word's bytes: lets a long segment step 64 bases at once */
     for (int k0 = 0; k0 < nn; k0 += 16) {
         uint32_t wd[4] = {0, 0, 0, 0};
         if (k0 + 16 <= nn) { const uint4 v = *(const uint4 *)(q + g0 + k0); wd[0] = v.x; wd[1] = v.y; wd[2] = v.z; wd[3] = v.w; }
@@ -1867,10 +1874,12 @@ k_pb_marks(int64_t n_bases, const uint8_t *__restrict__ q, const DParams *__rest
             const bool pres = any_pres && P->preserve_qual[v];
             int d = v - prev; d = d < 0 ? -d : d;
             if (k0 + k < nn && (pres || prev_pres || d > level2)) m |= 1ull << (k0 + k);
+            if (k0 + k < nn) { wmin = v < wmin ? v : wmin; wmax = v > wmax ? v : wmax; }
             prev = v; prev_pres = pres;
         }
     }
     stop[w] = m;
+    wmm[w] = (uint16_t)(wmin | (wmax << 8));
     rstart[w] = 0;
     runs[w] = 0;
 }
@@ -1890,7 +1899,7 @@ __global__ void __launch_bounds__(256)
 k_pb_segments(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_off, const uint8_t *__restrict__ out,
               const uint8_t *__restrict__ rflags, const int32_t *__restrict__ blk_read,
               const u64 *__restrict__ stop, const u64 *__restrict__ rstart, u64 *__restrict__ runs,
-              uint8_t *__restrict__ runval, const DParams *__restrict__ P)
+              uint8_t *__restrict__ runval, const uint16_t *__restrict__ wmm, const DParams *__restrict__ P)
 {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nwords = (n_bases + 63) >> 6;
@@ -1927,6 +1936,16 @@ k_pb_segments(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_
             else { const int bb = __builtin_ctzll(rest); e = ww * 64 + bb; at_read_end = (rstart[ww] >> bb) & 1; }
             open = true;
         } else if (i < e) {
+            if (!(i & 63) && i + 64 <= e) {                     /* a whole 64-base word lies inside the segment */
+                const unsigned mm = wmm[i >> 6];
+                const int cmin = (int)(mm & 255), cmax = (int)(mm >> 8);
+                const int nmin = cmin < qmin ? cmin : qmin, nmax = cmax > qmax ? cmax : qmax;
+                if (nmax - nmin <= level2) {
+                    qmin = last_qmin = nmin; qmax = last_qmax = nmax;
+                    i += 64;
+                    continue;
+                }
+            }
             const int64_t base = i & ~(int64_t)15;
             const uint4 v = *(const uint4 *)(out + base);       /* the buffer has >= 16 bytes of slack */
             const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
