@@ -1053,13 +1053,35 @@ __device__ inline void dev_mask_lc(const DBatch &B, const DParams *P, int r, int
      * per word */
     for (int k = 0; k * 32 < len; k++) {
         unsigned p0 = 0, p1 = 0;
-        #pragma unroll
-        for (int j = 0; j < 32; j++) {
-            const int i = k * 32 + j, qi = start + i;
-            unsigned c16 = 0;
-            if (i < len) c16 = (qi < lq) ? (unsigned)(bases[qi] & 15) : tail_code;
-            const unsigned c = nt16_to_str2(c16);
-            p0 |= (c & 1u) << j; p1 |= (c >> 1) << j;
+        if (k * 32 + 32 <= len && start + k * 32 + 32 <= lq) {
+            /* all 32 codes are bases of the read: eight dwords (+1 for the byte offset), four bases at
+             * a time with packed byte compares against C, G, T */
+            const uint8_t *bp = bases + start + k * 32;
+            const unsigned sh = (unsigned)((uintptr_t)bp & 3u), s8 = sh * 8u;
+            const uint32_t *bw = (const uint32_t *)(bp - sh);
+            uint32_t prev = bw[0];
+            #pragma unroll
+            for (int d = 0; d < 8; d++) {
+                const uint32_t next = (d < 7 || sh) ? bw[d + 1] : 0u;
+                const uint32_t c = (sh ? (prev >> s8) | (next << (32u - s8)) : prev) & 0x0f0f0f0fu;
+                prev = next;
+                #define STR_NZ(x) ((((x) + 0x7f7f7f7fu) & 0x80808080u) >> 7)          /* 1 in bytes that are != 0 */
+                const uint32_t nC = STR_NZ(c ^ 0x02020202u), nG = STR_NZ(c ^ 0x04040404u), nT = STR_NZ(c ^ 0x08080808u);
+                #undef STR_NZ
+                const uint32_t b0 = ~(nC & nT) & 0x01010101u;                        /* C or T: low bit of the code  */
+                const uint32_t b1 = ~(nG & nT) & 0x01010101u;                        /* G or T: high bit of the code */
+                p0 |= ((b0 * 0x01020408u) >> 24) << (4 * d);
+                p1 |= ((b1 * 0x01020408u) >> 24) << (4 * d);
+            }
+        } else {
+            #pragma unroll
+            for (int j = 0; j < 32; j++) {
+                const int i = k * 32 + j, qi = start + i;
+                unsigned c16 = 0;
+                if (i < len) c16 = (qi < lq) ? (unsigned)(bases[qi] & 15) : tail_code;
+                const unsigned c = nt16_to_str2(c16);
+                p0 |= (c & 1u) << j; p1 |= (c >> 1) << j;
+            }
         }
         lds_lane[k * 64] = p0; lds_lane[(STR_PW + k) * 64] = p1;
     }
