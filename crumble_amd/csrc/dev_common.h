@@ -107,6 +107,8 @@ struct DBatch {
     const int32_t *cix;     /* per base of every non-simple read: column (pos-p0), -1 none, -2 general routine */
     const SegRec *sr;
     const int32_t *stile_lo, *stile_hi;   /* candidate SegRec range per 64-column tile */
+    const int32_t *unit_first;            /* [n_units+1] first tile of every KCOL_UNIT-sized slice of the tiles' cost prefix */
+    int32_t n_units, pad1_;
     const uint8_t *bases, *quals;
     const int32_t *tile_lo, *tile_hi;
     const int32_t *bed_start, *bed_end, *bed_pmax;
@@ -159,6 +161,7 @@ struct Epoch {              /* running-average state of snp:1490-1491,1684   */
 #define MAX_EPOCHS 8192
 
 #define MAX_DEPTH_COL 20000     /* MAX_DEPTH snp:92   */
+#define KCOL_UNIT     256       /* estimated cost (~candidate records) handed to a wave per grab of k_columns' work counter */
 #define MASK_WIN_DEV  250       /* MASK_WIN  snp:1229 */
 #define STR_CAP       640       /* live repeats per window   */
 

@@ -56,7 +56,7 @@ struct crumble_hip {
     DParams hparams;
     DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc;
     /* batch (inputs) */
-    DevBuf d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
+    DevBuf d_ufirst, d_tcum, d_tpart, d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
            d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax;
     /* per position */
     DevBuf d_colrec, d_nplp, d_score, d_trigcnt, d_dpre, d_col_ord, d_trig_ord, d_item_off,
@@ -218,7 +218,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     DevBuf *all[] = { &h->d_params, &h->d_tables, &h->d_stats, &h->d_batch_stats, &h->d_misc,
-        &h->d_pbwmm, &h->d_act, &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
+        &h->d_ufirst, &h->d_tcum, &h->d_tpart, &h->d_pbwmm, &h->d_act, &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
         &h->d_slow_g, &h->d_slow_r, &h->d_cix, &h->d_sr, &h->d_stile_lo, &h->d_stile_hi, &h->d_rr, &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
         &h->d_cigar, &h->d_segs, &h->d_bases, &h->d_quals, &h->d_tile_lo, &h->d_tile_hi,
         &h->d_bed_start, &h->d_bed_end, &h->d_bed_pmax, &h->d_colrec, &h->d_nplp, &h->d_score,
@@ -372,6 +372,23 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
             CRUMBLE_LAUNCH_INDEP(k_p0_tiles, nblk(B.n_tiles, 256), 256, st, B.n_tiles, B.p0, (int64_t)ns, h->d_sr_ppos.as<int32_t>(),
                                  h->d_sr_pend.as<int32_t>(), h->d_stile_lo.as<int32_t>(), h->d_stile_hi.as<int32_t>());
         }
+        if (B.n_tiles > 0) {                                /* cost prefix of the tiles: k_columns' work split */
+            const int tch = (int)((B.n_tiles + P0_CHUNK - 1) / P0_CHUNK);
+            if ((e = h->d_tcum.reserve((size_t)(B.n_tiles + 2) * 8)) || (e = h->d_tpart.reserve((size_t)(tch + 2) * 8))) return e;
+            int64_t *cum = h->d_tcum.as<int64_t>(), *tp = h->d_tpart.as<int64_t>();
+            CRUMBLE_LAUNCH_INDEP(k_tile_cost, nblk(B.n_tiles, 256), 256, st, B.n_tiles, h->d_stile_lo.as<int32_t>(),
+                                 h->d_stile_hi.as<int32_t>(), (tot.nseg > n + n / 2) ? 1 : 0, cum);
+            CRUMBLE_LAUNCH_INDEP(k_i64scan_reduce, nblk(tch, 64), 64, st, (int64_t)B.n_tiles, cum, tp, tch);
+            CRUMBLE_LAUNCH_INDEP(k_i64scan_partials, 1, 1, st, tp, tch);
+            CRUMBLE_LAUNCH_INDEP(k_i64scan_apply, nblk(tch, 64), 64, st, (int64_t)B.n_tiles, cum, tp, tch);
+            int64_t total = 0;                              /* (one small read-back: sizes the unit table) */
+            HIPCHK(hipMemcpyAsync(&total, cum + B.n_tiles, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (total >= (int64_t)INT_MAX * (KCOL_UNIT / 2)) { g_last_error = "tile cost overflow"; return CRUMBLE_EINVAL; }
+            B.n_units = (int32_t)((total + KCOL_UNIT - 1) / KCOL_UNIT);
+            if ((e = h->d_ufirst.reserve((size_t)(B.n_units + 2) * 4))) return e;
+            CRUMBLE_LAUNCH_INDEP(k_unit_first, nblk(B.n_units + 1, 256), 256, st, B.n_units, B.n_tiles, cum, h->d_ufirst.as<int32_t>());
+        }
         if (nb > 0)
             CRUMBLE_LAUNCH_INDEP(k_p0_blkread, nblk((int64_t)nblkb, 256), 256, st, (int64_t)((nb + 63) / 64), n,
                                  h->d_seq_off.as<int64_t>(), h->d_blk_read.as<int32_t>());
@@ -382,6 +399,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     B.seg_off = h->d_seg_off.as<int64_t>(); B.cigar = h->d_cigar.as<uint32_t>();
     B.segs = h->d_segs.as<Seg>(); B.rr = h->d_rr.as<ReadRec>(); B.cix = h->d_cix.as<int32_t>();
     B.sr = h->d_sr.as<SegRec>(); B.stile_lo = h->d_stile_lo.as<int32_t>(); B.stile_hi = h->d_stile_hi.as<int32_t>();
+    B.unit_first = h->d_ufirst.as<int32_t>();
     B.bases = h->d_bases.as<uint8_t>(); B.quals = h->d_quals.as<uint8_t>();
     B.tile_lo = h->d_tile_lo.as<int32_t>(); B.tile_hi = h->d_tile_hi.as<int32_t>();
     B.bed_start = h->d_bed_start.as<int32_t>(); B.bed_end = h->d_bed_end.as<int32_t>();
@@ -461,7 +479,7 @@ extern "C" int crumble_hip_run(crumble_hip *h)
     h->n_stages = 0; h->have_run = false;
     memset(&h->totals, 0, sizeof(h->totals));
     HIPCHK(hipMemsetAsync(stats, 0, CRUMBLE_ST_N * 8, st));
-    HIPCHK(hipMemsetAsync(d_overflow, 0, 16, st));      /* [0] overflow, [1] n_epochs, [2] n_kept; [8..11] belong to upload */
+    HIPCHK(hipMemsetAsync(d_overflow, 0, 16, st));      /* [0] overflow, [1] n_epochs, [2] n_kept, [3] k_columns work counter; [8..11] belong to upload */
 
     if (L > 0) {
         STAGE("k_headtail", 0);
@@ -476,8 +494,8 @@ extern "C" int crumble_hip_run(crumble_hip *h)
         if (grid > pgrid) grid = pgrid;                 /* persistent: grid-stride over tiles */
         const bool modeA = h->hparams.min_qual_A != 0;
         const bool multi = h->n_segrec > h->n_reads + h->n_reads / 2;     /* long reads: many ops per read */
-#define KCOL_LAUNCH(M) do { if (multi) CRUMBLE_LAUNCH((k_columns<M, true>), grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, ht, stats); \
-                            else       CRUMBLE_LAUNCH((k_columns<M, false>), grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, ht, stats); } while (0)
+#define KCOL_LAUNCH(M) do { if (multi) CRUMBLE_LAUNCH((k_columns<M, true>), grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, ht, stats, (unsigned *)(d_overflow + 3)); \
+                            else       CRUMBLE_LAUNCH((k_columns<M, false>), grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, ht, stats, (unsigned *)(d_overflow + 3)); } while (0)
         if (modeA && modeB) KCOL_LAUNCH(2);
         else if (modeB)     KCOL_LAUNCH(1);
         else                KCOL_LAUNCH(0);

@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(KCOL_THREADS, MODE == 2 ? 3 : KCOL_WAVES)
 k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T,
           uint32_t *__restrict__ colrec, int32_t *__restrict__ nplp_out,
           int32_t *__restrict__ score_out, int32_t *__restrict__ trigcnt, const uint32_t *__restrict__ ht,
-          u64 *stats)
+          u64 *stats, unsigned *__restrict__ tile_ctr)
 {
     __shared__ double sTab[101 * 4];                       /* [aq] -> {MM, _M, 1 - q2p, -} : one 32-byte LDS row */
     constexpr bool MQ = MODE != 0;                          /* the active consensus uses CONS_MQUAL */
@@ -448,7 +448,24 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
     const bool use_cons = MODE == 0 ? (P->min_qual_A != 0) : (P->min_qual_B != 0);
     const int qcap = P->qcap, min_mqual = P->min_mqual, any_pres = P->any_preserve;
 
-    for (int tile = UNIFORM(wave0); tile < B.n_tiles; tile += nwaves) {
+    /* Work split.  The tiles' estimated costs (candidate records + a constant, prefix-summed with the
+     * batch) are cut into units of KCOL_UNIT; a wave takes the next unit from one counter and does the
+     * tiles that start in it: ~5 tiles of a 30x genome, one tile of a 300x target, a whole stretch of
+     * empty tiles between targets, and a 6000x spike tile alone.  Dynamic, because waves do not run
+     * at equal speed (clock, memory channel, neighbours on the CU) -- a fixed split, however well
+     * balanced on paper, left 15 % -- and in order, so that concurrently running waves share reads
+     * through L2.  One atomic per ~KCOL_UNIT record-iterations keeps the counter cool. */
+    (void)wave0; (void)nwaves;
+    for (;;) {
+    int t_begin, t_end;
+    {
+        int g = 0;
+        if (lane == 0) g = (int)atomicAdd(tile_ctr, 1u);
+        g = READLANE(g, 0);
+        if (g >= B.n_units) break;
+        t_begin = UNIFORM(B.unit_first[g]); t_end = UNIFORM(B.unit_first[g + 1]);
+    }
+    for (int tile = t_begin; tile < t_end; tile++) {
         const int c = tile * 64 + lane;
         const int apos = B.p0 + c;
         const bool inr = c < B.L;
@@ -612,6 +629,7 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
             st.n_overlap = st.n_plp - st.nref - (int)(h & 0xffff);
         }
         if (inr) col_decide<MODE>(st, B, P, T, c, apos, use_cons, colrec, nplp_out, score_out, trigcnt, sStat);
+    }
     }
     __syncthreads();
     if (threadIdx.x < 32 && sStat[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (u64)sStat[threadIdx.x]);

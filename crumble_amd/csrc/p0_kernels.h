@@ -265,4 +265,53 @@ __global__ void k_p0_blkread(int64_t nblocks, int64_t n, const int64_t *__restri
     blk_read[b] = (int32_t)(lo < n ? lo : n - 1);
 }
 
+/* Work split of k_columns: an estimated cost per 64-column tile (its candidate records plus a constant
+ * for the per-tile prologue/epilogue), prefix-summed, so that every wave can take a CONTIGUOUS run of
+ * tiles of equal total cost -- no atomics, adjacent tiles (which share their reads) stay in one wave. */
+__global__ void k_tile_cost(int n_tiles, const int32_t *__restrict__ slo, const int32_t *__restrict__ shi,
+                            int multi, int64_t *__restrict__ cost)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const int w = shi[t] - slo[t];
+    cost[t] = multi ? (w >> 2) + 4 : w + 2;      /* long reads: most candidates are screened out 64 at a time */
+}
+__global__ void k_i64scan_reduce(int64_t n, const int64_t *__restrict__ v, int64_t *__restrict__ partial, int nchunks)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    int64_t acc = 0;
+    const int64_t b = (int64_t)t * P0_CHUNK, e = b + P0_CHUNK < n ? b + P0_CHUNK : n;
+    for (int64_t i = b; i < e; i++) acc += v[i];
+    partial[t] = acc;
+}
+__global__ void k_i64scan_partials(int64_t *partial, int nchunks)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    int64_t run = 0;
+    for (int i = 0; i < nchunks; i++) { const int64_t v = partial[i]; partial[i] = run; run += v; }
+    partial[nchunks] = run;
+}
+/* exclusive scan in place; v[n] receives the total */
+__global__ void k_i64scan_apply(int64_t n, int64_t *__restrict__ v, const int64_t *__restrict__ partial, int nchunks)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    int64_t run = partial[t];
+    const int64_t b = (int64_t)t * P0_CHUNK, e = b + P0_CHUNK < n ? b + P0_CHUNK : n;
+    for (int64_t i = b; i < e; i++) { const int64_t x = v[i]; v[i] = run; run += x; }
+    if (t == nchunks - 1) v[n] = run;
+}
+
+/* unit g of the cost prefix starts at tile unit_first[g] = first t with cum[t] >= g*KCOL_UNIT */
+__global__ void k_unit_first(int n_units, int n_tiles, const int64_t *__restrict__ cum, int32_t *__restrict__ unit_first)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > n_units) return;
+    const int64_t c = (int64_t)g * KCOL_UNIT;
+    int lo = 0, hi = n_tiles;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (cum[mid] < c) lo = mid + 1; else hi = mid; }
+    unit_first[g] = g == n_units ? n_tiles : lo;
+}
+
 #endif
