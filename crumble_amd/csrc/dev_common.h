@@ -161,7 +161,9 @@ struct Epoch {              /* running-average state of snp:1490-1491,1684   */
 #define MAX_EPOCHS 8192
 
 #define MAX_DEPTH_COL 20000     /* MAX_DEPTH snp:92   */
+#ifndef KCOL_UNIT
 #define KCOL_UNIT     256       /* estimated cost (~candidate records) handed to a wave per grab of k_columns' work counter */
+#endif
 #define MASK_WIN_DEV  250       /* MASK_WIN  snp:1229 */
 #define STR_CAP       640       /* live repeats per window   */
 
