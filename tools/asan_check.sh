@@ -1,0 +1,35 @@
+#!/bin/bash
+# CPU only: AddressSanitizer + UBSan over the whole host path AND the kernels' literal sources (compiled
+# for the CPU through tests/emu/hip_emu.h), driven by the file -> file program on a small multi-contig BAM.
+# (GPU ASan is not available on the pool; this is the sanitizer coverage the kernels get.)
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+W=${1:-/tmp/crumble_asan}; mkdir -p $W; cd $W
+SRC=$R/crumble_amd/csrc; EMU=$R/tests/emu
+FL="-fsanitize=address,undefined -fno-omit-frame-pointer -g -O1"
+gcc $FL -fPIC -c $SRC/params.c -o params.o
+gcc $FL -fPIC -fopenmp -c $SRC/synth.c -o synth.o
+gcc $FL -fPIC -fopenmp -c $SRC/bamio.c -o bamio.o
+g++ $FL -std=c++17 -fPIC -ffp-contract=off -DCRUMBLE_EMU -include $EMU/hip_emu.h -Wno-unknown-pragmas -x c++ -c $SRC/engine.hip -o engine.o
+g++ $FL -std=c++17 -fPIC -c $EMU/hip_emu.cpp -o hip_emu.o
+gcc $FL -c $SRC/cli.c -o cli.o
+g++ $FL -o crumble-hip-asan cli.o engine.o hip_emu.o params.o synth.o bamio.o -lz -lgomp -lpthread -lm
+python3 - <<PY
+import sys; sys.path.insert(0, "$R")
+import numpy as np
+from crumble_amd import synth, bamio, HostBatch
+b0 = synth.generate(synth.config("ce", scale=0.5))
+b1 = synth.generate(synth.config("hifi", scale=0.0002, read_len=3000, tid=1))
+b2 = synth.generate(synth.config("panel", scale=0.0008, tid=2))
+rng = np.random.default_rng(3); n, L = 30, 100
+un = HostBatch(-1, np.full(n, -1), np.zeros(n), np.full(n, 4), np.arange(n + 1) * L, np.zeros(n + 1), np.zeros(0, np.uint32),
+               rng.choice([1, 2, 4, 8, 15], n * L), rng.integers(2, 42, n * L))
+bamio.write_batches("in.bam", [("a", 60000), ("b", 300000), ("c", 30000)], [b0, b1, b2, un])
+open("k.bed", "w").write("a\t1000\t3000\nb\t500\t9000\n")
+PY
+export ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1
+for args in "-5" "-9 -R k.bed -b s.bed" "-1 -S -k 30-35" "-9 -y pbccs -T XS" "-3 -B -P 1.2 -C 0.01"; do
+  ./crumble-hip-asan $args in.bam out.bam > run.log 2>&1 || { echo "FAILED: $args"; tail -20 run.log; exit 1; }
+  if grep -q "runtime error\|AddressSanitizer" run.log; then echo "SANITIZER REPORT: $args"; grep -m5 "runtime error\|AddressSanitizer" run.log; exit 1; fi
+  echo "clean: $args"
+done
