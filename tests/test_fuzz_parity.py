@@ -25,3 +25,53 @@ def test_fuzz_gpu(product, block):
             assert_parity(lambda q: ca.Engine(q, 0), p, hb)
         except AssertionError as e:
             raise AssertionError(f"{desc}: {e}") from e
+
+
+def tiny_reads_batch(seed, n=600):
+    """Reads of 0..40 bases (several per 16-byte chunk of the flat base array), with clips, indels, skips,
+    unmapped and zero-length records in between: the chunk / segment / per-read code paths at their seams."""
+    import numpy as np
+    from crumble_amd import HostBatch
+    rng = np.random.default_rng(seed)
+    reads, pos = [], 50
+    for i in range(n):
+        L = int(rng.choice([0, 1, 2, 3, 7, 15, 16, 17, 31, 32, 33, 40]))
+        kind = rng.integers(0, 8)
+        seq = "".join(rng.choice(list("ACGTN"), L, p=[.24, .24, .24, .24, .04]))
+        qual = rng.integers(2, 60, L)
+        flag, cigar = 0, f"{L}M"
+        if L == 0:
+            cigar = "*" if kind < 4 else "3D"
+        elif kind == 0 and L > 6:
+            a = int(rng.integers(1, L - 4)); cigar = f"{a}S{L - a}M"
+        elif kind == 1 and L > 6:
+            a = int(rng.integers(1, L - 4)); cigar = f"{L - a}M{a}S"
+        elif kind == 2 and L > 8:
+            a = int(rng.integers(2, L - 4)); cigar = f"{a}M2D{L - a}M"
+        elif kind == 3 and L > 8:
+            a = int(rng.integers(2, L - 5)); cigar = f"{a}M2I{L - a - 2}M"
+        elif kind == 4 and L > 8:
+            a = int(rng.integers(2, L - 4)); cigar = f"{a}M5N{L - a}M"
+        elif kind == 5:
+            flag, cigar = 4, "*"
+        reads.append(dict(pos=pos, cigar=cigar, seq=seq, qual=qual, mapq=int(rng.choice([0, 3, 20, 60])), flag=flag))
+        pos += int(rng.integers(0, 4))
+    return HostBatch.from_reads(reads)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_tiny_reads_emulated(product, seed):
+    import emu_lib
+    hb = tiny_reads_batch(seed)
+    for p in (ca.preset_params(9), ca.preset_params(1, min_mqual=3), ca.preset_params(5, pblock=2, keep="30"),
+              ca.preset_params(9, softclip=1, binary_qual=1)):
+        assert_parity(emu_lib.engine, p, hb)
+
+
+@pytest.mark.gpu
+def test_tiny_reads_gpu(product):
+    for seed in range(10, 30):
+        hb = tiny_reads_batch(seed, n=3000)
+        for p in (ca.preset_params(9), ca.preset_params(1, min_mqual=3), ca.preset_params(5, pblock=2, keep="30"),
+                  ca.preset_params(9, softclip=1, binary_qual=1)):
+            assert_parity(lambda q: ca.Engine(q, 0), p, hb)
