@@ -1538,62 +1538,91 @@ k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
     int64_t r = blk_read[g0 >> 6];
     ReadRec rr = B.rr[r];
     while (g0 >= rr.so + rr.lq) { r++; rr = B.rr[r]; }
+    /* The chunk's bytes belong to one read, or -- at a read boundary, i.e. in some lane of nearly every
+     * wave -- to two: up to two reads are gathered into slots and done in ONE pass of the packed body
+     * (per-byte merge of their action bytes); only chunks that touch more than two single-match reads
+     * (reads shorter than a chunk) go round again. */
     for (;;) {
-        if ((rr.info & RR_SIMPLE) && rr.end > rr.pos) {
-            /* bytes of this chunk that are aligned bases of this read */
-            const int64_t a0 = rr.so + rr.q0, a1 = a0 + (rr.end - rr.pos);
-            const int lo = (a0 > g0) ? (int)(a0 - g0) : 0, hi = (a1 < gend) ? (int)(a1 - g0) : (int)(gend - g0);
-            if (lo < hi) {
-                const unsigned vb = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-                const int c0 = rr.pos + (int)(g0 - a0) - B.p0;     /* column of byte 0 (may be < 0: padded) */
-                uint32_t hm = 0;                                   /* low-mapq read whose head column is live: snp:1852 */
-                if ((int)(rr.info & 255) <= min_mqual && !(colrec[rr.pos - B.p0] & CR_SKIP)) hm = 0xffffffffu;
-                uint32_t a[4];
-                {   /* 16 action bytes from an arbitrary byte address: aligned dwords + byte funnel */
-                    const uint8_t *ap = act + c0;
-                    const unsigned sh = (unsigned)((uintptr_t)ap & 3u);
-                    const uint32_t *aw = (const uint32_t *)(ap - sh);
-                    const uint32_t w0 = aw[0], w1 = aw[1], w2 = aw[2], w3 = aw[3], w4 = aw[4];
-                    const unsigned s8 = sh * 8u;
-                    a[0] = sh ? (w0 >> s8) | (w1 << (32u - s8)) : w0;
-                    a[1] = sh ? (w1 >> s8) | (w2 << (32u - s8)) : w1;
-                    a[2] = sh ? (w2 >> s8) | (w3 << (32u - s8)) : w2;
-                    a[3] = sh ? (w3 >> s8) | (w4 << (32u - s8)) : w3;
+        unsigned vb[2] = {0, 0};
+        int c0s[2] = {0, 0};
+        uint32_t hms[2] = {0, 0};
+        int64_t rid[2] = {r, r};
+        int ns = 0;
+        bool more = false;
+        for (;;) {
+            if ((rr.info & RR_SIMPLE) && rr.end > rr.pos) {
+                /* bytes of this chunk that are aligned bases of this read */
+                const int64_t a0 = rr.so + rr.q0, a1 = a0 + (rr.end - rr.pos);
+                const int lo = (a0 > g0) ? (int)(a0 - g0) : 0, hi = (a1 < gend) ? (int)(a1 - g0) : (int)(gend - g0);
+                if (lo < hi) {
+                    if (ns == 2) { more = true; break; }           /* a third read: next round */
+                    const unsigned m = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+                    const int c0 = rr.pos + (int)(g0 - a0) - B.p0; /* column of byte 0 (may be < 0: padded) */
+                    uint32_t hm = 0;                               /* low-mapq read whose head column is live: snp:1852 */
+                    if ((int)(rr.info & 255) <= min_mqual && !(colrec[rr.pos - B.p0] & CR_SKIP)) hm = 0xffffffffu;
+                    if (ns == 0) { vb[0] = m; c0s[0] = c0; hms[0] = hm; rid[0] = r; }
+                    else         { vb[1] = m; c0s[1] = c0; hms[1] = hm; rid[1] = r; }
+                    ns++;
                 }
-                uint32_t se = 0;
-                #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t q = qw[k], b = bw[k], ac = a[k];
-                    const uint32_t V = ((((vb >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;   /* this read's bytes */
-                    const uint32_t geq = PB_GE(q, QC);
-                    const uint32_t capq = (QC & geq) | (q & ~geq);                       /* cap_quality snp:1325 */
-                    const uint32_t hit = b & ac & 0x0f0f0f0fu;                          /* base shares a bit with a called allele */
-                    const uint32_t many = b & ((b | 0x80808080u) - 0x01010101u) & 0x0f0f0f0fu;   /* >= 2 bits: never equals a call */
-                    const uint32_t M = PB_NZ(hit) & ~PB_NZ(many);                       /* base == call1 || base == call2 (snp:1908) */
-                    uint32_t nm = q;
-                    if (reduce) {
-                        if (binary) { const uint32_t gc = PB_GE(q, CUT); nm = (QH & gc) | (QL & ~gc); }   /* bin2[], no -K here */
-                        else nm = QL;
-                    }
-                    const uint32_t qz = (QH & M) | (nm & ~M);
-                    const uint32_t U = (((ac >> 4) & 0x01010101u) * 0xffu) | hm;
-                    const uint32_t W = ((ac >> 5) & 0x01010101u) * 0xffu;
-                    const uint32_t v = ((capq & W) | (~W & ((q & U) | (qz & ~U)))) & 0x7f7f7f7fu;
-                    ow[k] = (v & V) | (ow[k] & ~V);
-                    se |= ac & V & 0x40404040u;
+            }
+            if (rr.so + rr.lq >= gend || r + 1 >= B.n_reads) break;
+            r++; rr = B.rr[r];
+        }
+        if (ns) {
+            uint32_t a[4], a2[4] = {0, 0, 0, 0};
+            #define LOAD_ACT16(dst, col) do {   /* 16 action bytes from an arbitrary byte address: aligned dwords + byte funnel */ \
+                const uint8_t *ap_ = act + (col); \
+                const unsigned sh_ = (unsigned)((uintptr_t)ap_ & 3u), s8_ = sh_ * 8u; \
+                const uint32_t *aw_ = (const uint32_t *)(ap_ - sh_); \
+                const uint32_t w0_ = aw_[0], w1_ = aw_[1], w2_ = aw_[2], w3_ = aw_[3], w4_ = aw_[4]; \
+                dst[0] = sh_ ? (w0_ >> s8_) | (w1_ << (32u - s8_)) : w0_; \
+                dst[1] = sh_ ? (w1_ >> s8_) | (w2_ << (32u - s8_)) : w1_; \
+                dst[2] = sh_ ? (w2_ >> s8_) | (w3_ << (32u - s8_)) : w2_; \
+                dst[3] = sh_ ? (w3_ >> s8_) | (w4_ << (32u - s8_)) : w3_; } while (0)
+            LOAD_ACT16(a, c0s[0]);
+            if (ns > 1) LOAD_ACT16(a2, c0s[1]);
+            #undef LOAD_ACT16
+            uint32_t se = 0, se2 = 0;
+            #pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t q = qw[k], b = bw[k];
+                const uint32_t V1 = ((((vb[0] >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;   /* first read's bytes  */
+                const uint32_t V2 = ((((vb[1] >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;   /* second read's bytes */
+                const uint32_t V = V1 | V2;
+                const uint32_t ac = (a[k] & V1) | (a2[k] & V2);
+                const uint32_t hm = (hms[0] & V1) | (hms[1] & V2);
+                const uint32_t geq = PB_GE(q, QC);
+                const uint32_t capq = (QC & geq) | (q & ~geq);                       /* cap_quality snp:1325 */
+                const uint32_t hit = b & ac & 0x0f0f0f0fu;                          /* base shares a bit with a called allele */
+                const uint32_t many = b & ((b | 0x80808080u) - 0x01010101u) & 0x0f0f0f0fu;   /* >= 2 bits: never equals a call */
+                const uint32_t M = PB_NZ(hit) & ~PB_NZ(many);                       /* base == call1 || base == call2 (snp:1908) */
+                uint32_t nm = q;
+                if (reduce) {
+                    if (binary) { const uint32_t gc = PB_GE(q, CUT); nm = (QH & gc) | (QL & ~gc); }   /* bin2[], no -K here */
+                    else nm = QL;
                 }
-                if (se) {                                          /* rare: a column raises a per-read flag */
-                    for (int k = lo; k < hi; k++) {
-                        const uint32_t rc = colrec[c0 + k];
+                const uint32_t qz = (QH & M) | (nm & ~M);
+                const uint32_t U = (((ac >> 4) & 0x01010101u) * 0xffu) | hm;
+                const uint32_t W = ((ac >> 5) & 0x01010101u) * 0xffu;
+                const uint32_t v = ((capq & W) | (~W & ((q & U) | (qz & ~U)))) & 0x7f7f7f7fu;
+                ow[k] = (v & V) | (ow[k] & ~V);
+                se |= ac & V1 & 0x40404040u;
+                se2 |= ac & V2 & 0x40404040u;
+            }
+            if (se | se2) {                                        /* rare: a column raises a per-read flag */
+                for (int s2 = 0; s2 < 2; s2++) {
+                    if (!(s2 ? se2 : se)) continue;
+                    for (int k = 0; k < 16; k++) {
+                        if (!((vb[s2] >> k) & 1)) continue;
+                        const uint32_t rc = colrec[c0s[s2] + k];
                         if (rc & CR_SKIP) continue;
-                        if (rc & CR_KEEP) keepf[r] = 1;
-                        if (CR_PRESERVE(rc) > 1) b15f[r] = 1;
+                        if (rc & CR_KEEP) keepf[rid[s2]] = 1;
+                        if (CR_PRESERVE(rc) > 1) b15f[rid[s2]] = 1;
                     }
                 }
             }
         }
-        if (rr.so + rr.lq >= gend || r + 1 >= B.n_reads) break;
-        r++; rr = B.rr[r];
+        if (!more) break;
     }
     if (gend - g0 == 16) { uint4 o4; o4.x = ow[0]; o4.y = ow[1]; o4.z = ow[2]; o4.w = ow[3]; *(uint4 *)(out + g0) = o4; }
     else for (int k = 0; k < (int)(gend - g0); k++) out[g0 + k] = (uint8_t)((ow[k >> 2] >> (8 * (k & 3))) & 255);
