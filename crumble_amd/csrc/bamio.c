@@ -310,6 +310,28 @@ const char *crumble_bam_header_text(const crumble_bam_reader *r, int64_t *len) {
 /* fixed part of a BAM alignment record, offsets from the block_size field */
 enum { F_REFID = 4, F_POS = 8, F_LNAME = 12, F_MAPQ = 13, F_NCIG = 16, F_FLAG = 18, F_LSEQ = 20, F_FIXED = 36 };
 
+static const uint8_t *aux_end(const uint8_t *s, const uint8_t *lim);
+
+/* SAMv1 4.2.2: a CIGAR of more than 65535 ops is stored in the CG:B,I tag and the record carries the
+ * placeholder "<l_seq>S<reflen>N".  Returns the tag's uint32 array (and its length) or NULL. */
+static const uint8_t *long_cigar(const uint8_t *p, uint32_t *n_ops)
+{
+    const uint32_t bs = le32(p), lname = p[F_LNAME], ncig = le16(p + F_NCIG);
+    const int32_t lseq = (int32_t)le32(p + F_LSEQ);
+    if (ncig != 2 || lseq <= 0) return NULL;
+    const uint8_t *cg = p + F_FIXED + lname;
+    const uint32_t c0 = le32(cg), c1 = le32(cg + 4);
+    if ((c0 & 15) != 4 || (c0 >> 4) != (uint32_t)lseq || (c1 & 15) != 3) return NULL;
+    const uint8_t *lim = p + 4 + bs;
+    for (const uint8_t *t = cg + 8 + ((size_t)lseq + 1) / 2 + (size_t)lseq; t + 3 <= lim; ) {
+        const uint8_t *e = aux_end(t + 2, lim);
+        if (!e) return NULL;
+        if (t[0] == 'C' && t[1] == 'G' && t[2] == 'B' && t[3] == 'I') { *n_ops = le32(t + 4); return t + 8; }
+        t = e;
+    }
+    return NULL;
+}
+
 /* Walks the complete records in [scan, raw_len): group membership, offsets of the record and of its
  * bases / CIGAR words in the SoA arrays.  Stops at the first record of another refID (group_done)
  * or at the first incomplete record.  Errors are left in scan_err / g_err. */
@@ -342,7 +364,9 @@ static void scan_records(crumble_bam_reader *r)
         }
         r->rec_off[r->n] = r->scan;
         r->seq_off[r->n] = r->acc_nb; r->cig_off[r->n] = r->acc_nc;
-        r->acc_nb += lseq; r->acc_nc += ncig;
+        uint32_t nops = ncig;
+        if (ncig == 2) (void)long_cigar(p, &nops);            /* real op count of a CG-tag CIGAR */
+        r->acc_nb += lseq; r->acc_nc += nops;
         r->n++;
         r->scan += 4 + (size_t)bs;
     }
@@ -412,9 +436,10 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
         r->flag[i] = le16(p + F_FLAG);
         const uint8_t *cg = p + F_FIXED + lname;
         uint32_t *co = r->cigar + r->cig_off[i];
-        for (uint32_t k = 0; k < ncig; k++) co[k] = le32(cg + 4 * k);
-        /* a 2-op "<lseq>S<reflen>N" placeholder means the real CIGAR sits in the CG tag (SAMv1 4.2.2) */
-        if (ncig == 2 && (co[0] & 15) == 4 && (co[0] >> 4) == (uint32_t)lseq && (co[1] & 15) == 3 && lseq > 0) unsupported |= 1;
+        uint32_t nlong = 0;
+        const uint8_t *lc = ncig == 2 ? long_cigar(p, &nlong) : NULL;
+        if (lc) { if ((int64_t)nlong != r->cig_off[i + 1] - r->cig_off[i]) unsupported |= 1; else for (uint32_t k = 0; k < nlong; k++) co[k] = le32(lc + 4 * k); }
+        else for (uint32_t k = 0; k < ncig; k++) co[k] = le32(cg + 4 * k);
         const uint8_t *sq = cg + 4 * (size_t)ncig;
         uint8_t *bo = r->bases + r->seq_off[i];
         for (int32_t k = 0; k + 1 < lseq; k += 2) { const uint8_t v = sq[k >> 1]; bo[k] = v >> 4; bo[k + 1] = v & 15; }
@@ -425,7 +450,7 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
         else memcpy(qo, ql, (size_t)lseq);
     }
     T_unpack += now_s() - tu0;
-    if (unsupported) return fail(CRUMBLE_BAM_EUNSUPP, "record with its CIGAR in the CG tag (>65535 ops) is not supported");
+    if (unsupported) return fail(CRUMBLE_BAM_EFORMAT, "inconsistent CG tag");
     memset(b, 0, sizeof *b);
     b->tid = r->tid; b->n_reads = n;
     b->pos = r->pos; b->mapq = r->mapq; b->flag = r->flag;

@@ -9,8 +9,8 @@
  * (zlib per block), record fields are unpacked per read in parallel.
  *
  * Plain C ABI, no HIP.  Lives in libcrumble_bamio.so so that hosts which already have htslib need
- * not link it.  Not supported (documented, fenced with an error): CRAM/SAM text, >65535-op CIGARs
- * stored in the CG tag, BAM index output.
+ * not link it.  CIGARs of more than 65535 ops (CG:B,I tag, SAMv1 4.2.2) are read from the tag; the
+ * record is written back as it came.  Not supported: CRAM/SAM text, BAM index output.
  */
 #ifndef CRUMBLE_BAMIO_H
 #define CRUMBLE_BAMIO_H

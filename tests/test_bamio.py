@@ -193,12 +193,14 @@ def test_reader_rejects_bad_input(tmp_path):
             list(rd)
     with pytest.raises(bamio.BamError):
         bamio.Reader(tmp_path / "missing.bam")
-    # CG-tag placeholder CIGAR (kSmN) is refused, not misread
-    raw = py_bam([("a", 100)], [dict(tid=0, pos=1, cigar=[(3 << 4) | 4, (50 << 4) | 3], seq=[1, 2, 4], qual=[1, 2, 3])])
+    # a CIGAR stored in the CG tag (SAMv1 4.2.2: placeholder kSmN + CG:B,I) is read from the tag
+    real = [(2 << 4) | 0, (1 << 4) | 1, (3 << 4) | 2, (1 << 4) | 0]          # 2M1I3D1M: 4 query bases, 6 reference bases
+    cgtag = b"NMC\x01CGBI" + struct.pack("<I4I", 4, *real) + b"XSZz\0"
+    raw = py_bam([("a", 100)], [dict(tid=0, pos=1, cigar=[(4 << 4) | 4, (6 << 4) | 3], seq=[1, 2, 4, 8], qual=[1, 2, 3, 4], aux=cgtag),
+                                dict(tid=0, pos=5, cigar=[(3 << 4) | 4, (50 << 4) | 3], seq=[1, 2, 4], qual=[1, 2, 3])])   # no CG tag: a real 3S50N
     (tmp_path / "cg.bam").write_bytes(py_bgzf(raw))
-    with pytest.raises(bamio.BamError) as e:
-        list(bamio.Reader(tmp_path / "cg.bam"))
-    assert e.value.code == -23
+    g, = list(bamio.Reader(tmp_path / "cg.bam"))
+    assert list(g.cig_off) == [0, 4, 6] and list(g.cigar) == real + [(3 << 4) | 4, (50 << 4) | 3]
 
 
 def test_load_bed_matches_bed_collapse(tmp_path):
