@@ -1255,10 +1255,11 @@ __global__ void k_window(DBatch B, int n_trig, const int32_t *trigcol_pos, const
  *       range [ref2query_pos(min_pos2), qpos] reaches down to x (snp:1875):
  *       the byte is then the capped original,
  *   (d) the OR of keep_qual over the read's columns (snp:1847,1939): capped original.
- * (a)+(b) are one lane per base over the flat base array (k_replay_flat, fully
- * coalesced, no cross-lane traffic); (c) is a scatter from the few trigger
- * columns (k_restore); (d) and the per-read flags are k_readfix.  (c) and (d)
- * write the same value, so their order does not matter. */
+ * (a)+(b) are a pass over the flat base array -- packed 16-byte chunks for short-read
+ * batches (k_actions / k_replay_fast / k_replay_reads), 16 bases per lane with general
+ * per-base logic otherwise (k_replay_flat), one lane per base with -S (k_replay_general);
+ * (c) is a scatter from the few trigger columns (k_restore); (d) and the per-read flags
+ * are k_readfix / k_keepfix.  (c) and (d) write the same value, so their order does not matter. */
 struct ColOp { uint8_t v; int keep, b15; };
 
 __device__ __forceinline__ uint8_t cap_q2(const DParams *__restrict__ P, int qcap, bool any_pres, uint8_t q)
@@ -1420,7 +1421,7 @@ k_replay_flat(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
                     const int off = (int)(g - rr.so) - rr.q0;
                     if (off >= 0 && off < rr.end - rr.pos) cidx[k] = rr.pos + off - B.p0;
                     if (hm) hmm |= 1u << k;
-                } else {                                   /* general CIGAR: host-built base -> column table */
+                } else {                                   /* general CIGAR: base -> column table built with the batch (k_p0_fill) */
                     const int c = B.cix[(size_t)rr.cix + (size_t)(g - rr.so)];
                     if (c == -2) slow |= 1u << k;          /* D/N columns report this base: sequence matters */
                     else { cidx[k] = c; if (hm) hmm |= 1u << k; }
@@ -1680,7 +1681,7 @@ k_replay_reads(DBatch B, const DParams *__restrict__ P, const uint32_t *__restri
 #undef PB_GE
 #undef PB_NZ
 
-/* the bases that D/N columns report (host-built list), after k_replay_flat */
+/* the bases that D/N columns report (list built with the batch), after the chunk kernels */
 __global__ void k_replay_slow(DBatch B, const DParams *__restrict__ P, const uint32_t *__restrict__ colrec,
                               const int32_t *__restrict__ pos_mn2, const int *__restrict__ n_slow, const int64_t *__restrict__ slow_g,
                               const int32_t *__restrict__ slow_r, uint8_t *__restrict__ out,
