@@ -665,6 +665,22 @@ __device__ __forceinline__ ScanVal scanval_wave_incl(ScanVal v, int lane)
     }
     return v;
 }
+/* the same for per-position values, whose four flag fields are 0/1: their prefix is a popcount of
+ * the ballot below the lane; only depth and items need the shuffle ladder */
+__device__ __forceinline__ ScanVal scanval_wave_incl01(ScanVal v, int lane)
+{
+    const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    v.cols = __popcll(__ballot(v.cols != 0) & le);
+    v.trigcols = __popcll(__ballot(v.trigcols != 0) & le);
+    v.ins = __popcll(__ballot(v.ins != 0) & le);
+    v.toodeep = __popcll(__ballot(v.toodeep != 0) & le);
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t od = __shfl_up(v.depth, d); const int oi = __shfl_up(v.items, d);
+        if (lane >= d) { v.depth += od; v.items += oi; }
+    }
+    return v;
+}
 
 /* one workgroup reduces one chunk of SCAN_CHUNK consecutive positions (coalesced) */
 __global__ void __launch_bounds__(256)
@@ -725,7 +741,7 @@ k_scan_apply(int L, const uint32_t *colrec, const int32_t *nplp,
         const int i = base + k * 256 + (int)threadIdx.x;
         ScanVal v = {0, 0, 0, 0, 0, 0, 0};
         if (i < L) scanval_of(colrec[i], nplp[i], trigcnt[i], v);
-        ScanVal inc = scanval_wave_incl(v, lane);
+        ScanVal inc = scanval_wave_incl01(v, lane);
         __syncthreads();                               /* ws reuse */
         if (lane == 63) ws[w] = inc;
         __syncthreads();
