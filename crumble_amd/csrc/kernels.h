@@ -749,8 +749,9 @@ k_scan_apply(int L, const uint32_t *colrec, const int32_t *nplp,
         for (int j = 0; j < w; j++) scanval_add(run, ws[j]);
         if (i < L) {
             dpre[i] = run.depth + inc.depth - v.depth; col_ord[i] = run.cols + inc.cols - v.cols;
-            trig_ord[i] = run.trigcols + inc.trigcols - v.trigcols;
-            item_off[i] = run.items + inc.items - v.items; ins_ord[i] = run.ins + inc.ins - v.ins;
+            /* only trigger / insertion columns are ever looked up in these three (k_overdepth) */
+            if (v.trigcols) { trig_ord[i] = run.trigcols + inc.trigcols - v.trigcols; item_off[i] = run.items + inc.items - v.items; }
+            if (v.ins) ins_ord[i] = run.ins + inc.ins - v.ins;
         }
         for (int j = 0; j < (int)(blockDim.x >> 6); j++) scanval_add(carry, ws[j]);
     }
