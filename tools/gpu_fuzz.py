@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""GPU box: long randomized parity run (tests/fuzz_util.py cases + tiny-read batches), engine == oracle.
+Usage: python tools/gpu_fuzz.py <first_seed> <n_seeds>"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import crumble_amd as ca
+from fuzz_util import random_case
+from parity_util import assert_parity
+from test_fuzz_parity import tiny_reads_batch
+s0, n = int(sys.argv[1]), int(sys.argv[2])
+bad, t0 = 0, time.time()
+for seed in range(s0, s0 + n):
+    p, hb, desc = random_case(seed, max_bases=300_000)
+    try:
+        assert_parity(lambda q: ca.Engine(q, 0), p, hb)
+        if seed % 10 == 0:
+            assert_parity(lambda q: ca.Engine(q, 0), p, tiny_reads_batch(seed, n=2000), check_columns=False)
+    except Exception as e:
+        bad += 1
+        print("FAIL", desc, str(e)[:300], flush=True)
+    if (seed - s0) % 200 == 199:
+        print(f"{seed - s0 + 1} cases, {bad} failures, {time.time() - t0:.0f} s", flush=True)
+print(f"done: {n} cases, {bad} failures, {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
