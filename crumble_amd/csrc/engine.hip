@@ -56,7 +56,7 @@ struct crumble_hip {
     DParams hparams;
     DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc;
     /* batch (inputs) */
-    DevBuf d_ufirst, d_tcum, d_tpart, d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
+    DevBuf d_pbdirty, d_ufirst, d_tcum, d_tpart, d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
            d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax;
     /* per position */
     DevBuf d_colrec, d_nplp, d_score, d_trigcnt, d_dpre, d_col_ord, d_trig_ord, d_item_off,
@@ -218,7 +218,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     DevBuf *all[] = { &h->d_params, &h->d_tables, &h->d_stats, &h->d_batch_stats, &h->d_misc,
-        &h->d_ufirst, &h->d_tcum, &h->d_tpart, &h->d_pbwmm, &h->d_act, &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
+        &h->d_ufirst, &h->d_tcum, &h->d_tpart, &h->d_pbdirty, &h->d_pbwmm, &h->d_act, &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
         &h->d_slow_g, &h->d_slow_r, &h->d_cix, &h->d_sr, &h->d_stile_lo, &h->d_stile_hi, &h->d_rr, &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
         &h->d_cigar, &h->d_segs, &h->d_bases, &h->d_quals, &h->d_tile_lo, &h->d_tile_hi,
         &h->d_bed_start, &h->d_bed_end, &h->d_bed_pmax, &h->d_colrec, &h->d_nplp, &h->d_score,
@@ -438,12 +438,30 @@ static int launch_pblock(crumble_hip *h, hipStream_t st, int64_t n_reads, int64_
      * CRUMBLE_HIP_PBLOCK=reads|segments overrides the choice (tuning / tests). */
     const char *force = getenv("CRUMBLE_HIP_PBLOCK");
     const bool per_read = force ? !strcmp(force, "reads") : nb < 1024 * n_reads;
-    if (per_read) {
+    const int64_t nwords = (nb + 63) / 64;
+    int e;
+    if (per_read && h->hparams.any_preserve) {          /* -k/-K: the byte-wise kernel knows the skip rule */
         CRUMBLE_LAUNCH_INDEP(k_pblock, nblk(n_reads, 64), 64, st, n_reads, seq_off, out, rflags, P);
         return CRUMBLE_OK;
     }
-    const int64_t nwords = (nb + 63) / 64;
-    int e;
+    if (per_read) {     /* chunk min/max (coalesced) -> runs per read -> fill of the words whose bytes change */
+        const int64_t nch = (nb + 15) / 16;
+        if ((e = h->d_pbstop.reserve((size_t)(nwords + 1) * 8)) || (e = h->d_pbruns.reserve((size_t)(nwords + 1) * 8)) ||
+            (e = h->d_pbval.reserve((size_t)nb + 64)) || (e = h->d_pbwmm.reserve((size_t)(nch + 1) * 2)) ||
+            (e = h->d_pbdirty.reserve((size_t)nwords + 64)))
+            return e;
+        u64 *stop = h->d_pbstop.as<u64>(), *runs = h->d_pbruns.as<u64>();
+        HIPCHK(hipMemsetAsync(stop, 0, (size_t)nwords * 8, st));
+        HIPCHK(hipMemsetAsync(runs, 0, (size_t)nwords * 8, st));
+        HIPCHK(hipMemsetAsync(h->d_pbdirty.p, 0, (size_t)nwords, st));
+        CRUMBLE_LAUNCH_INDEP(k_pb_chunkmm, nblk(nch, 256), 256, st, nb, out, h->d_pbwmm.as<uint16_t>());
+        CRUMBLE_LAUNCH_INDEP(k_pb_readstarts, nblk(n_reads, 256), 256, st, n_reads, seq_off, stop, (u64 *)nullptr);
+        CRUMBLE_LAUNCH_INDEP(k_pb_reads, nblk(n_reads, 256), 256, st, n_reads, seq_off, out, rflags,
+                             h->d_pbwmm.as<uint16_t>(), runs, h->d_pbval.as<uint8_t>(), h->d_pbdirty.as<uint8_t>(), P);
+        CRUMBLE_LAUNCH_INDEP(k_pb_fill, nblk(nch, 256), 256, st, nb, out, stop, runs, h->d_pbval.as<uint8_t>(),
+                             h->d_pbdirty.as<uint8_t>());
+        return CRUMBLE_OK;
+    }
     if ((e = h->d_pbstop.reserve((size_t)(nwords + 1) * 8)) || (e = h->d_pbrs.reserve((size_t)(nwords + 1) * 8)) ||
         (e = h->d_pbruns.reserve((size_t)(nwords + 1) * 8)) || (e = h->d_pbval.reserve((size_t)nb + 64)) ||
         (e = h->d_pbwmm.reserve((size_t)(nwords + 1) * 2)))
@@ -453,7 +471,7 @@ static int launch_pblock(crumble_hip *h, hipStream_t st, int64_t n_reads, int64_
     CRUMBLE_LAUNCH_INDEP(k_pb_marks, nblk(nwords, 256), 256, st, nb, out, P, stop, rs, runs, h->d_pbwmm.as<uint16_t>());
     CRUMBLE_LAUNCH_INDEP(k_pb_readstarts, nblk(n_reads, 256), 256, st, n_reads, seq_off, stop, rs);
     CRUMBLE_LAUNCH_INDEP(k_pb_segments, nblk(nwords, 256), 256, st, nb, n_reads, seq_off, out, rflags, blk_read, stop, rs, runs, val, h->d_pbwmm.as<uint16_t>(), P);
-    CRUMBLE_LAUNCH_INDEP(k_pb_fill, nblk((nb + 15) / 16, 256), 256, st, nb, out, stop, runs, val);
+    CRUMBLE_LAUNCH_INDEP(k_pb_fill, nblk((nb + 15) / 16, 256), 256, st, nb, out, stop, runs, val, (const uint8_t *)nullptr);
     return CRUMBLE_OK;
 }
 

@@ -1979,7 +1979,7 @@ __global__ void k_pb_readstarts(int64_t n_reads, const int64_t *__restrict__ seq
     const int64_t g = seq_off[r];
     if (seq_off[r + 1] == g) return;
     atomicOr((unsigned long long *)&stop[g >> 6], 1ull << (g & 63));
-    atomicOr((unsigned long long *)&rstart[g >> 6], 1ull << (g & 63));
+    if (rstart) atomicOr((unsigned long long *)&rstart[g >> 6], 1ull << (g & 63));
 }
 
 __global__ void __launch_bounds__(256)
@@ -2106,15 +2106,101 @@ k_pb_segments(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_
     }
 }
 
+/* Short reads without -k/-K.  One lane per read keeps a wave's lanes level, but a lane that walks its
+ * own read touches a different cache line than its neighbours at every step (5.9 ms at -9 on the
+ * chr20 contig).  So the bytes are read ONCE, coalesced, by k_pb_chunkmm (min and max of every aligned
+ * 16-byte chunk); k_pb_reads then walks a read through its chunks' (min, max) pairs -- contiguous,
+ * 2 bytes per 16 bases -- and only looks at bytes in the unaligned head and tail of the read and in
+ * the rare chunk where a run ends.  Runs are recorded (run-start bit, run value) and the words that
+ * hold a run whose bytes actually change are flagged, so that k_pb_fill skips everything else. */
+__global__ void __launch_bounds__(256)
+k_pb_chunkmm(int64_t n_bases, const uint8_t *__restrict__ out, uint16_t *__restrict__ cmm)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c * 16 >= n_bases) return;
+    const uint4 v = *(const uint4 *)(out + c * 16);
+    #define PBR_GE(a, b) (((((a) | 0x80808080u) - (b)) & 0x80808080u) >> 7) * 0xffu
+    uint32_t g01 = PBR_GE(v.x, v.y), g23 = PBR_GE(v.z, v.w);
+    const uint32_t mn01 = (v.y & g01) | (v.x & ~g01), mn23 = (v.w & g23) | (v.z & ~g23);
+    const uint32_t mx01 = (v.x & g01) | (v.y & ~g01), mx23 = (v.z & g23) | (v.w & ~g23);
+    const uint32_t gmn = PBR_GE(mn01, mn23), gmx = PBR_GE(mx01, mx23);
+    const uint32_t m4 = (mn23 & gmn) | (mn01 & ~gmn), x4 = (mx01 & gmx) | (mx23 & ~gmx);
+    #undef PBR_GE
+    unsigned cmin = m4 & 255, cmax = x4 & 255;
+    #pragma unroll
+    for (int t = 1; t < 4; t++) {
+        const unsigned u0 = (m4 >> (8 * t)) & 255, u1 = (x4 >> (8 * t)) & 255;
+        cmin = u0 < cmin ? u0 : cmin; cmax = u1 > cmax ? u1 : cmax;
+    }
+    cmm[c] = (uint16_t)(cmin | (cmax << 8));
+}
+
+__global__ void __launch_bounds__(256)
+k_pb_reads(int64_t n_reads, const int64_t *__restrict__ seq_off, const uint8_t *__restrict__ out,
+           const uint8_t *__restrict__ rflags, const uint16_t *__restrict__ cmm, u64 *__restrict__ runs,
+           uint8_t *__restrict__ runval, uint8_t *__restrict__ dirty, const DParams *__restrict__ P)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const int64_t so = seq_off[r], e = seq_off[r + 1];
+    if (e == so) return;
+    if (rflags && (rflags[r] & 2)) { runval[so] = (uint8_t)PB_KEEP; return; }   /* flag bit 15: snp:1098 */
+    const int level2 = P->pblock * 2, qcap = P->qcap;
+    int64_t j = so, i = so;
+    int qmin = INT_MAX, qmax = INT_MIN, last_qmin = 0, last_qmax = 0;
+    bool anydirty = false;
+    while (i < e) {
+        if (!(i & 15) && i + 16 <= e) {                         /* a whole aligned chunk of this read */
+            const unsigned mm = cmm[i >> 4];
+            const int cmin = (int)(mm & 255), cmax = (int)(mm >> 8);
+            const int nmin = cmin < qmin ? cmin : qmin, nmax = cmax > qmax ? cmax : qmax;
+            if (nmax - nmin <= level2) { qmin = last_qmin = nmin; qmax = last_qmax = nmax; i += 16; continue; }
+        }
+        /* the read's unaligned head or tail, or a chunk in which a run ends: byte by byte, every run end
+         * of the chunk in the same pass (quantised data changes level every few dozen bases) */
+        const int64_t base = i & ~(int64_t)15;
+        const uint4 v = *(const uint4 *)(out + base);           /* the buffer has >= 16 bytes of slack */
+        const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+        const int lo = (int)(i - base), hi = (e - base < 16) ? (int)(e - base) : 16;
+        const unsigned vb = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+        unsigned newruns = 0;
+        #pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if ((vb >> k) & 1u) {
+                const int q = (int)((wd[k >> 2] >> (8 * (k & 3))) & 255);
+                qmin = q < qmin ? q : qmin;
+                qmax = q > qmax ? q : qmax;
+                if (qmax - qmin > level2) {                  /* a run ends here (snp:817-826) */
+                    int mid = (last_qmin + last_qmax) >> 1;
+                    mid = mid > qcap ? qcap : mid;
+                    runval[j] = (uint8_t)mid;
+                    anydirty |= (last_qmin != last_qmax) | (mid != last_qmin);
+                    newruns |= 1u << k;
+                    qmin = qmax = q; j = base + k;
+                }
+                last_qmin = qmin; last_qmax = qmax;
+            }
+        }
+        if (newruns) atomicOr((unsigned long long *)&runs[base >> 6], (unsigned long long)newruns << (base & 63));
+        i = base + hi;
+    }
+    const int mid = (last_qmin + last_qmax) / 2;                 /* the final run is not capped (snp:832) */
+    runval[j] = (uint8_t)mid;
+    anydirty |= (last_qmin != last_qmax) | (mid != last_qmin);
+    if (anydirty)                                                /* some run of this read changes bytes: its words go through k_pb_fill */
+        for (int64_t w = so >> 6; w <= (e - 1) >> 6; w++) dirty[w] = 1;
+}
+
 /* every byte takes the value of the run that holds it */
 __global__ void __launch_bounds__(256)
 k_pb_fill(int64_t n_bases, uint8_t *__restrict__ out, const u64 *__restrict__ stop, const u64 *__restrict__ runs,
-          const uint8_t *__restrict__ runval)
+          const uint8_t *__restrict__ runval, const uint8_t *__restrict__ dirty)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t g0 = t * 16;
     if (g0 >= n_bases) return;
     const int64_t w = g0 >> 6;
+    if (dirty && !dirty[w]) return;                       /* no run that changes a byte touches this word */
     const int sh = (int)(g0 & 63);
     const u64 m = stop[w] | runs[w];
     /* run start governing the first byte: the last set bit at or before g0 */
@@ -2127,6 +2213,13 @@ k_pb_fill(int64_t n_bases, uint8_t *__restrict__ out, const u64 *__restrict__ st
     }
     uint32_t val = runval[s];
     const uint4 v = *(const uint4 *)(out + g0);
+    if (!((m >> sh) & 0xfffeu) && g0 + 16 <= n_bases) {
+        /* no run starts inside the chunk (bit 0 would be its own start, already in val): one value */
+        if (val == PB_KEEP) return;
+        const uint32_t vv = val * 0x01010101u;
+        if (v.x != vv || v.y != vv || v.z != vv || v.w != vv) { uint4 o; o.x = o.y = o.z = o.w = vv; *(uint4 *)(out + g0) = o; }
+        return;
+    }
     const uint4 rv4 = *(const uint4 *)(runval + g0);        /* only the bytes at run starts are meaningful */
     uint32_t wd[4] = {v.x, v.y, v.z, v.w};
     const uint32_t rv[4] = {rv4.x, rv4.y, rv4.z, rv4.w};
