@@ -68,6 +68,7 @@ struct crumble_hip {
     DBatch B;
     bool have_batch = false, have_run = false;
     unsigned persistent_blocks = 1024;
+    bool col_perm = false;          /* k_columns<.., PERM>: picked per batch in crumble_hip_upload */
     int64_t n_reads = 0, n_bases = 0, n_cigar = 0, n_slow = 0, n_segrec = 0;
     ScanVal totals;
     /* timing */
@@ -338,6 +339,18 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
         for (int i = 1; i < 256; i++) if (hist[i] > hist[best]) best = i;
         B.hot_mq = best;
     }
+    {   /* k_columns variant (a performance choice only; both give the same bits): per-column base classes pay
+         * when few base calls disagree with their column.  Estimate the batch's error rate from a sample of its
+         * qualities; measured break-even is near 2 % (see kernels.h).  CRUMBLE_KCOL_PERM=0|1 overrides. */
+        double esum = 0; int64_t cnt = 0;
+        static double q2e[128]; static bool q2e_init = false;
+        if (!q2e_init) { for (int q = 0; q < 128; q++) q2e[q] = pow(10.0, -q / 10.0); q2e_init = true; }
+        const int64_t step = nb > 65536 ? nb / 65536 : 1;
+        for (int64_t i = 0; i < nb; i += step, cnt++) esum += q2e[b->quals[i] & 127];
+        h->col_perm = cnt > 0 && esum < 0.02 * (double)cnt;
+        const char *ov = getenv("CRUMBLE_KCOL_PERM");
+        if (ov && (*ov == '0' || *ov == '1')) h->col_perm = *ov == '1';
+    }
     h->n_reads = n; h->n_bases = nb; h->n_cigar = nc;
     h->n_segrec = tot.nseg; h->n_slow = tot.nslow;  /* upper bound; the exact count is d_nslow */
 
@@ -512,12 +525,14 @@ extern "C" int crumble_hip_run(crumble_hip *h)
         if (grid > pgrid) grid = pgrid;                 /* persistent: grid-stride over tiles */
         const bool modeA = h->hparams.min_qual_A != 0;
         const bool multi = h->n_segrec > h->n_reads + h->n_reads / 2;     /* long reads: many ops per read */
-#define KCOL_LAUNCH(M) do { if (multi) CRUMBLE_LAUNCH((k_columns<M, true>), grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, ht, stats, (unsigned *)(d_overflow + 3)); \
-                            else       CRUMBLE_LAUNCH((k_columns<M, false>), grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, ht, stats, (unsigned *)(d_overflow + 3)); } while (0)
+#define KCOL_LAUNCH2(M, MU, PE) CRUMBLE_LAUNCH((k_columns<M, MU, PE>), grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, ht, stats, (unsigned *)(d_overflow + 3))
+#define KCOL_LAUNCH(M) do { if (multi) { if (h->col_perm) KCOL_LAUNCH2(M, true, true); else KCOL_LAUNCH2(M, true, false); } \
+                            else       { if (h->col_perm) KCOL_LAUNCH2(M, false, true); else KCOL_LAUNCH2(M, false, false); } } while (0)
         if (modeA && modeB) KCOL_LAUNCH(2);
         else if (modeB)     KCOL_LAUNCH(1);
         else                KCOL_LAUNCH(0);
 #undef KCOL_LAUNCH
+#undef KCOL_LAUNCH2
 
         STAGE("scan", 0);
         const int nchunks = (L + SCAN_CHUNK - 1) / SCAN_CHUNK;

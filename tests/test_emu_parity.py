@@ -59,6 +59,21 @@ def test_emu_consensus_modes(product):
     assert_parity(emu_lib.engine, ca.preset_params(5, min_qual_A=0, min_qual_B=0), hb)
 
 
+@pytest.mark.parametrize("perm", ["0", "1"])
+def test_emu_column_kernel_variants(product, perm, monkeypatch):
+    """Both k_columns accumulate variants: one block per base class, and per-column class numbering
+    (class = idx(base) ^ idx(key base)) undone by col_unpermute before the sums are read."""
+    monkeypatch.setenv("CRUMBLE_KCOL_PERM", perm)
+    hb = synth_batch("chr20", 0.0004)
+    assert_parity(emu_lib.engine, ca.preset_params(5), hb)
+    assert_parity(emu_lib.engine, ca.preset_params(5, min_qual_A=30, min_indel_A=60), hb)
+    assert_parity(emu_lib.engine, ca.preset_params(5, min_qual_A=30, min_qual_B=0), hb)
+    assert_parity(emu_lib.engine, ca.preset_params(9, keep="37", perfect_col=1), hb)
+    assert_parity(emu_lib.engine, ca.preset_params(9), synth_batch("panel", 0.001))
+    assert_parity(emu_lib.engine, ca.preset_params(9, tech="pbccs"), synth_batch("hifi", 0.0002, read_len=3000))
+    assert_parity(emu_lib.engine, ca.preset_params(1), synth_batch("ce", 0.3))
+
+
 def test_emu_indel_only(product):
     """indel_only.c:83-122 (D=20, Q=37) as a mode of the masking pass."""
     import oracle_lib as O

@@ -9,8 +9,9 @@ from parity_util import assert_parity
 
 
 @pytest.mark.parametrize("seed", range(100, 112))
-def test_fuzz_emulated(product, seed):
+def test_fuzz_emulated(product, seed, monkeypatch):
     import emu_lib
+    monkeypatch.setenv("CRUMBLE_KCOL_PERM", str(seed & 1))        # both k_columns variants, whatever the batch
     p, hb, desc = random_case(seed, max_bases=120_000)
     print(desc)
     assert_parity(emu_lib.engine, p, hb)
@@ -18,8 +19,9 @@ def test_fuzz_emulated(product, seed):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("block", range(6))
-def test_fuzz_gpu(product, block):
+def test_fuzz_gpu(product, block, monkeypatch):
     for seed in range(1000 + 25 * block, 1000 + 25 * (block + 1)):
+        monkeypatch.setenv("CRUMBLE_KCOL_PERM", str(seed & 1))    # both k_columns variants, whatever the batch
         p, hb, desc = random_case(seed, max_bases=400_000)
         try:
             assert_parity(lambda q: ca.Engine(q, 0), p, hb)

@@ -46,6 +46,26 @@ def test_hifi_pbccs(product):
     assert_parity(gpu_engine, ca.preset_params(5), hb)
 
 
+@pytest.mark.parametrize("perm", ["0", "1"])
+def test_column_kernel_variants(product, perm, monkeypatch):
+    """Both k_columns accumulate variants (one block per base class / per-column class numbering with the
+    XOR un-permutation) on every workload shape and consensus mode, whatever the batch heuristic would pick."""
+    monkeypatch.setenv("CRUMBLE_KCOL_PERM", perm)
+    hifi = synth_batch("hifi", 0.002)
+    for hb, p in ((synth_batch("chr20", 0.01), ca.preset_params(5)),
+                  (synth_batch("chr20", 0.002), ca.preset_params(5, min_qual_A=30, min_indel_A=60)),
+                  (synth_batch("chr20", 0.002), ca.preset_params(5, min_qual_A=30, min_qual_B=0)),
+                  (synth_batch("chr20", 0.002), ca.preset_params(9, keep="37", perfect_col=1)),
+                  (synth_batch("ce", 1.0), ca.preset_params(1)),
+                  (synth_batch("panel", 0.005), ca.preset_params(9)),
+                  (hifi, ca.preset_params(None, tech="pbccs")),
+                  (hifi, ca.preset_params(5, min_qual_A=30, min_indel_A=60))):
+        assert_parity(gpu_engine, p, hb)
+    from test_pileup_cases import CASES
+    for level in (1, 9):
+        assert_parity(gpu_engine, ca.preset_params(level, keep="30-33"), cigar_zoo(CASES))
+
+
 @pytest.mark.parametrize("path", ["reads", "segments"])
 def test_pblock_paths(product, path, monkeypatch):
     """Both P-block implementations (one lane per read / segment-parallel) on short and long reads."""
