@@ -249,13 +249,13 @@ static int up(crumble_hip *h, DevBuf &d, const T *src, size_t n)
 static int prefix_max(crumble_hip *h, int32_t *v, int64_t n)
 {
     if (n <= 0) return CRUMBLE_OK;
-    const int chunk = 2048, nch = (int)((n + chunk - 1) / chunk);
+    const int nch = (int)((n + PMAX_CHUNK - 1) / PMAX_CHUNK);
     int e = h->d_pmax_partial.reserve((size_t)(nch + 2) * 4);
     if (e) return e;
     int32_t *pp = h->d_pmax_partial.as<int32_t>();
-    CRUMBLE_LAUNCH_INDEP(k_pmax_reduce, nblk(nch, 64), 64, h->stream, (int)n, v, pp, nch, chunk);
-    CRUMBLE_LAUNCH_INDEP(k_pmax_partials, 1, 1, h->stream, pp, nch);
-    CRUMBLE_LAUNCH_INDEP(k_pmax_apply, nblk(nch, 64), 64, h->stream, (int)n, v, pp, nch, chunk);
+    CRUMBLE_LAUNCH(k_pmax_reduce, nch, 256, h->stream, (int)n, v, pp);
+    CRUMBLE_LAUNCH(k_pmax_partials, 1, 64, h->stream, pp, nch);
+    CRUMBLE_LAUNCH(k_pmax_apply, nch, 256, h->stream, (int)n, v, pp);
     return CRUMBLE_OK;
 }
 
@@ -538,7 +538,7 @@ extern "C" int crumble_hip_run(crumble_hip *h)
         const int nchunks = (L + SCAN_CHUNK - 1) / SCAN_CHUNK;
         ScanVal *partial = h->d_partial.as<ScanVal>();
         CRUMBLE_LAUNCH(k_scan_reduce, nchunks, 256, st, L, colrec, nplp, trigcnt, partial, nchunks);
-        CRUMBLE_LAUNCH(k_scan_partials, 1, 256, st, partial, nchunks);
+        CRUMBLE_LAUNCH(k_scan_partials, 1, 1024, st, partial, nchunks);
         CRUMBLE_LAUNCH(k_scan_apply, nchunks, 256, st, L, colrec, nplp, trigcnt, partial, nchunks,
                              h->d_dpre.as<int64_t>(), h->d_col_ord.as<int32_t>(), h->d_trig_ord.as<int32_t>(),
                              h->d_item_off.as<int32_t>(), h->d_ins_ord.as<int32_t>());
@@ -577,16 +577,11 @@ extern "C" int crumble_hip_run(crumble_hip *h)
             CRUMBLE_LAUNCH_INDEP(k_str, nblk(n_items, 64), 64, st, B, P, n_items, items, d_overflow);
             STAGE("k_fold", 0);
             int32_t *colhi = h->d_colhi.as<int32_t>(), *ub = h->d_ub.as<int32_t>();
-            int32_t *pp = h->d_pmax_partial.as<int32_t>();
-            const int chunk = 256, nch = (n_trig + chunk - 1) / chunk;
+            int pe;
             CRUMBLE_LAUNCH_INDEP(k_fold_bounds, nblk(n_trig, 64), 64, st, B, P, n_trig, trigcol_pos, trigcol_off, trigcnt, items, colhi);
-            CRUMBLE_LAUNCH_INDEP(k_pmax_reduce, nblk(nch, 64), 64, st, n_trig, colhi, pp, nch, chunk);
-            CRUMBLE_LAUNCH_INDEP(k_pmax_partials, 1, 1, st, pp, nch);
-            CRUMBLE_LAUNCH_INDEP(k_pmax_apply, nblk(nch, 64), 64, st, n_trig, colhi, pp, nch, chunk);
+            if ((pe = prefix_max(h, colhi, n_trig))) return pe;
             CRUMBLE_LAUNCH_INDEP(k_fold_ub, nblk(n_trig, 64), 64, st, B, P, n_trig, trigcol_pos, colhi, ub);
-            CRUMBLE_LAUNCH_INDEP(k_pmax_reduce, nblk(nch, 64), 64, st, n_trig, ub, pp, nch, chunk);
-            CRUMBLE_LAUNCH_INDEP(k_pmax_partials, 1, 1, st, pp, nch);
-            CRUMBLE_LAUNCH_INDEP(k_pmax_apply, nblk(nch, 64), 64, st, n_trig, ub, pp, nch, chunk);
+            if ((pe = prefix_max(h, ub, n_trig))) return pe;
             CRUMBLE_LAUNCH_INDEP(k_fold, nblk(n_trig, 64), 64, st, B, P, n_trig, trigcol_pos, trigcol_off, trigcnt, items, ub,
                                  colrec, h->d_pos_mn2.as<int32_t>(), h->d_trig_mx2.as<int32_t>());
             CRUMBLE_LAUNCH_INDEP(k_window, nblk(n_trig, 64), 64, st, B, n_trig, trigcol_pos, h->d_trig_mx2.as<int32_t>(), colrec);

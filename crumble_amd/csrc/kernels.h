@@ -778,10 +778,10 @@ k_scan_reduce(int L, const uint32_t *colrec, const int32_t *nplp,
 }
 
 /* one workgroup: exclusive scan of the chunk partials; totals -> partial[nchunks] */
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_scan_partials(ScanVal *partial, int nchunks)
 {
-    __shared__ ScanVal ws[4];
+    __shared__ ScanVal ws[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nt = blockDim.x;
     const int per = (nchunks + nt - 1) / nt;
     const int b = (int)threadIdx.x * per, e = (b + per < nchunks) ? b + per : nchunks;
@@ -1240,29 +1240,72 @@ __global__ void k_fold_bounds(DBatch B, const DParams *P, int n_trig, const int3
     colhi[k] = h;
 }
 
-/* generic chunked inclusive prefix-max over int32 */
-__global__ void k_pmax_reduce(int n, const int32_t *v, int32_t *partial, int nchunks, int chunk)
+/* generic chunked inclusive prefix-max over int32: one 256-thread workgroup per chunk of PMAX_CHUNK
+ * values (8 consecutive values per thread), the chunk maxima scanned by one wave */
+#define PMAX_CHUNK 2048
+__device__ __forceinline__ int pmax_wave_max(int m)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nchunks) return;
+    #pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(m, d); m = o > m ? o : m; }
+    return m;
+}
+__global__ void __launch_bounds__(256)
+k_pmax_reduce(int n, const int32_t *__restrict__ v, int32_t *__restrict__ partial)
+{
+    __shared__ int wm[4];
+    const int b = blockIdx.x * PMAX_CHUNK + threadIdx.x * 8;
     int m = INT_MIN;
-    const int b = t * chunk, e = b + chunk < n ? b + chunk : n;
-    for (int i = b; i < e; i++) if (v[i] > m) m = v[i];
-    partial[t] = m;
+    #pragma unroll
+    for (int i = 0; i < 8; i++) if (b + i < n) { const int x = v[b + i]; m = x > m ? x : m; }
+    m = pmax_wave_max(m);
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int r = wm[0];
+        #pragma unroll
+        for (int w = 1; w < 4; w++) r = wm[w] > r ? wm[w] : r;
+        partial[blockIdx.x] = r;
+    }
 }
-__global__ void k_pmax_partials(int32_t *partial, int nchunks)
+/* exclusive prefix-max of the chunk maxima, in place: one wave, 64 chunks per step */
+__global__ void __launch_bounds__(64)
+k_pmax_partials(int32_t *partial, int nchunks)
 {
-    if (blockIdx.x || threadIdx.x) return;
+    const int lane = threadIdx.x;
     int run = INT_MIN;
-    for (int i = 0; i < nchunks; i++) { int v = partial[i]; partial[i] = run; if (v > run) run = v; }
+    for (int base = 0; base < nchunks; base += 64) {
+        const int x = base + lane < nchunks ? partial[base + lane] : INT_MIN;
+        int incl = x;
+        #pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d && o > incl) incl = o; }
+        int excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = INT_MIN;
+        if (base + lane < nchunks) partial[base + lane] = excl > run ? excl : run;
+        const int tot = __shfl(incl, 63);
+        run = tot > run ? tot : run;
+    }
 }
-__global__ void k_pmax_apply(int n, int32_t *v, const int32_t *partial, int nchunks, int chunk)
+__global__ void __launch_bounds__(256)
+k_pmax_apply(int n, int32_t *__restrict__ v, const int32_t *__restrict__ partial)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nchunks) return;
-    int run = partial[t];
-    const int b = t * chunk, e = b + chunk < n ? b + chunk : n;
-    for (int i = b; i < e; i++) { if (v[i] > run) run = v[i]; v[i] = run; }
+    __shared__ int wm[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.x * PMAX_CHUNK + threadIdx.x * 8;
+    int x[8], m = INT_MIN;
+    #pragma unroll
+    for (int i = 0; i < 8; i++) { x[i] = b + i < n ? v[b + i] : INT_MIN; m = x[i] > m ? x[i] : m; x[i] = m; }   /* thread-local inclusive */
+    int incl = m;
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d && o > incl) incl = o; }
+    if (lane == 63) wm[w] = incl;
+    int excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = INT_MIN;
+    __syncthreads();
+    int run = partial[blockIdx.x];
+    for (int k = 0; k < w; k++) run = wm[k] > run ? wm[k] : run;
+    run = excl > run ? excl : run;
+    #pragma unroll
+    for (int i = 0; i < 8; i++) if (b + i < n) v[b + i] = x[i] > run ? x[i] : run;
 }
 
 /* colhi (already prefix-maxed = bound on max_pos) -> per-column bound on max_pos2 */
