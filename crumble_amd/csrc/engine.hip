@@ -562,7 +562,7 @@ extern "C" int crumble_hip_run(crumble_hip *h)
         TrigItem *items = h->d_items.as<TrigItem>();
 
         STAGE("k_overdepth", 0);
-        CRUMBLE_LAUNCH_INDEP(k_overdepth, nblk(L, 256), 256, st, L, colrec, nplp, h->d_col_ord.as<int32_t>(),
+        CRUMBLE_LAUNCH_INDEP(k_overdepth, nblk((L + 3) / 4, 256), 256, st, L, colrec, nplp, h->d_col_ord.as<int32_t>(),
                              h->d_dpre.as<int64_t>(), h->d_trig_ord.as<int32_t>(), h->d_item_off.as<int32_t>(),
                              h->d_ins_ord.as<int32_t>(), h->d_epochs.as<Epoch>(), d_nep, P,
                              trigcol_pos, trigcol_off, inscol_pos, stats);
@@ -572,7 +572,10 @@ extern "C" int crumble_hip_run(crumble_hip *h)
         }
         if (n_trig > 0) {
             STAGE("k_emit", 0);
-            CRUMBLE_LAUNCH_INDEP(k_emit, nblk(n_trig, 64), 64, st, B, P, n_trig, trigcol_pos, trigcol_off, colrec, items);
+            if (h->n_segrec > h->n_reads + h->n_reads / 2)       /* long reads: few candidates per column */
+                CRUMBLE_LAUNCH_INDEP(k_emit_lanes, nblk(n_trig, 64), 64, st, B, P, n_trig, trigcol_pos, trigcol_off, colrec, items);
+            else
+                CRUMBLE_LAUNCH(k_emit, nblk(n_trig, 4), 256, st, B, P, n_trig, trigcol_pos, trigcol_off, colrec, items);
             STAGE("k_str", 0);
             CRUMBLE_LAUNCH_INDEP(k_str, nblk(n_items, 64), 64, st, B, P, n_items, items, d_overflow);
             STAGE("k_fold", 0);

@@ -901,35 +901,55 @@ k_epochs_par(int L, const uint32_t *colrec, const int32_t *col_ord, const int64_
 
 /* over-depth test per column (snp:1673-1681) + compaction of the trigger and
  * histogram columns. */
-__global__ void k_overdepth(int L, uint32_t *colrec, const int32_t *nplp, const int32_t *col_ord,
-                            const int64_t *dpre, const int32_t *trig_ord, const int32_t *item_off,
-                            const int32_t *ins_ord, const Epoch *ep, const int *n_ep,
-                            const DParams *P, int32_t *trigcol_pos, int32_t *trigcol_off,
-                            int32_t *inscol_pos, u64 *stats)
+__device__ __forceinline__ void overdepth_col(int i, uint32_t rec, int64_t ord, int n, int64_t dp, uint32_t *colrec,
+                                              const int32_t *trig_ord, const int32_t *item_off, const int32_t *ins_ord,
+                                              const Epoch *ep, int nep, double over_depth, int32_t *trigcol_pos,
+                                              int32_t *trigcol_off, int32_t *inscol_pos, u64 *stats)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L) return;
-    uint32_t rec = colrec[i];
     if (!(rec & CR_COUNTED) || (rec & CR_TOODEEP)) return;
-    const int64_t ord = col_ord[i];
     /* last epoch with ord_start <= ord.  Epochs are ~2^20 columns first and ~2^19 afterwards, so an
      * arithmetic guess is right or off by one: two probes instead of a dependent binary search */
-    const int nep = *n_ep;
     int lo = ord < (1 << 20) ? 0 : 1 + (int)((ord - (1 << 20)) >> 19);
     if (lo > nep - 1) lo = nep - 1;
     while (lo + 1 < nep && ep[lo + 1].ord_start <= ord) lo++;
     while (lo > 0 && ep[lo].ord_start > ord) lo--;
     const Epoch e = ep[lo];
-    const int n = nplp[i];
     const int64_t total_col = e.tc_start + (ord - e.ord_start + 1);
-    const int64_t total_depth = e.td_start + (dpre[i] + n - e.dpre_start);
-    if ((double)((int64_t)n * (total_col + 1)) > P->over_depth * (double)(total_depth + 1)) {
+    const int64_t total_depth = e.td_start + (dp + n - e.dpre_start);
+    if ((double)((int64_t)n * (total_col + 1)) > over_depth * (double)(total_depth + 1)) {
         rec |= CR_KEEP | CR_R_DEEP;
         colrec[i] = rec;
         stat_inc(stats, ST_OVER_DEPTH, true);
     }
     if (rec & CR_TRIG) { trigcol_pos[trig_ord[i]] = i; trigcol_off[trig_ord[i]] = item_off[i]; }
     if (rec & CR_HASINS) inscol_pos[ins_ord[i]] = i;
+}
+/* four consecutive columns per thread (16-byte loads of the per-position arrays) */
+__global__ void __launch_bounds__(256)
+k_overdepth(int L, uint32_t *colrec, const int32_t *nplp, const int32_t *col_ord,
+            const int64_t *dpre, const int32_t *trig_ord, const int32_t *item_off,
+            const int32_t *ins_ord, const Epoch *ep, const int *n_ep,
+            const DParams *P, int32_t *trigcol_pos, int32_t *trigcol_off,
+            int32_t *inscol_pos, u64 *stats)
+{
+    const int i0 = (int)(blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 >= L) return;
+    const int nep = *n_ep;
+    const double od = P->over_depth;
+    if (i0 + 3 < L) {
+        const uint4 r4 = *(const uint4 *)(colrec + i0);
+        if (!((r4.x | r4.y | r4.z | r4.w) & CR_COUNTED)) return;
+        const int4 o4 = *(const int4 *)(col_ord + i0), n4 = *(const int4 *)(nplp + i0);
+        const longlong2 d01 = *(const longlong2 *)(dpre + i0), d23 = *(const longlong2 *)(dpre + i0 + 2);
+        overdepth_col(i0,     r4.x, o4.x, n4.x, d01.x, colrec, trig_ord, item_off, ins_ord, ep, nep, od, trigcol_pos, trigcol_off, inscol_pos, stats);
+        overdepth_col(i0 + 1, r4.y, o4.y, n4.y, d01.y, colrec, trig_ord, item_off, ins_ord, ep, nep, od, trigcol_pos, trigcol_off, inscol_pos, stats);
+        overdepth_col(i0 + 2, r4.z, o4.z, n4.z, d23.x, colrec, trig_ord, item_off, ins_ord, ep, nep, od, trigcol_pos, trigcol_off, inscol_pos, stats);
+        overdepth_col(i0 + 3, r4.w, o4.w, n4.w, d23.y, colrec, trig_ord, item_off, ins_ord, ep, nep, od, trigcol_pos, trigcol_off, inscol_pos, stats);
+    } else {
+        for (int i = i0; i < L; i++)
+            overdepth_col(i, colrec[i], col_ord[i], nplp[i], dpre[i], colrec, trig_ord, item_off, ins_ord, ep, nep, od,
+                          trigcol_pos, trigcol_off, inscol_pos, stats);
+    }
 }
 
 /* ------------------------------------------------------------------------ */
@@ -975,9 +995,42 @@ k_inshist(DBatch B, const DParams *P, int n_ins, const int32_t *inscol_pos,
 }
 
 /* ------------------------------------------------------------------------ */
-/* Ordered trigger list of each trigger column (snp:1695-1730). */
-__global__ void k_emit(DBatch B, const DParams *P, int n_trig, const int32_t *trigcol_pos,
-                       const int32_t *trigcol_off, const uint32_t *colrec, TrigItem *items)
+/* Ordered trigger list of each trigger column (snp:1695-1730).  One wave per trigger column: the lanes
+ * test 64 candidate reads at a time and the hits are written in file order (ballot + prefix popcount). */
+__global__ void __launch_bounds__(256)
+k_emit(DBatch B, const DParams *P, int n_trig, const int32_t *trigcol_pos,
+       const int32_t *trigcol_off, const uint32_t *colrec, TrigItem *items)
+{
+    const int t = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    if (t >= n_trig) return;                                     /* (the whole wave) */
+    const int c = trigcol_pos[t], apos = B.p0 + c, tile = c >> 6;
+    const int lo = B.tile_lo[tile], hi = B.tile_hi[tile];
+    const uint32_t rec = colrec[c];
+    const bool snp_kind = P->str_snp && CR_PRESERVE(rec);
+    int o = trigcol_off[t];
+    for (int base = lo; base < hi; base += 64) {
+        const int r = base + lane;
+        bool emit = false;
+        TrigItem it;
+        it.read = r; it.qpos1_kind = 0; it.lo = INT_MAX; it.hi = 0;
+        if (r < hi && apos >= B.pos[r] && apos < B.end[r]) {
+            Entry e;
+            resolve_entry(B, r, apos, e);
+            const int is_indel = (e.indel || e.is_del) ? 1 : 0;
+            if (!e.is_refskip && (is_indel || snp_kind)) {
+                emit = true;
+                it.qpos1_kind = (e.qpos + 1) | (is_indel << 30) | ((rec & CR_SCAN) ? 0 : (1 << 29));
+            }
+        }
+        const unsigned long long m = __ballot(emit);
+        if (emit) items[o + __popcll(m & ((1ull << lane) - 1ull))] = it;
+        o += __popcll(m);
+    }
+}
+
+/* the same with one lane per trigger column: long-read batches, where a column has only a few candidates */
+__global__ void k_emit_lanes(DBatch B, const DParams *P, int n_trig, const int32_t *trigcol_pos,
+                             const int32_t *trigcol_off, const uint32_t *colrec, TrigItem *items)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_trig) return;

@@ -47,6 +47,8 @@ struct dim3 {
 struct uint4 { unsigned x, y, z, w; };
 struct uint2 { unsigned x, y; };
 struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+struct longlong2 { long long x, y; };
 extern thread_local dim3 threadIdx, blockIdx;
 extern dim3 blockDim, gridDim;
 static const int warpSize = 64;
