@@ -85,3 +85,50 @@ def str_stress_batch(n_reads=400, seed=9):
         reads.append(dict(pos=pos, cigar=f"{L}M", seq=seq, qual=rng.integers(2, 60, L), mapq=60))
         pos += int(rng.integers(0, 30))
     return HostBatch.from_reads(reads)
+
+
+def pblock_stress(engine_factory, path, seed=3, n_reads=400):
+    """P-block seam (snp:803-834) on raw quality strings of every flavour: constant stretches with outliers,
+    binned values, drifting random walks (no jump but a range > 2*level), uniform noise; read lengths
+    0..300 so that segments start and end anywhere in the 16-byte chunks.  Returns the number of reads."""
+    import os
+    import oracle_lib as O
+    rng = np.random.default_rng(seed)
+    old = os.environ.get("CRUMBLE_HIP_PBLOCK")
+    os.environ["CRUMBLE_HIP_PBLOCK"] = path
+    try:
+        for level, qcap in ((8, 40), (1, 93), (2, 20), (16, 40), (40, 60), (70, 93), (3, 35)):
+            quals, so = [], [0]
+            for r in range(n_reads):
+                L = int(rng.choice([0, 1, 2, 15, 16, 17, 31, 33, 64, 100, 150, 151, 300]))
+                kind = rng.integers(0, 5)
+                if kind == 0:
+                    q = np.full(L, int(rng.integers(2, 94)))
+                    if L:
+                        k = rng.integers(0, L, max(1, L // 20)); q[k] = rng.integers(2, 94, len(k))
+                elif kind == 1:
+                    q = rng.choice([2, 11, 25, 37], L, p=[.05, .1, .25, .6])
+                elif kind == 2:
+                    q = np.clip(30 + np.cumsum(rng.integers(-level, level + 1, L)), 0, 93)
+                elif kind == 3:
+                    q = rng.integers(0, 94, L)
+                else:
+                    q = np.clip(40 + np.cumsum(rng.integers(-2, 3, L)), 0, 93)
+                quals.append(np.asarray(q, np.uint8)); so.append(so[-1] + L)
+            q = np.concatenate(quals) if quals else np.zeros(0, np.uint8)
+            so = np.asarray(so, np.int64)
+            eng = engine_factory(ca.preset_params(9, pblock=level, qcap=qcap))
+            try:
+                got = eng.pblock(so, q)
+            finally:
+                eng.close()
+            for r in range(n_reads):
+                a, b = so[r], so[r + 1]
+                want = O.pblock(q[a:b], level, qcap)
+                assert np.array_equal(got[a:b], want), (path, level, qcap, r, q[a:b].tolist(), got[a:b].tolist(), want.tolist())
+    finally:
+        if old is None:
+            os.environ.pop("CRUMBLE_HIP_PBLOCK", None)
+        else:
+            os.environ["CRUMBLE_HIP_PBLOCK"] = old
+    return n_reads

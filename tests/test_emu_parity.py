@@ -8,7 +8,7 @@ import pytest
 import crumble_amd as ca
 from crumble_amd import HostBatch
 import emu_lib
-from parity_util import assert_parity, synth_batch
+from parity_util import assert_parity, synth_batch, pblock_stress
 
 
 @pytest.mark.parametrize("level", [1, 5, 9])
@@ -38,6 +38,12 @@ def test_emu_pblock_paths(product, path, monkeypatch):
                   (synth_batch("panel", 0.001), ca.preset_params(9, pblock=3, keep="30-31")),
                   (synth_batch("hifi", 0.0002, read_len=3000), ca.preset_params(9, tech="pbccs"))):
         assert_parity(emu_lib.engine, p, hb, check_columns=False)
+
+
+@pytest.mark.parametrize("path", ["reads", "segments"])
+def test_emu_pblock_stress(product, path):
+    """The pblock operator seam on raw quality strings: jumps, drifts, outliers, every chunk alignment."""
+    pblock_stress(emu_lib.engine, path, n_reads=150)
 
 
 def test_emu_empty_and_passthrough(product):

@@ -7,7 +7,7 @@ import pytest
 import crumble_amd as ca
 from crumble_amd import HostBatch
 import oracle_lib as O
-from parity_util import assert_parity, synth_batch, cigar_zoo
+from parity_util import assert_parity, synth_batch, cigar_zoo, pblock_stress
 
 pytestmark = pytest.mark.gpu
 
@@ -75,6 +75,12 @@ def test_pblock_paths(product, path, monkeypatch):
                   (synth_batch("hifi", 0.002), ca.preset_params(9, tech="pbccs")),
                   (synth_batch("hifi", 0.002), ca.preset_params(9, pblock=2))):
         assert_parity(gpu_engine, p, hb, check_columns=False)
+
+
+@pytest.mark.parametrize("path", ["reads", "segments"])
+def test_pblock_stress(product, path):
+    """The pblock operator seam on raw quality strings: jumps, drifts, outliers, every chunk alignment."""
+    pblock_stress(gpu_engine, path, n_reads=2000)
 
 
 def test_empty_and_passthrough(product):

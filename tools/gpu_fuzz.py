@@ -12,6 +12,7 @@ s0, n = int(sys.argv[1]), int(sys.argv[2])
 bad, t0 = 0, time.time()
 for seed in range(s0, s0 + n):
     p, hb, desc = random_case(seed, max_bases=300_000)
+    os.environ["CRUMBLE_KCOL_PERM"] = str(seed & 1)          # both k_columns accumulate variants, whatever the batch
     try:
         assert_parity(lambda q: ca.Engine(q, 0), p, hb)
         if seed % 10 == 0:
