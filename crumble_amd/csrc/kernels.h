@@ -777,26 +777,32 @@ k_scan_reduce(int L, const uint32_t *colrec, const int32_t *nplp,
     }
 }
 
-/* one workgroup: exclusive scan of the chunk partials; totals -> partial[nchunks] */
+/* one workgroup: exclusive scan of the chunk partials; totals -> partial[nchunks].  The partials are taken
+ * in tiles of 1024 (thread t <- entry base + t: coalesced), each tile scanned by the workgroup (wave shuffles
+ * + the 16 wave totals in LDS), the carry running from tile to tile. */
 __global__ void __launch_bounds__(1024)
 k_scan_partials(ScanVal *partial, int nchunks)
 {
     __shared__ ScanVal ws[16];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nt = blockDim.x;
-    const int per = (nchunks + nt - 1) / nt;
-    const int b = (int)threadIdx.x * per, e = (b + per < nchunks) ? b + per : nchunks;
-    ScanVal acc = {0, 0, 0, 0, 0, 0, 0};
-    for (int i = b; i < e; i++) scanval_add(acc, partial[i]);
-    ScanVal inc = scanval_wave_incl(acc, lane);
-    if (lane == 63) ws[w] = inc;
-    __syncthreads();
-    ScanVal run = {0, 0, 0, 0, 0, 0, 0};
-    for (int j = 0; j < w; j++) scanval_add(run, ws[j]);
-    /* exclusive prefix of this thread = run + inc - acc */
-    run.depth += inc.depth - acc.depth; run.cols += inc.cols - acc.cols; run.trigcols += inc.trigcols - acc.trigcols;
-    run.items += inc.items - acc.items; run.ins += inc.ins - acc.ins; run.toodeep += inc.toodeep - acc.toodeep;
-    for (int i = b; i < e; i++) { ScanVal v = partial[i]; partial[i] = run; scanval_add(run, v); }
-    if ((int)threadIdx.x == nt - 1) partial[nchunks] = run;   /* last thread ends with the grand total */
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+    ScanVal carry = {0, 0, 0, 0, 0, 0, 0};
+    for (int base = 0; base < nchunks; base += (int)blockDim.x) {
+        const int i = base + (int)threadIdx.x;
+        ScanVal v = {0, 0, 0, 0, 0, 0, 0};
+        if (i < nchunks) v = partial[i];
+        const ScanVal inc = scanval_wave_incl(v, lane);
+        if (lane == 63) ws[w] = inc;
+        __syncthreads();
+        ScanVal run = carry;
+        for (int j = 0; j < w; j++) scanval_add(run, ws[j]);
+        /* exclusive prefix of this entry = run + inc - v */
+        run.depth += inc.depth - v.depth; run.cols += inc.cols - v.cols; run.trigcols += inc.trigcols - v.trigcols;
+        run.items += inc.items - v.items; run.ins += inc.ins - v.ins; run.toodeep += inc.toodeep - v.toodeep;
+        if (i < nchunks) partial[i] = run;
+        for (int j = 0; j < nw; j++) scanval_add(carry, ws[j]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[nchunks] = carry;           /* the grand total */
 }
 
 __global__ void __launch_bounds__(256)

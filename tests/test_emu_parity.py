@@ -132,3 +132,22 @@ def test_emu_find_str_stress(product):
     for i in range(len(idx)):
         assert O.mask_lc(p, hb, int(idx[i]), int(kind[i]), int(qpos1[i])) == (lo[i], hi[i]), (i, idx[i], qpos1[i])
     eng.close()
+
+
+def test_emu_long_sparse_contig(product):
+    """> 2^21 positions (more than 1024 scan chunks: the tile-to-tile carry of k_scan_partials, several
+    prefix-max chunks) with a handful of read clusters, some with indels so that triggers exist."""
+    rng = np.random.default_rng(5)
+    reads = []
+    for start in (100, 700_000, 1_400_000, 2_150_000, 2_200_000):
+        pos = start
+        for i in range(40):
+            seq = "".join(rng.choice(list("ACGT"), 100))
+            cigar = "100M" if i % 5 else "48M2D50M2S"
+            if cigar != "100M":
+                seq = seq[:98] + "AA"
+            reads.append(dict(pos=pos, cigar=cigar, seq=seq, qual=rng.integers(5, 41, 100), mapq=int(rng.choice([0, 60]))))
+            pos += int(rng.integers(0, 6))
+    hb = HostBatch.from_reads(reads)
+    for level in (5, 9):
+        assert_parity(emu_lib.engine, ca.preset_params(level), hb)
