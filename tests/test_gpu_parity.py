@@ -30,6 +30,14 @@ def test_chr20_running_depth_epochs(product, level):
     assert_parity(gpu_engine, ca.preset_params(level, over_depth=1.05), hb, check_columns=False)
 
 
+def test_chr20_many_scan_chunks(product):
+    """9.4 M columns: more than 1024 chunks in the position scan (the tile-to-tile carry of k_scan_partials),
+    several halvings of the running depth average, thousands of prefix-max chunks."""
+    hb = synth_batch("chr20", 0.15)
+    assert hb.pos.max() - hb.pos.min() > 1024 * 8192
+    assert_parity(gpu_engine, ca.preset_params(5), hb)
+
+
 def test_ce_like(product):
     assert_parity(gpu_engine, ca.preset_params(1), synth_batch("ce", 1.0))
 
