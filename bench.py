@@ -37,6 +37,23 @@ def prefix_batch(hb, n_reads):
                      hb.cig_off[:n + 1], hb.cigar[:nc], hb.bases[:nb], hb.quals[:nb])
 
 
+def _host_threads():
+    """Threads the BAM reader/writer uses: min(visible CPUs, affinity mask, cgroup cpu.max quota) -- the rule of
+    crumble_amd/csrc/bamio.c."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def file_to_file(hb, args, device):
     """Metric (ii): the same contig as a BAM file through the crumble-hip driver (BGZF inflate + BAM parse +
     H2D + kernels + D2H + BGZF deflate), wall clock of the whole process."""
@@ -59,7 +76,7 @@ def file_to_file(hb, args, device):
         st = [float(x) for x in m.groups()] if m else [None] * 4
         return {"value": round(hb.n_bases / wall / 1e9, 4), "unit": "Gbases/s", "process_wall_s": round(wall, 2),
                 "loop_s": st[0], "read_parse_s": st[1], "gpu_incl_pcie_s": st[2], "deflate_write_s": st[3],
-                "host_threads": os.cpu_count(), "in_bytes": os.path.getsize(src), "out_bytes": os.path.getsize(dst),
+                "host_threads": _host_threads(), "host_cpus_visible": os.cpu_count(), "in_bytes": os.path.getsize(src), "out_bytes": os.path.getsize(dst),
                 "note": "BAM (zlib level 1) -> crumble-hip -> BAM; includes process start, hipInit and engine creation"}
     finally:
         for f in (src, dst):
