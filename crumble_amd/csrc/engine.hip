@@ -64,7 +64,7 @@ struct crumble_hip {
     /* work lists */
     DevBuf d_trigcol_pos, d_trigcol_off, d_inscol_pos, d_items, d_colhi, d_ub, d_pmax_partial, d_trig_mx2;
     /* outputs */
-    DevBuf d_out, d_rflags, d_keepf, d_b15f, d_blk_read, d_kept;
+    DevBuf d_out, d_rflags, d_keepf, d_b15f, d_blk_read, d_chunk_read, d_kept;
     DBatch B;
     bool have_batch = false, have_run = false;
     unsigned persistent_blocks = 1024;
@@ -226,7 +226,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
         &h->d_trigcnt, &h->d_dpre, &h->d_col_ord, &h->d_trig_ord, &h->d_item_off, &h->d_ins_ord,
         &h->d_pos_mn2, &h->d_partial, &h->d_epochs, &h->d_ht, &h->d_trigcol_pos, &h->d_trigcol_off,
         &h->d_inscol_pos, &h->d_items, &h->d_colhi, &h->d_ub, &h->d_pmax_partial, &h->d_trig_mx2,
-        &h->d_out, &h->d_rflags, &h->d_keepf, &h->d_b15f, &h->d_blk_read, &h->d_kept };
+        &h->d_out, &h->d_rflags, &h->d_keepf, &h->d_b15f, &h->d_blk_read, &h->d_chunk_read, &h->d_kept };
     for (DevBuf *b : all) b->release();
     if (h->events_ok) for (int i = 0; i <= MAX_STAGES; i++) (void)hipEventDestroy(h->ev[i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -402,9 +402,16 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
             if ((e = h->d_ufirst.reserve((size_t)(B.n_units + 2) * 4))) return e;
             CRUMBLE_LAUNCH_INDEP(k_unit_first, nblk(B.n_units + 1, 256), 256, st, B.n_units, B.n_tiles, cum, h->d_ufirst.as<int32_t>());
         }
-        if (nb > 0)
+        if (nb > 0) {
             CRUMBLE_LAUNCH_INDEP(k_p0_blkread, nblk((int64_t)nblkb, 256), 256, st, (int64_t)((nb + 63) / 64), n,
                                  h->d_seq_off.as<int64_t>(), h->d_blk_read.as<int32_t>());
+            if (!(tot.nseg > n + n / 2)) {                      /* short reads: k_replay_fast's per-chunk table */
+                const int64_t nch = (nb + 15) / 16;
+                if ((e = h->d_chunk_read.reserve((size_t)(nch + 1) * 4))) return e;
+                CRUMBLE_LAUNCH_INDEP(k_p0_chunkread, nblk(nch, 256), 256, st, nch, n, h->d_seq_off.as<int64_t>(),
+                                     h->d_blk_read.as<int32_t>(), h->d_chunk_read.as<int32_t>());
+            }
+        }
     }
     B.pos = h->d_pos.as<int32_t>(); B.end = h->d_end.as<int32_t>();
     B.mapq = h->d_mapq.as<uint8_t>(); B.inplp = h->d_inplp.as<uint8_t>();
@@ -606,7 +613,7 @@ extern "C" int crumble_hip_run(crumble_hip *h)
             uint8_t *act = h->d_act.as<uint8_t>() + ACT_PAD;
             if (L > 0) CRUMBLE_LAUNCH_INDEP(k_actions, nblk(L, 256), 256, st, L, colrec, act);
             CRUMBLE_LAUNCH_INDEP(k_replay_fast, nblk((nb + 15) / 16, 256), 256, st, B, P, colrec, act,
-                                 h->d_blk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(),
+                                 h->d_chunk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(),
                                  h->d_b15f.as<uint8_t>());
             CRUMBLE_LAUNCH(k_replay_reads, nblk(n, 256), 256, st, B, P, colrec,
                            h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(), h->d_b15f.as<uint8_t>());

@@ -1717,7 +1717,7 @@ __global__ void k_actions(int L, const uint32_t *__restrict__ colrec, uint8_t *_
 
 __global__ void __launch_bounds__(256)
 k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restrict__ colrec,
-              const uint8_t *__restrict__ act, const int32_t *__restrict__ blk_read,
+              const uint8_t *__restrict__ act, const int32_t *__restrict__ chunk_read,
               uint8_t *__restrict__ out, uint8_t *__restrict__ keepf, uint8_t *__restrict__ b15f)
 {
     const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
@@ -1729,9 +1729,8 @@ k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
     const uint32_t QC = PB4(P->qcap), QH = PB4(P->qhigh), QL = PB4(P->qlow), CUT = PB4(P->qcutoff);
     const bool reduce = P->reduce_qual != 0, binary = P->binary_qual != 0;
     const int min_mqual = P->min_mqual;
-    int64_t r = blk_read[g0 >> 6];
+    int64_t r = chunk_read[g0 >> 4];                          /* the read of byte g0 (table built with the batch) */
     ReadRec rr = B.rr[r];
-    while (g0 >= rr.so + rr.lq) { r++; rr = B.rr[r]; }
     /* The chunk's bytes belong to one read, or -- at a read boundary, i.e. in some lane of nearly every
      * wave -- to two: up to two reads are gathered into slots and done in ONE pass of the packed body
      * (per-byte merge of their action bytes); only chunks that touch more than two single-match reads

@@ -13,7 +13,7 @@
  *                   (SURVEY.md App. C), ReadRec, base->column table and the list of bases that
  *                   D/N columns report (replay)
  *   k_p0_keys, k_pmax_*, k_p0_tiles   candidate ranges per 64-column tile (reads and ops)
- *   k_p0_blkread    owning read of every 64-base block of the flat base array
+ *   k_p0_blkread    owning read of every 64-base block of the flat base array (k_p0_chunkread: of every 16-base chunk)
  */
 #ifndef CRUMBLE_P0_KERNELS_H
 #define CRUMBLE_P0_KERNELS_H
@@ -263,6 +263,19 @@ __global__ void k_p0_blkread(int64_t nblocks, int64_t n, const int64_t *__restri
     int64_t lo = 0, hi = n;                                /* first r with seq_off[r + 1] > g0 */
     while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (seq_off[mid + 1] <= g0) lo = mid + 1; else hi = mid; }
     blk_read[b] = (int32_t)(lo < n ? lo : n - 1);
+}
+
+/* the same per 16-base chunk, from the block table (short-read batches: k_replay_fast starts its chunk
+ * without walking forward from the block's read -- one dependent load less for every wave) */
+__global__ void k_p0_chunkread(int64_t nchunks, int64_t n, const int64_t *__restrict__ seq_off,
+                               const int32_t *__restrict__ blk_read, int32_t *__restrict__ chunk_read)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    const int64_t g0 = c * 16;
+    int64_t r = blk_read[c >> 2];
+    while (r + 1 < n && seq_off[r + 1] <= g0) r++;
+    chunk_read[c] = (int32_t)r;
 }
 
 /* Work split of k_columns: an estimated cost per 64-column tile (its candidate records plus a constant
