@@ -343,8 +343,8 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
          * when few base calls disagree with their column.  Estimate the batch's error rate from a sample of its
          * qualities; measured break-even is near 2 % (see kernels.h).  CRUMBLE_KCOL_PERM=0|1 overrides. */
         double esum = 0; int64_t cnt = 0;
-        static double q2e[128]; static bool q2e_init = false;
-        if (!q2e_init) { for (int q = 0; q < 128; q++) q2e[q] = pow(10.0, -q / 10.0); q2e_init = true; }
+        double q2e[128];                                     /* (per call: handles may be used from several threads) */
+        for (int q = 0; q < 128; q++) q2e[q] = pow(10.0, -q / 10.0);
         const int64_t step = nb > 65536 ? nb / 65536 : 1;
         for (int64_t i = 0; i < nb; i += step, cnt++) esum += q2e[b->quals[i] & 127];
         h->col_perm = cnt > 0 && esum < 0.02 * (double)cnt;
