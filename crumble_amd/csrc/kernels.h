@@ -1587,6 +1587,18 @@ k_replay_flat(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
     const int nn = (B.n_bases - g0 < RPL_NB) ? (int)(B.n_bases - g0) : RPL_NB;
     const bool any_pres = P->any_preserve != 0;
     const int min_mqual = P->min_mqual;
+    /* the lane's qualities and bases first: nothing below depends on them until phase 3, so their latency runs
+     * beside the read-record / column-table / column-record chain of phases 1 and 2 */
+    uint32_t qw[RPL_NB / 4], bw[RPL_NB / 4];
+    if (nn == RPL_NB) {
+        const uint4 q4 = *(const uint4 *)(B.quals + g0), b4 = *(const uint4 *)(B.bases + g0);
+        qw[0] = q4.x; qw[1] = q4.y; qw[2] = q4.z; qw[3] = q4.w;
+        bw[0] = b4.x; bw[1] = b4.y; bw[2] = b4.z; bw[3] = b4.w;
+    } else {
+        #pragma unroll
+        for (int k = 0; k < RPL_NB / 4; k++) { qw[k] = 0; bw[k] = 0; }
+        for (int k = 0; k < nn; k++) { qw[k >> 2] |= (uint32_t)B.quals[g0 + k] << (8 * (k & 3)); bw[k >> 2] |= (uint32_t)B.bases[g0 + k] << (8 * (k & 3)); }
+    }
     /* phase 1: owning read and column of each base (reads are laid out back to back in file
      * order; at most a few read changes inside RPL_NB bases) */
     int64_t r = blk_read[g0 >> 6];
@@ -1634,16 +1646,6 @@ k_replay_flat(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
     } else {
         #pragma unroll
         for (int k = 0; k < RPL_NB; k++) { const uint32_t v = colrec[cidx[k] >= 0 ? cidx[k] : 0]; rec[k] = cidx[k] >= 0 ? v : CR_ALLREFSKIP; }
-    }
-    uint32_t qw[RPL_NB / 4], bw[RPL_NB / 4];
-    if (nn == RPL_NB) {
-        const uint4 q4 = *(const uint4 *)(B.quals + g0), b4 = *(const uint4 *)(B.bases + g0);
-        qw[0] = q4.x; qw[1] = q4.y; qw[2] = q4.z; qw[3] = q4.w;
-        bw[0] = b4.x; bw[1] = b4.y; bw[2] = b4.z; bw[3] = b4.w;
-    } else {
-        #pragma unroll
-        for (int k = 0; k < RPL_NB / 4; k++) { qw[k] = 0; bw[k] = 0; }
-        for (int k = 0; k < nn; k++) { qw[k >> 2] |= (uint32_t)B.quals[g0 + k] << (8 * (k & 3)); bw[k >> 2] |= (uint32_t)B.bases[g0 + k] << (8 * (k & 3)); }
     }
     /* phase 3 */
     const int qcap = P->qcap, qhigh = P->qhigh, qlow = P->qlow;
