@@ -44,7 +44,15 @@ struct DTables {
     double e_tab2[1001];    /* exp(i/10), i = -500..500  (index +500) */
     double min_e_exp;       /* DBL_MIN_EXP*log(2)+1  snp:540 */
     uint8_t adj[65536];     /* [mapq][qual] -> adjusted quality, snp:632-638 */
+    /* the same lookups with this engine's parameters folded in (k_columns2 stages table ROW INDICES):
+     *   capc[q]     = clamp(cap_quality(q), 1, 100)            the row of a quality without CONS_MQUAL (snp:1325, 641)
+     *   adjc[m][q]  = clamp(adj[m][cap_quality(q)], 1, 100)    the row with CONS_MQUAL (snp:632-641)
+     *   pvc[q]      = preserve_qual[cap_quality(q)]            call_preserve input (snp:611-623) */
+    uint8_t capc[256];
+    uint8_t pvc[256];
+    uint8_t adjc[65536];
 };
+#define BASE_FRONT_PAD 64   /* bytes in front of bases[0] / quals[0]: k_columns2 loads whole 16-column segments */
 
 /* One reference-consuming CIGAR op (M,=,X / D / N) of a read, with what
  * htslib's resolve_cigar2 would report on its last column. */
@@ -86,7 +94,7 @@ struct SegRec {
     int32_t  lq;            /* l_qseq                                                      */
     int32_t  qoff;          /* M: qpos = qoff + apos;  D/N: qpos = qoff (the next base)    */
     int32_t  indel_after;   /* bam_pileup1_t.indel on the op's last column                 */
-    uint32_t info;          /* mapq | type << 8 | SR_* flags                               */
+    uint32_t info;          /* mapq | type << 8 | SR_* flags | mapq slot << 16 (255: none) */
 };
 
 /* Device-resident batch. Positions are stored relative to p0. */
@@ -108,7 +116,9 @@ struct DBatch {
     const SegRec *sr;
     const int32_t *stile_lo, *stile_hi;   /* candidate SegRec range per 64-column tile */
     const int32_t *unit_first;            /* [n_units+1] first tile of every KCOL_UNIT-sized slice of the tiles' cost prefix */
-    int32_t n_units, pad1_;
+    int32_t n_units;
+    int32_t n_slots;                      /* mapq values (other than hot_mq) with a slot in k_columns2's compact adjustment table */
+    const uint8_t *slot_mq;               /* [n_slots] slot -> mapq, most frequent first; SegRec.info carries the slot */
     const uint8_t *bases, *quals;
     const int32_t *tile_lo, *tile_hi;
     const int32_t *bed_start, *bed_end, *bed_pmax;

@@ -15,6 +15,7 @@
 #include <float.h>
 #include <vector>
 #include <string>
+#include <algorithm>
 #ifndef CRUMBLE_EMU
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -54,7 +55,7 @@ struct crumble_hip {
     hipStream_t stream = nullptr;
     crumble_params params;
     DParams hparams;
-    DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc;
+    DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc, d_mqslot;
     /* batch (inputs) */
     DevBuf d_pbdirty, d_ufirst, d_tcum, d_tpart, d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
            d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax;
@@ -69,6 +70,10 @@ struct crumble_hip {
     bool have_batch = false, have_run = false;
     unsigned persistent_blocks = 1024;
     bool col_perm = false;          /* k_columns<.., PERM>: picked per batch in crumble_hip_upload */
+    /* crumble_hip_set_option(): kernel choices that never change a result (tests force every variant) */
+    int opt_kcol = 0;               /* 0 auto (k_columns2 where it applies), 1 k_columns, 2 k_columns PERM, 3 k_columns2 */
+    int opt_pblock = 0;             /* 0 auto, 1 one lane per read, 2 segment-parallel */
+    int opt_replay = 0;             /* 0 auto, 1 k_replay_flat */
     int64_t n_reads = 0, n_bases = 0, n_cigar = 0, n_slow = 0, n_segrec = 0;
     ScanVal totals;
     /* timing */
@@ -81,7 +86,7 @@ struct crumble_hip {
 };
 
 /* ---------------------------------------------------------------- tables */
-static void build_tables(DTables *t)
+static void build_tables(DTables *t, const DParams *dp)
 {
     /* consensus_init(P_HET = 1e-6) for STECH_SOLEXA (snp:378-489) and the
      * function statics of calculate_consensus_pileup (snp:560-575), evaluated
@@ -126,6 +131,16 @@ static void build_tables(DTables *t)
             double ph = -3.0103 * (val + log_2);
             t->adj[m * 256 + q] = (uint8_t)ph;
         }
+    /* parameter-dependent compositions for k_columns2 (row indices of its LDS table) */
+    for (int q = 0; q < 256; q++) {
+        const int cq = (q > dp->qcap && !dp->preserve_qual[q]) ? dp->qcap : q;      /* cap_quality snp:1325-1332 */
+        t->capc[q] = (uint8_t)(cq < 1 ? 1 : (cq > 100 ? 100 : cq));
+        t->pvc[q] = dp->preserve_qual[cq];
+        for (int m = 0; m < 256; m++) {
+            const int a = t->adj[m * 256 + cq];
+            t->adjc[m * 256 + q] = (uint8_t)(a < 1 ? 1 : (a > 100 ? 100 : a));
+        }
+    }
 }
 
 static int fill_dparams(const crumble_params *p, DParams *d)
@@ -197,7 +212,7 @@ extern "C" crumble_hip *crumble_hip_create(const crumble_params *p, int device, 
 #endif
     tab = (DTables *)calloc(1, sizeof(DTables));
     if (!tab) return fail(CRUMBLE_ENOMEM);
-    build_tables(tab);
+    build_tables(tab, &h->hparams);
     if ((e = h->d_params.reserve(sizeof(DParams))) || (e = h->d_tables.reserve(sizeof(DTables))) ||
         (e = h->d_stats.reserve(CRUMBLE_ST_N * 8)) || (e = h->d_batch_stats.reserve(CRUMBLE_ST_N * 8)) ||
         (e = h->d_misc.reserve(256)))
@@ -218,7 +233,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    DevBuf *all[] = { &h->d_params, &h->d_tables, &h->d_stats, &h->d_batch_stats, &h->d_misc,
+    DevBuf *all[] = { &h->d_params, &h->d_tables, &h->d_stats, &h->d_batch_stats, &h->d_misc, &h->d_mqslot,
         &h->d_ufirst, &h->d_tcum, &h->d_tpart, &h->d_pbdirty, &h->d_pbwmm, &h->d_act, &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
         &h->d_slow_g, &h->d_slow_r, &h->d_cix, &h->d_sr, &h->d_stile_lo, &h->d_stile_hi, &h->d_rr, &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
         &h->d_cigar, &h->d_segs, &h->d_bases, &h->d_quals, &h->d_tile_lo, &h->d_tile_hi,
@@ -233,6 +248,30 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
     delete h;
 }
 
+extern "C" int crumble_hip_set_option(crumble_hip *h, const char *name, const char *value)
+{
+    if (!h || !name || !value) return CRUMBLE_EINVAL;
+    auto pick = [&](const char *const *names, int n) -> int {
+        for (int i = 0; i < n; i++) if (!strcmp(value, names[i])) return i;
+        return -1;
+    };
+    int v;
+    if (!strcmp(name, "kcol")) {
+        static const char *const nm[] = {"auto", "v1", "v1perm", "v2"};
+        if ((v = pick(nm, 4)) < 0) return CRUMBLE_EINVAL;
+        h->opt_kcol = v;
+    } else if (!strcmp(name, "pblock")) {
+        static const char *const nm[] = {"auto", "reads", "segments"};
+        if ((v = pick(nm, 3)) < 0) return CRUMBLE_EINVAL;
+        h->opt_pblock = v;
+    } else if (!strcmp(name, "replay")) {
+        static const char *const nm[] = {"auto", "flat"};
+        if ((v = pick(nm, 2)) < 0) return CRUMBLE_EINVAL;
+        h->opt_replay = v;
+    } else return CRUMBLE_EINVAL;
+    return CRUMBLE_OK;
+}
+
 /* ------------------------------------------------------------- P0 expand */
 static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b > 0 ? (n + b - 1) / b : 1); }
 
@@ -242,6 +281,17 @@ static int up(crumble_hip *h, DevBuf &d, const T *src, size_t n)
     int e = d.reserve((n ? n : 1) * sizeof(T) + 64);      /* slack: kernels read whole 16-byte vectors */
     if (e) return e;
     if (n) HIPCHK(hipMemcpyAsync(d.p, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    return CRUMBLE_OK;
+}
+
+/* bases / qualities: BASE_FRONT_PAD zeroed bytes in front (k_columns2 loads the whole 16-column segment that
+ * holds a read's first aligned base) */
+static int up_padded(crumble_hip *h, DevBuf &d, const uint8_t *src, size_t n)
+{
+    int e = d.reserve(n + 2 * BASE_FRONT_PAD + 64);
+    if (e) return e;
+    HIPCHK(hipMemsetAsync(d.p, 0, BASE_FRONT_PAD, h->stream));
+    if (n) HIPCHK(hipMemcpyAsync((uint8_t *)d.p + BASE_FRONT_PAD, src, n, hipMemcpyHostToDevice, h->stream));
     return CRUMBLE_OK;
 }
 
@@ -275,7 +325,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     /* 1. raw arrays */
     if ((e = up(h, h->d_pos, b->pos, n)) || (e = up(h, h->d_mapq, b->mapq, n)) || (e = up(h, h->d_flag, b->flag, n)) ||
         (e = up(h, h->d_seq_off, b->seq_off, n + 1)) || (e = up(h, h->d_cig_off, b->cig_off, n + 1)) ||
-        (e = up(h, h->d_cigar, b->cigar, nc)) || (e = up(h, h->d_bases, b->bases, nb)) || (e = up(h, h->d_quals, b->quals, nb)))
+        (e = up(h, h->d_cigar, b->cigar, nc)) || (e = up_padded(h, h->d_bases, b->bases, nb)) || (e = up_padded(h, h->d_quals, b->quals, nb)))
         return e;
     if (n == 0) {                                   /* seq_off[0] may not exist on the host side */
         const int64_t z = 0;
@@ -306,7 +356,8 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
                              h->d_flag.as<uint16_t>(), h->d_seq_off.as<int64_t>(), h->d_cig_off.as<int64_t>(),
                              h->d_cigar.as<uint32_t>(), h->d_inplp.as<uint8_t>(), h->d_end.as<int32_t>(), cnt, d_err, d_minmax);
         CRUMBLE_LAUNCH_INDEP(k_p0_sorted, nblk(n, 256), 256, st, n, h->d_pos.as<int32_t>(), h->d_inplp.as<uint8_t>(), d_err);
-        if (nb > 0) CRUMBLE_LAUNCH_INDEP(k_p0_quals, nblk((nb + 15) / 16, 256), 256, st, nb, h->d_quals.as<uint8_t>(), d_err);
+        if (nb > 0) CRUMBLE_LAUNCH_INDEP(k_p0_basequal, nblk((nb + 15) / 16, 256), 256, st, nb, h->d_bases.as<uint8_t>() + BASE_FRONT_PAD,
+                                         h->d_quals.as<uint8_t>() + BASE_FRONT_PAD, d_err);
         CRUMBLE_LAUNCH_INDEP(k_p0scan_reduce, nblk(nchunks, 64), 64, st, n, cnt, part, nchunks);
         CRUMBLE_LAUNCH_INDEP(k_p0scan_partials, 1, 1, st, part, nchunks);
         CRUMBLE_LAUNCH_INDEP(k_p0scan_apply, nblk(nchunks, 64), 64, st, n, cnt, part, nchunks);
@@ -332,24 +383,39 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     B.p0 = any ? res[1] : 0;
     B.L = any ? res[2] - res[1] : 0;
     B.n_tiles = (B.L + 63) / 64;
-    {   /* the mapq most reads carry: k_columns keeps a composed quality table for it in LDS */
-        int hist[256] = {0}, best = 0;
-        const int64_t step = n > 4096 ? n / 4096 : 1;
-        for (int64_t i = 0; i < n; i += step) hist[b->mapq[i]]++;
-        for (int i = 1; i < 256; i++) if (hist[i] > hist[best]) best = i;
+    {   /* the mapq most reads carry: the column kernels keep a composed quality table for it in LDS; the next
+         * KC2_SLOTS most frequent ones get a row of k_columns2's compact adjustment table (their slot travels in
+         * SegRec.info); anything else is looked up in global memory.  Performance hints only. */
+        int64_t hist[256] = {0};
+        for (int64_t i = 0; i < n; i++) hist[b->mapq[i]]++;
+        int order[256], best = 0;
+        for (int i = 0; i < 256; i++) { order[i] = i; if (hist[i] > hist[best]) best = i; }
         B.hot_mq = best;
+        std::sort(order, order + 256, [&](int x, int y) { return hist[x] != hist[y] ? hist[x] > hist[y] : x < y; });
+        uint8_t tab[256 + KC2_SLOTS];
+        memset(tab, 255, 256); memset(tab + 256, 0, KC2_SLOTS);
+        int ns = 0;
+        for (int k = 0; k < 256 && ns < KC2_SLOTS; k++) {
+            const int m = order[k];
+            if (m == best || hist[m] == 0) continue;
+            tab[m] = (uint8_t)ns; tab[256 + ns] = (uint8_t)m; ns++;
+        }
+        B.n_slots = ns;
+        if ((e = h->d_mqslot.reserve(sizeof tab))) return e;
+        HIPCHK(hipMemcpyAsync(h->d_mqslot.p, tab, sizeof tab, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));               /* tab is a stack buffer */
+        B.slot_mq = h->d_mqslot.as<uint8_t>() + 256;
     }
     {   /* k_columns variant (a performance choice only; both give the same bits): per-column base classes pay
          * when few base calls disagree with their column.  Estimate the batch's error rate from a sample of its
-         * qualities; measured break-even is near 2 % (see kernels.h).  CRUMBLE_KCOL_PERM=0|1 overrides. */
+         * qualities; measured break-even is near 2 % (see kernels.h).  Option "kcol" overrides. */
         double esum = 0; int64_t cnt = 0;
         double q2e[128];                                     /* (per call: handles may be used from several threads) */
         for (int q = 0; q < 128; q++) q2e[q] = pow(10.0, -q / 10.0);
         const int64_t step = nb > 65536 ? nb / 65536 : 1;
         for (int64_t i = 0; i < nb; i += step, cnt++) esum += q2e[b->quals[i] & 127];
         h->col_perm = cnt > 0 && esum < 0.02 * (double)cnt;
-        const char *ov = getenv("CRUMBLE_KCOL_PERM");
-        if (ov && (*ov == '0' || *ov == '1')) h->col_perm = *ov == '1';
+        if (h->opt_kcol == 1 || h->opt_kcol == 2) h->col_perm = h->opt_kcol == 2;
     }
     h->n_reads = n; h->n_bases = nb; h->n_cigar = nc;
     h->n_segrec = tot.nseg; h->n_slow = tot.nslow;  /* upper bound; the exact count is d_nslow */
@@ -373,7 +439,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
                              h->d_inplp.as<uint8_t>(), h->d_end.as<int32_t>(), cnt, part + nchunks,
                              h->d_segs.as<Seg>(), h->d_sr.as<SegRec>(), h->d_sr_ppos.as<int32_t>(), h->d_sr_pend.as<int32_t>(),
                              h->d_rr.as<ReadRec>(), h->d_seg_off.as<int64_t>(), h->d_cix.as<int32_t>(),
-                             h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(), d_nslow);
+                             h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(), d_nslow, h->d_mqslot.as<uint8_t>());
         CRUMBLE_LAUNCH_INDEP(k_p0_keys, nblk(n, 256), 256, st, n, h->d_pos.as<int32_t>(), h->d_end.as<int32_t>(),
                              h->d_inplp.as<uint8_t>(), h->d_kpos.as<int32_t>(), h->d_kend.as<int32_t>());
         if ((e = prefix_max(h, h->d_kpos.as<int32_t>(), n)) || (e = prefix_max(h, h->d_kend.as<int32_t>(), n)) ||
@@ -420,7 +486,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     B.segs = h->d_segs.as<Seg>(); B.rr = h->d_rr.as<ReadRec>(); B.cix = h->d_cix.as<int32_t>();
     B.sr = h->d_sr.as<SegRec>(); B.stile_lo = h->d_stile_lo.as<int32_t>(); B.stile_hi = h->d_stile_hi.as<int32_t>();
     B.unit_first = h->d_ufirst.as<int32_t>();
-    B.bases = h->d_bases.as<uint8_t>(); B.quals = h->d_quals.as<uint8_t>();
+    B.bases = h->d_bases.as<uint8_t>() + BASE_FRONT_PAD; B.quals = h->d_quals.as<uint8_t>() + BASE_FRONT_PAD;
     B.tile_lo = h->d_tile_lo.as<int32_t>(); B.tile_hi = h->d_tile_hi.as<int32_t>();
     B.bed_start = h->d_bed_start.as<int32_t>(); B.bed_end = h->d_bed_end.as<int32_t>();
     B.bed_pmax = h->d_bed_pmax.as<int32_t>();
@@ -455,9 +521,8 @@ static int launch_pblock(crumble_hip *h, hipStream_t st, int64_t n_reads, int64_
     if (nb <= 0 || n_reads <= 0) return CRUMBLE_OK;
     const DParams *P = h->d_params.as<DParams>();
     /* short reads: one lane per read keeps the lanes of a wave evenly loaded; long reads: segment-parallel.
-     * CRUMBLE_HIP_PBLOCK=reads|segments overrides the choice (tuning / tests). */
-    const char *force = getenv("CRUMBLE_HIP_PBLOCK");
-    const bool per_read = force ? !strcmp(force, "reads") : nb < 1024 * n_reads;
+     * Option "pblock" = reads|segments overrides the choice (tuning / tests). */
+    const bool per_read = h->opt_pblock ? h->opt_pblock == 1 : nb < 1024 * n_reads;
     const int64_t nwords = (nb + 63) / 64;
     int e;
     if (per_read && h->hparams.any_preserve) {          /* -k/-K: the byte-wise kernel knows the skip rule */
@@ -524,7 +589,6 @@ extern "C" int crumble_hip_run(crumble_hip *h)
         uint32_t *ht = h->d_ht.as<uint32_t>();
         HIPCHK(hipMemsetAsync(ht, 0, (size_t)L * 4, st));
         CRUMBLE_LAUNCH_INDEP(k_headtail, nblk(n, 256), 256, st, B, ht);
-        STAGE("k_columns", 2.0 * nb + 32.0 * n + 8.0 * h->n_cigar);
         const bool modeB = h->hparams.min_qual_B != 0;
         const unsigned kw = KCOL_THREADS / 64;
         unsigned grid = nblk(B.n_tiles, kw);
@@ -535,7 +599,22 @@ extern "C" int crumble_hip_run(crumble_hip *h)
 #define KCOL_LAUNCH2(M, MU, PE) CRUMBLE_LAUNCH((k_columns<M, MU, PE>), grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, ht, stats, (unsigned *)(d_overflow + 3))
 #define KCOL_LAUNCH(M) do { if (multi) { if (h->col_perm) KCOL_LAUNCH2(M, true, true); else KCOL_LAUNCH2(M, true, false); } \
                             else       { if (h->col_perm) KCOL_LAUNCH2(M, false, true); else KCOL_LAUNCH2(M, false, false); } } while (0)
-        if (modeA && modeB) KCOL_LAUNCH(2);
+        /* k_columns2 (kcol2.h) covers one active consensus; both at once (-q with -Q) and a disabled consensus
+         * (min_qual 0) stay with k_columns */
+        const bool use_cons = modeB ? true : h->hparams.min_qual_A != 0;
+        const bool v2 = (h->opt_kcol == 0 || h->opt_kcol == 3) && !(modeA && modeB) && use_cons;
+        STAGE(v2 ? "k_columns2" : "k_columns", 2.0 * nb + 32.0 * n + 8.0 * h->n_cigar);
+        if (v2) {
+            unsigned g2 = (h->persistent_blocks + 3) / 4;       /* one workgroup of KC2_WAVES waves per CU */
+            if (g2 > nblk(B.n_tiles, KC2_WAVES)) g2 = nblk(B.n_tiles, KC2_WAVES);
+#define KCOL2_LAUNCH3(MQ_, AP_, MU_) CRUMBLE_LAUNCH((k_columns2<MQ_, AP_, MU_>), g2, KC2_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, ht, stats, (unsigned *)(d_overflow + 3))
+#define KCOL2_LAUNCH(MQ_, AP_) do { if (multi) KCOL2_LAUNCH3(MQ_, AP_, true); else KCOL2_LAUNCH3(MQ_, AP_, false); } while (0)
+            if (modeB) { if (h->hparams.any_preserve) KCOL2_LAUNCH(true, true); else KCOL2_LAUNCH(true, false); }
+            else       { if (h->hparams.any_preserve) KCOL2_LAUNCH(false, true); else KCOL2_LAUNCH(false, false); }
+#undef KCOL2_LAUNCH
+#undef KCOL2_LAUNCH3
+        }
+        else if (modeA && modeB) KCOL_LAUNCH(2);
         else if (modeB)     KCOL_LAUNCH(1);
         else                KCOL_LAUNCH(0);
 #undef KCOL_LAUNCH
@@ -606,7 +685,7 @@ extern "C" int crumble_hip_run(crumble_hip *h)
                                  h->d_blk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(),
                                  h->d_b15f.as<uint8_t>());
         else if (nb > 0 && !(h->n_segrec > h->n_reads + h->n_reads / 2) && !h->hparams.any_preserve && h->hparams.qcutoff >= 0 && h->hparams.qcutoff < 128 &&
-                 h->hparams.qcap < 128 && !getenv("CRUMBLE_HIP_REPLAY_FLAT")) {
+                 h->hparams.qcap < 128 && h->opt_replay != 1) {
             /* short reads, no -k/-K/-S: action bytes + packed 16-base chunks + per-read edges (kernels.h) */
             int ea;
             if ((ea = h->d_act.reserve((size_t)L + 2 * ACT_PAD))) return ea;

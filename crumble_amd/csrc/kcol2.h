@@ -1,0 +1,546 @@
+/*
+ * kcol2.h -- k_columns2: the column kernel (calculate_consensus_pileup snp:533-797 + the column heuristics
+ * snp:1438-1773), restructured around a tile-sized pileup matrix staged in LDS.
+ *
+ * k_columns (kernels.h) walks a tile's candidate records one by one: a scalar 32-byte record load, a scalar
+ * decode, two dependent byte gathers and four exec-masked blocks of FP64 adds per (tile, record) -- 65 VALU +
+ * 62 SALU wave-instructions per record.  Here a wave handles a 64-column tile, 64 candidate records at a time,
+ * in three phases:
+ *
+ *   stage     lanes = candidate records: one coalesced 32-byte record load per lane (long-read batches, where
+ *             most ops of a read lie elsewhere: 8 bytes first, the rest only for the hits); the records that
+ *             reach the tile are compacted in file order (ballot + prefix popcount) into the wave's LDS.
+ *   produce   lanes = (record, 16-column segment), 16 records per step, the global loads of two steps in flight
+ *             together.  A lane loads the 16 bases and 16 qualities of its segment (aligned dwords + byte
+ *             funnel) and writes 16 two-byte entries of the wave's LDS matrix plane[row][column]:
+ *                 entry = quality << 5 | class          (class 7 = the row does not reach the column)
+ *             class: A C G T = 0..3 (the high nibble k_p0_basequal left in the base byte), 4 = '*' (D op), 5 = N.
+ *   consume   lanes = columns.  Row by row (file order): one ds_read_u16 and one 24-byte table row per lane
+ *             (both issued a group of four rows ahead), no global loads, no scalar decode.  The LDS table is
+ *             indexed by the RAW quality: rows composed for the batch's dominant mapq (cap_quality, the
+ *             (mapq, qual) adjustment and the 1..100 clamp folded in, DTables.adjc).  Rows of reads with another
+ *             mapq (flagged per row) take one more LDS hop through a compact per-mapq table; rows with a D/N
+ *             op, an indel behind the op or no SEQ ("rare", ~3 %) look at their record (in LDS) again.
+ *
+ * FP64 adds.  Base classes are numbered PER COLUMN relative to a key base (class 0; majority vote of a few rows
+ * that span the tile): class k = idx(base) ^ idx(key).  XOR by a constant permutes {A,C,G,T}, the genotype
+ * table (snp:656-683) is symmetric under it, col_unpermute() undoes it.  With sums indexed
+ *   S: 00 01 02 03 04 | 11 12 13 14 | 22 23 24 | 33 34 | 44      (4 = '*'),  sC: 0 1 2 3 4
+ * an entry of class 0 touches S00 S01 S02 S03 S04 sC0; an entry of class k = 1..4 touches S0k -- and sCk, Skk,
+ * Skj (j != 0, k), which NO class-0 entry ever touches.  So every row does its "inline" part at once, in file
+ * order, with per-add exec masks:
+ *   S00 += MM [class 0]   sC0 += om [0]   S0k += _M [class 0 or k], k = 1..4   (N: MM MM MM MM _M)
+ * and a mismatching lane parks the rest of its entry in a one-deep pending slot (a VGPR).  The parked part only
+ * touches sums that inline parts never touch, so deferring it reorders no sum; parked parts are applied in their
+ * own order: a lane that needs its slot again forces a wave-level drain first.  A drain costs about two rows and
+ * happens every ~7 rows at 3 % mismatches (once per row only under a real heterozygous site).  Every sum still
+ * receives exactly its own addends in file order: bit-identical to the reference, 6 FP64
+ * wave-instructions per row instead of 24.
+ */
+#ifndef CRUMBLE_KCOL2_H
+#define CRUMBLE_KCOL2_H
+
+#define KC2_R        64            /* candidates screened per pass = records staged in LDS */
+#ifndef KC2_PR
+#define KC2_PR       64            /* rows of the matrix (a pass with more hits is produced / consumed in groups) */
+#endif
+#ifndef KC2_WAVES
+#define KC2_WAVES    12            /* one workgroup per CU: 3 waves per SIMD, <= 168 VGPRs */
+#endif
+#define KC2_THREADS  (KC2_WAVES * 64)
+#ifndef KC2_SLOTS
+#define KC2_SLOTS    64            /* mapq values with a row of the compact adjustment table in LDS */
+#endif
+#ifndef KC2_LDS_EXP
+#define KC2_LDS_EXP  1             /* cons_finalize's exp tables in LDS */
+#endif
+#define KC2_RARE     0x10000u      /* row flags in rowinfo[]: bits 0-7 mapq, 8-15 slot */
+#define KC2_LOWMQ    0x20000u
+#define KC2_FULL     0x40000u      /* a match op spanning the whole tile: takes part in the key vote */
+#define KC2_NONHOT   0x80000u      /* mapq != the batch's dominant one (CONS_MQUAL only) */
+#define KC2_NROWTAB  (128 + 101)
+
+#ifdef CRUMBLE_EMU
+#define WAVE_SYNC() emu_wave_sync()
+__device__ __forceinline__ uint32_t kc2_alignbyte(uint32_t hi, uint32_t lo, unsigned sh)
+{ return sh ? (lo >> (8u * sh)) | (hi << (32u - 8u * sh)) : lo; }
+__device__ __forceinline__ uint32_t kc2_perm(uint32_t s0, uint32_t s1, uint32_t sel)      /* v_perm_b32 */
+{
+    const uint64_t src = ((uint64_t)s0 << 32) | s1;
+    uint32_t d = 0;
+    for (int i = 0; i < 4; i++) {
+        const unsigned s = (sel >> (8 * i)) & 255u;
+        const unsigned byte = s < 8 ? (unsigned)((src >> (8 * s)) & 255u) : (s == 0x0c ? 0u : 0xffu);   /* (8..11 unused here) */
+        d |= byte << (8 * i);
+    }
+    return d;
+}
+#define KC2_MASKED
+#else
+/* LDS traffic between the lanes of ONE wave: the hardware keeps a wave's DS operations in order; the fence only
+ * stops the compiler from moving them across */
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+__device__ __forceinline__ uint32_t kc2_alignbyte(uint32_t hi, uint32_t lo, unsigned sh)
+{ return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+__device__ __forceinline__ uint32_t kc2_perm(uint32_t s0, uint32_t s1, uint32_t sel)
+{ return __builtin_amdgcn_perm(s0, s1, sel); }
+/* hipcc turns `if (m) s += x;` into an unconditional add plus two v_cndmask_b32 per double; an empty volatile asm
+ * in the block keeps it an exec-masked block (one s_and_saveexec for several adds, skipped when no lane is in it) */
+#define KC2_MASKED asm volatile("")
+#endif
+
+struct __attribute__((aligned(4))) KC2U4 { uint32_t x, y, z, w; };     /* 16 bytes at a 4-byte aligned address */
+
+struct __attribute__((aligned(16))) KC2Wave {      /* one wave's LDS */
+    uint16_t plane[KC2_PR][64];
+    uint4    recs[KC2_R][2];                       /* SegRec: {pos, end, so.lo, so.hi} {lq, qoff, indel_after, info} */
+    uint32_t rowinfo[KC2_R];
+    int32_t  cnt[2][68];                           /* difference arrays over the tile's columns: all records / low-mapq records */
+};
+
+/* The 15 genotype sums and 5 discrepancy sums are NAMED LOCAL SCALARS of the kernel (permuted numbering, see the
+ * header), and the two routines below are macros over them.  Not arrays, not a struct passed by reference: hipcc
+ * merges the parked part's four look-alike class blocks into one block with computed addresses, and whatever is
+ * addressed that way lives in scratch memory (first builds: 150 scratch instructions, 15.5 ms). */
+#define KC2_SUMS_DECL \
+    double s00 = 0, s01 = 0, s02 = 0, s03 = 0, s04 = 0, s11 = 0, s12 = 0, s13 = 0, s14 = 0, s22 = 0, s23 = 0, s24 = 0, \
+           s33 = 0, s34 = 0, s44 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0; \
+    int nN = 0
+
+/* the parked part of a mismatching entry: pend = 0x10000 | its matrix entry (table row byte offset | class) */
+#define KC2_DRAIN() do { \
+    const unsigned pe_ = pend; \
+    if (pe_) { \
+        const double *rw_ = (const double *)(rowbase + (pe_ & 0xffe0u)); \
+        const double pMM = rw_[0], p_M = rw_[1], pom = rw_[2]; \
+        const unsigned rc_ = pe_ & 7u; \
+        const unsigned k_ = rc_ < 4u ? (rc_ ^ key) : rc_; \
+        if (k_ == 1u) { KC2_MASKED; d1 += pom; s11 += pMM; s12 += p_M; s13 += p_M; s14 += p_M; } \
+        if (k_ == 2u) { KC2_MASKED; d2 += pom; s12 += p_M; s22 += pMM; s23 += p_M; s24 += p_M; } \
+        if (k_ == 3u) { KC2_MASKED; d3 += pom; s13 += p_M; s23 += p_M; s33 += pMM; s34 += p_M; } \
+        if (k_ == 4u) { KC2_MASKED; d4 += pom; s14 += p_M; s24 += p_M; s34 += p_M; s44 += pMM; } \
+        if (k_ == 5u) { KC2_MASKED; nN++; s11 += pMM; s12 += pMM; s13 += pMM; s14 += p_M; s22 += pMM; s23 += pMM; s24 += p_M; \
+                        s33 += pMM; s34 += p_M; } \
+        pend = 0; \
+    } } while (0)
+
+/* One row of the matrix for this lane's column: entry v_ (table row byte offset | class; class 7 = not reached),
+ * the table row's MM_, _M_, om_.  The inline part of the entry (header) plus the pending-slot bookkeeping.
+ * On the GPU the common path is one hand-written block: hipcc's version of the same statements came to ~25 VALU,
+ * ~39 SALU and ~14 branches per row, and at three waves per SIMD the kernel was bound by instruction issue
+ * (710 cycles per row and wave); the block is 13 VALU + 10 SALU and no branch.  It changes EXEC inside and
+ * restores it; every mask is a wave-uniform SGPR pair. */
+#ifdef CRUMBLE_EMU
+#define KC2_ROW(v_, MM_, _M_, om_) do { \
+    const unsigned cls_ = (v_) & 7u; \
+    const bool cov_ = cls_ != 7u; \
+    const bool m0_ = cls_ == k0, m1_ = cls_ == k1, m2_ = cls_ == k2, m3_ = cls_ == k3; \
+    const unsigned long long B0_ = __ballot(m0_), B123_ = __ballot(m1_ || m2_ || m3_), Bc_ = __ballot(cov_); \
+    const unsigned long long mis_ = Bc_ & ~B0_; \
+    if (mis_ & ~B123_) {                                  /* a '*' or an N somewhere in the row (rare) */ \
+        if (cls_ == 4u) { s04 += (_M_); } \
+        if (cls_ == 5u) { s00 += (MM_); s01 += (MM_); s02 += (MM_); s03 += (MM_); s04 += (_M_); } \
+    } \
+    if (m0_) { s00 += (MM_); d0 += (om_); s04 += (_M_); } \
+    if (m0_ || m1_) { s01 += (_M_); } \
+    if (m0_ || m2_) { s02 += (_M_); } \
+    if (m0_ || m3_) { s03 += (_M_); } \
+    if (mis_) { \
+        const bool ml_ = cov_ && !m0_; \
+        if (__ballot(ml_ && pend != 0u)) KC2_DRAIN(); \
+        if (ml_) pend = 0x10000u | (v_); \
+    } } while (0)
+#else
+#define KC2_ROW(v_, MM_, _M_, om_) do { \
+    unsigned long long mis_, odd_, coll_, m0_, m1_, m2_, m3_, t_, sv_; \
+    unsigned cls_; \
+    asm volatile( \
+        "v_and_b32_e32 %[cls], 7, %[v]\n\t" \
+        "v_cmp_eq_u32_e64 %[m0], %[cls], %[k0]\n\t" \
+        "v_cmp_eq_u32_e64 %[m1], %[cls], %[k1]\n\t" \
+        "v_cmp_eq_u32_e64 %[m2], %[cls], %[k2]\n\t" \
+        "v_cmp_eq_u32_e64 %[m3], %[cls], %[k3]\n\t" \
+        "v_cmp_ne_u32_e64 %[t], 7, %[cls]\n\t" \
+        "s_mov_b64 %[sv], exec\n\t" \
+        "s_andn2_b64 %[mis], %[t], %[m0]\n\t" \
+        "s_or_b64 %[t], %[m1], %[m2]\n\t" \
+        "s_or_b64 %[t], %[t], %[m3]\n\t" \
+        "s_andn2_b64 %[odd], %[mis], %[t]\n\t" \
+        "s_mov_b64 exec, %[m0]\n\t" \
+        "v_add_f64 %[s00], %[s00], %[MM]\n\t" \
+        "v_add_f64 %[d0], %[d0], %[om]\n\t" \
+        "v_add_f64 %[s04], %[s04], %[_M]\n\t" \
+        "s_or_b64 exec, %[m0], %[m1]\n\t" \
+        "v_add_f64 %[s01], %[s01], %[_M]\n\t" \
+        "s_or_b64 exec, %[m0], %[m2]\n\t" \
+        "v_add_f64 %[s02], %[s02], %[_M]\n\t" \
+        "s_or_b64 exec, %[m0], %[m3]\n\t" \
+        "v_add_f64 %[s03], %[s03], %[_M]\n\t" \
+        "s_mov_b64 exec, %[mis]\n\t" \
+        "v_cmp_ne_u32_e64 %[coll], 0, %[pend]\n\t" \
+        "s_mov_b64 exec, %[sv]" \
+        : [cls] "=&v"(cls_), [m0] "=&s"(m0_), [m1] "=&s"(m1_), [m2] "=&s"(m2_), [m3] "=&s"(m3_), [t] "=&s"(t_), \
+          [sv] "=&s"(sv_), [mis] "=&s"(mis_), [odd] "=&s"(odd_), [coll] "=&s"(coll_), \
+          [s00] "+v"(s00), [s01] "+v"(s01), [s02] "+v"(s02), [s03] "+v"(s03), [s04] "+v"(s04), [d0] "+v"(d0) \
+        : [v] "v"(v_), [k0] "v"(k0), [k1] "v"(k1), [k2] "v"(k2), [k3] "v"(k3), [MM] "v"(MM_), [_M] "v"(_M_), [om] "v"(om_), \
+          [pend] "v"(pend) \
+        : "scc"); \
+    if (__builtin_expect(odd_ != 0ull, 0)) {              /* a '*' or an N somewhere in the row (rare) */ \
+        if (cls_ == 4u) { KC2_MASKED; s04 += (_M_); } \
+        if (cls_ == 5u) { KC2_MASKED; s00 += (MM_); s01 += (MM_); s02 += (MM_); s03 += (MM_); s04 += (_M_); } \
+    } \
+    if (__builtin_expect(coll_ != 0ull, 0)) KC2_DRAIN(); \
+    asm volatile( \
+        "s_mov_b64 %[sv], exec\n\t" \
+        "s_mov_b64 exec, %[mis]\n\t" \
+        "v_or_b32_e32 %[pend], 0x10000, %[v]\n\t" \
+        "s_mov_b64 exec, %[sv]" \
+        : [pend] "+v"(pend), [sv] "=&s"(sv_) : [v] "v"(v_), [mis] "s"(mis_)); \
+    } while (0)
+#endif
+
+#ifdef KC2_EXP_STAMP      /* diagnostic build: cycles per phase, summed over waves, into the unused stats slots 24..29 */
+#define KC2_STAMP(k_) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); tacc[k_] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define KC2_STAMP(k_) do { } while (0)
+#endif
+
+/* MQ: the active consensus uses CONS_MQUAL (mode B, snp:1535); ANYPRES: -k/-K/-y pbccs set preserve_qual[];
+ * MULTI: long reads (many ops per read: candidates are screened by their first 8 bytes) */
+template <bool MQ, bool ANYPRES, bool MULTI>
+__global__ void __launch_bounds__(KC2_THREADS)
+k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T,
+           uint32_t *__restrict__ colrec, int32_t *__restrict__ nplp_out,
+           int32_t *__restrict__ score_out, int32_t *__restrict__ trigcnt, const uint32_t *__restrict__ ht,
+           u64 *stats, unsigned *__restrict__ tile_ctr)
+{
+    /* [index] -> {MM, _M, 1 - q2p, preserve_qual}: 32-byte rows.  0..127: a raw quality of a read with the dominant
+     * mapq (or of any read without CONS_MQUAL); 128 + a: adjusted quality a */
+    __shared__ double sRow[KC2_NROWTAB * 4];
+    __shared__ uint8_t sAdjC[MQ ? KC2_SLOTS * 128 : 16];   /* [slot][raw quality] -> adjusted quality, other mapqs */
+    __shared__ uint8_t sPv[128];                           /* pvc[] (call_preserve input of a raw quality) */
+    __shared__ double sE[KC2_LDS_EXP ? CONS_NEXP : 2];     /* the reachable halves of the exp tables (cons_finalize) */
+    __shared__ unsigned sStat[32];
+    __shared__ KC2Wave sWave[KC2_WAVES];
+    const int hot_mq = MQ ? B.hot_mq : -1;
+    if (threadIdx.x < 32) sStat[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < KC2_NROWTAB; i += blockDim.x) {
+        const int a = i >= 128 ? i - 128 : (MQ ? (int)T->adjc[hot_mq * 256 + i] : (int)T->capc[i]);
+        sRow[i * 4] = T->MMd[a]; sRow[i * 4 + 1] = T->_Md[a]; sRow[i * 4 + 2] = T->omq[a];
+        long long pvb = i < 128 ? (long long)T->pvc[i] : 0;
+        memcpy(&sRow[i * 4 + 3], &pvb, 8);
+    }
+    if (MQ)
+        for (int i = threadIdx.x; i < B.n_slots * 128; i += blockDim.x)
+            sAdjC[i] = T->adjc[(int)B.slot_mq[i >> 7] * 256 + (i & 127)];
+    if (threadIdx.x < 128) sPv[threadIdx.x] = T->pvc[threadIdx.x];
+    if (KC2_LDS_EXP)
+        for (int i = threadIdx.x; i < CONS_NEXP; i += blockDim.x) sE[i] = i <= 500 ? T->e_tab2[i] : T->e_tab[i - 501];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    KC2Wave &W = sWave[threadIdx.x >> 6];
+    const char *rowbase = (const char *)sRow;
+    const int min_mqual = P->min_mqual;
+    const int rsub = lane >> 2, seg = lane & 3;
+    const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;     /* lanes below this one */
+#ifdef KC2_EXP_STAMP
+    long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = (long long)__builtin_amdgcn_s_memtime();
+#endif
+
+    for (;;) {
+    int t_begin, t_end;
+    {
+        int g = 0;
+        if (lane == 0) g = (int)atomicAdd(tile_ctr, 1u);
+        g = READLANE(g, 0);
+        if (g >= B.n_units) break;
+        t_begin = UNIFORM(B.unit_first[g]); t_end = UNIFORM(B.unit_first[g + 1]);
+    }
+    KC2_STAMP(0);
+    for (int tile = t_begin; tile < t_end; tile++) {
+        const int c = tile * 64 + lane;
+        const int apos = B.p0 + c;
+        const bool inr = c < B.L;
+        const int lo = UNIFORM(B.stile_lo[tile]), hi = UNIFORM(B.stile_hi[tile]);
+        const int c0 = B.p0 + tile * 64, c1 = c0 + 63;
+
+        ColState st;
+        KC2_SUMS_DECL;
+        st.depth = st.nN = st.n_plp = st.nref = st.low_mq = st.indel_cnt = 0;
+        st.clipped = st.n_overlap = st.n_isindel = st.has_ins = 0;
+        st.cp = 0;
+        int n_lq0 = 0;
+        unsigned pend = 0, key = 0;
+        bool first = true;
+        int wnext = lo;
+
+        while (wnext < hi) {
+            /* ---- stage: the records that reach the tile, compacted in file order into W.recs[0, nq); the two
+             * order-independent per-column counts (n_plp, and the entries of low-mapq reads snp:1663) come from
+             * difference arrays over the tile's columns, not from the rows */
+            int nq = 0;
+            bool anylow = false;
+            W.cnt[0][lane] = 0; W.cnt[1][lane] = 0;
+            if (lane < 4) { W.cnt[0][64 + lane] = 0; W.cnt[1][64 + lane] = 0; }
+            WAVE_SYNC();
+            while (wnext < hi) {
+                const int idx = wnext + lane;
+                bool ov = false;
+                uint4 r0, r1;
+                r0.x = r0.y = r0.z = r0.w = 0; r1 = r0;
+                if (idx < hi) {
+                    const uint4 *rp = (const uint4 *)&B.sr[idx];
+                    if (MULTI) {
+                        const int2 pe = *(const int2 *)rp;
+                        r0.x = (uint32_t)pe.x; r0.y = (uint32_t)pe.y;
+                    } else { r0 = rp[0]; r1 = rp[1]; }
+                    ov = (int)r0.y > c0 && (int)r0.x <= c1;
+                }
+                const unsigned long long m = __ballot(ov);
+                const int h = __popcll(m);
+                if (nq + h > KC2_R) break;                               /* this window opens the next pass */
+                bool lowrec = false;
+                if (ov) {
+                    if (MULTI) { const uint4 *rp = (const uint4 *)&B.sr[idx]; r0 = rp[0]; r1 = rp[1]; }
+                    const int slot = nq + __popcll(m & lt);
+                    W.recs[slot][0] = r0; W.recs[slot][1] = r1;
+                    int a = (int)r0.x - c0, b = (int)r0.y - c0;
+                    a = a < 0 ? 0 : a; b = b > 64 ? 64 : b;
+                    atomicAdd(&W.cnt[0][a], 1); atomicAdd(&W.cnt[0][b], -1);
+                    lowrec = (int)(r1.w & 255u) <= min_mqual;
+                    if (lowrec) { atomicAdd(&W.cnt[1][a], 1); atomicAdd(&W.cnt[1][b], -1); }
+                }
+                anylow = anylow || __ballot(lowrec) != 0ull;
+                nq += h;
+                wnext += 64;
+                if (!MULTI) break;                                       /* short reads: most candidates are hits */
+            }
+            if (nq == 0) continue;
+            WAVE_SYNC();
+            KC2_STAMP(1);
+            {   /* inclusive prefix sums of the difference arrays across the lanes */
+                int dn = W.cnt[0][lane], dl = anylow ? W.cnt[1][lane] : 0;
+                #pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int on = __shfl_up(dn, d), ol = anylow ? __shfl_up(dl, d) : 0;
+                    if (lane >= d) { dn += on; dl += ol; }
+                }
+                st.n_plp += dn; st.low_mq += dl;
+            }
+            for (int g0 = 0; g0 < nq; g0 += KC2_PR) {
+            const int rows = nq - g0 < KC2_PR ? nq - g0 : KC2_PR, rows4 = (rows + 3) & ~3;
+            /* ---- produce: 16 records per step, four lanes (16-column segments) each; two steps' loads in flight */
+            for (int s0 = 0; s0 < rows; s0 += 32) {
+                uint32_t bwr[2][5], qwr[2][5];
+                unsigned shb[2], vbm[2], clD[2], info2[2];
+                bool act[2], isMv[2];
+                #pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int row = s0 + 16 * e + rsub;
+                    act[e] = false; isMv[e] = true; shb[e] = 0; vbm[e] = 0; clD[e] = 0; info2[e] = 0;
+                    #pragma unroll
+                    for (int t = 0; t < 5; t++) { bwr[e][t] = 0; qwr[e][t] = 0; }
+                    if (row < rows) {
+                        const uint4 r0 = W.recs[g0 + row][0], r1 = W.recs[g0 + row][1];
+                        const int rpos = (int)r0.x, rend = (int)r0.y, lq = (int)r1.x, qoff = (int)r1.y;
+                        const int64_t so = (int64_t)(((uint64_t)r0.w << 32) | r0.z);
+                        const unsigned info = r1.w, ty = SR_TYPE(info);
+                        const int sc0 = c0 + 16 * seg;                       /* first column of the segment */
+                        int a = rpos - sc0, b = rend - sc0;                  /* columns [a, b) of it are reached */
+                        a = a < 0 ? 0 : a; b = b > 16 ? 16 : b;
+                        const bool cons = ty != SEG_N && lq > 0;             /* snp:589,594 */
+                        info2[e] = (info & 0x1fffffffu) | ((unsigned)(r1.z != 0) << 30) | ((unsigned)(lq == 0) << 31) |
+                                   ((unsigned)(ty == SEG_M && cons && rpos <= c0 && rend > c1) << 29);
+                        if (cons && a < b) {
+                            act[e] = true;
+                            vbm[e] = ((1u << b) - 1u) & ~((1u << a) - 1u);
+                            if (ty == SEG_M) {
+                                const int64_t A = so + (int64_t)qoff + (int64_t)sc0;   /* qpos = qoff + apos */
+                                const uint8_t *pb = B.bases + A;
+                                shb[e] = (unsigned)((uintptr_t)pb & 3u);         /* bases and quals share the byte phase */
+                                const uint8_t *pba = pb - shb[e], *pqa = B.quals + A - shb[e];
+                                const KC2U4 vb4 = *(const KC2U4 *)pba, vq4 = *(const KC2U4 *)pqa;
+                                bwr[e][0] = vb4.x; bwr[e][1] = vb4.y; bwr[e][2] = vb4.z; bwr[e][3] = vb4.w;
+                                qwr[e][0] = vq4.x; qwr[e][1] = vq4.y; qwr[e][2] = vq4.z; qwr[e][3] = vq4.w;
+                                bwr[e][4] = *(const uint32_t *)(pba + 16); qwr[e][4] = *(const uint32_t *)(pqa + 16);
+                            } else {                                     /* D: '*' with the quality of the next base; fence: read ends in D */
+                                isMv[e] = false;
+                                clD[e] = qoff < lq ? (unsigned)B.quals[so + qoff] : 0u;
+                            }
+                        }
+                    }
+                }
+                #pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int row = s0 + 16 * e + rsub;
+                    if (row < rows) {
+                        uint32_t out[8];
+                        #pragma unroll
+                        for (int t = 0; t < 8; t++) out[t] = 0x00ff00ffu;    /* class 7: not reached */
+                        if (act[e]) {
+                            uint32_t cw[4], qw[4];
+                            if (isMv[e]) {
+                                #pragma unroll
+                                for (int t = 0; t < 4; t++) {
+                                    cw[t] = (kc2_alignbyte(bwr[e][t + 1], bwr[e][t], shb[e]) >> 4) & 0x07070707u;
+                                    qw[t] = kc2_alignbyte(qwr[e][t + 1], qwr[e][t], shb[e]);
+                                }
+                            } else {
+                                #pragma unroll
+                                for (int t = 0; t < 4; t++) { qw[t] = clD[e] * 0x01010101u; cw[t] = 0x04040404u; }
+                            }
+                            const unsigned nvb = ~vbm[e];
+                            #pragma unroll
+                            for (int t = 0; t < 4; t++) {
+                                /* bytes of the columns the record does not reach -> 0xff (class 7) */
+                                const uint32_t notM = ((((nvb >> (4 * t)) & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;
+                                const uint32_t cm = cw[t] | notM;
+                                out[2 * t]     = (kc2_perm(0u, qw[t], 0x0c010c00u) << 5) | kc2_perm(0u, cm, 0x0c010c00u);
+                                out[2 * t + 1] = (kc2_perm(0u, qw[t], 0x0c030c02u) << 5) | kc2_perm(0u, cm, 0x0c030c02u);
+                            }
+                        }
+                        uint4 *dst = (uint4 *)&W.plane[row][16 * seg];
+                        uint4 o0, o1;
+                        o0.x = out[0]; o0.y = out[1]; o0.z = out[2]; o0.w = out[3];
+                        o1.x = out[4]; o1.y = out[5]; o1.z = out[6]; o1.w = out[7];
+                        dst[0] = o0; dst[1] = o1;
+                        if (seg == 0) {
+                            const unsigned info = info2[e], ty = SR_TYPE(info);
+                            const int mq = (int)(info & 255u);
+                            const bool rare = ty != SEG_M || (info >> 30) != 0u;       /* D/N op, indel behind it, no SEQ */
+                            W.rowinfo[row] = (info & 0xffu) | ((info >> 8) & 0xff00u) | (rare ? KC2_RARE : 0u) |
+                                             (((info >> 29) & 1u) ? KC2_FULL : 0u) |
+                                             ((MQ && mq != hot_mq) ? KC2_NONHOT : 0u);
+                        }
+                    }
+                }
+            }
+            for (int r = rows; r < rows4; r++) W.plane[r][lane] = (uint16_t)0x00ff;
+            WAVE_SYNC();
+            KC2_STAMP(2);
+
+            /* ---- consume */
+            const unsigned ri = lane < rows ? W.rowinfo[lane] : 0u;
+            const unsigned long long slowmask = __ballot((ri & (KC2_RARE | KC2_NONHOT)) != 0u);
+            if (first) {
+                /* class 0 of each column: Boyer-Moore majority over a few rows, preferably rows that span the tile
+                 * (ANY key gives the same sums; a minority key only sends the column's entries through the
+                 * pending slot) */
+                first = false;
+                unsigned long long fm = __ballot((ri & KC2_FULL) != 0u);
+                if (!fm) fm = rows >= 64 ? ~0ull : ((1ull << rows) - 1ull);
+                int cand = 0, cnt = 0;
+                for (int ns = 0; fm && ns < 7; ns++) {
+                    const int j = __builtin_ctzll(fm);
+                    fm &= fm - 1;
+                    const int cl = (int)(W.plane[j][lane] & 7u);
+                    if (cl < 4) {
+                        if (cnt == 0) { cand = cl; cnt = 1; }
+                        else cnt += (cl == cand) ? 1 : -1;
+                    }
+                }
+                key = (unsigned)cand;
+            }
+            const unsigned k0 = key, k1 = key ^ 1u, k2 = key ^ 2u, k3 = key ^ 3u;
+            unsigned vn[4];
+            #pragma unroll
+            for (int u = 0; u < 4; u++) vn[u] = W.plane[u][lane];
+#ifdef KC2_EXP_NOCONSUME
+            for (int j0 = 0; j0 < 4; j0 += 4) {
+#else
+            for (int j0 = 0; j0 < rows4; j0 += 4) {
+#endif
+                /* the four entries were read a group ahead; their table rows and the next group's entries go out
+                 * together, before any of this group's arithmetic */
+                unsigned ve[4];
+                double rMM[4], r_M[4], rom[4];
+                long long rpv[4];
+                #pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    ve[u] = vn[u];
+                    const double *rw = (const double *)(rowbase + (ve[u] & 0xffe0u));
+                    rMM[u] = rw[0]; r_M[u] = rw[1]; rom[u] = rw[2];
+                    if (ANYPRES) memcpy(&rpv[u], &rw[3], 8); else rpv[u] = 0;
+                }
+                if (j0 + 4 < rows4) {
+                    #pragma unroll
+                    for (int u = 0; u < 4; u++) vn[u] = W.plane[j0 + 4 + u][lane];
+                }
+                const unsigned slow4 = (unsigned)(slowmask >> j0) & 15u;
+                #pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (__builtin_expect(((slow4 >> u) & 1u) != 0u, 0)) {  /* uniform */
+                        const unsigned rinfo = UNIFORM(W.rowinfo[j0 + u]);
+                        if (MQ && (rinfo & KC2_NONHOT)) {                 /* another mapq: the adjustment, then the row (snp:632-641) */
+                            const unsigned q = ve[u] >> 5, slot = (rinfo >> 8) & 255u;
+                            const unsigned aq = slot < (unsigned)B.n_slots ? (unsigned)sAdjC[slot * 128u + (q & 127u)]
+                                                                           : (unsigned)T->adjc[(rinfo & 255u) * 256u + (q & 255u)];
+                            if (ANYPRES) rpv[u] = sPv[q & 127u];
+                            ve[u] = ((128u + aq) << 5) | (ve[u] & 7u);
+                            const double *rw = (const double *)(rowbase + (ve[u] & 0xffe0u));
+                            rMM[u] = rw[0]; r_M[u] = rw[1]; rom[u] = rw[2];
+                        }
+                        if (rinfo & KC2_RARE) {                           /* back to the record */
+                            const uint4 r0 = W.recs[g0 + j0 + u][0], r1 = W.recs[g0 + j0 + u][1];
+                            const int rpos = (int)r0.x, rend = (int)r0.y, lq = UNIFORM((int)r1.x), qoff = (int)r1.y;
+                            const int indel_after = (int)r1.z;
+                            const unsigned info = UNIFORM(r1.w), ty = SR_TYPE(info);
+                            const bool isM = ty == SEG_M, isN = ty == SEG_N;
+                            const bool cov = inr & ((unsigned)(apos - rpos) < (unsigned)(rend - rpos));
+                            const int e_indel = (apos == rend - 1) ? indel_after : 0;
+                            const bool isind = (e_indel != 0) || !isM;
+                            const bool head = (info & SR_FIRST) && apos == rpos, tail = (info & SR_LAST) && apos == rend - 1;
+                            st.indel_cnt += (cov && isind) ? 1 : 0;                    /* snp:1664 */
+                            st.nref += (cov && isN) ? 1 : 0;                           /* snp:1468 */
+                            st.n_isindel += (cov && !isN && isind) ? 1 : 0;
+                            st.has_ins |= (cov && !isN && !head && !tail && e_indel > 0) ? 1 : 0;   /* snp:1708 */
+                            if (lq == 0) n_lq0 += cov ? 1 : 0;
+                            if (isN || lq == 0) continue;                /* no consensus entry (snp:589,594): the row is empty */
+                            if (ANYPRES && cov && e_indel > 0) {         /* qualities of the inserted bases, snp:616-622 */
+                                const int64_t so = (int64_t)(((uint64_t)r0.w << 32) | r0.z);
+                                const int e_qpos = isM ? qoff + apos : qoff;
+                                for (int ins = 0; ins < e_indel; ins++) {
+                                    const int qi = e_qpos + 1 + ins;
+                                    if (qi < lq && T->pvc[B.quals[so + qi]]) st.cp |= 1u << 4;
+                                }
+                            }
+                        }
+                    }
+                    KC2_ROW(ve[u], rMM[u], r_M[u], rom[u]);
+                    if (ANYPRES) {                                        /* call_preserve bits, snp:611-623 */
+                        const unsigned pv = (unsigned)rpv[u] & 3u, cl = ve[u] & 7u;
+                        if (cl != 7u && pv) { st.cp |= 1u << cl; if (pv > 1u) st.cp |= (1u << cl) << 8; }
+                    }
+                }
+            }
+            WAVE_SYNC();                                                 /* the next group / pass overwrites plane / recs */
+            KC2_STAMP(3);
+            }
+        }
+        KC2_DRAIN();
+        st.S[0] = s00; st.S[1] = s01; st.S[2] = s02; st.S[3] = s03; st.S[4] = s04;
+        st.S[5] = s11; st.S[6] = s12; st.S[7] = s13; st.S[8] = s14; st.S[9] = s22;
+        st.S[10] = s23; st.S[11] = s24; st.S[12] = s33; st.S[13] = s34; st.S[14] = s44;
+        st.sC[0] = d0; st.sC[1] = d1; st.sC[2] = d2; st.sC[3] = d3; st.sC[4] = d4;
+        st.nN = nN;
+        if (inr) {
+            const uint32_t h = ht[c];
+            st.depth = st.n_plp - st.nref - n_lq0;       /* entries that reached the sums (snp:685) */
+            st.clipped = (int)(h >> 16);
+            st.n_overlap = st.n_plp - st.nref - (int)(h & 0xffff);
+        }
+        if (key) col_unpermute(st.S, st.sC, (int)key);  /* back to the reference's A C G T numbering */
+        if (inr) col_decide<MQ ? 1 : 0>(st, B, P, T, c, apos, true, colrec, nplp_out, score_out, trigcnt, sStat, KC2_LDS_EXP ? sE : (const double *)nullptr);
+        KC2_STAMP(4);
+    }
+    }
+#ifdef KC2_EXP_STAMP
+    if (lane == 0) for (int k = 0; k < 5; k++) atomicAdd(&stats[24 + k], (u64)tacc[k]);
+#endif
+    __syncthreads();
+    if (threadIdx.x < 32 && sStat[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (u64)sStat[threadIdx.x]);
+}
+
+#endif /* CRUMBLE_KCOL2_H */

@@ -179,8 +179,13 @@ struct ConsOut { int call, het_call, het_phred, phred; float discrep; };
  * in registers: the reference's norm[j] (sum of all S[i], i != j, built from a
  * prefix and a suffix pass, snp:743-749) is prefix[j] + suffix[j] exactly,
  * because each norm[j] receives exactly those two addends starting from 0. */
+/* sE: optional LDS copy of the halves of the exp tables that a non-positive argument can reach
+ * (sE[0..500] = e_tab2[0..500] = exp(-50..0 step .1), sE[501..951] = e_tab[0..450] = exp(-500..-50)); the 15
+ * arguments are S[j] - max(S) <= 0, so fast_exp (snp:491-503) is one table read each and all 15 go out together
+ * (through dev_fast_exp they were 15 dependent global round trips per tile) */
+#define CONS_NEXP 952
 __device__ __forceinline__ void cons_finalize(const DTables *T, double *S, const double *sC,
-                                              int depth, int nN, ConsOut &o)
+                                              int depth, int nN, ConsOut &o, const double *sE = nullptr)
 {
     const double min_e_exp = T->min_e_exp;            /* DBL_MIN_EXP*log(2)+1 (snp:540), host libm */
     double shift = -DBL_MAX, max = -DBL_MAX, max_het = -DBL_MAX;
@@ -196,11 +201,27 @@ __device__ __forceinline__ void cons_finalize(const DTables *T, double *S, const
             if (max < S[j]) { max = S[j]; call = j; }
         }
     }
-    #pragma unroll
-    for (int j = 0; j < 15; j++) {                     /* snp:736-741 */
-        S[j] -= shift;
-        const double e = dev_fast_exp(T, S[j]);
-        S[j] = (S[j] > min_e_exp) ? e : DBL_MIN;
+    if (sE) {
+        int ix[15];
+        double e[15];
+        #pragma unroll
+        for (int j = 0; j < 15; j++) {                 /* snp:736-741 with fast_exp's index arithmetic (snp:496-502) */
+            const double y = S[j] - shift;             /* <= 0 */
+            S[j] = y;
+            const double yc = y < -500.0 ? -500.0 : y;
+            ix[j] = (y >= -50.0) ? (int)(y * 10) + 500 : 501 + (int)yc + 500;
+        }
+        #pragma unroll
+        for (int j = 0; j < 15; j++) e[j] = sE[ix[j]];
+        #pragma unroll
+        for (int j = 0; j < 15; j++) S[j] = (S[j] > min_e_exp) ? e[j] : DBL_MIN;
+    } else {
+        #pragma unroll
+        for (int j = 0; j < 15; j++) {                 /* snp:736-741 */
+            S[j] -= shift;
+            const double e = dev_fast_exp(T, S[j]);
+            S[j] = (S[j] > min_e_exp) ? e : DBL_MIN;
+        }
     }
     double pre[15], suf[15], tot1 = 0, tot2 = 0;       /* snp:743-749 */
     #pragma unroll
@@ -278,7 +299,8 @@ template <int MODE>
 __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const DParams *__restrict__ P,
                                            const DTables *__restrict__ T, int c, int apos, bool use_cons,
                                            uint32_t *__restrict__ colrec, int32_t *__restrict__ nplp_out,
-                                           int32_t *__restrict__ score_out, int32_t *__restrict__ trigcnt, unsigned *stats)
+                                           int32_t *__restrict__ score_out, int32_t *__restrict__ trigcnt, unsigned *stats,
+                                           const double *sE = nullptr)
 {
     const int n_plp = st.n_plp;
     if (n_plp == 0) { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; return; }
@@ -309,7 +331,7 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
         int hA = 0, sA = 0, hB = 0, sB = 0;
         const bool useA = MODE != 1, useB = MODE != 0;
         if (useA) {                                    /* snp:1523-1532, 1576-1583, 1594-1609 */
-            cons_finalize(T, MODE == 2 ? st.S2 : st.S, MODE == 2 ? st.sC2 : st.sC, st.depth, st.nN, coA);
+            cons_finalize(T, MODE == 2 ? st.S2 : st.S, MODE == 2 ? st.sC2 : st.sC, st.depth, st.nN, coA, sE);
             const bool het = coA.het_phred > 0;
             if (het) { a1 = coA.het_call / 5; a2 = coA.het_call % 5; } else { a1 = a2 = coA.call; }
             hA = het ? coA.het_call : coA.call * 5 + coA.call;
@@ -320,7 +342,7 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
             if ((int)cp != (1 << coA.call)) perfect = 0;                 /* snp:1606 */
         }
         if (useB) {                                    /* snp:1534-1543, 1584-1591, 1610-1622 */
-            cons_finalize(T, st.S, st.sC, st.depth, st.nN, coB);
+            cons_finalize(T, st.S, st.sC, st.depth, st.nN, coB, sE);
             const bool het = coB.het_phred > 0;
             if (het) { a1 = coB.het_call / 5; a2 = coB.het_call % 5; } else { a1 = a2 = coB.call; }
             hB = het ? coB.het_call : coB.call * 5 + coB.call;
@@ -706,6 +728,8 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
     __syncthreads();
     if (threadIdx.x < 32 && sStat[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (u64)sStat[threadIdx.x]);
 }
+
+#include "kcol2.h"
 
 /* ------------------------------------------------------------------------ */
 /* Chunked device-wide exclusive scan of ScanVal over positions.            */

@@ -6,7 +6,7 @@
  *   k_p0_classify   per read: pileup_callback's routing (snp_score.c:1130-1149) + htslib's default
  *                   flag filter, reference length / end, number of reference-consuming CIGAR ops,
  *                   input validation (the reference asserts instead: snp_score.c:1075)
- *   k_p0_quals      input qualities must be < 128
+ *   k_p0_basequal   input qualities must be < 128; consensus class of every base into its high nibble
  *   k_p0_sorted     coordinate order of the reads that enter the pileup (snp_score.c:1075)
  *   k_p0scan_*      exclusive prefix sums -> offsets of each read's ops / base->column entries
  *   k_p0_fill       per read: Seg + SegRec tables with htslib's resolve_cigar2 `indel` peek
@@ -108,7 +108,22 @@ __global__ void k_p0_sorted(int64_t n, const int32_t *__restrict__ pos, const ui
     if (q >= 0 && pos[r] < pos[q]) atomicMax(err, P0_ERR_UNSORTED);   /* snp:1075 */
 }
 
-__global__ void k_p0_quals(int64_t nb, const uint8_t *__restrict__ quals, int *err)
+/* One pass over the flat base / quality arrays: input qualities must be < 128, and every base
+ * byte gets its consensus class in the high nibble next to the nt16 code in the low one (what the reference
+ * derives per pileup entry, snp:603-609: A C G T -> 0..3, anything else -> 5 "N"; 4 is '*'), so that k_columns2
+ * stages classes with a shift instead of a per-byte decode.  Every reader of `bases` masks with 15. */
+__device__ __forceinline__ uint32_t p0_class4(uint32_t w)
+{
+    const uint32_t c = w & 0x0f0f0f0fu;
+    const uint32_t idx = ((c >> 1) & 0x07070707u) - ((c >> 3) & 0x01010101u);          /* one-hot: 1 2 4 8 -> 0 1 2 3 */
+    const uint32_t many = c & ((c | 0x80808080u) - 0x01010101u) & 0x0f0f0f0fu;         /* >= 2 bits set */
+    const uint32_t nz_many = (((many + 0x7f7f7f7fu) & 0x80808080u) >> 7) * 0xffu;
+    const uint32_t nz_c = (((c + 0x7f7f7f7fu) & 0x80808080u) >> 7) * 0xffu;
+    const uint32_t bad = nz_many | ~nz_c;                                               /* not exactly one bit */
+    const uint32_t cls = (idx & ~bad) | (0x05050505u & bad);
+    return c | (cls << 4);
+}
+__global__ void k_p0_basequal(int64_t nb, uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals, int *err)
 {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
     if (i >= nb) return;
@@ -116,8 +131,14 @@ __global__ void k_p0_quals(int64_t nb, const uint8_t *__restrict__ quals, int *e
     if (i + 16 <= nb) {
         const uint4 v = *(const uint4 *)(quals + i);
         bad = ((v.x | v.y | v.z | v.w) & 0x80808080u) != 0;
+        uint4 b = *(const uint4 *)(bases + i);
+        b.x = p0_class4(b.x); b.y = p0_class4(b.y); b.z = p0_class4(b.z); b.w = p0_class4(b.w);
+        *(uint4 *)(bases + i) = b;
     } else {
-        for (int64_t k = i; k < nb; k++) bad = bad || (quals[k] & 0x80);
+        for (int64_t k = i; k < nb; k++) {
+            bad = bad || (quals[k] & 0x80);
+            bases[k] = (uint8_t)(p0_class4(bases[k]) & 0xffu);
+        }
     }
     if (bad) atomicMax(err, P0_ERR_QUAL);
 }
@@ -157,7 +178,7 @@ __global__ void k_p0_fill(int64_t n, int p0, const int32_t *__restrict__ pos, co
                           Seg *__restrict__ segs, SegRec *__restrict__ sr, int32_t *__restrict__ sr_ppos,
                           int32_t *__restrict__ sr_pend, ReadRec *__restrict__ rr, int64_t *__restrict__ seg_off,
                           int32_t *__restrict__ cix, int64_t *__restrict__ slow_g, int32_t *__restrict__ slow_r,
-                          int *n_slow)
+                          int *n_slow, const uint8_t *__restrict__ mq_slot)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
@@ -188,7 +209,7 @@ __global__ void k_p0_fill(int64_t n, int p0, const int32_t *__restrict__ pos, co
                 q.pos = x.pos + xr; q.end = q.pos + l; q.so = so; q.lq = lq;
                 q.qoff = (ty == SEG_M) ? y - q.pos : y;
                 q.indel_after = s.indel_after;
-                q.info = (uint32_t)mapq[r] | (ty << 8);
+                q.info = (uint32_t)mapq[r] | (ty << 8) | ((uint32_t)mq_slot[mapq[r]] << 16);
                 if (si == s_first) { q.info |= SR_FIRST; if (y > 0) q.info |= SR_HEADCLIP; x.q0 = y; }
                 sr[si] = q; sr_ppos[si] = x.pos; sr_pend[si] = x.end;
                 si++; nseg++;

@@ -58,6 +58,7 @@ def load_library(path=None, make_default=True):
         "crumble_bed_collapse": (C.c_int, [vp, vp, vp, C.c_int]),
         "crumble_hip_create": (vp, [PP, C.c_int, C.POINTER(C.c_int)]),
         "crumble_hip_destroy": (None, [vp]),
+        "crumble_hip_set_option": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
         "crumble_hip_contig": (C.c_int, [vp, C.POINTER(Batch), vp, vp, vp]),
         "crumble_hip_upload": (C.c_int, [vp, C.POINTER(Batch)]),
         "crumble_hip_run": (C.c_int, [vp]),
@@ -92,7 +93,7 @@ def lib():
 EXPORTED = [
     "crumble_params_default", "crumble_params_preset", "crumble_params_tech",
     "crumble_params_keep_quals", "crumble_init_bins", "crumble_bed_collapse",
-    "crumble_hip_create", "crumble_hip_destroy", "crumble_hip_contig",
+    "crumble_hip_create", "crumble_hip_destroy", "crumble_hip_set_option", "crumble_hip_contig",
     "crumble_hip_upload", "crumble_hip_run", "crumble_hip_download",
     "crumble_hip_kernel_times", "crumble_hip_stats_devptr", "crumble_hip_stats_reset",
     "crumble_hip_stats_read", "crumble_hip_stats_allreduce", "crumble_hip_columns",
@@ -134,7 +135,9 @@ def _vp(a):
 class Engine:
     """One crumble_hip handle (one GPU, one stream)."""
 
-    def __init__(self, params, device=0, library=None):
+    def __init__(self, params, device=0, library=None, options=None):
+        """options: {"kcol": "v1"|"v1perm"|"v2", "pblock": "reads"|"segments", "replay": "flat"} -- implementation
+        choices that never change a result (crumble_hip_set_option)."""
         err = C.c_int(0)
         self._p = params
         self.L = library if library is not None else lib()
@@ -142,6 +145,11 @@ class Engine:
         if not self.h:
             raise CrumbleError(err.value, "crumble_hip_create", self.L)
         self._batch = None
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    def set_option(self, name, value):
+        self._chk(self.L.crumble_hip_set_option(self.h, str(name).encode(), str(value).encode()), f"set_option {name}={value}")
 
     def close(self):
         if getattr(self, "h", None):

@@ -152,6 +152,13 @@ typedef struct crumble_hip crumble_hip;
 crumble_hip *crumble_hip_create(const crumble_params *p, int device, int *err);
 void         crumble_hip_destroy(crumble_hip *h);
 
+/* Implementation choices that never change a result; the parity tests force every variant through this.
+ *   "kcol"   = auto | v1 | v1perm | v2      column kernel (k_columns, its per-column-class form, k_columns2)
+ *   "pblock" = auto | reads | segments      P-block decomposition
+ *   "replay" = auto | flat                  per-base replay kernel
+ * Takes effect at the next crumble_hip_upload().  Unknown names / values -> CRUMBLE_EINVAL. */
+int crumble_hip_set_option(crumble_hip *h, const char *name, const char *value);
+
 /* Replaces one contig's worth of transcode() loop iterations + flush:
  *   qual_out[seq_off[n_reads]]  final quality bytes (0x80 stripped, P-blocked)
  *   read_flags_out[n_reads]     CRUMBLE_RF_* (may be NULL)

@@ -24,5 +24,10 @@ def load():
     return _L
 
 
-def engine(params):
-    return crumble_amd.Engine(params, 0, library=load())
+def engine(params, **options):
+    return crumble_amd.Engine(params, 0, library=load(), options=options)
+
+
+def with_options(**options):
+    """engine factory with crumble_hip_set_option choices applied (tests force every kernel variant)"""
+    return lambda params: engine(params, **options)

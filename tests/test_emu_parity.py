@@ -31,13 +31,13 @@ def test_emu_hifi_long_reads(product):
 
 
 @pytest.mark.parametrize("path", ["reads", "segments"])
-def test_emu_pblock_paths(product, path, monkeypatch):
+def test_emu_pblock_paths(product, path):
     """Both P-block implementations (one lane per read / segment-parallel) on short and long reads."""
-    monkeypatch.setenv("CRUMBLE_HIP_PBLOCK", path)
+    eng = emu_lib.with_options(pblock=path)
     for hb, p in ((synth_batch("chr20", 0.0004), ca.preset_params(9)),
                   (synth_batch("panel", 0.001), ca.preset_params(9, pblock=3, keep="30-31")),
                   (synth_batch("hifi", 0.0002, read_len=3000), ca.preset_params(9, tech="pbccs"))):
-        assert_parity(emu_lib.engine, p, hb, check_columns=False)
+        assert_parity(eng, p, hb, check_columns=False)
 
 
 @pytest.mark.parametrize("path", ["reads", "segments"])
@@ -65,19 +65,20 @@ def test_emu_consensus_modes(product):
     assert_parity(emu_lib.engine, ca.preset_params(5, min_qual_A=0, min_qual_B=0), hb)
 
 
-@pytest.mark.parametrize("perm", ["0", "1"])
-def test_emu_column_kernel_variants(product, perm, monkeypatch):
-    """Both k_columns accumulate variants: one block per base class, and per-column class numbering
-    (class = idx(base) ^ idx(key base)) undone by col_unpermute before the sums are read."""
-    monkeypatch.setenv("CRUMBLE_KCOL_PERM", perm)
+@pytest.mark.parametrize("kcol", ["v1", "v1perm", "v2"])
+def test_emu_column_kernel_variants(product, kcol):
+    """Every column kernel gives the same bits: k_columns with one block per base class, with per-column class
+    numbering (class = idx(base) ^ idx(key base), undone by col_unpermute), and k_columns2 (pileup matrix staged in
+    LDS, inline / parked split of the FP64 adds)."""
+    eng = emu_lib.with_options(kcol=kcol)
     hb = synth_batch("chr20", 0.0004)
-    assert_parity(emu_lib.engine, ca.preset_params(5), hb)
-    assert_parity(emu_lib.engine, ca.preset_params(5, min_qual_A=30, min_indel_A=60), hb)
-    assert_parity(emu_lib.engine, ca.preset_params(5, min_qual_A=30, min_qual_B=0), hb)
-    assert_parity(emu_lib.engine, ca.preset_params(9, keep="37", perfect_col=1), hb)
-    assert_parity(emu_lib.engine, ca.preset_params(9), synth_batch("panel", 0.001))
-    assert_parity(emu_lib.engine, ca.preset_params(9, tech="pbccs"), synth_batch("hifi", 0.0002, read_len=3000))
-    assert_parity(emu_lib.engine, ca.preset_params(1), synth_batch("ce", 0.3))
+    assert_parity(eng, ca.preset_params(5), hb)
+    assert_parity(eng, ca.preset_params(5, min_qual_A=30, min_indel_A=60), hb)
+    assert_parity(eng, ca.preset_params(5, min_qual_A=30, min_qual_B=0), hb)
+    assert_parity(eng, ca.preset_params(9, keep="37", perfect_col=1), hb)
+    assert_parity(eng, ca.preset_params(9), synth_batch("panel", 0.001))
+    assert_parity(eng, ca.preset_params(9, tech="pbccs"), synth_batch("hifi", 0.0002, read_len=3000))
+    assert_parity(eng, ca.preset_params(1), synth_batch("ce", 0.3))
 
 
 def test_emu_indel_only(product):

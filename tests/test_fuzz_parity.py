@@ -9,22 +9,23 @@ from parity_util import assert_parity
 
 
 @pytest.mark.parametrize("seed", range(100, 112))
-def test_fuzz_emulated(product, seed, monkeypatch):
+def test_fuzz_emulated(product, seed):
     import emu_lib
-    monkeypatch.setenv("CRUMBLE_KCOL_PERM", str(seed & 1))        # both k_columns variants, whatever the batch
+    from parity_util import KCOL_VARIANTS
     p, hb, desc = random_case(seed, max_bases=120_000)
     print(desc)
-    assert_parity(emu_lib.engine, p, hb)
+    assert_parity(emu_lib.with_options(kcol=KCOL_VARIANTS[seed % 3]), p, hb)   # every column kernel, whatever the batch
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("block", range(6))
-def test_fuzz_gpu(product, block, monkeypatch):
+def test_fuzz_gpu(product, block):
+    from parity_util import KCOL_VARIANTS
     for seed in range(1000 + 25 * block, 1000 + 25 * (block + 1)):
-        monkeypatch.setenv("CRUMBLE_KCOL_PERM", str(seed & 1))    # both k_columns variants, whatever the batch
         p, hb, desc = random_case(seed, max_bases=400_000)
+        kcol = KCOL_VARIANTS[seed % 3] if seed % 4 else "auto"      # every column kernel, whatever the batch
         try:
-            assert_parity(lambda q: ca.Engine(q, 0), p, hb)
+            assert_parity(lambda q: ca.Engine(q, 0, options={"kcol": kcol}), p, hb)
         except AssertionError as e:
             raise AssertionError(f"{desc}: {e}") from e
 

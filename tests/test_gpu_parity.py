@@ -54,11 +54,13 @@ def test_hifi_pbccs(product):
     assert_parity(gpu_engine, ca.preset_params(5), hb)
 
 
-@pytest.mark.parametrize("perm", ["0", "1"])
-def test_column_kernel_variants(product, perm, monkeypatch):
-    """Both k_columns accumulate variants (one block per base class / per-column class numbering with the
-    XOR un-permutation) on every workload shape and consensus mode, whatever the batch heuristic would pick."""
-    monkeypatch.setenv("CRUMBLE_KCOL_PERM", perm)
+@pytest.mark.parametrize("kcol", ["v1", "v1perm", "v2"])
+def test_column_kernel_variants(product, kcol):
+    """Every column kernel (k_columns with one block per base class / with per-column class numbering and the XOR
+    un-permutation / k_columns2 with the LDS-staged pileup matrix) on every workload shape and consensus mode,
+    whatever the engine would pick by itself."""
+    def gpu_engine(q):
+        return ca.Engine(q, 0, options={"kcol": kcol})
     hifi = synth_batch("hifi", 0.002)
     for hb, p in ((synth_batch("chr20", 0.01), ca.preset_params(5)),
                   (synth_batch("chr20", 0.002), ca.preset_params(5, min_qual_A=30, min_indel_A=60)),
@@ -75,9 +77,10 @@ def test_column_kernel_variants(product, perm, monkeypatch):
 
 
 @pytest.mark.parametrize("path", ["reads", "segments"])
-def test_pblock_paths(product, path, monkeypatch):
+def test_pblock_paths(product, path):
     """Both P-block implementations (one lane per read / segment-parallel) on short and long reads."""
-    monkeypatch.setenv("CRUMBLE_HIP_PBLOCK", path)
+    def gpu_engine(q):
+        return ca.Engine(q, 0, options={"pblock": path})
     for hb, p in ((synth_batch("chr20", 0.01), ca.preset_params(9)),
                   (synth_batch("panel", 0.005), ca.preset_params(9, pblock=3, keep="30-31")),
                   (synth_batch("hifi", 0.002), ca.preset_params(9, tech="pbccs")),

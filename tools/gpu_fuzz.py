@@ -12,11 +12,11 @@ s0, n = int(sys.argv[1]), int(sys.argv[2])
 bad, t0 = 0, time.time()
 for seed in range(s0, s0 + n):
     p, hb, desc = random_case(seed, max_bases=300_000)
-    os.environ["CRUMBLE_KCOL_PERM"] = str(seed & 1)          # both k_columns accumulate variants, whatever the batch
+    kcol = ("v1", "v1perm", "v2", "v2", "auto")[seed % 5]       # every column kernel, whatever the batch
     try:
-        assert_parity(lambda q: ca.Engine(q, 0), p, hb)
+        assert_parity(lambda q: ca.Engine(q, 0, options={"kcol": kcol}), p, hb)
         if seed % 10 == 0:
-            assert_parity(lambda q: ca.Engine(q, 0), p, tiny_reads_batch(seed, n=2000), check_columns=False)
+            assert_parity(lambda q: ca.Engine(q, 0, options={"kcol": kcol}), p, tiny_reads_batch(seed, n=2000), check_columns=False)
     except Exception as e:
         bad += 1
         print("FAIL", desc, str(e)[:300], flush=True)

@@ -1,0 +1,11 @@
+import sys, os
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
+import numpy as np, crumble_amd as ca
+from crumble_amd import synth
+hb = synth.generate(synth.config(sys.argv[1] if len(sys.argv) > 1 else "chr20", scale=float(sys.argv[2]) if len(sys.argv) > 2 else 1.0))
+e = ca.Engine(ca.preset_params(int(sys.argv[3]) if len(sys.argv) > 3 else 5), 0)
+e.upload(hb); e.run(); e.stats_reset(); e.run()
+s = e.stats_read()
+kt = dict((n, ms) for n, ms, _ in e.kernel_times())
+t = s[24:29].astype(float)
+print("k_columns2 ms", kt.get("k_columns2"), "stamps (share): unit-grab %.3f stage %.3f produce %.3f consume %.3f decide %.3f" % tuple(t / t.sum()), "total wave-cycles %.3g" % t.sum())
