@@ -67,7 +67,8 @@ def file_to_file(hb, args, device):
         bamio.write_batches(src, [("chr20", 64444167)], [hb], level=1)
         env = dict(os.environ, CRUMBLE_HIP_DEVICE=str(device), CRUMBLE_BAM_LEVEL="1")
         t0 = time.perf_counter()
-        r = subprocess.run([os.path.join(ROOT, "crumble_amd", "crumble-hip"), "-v", f"-{args.preset}", src, dst],
+        lvl = [f"-{args.preset}"] if args.preset else []
+        r = subprocess.run([os.path.join(ROOT, "crumble_amd", "crumble-hip"), "-v"] + lvl + [src, dst],
                            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         wall = time.perf_counter() - t0
         if r.returncode:
@@ -85,21 +86,84 @@ def file_to_file(hb, args, device):
         os.rmdir(tmp)
 
 
+WORKLOADS = {   # name -> (label, default preset, default tech, keep-BED regions at scale 1)
+    "chr20": ("chr20-30x", 5, None, 0),          # BASELINE config 2 (the 1xMI355X config the metric is quoted on)
+    "panel": ("panel-300x", 9, None, 0),         # config 3
+    "hifi": ("hifi-20x", None, "pbccs", 5000),   # config 4: -y pbccs -R keep.bed (5000 x 2 kb)
+    "wgs": ("wgs-30x", 5, None, 0),              # config 5: 24 contigs, GRCh38 lengths
+}
+
+
+def keep_bed(contig_len, n_regions, width=2000):
+    """n evenly spread keep-regions of `width` bp (5000 x 2 kb on chr1)."""
+    if n_regions <= 0:
+        return None
+    starts = (np.arange(n_regions, dtype=np.int64) * (contig_len // n_regions) + 10000).astype(np.int64)
+    starts = starts[starts + width < contig_len]
+    return np.stack([starts, starts + width], 1).astype(np.int32)
+
+
+def interior_reads(hb, n_sample):
+    """Number k of leading reads of the first n_sample reads whose every column has its full pileup inside the
+    sample (all reads covering a column start at or before it): the oracle run on the prefix alone gives the exact
+    bytes, flags of reads 0..k-1 of the full contig."""
+    last_pos = int(hb.pos[n_sample - 1])
+    ops = hb.cigar[:int(hb.cig_off[n_sample])]
+    cons = np.isin(ops & 15, (0, 2, 3, 7, 8)) * (ops >> 4).astype(np.int64)     # M D N = X consume the reference
+    csum = np.concatenate([[0], np.cumsum(cons)])
+    reflen = csum[hb.cig_off[1:n_sample + 1]] - csum[hb.cig_off[:n_sample]]
+    bad = np.nonzero(hb.pos[:n_sample].astype(np.int64) + reflen > last_pos)[0]
+    return int(bad[0]) if len(bad) else n_sample
+
+
+def _cpu_worker(job):
+    """One independent unit of the all-core CPU baseline: the oracle on a window of reads of the contig."""
+    import oracle_lib as O
+    import crumble_amd as ca
+    hb, preset, tech = job
+    O.load()
+    p = ca.preset_params(preset, tech=tech)
+    t0 = time.perf_counter()
+    O.contig(p, hb)
+    return hb.n_bases, time.perf_counter() - t0
+
+
+def window_batch(hb, r0, n_reads):
+    from crumble_amd import HostBatch
+    r1 = min(hb.n_reads, r0 + n_reads)
+    b0, b1 = int(hb.seq_off[r0]), int(hb.seq_off[r1])
+    c0, c1 = int(hb.cig_off[r0]), int(hb.cig_off[r1])
+    return HostBatch(hb.tid, hb.pos[r0:r1], hb.mapq[r0:r1], hb.flag[r0:r1], hb.seq_off[r0:r1 + 1] - b0,
+                     hb.cig_off[r0:r1 + 1] - c0, hb.cigar[c0:c1], hb.bases[b0:b1], hb.quals[b0:b1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="chr20")
+    ap.add_argument("--workload", default="chr20", choices=sorted(WORKLOADS))
     ap.add_argument("--scale", type=float, default=1.0, help="contig length scale (1.0 = BASELINE config)")
-    ap.add_argument("--preset", type=int, default=5)
+    ap.add_argument("--preset", type=int, default=None, help="crumble -[1-9] (default: the workload's)")
+    ap.add_argument("--tech", default=None, help="crumble -y (default: the workload's; 'none' disables)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--cpu-all", action="store_true", help="also time the CPU restatement on all host cores "
+                    "(independent windows of the contig, one process per core): 'cpu_baseline_all'")
+    ap.add_argument("--pmc-json", default=None, help="profiles/*_pmc_traffic.json measured for THIS build and "
+                    "workload: fills roofline.traffic (null otherwise)")
+    ap.add_argument("--kcol", default="auto", help="crumble_hip_set_option kcol (auto|v1|v1perm|v2)")
     ap.add_argument("--e2e", action="store_true",
                     help="also time metric (ii): BAM file -> crumble-hip -> BAM file (SURVEY.md 8d), reported "
                          "as an extra 'end_to_end' object; never part of 'value'")
     args = ap.parse_args()
+    label, d_preset, d_tech, d_bed = WORKLOADS[args.workload]
+    preset = args.preset if args.preset is not None else d_preset
+    tech = (None if args.tech == "none" else args.tech) if args.tech is not None else d_tech
+    if args.preset is not None and args.tech is None:
+        tech = None                                   # an explicit numeric preset alone means just that preset
+    args.preset = preset
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -146,17 +210,22 @@ def main():
         cfg = synth.config(args.workload, scale=args.scale)
         cfg.seed = cfg.seed + 1000 * rank       # rank r owns "contig r"
         cfg.tid = rank
-        batches.append(synth.generate(cfg))
+        bed = keep_bed(cfg.contig_len, int(d_bed * args.scale + 0.5)) if tech == "pbccs" else None
+        batches.append(synth.generate(cfg, bed=bed))
         scaling = "weak"
     t_gen = time.time() - t0
     hb = batches[0]
-    params = ca.preset_params(args.preset)
+    params = ca.preset_params(args.preset, tech=tech)
+    opts = {} if args.kcol == "auto" else {"kcol": args.kcol}
 
     t0 = time.time()
     engines = []
+    h2d_ms = p0_ms = 0.0
     for b_ in batches:
-        e_ = ca.Engine(params, local_rank)      # raises if no GPU (no CPU fallback)
+        e_ = ca.Engine(params, local_rank, options=opts)      # raises if no GPU (no CPU fallback)
         e_.upload(b_)                           # contigs stay resident in HBM
+        a_, b2_ = e_.upload_times()
+        h2d_ms += a_; p0_ms += b2_
         engines.append(e_)
     eng = engines[0]
     t_up = time.time() - t0
@@ -205,6 +274,11 @@ def main():
     value = total_bases * args.steps / elapsed / 1e9
     ms_per_step = elapsed / args.steps * 1e3
 
+    # ---- download of the TIMED engine's result (what the verification below looks at) ----
+    t0 = time.perf_counter()
+    tq, tf, _ = eng.download(want_stats=False)
+    t_down = time.perf_counter() - t0
+
     # ---- roofline of the dominant kernel (HIP events on the engine's stream) ----
     dom = max(ktimes.items(), key=lambda kv: kv[1][0])
     dom_ms = dom[1][0] / dom[1][2]
@@ -212,26 +286,37 @@ def main():
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     algo_total = sum(3.0 * b_.n_bases + 32.0 * b_.n_reads + 8.0 * int(b_.cig_off[-1]) for b_ in batches)
     kernel_ms_total = sum(v[0] for v in ktimes.values()) / args.steps
-    # HBM traffic of that kernel from rocprofv3 PMC counters (FETCH_SIZE + WRITE_SIZE, separate
-    # passes, same command, committed under profiles/): per launch, bytes; None when not measured
-    traffic = None
-    try:
-        import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1:]:
-            kk = json.load(open(f))["kernels"]
+    # HBM traffic of that kernel from rocprofv3 PMC counters (FETCH_SIZE + WRITE_SIZE, separate passes): only when a
+    # summary measured for THIS build and workload is named on the command line; never a stale constant
+    traffic, traffic_src = None, None
+    if args.pmc_json:
+        try:
+            kk = json.load(open(args.pmc_json))["kernels"]
             key = [k for k in kk if k.split("<")[0] == dom[0]]
-            if key and args.workload == "chr20" and args.scale == 1.0:
+            if key:
                 t = kk[key[0]]
                 traffic = round((t["FETCH_SIZE_KB_per_launch"] + t["WRITE_SIZE_KB_per_launch"]) * 1024)
-    except Exception:
-        traffic = None
+                traffic_src = os.path.basename(args.pmc_json)
+        except Exception:
+            traffic = None
     roofline = {
         "bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
         "kernel_ms": round(dom_ms, 3),
         "pipeline_achieved": round(algo_total / (kernel_ms_total * 1e-3) / 1e9, 2),
         "pipeline_frac": round(algo_total / (kernel_ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
         "kernels_ms": {k: round(v[0] / v[2], 3) for k, v in ktimes.items()},
+    }
+
+    # what a real contig pays around the timed step: the device-side expansion (P0) once per upload, and PCIe
+    step_s = elapsed / args.steps
+    p0_s, h2d_s = p0_ms * 1e-3, h2d_ms * 1e-3
+    extra = {
+        "p0_ms": round(p0_ms, 3), "h2d_ms": round(h2d_ms, 3), "d2h_ms": round(t_down * 1e3 * len(batches), 3),
+        "value_incl_p0": round(bases_local / (step_s + p0_s) / 1e9, 3),
+        "value_incl_pcie": round(bases_local / (step_s + p0_s + h2d_s + t_down * len(batches)) / 1e9, 3),
+        "note": "value = kernels only, batch resident in HBM; value_incl_p0 adds the per-contig device-side "
+                "expansion; value_incl_pcie also the host->device copy (pageable numpy memory) and the download",
     }
 
     out = {
@@ -239,24 +324,32 @@ def main():
         "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": scaling, "vs_baseline": None, "dtype": "u8/f64", "data": "synthetic",
-        "config": {"workload": (f"{args.workload}-30x synthetic contig ({cfg.contig_len} bp, "
-                                f"{hb.n_reads} reads, {hb.n_bases} bases per GPU), preset -{args.preset}"
+        "config": {"workload": (f"{label} synthetic contig ({cfg.contig_len} bp, "
+                                f"{hb.n_reads} reads, {hb.n_bases} bases per GPU), "
+                                f"{'-' + str(args.preset) if args.preset else 'default level'}"
+                                f"{' -y ' + tech if tech else ''}"
+                                f"{' -R keep.bed (' + str(len(hb.bed_start)) + ' regions)' if len(hb.bed_start) else ''}"
                                 if args.workload != "wgs" else
-                                f"wgs-30x: 24 synthetic contigs (GRCh38 lengths x {args.scale}), {total_bases} bases "
-                                f"LPT-packed on {world} GPU(s), preset -{args.preset}"),
-                   "preset": args.preset, "scale": args.scale,
+                                f"{label}: 24 synthetic contigs (GRCh38 lengths x {args.scale}), {total_bases} bases "
+                                f"LPT-packed on {world} GPU(s), -{args.preset}"),
+                   "preset": args.preset, "tech": tech, "scale": args.scale,
                    "contigs": world if args.workload != "wgs" else 24,
+                   "parity": "every parity check is against oracle/ (a CPU restatement of crumble 0.9.1's transcode(); "
+                             "reference-pinned for str_finder.c only: htslib is absent offline)",
                    "gen_s": round(t_gen, 1), "upload_s": round(t_up, 2)},
         "roofline": roofline,
+        "around_the_step": extra,
     }
 
     if rank == 0:
-        # ---- parity spot check + CPU baseline on a bounded prefix of the same workload ----
+        # ---- parity of the TIMED result + CPU baseline on a bounded prefix of the same workload ----
         import oracle_lib as O
         ns_per_base = 60e-9
         n_sample_bases = args.cpu_seconds / ns_per_base
         n_sample = int(min(hb.n_reads, max(1000, n_sample_bases / max(1, hb.n_bases / max(1, hb.n_reads)))))
         sample = prefix_batch(hb, n_sample)
+        if len(hb.bed_start):
+            sample.bed_start, sample.bed_end = hb.bed_start, hb.bed_end
         if not args.no_cpu and world == 1:          # CPU baseline: rank 0 at N=1 only
             O.load()
             t0 = time.perf_counter()
@@ -269,11 +362,33 @@ def main():
                           f"{t_cpu:.1f} s, CPU restatement (oracle/) single thread like reference crumble",
             }
             if not args.no_verify:
-                e2 = ca.Engine(params, local_rank)
-                gq, gf, gs = e2.contig(sample)
-                e2.close()
+                # (a) the timed engine's own output: reads whose columns lie wholly inside the sample have their
+                #     exact bytes in the oracle's run on the sample alone
+                k = interior_reads(hb, n_sample)
+                nbk = int(hb.seq_off[k])
+                ok_q = bool(np.array_equal(tq[:nbk], wq[:nbk]))
+                ok_f = bool(np.array_equal(tf[:k], wf[:k]))
+                # (b) the same engine object, reused for another batch (the sample): everything incl. statistics
+                gq, gf, gs = eng.contig(sample)
+                out["config"]["verified_timed_output_leading_reads"] = k if (ok_q and ok_f) else False
                 out["config"]["verified_bit_exact_on_sample"] = bool(
                     np.array_equal(gq, wq) and np.array_equal(gf, wf) and np.array_equal(gs, ws))
+            if args.cpu_all:
+                import multiprocessing as mp
+                cores = _host_threads()
+                per = max(1000, n_sample // 4)
+                jobs = [(window_batch(hb, (k * (hb.n_reads // max(1, cores))) % max(1, hb.n_reads - per), per),
+                         args.preset, tech) for k in range(cores)]
+                t0 = time.perf_counter()
+                with mp.get_context("fork").Pool(cores) as pool:
+                    res = pool.map(_cpu_worker, jobs)
+                wall = time.perf_counter() - t0
+                out["cpu_baseline_all"] = {
+                    "value": round(sum(r[0] for r in res) / wall / 1e9, 5), "unit": "Gbases/s", "cores": cores,
+                    "kind": "port",
+                    "sample": f"{cores} independent windows of {per} reads of the same contig, one process per core "
+                              f"(contigs / windows are the independent unit), {wall:.1f} s wall",
+                }
         if args.e2e:
             out["end_to_end"] = file_to_file(hb, args, local_rank)
         print(json.dumps(out))

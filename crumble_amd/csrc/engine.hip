@@ -78,6 +78,8 @@ struct crumble_hip {
     ScanVal totals;
     /* timing */
     hipEvent_t ev[MAX_STAGES + 1];
+    hipEvent_t ev_up[3];            /* crumble_hip_upload: start / raw arrays copied / expanded */
+    float up_h2d_ms = 0, up_p0_ms = 0;
     const char *stage_name[MAX_STAGES];
     double stage_bytes[MAX_STAGES];
     float stage_ms[MAX_STAGES];
@@ -200,6 +202,8 @@ extern "C" crumble_hip *crumble_hip_create(const crumble_params *p, int device, 
     if (hipStreamCreate(&h->stream) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(CRUMBLE_EHIP); }
     for (int i = 0; i <= MAX_STAGES; i++)
         if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(CRUMBLE_EHIP); }
+    for (int i = 0; i < 3; i++)
+        if (hipEventCreate(&h->ev_up[i]) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(CRUMBLE_EHIP); }
     h->events_ok = true;
 #ifndef CRUMBLE_EMU
     {
@@ -243,7 +247,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
         &h->d_inscol_pos, &h->d_items, &h->d_colhi, &h->d_ub, &h->d_pmax_partial, &h->d_trig_mx2,
         &h->d_out, &h->d_rflags, &h->d_keepf, &h->d_b15f, &h->d_blk_read, &h->d_chunk_read, &h->d_kept };
     for (DevBuf *b : all) b->release();
-    if (h->events_ok) for (int i = 0; i <= MAX_STAGES; i++) (void)hipEventDestroy(h->ev[i]);
+    if (h->events_ok) { for (int i = 0; i <= MAX_STAGES; i++) (void)hipEventDestroy(h->ev[i]); for (int i = 0; i < 3; i++) (void)hipEventDestroy(h->ev_up[i]); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -322,6 +326,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     h->have_batch = false; h->have_run = false;
     int e;
 
+    HIPCHK(hipEventRecord(h->ev_up[0], st));
     /* 1. raw arrays */
     if ((e = up(h, h->d_pos, b->pos, n)) || (e = up(h, h->d_mapq, b->mapq, n)) || (e = up(h, h->d_flag, b->flag, n)) ||
         (e = up(h, h->d_seq_off, b->seq_off, n + 1)) || (e = up(h, h->d_cig_off, b->cig_off, n + 1)) ||
@@ -339,6 +344,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
         (e = up(h, h->d_bed_pmax, pmax.data(), n_bed)))
         return e;
 
+    HIPCHK(hipEventRecord(h->ev_up[1], st));
     /* 2. classify + validate + count */
     const int nchunks = (int)((n + P0_CHUNK - 1) / P0_CHUNK);
     if ((e = h->d_inplp.reserve((size_t)(n + 1))) || (e = h->d_end.reserve((size_t)(n + 1) * 4)) ||
@@ -352,14 +358,14 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     P0Cnt tot = {0, 0, 0};
     int res[4] = {0, INT_MAX, INT_MIN, 0};
     if (n > 0) {
-        CRUMBLE_LAUNCH_INDEP(k_p0_classify, nblk(n, 256), 256, st, n, (int)b->tid, h->d_pos.as<int32_t>(),
+        CRUMBLE_LAUNCH(k_p0_classify, nblk(n, 256), 256, st, n, (int)b->tid, h->d_pos.as<int32_t>(),
                              h->d_flag.as<uint16_t>(), h->d_seq_off.as<int64_t>(), h->d_cig_off.as<int64_t>(),
-                             h->d_cigar.as<uint32_t>(), h->d_inplp.as<uint8_t>(), h->d_end.as<int32_t>(), cnt, d_err, d_minmax);
+                             h->d_cigar.as<uint32_t>(), h->d_inplp.as<uint8_t>(), h->d_end.as<int32_t>(), cnt, d_err, d_minmax, nb, nc);
         CRUMBLE_LAUNCH_INDEP(k_p0_sorted, nblk(n, 256), 256, st, n, h->d_pos.as<int32_t>(), h->d_inplp.as<uint8_t>(), d_err);
         if (nb > 0) CRUMBLE_LAUNCH_INDEP(k_p0_basequal, nblk((nb + 15) / 16, 256), 256, st, nb, h->d_bases.as<uint8_t>() + BASE_FRONT_PAD,
                                          h->d_quals.as<uint8_t>() + BASE_FRONT_PAD, d_err);
         CRUMBLE_LAUNCH_INDEP(k_p0scan_reduce, nblk(nchunks, 64), 64, st, n, cnt, part, nchunks);
-        CRUMBLE_LAUNCH_INDEP(k_p0scan_partials, 1, 1, st, part, nchunks);
+        CRUMBLE_LAUNCH(k_p0scan_partials, 1, 1024, st, part, nchunks);
         CRUMBLE_LAUNCH_INDEP(k_p0scan_apply, nblk(nchunks, 64), 64, st, n, cnt, part, nchunks);
         HIPCHK(hipMemcpyAsync(&tot, part + nchunks, sizeof tot, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(res, d_err, sizeof res, hipMemcpyDeviceToHost, st));
@@ -387,7 +393,8 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
          * KC2_SLOTS most frequent ones get a row of k_columns2's compact adjustment table (their slot travels in
          * SegRec.info); anything else is looked up in global memory.  Performance hints only. */
         int64_t hist[256] = {0};
-        for (int64_t i = 0; i < n; i++) hist[b->mapq[i]]++;
+        const int64_t hstep = n > 65536 ? n / 65536 : 1;     /* a sample: mapq values it misses are looked up in global memory */
+        for (int64_t i = 0; i < n; i += hstep) hist[b->mapq[i]]++;
         int order[256], best = 0;
         for (int i = 0; i < 256; i++) { order[i] = i; if (hist[i] > hist[best]) best = i; }
         B.hot_mq = best;
@@ -458,7 +465,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
             CRUMBLE_LAUNCH_INDEP(k_tile_cost, nblk(B.n_tiles, 256), 256, st, B.n_tiles, h->d_stile_lo.as<int32_t>(),
                                  h->d_stile_hi.as<int32_t>(), (tot.nseg > n + n / 2) ? 1 : 0, cum);
             CRUMBLE_LAUNCH_INDEP(k_i64scan_reduce, nblk(tch, 64), 64, st, (int64_t)B.n_tiles, cum, tp, tch);
-            CRUMBLE_LAUNCH_INDEP(k_i64scan_partials, 1, 1, st, tp, tch);
+            CRUMBLE_LAUNCH(k_i64scan_partials, 1, 1024, st, tp, tch);
             CRUMBLE_LAUNCH_INDEP(k_i64scan_apply, nblk(tch, 64), 64, st, (int64_t)B.n_tiles, cum, tp, tch);
             int64_t total = 0;                              /* (one small read-back: sizes the unit table) */
             HIPCHK(hipMemcpyAsync(&total, cum + B.n_tiles, 8, hipMemcpyDeviceToHost, st));
@@ -469,13 +476,18 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
             CRUMBLE_LAUNCH_INDEP(k_unit_first, nblk(B.n_units + 1, 256), 256, st, B.n_units, B.n_tiles, cum, h->d_ufirst.as<int32_t>());
         }
         if (nb > 0) {
-            CRUMBLE_LAUNCH_INDEP(k_p0_blkread, nblk((int64_t)nblkb, 256), 256, st, (int64_t)((nb + 63) / 64), n,
-                                 h->d_seq_off.as<int64_t>(), h->d_blk_read.as<int32_t>());
-            if (!(tot.nseg > n + n / 2)) {                      /* short reads: k_replay_fast's per-chunk table */
-                const int64_t nch = (nb + 15) / 16;
-                if ((e = h->d_chunk_read.reserve((size_t)(nch + 1) * 4))) return e;
-                CRUMBLE_LAUNCH_INDEP(k_p0_chunkread, nblk(nch, 256), 256, st, nch, n, h->d_seq_off.as<int64_t>(),
+            const bool shortreads = !(tot.nseg > n + n / 2) && nb < 1024 * n;
+            const int64_t nch = (nb + 15) / 16;
+            if ((e = h->d_chunk_read.reserve((size_t)(nch + 2) * 4))) return e;
+            if (shortreads) {                                   /* both owner tables by scatter from the reads */
+                CRUMBLE_LAUNCH_INDEP(k_p0_owner_scatter, nblk(n, 256), 256, st, n, nb, h->d_seq_off.as<int64_t>(),
                                      h->d_blk_read.as<int32_t>(), h->d_chunk_read.as<int32_t>());
+            } else {
+                CRUMBLE_LAUNCH_INDEP(k_p0_blkread, nblk((int64_t)nblkb, 256), 256, st, (int64_t)((nb + 63) / 64), n,
+                                     h->d_seq_off.as<int64_t>(), h->d_blk_read.as<int32_t>());
+                if (!(tot.nseg > n + n / 2))                        /* k_replay_fast's per-chunk table */
+                    CRUMBLE_LAUNCH_INDEP(k_p0_chunkread, nblk(nch, 256), 256, st, nch, n, h->d_seq_off.as<int64_t>(),
+                                         h->d_blk_read.as<int32_t>(), h->d_chunk_read.as<int32_t>());
             }
         }
     }
@@ -501,8 +513,11 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
         (e = h->d_out.reserve((size_t)nb + 64)) || (e = h->d_rflags.reserve((size_t)(n ? n : 1))) ||
         (e = h->d_keepf.reserve((size_t)(n ? n : 1))) || (e = h->d_kept.reserve((size_t)(n ? n : 1) * 4)) || (e = h->d_b15f.reserve((size_t)(n ? n : 1))))
         return e;
+    HIPCHK(hipEventRecord(h->ev_up[2], st));
     HIPCHK(hipStreamSynchronize(st));               /* the caller may free its host buffers */
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventElapsedTime(&h->up_h2d_ms, h->ev_up[0], h->ev_up[1]));
+    HIPCHK(hipEventElapsedTime(&h->up_p0_ms, h->ev_up[1], h->ev_up[2]));
     h->have_batch = true;
     return CRUMBLE_OK;
 }
@@ -585,10 +600,7 @@ extern "C" int crumble_hip_run(crumble_hip *h)
     HIPCHK(hipMemsetAsync(d_overflow, 0, 16, st));      /* [0] overflow, [1] n_epochs, [2] n_kept, [3] k_columns work counter; [8..11] belong to upload */
 
     if (L > 0) {
-        STAGE("k_headtail", 0);
         uint32_t *ht = h->d_ht.as<uint32_t>();
-        HIPCHK(hipMemsetAsync(ht, 0, (size_t)L * 4, st));
-        CRUMBLE_LAUNCH_INDEP(k_headtail, nblk(n, 256), 256, st, B, ht);
         const bool modeB = h->hparams.min_qual_B != 0;
         const unsigned kw = KCOL_THREADS / 64;
         unsigned grid = nblk(B.n_tiles, kw);
@@ -603,6 +615,11 @@ extern "C" int crumble_hip_run(crumble_hip *h)
          * (min_qual 0) stay with k_columns */
         const bool use_cons = modeB ? true : h->hparams.min_qual_A != 0;
         const bool v2 = (h->opt_kcol == 0 || h->opt_kcol == 3) && !(modeA && modeB) && use_cons;
+        if (!v2) {                                          /* k_columns2 counts heads / tails while it stages its records */
+            STAGE("k_headtail", 0);
+            HIPCHK(hipMemsetAsync(ht, 0, (size_t)L * 4, st));
+            CRUMBLE_LAUNCH_INDEP(k_headtail, nblk(n, 256), 256, st, B, ht);
+        }
         STAGE(v2 ? "k_columns2" : "k_columns", 2.0 * nb + 32.0 * n + 8.0 * h->n_cigar);
         if (v2) {
             unsigned g2 = (h->persistent_blocks + 3) / 4;       /* one workgroup of KC2_WAVES waves per CU */
@@ -780,6 +797,14 @@ extern "C" int crumble_hip_kernel_times(crumble_hip *h, const char **names, floa
         if (bytes) bytes[i] = h->stage_bytes[i];
     }
     return n;
+}
+
+extern "C" int crumble_hip_upload_times(crumble_hip *h, float *h2d_ms, float *p0_ms)
+{
+    if (!h || !h->have_batch) return CRUMBLE_EINVAL;
+    if (h2d_ms) *h2d_ms = h->up_h2d_ms;
+    if (p0_ms) *p0_ms = h->up_p0_ms;
+    return CRUMBLE_OK;
 }
 
 /* ------------------------------------------------------------------ stats */

@@ -97,6 +97,7 @@ struct __attribute__((aligned(16))) KC2Wave {      /* one wave's LDS */
     uint4    recs[KC2_R][2];                       /* SegRec: {pos, end, so.lo, so.hi} {lq, qoff, indel_after, info} */
     uint32_t rowinfo[KC2_R];
     int32_t  cnt[2][68];                           /* difference arrays over the tile's columns: all records / low-mapq records */
+    uint32_t ht[64];                               /* per column: head/tail entries (low half), clipped ones (high half) */
 };
 
 /* The 15 genotype sums and 5 discrepancy sums are NAMED LOCAL SCALARS of the kernel (permuted numbering, see the
@@ -272,6 +273,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
         st.clipped = st.n_overlap = st.n_isindel = st.has_ins = 0;
         st.cp = 0;
         int n_lq0 = 0;
+        unsigned htacc = 0;
         unsigned pend = 0, key = 0;
         bool first = true;
         int wnext = lo;
@@ -282,7 +284,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
              * difference arrays over the tile's columns, not from the rows */
             int nq = 0;
             bool anylow = false;
-            W.cnt[0][lane] = 0; W.cnt[1][lane] = 0;
+            W.cnt[0][lane] = 0; W.cnt[1][lane] = 0; W.ht[lane] = 0;
             if (lane < 4) { W.cnt[0][64 + lane] = 0; W.cnt[1][64 + lane] = 0; }
             WAVE_SYNC();
             while (wnext < hi) {
@@ -311,6 +313,19 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                     atomicAdd(&W.cnt[0][a], 1); atomicAdd(&W.cnt[0][b], -1);
                     lowrec = (int)(r1.w & 255u) <= min_mqual;
                     if (lowrec) { atomicAdd(&W.cnt[1][a], 1); atomicAdd(&W.cnt[1][b], -1); }
+                    /* is_head / is_tail bookkeeping (snp:1701-1706): two columns per read; a ref-skip entry is not
+                     * counted (snp:1696); head and tail on one column count once */
+                    const unsigned info = r1.w;
+                    if (SR_TYPE(info) != SEG_N && (info & (SR_FIRST | SR_LAST))) {
+                        const int hc = (int)r0.x - c0, tc = (int)r0.y - 1 - c0;
+                        const bool hd = (info & SR_FIRST) && hc >= 0, tl = (info & SR_LAST) && tc < 64;
+                        if (hd && tl && hc == tc)
+                            atomicAdd(&W.ht[hc], 1u + ((info & (SR_HEADCLIP | SR_TAILCLIP)) ? 0x10000u : 0u));
+                        else {
+                            if (hd) atomicAdd(&W.ht[hc], 1u + ((info & SR_HEADCLIP) ? 0x10000u : 0u));
+                            if (tl) atomicAdd(&W.ht[tc], 1u + ((info & SR_TAILCLIP) ? 0x10000u : 0u));
+                        }
+                    }
                 }
                 anylow = anylow || __ballot(lowrec) != 0ull;
                 nq += h;
@@ -328,6 +343,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                     if (lane >= d) { dn += on; dl += ol; }
                 }
                 st.n_plp += dn; st.low_mq += dl;
+                htacc += W.ht[lane];
             }
             for (int g0 = 0; g0 < nq; g0 += KC2_PR) {
             const int rows = nq - g0 < KC2_PR ? nq - g0 : KC2_PR, rows4 = (rows + 3) & ~3;
@@ -526,7 +542,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
         st.sC[0] = d0; st.sC[1] = d1; st.sC[2] = d2; st.sC[3] = d3; st.sC[4] = d4;
         st.nN = nN;
         if (inr) {
-            const uint32_t h = ht[c];
+            const uint32_t h = htacc;
             st.depth = st.n_plp - st.nref - n_lq0;       /* entries that reached the sums (snp:685) */
             st.clipped = (int)(h >> 16);
             st.n_overlap = st.n_plp - st.nref - (int)(h & 0xffff);

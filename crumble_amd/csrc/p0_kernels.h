@@ -58,18 +58,20 @@ __device__ __forceinline__ int p0_indel_after(const uint32_t *cig, int n, int k)
     return indel;
 }
 
-__global__ void k_p0_classify(int64_t n, int tid, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
+__device__ __forceinline__ void p0_classify_read(int64_t r, int tid, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
                               const int64_t *__restrict__ seq_off, const int64_t *__restrict__ cig_off,
                               const uint32_t *__restrict__ cigar, uint8_t *__restrict__ inplp,
-                              int32_t *__restrict__ end, P0Cnt *__restrict__ cnt, int *err, int *minmax)
+                              int32_t *__restrict__ end, P0Cnt *__restrict__ cnt, int *err, int &mn, int &mx,
+                              int64_t nb, int64_t nc)
 {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const uint32_t *cig = cigar + cig_off[r];
-    const int64_t ncg64 = cig_off[r + 1] - cig_off[r], lq = seq_off[r + 1] - seq_off[r];
+    const int64_t co0 = cig_off[r], co1 = cig_off[r + 1], so0 = seq_off[r], so1 = seq_off[r + 1];
+    const int64_t ncg64 = co1 - co0, lq = so1 - so0;
     P0Cnt c = {0, 0, 0};
     inplp[r] = 0; end[r] = pos[r];
-    if (lq < 0 || ncg64 < 0 || lq > 0x3fffffff) { atomicMax(err, P0_ERR_NEG); cnt[r] = c; return; }
+    /* offsets must run 0 <= off[r] <= off[r+1] <= total before anything is dereferenced through them */
+    if (lq < 0 || ncg64 < 0 || lq > 0x3fffffff || co0 < 0 || co1 > nc || so0 < 0 || so1 > nb ||
+        (r == 0 && (co0 != 0 || so0 != 0))) { atomicMax(err, P0_ERR_NEG); cnt[r] = c; return; }
+    const uint32_t *cig = cigar + co0;
     const int ncg = (int)ncg64;
     /* pileup_callback routing (snp:1130-1149) + htslib's default filter */
     if (tid < 0 || (flag[r] & (4 | 256 | 512 | 1024))) { cnt[r] = c; return; }
@@ -95,8 +97,28 @@ __global__ void k_p0_classify(int64_t n, int tid, const int32_t *__restrict__ po
     const bool simple = nseg == 1 && first_type == 0 && first_ia == 0 && lq > 0;
     c.nseg = nseg; c.ncix = simple ? 0 : lq; c.nslow = simple ? 0 : ndn;
     cnt[r] = c;
-    atomicMin(&minmax[0], pos[r]);
-    atomicMax(&minmax[1], end[r]);
+    mn = pos[r]; mx = end[r];                              /* extent of the pileup */
+}
+
+__global__ void k_p0_classify(int64_t n, int tid, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
+                              const int64_t *__restrict__ seq_off, const int64_t *__restrict__ cig_off,
+                              const uint32_t *__restrict__ cigar, uint8_t *__restrict__ inplp,
+                              int32_t *__restrict__ end, P0Cnt *__restrict__ cnt, int *err, int *minmax,
+                              int64_t nb, int64_t nc)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int mn = INT_MAX, mx = INT_MIN;
+    if (r < n) p0_classify_read(r, tid, pos, flag, seq_off, cig_off, cigar, inplp, end, cnt, err, mn, mx, nb, nc);
+    /* one atomic pair per wave, not per read (12.6 M atomics on two words were most of this kernel's 4.5 ms) */
+    #pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int a = __shfl_xor(mn, d), b = __shfl_xor(mx, d);
+        mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (mn != INT_MAX) atomicMin(&minmax[0], mn);
+        if (mx != INT_MIN) atomicMax(&minmax[1], mx);
+    }
 }
 
 __global__ void k_p0_sorted(int64_t n, const int32_t *__restrict__ pos, const uint8_t *__restrict__ inplp, int *err)
@@ -155,12 +177,30 @@ __global__ void k_p0scan_reduce(int64_t n, const P0Cnt *__restrict__ cnt, P0Cnt 
     for (int64_t i = b; i < e; i++) p0cnt_add(acc, cnt[i]);
     partial[t] = acc;
 }
-__global__ void k_p0scan_partials(P0Cnt *partial, int nchunks)
+/* exclusive scan of the chunk sums by ONE 1024-thread workgroup: a contiguous slice per thread, the thread sums
+ * scanned through LDS (it was one thread walking 12 000 chunks: 1.7 ms per upload) */
+__global__ void __launch_bounds__(1024)
+k_p0scan_partials(P0Cnt *partial, int nchunks)
 {
-    if (blockIdx.x || threadIdx.x) return;
+    __shared__ P0Cnt sh[1024];
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int per = (nchunks + nt - 1) / nt;
+    const int b = t * per, e = b + per < nchunks ? b + per : nchunks;
+    P0Cnt acc = {0, 0, 0};
+    for (int i = b; i < e; i++) p0cnt_add(acc, partial[i]);
+    sh[t] = acc;
+    __syncthreads();
+    for (int d = 1; d < nt; d <<= 1) {                    /* Hillis-Steele inclusive scan of the thread sums */
+        P0Cnt v = {0, 0, 0};
+        if (t >= d) v = sh[t - d];
+        __syncthreads();
+        p0cnt_add(sh[t], v);
+        __syncthreads();
+    }
     P0Cnt run = {0, 0, 0};
-    for (int i = 0; i < nchunks; i++) { const P0Cnt v = partial[i]; partial[i] = run; p0cnt_add(run, v); }
-    partial[nchunks] = run;
+    if (t > 0) run = sh[t - 1];
+    for (int i = b; i < e; i++) { const P0Cnt v = partial[i]; partial[i] = run; p0cnt_add(run, v); }
+    if (t == nt - 1) partial[nchunks] = sh[nt - 1];
 }
 __global__ void k_p0scan_apply(int64_t n, P0Cnt *__restrict__ cnt, const P0Cnt *__restrict__ partial, int nchunks)
 {
@@ -299,6 +339,24 @@ __global__ void k_p0_chunkread(int64_t nchunks, int64_t n, const int64_t *__rest
     chunk_read[c] = (int32_t)r;
 }
 
+/* The same two tables for short-read batches, by scatter: read r owns the blocks / chunks whose first base lies in
+ * [seq_off[r], seq_off[r+1]) -- a couple of blocks and ~10 chunks per 150-base read, instead of a 24-step binary
+ * search per block (0.64 + 0.44 ms per upload) */
+__global__ void k_p0_owner_scatter(int64_t n, int64_t nb, const int64_t *__restrict__ seq_off,
+                                   int32_t *__restrict__ blk_read, int32_t *__restrict__ chunk_read)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int64_t a = seq_off[r], b = seq_off[r + 1];
+    if (b <= a) return;
+    for (int64_t k = (a + 63) >> 6; k * 64 < b; k++) blk_read[k] = (int32_t)r;
+    for (int64_t k = (a + 15) >> 4; k * 16 < b; k++) chunk_read[k] = (int32_t)r;
+    if (b == nb) {                                         /* the entries past the last base (readers clamp) */
+        blk_read[(nb + 63) >> 6] = (int32_t)r;
+        chunk_read[(nb + 15) >> 4] = (int32_t)r;
+    }
+}
+
 /* Work split of k_columns: an estimated cost per 64-column tile (its candidate records plus a constant
  * for the per-tile prologue/epilogue), prefix-summed, so that every wave can take a CONTIGUOUS run of
  * tiles of equal total cost -- no atomics, adjacent tiles (which share their reads) stay in one wave. */
@@ -319,12 +377,27 @@ __global__ void k_i64scan_reduce(int64_t n, const int64_t *__restrict__ v, int64
     for (int64_t i = b; i < e; i++) acc += v[i];
     partial[t] = acc;
 }
-__global__ void k_i64scan_partials(int64_t *partial, int nchunks)
+__global__ void __launch_bounds__(1024)
+k_i64scan_partials(int64_t *partial, int nchunks)
 {
-    if (blockIdx.x || threadIdx.x) return;
-    int64_t run = 0;
-    for (int i = 0; i < nchunks; i++) { const int64_t v = partial[i]; partial[i] = run; run += v; }
-    partial[nchunks] = run;
+    __shared__ int64_t sh[1024];
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int per = (nchunks + nt - 1) / nt;
+    const int b = t * per, e = b + per < nchunks ? b + per : nchunks;
+    int64_t acc = 0;
+    for (int i = b; i < e; i++) acc += partial[i];
+    sh[t] = acc;
+    __syncthreads();
+    for (int d = 1; d < nt; d <<= 1) {
+        int64_t v = 0;
+        if (t >= d) v = sh[t - d];
+        __syncthreads();
+        sh[t] += v;
+        __syncthreads();
+    }
+    int64_t run = t > 0 ? sh[t - 1] : 0;
+    for (int i = b; i < e; i++) { const int64_t v = partial[i]; partial[i] = run; run += v; }
+    if (t == nt - 1) partial[nchunks] = sh[nt - 1];
 }
 /* exclusive scan in place; v[n] receives the total */
 __global__ void k_i64scan_apply(int64_t n, int64_t *__restrict__ v, const int64_t *__restrict__ partial, int nchunks)

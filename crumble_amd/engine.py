@@ -64,6 +64,7 @@ def load_library(path=None, make_default=True):
         "crumble_hip_run": (C.c_int, [vp]),
         "crumble_hip_download": (C.c_int, [vp, vp, vp, vp]),
         "crumble_hip_kernel_times": (C.c_int, [vp, vp, vp, vp, C.c_int]),
+        "crumble_hip_upload_times": (C.c_int, [vp, vp, vp]),
         "crumble_hip_stats_devptr": (vp, [vp]),
         "crumble_hip_stats_reset": (C.c_int, [vp]),
         "crumble_hip_stats_read": (C.c_int, [vp, vp]),
@@ -95,7 +96,7 @@ EXPORTED = [
     "crumble_params_keep_quals", "crumble_init_bins", "crumble_bed_collapse",
     "crumble_hip_create", "crumble_hip_destroy", "crumble_hip_set_option", "crumble_hip_contig",
     "crumble_hip_upload", "crumble_hip_run", "crumble_hip_download",
-    "crumble_hip_kernel_times", "crumble_hip_stats_devptr", "crumble_hip_stats_reset",
+    "crumble_hip_kernel_times", "crumble_hip_upload_times", "crumble_hip_stats_devptr", "crumble_hip_stats_reset",
     "crumble_hip_stats_read", "crumble_hip_stats_allreduce", "crumble_hip_columns",
     "crumble_hip_mask_lc", "crumble_hip_pblock", "crumble_hip_indel_only", "crumble_hip_strerror",
     "crumble_hip_last_error",
@@ -204,6 +205,12 @@ class Engine:
         n = self.L.crumble_hip_kernel_times(self.h, C.cast(names, C.c_void_p), _vp(ms),
                                            _vp(by), maxk)
         return [(names[i].decode(), float(ms[i]), float(by[i])) for i in range(n)]
+
+    def upload_times(self):
+        """(h2d_ms, p0_ms) of the last upload(): raw copies, device-side expansion."""
+        a, b = C.c_float(0), C.c_float(0)
+        self._chk(self.L.crumble_hip_upload_times(self.h, C.byref(a), C.byref(b)), "upload_times")
+        return float(a.value), float(b.value)
 
     def mask_lc(self, read_idx, qpos1, is_indel):
         r = np.ascontiguousarray(read_idx, np.int64)

@@ -180,6 +180,10 @@ int crumble_hip_download(crumble_hip *h, uint8_t *qual_out,
 int crumble_hip_kernel_times(crumble_hip *h, const char **names, float *ms,
                              double *bytes, int max);
 
+/* Stream time of the last crumble_hip_upload(): the host->device copies of the raw arrays, and the device-side
+ * expansion (P0: routing, validation, op tables, tile ranges) including its two small size read-backs. */
+int crumble_hip_upload_times(crumble_hip *h, float *h2d_ms, float *p0_ms);
+
 /* Accumulated device-side stats vector (int64[CRUMBLE_ST_N]) of this engine:
  * a raw device pointer so torch.distributed / RCCL can all-reduce it in place. */
 void *crumble_hip_stats_devptr(crumble_hip *h);

@@ -25,6 +25,11 @@ def load():
 
 
 def engine(params, **options):
+    """Emulated engine.  k_columns2's wave-level idioms (a ballot or an LDS hand-off per matrix row) cost a fiber
+    rendezvous each under emulation, ~10x the time of k_columns, so tests that are not about the column kernel get
+    k_columns here unless they ask; the column-kernel, fuzz and tiny-read tests force every variant, and on the GPU
+    every test runs the engine's own choice (k_columns2)."""
+    options.setdefault("kcol", "v1")
     return crumble_amd.Engine(params, 0, library=load(), options=options)
 
 

@@ -284,3 +284,22 @@ def test_find_str_stress(product):
     for i in range(len(idx)):
         assert O.mask_lc(p, hb, int(idx[i]), int(kind[i]), int(qpos1[i])) == (lo[i], hi[i]), (i, idx[i], qpos1[i])
     eng.close()
+
+
+def test_rerun_and_engine_reuse(product):
+    """The work bench.py times: run(); download == run(); run(); download (grow-only buffers, partially written
+    arrays), and one engine reused for batches of different shapes == the oracle every time."""
+    p = ca.preset_params(9)
+    eng = ca.Engine(p, 0)
+    a, b, c = synth_batch("chr20", 0.01), synth_batch("panel", 0.005), synth_batch("hifi", 0.002)
+    eng.upload(a); eng.run()
+    q1, f1, s1 = eng.download()
+    eng.run(); eng.run()
+    q2, f2, s2 = eng.download()
+    assert np.array_equal(q1, q2) and np.array_equal(f1, f2) and np.array_equal(s1, s2)
+    import oracle_lib as O
+    for hb in (b, c, a, HostBatch.from_reads([]), b):
+        got = eng.contig(hb)
+        want = O.contig(p, hb)
+        assert all(np.array_equal(x, y) for x, y in zip(got, want))
+    eng.close()
