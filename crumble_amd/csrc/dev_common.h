@@ -52,6 +52,7 @@ struct DTables {
     uint8_t pvc[256];
     uint8_t adjc[65536];
 };
+#define CIX_UNIT 16
 #define BASE_FRONT_PAD 64   /* bytes in front of bases[0] / quals[0]: k_columns2 loads whole 16-column segments */
 
 /* One reference-consuming CIGAR op (M,=,X / D / N) of a read, with what
@@ -77,7 +78,8 @@ struct ReadRec {
     int32_t  lq;            /* l_qseq */
     int32_t  q0;            /* query index of the first aligned base */
     uint32_t info;          /* mapq | RR_SIMPLE */
-    uint32_t cix;           /* general CIGARs: first entry of this read in the base->column table */
+    uint32_t cix;           /* general CIGARs: first entry of this read in the base->column table, in units of
+                             * CIX_UNIT entries (every read's slice is padded to a multiple: 2^32 * 16 entries reachable) */
 };
 
 /* One reference-consuming CIGAR op of one read, self-contained, in file order: the unit

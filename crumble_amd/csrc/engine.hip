@@ -380,7 +380,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     default:           g_last_error = "negative or oversized read / cigar length"; return CRUMBLE_EINVAL;
     }
     if (tot.nseg >= (int64_t)INT_MAX - 64) { g_last_error = "too many CIGAR segments in one batch"; return CRUMBLE_EINVAL; }
-    if (tot.ncix >= (int64_t)0xfffffff0u) { g_last_error = "base->column table too large"; return CRUMBLE_EINVAL; }
+    if (tot.ncix / CIX_UNIT >= (int64_t)0xfffffff0u) { g_last_error = "base->column table too large"; return CRUMBLE_EINVAL; }
 
     DBatch &B = h->B;
     memset(&B, 0, sizeof(B));

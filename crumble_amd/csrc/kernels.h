@@ -1651,7 +1651,7 @@ k_replay_flat(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
                     if (off >= 0 && off < rr.end - rr.pos) cidx[k] = rr.pos + off - B.p0;
                     if (hm) hmm |= 1u << k;
                 } else {                                   /* general CIGAR: base -> column table built with the batch (k_p0_fill) */
-                    const int c = B.cix[(size_t)rr.cix + (size_t)(g - rr.so)];
+                    const int c = B.cix[(size_t)rr.cix * CIX_UNIT + (size_t)(g - rr.so)];
                     if (c == -2) slow |= 1u << k;          /* D/N columns report this base: sequence matters */
                     else { cidx[k] = c; if (hm) hmm |= 1u << k; }
                 }
@@ -1883,7 +1883,7 @@ k_replay_reads(DBatch B, const DParams *__restrict__ P, const uint32_t *__restri
             for (int u = 0; u < 4; u++) {
                 const int x = x0 + 64 * u;
                 c4[u] = -1; q4[u] = 0; b4[u] = 0;
-                if (x < n) { c4[u] = B.cix[(size_t)cx + (size_t)x]; q4[u] = B.quals[s0 + x]; b4[u] = B.bases[s0 + x]; }
+                if (x < n) { c4[u] = B.cix[(size_t)cx * CIX_UNIT + (size_t)x]; q4[u] = B.quals[s0 + x]; b4[u] = B.bases[s0 + x]; }
             }
             #pragma unroll
             for (int u = 0; u < 4; u++) r4[u] = c4[u] >= 0 ? colrec[c4[u]] : 0u;

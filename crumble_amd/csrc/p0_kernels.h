@@ -95,7 +95,7 @@ __device__ __forceinline__ void p0_classify_read(int64_t r, int tid, const int32
     inplp[r] = 1;
     end[r] = pos[r] + (int32_t)x;
     const bool simple = nseg == 1 && first_type == 0 && first_ia == 0 && lq > 0;
-    c.nseg = nseg; c.ncix = simple ? 0 : lq; c.nslow = simple ? 0 : ndn;
+    c.nseg = nseg; c.ncix = simple ? 0 : ((lq + CIX_UNIT - 1) & ~(int64_t)(CIX_UNIT - 1)); c.nslow = simple ? 0 : ndn;
     cnt[r] = c;
     mn = pos[r]; mx = end[r];                              /* extent of the pileup */
 }
@@ -270,7 +270,7 @@ __global__ void k_p0_fill(int64_t n, int p0, const int32_t *__restrict__ pos, co
     const bool simple = nseg == 1 && seg_type(s0) == SEG_M && s0.indel_after == 0 && lq > 0;
     if (simple) { x.info |= RR_SIMPLE; rr[r] = x; return; }
     /* pass 2: base -> column table of a general CIGAR (replay) */
-    x.cix = (uint32_t)o.ncix;
+    x.cix = (uint32_t)(o.ncix / CIX_UNIT);
     rr[r] = x;
     int32_t *cx = cix + o.ncix;
     for (int i = 0; i < lq; i++) cx[i] = -1;
