@@ -106,6 +106,7 @@ struct crumble_bam_reader {
     /* the uncompressed stream window: [0, raw_len) valid, scan = parse position     */
     uint8_t *raw; size_t raw_len, raw_cap, scan;
     size_t group_end;                         /* end of the current group inside raw */
+    size_t head;                              /* bytes in front of it that are done with (dropped lazily) */
     /* header */
     char *text; int64_t l_text;
     int32_t n_ref; char **ref_name; int64_t *ref_len;
@@ -375,13 +376,19 @@ static void scan_records(crumble_bam_reader *r)
 
 int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
 {
-    /* drop the previous group (or the header) from the window */
-    if (r->group_end) {
-        memmove(r->raw, r->raw + r->group_end, r->raw_len - r->group_end);
-        r->raw_len -= r->group_end; r->scan -= r->group_end; r->group_end = 0;
+    /* drop the previous group (or the header) from the window: only the offset moves; the bytes are
+     * compacted once the dead prefix is both large and most of the window (a file of thousands of
+     * small contigs used to memmove the whole read-ahead window per contig) */
+    if (r->group_end) { r->head = r->group_end; r->group_end = 0; }
+    if (r->head > ((size_t)64 << 20) && r->head * 2 > r->raw_len) {
+        memmove(r->raw, r->raw + r->head, r->raw_len - r->head);
+        r->raw_len -= r->head; r->scan -= r->head; r->head = 0;
     }
     r->n = 0; r->have_tid = 0; r->group_done = 0; r->scan_err = 0; r->acc_nb = r->acc_nc = 0;
-    for (;;) {
+    /* the resident bytes may already hold the whole next group: walk them before reading ahead */
+    scan_records(r);
+    if (r->scan_err) return r->scan_err;
+    while (!r->group_done) {
         /* inflate the next chunk while one thread walks the records that are already there */
         const int rc = refill(r, 1);
         if (rc < 0) return rc;
@@ -457,6 +464,44 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
     b->seq_off = r->seq_off; b->cig_off = r->cig_off; b->cigar = r->cigar;
     b->bases = r->bases; b->quals = r->quals;
     return 1;
+}
+
+/* A detached group: the reader-shaped shell that owns one contig's record bytes and SoA arrays, so that the
+ * reader can go on to the next contig while this one is on a GPU or being written (crumble-hip --gpus N). */
+crumble_bam_group *crumble_bam_detach_group(crumble_bam_reader *r)
+{
+    crumble_bam_reader *g = calloc(1, sizeof *g);
+    if (!g) { fail(CRUMBLE_BAM_ENOMEM, "out of memory"); return NULL; }
+    const size_t tail = r->raw_len - r->group_end;
+    size_t ncap = (size_t)64 << 20;
+    while (ncap < tail + ((size_t)1 << 20)) ncap *= 2;
+    uint8_t *nraw = big_alloc(ncap);
+    if (!nraw) { free(g); fail(CRUMBLE_BAM_ENOMEM, "out of memory"); return NULL; }
+    memcpy(nraw, r->raw + r->group_end, tail);
+    g->threads = r->threads;
+    g->raw = r->raw; g->raw_cap = r->raw_cap; g->raw_len = r->group_end; g->group_end = r->group_end; g->head = r->head;
+    g->n = r->n; g->cap_n = r->cap_n; g->rec_off = r->rec_off; g->tid = r->tid;
+    g->pos = r->pos; g->mapq = r->mapq; g->flag = r->flag; g->seq_off = r->seq_off; g->cig_off = r->cig_off;
+    g->cigar = r->cigar; g->bases = r->bases; g->quals = r->quals;
+    g->cap_reads = r->cap_reads; g->cap_bases = r->cap_bases; g->cap_cig = r->cap_cig;
+    r->raw = nraw; r->raw_cap = ncap; r->raw_len = tail; r->scan -= r->group_end; r->group_end = 0; r->head = 0;
+    r->n = 0; r->cap_n = 0; r->rec_off = NULL; r->seq_off = NULL; r->cig_off = NULL;
+    r->pos = NULL; r->mapq = NULL; r->flag = NULL; r->cigar = NULL; r->bases = NULL; r->quals = NULL;
+    r->cap_reads = r->cap_bases = r->cap_cig = 0;
+    return (crumble_bam_group *)g;
+}
+int crumble_bam_write_detached(crumble_bam_writer *w, crumble_bam_group *g, const uint8_t *qual_out)
+{
+    return crumble_bam_write_group(w, (crumble_bam_reader *)g, qual_out);
+}
+void crumble_bam_group_free(crumble_bam_group *gg)
+{
+    crumble_bam_reader *g = (crumble_bam_reader *)gg;
+    if (!g) return;
+    big_free(g->raw, g->raw_cap); free(g->rec_off); free(g->seq_off); free(g->cig_off);
+    free(g->pos); free(g->mapq); free(g->flag); free(g->cigar);
+    big_free(g->bases, g->cap_bases); big_free(g->quals, g->cap_bases);
+    free(g);
 }
 
 /* ----------------------------------------------------------------- BGZF out */

@@ -17,6 +17,7 @@
 #include <strings.h>
 #include <unistd.h>
 #include <time.h>
+#include <pthread.h>
 #include "../../include/crumble_hip.h"
 #include "../../include/crumble_bamio.h"
 
@@ -43,7 +44,10 @@ static void usage(FILE *fp)
         "  -z                      no @PG header line\n"
         "  -v                      statistics and timings on stderr\n"
         "  -@ N                    host threads for BGZF/BAM work\n"
-        "  (device: environment CRUMBLE_HIP_DEVICE, default 0; output level: CRUMBLE_BAM_LEVEL)\n");
+        "  -j N                    GPUs: contigs are LPT-packed onto devices 0..N-1 by reference length, one engine\n"
+        "                          (and one host thread) per device, output in input order, one RCCL all-reduce of\n"
+        "                          the statistics at the end\n"
+        "  (devices: environment CRUMBLE_HIP_DEVICES=\"0,1,..\" or CRUMBLE_HIP_DEVICE, default 0; output level: CRUMBLE_BAM_LEVEL)\n");
 }
 
 static const char *const ST_NAME[] = {
@@ -51,15 +55,147 @@ static const char *const ST_NAME[] = {
     "hom_qual_B", "discrep_B", "diff", "indel", "indel_qual", "low_mqual_perc", "clip_perc", "ins_len_perc",
     "indel_ov_perc", "over_depth", "reads", "bases", "bases_changed", "triggers", "too_deep" };
 
+/* ---- the contig pipeline: reader (main thread) -> one worker per GPU -> writer, contigs in flight are detached
+ * groups (crumble_bam_detach_group).  Every cross-column state of the reference resets on a contig change
+ * (snp_score.c:1478-1488), so contigs are independent units; the writer restores input order. */
+#define MAX_DEV 16
+#define MAX_INFLIGHT 4              /* per device */
+typedef struct job {
+    struct job *next;
+    int64_t seq; int dev, done, err;
+    crumble_bam_group *g; crumble_batch B;
+    uint8_t *qout; size_t qcap;
+    int32_t *sus_pos; uint8_t *sus_why; int64_t n_sus;     /* -b */
+    char errtxt[256];
+} job;
+typedef struct {
+    pthread_mutex_t mu; pthread_cond_t cv;
+    job *q_head[MAX_DEV], *q_tail[MAX_DEV]; int q_len[MAX_DEV];
+    job *done_head;                 /* finished jobs, any order */
+    int64_t next_write; int closing, failed;
+    int ndev, devices[MAX_DEV]; crumble_hip *eng[MAX_DEV]; void *comm[MAX_DEV];
+    int want_suspect, use_rccl;
+    crumble_bam_writer *wr; crumble_bam_reader *rd; FILE *bed_fp;
+    double t_gpu[MAX_DEV], t_write; int verbose;
+    int64_t stats[CRUMBLE_ST_N];
+} pipe_t;
+typedef struct { pipe_t *p; int d; } worker_arg;
+
+static void *gpu_worker(void *a_)
+{
+    worker_arg *a = a_; pipe_t *p = a->p; const int d = a->d;
+    for (;;) {
+        pthread_mutex_lock(&p->mu);
+        while (!p->q_head[d] && !p->closing) pthread_cond_wait(&p->cv, &p->mu);
+        job *j = p->q_head[d];
+        if (!j) { pthread_mutex_unlock(&p->mu); break; }
+        p->q_head[d] = j->next; if (!p->q_head[d]) p->q_tail[d] = NULL;
+        pthread_mutex_unlock(&p->mu);
+        const double t0 = now();
+        const size_t nb = (size_t)j->B.seq_off[j->B.n_reads];
+        j->qcap = nb + 64; j->qout = crumble_bam_big_alloc(j->qcap);
+        if (!j->qout) { j->err = CRUMBLE_ENOMEM; snprintf(j->errtxt, sizeof j->errtxt, "out of memory"); }
+        else {
+            j->err = crumble_hip_contig(p->eng[d], &j->B, j->qout, NULL, NULL);   /* stats stay on the device */
+            if (j->err) snprintf(j->errtxt, sizeof j->errtxt, "%s (%s)", crumble_hip_strerror(j->err), crumble_hip_last_error());
+        }
+        if (!j->err && p->want_suspect && j->B.tid >= 0) {        /* -b: snp_score.c:1496,1676,1768,1802,1810 */
+            const int64_t ns = crumble_hip_suspect(p->eng[d], NULL, NULL, 0);
+            j->sus_pos = malloc((size_t)(ns > 0 ? ns : 1) * 4); j->sus_why = malloc((size_t)(ns > 0 ? ns : 1));
+            if (ns < 0 || !j->sus_pos || !j->sus_why || crumble_hip_suspect(p->eng[d], j->sus_pos, j->sus_why, ns) != ns) {
+                j->err = ns < 0 ? (int)ns : CRUMBLE_ENOMEM; snprintf(j->errtxt, sizeof j->errtxt, "-b failed");
+            }
+            j->n_sus = ns > 0 ? ns : 0;
+        }
+        pthread_mutex_lock(&p->mu);
+        p->t_gpu[d] += now() - t0;
+        p->q_len[d]--;
+        j->done = 1; j->next = p->done_head; p->done_head = j;
+        pthread_cond_broadcast(&p->cv);
+        pthread_mutex_unlock(&p->mu);
+    }
+    /* the one collective of the path: every engine's accumulated statistics vector, summed over the devices */
+    if (p->use_rccl) {
+        const int e = crumble_hip_stats_allreduce(p->eng[d], p->comm[d]);
+        if (e) { pthread_mutex_lock(&p->mu); p->failed = 1; fprintf(stderr, "crumble-hip: stats all-reduce on device %d: %s (%s)\n", p->devices[d], crumble_hip_strerror(e), crumble_hip_last_error()); pthread_mutex_unlock(&p->mu); }
+    }
+    return NULL;
+}
+
+static void *writer_thread(void *p_)
+{
+    pipe_t *p = p_;
+    static const struct { int bit; const char *name; } why[] = {
+        { CRUMBLE_WHY_VDEEP, "VDEEP" }, { CRUMBLE_WHY_DEEP, "DEEP" }, { CRUMBLE_WHY_CLIP, "CLIP" },
+        { CRUMBLE_WHY_INDEL_LEN, "INDEL_LEN" }, { CRUMBLE_WHY_INDEL_COVERAGE, "INDEL_COVERAGE" } };
+    for (;;) {
+        pthread_mutex_lock(&p->mu);
+        job *j = NULL;
+        for (;;) {
+            job **pp = &p->done_head;
+            while (*pp && (*pp)->seq != p->next_write) pp = &(*pp)->next;
+            if (*pp) { j = *pp; *pp = j->next; break; }
+            int pending = 0;
+            for (int d = 0; d < p->ndev; d++) pending += p->q_len[d];
+            if (p->closing && !pending && !p->done_head) break;
+            pthread_cond_wait(&p->cv, &p->mu);
+        }
+        pthread_mutex_unlock(&p->mu);
+        if (!j) break;
+        const double t0 = now();
+        if (j->err && !p->failed) {
+            fprintf(stderr, "crumble-hip: contig %s: %s\n", crumble_bam_ref_name(p->rd, j->B.tid), j->errtxt);
+            p->failed = 2;
+        }
+        if (!p->failed) {
+            for (int64_t k = 0; k < j->n_sus; k++)
+                for (int y = 0; y < 5; y++)
+                    if (j->sus_why[k] & why[y].bit)
+                        fprintf(p->bed_fp, "%s\t%d\t%d\t%s\n", crumble_bam_ref_name(p->rd, j->B.tid),
+                                j->sus_pos[k] > 50 ? j->sus_pos[k] - 50 : 0, j->sus_pos[k] + 50, why[y].name);
+            if (crumble_bam_write_detached(p->wr, j->g, j->qout)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); p->failed = 1; }
+        }
+        if (p->verbose > 1) fprintf(stderr, "  %s: %lld reads on device %d\n", crumble_bam_ref_name(p->rd, j->B.tid), (long long)j->B.n_reads, p->devices[j->dev]);
+        crumble_bam_group_free(j->g); crumble_bam_big_free(j->qout, j->qcap); free(j->sus_pos); free(j->sus_why);
+        pthread_mutex_lock(&p->mu);
+        p->t_write += now() - t0;
+        p->next_write++;
+        free(j);
+        pthread_cond_broadcast(&p->cv);
+        pthread_mutex_unlock(&p->mu);
+    }
+    return NULL;
+}
+
+/* lpt_pack (crumble_amd/shard.py): longest first onto the least loaded device */
+static void lpt_assign(const crumble_bam_reader *rd, int ndev, int *dev_of)
+{
+    const int32_t n = crumble_bam_n_ref(rd);
+    int32_t *order = malloc((size_t)(n > 0 ? n : 1) * sizeof *order);
+    int64_t load[MAX_DEV] = {0};
+    for (int32_t i = 0; i < n; i++) order[i] = i;
+    for (int32_t i = 1; i < n; i++) {                      /* insertion sort by (-length, index): n is a few thousand at most */
+        const int32_t v = order[i]; int32_t k = i;
+        while (k > 0 && crumble_bam_ref_len(rd, order[k - 1]) < crumble_bam_ref_len(rd, v)) { order[k] = order[k - 1]; k--; }
+        order[k] = v;
+    }
+    for (int32_t i = 0; i < n; i++) {
+        int best = 0;
+        for (int d = 1; d < ndev; d++) if (load[d] < load[best]) best = d;
+        dev_of[order[i]] = best; load[best] += crumble_bam_ref_len(rd, order[i]);
+    }
+    free(order);
+}
+
 int main(int argc, char **argv)
 {
     crumble_params P;
     crumble_params_default(&P);
-    int opt, verbose = 0, threads = 0, no_pg = 0;
+    int opt, verbose = 0, threads = 0, no_pg = 0, ngpu = 1;
     const char *bed_fn = NULL, *wl = NULL, *bl = NULL;
     int bd[3] = {0, 0, 0}, bi[3] = {0, 0, 0};
     FILE *bed_fp = NULL;
-    while ((opt = getopt(argc, argv, "I:O:q:d:x:Q:D:X:m:l:u:U:c:i:L:Bs:t:T:hr:b:vC:M:Z:P:V:p:e:f:g:E:F:G:S135789zR:Y:y:k:K:N@:")) != -1) {
+    while ((opt = getopt(argc, argv, "I:O:q:d:x:Q:D:X:m:l:u:U:c:i:L:Bs:t:T:hr:b:vC:M:Z:P:V:p:e:f:g:E:F:G:S135789zR:Y:y:k:K:N@:j:")) != -1) {
         switch (opt) {
         case 'q': P.min_qual_A = atoi(optarg); break;
         case 'd': P.min_indel_A = atoi(optarg); break;
@@ -93,6 +229,7 @@ int main(int argc, char **argv)
         case 'z': no_pg = 1; break;
         case 'v': verbose++; break;
         case '@': threads = atoi(optarg); break;
+        case 'j': ngpu = atoi(optarg); break;
         case 'h': usage(stdout); return 0;
         case 't': wl = optarg; break;
         case 'T': bl = optarg; break;
@@ -112,14 +249,36 @@ int main(int argc, char **argv)
     }
     if (argc - optind != 2) { usage(stderr); return 1; }
     const char *in_fn = argv[optind], *out_fn = argv[optind + 1];
-    const int device = getenv("CRUMBLE_HIP_DEVICE") ? atoi(getenv("CRUMBLE_HIP_DEVICE")) : 0;
     const int level = getenv("CRUMBLE_BAM_LEVEL") ? atoi(getenv("CRUMBLE_BAM_LEVEL")) : -1;
 
-    int err = 0;
-    crumble_hip *eng = crumble_hip_create(&P, device, &err);
-    if (!eng) { fprintf(stderr, "crumble-hip: %s (%s)\n", crumble_hip_strerror(err), crumble_hip_last_error()); return 2; }
+    static pipe_t p;
+    memset(&p, 0, sizeof p);
+    pthread_mutex_init(&p.mu, NULL); pthread_cond_init(&p.cv, NULL);
+    p.verbose = verbose; p.bed_fp = bed_fp; p.want_suspect = bed_fp != NULL;
+    if (ngpu < 1 || ngpu > MAX_DEV) { fprintf(stderr, "crumble-hip: -j must be 1..%d\n", MAX_DEV); return 1; }
+    p.ndev = ngpu;
+    {   /* device list: CRUMBLE_HIP_DEVICES="a,b,.." (tests may name one device twice), else CRUMBLE_HIP_DEVICE + k */
+        const char *dl = getenv("CRUMBLE_HIP_DEVICES");
+        const int base = getenv("CRUMBLE_HIP_DEVICE") ? atoi(getenv("CRUMBLE_HIP_DEVICE")) : 0;
+        for (int d = 0; d < ngpu; d++) {
+            p.devices[d] = base + d;
+            if (dl && *dl) { p.devices[d] = atoi(dl); dl = strchr(dl, ','); dl = dl ? dl + 1 : ""; }
+        }
+    }
+    int err = 0, distinct = 1;
+    for (int d = 0; d < ngpu; d++) {
+        for (int k = 0; k < d; k++) if (p.devices[k] == p.devices[d]) distinct = 0;
+        p.eng[d] = crumble_hip_create(&P, p.devices[d], &err);
+        if (!p.eng[d]) { fprintf(stderr, "crumble-hip: device %d: %s (%s)\n", p.devices[d], crumble_hip_strerror(err), crumble_hip_last_error()); return 2; }
+    }
+    if (ngpu > 1 && distinct) {
+        const int e = crumble_hip_comm_init_all(ngpu, p.devices, p.comm);
+        if (e) { fprintf(stderr, "crumble-hip: RCCL communicator: %s (%s)\n", crumble_hip_strerror(e), crumble_hip_last_error()); return 2; }
+        p.use_rccl = 1;
+    }
     crumble_bam_reader *rd = crumble_bam_open(in_fn, threads, &err);
     if (!rd) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
+    p.rd = rd;
 
     int32_t *bt = NULL, *bs = NULL, *be = NULL; int nbed = 0;
     if (bed_fn && (nbed = crumble_bam_load_bed(rd, bed_fn, &bt, &bs, &be)) < 0) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
@@ -129,72 +288,82 @@ int main(int argc, char **argv)
         size_t len = 64;
         for (int i = 0; i < argc; i++) len += strlen(argv[i]) + 1;
         pg = malloc(len);
-        char *q = pg + sprintf(pg, "@PG\tID:crumble-hip\tPN:crumble-hip\tVN:0.1\tCL:");
+        char *q = pg + sprintf(pg, "@PG\tID:crumble-hip\tPN:crumble-hip\tVN:0.2\tCL:");
         for (int i = 0; i < argc; i++) q += sprintf(q, "%s%s", i ? " " : "", argv[i]);
     }
     crumble_bam_writer *wr = crumble_bam_create(out_fn, rd, pg, level, threads, &err);
     if (!wr) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
     if (crumble_bam_set_aux_filter(wr, wl, bl, bd, bi)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
+    p.wr = wr;
 
-    int64_t stats[CRUMBLE_ST_N] = {0};
-    uint8_t *qout = NULL; size_t qcap = 0;
-    double t_read = 0, t_gpu = 0, t_write = 0;
+    const int32_t nref = crumble_bam_n_ref(rd);
+    int *dev_of = calloc((size_t)(nref > 0 ? nref : 1), sizeof *dev_of);
+    lpt_assign(rd, ngpu, dev_of);
+
+    pthread_t wt, gt[MAX_DEV]; worker_arg wa[MAX_DEV];
+    pthread_create(&wt, NULL, writer_thread, &p);
+    for (int d = 0; d < ngpu; d++) { wa[d].p = &p; wa[d].d = d; pthread_create(&gt[d], NULL, gpu_worker, &wa[d]); }
+
+    double t_read = 0;
     const double t_all = now();
-    int bed_i = 0;
+    int bed_i = 0, rc_main = 0;
+    int64_t seq = 0, total_reads = 0, total_bases = 0;
     for (;;) {
         crumble_batch B;
         double t0 = now();
         const int rc = crumble_bam_next_contig(rd, &B);
         t_read += now() - t0;
-        if (rc < 0) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
+        if (rc < 0) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); rc_main = 1; break; }
         if (rc == 0) break;
         while (bed_i < nbed && bt[bed_i] < B.tid) bed_i++;      /* groups arrive in header order, tid -1 last */
-        int j = bed_i;
-        while (j < nbed && bt[j] == B.tid) j++;
-        if (B.tid >= 0 && j > bed_i) { B.n_bed = j - bed_i; B.bed_start = bs + bed_i; B.bed_end = be + bed_i; }
-        const size_t nb = (size_t)B.seq_off[B.n_reads];
-        if (qcap < nb + 16) {
-            crumble_bam_big_free(qout, qcap);
-            qcap = nb + nb / 8 + 64; qout = crumble_bam_big_alloc(qcap);
-            if (!qout) { fprintf(stderr, "crumble-hip: out of memory\n"); return 1; }
-        }
+        int j2 = bed_i;
+        while (j2 < nbed && bt[j2] == B.tid) j2++;
+        if (B.tid >= 0 && j2 > bed_i) { B.n_bed = j2 - bed_i; B.bed_start = bs + bed_i; B.bed_end = be + bed_i; }
+        job *j = calloc(1, sizeof *j);
         t0 = now();
-        const int e = crumble_hip_contig(eng, &B, qout, NULL, stats);
-        t_gpu += now() - t0;
-        if (e) { fprintf(stderr, "crumble-hip: contig %s: %s (%s)\n", crumble_bam_ref_name(rd, B.tid), crumble_hip_strerror(e), crumble_hip_last_error()); return 2; }
-        if (bed_fp && B.tid >= 0) {                             /* -b: snp_score.c:1496,1676,1768,1802,1810 */
-            const int64_t ns = crumble_hip_suspect(eng, NULL, NULL, 0);
-            if (ns < 0) { fprintf(stderr, "crumble-hip: %s\n", crumble_hip_strerror((int)ns)); return 2; }
-            int32_t *sp = malloc((size_t)(ns + 1) * 4); uint8_t *sw = malloc((size_t)ns + 1);
-            if (!sp || !sw || crumble_hip_suspect(eng, sp, sw, ns) != ns) { fprintf(stderr, "crumble-hip: -b failed\n"); return 2; }
-            static const struct { int bit; const char *name; } why[] = {
-                { CRUMBLE_WHY_VDEEP, "VDEEP" }, { CRUMBLE_WHY_DEEP, "DEEP" }, { CRUMBLE_WHY_CLIP, "CLIP" },
-                { CRUMBLE_WHY_INDEL_LEN, "INDEL_LEN" }, { CRUMBLE_WHY_INDEL_COVERAGE, "INDEL_COVERAGE" } };
-            for (int64_t k = 0; k < ns; k++)
-                for (int y = 0; y < 5; y++)
-                    if (sw[k] & why[y].bit)
-                        fprintf(bed_fp, "%s\t%d\t%d\t%s\n", crumble_bam_ref_name(rd, B.tid), sp[k] > 50 ? sp[k] - 50 : 0, sp[k] + 50, why[y].name);
-            free(sp); free(sw);
-        }
-        t0 = now();
-        if (crumble_bam_write_group(wr, rd, qout)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
-        t_write += now() - t0;
-        if (verbose > 1) fprintf(stderr, "  %s: %lld reads, %zu bases\n", crumble_bam_ref_name(rd, B.tid), (long long)B.n_reads, nb);
+        j->g = j ? crumble_bam_detach_group(rd) : NULL;
+        t_read += now() - t0;
+        if (!j || !j->g) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); rc_main = 1; free(j); break; }
+        j->B = B; j->seq = seq++;
+        j->dev = (B.tid >= 0 && B.tid < nref) ? dev_of[B.tid] : 0;
+        total_reads += B.n_reads; total_bases += B.seq_off[B.n_reads];
+        pthread_mutex_lock(&p.mu);
+        while (p.q_len[j->dev] >= MAX_INFLIGHT && !p.failed) pthread_cond_wait(&p.cv, &p.mu);   /* bounds the host memory */
+        if (p.q_tail[j->dev]) p.q_tail[j->dev]->next = j; else p.q_head[j->dev] = j;
+        p.q_tail[j->dev] = j; p.q_len[j->dev]++;
+        const int failed = p.failed;
+        pthread_cond_broadcast(&p.cv);
+        pthread_mutex_unlock(&p.mu);
+        if (failed) break;
     }
-    if (bed_fp && fclose(bed_fp)) { perror("-b"); return 1; }
-    if (crumble_bam_writer_close(wr)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
+    pthread_mutex_lock(&p.mu); p.closing = 1; pthread_cond_broadcast(&p.cv); pthread_mutex_unlock(&p.mu);
+    for (int d = 0; d < ngpu; d++) pthread_join(gt[d], NULL);
+    pthread_join(wt, NULL);
+    if (p.failed) rc_main = p.failed == 2 ? 2 : 1;
+    if (bed_fp && fclose(bed_fp)) { perror("-b"); rc_main = 1; }
+    if (crumble_bam_writer_close(wr)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); rc_main = 1; }
+    /* statistics: after the all-reduce every engine holds the sum; without RCCL (one device, or one device named
+     * twice) the host adds the engines' vectors */
+    for (int d = 0; d < (p.use_rccl ? 1 : ngpu); d++) {
+        int64_t s1[CRUMBLE_ST_N];
+        if (crumble_hip_stats_read(p.eng[d], s1) == 0) for (int i = 0; i < CRUMBLE_ST_N; i++) p.stats[i] += s1[i];
+    }
     const double wall = now() - t_all;
-    if (verbose) {
-        for (int i = 0; i < (int)(sizeof ST_NAME / sizeof *ST_NAME); i++) fprintf(stderr, "%-16s %lld\n", ST_NAME[i], (long long)stats[i]);
-        const double gb = stats[CRUMBLE_ST_BASES] / 1e9;
+    if (verbose && !rc_main) {
+        for (int i = 0; i < (int)(sizeof ST_NAME / sizeof *ST_NAME); i++) fprintf(stderr, "%-16s %lld\n", ST_NAME[i], (long long)p.stats[i]);
+        const double gb = p.stats[CRUMBLE_ST_BASES] / 1e9;
+        double tg = 0;
+        for (int d = 0; d < ngpu; d++) tg += p.t_gpu[d];
         fprintf(stderr, "end-to-end %.3f s (read+parse %.3f, upload+kernels+download %.3f, write %.3f): %.4f Gbases/s file to file\n",
-                wall, t_read, t_gpu, t_write, wall > 0 ? gb / wall : 0.0);
+                wall, t_read, tg, p.t_write, wall > 0 ? gb / wall : 0.0);
+        fprintf(stderr, "%d device(s)%s, reader / GPU workers / writer overlapped; %lld reads, %lld bases\n", ngpu,
+                p.use_rccl ? ", statistics summed by RCCL all-reduce" : "", (long long)total_reads, (long long)total_bases);
         char tb[512];
         crumble_bam_timing(tb, sizeof tb);
         fprintf(stderr, "%s\n", tb);
     }
     crumble_bam_close(rd);
-    crumble_hip_destroy(eng);
-    crumble_bam_big_free(qout, qcap); free(bt); free(bs); free(be); free(pg);
-    return 0;
+    for (int d = 0; d < ngpu; d++) { if (p.use_rccl) crumble_hip_comm_destroy(p.comm[d]); crumble_hip_destroy(p.eng[d]); }
+    free(bt); free(bs); free(be); free(pg); free(dev_of);
+    return rc_main;
 }

@@ -213,6 +213,8 @@ extern "C" crumble_hip *crumble_hip_create(const crumble_params *p, int device, 
     }
 #else
     h->persistent_blocks = 3;
+    h->opt_kcol = 1;        /* under the CPU emulator k_columns2's per-row wave rendezvous cost ~10x k_columns: the
+                             * emulated tier takes k_columns unless a test asks for "kcol" = v2 */
 #endif
     tab = (DTables *)calloc(1, sizeof(DTables));
     if (!tab) return fail(CRUMBLE_ENOMEM);
@@ -849,6 +851,42 @@ extern "C" int crumble_hip_stats_allreduce(crumble_hip *h, void *nccl_comm)
     if (rc != 0) { g_last_error = "ncclAllReduce failed"; return CRUMBLE_ERCCL; }
     HIPCHK(hipStreamSynchronize(h->stream));
     return CRUMBLE_OK;
+#endif
+}
+
+/* One RCCL communicator per device of ONE process (crumble-hip -j N: an engine and a host thread per device).
+ * comms[i] belongs to devices[i]; pass it to crumble_hip_stats_allreduce() of the engine on that device, all
+ * engines concurrently (one call per host thread). */
+extern "C" int crumble_hip_comm_init_all(int n, const int *devices, void **comms)
+{
+#ifdef CRUMBLE_EMU
+    (void)n; (void)devices; (void)comms;
+    return CRUMBLE_ERCCL;
+#else
+    typedef int (*init_fn)(void **, int, const int *);
+    if (n < 1 || !devices || !comms) return CRUMBLE_EINVAL;
+    void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) { g_last_error = "librccl.so not found"; return CRUMBLE_ERCCL; }
+    init_fn fn = (init_fn)dlsym(lib, "ncclCommInitAll");
+    if (!fn) { g_last_error = "ncclCommInitAll not found"; return CRUMBLE_ERCCL; }
+    const int rc = fn(comms, n, devices);
+    if (rc != 0) { g_last_error = "ncclCommInitAll failed (code " + std::to_string(rc) + ")"; return CRUMBLE_ERCCL; }
+    return CRUMBLE_OK;
+#endif
+}
+extern "C" void crumble_hip_comm_destroy(void *comm)
+{
+#ifndef CRUMBLE_EMU
+    typedef int (*destroy_fn)(void *);
+    if (!comm) return;
+    void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return;
+    destroy_fn fn = (destroy_fn)dlsym(lib, "ncclCommDestroy");
+    if (fn) (void)fn(comm);
+#else
+    (void)comm;
 #endif
 }
 

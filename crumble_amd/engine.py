@@ -69,6 +69,8 @@ def load_library(path=None, make_default=True):
         "crumble_hip_stats_reset": (C.c_int, [vp]),
         "crumble_hip_stats_read": (C.c_int, [vp, vp]),
         "crumble_hip_stats_allreduce": (C.c_int, [vp, vp]),
+        "crumble_hip_comm_init_all": (C.c_int, [C.c_int, vp, vp]),
+        "crumble_hip_comm_destroy": (None, [vp]),
         "crumble_hip_columns": (i64, [vp, vp, i64]),
         "crumble_hip_mask_lc": (C.c_int, [vp, i64, vp, vp, vp, vp, vp]),
         "crumble_hip_pblock": (C.c_int, [vp, i64, vp, vp]),
@@ -97,7 +99,8 @@ EXPORTED = [
     "crumble_hip_create", "crumble_hip_destroy", "crumble_hip_set_option", "crumble_hip_contig",
     "crumble_hip_upload", "crumble_hip_run", "crumble_hip_download",
     "crumble_hip_kernel_times", "crumble_hip_upload_times", "crumble_hip_stats_devptr", "crumble_hip_stats_reset",
-    "crumble_hip_stats_read", "crumble_hip_stats_allreduce", "crumble_hip_columns",
+    "crumble_hip_stats_read", "crumble_hip_stats_allreduce", "crumble_hip_comm_init_all",
+    "crumble_hip_comm_destroy", "crumble_hip_columns",
     "crumble_hip_mask_lc", "crumble_hip_pblock", "crumble_hip_indel_only", "crumble_hip_strerror",
     "crumble_hip_last_error",
 ]

@@ -30,6 +30,7 @@ extern "C" {
 
 typedef struct crumble_bam_reader crumble_bam_reader;
 typedef struct crumble_bam_writer crumble_bam_writer;
+typedef struct crumble_bam_group  crumble_bam_group;
 
 /* Opens a BAM file and parses its header.  threads <= 0: the CPUs the process may use (affinity, cgroup quota), at most 64. */
 crumble_bam_reader *crumble_bam_open(const char *path, int threads, int *err);
@@ -45,6 +46,15 @@ const char *crumble_bam_header_text(const crumble_bam_reader *r, int64_t *len);
  * Missing qualities (0xff, SAMv1 4.2.3) are presented as 0 and written back untouched.
  * Returns 1 when a group was produced, 0 at end of file, < 0 on error. */
 int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b);
+
+/* Takes the group that crumble_bam_next_contig() just returned out of the reader: its record bytes and the arrays
+ * behind the crumble_batch now belong to the returned object (the batch's pointers stay valid until
+ * crumble_bam_group_free) and the reader is free to read the next contig -- several contigs can be in flight
+ * (one per GPU, one being written).  crumble_bam_write_detached() = crumble_bam_write_group() for such a group;
+ * groups must be written in the order they were read. */
+crumble_bam_group *crumble_bam_detach_group(crumble_bam_reader *r);
+int  crumble_bam_write_detached(crumble_bam_writer *w, crumble_bam_group *g, const uint8_t *qual_out);
+void crumble_bam_group_free(crumble_bam_group *g);
 
 /* Creates an output BAM with the reader's header; pg_line (may be NULL) is a complete "@PG\t..."
  * line without newline that is appended to the header text (the reference adds its @PG through

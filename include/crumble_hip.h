@@ -192,6 +192,10 @@ int   crumble_hip_stats_read(crumble_hip *h, int64_t *stats);
 /* Sums the stats vector over all ranks of an RCCL communicator (ncclComm_t
  * passed as void*). The only collective on the path. */
 int   crumble_hip_stats_allreduce(crumble_hip *h, void *nccl_comm);
+/* For a single-process multi-GPU host (crumble-hip -j N): one communicator per device (ncclCommInitAll);
+ * comms[i] goes with devices[i].  The all-reduce is then called once per engine, concurrently. */
+int   crumble_hip_comm_init_all(int n, const int *devices, void **comms);
+void  crumble_hip_comm_destroy(void *comm);
 
 /* Operator-level seams (used by the parity tests; same maths as the engine):
  *  calculate_consensus_pileup (snp:533) over every column of a batch ->

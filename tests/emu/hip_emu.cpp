@@ -72,6 +72,10 @@ uint64_t *emu_wave_slots() { return g_w->wave_slots[threadIdx.x >> 6]; }
 
 void emu_run_blocks(dim3 grid, dim3 block, bool independent, const std::function<void()> &body)
 {
+    /* blockDim / gridDim are process-wide here: launches from several host threads (crumble-hip -j N runs one
+     * engine per thread) take turns */
+    static std::mutex launch_mu;
+    std::lock_guard<std::mutex> launch_lock(launch_mu);
     const uint64_t nblocks = (uint64_t)grid.x * grid.y * grid.z;
     const unsigned nthreads = block.x * block.y * block.z;
     if (block.y != 1 || block.z != 1 || nthreads > 1024) { fprintf(stderr, "hip_emu: 1-D blocks only\n"); abort(); }

@@ -350,6 +350,40 @@ def test_cli_end_to_end_emulated(tmp_path):
     assert r.returncode == 1 and "does not provide" in r.stderr
 
 
+def test_cli_multi_device_emulated(tmp_path):
+    """crumble-hip -j 2 (csrc/cli.c: contigs LPT-packed onto per-device engines, one worker thread per engine, a
+    reader and a writer thread, groups detached from the reader) writes byte for byte what -j 1 writes, reports
+    the same summed statistics and is bit-exact against the oracle -- here with both engines on the one emulated
+    device (CRUMBLE_HIP_DEVICES=0,0: the statistics are then added on the host instead of by RCCL)."""
+    import emu_lib
+    emu_lib.load()
+    exe = os.path.join(ROOT, "tests", "emu", "crumble-hip-emu")
+    refs = [("chrI", 400000), ("chrII", 20000), ("chrIII", 90000), ("chrIV", 150000), ("chrV", 5000)]
+    bs = []
+    for tid, (_, ln) in enumerate(refs):
+        cfg = synth.config("ce", scale=1.0, contig_len=max(4500, ln // 60), seed=77 + tid, tid=tid, depth=6.0)
+        bs.append(synth.generate(cfg))
+    bs.append(HostBatch.from_reads([dict(pos=0, cigar="*", seq="ACGTAC", qual=[9, 30, 31, 12, 40, 2], flag=4)], tid=-1))
+    bamio.write_batches(tmp_path / "in.bam", refs, bs)
+    outs = {}
+    for j in ("1", "2", "3"):
+        env = dict(os.environ, CRUMBLE_HIP_DEVICES=",".join("0" * int(j)))
+        r = subprocess.run([exe, "-v", "-v", "-5", "-j", j, "-b", str(tmp_path / f"s{j}.bed"), str(tmp_path / "in.bam"), str(tmp_path / f"out{j}.bam")],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr
+        outs[j] = (open(tmp_path / f"out{j}.bam", "rb").read(), open(tmp_path / f"s{j}.bed").read(),
+                   [l for l in r.stderr.splitlines() if l.split() and l.split()[0] in ("columns", "bases", "bases_changed", "triggers", "reads")])
+        if j != "1":
+            assert f"{j} device(s)" in r.stderr
+    text1 = walk_bam(tmp_path / "out1.bam")
+    for j in ("2", "3"):
+        t = walk_bam(tmp_path / f"out{j}.bam")
+        assert t[1] == text1[1] and [x["qual"] for x in t[2]] == [x["qual"] for x in text1[2]] and len(t[2]) == len(text1[2])
+        assert outs[j][1] == outs["1"][1] and outs[j][2] == outs["1"][2]
+    want = _oracle_file(ca.preset_params(5), tmp_path / "in.bam", None)
+    assert np.array_equal(_file_quals(tmp_path / "out2.bam"), want)
+
+
 def _oracle_bed(params, path):
     """The -b lines the reference would print (snp_score.c:1496,1676,1768,1802,1810), from the oracle's trace."""
     O.load()
@@ -414,3 +448,55 @@ def test_cli_end_to_end_gpu(tmp_path):
         want = _oracle_file(params, tmp_path / "in.bam")
         got = _file_quals(tmp_path / "out.bam")
         assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_cli_multi_device_and_options_gpu(tmp_path):
+    """The shipped binary on the GPU box: (1) -j 2 / -j 3 == -j 1 byte for byte (qualities, -b lines, summed
+    statistics) and == the oracle; with one visible GPU both engines sit on device 0 (CRUMBLE_HIP_DEVICES=0,0,
+    statistics added on the host), with >= 2 visible GPUs the engines sit on devices 0 and 1 and the statistics go
+    through ncclCommInitAll + crumble_hip_stats_allreduce.  (2) the host-plumbing options -t / -T, -e..-G, -z and
+    -b through the real binary."""
+    import torch
+    exe = os.path.join(ROOT, "crumble_amd", "crumble-hip")
+    refs = [("chrI", 4000000), ("chrII", 200000), ("chrIII", 900000), ("chrIV", 1500000), ("chrV", 50000)]
+    bs = []
+    for tid, (_, ln) in enumerate(refs):
+        cfg = synth.config("chr20", scale=1.0, contig_len=max(4700, ln // 20), seed=31 + tid, tid=tid)
+        bs.append(synth.generate(cfg))
+    bs.append(HostBatch.from_reads([dict(pos=0, cigar="*", seq="ACGTAC", qual=[9, 30, 31, 12, 40, 2], flag=4)], tid=-1))
+    bamio.write_batches(tmp_path / "in.bam", refs, bs)
+    ndev = torch.cuda.device_count()
+    outs = {}
+    for j in (1, 2, 3):
+        devs = ",".join(str(k if ndev >= j else 0) for k in range(j))
+        env = dict(os.environ, CRUMBLE_HIP_DEVICES=devs)
+        r = subprocess.run([exe, "-v", "-5", "-j", str(j), "-b", str(tmp_path / f"s{j}.bed"), str(tmp_path / "in.bam"), str(tmp_path / f"out{j}.bam")],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr
+        stats = [l for l in r.stderr.splitlines() if l.split() and l.split()[0] in ("columns", "bases", "bases_changed", "triggers", "reads", "hom_B", "indel")]
+        outs[j] = (_file_quals(tmp_path / f"out{j}.bam"), open(tmp_path / f"s{j}.bed").read(), stats)
+        assert f"{j} device(s)" in r.stderr
+        if j > 1 and ndev >= j:
+            assert "RCCL all-reduce" in r.stderr
+    want = _oracle_file(ca.preset_params(5), tmp_path / "in.bam", None)
+    assert np.array_equal(outs[1][0], want)
+    for j in (2, 3):
+        assert np.array_equal(outs[j][0], outs[1][0]) and outs[j][1] == outs[1][1] and outs[j][2] == outs[1][2]
+    assert outs[1][1] == "".join(_oracle_bed(ca.preset_params(5), tmp_path / "in.bam"))
+    # (2) purge_tags and @PG through the real binary
+    raw = py_bam(refs, [dict(tid=0, pos=100 + i, cigar=[(50 << 4)], seq=[1] * 50, qual=[30] * 50, name=f"t{i}",
+                             aux=b"NMC\x01BDZ" + bytes([40 + i, 70]) + b"\0BIZ" + bytes([36 + i, 80]) + b"\0XSZab\0") for i in range(5)])
+    (tmp_path / "tags.bam").write_bytes(py_bgzf(raw))
+    r = subprocess.run([exe, "-9", "-z", "-T", "XS", "-e", "2", "-f", "20", "-g", "40", "-E", "1", "-F", "10", "-G", "50",
+                        str(tmp_path / "tags.bam"), str(tmp_path / "t2.bam")], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    text, _, recs = walk_bam(tmp_path / "t2.bam")
+    assert "@PG\tID:crumble-hip" not in text
+    src = [b"NMC\x01BDZ" + bytes([40 + i, 70]) + b"\0BIZ" + bytes([36 + i, 80]) + b"\0XSZab\0" for i in range(5)]
+    assert [x["aux"] for x in recs] == [py_purge(a, None, {b"XS"}, (35, 53, 73), (34, 43, 83)) for a in src]
+    assert recs[0]["aux"] != src[0]
+    r = subprocess.run([exe, "-9", "-t", "NM", str(tmp_path / "tags.bam"), str(tmp_path / "t3.bam")], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    text, _, recs = walk_bam(tmp_path / "t3.bam")
+    assert "@PG\tID:crumble-hip" in text and [x["aux"] for x in recs] == [b"NMC\x01"] * 5
