@@ -260,10 +260,36 @@ def main():
     # ---- the one collective of the path: statistics / quality histogram ----
     stats = sum(e_.stats_read() for e_ in engines)
     bases_local = sum(b_.n_bases for b_ in batches)
+    stats_via = "none (one rank)"
     if dist is not None:
-        st = torch.from_numpy(stats.copy()).to(red_dev)
-        dist.all_reduce(st, op=dist.ReduceOp.SUM)
-        stats = st.cpu().numpy()
+        if red_dev == "cuda" and len(engines) == 1:
+            # the product's own collective: crumble_hip_stats_allreduce (RCCL, in place on the engine's device
+            # vector) over a communicator built from an id that rank 0 hands round
+            import ctypes as C
+
+            class UniqueId(C.Structure):
+                _fields_ = [("internal", C.c_char * 128)]
+            rccl = C.CDLL("librccl.so")
+            uid = UniqueId()
+            if rank == 0:
+                assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+            box = [bytes(uid.internal) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            C.memmove(C.byref(uid), box[0], 128)
+            comm = C.c_void_p()
+            rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+            assert rccl.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0
+            rc = eng.L.crumble_hip_stats_allreduce(eng.h, comm)
+            assert rc == 0, eng.L.crumble_hip_last_error()
+            stats = eng.stats_read()
+            rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+            rccl.ncclCommDestroy(comm)
+            stats_via = "crumble_hip_stats_allreduce (RCCL)"
+        else:
+            st = torch.from_numpy(stats.copy()).to(red_dev)
+            dist.all_reduce(st, op=dist.ReduceOp.SUM)
+            stats = st.cpu().numpy()
+            stats_via = f"torch.distributed all_reduce ({'RCCL' if red_dev == 'cuda' else 'gloo'})"
         tb = torch.tensor([bases_local], dtype=torch.int64, device=red_dev)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         total_bases = int(tb.item())
@@ -333,7 +359,7 @@ def main():
                                 f"{label}: 24 synthetic contigs (GRCh38 lengths x {args.scale}), {total_bases} bases "
                                 f"LPT-packed on {world} GPU(s), -{args.preset}"),
                    "preset": args.preset, "tech": tech, "scale": args.scale,
-                   "contigs": world if args.workload != "wgs" else 24,
+                   "contigs": world if args.workload != "wgs" else 24, "stats_allreduce": stats_via,
                    "parity": "every parity check is against oracle/ (a CPU restatement of crumble 0.9.1's transcode(); "
                              "reference-pinned for str_finder.c only: htslib is absent offline)",
                    "gen_s": round(t_gen, 1), "upload_s": round(t_up, 2)},

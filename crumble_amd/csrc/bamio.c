@@ -51,20 +51,57 @@ static inline void put16(uint8_t *p, uint16_t v) { p[0] = v; p[1] = v >> 8; }
 /* Multi-GB buffers come straight from mmap with MADV_HUGEPAGE: first touch of 4 KiB pages by a
  * large OpenMP team is otherwise the dominant host cost (one page fault per 4 KiB, serialised on
  * the address-space lock).  Growing keeps the contents through mremap (no copy). */
+/* Sizes are rounded up to size classes (2^k and 1.5 * 2^k, at least 2 MiB) and freed buffers of a class wait in a
+ * small pool: a contig pipeline (crumble-hip: several groups in flight, a quality buffer per group) would otherwise
+ * map, fault in and unmap gigabytes per contig.  The class is a pure function of the requested size, so callers
+ * keep passing the size they asked for. */
+#include <pthread.h>
+static size_t big_class(size_t n)
+{
+    size_t c = (size_t)2 << 20;
+    while (c < n) { if (c + c / 2 >= n) return c + c / 2; c *= 2; }
+    return c;
+}
+#define BIG_POOL 12
+static struct { void *p; size_t c; } big_pool[BIG_POOL];
+static pthread_mutex_t big_mu = PTHREAD_MUTEX_INITIALIZER;
 static void *big_alloc(size_t n)
 {
-    void *p = mmap(NULL, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (!n) n = 1;
+    const size_t c = big_class(n);
+    pthread_mutex_lock(&big_mu);
+    for (int i = 0; i < BIG_POOL; i++)
+        if (big_pool[i].p && big_pool[i].c == c) { void *p = big_pool[i].p; big_pool[i].p = NULL; pthread_mutex_unlock(&big_mu); return p; }
+    pthread_mutex_unlock(&big_mu);
+    void *p = mmap(NULL, c, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (p == MAP_FAILED) return NULL;
-    madvise(p, n, MADV_HUGEPAGE);
+    madvise(p, c, MADV_HUGEPAGE);
     return p;
 }
-static void big_free(void *p, size_t n) { if (p && n) munmap(p, n); }
+static void big_free(void *p, size_t n)
+{
+    if (!p || !n) return;
+    const size_t c = big_class(n);
+    pthread_mutex_lock(&big_mu);
+    int slot = -1;
+    for (int i = 0; i < BIG_POOL; i++) if (!big_pool[i].p) { slot = i; break; }
+    if (slot < 0) {                                         /* pool full: the smallest parked buffer goes */
+        int sm = 0;
+        for (int i = 1; i < BIG_POOL; i++) if (big_pool[i].c < big_pool[sm].c) sm = i;
+        if (big_pool[sm].c < c) { munmap(big_pool[sm].p, big_pool[sm].c); slot = sm; }
+    }
+    if (slot >= 0) { big_pool[slot].p = p; big_pool[slot].c = c; p = NULL; }
+    pthread_mutex_unlock(&big_mu);
+    if (p) munmap(p, c);
+}
 static void *big_grow(void *p, size_t old, size_t n)
 {
     if (!p || !old) return big_alloc(n);
-    void *q = mremap(p, old, n, MREMAP_MAYMOVE);
+    const size_t co = big_class(old), cn = big_class(n);
+    if (cn == co) return p;
+    void *q = mremap(p, co, cn, MREMAP_MAYMOVE);
     if (q == MAP_FAILED) return NULL;
-    madvise(q, n, MADV_HUGEPAGE);
+    madvise(q, cn, MADV_HUGEPAGE);
     return q;
 }
 void *crumble_bam_big_alloc(size_t n) { return big_alloc(n); }

@@ -1,6 +1,7 @@
-"""N>1 path on CPU: world_size-2 gloo. Contigs are LPT-packed onto ranks, each rank
-runs its contigs (here through the CPU checker, the GPU engine has the same C ABI)
-and the statistics vector is all-reduced; the sum must equal the single-process run."""
+"""N>1 path on CPU: world_size-2 gloo.  Contigs are LPT-packed onto ranks, each rank runs its contigs through the
+ENGINE (the literal kernel sources under the CPU emulator, tests/emu -- same C ABI, same host code as the GPU
+build), the per-rank engine's accumulated statistics vector is all-reduced; every contig's bytes and flags must
+equal the oracle's and the reduced vector the single-process oracle sum."""
 import os
 import socket
 import sys
@@ -25,18 +26,24 @@ def _worker(rank, world, port, scales, q):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch.distributed as dist
     import oracle_lib as O
+    import emu_lib
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sizes = [int(1e6 * s) for s in scales]
     assign, _ = shard.lpt_pack(sizes, world)
     p = ca.preset_params(5)
-    local = np.zeros(ca.ST_N, np.int64)
+    eng = emu_lib.engine(p, kcol=("v1", "v2")[rank & 1])   # one engine per rank, reused for all its contigs
+    ok = True
     for tid in assign[rank]:
         cfg = synth.config("chr20", scale=scales[tid] * 0.001, seed=100 + tid, tid=tid)
         hb = synth.generate(cfg, threads=2)
-        _, _, s = O.contig(p, hb)
-        local += s
+        q1, f1, _ = eng.contig(hb)
+        wq, wf, _ = O.contig(p, hb)
+        ok = ok and np.array_equal(q1, wq) and np.array_equal(f1, wf)
+    local = eng.stats_read()                                # what crumble_hip_stats_allreduce sums on the GPU
+    eng.close()
+    assert ok, "engine output differs from the oracle"
     total = shard.allreduce_stats(local, dist)
     dist.barrier()
     dist.destroy_process_group()
