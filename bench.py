@@ -185,7 +185,7 @@ def main():
     red_dev = "cuda" if os.environ.get("CRUMBLE_BENCH_BACKEND", "nccl") == "nccl" else "cpu"
 
     import crumble_amd as ca
-    from crumble_amd import synth
+    import synth
     if not os.path.exists(ca.LIB_PATH):
         ca.build_library()
 

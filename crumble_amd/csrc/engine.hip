@@ -746,22 +746,16 @@ extern "C" int crumble_hip_run(crumble_hip *h)
         CRUMBLE_LAUNCH(k_stats, 1024, 256, st, nb, n, h->d_out.as<uint8_t>(), B.quals, stats);
     }
     HIPCHK(hipEventRecord(h->ev[h->n_stages], st));
+    /* fold this batch's counters into the engine's accumulated stats vector, on the device */
+    CRUMBLE_LAUNCH_INDEP(k_stats_fold, nblk(CRUMBLE_ST_N, 64), 64, st, h->d_stats.as<u64>(), (const u64 *)stats, CRUMBLE_ST_N);
+    int ovf[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(ovf, d_overflow, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     for (int i = 0; i < h->n_stages; i++)
         HIPCHK(hipEventElapsedTime(&h->stage_ms[i], h->ev[i], h->ev[i + 1]));
     (void)algo_bytes;
-    int ovf[2] = {0, 0};
-    HIPCHK(hipMemcpy(ovf, d_overflow, 8, hipMemcpyDeviceToHost));
     if (ovf[0]) { g_last_error = "STR repeat list overflow"; return CRUMBLE_EOVERFLOW; }
-    /* fold this batch's counters into the engine's accumulated stats vector (device side) */
-    {
-        std::vector<int64_t> a(CRUMBLE_ST_N), bsum(CRUMBLE_ST_N);
-        HIPCHK(hipMemcpy(a.data(), h->d_stats.p, CRUMBLE_ST_N * 8, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(bsum.data(), h->d_batch_stats.p, CRUMBLE_ST_N * 8, hipMemcpyDeviceToHost));
-        for (int i = 0; i < CRUMBLE_ST_N; i++) a[i] += bsum[i];
-        HIPCHK(hipMemcpy(h->d_stats.p, a.data(), CRUMBLE_ST_N * 8, hipMemcpyHostToDevice));
-    }
     h->have_run = true;
     return CRUMBLE_OK;
 }

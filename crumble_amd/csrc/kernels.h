@@ -2545,4 +2545,11 @@ k_stats(int64_t n_bases, int64_t n_reads, const uint8_t *out, const uint8_t *in,
     }
 }
 
+/* this batch's counters into the engine's accumulated vector (what the multi-GPU all-reduce sums) */
+__global__ void k_stats_fold(u64 *__restrict__ total, const u64 *__restrict__ batch, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) total[i] += batch[i];
+}
+
 #endif /* CRUMBLE_KERNELS_H */

@@ -2,7 +2,7 @@
 import numpy as np
 
 import crumble_amd as ca
-from crumble_amd import synth
+import synth
 
 
 def random_case(seed, max_bases=250_000):

@@ -2,7 +2,8 @@
 import numpy as np
 
 import crumble_amd as ca
-from crumble_amd import synth, HostBatch
+from crumble_amd import HostBatch
+import synth
 import oracle_lib as O
 
 _cache = {}

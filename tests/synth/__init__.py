@@ -1,10 +1,27 @@
-"""Python driver for the C synthetic-alignment generator (include/crumble_synth.h)."""
+"""Python driver for the C synthetic-alignment generator (tests/synth/crumble_synth.h): test / bench
+infrastructure in its own libcrumble_synth.so -- the product libraries do not contain it."""
 import ctypes as C
+import os
+import subprocess
 
 import numpy as np
 
-from .capi import Batch, HostBatch
-from .engine import lib
+from crumble_amd.capi import Batch, HostBatch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libcrumble_synth.so")
+_L = None
+
+
+def lib():
+    global _L
+    if _L is None:
+        r = subprocess.run(["make", "-C", HERE], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode:
+            print(r.stdout)
+            raise RuntimeError("building libcrumble_synth.so failed")
+        _L = C.CDLL(LIB, mode=C.RTLD_LOCAL)
+    return _L
 
 
 class SynthCfg(C.Structure):

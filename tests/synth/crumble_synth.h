@@ -1,5 +1,6 @@
 /*
- * crumble_synth.h -- seeded synthetic alignment generator (bench / test utility).
+ * crumble_synth.h -- seeded synthetic alignment generator.  TEST / BENCH INFRASTRUCTURE: built into its own
+ * tests/synth/libcrumble_synth.so, never part of the product libraries.
  *
  * There is no NA12878 BAM, no htslib and no network in the build or GPU images,
  * so the benchmark configurations of BASELINE.json are generated on the fly:
@@ -13,7 +14,7 @@
 #ifndef CRUMBLE_SYNTH_H
 #define CRUMBLE_SYNTH_H
 #include <stdint.h>
-#include "crumble_hip.h"
+#include "../../include/crumble_hip.h"
 #ifdef __cplusplus
 extern "C" {
 #endif

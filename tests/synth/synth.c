@@ -7,7 +7,7 @@
 #include <string.h>
 #include <math.h>
 #include <omp.h>
-#include "../../include/crumble_synth.h"
+#include "crumble_synth.h"
 
 #define WIN 16384            /* start positions per generation window */
 

@@ -12,7 +12,8 @@ import numpy as np
 import pytest
 
 import crumble_amd as ca
-from crumble_amd import bamio, synth
+from crumble_amd import bamio
+import synth
 from crumble_amd.capi import ROOT, HostBatch
 
 import oracle_lib as O

@@ -13,7 +13,8 @@ import numpy as np
 import pytest
 
 import crumble_amd as ca
-from crumble_amd import synth, shard, HostBatch
+from crumble_amd import shard, HostBatch
+import synth
 import oracle_lib as O
 
 pytestmark = pytest.mark.gpu

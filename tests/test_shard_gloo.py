@@ -10,7 +10,8 @@ import numpy as np
 import pytest
 
 import crumble_amd as ca
-from crumble_amd import shard, synth
+from crumble_amd import shard
+import synth
 
 
 def test_lpt_pack_balances_grch38():

@@ -8,7 +8,7 @@ W=${1:-/tmp/crumble_asan}; mkdir -p $W; cd $W
 SRC=$R/crumble_amd/csrc; EMU=$R/tests/emu
 FL="-fsanitize=address,undefined -fno-omit-frame-pointer -g -O1"
 gcc $FL -fPIC -c $SRC/params.c -o params.o
-gcc $FL -fPIC -fopenmp -c $SRC/synth.c -o synth.o
+gcc $FL -fPIC -fopenmp -c $R/tests/synth/synth.c -o synth.o
 gcc $FL -fPIC -fopenmp -c $SRC/bamio.c -o bamio.o
 g++ $FL -std=c++17 -fPIC -ffp-contract=off -DCRUMBLE_EMU -include $EMU/hip_emu.h -Wno-unknown-pragmas -x c++ -c $SRC/engine.hip -o engine.o
 g++ $FL -std=c++17 -fPIC -c $EMU/hip_emu.cpp -o hip_emu.o
@@ -17,7 +17,8 @@ g++ $FL -o crumble-hip-asan cli.o engine.o hip_emu.o params.o synth.o bamio.o -l
 python3 - <<PY
 import sys; sys.path.insert(0, "$R")
 import numpy as np
-from crumble_amd import synth, bamio, HostBatch
+from crumble_amd import bamio, HostBatch
+import synth
 b0 = synth.generate(synth.config("ce", scale=0.5))
 b1 = synth.generate(synth.config("hifi", scale=0.0002, read_len=3000, tid=1))
 b2 = synth.generate(synth.config("panel", scale=0.0008, tid=2))

@@ -1,7 +1,8 @@
 """GPU box: file -> file through crumble-hip on a multi-contig BAM (contig pipeline: read / GPU / write overlap)."""
 import os, sys, time, subprocess, re
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
-from crumble_amd import bamio, synth
+from crumble_amd import bamio
+import synth
 ROOT = os.getcwd()
 n, scale = int(sys.argv[1]) if len(sys.argv) > 1 else 6, float(sys.argv[2]) if len(sys.argv) > 2 else 0.15
 tmp = os.environ.get("TMPDIR", "/tmp")

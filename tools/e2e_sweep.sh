@@ -7,7 +7,8 @@ threads=${@:-"16 64 256"}
 tmp=$(mktemp -d /tmp/e2e.XXXX)
 python3 - <<PY
 import sys; sys.path.insert(0, "$R")
-from crumble_amd import synth, bamio
+from crumble_amd import bamio
+import synth
 hb = synth.generate(synth.config("chr20", scale=$scale))
 bamio.write_batches("$tmp/in.bam", [("chr20", 64444167)], [hb], level=1)
 print("bases", hb.n_bases)

@@ -12,7 +12,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import crumble_amd as ca
-from crumble_amd import synth, HostBatch
+from crumble_amd import HostBatch
+import synth
 import oracle_lib as O
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 2.4

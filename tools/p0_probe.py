@@ -2,7 +2,7 @@
 import sys, os, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
 import crumble_amd as ca
-from crumble_amd import synth
+import synth
 wl = sys.argv[1] if len(sys.argv) > 1 else "chr20"
 hb = synth.generate(synth.config(wl, scale=float(sys.argv[2]) if len(sys.argv) > 2 else 1.0))
 e = ca.Engine(ca.preset_params(5), 0)

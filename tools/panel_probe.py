@@ -4,7 +4,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import crumble_amd as ca
-from crumble_amd import synth
+import synth
 for kw in (dict(), dict(spike_depth=0), dict(spike_depth=0, depth=100.0), dict(spike_depth=0, depth_sigma=0.0)):
     hb = synth.generate(synth.config("panel", scale=1.0, **kw))
     eng = ca.Engine(ca.preset_params(9), 0)

@@ -5,7 +5,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import crumble_amd as ca
-from crumble_amd import synth
+import synth
 eng = ca.Engine(ca.preset_params(5), 0)
 for clen in (5000, 50000, 500000, 5000000):
     cfg = synth.config("chr20", scale=1.0); cfg.contig_len = clen

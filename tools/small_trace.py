@@ -2,7 +2,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import crumble_amd as ca
-from crumble_amd import synth
+import synth
 eng = ca.Engine(ca.preset_params(5), 0)
 cfg = synth.config("chr20", scale=1.0); cfg.contig_len = 50000
 hb = synth.generate(cfg)

@@ -1,7 +1,7 @@
 import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
 import numpy as np, crumble_amd as ca
-from crumble_amd import synth
+import synth
 hb = synth.generate(synth.config(sys.argv[1] if len(sys.argv) > 1 else "chr20", scale=float(sys.argv[2]) if len(sys.argv) > 2 else 1.0))
 e = ca.Engine(ca.preset_params(int(sys.argv[3]) if len(sys.argv) > 3 else 5), 0)
 e.upload(hb); e.run(); e.stats_reset(); e.run()
