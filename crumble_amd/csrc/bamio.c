@@ -917,3 +917,265 @@ int crumble_bam_load_bed(const crumble_bam_reader *r, const char *path, int32_t 
     *tid = t; *start = st; *end = en;
     return n;
 }
+
+/* ------------------------------------------------------------- htslib backend
+ * SAM / BAM / CRAM in and out through a system libhts, resolved at run time: what reference
+ * crumble does with sam_open_format / sam_hdr_read / sam_read1 / sam_write1 / sam_hdr_add_PG
+ * (snp_score.c:2201-2207, 2561-2626, 1116-1117, 1101).  htslib is not in the build image and not under
+ * /root/reference, so nothing here can be exercised offline beyond "library absent -> CRUMBLE_BAM_ENOHTS";
+ * the code targets the libhts.so.3 ABI (htslib >= 1.10: 64-bit positions in bam1_core_t) and refuses anything
+ * else.  Records of one contig are collected as bam1_t objects, unpacked into the same SoA crumble_batch the
+ * native reader produces, and written back with the engine's qualities in place. */
+#include <dlfcn.h>
+
+typedef struct {                /* htslib/sam.h, libhts.so.3 */
+    int64_t pos; int32_t tid; uint16_t bin; uint8_t qual, l_extranul; uint16_t flag, l_qname;
+    uint32_t n_cigar; int32_t l_qseq, mtid; int64_t mpos, isize;
+} hts_core_t;
+typedef struct { hts_core_t core; uint64_t id; uint8_t *data; int l_data; uint32_t m_data; uint32_t mempolicy; } hts_bam1_t;
+typedef char hts_core_size_check[sizeof(hts_core_t) == 48 ? 1 : -1];
+
+static struct {
+    void *lib; int tried, ok;
+    const char *(*hts_version)(void);
+    int   (*hts_parse_format)(void *fmt, const char *str);
+    void *(*hts_open_format)(const char *fn, const char *mode, const void *fmt);
+    int   (*sam_open_mode)(char *mode, const char *fn, const char *format);
+    int   (*hts_close)(void *fp);
+    int   (*hts_set_threads)(void *fp, int n);
+    void *(*sam_hdr_read)(void *fp);
+    int   (*sam_hdr_write)(void *fp, const void *h);
+    void  (*sam_hdr_destroy)(void *h);
+    int   (*sam_hdr_nref)(const void *h);
+    const char *(*sam_hdr_tid2name)(const void *h, int tid);
+    int64_t (*sam_hdr_tid2len)(const void *h, int tid);
+    int   (*sam_hdr_add_pg)(void *h, const char *name, ...);
+    int   (*sam_read1)(void *fp, void *h, hts_bam1_t *b);
+    int   (*sam_write1)(void *fp, const void *h, const hts_bam1_t *b);
+    hts_bam1_t *(*bam_init1)(void);
+    void  (*bam_destroy1)(hts_bam1_t *b);
+} H;
+
+static int hts_load(void)
+{
+    if (H.tried) return H.ok ? 0 : CRUMBLE_BAM_ENOHTS;
+    H.tried = 1;
+    H.lib = dlopen("libhts.so.3", RTLD_NOW | RTLD_LOCAL);
+    if (!H.lib) H.lib = dlopen("libhts.so", RTLD_NOW | RTLD_LOCAL);
+    if (!H.lib) return fail(CRUMBLE_BAM_ENOHTS, "libhts.so.3 not found: SAM / CRAM and -I / -O need a system htslib (>= 1.10); BAM works without it");
+#define HSYM(name) do { *(void **)&H.name = dlsym(H.lib, #name); if (!H.name) return fail(CRUMBLE_BAM_ENOHTS, "libhts lacks %s (htslib >= 1.10 is required)", #name); } while (0)
+    HSYM(hts_version); HSYM(hts_parse_format); HSYM(hts_open_format); HSYM(sam_open_mode); HSYM(hts_close);
+    HSYM(hts_set_threads); HSYM(sam_hdr_read); HSYM(sam_hdr_write); HSYM(sam_hdr_destroy); HSYM(sam_hdr_nref);
+    HSYM(sam_hdr_tid2name); HSYM(sam_hdr_tid2len); HSYM(sam_hdr_add_pg); HSYM(sam_read1); HSYM(sam_write1);
+    HSYM(bam_init1); HSYM(bam_destroy1);
+#undef HSYM
+    const char *v = H.hts_version();
+    int maj = 0, min = 0;
+    if (!v || sscanf(v, "%d.%d", &maj, &min) < 2 || maj != 1 || min < 10)
+        return fail(CRUMBLE_BAM_ENOHTS, "htslib %s: need 1.10 or later (64-bit positions in bam1_core_t)", v ? v : "?");
+    H.ok = 1;
+    return 0;
+}
+
+int crumble_hts_available(char *version, size_t len)
+{
+    if (hts_load()) return 0;
+    if (version && len) snprintf(version, len, "%s", H.hts_version());
+    return 1;
+}
+
+struct crumble_hts {
+    void *in, *out, *hdr;
+    uint64_t in_fmt[8], out_fmt[8];          /* htsFormat, opaque (32 bytes in libhts.so.3) */
+    hts_bam1_t **rec; int64_t n, cap;        /* the current group's records */
+    hts_bam1_t *ahead;                       /* first record of the next group */
+    hts_bam1_t **pool; int64_t npool, cappool;
+    int eof;
+    crumble_bam_writer filt;                 /* purge_tags settings only */
+    /* SoA views */
+    int32_t *pos; uint8_t *mapq; uint16_t *flag; int64_t *seq_off, *cig_off; uint32_t *cigar; uint8_t *bases, *quals;
+    size_t cap_reads, cap_bases, cap_cig;
+};
+
+static hts_bam1_t *hts_get(crumble_hts *h)
+{
+    if (h->npool) return h->pool[--h->npool];
+    return H.bam_init1();
+}
+
+crumble_hts *crumble_hts_open(const char *in_fn, const char *in_fmt, const char *out_fn, const char *out_fmt,
+                              const char *pg_name, const char *pg_version, const char *pg_cmdline, int threads, int *err)
+{
+    int e = hts_load();
+    if (e) { if (err) *err = e; return NULL; }
+    crumble_hts *h = calloc(1, sizeof *h);
+    if (!h) { if (err) *err = CRUMBLE_BAM_ENOMEM; return NULL; }
+    if ((in_fmt && H.hts_parse_format(h->in_fmt, in_fmt) < 0) || (out_fmt && H.hts_parse_format(h->out_fmt, out_fmt) < 0)) {
+        e = fail(CRUMBLE_EINVAL, "bad -I / -O format string");
+        goto bad;
+    }
+    if (!(h->in = H.hts_open_format(in_fn, "r", in_fmt ? h->in_fmt : NULL))) { e = fail(CRUMBLE_BAM_EIO, "cannot open %s", in_fn); goto bad; }
+    char mode[8] = "w";
+    H.sam_open_mode(mode + 1, out_fn, NULL);                 /* format by file name, snp_score.c:2569 */
+    if (!(h->out = H.hts_open_format(out_fn, mode, out_fmt ? h->out_fmt : NULL))) { e = fail(CRUMBLE_BAM_EIO, "cannot open %s", out_fn); goto bad; }
+    if (threads > 1) { H.hts_set_threads(h->in, threads); H.hts_set_threads(h->out, threads); }
+    if (!(h->hdr = H.sam_hdr_read(h->in))) { e = fail(CRUMBLE_BAM_EFORMAT, "failed to read the file header"); goto bad; }
+    if (pg_name && H.sam_hdr_add_pg(h->hdr, pg_name, "VN", pg_version ? pg_version : "0", pg_cmdline ? "CL" : NULL, pg_cmdline, NULL) != 0) {
+        e = fail(CRUMBLE_BAM_EFORMAT, "failed to add the @PG line"); goto bad;
+    }
+    if (H.sam_hdr_write(h->out, h->hdr) != 0) { e = fail(CRUMBLE_BAM_EIO, "failed to write the file header"); goto bad; }
+    if (err) *err = 0;
+    return h;
+bad:
+    if (err) *err = e;
+    crumble_hts_close(h);
+    return NULL;
+}
+
+int32_t crumble_hts_n_ref(const crumble_hts *h) { return H.sam_hdr_nref(h->hdr); }
+const char *crumble_hts_ref_name(const crumble_hts *h, int32_t tid) { const char *s = tid >= 0 ? H.sam_hdr_tid2name(h->hdr, tid) : NULL; return s ? s : "*"; }
+int crumble_hts_load_bed(const crumble_hts *h, const char *path, int32_t **tid, int32_t **start, int32_t **end)
+{
+    crumble_bam_reader fake;                                  /* bed_load only needs the reference names */
+    memset(&fake, 0, sizeof fake);
+    fake.n_ref = H.sam_hdr_nref(h->hdr);
+    fake.ref_name = calloc((size_t)(fake.n_ref > 0 ? fake.n_ref : 1), sizeof *fake.ref_name);
+    if (!fake.ref_name) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+    for (int32_t i = 0; i < fake.n_ref; i++) fake.ref_name[i] = (char *)H.sam_hdr_tid2name(h->hdr, i);
+    const int n = crumble_bam_load_bed(&fake, path, tid, start, end);
+    free(fake.ref_name);
+    return n;
+}
+int crumble_hts_set_aux_filter(crumble_hts *h, const char *whitelist, const char *blacklist, const int bd[3], const int bi[3])
+{ return crumble_bam_set_aux_filter(&h->filt, whitelist, blacklist, bd, bi); }
+
+/* the next run of records sharing one refID -> SoA views (same contract as crumble_bam_next_contig) */
+int crumble_hts_next_contig(crumble_hts *h, crumble_batch *b)
+{
+    for (int64_t i = 0; i < h->n; i++) {                      /* recycle the previous group's records */
+        if (h->npool == h->cappool) {
+            const int64_t c = h->cappool ? h->cappool * 2 : 4096;
+            hts_bam1_t **p = realloc(h->pool, (size_t)c * sizeof *p);
+            if (!p) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+            h->pool = p; h->cappool = c;
+        }
+        h->pool[h->npool++] = h->rec[i];
+    }
+    h->n = 0;
+    int32_t tid = 0;
+    int64_t nb = 0, nc = 0;
+    for (;;) {
+        hts_bam1_t *r = h->ahead;
+        h->ahead = NULL;
+        if (!r) {
+            if (h->eof) break;
+            r = hts_get(h);
+            if (!r) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+            const int rc = H.sam_read1(h->in, h->hdr, r);
+            if (rc < -1) return fail(CRUMBLE_BAM_EFORMAT, "sam_read1 failed (%d)", rc);
+            if (rc == -1) { h->eof = 1; H.bam_destroy1(r); break; }
+        }
+        if (h->n == 0) tid = r->core.tid;
+        else if (r->core.tid != tid) { h->ahead = r; break; }
+        if (r->core.pos > INT32_MAX - 64 || r->core.l_qseq < 0) return fail(CRUMBLE_BAM_EUNSUPP, "coordinate beyond 2^31");
+        if (h->n == h->cap) {
+            const int64_t c = h->cap ? h->cap * 2 : (1 << 16);
+            hts_bam1_t **p = realloc(h->rec, (size_t)c * sizeof *p);
+            if (!p) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+            h->rec = p; h->cap = c;
+        }
+        h->rec[h->n++] = r;
+        nb += r->core.l_qseq; nc += r->core.n_cigar;
+    }
+    if (h->n == 0) return 0;
+    const int64_t n = h->n;
+    if (h->cap_reads < (size_t)n + 1) {
+        const size_t c = (size_t)n + (size_t)n / 4 + 64;
+        free(h->pos); free(h->mapq); free(h->flag); free(h->seq_off); free(h->cig_off);
+        h->pos = malloc(c * 4); h->mapq = malloc(c); h->flag = malloc(c * 2); h->seq_off = malloc(c * 8); h->cig_off = malloc(c * 8);
+        h->cap_reads = (h->pos && h->mapq && h->flag && h->seq_off && h->cig_off) ? c : 0;
+        if (!h->cap_reads) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+    }
+    if (h->cap_bases < (size_t)nb + 64) {
+        big_free(h->bases, h->cap_bases); big_free(h->quals, h->cap_bases);
+        const size_t c = (size_t)nb + (size_t)nb / 8 + 4096;
+        h->bases = big_alloc(c); h->quals = big_alloc(c);
+        h->cap_bases = (h->bases && h->quals) ? c : 0;
+        if (!h->cap_bases) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+    }
+    if (h->cap_cig < (size_t)nc + 1) {
+        free(h->cigar);
+        const size_t c = (size_t)nc + (size_t)nc / 8 + 64;
+        h->cigar = malloc(c * 4);
+        h->cap_cig = h->cigar ? c : 0;
+        if (!h->cap_cig) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+    }
+    int64_t ab = 0, ac = 0;
+    for (int64_t i = 0; i < n; i++) { h->seq_off[i] = ab; h->cig_off[i] = ac; ab += h->rec[i]->core.l_qseq; ac += h->rec[i]->core.n_cigar; }
+    h->seq_off[n] = ab; h->cig_off[n] = ac;
+    #pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        const hts_bam1_t *r = h->rec[i];
+        const int32_t lseq = r->core.l_qseq;
+        h->pos[i] = (int32_t)r->core.pos; h->mapq[i] = r->core.qual; h->flag[i] = r->core.flag;
+        const uint8_t *cg = r->data + r->core.l_qname;
+        memcpy(h->cigar + h->cig_off[i], cg, 4 * (size_t)r->core.n_cigar);
+        const uint8_t *sq = cg + 4 * (size_t)r->core.n_cigar;
+        uint8_t *bo = h->bases + h->seq_off[i];
+        for (int32_t k = 0; k + 1 < lseq; k += 2) { const uint8_t v = sq[k >> 1]; bo[k] = v >> 4; bo[k + 1] = v & 15; }
+        if (lseq & 1) bo[lseq - 1] = sq[lseq >> 1] >> 4;
+        const uint8_t *ql = sq + ((size_t)lseq + 1) / 2;
+        uint8_t *qo = h->quals + h->seq_off[i];
+        if (lseq > 0 && ql[0] == 0xff) memset(qo, 0, (size_t)lseq);     /* absent qualities */
+        else memcpy(qo, ql, (size_t)lseq);
+    }
+    memset(b, 0, sizeof *b);
+    b->tid = tid; b->n_reads = n;
+    b->pos = h->pos; b->mapq = h->mapq; b->flag = h->flag; b->seq_off = h->seq_off; b->cig_off = h->cig_off;
+    b->cigar = h->cigar; b->bases = h->bases; b->quals = h->quals;
+    return 1;
+}
+
+/* flush_bam_list() (snp_score.c:1081-1105): qualities replaced, purge_tags applied, sam_write1 per record */
+int crumble_hts_write_group(crumble_hts *h, const uint8_t *qual_out)
+{
+    const crumble_bam_writer *w = &h->filt;
+    const int binning = w->bd[0] | w->bd[1] | w->bd[2] | w->bi[0] | w->bi[1] | w->bi[2];
+    for (int64_t i = 0; i < h->n; i++) {
+        hts_bam1_t *r = h->rec[i];
+        const int32_t lseq = r->core.l_qseq;
+        uint8_t *ql = r->data + r->core.l_qname + 4 * (size_t)r->core.n_cigar + ((size_t)lseq + 1) / 2;
+        if (qual_out && lseq > 0 && ql[0] != 0xff) memcpy(ql, qual_out + h->seq_off[i], (size_t)lseq);
+        if (w->aux_mode || binning) {                        /* purge_tags, in place (records only shrink) */
+            uint8_t *aux = ql + lseq, *lim = r->data + r->l_data, *q = aux;
+            for (uint8_t *t = aux; t < lim; ) {
+                const uint8_t *e2 = (t + 3 <= lim) ? aux_end(t + 2, lim) : NULL;
+                if (!e2) return fail(CRUMBLE_BAM_EFORMAT, "malformed auxiliary field");
+                const size_t len = (size_t)(e2 - t);
+                if (aux_keep(w, t)) { memmove(q, t, len); if (binning) aux_bin(w, q); q += len; }
+                t += len;
+            }
+            r->l_data = (int)(q - r->data);
+        }
+        if (H.sam_write1(h->out, h->hdr, r) < 0) return fail(CRUMBLE_BAM_EIO, "sam_write1 failed");
+    }
+    return 0;
+}
+
+int crumble_hts_close(crumble_hts *h)
+{
+    int rc = 0;
+    if (!h) return 0;
+    if (H.ok) {
+        for (int64_t i = 0; i < h->n; i++) H.bam_destroy1(h->rec[i]);
+        for (int64_t i = 0; i < h->npool; i++) H.bam_destroy1(h->pool[i]);
+        if (h->ahead) H.bam_destroy1(h->ahead);
+        if (h->hdr) H.sam_hdr_destroy(h->hdr);
+        if (h->in && H.hts_close(h->in) != 0) rc = fail(CRUMBLE_BAM_EIO, "error while closing the input");
+        if (h->out && H.hts_close(h->out) != 0) rc = fail(CRUMBLE_BAM_EIO, "error while closing the output");
+    }
+    free(h->rec); free(h->pool); free(h->pos); free(h->mapq); free(h->flag); free(h->seq_off); free(h->cig_off); free(h->cigar);
+    big_free(h->bases, h->cap_bases); big_free(h->quals, h->cap_bases); free(h->filt.aux_set);
+    free(h);
+    return rc;
+}

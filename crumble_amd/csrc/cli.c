@@ -5,10 +5,11 @@
  * with the loop body replaced by crumble_hip_contig(): options are parsed with the reference's own
  * getopt string (snp_score.c:2199) in argv order (presets overwrite, later options refine), records
  * are gathered per contig (the unit the reference resets its state on, snp_score.c:1478-1488), the
- * engine rewrites the qualities, records go out in input order.  BAM only (no htslib here): options
- * that belong to htslib / host plumbing that was not rebuilt (-I -O -r) are refused
- * rather than silently ignored.  There is no CPU path: without a GPU the program stops with
- * CRUMBLE_ENODEVICE.
+ * engine rewrites the qualities, records go out in input order.  BAM goes through the native reader / writer
+ * (bamio.c) and the contig pipeline below; SAM, CRAM and the -I / -O format strings go through a system
+ * htslib when one can be dlopen'ed (bamio.c, "htslib backend") and stop with a clear error otherwise; -r
+ * (index iterator) is refused rather than silently ignored.  There is no CPU path: without a GPU the
+ * program stops with CRUMBLE_ENODEVICE.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -42,6 +43,8 @@ static void usage(FILE *fp)
         "  -t list  -T list        auxiliary tags to keep (white list) / to drop (black list)\n"
         "  -e -f -g / -E -F -G n   BD / BI tag low, cutoff, high values\n"
         "  -z                      no @PG header line\n"
+        "  -I fmt  -O fmt          input / output format[,options] as htslib understands them; SAM and CRAM files and\n"
+        "                          these two options need a system libhts (>= 1.10), looked up at run time\n"
         "  -v                      statistics and timings on stderr\n"
         "  -@ N                    host threads for BGZF/BAM work\n"
         "  -j N                    GPUs: contigs are LPT-packed onto devices 0..N-1 by reference length, one engine\n"
@@ -192,7 +195,7 @@ int main(int argc, char **argv)
     crumble_params P;
     crumble_params_default(&P);
     int opt, verbose = 0, threads = 0, no_pg = 0, ngpu = 1;
-    const char *bed_fn = NULL, *wl = NULL, *bl = NULL;
+    const char *bed_fn = NULL, *wl = NULL, *bl = NULL, *in_fmt = NULL, *out_fmt = NULL;
     int bd[3] = {0, 0, 0}, bi[3] = {0, 0, 0};
     FILE *bed_fp = NULL;
     while ((opt = getopt(argc, argv, "I:O:q:d:x:Q:D:X:m:l:u:U:c:i:L:Bs:t:T:hr:b:vC:M:Z:P:V:p:e:f:g:E:F:G:S135789zR:Y:y:k:K:N@:j:")) != -1) {
@@ -240,9 +243,11 @@ int main(int argc, char **argv)
         case 'F': bi[1] = atoi(optarg) + 33; break;
         case 'G': bi[2] = atoi(optarg) + 33; break;
         case 'b': if (!(bed_fp = fopen(optarg, "w"))) { perror(optarg); return 1; } break;
-        case 'I': case 'O': case 'r':
-            fprintf(stderr, "crumble-hip: option -%c (htslib formats / regions) is host "
-                            "plumbing that this build does not provide\n", opt);
+        case 'I': in_fmt = optarg; break;                       /* hts_parse_format strings, snp_score.c:2201-2207 */
+        case 'O': out_fmt = optarg; break;
+        case 'r':
+            fprintf(stderr, "crumble-hip: option -r (index region iterator) is host "
+                            "plumbing that this build does not provide\n");
             return 1;
         default: usage(stderr); return 1;
         }
@@ -250,6 +255,52 @@ int main(int argc, char **argv)
     if (argc - optind != 2) { usage(stderr); return 1; }
     const char *in_fn = argv[optind], *out_fn = argv[optind + 1];
     const int level = getenv("CRUMBLE_BAM_LEVEL") ? atoi(getenv("CRUMBLE_BAM_LEVEL")) : -1;
+
+    {   /* SAM / CRAM / explicit formats: the htslib backend, one contig at a time on one device */
+        unsigned char magic[4] = {0, 0, 0, 0};
+        FILE *mf = fopen(in_fn, "rb");
+        if (mf) { if (fread(magic, 1, 4, mf) != 4) magic[0] = 0; fclose(mf); }
+        const size_t ol = strlen(out_fn);
+        const int bgzf = magic[0] == 0x1f && magic[1] == 0x8b && magic[2] == 8 && (magic[3] & 4);
+        const int out_other = (ol > 5 && !strcasecmp(out_fn + ol - 5, ".cram")) || (ol > 4 && !strcasecmp(out_fn + ol - 4, ".sam"));
+        if (in_fmt || out_fmt || !bgzf || out_other) {
+            size_t len = 1;
+            for (int i = 0; i < argc; i++) len += strlen(argv[i]) + 1;
+            char *cl = malloc(len), *q = cl;
+            for (int i = 0; i < argc; i++) q += sprintf(q, "%s%s", i ? " " : "", argv[i]);
+            int herr = 0;
+            crumble_hts *hs = crumble_hts_open(in_fn, in_fmt, out_fn, out_fmt, no_pg ? NULL : "crumble-hip", "0.2", cl, threads, &herr);
+            if (!hs) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
+            if (crumble_hts_set_aux_filter(hs, wl, bl, bd, bi)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
+            int32_t *bt = NULL, *bs = NULL, *be = NULL; int nbed = 0, bed_i = 0, e2 = 0;
+            if (bed_fn && (nbed = crumble_hts_load_bed(hs, bed_fn, &bt, &bs, &be)) < 0) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
+            const int device = getenv("CRUMBLE_HIP_DEVICE") ? atoi(getenv("CRUMBLE_HIP_DEVICE")) : 0;
+            crumble_hip *eng = crumble_hip_create(&P, device, &e2);
+            if (!eng) { fprintf(stderr, "crumble-hip: %s (%s)\n", crumble_hip_strerror(e2), crumble_hip_last_error()); return 2; }
+            int64_t stats[CRUMBLE_ST_N] = {0};
+            uint8_t *qout = NULL; size_t qcap = 0;
+            for (;;) {
+                crumble_batch B;
+                const int rc = crumble_hts_next_contig(hs, &B);
+                if (rc < 0) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
+                if (rc == 0) break;
+                while (bed_i < nbed && bt[bed_i] < B.tid) bed_i++;
+                int j2 = bed_i;
+                while (j2 < nbed && bt[j2] == B.tid) j2++;
+                if (B.tid >= 0 && j2 > bed_i) { B.n_bed = j2 - bed_i; B.bed_start = bs + bed_i; B.bed_end = be + bed_i; }
+                const size_t nb = (size_t)B.seq_off[B.n_reads];
+                if (qcap < nb + 16) { crumble_bam_big_free(qout, qcap); qcap = nb + nb / 8 + 64; qout = crumble_bam_big_alloc(qcap); if (!qout) { fprintf(stderr, "crumble-hip: out of memory\n"); return 1; } }
+                const int e = crumble_hip_contig(eng, &B, qout, NULL, stats);
+                if (e) { fprintf(stderr, "crumble-hip: contig %s: %s (%s)\n", crumble_hts_ref_name(hs, B.tid), crumble_hip_strerror(e), crumble_hip_last_error()); return 2; }
+                if (crumble_hts_write_group(hs, qout)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
+            }
+            if (crumble_hts_close(hs)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
+            if (verbose) for (int i = 0; i < (int)(sizeof ST_NAME / sizeof *ST_NAME); i++) fprintf(stderr, "%-16s %lld\n", ST_NAME[i], (long long)stats[i]);
+            crumble_hip_destroy(eng); crumble_bam_big_free(qout, qcap); free(bt); free(bs); free(be); free(cl);
+            if (bed_fp) fclose(bed_fp);
+            return 0;
+        }
+    }
 
     static pipe_t p;
     memset(&p, 0, sizeof p);

@@ -27,6 +27,7 @@ extern "C" {
 #define CRUMBLE_BAM_EFORMAT  -21   /* not BGZF / not BAM / truncated / corrupt    */
 #define CRUMBLE_BAM_ENOMEM   -22
 #define CRUMBLE_BAM_EUNSUPP  -23   /* valid BAM feature this reader does not take */
+#define CRUMBLE_BAM_ENOHTS   -24   /* SAM / CRAM / -I / -O need a system libhts (>= 1.10); none was found */
 
 typedef struct crumble_bam_reader crumble_bam_reader;
 typedef struct crumble_bam_writer crumble_bam_writer;
@@ -84,6 +85,24 @@ int crumble_bam_write_batches(const char *path, int32_t n_ref, const char *const
  * number of regions (arrays malloc'ed, sorted by tid then start; caller frees) or < 0. */
 int crumble_bam_load_bed(const crumble_bam_reader *r, const char *path,
                          int32_t **tid, int32_t **start, int32_t **end);
+
+/* htslib backend: SAM / BAM / CRAM in and out through a system libhts.so.3 resolved with dlopen at run time -- what
+ * reference crumble's main() does with sam_open_format / sam_hdr_read / sam_read1 / sam_write1 / sam_hdr_add_PG
+ * (snp_score.c:2201-2207, 2561-2626).  Same group contract as the native reader; without a usable libhts every
+ * entry point fails with CRUMBLE_BAM_ENOHTS (crumble_hts_available() returns 0) and BAM keeps working through the
+ * native reader / writer.  in_fmt / out_fmt are the reference's -I / -O strings (hts_parse_format), NULL = by
+ * file content / name.  pg_name NULL = no @PG line (-z). */
+typedef struct crumble_hts crumble_hts;
+int  crumble_hts_available(char *version, size_t len);
+crumble_hts *crumble_hts_open(const char *in_fn, const char *in_fmt, const char *out_fn, const char *out_fmt,
+                              const char *pg_name, const char *pg_version, const char *pg_cmdline, int threads, int *err);
+int32_t     crumble_hts_n_ref(const crumble_hts *h);
+const char *crumble_hts_ref_name(const crumble_hts *h, int32_t tid);
+int  crumble_hts_load_bed(const crumble_hts *h, const char *path, int32_t **tid, int32_t **start, int32_t **end);
+int  crumble_hts_set_aux_filter(crumble_hts *h, const char *whitelist, const char *blacklist, const int bd[3], const int bi[3]);
+int  crumble_hts_next_contig(crumble_hts *h, crumble_batch *b);
+int  crumble_hts_write_group(crumble_hts *h, const uint8_t *qual_out);
+int  crumble_hts_close(crumble_hts *h);
 
 /* Huge-page backed host buffers for multi-GB arrays (e.g. the caller's qual_out): mmap +
  * MADV_HUGEPAGE; release with the same size. */

@@ -422,6 +422,36 @@ def test_cli_suspect_bed_emulated(tmp_path):
     assert got == want
 
 
+def test_htslib_backend_absent_is_a_clean_error(tmp_path):
+    """SAM / CRAM and -I / -O go through a system libhts resolved with dlopen.  There is none in
+    this image (and none may be stood in for): the library says so (crumble_hts_available 0, CRUMBLE_BAM_ENOHTS),
+    the driver stops with exit 1 and a message, nothing is written, and BAM keeps working (every other test)."""
+    import ctypes as C
+    L = bamio.lib()
+    L.crumble_hts_available.argtypes = [C.c_char_p, C.c_size_t]
+    buf = C.create_string_buffer(64)
+    if L.crumble_hts_available(buf, 64):
+        pytest.skip(f"a system htslib {buf.value.decode()} is present")
+    err = C.c_int(0)
+    L.crumble_hts_open.restype = C.c_void_p
+    L.crumble_hts_open.argtypes = [C.c_char_p] * 7 + [C.c_int, C.POINTER(C.c_int)]
+    assert L.crumble_hts_open(b"x.sam", None, b"y.sam", None, None, None, None, 1, C.byref(err)) is None
+    assert err.value == -24 and b"libhts" in L.crumble_bam_last_error()
+    import emu_lib
+    emu_lib.load()
+    exe = os.path.join(ROOT, "tests", "emu", "crumble-hip-emu")
+    refs, bs = three_groups()
+    bamio.write_batches(tmp_path / "in.bam", refs, bs[:1])
+    (tmp_path / "in.sam").write_text("@HD\tVN:1.6\n@SQ\tSN:chrI\tLN:1000\nr1\t0\tchrI\t10\t60\t4M\t*\t0\t0\tACGT\tIIII\n")
+    for args in (["-I", "bam", str(tmp_path / "in.bam"), str(tmp_path / "o.bam")],
+                 ["-O", "cram,version=3.0", str(tmp_path / "in.bam"), str(tmp_path / "o.cram")],
+                 [str(tmp_path / "in.bam"), str(tmp_path / "o.cram")],
+                 [str(tmp_path / "in.sam"), str(tmp_path / "o.bam")]):
+        r = subprocess.run([exe, "-5", *args], stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 1 and "libhts" in r.stderr, (args, r.stderr)
+        assert not os.path.exists(args[-1])
+
+
 def test_cli_has_no_cpu_path(tmp_path):
     """Without a GPU the shipped binary stops with ENODEVICE (exit 2); it never computes on the host."""
     import torch
@@ -458,7 +488,7 @@ def test_cli_multi_device_and_options_gpu(tmp_path):
     statistics added on the host), with >= 2 visible GPUs the engines sit on devices 0 and 1 and the statistics go
     through ncclCommInitAll + crumble_hip_stats_allreduce.  (2) the host-plumbing options -t / -T, -e..-G, -z and
     -b through the real binary."""
-    import torch
+    import ctypes
     exe = os.path.join(ROOT, "crumble_amd", "crumble-hip")
     refs = [("chrI", 4000000), ("chrII", 200000), ("chrIII", 900000), ("chrIV", 1500000), ("chrV", 50000)]
     bs = []
@@ -467,7 +497,9 @@ def test_cli_multi_device_and_options_gpu(tmp_path):
         bs.append(synth.generate(cfg))
     bs.append(HostBatch.from_reads([dict(pos=0, cigar="*", seq="ACGTAC", qual=[9, 30, 31, 12, 40, 2], flag=4)], tid=-1))
     bamio.write_batches(tmp_path / "in.bam", refs, bs)
-    ndev = torch.cuda.device_count()
+    nd = ctypes.c_int(0)                         # (not through torch: importing it would pull in its own librccl)
+    ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(nd))
+    ndev = nd.value
     outs = {}
     for j in (1, 2, 3):
         devs = ",".join(str(k if ndev >= j else 0) for k in range(j))
