@@ -76,6 +76,7 @@ __device__ __forceinline__ uint32_t kc2_perm(uint32_t s0, uint32_t s1, uint32_t 
     return d;
 }
 #define KC2_MASKED
+#define KC2_PIN(x)
 #else
 /* LDS traffic between the lanes of ONE wave: the hardware keeps a wave's DS operations in order; the fence only
  * stops the compiler from moving them across */
@@ -88,6 +89,7 @@ __device__ __forceinline__ uint32_t kc2_perm(uint32_t s0, uint32_t s1, uint32_t 
 /* hipcc turns `if (m) s += x;` into an unconditional add plus two v_cndmask_b32 per double; an empty volatile asm
  * in the block keeps it an exec-masked block (one s_and_saveexec for several adds, skipped when no lane is in it) */
 #define KC2_MASKED asm volatile("")
+#define KC2_PIN(x) asm volatile("" : "+v"(x))      /* the value exists HERE (a load above it cannot sink past the block) */
 #endif
 
 struct __attribute__((aligned(4))) KC2U4 { uint32_t x, y, z, w; };     /* 16 bytes at a 4-byte aligned address */
@@ -152,6 +154,23 @@ struct __attribute__((aligned(16))) KC2Wave {      /* one wave's LDS */
         if (__ballot(ml_ && pend != 0u)) KC2_DRAIN(); \
         if (ml_) pend = 0x10000u | (v_); \
     } } while (0)
+#elif defined(KC2_EXP_SELECT)
+/* experiment: no EXEC writes at all -- addends selected against +0.0 (exact: the sums are never -0.0) */
+#define KC2_ROW(v_, MM_, _M_, om_) do { \
+    const unsigned cls_ = (v_) & 7u; \
+    const bool cov_ = cls_ != 7u; \
+    const bool m0_ = cls_ == k0, m1_ = cls_ == k1, m2_ = cls_ == k2, m3_ = cls_ == k3; \
+    const bool ml_ = cov_ && !m0_; \
+    const unsigned long long mis_ = __ballot(ml_); \
+    if (__builtin_expect((mis_ & ~__ballot(m1_ || m2_ || m3_)) != 0ull, 0)) { \
+        if (cls_ == 4u) { KC2_MASKED; s04 += (_M_); } \
+        if (cls_ == 5u) { KC2_MASKED; s00 += (MM_); s01 += (MM_); s02 += (MM_); s03 += (MM_); s04 += (_M_); } \
+    } \
+    s00 += m0_ ? (MM_) : 0.0; d0 += m0_ ? (om_) : 0.0; s04 += m0_ ? (_M_) : 0.0; \
+    s01 += (m0_ || m1_) ? (_M_) : 0.0; s02 += (m0_ || m2_) ? (_M_) : 0.0; s03 += (m0_ || m3_) ? (_M_) : 0.0; \
+    if (__builtin_expect(__ballot(ml_ && pend != 0u) != 0ull, 0)) KC2_DRAIN(); \
+    pend = ml_ ? (0x10000u | (v_)) : pend; \
+    } while (0)
 #else
 #define KC2_ROW(v_, MM_, _M_, om_) do { \
     unsigned long long mis_, odd_, coll_, m0_, m1_, m2_, m3_, t_, sv_; \
@@ -485,14 +504,22 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                     for (int u = 0; u < 4; u++) vn[u] = W.plane[j0 + 4 + u][lane];
                 }
                 const unsigned slow4 = (unsigned)(slowmask >> j0) & 15u;
+#ifdef KC2_EXP_STAMP
+                KC2_STAMP(3);                                            /* issue of the group's LDS reads */
+                __builtin_amdgcn_s_waitcnt(0xc07f);                      /* lgkmcnt(0) */
+                KC2_STAMP(5);                                            /* waiting for them */
+#endif
                 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     if (__builtin_expect(((slow4 >> u) & 1u) != 0u, 0)) {  /* uniform */
                         const unsigned rinfo = UNIFORM(W.rowinfo[j0 + u]);
                         if (MQ && (rinfo & KC2_NONHOT)) {                 /* another mapq: the adjustment, then the row (snp:632-641) */
                             const unsigned q = ve[u] >> 5, slot = (rinfo >> 8) & 255u;
-                            const unsigned aq = slot < (unsigned)B.n_slots ? (unsigned)sAdjC[slot * 128u + (q & 127u)]
-                                                                           : (unsigned)T->adjc[(rinfo & 255u) * 256u + (q & 255u)];
+                            unsigned aq;
+                            /* two real branches (the empty asm keeps hipcc from merging them into one flat load
+                             * through a pointer select: a flat load waits out the global-memory latency) */
+                            if (slot < (unsigned)B.n_slots) { aq = sAdjC[slot * 128u + (q & 127u)]; KC2_PIN(aq); }
+                            else aq = T->adjc[(rinfo & 255u) * 256u + (q & 255u)];
                             if (ANYPRES) rpv[u] = sPv[q & 127u];
                             ve[u] = ((128u + aq) << 5) | (ve[u] & 7u);
                             const double *rw = (const double *)(rowbase + (ve[u] & 0xffe0u));
@@ -547,13 +574,17 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
             st.clipped = (int)(h >> 16);
             st.n_overlap = st.n_plp - st.nref - (int)(h & 0xffff);
         }
+#ifdef KC2_EXP_NODECIDE
+        if (inr) { colrec[c] = (st.S[0] + st.S[7] + st.sC[2] > 1e300) ? 1u : 0u; nplp_out[c] = st.n_plp; score_out[c] = 0; trigcnt[c] = 0; }
+        continue;
+#endif
         if (key) col_unpermute(st.S, st.sC, (int)key);  /* back to the reference's A C G T numbering */
         if (inr) col_decide<MQ ? 1 : 0>(st, B, P, T, c, apos, true, colrec, nplp_out, score_out, trigcnt, sStat, KC2_LDS_EXP ? sE : (const double *)nullptr);
         KC2_STAMP(4);
     }
     }
 #ifdef KC2_EXP_STAMP
-    if (lane == 0) for (int k = 0; k < 5; k++) atomicAdd(&stats[24 + k], (u64)tacc[k]);
+    if (lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&stats[24 + k], (u64)tacc[k]);
 #endif
     __syncthreads();
     if (threadIdx.x < 32 && sStat[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (u64)sStat[threadIdx.x]);

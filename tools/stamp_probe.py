@@ -7,5 +7,5 @@ e = ca.Engine(ca.preset_params(int(sys.argv[3]) if len(sys.argv) > 3 else 5), 0)
 e.upload(hb); e.run(); e.stats_reset(); e.run()
 s = e.stats_read()
 kt = dict((n, ms) for n, ms, _ in e.kernel_times())
-t = s[24:29].astype(float)
-print("k_columns2 ms", kt.get("k_columns2"), "stamps (share): unit-grab %.3f stage %.3f produce %.3f consume %.3f decide %.3f" % tuple(t / t.sum()), "total wave-cycles %.3g" % t.sum())
+t = s[24:30].astype(float)
+print("k_columns2 ms", kt.get("k_columns2"), "stamps (share): unit-grab %.3f stage %.3f produce %.3f consume(rows+issue) %.3f decide %.3f consume(LDS wait) %.3f" % tuple(t / t.sum()), "total wave-cycles %.3g" % t.sum())
