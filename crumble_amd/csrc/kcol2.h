@@ -102,6 +102,15 @@ struct __attribute__((aligned(16))) KC2Wave {      /* one wave's LDS */
     uint32_t ht[64];                               /* per column: head/tail entries (low half), clipped ones (high half) */
 };
 
+struct __attribute__((aligned(16))) KC2Lds {
+    double   row[KC2_NROWTAB * 4];
+    double   e[KC2_LDS_EXP ? CONS_NEXP : 2];
+    unsigned stat[32];
+    uint8_t  adjc[KC2_SLOTS * 128];
+    uint8_t  pv[128];
+    KC2Wave  wave[KC2_WAVES];
+};
+
 /* The 15 genotype sums and 5 discrepancy sums are NAMED LOCAL SCALARS of the kernel (permuted numbering, see the
  * header), and the two routines below are macros over them.  Not arrays, not a struct passed by reference: hipcc
  * merges the parked part's four look-alike class blocks into one block with computed addresses, and whatever is
@@ -111,9 +120,9 @@ struct __attribute__((aligned(16))) KC2Wave {      /* one wave's LDS */
            s33 = 0, s34 = 0, s44 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0; \
     int nN = 0
 
-/* the parked part of a mismatching entry: pend = 0x10000 | its matrix entry (table row byte offset | class) */
-#define KC2_DRAIN() do { \
-    const unsigned pe_ = pend; \
+/* the parked part of a mismatching entry x_ = 0x10000 | its matrix entry (table row byte offset | class), 0 = none */
+#define KC2_DRAIN_V(x_) do { \
+    const unsigned pe_ = (x_); \
     if (pe_) { \
         const double *rw_ = (const double *)(rowbase + (pe_ & 0xffe0u)); \
         const double pMM = rw_[0], p_M = rw_[1], pom = rw_[2]; \
@@ -125,8 +134,8 @@ struct __attribute__((aligned(16))) KC2Wave {      /* one wave's LDS */
         if (k_ == 4u) { KC2_MASKED; d4 += pom; s14 += p_M; s24 += p_M; s34 += p_M; s44 += pMM; } \
         if (k_ == 5u) { KC2_MASKED; nN++; s11 += pMM; s12 += pMM; s13 += pMM; s14 += p_M; s22 += pMM; s23 += pMM; s24 += p_M; \
                         s33 += pMM; s34 += p_M; } \
-        pend = 0; \
     } } while (0)
+#define KC2_DRAIN() do { KC2_DRAIN_V(pend); pend = 0; } while (0)
 
 /* One row of the matrix for this lane's column: entry v_ (table row byte offset | class; class 7 = not reached),
  * the table row's MM_, _M_, om_.  The inline part of the entry (header) plus the pending-slot bookkeeping.
@@ -173,10 +182,11 @@ struct __attribute__((aligned(16))) KC2Wave {      /* one wave's LDS */
     } while (0)
 #else
 #define KC2_ROW(v_, MM_, _M_, om_) do { \
-    unsigned long long mis_, odd_, coll_, m0_, m1_, m2_, m3_, t_, sv_; \
-    unsigned cls_; \
+    unsigned long long mis_, odd_, coll_, rare_, m0_, m1_, m2_, m3_, t_, sv_; \
+    unsigned cls_, old_; \
     asm volatile( \
         "v_and_b32_e32 %[cls], 7, %[v]\n\t" \
+        "v_mov_b32_e32 %[old], %[pend]\n\t" \
         "v_cmp_eq_u32_e64 %[m0], %[cls], %[k0]\n\t" \
         "v_cmp_eq_u32_e64 %[m1], %[cls], %[k1]\n\t" \
         "v_cmp_eq_u32_e64 %[m2], %[cls], %[k2]\n\t" \
@@ -198,26 +208,27 @@ struct __attribute__((aligned(16))) KC2Wave {      /* one wave's LDS */
         "s_or_b64 exec, %[m0], %[m3]\n\t" \
         "v_add_f64 %[s03], %[s03], %[_M]\n\t" \
         "s_mov_b64 exec, %[mis]\n\t" \
-        "v_cmp_ne_u32_e64 %[coll], 0, %[pend]\n\t" \
+        "v_cmp_ne_u32_e64 %[coll], 0, %[pend]\n\t"      /* a mismatching lane whose slot is taken */ \
+        "v_or_b32_e32 %[pend], 0x10000, %[v]\n\t"       /* park this entry (the old one is in old_) */ \
+        "s_or_b64 %[rare], %[odd], %[coll]\n\t" \
         "s_mov_b64 exec, %[sv]" \
-        : [cls] "=&v"(cls_), [m0] "=&s"(m0_), [m1] "=&s"(m1_), [m2] "=&s"(m2_), [m3] "=&s"(m3_), [t] "=&s"(t_), \
-          [sv] "=&s"(sv_), [mis] "=&s"(mis_), [odd] "=&s"(odd_), [coll] "=&s"(coll_), \
-          [s00] "+v"(s00), [s01] "+v"(s01), [s02] "+v"(s02), [s03] "+v"(s03), [s04] "+v"(s04), [d0] "+v"(d0) \
-        : [v] "v"(v_), [k0] "v"(k0), [k1] "v"(k1), [k2] "v"(k2), [k3] "v"(k3), [MM] "v"(MM_), [_M] "v"(_M_), [om] "v"(om_), \
-          [pend] "v"(pend) \
+        : [cls] "=&v"(cls_), [old] "=&v"(old_), [m0] "=&s"(m0_), [m1] "=&s"(m1_), [m2] "=&s"(m2_), [m3] "=&s"(m3_), \
+          [t] "=&s"(t_), [sv] "=&s"(sv_), [mis] "=&s"(mis_), [odd] "=&s"(odd_), [coll] "=&s"(coll_), [rare] "=&s"(rare_), \
+          [s00] "+v"(s00), [s01] "+v"(s01), [s02] "+v"(s02), [s03] "+v"(s03), [s04] "+v"(s04), [d0] "+v"(d0), \
+          [pend] "+v"(pend) \
+        : [v] "v"(v_), [k0] "v"(k0), [k1] "v"(k1), [k2] "v"(k2), [k3] "v"(k3), [MM] "v"(MM_), [_M] "v"(_M_), [om] "v"(om_) \
         : "scc"); \
-    if (__builtin_expect(odd_ != 0ull, 0)) {              /* a '*' or an N somewhere in the row (rare) */ \
-        if (cls_ == 4u) { KC2_MASKED; s04 += (_M_); } \
-        if (cls_ == 5u) { KC2_MASKED; s00 += (MM_); s01 += (MM_); s02 += (MM_); s03 += (MM_); s04 += (_M_); } \
-    } \
-    if (__builtin_expect(coll_ != 0ull, 0)) KC2_DRAIN(); \
-    asm volatile( \
-        "s_mov_b64 %[sv], exec\n\t" \
-        "s_mov_b64 exec, %[mis]\n\t" \
-        "v_or_b32_e32 %[pend], 0x10000, %[v]\n\t" \
-        "s_mov_b64 exec, %[sv]" \
-        : [pend] "+v"(pend), [sv] "=&s"(sv_) : [v] "v"(v_), [mis] "s"(mis_)); \
-    } while (0)
+    if (__builtin_expect(rare_ != 0ull, 0)) { \
+        if (odd_ != 0ull) {                               /* a '*' or an N somewhere in the row */ \
+            if (cls_ == 4u) { KC2_MASKED; s04 += (_M_); } \
+            if (cls_ == 5u) { KC2_MASKED; s00 += (MM_); s01 += (MM_); s02 += (MM_); s03 += (MM_); s04 += (_M_); } \
+        } \
+        if (coll_ != 0ull) {                              /* drain what was parked BEFORE this row, keep this row's entries */ \
+            const bool ml_ = cls_ != 7u && cls_ != k0; \
+            KC2_DRAIN_V(ml_ ? old_ : pend); \
+            pend = ml_ ? pend : 0u; \
+        } \
+    } } while (0)
 #endif
 
 #ifdef KC2_EXP_STAMP      /* diagnostic build: cycles per phase, summed over waves, into the unused stats slots 24..29 */
@@ -235,14 +246,17 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
            int32_t *__restrict__ score_out, int32_t *__restrict__ trigcnt, const uint32_t *__restrict__ ht,
            u64 *stats, unsigned *__restrict__ tile_ctr)
 {
-    /* [index] -> {MM, _M, 1 - q2p, preserve_qual}: 32-byte rows.  0..127: a raw quality of a read with the dominant
-     * mapq (or of any read without CONS_MQUAL); 128 + a: adjusted quality a */
-    __shared__ double sRow[KC2_NROWTAB * 4];
-    __shared__ uint8_t sAdjC[MQ ? KC2_SLOTS * 128 : 16];   /* [slot][raw quality] -> adjusted quality, other mapqs */
-    __shared__ uint8_t sPv[128];                           /* pvc[] (call_preserve input of a raw quality) */
-    __shared__ double sE[KC2_LDS_EXP ? CONS_NEXP : 2];     /* the reachable halves of the exp tables (cons_finalize) */
-    __shared__ unsigned sStat[32];
-    __shared__ KC2Wave sWave[KC2_WAVES];
+    /* ONE shared object, the table first: its rows then sit at LDS offsets below 64 KB and the consumer's row reads
+     * need no address add (the offset is an immediate) */
+    __shared__ KC2Lds L;
+    double *const sRow = L.row;            /* [index] -> {MM, _M, 1 - q2p, preserve_qual}: 32-byte rows.  0..127: a raw
+                                            * quality of a read with the dominant mapq (or of any read without
+                                            * CONS_MQUAL); 128 + a: adjusted quality a */
+    uint8_t *const sAdjC = L.adjc;         /* [slot][raw quality] -> adjusted quality, other mapqs */
+    uint8_t *const sPv = L.pv;             /* pvc[] (call_preserve input of a raw quality) */
+    double *const sE = L.e;                /* the reachable halves of the exp tables (cons_finalize) */
+    unsigned *const sStat = L.stat;
+    KC2Wave *const sWave = L.wave;
     const int hot_mq = MQ ? B.hot_mq : -1;
     if (threadIdx.x < 32) sStat[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < KC2_NROWTAB; i += blockDim.x) {
@@ -261,7 +275,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
 
     const int lane = threadIdx.x & 63;
     KC2Wave &W = sWave[threadIdx.x >> 6];
-    const char *rowbase = (const char *)sRow;
+    const char *rowbase = (const char *)L.row;
     const int min_mqual = P->min_mqual;
     const int rsub = lane >> 2, seg = lane & 3;
     const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;     /* lanes below this one */
@@ -509,15 +523,16 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                 __builtin_amdgcn_s_waitcnt(0xc07f);                      /* lgkmcnt(0) */
                 KC2_STAMP(5);                                            /* waiting for them */
 #endif
-                #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (__builtin_expect(((slow4 >> u) & 1u) != 0u, 0)) {  /* uniform */
+                if (__builtin_expect(slow4 != 0u, 0)) {                  /* (uniform) rows that need a look-up first */
+                    #pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (!((slow4 >> u) & 1u)) continue;
                         const unsigned rinfo = UNIFORM(W.rowinfo[j0 + u]);
                         if (MQ && (rinfo & KC2_NONHOT)) {                 /* another mapq: the adjustment, then the row (snp:632-641) */
                             const unsigned q = ve[u] >> 5, slot = (rinfo >> 8) & 255u;
                             unsigned aq;
-                            /* two real branches (the empty asm keeps hipcc from merging them into one flat load
-                             * through a pointer select: a flat load waits out the global-memory latency) */
+                            /* two real branches (hipcc would merge them into one flat load through a pointer
+                             * select: a flat load waits out the global-memory latency) */
                             if (slot < (unsigned)B.n_slots) { aq = sAdjC[slot * 128u + (q & 127u)]; KC2_PIN(aq); }
                             else aq = T->adjc[(rinfo & 255u) * 256u + (q & 255u)];
                             if (ANYPRES) rpv[u] = sPv[q & 127u];
@@ -540,8 +555,8 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                             st.n_isindel += (cov && !isN && isind) ? 1 : 0;
                             st.has_ins |= (cov && !isN && !head && !tail && e_indel > 0) ? 1 : 0;   /* snp:1708 */
                             if (lq == 0) n_lq0 += cov ? 1 : 0;
-                            if (isN || lq == 0) continue;                /* no consensus entry (snp:589,594): the row is empty */
-                            if (ANYPRES && cov && e_indel > 0) {         /* qualities of the inserted bases, snp:616-622 */
+                            /* no consensus entry (snp:589,594): the producer left the row empty (class 7 everywhere) */
+                            if (!(isN || lq == 0) && ANYPRES && cov && e_indel > 0) {   /* qualities of the inserted bases, snp:616-622 */
                                 const int64_t so = (int64_t)(((uint64_t)r0.w << 32) | r0.z);
                                 const int e_qpos = isM ? qoff + apos : qoff;
                                 for (int ins = 0; ins < e_indel; ins++) {
@@ -551,6 +566,9 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                             }
                         }
                     }
+                }
+                #pragma unroll
+                for (int u = 0; u < 4; u++) {
                     KC2_ROW(ve[u], rMM[u], r_M[u], rom[u]);
                     if (ANYPRES) {                                        /* call_preserve bits, snp:611-623 */
                         const unsigned pv = (unsigned)rpv[u] & 3u, cl = ve[u] & 7u;
