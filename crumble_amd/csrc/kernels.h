@@ -203,18 +203,18 @@ __device__ __forceinline__ void cons_finalize(const DTables *T, double *S, const
     }
     if (sE) {
         int ix[15];
-        double e[15];
+        unsigned live = 0;                             /* bit j: S[j] > min_e_exp (else DBL_MIN, snp:739) */
         #pragma unroll
         for (int j = 0; j < 15; j++) {                 /* snp:736-741 with fast_exp's index arithmetic (snp:496-502) */
             const double y = S[j] - shift;             /* <= 0 */
-            S[j] = y;
             const double yc = y < -500.0 ? -500.0 : y;
             ix[j] = (y >= -50.0) ? (int)(y * 10) + 500 : 501 + (int)yc + 500;
+            live |= (y > min_e_exp) ? (1u << j) : 0u;
         }
         #pragma unroll
-        for (int j = 0; j < 15; j++) e[j] = sE[ix[j]];
+        for (int j = 0; j < 15; j++) S[j] = sE[ix[j]];                       /* the 15 loads go out together */
         #pragma unroll
-        for (int j = 0; j < 15; j++) S[j] = (S[j] > min_e_exp) ? e[j] : DBL_MIN;
+        for (int j = 0; j < 15; j++) S[j] = ((live >> j) & 1u) ? S[j] : DBL_MIN;
     } else {
         #pragma unroll
         for (int j = 0; j < 15; j++) {                 /* snp:736-741 */
@@ -223,19 +223,25 @@ __device__ __forceinline__ void cons_finalize(const DTables *T, double *S, const
             S[j] = (S[j] > min_e_exp) ? e : DBL_MIN;
         }
     }
-    double pre[15], suf[15], tot1 = 0, tot2 = 0;       /* snp:743-749 */
+    /* norm[j] = (0 + sum of S[i], i < j, left to right) + (sum of S[i], i > j, right to left) (snp:743-749), needed
+     * for j = call and j = het_call only: the running sums are captured as they pass those two indices (no
+     * pre[] / suf[] arrays: 60 fewer live registers).  call is one of 0 5 9 12 14, het_call one of the others. */
+    double tot1 = 0, tot2 = 0, pre_c = 0, pre_h = 0, suf_c = 0, suf_h = 0, s_het = 0;
     #pragma unroll
     for (int j = 0; j < 15; j++) {
-        pre[j] = tot1; suf[14 - j] = tot2;
-        tot1 += S[j]; tot2 += S[14 - j];
+        const bool hom = (j == 0 || j == 5 || j == 9 || j == 12 || j == 14);
+        if (hom) { if (j == call) pre_c = tot1; }
+        else     { if (j == het_call) pre_h = tot1; }
+        tot1 += S[j];
     }
-    double nc = 0, nh = 0, s_het = 0;
     #pragma unroll
-    for (int j = 0; j < 15; j++) {
-        const double nj = (0.0 + pre[j]) + suf[j];
-        if (j == call) nc = nj;
-        if (j == het_call) { nh = nj; s_het = S[j]; }
+    for (int j = 14; j >= 0; j--) {
+        const bool hom = (j == 0 || j == 5 || j == 9 || j == 12 || j == 14);
+        if (hom) { if (j == call) suf_c = tot2; }
+        else     { if (j == het_call) { suf_h = tot2; s_het = S[j]; } }
+        tot2 += S[j];
     }
+    double nc = (0.0 + pre_c) + suf_c, nh = (0.0 + pre_h) + suf_h;
     if (depth && depth != nN) {
         /* map_sing / map_het (snp:547-558) */
         o.call = (call == 0) ? 0 : (call == 5) ? 1 : (call == 9) ? 2 : (call == 12) ? 3 : 4;
