@@ -49,10 +49,16 @@
 #endif
 #define KC2_THREADS  (KC2_WAVES * 64)
 #ifndef KC2_SLOTS
-#define KC2_SLOTS    64            /* mapq values with a row of the compact adjustment table in LDS */
+#define KC2_SLOTS    48            /* mapq values with a row of the compact adjustment table in LDS */
 #endif
 #ifndef KC2_LDS_EXP
 #define KC2_LDS_EXP  1             /* cons_finalize's exp tables in LDS */
+#endif
+#ifndef KC2_DIAG
+#define KC2_DIAG     1             /* the consumer's lanes start at their own first row (see "consume" below) */
+#endif
+#if KC2_DIAG && KC2_PR != KC2_R
+#error "KC2_DIAG needs the whole pass in the matrix (KC2_PR == KC2_R)"
 #endif
 #define KC2_RARE     0x10000u      /* row flags in rowinfo[]: bits 0-7 mapq, 8-15 slot */
 #define KC2_LOWMQ    0x20000u
@@ -77,6 +83,13 @@ __device__ __forceinline__ uint32_t kc2_perm(uint32_t s0, uint32_t s1, uint32_t 
 }
 #define KC2_MASKED
 #define KC2_PIN(x)
+/* inclusive scans across the wave's lanes */
+#define KC2_EMU_SCAN(name, OP) \
+__device__ __forceinline__ int name(int v) \
+{ const int ln = threadIdx.x & 63; for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d); if (ln >= d) v = OP; } return v; }
+KC2_EMU_SCAN(kc2_scan_add, v + o)
+KC2_EMU_SCAN(kc2_scan_max, (o > v ? o : v))
+KC2_EMU_SCAN(kc2_scan_min, (o < v ? o : v))
 #else
 /* LDS traffic between the lanes of ONE wave: the hardware keeps a wave's DS operations in order; the fence only
  * stops the compiler from moving them across */
@@ -90,6 +103,25 @@ __device__ __forceinline__ uint32_t kc2_perm(uint32_t s0, uint32_t s1, uint32_t 
  * in the block keeps it an exec-masked block (one s_and_saveexec for several adds, skipped when no lane is in it) */
 #define KC2_MASKED asm volatile("")
 #define KC2_PIN(x) asm volatile("" : "+v"(x))      /* the value exists HERE (a load above it cannot sink past the block) */
+/* inclusive scans across the wave's lanes in six DPP steps (row_shr 1/2/4/8 inside the rows of 16, then row_bcast:15
+ * into rows 1 and 3 and row_bcast:31 into rows 2 and 3): VALU only, where __shfl_up is a chain of ds_bpermute
+ * round trips.  Lanes a step has no source for take the operation's identity. */
+#define KC2_DPP(id_, v_, ctrl_, rows_) __builtin_amdgcn_update_dpp((int)(id_), (v_), (ctrl_), (rows_), 0xf, false)
+#define KC2_DPP_SCAN(name, ID, OP) \
+__device__ __forceinline__ int name(int v) \
+{ \
+    int o; \
+    o = KC2_DPP(ID, v, 0x111, 0xf); v = OP; \
+    o = KC2_DPP(ID, v, 0x112, 0xf); v = OP; \
+    o = KC2_DPP(ID, v, 0x114, 0xf); v = OP; \
+    o = KC2_DPP(ID, v, 0x118, 0xf); v = OP; \
+    o = KC2_DPP(ID, v, 0x142, 0xa); v = OP; \
+    o = KC2_DPP(ID, v, 0x143, 0xc); v = OP; \
+    return v; \
+}
+KC2_DPP_SCAN(kc2_scan_add, 0, v + o)
+KC2_DPP_SCAN(kc2_scan_max, (-0x7fffffff - 1), (o > v ? o : v))
+KC2_DPP_SCAN(kc2_scan_min, 0x7fffffff, (o < v ? o : v))
 #endif
 
 struct __attribute__((aligned(4))) KC2U4 { uint32_t x, y, z, w; };     /* 16 bytes at a 4-byte aligned address */
@@ -100,6 +132,8 @@ struct __attribute__((aligned(16))) KC2Wave {      /* one wave's LDS */
     uint32_t rowinfo[KC2_R];
     int32_t  cnt[2][68];                           /* difference arrays over the tile's columns: all records / low-mapq records */
     uint32_t ht[64];                               /* per column: head/tail entries (low half), clipped ones (high half) */
+    int32_t  rowhi[64], rowlo[64];                 /* per column: 1 + the last row that starts there / the first row that
+                                                    * ends there: the lanes' row windows (KC2_DIAG) */
 };
 
 struct __attribute__((aligned(16))) KC2Lds {
@@ -317,7 +351,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
              * difference arrays over the tile's columns, not from the rows */
             int nq = 0;
             bool anylow = false;
-            W.cnt[0][lane] = 0; W.cnt[1][lane] = 0; W.ht[lane] = 0;
+            W.cnt[0][lane] = 0; W.cnt[1][lane] = 0; W.ht[lane] = 0; W.rowhi[lane] = 0; W.rowlo[lane] = KC2_R;
             if (lane < 4) { W.cnt[0][64 + lane] = 0; W.cnt[1][64 + lane] = 0; }
             WAVE_SYNC();
             while (wnext < hi) {
@@ -343,6 +377,10 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                     W.recs[slot][0] = r0; W.recs[slot][1] = r1;
                     int a = (int)r0.x - c0, b = (int)r0.y - c0;
                     a = a < 0 ? 0 : a; b = b > 64 ? 64 : b;
+#if KC2_DIAG
+                    atomicMax(&W.rowhi[a], slot + 1);                    /* (op starts are not sorted: a read's later ops) */
+                    atomicMin(&W.rowlo[b - 1], slot);
+#endif
                     atomicAdd(&W.cnt[0][a], 1); atomicAdd(&W.cnt[0][b], -1);
                     lowrec = (int)(r1.w & 255u) <= min_mqual;
                     if (lowrec) { atomicAdd(&W.cnt[1][a], 1); atomicAdd(&W.cnt[1][b], -1); }
@@ -369,15 +407,20 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
             WAVE_SYNC();
             KC2_STAMP(1);
             {   /* inclusive prefix sums of the difference arrays across the lanes */
-                int dn = W.cnt[0][lane], dl = anylow ? W.cnt[1][lane] : 0;
-                #pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int on = __shfl_up(dn, d), ol = anylow ? __shfl_up(dl, d) : 0;
-                    if (lane >= d) { dn += on; dl += ol; }
-                }
-                st.n_plp += dn; st.low_mq += dl;
+                st.n_plp += kc2_scan_add(W.cnt[0][lane]);
+                if (anylow) st.low_mq += kc2_scan_add(W.cnt[1][lane]);
                 htacc += W.ht[lane];
             }
+#if KC2_DIAG
+            /* lane c's rows: [rowL, rowL + rowD) = from the first row that ends beyond c to the last row that starts
+             * at or before c (a suffix minimum / a prefix maximum over the columns; the minimum runs over the
+             * mirrored lanes).  Rows in between that do not reach c hold class 7 there.  For reads of one length the
+             * window is exactly the column's depth. */
+            int rowL = __shfl(kc2_scan_min(W.rowlo[63 - lane]), 63 - lane), rowD = kc2_scan_max(W.rowhi[lane]);
+            rowD = rowD > rowL ? rowD - rowL : 0;
+            if (rowD == 0) rowL = 0;
+            const int maxd = READLANE(kc2_scan_max(rowD), 63);
+#endif
             for (int g0 = 0; g0 < nq; g0 += KC2_PR) {
             const int rows = nq - g0 < KC2_PR ? nq - g0 : KC2_PR, rows4 = (rows + 3) & ~3;
             /* ---- produce: 16 records per step, four lanes (16-column segments) each; two steps' loads in flight */
@@ -493,6 +536,93 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                 key = (unsigned)cand;
             }
             const unsigned k0 = key, k1 = key ^ 1u, k2 = key ^ 2u, k3 = key ^ 3u;
+#if KC2_DIAG
+            if (MQ) {
+                /* rows of reads with another mapq than the batch's dominant one: the entries' table row index becomes
+                 * 128 + adjusted quality (snp:632-641), one row per step with a lane per column (the lanes sit on
+                 * different rows in the steps below, so a row-uniform look-up has no place there); the call_preserve
+                 * input of the raw quality travels in bits 3-4 of the class byte */
+                unsigned long long nm = __ballot((ri & KC2_NONHOT) != 0u);
+                if (nm) {
+                    while (nm) {
+                        const int j = __builtin_ctzll(nm);
+                        nm &= nm - 1;
+                        const unsigned rinfo = READLANE(ri, j), slot = (rinfo >> 8) & 255u;
+                        const unsigned e = W.plane[j][lane], q = e >> 5;
+                        unsigned aq;
+                        if (slot < (unsigned)B.n_slots) { aq = sAdjC[slot * 128u + (q & 127u)]; KC2_PIN(aq); }
+                        else aq = T->adjc[(rinfo & 255u) * 256u + (q & 255u)];
+                        const unsigned pvb = ANYPRES ? (unsigned)sPv[q & 127u] << 3 : 0u;
+                        if ((e & 7u) != 7u) W.plane[j][lane] = (uint16_t)(((128u + aq) << 5) | pvb | (e & 7u));
+                    }
+                    WAVE_SYNC();
+                }
+            }
+            {   /* rows with a D/N op, an indel behind the op or no SEQ: the order-independent indel bookkeeping of
+                 * the whole row at once (their consensus entries are ordinary matrix entries) */
+                unsigned long long rm = __ballot((ri & KC2_RARE) != 0u);
+                while (rm) {
+                    const int j = __builtin_ctzll(rm);
+                    rm &= rm - 1;
+                    const uint4 r0 = W.recs[j][0], r1 = W.recs[j][1];
+                    const int rpos = (int)r0.x, rend = (int)r0.y, lq = UNIFORM((int)r1.x), qoff = (int)r1.y;
+                    const int indel_after = (int)r1.z;
+                    const unsigned info = UNIFORM(r1.w), ty = SR_TYPE(info);
+                    const bool isM = ty == SEG_M, isN = ty == SEG_N;
+                    const bool cov = inr & ((unsigned)(apos - rpos) < (unsigned)(rend - rpos));
+                    const int e_indel = (apos == rend - 1) ? indel_after : 0;
+                    const bool isind = (e_indel != 0) || !isM;
+                    const bool head = (info & SR_FIRST) && apos == rpos, tail = (info & SR_LAST) && apos == rend - 1;
+                    st.indel_cnt += (cov && isind) ? 1 : 0;                    /* snp:1664 */
+                    st.nref += (cov && isN) ? 1 : 0;                           /* snp:1468 */
+                    st.n_isindel += (cov && !isN && isind) ? 1 : 0;
+                    st.has_ins |= (cov && !isN && !head && !tail && e_indel > 0) ? 1 : 0;   /* snp:1708 */
+                    if (lq == 0) n_lq0 += cov ? 1 : 0;
+                    if (!(isN || lq == 0) && ANYPRES && cov && e_indel > 0) {  /* qualities of the inserted bases, snp:616-622 */
+                        const int64_t so = (int64_t)(((uint64_t)r0.w << 32) | r0.z);
+                        const int e_qpos = isM ? qoff + apos : qoff;
+                        for (int ins = 0; ins < e_indel; ins++) {
+                            const int qi = e_qpos + 1 + ins;
+                            if (qi < lq && T->pvc[B.quals[so + qi]]) st.cp |= 1u << 4;
+                        }
+                    }
+                }
+            }
+            /* every lane walks its own row window, all lanes in step: step t is row rowL + t of the lane's column */
+            const uint16_t *basep = &W.plane[0][0] + rowL * 64 + lane;
+            const int steps4 = (maxd + 3) & ~3;
+            unsigned vn[4];
+            #pragma unroll
+            for (int u = 0; u < 4; u++) vn[u] = (u < rowD) ? (unsigned)basep[u * 64] : 0xffu;
+#ifdef KC2_EXP_NOCONSUME
+            for (int j0 = 0; j0 < 4 && j0 < steps4; j0 += 4) {
+#else
+            for (int j0 = 0; j0 < steps4; j0 += 4) {
+#endif
+                unsigned ve[4];
+                double rMM[4], r_M[4], rom[4];
+                long long rpv[4];
+                #pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    ve[u] = vn[u];
+                    const double *rw = (const double *)(rowbase + (ve[u] & 0xffe0u));
+                    rMM[u] = rw[0]; r_M[u] = rw[1]; rom[u] = rw[2];
+                    if (ANYPRES) memcpy(&rpv[u], &rw[3], 8); else rpv[u] = 0;
+                }
+                if (j0 + 4 < steps4) {
+                    #pragma unroll
+                    for (int u = 0; u < 4; u++) vn[u] = (j0 + 4 + u < rowD) ? (unsigned)basep[(j0 + 4 + u) * 64] : 0xffu;
+                }
+                #pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    KC2_ROW(ve[u], rMM[u], r_M[u], rom[u]);
+                    if (ANYPRES) {                                        /* call_preserve bits, snp:611-623 */
+                        const unsigned pv = ((unsigned)rpv[u] | (ve[u] >> 3)) & 3u, cl = ve[u] & 7u;
+                        if (cl != 7u && pv) { st.cp |= 1u << cl; if (pv > 1u) st.cp |= (1u << cl) << 8; }
+                    }
+                }
+            }
+#else
             unsigned vn[4];
             #pragma unroll
             for (int u = 0; u < 4; u++) vn[u] = W.plane[u][lane];
@@ -576,6 +706,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                     }
                 }
             }
+#endif  /* KC2_DIAG */
             WAVE_SYNC();                                                 /* the next group / pass overwrites plane / recs */
             KC2_STAMP(3);
             }
