@@ -54,17 +54,16 @@
 #ifndef KC2_LDS_EXP
 #define KC2_LDS_EXP  1             /* cons_finalize's exp tables in LDS */
 #endif
-#ifndef KC2_DIAG
-#define KC2_DIAG     1             /* the consumer's lanes start at their own first row (see "consume" below) */
-#endif
-#if KC2_DIAG && KC2_PR != KC2_R
-#error "KC2_DIAG needs the whole pass in the matrix (KC2_PR == KC2_R)"
+#if KC2_PR != KC2_R
+#error "the consumer's row windows need the whole pass in the matrix (KC2_PR == KC2_R)"
 #endif
 #define KC2_RARE     0x10000u      /* row flags in rowinfo[]: bits 0-7 mapq, 8-15 slot */
 #define KC2_LOWMQ    0x20000u
 #define KC2_FULL     0x40000u      /* a match op spanning the whole tile: takes part in the key vote */
 #define KC2_NONHOT   0x80000u      /* mapq != the batch's dominant one (CONS_MQUAL only) */
 #define KC2_NROWTAB  (128 + 101)
+#define KC2_ROWMASK  0x1fe0u       /* matrix entry: bit 15 set | table row byte offset (bits 5-12) | class (bits 0-2; 7 = the
+                                    * record does not reach the column) | call_preserve input (bits 3-4, translated rows) */
 
 #ifdef CRUMBLE_EMU
 #define WAVE_SYNC() emu_wave_sync()
@@ -133,7 +132,7 @@ struct __attribute__((aligned(16))) KC2Wave {      /* one wave's LDS */
     int32_t  cnt[2][68];                           /* difference arrays over the tile's columns: all records / low-mapq records */
     uint32_t ht[64];                               /* per column: head/tail entries (low half), clipped ones (high half) */
     int32_t  rowhi[64], rowlo[64];                 /* per column: 1 + the last row that starts there / the first row that
-                                                    * ends there: the lanes' row windows (KC2_DIAG) */
+                                                    * ends there: the lanes' row windows */
 };
 
 struct __attribute__((aligned(16))) KC2Lds {
@@ -154,11 +153,11 @@ struct __attribute__((aligned(16))) KC2Lds {
            s33 = 0, s34 = 0, s44 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0; \
     int nN = 0
 
-/* the parked part of a mismatching entry x_ = 0x10000 | its matrix entry (table row byte offset | class), 0 = none */
+/* the parked part of a mismatching entry x_ = its matrix entry (bit 15 | table row byte offset | class), 0 = none */
 #define KC2_DRAIN_V(x_) do { \
     const unsigned pe_ = (x_); \
     if (pe_) { \
-        const double *rw_ = (const double *)(rowbase + (pe_ & 0xffe0u)); \
+        const double *rw_ = (const double *)(rowbase + (pe_ & KC2_ROWMASK)); \
         const double pMM = rw_[0], p_M = rw_[1], pom = rw_[2]; \
         const unsigned rc_ = pe_ & 7u; \
         const unsigned k_ = rc_ < 4u ? (rc_ ^ key) : rc_; \
@@ -169,7 +168,8 @@ struct __attribute__((aligned(16))) KC2Lds {
         if (k_ == 5u) { KC2_MASKED; nN++; s11 += pMM; s12 += pMM; s13 += pMM; s14 += p_M; s22 += pMM; s23 += pMM; s24 += p_M; \
                         s33 += pMM; s34 += p_M; } \
     } } while (0)
-#define KC2_DRAIN() do { KC2_DRAIN_V(pend); pend = 0; } while (0)
+/* a lane parks up to two entries: the older one in the high half (file order of the adds) */
+#define KC2_DRAIN() do { KC2_DRAIN_V(pend >> 16); KC2_DRAIN_V(pend & 0xffffu); pend = 0; } while (0)
 
 /* One row of the matrix for this lane's column: entry v_ (table row byte offset | class; class 7 = not reached),
  * the table row's MM_, _M_, om_.  The inline part of the entry (header) plus the pending-slot bookkeeping.
@@ -194,33 +194,15 @@ struct __attribute__((aligned(16))) KC2Lds {
     if (m0_ || m3_) { s03 += (_M_); } \
     if (mis_) { \
         const bool ml_ = cov_ && !m0_; \
-        if (__ballot(ml_ && pend != 0u)) KC2_DRAIN(); \
-        if (ml_) pend = 0x10000u | (v_); \
+        if (ml_) pend = (pend << 16) | (v_); \
+        if (__ballot(ml_ && pend > 0xffffu)) KC2_DRAIN(); \
     } } while (0)
-#elif defined(KC2_EXP_SELECT)
-/* experiment: no EXEC writes at all -- addends selected against +0.0 (exact: the sums are never -0.0) */
-#define KC2_ROW(v_, MM_, _M_, om_) do { \
-    const unsigned cls_ = (v_) & 7u; \
-    const bool cov_ = cls_ != 7u; \
-    const bool m0_ = cls_ == k0, m1_ = cls_ == k1, m2_ = cls_ == k2, m3_ = cls_ == k3; \
-    const bool ml_ = cov_ && !m0_; \
-    const unsigned long long mis_ = __ballot(ml_); \
-    if (__builtin_expect((mis_ & ~__ballot(m1_ || m2_ || m3_)) != 0ull, 0)) { \
-        if (cls_ == 4u) { KC2_MASKED; s04 += (_M_); } \
-        if (cls_ == 5u) { KC2_MASKED; s00 += (MM_); s01 += (MM_); s02 += (MM_); s03 += (MM_); s04 += (_M_); } \
-    } \
-    s00 += m0_ ? (MM_) : 0.0; d0 += m0_ ? (om_) : 0.0; s04 += m0_ ? (_M_) : 0.0; \
-    s01 += (m0_ || m1_) ? (_M_) : 0.0; s02 += (m0_ || m2_) ? (_M_) : 0.0; s03 += (m0_ || m3_) ? (_M_) : 0.0; \
-    if (__builtin_expect(__ballot(ml_ && pend != 0u) != 0ull, 0)) KC2_DRAIN(); \
-    pend = ml_ ? (0x10000u | (v_)) : pend; \
-    } while (0)
 #else
 #define KC2_ROW(v_, MM_, _M_, om_) do { \
     unsigned long long mis_, odd_, coll_, rare_, m0_, m1_, m2_, m3_, t_, sv_; \
-    unsigned cls_, old_; \
+    unsigned cls_; \
     asm volatile( \
         "v_and_b32_e32 %[cls], 7, %[v]\n\t" \
-        "v_mov_b32_e32 %[old], %[pend]\n\t" \
         "v_cmp_eq_u32_e64 %[m0], %[cls], %[k0]\n\t" \
         "v_cmp_eq_u32_e64 %[m1], %[cls], %[k1]\n\t" \
         "v_cmp_eq_u32_e64 %[m2], %[cls], %[k2]\n\t" \
@@ -242,26 +224,23 @@ struct __attribute__((aligned(16))) KC2Lds {
         "s_or_b64 exec, %[m0], %[m3]\n\t" \
         "v_add_f64 %[s03], %[s03], %[_M]\n\t" \
         "s_mov_b64 exec, %[mis]\n\t" \
-        "v_cmp_ne_u32_e64 %[coll], 0, %[pend]\n\t"      /* a mismatching lane whose slot is taken */ \
-        "v_or_b32_e32 %[pend], 0x10000, %[v]\n\t"       /* park this entry (the old one is in old_) */ \
+        "v_lshl_or_b32 %[pend], %[pend], 16, %[v]\n\t"          /* park this entry behind the lane's older one */ \
+        "v_cmp_lt_u32_e64 %[coll], %[ffff], %[pend]\n\t"        /* a lane with two parked entries: drain */ \
         "s_or_b64 %[rare], %[odd], %[coll]\n\t" \
         "s_mov_b64 exec, %[sv]" \
-        : [cls] "=&v"(cls_), [old] "=&v"(old_), [m0] "=&s"(m0_), [m1] "=&s"(m1_), [m2] "=&s"(m2_), [m3] "=&s"(m3_), \
+        : [cls] "=&v"(cls_), [m0] "=&s"(m0_), [m1] "=&s"(m1_), [m2] "=&s"(m2_), [m3] "=&s"(m3_), \
           [t] "=&s"(t_), [sv] "=&s"(sv_), [mis] "=&s"(mis_), [odd] "=&s"(odd_), [coll] "=&s"(coll_), [rare] "=&s"(rare_), \
           [s00] "+v"(s00), [s01] "+v"(s01), [s02] "+v"(s02), [s03] "+v"(s03), [s04] "+v"(s04), [d0] "+v"(d0), \
           [pend] "+v"(pend) \
-        : [v] "v"(v_), [k0] "v"(k0), [k1] "v"(k1), [k2] "v"(k2), [k3] "v"(k3), [MM] "v"(MM_), [_M] "v"(_M_), [om] "v"(om_) \
+        : [v] "v"(v_), [k0] "v"(k0), [k1] "v"(k1), [k2] "v"(k2), [k3] "v"(k3), [MM] "v"(MM_), [_M] "v"(_M_), [om] "v"(om_), \
+          [ffff] "s"(0xffffu) \
         : "scc"); \
     if (__builtin_expect(rare_ != 0ull, 0)) { \
         if (odd_ != 0ull) {                               /* a '*' or an N somewhere in the row */ \
             if (cls_ == 4u) { KC2_MASKED; s04 += (_M_); } \
             if (cls_ == 5u) { KC2_MASKED; s00 += (MM_); s01 += (MM_); s02 += (MM_); s03 += (MM_); s04 += (_M_); } \
         } \
-        if (coll_ != 0ull) {                              /* drain what was parked BEFORE this row, keep this row's entries */ \
-            const bool ml_ = cls_ != 7u && cls_ != k0; \
-            KC2_DRAIN_V(ml_ ? old_ : pend); \
-            pend = ml_ ? pend : 0u; \
-        } \
+        if (coll_ != 0ull) KC2_DRAIN(); \
     } } while (0)
 #endif
 
@@ -315,6 +294,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
     const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;     /* lanes below this one */
 #ifdef KC2_EXP_STAMP
     long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = (long long)__builtin_amdgcn_s_memtime();
+    long long npass = 0, nstep = 0;
 #endif
 
     for (;;) {
@@ -377,10 +357,8 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                     W.recs[slot][0] = r0; W.recs[slot][1] = r1;
                     int a = (int)r0.x - c0, b = (int)r0.y - c0;
                     a = a < 0 ? 0 : a; b = b > 64 ? 64 : b;
-#if KC2_DIAG
                     atomicMax(&W.rowhi[a], slot + 1);                    /* (op starts are not sorted: a read's later ops) */
                     atomicMin(&W.rowlo[b - 1], slot);
-#endif
                     atomicAdd(&W.cnt[0][a], 1); atomicAdd(&W.cnt[0][b], -1);
                     lowrec = (int)(r1.w & 255u) <= min_mqual;
                     if (lowrec) { atomicAdd(&W.cnt[1][a], 1); atomicAdd(&W.cnt[1][b], -1); }
@@ -411,7 +389,6 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                 if (anylow) st.low_mq += kc2_scan_add(W.cnt[1][lane]);
                 htacc += W.ht[lane];
             }
-#if KC2_DIAG
             /* lane c's rows: [rowL, rowL + rowD) = from the first row that ends beyond c to the last row that starts
              * at or before c (a suffix minimum / a prefix maximum over the columns; the minimum runs over the
              * mirrored lanes).  Rows in between that do not reach c hold class 7 there.  For reads of one length the
@@ -420,7 +397,6 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
             rowD = rowD > rowL ? rowD - rowL : 0;
             if (rowD == 0) rowL = 0;
             const int maxd = READLANE(kc2_scan_max(rowD), 63);
-#endif
             for (int g0 = 0; g0 < nq; g0 += KC2_PR) {
             const int rows = nq - g0 < KC2_PR ? nq - g0 : KC2_PR, rows4 = (rows + 3) & ~3;
             /* ---- produce: 16 records per step, four lanes (16-column segments) each; two steps' loads in flight */
@@ -489,8 +465,9 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                                 /* bytes of the columns the record does not reach -> 0xff (class 7) */
                                 const uint32_t notM = ((((nvb >> (4 * t)) & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;
                                 const uint32_t cm = cw[t] | notM;
-                                out[2 * t]     = (kc2_perm(0u, qw[t], 0x0c010c00u) << 5) | kc2_perm(0u, cm, 0x0c010c00u);
-                                out[2 * t + 1] = (kc2_perm(0u, qw[t], 0x0c030c02u) << 5) | kc2_perm(0u, cm, 0x0c030c02u);
+                                /* (the 0x04 bytes become bit 15 of the entries: a parked entry is never zero) */
+                                out[2 * t]     = (kc2_perm(0x04040404u, qw[t], 0x04010400u) << 5) | kc2_perm(0u, cm, 0x0c010c00u);
+                                out[2 * t + 1] = (kc2_perm(0x04040404u, qw[t], 0x04030402u) << 5) | kc2_perm(0u, cm, 0x0c030c02u);
                             }
                         }
                         uint4 *dst = (uint4 *)&W.plane[row][16 * seg];
@@ -515,7 +492,6 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
 
             /* ---- consume */
             const unsigned ri = lane < rows ? W.rowinfo[lane] : 0u;
-            const unsigned long long slowmask = __ballot((ri & (KC2_RARE | KC2_NONHOT)) != 0u);
             if (first) {
                 /* class 0 of each column: Boyer-Moore majority over a few rows, preferably rows that span the tile
                  * (ANY key gives the same sums; a minority key only sends the column's entries through the
@@ -536,7 +512,6 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                 key = (unsigned)cand;
             }
             const unsigned k0 = key, k1 = key ^ 1u, k2 = key ^ 2u, k3 = key ^ 3u;
-#if KC2_DIAG
             if (MQ) {
                 /* rows of reads with another mapq than the batch's dominant one: the entries' table row index becomes
                  * 128 + adjusted quality (snp:632-641), one row per step with a lane per column (the lanes sit on
@@ -548,12 +523,12 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                         const int j = __builtin_ctzll(nm);
                         nm &= nm - 1;
                         const unsigned rinfo = READLANE(ri, j), slot = (rinfo >> 8) & 255u;
-                        const unsigned e = W.plane[j][lane], q = e >> 5;
+                        const unsigned e = W.plane[j][lane], q = (e >> 5) & 255u;
                         unsigned aq;
                         if (slot < (unsigned)B.n_slots) { aq = sAdjC[slot * 128u + (q & 127u)]; KC2_PIN(aq); }
                         else aq = T->adjc[(rinfo & 255u) * 256u + (q & 255u)];
                         const unsigned pvb = ANYPRES ? (unsigned)sPv[q & 127u] << 3 : 0u;
-                        if ((e & 7u) != 7u) W.plane[j][lane] = (uint16_t)(((128u + aq) << 5) | pvb | (e & 7u));
+                        if ((e & 7u) != 7u) W.plane[j][lane] = (uint16_t)(0x8000u | ((128u + aq) << 5) | pvb | (e & 7u));
                     }
                     WAVE_SYNC();
                 }
@@ -589,11 +564,16 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                 }
             }
             /* every lane walks its own row window, all lanes in step: step t is row rowL + t of the lane's column */
-            const uint16_t *basep = &W.plane[0][0] + rowL * 64 + lane;
             const int steps4 = (maxd + 3) & ~3;
+            /* all lanes take steps4 rows; a window that would run past the padded matrix starts earlier instead
+             * (rows before it ended before the column, rows behind it start after it: class 7 either way) */
+            const uint16_t *basep = &W.plane[0][0] + (rowL < rows4 - steps4 ? rowL : rows4 - steps4) * 64 + lane;
+#ifdef KC2_EXP_STAMP
+            npass++; nstep += steps4;
+#endif
             unsigned vn[4];
             #pragma unroll
-            for (int u = 0; u < 4; u++) vn[u] = (u < rowD) ? (unsigned)basep[u * 64] : 0xffu;
+            for (int u = 0; u < 4; u++) vn[u] = basep[u * 64];
 #ifdef KC2_EXP_NOCONSUME
             for (int j0 = 0; j0 < 4 && j0 < steps4; j0 += 4) {
 #else
@@ -605,13 +585,13 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     ve[u] = vn[u];
-                    const double *rw = (const double *)(rowbase + (ve[u] & 0xffe0u));
+                    const double *rw = (const double *)(rowbase + (ve[u] & KC2_ROWMASK));
                     rMM[u] = rw[0]; r_M[u] = rw[1]; rom[u] = rw[2];
                     if (ANYPRES) memcpy(&rpv[u], &rw[3], 8); else rpv[u] = 0;
                 }
                 if (j0 + 4 < steps4) {
                     #pragma unroll
-                    for (int u = 0; u < 4; u++) vn[u] = (j0 + 4 + u < rowD) ? (unsigned)basep[(j0 + 4 + u) * 64] : 0xffu;
+                    for (int u = 0; u < 4; u++) vn[u] = basep[(j0 + 4 + u) * 64];
                 }
                 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -622,91 +602,6 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                     }
                 }
             }
-#else
-            unsigned vn[4];
-            #pragma unroll
-            for (int u = 0; u < 4; u++) vn[u] = W.plane[u][lane];
-#ifdef KC2_EXP_NOCONSUME
-            for (int j0 = 0; j0 < 4; j0 += 4) {
-#else
-            for (int j0 = 0; j0 < rows4; j0 += 4) {
-#endif
-                /* the four entries were read a group ahead; their table rows and the next group's entries go out
-                 * together, before any of this group's arithmetic */
-                unsigned ve[4];
-                double rMM[4], r_M[4], rom[4];
-                long long rpv[4];
-                #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    ve[u] = vn[u];
-                    const double *rw = (const double *)(rowbase + (ve[u] & 0xffe0u));
-                    rMM[u] = rw[0]; r_M[u] = rw[1]; rom[u] = rw[2];
-                    if (ANYPRES) memcpy(&rpv[u], &rw[3], 8); else rpv[u] = 0;
-                }
-                if (j0 + 4 < rows4) {
-                    #pragma unroll
-                    for (int u = 0; u < 4; u++) vn[u] = W.plane[j0 + 4 + u][lane];
-                }
-                const unsigned slow4 = (unsigned)(slowmask >> j0) & 15u;
-#ifdef KC2_EXP_STAMP
-                KC2_STAMP(3);                                            /* issue of the group's LDS reads */
-                __builtin_amdgcn_s_waitcnt(0xc07f);                      /* lgkmcnt(0) */
-                KC2_STAMP(5);                                            /* waiting for them */
-#endif
-                if (__builtin_expect(slow4 != 0u, 0)) {                  /* (uniform) rows that need a look-up first */
-                    #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (!((slow4 >> u) & 1u)) continue;
-                        const unsigned rinfo = UNIFORM(W.rowinfo[j0 + u]);
-                        if (MQ && (rinfo & KC2_NONHOT)) {                 /* another mapq: the adjustment, then the row (snp:632-641) */
-                            const unsigned q = ve[u] >> 5, slot = (rinfo >> 8) & 255u;
-                            unsigned aq;
-                            /* two real branches (hipcc would merge them into one flat load through a pointer
-                             * select: a flat load waits out the global-memory latency) */
-                            if (slot < (unsigned)B.n_slots) { aq = sAdjC[slot * 128u + (q & 127u)]; KC2_PIN(aq); }
-                            else aq = T->adjc[(rinfo & 255u) * 256u + (q & 255u)];
-                            if (ANYPRES) rpv[u] = sPv[q & 127u];
-                            ve[u] = ((128u + aq) << 5) | (ve[u] & 7u);
-                            const double *rw = (const double *)(rowbase + (ve[u] & 0xffe0u));
-                            rMM[u] = rw[0]; r_M[u] = rw[1]; rom[u] = rw[2];
-                        }
-                        if (rinfo & KC2_RARE) {                           /* back to the record */
-                            const uint4 r0 = W.recs[g0 + j0 + u][0], r1 = W.recs[g0 + j0 + u][1];
-                            const int rpos = (int)r0.x, rend = (int)r0.y, lq = UNIFORM((int)r1.x), qoff = (int)r1.y;
-                            const int indel_after = (int)r1.z;
-                            const unsigned info = UNIFORM(r1.w), ty = SR_TYPE(info);
-                            const bool isM = ty == SEG_M, isN = ty == SEG_N;
-                            const bool cov = inr & ((unsigned)(apos - rpos) < (unsigned)(rend - rpos));
-                            const int e_indel = (apos == rend - 1) ? indel_after : 0;
-                            const bool isind = (e_indel != 0) || !isM;
-                            const bool head = (info & SR_FIRST) && apos == rpos, tail = (info & SR_LAST) && apos == rend - 1;
-                            st.indel_cnt += (cov && isind) ? 1 : 0;                    /* snp:1664 */
-                            st.nref += (cov && isN) ? 1 : 0;                           /* snp:1468 */
-                            st.n_isindel += (cov && !isN && isind) ? 1 : 0;
-                            st.has_ins |= (cov && !isN && !head && !tail && e_indel > 0) ? 1 : 0;   /* snp:1708 */
-                            if (lq == 0) n_lq0 += cov ? 1 : 0;
-                            /* no consensus entry (snp:589,594): the producer left the row empty (class 7 everywhere) */
-                            if (!(isN || lq == 0) && ANYPRES && cov && e_indel > 0) {   /* qualities of the inserted bases, snp:616-622 */
-                                const int64_t so = (int64_t)(((uint64_t)r0.w << 32) | r0.z);
-                                const int e_qpos = isM ? qoff + apos : qoff;
-                                for (int ins = 0; ins < e_indel; ins++) {
-                                    const int qi = e_qpos + 1 + ins;
-                                    if (qi < lq && T->pvc[B.quals[so + qi]]) st.cp |= 1u << 4;
-                                }
-                            }
-                        }
-                    }
-                }
-                #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    KC2_ROW(ve[u], rMM[u], r_M[u], rom[u]);
-                    if (ANYPRES) {                                        /* call_preserve bits, snp:611-623 */
-                        const unsigned pv = (unsigned)rpv[u] & 3u, cl = ve[u] & 7u;
-                        if (cl != 7u && pv) { st.cp |= 1u << cl; if (pv > 1u) st.cp |= (1u << cl) << 8; }
-                    }
-                }
-            }
-#endif  /* KC2_DIAG */
             WAVE_SYNC();                                                 /* the next group / pass overwrites plane / recs */
             KC2_STAMP(3);
             }
@@ -734,9 +629,11 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
     }
 #ifdef KC2_EXP_STAMP
     if (lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&stats[24 + k], (u64)tacc[k]);
+    if (lane == 0) { atomicAdd(&stats[30], (u64)npass); atomicAdd(&stats[31], (u64)nstep); }
 #endif
     __syncthreads();
     if (threadIdx.x < 32 && sStat[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (u64)sStat[threadIdx.x]);
 }
+
 
 #endif /* CRUMBLE_KCOL2_H */

@@ -9,3 +9,4 @@ s = e.stats_read()
 kt = dict((n, ms) for n, ms, _ in e.kernel_times())
 t = s[24:30].astype(float)
 print("k_columns2 ms", kt.get("k_columns2"), "stamps (share): unit-grab %.3f stage %.3f produce %.3f consume(rows+issue) %.3f decide %.3f consume(LDS wait) %.3f" % tuple(t / t.sum()), "total wave-cycles %.3g" % t.sum())
+print("passes %d row-steps %d (%.1f per pass); lane-steps / bases = %.2f; wave-cycles per step in consume %.0f" % (s[30], s[31], s[31] / max(1, s[30]), s[31] * 64 / hb.n_bases, (t[3] + t[5]) / max(1, s[31])))
