@@ -465,13 +465,14 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
             if ((e = h->d_tcum.reserve((size_t)(B.n_tiles + 2) * 8)) || (e = h->d_tpart.reserve((size_t)(tch + 2) * 8))) return e;
             int64_t *cum = h->d_tcum.as<int64_t>(), *tp = h->d_tpart.as<int64_t>();
             CRUMBLE_LAUNCH_INDEP(k_tile_cost, nblk(B.n_tiles, 256), 256, st, B.n_tiles, h->d_stile_lo.as<int32_t>(),
-                                 h->d_stile_hi.as<int32_t>(), (tot.nseg > n + n / 2) ? 1 : 0, cum);
+                                 h->d_stile_hi.as<int32_t>(), h->d_sr.as<SegRec>(), (tot.nseg > n + n / 2) ? 1 : 0, cum);
             CRUMBLE_LAUNCH_INDEP(k_i64scan_reduce, nblk(tch, 64), 64, st, (int64_t)B.n_tiles, cum, tp, tch);
             CRUMBLE_LAUNCH(k_i64scan_partials, 1, 1024, st, tp, tch);
             CRUMBLE_LAUNCH_INDEP(k_i64scan_apply, nblk(tch, 64), 64, st, (int64_t)B.n_tiles, cum, tp, tch);
             int64_t total = 0;                              /* (one small read-back: sizes the unit table) */
             HIPCHK(hipMemcpyAsync(&total, cum + B.n_tiles, 8, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
+            if (total >= TILE_COST_SPAN) { g_last_error = "the reads over one 64-column tile span more than 3.7 GB of bases"; return CRUMBLE_EINVAL; }
             if (total >= (int64_t)INT_MAX * (KCOL_UNIT / 2)) { g_last_error = "tile cost overflow"; return CRUMBLE_EINVAL; }
             B.n_units = (int32_t)((total + KCOL_UNIT - 1) / KCOL_UNIT);
             if ((e = h->d_ufirst.reserve((size_t)(B.n_units + 2) * 4))) return e;

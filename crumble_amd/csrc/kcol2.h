@@ -62,8 +62,10 @@
 #define KC2_FULL     0x40000u      /* a match op spanning the whole tile: takes part in the key vote */
 #define KC2_NONHOT   0x80000u      /* mapq != the batch's dominant one (CONS_MQUAL only) */
 #define KC2_NROWTAB  (128 + 101)
-#define KC2_ROWMASK  0x1fe0u       /* matrix entry: bit 15 set | table row byte offset (bits 5-12) | class (bits 0-2; 7 = the
-                                    * record does not reach the column) | call_preserve input (bits 3-4, translated rows) */
+#define KC2_ROWMASK  0x1fe0u       /* matrix entry: table row byte offset (bits 5-12) | class (bits 1-3; 7 = the record does
+                                    * not reach the column) | bit 0 set (never zero) | call_preserve input of a translated
+                                    * row (bits 13-14) */
+#define KC2_CLS(v_)  (((v_) >> 1) & 7u)
 
 #ifdef CRUMBLE_EMU
 #define WAVE_SYNC() emu_wave_sync()
@@ -82,6 +84,7 @@ __device__ __forceinline__ uint32_t kc2_perm(uint32_t s0, uint32_t s1, uint32_t 
 }
 #define KC2_MASKED
 #define KC2_PIN(x)
+#define KC2_UNDEF(x) ((x) = 0)
 /* inclusive scans across the wave's lanes */
 #define KC2_EMU_SCAN(name, OP) \
 __device__ __forceinline__ int name(int v) \
@@ -102,6 +105,7 @@ __device__ __forceinline__ uint32_t kc2_perm(uint32_t s0, uint32_t s1, uint32_t 
  * in the block keeps it an exec-masked block (one s_and_saveexec for several adds, skipped when no lane is in it) */
 #define KC2_MASKED asm volatile("")
 #define KC2_PIN(x) asm volatile("" : "+v"(x))      /* the value exists HERE (a load above it cannot sink past the block) */
+#define KC2_UNDEF(x) asm volatile("" : "=v"(x))    /* any value (no instruction): lanes that load nothing compute on it, masked out later */
 /* inclusive scans across the wave's lanes in six DPP steps (row_shr 1/2/4/8 inside the rows of 16, then row_bcast:15
  * into rows 1 and 3 and row_bcast:31 into rows 2 and 3): VALU only, where __shfl_up is a chain of ds_bpermute
  * round trips.  Lanes a step has no source for take the operation's identity. */
@@ -141,6 +145,7 @@ struct __attribute__((aligned(16))) KC2Lds {
     unsigned stat[32];
     uint8_t  adjc[KC2_SLOTS * 128];
     uint8_t  pv[128];
+    uint4    mask_lt[17], mask_ge[17];             /* producer: byte k of [a] = 0x08 | (k < a ? 0x70 : 0); of [b] = (k >= b ? 0x70 : 0) */
     KC2Wave  wave[KC2_WAVES];
 };
 
@@ -159,7 +164,7 @@ struct __attribute__((aligned(16))) KC2Lds {
     if (pe_) { \
         const double *rw_ = (const double *)(rowbase + (pe_ & KC2_ROWMASK)); \
         const double pMM = rw_[0], p_M = rw_[1], pom = rw_[2]; \
-        const unsigned rc_ = pe_ & 7u; \
+        const unsigned rc_ = KC2_CLS(pe_); \
         const unsigned k_ = rc_ < 4u ? (rc_ ^ key) : rc_; \
         if (k_ == 1u) { KC2_MASKED; d1 += pom; s11 += pMM; s12 += p_M; s13 += p_M; s14 += p_M; } \
         if (k_ == 2u) { KC2_MASKED; d2 += pom; s12 += p_M; s22 += pMM; s23 += p_M; s24 += p_M; } \
@@ -179,7 +184,7 @@ struct __attribute__((aligned(16))) KC2Lds {
  * restores it; every mask is a wave-uniform SGPR pair. */
 #ifdef CRUMBLE_EMU
 #define KC2_ROW(v_, MM_, _M_, om_) do { \
-    const unsigned cls_ = (v_) & 7u; \
+    const unsigned cls_ = KC2_CLS(v_); \
     const bool cov_ = cls_ != 7u; \
     const bool m0_ = cls_ == k0, m1_ = cls_ == k1, m2_ = cls_ == k2, m3_ = cls_ == k3; \
     const unsigned long long B0_ = __ballot(m0_), B123_ = __ballot(m1_ || m2_ || m3_), Bc_ = __ballot(cov_); \
@@ -202,7 +207,7 @@ struct __attribute__((aligned(16))) KC2Lds {
     unsigned long long mis_, odd_, coll_, rare_, m0_, m1_, m2_, m3_, t_, sv_; \
     unsigned cls_; \
     asm volatile( \
-        "v_and_b32_e32 %[cls], 7, %[v]\n\t" \
+        "v_bfe_u32 %[cls], %[v], 1, 3\n\t" \
         "v_cmp_eq_u32_e64 %[m0], %[cls], %[k0]\n\t" \
         "v_cmp_eq_u32_e64 %[m1], %[cls], %[k1]\n\t" \
         "v_cmp_eq_u32_e64 %[m2], %[cls], %[k2]\n\t" \
@@ -282,6 +287,11 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
         for (int i = threadIdx.x; i < B.n_slots * 128; i += blockDim.x)
             sAdjC[i] = T->adjc[(int)B.slot_mq[i >> 7] * 256 + (i & 127)];
     if (threadIdx.x < 128) sPv[threadIdx.x] = T->pvc[threadIdx.x];
+    if (threadIdx.x < 17 * 16) {
+        const int x = threadIdx.x >> 4, k = threadIdx.x & 15;
+        ((uint8_t *)L.mask_lt)[threadIdx.x] = (uint8_t)(0x08 | (k < x ? 0x70 : 0));
+        ((uint8_t *)L.mask_ge)[threadIdx.x] = (uint8_t)(k >= x ? 0x70 : 0);
+    }
     if (KC2_LDS_EXP)
         for (int i = threadIdx.x; i < CONS_NEXP; i += blockDim.x) sE[i] = i <= 500 ? T->e_tab2[i] : T->e_tab[i - 501];
     __syncthreads();
@@ -361,6 +371,13 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                     atomicMin(&W.rowlo[b - 1], slot);
                     atomicAdd(&W.cnt[0][a], 1); atomicAdd(&W.cnt[0][b], -1);
                     lowrec = (int)(r1.w & 255u) <= min_mqual;
+                    {   /* the row's flags for the consumer */
+                        const unsigned info = r1.w, ty = SR_TYPE(info);
+                        const bool rare = ty != SEG_M || r1.z != 0u || r1.x == 0u;          /* D/N op, indel behind it, no SEQ */
+                        const bool full = ty == SEG_M && (int)r1.x > 0 && (int)r0.x <= c0 && (int)r0.y > c1;
+                        W.rowinfo[slot] = (info & 0xffu) | ((info >> 8) & 0xff00u) | (rare ? KC2_RARE : 0u) |
+                                          (full ? KC2_FULL : 0u) | ((MQ && (int)(info & 255u) != hot_mq) ? KC2_NONHOT : 0u);
+                    }
                     if (lowrec) { atomicAdd(&W.cnt[1][a], 1); atomicAdd(&W.cnt[1][b], -1); }
                     /* is_head / is_tail bookkeeping (snp:1701-1706): two columns per read; a ref-skip entry is not
                      * counted (snp:1696); head and tail on one column count once */
@@ -399,94 +416,87 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
             const int maxd = READLANE(kc2_scan_max(rowD), 63);
             for (int g0 = 0; g0 < nq; g0 += KC2_PR) {
             const int rows = nq - g0 < KC2_PR ? nq - g0 : KC2_PR, rows4 = (rows + 3) & ~3;
-            /* ---- produce: 16 records per step, four lanes (16-column segments) each; two steps' loads in flight */
+            /* ---- produce: 16 records per step, four lanes (16-column segments) each; two steps' loads in flight.
+             * Straight-line code over all lanes: a lane without a record or whose record does not reach its segment
+             * takes the all-invalid byte mask and writes sixteen class-7 entries (that also pads the matrix to a
+             * multiple of four rows); only the loads are under EXEC.  Addresses are 32-bit offsets from the pass's
+             * first read (uniform base; the upload refuses batches where a tile's reads span 4 GB of bases). */
+            const uint2 sof = *(const uint2 *)&W.recs[g0][0].z;
+            const uint32_t so_lo = (uint32_t)UNIFORM(sof.x);
+            const uint64_t so_first = ((uint64_t)(uint32_t)UNIFORM(sof.y) << 32) | so_lo;
+            const uint8_t *const pbase = B.bases + so_first - BASE_FRONT_PAD, *const qbase = B.quals + so_first - BASE_FRONT_PAD;
+            const unsigned phase = (unsigned)(uintptr_t)pbase & 3u;          /* bases and quals share the byte phase */
             for (int s0 = 0; s0 < rows; s0 += 32) {
+                const int ne = rows - s0 > 16 ? 2 : 1;
                 uint32_t bwr[2][5], qwr[2][5];
-                unsigned shb[2], vbm[2], clD[2], info2[2];
-                bool act[2], isMv[2];
+                unsigned shb[2], clD[2];
+                uint4 mkA[2], mkB[2];
+                bool isD[2];
                 #pragma unroll
                 for (int e = 0; e < 2; e++) {
+                    if (e >= ne) continue;
                     const int row = s0 + 16 * e + rsub;
-                    act[e] = false; isMv[e] = true; shb[e] = 0; vbm[e] = 0; clD[e] = 0; info2[e] = 0;
+                    const bool rv = row < rows;
+                    const uint4 r0 = W.recs[g0 + (rv ? row : 0)][0], r1 = W.recs[g0 + (rv ? row : 0)][1];
+                    const int rpos = (int)r0.x, rend = (int)r0.y, lq = (int)r1.x, qoff = (int)r1.y;
+                    const unsigned ty = SR_TYPE(r1.w);
+                    const int sc0 = c0 + 16 * seg;                           /* first column of the segment */
+                    int a = rpos - sc0, b = rend - sc0;                      /* columns [a, b) of it are reached */
+                    a = a < 0 ? 0 : a; b = b > 16 ? 16 : b;
+                    const bool act = rv && ty != SEG_N && lq > 0 && a < b;   /* snp:589,594 */
+                    const uint32_t rel = r0.z - so_lo + (uint32_t)BASE_FRONT_PAD;
+                    mkA[e] = L.mask_lt[act ? a : 16]; mkB[e] = L.mask_ge[act ? b : 16];
+                    isD[e] = false;
                     #pragma unroll
-                    for (int t = 0; t < 5; t++) { bwr[e][t] = 0; qwr[e][t] = 0; }
-                    if (row < rows) {
-                        const uint4 r0 = W.recs[g0 + row][0], r1 = W.recs[g0 + row][1];
-                        const int rpos = (int)r0.x, rend = (int)r0.y, lq = (int)r1.x, qoff = (int)r1.y;
-                        const int64_t so = (int64_t)(((uint64_t)r0.w << 32) | r0.z);
-                        const unsigned info = r1.w, ty = SR_TYPE(info);
-                        const int sc0 = c0 + 16 * seg;                       /* first column of the segment */
-                        int a = rpos - sc0, b = rend - sc0;                  /* columns [a, b) of it are reached */
-                        a = a < 0 ? 0 : a; b = b > 16 ? 16 : b;
-                        const bool cons = ty != SEG_N && lq > 0;             /* snp:589,594 */
-                        info2[e] = (info & 0x1fffffffu) | ((unsigned)(r1.z != 0) << 30) | ((unsigned)(lq == 0) << 31) |
-                                   ((unsigned)(ty == SEG_M && cons && rpos <= c0 && rend > c1) << 29);
-                        if (cons && a < b) {
-                            act[e] = true;
-                            vbm[e] = ((1u << b) - 1u) & ~((1u << a) - 1u);
-                            if (ty == SEG_M) {
-                                const int64_t A = so + (int64_t)qoff + (int64_t)sc0;   /* qpos = qoff + apos */
-                                const uint8_t *pb = B.bases + A;
-                                shb[e] = (unsigned)((uintptr_t)pb & 3u);         /* bases and quals share the byte phase */
-                                const uint8_t *pba = pb - shb[e], *pqa = B.quals + A - shb[e];
-                                const KC2U4 vb4 = *(const KC2U4 *)pba, vq4 = *(const KC2U4 *)pqa;
-                                bwr[e][0] = vb4.x; bwr[e][1] = vb4.y; bwr[e][2] = vb4.z; bwr[e][3] = vb4.w;
-                                qwr[e][0] = vq4.x; qwr[e][1] = vq4.y; qwr[e][2] = vq4.z; qwr[e][3] = vq4.w;
-                                bwr[e][4] = *(const uint32_t *)(pba + 16); qwr[e][4] = *(const uint32_t *)(pqa + 16);
-                            } else {                                     /* D: '*' with the quality of the next base; fence: read ends in D */
-                                isMv[e] = false;
-                                clD[e] = qoff < lq ? (unsigned)B.quals[so + qoff] : 0u;
-                            }
+                    for (int t = 0; t < 5; t++) { KC2_UNDEF(bwr[e][t]); KC2_UNDEF(qwr[e][t]); }
+                    KC2_UNDEF(shb[e]); KC2_UNDEF(clD[e]);
+                    if (act) {
+                        if (ty == SEG_M) {
+                            const uint32_t vo = rel + (uint32_t)(qoff + sc0);    /* qpos = qoff + apos */
+                            shb[e] = (vo + phase) & 3u;
+                            const uint32_t va = vo - shb[e];
+                            const KC2U4 vb4 = *(const KC2U4 *)(pbase + va), vq4 = *(const KC2U4 *)(qbase + va);
+                            bwr[e][0] = vb4.x; bwr[e][1] = vb4.y; bwr[e][2] = vb4.z; bwr[e][3] = vb4.w;
+                            qwr[e][0] = vq4.x; qwr[e][1] = vq4.y; qwr[e][2] = vq4.z; qwr[e][3] = vq4.w;
+                            bwr[e][4] = *(const uint32_t *)(pbase + va + 16); qwr[e][4] = *(const uint32_t *)(qbase + va + 16);
+                        } else {                                             /* D: '*' with the quality of the next base; fence: read ends in D */
+                            isD[e] = true;
+                            clD[e] = qoff < lq ? (unsigned)qbase[rel + (uint32_t)qoff] : 0u;
                         }
                     }
                 }
                 #pragma unroll
                 for (int e = 0; e < 2; e++) {
+                    if (e >= ne) continue;
                     const int row = s0 + 16 * e + rsub;
-                    if (row < rows) {
-                        uint32_t out[8];
-                        #pragma unroll
-                        for (int t = 0; t < 8; t++) out[t] = 0x00ff00ffu;    /* class 7: not reached */
-                        if (act[e]) {
-                            uint32_t cw[4], qw[4];
-                            if (isMv[e]) {
-                                #pragma unroll
-                                for (int t = 0; t < 4; t++) {
-                                    cw[t] = (kc2_alignbyte(bwr[e][t + 1], bwr[e][t], shb[e]) >> 4) & 0x07070707u;
-                                    qw[t] = kc2_alignbyte(qwr[e][t + 1], qwr[e][t], shb[e]);
-                                }
-                            } else {
-                                #pragma unroll
-                                for (int t = 0; t < 4; t++) { qw[t] = clD[e] * 0x01010101u; cw[t] = 0x04040404u; }
-                            }
-                            const unsigned nvb = ~vbm[e];
-                            #pragma unroll
-                            for (int t = 0; t < 4; t++) {
-                                /* bytes of the columns the record does not reach -> 0xff (class 7) */
-                                const uint32_t notM = ((((nvb >> (4 * t)) & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;
-                                const uint32_t cm = cw[t] | notM;
-                                /* (the 0x04 bytes become bit 15 of the entries: a parked entry is never zero) */
-                                out[2 * t]     = (kc2_perm(0x04040404u, qw[t], 0x04010400u) << 5) | kc2_perm(0u, cm, 0x0c010c00u);
-                                out[2 * t + 1] = (kc2_perm(0x04040404u, qw[t], 0x04030402u) << 5) | kc2_perm(0u, cm, 0x0c030c02u);
-                            }
-                        }
-                        uint4 *dst = (uint4 *)&W.plane[row][16 * seg];
-                        uint4 o0, o1;
-                        o0.x = out[0]; o0.y = out[1]; o0.z = out[2]; o0.w = out[3];
-                        o1.x = out[4]; o1.y = out[5]; o1.z = out[6]; o1.w = out[7];
-                        dst[0] = o0; dst[1] = o1;
-                        if (seg == 0) {
-                            const unsigned info = info2[e], ty = SR_TYPE(info);
-                            const int mq = (int)(info & 255u);
-                            const bool rare = ty != SEG_M || (info >> 30) != 0u;       /* D/N op, indel behind it, no SEQ */
-                            W.rowinfo[row] = (info & 0xffu) | ((info >> 8) & 0xff00u) | (rare ? KC2_RARE : 0u) |
-                                             (((info >> 29) & 1u) ? KC2_FULL : 0u) |
-                                             ((MQ && mq != hot_mq) ? KC2_NONHOT : 0u);
-                        }
+                    uint32_t cb[4], qw[4];
+                    #pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        cb[t] = kc2_alignbyte(bwr[e][t + 1], bwr[e][t], shb[e]) & 0x70707070u;    /* class << 4 */
+                        qw[t] = kc2_alignbyte(qwr[e][t + 1], qwr[e][t], shb[e]);
                     }
+                    if (isD[e]) {
+                        KC2_MASKED;
+                        #pragma unroll
+                        for (int t = 0; t < 4; t++) { qw[t] = clD[e] * 0x01010101u; cb[t] = 0x40404040u; }
+                    }
+                    const uint32_t ma[4] = {mkA[e].x, mkA[e].y, mkA[e].z, mkA[e].w}, mb[4] = {mkB[e].x, mkB[e].y, mkB[e].z, mkB[e].w};
+                    uint32_t out[8];
+                    #pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        /* class byte: class << 4 | 0x08 (the mask's), 0x78 where the record does not reach the column;
+                         * u16 = quality << 8 | class byte, shifted down 3: quality << 5 | class << 1 | 1 */
+                        const uint32_t cm = cb[t] | ma[t] | mb[t];
+                        out[2 * t]     = kc2_perm(qw[t], cm, 0x05010400u) >> 3;
+                        out[2 * t + 1] = kc2_perm(qw[t], cm, 0x07030602u) >> 3;
+                    }
+                    uint4 *dst = (uint4 *)&W.plane[row][16 * seg];
+                    uint4 o0, o1;
+                    o0.x = out[0]; o0.y = out[1]; o0.z = out[2]; o0.w = out[3];
+                    o1.x = out[4]; o1.y = out[5]; o1.z = out[6]; o1.w = out[7];
+                    dst[0] = o0; dst[1] = o1;
                 }
             }
-            for (int r = rows; r < rows4; r++) W.plane[r][lane] = (uint16_t)0x00ff;
             WAVE_SYNC();
             KC2_STAMP(2);
 
@@ -503,7 +513,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                 for (int ns = 0; fm && ns < 7; ns++) {
                     const int j = __builtin_ctzll(fm);
                     fm &= fm - 1;
-                    const int cl = (int)(W.plane[j][lane] & 7u);
+                    const int cl = (int)KC2_CLS(W.plane[j][lane]);
                     if (cl < 4) {
                         if (cnt == 0) { cand = cl; cnt = 1; }
                         else cnt += (cl == cand) ? 1 : -1;
@@ -516,7 +526,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                 /* rows of reads with another mapq than the batch's dominant one: the entries' table row index becomes
                  * 128 + adjusted quality (snp:632-641), one row per step with a lane per column (the lanes sit on
                  * different rows in the steps below, so a row-uniform look-up has no place there); the call_preserve
-                 * input of the raw quality travels in bits 3-4 of the class byte */
+                 * input of the raw quality travels in bits 13-14 of the entry */
                 unsigned long long nm = __ballot((ri & KC2_NONHOT) != 0u);
                 if (nm) {
                     while (nm) {
@@ -527,8 +537,8 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                         unsigned aq;
                         if (slot < (unsigned)B.n_slots) { aq = sAdjC[slot * 128u + (q & 127u)]; KC2_PIN(aq); }
                         else aq = T->adjc[(rinfo & 255u) * 256u + (q & 255u)];
-                        const unsigned pvb = ANYPRES ? (unsigned)sPv[q & 127u] << 3 : 0u;
-                        if ((e & 7u) != 7u) W.plane[j][lane] = (uint16_t)(0x8000u | ((128u + aq) << 5) | pvb | (e & 7u));
+                        const unsigned pvb = ANYPRES ? (unsigned)sPv[q & 127u] << 13 : 0u;
+                        if (KC2_CLS(e) != 7u) W.plane[j][lane] = (uint16_t)(((128u + aq) << 5) | pvb | (e & 0x1fu));
                     }
                     WAVE_SYNC();
                 }
@@ -597,7 +607,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                 for (int u = 0; u < 4; u++) {
                     KC2_ROW(ve[u], rMM[u], r_M[u], rom[u]);
                     if (ANYPRES) {                                        /* call_preserve bits, snp:611-623 */
-                        const unsigned pv = ((unsigned)rpv[u] | (ve[u] >> 3)) & 3u, cl = ve[u] & 7u;
+                        const unsigned pv = ((unsigned)rpv[u] | (ve[u] >> 13)) & 3u, cl = KC2_CLS(ve[u]);
                         if (cl != 7u && pv) { st.cp |= 1u << cl; if (pv > 1u) st.cp |= (1u << cl) << 8; }
                     }
                 }

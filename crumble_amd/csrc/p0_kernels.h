@@ -360,13 +360,17 @@ __global__ void k_p0_owner_scatter(int64_t n, int64_t nb, const int64_t *__restr
 /* Work split of k_columns: an estimated cost per 64-column tile (its candidate records plus a constant
  * for the per-tile prologue/epilogue), prefix-summed, so that every wave can take a CONTIGUOUS run of
  * tiles of equal total cost -- no atomics, adjacent tiles (which share their reads) stay in one wave. */
+#define TILE_COST_SPAN (1ll << 56)               /* marks a tile whose reads span too much of the base array */
 __global__ void k_tile_cost(int n_tiles, const int32_t *__restrict__ slo, const int32_t *__restrict__ shi,
-                            int multi, int64_t *__restrict__ cost)
+                            const SegRec *__restrict__ sr, int multi, int64_t *__restrict__ cost)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
     const int w = shi[t] - slo[t];
-    cost[t] = multi ? (w >> 2) + 4 : w + 2;      /* long reads: most candidates are screened out 64 at a time */
+    int64_t c = multi ? (w >> 2) + 4 : w + 2;    /* long reads: most candidates are screened out 64 at a time */
+    /* k_columns2 addresses the bases of a tile's reads with 32-bit offsets from the first one */
+    if (w > 0 && sr[shi[t] - 1].so - sr[slo[t]].so > 0xf0000000ll) c = TILE_COST_SPAN;
+    cost[t] = c;
 }
 __global__ void k_i64scan_reduce(int64_t n, const int64_t *__restrict__ v, int64_t *__restrict__ partial, int nchunks)
 {
