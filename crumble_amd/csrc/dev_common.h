@@ -108,6 +108,9 @@ struct DBatch {
     int32_t n_bed;
     int32_t hot_mq;         /* most frequent mapq of the batch (sampled): a performance hint only */
     int32_t pad0_;
+    /* window of a contig (crumble_hip_set_window; the whole batch by default): columns [col_lo, col_hi) are decided
+     * (the others read as empty), columns < stat_hi enter the statistics */
+    int32_t col_lo, col_hi, stat_hi, pad1_;
     const int32_t *pos, *end;       /* end = pos + reflen; == pos if passthru */
     const uint8_t *mapq, *inplp;
     const int64_t *seq_off, *cig_off, *seg_off;

@@ -76,6 +76,12 @@ struct crumble_hip {
     int opt_replay = 0;             /* 0 auto, 1 k_replay_flat */
     int64_t n_reads = 0, n_bases = 0, n_cigar = 0, n_slow = 0, n_segrec = 0;
     ScanVal totals;
+    /* window of a contig (crumble_hip_set_window) and the phase the run is in */
+    bool windowed = false;
+    crumble_window win;
+    int64_t own_b_lo = 0, own_b_hi = 0;     /* byte range of the owned reads */
+    int phase = 0;                          /* 0 nothing run; 1 columns; 2 depth; 3 triggers; 4 fold; 5 finished */
+    crumble_carry carry_in;                 /* what phases 2 and 4 started from */
     /* timing */
     hipEvent_t ev[MAX_STAGES + 1];
     hipEvent_t ev_up[3];            /* crumble_hip_upload: start / raw arrays copied / expanded */
@@ -391,6 +397,8 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     B.p0 = any ? res[1] : 0;
     B.L = any ? res[2] - res[1] : 0;
     B.n_tiles = (B.L + 63) / 64;
+    B.col_lo = 0; B.col_hi = B.L; B.stat_hi = B.L; B.pad1_ = 0;       /* the whole batch (crumble_hip_set_window narrows it) */
+    h->windowed = false; h->phase = 0;
     {   /* the mapq most reads carry: the column kernels keep a composed quality table for it in LDS; the next
          * KC2_SLOTS most frequent ones get a row of k_columns2's compact adjustment table (their slot travels in
          * SegRec.info); anything else is looked up in global memory.  Performance hints only. */
@@ -578,25 +586,72 @@ static int launch_pblock(crumble_hip *h, hipStream_t st, int64_t n_reads, int64_
     return CRUMBLE_OK;
 }
 
-extern "C" int crumble_hip_run(crumble_hip *h)
+extern "C" void crumble_carry_init(crumble_carry *c)
+{
+    if (!c) return;
+    c->total_col = c->total_depth = 0;
+    c->min_pos = INT_MAX; c->max_pos = 0; c->min_pos2 = INT_MAX; c->max_pos2 = 0;
+}
+
+extern "C" int crumble_hip_set_window(crumble_hip *h, const crumble_window *w)
+{
+    if (!h || !h->have_batch) { g_last_error = "crumble_hip_set_window: no batch uploaded"; return CRUMBLE_EINVAL; }
+    DBatch &B = h->B;
+    h->phase = 0; h->have_run = false;
+    if (!w) { B.col_lo = 0; B.col_hi = B.L; B.stat_hi = B.L; h->windowed = false; return CRUMBLE_OK; }
+    if (w->col_start > w->stat_end || w->stat_end > w->col_end || w->read_first < 0 || w->read_first > w->read_end ||
+        w->read_end > h->n_reads) { g_last_error = "crumble_hip_set_window: inconsistent window"; return CRUMBLE_EINVAL; }
+    /* positions -> column indices of this batch, clipped to what it covers */
+    const int64_t lo = (int64_t)w->col_start - B.p0, hi = (int64_t)w->col_end - B.p0, sh = (int64_t)w->stat_end - B.p0;
+    B.col_lo = (int32_t)(lo < 0 ? 0 : lo > B.L ? B.L : lo);
+    B.col_hi = (int32_t)(hi < 0 ? 0 : hi > B.L ? B.L : hi);
+    B.stat_hi = (int32_t)(sh < B.col_lo ? B.col_lo : sh > B.col_hi ? B.col_hi : sh);
+    h->win = *w; h->windowed = true;
+    /* byte range of the owned reads (two 8-byte reads of the offset table) */
+    int64_t o2[2] = {0, 0};
+    HIPCHK(hipSetDevice(h->device));
+    if (h->n_reads > 0) {
+        HIPCHK(hipMemcpy(&o2[0], h->d_seq_off.as<int64_t>() + w->read_first, 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&o2[1], h->d_seq_off.as<int64_t>() + w->read_end, 8, hipMemcpyDeviceToHost));
+    }
+    h->own_b_lo = o2[0]; h->own_b_hi = o2[1];
+    return CRUMBLE_OK;
+}
+
+/* The run of a batch is five phases.  crumble_hip_run() does them back to back for a whole contig; a contig cut into
+ * windows (include/crumble_hip.h, crumble_hip_set_window) runs phases 1, 3 and 5 of all its windows in parallel -- one
+ * engine per device -- and only the two tiny chained phases in window order: 2 hands the running depth average on
+ * (snp:1490-1491,1684-1687), 4 the STR window state (snp:1508-1511,1741-1755). */
+/* what every phase needs from the handle (d_misc: [0] overflow flag, [1] n_epochs, [2] n_kept, [3] k_columns work counter,
+ * [8..11] upload, [16..19] depth state out, [24..27] window state out) */
+#define RUN_LOCALS \
+    HIPCHK(hipSetDevice(h->device)); \
+    hipStream_t st = h->stream; \
+    const DBatch &B = h->B; \
+    const DParams *P = h->d_params.as<DParams>(); \
+    const DTables *T = h->d_tables.as<DTables>(); \
+    u64 *stats = h->d_batch_stats.as<u64>(); \
+    int *d_overflow = h->d_misc.as<int>(); \
+    int *d_nep = d_overflow + 1; \
+    const int L = B.L; \
+    const int64_t n = B.n_reads, nb = B.n_bases; \
+    uint32_t *colrec = h->d_colrec.as<uint32_t>(); \
+    int32_t *nplp = h->d_nplp.as<int32_t>(), *score = h->d_score.as<int32_t>(); \
+    int32_t *trigcnt = h->d_trigcnt.as<int32_t>(); \
+    const int nchunks = (L + SCAN_CHUNK - 1) / SCAN_CHUNK; \
+    ScanVal *partial = h->d_partial.as<ScanVal>(); \
+    const int n_trig = h->totals.trigcols, n_items = h->totals.items, n_ins = h->totals.ins; \
+    int32_t *trigcol_pos = h->d_trigcol_pos.as<int32_t>(), *trigcol_off = h->d_trigcol_off.as<int32_t>(); \
+    int32_t *inscol_pos = h->d_inscol_pos.as<int32_t>(); \
+    TrigItem *items = h->d_items.as<TrigItem>(); \
+    (void)P; (void)T; (void)stats; (void)d_nep; (void)L; (void)n; (void)nb; (void)colrec; (void)nplp; (void)score; (void)trigcnt; \
+    (void)nchunks; (void)partial; (void)n_trig; (void)n_items; (void)n_ins; (void)trigcol_pos; (void)trigcol_off; (void)inscol_pos; (void)items;
+static const crumble_carry CARRY0 = {0, 0, INT_MAX, 0, INT_MAX, 0};
+
+extern "C" int crumble_hip_run_columns(crumble_hip *h)
 {
     if (!h || !h->have_batch) { g_last_error = "no batch uploaded"; return CRUMBLE_EINVAL; }
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t st = h->stream;
-    const DBatch &B = h->B;
-    const DParams *P = h->d_params.as<DParams>();
-    const DTables *T = h->d_tables.as<DTables>();
-    u64 *stats = h->d_batch_stats.as<u64>();
-    int *d_overflow = h->d_misc.as<int>();        /* [0] overflow flag, [1] n_epochs */
-    int *d_nep = d_overflow + 1;
-    const int L = B.L;
-    const int64_t n = B.n_reads, nb = B.n_bases;
-    uint32_t *colrec = h->d_colrec.as<uint32_t>();
-    int32_t *nplp = h->d_nplp.as<int32_t>(), *score = h->d_score.as<int32_t>();
-    int32_t *trigcnt = h->d_trigcnt.as<int32_t>();
-    /* algorithmic bytes of the whole pass: 3 B/base + 32 B/read + 8 B/cigar op */
-    const double algo_bytes = 3.0 * nb + 32.0 * n + 8.0 * h->n_cigar;
-
+    RUN_LOCALS
     h->n_stages = 0; h->have_run = false;
     memset(&h->totals, 0, sizeof(h->totals));
     HIPCHK(hipMemsetAsync(stats, 0, CRUMBLE_ST_N * 8, st));
@@ -641,8 +696,6 @@ extern "C" int crumble_hip_run(crumble_hip *h)
 #undef KCOL_LAUNCH2
 
         STAGE("scan", 0);
-        const int nchunks = (L + SCAN_CHUNK - 1) / SCAN_CHUNK;
-        ScanVal *partial = h->d_partial.as<ScanVal>();
         CRUMBLE_LAUNCH(k_scan_reduce, nchunks, 256, st, L, colrec, nplp, trigcnt, partial, nchunks);
         CRUMBLE_LAUNCH(k_scan_partials, 1, 1024, st, partial, nchunks);
         CRUMBLE_LAUNCH(k_scan_apply, nchunks, 256, st, L, colrec, nplp, trigcnt, partial, nchunks,
@@ -650,28 +703,58 @@ extern "C" int crumble_hip_run(crumble_hip *h)
                              h->d_item_off.as<int32_t>(), h->d_ins_ord.as<int32_t>());
         HIPCHK(hipMemcpyAsync(&h->totals, partial + nchunks, sizeof(ScanVal), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));           /* sizes of the work lists */
-        const int n_trig = h->totals.trigcols, n_items = h->totals.items, n_ins = h->totals.ins;
+        const int nt = h->totals.trigcols, nit = h->totals.items, ni = h->totals.ins;
+        int e;
+        if ((e = h->d_trigcol_pos.reserve((size_t)(nt + 1) * 4)) || (e = h->d_trigcol_off.reserve((size_t)(nt + 1) * 4)) ||
+            (e = h->d_inscol_pos.reserve((size_t)(ni + 1) * 4)) || (e = h->d_items.reserve((size_t)(nit + 1) * sizeof(TrigItem))) ||
+            (e = h->d_colhi.reserve((size_t)(nt + 1) * 4)) || (e = h->d_ub.reserve((size_t)(nt + 1) * 4)) ||
+            (e = h->d_trig_mx2.reserve((size_t)(nt + 1) * 4)) || (e = h->d_pmax_partial.reserve((size_t)(nt / 256 + 2) * 4)))
+            return e;
+
+    } else memset(&h->totals, 0, sizeof(h->totals));
+    h->phase = 1;
+    return CRUMBLE_OK;
+}
+
+extern "C" int crumble_hip_run_depth(crumble_hip *h, const crumble_carry *in, crumble_carry *out)
+{
+    if (!h || !h->have_batch || h->phase != 1) { g_last_error = "crumble_hip_run_depth: run the columns first"; return CRUMBLE_EINVAL; }
+    RUN_LOCALS
+    const crumble_carry cin = in ? *in : CARRY0;
+    if (cin.total_col < 0 || cin.total_col > 1048576 || cin.total_depth < 0) { g_last_error = "crumble_hip_run_depth: impossible carried state"; return CRUMBLE_EINVAL; }
+    h->carry_in.total_col = cin.total_col; h->carry_in.total_depth = cin.total_depth;
+    if (out) { out->total_col = cin.total_col; out->total_depth = cin.total_depth; }
+    if (L > 0) {
         if (h->totals.toodeep == 0)
             CRUMBLE_LAUNCH(k_epochs_par, 1, 256, st, L, colrec, h->d_col_ord.as<int32_t>(), h->d_dpre.as<int64_t>(),
-                           partial + nchunks, h->d_epochs.as<Epoch>(), d_nep);
+                           partial + nchunks, h->d_epochs.as<Epoch>(), d_nep, (int64_t)cin.total_col, (int64_t)cin.total_depth);
         else
             CRUMBLE_LAUNCH_INDEP(k_epochs, 1, 1, st, L, colrec, nplp, h->d_col_ord.as<int32_t>(), h->d_dpre.as<int64_t>(),
-                                 partial + nchunks, h->d_epochs.as<Epoch>(), d_nep);
-        int e;
-        if ((e = h->d_trigcol_pos.reserve((size_t)(n_trig + 1) * 4)) || (e = h->d_trigcol_off.reserve((size_t)(n_trig + 1) * 4)) ||
-            (e = h->d_inscol_pos.reserve((size_t)(n_ins + 1) * 4)) || (e = h->d_items.reserve((size_t)(n_items + 1) * sizeof(TrigItem))) ||
-            (e = h->d_colhi.reserve((size_t)(n_trig + 1) * 4)) || (e = h->d_ub.reserve((size_t)(n_trig + 1) * 4)) ||
-            (e = h->d_trig_mx2.reserve((size_t)(n_trig + 1) * 4)) || (e = h->d_pmax_partial.reserve((size_t)(n_trig / 256 + 2) * 4)))
-            return e;
-        int32_t *trigcol_pos = h->d_trigcol_pos.as<int32_t>(), *trigcol_off = h->d_trigcol_off.as<int32_t>();
-        int32_t *inscol_pos = h->d_inscol_pos.as<int32_t>();
-        TrigItem *items = h->d_items.as<TrigItem>();
+                                 partial + nchunks, h->d_epochs.as<Epoch>(), d_nep, (int64_t)cin.total_col, (int64_t)cin.total_depth);
+        if (out) {
+            int64_t *d_state = (int64_t *)(h->d_misc.as<int>() + 16);
+            CRUMBLE_LAUNCH_INDEP(k_depth_state_at, 1, 1, st, L, B.stat_hi, colrec, nplp, h->d_col_ord.as<int32_t>(), h->d_dpre.as<int64_t>(),
+                                 partial + nchunks, h->d_epochs.as<Epoch>(), d_nep, (int64_t)cin.total_col, (int64_t)cin.total_depth, d_state);
+            int64_t res[2];
+            HIPCHK(hipMemcpyAsync(res, d_state, sizeof res, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            out->total_col = res[0]; out->total_depth = res[1];
+        }
+    }
+    h->phase = 2;
+    return CRUMBLE_OK;
+}
 
+extern "C" int crumble_hip_run_triggers(crumble_hip *h)
+{
+    if (!h || !h->have_batch || h->phase != 2) { g_last_error = "crumble_hip_run_triggers: run the depth phase first"; return CRUMBLE_EINVAL; }
+    RUN_LOCALS
+    if (L > 0) {
         STAGE("k_overdepth", 0);
         CRUMBLE_LAUNCH_INDEP(k_overdepth, nblk((L + 3) / 4, 256), 256, st, L, colrec, nplp, h->d_col_ord.as<int32_t>(),
                              h->d_dpre.as<int64_t>(), h->d_trig_ord.as<int32_t>(), h->d_item_off.as<int32_t>(),
                              h->d_ins_ord.as<int32_t>(), h->d_epochs.as<Epoch>(), d_nep, P,
-                             trigcol_pos, trigcol_off, inscol_pos, stats);
+                             trigcol_pos, trigcol_off, inscol_pos, stats, B.stat_hi);
         if (n_ins > 0) {
             STAGE("k_inshist", 0);
             CRUMBLE_LAUNCH(k_inshist, n_ins, 64, st, B, P, n_ins, inscol_pos, colrec, nplp, stats);
@@ -684,17 +767,52 @@ extern "C" int crumble_hip_run(crumble_hip *h)
                 CRUMBLE_LAUNCH(k_emit, nblk(n_trig, 4), 256, st, B, P, n_trig, trigcol_pos, trigcol_off, colrec, items);
             STAGE("k_str", 0);
             CRUMBLE_LAUNCH_INDEP(k_str, nblk(n_items, 64), 64, st, B, P, n_items, items, d_overflow);
+        }
+    }
+    h->phase = 3;
+    return CRUMBLE_OK;
+}
+
+extern "C" int crumble_hip_run_fold(crumble_hip *h, const crumble_carry *in, crumble_carry *out)
+{
+    if (!h || !h->have_batch || h->phase != 3) { g_last_error = "crumble_hip_run_fold: run the trigger phase first"; return CRUMBLE_EINVAL; }
+    RUN_LOCALS
+    const crumble_carry cin = in ? *in : CARRY0;
+    h->carry_in.min_pos = cin.min_pos; h->carry_in.max_pos = cin.max_pos; h->carry_in.min_pos2 = cin.min_pos2; h->carry_in.max_pos2 = cin.max_pos2;
+    int32_t *d_carry = h->d_misc.as<int>() + 24;
+    const int32_t c4[4] = {cin.min_pos, cin.max_pos, cin.min_pos2, cin.max_pos2};   /* no trigger column before the cut: unchanged */
+    if (L > 0) {
+        if (out) HIPCHK(hipMemcpyAsync(d_carry, c4, sizeof c4, hipMemcpyHostToDevice, st));
+        if (n_trig > 0) {
             STAGE("k_fold", 0);
             int32_t *colhi = h->d_colhi.as<int32_t>(), *ub = h->d_ub.as<int32_t>();
             int pe;
-            CRUMBLE_LAUNCH_INDEP(k_fold_bounds, nblk(n_trig, 64), 64, st, B, P, n_trig, trigcol_pos, trigcol_off, trigcnt, items, colhi);
+            CRUMBLE_LAUNCH_INDEP(k_fold_bounds, nblk(n_trig, 64), 64, st, B, P, n_trig, trigcol_pos, trigcol_off, trigcnt, items, colhi, cin.max_pos);
             if ((pe = prefix_max(h, colhi, n_trig))) return pe;
-            CRUMBLE_LAUNCH_INDEP(k_fold_ub, nblk(n_trig, 64), 64, st, B, P, n_trig, trigcol_pos, colhi, ub);
+            CRUMBLE_LAUNCH_INDEP(k_fold_ub, nblk(n_trig, 64), 64, st, B, P, n_trig, trigcol_pos, colhi, ub, cin.max_pos2);
             if ((pe = prefix_max(h, ub, n_trig))) return pe;
             CRUMBLE_LAUNCH_INDEP(k_fold, nblk(n_trig, 64), 64, st, B, P, n_trig, trigcol_pos, trigcol_off, trigcnt, items, ub,
-                                 colrec, h->d_pos_mn2.as<int32_t>(), h->d_trig_mx2.as<int32_t>());
-            CRUMBLE_LAUNCH_INDEP(k_window, nblk(n_trig, 64), 64, st, B, n_trig, trigcol_pos, h->d_trig_mx2.as<int32_t>(), colrec);
+                                 colrec, h->d_pos_mn2.as<int32_t>(), h->d_trig_mx2.as<int32_t>(),
+                                 cin.min_pos, cin.max_pos, cin.min_pos2, cin.max_pos2, B.p0 + B.stat_hi, d_carry);
         }
+        if (h->windowed && (int64_t)cin.max_pos2 >= (int64_t)B.p0 + B.col_lo)
+            CRUMBLE_LAUNCH_INDEP(k_window_head, 64, 256, st, B, n_trig, trigcol_pos, cin.max_pos2, colrec);
+    }
+    if (out) {
+        int32_t r4[4] = {c4[0], c4[1], c4[2], c4[3]};
+        if (L > 0) { HIPCHK(hipMemcpyAsync(r4, d_carry, sizeof r4, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); }
+        out->min_pos = r4[0]; out->max_pos = r4[1]; out->min_pos2 = r4[2]; out->max_pos2 = r4[3];
+    }
+    h->phase = 4;
+    return CRUMBLE_OK;
+}
+
+extern "C" int crumble_hip_run_finish(crumble_hip *h)
+{
+    if (!h || !h->have_batch || h->phase != 4) { g_last_error = "crumble_hip_run_finish: run the fold phase first"; return CRUMBLE_EINVAL; }
+    RUN_LOCALS
+    if (L > 0 && n_trig > 0) {
+        CRUMBLE_LAUNCH_INDEP(k_window, nblk(n_trig, 64), 64, st, B, n_trig, trigcol_pos, h->d_trig_mx2.as<int32_t>(), colrec);
     }
     if (n > 0) {
         STAGE("k_replay", 3.0 * nb);
@@ -744,7 +862,10 @@ extern "C" int crumble_hip_run(crumble_hip *h)
             if (pe) return pe;
         }
         STAGE("k_stats", 2.0 * nb);
-        CRUMBLE_LAUNCH(k_stats, 1024, 256, st, nb, n, h->d_out.as<uint8_t>(), B.quals, stats);
+        if (h->windowed)
+            CRUMBLE_LAUNCH(k_stats, 1024, 256, st, h->own_b_lo, h->own_b_hi, h->win.read_end - h->win.read_first, h->d_out.as<uint8_t>(), B.quals, stats);
+        else
+            CRUMBLE_LAUNCH(k_stats, 1024, 256, st, (int64_t)0, nb, n, h->d_out.as<uint8_t>(), B.quals, stats);
     }
     HIPCHK(hipEventRecord(h->ev[h->n_stages], st));
     /* fold this batch's counters into the engine's accumulated stats vector, on the device */
@@ -755,9 +876,18 @@ extern "C" int crumble_hip_run(crumble_hip *h)
     HIPCHK(hipGetLastError());
     for (int i = 0; i < h->n_stages; i++)
         HIPCHK(hipEventElapsedTime(&h->stage_ms[i], h->ev[i], h->ev[i + 1]));
-    (void)algo_bytes;
     if (ovf[0]) { g_last_error = "STR repeat list overflow"; return CRUMBLE_EOVERFLOW; }
-    h->have_run = true;
+    h->have_run = true; h->phase = 5;
+    return CRUMBLE_OK;
+}
+
+
+extern "C" int crumble_hip_run(crumble_hip *h)
+{
+    int e;
+    if ((e = crumble_hip_run_columns(h)) || (e = crumble_hip_run_depth(h, nullptr, nullptr)) || (e = crumble_hip_run_triggers(h)) ||
+        (e = crumble_hip_run_fold(h, nullptr, nullptr)) || (e = crumble_hip_run_finish(h)))
+        return e;
     return CRUMBLE_OK;
 }
 

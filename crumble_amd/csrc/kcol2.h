@@ -142,7 +142,7 @@ struct __attribute__((aligned(16))) KC2Wave {      /* one wave's LDS */
 struct __attribute__((aligned(16))) KC2Lds {
     double   row[KC2_NROWTAB * 4];
     double   e[KC2_LDS_EXP ? CONS_NEXP : 2];
-    unsigned stat[32];
+    unsigned stat[64];                            /* [32..63]: columns outside the window's statistics range */
     uint8_t  adjc[KC2_SLOTS * 128];
     uint8_t  pv[128];
     uint4    mask_lt[17], mask_ge[17];             /* producer: byte k of [a] = 0x08 | (k < a ? 0x70 : 0); of [b] = (k >= b ? 0x70 : 0) */
@@ -276,7 +276,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
     unsigned *const sStat = L.stat;
     KC2Wave *const sWave = L.wave;
     const int hot_mq = MQ ? B.hot_mq : -1;
-    if (threadIdx.x < 32) sStat[threadIdx.x] = 0;
+    if (threadIdx.x < 64) sStat[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < KC2_NROWTAB; i += blockDim.x) {
         const int a = i >= 128 ? i - 128 : (MQ ? (int)T->adjc[hot_mq * 256 + i] : (int)T->capc[i]);
         sRow[i * 4] = T->MMd[a]; sRow[i * 4 + 1] = T->_Md[a]; sRow[i * 4 + 2] = T->omq[a];
@@ -321,6 +321,10 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
         const int c = tile * 64 + lane;
         const int apos = B.p0 + c;
         const bool inr = c < B.L;
+        if (tile * 64 + 63 < B.col_lo || tile * 64 >= B.col_hi) {       /* outside the window: empty columns */
+            if (inr) { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; }
+            continue;
+        }
         const int lo = UNIFORM(B.stile_lo[tile]), hi = UNIFORM(B.stile_hi[tile]);
         const int c0 = B.p0 + tile * 64, c1 = c0 + 63;
 
@@ -633,7 +637,12 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
         continue;
 #endif
         if (key) col_unpermute(st.S, st.sC, (int)key);  /* back to the reference's A C G T numbering */
-        if (inr) col_decide<MQ ? 1 : 0>(st, B, P, T, c, apos, true, colrec, nplp_out, score_out, trigcnt, sStat, KC2_LDS_EXP ? sE : (const double *)nullptr);
+        if (inr) {
+            if (c >= B.col_lo && c < B.col_hi)          /* (columns at or beyond stat_hi count into the unused upper half) */
+                col_decide<MQ ? 1 : 0>(st, B, P, T, c, apos, true, colrec, nplp_out, score_out, trigcnt,
+                                       c < B.stat_hi ? sStat : sStat + 32, KC2_LDS_EXP ? sE : (const double *)nullptr);
+            else { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; }
+        }
         KC2_STAMP(4);
     }
     }

@@ -481,12 +481,12 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
     __shared__ double sTab[101 * 4];                       /* [aq] -> {MM, _M, 1 - q2p, -} : one 32-byte LDS row */
     constexpr bool MQ = MODE != 0;                          /* the active consensus uses CONS_MQUAL */
     __shared__ uint8_t sAdj[MQ ? 256 * 128 : 16];
-    __shared__ unsigned sStat[32];
+    __shared__ unsigned sStat[64];                  /* [32..63]: columns outside the window's statistics range */
     /* composed row table of the batch's dominant mapq: sHot[q] = sTab[adj[hot_mq][q]], so that most
      * records need one dependent LDS round trip instead of two */
     __shared__ double sHot[MQ ? 128 * 4 : 4];
     const int hot_mq = MQ ? B.hot_mq : -1;
-    if (threadIdx.x < 32) sStat[threadIdx.x] = 0;
+    if (threadIdx.x < 64) sStat[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < 101; i += blockDim.x) {
         sTab[i * 4] = T->MMd[i]; sTab[i * 4 + 1] = T->_Md[i]; sTab[i * 4 + 2] = T->omq[i]; sTab[i * 4 + 3] = 0;
     }
@@ -728,7 +728,11 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
             col_unpermute(st.S, st.sC, k);
             if (MODE == 2) col_unpermute(st.S2, st.sC2, k);
         }
-        if (inr) col_decide<MODE>(st, B, P, T, c, apos, use_cons, colrec, nplp_out, score_out, trigcnt, sStat);
+        if (inr) {
+            if (c >= B.col_lo && c < B.col_hi)
+                col_decide<MODE>(st, B, P, T, c, apos, use_cons, colrec, nplp_out, score_out, trigcnt, c < B.stat_hi ? sStat : sStat + 32);
+            else { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; }
+        }
     }
     }
     __syncthreads();
@@ -885,11 +889,11 @@ __device__ __forceinline__ int ord_to_pos(const int32_t *col_ord, const uint32_t
 }
 
 __global__ void k_epochs(int L, const uint32_t *colrec, const int32_t *nplp, const int32_t *col_ord,
-                         const int64_t *dpre, const ScanVal *totals, Epoch *ep, int *n_ep)
+                         const int64_t *dpre, const ScanVal *totals, Epoch *ep, int *n_ep, int64_t tc0, int64_t td0)
 {
     if (blockIdx.x || threadIdx.x) return;
     const int64_t ncols = totals->cols;
-    int64_t tc = 0, td = 0, ord = 0;
+    int64_t tc = tc0, td = td0, ord = 0;            /* (tc0, td0): the state a window of a contig starts from */
     int n = 0;
     while (ord < ncols && n < MAX_EPOCHS - 1) {
         int p0 = ord_to_pos(col_ord, colrec, L, ord);
@@ -915,20 +919,22 @@ __global__ void k_epochs(int L, const uint32_t *colrec, const int32_t *nplp, con
  * prefix lookup is independent; only the tiny td recurrence is sequential. */
 __global__ void __launch_bounds__(256)
 k_epochs_par(int L, const uint32_t *colrec, const int32_t *col_ord, const int64_t *dpre,
-             const ScanVal *totals, Epoch *ep, int *n_ep)
+             const ScanVal *totals, Epoch *ep, int *n_ep, int64_t tc0, int64_t td0)
 {
-    const int64_t ncols = totals->cols;
+    /* (tc0 <= 2^20, td0): the state a window of a contig starts from; the first halving column is the one that
+     * brings total_col to 2^20 + 1 */
+    const int64_t ncols = totals->cols, first = 1048577 - tc0;
     int n = 0;
-    if (ncols > 0) n = 1 + (int)((ncols > 1048577) ? (ncols - 1048577 + 524288) / 524289 : 0);
+    if (ncols > 0) n = 1 + (int)((ncols > first) ? (ncols - first + 524288) / 524289 : 0);
     if (n > MAX_EPOCHS - 1) n = MAX_EPOCHS - 1;
     for (int k = threadIdx.x; k < n; k += blockDim.x) {
-        const int64_t ord = (k == 0) ? 0 : 1048577 + (int64_t)(k - 1) * 524289;
+        const int64_t ord = (k == 0) ? 0 : first + (int64_t)(k - 1) * 524289;
         const int p = ord_to_pos(col_ord, colrec, L, ord);
-        ep[k].ord_start = ord; ep[k].tc_start = (k == 0) ? 0 : 524288; ep[k].dpre_start = dpre[p]; ep[k].td_start = 0;
+        ep[k].ord_start = ord; ep[k].tc_start = (k == 0) ? tc0 : 524288; ep[k].dpre_start = dpre[p]; ep[k].td_start = td0;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int64_t td = 0;
+        int64_t td = td0;
         for (int k = 0; k + 1 < n; k++) {
             td = (td + ep[k + 1].dpre_start - ep[k].dpre_start) >> 1;
             ep[k + 1].td_start = td;
@@ -937,12 +943,34 @@ k_epochs_par(int L, const uint32_t *colrec, const int32_t *col_ord, const int64_
     }
 }
 
+/* (total_col, total_depth) before the column at index `cut` (snp:1490-1491, 1684-1687): what the next window of the
+ * contig starts from.  The counted column before the cut is looked up in its epoch, then the halving rule is applied
+ * to it as the reference does after its test. */
+__global__ void k_depth_state_at(int L, int cut, const uint32_t *colrec, const int32_t *nplp, const int32_t *col_ord,
+                                 const int64_t *dpre, const ScanVal *totals, const Epoch *ep, const int *n_ep,
+                                 int64_t tc0, int64_t td0, int64_t *out)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    const int64_t o = cut < L ? (int64_t)col_ord[cut] : totals->cols;    /* counted columns before the cut */
+    int64_t tc = tc0, td = td0;
+    if (o > 0) {
+        const int p = ord_to_pos(col_ord, colrec, L, o - 1);
+        const int nep = *n_ep;
+        int e = 0;
+        while (e + 1 < nep && ep[e + 1].ord_start <= o - 1) e++;
+        tc = ep[e].tc_start + (o - 1 - ep[e].ord_start + 1);
+        td = ep[e].td_start + (dpre[p] + nplp[p] - ep[e].dpre_start);
+        if (tc > 1048576 && !(colrec[p] & CR_TOODEEP)) { tc >>= 1; td >>= 1; }
+    }
+    out[0] = tc; out[1] = td;
+}
+
 /* over-depth test per column (snp:1673-1681) + compaction of the trigger and
  * histogram columns. */
 __device__ __forceinline__ void overdepth_col(int i, uint32_t rec, int64_t ord, int n, int64_t dp, uint32_t *colrec,
                                               const int32_t *trig_ord, const int32_t *item_off, const int32_t *ins_ord,
                                               const Epoch *ep, int nep, double over_depth, int32_t *trigcol_pos,
-                                              int32_t *trigcol_off, int32_t *inscol_pos, u64 *stats)
+                                              int32_t *trigcol_off, int32_t *inscol_pos, u64 *stats, int stat_hi)
 {
     if (!(rec & CR_COUNTED) || (rec & CR_TOODEEP)) return;
     /* last epoch with ord_start <= ord.  Epochs are ~2^20 columns first and ~2^19 afterwards, so an
@@ -957,7 +985,7 @@ __device__ __forceinline__ void overdepth_col(int i, uint32_t rec, int64_t ord, 
     if ((double)((int64_t)n * (total_col + 1)) > over_depth * (double)(total_depth + 1)) {
         rec |= CR_KEEP | CR_R_DEEP;
         colrec[i] = rec;
-        stat_inc(stats, ST_OVER_DEPTH, true);
+        stat_inc(stats, ST_OVER_DEPTH, i < stat_hi);
     }
     if (rec & CR_TRIG) { trigcol_pos[trig_ord[i]] = i; trigcol_off[trig_ord[i]] = item_off[i]; }
     if (rec & CR_HASINS) inscol_pos[ins_ord[i]] = i;
@@ -968,7 +996,7 @@ k_overdepth(int L, uint32_t *colrec, const int32_t *nplp, const int32_t *col_ord
             const int64_t *dpre, const int32_t *trig_ord, const int32_t *item_off,
             const int32_t *ins_ord, const Epoch *ep, const int *n_ep,
             const DParams *P, int32_t *trigcol_pos, int32_t *trigcol_off,
-            int32_t *inscol_pos, u64 *stats)
+            int32_t *inscol_pos, u64 *stats, int stat_hi)
 {
     const int i0 = (int)(blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i0 >= L) return;
@@ -979,14 +1007,14 @@ k_overdepth(int L, uint32_t *colrec, const int32_t *nplp, const int32_t *col_ord
         if (!((r4.x | r4.y | r4.z | r4.w) & CR_COUNTED)) return;
         const int4 o4 = *(const int4 *)(col_ord + i0), n4 = *(const int4 *)(nplp + i0);
         const longlong2 d01 = *(const longlong2 *)(dpre + i0), d23 = *(const longlong2 *)(dpre + i0 + 2);
-        overdepth_col(i0,     r4.x, o4.x, n4.x, d01.x, colrec, trig_ord, item_off, ins_ord, ep, nep, od, trigcol_pos, trigcol_off, inscol_pos, stats);
-        overdepth_col(i0 + 1, r4.y, o4.y, n4.y, d01.y, colrec, trig_ord, item_off, ins_ord, ep, nep, od, trigcol_pos, trigcol_off, inscol_pos, stats);
-        overdepth_col(i0 + 2, r4.z, o4.z, n4.z, d23.x, colrec, trig_ord, item_off, ins_ord, ep, nep, od, trigcol_pos, trigcol_off, inscol_pos, stats);
-        overdepth_col(i0 + 3, r4.w, o4.w, n4.w, d23.y, colrec, trig_ord, item_off, ins_ord, ep, nep, od, trigcol_pos, trigcol_off, inscol_pos, stats);
+        overdepth_col(i0,     r4.x, o4.x, n4.x, d01.x, colrec, trig_ord, item_off, ins_ord, ep, nep, od, trigcol_pos, trigcol_off, inscol_pos, stats, stat_hi);
+        overdepth_col(i0 + 1, r4.y, o4.y, n4.y, d01.y, colrec, trig_ord, item_off, ins_ord, ep, nep, od, trigcol_pos, trigcol_off, inscol_pos, stats, stat_hi);
+        overdepth_col(i0 + 2, r4.z, o4.z, n4.z, d23.x, colrec, trig_ord, item_off, ins_ord, ep, nep, od, trigcol_pos, trigcol_off, inscol_pos, stats, stat_hi);
+        overdepth_col(i0 + 3, r4.w, o4.w, n4.w, d23.y, colrec, trig_ord, item_off, ins_ord, ep, nep, od, trigcol_pos, trigcol_off, inscol_pos, stats, stat_hi);
     } else {
         for (int i = i0; i < L; i++)
             overdepth_col(i, colrec[i], col_ord[i], nplp[i], dpre[i], colrec, trig_ord, item_off, ins_ord, ep, nep, od,
-                          trigcol_pos, trigcol_off, inscol_pos, stats);
+                          trigcol_pos, trigcol_off, inscol_pos, stats, stat_hi);
     }
 }
 
@@ -995,7 +1023,7 @@ k_overdepth(int L, uint32_t *colrec, const int32_t *nplp, const int32_t *col_ord
  * insertion only.  One thread per such column. */
 __global__ void __launch_bounds__(64)
 k_inshist(DBatch B, const DParams *P, int n_ins, const int32_t *inscol_pos,
-          uint32_t *colrec, const int32_t *nplp, u64 *stats)
+          uint32_t *colrec, const int32_t *nplp, u64 *stats)     /* (statistics: columns < B.stat_hi) */
 {
     /* one 64-lane workgroup per column, lanes over its candidate reads */
     __shared__ int hist[100];
@@ -1027,8 +1055,8 @@ k_inshist(DBatch B, const DParams *P, int n_ins, const int32_t *inscol_pos,
         else if (qd2 < hist[i]) qd2 = hist[i];
     }
     uint32_t why = 0;
-    if ((double)(ov - qd1 - qd2) > P->ins_len_perc * (ov + .1)) { why |= CR_KEEP | CR_R_INSLEN; stat_inc(stats, ST_INS_LEN_PERC, true); }
-    if ((double)ov < P->indel_ov_perc * nplp[c]) { why |= CR_KEEP | CR_R_INDELOV; stat_inc(stats, ST_INDEL_OV_PERC, true); }
+    if ((double)(ov - qd1 - qd2) > P->ins_len_perc * (ov + .1)) { why |= CR_KEEP | CR_R_INSLEN; stat_inc(stats, ST_INS_LEN_PERC, c < B.stat_hi); }
+    if ((double)ov < P->indel_ov_perc * nplp[c]) { why |= CR_KEEP | CR_R_INDELOV; stat_inc(stats, ST_INDEL_OV_PERC, c < B.stat_hi); }
     if (why) colrec[c] |= why;
 }
 
@@ -1320,7 +1348,7 @@ k_str(DBatch B, const DParams *P, int n_items, TrigItem *items, int *overflow)
  * those are independent segments, folded sequentially by one thread each. */
 __global__ void k_fold_bounds(DBatch B, const DParams *P, int n_trig, const int32_t *trigcol_pos,
                               const int32_t *trigcol_off, const int32_t *trigcnt,
-                              const TrigItem *items, int32_t *colhi)
+                              const TrigItem *items, int32_t *colhi, int in_max_pos)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_trig) return;
@@ -1328,6 +1356,7 @@ __global__ void k_fold_bounds(DBatch B, const DParams *P, int n_trig, const int3
     const int o = trigcol_off[k], n = trigcnt[c];
     int h = pos;
     for (int i = 0; i < n; i++) if (items[o + i].hi > h) h = items[o + i].hi;
+    if (k == 0 && in_max_pos > h) h = in_max_pos;            /* the state the window starts from */
     colhi[k] = h;
 }
 
@@ -1401,7 +1430,7 @@ k_pmax_apply(int n, int32_t *__restrict__ v, const int32_t *__restrict__ partial
 
 /* colhi (already prefix-maxed = bound on max_pos) -> per-column bound on max_pos2 */
 __global__ void k_fold_ub(DBatch B, const DParams *P, int n_trig, const int32_t *trigcol_pos,
-                          const int32_t *colhi, int32_t *ub)
+                          const int32_t *colhi, int32_t *ub, int in_max_pos2)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_trig) return;
@@ -1411,18 +1440,23 @@ __global__ void k_fold_ub(DBatch B, const DParams *P, int n_trig, const int32_t 
     double m = a > b ? a : b;
     if (m < pos) m = pos;
     m += 2;                                         /* slack over the truncations */
+    if (k == 0 && (double)in_max_pos2 > m) m = in_max_pos2;
     ub[k] = m > 2147483000.0 ? 2147483000 : (int)m;
 }
 
 __global__ void k_fold(DBatch B, const DParams *P, int n_trig, const int32_t *trigcol_pos,
                        const int32_t *trigcol_off, const int32_t *trigcnt, const TrigItem *items,
                        const int32_t *ubmax /* inclusive prefix max of ub */,
-                       uint32_t *colrec, int32_t *pos_mn2, int32_t *trig_mx2)
+                       uint32_t *colrec, int32_t *pos_mn2, int32_t *trig_mx2,
+                       int in_min_pos, int in_max_pos, int in_min_pos2, int in_max_pos2, int cut_pos, int32_t *carry_out)
 {
+    /* (in_*: the state the first column starts from -- INT_MAX 0 INT_MAX 0 for a whole contig; carry_out: the
+     * state after the last trigger column before cut_pos, for the next window of the contig) */
     const int k0 = blockIdx.x * blockDim.x + threadIdx.x;
     if (k0 >= n_trig) return;
     if (k0 > 0 && !(B.p0 + trigcol_pos[k0] > ubmax[k0 - 1])) return;   /* not a segment start */
     int min_pos = INT_MAX, max_pos = 0, min_pos2 = INT_MAX, max_pos2 = 0;
+    if (k0 == 0) { min_pos = in_min_pos; max_pos = in_max_pos; min_pos2 = in_min_pos2; max_pos2 = in_max_pos2; }
     const double imul = P->iSTR_mul, smul = P->sSTR_mul;
     const int iadd = P->iSTR_add, sadd = P->sSTR_add;
     for (int k = k0; k < n_trig; k++) {
@@ -1449,7 +1483,21 @@ __global__ void k_fold(DBatch B, const DParams *P, int n_trig, const int32_t *tr
         }
         pos_mn2[c] = min_pos2;
         trig_mx2[k] = max_pos2;
+        if (pos < cut_pos && (k + 1 == n_trig || B.p0 + trigcol_pos[k + 1] >= cut_pos)) {
+            carry_out[0] = min_pos; carry_out[1] = max_pos; carry_out[2] = min_pos2; carry_out[3] = max_pos2;
+        }
     }
+}
+
+/* the columns from the window's first one up to the first trigger column are "in window" while pos <= the
+ * max_pos2 the window starts from (snp:1880) */
+__global__ void k_window_head(DBatch B, int n_trig, const int32_t *trigcol_pos, int in_max_pos2, uint32_t *colrec)
+{
+    const int next = n_trig > 0 ? trigcol_pos[0] : B.col_hi;
+    int64_t last = (int64_t)in_max_pos2 - B.p0;
+    if (last > next - 1) last = next - 1;
+    for (int64_t i = B.col_lo + (int64_t)(blockIdx.x * blockDim.x + threadIdx.x); i <= last; i += (int64_t)gridDim.x * blockDim.x)
+        colrec[i] |= CR_WIN;
 }
 
 /* columns after a trigger column stay "in window" while pos <= max_pos2 (snp:1880) */
@@ -2502,8 +2550,14 @@ k_pb_fill(int64_t n_bases, uint8_t *__restrict__ out, const u64 *__restrict__ st
  * serialise the LDS atomics. */
 #define HIST_COPIES 32
 __global__ void __launch_bounds__(256)
-k_stats(int64_t n_bases, int64_t n_reads, const uint8_t *out, const uint8_t *in, u64 *stats)
+k_stats(int64_t b_lo, int64_t b_hi, int64_t n_reads, const uint8_t *out, const uint8_t *in, u64 *stats)
 {
+    /* bytes [b_lo, b_hi) of the batch (a window of a contig counts the reads it owns): the unaligned head is counted
+     * here by workgroup 0, the rest as 16-byte vectors from the next aligned offset */
+    const int64_t a_lo = ((b_lo + 15) & ~(int64_t)15) < b_hi ? ((b_lo + 15) & ~(int64_t)15) : b_hi;
+    const int64_t head_lo = b_lo, head_hi = a_lo, bases_total = b_hi - b_lo;
+    out += a_lo; in += a_lo;
+    const int64_t n_bases = b_hi - a_lo;
     __shared__ unsigned int h[256 * HIST_COPIES];
     __shared__ unsigned int hchg;
     for (int i = threadIdx.x; i < 256 * HIST_COPIES; i += blockDim.x) h[i] = 0;
@@ -2527,9 +2581,14 @@ k_stats(int64_t n_bases, int64_t n_reads, const uint8_t *out, const uint8_t *in,
             }
         }
     }
-    /* tail bytes */
+    /* head and tail bytes */
     if (blockIdx.x == 0) {
         for (int64_t i = (nvec << 4) + threadIdx.x; i < n_bases; i += blockDim.x) {
+            const unsigned o = out[i];
+            atomicAdd(&h[o * HIST_COPIES + copy], 1u);
+            changed += (o != in[i]);
+        }
+        for (int64_t i = head_lo - a_lo + threadIdx.x; i < head_hi - a_lo; i += blockDim.x) {   /* (negative offsets) */
             const unsigned o = out[i];
             atomicAdd(&h[o * HIST_COPIES + copy], 1u);
             changed += (o != in[i]);
@@ -2546,7 +2605,7 @@ k_stats(int64_t n_bases, int64_t n_reads, const uint8_t *out, const uint8_t *in,
         if (hchg) atomicAdd(&stats[ST_BASES_CHANGED], (u64)hchg);
         if (blockIdx.x == 0) {
             atomicAdd(&stats[ST_READS], (u64)n_reads);
-            atomicAdd(&stats[ST_BASES], (u64)n_bases);
+            atomicAdd(&stats[ST_BASES], (u64)bases_total);
         }
     }
 }

@@ -62,6 +62,13 @@ def load_library(path=None, make_default=True):
         "crumble_hip_contig": (C.c_int, [vp, C.POINTER(Batch), vp, vp, vp]),
         "crumble_hip_upload": (C.c_int, [vp, C.POINTER(Batch)]),
         "crumble_hip_run": (C.c_int, [vp]),
+        "crumble_hip_set_window": (C.c_int, [vp, vp]),
+        "crumble_carry_init": (None, [vp]),
+        "crumble_hip_run_columns": (C.c_int, [vp]),
+        "crumble_hip_run_depth": (C.c_int, [vp, vp, vp]),
+        "crumble_hip_run_triggers": (C.c_int, [vp]),
+        "crumble_hip_run_fold": (C.c_int, [vp, vp, vp]),
+        "crumble_hip_run_finish": (C.c_int, [vp]),
         "crumble_hip_download": (C.c_int, [vp, vp, vp, vp]),
         "crumble_hip_kernel_times": (C.c_int, [vp, vp, vp, vp, C.c_int]),
         "crumble_hip_upload_times": (C.c_int, [vp, vp, vp]),
@@ -98,6 +105,8 @@ EXPORTED = [
     "crumble_params_keep_quals", "crumble_init_bins", "crumble_bed_collapse",
     "crumble_hip_create", "crumble_hip_destroy", "crumble_hip_set_option", "crumble_hip_contig",
     "crumble_hip_upload", "crumble_hip_run", "crumble_hip_download",
+    "crumble_hip_set_window", "crumble_carry_init", "crumble_hip_run_columns", "crumble_hip_run_depth",
+    "crumble_hip_run_triggers", "crumble_hip_run_fold", "crumble_hip_run_finish",
     "crumble_hip_kernel_times", "crumble_hip_upload_times", "crumble_hip_stats_devptr", "crumble_hip_stats_reset",
     "crumble_hip_stats_read", "crumble_hip_stats_allreduce", "crumble_hip_comm_init_all",
     "crumble_hip_comm_destroy", "crumble_hip_columns",
@@ -173,6 +182,25 @@ class Engine:
 
     def run(self):
         self._chk(self.L.crumble_hip_run(self.h), "run")
+
+    # one contig over several engines: windows (include/crumble_hip.h, crumble_amd/windows.py)
+    def set_window(self, w):
+        self._chk(self.L.crumble_hip_set_window(self.h, C.byref(w) if w is not None else None), "set_window")
+
+    def run_columns(self):
+        self._chk(self.L.crumble_hip_run_columns(self.h), "run_columns")
+
+    def run_depth(self, carry_in, carry_out):
+        self._chk(self.L.crumble_hip_run_depth(self.h, C.byref(carry_in), C.byref(carry_out)), "run_depth")
+
+    def run_triggers(self):
+        self._chk(self.L.crumble_hip_run_triggers(self.h), "run_triggers")
+
+    def run_fold(self, carry_in, carry_out):
+        self._chk(self.L.crumble_hip_run_fold(self.h, C.byref(carry_in), C.byref(carry_out)), "run_fold")
+
+    def run_finish(self):
+        self._chk(self.L.crumble_hip_run_finish(self.h), "run_finish")
 
     def download(self, want_flags=True, want_stats=True):
         hb = self._batch

@@ -174,6 +174,42 @@ int crumble_hip_run(crumble_hip *h);      /* asynchronous launches + one sync */
 int crumble_hip_download(crumble_hip *h, uint8_t *qual_out,
                          uint8_t *read_flags_out, int64_t *stats);
 
+/* ---- one contig over several devices: windows ------------------------------------------------
+ * transcode() carries three pieces of state from column to column: the running depth average total_col / total_depth
+ * with its halvings (snp_score.c:1490-1491, 1684-1687), the STR window min_pos max_pos min_pos2 max_pos2
+ * (snp_score.c:1508-1511, 1741-1755) and the BED cursor (a search here).  A contig is cut at reference positions
+ * w_0 < w_1 < ...; window k OWNS the reads that start in [w_k, w_k+1) and is uploaded as a batch of the contig's reads
+ * that overlap [w_k, E_k), E_k = the largest end of an owned read (reads are in file order, so that is one contiguous
+ * slice: owned reads, the reads before them that reach w_k, the reads after them that start before E_k).  The window
+ * decides the columns [w_k, E_k) -- every read that covers them is in the batch -- counts the columns [w_k, w_k+1)
+ * and the owned reads in the statistics, and starts from the state window k-1 reached at w_k.  Everything else is
+ * what a whole contig does; the owned reads' bytes, flags and the summed statistics equal the unsharded run's.
+ *
+ * crumble_hip_run() is five phases; a caller with one engine per device runs crumble_hip_run_columns, _triggers and
+ * _finish of all windows at once and only _depth and _fold (a few small kernels each) in window order, handing the
+ * crumble_carry on. */
+typedef struct crumble_window {
+    int32_t col_start;      /* w_k: first reference position whose column this window decides               */
+    int32_t col_end;        /* E_k: one past the last decided column (>= the end of every owned read)        */
+    int32_t stat_end;       /* w_k+1: columns before it enter the statistics; the carry is reported there    */
+    int32_t pad_;
+    int64_t read_first;     /* owned reads [read_first, read_end) of the uploaded batch                      */
+    int64_t read_end;
+} crumble_window;
+typedef struct crumble_carry {
+    int64_t total_col, total_depth;                 /* <- / -> crumble_hip_run_depth */
+    int32_t min_pos, max_pos, min_pos2, max_pos2;   /* <- / -> crumble_hip_run_fold  */
+} crumble_carry;
+/* After crumble_hip_upload(), before the run.  NULL: the whole batch again.  crumble_hip_download() still copies
+ * every read of the batch; only the owned ones are final. */
+int crumble_hip_set_window(crumble_hip *h, const crumble_window *w);
+void crumble_carry_init(crumble_carry *c);          /* the state at the start of a contig (snp_score.c:1478-1488) */
+int crumble_hip_run_columns(crumble_hip *h);
+int crumble_hip_run_depth(crumble_hip *h, const crumble_carry *in, crumble_carry *out);   /* in/out may be NULL */
+int crumble_hip_run_triggers(crumble_hip *h);
+int crumble_hip_run_fold(crumble_hip *h, const crumble_carry *in, crumble_carry *out);
+int crumble_hip_run_finish(crumble_hip *h);
+
 /* HIP-event timings of the last crumble_hip_run(): names[i] / ms[i] for up to
  * `max` kernels (returns the number filled).  bytes[i] (may be NULL) receives
  * the algorithmic bytes that launch is charged with. */

@@ -1,0 +1,111 @@
+"""One contig cut into windows over several engines (include/crumble_hip.h "windows"): the owned
+reads' quality bytes and flags and the summed statistics must equal the unsharded run's and the oracle's.  The CPU
+tier runs the literal kernel sources under the emulator (both column kernels); the GPU tier adds sizes where the
+running depth average halves several times inside the contig and the long-read path."""
+import numpy as np
+import pytest
+
+import crumble_amd as ca
+from crumble_amd import windows
+import synth
+import oracle_lib as O
+
+
+def _check(make_engine, hb, params, n_windows, want=None):
+    engines = [make_engine(params) for _ in range(n_windows)]
+    try:
+        q, f, s = windows.run(engines, hb, n_windows)
+    finally:
+        for e in engines:
+            e.close()
+    if want is None:
+        want = O.contig(params, hb)
+    wq, wf, ws = want
+    assert np.array_equal(q, wq), ("quality bytes", int((q != wq).sum()), np.nonzero(q != wq)[0][:5])
+    assert np.array_equal(f, wf), ("read flags", np.nonzero(f != wf)[0][:5])
+    bad = np.nonzero(s != ws)[0]
+    assert len(bad) == 0, ("statistics", [(ca.ST_NAMES[i] if i < len(ca.ST_NAMES) else i, int(s[i]), int(ws[i])) for i in bad[:6]])
+
+
+def test_plan_covers_every_read_once():
+    hb = synth.generate(synth.config("chr20", scale=0.0006, seed=3))
+    for k in (1, 2, 3, 7):
+        wins = windows.plan(hb, k)
+        owned = []
+        end = windows.ref_ends(hb)
+        for lo, hi, w in wins:
+            r0, r1 = lo + w.read_first, lo + w.read_end
+            owned += list(range(r0, r1))
+            assert w.col_start <= w.stat_end <= w.col_end
+            assert (hb.pos[r0:r1] >= w.col_start).all() and (end[r0:r1] <= w.col_end).all()
+            # every read that overlaps a decided column is in the slice
+            ov = np.nonzero((end > w.col_start) & (hb.pos < w.col_end))[0]
+            assert len(ov) == 0 or (ov.min() >= lo and ov.max() < hi)
+        assert owned == list(range(hb.n_reads))
+        for (lo, hi, w), (lo2, hi2, w2) in zip(wins, wins[1:]):
+            assert w.stat_end == w2.col_start or w.stat_end == w.col_end
+
+
+@pytest.mark.parametrize("kcol", ["v1", "v2"])
+def test_emu_windows_chr20(kcol):
+    import emu_lib
+    hb = synth.generate(synth.config("chr20", scale=0.0005, seed=11))
+    p = ca.preset_params(5)
+    _check(emu_lib.with_options(kcol=kcol), hb, p, 3)
+
+
+def test_emu_windows_panel_and_bed():
+    import emu_lib
+    cfg = synth.config("panel", scale=0.02, seed=5)
+    hb0 = synth.generate(cfg)
+    lo, hi = int(hb0.pos.min()), int(hb0.pos.max())
+    bed = np.array([[lo + 200, lo + 900], [(lo + hi) // 2 - 300, (lo + hi) // 2 + 300]], np.int32)
+    hb = synth.generate(cfg, bed=bed)
+    p = ca.preset_params(9)
+    _check(emu_lib.engine, hb, p, 4)
+
+
+def test_emu_windows_more_windows_than_starts():
+    import emu_lib
+    hb = synth.generate(synth.config("chr20", scale=0.0001, seed=2))
+    _check(emu_lib.engine, hb, ca.preset_params(9), 6)
+
+
+def test_emu_window_phase_order_is_checked():
+    import emu_lib
+    hb = synth.generate(synth.config("chr20", scale=0.0001, seed=2))
+    eng = emu_lib.engine(ca.preset_params(5))
+    eng.upload(hb)
+    with pytest.raises(ca.CrumbleError):
+        eng.run_triggers()
+    eng.run_columns()
+    with pytest.raises(ca.CrumbleError):
+        eng.run_fold(windows.Carry.start(), windows.Carry.start())
+    bad = windows.Carry.start(); bad.total_col = 1 << 21
+    with pytest.raises(ca.CrumbleError):
+        eng.run_depth(bad, windows.Carry.start())
+    eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,scale,preset,nw", [("chr20", 0.08, 5, 4), ("chr20", 0.02, 9, 3), ("panel", 1.0, 9, 5)])
+def test_gpu_windows_match_the_whole_contig(product, name, scale, preset, nw):
+    """chr20 at scale 0.08: 5 M columns, the depth average halves eight times; cuts fall inside live STR windows."""
+    hb = synth.generate(synth.config(name, scale=scale, seed=21))
+    p = ca.preset_params(preset)
+    eng = ca.Engine(p, 0)
+    want = eng.contig(hb)
+    eng.close()
+    _check(lambda pp: ca.Engine(pp, 0), hb, p, nw, want=want)
+
+
+@pytest.mark.gpu
+def test_gpu_windows_vs_oracle_and_long_reads(product):
+    hb = synth.generate(synth.config("chr20", scale=0.004, seed=8))
+    _check(lambda pp: ca.Engine(pp, 0), hb, ca.preset_params(5), 3)
+    hf = synth.generate(synth.config("hifi", scale=0.004, seed=9))
+    p = ca.preset_params(None, tech="pbccs")
+    eng = ca.Engine(p, 0)
+    want = eng.contig(hf)
+    eng.close()
+    _check(lambda pp: ca.Engine(pp, 0), hf, p, 3, want=want)
