@@ -50,6 +50,9 @@ static void usage(FILE *fp)
         "  -j N                    GPUs: contigs are LPT-packed onto devices 0..N-1 by reference length, one engine\n"
         "                          (and one host thread) per device, output in input order, one RCCL all-reduce of\n"
         "                          the statistics at the end\n"
+        "  -w                      with -j N: every contig is cut into N windows of about equal bases, one per device\n"
+        "                          (reads around a cut go to both sides; the running depth average and the STR window\n"
+        "                          state are handed from window to window), for inputs with fewer large contigs than GPUs\n"
         "  (devices: environment CRUMBLE_HIP_DEVICES=\"0,1,..\" or CRUMBLE_HIP_DEVICE, default 0; output level: CRUMBLE_BAM_LEVEL)\n");
 }
 
@@ -170,6 +173,170 @@ static void *writer_thread(void *p_)
     return NULL;
 }
 
+/* ---- one contig over all devices (-w): windows of about equal bases (include/crumble_hip.h "windows",
+ * crumble_amd/windows.py is the same plan and schedule in Python).  Window k owns the reads that start in
+ * [w_k, w_k+1); its batch is the slice of the contig's reads that overlap the columns it decides. */
+typedef struct {
+    int64_t lo, hi;                 /* slice of the contig's reads */
+    crumble_window w;
+    crumble_batch vb;               /* view into the contig's arrays, offsets rebased */
+    int64_t *seq_off, *cig_off;
+    uint8_t *q; size_t qcap;        /* the slice's output qualities */
+    int32_t *sus_pos; uint8_t *sus_why; int64_t n_sus;
+    int err; char errtxt[200];
+} win_t;
+typedef struct { pipe_t *p; int d, phase; win_t *w; } win_task;
+
+static void win_fail(win_t *w, int e)
+{
+    w->err = e;
+    snprintf(w->errtxt, sizeof w->errtxt, "%s (%s)", crumble_hip_strerror(e), crumble_hip_last_error());
+}
+
+static void *win_phase(void *a_)
+{
+    win_task *t = a_; pipe_t *p = t->p; win_t *w = t->w; crumble_hip *eng = p->eng[t->d];
+    int e = 0;
+    if (w->err) return NULL;
+    if (t->phase == 0) {
+        if ((e = crumble_hip_upload(eng, &w->vb)) || (e = crumble_hip_set_window(eng, &w->w)) || (e = crumble_hip_run_columns(eng))) win_fail(w, e);
+    } else if (t->phase == 1) {
+        if ((e = crumble_hip_run_triggers(eng))) win_fail(w, e);
+    } else {
+        if ((e = crumble_hip_run_finish(eng)) || (e = crumble_hip_download(eng, w->q, NULL, NULL))) { win_fail(w, e); return NULL; }
+        if (p->want_suspect) {                                   /* -b: the columns this window counts */
+            const int64_t ns = crumble_hip_suspect(eng, NULL, NULL, 0);
+            int32_t *sp = malloc((size_t)(ns > 0 ? ns : 1) * 4); uint8_t *sw = malloc((size_t)(ns > 0 ? ns : 1));
+            if (ns < 0 || !sp || !sw || crumble_hip_suspect(eng, sp, sw, ns) != ns) { w->err = CRUMBLE_ENOMEM; snprintf(w->errtxt, sizeof w->errtxt, "-b failed"); free(sp); free(sw); return NULL; }
+            int64_t k2 = 0;
+            for (int64_t k = 0; k < ns; k++) if (sp[k] >= w->w.col_start && sp[k] < w->w.stat_end) { sp[k2] = sp[k]; sw[k2] = sw[k]; k2++; }
+            w->sus_pos = sp; w->sus_why = sw; w->n_sus = k2;
+        }
+    }
+    return NULL;
+}
+
+static void win_run_phase(pipe_t *p, win_t *wins, int nw, int phase)
+{
+    pthread_t th[MAX_DEV]; win_task tk[MAX_DEV];
+    for (int k = 0; k < nw; k++) { tk[k].p = p; tk[k].d = k; tk[k].phase = phase; tk[k].w = &wins[k]; pthread_create(&th[k], NULL, win_phase, &tk[k]); }
+    for (int k = 0; k < nw; k++) pthread_join(th[k], NULL);
+}
+
+/* the whole contig of job j through up to p->ndev windows; fills j->qout */
+static void run_windowed(pipe_t *p, job *j)
+{
+    const crumble_batch *B = &j->B;
+    const int64_t n = B->n_reads, nb = n ? B->seq_off[n] : 0;
+    win_t wins[MAX_DEV];
+    int nw = 0;
+    memset(wins, 0, sizeof wins);
+    j->qcap = (size_t)nb + 64; j->qout = crumble_bam_big_alloc(j->qcap);
+    int64_t *end = malloc((size_t)(n > 0 ? n : 1) * 8), *pmax = malloc((size_t)(n > 0 ? n : 1) * 8);
+    if (!j->qout || !end || !pmax) { j->err = CRUMBLE_ENOMEM; snprintf(j->errtxt, sizeof j->errtxt, "out of memory"); goto done; }
+    if (B->tid < 0 || n < 4 * p->ndev) {                        /* the unmapped tail / a tiny contig: one device */
+        j->err = crumble_hip_contig(p->eng[0], &j->B, j->qout, NULL, NULL);
+        if (j->err) snprintf(j->errtxt, sizeof j->errtxt, "%s (%s)", crumble_hip_strerror(j->err), crumble_hip_last_error());
+        goto done;
+    }
+    for (int64_t i = 0; i < n; i++) {                           /* pos + reference length (M D N = X) */
+        int64_t rl = 0;
+        for (int64_t c = B->cig_off[i]; c < B->cig_off[i + 1]; c++) {
+            const unsigned op = B->cigar[c] & 15;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += B->cigar[c] >> 4;
+        }
+        end[i] = (int64_t)B->pos[i] + rl;
+        pmax[i] = i && pmax[i - 1] > end[i] ? pmax[i - 1] : end[i];
+    }
+    int64_t firsts[MAX_DEV + 1];
+    int nf = 0;
+    firsts[nf++] = 0;
+    for (int k = 1; k < p->ndev; k++) {
+        const int64_t target = nb / p->ndev * k;
+        int64_t lo = 0, hi = n;                                 /* first read whose bases start at or after the target */
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (B->seq_off[mid] < target) lo = mid + 1; else hi = mid; }
+        int64_t r = lo < n ? lo : n - 1;
+        while (r > 0 && B->pos[r - 1] == B->pos[r]) r--;        /* all reads of one start position go together */
+        if (r > firsts[nf - 1]) firsts[nf++] = r;
+    }
+    firsts[nf] = n;
+    nw = nf;
+    for (int k = 0; k < nw; k++) {
+        win_t *w = &wins[k];
+        const int64_t r0 = firsts[k], r1 = firsts[k + 1];
+        const int64_t w0 = B->pos[r0];
+        int64_t ek = w0;
+        for (int64_t i = r0; i < r1; i++) if (end[i] > ek) ek = end[i];
+        int64_t stat_end = r1 < n ? (int64_t)B->pos[r1] : (ek > pmax[n - 1] ? ek : pmax[n - 1]);
+        if (r1 >= n) ek = stat_end;
+        int64_t lo = 0;
+        if (k) { int64_t a = 0, b = r0; while (a < b) { const int64_t mid = (a + b) >> 1; if (pmax[mid] <= w0) a = mid + 1; else b = mid; } lo = a; }
+        int64_t hi; { int64_t a = r1, b = n; while (a < b) { const int64_t mid = (a + b) >> 1; if (B->pos[mid] < ek) a = mid + 1; else b = mid; } hi = a; }
+        if (ek > INT32_MAX || stat_end > INT32_MAX) { j->err = CRUMBLE_EINVAL; snprintf(j->errtxt, sizeof j->errtxt, "coordinate out of range"); goto done; }
+        w->lo = lo; w->hi = hi;
+        w->w.col_start = (int32_t)w0; w->w.col_end = (int32_t)ek; w->w.stat_end = (int32_t)(stat_end < ek ? stat_end : ek);
+        w->w.read_first = r0 - lo; w->w.read_end = r1 - lo;
+        const int64_t m = hi - lo, b0 = B->seq_off[lo], c0 = B->cig_off[lo];
+        w->seq_off = malloc((size_t)(m + 1) * 8); w->cig_off = malloc((size_t)(m + 1) * 8);
+        w->qcap = (size_t)(B->seq_off[hi] - b0) + 64; w->q = crumble_bam_big_alloc(w->qcap);
+        if (!w->seq_off || !w->cig_off || !w->q) { j->err = CRUMBLE_ENOMEM; snprintf(j->errtxt, sizeof j->errtxt, "out of memory"); goto done; }
+        for (int64_t i = 0; i <= m; i++) { w->seq_off[i] = B->seq_off[lo + i] - b0; w->cig_off[i] = B->cig_off[lo + i] - c0; }
+        w->vb = *B;
+        w->vb.n_reads = m; w->vb.pos = B->pos + lo; w->vb.mapq = B->mapq + lo; w->vb.flag = B->flag + lo;
+        w->vb.seq_off = w->seq_off; w->vb.cig_off = w->cig_off; w->vb.cigar = B->cigar + c0;
+        w->vb.bases = B->bases + b0; w->vb.quals = B->quals + b0;
+    }
+    {
+        crumble_carry carry, nxt;
+        crumble_carry_init(&carry);
+        win_run_phase(p, wins, nw, 0);                          /* upload + columns: all windows at once */
+        for (int k = 0; k < nw && !wins[k].err; k++) {          /* the running depth average, window to window */
+            crumble_carry_init(&nxt);
+            const int e = crumble_hip_run_depth(p->eng[k], &carry, &nxt);
+            if (e) { win_fail(&wins[k], e); break; }
+            carry.total_col = nxt.total_col; carry.total_depth = nxt.total_depth;
+        }
+        win_run_phase(p, wins, nw, 1);                          /* over-depth test, trigger lists, STR search */
+        for (int k = 0; k < nw && !wins[k].err; k++) {          /* the STR window state, window to window */
+            crumble_carry_init(&nxt);
+            const int e = crumble_hip_run_fold(p->eng[k], &carry, &nxt);
+            if (e) { win_fail(&wins[k], e); break; }
+            carry.min_pos = nxt.min_pos; carry.max_pos = nxt.max_pos; carry.min_pos2 = nxt.min_pos2; carry.max_pos2 = nxt.max_pos2;
+        }
+        win_run_phase(p, wins, nw, 2);                          /* replay, P-block, statistics, download */
+    }
+    {
+        int64_t ns = 0;
+        for (int k = 0; k < nw; k++) {
+            win_t *w = &wins[k];
+            if (w->err) { if (!j->err) { j->err = w->err; snprintf(j->errtxt, sizeof j->errtxt, "window %d: %s", k, w->errtxt); } continue; }
+            const int64_t r0 = w->w.read_first, r1 = w->w.read_end;
+            memcpy(j->qout + B->seq_off[w->lo + r0], w->q + w->seq_off[r0], (size_t)(w->seq_off[r1] - w->seq_off[r0]));
+            ns += w->n_sus;
+        }
+        if (!j->err && p->want_suspect) {
+            j->sus_pos = malloc((size_t)(ns > 0 ? ns : 1) * 4); j->sus_why = malloc((size_t)(ns > 0 ? ns : 1));
+            if (!j->sus_pos || !j->sus_why) { j->err = CRUMBLE_ENOMEM; snprintf(j->errtxt, sizeof j->errtxt, "out of memory"); }
+            else for (int k = 0; k < nw; k++) {
+                memcpy(j->sus_pos + j->n_sus, wins[k].sus_pos, (size_t)wins[k].n_sus * 4);
+                memcpy(j->sus_why + j->n_sus, wins[k].sus_why, (size_t)wins[k].n_sus);
+                j->n_sus += wins[k].n_sus;
+            }
+        }
+    }
+done:
+    for (int k = 0; k < MAX_DEV; k++) { free(wins[k].seq_off); free(wins[k].cig_off); crumble_bam_big_free(wins[k].q, wins[k].qcap); free(wins[k].sus_pos); free(wins[k].sus_why); }
+    free(end); free(pmax);
+}
+
+static void *allreduce_thread(void *a_)
+{
+    win_task *t = a_; pipe_t *p = t->p;
+    const int e = crumble_hip_stats_allreduce(p->eng[t->d], p->comm[t->d]);
+    if (e) { pthread_mutex_lock(&p->mu); p->failed = 1; fprintf(stderr, "crumble-hip: stats all-reduce on device %d: %s (%s)\n", p->devices[t->d], crumble_hip_strerror(e), crumble_hip_last_error()); pthread_mutex_unlock(&p->mu); }
+    return NULL;
+}
+
 /* lpt_pack (crumble_amd/shard.py): longest first onto the least loaded device */
 static void lpt_assign(const crumble_bam_reader *rd, int ndev, int *dev_of)
 {
@@ -194,11 +361,11 @@ int main(int argc, char **argv)
 {
     crumble_params P;
     crumble_params_default(&P);
-    int opt, verbose = 0, threads = 0, no_pg = 0, ngpu = 1;
+    int opt, verbose = 0, threads = 0, no_pg = 0, ngpu = 1, windowed = 0;
     const char *bed_fn = NULL, *wl = NULL, *bl = NULL, *in_fmt = NULL, *out_fmt = NULL;
     int bd[3] = {0, 0, 0}, bi[3] = {0, 0, 0};
     FILE *bed_fp = NULL;
-    while ((opt = getopt(argc, argv, "I:O:q:d:x:Q:D:X:m:l:u:U:c:i:L:Bs:t:T:hr:b:vC:M:Z:P:V:p:e:f:g:E:F:G:S135789zR:Y:y:k:K:N@:j:")) != -1) {
+    while ((opt = getopt(argc, argv, "I:O:q:d:x:Q:D:X:m:l:u:U:c:i:L:Bs:t:T:hr:b:vC:M:Z:P:V:p:e:f:g:E:F:G:S135789zR:Y:y:k:K:N@:j:w")) != -1) {
         switch (opt) {
         case 'q': P.min_qual_A = atoi(optarg); break;
         case 'd': P.min_indel_A = atoi(optarg); break;
@@ -233,6 +400,7 @@ int main(int argc, char **argv)
         case 'v': verbose++; break;
         case '@': threads = atoi(optarg); break;
         case 'j': ngpu = atoi(optarg); break;
+        case 'w': windowed = 1; break;
         case 'h': usage(stdout); return 0;
         case 't': wl = optarg; break;
         case 'T': bl = optarg; break;
@@ -353,7 +521,8 @@ int main(int argc, char **argv)
 
     pthread_t wt, gt[MAX_DEV]; worker_arg wa[MAX_DEV];
     pthread_create(&wt, NULL, writer_thread, &p);
-    for (int d = 0; d < ngpu; d++) { wa[d].p = &p; wa[d].d = d; pthread_create(&gt[d], NULL, gpu_worker, &wa[d]); }
+    if (!windowed)
+        for (int d = 0; d < ngpu; d++) { wa[d].p = &p; wa[d].d = d; pthread_create(&gt[d], NULL, gpu_worker, &wa[d]); }
 
     double t_read = 0;
     const double t_all = now();
@@ -378,6 +547,19 @@ int main(int argc, char **argv)
         j->B = B; j->seq = seq++;
         j->dev = (B.tid >= 0 && B.tid < nref) ? dev_of[B.tid] : 0;
         total_reads += B.n_reads; total_bases += B.seq_off[B.n_reads];
+        if (windowed) {                                         /* -w: this contig over all devices, then to the writer */
+            t0 = now();
+            run_windowed(&p, j);
+            pthread_mutex_lock(&p.mu);
+            p.t_gpu[0] += now() - t0;
+            j->done = 1; j->next = p.done_head; p.done_head = j;
+            const int failed = p.failed;
+            pthread_cond_broadcast(&p.cv);
+            while (seq - p.next_write > MAX_INFLIGHT && !p.failed) pthread_cond_wait(&p.cv, &p.mu);   /* bounds the host memory */
+            pthread_mutex_unlock(&p.mu);
+            if (failed) break;
+            continue;
+        }
         pthread_mutex_lock(&p.mu);
         while (p.q_len[j->dev] >= MAX_INFLIGHT && !p.failed) pthread_cond_wait(&p.cv, &p.mu);   /* bounds the host memory */
         if (p.q_tail[j->dev]) p.q_tail[j->dev]->next = j; else p.q_head[j->dev] = j;
@@ -388,7 +570,12 @@ int main(int argc, char **argv)
         if (failed) break;
     }
     pthread_mutex_lock(&p.mu); p.closing = 1; pthread_cond_broadcast(&p.cv); pthread_mutex_unlock(&p.mu);
-    for (int d = 0; d < ngpu; d++) pthread_join(gt[d], NULL);
+    if (!windowed) for (int d = 0; d < ngpu; d++) pthread_join(gt[d], NULL);
+    else if (p.use_rccl) {
+        win_task tk[MAX_DEV];
+        for (int d = 0; d < ngpu; d++) { tk[d].p = &p; tk[d].d = d; pthread_create(&gt[d], NULL, allreduce_thread, &tk[d]); }
+        for (int d = 0; d < ngpu; d++) pthread_join(gt[d], NULL);
+    }
     pthread_join(wt, NULL);
     if (p.failed) rc_main = p.failed == 2 ? 2 : 1;
     if (bed_fp && fclose(bed_fp)) { perror("-b"); rc_main = 1; }

@@ -383,6 +383,14 @@ def test_cli_multi_device_emulated(tmp_path):
         assert outs[j][1] == outs["1"][1] and outs[j][2] == outs["1"][2]
     want = _oracle_file(ca.preset_params(5), tmp_path / "in.bam", None)
     assert np.array_equal(_file_quals(tmp_path / "out2.bam"), want)
+    # -w: every contig cut into windows over the engines, same bytes, -b lines and statistics
+    env = dict(os.environ, CRUMBLE_HIP_DEVICES="0,0,0")
+    r = subprocess.run([exe, "-v", "-5", "-j", "3", "-w", "-b", str(tmp_path / "sw.bed"), str(tmp_path / "in.bam"), str(tmp_path / "outw.bam")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(_file_quals(tmp_path / "outw.bam"), want)
+    assert open(tmp_path / "sw.bed").read() == outs["1"][1]
+    assert [l for l in r.stderr.splitlines() if l.split() and l.split()[0] in ("columns", "bases", "bases_changed", "triggers", "reads")] == outs["1"][2]
 
 
 def _oracle_bed(params, path):
@@ -517,6 +525,14 @@ def test_cli_multi_device_and_options_gpu(tmp_path):
     for j in (2, 3):
         assert np.array_equal(outs[j][0], outs[1][0]) and outs[j][1] == outs[1][1] and outs[j][2] == outs[1][2]
     assert outs[1][1] == "".join(_oracle_bed(ca.preset_params(5), tmp_path / "in.bam"))
+    # (1b) -w: every contig cut into windows over the engines
+    for j in (2, 3):
+        devs = ",".join(str(k if ndev >= j else 0) for k in range(j))
+        r = subprocess.run([exe, "-v", "-5", "-j", str(j), "-w", "-b", str(tmp_path / "sw.bed"), str(tmp_path / "in.bam"), str(tmp_path / "outw.bam")],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=dict(os.environ, CRUMBLE_HIP_DEVICES=devs))
+        assert r.returncode == 0, r.stderr
+        stats = [l for l in r.stderr.splitlines() if l.split() and l.split()[0] in ("columns", "bases", "bases_changed", "triggers", "reads", "hom_B", "indel")]
+        assert np.array_equal(_file_quals(tmp_path / "outw.bam"), want) and open(tmp_path / "sw.bed").read() == outs[1][1] and stats == outs[1][2]
     # (2) purge_tags and @PG through the real binary
     raw = py_bam(refs, [dict(tid=0, pos=100 + i, cigar=[(50 << 4)], seq=[1] * 50, qual=[30] * 50, name=f"t{i}",
                              aux=b"NMC\x01BDZ" + bytes([40 + i, 70]) + b"\0BIZ" + bytes([36 + i, 80]) + b"\0XSZab\0") for i in range(5)])
