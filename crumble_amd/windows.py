@@ -122,3 +122,40 @@ def run(engines, hb, n_windows=None):
         f[lo + r0:lo + r1] = wf[r0:r1]
         stats += ws
     return q, f, stats
+
+
+def run_rank(engine, hb, dist, n_windows=None):
+    """The same protocol with one process per window (torch.distributed: rank k takes window k; ranks beyond the
+    number of windows idle).  The carried state travels rank to rank as two point-to-point messages (2 and 4
+    integers); there is no collective on the data path.  Returns (lo, hi, Window, qualities, flags, statistics) of
+    this rank's slice -- only the owned reads [read_first, read_end) of it are final -- or None for an idle rank."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    wins = plan(hb, n_windows or world)
+    if rank >= len(wins):
+        return None
+    lo, hi, w = wins[rank]
+    sb = _slice(hb, lo, hi)
+    engine.upload(sb)
+    engine.set_window(w)
+    engine.run_columns()
+    carry, nxt = Carry.start(), Carry.start()
+    last = len(wins) - 1
+    if rank > 0:
+        t = torch.zeros(2, dtype=torch.int64)
+        dist.recv(t, src=rank - 1)
+        carry.total_col, carry.total_depth = int(t[0]), int(t[1])
+    engine.run_depth(carry, nxt)
+    if rank < last:
+        dist.send(torch.tensor([nxt.total_col, nxt.total_depth], dtype=torch.int64), dst=rank + 1)
+    engine.run_triggers()
+    if rank > 0:
+        t = torch.zeros(4, dtype=torch.int64)
+        dist.recv(t, src=rank - 1)
+        carry.min_pos, carry.max_pos, carry.min_pos2, carry.max_pos2 = (int(x) for x in t)
+    engine.run_fold(carry, nxt)
+    if rank < last:
+        dist.send(torch.tensor([nxt.min_pos, nxt.max_pos, nxt.min_pos2, nxt.max_pos2], dtype=torch.int64), dst=rank + 1)
+    engine.run_finish()
+    q, f, s = engine.download()
+    return lo, hi, w, q, f, s

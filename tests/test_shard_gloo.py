@@ -75,3 +75,51 @@ def test_world_size_2_stats_allreduce(product):
         want += O.contig(p, hb)[2]
     assert np.array_equal(res[0], want) and np.array_equal(res[1], want)
     assert want[ca.ST_HIST0:].sum() == want[ca.ST_NAMES.index("bases")]
+
+
+def _window_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    import emu_lib
+    from crumble_amd import windows
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hb = synth.generate(synth.config("chr20", scale=0.0006, seed=41), threads=2)     # every rank sees the contig
+    p = ca.preset_params(5)
+    eng = emu_lib.engine(p, kcol=("v1", "v2")[rank & 1])
+    lo, hi, w, wq, wf, ws = windows.run_rank(eng, hb, dist)
+    total = shard.allreduce_stats(eng.stats_read(), dist)
+    eng.close()
+    r0, r1 = lo + int(w.read_first), lo + int(w.read_end)
+    b0 = int(hb.seq_off[r0]) - int(hb.seq_off[lo])
+    own_q = wq[b0:b0 + int(hb.seq_off[r1] - hb.seq_off[r0])]
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, r0, r1, own_q, wf[int(w.read_first):int(w.read_end)], total))
+
+
+def test_world_size_2_one_contig_in_windows(product):
+    """One contig cut into two windows, one process (and one emulated engine) per window: the carried depth average
+    and STR window state travel rank to rank (crumble_amd/windows.py run_rank); owned bytes + flags of both ranks
+    put together and the all-reduced statistics equal the oracle's run of the whole contig."""
+    import torch.multiprocessing as mp
+    import oracle_lib as O
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_window_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    hb = synth.generate(synth.config("chr20", scale=0.0006, seed=41), threads=2)
+    wq, wf, ws = O.contig(ca.preset_params(5), hb)
+    assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == hb.n_reads and res[0][2] > 0
+    for rank, r0, r1, oq, of, total in res:
+        assert np.array_equal(oq, wq[int(hb.seq_off[r0]):int(hb.seq_off[r1])]), rank
+        assert np.array_equal(of, wf[r0:r1]), rank
+        assert np.array_equal(total, ws), rank
