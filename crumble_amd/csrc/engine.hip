@@ -682,12 +682,14 @@ extern "C" int crumble_hip_run_columns(crumble_hip *h)
         if (v2) {
             unsigned g2 = (h->persistent_blocks + 3) / 4;       /* one workgroup of KC2_WAVES waves per CU */
             if (g2 > nblk(B.n_tiles, KC2_WAVES)) g2 = nblk(B.n_tiles, KC2_WAVES);
-#define KCOL2_LAUNCH3(MQ_, AP_, MU_) CRUMBLE_LAUNCH((k_columns2<MQ_, AP_, MU_>), g2, KC2_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, ht, stats, (unsigned *)(d_overflow + 3))
+#define KCOL2_LAUNCH4(MQ_, AP_, MU_, W_) CRUMBLE_LAUNCH((k_columns2<MQ_, AP_, MU_, W_>), g2, KC2_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, ht, stats, (unsigned *)(d_overflow + 3))
+#define KCOL2_LAUNCH3(MQ_, AP_, MU_) do { if (h->windowed) KCOL2_LAUNCH4(MQ_, AP_, MU_, true); else KCOL2_LAUNCH4(MQ_, AP_, MU_, false); } while (0)
 #define KCOL2_LAUNCH(MQ_, AP_) do { if (multi) KCOL2_LAUNCH3(MQ_, AP_, true); else KCOL2_LAUNCH3(MQ_, AP_, false); } while (0)
             if (modeB) { if (h->hparams.any_preserve) KCOL2_LAUNCH(true, true); else KCOL2_LAUNCH(true, false); }
             else       { if (h->hparams.any_preserve) KCOL2_LAUNCH(false, true); else KCOL2_LAUNCH(false, false); }
 #undef KCOL2_LAUNCH
 #undef KCOL2_LAUNCH3
+#undef KCOL2_LAUNCH4
         }
         else if (modeA && modeB) KCOL_LAUNCH(2);
         else if (modeB)     KCOL_LAUNCH(1);

@@ -142,7 +142,7 @@ struct __attribute__((aligned(16))) KC2Wave {      /* one wave's LDS */
 struct __attribute__((aligned(16))) KC2Lds {
     double   row[KC2_NROWTAB * 4];
     double   e[KC2_LDS_EXP ? CONS_NEXP : 2];
-    unsigned stat[64];                            /* [32..63]: columns outside the window's statistics range */
+    unsigned stat[32];
     uint8_t  adjc[KC2_SLOTS * 128];
     uint8_t  pv[128];
     uint4    mask_lt[17], mask_ge[17];             /* producer: byte k of [a] = 0x08 | (k < a ? 0x70 : 0); of [b] = (k >= b ? 0x70 : 0) */
@@ -256,8 +256,10 @@ struct __attribute__((aligned(16))) KC2Lds {
 #endif
 
 /* MQ: the active consensus uses CONS_MQUAL (mode B, snp:1535); ANYPRES: -k/-K/-y pbccs set preserve_qual[];
- * MULTI: long reads (many ops per read: candidates are screened by their first 8 bytes) */
-template <bool MQ, bool ANYPRES, bool MULTI>
+ * MULTI: long reads (many ops per read: candidates are screened by their first 8 bytes); WIN: the batch is a window
+ * of a contig (crumble_hip_set_window: columns outside [col_lo, col_hi) read as empty, columns from stat_hi on stay
+ * out of the statistics) -- its own instances, the whole-contig ones carry none of it */
+template <bool MQ, bool ANYPRES, bool MULTI, bool WIN>
 __global__ void __launch_bounds__(KC2_THREADS)
 k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T,
            uint32_t *__restrict__ colrec, int32_t *__restrict__ nplp_out,
@@ -276,7 +278,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
     unsigned *const sStat = L.stat;
     KC2Wave *const sWave = L.wave;
     const int hot_mq = MQ ? B.hot_mq : -1;
-    if (threadIdx.x < 64) sStat[threadIdx.x] = 0;
+    if (threadIdx.x < 32) sStat[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < KC2_NROWTAB; i += blockDim.x) {
         const int a = i >= 128 ? i - 128 : (MQ ? (int)T->adjc[hot_mq * 256 + i] : (int)T->capc[i]);
         sRow[i * 4] = T->MMd[a]; sRow[i * 4 + 1] = T->_Md[a]; sRow[i * 4 + 2] = T->omq[a];
@@ -321,7 +323,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
         const int c = tile * 64 + lane;
         const int apos = B.p0 + c;
         const bool inr = c < B.L;
-        if (tile * 64 + 63 < B.col_lo || tile * 64 >= B.col_hi) {       /* outside the window: empty columns */
+        if (WIN && (tile * 64 + 63 < B.col_lo || tile * 64 >= B.col_hi)) {       /* outside the window: empty columns */
             if (inr) { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; }
             continue;
         }
@@ -638,9 +640,9 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
 #endif
         if (key) col_unpermute(st.S, st.sC, (int)key);  /* back to the reference's A C G T numbering */
         if (inr) {
-            if (c >= B.col_lo && c < B.col_hi)          /* (columns at or beyond stat_hi count into the unused upper half) */
+            if (!WIN || (c >= B.col_lo && c < B.col_hi))
                 col_decide<MQ ? 1 : 0>(st, B, P, T, c, apos, true, colrec, nplp_out, score_out, trigcnt,
-                                       c < B.stat_hi ? sStat : sStat + 32, KC2_LDS_EXP ? sE : (const double *)nullptr);
+                                       sStat, KC2_LDS_EXP ? sE : (const double *)nullptr, WIN ? c < B.stat_hi : true);
             else { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; }
         }
         KC2_STAMP(4);

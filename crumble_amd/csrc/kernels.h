@@ -306,7 +306,7 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
                                            const DTables *__restrict__ T, int c, int apos, bool use_cons,
                                            uint32_t *__restrict__ colrec, int32_t *__restrict__ nplp_out,
                                            int32_t *__restrict__ score_out, int32_t *__restrict__ trigcnt, unsigned *stats,
-                                           const double *sE = nullptr)
+                                           const double *sE = nullptr, const bool cnt = true)
 {
     const int n_plp = st.n_plp;
     if (n_plp == 0) { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; return; }
@@ -320,9 +320,9 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
         return;
     }
     rec |= CR_COUNTED;
-    lds_inc(stats, ST_COLUMNS, true);
+    lds_inc(stats, ST_COLUMNS, cnt && (true));
     if (n_plp > MAX_DEPTH_COL) {                       /* snp:1493-1500 */
-        lds_inc(stats, ST_TOO_DEEP, true);
+        lds_inc(stats, ST_TOO_DEEP, cnt && (true));
         colrec[c] = rec | CR_TOODEEP; score_out[c] = 0; trigcnt[c] = 0;
         return;
     }
@@ -342,9 +342,9 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
             if (het) { a1 = coA.het_call / 5; a2 = coA.het_call % 5; } else { a1 = a2 = coA.call; }
             hA = het ? coA.het_call : coA.call * 5 + coA.call;
             sA = het ? coA.het_phred : coA.phred;
-            lds_inc(stats, ST_HET_A, het); lds_inc(stats, ST_HET_QUAL_A, het && sA < P->min_qual_A);
-            lds_inc(stats, ST_HOM_A, !het); lds_inc(stats, ST_HOM_QUAL_A, !het && sA < P->min_qual_A);
-            lds_inc(stats, ST_DISCREP_A, coA.discrep >= P->min_discrep_A);
+            lds_inc(stats, ST_HET_A, cnt && (het)); lds_inc(stats, ST_HET_QUAL_A, cnt && (het && sA < P->min_qual_A));
+            lds_inc(stats, ST_HOM_A, cnt && (!het)); lds_inc(stats, ST_HOM_QUAL_A, cnt && (!het && sA < P->min_qual_A));
+            lds_inc(stats, ST_DISCREP_A, cnt && (coA.discrep >= P->min_discrep_A));
             if ((int)cp != (1 << coA.call)) perfect = 0;                 /* snp:1606 */
         }
         if (useB) {                                    /* snp:1534-1543, 1584-1591, 1610-1622 */
@@ -353,11 +353,11 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
             if (het) { a1 = coB.het_call / 5; a2 = coB.het_call % 5; } else { a1 = a2 = coB.call; }
             hB = het ? coB.het_call : coB.call * 5 + coB.call;
             sB = het ? coB.het_phred : coB.phred;
-            lds_inc(stats, ST_HET_B, het); lds_inc(stats, ST_HET_QUAL_B, het && sB < P->min_qual_B);
-            lds_inc(stats, ST_HOM_B, !het); lds_inc(stats, ST_HOM_QUAL_B, !het && sB < P->min_qual_B);
-            lds_inc(stats, ST_DISCREP_B, coB.discrep >= P->min_discrep_B);
+            lds_inc(stats, ST_HET_B, cnt && (het)); lds_inc(stats, ST_HET_QUAL_B, cnt && (het && sB < P->min_qual_B));
+            lds_inc(stats, ST_HOM_B, cnt && (!het)); lds_inc(stats, ST_HOM_QUAL_B, cnt && (!het && sB < P->min_qual_B));
+            lds_inc(stats, ST_DISCREP_B, cnt && (coB.discrep >= P->min_discrep_B));
         }
-        if (MODE == 2) lds_inc(stats, ST_DIFF, hA != hB);                /* snp:1593 */
+        if (MODE == 2) lds_inc(stats, ST_DIFF, cnt && (hA != hB));                /* snp:1593 */
         preserve |= ((MODE == 2 && hA != hB) || (useA && sA < P->min_qual_A) || (useB && sB < P->min_qual_B)) ? 1 : 0;   /* snp:1624 */
         preserve |= ((useA && coA.discrep >= P->min_discrep_A) || (useB && coB.discrep >= P->min_discrep_B)) ? 1 : 0;   /* float vs double */
         if (useA && !preserve) {                                         /* snp:1633-1638 */
@@ -373,17 +373,17 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
 
     bool why_clip = false;
     bool keep = (double)st.low_mq > P->low_mqual_perc * (n_plp + .01);   /* snp:1668 */
-    lds_inc(stats, ST_LOW_MQUAL_PERC, keep);
+    lds_inc(stats, ST_LOW_MQUAL_PERC, cnt && (keep));
     if ((st.clipped - 1.0) >= P->clip_perc * st.n_overlap) {          /* snp:1764 */
         keep = true;
         why_clip = true;
-        lds_inc(stats, ST_CLIP_PERC, true);
+        lds_inc(stats, ST_CLIP_PERC, cnt && (true));
     }
     if (cond_score)                                                   /* snp:1718 */
         tcnt = (P->str_snp && preserve) ? (n_plp - st.nref) : st.n_isindel;
-    lds_inc(stats, ST_INDEL, st.indel_cnt > 0);                      /* snp:1761 */
-    lds_inc(stats, ST_INDEL_QUAL, cond_score && st.n_isindel > 0);   /* snp:1762 */
-    if (tcnt) atomicAdd(&stats[ST_TRIGGERS], (unsigned)tcnt);
+    lds_inc(stats, ST_INDEL, cnt && (st.indel_cnt > 0));                      /* snp:1761 */
+    lds_inc(stats, ST_INDEL_QUAL, cnt && (cond_score && st.n_isindel > 0));   /* snp:1762 */
+    if (tcnt && cnt) atomicAdd(&stats[ST_TRIGGERS], (unsigned)tcnt);
 
     rec |= (uint32_t)a1 | ((uint32_t)a2 << 3) | ((uint32_t)preserve << 6);
     if (perfect) rec |= CR_PERFECT;
@@ -481,12 +481,12 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
     __shared__ double sTab[101 * 4];                       /* [aq] -> {MM, _M, 1 - q2p, -} : one 32-byte LDS row */
     constexpr bool MQ = MODE != 0;                          /* the active consensus uses CONS_MQUAL */
     __shared__ uint8_t sAdj[MQ ? 256 * 128 : 16];
-    __shared__ unsigned sStat[64];                  /* [32..63]: columns outside the window's statistics range */
+    __shared__ unsigned sStat[32];
     /* composed row table of the batch's dominant mapq: sHot[q] = sTab[adj[hot_mq][q]], so that most
      * records need one dependent LDS round trip instead of two */
     __shared__ double sHot[MQ ? 128 * 4 : 4];
     const int hot_mq = MQ ? B.hot_mq : -1;
-    if (threadIdx.x < 64) sStat[threadIdx.x] = 0;
+    if (threadIdx.x < 32) sStat[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < 101; i += blockDim.x) {
         sTab[i * 4] = T->MMd[i]; sTab[i * 4 + 1] = T->_Md[i]; sTab[i * 4 + 2] = T->omq[i]; sTab[i * 4 + 3] = 0;
     }
@@ -730,7 +730,7 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
         }
         if (inr) {
             if (c >= B.col_lo && c < B.col_hi)
-                col_decide<MODE>(st, B, P, T, c, apos, use_cons, colrec, nplp_out, score_out, trigcnt, c < B.stat_hi ? sStat : sStat + 32);
+                col_decide<MODE>(st, B, P, T, c, apos, use_cons, colrec, nplp_out, score_out, trigcnt, sStat, nullptr, c < B.stat_hi);
             else { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; }
         }
     }
