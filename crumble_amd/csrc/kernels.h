@@ -1994,7 +1994,7 @@ __global__ void k_replay_general(DBatch B, const DParams *__restrict__ P, const 
  * the entry's own qpos (the entry's own byte is handled by apply_col). */
 __global__ void __launch_bounds__(64)
 k_restore(DBatch B, const DParams *__restrict__ P, int n_trig, const int32_t *trigcol_pos,
-          const int32_t *__restrict__ pos_mn2, uint8_t *__restrict__ out, int coop)
+          const int32_t *__restrict__ pos_mn2, const int32_t *__restrict__ trig_mx2, uint8_t *__restrict__ out, int coop)
 {
     /* one wave per trigger column.  Step 1: every lane resolves one candidate read (entry, start of
      * the back-fill in query coordinates).  Step 2: the wave writes the ranges one read at a time,
@@ -2007,6 +2007,11 @@ k_restore(DBatch B, const DParams *__restrict__ P, int n_trig, const int32_t *tr
     const int lo = B.tile_lo[tile], hi = B.tile_hi[tile];
     const int mn2 = pos_mn2[c], qcap = P->qcap;
     const bool any_pres = P->any_preserve != 0, softclip = P->softclip != 0;
+    /* The next trigger column, when no reset lies between (pos <= max_pos2 after this column, snp:1508): min_pos2 only
+     * falls along such a chain, so for a one-match-op read that also covers the next column, the next column's range
+     * [ref2query_pos(min_pos2'), qpos') contains this one's and writes the same bytes -- this column leaves the read
+     * to it (runs of trigger columns over an STR rewrote the same bytes once per column) */
+    const int nxt_apos = (t + 1 < n_trig && B.p0 + trigcol_pos[t + 1] <= trig_mx2[t]) ? B.p0 + trigcol_pos[t + 1] : INT_MAX;
     for (int r0 = lo; r0 < hi; r0 += 64) {
         const int r = r0 + lane;
         int start = 0, stop = 0;
@@ -2018,7 +2023,8 @@ k_restore(DBatch B, const DParams *__restrict__ P, int n_trig, const int32_t *tr
                 /* one match op (clips around it at most): qpos and ref2query_pos (snp:1156) in closed form
                  * from the 32-byte read record instead of the op table, the offsets and the CIGAR */
                 const int qp = rr.q0 + (apos - rp);
-                if (qp < rr.lq) {
+                const bool later = nxt_apos < rr.end && rr.q0 + (nxt_apos - rp) < rr.lq;
+                if (qp < rr.lq && !later) {
                     start = mn2 <= rp ? 0 : rr.q0 + (mn2 - rp);
                     stop = qp;
                     so_lo = (unsigned)(uint64_t)rr.so; so_hi = (unsigned)((uint64_t)rr.so >> 32);
