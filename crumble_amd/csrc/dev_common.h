@@ -30,6 +30,10 @@ struct DParams {
     double  clip_perc, ins_len_perc, over_depth, indel_ov_perc;
     int32_t str_snp;        /* sSTR_add || sSTR_mul          snp:1345 */
     int32_t any_preserve;   /* any preserve_qual[] non-zero            */
+    /* the preserved qualities as a short list, for the packed replay (k_replay_fast): n_pv = -1 when there are more
+     * than four of them or one is >= 128 (then only the byte-wise kernels apply) */
+    int32_t n_pv;
+    uint8_t pv_val[4], pv_lvl[4];
     uint8_t preserve_qual[256];
     uint8_t bin2[256];      /* init_bins                     snp:234  */
 };
@@ -82,6 +86,19 @@ struct ReadRec {
                              * CIX_UNIT entries (every read's slice is padded to a multiple: 2^32 * 16 entries reachable) */
 };
 
+/* Long-read batches, replay: the base array cut into territories, one per reference-consuming op of a read (bases
+ * from the op's first query base up to the next op's) plus one in front of every read (leading clip; the whole read
+ * when it is outside the pileup).  A match op's territory starts with its aligned bases, so k_replay_fast treats a
+ * territory exactly like a single-match read: slot = seg_off[r] + r + (1 + op index). */
+struct VRec {
+    int64_t  so;            /* first byte of the territory in the flat base array                */
+    int32_t  pos, end;      /* reference span of a match op; end == pos: no aligned bases here   */
+    int32_t  lq;            /* bytes in the territory                                            */
+    int32_t  q0;            /* (0: aligned bases start the territory)                            */
+    int32_t  hcol;          /* head column of a low-mapq read (snp:1852), -1: no mark            */
+    int32_t  read;          /* the read, for the per-read flags                                  */
+};
+
 /* One reference-consuming CIGAR op of one read, self-contained, in file order: the unit
  * the column kernel iterates over (a read with k such ops contributes k consecutive
  * records, so every record is "one op covering [pos,end)" and the kernel has one path). */
@@ -118,6 +135,8 @@ struct DBatch {
     const Seg *segs;
     const ReadRec *rr;
     const int32_t *cix;     /* per base of every non-simple read: column (pos-p0), -1 none, -2 general routine */
+    const VRec *vr;         /* long-read batches: territories (see VRec); n_vrec of them, chunk table in chunk_read */
+    int64_t n_vrec;
     const SegRec *sr;
     const int32_t *stile_lo, *stile_hi;   /* candidate SegRec range per 64-column tile */
     const int32_t *unit_first;            /* [n_units+1] first tile of every KCOL_UNIT-sized slice of the tiles' cost prefix */

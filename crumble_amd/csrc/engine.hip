@@ -57,7 +57,7 @@ struct crumble_hip {
     DParams hparams;
     DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc, d_mqslot;
     /* batch (inputs) */
-    DevBuf d_pbdirty, d_ufirst, d_tcum, d_tpart, d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
+    DevBuf d_vrec, d_pbdirty, d_ufirst, d_tcum, d_tpart, d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
            d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax;
     /* per position */
     DevBuf d_colrec, d_nplp, d_score, d_trigcnt, d_dpre, d_col_ord, d_trig_ord, d_item_off,
@@ -75,6 +75,8 @@ struct crumble_hip {
     int opt_pblock = 0;             /* 0 auto, 1 one lane per read, 2 segment-parallel */
     int opt_replay = 0;             /* 0 auto, 1 k_replay_flat */
     int64_t n_reads = 0, n_bases = 0, n_cigar = 0, n_slow = 0, n_segrec = 0;
+    bool packed_ok = false;         /* the packed replay's value formulas hold for these parameters (set at create) */
+    bool have_vrec = false;         /* long-read batch: territories + chunk table built (k_p0_vrecs) */
     ScanVal totals;
     /* window of a contig (crumble_hip_set_window) and the phase the run is in */
     bool windowed = false;
@@ -172,6 +174,12 @@ static int fill_dparams(const crumble_params *p, DParams *d)
         if (p->preserve_qual[i]) d->any_preserve = 1;
     }
     crumble_init_bins(p, d->bin2);
+    d->n_pv = 0;                                    /* the preserved qualities as a short list (packed replay) */
+    for (int i = 0; i < 256 && d->n_pv >= 0; i++)
+        if (p->preserve_qual[i]) {
+            if (i >= 128 || d->n_pv == 4) { d->n_pv = -1; break; }
+            d->pv_val[d->n_pv] = (uint8_t)i; d->pv_lvl[d->n_pv] = p->preserve_qual[i]; d->n_pv++;
+        }
     /* fences */
     if (p->qcap < 0 || p->qcap > 100 || p->qlow < 0 || p->qlow > 127 || p->qhigh < 0 || p->qhigh > 127) {
         g_last_error = "qcap must be in 0..100 and qlow/qhigh in 0..127 (SURVEY.md Q5/Q13)";
@@ -204,6 +212,14 @@ extern "C" crumble_hip *crumble_hip_create(const crumble_params *p, int device, 
     h->device = device;
     h->params = *p;
     if ((e = fill_dparams(p, &h->hparams)) != CRUMBLE_OK) return fail(e);
+    {   /* k_replay_fast's packed formulas: no -S, byte values that leave bit 7 free, at most four preserved qualities
+         * (all < 128), and in binary mode bin2[] == (q >= qcutoff ? qhigh : qlow) on the values a base can have */
+        const DParams &d = h->hparams;
+        bool ok = !d.softclip && d.qcutoff >= 0 && d.qcutoff < 128 && d.qcap < 128 && d.n_pv >= 0;
+        if (ok && d.reduce_qual && d.binary_qual)
+            for (int q = 0; q < 128; q++) if (d.bin2[q] != (q >= d.qcutoff ? d.qhigh : d.qlow)) ok = false;
+        h->packed_ok = ok;
+    }
     if (hipSetDevice(device) != hipSuccess) { g_last_error = "hipSetDevice failed"; return fail(CRUMBLE_EHIP); }
     if (hipStreamCreate(&h->stream) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(CRUMBLE_EHIP); }
     for (int i = 0; i <= MAX_STAGES; i++)
@@ -245,7 +261,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    DevBuf *all[] = { &h->d_params, &h->d_tables, &h->d_stats, &h->d_batch_stats, &h->d_misc, &h->d_mqslot,
+    DevBuf *all[] = { &h->d_vrec, &h->d_params, &h->d_tables, &h->d_stats, &h->d_batch_stats, &h->d_misc, &h->d_mqslot,
         &h->d_ufirst, &h->d_tcum, &h->d_tpart, &h->d_pbdirty, &h->d_pbwmm, &h->d_act, &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
         &h->d_slow_g, &h->d_slow_r, &h->d_cix, &h->d_sr, &h->d_stile_lo, &h->d_stile_hi, &h->d_rr, &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
         &h->d_cigar, &h->d_segs, &h->d_bases, &h->d_quals, &h->d_tile_lo, &h->d_tile_hi,
@@ -500,6 +516,16 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
                     CRUMBLE_LAUNCH_INDEP(k_p0_chunkread, nblk(nch, 256), 256, st, nch, n, h->d_seq_off.as<int64_t>(),
                                          h->d_blk_read.as<int32_t>(), h->d_chunk_read.as<int32_t>());
             }
+            h->have_vrec = false;
+            if (tot.nseg > n + n / 2 && h->packed_ok && tot.nseg + n < (int64_t)INT_MAX - 64) {
+                /* long reads: one territory per reference-consuming op (+ one per read) and the chunk -> territory
+                 * table: k_replay_fast<VREC> then treats a match op like a single-match read */
+                const int64_t nv = tot.nseg + n;
+                if ((e = h->d_vrec.reserve((size_t)(nv + 1) * sizeof(VRec)))) return e;
+                CRUMBLE_LAUNCH_INDEP(k_p0_vrecs, nblk(n, 256), 256, st, n, nb, B.p0, h->hparams.min_mqual, h->d_rr.as<ReadRec>(),
+                                     h->d_seg_off.as<int64_t>(), h->d_segs.as<Seg>(), h->d_vrec.as<VRec>(), h->d_chunk_read.as<int32_t>());
+                B.n_vrec = nv; h->have_vrec = true;
+            }
         }
     }
     B.pos = h->d_pos.as<int32_t>(); B.end = h->d_end.as<int32_t>();
@@ -507,6 +533,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     B.seq_off = h->d_seq_off.as<int64_t>(); B.cig_off = h->d_cig_off.as<int64_t>();
     B.seg_off = h->d_seg_off.as<int64_t>(); B.cigar = h->d_cigar.as<uint32_t>();
     B.segs = h->d_segs.as<Seg>(); B.rr = h->d_rr.as<ReadRec>(); B.cix = h->d_cix.as<int32_t>();
+    B.vr = h->d_vrec.as<VRec>(); if (!h->have_vrec) B.n_vrec = 0;
     B.sr = h->d_sr.as<SegRec>(); B.stile_lo = h->d_stile_lo.as<int32_t>(); B.stile_hi = h->d_stile_hi.as<int32_t>();
     B.unit_first = h->d_ufirst.as<int32_t>();
     B.bases = h->d_bases.as<uint8_t>() + BASE_FRONT_PAD; B.quals = h->d_quals.as<uint8_t>() + BASE_FRONT_PAD;
@@ -824,18 +851,23 @@ extern "C" int crumble_hip_run_finish(crumble_hip *h)
             CRUMBLE_LAUNCH_INDEP(k_replay_general, nblk(nb, 256), 256, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
                                  h->d_blk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(),
                                  h->d_b15f.as<uint8_t>());
-        else if (nb > 0 && !(h->n_segrec > h->n_reads + h->n_reads / 2) && !h->hparams.any_preserve && h->hparams.qcutoff >= 0 && h->hparams.qcutoff < 128 &&
-                 h->hparams.qcap < 128 && h->opt_replay != 1) {
-            /* short reads, no -k/-K/-S: action bytes + packed 16-base chunks + per-read edges (kernels.h) */
+        else if (nb > 0 && h->packed_ok && h->opt_replay != 1 && (!(h->n_segrec > h->n_reads + h->n_reads / 2) || h->have_vrec)) {
+            /* action bytes + packed 16-base chunks (kernels.h): per read for short reads (+ the general-CIGAR reads
+             * one at a time), per reference-consuming op for long reads */
             int ea;
             if ((ea = h->d_act.reserve((size_t)L + 2 * ACT_PAD))) return ea;
             uint8_t *act = h->d_act.as<uint8_t>() + ACT_PAD;
             if (L > 0) CRUMBLE_LAUNCH_INDEP(k_actions, nblk(L, 256), 256, st, L, colrec, act);
-            CRUMBLE_LAUNCH_INDEP(k_replay_fast, nblk((nb + 15) / 16, 256), 256, st, B, P, colrec, act,
-                                 h->d_chunk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(),
-                                 h->d_b15f.as<uint8_t>());
-            CRUMBLE_LAUNCH(k_replay_reads, nblk(n, 256), 256, st, B, P, colrec,
-                           h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(), h->d_b15f.as<uint8_t>());
+#define RFAST_LAUNCH(V_, PV_) CRUMBLE_LAUNCH_INDEP((k_replay_fast<V_, PV_>), nblk((nb + 15) / 16, 256), 256, st, B, P, colrec, act, \
+                                     h->d_chunk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(), h->d_b15f.as<uint8_t>())
+            const bool pv = h->hparams.n_pv > 0;
+            if (h->have_vrec) { if (pv) RFAST_LAUNCH(true, true); else RFAST_LAUNCH(true, false); }
+            else {
+                if (pv) RFAST_LAUNCH(false, true); else RFAST_LAUNCH(false, false);
+                CRUMBLE_LAUNCH(k_replay_reads, nblk(n, 256), 256, st, B, P, colrec,
+                               h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(), h->d_b15f.as<uint8_t>());
+            }
+#undef RFAST_LAUNCH
             if (h->n_slow > 0)
                 CRUMBLE_LAUNCH_INDEP(k_replay_slow, nblk(h->n_slow, 64), 64, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
                                      h->d_misc.as<int>() + 11, h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(),

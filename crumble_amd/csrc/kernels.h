@@ -1767,6 +1767,7 @@ k_replay_flat(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
  *                     bit  4    value stays (skipped column, or preserve != 0)
  *                     bit  5    window column: capped original (snp:1880)
  *                     bit  6    the column sets a per-read flag (keep_qual / bit 15): rare follow-up
+ *                     bit  7    perfect column (a quality preserved at level 1 is not kept there, snp:1885)
  *   k_replay_fast   one lane per 16-byte chunk of the flat base array.  For every single-match read
  *                   that overlaps the chunk, 16 qualities, 16 bases and the 16 action bytes of the
  *                   columns they would sit on are combined with packed byte arithmetic (values < 128
@@ -1787,6 +1788,7 @@ __global__ void k_actions(int L, const uint32_t *__restrict__ colrec, uint8_t *_
     if (skip || pres) a |= 16u;
     if (!skip && (r & CR_WIN)) a |= 32u;
     if (!skip && ((r & CR_KEEP) || pres > 1)) a |= 64u;
+    if (r & CR_PERFECT) a |= 128u;
     act[c] = (uint8_t)a;
 }
 
@@ -1795,6 +1797,21 @@ __global__ void k_actions(int L, const uint32_t *__restrict__ colrec, uint8_t *_
 #define PB_NZ(x)     (((((x) + 0x7f7f7f7fu) & 0x80808080u) >> 7) * 0xffu)             /* bytes where x != 0 (x < 128)    */
 #define ACT_PAD 64   /* bytes in front of act[0]: a chunk may start up to 15 columns before the read */
 
+/* the owner of a byte range: a read (short-read batches: ReadRec) or a territory of a read (long-read batches:
+ * VRec, one per reference-consuming op); both carry so, pos, end, lq, q0 */
+__device__ __forceinline__ bool rf_aligned(const ReadRec &x) { return (x.info & RR_SIMPLE) && x.end > x.pos; }
+__device__ __forceinline__ bool rf_aligned(const VRec &x) { return x.end > x.pos; }
+/* low-mapq read whose head column is live: snp:1852 */
+__device__ __forceinline__ bool rf_headmark(const ReadRec &x, const DBatch &B, int min_mqual, const uint32_t *__restrict__ colrec)
+{ return (int)(x.info & 255) <= min_mqual && !(colrec[x.pos - B.p0] & CR_SKIP); }
+__device__ __forceinline__ bool rf_headmark(const VRec &x, const DBatch &, int, const uint32_t *__restrict__ colrec)
+{ return x.hcol >= 0 && !(colrec[x.hcol] & CR_SKIP); }
+__device__ __forceinline__ int64_t rf_read(const ReadRec &, int64_t r) { return r; }
+__device__ __forceinline__ int64_t rf_read(const VRec &x, int64_t) { return x.read; }
+template <bool VREC> struct RfSel { typedef ReadRec T; static __device__ __forceinline__ const T *tab(const DBatch &B) { return B.rr; } };
+template <> struct RfSel<true> { typedef VRec T; static __device__ __forceinline__ const T *tab(const DBatch &B) { return B.vr; } };
+
+template <bool VREC, bool PV>
 __global__ void __launch_bounds__(256)
 k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restrict__ colrec,
               const uint8_t *__restrict__ act, const int32_t *__restrict__ chunk_read,
@@ -1808,9 +1825,12 @@ k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
     uint32_t ow[4] = {qw[0] & 0x7f7f7f7fu, qw[1] & 0x7f7f7f7fu, qw[2] & 0x7f7f7f7fu, qw[3] & 0x7f7f7f7fu};
     const uint32_t QC = PB4(P->qcap), QH = PB4(P->qhigh), QL = PB4(P->qlow), CUT = PB4(P->qcutoff);
     const bool reduce = P->reduce_qual != 0, binary = P->binary_qual != 0;
-    const int min_mqual = P->min_mqual;
-    int64_t r = chunk_read[g0 >> 4];                          /* the read of byte g0 (table built with the batch) */
-    ReadRec rr = B.rr[r];
+    const int min_mqual = P->min_mqual, npv = PV ? P->n_pv : 0;
+    const int64_t n_owner = VREC ? B.n_vrec : B.n_reads;
+    int64_t r = chunk_read[g0 >> 4];                          /* the owner of byte g0 (table built with the batch) */
+    typedef typename RfSel<VREC>::T Rec;
+    const Rec *const recs = RfSel<VREC>::tab(B);
+    Rec rr = recs[r];
     /* The chunk's bytes belong to one read, or -- at a read boundary, i.e. in some lane of nearly every
      * wave -- to two: up to two reads are gathered into slots and done in ONE pass of the packed body
      * (per-byte merge of their action bytes); only chunks that touch more than two single-match reads
@@ -1823,7 +1843,7 @@ k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
         int ns = 0;
         bool more = false;
         for (;;) {
-            if ((rr.info & RR_SIMPLE) && rr.end > rr.pos) {
+            if (rf_aligned(rr)) {
                 /* bytes of this chunk that are aligned bases of this read */
                 const int64_t a0 = rr.so + rr.q0, a1 = a0 + (rr.end - rr.pos);
                 const int lo = (a0 > g0) ? (int)(a0 - g0) : 0, hi = (a1 < gend) ? (int)(a1 - g0) : (int)(gend - g0);
@@ -1832,14 +1852,14 @@ k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
                     const unsigned m = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
                     const int c0 = rr.pos + (int)(g0 - a0) - B.p0; /* column of byte 0 (may be < 0: padded) */
                     uint32_t hm = 0;                               /* low-mapq read whose head column is live: snp:1852 */
-                    if ((int)(rr.info & 255) <= min_mqual && !(colrec[rr.pos - B.p0] & CR_SKIP)) hm = 0xffffffffu;
-                    if (ns == 0) { vb[0] = m; c0s[0] = c0; hms[0] = hm; rid[0] = r; }
-                    else         { vb[1] = m; c0s[1] = c0; hms[1] = hm; rid[1] = r; }
+                    if (rf_headmark(rr, B, min_mqual, colrec)) hm = 0xffffffffu;
+                    if (ns == 0) { vb[0] = m; c0s[0] = c0; hms[0] = hm; rid[0] = rf_read(rr, r); }
+                    else         { vb[1] = m; c0s[1] = c0; hms[1] = hm; rid[1] = rf_read(rr, r); }
                     ns++;
                 }
             }
-            if (rr.so + rr.lq >= gend || r + 1 >= B.n_reads) break;
-            r++; rr = B.rr[r];
+            if (rr.so + rr.lq >= gend || r + 1 >= n_owner) break;
+            r++; rr = recs[r];
         }
         if (ns) {
             uint32_t a[4], a2[4] = {0, 0, 0, 0};
@@ -1864,7 +1884,14 @@ k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
                 const uint32_t V = V1 | V2;
                 const uint32_t ac = (a[k] & V1) | (a2[k] & V2);
                 const uint32_t hm = (hms[0] & V1) | (hms[1] & V2);
-                const uint32_t geq = PB_GE(q, QC);
+                uint32_t PV1 = 0, PV2 = 0;                                           /* -k / -K: bytes of a preserved quality */
+                if (PV)
+                    for (int i = 0; i < npv; i++) {
+                        const uint32_t eq = ~PB_NZ(q ^ PB4(P->pv_val[i]));
+                        PV1 |= eq;
+                        if (P->pv_lvl[i] > 1) PV2 |= eq;
+                    }
+                const uint32_t geq = PB_GE(q, QC) & ~PV1;
                 const uint32_t capq = (QC & geq) | (q & ~geq);                       /* cap_quality snp:1325 */
                 const uint32_t hit = b & ac & 0x0f0f0f0fu;                          /* base shares a bit with a called allele */
                 const uint32_t many = b & ((b | 0x80808080u) - 0x01010101u) & 0x0f0f0f0fu;   /* >= 2 bits: never equals a call */
@@ -1875,7 +1902,7 @@ k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
                     else nm = QL;
                 }
                 const uint32_t qz = (QH & M) | (nm & ~M);
-                const uint32_t U = (((ac >> 4) & 0x01010101u) * 0xffu) | hm;
+                const uint32_t U = (((ac >> 4) & 0x01010101u) * 0xffu) | hm | PV2 | (PV1 & ~(((ac >> 7) & 0x01010101u) * 0xffu));   /* snp:1885 */
                 const uint32_t W = ((ac >> 5) & 0x01010101u) * 0xffu;
                 const uint32_t v = ((capq & W) | (~W & ((q & U) | (qz & ~U)))) & 0x7f7f7f7fu;
                 ow[k] = (v & V) | (ow[k] & ~V);
@@ -1918,7 +1945,7 @@ k_replay_reads(DBatch B, const DParams *__restrict__ P, const uint32_t *__restri
         if (general) hm = (int)(rr.info & 255) <= P->min_mqual && !(colrec[rr.pos - B.p0] & CR_SKIP);
     }
     const int qcap = P->qcap, qhigh = P->qhigh, qlow = P->qlow;
-    const bool reduce = P->reduce_qual != 0, binary = P->binary_qual != 0;
+    const bool reduce = P->reduce_qual != 0, binary = P->binary_qual != 0, any_pres = P->any_preserve != 0;
     unsigned long long todo = __ballot(general);
     while (todo) {
         const int src = __builtin_ctzll(todo);
@@ -1952,9 +1979,11 @@ k_replay_reads(DBatch B, const DParams *__restrict__ P, const uint32_t *__restri
                     const bool skip = (rcd & CR_SKIP) != 0;
                     const int pres = CR_PRESERVE(rcd), base = (int)(b4[u] & 15);
                     const bool match = base == (1 << CR_A1(rcd)) || base == (1 << CR_A2(rcd));
-                    const uint32_t capq = q0 > (uint32_t)qcap ? (uint32_t)qcap : q0;
+                    const uint32_t capq = any_pres ? (uint32_t)cap_q2(P, qcap, true, (uint8_t)q0) : (q0 > (uint32_t)qcap ? (uint32_t)qcap : q0);
                     const uint32_t qz = match ? (uint32_t)qhigh : (reduce ? (binary ? (uint32_t)P->bin2[q0] : (uint32_t)qlow) : q0);
-                    v = (!skip && (rcd & CR_WIN)) ? capq : ((hms || skip || pres) ? q0 : qz);
+                    bool keepv = hms || skip || pres;
+                    if (any_pres) keepv = keepv || P->preserve_qual[q0 & 0x7f] >= 1 + ((rcd & CR_PERFECT) ? 1 : 0);   /* snp:1885 */
+                    v = (!skip && (rcd & CR_WIN)) ? capq : (keepv ? q0 : qz);
                     if (!skip && (rcd & CR_KEEP)) keepf[rs] = 1;
                     if (!skip && pres > 1) b15f[rs] = 1;
                 }

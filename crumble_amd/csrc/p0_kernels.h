@@ -357,6 +357,42 @@ __global__ void k_p0_owner_scatter(int64_t n, int64_t nb, const int64_t *__restr
     }
 }
 
+/* Long-read batches: the territories of every read (VRec, dev_common.h) and the chunk -> territory table, by scatter
+ * like k_p0_owner_scatter.  One thread per read. */
+__global__ void k_p0_vrecs(int64_t n, int64_t nb, int p0, int min_mqual, const ReadRec *__restrict__ rr,
+                           const int64_t *__restrict__ seg_off, const Seg *__restrict__ segs,
+                           VRec *__restrict__ vr, int32_t *__restrict__ chunk_vr)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const ReadRec x = rr[r];
+    const int64_t s0 = seg_off[r], base = s0 + r;
+    const int ns = (int)(seg_off[r + 1] - s0);
+    const int lq = x.lq;
+    const int hcol = (x.end > x.pos && (int)(x.info & 255u) <= min_mqual) ? x.pos - p0 : -1;
+    for (int j = -1; j < ns; j++) {
+        int qs = 0, qn = lq;
+        VRec v;
+        v.pos = v.end = 0; v.q0 = 0; v.hcol = hcol; v.read = (int32_t)r;
+        if (j >= 0) {
+            const Seg sg = segs[s0 + j];
+            qs = sg.qstart < lq ? sg.qstart : lq;
+            if (seg_type(sg) == SEG_M) {
+                const int len = seg_len(sg) < lq - qs ? seg_len(sg) : lq - qs;     /* fence: query bases that exist */
+                v.pos = x.pos + sg.roff; v.end = v.pos + (len > 0 ? len : 0);
+            }
+        }
+        if (j + 1 < ns) { const int q2 = segs[s0 + j + 1].qstart; qn = q2 < lq ? q2 : lq; }
+        if (qn < qs) qn = qs;
+        v.so = x.so + qs; v.lq = qn - qs;
+        const int64_t slot = base + 1 + j;
+        vr[slot] = v;
+        const int64_t a = v.so, b = v.so + v.lq;
+        for (int64_t k = (a + 15) >> 4; k * 16 < b; k++) chunk_vr[k] = (int32_t)slot;
+        if (b > a && b == nb) chunk_vr[(nb + 15) >> 4] = (int32_t)slot;           /* the entry past the last base */
+    }
+}
+
 /* Work split of k_columns: an estimated cost per 64-column tile (its candidate records plus a constant
  * for the per-tile prologue/epilogue), prefix-summed, so that every wave can take a CONTIGUOUS run of
  * tiles of equal total cost -- no atomics, adjacent tiles (which share their reads) stay in one wave. */
