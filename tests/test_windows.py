@@ -109,3 +109,37 @@ def test_gpu_windows_vs_oracle_and_long_reads(product):
     want = eng.contig(hf)
     eng.close()
     _check(lambda pp: ca.Engine(pp, 0), hf, p, 3, want=want)
+
+
+def _fuzz_windows(make_engine, seeds, max_bases):
+    from fuzz_util import random_case
+    for seed in seeds:
+        p, hb, desc = random_case(seed, max_bases=max_bases)
+        if hb.n_reads < 8 or hb.tid < 0:
+            continue
+        try:
+            _check(make_engine, hb, p, 2 + seed % 4)
+        except AssertionError as e:
+            raise AssertionError(f"{desc}: {e}") from e
+
+
+@pytest.mark.parametrize("seed", range(300, 306))
+def test_fuzz_windows_emulated(product, seed):
+    """Random option sets x random alignments (long reads, BEDs, -k/-K, -S, deep spots) cut into 2..5 windows."""
+    import emu_lib
+    _fuzz_windows(emu_lib.with_options(kcol=("v1", "v2")[seed & 1]), [seed], 120_000)
+
+
+def test_tiny_reads_windows_emulated(product):
+    """Reads of 0..40 bases with clips, indels, skips and unmapped records: cuts between reads that start within a
+    few bases of each other (several windows' halos overlap)."""
+    import emu_lib
+    from test_fuzz_parity import tiny_reads_batch
+    hb = tiny_reads_batch(5)
+    for p in (ca.preset_params(9), ca.preset_params(5, pblock=2, keep="30"), ca.preset_params(9, softclip=1, binary_qual=1)):
+        _check(emu_lib.engine, hb, p, 5)
+
+
+@pytest.mark.gpu
+def test_fuzz_windows_gpu(product):
+    _fuzz_windows(lambda pp: ca.Engine(pp, 0), range(2000, 2060), 400_000)
