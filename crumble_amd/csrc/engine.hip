@@ -382,7 +382,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     P0Cnt tot = {0, 0, 0};
     int res[4] = {0, INT_MAX, INT_MIN, 0};
     if (n > 0) {
-        CRUMBLE_LAUNCH(k_p0_classify, nblk(n, 256), 256, st, n, (int)b->tid, h->d_pos.as<int32_t>(),
+        CRUMBLE_LAUNCH(k_p0_classify, nblk(n, 1024), 1024, st, n, (int)b->tid, h->d_pos.as<int32_t>(),
                              h->d_flag.as<uint16_t>(), h->d_seq_off.as<int64_t>(), h->d_cig_off.as<int64_t>(),
                              h->d_cigar.as<uint32_t>(), h->d_inplp.as<uint8_t>(), h->d_end.as<int32_t>(), cnt, d_err, d_minmax, nb, nc);
         CRUMBLE_LAUNCH_INDEP(k_p0_sorted, nblk(n, 256), 256, st, n, h->d_pos.as<int32_t>(), h->d_inplp.as<uint8_t>(), d_err);

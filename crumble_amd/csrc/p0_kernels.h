@@ -100,7 +100,8 @@ __device__ __forceinline__ void p0_classify_read(int64_t r, int tid, const int32
     mn = pos[r]; mx = end[r];                              /* extent of the pileup */
 }
 
-__global__ void k_p0_classify(int64_t n, int tid, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
+__global__ void __launch_bounds__(1024)
+k_p0_classify(int64_t n, int tid, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
                               const int64_t *__restrict__ seq_off, const int64_t *__restrict__ cig_off,
                               const uint32_t *__restrict__ cigar, uint8_t *__restrict__ inplp,
                               int32_t *__restrict__ end, P0Cnt *__restrict__ cnt, int *err, int *minmax,
@@ -109,13 +110,18 @@ __global__ void k_p0_classify(int64_t n, int tid, const int32_t *__restrict__ po
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int mn = INT_MAX, mx = INT_MIN;
     if (r < n) p0_classify_read(r, tid, pos, flag, seq_off, cig_off, cigar, inplp, end, cnt, err, mn, mx, nb, nc);
-    /* one atomic pair per wave, not per read (12.6 M atomics on two words were most of this kernel's 4.5 ms) */
+    /* one atomic pair per 1024-thread workgroup (an atomic pair per read, 12.6 M on two words, was most of this
+     * kernel's time; one per wave still left 4.4 ms of it: a hot word takes ~90 atomics per microsecond) */
+    __shared__ int wmn[16], wmx[16];
     #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         const int a = __shfl_xor(mn, d), b = __shfl_xor(mx, d);
         mn = a < mn ? a : mn; mx = b > mx ? b : mx;
     }
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0) { wmn[threadIdx.x >> 6] = mn; wmx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) { mn = wmn[w] < mn ? wmn[w] : mn; mx = wmx[w] > mx ? wmx[w] : mx; }
         if (mn != INT_MAX) atomicMin(&minmax[0], mn);
         if (mx != INT_MIN) atomicMax(&minmax[1], mx);
     }
