@@ -71,14 +71,16 @@ def test_emu_column_kernel_variants(product, kcol):
     numbering (class = idx(base) ^ idx(key base), undone by col_unpermute), and k_columns2 (pileup matrix staged in
     LDS, inline / parked split of the FP64 adds)."""
     eng = emu_lib.with_options(kcol=kcol)
-    hb = synth_batch("chr20", 0.0004)
+    slow = kcol == "v2"        # k_columns2 under the emulator: a fiber rendezvous per matrix row (emu_lib.engine)
+    hb = synth_batch("chr20", 0.00016 if slow else 0.0004)
     assert_parity(eng, ca.preset_params(5), hb)
-    assert_parity(eng, ca.preset_params(5, min_qual_A=30, min_indel_A=60), hb)
+    if not slow:               # both consensus modes at once: k_columns whatever the option says
+        assert_parity(eng, ca.preset_params(5, min_qual_A=30, min_indel_A=60), hb)
     assert_parity(eng, ca.preset_params(5, min_qual_A=30, min_qual_B=0), hb)
     assert_parity(eng, ca.preset_params(9, keep="37", perfect_col=1), hb)
     assert_parity(eng, ca.preset_params(9), synth_batch("panel", 0.001 if kcol != "v2" else 0.0003))
-    assert_parity(eng, ca.preset_params(9, tech="pbccs"), synth_batch("hifi", 0.0002, read_len=3000))
-    assert_parity(eng, ca.preset_params(1), synth_batch("ce", 0.3))
+    assert_parity(eng, ca.preset_params(9, tech="pbccs"), synth_batch("hifi", 0.0001 if slow else 0.0002, read_len=3000))
+    assert_parity(eng, ca.preset_params(1), synth_batch("ce", 0.12 if slow else 0.3))
 
 
 def test_emu_indel_only(product):
