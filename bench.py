@@ -149,8 +149,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--cpu-all", action="store_true", help="also time the CPU restatement on all host cores "
-                    "(independent windows of the contig, one process per core): 'cpu_baseline_all'")
+    ap.add_argument("--cpu-all", action="store_true", help="(default now) also time the CPU restatement on all host "
+                    "cores (independent windows of the contig, one process per core): 'cpu_baseline_all'")
+    ap.add_argument("--no-cpu-all", action="store_true", help="skip the all-core CPU leg")
     ap.add_argument("--pmc-json", default=None, help="profiles/*_pmc_traffic.json measured for THIS build and "
                     "workload: fills roofline.traffic (null otherwise)")
     ap.add_argument("--kcol", default="auto", help="crumble_hip_set_option kcol (auto|v1|v1perm|v2)")
@@ -399,7 +400,7 @@ def main():
                 out["config"]["verified_timed_output_leading_reads"] = k if (ok_q and ok_f) else False
                 out["config"]["verified_bit_exact_on_sample"] = bool(
                     np.array_equal(gq, wq) and np.array_equal(gf, wf) and np.array_equal(gs, ws))
-            if args.cpu_all:
+            if not args.no_cpu_all:
                 import multiprocessing as mp
                 cores = _host_threads()
                 per = max(1000, n_sample // 4)
