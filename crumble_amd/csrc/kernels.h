@@ -1263,6 +1263,24 @@ __device__ __forceinline__ int dev_ref2query_pos(const uint32_t *cig, int nc, in
     return q;
 }
 
+/* ref2query_pos (snp:1156-1179) from the op table instead of the CIGAR walk (k_restore on long reads: the walk is a
+ * chain of dependent loads, ~25 ops per HiFi read).  The reference stops at the first op -- in CIGAR order, clips
+ * and insertions included -- with p + (ref-consuming ? len : 0) >= pos.  For pos <= rpos0 that is the first op and
+ * the result is 0.  Otherwise a non-reference op never stops the walk (the reference op before it did not, so
+ * p < pos there), and the stopping op is the first reference-consuming op whose end reaches pos: Seg.qstart is the
+ * query length consumed before it (M: + the offset inside it; D/N: as it is); past the last one the walk returns the
+ * whole query length. */
+__device__ __forceinline__ int dev_ref2query_seg(const Seg *__restrict__ segs, int ns, int rpos0, int pos, int lq)
+{
+    if (pos <= rpos0) return 0;
+    const int off = pos - rpos0;
+    int lo = 0, hi = ns;                                   /* first op with roff + len >= off */
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (segs[mid].roff + seg_len(segs[mid]) < off) lo = mid + 1; else hi = mid; }
+    if (lo >= ns) return lq;
+    const Seg sg = segs[lo];
+    return seg_type(sg) == SEG_M ? sg.qstart + (off - sg.roff) : sg.qstart;
+}
+
 __device__ inline void dev_mask_lc(const DBatch &B, const DParams *P, int r, int rpos, int is_indel,
                                    int *min_pos, int *max_pos, int *overflow, unsigned *lds_lane)
 {
@@ -2065,8 +2083,8 @@ k_restore(DBatch B, const DParams *__restrict__ P, int n_trig, const int32_t *tr
                 const int64_t so = B.seq_off[r];
                 const int lq = (int)(B.seq_off[r + 1] - so);
                 if (lq && e.qpos < lq) {                       /* snp:1861 / fence */
-                    const uint32_t *cig = B.cigar + B.cig_off[r];
-                    start = dev_ref2query_pos(cig, (int)(B.cig_off[r + 1] - B.cig_off[r]), rp, mn2);
+                    const int64_t sgo = B.seg_off[r];
+                    start = dev_ref2query_seg(B.segs + sgo, (int)(B.seg_off[r + 1] - sgo), rp, mn2, lq);
                     stop = e.qpos;
                     so_lo = (unsigned)(uint64_t)so; so_hi = (unsigned)((uint64_t)so >> 32);
                 }
