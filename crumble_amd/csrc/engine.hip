@@ -77,6 +77,7 @@ struct crumble_hip {
     int64_t n_reads = 0, n_bases = 0, n_cigar = 0, n_slow = 0, n_segrec = 0;
     bool packed_ok = false;         /* the packed replay's value formulas hold for these parameters (set at create) */
     bool have_vrec = false;         /* long-read batch: territories + chunk table built (k_p0_vrecs) */
+    bool batch_flat = false;        /* "replay" = flat as it stood when the batch was uploaded (decides which tables exist) */
     ScanVal totals;
     /* window of a contig (crumble_hip_set_window) and the phase the run is in */
     bool windowed = false;
@@ -455,11 +456,15 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
 
     /* 3. expanded tables */
     const size_t ns = (size_t)tot.nseg;
+    /* long reads through the packed replay need no base -> column table (4 B per base of every multi-op read) */
+    h->batch_flat = h->opt_replay == 1;
+    const bool vrec_path = tot.nseg > n + n / 2 && h->packed_ok && !h->batch_flat && tot.nseg + n < (int64_t)INT_MAX - 64;
+    const int want_cix = vrec_path ? 0 : 1;
     const size_t nblkb = (size_t)(nb / 64 + 1);
     if ((e = h->d_segs.reserve((ns + 1) * sizeof(Seg))) || (e = h->d_sr.reserve((ns + 1) * sizeof(SegRec))) ||
         (e = h->d_sr_ppos.reserve((ns + 1) * 4)) || (e = h->d_sr_pend.reserve((ns + 1) * 4)) ||
         (e = h->d_rr.reserve((size_t)(n + 1) * sizeof(ReadRec))) || (e = h->d_seg_off.reserve((size_t)(n + 2) * 8)) ||
-        (e = h->d_cix.reserve(((size_t)tot.ncix + 1) * 4)) || (e = h->d_slow_g.reserve(((size_t)tot.nslow + 1) * 8)) ||
+        (e = h->d_cix.reserve((want_cix ? (size_t)tot.ncix + 1 : 1) * 4)) || (e = h->d_slow_g.reserve(((size_t)tot.nslow + 1) * 8)) ||
         (e = h->d_slow_r.reserve(((size_t)tot.nslow + 1) * 4)) || (e = h->d_kpos.reserve((size_t)(n + 1) * 4)) ||
         (e = h->d_kend.reserve((size_t)(n + 1) * 4)) || (e = h->d_tile_lo.reserve((size_t)(B.n_tiles + 1) * 4)) ||
         (e = h->d_tile_hi.reserve((size_t)(B.n_tiles + 1) * 4)) || (e = h->d_stile_lo.reserve((size_t)(B.n_tiles + 1) * 4)) ||
@@ -472,7 +477,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
                              h->d_inplp.as<uint8_t>(), h->d_end.as<int32_t>(), cnt, part + nchunks,
                              h->d_segs.as<Seg>(), h->d_sr.as<SegRec>(), h->d_sr_ppos.as<int32_t>(), h->d_sr_pend.as<int32_t>(),
                              h->d_rr.as<ReadRec>(), h->d_seg_off.as<int64_t>(), h->d_cix.as<int32_t>(),
-                             h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(), d_nslow, h->d_mqslot.as<uint8_t>());
+                             h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(), d_nslow, h->d_mqslot.as<uint8_t>(), want_cix);
         CRUMBLE_LAUNCH_INDEP(k_p0_keys, nblk(n, 256), 256, st, n, h->d_pos.as<int32_t>(), h->d_end.as<int32_t>(),
                              h->d_inplp.as<uint8_t>(), h->d_kpos.as<int32_t>(), h->d_kend.as<int32_t>());
         if ((e = prefix_max(h, h->d_kpos.as<int32_t>(), n)) || (e = prefix_max(h, h->d_kend.as<int32_t>(), n)) ||
@@ -517,7 +522,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
                                          h->d_blk_read.as<int32_t>(), h->d_chunk_read.as<int32_t>());
             }
             h->have_vrec = false;
-            if (tot.nseg > n + n / 2 && h->packed_ok && tot.nseg + n < (int64_t)INT_MAX - 64) {
+            if (vrec_path) {
                 /* long reads: one territory per reference-consuming op (+ one per read) and the chunk -> territory
                  * table: k_replay_fast<VREC> then treats a match op like a single-match read */
                 const int64_t nv = tot.nseg + n;
@@ -851,7 +856,7 @@ extern "C" int crumble_hip_run_finish(crumble_hip *h)
             CRUMBLE_LAUNCH_INDEP(k_replay_general, nblk(nb, 256), 256, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
                                  h->d_blk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(),
                                  h->d_b15f.as<uint8_t>());
-        else if (nb > 0 && h->packed_ok && h->opt_replay != 1 && (!(h->n_segrec > h->n_reads + h->n_reads / 2) || h->have_vrec)) {
+        else if (nb > 0 && h->packed_ok && !h->batch_flat && (!(h->n_segrec > h->n_reads + h->n_reads / 2) || h->have_vrec)) {
             /* action bytes + packed 16-base chunks (kernels.h): per read for short reads (+ the general-CIGAR reads
              * one at a time), per reference-consuming op for long reads */
             int ea;

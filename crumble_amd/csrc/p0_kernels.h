@@ -224,7 +224,7 @@ __global__ void k_p0_fill(int64_t n, int p0, const int32_t *__restrict__ pos, co
                           Seg *__restrict__ segs, SegRec *__restrict__ sr, int32_t *__restrict__ sr_ppos,
                           int32_t *__restrict__ sr_pend, ReadRec *__restrict__ rr, int64_t *__restrict__ seg_off,
                           int32_t *__restrict__ cix, int64_t *__restrict__ slow_g, int32_t *__restrict__ slow_r,
-                          int *n_slow, const uint8_t *__restrict__ mq_slot)
+                          int *n_slow, const uint8_t *__restrict__ mq_slot, int want_cix)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
@@ -275,9 +275,23 @@ __global__ void k_p0_fill(int64_t n, int p0, const int32_t *__restrict__ pos, co
     const Seg s0 = segs[s_first];
     const bool simple = nseg == 1 && seg_type(s0) == SEG_M && s0.indel_after == 0 && lq > 0;
     if (simple) { x.info |= RR_SIMPLE; rr[r] = x; return; }
-    /* pass 2: base -> column table of a general CIGAR (replay) */
+    /* pass 2: base -> column table of a general CIGAR (replay).  Long-read batches that go through the packed replay
+     * (territories, k_p0_vrecs) never look a base up: only the list of bases that D/N columns report is made -- a
+     * base is reported by a run of consecutive D/N ops, so equal qstart of consecutive ops is the duplicate test */
     x.cix = (uint32_t)(o.ncix / CIX_UNIT);
     rr[r] = x;
+    if (!want_cix) {
+        int last = -1;
+        for (int64_t k = s_first; k < si; k++) {
+            const Seg sg = segs[k];
+            if (seg_type(sg) != SEG_M && sg.qstart < lq && sg.qstart != last) {
+                last = sg.qstart;
+                const int w = atomicAdd(n_slow, 1);
+                slow_g[w] = so + sg.qstart; slow_r[w] = (int32_t)r;
+            }
+        }
+        return;
+    }
     int32_t *cx = cix + o.ncix;
     for (int i = 0; i < lq; i++) cx[i] = -1;
     for (int64_t k = s_first; k < si; k++) {
