@@ -368,6 +368,22 @@ def main():
         "around_the_step": extra,
     }
 
+    if rank == 0 and args.workload != "wgs":
+        # compression proxy (no CRAM writer offline): share of the quality bytes the pass
+        # rewrote and the order-0 entropy of the quality bytes before / after, from the engine's own statistics
+        names = ca.capi.ST_NAMES
+        h_out = stats[ca.capi.ST_HIST0:ca.capi.ST_HIST0 + 256].astype(np.float64) / max(1, args.steps * world)
+        n_in = min(hb.n_bases, 200_000_000)
+        h_in = np.bincount(hb.quals[:n_in], minlength=256).astype(np.float64)
+
+        def entropy(h):
+            p = h[h > 0] / h.sum()
+            return float(-(p * np.log2(p)).sum()) if h.sum() else 0.0
+        out["compression_proxy"] = {
+            "fraction_rewritten": round(float(stats[names.index("bases_changed")]) / max(1.0, float(stats[names.index("bases")])), 5),
+            "entropy_in_bits_per_quality": round(entropy(h_in), 4), "entropy_out_bits_per_quality": round(entropy(h_out), 4),
+            "note": f"order-0 entropy; input histogram over the first {n_in} qualities of rank 0's contig, output from the "
+                    "statistics vector (all ranks)"}
     if rank == 0:
         # ---- parity of the TIMED result + CPU baseline on a bounded prefix of the same workload ----
         import oracle_lib as O
