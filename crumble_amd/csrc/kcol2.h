@@ -255,6 +255,40 @@ struct __attribute__((aligned(16))) KC2Lds {
 #define KC2_STAMP(k_) do { } while (0)
 #endif
 
+/* a staged record (r0, r1 at matrix row `slot` of the pass): the record itself, the difference arrays, the row window
+ * bounds, the row's flags and the head / tail counts */
+#define KC2_STAGE_HIT() \
+                if (ov) { \
+                    W.recs[slot][0] = r0; W.recs[slot][1] = r1; \
+                    int a = (int)r0.x - c0, b = (int)r0.y - c0; \
+                    a = a < 0 ? 0 : a; b = b > 64 ? 64 : b; \
+                    atomicMax(&W.rowhi[a], slot + 1);                    /* (op starts are not sorted: a read's later ops) */ \
+                    atomicMin(&W.rowlo[b - 1], slot); \
+                    atomicAdd(&W.cnt[0][a], 1); atomicAdd(&W.cnt[0][b], -1); \
+                    lowrec = (int)(r1.w & 255u) <= min_mqual; \
+                    {   /* the row's flags for the consumer */ \
+                        const unsigned info = r1.w, ty = SR_TYPE(info); \
+                        const bool rare = ty != SEG_M || r1.z != 0u || r1.x == 0u;          /* D/N op, indel behind it, no SEQ */ \
+                        const bool full = ty == SEG_M && (int)r1.x > 0 && (int)r0.x <= c0 && (int)r0.y > c1; \
+                        W.rowinfo[slot] = (info & 0xffu) | ((info >> 8) & 0xff00u) | (rare ? KC2_RARE : 0u) | \
+                                          (full ? KC2_FULL : 0u) | ((MQ && (int)(info & 255u) != hot_mq) ? KC2_NONHOT : 0u); \
+                    } \
+                    if (lowrec) { atomicAdd(&W.cnt[1][a], 1); atomicAdd(&W.cnt[1][b], -1); } \
+                    /* is_head / is_tail bookkeeping (snp:1701-1706): two columns per read; a ref-skip entry is not \
+                     * counted (snp:1696); head and tail on one column count once */ \
+                    const unsigned info = r1.w; \
+                    if (SR_TYPE(info) != SEG_N && (info & (SR_FIRST | SR_LAST))) { \
+                        const int hc = (int)r0.x - c0, tc = (int)r0.y - 1 - c0; \
+                        const bool hd = (info & SR_FIRST) && hc >= 0, tl = (info & SR_LAST) && tc < 64; \
+                        if (hd && tl && hc == tc) \
+                            atomicAdd(&W.ht[hc], 1u + ((info & (SR_HEADCLIP | SR_TAILCLIP)) ? 0x10000u : 0u)); \
+                        else { \
+                            if (hd) atomicAdd(&W.ht[hc], 1u + ((info & SR_HEADCLIP) ? 0x10000u : 0u)); \
+                            if (tl) atomicAdd(&W.ht[tc], 1u + ((info & SR_TAILCLIP) ? 0x10000u : 0u)); \
+                        } \
+                    } \
+                }
+
 /* MQ: the active consensus uses CONS_MQUAL (mode B, snp:1535); ANYPRES: -k/-K/-y pbccs set preserve_qual[];
  * MULTI: long reads (many ops per read: candidates are screened by their first 8 bytes); WIN: the batch is a window
  * of a contig (crumble_hip_set_window: columns outside [col_lo, col_hi) read as empty, columns from stat_hi on stay
@@ -350,59 +384,65 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
             W.cnt[0][lane] = 0; W.cnt[1][lane] = 0; W.ht[lane] = 0; W.rowhi[lane] = 0; W.rowlo[lane] = KC2_R;
             if (lane < 4) { W.cnt[0][64 + lane] = 0; W.cnt[1][64 + lane] = 0; }
             WAVE_SYNC();
-            while (wnext < hi) {
-                const int idx = wnext + lane;
-                bool ov = false;
+            if (MULTI) {
+                /* long reads: most candidate ops of the overlapping reads miss the tile.  Screen them by their first 8
+                 * bytes, four windows of 64 per round trip, and collect the hits' indices in file order (W.rowinfo
+                 * holds them until the rows' flags are written); then one more round trip brings the hits' records,
+                 * a lane each */
+                bool full = false;
+                while (wnext < hi && !full) {
+                    int2 pe[4];
+                    #pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int idx = wnext + 64 * u + lane;
+                        pe[u].x = 0; pe[u].y = 0;
+                        if (idx < hi) pe[u] = *(const int2 *)&B.sr[idx];
+                    }
+                    #pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (full || wnext >= hi) break;
+                        const int idx = wnext + lane;
+                        const bool o = idx < hi && pe[u].y > c0 && pe[u].x <= c1;
+                        const unsigned long long m = __ballot(o);
+                        const int h = __popcll(m);
+                        if (nq + h > KC2_R) { full = true; break; }      /* this window opens the next pass */
+                        if (o) W.rowinfo[nq + __popcll(m & lt)] = (uint32_t)idx;
+                        nq += h;
+                        wnext += 64;
+                    }
+                }
+                WAVE_SYNC();
+                const bool ov = lane < nq;
+                const int slot = lane;
                 uint4 r0, r1;
                 r0.x = r0.y = r0.z = r0.w = 0; r1 = r0;
-                if (idx < hi) {
-                    const uint4 *rp = (const uint4 *)&B.sr[idx];
-                    if (MULTI) {
-                        const int2 pe = *(const int2 *)rp;
-                        r0.x = (uint32_t)pe.x; r0.y = (uint32_t)pe.y;
-                    } else { r0 = rp[0]; r1 = rp[1]; }
-                    ov = (int)r0.y > c0 && (int)r0.x <= c1;
-                }
-                const unsigned long long m = __ballot(ov);
-                const int h = __popcll(m);
-                if (nq + h > KC2_R) break;                               /* this window opens the next pass */
+                if (ov) { const uint4 *rp = (const uint4 *)&B.sr[W.rowinfo[lane]]; r0 = rp[0]; r1 = rp[1]; }
+                WAVE_SYNC();                                             /* (rowinfo is rewritten below) */
                 bool lowrec = false;
-                if (ov) {
-                    if (MULTI) { const uint4 *rp = (const uint4 *)&B.sr[idx]; r0 = rp[0]; r1 = rp[1]; }
+                KC2_STAGE_HIT();
+                anylow = __ballot(lowrec) != 0ull;
+            } else {
+                while (wnext < hi) {                                     /* short reads: one window, most candidates are hits */
+                    const int idx = wnext + lane;
+                    bool ov = false;
+                    uint4 r0, r1;
+                    r0.x = r0.y = r0.z = r0.w = 0; r1 = r0;
+                    if (idx < hi) {
+                        const uint4 *rp = (const uint4 *)&B.sr[idx];
+                        r0 = rp[0]; r1 = rp[1];
+                        ov = (int)r0.y > c0 && (int)r0.x <= c1;
+                    }
+                    const unsigned long long m = __ballot(ov);
+                    const int h = __popcll(m);
+                    if (nq + h > KC2_R) break;
                     const int slot = nq + __popcll(m & lt);
-                    W.recs[slot][0] = r0; W.recs[slot][1] = r1;
-                    int a = (int)r0.x - c0, b = (int)r0.y - c0;
-                    a = a < 0 ? 0 : a; b = b > 64 ? 64 : b;
-                    atomicMax(&W.rowhi[a], slot + 1);                    /* (op starts are not sorted: a read's later ops) */
-                    atomicMin(&W.rowlo[b - 1], slot);
-                    atomicAdd(&W.cnt[0][a], 1); atomicAdd(&W.cnt[0][b], -1);
-                    lowrec = (int)(r1.w & 255u) <= min_mqual;
-                    {   /* the row's flags for the consumer */
-                        const unsigned info = r1.w, ty = SR_TYPE(info);
-                        const bool rare = ty != SEG_M || r1.z != 0u || r1.x == 0u;          /* D/N op, indel behind it, no SEQ */
-                        const bool full = ty == SEG_M && (int)r1.x > 0 && (int)r0.x <= c0 && (int)r0.y > c1;
-                        W.rowinfo[slot] = (info & 0xffu) | ((info >> 8) & 0xff00u) | (rare ? KC2_RARE : 0u) |
-                                          (full ? KC2_FULL : 0u) | ((MQ && (int)(info & 255u) != hot_mq) ? KC2_NONHOT : 0u);
-                    }
-                    if (lowrec) { atomicAdd(&W.cnt[1][a], 1); atomicAdd(&W.cnt[1][b], -1); }
-                    /* is_head / is_tail bookkeeping (snp:1701-1706): two columns per read; a ref-skip entry is not
-                     * counted (snp:1696); head and tail on one column count once */
-                    const unsigned info = r1.w;
-                    if (SR_TYPE(info) != SEG_N && (info & (SR_FIRST | SR_LAST))) {
-                        const int hc = (int)r0.x - c0, tc = (int)r0.y - 1 - c0;
-                        const bool hd = (info & SR_FIRST) && hc >= 0, tl = (info & SR_LAST) && tc < 64;
-                        if (hd && tl && hc == tc)
-                            atomicAdd(&W.ht[hc], 1u + ((info & (SR_HEADCLIP | SR_TAILCLIP)) ? 0x10000u : 0u));
-                        else {
-                            if (hd) atomicAdd(&W.ht[hc], 1u + ((info & SR_HEADCLIP) ? 0x10000u : 0u));
-                            if (tl) atomicAdd(&W.ht[tc], 1u + ((info & SR_TAILCLIP) ? 0x10000u : 0u));
-                        }
-                    }
+                    bool lowrec = false;
+                    KC2_STAGE_HIT();
+                    anylow = anylow || __ballot(lowrec) != 0ull;
+                    nq += h;
+                    wnext += 64;
+                    break;
                 }
-                anylow = anylow || __ballot(lowrec) != 0ull;
-                nq += h;
-                wnext += 64;
-                if (!MULTI) break;                                       /* short reads: most candidates are hits */
             }
             if (nq == 0) continue;
             WAVE_SYNC();
