@@ -268,7 +268,9 @@ struct __attribute__((aligned(16))) KC2Lds {
                     lowrec = (int)(r1.w & 255u) <= min_mqual; \
                     {   /* the row's flags for the consumer */ \
                         const unsigned info = r1.w, ty = SR_TYPE(info); \
-                        const bool rare = ty != SEG_M || r1.z != 0u || r1.x == 0u;          /* D/N op, indel behind it, no SEQ */ \
+                        /* D/N op, no SEQ, or an indel behind the op -- which only its last column sees (long reads: \
+                         * nearly every op ends in one, but rarely inside this tile) */ \
+                        const bool rare = ty != SEG_M || r1.x == 0u || (r1.z != 0u && (int)r0.y - 1 <= c1); \
                         const bool full = ty == SEG_M && (int)r1.x > 0 && (int)r0.x <= c0 && (int)r0.y > c1; \
                         W.rowinfo[slot] = (info & 0xffu) | ((info >> 8) & 0xff00u) | (rare ? KC2_RARE : 0u) | \
                                           (full ? KC2_FULL : 0u) | ((MQ && (int)(info & 255u) != hot_mq) ? KC2_NONHOT : 0u); \
