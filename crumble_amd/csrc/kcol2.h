@@ -49,7 +49,7 @@
 #endif
 #define KC2_THREADS  (KC2_WAVES * 64)
 #ifndef KC2_SLOTS
-#define KC2_SLOTS    48            /* mapq values with a row of the compact adjustment table in LDS */
+#define KC2_SLOTS    64            /* mapq values with a row of the compact adjustment table in LDS */
 #endif
 #ifndef KC2_LDS_EXP
 #define KC2_LDS_EXP  1             /* cons_finalize's exp tables in LDS */
@@ -133,7 +133,9 @@ struct __attribute__((aligned(16))) KC2Wave {      /* one wave's LDS */
     uint16_t plane[KC2_PR][64];
     uint4    recs[KC2_R][2];                       /* SegRec: {pos, end, so.lo, so.hi} {lq, qoff, indel_after, info} */
     uint32_t rowinfo[KC2_R];
-    int32_t  cnt[2][68];                           /* difference arrays over the tile's columns: all records / low-mapq records */
+    uint32_t cnt[68];                              /* difference array over the tile's columns: all records (low half) and
+                                                    * low-mapq records (high half) in one word -- the prefix sums of both are
+                                                    * counts in 0..64, so the packed sum splits again after the scan */
     uint32_t ht[64];                               /* per column: head/tail entries (low half), clipped ones (high half) */
     int32_t  rowhi[64], rowlo[64];                 /* per column: 1 + the last row that starts there / the first row that
                                                     * ends there: the lanes' row windows */
@@ -264,8 +266,8 @@ struct __attribute__((aligned(16))) KC2Lds {
                     a = a < 0 ? 0 : a; b = b > 64 ? 64 : b; \
                     atomicMax(&W.rowhi[a], slot + 1);                    /* (op starts are not sorted: a read's later ops) */ \
                     atomicMin(&W.rowlo[b - 1], slot); \
-                    atomicAdd(&W.cnt[0][a], 1); atomicAdd(&W.cnt[0][b], -1); \
                     lowrec = (int)(r1.w & 255u) <= min_mqual; \
+                    { const uint32_t one = lowrec ? 0x10001u : 1u; atomicAdd(&W.cnt[a], one); atomicAdd(&W.cnt[b], 0u - one); } \
                     {   /* the row's flags for the consumer */ \
                         const unsigned info = r1.w, ty = SR_TYPE(info); \
                         /* D/N op, no SEQ, or an indel behind the op -- which only its last column sees (long reads: \
@@ -275,7 +277,6 @@ struct __attribute__((aligned(16))) KC2Lds {
                         W.rowinfo[slot] = (info & 0xffu) | ((info >> 8) & 0xff00u) | (rare ? KC2_RARE : 0u) | \
                                           (full ? KC2_FULL : 0u) | ((MQ && (int)(info & 255u) != hot_mq) ? KC2_NONHOT : 0u); \
                     } \
-                    if (lowrec) { atomicAdd(&W.cnt[1][a], 1); atomicAdd(&W.cnt[1][b], -1); } \
                     /* is_head / is_tail bookkeeping (snp:1701-1706): two columns per read; a ref-skip entry is not \
                      * counted (snp:1696); head and tail on one column count once */ \
                     const unsigned info = r1.w; \
@@ -382,9 +383,8 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
              * order-independent per-column counts (n_plp, and the entries of low-mapq reads snp:1663) come from
              * difference arrays over the tile's columns, not from the rows */
             int nq = 0;
-            bool anylow = false;
-            W.cnt[0][lane] = 0; W.cnt[1][lane] = 0; W.ht[lane] = 0; W.rowhi[lane] = 0; W.rowlo[lane] = KC2_R;
-            if (lane < 4) { W.cnt[0][64 + lane] = 0; W.cnt[1][64 + lane] = 0; }
+            W.cnt[lane] = 0; W.ht[lane] = 0; W.rowhi[lane] = 0; W.rowlo[lane] = KC2_R;
+            if (lane < 4) W.cnt[64 + lane] = 0;
             WAVE_SYNC();
             if (MULTI) {
                 /* long reads: most candidate ops of the overlapping reads miss the tile.  Screen them by their first 8
@@ -422,7 +422,6 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                 WAVE_SYNC();                                             /* (rowinfo is rewritten below) */
                 bool lowrec = false;
                 KC2_STAGE_HIT();
-                anylow = __ballot(lowrec) != 0ull;
             } else {
                 while (wnext < hi) {                                     /* short reads: one window, most candidates are hits */
                     const int idx = wnext + lane;
@@ -440,7 +439,6 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                     const int slot = nq + __popcll(m & lt);
                     bool lowrec = false;
                     KC2_STAGE_HIT();
-                    anylow = anylow || __ballot(lowrec) != 0ull;
                     nq += h;
                     wnext += 64;
                     break;
@@ -450,8 +448,8 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
             WAVE_SYNC();
             KC2_STAMP(1);
             {   /* inclusive prefix sums of the difference arrays across the lanes */
-                st.n_plp += kc2_scan_add(W.cnt[0][lane]);
-                if (anylow) st.low_mq += kc2_scan_add(W.cnt[1][lane]);
+                const uint32_t w2 = (uint32_t)kc2_scan_add((int)W.cnt[lane]);
+                st.n_plp += (int)(w2 & 0xffffu); st.low_mq += (int)(w2 >> 16);
                 htacc += W.ht[lane];
             }
             /* lane c's rows: [rowL, rowL + rowD) = from the first row that ends beyond c to the last row that starts
