@@ -143,3 +143,30 @@ def test_tiny_reads_windows_emulated(product):
 @pytest.mark.gpu
 def test_fuzz_windows_gpu(product):
     _fuzz_windows(lambda pp: ca.Engine(pp, 0), range(2000, 2060), 400_000)
+
+
+def test_emu_window_then_whole_batch_again(product):
+    """crumble_hip_set_window(NULL) after a windowed run: the same upload gives the whole contig's result again
+    (and a window's statistics only count its own columns and reads)."""
+    import emu_lib
+    hb = synth.generate(synth.config("chr20", scale=0.0003, seed=4))
+    p = ca.preset_params(5)
+    eng = emu_lib.engine(p)
+    want = eng.contig(hb)
+    (lo0, hi0, w0), (lo1, hi1, w1) = windows.plan(hb, 2)
+    assert lo0 == 0
+    eng.upload(windows._slice(hb, lo0, hi0))
+    eng.set_window(w0)
+    c, n = windows.Carry.start(), windows.Carry.start()
+    eng.run_columns(); eng.run_depth(c, n); eng.run_triggers(); eng.run_fold(c, n); eng.run_finish()
+    q0, f0, s0 = eng.download()
+    r1 = int(w0.read_end)
+    assert np.array_equal(q0[:int(hb.seq_off[r1])], want[0][:int(hb.seq_off[r1])]) and np.array_equal(f0[:r1], want[1][:r1])
+    assert s0[ca.ST_NAMES.index("reads")] == r1 and 0 < s0[ca.ST_NAMES.index("columns")] < want[2][ca.ST_NAMES.index("columns")]
+    eng.upload(hb)
+    eng.set_window(w0)                       # a window on the whole batch ...
+    eng.set_window(None)                     # ... taken back
+    eng.run()
+    got = eng.download()
+    eng.close()
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
