@@ -84,6 +84,7 @@ struct crumble_hip {
     crumble_window win;
     int64_t own_b_lo = 0, own_b_hi = 0;     /* byte range of the owned reads */
     int phase = 0;                          /* 0 nothing run; 1 columns; 2 depth; 3 triggers; 4 fold; 5 finished */
+    bool scan_fused = false;                /* no per-column prefix arrays: k_epochs_find + k_scan_overdepth (whole contig, no too-deep column) */
     crumble_carry carry_in;                 /* what phases 2 and 4 started from */
     /* timing */
     hipEvent_t ev[MAX_STAGES + 1];
@@ -732,11 +733,14 @@ extern "C" int crumble_hip_run_columns(crumble_hip *h)
         STAGE("scan", 0);
         CRUMBLE_LAUNCH(k_scan_reduce, nchunks, 256, st, L, colrec, nplp, trigcnt, partial, nchunks);
         CRUMBLE_LAUNCH(k_scan_partials, 1, 1024, st, partial, nchunks);
-        CRUMBLE_LAUNCH(k_scan_apply, nchunks, 256, st, L, colrec, nplp, trigcnt, partial, nchunks,
-                             h->d_dpre.as<int64_t>(), h->d_col_ord.as<int32_t>(), h->d_trig_ord.as<int32_t>(),
-                             h->d_item_off.as<int32_t>(), h->d_ins_ord.as<int32_t>());
         HIPCHK(hipMemcpyAsync(&h->totals, partial + nchunks, sizeof(ScanVal), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));           /* sizes of the work lists */
+        /* a whole contig without a too-deep column needs no per-column prefix arrays (kernels.h, k_scan_overdepth) */
+        h->scan_fused = !h->windowed && h->totals.toodeep == 0;
+        if (!h->scan_fused)
+            CRUMBLE_LAUNCH(k_scan_apply, nchunks, 256, st, L, colrec, nplp, trigcnt, partial, nchunks,
+                                 h->d_dpre.as<int64_t>(), h->d_col_ord.as<int32_t>(), h->d_trig_ord.as<int32_t>(),
+                                 h->d_item_off.as<int32_t>(), h->d_ins_ord.as<int32_t>());
         const int nt = h->totals.trigcols, nit = h->totals.items, ni = h->totals.ins;
         int e;
         if ((e = h->d_trigcol_pos.reserve((size_t)(nt + 1) * 4)) || (e = h->d_trigcol_off.reserve((size_t)(nt + 1) * 4)) ||
@@ -758,6 +762,21 @@ extern "C" int crumble_hip_run_depth(crumble_hip *h, const crumble_carry *in, cr
     if (cin.total_col < 0 || cin.total_col > 1048576 || cin.total_depth < 0) { g_last_error = "crumble_hip_run_depth: impossible carried state"; return CRUMBLE_EINVAL; }
     h->carry_in.total_col = cin.total_col; h->carry_in.total_depth = cin.total_depth;
     if (out) { out->total_col = cin.total_col; out->total_depth = cin.total_depth; }
+    if (L > 0 && h->scan_fused && out) {              /* the state at a cut is read from the prefix arrays */
+        CRUMBLE_LAUNCH(k_scan_apply, nchunks, 256, st, L, colrec, nplp, trigcnt, partial, nchunks,
+                             h->d_dpre.as<int64_t>(), h->d_col_ord.as<int32_t>(), h->d_trig_ord.as<int32_t>(),
+                             h->d_item_off.as<int32_t>(), h->d_ins_ord.as<int32_t>());
+        h->scan_fused = false;
+    }
+    if (L > 0 && h->scan_fused) {
+        const int64_t ncols = h->totals.cols, first = 1048577 - cin.total_col;
+        int n = 0;
+        if (ncols > 0) n = 1 + (int)((ncols > first) ? (ncols - first + 524288) / 524289 : 0);
+        if (n > MAX_EPOCHS - 1) n = MAX_EPOCHS - 1;
+        if (n > 1)
+            CRUMBLE_LAUNCH(k_epochs_find, n - 1, 64, st, L, colrec, nplp, partial, nchunks, h->d_epochs.as<Epoch>(), (int64_t)cin.total_col);
+        CRUMBLE_LAUNCH_INDEP(k_epochs_td, 1, 1, st, h->d_epochs.as<Epoch>(), n, d_nep, (int64_t)cin.total_col, (int64_t)cin.total_depth);
+    } else
     if (L > 0) {
         if (h->totals.toodeep == 0)
             CRUMBLE_LAUNCH(k_epochs_par, 1, 256, st, L, colrec, h->d_col_ord.as<int32_t>(), h->d_dpre.as<int64_t>(),
@@ -785,6 +804,10 @@ extern "C" int crumble_hip_run_triggers(crumble_hip *h)
     RUN_LOCALS
     if (L > 0) {
         STAGE("k_overdepth", 0);
+        if (h->scan_fused)
+            CRUMBLE_LAUNCH(k_scan_overdepth, nchunks, 256, st, L, colrec, nplp, trigcnt, partial, h->d_epochs.as<Epoch>(), d_nep, P,
+                           trigcol_pos, trigcol_off, inscol_pos, stats, B.stat_hi);
+        else
         CRUMBLE_LAUNCH_INDEP(k_overdepth, nblk((L + 3) / 4, 256), 256, st, L, colrec, nplp, h->d_col_ord.as<int32_t>(),
                              h->d_dpre.as<int64_t>(), h->d_trig_ord.as<int32_t>(), h->d_item_off.as<int32_t>(),
                              h->d_ins_ord.as<int32_t>(), h->d_epochs.as<Epoch>(), d_nep, P,

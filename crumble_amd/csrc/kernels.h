@@ -967,12 +967,10 @@ __global__ void k_depth_state_at(int L, int cut, const uint32_t *colrec, const i
 
 /* over-depth test per column (snp:1673-1681) + compaction of the trigger and
  * histogram columns. */
-__device__ __forceinline__ void overdepth_col(int i, uint32_t rec, int64_t ord, int n, int64_t dp, uint32_t *colrec,
-                                              const int32_t *trig_ord, const int32_t *item_off, const int32_t *ins_ord,
-                                              const Epoch *ep, int nep, double over_depth, int32_t *trigcol_pos,
-                                              int32_t *trigcol_off, int32_t *inscol_pos, u64 *stats, int stat_hi)
+/* the test of one counted, not too deep column: sets CR_KEEP | CR_R_DEEP in its record when it fires */
+__device__ __forceinline__ void overdepth_test(int i, uint32_t rec, int64_t ord, int n, int64_t dp, uint32_t *colrec,
+                                               const Epoch *ep, int nep, double over_depth, u64 *stats, int stat_hi)
 {
-    if (!(rec & CR_COUNTED) || (rec & CR_TOODEEP)) return;
     /* last epoch with ord_start <= ord.  Epochs are ~2^20 columns first and ~2^19 afterwards, so an
      * arithmetic guess is right or off by one: two probes instead of a dependent binary search */
     int lo = ord < (1 << 20) ? 0 : 1 + (int)((ord - (1 << 20)) >> 19);
@@ -983,10 +981,17 @@ __device__ __forceinline__ void overdepth_col(int i, uint32_t rec, int64_t ord, 
     const int64_t total_col = e.tc_start + (ord - e.ord_start + 1);
     const int64_t total_depth = e.td_start + (dp + n - e.dpre_start);
     if ((double)((int64_t)n * (total_col + 1)) > over_depth * (double)(total_depth + 1)) {
-        rec |= CR_KEEP | CR_R_DEEP;
-        colrec[i] = rec;
+        colrec[i] = rec | CR_KEEP | CR_R_DEEP;
         stat_inc(stats, ST_OVER_DEPTH, i < stat_hi);
     }
+}
+__device__ __forceinline__ void overdepth_col(int i, uint32_t rec, int64_t ord, int n, int64_t dp, uint32_t *colrec,
+                                              const int32_t *trig_ord, const int32_t *item_off, const int32_t *ins_ord,
+                                              const Epoch *ep, int nep, double over_depth, int32_t *trigcol_pos,
+                                              int32_t *trigcol_off, int32_t *inscol_pos, u64 *stats, int stat_hi)
+{
+    if (!(rec & CR_COUNTED) || (rec & CR_TOODEEP)) return;
+    overdepth_test(i, rec, ord, n, dp, colrec, ep, nep, over_depth, stats, stat_hi);
     if (rec & CR_TRIG) { trigcol_pos[trig_ord[i]] = i; trigcol_off[trig_ord[i]] = item_off[i]; }
     if (rec & CR_HASINS) inscol_pos[ins_ord[i]] = i;
 }
@@ -1015,6 +1020,99 @@ k_overdepth(int L, uint32_t *colrec, const int32_t *nplp, const int32_t *col_ord
         for (int i = i0; i < L; i++)
             overdepth_col(i, colrec[i], col_ord[i], nplp[i], dpre[i], colrec, trig_ord, item_off, ins_ord, ep, nep, od,
                           trigcol_pos, trigcol_off, inscol_pos, stats, stat_hi);
+    }
+}
+
+/* ---- the same two steps without the per-column prefix arrays (whole contigs without a too-deep column: the usual
+ * case).  k_scan_apply wrote 12 B per column (depth prefix, ordinal) that only k_epochs_par and k_overdepth read
+ * back.  Here the epochs come from the chunk prefixes plus a walk inside one chunk each, and the pass that knows
+ * every column's prefixes applies the over-depth test and fills the trigger / insertion column lists itself. */
+
+/* one wave per epoch k >= 1: the counted column with ordinal ord_k and the depth prefix in front of it */
+__global__ void __launch_bounds__(64)
+k_epochs_find(int L, const uint32_t *__restrict__ colrec, const int32_t *__restrict__ nplp,
+              const ScanVal *__restrict__ partial, int nchunks, Epoch *__restrict__ ep, int64_t tc0)
+{
+    const int k = blockIdx.x + 1, lane = threadIdx.x;
+    const int64_t ord = (1048577 - tc0) + (int64_t)(k - 1) * 524289;
+    int lo = 0, hi = nchunks;                              /* last chunk whose exclusive column count is <= ord */
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int64_t)partial[mid].cols <= ord) lo = mid; else hi = mid; }
+    const int base = lo * SCAN_CHUNK, per = SCAN_CHUNK / 64;
+    /* lane l takes `per` consecutive columns: its sums, the wave's exclusive prefix, then the lane that holds the
+     * ordinal walks its slice */
+    int cnt = 0;
+    int64_t dep = 0;
+    for (int j = 0; j < per; j++) {
+        const int i = base + lane * per + j;
+        if (i < L && (colrec[i] & CR_COUNTED)) { cnt++; dep += nplp[i]; }
+    }
+    int pc = cnt;
+    int64_t pd = dep;
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int oc = __shfl_up(pc, d); const int64_t od = __shfl_up(pd, d);
+        if (lane >= d) { pc += oc; pd += od; }
+    }
+    const int64_t c0 = (int64_t)partial[lo].cols + (pc - cnt);      /* counted columns before this lane's slice */
+    int64_t d0 = (int64_t)partial[lo].depth + (pd - dep);
+    if (ord >= c0 && ord < c0 + cnt) {
+        int64_t c = c0;
+        for (int j = 0; j < per; j++) {
+            const int i = base + lane * per + j;
+            if (i < L && (colrec[i] & CR_COUNTED)) {
+                if (c == ord) { ep[k].ord_start = ord; ep[k].tc_start = 524288; ep[k].dpre_start = d0; ep[k].td_start = 0; break; }
+                c++; d0 += nplp[i];
+            }
+        }
+    }
+}
+__global__ void k_epochs_td(Epoch *ep, int n, int *n_ep, int64_t tc0, int64_t td0)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    ep[0].ord_start = 0; ep[0].tc_start = tc0; ep[0].dpre_start = 0; ep[0].td_start = td0;
+    int64_t td = td0;
+    for (int k = 0; k + 1 < n; k++) {
+        td = (td + ep[k + 1].dpre_start - ep[k].dpre_start) >> 1;
+        ep[k + 1].td_start = td;
+    }
+    *n_ep = n;
+}
+
+/* k_scan_apply + k_overdepth in one pass over the columns */
+__global__ void __launch_bounds__(256)
+k_scan_overdepth(int L, uint32_t *colrec, const int32_t *nplp, const int32_t *trigcnt, const ScanVal *partial,
+                 const Epoch *ep, const int *n_ep, const DParams *P, int32_t *trigcol_pos, int32_t *trigcol_off,
+                 int32_t *inscol_pos, u64 *stats, int stat_hi)
+{
+    __shared__ ScanVal ws[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int base = blockIdx.x * SCAN_CHUNK;
+    const int nep = *n_ep;
+    const double od = P->over_depth;
+    ScanVal carry = partial[blockIdx.x];
+    for (int k = 0; k < SCAN_CHUNK / 256; k++) {
+        const int i = base + k * 256 + (int)threadIdx.x;
+        ScanVal v = {0, 0, 0, 0, 0, 0, 0};
+        uint32_t rec = 0;
+        int n = 0;
+        if (i < L) { rec = colrec[i]; n = nplp[i]; scanval_of(rec, n, trigcnt[i], v); }
+        ScanVal inc = scanval_wave_incl01(v, lane);
+        __syncthreads();                               /* ws reuse */
+        if (lane == 63) ws[w] = inc;
+        __syncthreads();
+        ScanVal run = carry;
+        for (int j = 0; j < w; j++) scanval_add(run, ws[j]);
+        if (i < L && (rec & CR_COUNTED) && !(rec & CR_TOODEEP)) {
+            const int64_t ord = run.cols + inc.cols - v.cols, dp = run.depth + inc.depth - v.depth;
+            overdepth_test(i, rec, ord, n, dp, colrec, ep, nep, od, stats, stat_hi);
+            /* the lists are indexed by the exclusive prefixes k_scan_apply would have stored */
+            if (rec & CR_TRIG) {
+                const int t = (int)(run.trigcols + inc.trigcols - v.trigcols);
+                trigcol_pos[t] = i; trigcol_off[t] = (int)(run.items + inc.items - v.items);
+            }
+            if (rec & CR_HASINS) inscol_pos[(int)(run.ins + inc.ins - v.ins)] = i;
+        }
+        for (int j = 0; j < (int)(blockDim.x >> 6); j++) scanval_add(carry, ws[j]);
     }
 }
 
