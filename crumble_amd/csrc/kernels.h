@@ -1275,11 +1275,16 @@ __device__ __forceinline__ int dev_add_rep(const StrWin &w, int len, int pos, in
  * time on the two bit planes (funnel shifts across the word boundary, run-ANDs by doubling); the
  * positions with a hit are then visited in order, and only those reach add_rep().  The first 15
  * positions (every period that fits, ascending) keep the reference's rolling word. */
-__device__ __forceinline__ int dev_find_STR(const StrWin &w, int len, short *st, short *en, int *overflow)
+/* pos_limit: positions beyond it are not visited.  mask_LC_regions only keeps the repeats that overlap
+ * [rpos - add, rpos + add]; a repeat found at position p starts at p + 1 - 2 * period >= p - 15 and can evict only
+ * repeats that start at or after its own start, so what is found more than 15 positions to the right of that zone
+ * neither is kept nor evicts anything that is (the extension of a repeat to the right still reads the whole
+ * window). */
+__device__ __forceinline__ int dev_find_STR(const StrWin &w, int len, short *st, short *en, int *overflow, int pos_limit)
 {
     int n = 0, ts = 0, te = -1;
     uint32_t word = 0;
-    for (int i = 0; i < len && i < 15; i++) {
+    for (int i = 0; i < len && i < 15 && i <= pos_limit; i++) {
         word = (word << 2) | (uint32_t)str_code(w, i);
         for (int rlen = 1; rlen <= 7; rlen++) {             /* every period that fits */
             if (i < 2 * rlen - 1) break;
@@ -1292,7 +1297,9 @@ __device__ __forceinline__ int dev_find_STR(const StrWin &w, int len, short *st,
      * cross the word boundary) */
     uint32_t Dp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t x0p = 0, x1p = 0;                              /* planes of the previous word */
-    const int nw = (len + 31) >> 5;
+    int nw = (len + 31) >> 5;
+    if (pos_limit < 0) nw = 0;
+    else if ((pos_limit >> 5) + 1 < nw) nw = (pos_limit >> 5) + 1;
     for (int wi = 0; wi < nw; wi++) {
         const uint32_t x0 = w.w[wi * 64], x1 = w.w[(STR_PW + wi) * 64];
         uint32_t E[8];
@@ -1318,7 +1325,8 @@ __device__ __forceinline__ int dev_find_STR(const StrWin &w, int len, short *st,
         x0p = x0; x1p = x1;
         uint32_t any = E[0] | E[1] | E[2] | E[3] | E[4] | E[5] | E[6] | E[7];
         if (wi == 0) any &= ~0x7fffu;                       /* positions 0..14 were handled above */
-        if (wi == nw - 1 && (len & 31)) any &= (1u << (len & 31)) - 1u;
+        if (wi == ((len + 31) >> 5) - 1 && (len & 31)) any &= (1u << (len & 31)) - 1u;
+        if (wi == (pos_limit >> 5) && (pos_limit & 31) != 31) any &= (2u << (pos_limit & 31)) - 1u;
         while (any) {
             const int b = __builtin_ctz(any);
             any &= any - 1;
@@ -1428,8 +1436,9 @@ __device__ inline void dev_mask_lc(const DBatch &B, const DParams *P, int r, int
         lds_lane[k * 64] = p0; lds_lane[(STR_PW + k) * 64] = p1;
     }
     StrWin w; w.w = lds_lane;
-    const int n = dev_find_STR(w, len, st, en, overflow);
     const int add = is_indel ? P->iSTR_add : P->sSTR_add;
+    const int64_t lim = (int64_t)rpos + (add > 0 ? add : 0) - start + 15;
+    const int n = dev_find_STR(w, len, st, en, overflow, lim > len ? len : (int)lim);
     const uint32_t *cig = B.cigar + B.cig_off[r];
     const int nc = (int)(B.cig_off[r + 1] - B.cig_off[r]);
     for (int i = 0; i < n; i++) {
