@@ -852,7 +852,9 @@ extern "C" int crumble_hip_run_fold(crumble_hip *h, const crumble_carry *in, cru
                                  colrec, h->d_pos_mn2.as<int32_t>(), h->d_trig_mx2.as<int32_t>(),
                                  cin.min_pos, cin.max_pos, cin.min_pos2, cin.max_pos2, B.p0 + B.stat_hi, d_carry);
         }
-        if (h->windowed && (int64_t)cin.max_pos2 >= (int64_t)B.p0 + B.col_lo)
+        /* the window's first columns are "in window" while the carried state is live: snp:1880 tests
+         * min_pos != INT_MAX, after the reset of every column with pos > max_pos2 (snp:1508) */
+        if (h->windowed && cin.min_pos != INT_MAX && (int64_t)cin.max_pos2 >= (int64_t)B.p0 + B.col_lo)
             CRUMBLE_LAUNCH_INDEP(k_window_head, 64, 256, st, B, n_trig, trigcol_pos, cin.max_pos2, colrec);
     }
     if (out) {

@@ -170,3 +170,14 @@ def test_emu_window_then_whole_batch_again(product):
     got = eng.download()
     eng.close()
     assert all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
+def test_emu_windows_contig_starting_at_position_zero(product):
+    """The start-of-contig carry has max_pos2 == 0: position 0 is not "in window" for that (snp:1880 tests
+    min_pos != INT_MAX, not pos <= max_pos2) -- found by tools/gpu_fuzz.py seed 5121."""
+    import emu_lib
+    hb = synth.generate(synth.config("chr20", scale=0.0003, seed=12))
+    hb.pos -= hb.pos.min()
+    assert hb.pos[0] == 0
+    _check(emu_lib.engine, hb, ca.preset_params(5), 3)
+    _check(emu_lib.engine, hb, ca.preset_params(9, qlow=5), 2)

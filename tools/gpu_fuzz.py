@@ -17,6 +17,19 @@ for seed in range(s0, s0 + n):
         assert_parity(lambda q: ca.Engine(q, 0, options={"kcol": kcol}), p, hb)
         if seed % 10 == 0:
             assert_parity(lambda q: ca.Engine(q, 0, options={"kcol": kcol}), p, tiny_reads_batch(seed, n=2000), check_columns=False)
+        if seed % 3 == 0 and hb.n_reads >= 8 and hb.tid >= 0:          # the same contig cut into windows
+            import numpy as np
+            import oracle_lib as O
+            from crumble_amd import windows
+            nw = 2 + seed % 4
+            engs = [ca.Engine(p, 0) for _ in range(nw)]
+            try:
+                got = windows.run(engs, hb, nw)
+            finally:
+                for e_ in engs:
+                    e_.close()
+            want = O.contig(p, hb)
+            assert all(np.array_equal(a, b) for a, b in zip(got, want)), "windows differ from the whole contig"
     except Exception as e:
         bad += 1
         print("FAIL", desc, str(e)[:300], flush=True)
