@@ -759,10 +759,12 @@ extern "C" int crumble_hip_run_depth(crumble_hip *h, const crumble_carry *in, cr
     if (!h || !h->have_batch || h->phase != 1) { g_last_error = "crumble_hip_run_depth: run the columns first"; return CRUMBLE_EINVAL; }
     RUN_LOCALS
     const crumble_carry cin = in ? *in : CARRY0;
-    if (cin.total_col < 0 || cin.total_col > 1048576 || cin.total_depth < 0) { g_last_error = "crumble_hip_run_depth: impossible carried state"; return CRUMBLE_EINVAL; }
+    /* (total_col passes 2^20 + 1 only while the columns at the halving point are too deep: snp:1493-1500 skips the halving) */
+    if (cin.total_col < 0 || cin.total_col > ((int64_t)1 << 40) || cin.total_depth < 0) { g_last_error = "crumble_hip_run_depth: impossible carried state"; return CRUMBLE_EINVAL; }
+    const bool late = cin.total_col > 1048576;         /* the halving is overdue: the general epoch walk */
     h->carry_in.total_col = cin.total_col; h->carry_in.total_depth = cin.total_depth;
     if (out) { out->total_col = cin.total_col; out->total_depth = cin.total_depth; }
-    if (L > 0 && h->scan_fused && out) {              /* the state at a cut is read from the prefix arrays */
+    if (L > 0 && h->scan_fused && (out || late)) {    /* the state at a cut is read from the prefix arrays */
         CRUMBLE_LAUNCH(k_scan_apply, nchunks, 256, st, L, colrec, nplp, trigcnt, partial, nchunks,
                              h->d_dpre.as<int64_t>(), h->d_col_ord.as<int32_t>(), h->d_trig_ord.as<int32_t>(),
                              h->d_item_off.as<int32_t>(), h->d_ins_ord.as<int32_t>());
@@ -778,7 +780,7 @@ extern "C" int crumble_hip_run_depth(crumble_hip *h, const crumble_carry *in, cr
         CRUMBLE_LAUNCH_INDEP(k_epochs_td, 1, 1, st, h->d_epochs.as<Epoch>(), n, d_nep, (int64_t)cin.total_col, (int64_t)cin.total_depth);
     } else
     if (L > 0) {
-        if (h->totals.toodeep == 0)
+        if (h->totals.toodeep == 0 && !late)
             CRUMBLE_LAUNCH(k_epochs_par, 1, 256, st, L, colrec, h->d_col_ord.as<int32_t>(), h->d_dpre.as<int64_t>(),
                            partial + nchunks, h->d_epochs.as<Epoch>(), d_nep, (int64_t)cin.total_col, (int64_t)cin.total_depth);
         else

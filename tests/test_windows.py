@@ -81,9 +81,21 @@ def test_emu_window_phase_order_is_checked():
     eng.run_columns()
     with pytest.raises(ca.CrumbleError):
         eng.run_fold(windows.Carry.start(), windows.Carry.start())
-    bad = windows.Carry.start(); bad.total_col = 1 << 21
+    bad = windows.Carry.start(); bad.total_col = -1
     with pytest.raises(ca.CrumbleError):
         eng.run_depth(bad, windows.Carry.start())
+    # a carried state whose halving is overdue (total_col beyond 2^20 + 1: the columns at the halving point of the
+    # window before were too deep, snp:1493-1500): the first counted column halves it (snp:1684-1687)
+    late, out = windows.Carry.start(), windows.Carry.start()
+    late.total_col, late.total_depth = (1 << 20) + 5, 31_000_000
+    eng.set_window(windows.Window(int(hb.pos[0]), 2**31 - 2, 2**31 - 2, 0, 0, hb.n_reads))
+    eng.run_columns()
+    eng.run_depth(late, out)
+    eng.run_triggers(); eng.run_fold(late, windows.Carry.start()); eng.run_finish()
+    cols = eng.columns()
+    d = cols["n_plp"][cols["skipped"] != 1].astype(np.int64)         # counted columns (all-refskip ones are not)
+    assert out.total_col == ((late.total_col + 1) >> 1) + len(d) - 1
+    assert out.total_depth == ((late.total_depth + int(d[0])) >> 1) + int(d[1:].sum())
     eng.close()
 
 
