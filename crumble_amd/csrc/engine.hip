@@ -57,7 +57,7 @@ struct crumble_hip {
     DParams hparams;
     DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc, d_mqslot;
     /* batch (inputs) */
-    DevBuf d_vrec, d_pbdirty, d_ufirst, d_tcum, d_tpart, d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
+    DevBuf d_genlist, d_vrec, d_pbdirty, d_ufirst, d_tcum, d_tpart, d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
            d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax;
     /* per position */
     DevBuf d_colrec, d_nplp, d_score, d_trigcnt, d_dpre, d_col_ord, d_trig_ord, d_item_off,
@@ -74,7 +74,7 @@ struct crumble_hip {
     int opt_kcol = 0;               /* 0 auto (k_columns2 where it applies), 1 k_columns, 2 k_columns PERM, 3 k_columns2 */
     int opt_pblock = 0;             /* 0 auto, 1 one lane per read, 2 segment-parallel */
     int opt_replay = 0;             /* 0 auto, 1 k_replay_flat */
-    int64_t n_reads = 0, n_bases = 0, n_cigar = 0, n_slow = 0, n_segrec = 0;
+    int64_t n_reads = 0, n_bases = 0, n_cigar = 0, n_slow = 0, n_segrec = 0, n_general_max = 0;
     bool packed_ok = false;         /* the packed replay's value formulas hold for these parameters (set at create) */
     bool have_vrec = false;         /* long-read batch: territories + chunk table built (k_p0_vrecs) */
     bool batch_flat = false;        /* "replay" = flat as it stood when the batch was uploaded (decides which tables exist) */
@@ -263,7 +263,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    DevBuf *all[] = { &h->d_vrec, &h->d_params, &h->d_tables, &h->d_stats, &h->d_batch_stats, &h->d_misc, &h->d_mqslot,
+    DevBuf *all[] = { &h->d_genlist, &h->d_vrec, &h->d_params, &h->d_tables, &h->d_stats, &h->d_batch_stats, &h->d_misc, &h->d_mqslot,
         &h->d_ufirst, &h->d_tcum, &h->d_tpart, &h->d_pbdirty, &h->d_pbwmm, &h->d_act, &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
         &h->d_slow_g, &h->d_slow_r, &h->d_cix, &h->d_sr, &h->d_stile_lo, &h->d_stile_hi, &h->d_rr, &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
         &h->d_cigar, &h->d_segs, &h->d_bases, &h->d_quals, &h->d_tile_lo, &h->d_tile_hi,
@@ -378,7 +378,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
         (e = h->d_p0part.reserve((size_t)(nchunks + 2) * sizeof(P0Cnt))) || (e = h->d_misc.reserve(256)))
         return e;
     int *d_err = h->d_misc.as<int>() + 8, *d_minmax = d_err + 1, *d_nslow = d_err + 3;
-    const int init[4] = {0, INT_MAX, INT_MIN, 0};
+    const int init[5] = {0, INT_MAX, INT_MIN, 0, 0};        /* error, min pos, max end, n_slow, n_general */
     HIPCHK(hipMemcpyAsync(d_err, init, sizeof init, hipMemcpyHostToDevice, st));
     P0Cnt *cnt = h->d_p0cnt.as<P0Cnt>(), *part = h->d_p0part.as<P0Cnt>();
     P0Cnt tot = {0, 0, 0};
@@ -454,6 +454,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     }
     h->n_reads = n; h->n_bases = nb; h->n_cigar = nc;
     h->n_segrec = tot.nseg; h->n_slow = tot.nslow;  /* upper bound; the exact count is d_nslow */
+    h->n_general_max = tot.ncix / CIX_UNIT;         /* upper bound; the exact count is d_nslow[1] */
 
     /* 3. expanded tables */
     const size_t ns = (size_t)tot.nseg;
@@ -465,7 +466,8 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     if ((e = h->d_segs.reserve((ns + 1) * sizeof(Seg))) || (e = h->d_sr.reserve((ns + 1) * sizeof(SegRec))) ||
         (e = h->d_sr_ppos.reserve((ns + 1) * 4)) || (e = h->d_sr_pend.reserve((ns + 1) * 4)) ||
         (e = h->d_rr.reserve((size_t)(n + 1) * sizeof(ReadRec))) || (e = h->d_seg_off.reserve((size_t)(n + 2) * 8)) ||
-        (e = h->d_cix.reserve((want_cix ? (size_t)tot.ncix + 1 : 1) * 4)) || (e = h->d_slow_g.reserve(((size_t)tot.nslow + 1) * 8)) ||
+        (e = h->d_cix.reserve((want_cix ? (size_t)tot.ncix + 1 : 1) * 4)) ||
+        (e = h->d_genlist.reserve(((size_t)(tot.ncix / CIX_UNIT) + 1) * 4)) ||     /* every general read with bases has >= one unit */ (e = h->d_slow_g.reserve(((size_t)tot.nslow + 1) * 8)) ||
         (e = h->d_slow_r.reserve(((size_t)tot.nslow + 1) * 4)) || (e = h->d_kpos.reserve((size_t)(n + 1) * 4)) ||
         (e = h->d_kend.reserve((size_t)(n + 1) * 4)) || (e = h->d_tile_lo.reserve((size_t)(B.n_tiles + 1) * 4)) ||
         (e = h->d_tile_hi.reserve((size_t)(B.n_tiles + 1) * 4)) || (e = h->d_stile_lo.reserve((size_t)(B.n_tiles + 1) * 4)) ||
@@ -478,7 +480,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
                              h->d_inplp.as<uint8_t>(), h->d_end.as<int32_t>(), cnt, part + nchunks,
                              h->d_segs.as<Seg>(), h->d_sr.as<SegRec>(), h->d_sr_ppos.as<int32_t>(), h->d_sr_pend.as<int32_t>(),
                              h->d_rr.as<ReadRec>(), h->d_seg_off.as<int64_t>(), h->d_cix.as<int32_t>(),
-                             h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(), d_nslow, h->d_mqslot.as<uint8_t>(), want_cix);
+                             h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(), d_nslow, h->d_mqslot.as<uint8_t>(), want_cix, h->d_genlist.as<int32_t>());
         CRUMBLE_LAUNCH_INDEP(k_p0_keys, nblk(n, 256), 256, st, n, h->d_pos.as<int32_t>(), h->d_end.as<int32_t>(),
                              h->d_inplp.as<uint8_t>(), h->d_kpos.as<int32_t>(), h->d_kend.as<int32_t>());
         if ((e = prefix_max(h, h->d_kpos.as<int32_t>(), n)) || (e = prefix_max(h, h->d_kend.as<int32_t>(), n)) ||
@@ -889,15 +891,17 @@ extern "C" int crumble_hip_run_finish(crumble_hip *h)
             int ea;
             if ((ea = h->d_act.reserve((size_t)L + 2 * ACT_PAD))) return ea;
             uint8_t *act = h->d_act.as<uint8_t>() + ACT_PAD;
-            if (L > 0) CRUMBLE_LAUNCH_INDEP(k_actions, nblk(L, 256), 256, st, L, colrec, act);
+            if (L > 0) CRUMBLE_LAUNCH_INDEP(k_actions, nblk((L + 3) / 4, 256), 256, st, L, colrec, act);
 #define RFAST_LAUNCH(V_, PV_) CRUMBLE_LAUNCH_INDEP((k_replay_fast<V_, PV_>), nblk((nb + 15) / 16, 256), 256, st, B, P, colrec, act, \
                                      h->d_chunk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(), h->d_b15f.as<uint8_t>())
             const bool pv = h->hparams.n_pv > 0;
             if (h->have_vrec) { if (pv) RFAST_LAUNCH(true, true); else RFAST_LAUNCH(true, false); }
             else {
                 if (pv) RFAST_LAUNCH(false, true); else RFAST_LAUNCH(false, false);
-                CRUMBLE_LAUNCH(k_replay_reads, nblk(n, 256), 256, st, B, P, colrec,
-                               h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(), h->d_b15f.as<uint8_t>());
+                if (h->n_general_max > 0)
+                    CRUMBLE_LAUNCH_INDEP(k_replay_reads, (unsigned)(h->n_general_max < 16384 ? h->n_general_max : 16384), 64, st, B, P, colrec,
+                                         h->d_genlist.as<int32_t>(), h->d_misc.as<int>() + 12,
+                                         h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(), h->d_b15f.as<uint8_t>());
             }
 #undef RFAST_LAUNCH
             if (h->n_slow > 0)

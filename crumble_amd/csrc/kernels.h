@@ -1902,11 +1902,8 @@ k_replay_flat(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
  *                   and the store are 16 bytes wide and coalesced.
  *   k_replay_reads  the reads with a general CIGAR (a few %): the wave takes them one at a time,
  *                   one lane per base, through replay_base(). */
-__global__ void k_actions(int L, const uint32_t *__restrict__ colrec, uint8_t *__restrict__ act)
+__device__ __forceinline__ unsigned action_of(uint32_t r)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= L) return;
-    const uint32_t r = colrec[c];
     const bool skip = (r & CR_SKIP) != 0;
     const unsigned pres = CR_PRESERVE(r);
     unsigned a = ((1u << CR_A1(r)) | (1u << CR_A2(r))) & 15u;
@@ -1914,7 +1911,18 @@ __global__ void k_actions(int L, const uint32_t *__restrict__ colrec, uint8_t *_
     if (!skip && (r & CR_WIN)) a |= 32u;
     if (!skip && ((r & CR_KEEP) || pres > 1)) a |= 64u;
     if (r & CR_PERFECT) a |= 128u;
-    act[c] = (uint8_t)a;
+    return a;
+}
+/* four columns per thread: one 16-byte load, one 4-byte store (the arrays start 16-byte aligned) */
+__global__ void k_actions(int L, const uint32_t *__restrict__ colrec, uint8_t *__restrict__ act)
+{
+    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (c >= L) return;
+    if (c + 3 < L) {
+        const uint4 r = *(const uint4 *)(colrec + c);
+        *(uint32_t *)(act + c) = action_of(r.x) | (action_of(r.y) << 8) | (action_of(r.z) << 16) | (action_of(r.w) << 24);
+    } else
+        for (int i = c; i < L; i++) act[i] = (uint8_t)action_of(colrec[i]);
 }
 
 #define PB4(x)       ((uint32_t)(x) * 0x01010101u)
@@ -2055,31 +2063,23 @@ k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
 
 __global__ void __launch_bounds__(256)
 k_replay_reads(DBatch B, const DParams *__restrict__ P, const uint32_t *__restrict__ colrec,
+               const int32_t *__restrict__ gen_list, const int *__restrict__ n_gen,
                uint8_t *__restrict__ out, uint8_t *__restrict__ keepf, uint8_t *__restrict__ b15f)
 {
+    /* one wave per general-CIGAR read of the list the upload made (k_p0_fill; it used to find them by scanning
+     * every read record: 0.34 ms on the chr20 set for 3 % of the reads) */
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int lq = 0, hm = 0;
-    unsigned cix = 0;
-    int64_t so = 0;
-    bool general = false;
-    if (r < B.n_reads) {
-        const ReadRec rr = B.rr[r];
-        lq = rr.lq; so = rr.so; cix = rr.cix;
-        general = rr.lq > 0 && rr.end > rr.pos && !(rr.info & RR_SIMPLE);
-        if (general) hm = (int)(rr.info & 255) <= P->min_mqual && !(colrec[rr.pos - B.p0] & CR_SKIP);
-    }
     const int qcap = P->qcap, qhigh = P->qhigh, qlow = P->qlow;
     const bool reduce = P->reduce_qual != 0, binary = P->binary_qual != 0, any_pres = P->any_preserve != 0;
-    unsigned long long todo = __ballot(general);
-    while (todo) {
-        const int src = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const int64_t rs = r - lane + src;
-        const int n = READLANE(lq, src), hms = READLANE(hm, src);
-        const unsigned cx = (unsigned)READLANE((int)cix, src);
-        const int64_t s0 = (int64_t)(((uint64_t)(unsigned)READLANE((int)((uint64_t)so >> 32), src) << 32) |
-                                     (unsigned)READLANE((int)(uint64_t)so, src));
+    const int ng = *n_gen;
+    for (int gi = blockIdx.x; gi < ng; gi += gridDim.x) {
+        const int64_t rs = gen_list[gi];
+        const ReadRec rr = B.rr[rs];
+        if (!(rr.lq > 0 && rr.end > rr.pos && !(rr.info & RR_SIMPLE))) continue;
+        const int n = rr.lq;
+        const int hms = ((int)(rr.info & 255) <= P->min_mqual && !(colrec[rr.pos - B.p0] & CR_SKIP)) ? 1 : 0;
+        const unsigned cx = rr.cix;
+        const int64_t s0 = rr.so;
         for (int x0 = lane; x0 < n; x0 += 256) {               /* four bases per lane: the gathers of all four in flight */
             /* base -> column table of the read (built with the batch): -1 no column, -2 a D/N column
              * reports this base (k_replay_slow, afterwards) */

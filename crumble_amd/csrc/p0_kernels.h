@@ -224,7 +224,7 @@ __global__ void k_p0_fill(int64_t n, int p0, const int32_t *__restrict__ pos, co
                           Seg *__restrict__ segs, SegRec *__restrict__ sr, int32_t *__restrict__ sr_ppos,
                           int32_t *__restrict__ sr_pend, ReadRec *__restrict__ rr, int64_t *__restrict__ seg_off,
                           int32_t *__restrict__ cix, int64_t *__restrict__ slow_g, int32_t *__restrict__ slow_r,
-                          int *n_slow, const uint8_t *__restrict__ mq_slot, int want_cix)
+                          int *n_slow, const uint8_t *__restrict__ mq_slot, int want_cix, int32_t *__restrict__ gen_list)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
@@ -275,6 +275,7 @@ __global__ void k_p0_fill(int64_t n, int p0, const int32_t *__restrict__ pos, co
     const Seg s0 = segs[s_first];
     const bool simple = nseg == 1 && seg_type(s0) == SEG_M && s0.indel_after == 0 && lq > 0;
     if (simple) { x.info |= RR_SIMPLE; rr[r] = x; return; }
+    if (lq > 0) gen_list[atomicAdd(n_slow + 1, 1)] = (int32_t)r;       /* k_replay_reads' work list (any order) */
     /* pass 2: base -> column table of a general CIGAR (replay).  Long-read batches that go through the packed replay
      * (territories, k_p0_vrecs) never look a base up: only the list of bases that D/N columns report is made -- a
      * base is reported by a run of consecutive D/N ops, so equal qstart of consecutive ops is the duplicate test */
