@@ -480,7 +480,9 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
                              h->d_inplp.as<uint8_t>(), h->d_end.as<int32_t>(), cnt, part + nchunks,
                              h->d_segs.as<Seg>(), h->d_sr.as<SegRec>(), h->d_sr_ppos.as<int32_t>(), h->d_sr_pend.as<int32_t>(),
                              h->d_rr.as<ReadRec>(), h->d_seg_off.as<int64_t>(), h->d_cix.as<int32_t>(),
-                             h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(), d_nslow, h->d_mqslot.as<uint8_t>(), want_cix, h->d_genlist.as<int32_t>());
+                             h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(), d_nslow, h->d_mqslot.as<uint8_t>(), want_cix);
+        if (tot.ncix > 0 && !vrec_path)                      /* short-read batches: k_replay_reads' list of general-CIGAR reads */
+            CRUMBLE_LAUNCH(k_p0_genlist, nblk(n, 1024), 1024, st, n, h->d_rr.as<ReadRec>(), h->d_genlist.as<int32_t>(), d_nslow + 1);
         CRUMBLE_LAUNCH_INDEP(k_p0_keys, nblk(n, 256), 256, st, n, h->d_pos.as<int32_t>(), h->d_end.as<int32_t>(),
                              h->d_inplp.as<uint8_t>(), h->d_kpos.as<int32_t>(), h->d_kend.as<int32_t>());
         if ((e = prefix_max(h, h->d_kpos.as<int32_t>(), n)) || (e = prefix_max(h, h->d_kend.as<int32_t>(), n)) ||

@@ -224,7 +224,7 @@ __global__ void k_p0_fill(int64_t n, int p0, const int32_t *__restrict__ pos, co
                           Seg *__restrict__ segs, SegRec *__restrict__ sr, int32_t *__restrict__ sr_ppos,
                           int32_t *__restrict__ sr_pend, ReadRec *__restrict__ rr, int64_t *__restrict__ seg_off,
                           int32_t *__restrict__ cix, int64_t *__restrict__ slow_g, int32_t *__restrict__ slow_r,
-                          int *n_slow, const uint8_t *__restrict__ mq_slot, int want_cix, int32_t *__restrict__ gen_list)
+                          int *n_slow, const uint8_t *__restrict__ mq_slot, int want_cix)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
@@ -275,7 +275,6 @@ __global__ void k_p0_fill(int64_t n, int p0, const int32_t *__restrict__ pos, co
     const Seg s0 = segs[s_first];
     const bool simple = nseg == 1 && seg_type(s0) == SEG_M && s0.indel_after == 0 && lq > 0;
     if (simple) { x.info |= RR_SIMPLE; rr[r] = x; return; }
-    if (lq > 0) gen_list[atomicAdd(n_slow + 1, 1)] = (int32_t)r;       /* k_replay_reads' work list (any order) */
     /* pass 2: base -> column table of a general CIGAR (replay).  Long-read batches that go through the packed replay
      * (territories, k_p0_vrecs) never look a base up: only the list of bases that D/N columns report is made -- a
      * base is reported by a run of consecutive D/N ops, so equal qstart of consecutive ops is the duplicate test */
@@ -376,6 +375,30 @@ __global__ void k_p0_owner_scatter(int64_t n, int64_t nb, const int64_t *__restr
         blk_read[(nb + 63) >> 6] = (int32_t)r;
         chunk_read[(nb + 15) >> 4] = (int32_t)r;
     }
+}
+
+/* k_replay_reads' work list: the reads with a general CIGAR and bases, in any order.  One atomic per 1024-thread
+ * workgroup (ballot + prefix popcount inside the waves, the wave totals through LDS): an atomic per read or per wave
+ * on the one counter costs more than the rest of the upload's kernels together. */
+__global__ void __launch_bounds__(1024)
+k_p0_genlist(int64_t n, const ReadRec *__restrict__ rr, int32_t *__restrict__ list, int *__restrict__ count)
+{
+    __shared__ int wcnt[16], wbase[16];
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    bool gen = false;
+    if (r < n) { const ReadRec x = rr[r]; gen = x.lq > 0 && x.end > x.pos && !(x.info & RR_SIMPLE); }
+    const unsigned long long m = __ballot(gen);
+    if (lane == 0) wcnt[w] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); k++) { wbase[k] = tot; tot += wcnt[k]; }
+        const int base = tot ? atomicAdd(count, tot) : 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); k++) wbase[k] += base;
+    }
+    __syncthreads();
+    if (gen) list[wbase[w] + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)r;
 }
 
 /* Long-read batches: the territories of every read (VRec, dev_common.h) and the chunk -> territory table, by scatter
