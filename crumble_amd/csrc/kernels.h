@@ -2409,9 +2409,14 @@ k_pb_marks(int64_t n_bases, const uint8_t *__restrict__ q, const DParams *__rest
     if (g0 >= n_bases) return;
     const int level2 = P->pblock * 2;
     const bool any_pres = P->any_preserve != 0;
+    /* the preserved values as (at most four) scalars: a table look-up per byte is a vector load per byte */
+    const int npv = P->n_pv;
+    const int pv0 = npv > 0 ? (int)P->pv_val[0] : -1, pv1 = npv > 1 ? (int)P->pv_val[1] : -1,
+              pv2 = npv > 2 ? (int)P->pv_val[2] : -1, pv3 = npv > 3 ? (int)P->pv_val[3] : -1;
+#define PB_IS_PRES(v_) (any_pres && (npv < 0 ? P->preserve_qual[v_] != 0 : ((v_) == pv0 || (v_) == pv1 || (v_) == pv2 || (v_) == pv3)))
     const int nn = (n_bases - g0 < 64) ? (int)(n_bases - g0) : 64;
     int prev = g0 > 0 ? (int)q[g0 - 1] : -1000;
-    bool prev_pres = g0 > 0 && any_pres && P->preserve_qual[prev];
+    bool prev_pres = g0 > 0 && PB_IS_PRES(prev);
     u64 m = 0;
     int wmin = 255, wmax = 0;                            /* of the word's bytes: lets a long segment step 64 bases at once */
     for (int k0 = 0; k0 < nn; k0 += 16) {
@@ -2421,13 +2426,14 @@ k_pb_marks(int64_t n_bases, const uint8_t *__restrict__ q, const DParams *__rest
         #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int v = (int)((wd[k >> 2] >> (8 * (k & 3))) & 255);
-            const bool pres = any_pres && P->preserve_qual[v];
+            const bool pres = PB_IS_PRES(v);
             int d = v - prev; d = d < 0 ? -d : d;
             if (k0 + k < nn && (pres || prev_pres || d > level2)) m |= 1ull << (k0 + k);
             if (k0 + k < nn) { wmin = v < wmin ? v : wmin; wmax = v > wmax ? v : wmax; }
             prev = v; prev_pres = pres;
         }
     }
+#undef PB_IS_PRES
     stop[w] = m;
     wmm[w] = (uint16_t)(wmin | (wmax << 8));
     rstart[w] = 0;
