@@ -612,14 +612,15 @@ static int launch_pblock(crumble_hip *h, hipStream_t st, int64_t n_reads, int64_
     }
     if ((e = h->d_pbstop.reserve((size_t)(nwords + 1) * 8)) || (e = h->d_pbrs.reserve((size_t)(nwords + 1) * 8)) ||
         (e = h->d_pbruns.reserve((size_t)(nwords + 1) * 8)) || (e = h->d_pbval.reserve((size_t)nb + 64)) ||
-        (e = h->d_pbwmm.reserve((size_t)(nwords + 1) * 2)))
+        (e = h->d_pbwmm.reserve((size_t)(nwords + 1) * 2)) || (e = h->d_pbdirty.reserve((size_t)nwords + 64)))
         return e;
     u64 *stop = h->d_pbstop.as<u64>(), *rs = h->d_pbrs.as<u64>(), *runs = h->d_pbruns.as<u64>();
     uint8_t *val = h->d_pbval.as<uint8_t>();
+    HIPCHK(hipMemsetAsync(h->d_pbdirty.p, 0, (size_t)nwords, st));
     CRUMBLE_LAUNCH_INDEP(k_pb_marks, nblk(nwords, 256), 256, st, nb, out, P, stop, rs, runs, h->d_pbwmm.as<uint16_t>());
     CRUMBLE_LAUNCH_INDEP(k_pb_readstarts, nblk(n_reads, 256), 256, st, n_reads, seq_off, stop, rs);
-    CRUMBLE_LAUNCH_INDEP(k_pb_segments, nblk(nwords, 256), 256, st, nb, n_reads, seq_off, out, rflags, blk_read, stop, rs, runs, val, h->d_pbwmm.as<uint16_t>(), P);
-    CRUMBLE_LAUNCH_INDEP(k_pb_fill, nblk((nb + 15) / 16, 256), 256, st, nb, out, stop, runs, val, (const uint8_t *)nullptr);
+    CRUMBLE_LAUNCH_INDEP(k_pb_segments, nblk(nwords, 256), 256, st, nb, n_reads, seq_off, out, rflags, blk_read, stop, rs, runs, val, h->d_pbwmm.as<uint16_t>(), h->d_pbdirty.as<uint8_t>(), P);
+    CRUMBLE_LAUNCH_INDEP(k_pb_fill, nblk((nb + 15) / 16, 256), 256, st, nb, out, stop, runs, val, h->d_pbdirty.as<uint8_t>());
     return CRUMBLE_OK;
 }
 

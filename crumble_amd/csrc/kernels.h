@@ -2455,8 +2455,11 @@ __global__ void __launch_bounds__(256)
 k_pb_segments(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_off, const uint8_t *__restrict__ out,
               const uint8_t *__restrict__ rflags, const int32_t *__restrict__ blk_read,
               const u64 *__restrict__ stop, const u64 *__restrict__ rstart, u64 *__restrict__ runs,
-              uint8_t *__restrict__ runval, const uint16_t *__restrict__ wmm, const DParams *__restrict__ P)
+              uint8_t *__restrict__ runval, const uint16_t *__restrict__ wmm, uint8_t *__restrict__ dirty,
+              const DParams *__restrict__ P)
 {
+    /* dirty[word] = 1 for the words under a run that changes a byte (not all its bytes equal its value): k_pb_fill
+     * skips the others -- after the replay most long-read bases sit in runs of one repeated value */
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nwords = (n_bases + 63) >> 6;
     if (w >= nwords) return;
@@ -2569,6 +2572,8 @@ k_pb_segments(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_
                 int mid = (last_qmin + last_qmax) / 2;
                 if (mid > qcap) mid = qcap;
                 runval[j] = (uint8_t)mid;
+                if (last_qmin != last_qmax || mid != last_qmin)
+                    for (int64_t dw = j >> 6; dw <= (pos - 1) >> 6; dw++) dirty[dw] = 1;
                 atomicOr((unsigned long long *)&runs[pos >> 6], 1ull << (pos & 63));   /* the next run starts at pos */
                 qmin = qmax = last_qmin = last_qmax = hitq; j = pos; i = pos + 1;
             } else i = (base + 16 < e) ? base + 16 : e;
@@ -2579,6 +2584,8 @@ k_pb_segments(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_
             int mid = (last_qmin + last_qmax) / 2;
             if (!at_read_end && mid > qcap) mid = qcap;         /* the read's final run is not capped (snp:832) */
             runval[j] = (uint8_t)mid;
+            if (last_qmin != last_qmax || mid != last_qmin)
+                for (int64_t dw = j >> 6; dw <= (e - 1) >> 6; dw++) dirty[dw] = 1;
             open = false;
         }
     }
