@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--cpu-all", action="store_true", help="(default now) also time the CPU restatement on all host "
                     "cores (independent windows of the contig, one process per core): 'cpu_baseline_all'")
     ap.add_argument("--no-cpu-all", action="store_true", help="skip the all-core CPU leg")
+    ap.add_argument("--contig-threads", type=int, default=4, help="wgs: host threads that run the contigs' engines "
+                    "(one HIP stream each) side by side on the GPU; 1 = one contig at a time")
     ap.add_argument("--pmc-json", default=None, help="profiles/*_pmc_traffic.json measured for THIS build and "
                     "workload: fills roofline.traffic (null otherwise)")
     ap.add_argument("--kcol", default="auto", help="crumble_hip_set_option kcol (auto|v1|v1perm|v2)")
@@ -243,21 +245,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Several contigs per GPU (wgs): every contig has its own engine, i.e. its own HIP stream; a few host threads
+    # drive them side by side the way `crumble-hip -j N` with repeated devices does, so one contig's launch gaps,
+    # its mid-run size read-back and its tail run under another contig's kernels (~0.5 ms of each per contig).
+    pool = None
+    if len(engines) > 1 and args.contig_threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=args.contig_threads)
+
+    def run_all():
+        if pool is None:
+            for e_ in engines:
+                e_.run()                         # launches every kernel + stream sync
+        else:
+            list(pool.map(lambda e_: e_.run(), engines))    # (ctypes releases the GIL for the call)
+
     for _ in range(args.warmup):
-        for e_ in engines:
-            e_.run()
+        run_all()
     for e_ in engines:
         e_.stats_reset()
     sync_all()
     t0 = time.perf_counter()
     ktimes = {}
     for _ in range(args.steps):
+        run_all()
         for e_ in engines:
-            e_.run()                             # launches every kernel + stream sync
             for name, ms, by in e_.kernel_times():
                 a = ktimes.setdefault(name, [0.0, 0.0, 0])
                 a[0] += ms; a[1] += by; a[2] += 1
     sync_all()
+    if pool is not None:
+        pool.shutdown()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
