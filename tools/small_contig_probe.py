@@ -3,7 +3,7 @@
 reference: thousands of them, a few kb to a few hundred kb each)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import crumble_amd as ca
 import synth
 eng = ca.Engine(ca.preset_params(5), 0)
