@@ -75,6 +75,7 @@ struct crumble_hip {
     int opt_pblock = 0;             /* 0 auto, 1 one lane per read, 2 segment-parallel */
     int opt_replay = 0;             /* 0 auto, 1 k_replay_flat */
     int64_t n_reads = 0, n_bases = 0, n_cigar = 0, n_slow = 0, n_segrec = 0, n_general_max = 0;
+    void *pinned = nullptr;         /* 256 bytes of page-locked host memory: the small device->host read-backs land here */
     bool packed_ok = false;         /* the packed replay's value formulas hold for these parameters (set at create) */
     bool have_vrec = false;         /* long-read batch: territories + chunk table built (k_p0_vrecs) */
     bool batch_flat = false;        /* "replay" = flat as it stood when the batch was uploaded (decides which tables exist) */
@@ -224,6 +225,7 @@ extern "C" crumble_hip *crumble_hip_create(const crumble_params *p, int device, 
     }
     if (hipSetDevice(device) != hipSuccess) { g_last_error = "hipSetDevice failed"; return fail(CRUMBLE_EHIP); }
     if (hipStreamCreate(&h->stream) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(CRUMBLE_EHIP); }
+    if (hipHostMalloc(&h->pinned, 256, 0) != hipSuccess) { h->pinned = nullptr; g_last_error = "hipHostMalloc failed"; return fail(CRUMBLE_ENOMEM); }
     for (int i = 0; i <= MAX_STAGES; i++)
         if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(CRUMBLE_EHIP); }
     for (int i = 0; i < 3; i++)
@@ -274,6 +276,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
         &h->d_out, &h->d_rflags, &h->d_keepf, &h->d_b15f, &h->d_blk_read, &h->d_chunk_read, &h->d_kept };
     for (DevBuf *b : all) b->release();
     if (h->events_ok) { for (int i = 0; i <= MAX_STAGES; i++) (void)hipEventDestroy(h->ev[i]); for (int i = 0; i < 3; i++) (void)hipEventDestroy(h->ev_up[i]); }
+    if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -738,8 +741,9 @@ extern "C" int crumble_hip_run_columns(crumble_hip *h)
         STAGE("scan", 0);
         CRUMBLE_LAUNCH(k_scan_reduce, nchunks, 256, st, L, colrec, nplp, trigcnt, partial, nchunks);
         CRUMBLE_LAUNCH(k_scan_partials, 1, 1024, st, partial, nchunks);
-        HIPCHK(hipMemcpyAsync(&h->totals, partial + nchunks, sizeof(ScanVal), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h->pinned, partial + nchunks, sizeof(ScanVal), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));           /* sizes of the work lists */
+        memcpy(&h->totals, h->pinned, sizeof(ScanVal));
         /* a whole contig without a too-deep column needs no per-column prefix arrays (kernels.h, k_scan_overdepth) */
         h->scan_fused = !h->windowed && h->totals.toodeep == 0;
         if (!h->scan_fused)
@@ -944,8 +948,9 @@ extern "C" int crumble_hip_run_finish(crumble_hip *h)
     /* fold this batch's counters into the engine's accumulated stats vector, on the device */
     CRUMBLE_LAUNCH_INDEP(k_stats_fold, nblk(CRUMBLE_ST_N, 64), 64, st, h->d_stats.as<u64>(), (const u64 *)stats, CRUMBLE_ST_N);
     int ovf[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(ovf, d_overflow, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h->pinned, d_overflow, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    memcpy(ovf, h->pinned, 8);
     HIPCHK(hipGetLastError());
     for (int i = 0; i < h->n_stages; i++)
         HIPCHK(hipEventElapsedTime(&h->stage_ms[i], h->ev[i], h->ev[i + 1]));
