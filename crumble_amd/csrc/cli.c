@@ -128,12 +128,21 @@ static void *gpu_worker(void *a_)
     return NULL;
 }
 
-static void *writer_thread(void *p_)
+/* -b lines of one contig (snp_score.c:1496,1676,1768,1802,1810): name, pos-50 (>= 0), pos+50, reason */
+static void print_suspects(FILE *fp, const char *ref, const int32_t *pos, const uint8_t *bits, int64_t n)
 {
-    pipe_t *p = p_;
     static const struct { int bit; const char *name; } why[] = {
         { CRUMBLE_WHY_VDEEP, "VDEEP" }, { CRUMBLE_WHY_DEEP, "DEEP" }, { CRUMBLE_WHY_CLIP, "CLIP" },
         { CRUMBLE_WHY_INDEL_LEN, "INDEL_LEN" }, { CRUMBLE_WHY_INDEL_COVERAGE, "INDEL_COVERAGE" } };
+    for (int64_t k = 0; k < n; k++)
+        for (int y = 0; y < 5; y++)
+            if (bits[k] & why[y].bit)
+                fprintf(fp, "%s\t%d\t%d\t%s\n", ref, pos[k] > 50 ? pos[k] - 50 : 0, pos[k] + 50, why[y].name);
+}
+
+static void *writer_thread(void *p_)
+{
+    pipe_t *p = p_;
     for (;;) {
         pthread_mutex_lock(&p->mu);
         job *j = NULL;
@@ -154,11 +163,7 @@ static void *writer_thread(void *p_)
             p->failed = 2;
         }
         if (!p->failed) {
-            for (int64_t k = 0; k < j->n_sus; k++)
-                for (int y = 0; y < 5; y++)
-                    if (j->sus_why[k] & why[y].bit)
-                        fprintf(p->bed_fp, "%s\t%d\t%d\t%s\n", crumble_bam_ref_name(p->rd, j->B.tid),
-                                j->sus_pos[k] > 50 ? j->sus_pos[k] - 50 : 0, j->sus_pos[k] + 50, why[y].name);
+            if (j->n_sus) print_suspects(p->bed_fp, crumble_bam_ref_name(p->rd, j->B.tid), j->sus_pos, j->sus_why, j->n_sus);
             if (crumble_bam_write_detached(p->wr, j->g, j->qout)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); p->failed = 1; }
         }
         if (p->verbose > 1) fprintf(stderr, "  %s: %lld reads on device %d\n", crumble_bam_ref_name(p->rd, j->B.tid), (long long)j->B.n_reads, p->devices[j->dev]);
@@ -268,13 +273,14 @@ static void run_windowed(pipe_t *p, job *j)
         int64_t ek = w0;
         for (int64_t i = r0; i < r1; i++) if (end[i] > ek) ek = end[i];
         int64_t stat_end = r1 < n ? (int64_t)B->pos[r1] : (ek > pmax[n - 1] ? ek : pmax[n - 1]);
-        if (r1 >= n) ek = stat_end;
+        if (stat_end > ek) ek = stat_end;                       /* decide and count through to the next start: a read of an earlier
+                                                                 * window may cover columns behind the owned reads' end */
         int64_t lo = 0;
         if (k) { int64_t a = 0, b = r0; while (a < b) { const int64_t mid = (a + b) >> 1; if (pmax[mid] <= w0) a = mid + 1; else b = mid; } lo = a; }
         int64_t hi; { int64_t a = r1, b = n; while (a < b) { const int64_t mid = (a + b) >> 1; if (B->pos[mid] < ek) a = mid + 1; else b = mid; } hi = a; }
         if (ek > INT32_MAX || stat_end > INT32_MAX) { j->err = CRUMBLE_EINVAL; snprintf(j->errtxt, sizeof j->errtxt, "coordinate out of range"); goto done; }
         w->lo = lo; w->hi = hi;
-        w->w.col_start = (int32_t)w0; w->w.col_end = (int32_t)ek; w->w.stat_end = (int32_t)(stat_end < ek ? stat_end : ek);
+        w->w.col_start = (int32_t)w0; w->w.col_end = (int32_t)ek; w->w.stat_end = (int32_t)stat_end;
         w->w.read_first = r0 - lo; w->w.read_end = r1 - lo;
         const int64_t m = hi - lo, b0 = B->seq_off[lo], c0 = B->cig_off[lo];
         w->seq_off = malloc((size_t)(m + 1) * 8); w->cig_off = malloc((size_t)(m + 1) * 8);
@@ -437,6 +443,8 @@ int main(int argc, char **argv)
             char *cl = malloc(len), *q = cl;
             for (int i = 0; i < argc; i++) q += sprintf(q, "%s%s", i ? " " : "", argv[i]);
             int herr = 0;
+            if (ngpu > 1 || windowed)
+                fprintf(stderr, "crumble-hip: -j / -w apply to BAM in and out only; SAM / CRAM / -I / -O run one contig at a time on one device\n");
             crumble_hts *hs = crumble_hts_open(in_fn, in_fmt, out_fn, out_fmt, no_pg ? NULL : "crumble-hip", "0.2", cl, threads, &herr);
             if (!hs) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
             if (crumble_hts_set_aux_filter(hs, wl, bl, bd, bi)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
@@ -460,12 +468,19 @@ int main(int argc, char **argv)
                 if (qcap < nb + 16) { crumble_bam_big_free(qout, qcap); qcap = nb + nb / 8 + 64; qout = crumble_bam_big_alloc(qcap); if (!qout) { fprintf(stderr, "crumble-hip: out of memory\n"); return 1; } }
                 const int e = crumble_hip_contig(eng, &B, qout, NULL, stats);
                 if (e) { fprintf(stderr, "crumble-hip: contig %s: %s (%s)\n", crumble_hts_ref_name(hs, B.tid), crumble_hip_strerror(e), crumble_hip_last_error()); return 2; }
+                if (bed_fp && B.tid >= 0) {                              /* -b: the same lines as the BAM path */
+                    const int64_t ns = crumble_hip_suspect(eng, NULL, NULL, 0);
+                    int32_t *sp = malloc((size_t)(ns > 0 ? ns : 1) * 4); uint8_t *sw = malloc((size_t)(ns > 0 ? ns : 1));
+                    if (ns < 0 || !sp || !sw || crumble_hip_suspect(eng, sp, sw, ns) != ns) { fprintf(stderr, "crumble-hip: -b failed\n"); return 2; }
+                    print_suspects(bed_fp, crumble_hts_ref_name(hs, B.tid), sp, sw, ns);
+                    free(sp); free(sw);
+                }
                 if (crumble_hts_write_group(hs, qout)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
             }
             if (crumble_hts_close(hs)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
             if (verbose) for (int i = 0; i < (int)(sizeof ST_NAME / sizeof *ST_NAME); i++) fprintf(stderr, "%-16s %lld\n", ST_NAME[i], (long long)stats[i]);
             crumble_hip_destroy(eng); crumble_bam_big_free(qout, qcap); free(bt); free(bs); free(be); free(cl);
-            if (bed_fp) fclose(bed_fp);
+            if (bed_fp && fclose(bed_fp)) { perror("-b"); return 1; }
             return 0;
         }
     }
@@ -541,7 +556,7 @@ int main(int argc, char **argv)
         if (B.tid >= 0 && j2 > bed_i) { B.n_bed = j2 - bed_i; B.bed_start = bs + bed_i; B.bed_end = be + bed_i; }
         job *j = calloc(1, sizeof *j);
         t0 = now();
-        j->g = j ? crumble_bam_detach_group(rd) : NULL;
+        if (j) j->g = crumble_bam_detach_group(rd);
         t_read += now() - t0;
         if (!j || !j->g) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); rc_main = 1; free(j); break; }
         j->B = B; j->seq = seq++;
@@ -561,7 +576,10 @@ int main(int argc, char **argv)
             continue;
         }
         pthread_mutex_lock(&p.mu);
-        while (p.q_len[j->dev] >= MAX_INFLIGHT && !p.failed) pthread_cond_wait(&p.cv, &p.mu);   /* bounds the host memory */
+        /* bounds the host memory: a detached contig holds its records and output bytes until the WRITER has
+         * written it, so the bound counts contigs read but not yet written, not only the device's queue */
+        while ((p.q_len[j->dev] >= MAX_INFLIGHT || j->seq - p.next_write >= (int64_t)p.ndev * MAX_INFLIGHT) && !p.failed)
+            pthread_cond_wait(&p.cv, &p.mu);
         if (p.q_tail[j->dev]) p.q_tail[j->dev]->next = j; else p.q_head[j->dev] = j;
         p.q_tail[j->dev] = j; p.q_len[j->dev]++;
         const int failed = p.failed;

@@ -74,6 +74,7 @@ struct crumble_hip {
     int opt_kcol = 0;               /* 0 auto (k_columns2 where it applies), 1 k_columns, 2 k_columns PERM, 3 k_columns2 */
     int opt_pblock = 0;             /* 0 auto, 1 one lane per read, 2 segment-parallel */
     int opt_replay = 0;             /* 0 auto, 1 k_replay_flat */
+    int b_kcol = 0, b_pblock = 0;   /* the batch's snapshot of opt_kcol / opt_pblock (options take effect at an upload) */
     int64_t n_reads = 0, n_bases = 0, n_cigar = 0, n_slow = 0, n_segrec = 0, n_general_max = 0;
     void *pinned = nullptr;         /* 256 bytes of page-locked host memory: the small device->host read-backs land here */
     bool packed_ok = false;         /* the packed replay's value formulas hold for these parameters (set at create) */
@@ -455,6 +456,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
         h->col_perm = cnt > 0 && esum < 0.02 * (double)cnt;
         if (h->opt_kcol == 1 || h->opt_kcol == 2) h->col_perm = h->opt_kcol == 2;
     }
+    h->b_kcol = h->opt_kcol; h->b_pblock = h->opt_pblock;
     h->n_reads = n; h->n_bases = nb; h->n_cigar = nc;
     h->n_segrec = tot.nseg; h->n_slow = tot.nslow;  /* upper bound; the exact count is d_nslow */
     h->n_general_max = tot.ncix / CIX_UNIT;         /* upper bound; the exact count is d_nslow[1] */
@@ -582,13 +584,13 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
 /* P-block over a flat quality array (snp:803-834): stop masks, then one lane per 64-base word
  * replays the segments that start in its word (kernels.h). */
 static int launch_pblock(crumble_hip *h, hipStream_t st, int64_t n_reads, int64_t nb, const int64_t *seq_off,
-                         uint8_t *out, const uint8_t *rflags, const int32_t *blk_read)
+                         uint8_t *out, const uint8_t *rflags, const int32_t *blk_read, int mode)
 {
     if (nb <= 0 || n_reads <= 0) return CRUMBLE_OK;
     const DParams *P = h->d_params.as<DParams>();
     /* short reads: one lane per read keeps the lanes of a wave evenly loaded; long reads: segment-parallel.
      * Option "pblock" = reads|segments overrides the choice (tuning / tests). */
-    const bool per_read = h->opt_pblock ? h->opt_pblock == 1 : nb < 1024 * n_reads;
+    const bool per_read = mode ? mode == 1 : nb < 1024 * n_reads;
     const int64_t nwords = (nb + 63) / 64;
     int e;
     if (per_read && h->hparams.any_preserve) {          /* -k/-K: the byte-wise kernel knows the skip rule */
@@ -713,7 +715,7 @@ extern "C" int crumble_hip_run_columns(crumble_hip *h)
         /* k_columns2 (kcol2.h) covers one active consensus; both at once (-q with -Q) and a disabled consensus
          * (min_qual 0) stay with k_columns */
         const bool use_cons = modeB ? true : h->hparams.min_qual_A != 0;
-        const bool v2 = (h->opt_kcol == 0 || h->opt_kcol == 3) && !(modeA && modeB) && use_cons;
+        const bool v2 = (h->b_kcol == 0 || h->b_kcol == 3) && !(modeA && modeB) && use_cons;
         if (!v2) {                                          /* k_columns2 counts heads / tails while it stages its records */
             STAGE("k_headtail", 0);
             HIPCHK(hipMemsetAsync(ht, 0, (size_t)L * 4, st));
@@ -935,7 +937,7 @@ extern "C" int crumble_hip_run_finish(crumble_hip *h)
         if (h->hparams.pblock) {
             STAGE("k_pblock", 2.0 * nb);
             const int pe = launch_pblock(h, st, n, nb, B.seq_off, h->d_out.as<uint8_t>(), h->d_rflags.as<uint8_t>(),
-                                         h->d_blk_read.as<int32_t>());
+                                         h->d_blk_read.as<int32_t>(), h->b_pblock);
             if (pe) return pe;
         }
         STAGE("k_stats", 2.0 * nb);
@@ -946,7 +948,7 @@ extern "C" int crumble_hip_run_finish(crumble_hip *h)
     }
     HIPCHK(hipEventRecord(h->ev[h->n_stages], st));
     /* fold this batch's counters into the engine's accumulated stats vector, on the device */
-    CRUMBLE_LAUNCH_INDEP(k_stats_fold, nblk(CRUMBLE_ST_N, 64), 64, st, h->d_stats.as<u64>(), (const u64 *)stats, CRUMBLE_ST_N);
+    CRUMBLE_LAUNCH_INDEP(k_stats_fold, nblk(CRUMBLE_ST_N, 64), 64, st, h->d_stats.as<u64>(), (const u64 *)stats, CRUMBLE_ST_N, (const int *)d_overflow);
     int ovf[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(h->pinned, d_overflow, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1199,7 +1201,7 @@ extern "C" int crumble_hip_pblock(crumble_hip *h, int64_t n_reads, const int64_t
     if ((e = dq.reserve((size_t)nb + 64)) || (e = ds.reserve((size_t)(n_reads + 1) * 8))) return e;
     if (nb) HIPCHK(hipMemcpy(dq.p, quals, (size_t)nb, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ds.p, seq_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice));
-    if (h->hparams.pblock && nb > 0 && (e = launch_pblock(h, h->stream, n_reads, nb, ds.as<int64_t>(), dq.as<uint8_t>(), nullptr, nullptr)))
+    if (h->hparams.pblock && nb > 0 && (e = launch_pblock(h, h->stream, n_reads, nb, ds.as<int64_t>(), dq.as<uint8_t>(), nullptr, nullptr, h->opt_pblock)))
         return e;
     HIPCHK(hipStreamSynchronize(h->stream));
     if (nb) HIPCHK(hipMemcpy(quals, dq.p, (size_t)nb, hipMemcpyDeviceToHost));

@@ -2793,10 +2793,11 @@ k_stats(int64_t b_lo, int64_t b_hi, int64_t n_reads, const uint8_t *out, const u
 }
 
 /* this batch's counters into the engine's accumulated vector (what the multi-GPU all-reduce sums) */
-__global__ void k_stats_fold(u64 *__restrict__ total, const u64 *__restrict__ batch, int n)
+/* (a run that ends in CRUMBLE_EOVERFLOW adds nothing: its partial counters must not reach the all-reduced vector) */
+__global__ void k_stats_fold(u64 *__restrict__ total, const u64 *__restrict__ batch, int n, const int *__restrict__ overflow)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) total[i] += batch[i];
+    if (i < n && !*overflow) total[i] += batch[i];
 }
 
 #endif /* CRUMBLE_KERNELS_H */

@@ -74,12 +74,14 @@ def plan(hb, n_windows):
         r0, r1 = firsts[k], firsts[k + 1]
         w0 = int(pos[r0])
         e_k = max(int(end[r0:r1].max()), w0)
+        # the window decides AND counts through to the next window's start: columns between the end of the owned
+        # reads and w_k+1 can still be covered by a read of an earlier window (a long deletion / splice over a
+        # coverage gap); the lo rule below already has every such read in the slice
         stat_end = int(pos[r1]) if r1 < n else max(e_k, int(pmax[-1]))
-        if r1 >= n:
-            e_k = stat_end
+        e_k = max(e_k, stat_end)
         lo = min(int(np.searchsorted(pmax, w0, side="right")), r0) if k else 0
         hi = max(int(np.searchsorted(pos, e_k, side="left")), r1)
-        out.append((lo, hi, Window(w0, e_k, min(stat_end, e_k) if r1 < n else stat_end, 0, r0 - lo, r1 - lo)))
+        out.append((lo, hi, Window(w0, e_k, stat_end, 0, r0 - lo, r1 - lo)))
     return out
 
 

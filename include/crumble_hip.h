@@ -179,8 +179,9 @@ int crumble_hip_download(crumble_hip *h, uint8_t *qual_out,
  * with its halvings (snp_score.c:1490-1491, 1684-1687), the STR window min_pos max_pos min_pos2 max_pos2
  * (snp_score.c:1508-1511, 1741-1755) and the BED cursor (a search here).  A contig is cut at reference positions
  * w_0 < w_1 < ...; window k OWNS the reads that start in [w_k, w_k+1) and is uploaded as a batch of the contig's reads
- * that overlap [w_k, E_k), E_k = the largest end of an owned read (reads are in file order, so that is one contiguous
- * slice: owned reads, the reads before them that reach w_k, the reads after them that start before E_k).  The window
+ * that overlap [w_k, E_k), E_k = max(the largest end of an owned read, w_k+1) (reads are in file order, so that is one
+ * contiguous slice: owned reads, the reads before them that reach w_k, the reads after them that start before E_k;
+ * E_k >= w_k+1 because a read of an EARLIER window may still cover columns behind the owned reads' end).  The window
  * decides the columns [w_k, E_k) -- every read that covers them is in the batch -- counts the columns [w_k, w_k+1)
  * and the owned reads in the statistics, and starts from the state window k-1 reached at w_k.  Everything else is
  * what a whole contig does; the owned reads' bytes, flags and the summed statistics equal the unsharded run's.
@@ -190,7 +191,7 @@ int crumble_hip_download(crumble_hip *h, uint8_t *qual_out,
  * crumble_carry on. */
 typedef struct crumble_window {
     int32_t col_start;      /* w_k: first reference position whose column this window decides               */
-    int32_t col_end;        /* E_k: one past the last decided column (>= the end of every owned read)        */
+    int32_t col_end;        /* E_k: one past the last decided column (>= every owned read's end, >= stat_end) */
     int32_t stat_end;       /* w_k+1: columns before it enter the statistics; the carry is reported there    */
     int32_t pad_;
     int64_t read_first;     /* owned reads [read_first, read_end) of the uploaded batch                      */

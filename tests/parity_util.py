@@ -129,3 +129,21 @@ def pblock_stress(engine_factory, path, seed=3, n_reads=400):
 
 
 KCOL_VARIANTS = ("v1", "v1perm", "v2")     # crumble_hip_set_option("kcol", ...): every column kernel must give the same bits
+
+
+def gap_batch(tid=0):
+    """Five clusters of reads with coverage gaps between them and ONE read (10M5980D10M) that spans every gap: the
+    columns under its deletion belong to no cluster's owned reads (round-2 advisor finding: windows dropped them from
+    the statistics and from the carried depth average)."""
+    rng = np.random.default_rng(17)
+    seq = "".join("ACGT"[i] for i in rng.integers(0, 4, 6100))
+    reads = [dict(pos=1000, cigar="10M5980D10M", seq=seq[:10] + seq[5990:6000], qual=30, mapq=60)]
+    for c in range(5):
+        start = 1100 + c * 1200
+        for i in range(40):
+            p = start + int(rng.integers(0, 300))
+            reads.append(dict(pos=p, cigar="100M", seq=seq[p - 1000:p - 900], qual=int(rng.integers(20, 40)), mapq=60))
+    reads[1:] = sorted(reads[1:], key=lambda r: r["pos"])
+    return HostBatch.from_reads(reads, tid=tid)
+
+

@@ -364,6 +364,9 @@ def test_cli_multi_device_emulated(tmp_path):
     for tid, (_, ln) in enumerate(refs):
         cfg = synth.config("ce", scale=1.0, contig_len=max(4500, ln // 60), seed=77 + tid, tid=tid, depth=6.0)
         bs.append(synth.generate(cfg))
+    # a read that spans coverage gaps: the columns under its deletion are counted by -w's windows too (round-2 advisor)
+    from parity_util import gap_batch
+    refs.append(("chrGap", 8000)); bs.append(gap_batch(tid=len(refs) - 1))
     bs.append(HostBatch.from_reads([dict(pos=0, cigar="*", seq="ACGTAC", qual=[9, 30, 31, 12, 40, 2], flag=4)], tid=-1))
     bamio.write_batches(tmp_path / "in.bam", refs, bs)
     outs = {}

@@ -9,6 +9,7 @@ import crumble_amd as ca
 from crumble_amd import windows
 import synth
 import oracle_lib as O
+from parity_util import gap_batch
 
 
 def _check(make_engine, hb, params, n_windows, want=None):
@@ -43,7 +44,22 @@ def test_plan_covers_every_read_once():
             assert len(ov) == 0 or (ov.min() >= lo and ov.max() < hi)
         assert owned == list(range(hb.n_reads))
         for (lo, hi, w), (lo2, hi2, w2) in zip(wins, wins[1:]):
-            assert w.stat_end == w2.col_start or w.stat_end == w.col_end
+            assert w.stat_end == w2.col_start          # counted column ranges tile the contig: no column is dropped
+
+
+@pytest.mark.parametrize("n_windows", [2, 5])
+def test_emu_windows_read_spanning_coverage_gaps(n_windows):
+    import emu_lib
+    hb = gap_batch()
+    wins = windows.plan(hb, n_windows)
+    assert len(wins) == n_windows
+    for (lo, hi, w), (lo2, hi2, w2) in zip(wins, wins[1:]):
+        assert w.stat_end == w2.col_start and w.col_end >= w.stat_end
+    p = ca.preset_params(5)
+    want = O.contig(p, hb)
+    assert want[2][ca.ST_NAMES.index("columns")] == 6000          # every column under the long deletion is counted
+    _check(emu_lib.with_options(kcol="v1"), hb, p, n_windows, want=want)
+    _check(emu_lib.with_options(kcol="v2"), hb, ca.preset_params(9), n_windows)
 
 
 @pytest.mark.parametrize("kcol", ["v1", "v2"])

@@ -8,14 +8,13 @@ W=${1:-/tmp/crumble_asan}; mkdir -p $W; cd $W
 SRC=$R/crumble_amd/csrc; EMU=$R/tests/emu
 FL="-fsanitize=address,undefined -fno-omit-frame-pointer -g -O1"
 gcc $FL -fPIC -c $SRC/params.c -o params.o
-gcc $FL -fPIC -fopenmp -c $R/tests/synth/synth.c -o synth.o
 gcc $FL -fPIC -fopenmp -c $SRC/bamio.c -o bamio.o
 g++ $FL -std=c++17 -fPIC -ffp-contract=off -DCRUMBLE_EMU -include $EMU/hip_emu.h -Wno-unknown-pragmas -x c++ -c $SRC/engine.hip -o engine.o
 g++ $FL -std=c++17 -fPIC -c $EMU/hip_emu.cpp -o hip_emu.o
 gcc $FL -c $SRC/cli.c -o cli.o
-g++ $FL -o crumble-hip-asan cli.o engine.o hip_emu.o params.o synth.o bamio.o -lz -lgomp -lpthread -lm
+g++ $FL -o crumble-hip-asan cli.o engine.o hip_emu.o params.o bamio.o -lz -lgomp -lpthread -lm
 python3 - <<PY
-import sys; sys.path.insert(0, "$R")
+import sys; sys.path.insert(0, "$R"); sys.path.insert(0, "$R/tests")
 import numpy as np
 from crumble_amd import bamio, HostBatch
 import synth
@@ -29,7 +28,9 @@ bamio.write_batches("in.bam", [("a", 60000), ("b", 300000), ("c", 30000)], [b0, 
 open("k.bed", "w").write("a\t1000\t3000\nb\t500\t9000\n")
 PY
 export ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1
-for args in "-5" "-9 -R k.bed -b s.bed" "-1 -S -k 30-35" "-9 -y pbccs -T XS" "-3 -B -P 1.2 -C 0.01"; do
+# (-j 3 / -j 3 -w with one emulated device named three times: the pthread pipeline, detach_group and run_windowed)
+export CRUMBLE_HIP_DEVICES=0,0,0
+for args in "-5" "-9 -R k.bed -b s.bed" "-1 -S -k 30-35" "-9 -y pbccs -T XS" "-3 -B -P 1.2 -C 0.01" "-5 -j 3 -b s3.bed" "-9 -j 3 -w -b s3w.bed -R k.bed"; do
   ./crumble-hip-asan $args in.bam out.bam > run.log 2>&1 || { echo "FAILED: $args"; tail -20 run.log; exit 1; }
   if grep -q "runtime error\|AddressSanitizer" run.log; then echo "SANITIZER REPORT: $args"; grep -m5 "runtime error\|AddressSanitizer" run.log; exit 1; fi
   echo "clean: $args"

@@ -6,7 +6,7 @@ scale=${1:-1.0}; shift
 threads=${@:-"16 64 256"}
 tmp=$(mktemp -d /tmp/e2e.XXXX)
 python3 - <<PY
-import sys; sys.path.insert(0, "$R")
+import sys; sys.path.insert(0, "$R"); sys.path.insert(0, "$R/tests")
 from crumble_amd import bamio
 import synth
 hb = synth.generate(synth.config("chr20", scale=$scale))
