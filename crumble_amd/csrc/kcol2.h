@@ -54,6 +54,9 @@
 #ifndef KC2_LDS_EXP
 #define KC2_LDS_EXP  1             /* cons_finalize's exp tables in LDS */
 #endif
+#ifndef KC2_FASTFIN
+#define KC2_FASTFIN  1             /* tiles whose columns are all "common" take cons_finalize_fast (needs KC2_LDS_EXP) */
+#endif
 #if KC2_PR != KC2_R
 #error "the consumer's row windows need the whole pass in the matrix (KC2_PR == KC2_R)"
 #endif
@@ -68,6 +71,8 @@
 #define KC2_CLS(v_)  (((v_) >> 1) & 7u)
 
 #ifdef CRUMBLE_EMU
+static unsigned long long kc2_emu_fin[2];      /* test hook (emulator only): tiles through cons_finalize_fast / the general finalize */
+#define KC2_EMU_COUNT(i_) do { if ((threadIdx.x & 63) == 0) __atomic_fetch_add(&kc2_emu_fin[i_], 1ull, __ATOMIC_RELAXED); } while (0)
 #define WAVE_SYNC() emu_wave_sync()
 __device__ __forceinline__ uint32_t kc2_alignbyte(uint32_t hi, uint32_t lo, unsigned sh)
 { return sh ? (lo >> (8u * sh)) | (hi << (32u - 8u * sh)) : lo; }
@@ -93,6 +98,7 @@ KC2_EMU_SCAN(kc2_scan_add, v + o)
 KC2_EMU_SCAN(kc2_scan_max, (o > v ? o : v))
 KC2_EMU_SCAN(kc2_scan_min, (o < v ? o : v))
 #else
+#define KC2_EMU_COUNT(i_) do { } while (0)
 /* LDS traffic between the lanes of ONE wave: the hardware keeps a wave's DS operations in order; the fence only
  * stops the compiler from moving them across */
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
@@ -641,7 +647,11 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     ve[u] = vn[u];
+#ifdef KC2_EXP_NOCONFLICT    /* diagnostic build (wrong results): every lane reads ONE table row -- no LDS bank conflicts */
+                    const double *rw = (const double *)(rowbase + ((ve[u] & 0u) | (37u << 5)));
+#else
                     const double *rw = (const double *)(rowbase + (ve[u] & KC2_ROWMASK));
+#endif
                     rMM[u] = rw[0]; r_M[u] = rw[1]; rom[u] = rw[2];
                     if (ANYPRES) memcpy(&rpv[u], &rw[3], 8); else rpv[u] = 0;
                 }
@@ -663,10 +673,6 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
             }
         }
         KC2_DRAIN();
-        st.S[0] = s00; st.S[1] = s01; st.S[2] = s02; st.S[3] = s03; st.S[4] = s04;
-        st.S[5] = s11; st.S[6] = s12; st.S[7] = s13; st.S[8] = s14; st.S[9] = s22;
-        st.S[10] = s23; st.S[11] = s24; st.S[12] = s33; st.S[13] = s34; st.S[14] = s44;
-        st.sC[0] = d0; st.sC[1] = d1; st.sC[2] = d2; st.sC[3] = d3; st.sC[4] = d4;
         st.nN = nN;
         if (inr) {
             const uint32_t h = htacc;
@@ -675,12 +681,40 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
             st.n_overlap = st.n_plp - st.nref - (int)(h & 0xffff);
         }
 #ifdef KC2_EXP_NODECIDE
-        if (inr) { colrec[c] = (st.S[0] + st.S[7] + st.sC[2] > 1e300) ? 1u : 0u; nplp_out[c] = st.n_plp; score_out[c] = 0; trigcnt[c] = 0; }
+        if (inr) { colrec[c] = (s00 + s13 + d2 > 1e300) ? 1u : 0u; nplp_out[c] = st.n_plp; score_out[c] = 0; trigcnt[c] = 0; }
         continue;
 #endif
+        const bool in_win = !WIN || (c >= B.col_lo && c < B.col_hi);
+#if KC2_FASTFIN
+        {   /* the common tile: in every column that reaches the consensus the ten genotypes without the key base are out
+             * of reach (cons_fast_ok, kernels.h) -- the result comes from the five key genotypes in place, no un-permute
+             * of 20 sums, 5 exp look-ups instead of 15 */
+            const bool needs = inr && in_win && st.n_plp > 0 && st.nref != st.n_plp && st.n_plp <= MAX_DEPTH_COL;
+            const double dmax = fmax(fmax(fmax(fmax(s11, s12), fmax(s13, s14)), fmax(fmax(s22, s23), fmax(s24, s33))), fmax(s34, s44));
+            const bool ok = !needs || cons_fast_ok(T, s00, s01, s02, s03, s04, dmax, st.depth, st.nN);
+            if (__ballot(!ok) == 0ull) {
+                KC2_EMU_COUNT(0);
+                if (inr) {
+                    if (in_win) {
+                        ConsOut co;
+                        cons_finalize_fast(T, s00, s01, s02, s03, s04, d0, d1, d2, d3, d4, key, co, sE);
+                        col_decide<MQ ? 1 : 0, true>(st, B, P, T, c, apos, true, colrec, nplp_out, score_out, trigcnt,
+                                                     sStat, sE, WIN ? c < B.stat_hi : true, &co);
+                    } else { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; }
+                }
+                KC2_STAMP(4);
+                continue;
+            }
+        }
+#endif
+        KC2_EMU_COUNT(1);
+        st.S[0] = s00; st.S[1] = s01; st.S[2] = s02; st.S[3] = s03; st.S[4] = s04;
+        st.S[5] = s11; st.S[6] = s12; st.S[7] = s13; st.S[8] = s14; st.S[9] = s22;
+        st.S[10] = s23; st.S[11] = s24; st.S[12] = s33; st.S[13] = s34; st.S[14] = s44;
+        st.sC[0] = d0; st.sC[1] = d1; st.sC[2] = d2; st.sC[3] = d3; st.sC[4] = d4;
         if (key) col_unpermute(st.S, st.sC, (int)key);  /* back to the reference's A C G T numbering */
         if (inr) {
-            if (!WIN || (c >= B.col_lo && c < B.col_hi))
+            if (in_win)
                 col_decide<MQ ? 1 : 0>(st, B, P, T, c, apos, true, colrec, nplp_out, score_out, trigcnt,
                                        sStat, KC2_LDS_EXP ? sE : (const double *)nullptr, WIN ? c < B.stat_hi : true);
             else { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; }

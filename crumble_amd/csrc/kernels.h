@@ -272,6 +272,86 @@ __device__ __forceinline__ void cons_finalize(const DTables *T, double *S, const
     }
 }
 
+#define COL_CSWAP(a, b, c) { const double ta_ = (c) ? (b) : (a), tb_ = (c) ? (a) : (b); (a) = ta_; (b) = tb_; }
+/* The same "speculate" half for the common column, straight from k_columns2's key-relative sums (kcol2.h header:
+ * class 0 = the column's key base).  v0..v4 = S00 S01 S02 S03 S04 -- the five genotypes that contain the key base --
+ * WITHOUT the priors; dmax = the largest of the ten other sums.  When every one of those ten is so far below the five
+ * that its exp() term cannot move a bit of any partial sum (cons_fast_ok), the reference's result follows from the five
+ * alone:
+ *   - shift, call and het_call: a smaller value never wins a strict "<" scan (snp:707-725), so call = the key base's
+ *     homozygote and het_call = the first maximum among the four key/x heterozygotes in the reference's order j;
+ *   - norm[] (snp:743-749): a left-to-right FP64 sum of positive terms is unchanged by terms whose total stays below
+ *     2^-55 of every other term: before the first large term a the small ones add up to T < ulp(a)/2, so T + a == a,
+ *     and after it every P + d == P.  The ten terms are each <= exp(y + 1) (fast_exp truncates its index towards
+ *     zero, snp:491-503; below -500 the clamp or DBL_MIN, snp:736-741, is smaller still), so
+ *         max(y_other, -500) + 1 + ln 10 + 55 ln 2  <=  y_min_of_the_five          (41.5; the test uses 45)
+ *     is sufficient; y_min >= -455 keeps the five clear of the clamp and of min_e_exp.
+ * The five in the reference's order j are {a, key} for a = A C G T, then {key, *}: v[a ^ key] -- the homozygote lands
+ * at a == key.  All priors of a kind are one value (snp:389-407: lprior15[0] for the homozygotes, [1] for the rest).
+ * Everything else is the reference's arithmetic operation for operation. */
+__device__ __forceinline__ bool cons_fast_ok(const DTables *T, double v0, double v1, double v2, double v3, double v4,
+                                             double dmax, int depth, int nN)
+{
+    const double lph = T->lprior15[0], lpt = T->lprior15[1];
+    const double a0 = v0 + lph, a1 = v1 + lpt, a2 = v2 + lpt, a3 = v3 + lpt, a4 = v4 + lpt;
+    const double lmin = fmin(fmin(fmin(a0, a1), fmin(a2, a3)), a4), lmax = fmax(fmax(fmax(a0, a1), fmax(a2, a3)), a4);
+    return depth > 0 && depth != nN && dmax + lph + 45.0 <= lmin && lmin - lmax >= -455.0;
+}
+
+#define CONS_SEL2(k1_, k2_, x0, x1, x2, x3) ((k2_) ? ((k1_) ? (x3) : (x2)) : ((k1_) ? (x1) : (x0)))
+__device__ __forceinline__ void cons_finalize_fast(const DTables *T, double v0, double v1, double v2, double v3, double v4,
+                                                   double c0, double c1, double c2, double c3, double c4,
+                                                   unsigned key, ConsOut &o, const double *sE)
+{
+    const bool k1 = (key & 1u) != 0u, k2 = (key & 2u) != 0u;
+    const double lph = T->lprior15[0], lpt = T->lprior15[1];
+    v0 += lph; v1 += lpt; v2 += lpt; v3 += lpt; v4 += lpt;                          /* snp:708 */
+    /* into the reference's order: L[a] = v[a ^ key] (and the discrepancy sums with them) */
+    COL_CSWAP(v0, v1, k1); COL_CSWAP(v2, v3, k1); COL_CSWAP(v0, v2, k2); COL_CSWAP(v1, v3, k2);
+    COL_CSWAP(c0, c1, k1); COL_CSWAP(c2, c3, k1); COL_CSWAP(c0, c2, k2); COL_CSWAP(c1, c3, k2);
+    const double shift = fmax(fmax(fmax(v0, v1), fmax(v2, v3)), v4);
+    /* het_call: first maximum among the heterozygotes in order j (strict <, snp:715-718) */
+    double max_het = -DBL_MAX; int h = 0;
+    if (key != 0u && max_het < v0) { max_het = v0; h = 0; }
+    if (key != 1u && max_het < v1) { max_het = v1; h = 1; }
+    if (key != 2u && max_het < v2) { max_het = v2; h = 2; }
+    if (key != 3u && max_het < v3) { max_het = v3; h = 3; }
+    if (max_het < v4) { max_het = v4; h = 4; }
+    /* fast_exp of the five (snp:491-503, 736-741): arguments in [-455, 0], so no clamp and never DBL_MIN */
+    double e0, e1, e2, e3, e4;
+#define CONS_FEXP(e_, v_) { const double y_ = (v_) - shift; const int i1_ = (int)(y_ * 10) + 500, i2_ = (int)y_ + 1001; \
+                            e_ = sE[(y_ >= -50.0) ? i1_ : i2_]; }
+    CONS_FEXP(e0, v0) CONS_FEXP(e1, v1) CONS_FEXP(e2, v2) CONS_FEXP(e3, v3) CONS_FEXP(e4, v4)
+#undef CONS_FEXP
+    /* norm[j] = (0 + sum of the terms before j, left to right) + (sum of the terms behind j, right to left) */
+    const double p1 = 0.0 + e0, p2 = p1 + e1, p3 = p2 + e2, p4 = p3 + e3;
+    const double u3 = 0.0 + e4, u2 = u3 + e3, u1 = u2 + e2, u0 = u1 + e1;
+    const double pre_c = CONS_SEL2(k1, k2, 0.0, p1, p2, p3), suf_c = CONS_SEL2(k1, k2, u0, u1, u2, u3);
+    const double pre_h = (h == 0) ? 0.0 : (h == 1) ? p1 : (h == 2) ? p2 : (h == 3) ? p3 : p4;
+    const double suf_h = (h == 0) ? u0 : (h == 1) ? u1 : (h == 2) ? u2 : (h == 3) ? u3 : 0.0;
+    const double s_het = (h == 0) ? e0 : (h == 1) ? e1 : (h == 2) ? e2 : (h == 3) ? e3 : e4;
+    const double nc = (0.0 + pre_c) + suf_c, nh = (0.0 + pre_h) + suf_h;             /* > 0: no DBL_MIN substitution */
+    int ph = (int)(dev_ph_log(nc) + .5);
+    o.call = (int)key;
+    o.phred = ph > 255 ? 255 : (ph < 0 ? 0 : ph);
+    {   /* map_het (snp:551-558): genotype {x < y} -> 5 x + y */
+        const int a = h, b = (int)key;
+        o.het_call = a < b ? 5 * a + b : 5 * b + a;
+    }
+    ph = (int)(DEV_TENLOG2OVERLOG10 * (dev_fast_log2(s_het) - dev_fast_log2(nh)) + .5);
+    o.het_phred = ph;
+    {
+        const double m = c0 + c1 + c2 + c3 + c4;                                    /* snp:776, in the reference's order */
+        const double ck = CONS_SEL2(k1, k2, c0, c1, c2, c3);                        /* sumsC[call] */
+        double c;
+        if (ph > 0) {                                                               /* sumsC[het_call % 5] + sumsC[het_call / 5] */
+            const double ch = (h == 0) ? c0 : (h == 1) ? c1 : (h == 2) ? c2 : (h == 3) ? c3 : c4;
+            c = ck + ch;                                                            /* (two addends: the order is immaterial) */
+        } else c = ck;
+        o.discrep = (float)((m - c) / sqrt(m));
+    }
+}
+
 /* ------------------------------------------------------------------------ */
 /* k_columns: one lane per reference position; a wave owns 64 consecutive
  * positions (a tile) and walks the candidate reads of its tile in file order,
@@ -301,12 +381,13 @@ struct ColState {
 /* column decisions: snp:1438-1773 minus the passes that need cross-column state */
 /* MODE 0: consensus A only (snp:1523, plain qualities); 1: B only (snp:1534, mapq-adjusted);
  * 2: both.  No preset enables A; -q does. */
-template <int MODE>
+/* PRE: the consensus result comes from the caller (cons_finalize_fast), st.S / st.sC are not read */
+template <int MODE, bool PRE = false>
 __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const DParams *__restrict__ P,
                                            const DTables *__restrict__ T, int c, int apos, bool use_cons,
                                            uint32_t *__restrict__ colrec, int32_t *__restrict__ nplp_out,
                                            int32_t *__restrict__ score_out, int32_t *__restrict__ trigcnt, unsigned *stats,
-                                           const double *sE = nullptr, const bool cnt = true)
+                                           const double *sE = nullptr, const bool cnt = true, const ConsOut *pre = nullptr)
 {
     const int n_plp = st.n_plp;
     if (n_plp == 0) { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; return; }
@@ -337,7 +418,8 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
         int hA = 0, sA = 0, hB = 0, sB = 0;
         const bool useA = MODE != 1, useB = MODE != 0;
         if (useA) {                                    /* snp:1523-1532, 1576-1583, 1594-1609 */
-            cons_finalize(T, MODE == 2 ? st.S2 : st.S, MODE == 2 ? st.sC2 : st.sC, st.depth, st.nN, coA, sE);
+            if (PRE) coA = *pre;
+            else cons_finalize(T, MODE == 2 ? st.S2 : st.S, MODE == 2 ? st.sC2 : st.sC, st.depth, st.nN, coA, sE);
             const bool het = coA.het_phred > 0;
             if (het) { a1 = coA.het_call / 5; a2 = coA.het_call % 5; } else { a1 = a2 = coA.call; }
             hA = het ? coA.het_call : coA.call * 5 + coA.call;
@@ -348,7 +430,8 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
             if ((int)cp != (1 << coA.call)) perfect = 0;                 /* snp:1606 */
         }
         if (useB) {                                    /* snp:1534-1543, 1584-1591, 1610-1622 */
-            cons_finalize(T, st.S, st.sC, st.depth, st.nN, coB, sE);
+            if (PRE) coB = *pre;
+            else cons_finalize(T, st.S, st.sC, st.depth, st.nN, coB, sE);
             const bool het = coB.het_phred > 0;
             if (het) { a1 = coB.het_call / 5; a2 = coB.het_call % 5; } else { a1 = a2 = coB.call; }
             hB = het ? coB.het_call : coB.call * 5 + coB.call;
@@ -429,7 +512,6 @@ __global__ void k_headtail(DBatch B, uint32_t *__restrict__ ht)
  * XOR by k maps genotype {i,j} to {i^k, j^k}: bit 0 of k swaps A<->C and G<->T, bit 1 swaps A<->G and
  * C<->T ('*' stays).  The same involution brings the 15 sums and the 5 discrepancy sums back.
  * Genotype order: AA AC AG AT A* CC CG CT C* GG GT G* TT T* **  (snp:  the reference's 15 pairs). */
-#define COL_CSWAP(a, b, c) { const double ta_ = (c) ? (b) : (a), tb_ = (c) ? (a) : (b); (a) = ta_; (b) = tb_; }
 __device__ __forceinline__ void col_unpermute(double *S, double *sC, int k)
 {
     const bool k1 = (k & 1) != 0, k2 = (k & 2) != 0;

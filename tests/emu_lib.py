@@ -36,3 +36,11 @@ def engine(params, **options):
 def with_options(**options):
     """engine factory with crumble_hip_set_option choices applied (tests force every kernel variant)"""
     return lambda params: engine(params, **options)
+
+
+def fin_counts():
+    """(tiles k_columns2 finished through cons_finalize_fast, through the general finalize) since the last call"""
+    import ctypes as C
+    out = (C.c_ulonglong * 2)()
+    load().crumble_emu_fin_counts(out)
+    return int(out[0]), int(out[1])

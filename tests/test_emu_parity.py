@@ -73,7 +73,11 @@ def test_emu_column_kernel_variants(product, kcol):
     eng = emu_lib.with_options(kcol=kcol)
     slow = kcol == "v2"        # k_columns2 under the emulator: a fiber rendezvous per matrix row (emu_lib.engine)
     hb = synth_batch("chr20", 0.00016 if slow else 0.0004)
+    emu_lib.fin_counts()
     assert_parity(eng, ca.preset_params(5), hb)
+    if slow:                   # k_columns2 finishes a tile one of two ways (cons_finalize_fast / the general path): both ran
+        fast, general = emu_lib.fin_counts()
+        assert fast > 20 and general > 5, (fast, general)
     if not slow:               # both consensus modes at once: k_columns whatever the option says
         assert_parity(eng, ca.preset_params(5, min_qual_A=30, min_indel_A=60), hb)
     assert_parity(eng, ca.preset_params(5, min_qual_A=30, min_qual_B=0), hb)
