@@ -690,14 +690,14 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
              * of reach (cons_fast_ok, kernels.h) -- the result comes from the five key genotypes in place, no un-permute
              * of 20 sums, 5 exp look-ups instead of 15 */
             const bool needs = inr && in_win && st.n_plp > 0 && st.nref != st.n_plp && st.n_plp <= MAX_DEPTH_COL;
-            const double dmax = fmax(fmax(fmax(fmax(s11, s12), fmax(s13, s14)), fmax(fmax(s22, s23), fmax(s24, s33))), fmax(s34, s44));
+            const double dmax = dev_max(dev_max(dev_max(dev_max(s11, s12), dev_max(s13, s14)), dev_max(dev_max(s22, s23), dev_max(s24, s33))), dev_max(s34, s44));
             const bool ok = !needs || cons_fast_ok(T, s00, s01, s02, s03, s04, dmax, st.depth, st.nN);
             if (__ballot(!ok) == 0ull) {
                 KC2_EMU_COUNT(0);
                 if (inr) {
                     if (in_win) {
                         ConsOut co;
-                        cons_finalize_fast(T, s00, s01, s02, s03, s04, d0, d1, d2, d3, d4, key, co, sE);
+                        cons_finalize_fast(T, s00, s01, s02, s03, s04, d0, d1, d2, d3, d4, key, co, sE, MQ ? P->min_discrep_B : P->min_discrep_A);
                         col_decide<MQ ? 1 : 0, true>(st, B, P, T, c, apos, true, colrec, nplp_out, score_out, trigcnt,
                                                      sStat, sE, WIN ? c < B.stat_hi : true, &co);
                     } else { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; }

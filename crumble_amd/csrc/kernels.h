@@ -172,7 +172,20 @@ __device__ __forceinline__ int bed_preserve(const DBatch &B, int apos)
 }
 
 /* ------------------------------------------------------------------------ */
-struct ConsOut { int call, het_call, het_phred, phred; float discrep; };
+struct ConsOut { int call, het_call, het_phred, phred; float discrep;
+                 int disc_ge; };      /* cons_finalize_fast: discrep >= the active min_discrep, decided (0 / 1) without the value */
+
+/* v_max_f64 / v_min_f64 as they are: fmax() / fmin() canonicalise both operands first (an extra v_max_f64 x, x each) --
+ * the sums are never NaN */
+#ifdef CRUMBLE_EMU
+__device__ __forceinline__ double dev_max(double a, double b) { return a > b ? a : b; }
+__device__ __forceinline__ double dev_min(double a, double b) { return a < b ? a : b; }
+__device__ __forceinline__ double dev_rsq(double a) { return 1.0 / sqrt(a); }
+#else
+__device__ __forceinline__ double dev_max(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double dev_min(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double dev_rsq(double a) { return __builtin_amdgcn_rsq(a); }
+#endif
 
 /* The "speculate" half of calculate_consensus_pileup (snp:689-794).
  * Written without dynamically indexed arrays so that the 15 genotype sums stay
@@ -294,14 +307,14 @@ __device__ __forceinline__ bool cons_fast_ok(const DTables *T, double v0, double
 {
     const double lph = T->lprior15[0], lpt = T->lprior15[1];
     const double a0 = v0 + lph, a1 = v1 + lpt, a2 = v2 + lpt, a3 = v3 + lpt, a4 = v4 + lpt;
-    const double lmin = fmin(fmin(fmin(a0, a1), fmin(a2, a3)), a4), lmax = fmax(fmax(fmax(a0, a1), fmax(a2, a3)), a4);
+    const double lmin = dev_min(dev_min(dev_min(a0, a1), dev_min(a2, a3)), a4), lmax = dev_max(dev_max(dev_max(a0, a1), dev_max(a2, a3)), a4);
     return depth > 0 && depth != nN && dmax + lph + 45.0 <= lmin && lmin - lmax >= -455.0;
 }
 
 #define CONS_SEL2(k1_, k2_, x0, x1, x2, x3) ((k2_) ? ((k1_) ? (x3) : (x2)) : ((k1_) ? (x1) : (x0)))
 __device__ __forceinline__ void cons_finalize_fast(const DTables *T, double v0, double v1, double v2, double v3, double v4,
                                                    double c0, double c1, double c2, double c3, double c4,
-                                                   unsigned key, ConsOut &o, const double *sE)
+                                                   unsigned key, ConsOut &o, const double *sE, double min_discrep)
 {
     const bool k1 = (key & 1u) != 0u, k2 = (key & 2u) != 0u;
     const double lph = T->lprior15[0], lpt = T->lprior15[1];
@@ -309,7 +322,7 @@ __device__ __forceinline__ void cons_finalize_fast(const DTables *T, double v0, 
     /* into the reference's order: L[a] = v[a ^ key] (and the discrepancy sums with them) */
     COL_CSWAP(v0, v1, k1); COL_CSWAP(v2, v3, k1); COL_CSWAP(v0, v2, k2); COL_CSWAP(v1, v3, k2);
     COL_CSWAP(c0, c1, k1); COL_CSWAP(c2, c3, k1); COL_CSWAP(c0, c2, k2); COL_CSWAP(c1, c3, k2);
-    const double shift = fmax(fmax(fmax(v0, v1), fmax(v2, v3)), v4);
+    const double shift = dev_max(dev_max(dev_max(v0, v1), dev_max(v2, v3)), v4);
     /* het_call: first maximum among the heterozygotes in order j (strict <, snp:715-718) */
     double max_het = -DBL_MAX; int h = 0;
     if (key != 0u && max_het < v0) { max_het = v0; h = 0; }
@@ -348,7 +361,19 @@ __device__ __forceinline__ void cons_finalize_fast(const DTables *T, double v0, 
             const double ch = (h == 0) ? c0 : (h == 1) ? c1 : (h == 2) ? c2 : (h == 3) ? c3 : c4;
             c = ck + ch;                                                            /* (two addends: the order is immaterial) */
         } else c = ck;
-        o.discrep = (float)((m - c) / sqrt(m));
+        /* discrep = (float)((m - c) / sqrt(m)) (snp:776-784) is only ever compared with min_discrep (snp:1604,1620,
+         * 1624-1628).  (m - c) * rsq(m) is within 2^-22 of the quotient (v_rsq_f64: 2^29 ulp) and the reference's two
+         * roundings and the float conversion move it by less than 2^-23, so outside a band of 1e-4 around the
+         * threshold the comparison is decided; a wave with a lane inside the band divides */
+        const double t = m - c, qa = t * dev_rsq(m);
+        const bool sure_ge = qa >= min_discrep * (1.0 + 1e-4) && qa >= min_discrep * (1.0 - 1e-4);
+        const bool sure_lt = qa < min_discrep * (1.0 - 1e-4) && qa < min_discrep * (1.0 + 1e-4);
+        o.disc_ge = sure_ge ? 1 : 0;
+        o.discrep = 0;
+        if (__ballot(!(sure_ge || sure_lt))) {
+            o.discrep = (float)(t / sqrt(m));
+            o.disc_ge = o.discrep >= min_discrep ? 1 : 0;
+        }
     }
 }
 
@@ -416,6 +441,7 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
         const int b2c = (lowb == 1) ? 0 : (lowb == 2) ? 1 : (lowb == 4) ? 2 : (lowb == 8) ? 3 : (lowb == 16) ? 4 : 99;
         ConsOut coA, coB;
         int hA = 0, sA = 0, hB = 0, sB = 0;
+        bool dgeA_ = false, dgeB_ = false;               /* discrep >= min_discrep (snp:1604,1620) */
         const bool useA = MODE != 1, useB = MODE != 0;
         if (useA) {                                    /* snp:1523-1532, 1576-1583, 1594-1609 */
             if (PRE) coA = *pre;
@@ -426,7 +452,8 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
             sA = het ? coA.het_phred : coA.phred;
             lds_inc(stats, ST_HET_A, cnt && (het)); lds_inc(stats, ST_HET_QUAL_A, cnt && (het && sA < P->min_qual_A));
             lds_inc(stats, ST_HOM_A, cnt && (!het)); lds_inc(stats, ST_HOM_QUAL_A, cnt && (!het && sA < P->min_qual_A));
-            lds_inc(stats, ST_DISCREP_A, cnt && (coA.discrep >= P->min_discrep_A));
+            dgeA_ = PRE ? coA.disc_ge != 0 : coA.discrep >= P->min_discrep_A;
+            lds_inc(stats, ST_DISCREP_A, cnt && dgeA_);
             if ((int)cp != (1 << coA.call)) perfect = 0;                 /* snp:1606 */
         }
         if (useB) {                                    /* snp:1534-1543, 1584-1591, 1610-1622 */
@@ -438,11 +465,12 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
             sB = het ? coB.het_phred : coB.phred;
             lds_inc(stats, ST_HET_B, cnt && (het)); lds_inc(stats, ST_HET_QUAL_B, cnt && (het && sB < P->min_qual_B));
             lds_inc(stats, ST_HOM_B, cnt && (!het)); lds_inc(stats, ST_HOM_QUAL_B, cnt && (!het && sB < P->min_qual_B));
-            lds_inc(stats, ST_DISCREP_B, cnt && (coB.discrep >= P->min_discrep_B));
+            dgeB_ = PRE ? coB.disc_ge != 0 : coB.discrep >= P->min_discrep_B;
+            lds_inc(stats, ST_DISCREP_B, cnt && dgeB_);
         }
         if (MODE == 2) lds_inc(stats, ST_DIFF, cnt && (hA != hB));                /* snp:1593 */
         preserve |= ((MODE == 2 && hA != hB) || (useA && sA < P->min_qual_A) || (useB && sB < P->min_qual_B)) ? 1 : 0;   /* snp:1624 */
-        preserve |= ((useA && coA.discrep >= P->min_discrep_A) || (useB && coB.discrep >= P->min_discrep_B)) ? 1 : 0;   /* float vs double */
+        preserve |= ((useA && dgeA_) || (useB && dgeB_)) ? 1 : 0;   /* float vs double */
         if (useA && !preserve) {                                         /* snp:1633-1638 */
             if ((coA.het_phred <= 0 && b2c != coA.call) || (cp >> 8)) perfect = 0;
         }
