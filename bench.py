@@ -137,6 +137,161 @@ def window_batch(hb, r0, n_reads):
                      hb.cig_off[r0:r1 + 1] - c0, hb.cigar[c0:c1], hb.bases[b0:b1], hb.quals[b0:b1])
 
 
+def _algo_bytes(b_):
+    """3 B per base + 32 B per read + 8 B per CIGAR op."""
+    return 3.0 * b_.n_bases + 32.0 * b_.n_reads + 8.0 * int(b_.cig_off[-1])
+
+
+def measure_config(ca, synth, workload, scale, device, steps=3, warmup=1, verify_seconds=3.0):
+    """One more BASELINE configuration through the same engine, kernels only, batch resident (what `value` is for the
+    headline config): ms per step, the dominant kernel's and the whole path's fraction of the HBM roof, and the
+    TIMED engine's output checked against the oracle on the leading reads whose columns lie inside a bounded sample."""
+    import oracle_lib as O
+    label, d_preset, d_tech, d_bed = WORKLOADS[workload]
+    cfg = synth.config(workload, scale=scale)
+    bed = keep_bed(cfg.contig_len, int(d_bed * scale + 0.5)) if d_tech == "pbccs" else None
+    t0 = time.time()
+    hb = synth.generate(cfg, bed=bed)
+    t_gen = time.time() - t0
+    params = ca.preset_params(d_preset, tech=d_tech)
+    eng = ca.Engine(params, device)
+    try:
+        eng.upload(hb)
+        for _ in range(warmup):
+            eng.run()
+        kt = {}
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.run()                                    # every kernel of the path + one stream sync
+            for name, ms, by in eng.kernel_times():
+                a = kt.setdefault(name, [0.0, 0.0, 0])
+                a[0] += ms; a[1] += by; a[2] += 1
+        step_s = (time.perf_counter() - t0) / steps
+        dom = max(kt.items(), key=lambda kv: kv[1][0])
+        dom_ms, dom_bytes = dom[1][0] / dom[1][2], dom[1][1] / dom[1][2]
+        kernels_ms = sum(v[0] for v in kt.values()) / steps
+        out = {
+            "workload": f"{label} synthetic contig ({cfg.contig_len} bp, {hb.n_reads} reads, {hb.n_bases} bases), "
+                        f"{'-' + str(d_preset) if d_preset else 'default level'}{' -y ' + d_tech if d_tech else ''}"
+                        f"{' -R keep.bed (' + str(len(hb.bed_start)) + ' regions)' if len(hb.bed_start) else ''}",
+            "value": round(hb.n_bases / step_s / 1e9, 3), "unit": "Gbases/s", "ms_per_step": round(step_s * 1e3, 3),
+            "roofline": {"kernel": dom[0], "kernel_ms": round(dom_ms, 3),
+                         "frac": round(dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if dom_ms > 0 else 0.0},
+            "pipeline_frac": round(_algo_bytes(hb) / (kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "kernels_ms": {k: round(v[0] / v[2], 3) for k, v in kt.items()}, "gen_s": round(t_gen, 1),
+        }
+        if verify_seconds > 0:
+            tq, tf, _ = eng.download(want_stats=False)
+            n_sample = int(min(hb.n_reads, max(200, verify_seconds / 60e-9 / max(1, hb.n_bases / max(1, hb.n_reads)))))
+            sample = prefix_batch(hb, n_sample)
+            if len(hb.bed_start):
+                sample.bed_start, sample.bed_end = hb.bed_start, hb.bed_end
+            wq, wf, _ = O.contig(params, sample)
+            k = interior_reads(hb, n_sample)
+            nbk = int(hb.seq_off[k])
+            out["verified_timed_output_leading_reads"] = k if (k > 0 and np.array_equal(tq[:nbk], wq[:nbk]) and
+                                                               np.array_equal(tf[:k], wf[:k])) else False
+        return out
+    finally:
+        eng.close()
+
+
+def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=3):
+    """BASELINE config 5 on ONE GPU as the stream it is (snp_score.c:1437: contigs one after another): the 24 contigs
+    sit in host memory; contig k+1's host -> device copy + device-side expansion, contig k's kernels and contig k-1's
+    download (page-locked staging, engine.hip staged_d2h) run side by side -- three host threads, a ring of engines
+    (each its own HIP stream).  Reports the wall time per pass, the three stages' summed times and wall / sum
+    (1.0 = nothing overlaps, 1/3 = perfect overlap of three equal stages)."""
+    import queue
+    import threading
+    sizes = [int(l * scale) for l in shard.GRCH38]
+    batches = []
+    t0 = time.time()
+    for tid, ln in enumerate(sizes):
+        cfg = synth.config("chr20", scale=1.0)
+        cfg.contig_len = max(ln, 4 * cfg.read_len + 4096)
+        cfg.seed = 5000 + tid
+        cfg.tid = tid
+        batches.append(synth.generate(cfg))
+    t_gen = time.time() - t0
+    params = ca.preset_params(preset)
+    engines = [ca.Engine(params, device) for _ in range(n_engines)]
+    outs = [None] * len(batches)
+    try:
+        def one_pass(keep):
+            free_q, run_q, dl_q = queue.Queue(), queue.Queue(), queue.Queue()
+            for e in engines:
+                free_q.put(e)
+            t_stage = [0.0, 0.0, 0.0]
+            err = []
+
+            def uploader():
+                try:
+                    for i, b in enumerate(batches):
+                        e = free_q.get()
+                        t = time.perf_counter(); e.upload(b); t_stage[0] += time.perf_counter() - t
+                        run_q.put((i, e))
+                except Exception as ex:            # noqa: BLE001
+                    err.append(ex)
+                run_q.put(None)
+
+            def runner():
+                try:
+                    while True:
+                        it = run_q.get()
+                        if it is None:
+                            break
+                        t = time.perf_counter(); it[1].run(); t_stage[1] += time.perf_counter() - t
+                        dl_q.put(it)
+                except Exception as ex:            # noqa: BLE001
+                    err.append(ex)
+                dl_q.put(None)
+
+            def downloader():
+                try:
+                    while True:
+                        it = dl_q.get()
+                        if it is None:
+                            break
+                        t = time.perf_counter(); q, f, _ = it[1].download(want_stats=False); t_stage[2] += time.perf_counter() - t
+                        if keep:
+                            outs[it[0]] = (q, f)
+                        free_q.put(it[1])
+                except Exception as ex:            # noqa: BLE001
+                    err.append(ex)
+            th = [threading.Thread(target=f) for f in (uploader, runner, downloader)]
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            wall = time.perf_counter() - t0
+            if err:
+                raise err[0]
+            return wall, t_stage
+        one_pass(False)                                   # warm-up: code objects, buffer growth, page-locked buffers
+        wall, st = one_pass(True)
+        total = sum(b.n_bases for b in batches)
+        # the smallest contig's bytes and flags against the oracle (bounded CPU time), everything else by properties
+        import oracle_lib as O
+        k = int(np.argmin([b.n_bases for b in batches]))
+        wq, wf, _ = O.contig(params, batches[k])
+        ok = bool(np.array_equal(outs[k][0], wq) and np.array_equal(outs[k][1], wf))
+        ok = ok and all(o is not None and len(o[0]) == b.n_bases for o, b in zip(outs, batches))
+        return {
+            "workload": f"wgs-30x: 24 synthetic contigs (GRCh38 lengths x {scale}), {total} bases, -{preset}, streamed through "
+                        f"{n_engines} engines on one GPU (upload || kernels || download)",
+            "value_incl_pcie": round(total / wall / 1e9, 3), "unit": "Gbases/s", "ms_per_pass": round(wall * 1e3, 2),
+            "stages_ms": {"h2d_and_p0": round(st[0] * 1e3, 2), "kernels": round(st[1] * 1e3, 2), "d2h": round(st[2] * 1e3, 2)},
+            "overlap_wall_over_sum_of_stages": round(wall / max(1e-9, sum(st)), 3),
+            "verified_smallest_contig": ok, "gen_s": round(t_gen, 1),
+            "note": "host buffers are pageable numpy memory; this is a PCIe-inclusive rate and never `value`",
+        }
+    finally:
+        for e in engines:
+            e.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +312,9 @@ def main():
     ap.add_argument("--pmc-json", default=None, help="profiles/*_pmc_traffic.json measured for THIS build and "
                     "workload: fills roofline.traffic (null otherwise)")
     ap.add_argument("--kcol", default="auto", help="crumble_hip_set_option kcol (auto|v1|v1perm|v2)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the `other_configs` object (BASELINE configs "
+                    "3, 4 and 5 measured after the headline config; default line, one GPU only)")
+    ap.add_argument("--wgs-stream-scale", type=float, default=0.05, help="other_configs.wgs_streamed: contig length scale")
     ap.add_argument("--e2e", action="store_true",
                     help="also time metric (ii): BAM file -> crumble-hip -> BAM file (SURVEY.md 8d), reported "
                          "as an extra 'end_to_end' object; never part of 'value'")
@@ -201,7 +359,8 @@ def main():
     batches = []
     if args.workload == "wgs":
         sizes = [int(l * args.scale) for l in shard.GRCH38]
-        assign, _ = shard.lpt_pack(sizes, world)
+        assign, loads = shard.lpt_pack(sizes, world)
+        lpt_imbalance = max(loads) / (sum(loads) / len(loads))   # max / mean of the ranks' loads: what bounds the strong scaling
         for tid in assign[rank]:
             cfg = synth.config("chr20", scale=1.0)
             cfg.contig_len = max(sizes[tid], 4 * cfg.read_len + 4096)
@@ -335,7 +494,7 @@ def main():
     dom_ms = dom[1][0] / dom[1][2]
     dom_bytes = dom[1][1] / dom[1][2]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    algo_total = sum(3.0 * b_.n_bases + 32.0 * b_.n_reads + 8.0 * int(b_.cig_off[-1]) for b_ in batches)
+    algo_total = sum(_algo_bytes(b_) for b_ in batches)
     kernel_ms_total = sum(v[0] for v in ktimes.values()) / args.steps
     # HBM traffic of that kernel from rocprofv3 PMC counters (FETCH_SIZE + WRITE_SIZE, separate passes): only when a
     # summary measured for THIS build and workload is named on the command line; never a stale constant
@@ -386,6 +545,7 @@ def main():
                                 f"LPT-packed on {world} GPU(s), -{args.preset}"),
                    "preset": args.preset, "tech": tech, "scale": args.scale,
                    "contigs": world if args.workload != "wgs" else 24, "stats_allreduce": stats_via,
+                   **({"lpt_max_over_mean_load": round(lpt_imbalance, 4)} if args.workload == "wgs" else {}),
                    "parity": "every parity check is against oracle/ (a CPU restatement of crumble 0.9.1's transcode(); "
                              "reference-pinned for str_finder.c only: htslib is absent offline)",
                    "gen_s": round(t_gen, 1), "upload_s": round(t_up, 2)},
@@ -459,6 +619,23 @@ def main():
                 }
         if args.e2e:
             out["end_to_end"] = file_to_file(hb, args, local_rank)
+        if world == 1 and args.workload == "chr20" and args.scale == 1.0 and not args.no_other_configs:
+            # the other single-GPU configurations of BASELINE.json, measured by the same run (never part of `value`)
+            for e_ in engines:
+                e_.close()
+            engines = []
+            del tq, tf
+            oc = {}
+            for key, wl, sc in (("config3_panel", "panel", 1.0), ("config4_hifi", "hifi", 1.0)):
+                try:
+                    oc[key] = measure_config(ca, synth, wl, sc, local_rank)
+                except Exception as ex:            # noqa: BLE001
+                    oc[key] = {"error": repr(ex)[:300]}
+            try:
+                oc["config5_wgs_streamed"] = measure_wgs_streamed(ca, synth, shard, args.wgs_stream_scale, local_rank)
+            except Exception as ex:                # noqa: BLE001
+                oc["config5_wgs_streamed"] = {"error": repr(ex)[:300]}
+            out["other_configs"] = oc
         print(json.dumps(out))
     for e_ in engines:
         e_.close()

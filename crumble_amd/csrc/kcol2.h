@@ -54,6 +54,10 @@
 #ifndef KC2_LDS_EXP
 #define KC2_LDS_EXP  1             /* cons_finalize's exp tables in LDS */
 #endif
+#ifndef KC2_WGDEAL
+#define KC2_WGDEAL   1             /* the waves of a workgroup take the tiles of ONE unit between them, tile by tile: tiles in
+                                    * flight on a CU are neighbours, their reads' cache lines are shared while they are hot */
+#endif
 #ifndef KC2_FASTFIN
 #define KC2_FASTFIN  1             /* tiles whose columns are all "common" take cons_finalize_fast (needs KC2_LDS_EXP) */
 #endif
@@ -73,6 +77,8 @@
 #ifdef CRUMBLE_EMU
 static unsigned long long kc2_emu_fin[2];      /* test hook (emulator only): tiles through cons_finalize_fast / the general finalize */
 #define KC2_EMU_COUNT(i_) do { if ((threadIdx.x & 63) == 0) __atomic_fetch_add(&kc2_emu_fin[i_], 1ull, __ATOMIC_RELAXED); } while (0)
+#define KC2_SLEEP() do { } while (0)       /* (the emulator's fibers switch at wave rendezvous only: a lock is never seen held) */
+#define KC2_FENCE_WG() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define WAVE_SYNC() emu_wave_sync()
 __device__ __forceinline__ uint32_t kc2_alignbyte(uint32_t hi, uint32_t lo, unsigned sh)
 { return sh ? (lo >> (8u * sh)) | (hi << (32u - 8u * sh)) : lo; }
@@ -99,6 +105,8 @@ KC2_EMU_SCAN(kc2_scan_max, (o > v ? o : v))
 KC2_EMU_SCAN(kc2_scan_min, (o < v ? o : v))
 #else
 #define KC2_EMU_COUNT(i_) do { } while (0)
+#define KC2_SLEEP() __builtin_amdgcn_s_sleep(1)
+#define KC2_FENCE_WG() __threadfence_block()
 /* LDS traffic between the lanes of ONE wave: the hardware keeps a wave's DS operations in order; the fence only
  * stops the compiler from moving them across */
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
@@ -154,6 +162,8 @@ struct __attribute__((aligned(16))) KC2Lds {
     uint8_t  adjc[KC2_SLOTS * 128];
     uint8_t  pv[128];
     uint4    mask_lt[17], mask_ge[17];             /* producer: byte k of [a] = 0x08 | (k < a ? 0x70 : 0); of [b] = (k >= b ? 0x70 : 0) */
+    unsigned long long deal;                       /* KC2_WGDEAL: the workgroup's current unit, end tile << 32 | next tile */
+    unsigned deal_lock, deal_done;
     KC2Wave  wave[KC2_WAVES];
 };
 
@@ -352,6 +362,51 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
     long long npass = 0, nstep = 0;
 #endif
 
+#if KC2_WGDEAL
+    if (threadIdx.x == 0) { L.deal = 0ull; L.deal_lock = 0u; L.deal_done = 0u; }
+    __syncthreads();
+    for (;;) {
+    int tile;
+    {
+        /* next tile of the workgroup's unit (one 64-bit LDS atomic: a consistent next / end pair); an exhausted unit is
+         * replaced by whichever wave gets the lock -- it takes the new unit's first tile itself */
+        unsigned lo32 = 0, hi32 = 0, st = 0;
+        for (;;) {
+            if (lane == 0) {
+                const unsigned long long d = atomicAdd(&L.deal, 1ull);
+                lo32 = (unsigned)d; hi32 = (unsigned)(d >> 32);
+                st = lo32 < hi32 ? 1u : 0u;
+                if (!st) {
+                    if (L.deal_done) st = 2u;
+                    else if (atomicCAS(&L.deal_lock, 0u, 1u) == 0u) {
+                        const unsigned long long d2 = *(volatile unsigned long long *)&L.deal;     /* refilled meanwhile? */
+                        if ((unsigned)d2 < (unsigned)(d2 >> 32)) st = 3u;
+                        else {
+                            const int g = (int)atomicAdd(tile_ctr, 1u);
+                            if (g >= B.n_units) { L.deal_done = 1u; st = 2u; }
+                            else {
+                                const unsigned tb = (unsigned)B.unit_first[g], te = (unsigned)B.unit_first[g + 1];
+                                atomicExch(&L.deal, ((unsigned long long)te << 32) | (tb + 1u));
+                                lo32 = tb; hi32 = te; st = tb < te ? 1u : 3u;
+                            }
+                        }
+                        KC2_FENCE_WG();
+                        atomicExch(&L.deal_lock, 0u);
+                    } else {
+                        while (*(volatile unsigned *)&L.deal_lock) KC2_SLEEP();
+                        st = 3u;
+                    }
+                }
+            }
+            st = (unsigned)READLANE(st, 0);
+            if (st != 3u) break;                                         /* 3: look again */
+        }
+        if (st == 2u) break;
+        tile = READLANE(lo32, 0);
+    }
+    KC2_STAMP(0);
+    {
+#else
     for (;;) {
     int t_begin, t_end;
     {
@@ -363,6 +418,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
     }
     KC2_STAMP(0);
     for (int tile = t_begin; tile < t_end; tile++) {
+#endif
         const int c = tile * 64 + lane;
         const int apos = B.p0 + c;
         const bool inr = c < B.L;

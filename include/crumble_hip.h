@@ -156,6 +156,8 @@ void         crumble_hip_destroy(crumble_hip *h);
  *   "kcol"   = auto | v1 | v1perm | v2      column kernel (k_columns, its per-column-class form, k_columns2)
  *   "pblock" = auto | reads | segments      P-block decomposition
  *   "replay" = auto | flat                  per-base replay kernel
+ *   "dl_chunk" = <bytes>                    size of one staged device -> host copy (256 .. 8 MiB; crumble_hip_download
+ *                                           of >= 4 chunks goes through page-locked staging buffers on 8 streams)
  * Takes effect at the next crumble_hip_upload().  Unknown names / values -> CRUMBLE_EINVAL. */
 int crumble_hip_set_option(crumble_hip *h, const char *name, const char *value);
 

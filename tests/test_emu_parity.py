@@ -148,6 +148,22 @@ def test_emu_rerun_and_engine_reuse(product):
     eng.close()
 
 
+def test_emu_staged_download(product):
+    """crumble_hip_download through the page-locked staging lanes (8 host threads, double-buffered chunks): with the
+    chunk shrunk so that this batch is hundreds of chunks -- whole chunks, a ragged last one, more lanes than chunks --
+    the bytes equal the plain copy's."""
+    p = ca.preset_params(5)
+    hb = synth_batch("chr20", 0.0002)
+    plain = emu_lib.engine(p)
+    want = plain.contig(hb)
+    plain.close()
+    for chunk in (256, 4096, 1000003 // 256 * 256 + 256, hb.n_bases // 5 // 256 * 256 + 256):
+        e = emu_lib.engine(p, dl_chunk=str(chunk))
+        got = e.contig(hb)
+        e.close()
+        assert all(np.array_equal(x, y) for x, y in zip(got, want)), chunk
+
+
 def test_emu_find_str_stress(product):
     """mask_LC_regions / find_STR seam on repeat-rich reads of many lengths vs the oracle (whose find_STR is
     pinned against the real reference str_finder.c)."""

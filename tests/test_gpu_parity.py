@@ -172,6 +172,21 @@ def test_large_properties(product):
     eng.close()
 
 
+def test_staged_download(product):
+    """crumble_hip_download of a batch large enough for the page-locked staging lanes (8 streams, double-buffered
+    8 MiB chunks; include/crumble_hip.h "dl_chunk"): equal to the oracle, and to itself with other chunk sizes."""
+    import oracle_lib as O
+    hb = synth_batch("chr20", 0.05)
+    assert hb.n_bases > 4 * (8 << 20)
+    p = ca.preset_params(5)
+    want = O.contig(p, hb)
+    for chunk in (None, "1048576", "3000064"):
+        eng = ca.Engine(p, 0, options={"dl_chunk": chunk} if chunk else None)
+        got = eng.contig(hb)
+        eng.close()
+        assert all(np.array_equal(x, y) for x, y in zip(got, want)), chunk
+
+
 def test_rccl_stats_allreduce_single_rank(product):
     """crumble_hip_stats_allreduce: the one collective of the path, through RCCL (world size 1 here;
     the N>1 semantics are covered by tests/test_shard_gloo.py and bench.py --gpus N)."""
@@ -266,6 +281,47 @@ def test_bench_two_ranks(product, workload):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == ("weak" if workload == "chr20" else "strong")
     assert "roofline" in d and "cpu_baseline" not in d
+
+
+@pytest.mark.parametrize("workload", ["chr20", "wgs"])
+def test_bench_multi_gpu_rccl(product, workload):
+    """The real thing when the box has it: one process per DISTINCT GPU, backend nccl (= RCCL over xGMI), the product's
+    own crumble_hip_stats_allreduce.  Skipped on a one-GPU box (the gloo test above covers the control flow there)."""
+    import json, os, subprocess, sys
+    import torch
+    from crumble_amd.capi import ROOT
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("one visible GPU")
+    n = 2 if n < 4 else 4
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("CRUMBLE_BENCH_BACKEND", None); env.pop("CRUMBLE_BENCH_DEVICE", None)
+    scale = "0.02" if workload == "chr20" else "0.002"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"),
+                        "--gpus", str(n), "--steps", "2", "--warmup", "1", "--workload", workload, "--scale", scale],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == n and d["value"] > 0
+    assert "RCCL" in d["config"]["stats_allreduce"]
+    if workload == "wgs":
+        assert 1.0 <= d["config"]["lpt_max_over_mean_load"] < 1.5
+
+
+def test_bench_other_configs_small(product):
+    """bench.py's `other_configs` legs (configs 3, 4 and the streamed config 5) at small scales: every leg verifies
+    the timed engine's own output against the oracle, and the streamed leg reports its overlap."""
+    import bench
+    import synth
+    from crumble_amd import shard
+    oc3 = bench.measure_config(ca, synth, "panel", 0.01, 0, steps=1, warmup=1, verify_seconds=1.0)
+    assert oc3["verified_timed_output_leading_reads"] and oc3["pipeline_frac"] > 0
+    oc4 = bench.measure_config(ca, synth, "hifi", 0.002, 0, steps=1, warmup=1, verify_seconds=1.0)
+    assert oc4["verified_timed_output_leading_reads"] and "keep.bed" in oc4["workload"]
+    w = bench.measure_wgs_streamed(ca, synth, shard, 0.0008, 0)
+    assert w["verified_smallest_contig"] and 0 < w["overlap_wall_over_sum_of_stages"] <= 1.05
+    assert set(w["stages_ms"]) == {"h2d_and_p0", "kernels", "d2h"}
 
 
 def test_find_str_stress(product):
