@@ -312,6 +312,7 @@ def main():
     ap.add_argument("--pmc-json", default=None, help="profiles/*_pmc_traffic.json measured for THIS build and "
                     "workload: fills roofline.traffic (null otherwise)")
     ap.add_argument("--kcol", default="auto", help="crumble_hip_set_option kcol (auto|v1|v1perm|v2)")
+    ap.add_argument("--pblock", default="auto", help="crumble_hip_set_option pblock (auto|reads|segments|words)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the `other_configs` object (BASELINE configs "
                     "3, 4 and 5 measured after the headline config; default line, one GPU only)")
     ap.add_argument("--wgs-stream-scale", type=float, default=0.05, help="other_configs.wgs_streamed: contig length scale")
@@ -379,6 +380,8 @@ def main():
     hb = batches[0]
     params = ca.preset_params(args.preset, tech=tech)
     opts = {} if args.kcol == "auto" else {"kcol": args.kcol}
+    if args.pblock != "auto":
+        opts["pblock"] = args.pblock
 
     t0 = time.time()
     engines = []

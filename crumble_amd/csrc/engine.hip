@@ -61,7 +61,7 @@ struct crumble_hip {
     DParams hparams;
     DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc, d_mqslot;
     /* batch (inputs) */
-    DevBuf d_genlist, d_vrec, d_pbdirty, d_ufirst, d_tcum, d_tpart, d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
+    DevBuf d_genlist, d_vrec, d_pbdirty, d_pbcarry, d_pbhmm, d_ufirst, d_tcum, d_tpart, d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
            d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax;
     /* per position */
     DevBuf d_colrec, d_nplp, d_score, d_trigcnt, d_dpre, d_col_ord, d_trig_ord, d_item_off,
@@ -76,7 +76,7 @@ struct crumble_hip {
     bool col_perm = false;          /* k_columns<.., PERM>: picked per batch in crumble_hip_upload */
     /* crumble_hip_set_option(): kernel choices that never change a result (tests force every variant) */
     int opt_kcol = 0;               /* 0 auto (k_columns2 where it applies), 1 k_columns, 2 k_columns PERM, 3 k_columns2 */
-    int opt_pblock = 0;             /* 0 auto, 1 one lane per read, 2 segment-parallel */
+    int opt_pblock = 0;             /* 0 auto (= 3), 1 one lane per read, 2 segment-parallel, 3 word-parallel (k_pb_words / k_pb_chains) */
     int opt_replay = 0;             /* 0 auto, 1 k_replay_flat */
     int b_kcol = 0, b_pblock = 0;   /* the batch's snapshot of opt_kcol / opt_pblock (options take effect at an upload) */
     int64_t n_reads = 0, n_bases = 0, n_cigar = 0, n_slow = 0, n_segrec = 0, n_general_max = 0;
@@ -275,7 +275,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     DevBuf *all[] = { &h->d_genlist, &h->d_vrec, &h->d_params, &h->d_tables, &h->d_stats, &h->d_batch_stats, &h->d_misc, &h->d_mqslot,
-        &h->d_ufirst, &h->d_tcum, &h->d_tpart, &h->d_pbdirty, &h->d_pbwmm, &h->d_act, &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
+        &h->d_ufirst, &h->d_tcum, &h->d_tpart, &h->d_pbdirty, &h->d_pbcarry, &h->d_pbhmm, &h->d_pbwmm, &h->d_act, &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
         &h->d_slow_g, &h->d_slow_r, &h->d_cix, &h->d_sr, &h->d_stile_lo, &h->d_stile_hi, &h->d_rr, &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
         &h->d_cigar, &h->d_segs, &h->d_bases, &h->d_quals, &h->d_tile_lo, &h->d_tile_hi,
         &h->d_bed_start, &h->d_bed_end, &h->d_bed_pmax, &h->d_colrec, &h->d_nplp, &h->d_score,
@@ -307,8 +307,8 @@ extern "C" int crumble_hip_set_option(crumble_hip *h, const char *name, const ch
         if ((v = pick(nm, 4)) < 0) return CRUMBLE_EINVAL;
         h->opt_kcol = v;
     } else if (!strcmp(name, "pblock")) {
-        static const char *const nm[] = {"auto", "reads", "segments"};
-        if ((v = pick(nm, 3)) < 0) return CRUMBLE_EINVAL;
+        static const char *const nm[] = {"auto", "reads", "segments", "words"};
+        if ((v = pick(nm, 4)) < 0) return CRUMBLE_EINVAL;
         h->opt_pblock = v;
     } else if (!strcmp(name, "replay")) {
         static const char *const nm[] = {"auto", "flat"};
@@ -604,9 +604,10 @@ static int launch_pblock(crumble_hip *h, hipStream_t st, int64_t n_reads, int64_
 {
     if (nb <= 0 || n_reads <= 0) return CRUMBLE_OK;
     const DParams *P = h->d_params.as<DParams>();
-    /* short reads: one lane per read keeps the lanes of a wave evenly loaded; long reads: segment-parallel.
-     * Option "pblock" = reads|segments overrides the choice (tuning / tests). */
-    const bool per_read = mode ? mode == 1 : nb < 1024 * n_reads;
+    /* word-parallel (kernels.h, k_pb_words / k_pb_chains) unless option "pblock" = reads | segments asks for one of the
+     * two earlier decompositions (tuning / tests: all three must give the same bytes) */
+    const bool per_read = mode == 1;
+    const bool words = mode == 0 || mode == 3;
     const int64_t nwords = (nb + 63) / 64;
     int e;
     if (per_read && h->hparams.any_preserve) {          /* -k/-K: the byte-wise kernel knows the skip rule */
@@ -638,8 +639,24 @@ static int launch_pblock(crumble_hip *h, hipStream_t st, int64_t n_reads, int64_
     u64 *stop = h->d_pbstop.as<u64>(), *rs = h->d_pbrs.as<u64>(), *runs = h->d_pbruns.as<u64>();
     uint8_t *val = h->d_pbval.as<uint8_t>();
     HIPCHK(hipMemsetAsync(h->d_pbdirty.p, 0, (size_t)nwords, st));
-    CRUMBLE_LAUNCH_INDEP(k_pb_marks, nblk(nwords, 256), 256, st, nb, out, P, stop, rs, runs, h->d_pbwmm.as<uint16_t>());
-    CRUMBLE_LAUNCH_INDEP(k_pb_readstarts, nblk(n_reads, 256), 256, st, n_reads, seq_off, stop, rs);
+    if (words) {
+        /* read starts first: k_pb_marks folds them into the stops and knows every word's head */
+        if ((e = h->d_pbhmm.reserve((size_t)(nwords + 1) * 2))) return e;
+        HIPCHK(hipMemsetAsync(rs, 0, (size_t)nwords * 8, st));
+        CRUMBLE_LAUNCH_INDEP(k_pb_readstarts, nblk(n_reads, 256), 256, st, n_reads, seq_off, (u64 *)nullptr, rs);
+        CRUMBLE_LAUNCH_INDEP(k_pb_marks, nblk(nwords, 256), 256, st, nb, out, P, stop, rs, runs, h->d_pbwmm.as<uint16_t>(), h->d_pbhmm.as<uint16_t>());
+    } else {
+        CRUMBLE_LAUNCH_INDEP(k_pb_marks, nblk(nwords, 256), 256, st, nb, out, P, stop, rs, runs, h->d_pbwmm.as<uint16_t>(), (uint16_t *)nullptr);
+        CRUMBLE_LAUNCH_INDEP(k_pb_readstarts, nblk(n_reads, 256), 256, st, n_reads, seq_off, stop, rs);
+    }
+    if (words) {
+        if ((e = h->d_pbcarry.reserve((size_t)(nwords + 1) * 8))) return e;
+        u64 *carry = h->d_pbcarry.as<u64>();
+        CRUMBLE_LAUNCH_INDEP(k_pb_words, nblk(nwords, 256), 256, st, nb, n_reads, seq_off, out, rflags, blk_read, stop, rs, runs, val, carry, h->d_pbdirty.as<uint8_t>(), P);
+        CRUMBLE_LAUNCH_INDEP(k_pb_chains, nblk(nwords, 256), 256, st, nb, out, stop, rs, runs, val, carry, h->d_pbwmm.as<uint16_t>(), h->d_pbhmm.as<uint16_t>(), h->d_pbdirty.as<uint8_t>(), P);
+        CRUMBLE_LAUNCH_INDEP(k_pb_fill, nblk((nb + 15) / 16, 256), 256, st, nb, out, stop, runs, val, h->d_pbdirty.as<uint8_t>());
+        return CRUMBLE_OK;
+    }
     CRUMBLE_LAUNCH_INDEP(k_pb_segments, nblk(nwords, 256), 256, st, nb, n_reads, seq_off, out, rflags, blk_read, stop, rs, runs, val, h->d_pbwmm.as<uint16_t>(), h->d_pbdirty.as<uint8_t>(), P);
     CRUMBLE_LAUNCH_INDEP(k_pb_fill, nblk((nb + 15) / 16, 256), 256, st, nb, out, stop, runs, val, h->d_pbdirty.as<uint8_t>());
     return CRUMBLE_OK;

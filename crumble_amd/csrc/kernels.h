@@ -2512,8 +2512,11 @@ __global__ void k_pblock(int64_t n_reads, const int64_t *seq_off, uint8_t *out,
 
 __global__ void __launch_bounds__(256)
 k_pb_marks(int64_t n_bases, const uint8_t *__restrict__ q, const DParams *__restrict__ P,
-           u64 *__restrict__ stop, u64 *__restrict__ rstart, u64 *__restrict__ runs, uint16_t *__restrict__ wmm)
+           u64 *__restrict__ stop, u64 *__restrict__ rstart, u64 *__restrict__ runs, uint16_t *__restrict__ wmm,
+           uint16_t *__restrict__ hmm = nullptr)
 {
+    /* hmm != nullptr (word-parallel P-block): rstart[] already holds the read starts (k_pb_readstarts ran first); they
+     * are stops too, and the word's head -- the bytes before its first stop of either kind -- gets its (min, max) */
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t g0 = w * 64;
     if (g0 >= n_bases) return;
@@ -2528,7 +2531,10 @@ k_pb_marks(int64_t n_bases, const uint8_t *__restrict__ q, const DParams *__rest
     int prev = g0 > 0 ? (int)q[g0 - 1] : -1000;
     bool prev_pres = g0 > 0 && PB_IS_PRES(prev);
     u64 m = 0;
+    const u64 rsw = hmm ? rstart[w] : 0ull;
     int wmin = 255, wmax = 0;                            /* of the word's bytes: lets a long segment step 64 bases at once */
+    int hmin = 255, hmax = 0;                            /* of the bytes before the word's first stop (k_pb_chains: the tail of a
+                                                          * segment that began in an earlier word) */
     for (int k0 = 0; k0 < nn; k0 += 16) {
         uint32_t wd[4] = {0, 0, 0, 0};
         if (k0 + 16 <= nn) { const uint4 v = *(const uint4 *)(q + g0 + k0); wd[0] = v.x; wd[1] = v.y; wd[2] = v.z; wd[3] = v.w; }
@@ -2540,13 +2546,15 @@ k_pb_marks(int64_t n_bases, const uint8_t *__restrict__ q, const DParams *__rest
             int d = v - prev; d = d < 0 ? -d : d;
             if (k0 + k < nn && (pres || prev_pres || d > level2)) m |= 1ull << (k0 + k);
             if (k0 + k < nn) { wmin = v < wmin ? v : wmin; wmax = v > wmax ? v : wmax; }
+            if (k0 + k < nn && !((m | rsw) & ((2ull << (k0 + k)) - 1ull))) { hmin = v < hmin ? v : hmin; hmax = v > hmax ? v : hmax; }
             prev = v; prev_pres = pres;
         }
     }
 #undef PB_IS_PRES
-    stop[w] = m;
+    stop[w] = m | rsw;
     wmm[w] = (uint16_t)(wmin | (wmax << 8));
-    rstart[w] = 0;
+    if (hmm) hmm[w] = (uint16_t)(hmin | (hmax << 8));   /* (no byte before a stop at bit 0: 255 | 0 -- joins any run) */
+    else rstart[w] = 0;
     runs[w] = 0;
 }
 
@@ -2557,7 +2565,7 @@ __global__ void k_pb_readstarts(int64_t n_reads, const int64_t *__restrict__ seq
     if (r >= n_reads) return;
     const int64_t g = seq_off[r];
     if (seq_off[r + 1] == g) return;
-    atomicOr((unsigned long long *)&stop[g >> 6], 1ull << (g & 63));
+    if (stop) atomicOr((unsigned long long *)&stop[g >> 6], 1ull << (g & 63));
     if (rstart) atomicOr((unsigned long long *)&rstart[g >> 6], 1ull << (g & 63));
 }
 
@@ -2700,6 +2708,242 @@ k_pb_segments(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_
         }
     }
 }
+
+/* ------------------------------------------------------------------------ */
+/* P-block, word-parallel (round 3; replaces k_pb_segments and the per-read walk where it is faster -- see DESIGN).
+ * k_pb_segments gives a segment to the lane that owns its first byte and pays a loop trip per segment: a 64-byte word
+ * with thirty one-base segments around preserved values is thirty trips for one lane while its wave waits, and a
+ * 2000-byte run is thirty dependent loads for another.  Here
+ *   k_pb_words    one lane per 64-byte word that holds a stop: ONE pass of the reference's state machine (snp:807-833)
+ *                 over the word's bytes from its first stop on, in registers -- every segment and run that starts in the
+ *                 word, up to the word's end.  Run starts go to the word's `runs` bits, run values to the word's 64-byte
+ *                 row of `runval` (staged in LDS, written as one row).  A segment still open at the word's end, with no
+ *                 stop at the next word's first byte, leaves its state in carry[w] (8 bytes).
+ *   k_pb_chains   one lane per carried state: walks on word by word -- a word without a stop whose (min, max) keeps the
+ *                 run inside 2 * level is one step (wmm[]) -- to the segment's end; bytes are looked at only in the word
+ *                 where a run breaks and in the last, partial word.
+ * Both record runs exactly as k_pb_segments does; k_pb_fill writes the bytes. */
+#define PBW_ROW 80              /* LDS bytes per lane's runval row (64 used; 16-byte aligned, off the 64-byte bank period) */
+#define PBW_CARRY_VALID (1ull << 63)
+#define PBW_CARRY(jl, qmin, qmax, lmin, lmax) (PBW_CARRY_VALID | (u64)(jl) | ((u64)(qmin) << 8) | ((u64)(qmax) << 16) | ((u64)(lmin) << 24) | ((u64)(lmax) << 32))
+
+/* one byte q at word position k_ (global g0 + k_) without a stop, inside an open segment: snp:813-829 */
+#define PBW_STEP(q_, k_, ON_BREAK) do { \
+    const int nmin_ = (q_) < qmin ? (q_) : qmin, nmax_ = (q_) > qmax ? (q_) : qmax; \
+    if (nmax_ - nmin_ > level2) { \
+        int mid_ = (lmin + lmax) >> 1; \
+        mid_ = mid_ > qcap ? qcap : mid_; \
+        ON_BREAK(mid_, k_); \
+        qmin = qmax = lmin = lmax = (q_); \
+    } else { qmin = lmin = nmin_; qmax = lmax = nmax_; } } while (0)
+
+__global__ void __launch_bounds__(256)
+k_pb_words(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_off, const uint8_t *__restrict__ out,
+           const uint8_t *__restrict__ rflags, const int32_t *__restrict__ blk_read,
+           const u64 *__restrict__ stop, const u64 *__restrict__ rstart, u64 *__restrict__ runs,
+           uint8_t *__restrict__ runval, u64 *__restrict__ carry, uint8_t *__restrict__ dirty,
+           const DParams *__restrict__ P)
+{
+    /* per lane: the word's 64 bytes (a segment's walk indexes them at run time) and its row of run values */
+    __shared__ __attribute__((aligned(16))) uint8_t sbytes[256 * PBW_ROW], rows[256 * PBW_ROW];
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nwords = (n_bases + 63) >> 6;
+    if (w >= nwords) return;
+    u64 st = stop[w];
+    carry[w] = 0;
+    if (!st) return;
+    const int64_t g0 = w * 64;
+    const int nn = (n_bases - g0 < 64) ? (int)(n_bases - g0) : 64;
+    const int level2 = P->pblock * 2, qcap = P->qcap;
+    const u64 rs = rstart[w];
+    uint32_t wd[16];
+    uint8_t *const byt = sbytes + threadIdx.x * PBW_ROW, *const row = rows + threadIdx.x * PBW_ROW;
+    {
+        const uint4 *src = (const uint4 *)(out + g0);           /* (d_out carries 64 bytes of slack) */
+        uint4 *dstb = (uint4 *)byt, *dstr = (uint4 *)row;
+        uint4 ff; ff.x = ff.y = ff.z = ff.w = 0xffffffffu;       /* PB_KEEP everywhere: a run that changes nothing needs no value */
+        #pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint4 v = src[t];
+            wd[4 * t] = v.x; wd[4 * t + 1] = v.y; wd[4 * t + 2] = v.z; wd[4 * t + 3] = v.w;
+            dstb[t] = v; dstr[t] = ff;
+        }
+    }
+    /* bit masks over the word's bytes (packed byte arithmetic, 4 bits per dword):
+     *   keep  the byte's value stays: a preserved quality (snp:817,822; at most four values as scalars, else the
+     *         table) or any byte of a read with flag bit 15 (snp:1098)
+     *   chg   the byte differs from the byte before it: a segment without such a byte (other than at its start) is
+     *         one run of one value -- its bytes do not change unless that value is above qcap
+     *   big   a byte above qcap */
+#define PBW_BITS4(m_) ((u64)(((((m_) >> 7) * 0x00204081u) >> 21) & 15u))       /* bit 7 of the four bytes -> 4 bits */
+#define PBW_ZERO(x_) (~((((x_) & 0x7f7f7f7fu) + 0x7f7f7f7fu) | (x_)) & 0x80808080u)  /* bit 7 of every zero byte */
+    u64 keep = 0, chg = 0, big = 0;
+    {
+        const int npv = P->any_preserve ? P->n_pv : 0;
+        const uint32_t QC = (uint32_t)qcap * 0x01010101u;
+        uint32_t prevd = 0;
+        #pragma unroll
+        for (int t = 0; t < 16; t++) {
+            uint32_t eq = 0;
+            for (int i = 0; i < npv; i++) eq |= PBW_ZERO(wd[t] ^ ((uint32_t)P->pv_val[i] * 0x01010101u));
+            keep |= PBW_BITS4(eq) << (4 * t);
+            const uint32_t sh = (wd[t] << 8) | (prevd >> 24);                     /* every byte's predecessor */
+            chg |= PBW_BITS4(~PBW_ZERO(wd[t] ^ sh) & 0x80808080u) << (4 * t);
+            big |= PBW_BITS4(~((QC | 0x80808080u) - (wd[t] & 0x7f7f7f7fu)) & 0x80808080u) << (4 * t);   /* QC - q borrows: q > qcap */
+            prevd = wd[t];
+        }
+        if (P->any_preserve && P->n_pv < 0)
+            for (int k = 0; k < nn; k++) if (P->preserve_qual[byt[k]]) keep |= 1ull << k;
+    }
+    if (rflags) {
+        int64_t r = blk_read[w];
+        while (r < n_reads && seq_off[r] < g0 + nn) {
+            const int64_t a = seq_off[r], b = seq_off[r + 1];
+            if (b > g0 && (rflags[r] & 2)) {
+                const int lo = a > g0 ? (int)(a - g0) : 0, hi = b < g0 + 64 ? (int)(b - g0) : 64;
+                if (lo < hi) keep |= ((hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull));
+            }
+            r++;
+        }
+    }
+    /* the end of the data is the last read's end */
+    const u64 valid = nn >= 64 ? ~0ull : ((1ull << nn) - 1ull);
+    st &= valid;
+    const u64 seg_starts = st & ~keep;                          /* a kept stop ends a segment and starts none */
+    /* segments to walk: those with a changing byte inside, all of them if a byte is above qcap (its run is capped) */
+    u64 walk = (big & ~keep & valid) ? seg_starts : 0ull;
+    {
+        u64 c = chg & ~st & valid;                              /* changing bytes that are not themselves stops */
+        while (c) {
+            const int b = __builtin_ctzll(c);
+            const u64 below = st & ((1ull << b) - 1ull);        /* the stops before it: the last one starts its segment */
+            const u64 nx = st & ~((2ull << b) - 1ull);          /* the stops behind it: the first one ends the segment */
+            const u64 upto = nx ? (nx & (0ull - nx)) - 1ull : ~0ull;
+            if (below) {                                        /* (no stop before it: the tail of an earlier word's segment, k_pb_chains) */
+                const int sb = 63 - __builtin_clzll(below);
+                if ((seg_starts >> sb) & 1ull) walk |= 1ull << sb;
+            }
+            c &= ~upto;                                         /* the segment's other changing bytes */
+        }
+    }
+    u64 newruns = 0;
+    bool isdirty = false;
+    /* the state the word's last segment is left in (if it is still open at the word's end) */
+    const int last_stop = 63 - __builtin_clzll(st);
+    int cj = last_stop, cmin = (int)byt[last_stop], cmax = cmin;
+    const bool last_open = ((seg_starts >> last_stop) & 1ull) != 0;
+    while (walk) {
+        const int s0 = __builtin_ctzll(walk);
+        walk &= walk - 1;
+        const u64 nx = st & ~((2ull << s0) - 1ull);
+        const int e = nx ? __builtin_ctzll(nx) : nn;
+        int j = s0, qmin = (int)byt[s0], qmax = qmin;
+        for (int k = s0 + 1; k < e; k++) {
+            const int q = (int)byt[k];
+            const int nmin = q < qmin ? q : qmin, nmax = q > qmax ? q : qmax;
+            if (nmax - nmin > level2) {                          /* snp:817-826 */
+                int mid = (qmin + qmax) >> 1;
+                mid = mid > qcap ? qcap : mid;
+                row[j] = (uint8_t)mid; isdirty |= (qmin != qmax) | (mid != qmin);
+                newruns |= 1ull << k; j = k; qmin = qmax = q;
+            } else { qmin = nmin; qmax = nmax; }
+        }
+        if (nx || nn < 64) {                                    /* ends inside the word: at a stop, or with the data */
+            int mid = (qmin + qmax) >> 1;
+            const bool at_read_end = nx ? ((rs >> e) & 1ull) != 0 : true;
+            if (!at_read_end && mid > qcap) mid = qcap;         /* a read's final run is not capped (snp:832) */
+            row[j] = (uint8_t)mid; isdirty |= (qmin != qmax) | (mid != qmin);
+        } else { cj = j; cmin = qmin; cmax = qmax; }             /* (the word's last segment) */
+    }
+    if (last_open && nn == 64) {
+        const bool last = w + 1 >= nwords;
+        const u64 nst = last ? 1ull : stop[w + 1];
+        if (nst & 1ull) {                                       /* the next byte is a stop (or there is none): the segment ends here */
+            const bool at_read_end = last ? true : (rstart[w + 1] & 1ull) != 0;
+            int mid = (cmin + cmax) >> 1;
+            if (!at_read_end && mid > qcap) mid = qcap;
+            if (cmin != cmax || mid != cmin) { row[cj] = (uint8_t)mid; isdirty = true; }
+        } else carry[w] = PBW_CARRY(cj, cmin, cmax, cmin, cmax);
+    }
+    if (newruns) runs[w] = newruns;
+    if (isdirty) dirty[w] = 1;
+    {   /* the row: PB_KEEP but for the runs written above (only bytes at run starts are ever read back) */
+        const uint4 *rsrc = (const uint4 *)row;
+        uint4 *dst = (uint4 *)(runval + g0);
+        #pragma unroll
+        for (int t = 0; t < 4; t++) dst[t] = rsrc[t];
+    }
+#undef PBW_BITS4
+#undef PBW_ZERO
+}
+
+__global__ void __launch_bounds__(256)
+k_pb_chains(int64_t n_bases, const uint8_t *__restrict__ out, const u64 *__restrict__ stop, const u64 *__restrict__ rstart,
+            u64 *__restrict__ runs, uint8_t *__restrict__ runval, const u64 *__restrict__ carry,
+            const uint16_t *__restrict__ wmm, const uint16_t *__restrict__ hmm, uint8_t *__restrict__ dirty,
+            const DParams *__restrict__ P)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nwords = (n_bases + 63) >> 6;
+    if (w >= nwords) return;
+    const u64 cy = carry[w];
+    if (!(cy & PBW_CARRY_VALID)) return;
+    const int level2 = P->pblock * 2, qcap = P->qcap;
+    int64_t j = w * 64 + (int64_t)(cy & 63u);
+    int qmin = (int)((cy >> 8) & 255u), qmax = (int)((cy >> 16) & 255u), lmin = (int)((cy >> 24) & 255u), lmax = (int)((cy >> 32) & 255u);
+    /* a run [j, pos) ends: its value, the words it changes, the next run's start bit */
+#define PBC_CLOSE(mid_, pos_) do { \
+        runval[j] = (uint8_t)(mid_); \
+        if (lmin != lmax || (mid_) != lmin) for (int64_t dw_ = j >> 6; dw_ <= ((pos_) - 1) >> 6; dw_++) dirty[dw_] = 1; } while (0)
+#define PBC_BREAK(mid_, k_) do { const int64_t pos_ = wbase + (k_); PBC_CLOSE(mid_, pos_); \
+        atomicOr((unsigned long long *)&runs[pos_ >> 6], 1ull << (pos_ & 63)); j = pos_; } while (0)
+    for (int64_t ww = w + 1;; ww++) {
+        const bool beyond = ww >= nwords;
+        const u64 s = beyond ? 1ull : stop[ww];
+        const int64_t wbase = ww * 64;
+        const int wn = beyond ? 0 : ((n_bases - wbase < 64) ? (int)(n_bases - wbase) : 64);
+        if (!beyond && !s && wn == 64) {
+            const unsigned mm = wmm[ww];
+            const int cmin = (int)(mm & 255u), cmax = (int)(mm >> 8);
+            const int nmin = cmin < qmin ? cmin : qmin, nmax = cmax > qmax ? cmax : qmax;
+            if (nmax - nmin <= level2) { qmin = lmin = nmin; qmax = lmax = nmax; continue; }    /* the whole word joins the run */
+        }
+        /* bytes [0, e) of this word belong to the segment: e = the first stop, or all of it */
+        const int e = beyond ? 0 : (s ? __builtin_ctzll(s) : wn);
+        bool joined = false;
+        if (e > 0 && s) {                                           /* the bytes before the first stop as one step (k_pb_marks' hmm[]) */
+            const unsigned mm = hmm[ww];
+            const int cmin = (int)(mm & 255u), cmax = (int)(mm >> 8);
+            const int nmin = cmin < qmin ? cmin : qmin, nmax = cmax > qmax ? cmax : qmax;
+            if (nmax - nmin <= level2) { qmin = lmin = nmin; qmax = lmax = nmax; joined = true; }
+        }
+        if (e > 0 && !joined) {
+            const uint4 *src = (const uint4 *)(out + wbase);
+            #pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (16 * c >= e) continue;
+                const uint4 v = src[c];
+                const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+                #pragma unroll
+                for (int kk = 0; kk < 16; kk++) {
+                    const int k = 16 * c + kk;
+                    if (k < e) { const int q = (int)((wd[kk >> 2] >> (8 * (kk & 3))) & 255u); PBW_STEP(q, k, PBC_BREAK); }
+                }
+            }
+        }
+        if (beyond || s || wn < 64) {                               /* the segment ends in this word */
+            const bool at_read_end = (beyond || !s) ? true : ((rstart[ww] >> e) & 1ull) != 0;
+            int mid = (lmin + lmax) >> 1;
+            if (!at_read_end && mid > qcap) mid = qcap;
+            const int64_t pos = beyond ? n_bases : wbase + e;
+            PBC_CLOSE(mid, pos);
+            break;
+        }
+    }
+#undef PBC_BREAK
+#undef PBC_CLOSE
+}
+#undef PBW_STEP
 
 /* Short reads without -k/-K.  One lane per read keeps a wave's lanes level, but a lane that walks its
  * own read touches a different cache line than its neighbours at every step (5.9 ms at -9 on the

@@ -30,7 +30,7 @@ def test_emu_hifi_long_reads(product):
     assert_parity(emu_lib.engine, ca.preset_params(5), hb)
 
 
-@pytest.mark.parametrize("path", ["reads", "segments"])
+@pytest.mark.parametrize("path", ["reads", "segments", "words"])
 def test_emu_pblock_paths(product, path):
     """Both P-block implementations (one lane per read / segment-parallel) on short and long reads."""
     eng = emu_lib.with_options(pblock=path)
@@ -40,7 +40,7 @@ def test_emu_pblock_paths(product, path):
         assert_parity(eng, p, hb, check_columns=False)
 
 
-@pytest.mark.parametrize("path", ["reads", "segments"])
+@pytest.mark.parametrize("path", ["reads", "segments", "words"])
 def test_emu_pblock_stress(product, path):
     """The pblock operator seam on raw quality strings: jumps, drifts, outliers, every chunk alignment."""
     pblock_stress(emu_lib.engine, path, n_reads=150)

@@ -76,7 +76,7 @@ def test_column_kernel_variants(product, kcol):
         assert_parity(gpu_engine, ca.preset_params(level, keep="30-33"), cigar_zoo(CASES))
 
 
-@pytest.mark.parametrize("path", ["reads", "segments"])
+@pytest.mark.parametrize("path", ["reads", "segments", "words"])
 def test_pblock_paths(product, path):
     """Both P-block implementations (one lane per read / segment-parallel) on short and long reads."""
     def gpu_engine(q):
@@ -88,7 +88,7 @@ def test_pblock_paths(product, path):
         assert_parity(gpu_engine, p, hb, check_columns=False)
 
 
-@pytest.mark.parametrize("path", ["reads", "segments"])
+@pytest.mark.parametrize("path", ["reads", "segments", "words"])
 def test_pblock_stress(product, path):
     """The pblock operator seam on raw quality strings: jumps, drifts, outliers, every chunk alignment."""
     pblock_stress(gpu_engine, path, n_reads=2000)

@@ -135,7 +135,7 @@ def test_hip_engine_reproduces_the_man_page(seed):
     e = ca.Engine(params(8), 0)
     try:
         check_pblock(e.pblock, hb, cmap, d, q)
-        for opt in ("reads", "segments"):                                          # both P-block decompositions
+        for opt in ("reads", "segments", "words"):                                        # both P-block decompositions
             e.set_option("pblock", opt)
             check_pblock(e.pblock, hb, cmap, d, q)
     finally:
