@@ -750,13 +750,13 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
             const bool ok = !needs || cons_fast_ok(T, s00, s01, s02, s03, s04, dmax, st.depth, st.nN);
             if (__ballot(!ok) == 0ull) {
                 KC2_EMU_COUNT(0);
+                ConsOut co;
+                cons_finalize_fast(T, s00, s01, s02, s03, s04, d0, d1, d2, d3, d4, key, co, sE, MQ ? P->min_discrep_B : P->min_discrep_A, needs);
                 if (inr) {
-                    if (in_win) {
-                        ConsOut co;
-                        cons_finalize_fast(T, s00, s01, s02, s03, s04, d0, d1, d2, d3, d4, key, co, sE, MQ ? P->min_discrep_B : P->min_discrep_A);
+                    if (in_win)
                         col_decide<MQ ? 1 : 0, true>(st, B, P, T, c, apos, true, colrec, nplp_out, score_out, trigcnt,
                                                      sStat, sE, WIN ? c < B.stat_hi : true, &co);
-                    } else { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; }
+                    else { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; }
                 }
                 KC2_STAMP(4);
                 continue;

@@ -314,8 +314,8 @@ __device__ __forceinline__ bool cons_fast_ok(const DTables *T, double v0, double
 #define CONS_SEL2(k1_, k2_, x0, x1, x2, x3) ((k2_) ? ((k1_) ? (x3) : (x2)) : ((k1_) ? (x1) : (x0)))
 __device__ __forceinline__ void cons_finalize_fast(const DTables *T, double v0, double v1, double v2, double v3, double v4,
                                                    double c0, double c1, double c2, double c3, double c4,
-                                                   unsigned key, ConsOut &o, const double *sE, double min_discrep)
-{
+                                                   unsigned key, ConsOut &o, const double *sE, double min_discrep, bool live)
+{   /* called by every lane of the wave (the ballot below); live = the lane's column reaches the consensus */
     const bool k1 = (key & 1u) != 0u, k2 = (key & 2u) != 0u;
     const double lph = T->lprior15[0], lpt = T->lprior15[1];
     v0 += lph; v1 += lpt; v2 += lpt; v3 += lpt; v4 += lpt;                          /* snp:708 */
@@ -370,7 +370,7 @@ __device__ __forceinline__ void cons_finalize_fast(const DTables *T, double v0, 
         const bool sure_lt = qa < min_discrep * (1.0 - 1e-4) && qa < min_discrep * (1.0 + 1e-4);
         o.disc_ge = sure_ge ? 1 : 0;
         o.discrep = 0;
-        if (__ballot(!(sure_ge || sure_lt))) {
+        if (__ballot(live && !(sure_ge || sure_lt))) {
             o.discrep = (float)(t / sqrt(m));
             o.disc_ge = o.discrep >= min_discrep ? 1 : 0;
         }
@@ -2744,27 +2744,36 @@ k_pb_words(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_off
            uint8_t *__restrict__ runval, u64 *__restrict__ carry, uint8_t *__restrict__ dirty,
            const DParams *__restrict__ P)
 {
-    /* per lane: the word's 64 bytes (a segment's walk indexes them at run time) and its row of run values */
-    __shared__ __attribute__((aligned(16))) uint8_t sbytes[256 * PBW_ROW], rows[256 * PBW_ROW];
+    /* per lane: the word's 64 bytes (a segment's walk indexes them at run time) */
+    __shared__ __attribute__((aligned(16))) uint8_t sbytes[256 * PBW_ROW];
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nwords = (n_bases + 63) >> 6;
     if (w >= nwords) return;
-    u64 st = stop[w];
-    carry[w] = 0;
-    if (!st) return;
     const int64_t g0 = w * 64;
-    const int nn = (n_bases - g0 < 64) ? (int)(n_bases - g0) : 64;
-    const int level2 = P->pblock * 2, qcap = P->qcap;
+    /* every load the lane may need goes out before the first one is looked at */
+    u64 st = stop[w];
     const u64 rs = rstart[w];
-    uint32_t wd[16];
-    uint8_t *const byt = sbytes + threadIdx.x * PBW_ROW, *const row = rows + threadIdx.x * PBW_ROW;
+    int64_t r = rflags ? blk_read[w] : 0;
+    uint4 v4[4];
     {
         const uint4 *src = (const uint4 *)(out + g0);           /* (d_out carries 64 bytes of slack) */
+        #pragma unroll
+        for (int t = 0; t < 4; t++) v4[t] = src[t];
+    }
+    carry[w] = 0;
+    if (!st) return;
+    const int nn = (n_bases - g0 < 64) ? (int)(n_bases - g0) : 64;
+    const int level2 = P->pblock * 2, qcap = P->qcap;
+    uint32_t wd[16];
+    uint8_t *const byt = sbytes + threadIdx.x * PBW_ROW;
+    uint8_t *const row = runval + g0;                           /* the word's run values: PB_KEEP everywhere (a run that changes
+                                                                 * nothing needs no value), then the walked runs' values */
+    {
         uint4 *dstb = (uint4 *)byt, *dstr = (uint4 *)row;
-        uint4 ff; ff.x = ff.y = ff.z = ff.w = 0xffffffffu;       /* PB_KEEP everywhere: a run that changes nothing needs no value */
+        uint4 ff; ff.x = ff.y = ff.z = ff.w = 0xffffffffu;
         #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const uint4 v = src[t];
+            const uint4 v = v4[t];
             wd[4 * t] = v.x; wd[4 * t + 1] = v.y; wd[4 * t + 2] = v.z; wd[4 * t + 3] = v.w;
             dstb[t] = v; dstr[t] = ff;
         }
@@ -2796,7 +2805,6 @@ k_pb_words(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_off
             for (int k = 0; k < nn; k++) if (P->preserve_qual[byt[k]]) keep |= 1ull << k;
     }
     if (rflags) {
-        int64_t r = blk_read[w];
         while (r < n_reads && seq_off[r] < g0 + nn) {
             const int64_t a = seq_off[r], b = seq_off[r + 1];
             if (b > g0 && (rflags[r] & 2)) {
@@ -2838,15 +2846,22 @@ k_pb_words(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_off
         const u64 nx = st & ~((2ull << s0) - 1ull);
         const int e = nx ? __builtin_ctzll(nx) : nn;
         int j = s0, qmin = (int)byt[s0], qmax = qmin;
-        for (int k = s0 + 1; k < e; k++) {
-            const int q = (int)byt[k];
-            const int nmin = q < qmin ? q : qmin, nmax = q > qmax ? q : qmax;
-            if (nmax - nmin > level2) {                          /* snp:817-826 */
-                int mid = (qmin + qmax) >> 1;
-                mid = mid > qcap ? qcap : mid;
-                row[j] = (uint8_t)mid; isdirty |= (qmin != qmax) | (mid != qmin);
-                newruns |= 1ull << k; j = k; qmin = qmax = q;
-            } else { qmin = nmin; qmax = nmax; }
+        for (int kd = (s0 + 1) & ~3; kd < e; kd += 4) {         /* four bytes per LDS read */
+            const uint32_t d4 = *(const uint32_t *)(byt + kd);
+            #pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int k = kd + u;
+                if (k > s0 && k < e) {
+                    const int q = (int)((d4 >> (8 * u)) & 255u);
+                    const int nmin = q < qmin ? q : qmin, nmax = q > qmax ? q : qmax;
+                    if (nmax - nmin > level2) {                  /* snp:817-826 */
+                        int mid = (qmin + qmax) >> 1;
+                        mid = mid > qcap ? qcap : mid;
+                        row[j] = (uint8_t)mid; isdirty |= (qmin != qmax) | (mid != qmin);
+                        newruns |= 1ull << k; j = k; qmin = qmax = q;
+                    } else { qmin = nmin; qmax = nmax; }
+                }
+            }
         }
         if (nx || nn < 64) {                                    /* ends inside the word: at a stop, or with the data */
             int mid = (qmin + qmax) >> 1;
@@ -2867,12 +2882,6 @@ k_pb_words(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_off
     }
     if (newruns) runs[w] = newruns;
     if (isdirty) dirty[w] = 1;
-    {   /* the row: PB_KEEP but for the runs written above (only bytes at run starts are ever read back) */
-        const uint4 *rsrc = (const uint4 *)row;
-        uint4 *dst = (uint4 *)(runval + g0);
-        #pragma unroll
-        for (int t = 0; t < 4; t++) dst[t] = rsrc[t];
-    }
 #undef PBW_BITS4
 #undef PBW_ZERO
 }
