@@ -76,7 +76,7 @@ struct crumble_hip {
     bool col_perm = false;          /* k_columns<.., PERM>: picked per batch in crumble_hip_upload */
     /* crumble_hip_set_option(): kernel choices that never change a result (tests force every variant) */
     int opt_kcol = 0;               /* 0 auto (k_columns2 where it applies), 1 k_columns, 2 k_columns PERM, 3 k_columns2 */
-    int opt_pblock = 0;             /* 0 auto (= 3), 1 one lane per read, 2 segment-parallel, 3 word-parallel (k_pb_words / k_pb_chains) */
+    int opt_pblock = 0;             /* 0 auto, 1 one lane per read, 2 segment-parallel (round 2), 3 word-parallel (k_pb_words / k_pb_chains) */
     int opt_replay = 0;             /* 0 auto, 1 k_replay_flat */
     int b_kcol = 0, b_pblock = 0;   /* the batch's snapshot of opt_kcol / opt_pblock (options take effect at an upload) */
     int64_t n_reads = 0, n_bases = 0, n_cigar = 0, n_slow = 0, n_segrec = 0, n_general_max = 0;
@@ -604,10 +604,12 @@ static int launch_pblock(crumble_hip *h, hipStream_t st, int64_t n_reads, int64_
 {
     if (nb <= 0 || n_reads <= 0) return CRUMBLE_OK;
     const DParams *P = h->d_params.as<DParams>();
-    /* word-parallel (kernels.h, k_pb_words / k_pb_chains) unless option "pblock" = reads | segments asks for one of the
-     * two earlier decompositions (tuning / tests: all three must give the same bytes) */
-    const bool per_read = mode == 1;
-    const bool words = mode == 0 || mode == 3;
+    /* short reads: one lane per read keeps the lanes of a wave evenly loaded (k_pb_chunkmm / k_pb_reads; measured on the
+     * 300x panel 0.78 ms against 1.3 for the word-parallel kernels, chr20 -9 equal); long reads: word-parallel
+     * (kernels.h, k_pb_words / k_pb_chains; HiFi 0.3 x config 4: 3.7 ms against 5.8 for k_pb_segments, 13.6 per read).
+     * Option "pblock" = reads | segments | words overrides the choice (tuning / tests: all give the same bytes). */
+    const bool per_read = mode ? mode == 1 : nb < 1024 * n_reads;
+    const bool words = mode ? mode == 3 : !per_read;
     const int64_t nwords = (nb + 63) / 64;
     int e;
     if (per_read && h->hparams.any_preserve) {          /* -k/-K: the byte-wise kernel knows the skip rule */

@@ -154,7 +154,7 @@ void         crumble_hip_destroy(crumble_hip *h);
 
 /* Implementation choices that never change a result; the parity tests force every variant through this.
  *   "kcol"   = auto | v1 | v1perm | v2      column kernel (k_columns, its per-column-class form, k_columns2)
- *   "pblock" = auto | reads | segments      P-block decomposition
+ *   "pblock" = auto | reads | segments | words   P-block decomposition
  *   "replay" = auto | flat                  per-base replay kernel
  *   "dl_chunk" = <bytes>                    size of one staged device -> host copy (256 .. 8 MiB; crumble_hip_download
  *                                           of >= 4 chunks goes through page-locked staging buffers on 8 streams)
