@@ -153,6 +153,8 @@ def measure_config(ca, synth, workload, scale, device, steps=3, warmup=1, verify
     t0 = time.time()
     hb = synth.generate(cfg, bed=bed)
     t_gen = time.time() - t0
+    if hasattr(ca, "lib"):
+        hb.pack4(ca.lib())
     params = ca.preset_params(d_preset, tech=d_tech)
     eng = ca.Engine(params, device)
     try:
@@ -213,6 +215,8 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=3)
         cfg.seed = 5000 + tid
         cfg.tid = tid
         batches.append(synth.generate(cfg))
+        if hasattr(ca, "lib"):
+            batches[-1].pack4(ca.lib())
     t_gen = time.time() - t0
     params = ca.preset_params(preset)
     engines = [ca.Engine(params, device) for _ in range(n_engines)]
@@ -377,6 +381,8 @@ def main():
         batches.append(synth.generate(cfg, bed=bed))
         scaling = "weak"
     t_gen = time.time() - t0
+    for b_ in batches:
+        b_.pack4(ca.lib())          # the bases cross PCIe as BAM packs them (crumble_batch.bases4), as crumble-hip sends them
     hb = batches[0]
     params = ca.preset_params(args.preset, tech=tech)
     opts = {} if args.kcol == "auto" else {"kcol": args.kcol}
@@ -490,6 +496,9 @@ def main():
     # ---- download of the TIMED engine's result (what the verification below looks at) ----
     t0 = time.perf_counter()
     tq, tf, _ = eng.download(want_stats=False)
+    t_down_first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    tq, tf, _ = eng.download(want_stats=False, out=(tq, tf))      # steady state: the caller's buffers are already mapped
     t_down = time.perf_counter() - t0
 
     # ---- roofline of the dominant kernel (HIP events on the engine's stream) ----
@@ -526,11 +535,13 @@ def main():
     p0_s, h2d_s = p0_ms * 1e-3, h2d_ms * 1e-3
     extra = {
         "p0_ms": round(p0_ms, 3), "h2d_ms": round(h2d_ms, 3), "d2h_ms": round(t_down * 1e3 * len(batches), 3),
+        "d2h_first_ms": round(t_down_first * 1e3 * len(batches), 3),
         "value_incl_p0": round(bases_local / (step_s + p0_s) / 1e9, 3),
         "value_incl_pcie": round(bases_local / (step_s + p0_s + h2d_s + t_down * len(batches)) / 1e9, 3),
         "note": "value = kernels only, batch resident in HBM; value_incl_p0 adds the per-contig device-side "
                 "expansion (second upload of the batch: steady state, no first-launch cost); value_incl_pcie also the "
-                "host->device copy (pageable numpy memory) and the download",
+                "host->device copy (pageable numpy memory, bases as BAM packs them: crumble_batch.bases4) and the download (second download into the same pageable buffers: a "
+                "first download into fresh memory also pays the page faults, d2h_first_ms)",
     }
 
     out = {

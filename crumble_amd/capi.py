@@ -51,6 +51,7 @@ class Batch(C.Structure):
         ("seq_off", C.c_void_p), ("cig_off", C.c_void_p), ("cigar", C.c_void_p),
         ("bases", C.c_void_p), ("quals", C.c_void_p),
         ("n_bed", C.c_int32), ("bed_start", C.c_void_p), ("bed_end", C.c_void_p),
+        ("bases4", C.c_void_p),
     ]
 
 
@@ -130,7 +131,20 @@ class HostBatch:
                      "quals", "bed_start", "bed_end"):
             setattr(b, name, self._ptr(getattr(self, name)))
         b.n_bed = len(self.bed_start)
+        b.bases4 = None
+        if getattr(self, "bases4", None) is not None:       # BAM-packed bases instead (crumble_batch.bases4)
+            b.bases4 = self.bases4.ctypes.data
+            b.bases = None
         return b
+
+    def pack4(self, lib):
+        """Attach the bases in BAM's packing (crumble_pack_bases4): struct() then hands the engine bases4 and no bases."""
+        out = np.zeros((self.n_bases >> 1) + self.n_reads + 1, np.uint8)
+        lib.crumble_pack_bases4.restype = None
+        lib.crumble_pack_bases4.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.crumble_pack_bases4(self.n_reads, self.seq_off.ctypes.data, self._ptr(self.bases), out.ctypes.data)
+        self.bases4 = out
+        return self
 
     @classmethod
     def from_reads(cls, reads, tid=0, bed=None):

@@ -153,6 +153,7 @@ struct crumble_bam_reader {
     int32_t tid;
     int32_t *pos; uint8_t *mapq; uint16_t *flag; int64_t *seq_off, *cig_off;
     uint32_t *cigar; uint8_t *bases, *quals;
+    int packed4;                    /* bases[] holds BAM's packing in the crumble_batch.bases4 layout (crumble_bam_set_packed_bases) */
     size_t cap_reads, cap_bases, cap_cig;
     /* record scan (runs beside the inflate team) */
     int have_tid, group_done, scan_err;
@@ -452,8 +453,10 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
     }
     const int64_t nb = r->acc_nb, nc = r->acc_nc;
     r->seq_off[n] = nb; r->cig_off[n] = nc;
-    if (r->cap_bases < (size_t)nb + 16) {
-        const size_t c = ((size_t)nb + (size_t)nb / 8 + ((size_t)2 << 20)) & ~(((size_t)2 << 20) - 1);
+    const size_t need4 = r->packed4 ? (size_t)CRUMBLE_BASES4_SIZE(nb, n) : 0;
+    if (r->cap_bases < (size_t)nb + 16 || r->cap_bases < need4 + 16) {
+        const size_t want = (size_t)nb > need4 ? (size_t)nb : need4;
+        const size_t c = (want + want / 8 + ((size_t)2 << 20)) & ~(((size_t)2 << 20) - 1);
         big_free(r->bases, r->cap_bases); big_free(r->quals, r->cap_bases);
         r->bases = big_alloc(c); r->quals = big_alloc(c);
         if (!r->bases || !r->quals) { big_free(r->bases, c); big_free(r->quals, c); r->bases = r->quals = NULL; }
@@ -485,9 +488,12 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
         if (lc) { if ((int64_t)nlong != r->cig_off[i + 1] - r->cig_off[i]) unsupported |= 1; else for (uint32_t k = 0; k < nlong; k++) co[k] = le32(lc + 4 * k); }
         else for (uint32_t k = 0; k < ncig; k++) co[k] = le32(cg + 4 * k);
         const uint8_t *sq = cg + 4 * (size_t)ncig;
-        uint8_t *bo = r->bases + r->seq_off[i];
-        for (int32_t k = 0; k + 1 < lseq; k += 2) { const uint8_t v = sq[k >> 1]; bo[k] = v >> 4; bo[k + 1] = v & 15; }
-        if (lseq & 1) bo[lseq - 1] = sq[lseq >> 1] >> 4;
+        if (r->packed4) memcpy(r->bases + CRUMBLE_BASES4_OFF(r->seq_off[i], i), sq, ((size_t)lseq + 1) / 2);   /* as they are */
+        else {
+            uint8_t *bo = r->bases + r->seq_off[i];
+            for (int32_t k = 0; k + 1 < lseq; k += 2) { const uint8_t v = sq[k >> 1]; bo[k] = v >> 4; bo[k + 1] = v & 15; }
+            if (lseq & 1) bo[lseq - 1] = sq[lseq >> 1] >> 4;
+        }
         const uint8_t *ql = sq + ((size_t)lseq + 1) / 2;
         uint8_t *qo = r->quals + r->seq_off[i];
         if (lseq > 0 && ql[0] == 0xff) memset(qo, 0, (size_t)lseq);     /* absent qualities */
@@ -499,9 +505,14 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
     b->tid = r->tid; b->n_reads = n;
     b->pos = r->pos; b->mapq = r->mapq; b->flag = r->flag;
     b->seq_off = r->seq_off; b->cig_off = r->cig_off; b->cigar = r->cigar;
-    b->bases = r->bases; b->quals = r->quals;
+    b->quals = r->quals;
+    if (r->packed4) b->bases4 = r->bases; else b->bases = r->bases;
     return 1;
 }
+
+/* The reader hands the bases on as BAM packs them (crumble_batch.bases4, bases == NULL): no nibble expansion on the
+ * host, half the bytes to the device.  Takes effect at the next crumble_bam_next_contig(). */
+void crumble_bam_set_packed_bases(crumble_bam_reader *r, int on) { if (r) r->packed4 = on ? 1 : 0; }
 
 /* A detached group: the reader-shaped shell that owns one contig's record bytes and SoA arrays, so that the
  * reader can go on to the next contig while this one is on a GPU or being written (crumble-hip --gpus N). */

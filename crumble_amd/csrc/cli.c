@@ -513,6 +513,8 @@ int main(int argc, char **argv)
     crumble_bam_reader *rd = crumble_bam_open(in_fn, threads, &err);
     if (!rd) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
     p.rd = rd;
+    /* the bases go to the device as BAM packs them (the window planner of -w slices one-code-per-byte arrays) */
+    if (!windowed) crumble_bam_set_packed_bases(rd, 1);
 
     int32_t *bt = NULL, *bs = NULL, *be = NULL; int nbed = 0;
     if (bed_fn && (nbed = crumble_bam_load_bed(rd, bed_fn, &bt, &bs, &be)) < 0) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }

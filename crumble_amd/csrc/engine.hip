@@ -61,7 +61,7 @@ struct crumble_hip {
     DParams hparams;
     DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc, d_mqslot;
     /* batch (inputs) */
-    DevBuf d_genlist, d_vrec, d_pbdirty, d_pbcarry, d_pbhmm, d_ufirst, d_tcum, d_tpart, d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
+    DevBuf d_genlist, d_vrec, d_pbdirty, d_pbcarry, d_pbhmm, d_bases4, d_ufirst, d_tcum, d_tpart, d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
            d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax;
     /* per position */
     DevBuf d_colrec, d_nplp, d_score, d_trigcnt, d_dpre, d_col_ord, d_trig_ord, d_item_off,
@@ -275,7 +275,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     DevBuf *all[] = { &h->d_genlist, &h->d_vrec, &h->d_params, &h->d_tables, &h->d_stats, &h->d_batch_stats, &h->d_misc, &h->d_mqslot,
-        &h->d_ufirst, &h->d_tcum, &h->d_tpart, &h->d_pbdirty, &h->d_pbcarry, &h->d_pbhmm, &h->d_pbwmm, &h->d_act, &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
+        &h->d_ufirst, &h->d_tcum, &h->d_tpart, &h->d_pbdirty, &h->d_pbcarry, &h->d_pbhmm, &h->d_bases4, &h->d_pbwmm, &h->d_act, &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
         &h->d_slow_g, &h->d_slow_r, &h->d_cix, &h->d_sr, &h->d_stile_lo, &h->d_stile_hi, &h->d_rr, &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
         &h->d_cigar, &h->d_segs, &h->d_bases, &h->d_quals, &h->d_tile_lo, &h->d_tile_hi,
         &h->d_bed_start, &h->d_bed_end, &h->d_bed_pmax, &h->d_colrec, &h->d_nplp, &h->d_score,
@@ -376,8 +376,14 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     /* 1. raw arrays */
     if ((e = up(h, h->d_pos, b->pos, n)) || (e = up(h, h->d_mapq, b->mapq, n)) || (e = up(h, h->d_flag, b->flag, n)) ||
         (e = up(h, h->d_seq_off, b->seq_off, n + 1)) || (e = up(h, h->d_cig_off, b->cig_off, n + 1)) ||
-        (e = up(h, h->d_cigar, b->cigar, nc)) || (e = up_padded(h, h->d_bases, b->bases, nb)) || (e = up_padded(h, h->d_quals, b->quals, nb)))
+        (e = up(h, h->d_cigar, b->cigar, nc)) || (e = up_padded(h, h->d_quals, b->quals, nb)))
         return e;
+    const bool packed4 = b->bases4 != nullptr;      /* BAM-packed bases: half the bytes over PCIe, unpacked by k_p0_unpack4 */
+    if (!packed4 && !b->bases && nb > 0) { g_last_error = "crumble_batch: neither bases nor bases4"; return CRUMBLE_EINVAL; }
+    if (packed4) {
+        if ((e = up(h, h->d_bases4, b->bases4, (size_t)CRUMBLE_BASES4_SIZE(nb, n))) || (e = h->d_bases.reserve((size_t)nb + 2 * BASE_FRONT_PAD + 64))) return e;
+        HIPCHK(hipMemsetAsync(h->d_bases.p, 0, BASE_FRONT_PAD, st));
+    } else if ((e = up_padded(h, h->d_bases, b->bases, nb))) return e;
     if (n == 0) {                                   /* seq_off[0] may not exist on the host side */
         const int64_t z = 0;
         if ((e = up(h, h->d_seq_off, &z, 1)) || (e = up(h, h->d_cig_off, &z, 1))) return e;
@@ -408,8 +414,11 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
                              h->d_flag.as<uint16_t>(), h->d_seq_off.as<int64_t>(), h->d_cig_off.as<int64_t>(),
                              h->d_cigar.as<uint32_t>(), h->d_inplp.as<uint8_t>(), h->d_end.as<int32_t>(), cnt, d_err, d_minmax, nb, nc);
         CRUMBLE_LAUNCH_INDEP(k_p0_sorted, nblk(n, 256), 256, st, n, h->d_pos.as<int32_t>(), h->d_inplp.as<uint8_t>(), d_err);
+        if (nb > 0 && packed4)
+            CRUMBLE_LAUNCH(k_p0_unpack4, (unsigned)(n < 4 * 8192 ? (n + 3) / 4 : 8192), 256, st, n, h->d_seq_off.as<int64_t>(),
+                           h->d_bases4.as<uint8_t>(), h->d_bases.as<uint8_t>() + BASE_FRONT_PAD);
         if (nb > 0) CRUMBLE_LAUNCH_INDEP(k_p0_basequal, nblk((nb + 15) / 16, 256), 256, st, nb, h->d_bases.as<uint8_t>() + BASE_FRONT_PAD,
-                                         h->d_quals.as<uint8_t>() + BASE_FRONT_PAD, d_err);
+                                         h->d_quals.as<uint8_t>() + BASE_FRONT_PAD, d_err, packed4 ? 0 : 1);
         CRUMBLE_LAUNCH_INDEP(k_p0scan_reduce, nblk(nchunks, 64), 64, st, n, cnt, part, nchunks);
         CRUMBLE_LAUNCH(k_p0scan_partials, 1, 1024, st, part, nchunks);
         CRUMBLE_LAUNCH_INDEP(k_p0scan_apply, nblk(nchunks, 64), 64, st, n, cnt, part, nchunks);

@@ -151,7 +151,8 @@ __device__ __forceinline__ uint32_t p0_class4(uint32_t w)
     const uint32_t cls = (idx & ~bad) | (0x05050505u & bad);
     return c | (cls << 4);
 }
-__global__ void k_p0_basequal(int64_t nb, uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals, int *err)
+/* (do_bases == 0: the base bytes already carry their class, k_p0_unpack4 wrote them) */
+__global__ void k_p0_basequal(int64_t nb, uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals, int *err, int do_bases)
 {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
     if (i >= nb) return;
@@ -159,16 +160,40 @@ __global__ void k_p0_basequal(int64_t nb, uint8_t *__restrict__ bases, const uin
     if (i + 16 <= nb) {
         const uint4 v = *(const uint4 *)(quals + i);
         bad = ((v.x | v.y | v.z | v.w) & 0x80808080u) != 0;
-        uint4 b = *(const uint4 *)(bases + i);
-        b.x = p0_class4(b.x); b.y = p0_class4(b.y); b.z = p0_class4(b.z); b.w = p0_class4(b.w);
-        *(uint4 *)(bases + i) = b;
+        if (do_bases) {
+            uint4 b = *(const uint4 *)(bases + i);
+            b.x = p0_class4(b.x); b.y = p0_class4(b.y); b.z = p0_class4(b.z); b.w = p0_class4(b.w);
+            *(uint4 *)(bases + i) = b;
+        }
     } else {
         for (int64_t k = i; k < nb; k++) {
             bad = bad || (quals[k] & 0x80);
-            bases[k] = (uint8_t)(p0_class4(bases[k]) & 0xffu);
+            if (do_bases) bases[k] = (uint8_t)(p0_class4(bases[k]) & 0xffu);
         }
     }
     if (bad) atomicMax(err, P0_ERR_QUAL);
+}
+
+/* crumble_batch.bases4 (BAM's two codes per byte, read i from byte (seq_off[i] >> 1) + i) -> one byte per base with the
+ * consensus class in its high nibble, i.e. what k_p0_basequal leaves.  A wave per read, a lane per four bases (two
+ * packed bytes in, one dword out). */
+__global__ void __launch_bounds__(256)
+k_p0_unpack4(int64_t n, const int64_t *__restrict__ seq_off, const uint8_t *__restrict__ b4, uint8_t *__restrict__ bases)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n; r += nwaves) {
+        const int64_t so = seq_off[r], lq = seq_off[r + 1] - so;
+        const uint8_t *src = b4 + (so >> 1) + r;
+        uint8_t *dst = bases + so;
+        for (int64_t k = 4 * (int64_t)lane; k < lq; k += 256) {
+            const uint32_t p0 = src[k >> 1], p1 = k + 2 < lq ? src[(k >> 1) + 1] : 0u;
+            const uint32_t codes = (p0 >> 4) | ((p0 & 15u) << 8) | ((p1 >> 4) << 16) | ((p1 & 15u) << 24);
+            const uint32_t v = p0_class4(codes);
+            if (k + 4 <= lq) { dst[k] = (uint8_t)v; dst[k + 1] = (uint8_t)(v >> 8); dst[k + 2] = (uint8_t)(v >> 16); dst[k + 3] = (uint8_t)(v >> 24); }
+            else for (int64_t t = k; t < lq; t++) dst[t] = (uint8_t)(v >> (8 * (t - k)));
+        }
+    }
 }
 
 /* chunked exclusive scan of P0Cnt over reads; totals -> partial[nchunks] */

@@ -162,3 +162,17 @@ const char *crumble_hip_strerror(int err)
     default:                return "unknown error";
     }
 }
+
+/* one nt16 code per byte -> BAM's packing in the crumble_batch.bases4 layout (include/crumble_hip.h) */
+void crumble_pack_bases4(int64_t n_reads, const int64_t *seq_off, const uint8_t *bases, uint8_t *out)
+{
+    #pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n_reads; i++) {
+        const uint8_t *b = bases + seq_off[i];
+        const int64_t lq = seq_off[i + 1] - seq_off[i];
+        uint8_t *o = out + CRUMBLE_BASES4_OFF(seq_off[i], i);
+        int64_t k = 0;
+        for (; k + 1 < lq; k += 2) *o++ = (uint8_t)((b[k] & 15) << 4 | (b[k + 1] & 15));
+        if (k < lq) *o = (uint8_t)((b[k] & 15) << 4);
+    }
+}

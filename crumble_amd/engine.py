@@ -202,10 +202,12 @@ class Engine:
     def run_finish(self):
         self._chk(self.L.crumble_hip_run_finish(self.h), "run_finish")
 
-    def download(self, want_flags=True, want_stats=True):
+    def download(self, want_flags=True, want_stats=True, out=None):
+        """out: (qualities, flags) arrays of an earlier download to write into again (a caller that reuses its buffers,
+        as crumble-hip's pool does, pays no first-touch page faults)."""
         hb = self._batch
-        q = np.empty(max(hb.n_bases, 1), np.uint8)
-        f = np.zeros(max(hb.n_reads, 1), np.uint8) if want_flags else None
+        q = out[0] if out is not None else np.empty(max(hb.n_bases, 1), np.uint8)
+        f = (out[1] if out is not None and out[1] is not None else np.zeros(max(hb.n_reads, 1), np.uint8)) if want_flags else None
         s = np.zeros(ST_N, np.int64) if want_stats else None
         self._chk(self.L.crumble_hip_download(self.h, _vp(q), _vp(f), _vp(s)), "download")
         return q[:hb.n_bases], (f[:hb.n_reads] if f is not None else None), s

@@ -47,6 +47,10 @@ const char *crumble_bam_header_text(const crumble_bam_reader *r, int64_t *len);
  * Missing qualities (0xff, SAMv1 4.2.3) are presented as 0 and written back untouched.
  * Returns 1 when a group was produced, 0 at end of file, < 0 on error. */
 int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b);
+/* on != 0: batches carry the bases as BAM packs them (crumble_batch.bases4; bases == NULL) -- no nibble expansion on
+ * the host and half the host -> device bytes (sam_read1's bam_get_seq layout handed on as it is).  From the next
+ * crumble_bam_next_contig() on. */
+void crumble_bam_set_packed_bases(crumble_bam_reader *r, int on);
 
 /* Takes the group that crumble_bam_next_contig() just returned out of the reader: its record bytes and the arrays
  * behind the crumble_batch now belong to the returned object (the batch's pointers stay valid until

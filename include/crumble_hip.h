@@ -112,7 +112,17 @@ typedef struct crumble_batch {
     int32_t  n_bed;           /* keep-regions of THIS contig, after             */
     const int32_t *bed_start; /* crumble_bed_collapse() (bed.c:20-40)           */
     const int32_t *bed_end;
+    /* Optional, INSTEAD of bases (then bases == NULL): the bases as BAM stores them (bam_get_seq: two nt16 codes per
+     * byte, the earlier base in the high nibble, every read starting on a byte).  Read i occupies the
+     * (l_qseq(i) + 1) / 2 bytes from CRUMBLE_BASES4_OFF(seq_off[i], i); the array is CRUMBLE_BASES4_SIZE(n_bases,
+     * n_reads) bytes.  Half the host -> device bytes of the one-code-per-byte form and no expansion pass on the host:
+     * the device unpacks while it rewrites the base bytes anyway (k_p0_unpack4). */
+    const uint8_t  *bases4;
 } crumble_batch;
+#define CRUMBLE_BASES4_OFF(seq_off_i, i)      (((int64_t)(seq_off_i) >> 1) + (int64_t)(i))
+#define CRUMBLE_BASES4_SIZE(n_bases, n_reads) (((int64_t)(n_bases) >> 1) + (int64_t)(n_reads) + 1)
+/* bases (one code per byte) -> the bases4 layout above; out has CRUMBLE_BASES4_SIZE bytes.  Host helper (OpenMP). */
+void crumble_pack_bases4(int64_t n_reads, const int64_t *seq_off, const uint8_t *bases, uint8_t *out);
 
 /* per-read output flags */
 #define CRUMBLE_RF_KEEP     1   /* bam_sorted_item.keep_qual was set (snp:1847) */

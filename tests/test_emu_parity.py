@@ -148,6 +148,25 @@ def test_emu_rerun_and_engine_reuse(product):
     eng.close()
 
 
+def test_emu_packed_bases(product):
+    """crumble_batch.bases4 (BAM's two codes per byte, unpacked on the device by k_p0_unpack4) gives what the
+    one-code-per-byte form gives: short and long reads, odd lengths, tiny and empty reads, the unmapped tail."""
+    import copy
+    p = ca.preset_params(9)
+    L = emu_lib.load()
+    tiny = HostBatch.from_reads([dict(pos=10, cigar="1M", seq="A", qual=[30]), dict(pos=10, cigar="*", seq="", qual=[]),
+                                 dict(pos=11, cigar="3M", seq="ACG", qual=[30, 31, 2]), dict(pos=12, cigar="2M1I2M", seq="NACGT", qual=20),
+                                 dict(pos=12, cigar="7M", seq="ACGTACG", qual=33)])
+    for hb in (synth_batch("chr20", 0.0002), synth_batch("hifi", 0.0001, read_len=3001), synth_batch("ce", 0.2), tiny):
+        e = emu_lib.engine(p)
+        want = e.contig(hb)
+        hb4 = copy.copy(hb).pack4(L)
+        assert hb4.struct().bases is None and hb4.struct().bases4
+        got = e.contig(hb4)
+        e.close()
+        assert all(np.array_equal(x, y) for x, y in zip(got, want))
+
+
 def test_emu_staged_download(product):
     """crumble_hip_download through the page-locked staging lanes (8 host threads, double-buffered chunks): with the
     chunk shrunk so that this batch is hundreds of chunks -- whole chunks, a ragged last one, more lanes than chunks --

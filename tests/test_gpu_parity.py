@@ -172,6 +172,20 @@ def test_large_properties(product):
     eng.close()
 
 
+def test_packed_bases(product):
+    """crumble_batch.bases4 (BAM's packing, unpacked by k_p0_unpack4) == the one-code-per-byte form == the oracle."""
+    import copy
+    import oracle_lib as O
+    p = ca.preset_params(9)
+    for hb in (synth_batch("chr20", 0.01), synth_batch("hifi", 0.002), synth_batch("panel", 0.005), synth_batch("ce", 0.3)):
+        want = O.contig(p, hb)
+        eng = gpu_engine(p)
+        hb4 = copy.copy(hb).pack4(eng.L)
+        got = eng.contig(hb4)
+        eng.close()
+        assert all(np.array_equal(x, y) for x, y in zip(got, want))
+
+
 def test_staged_download(product):
     """crumble_hip_download of a batch large enough for the page-locked staging lanes (8 streams, double-buffered
     8 MiB chunks; include/crumble_hip.h "dl_chunk"): equal to the oracle, and to itself with other chunk sizes."""
