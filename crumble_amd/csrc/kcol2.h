@@ -741,6 +741,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
         continue;
 #endif
         const bool in_win = !WIN || (c >= B.col_lo && c < B.col_hi);
+        const int bed_lo = B.n_bed ? bed_tile(B, c0, lane) : 0;     /* keep-regions: one search per tile, not one per column */
 #if KC2_FASTFIN
         {   /* the common tile: in every column that reaches the consensus the ten genotypes without the key base are out
              * of reach (cons_fast_ok, kernels.h) -- the result comes from the five key genotypes in place, no un-permute
@@ -755,7 +756,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                 if (inr) {
                     if (in_win)
                         col_decide<MQ ? 1 : 0, true>(st, B, P, T, c, apos, true, colrec, nplp_out, score_out, trigcnt,
-                                                     sStat, sE, WIN ? c < B.stat_hi : true, &co);
+                                                     sStat, sE, WIN ? c < B.stat_hi : true, &co, bed_lo);
                     else { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; }
                 }
                 KC2_STAMP(4);
@@ -772,7 +773,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
         if (inr) {
             if (in_win)
                 col_decide<MQ ? 1 : 0>(st, B, P, T, c, apos, true, colrec, nplp_out, score_out, trigcnt,
-                                       sStat, KC2_LDS_EXP ? sE : (const double *)nullptr, WIN ? c < B.stat_hi : true);
+                                       sStat, KC2_LDS_EXP ? sE : (const double *)nullptr, WIN ? c < B.stat_hi : true, nullptr, bed_lo);
             else { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; }
         }
         KC2_STAMP(4);

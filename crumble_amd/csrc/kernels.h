@@ -170,6 +170,33 @@ __device__ __forceinline__ int bed_preserve(const DBatch &B, int apos)
     if (lo < B.n_bed && B.bed_start[lo] <= apos && B.bed_end[lo] > apos) return 2;
     return 0;
 }
+/* The same for the 64 columns of a tile at once (k_columns2): the per-column search is ~13 dependent loads with
+ * thousands of regions, and nearly every tile lies between two regions.  bed_tile() returns the first region whose
+ * prefix-max of `end` reaches the tile's first column c0 -- every column's own cursor position is at or behind it --
+ * found by the wave's lanes probing 64 keys per round (three rounds for 5000 regions); bed_preserve_from() walks on
+ * from there for one column.  Called by every lane of the wave. */
+__device__ __forceinline__ int bed_tile(const DBatch &B, int c0, int lane)
+{
+    int lo = 0, hi = B.n_bed;                              /* the answer is in [lo, hi]: keys before lo are < c0, key hi is not */
+    while (hi > lo) {
+        const int len = hi - lo, step = (len + 63) >> 6;   /* probes at lo, lo + step, ...: at most 64 of them */
+        const int idx = lo + lane * step;
+        const bool below = idx < hi && B.bed_pmax[idx] < c0;
+        const int nb = __popcll(__ballot(below));          /* the keys do not decrease: the probes below c0 are a prefix */
+        const int nprobes = (len + step - 1) / step;
+        const int nhi = nb < nprobes ? lo + nb * step : hi;
+        lo = nb > 0 ? lo + (nb - 1) * step + 1 : lo;
+        hi = nhi;
+        if (step == 1) { lo = hi; break; }                 /* every key in between was probed */
+    }
+    return lo;
+}
+__device__ __forceinline__ int bed_preserve_from(const DBatch &B, int apos, int lo)
+{
+    while (lo < B.n_bed && B.bed_pmax[lo] < apos) lo++;
+    if (lo < B.n_bed && B.bed_start[lo] <= apos && B.bed_end[lo] > apos) return 2;
+    return 0;
+}
 
 /* ------------------------------------------------------------------------ */
 struct ConsOut { int call, het_call, het_phred, phred; float discrep;
@@ -412,13 +439,14 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
                                            const DTables *__restrict__ T, int c, int apos, bool use_cons,
                                            uint32_t *__restrict__ colrec, int32_t *__restrict__ nplp_out,
                                            int32_t *__restrict__ score_out, int32_t *__restrict__ trigcnt, unsigned *stats,
-                                           const double *sE = nullptr, const bool cnt = true, const ConsOut *pre = nullptr)
-{
+                                           const double *sE = nullptr, const bool cnt = true, const ConsOut *pre = nullptr,
+                                           const int bed_lo = -1)
+{   /* bed_lo >= 0: bed_tile()'s answer for the column's tile */
     const int n_plp = st.n_plp;
     if (n_plp == 0) { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; return; }
 
     uint32_t rec = CR_EXISTS;
-    int preserve = bed_preserve(B, apos);              /* snp:1443-1463 */
+    int preserve = bed_lo >= 0 ? bed_preserve_from(B, apos, bed_lo) : bed_preserve(B, apos);   /* snp:1443-1463 */
     int perfect = 1, score = 0, tcnt = 0;
     nplp_out[c] = n_plp;
     if (st.nref == n_plp) {                            /* snp:1466-1472 */

@@ -2,8 +2,16 @@ import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
 import numpy as np, crumble_amd as ca
 import synth
-hb = synth.generate(synth.config(sys.argv[1] if len(sys.argv) > 1 else "chr20", scale=float(sys.argv[2]) if len(sys.argv) > 2 else 1.0))
-e = ca.Engine(ca.preset_params(int(sys.argv[3]) if len(sys.argv) > 3 else 5), 0)
+wl = sys.argv[1] if len(sys.argv) > 1 else "chr20"
+cfg = synth.config(wl, scale=float(sys.argv[2]) if len(sys.argv) > 2 else 1.0)
+lvl = sys.argv[3] if len(sys.argv) > 3 else "5"
+if lvl == "pbccs":          # config 4: -y pbccs -R keep.bed
+    import bench
+    hb = synth.generate(cfg, bed=bench.keep_bed(cfg.contig_len, int(5000 * cfg.contig_len / 248956422 + 0.5)))
+    e = ca.Engine(ca.preset_params(None, tech="pbccs"), 0)
+else:
+    hb = synth.generate(cfg)
+    e = ca.Engine(ca.preset_params(int(lvl)), 0)
 e.upload(hb); e.run(); e.stats_reset(); e.run()
 s = e.stats_read()
 kt = dict((n, ms) for n, ms, _ in e.kernel_times())
