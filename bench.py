@@ -318,7 +318,8 @@ def main():
     ap.add_argument("--kcol", default="auto", help="crumble_hip_set_option kcol (auto|v1|v1perm|v2)")
     ap.add_argument("--pblock", default="auto", help="crumble_hip_set_option pblock (auto|reads|segments|words)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the `other_configs` object (BASELINE configs "
-                    "3, 4 and 5 measured after the headline config; default line, one GPU only)")
+                    "3, 4 and 5 measured after the headline config; default line, one GPU only; --no-cpu skips it too: its "
+                    "legs check themselves against the CPU oracle)")
     ap.add_argument("--wgs-stream-scale", type=float, default=0.05, help="other_configs.wgs_streamed: contig length scale")
     ap.add_argument("--e2e", action="store_true",
                     help="also time metric (ii): BAM file -> crumble-hip -> BAM file (SURVEY.md 8d), reported "
@@ -635,7 +636,7 @@ def main():
                 }
         if args.e2e:
             out["end_to_end"] = file_to_file(hb, args, local_rank)
-        if world == 1 and args.workload == "chr20" and args.scale == 1.0 and not args.no_other_configs:
+        if world == 1 and args.workload == "chr20" and args.scale == 1.0 and not args.no_other_configs and not args.no_cpu:
             # the other single-GPU configurations of BASELINE.json, measured by the same run (never part of `value`)
             for e_ in engines:
                 e_.close()

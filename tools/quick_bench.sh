@@ -8,7 +8,7 @@ for cfg in ${QB_CONFIGS:-chr20 panel hifi}; do
     panel) args="--workload panel --preset 9";;
     hifi)  args="--workload hifi --scale 0.1 --preset 9";;
   esac
-  python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-verify $args 2>/dev/null | python3 -c "
+  python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-verify --no-other-configs $args 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$args', d['value'], d['ms_per_step'], d['roofline']['kernels_ms'])"
 done
