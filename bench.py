@@ -28,6 +28,30 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def kernel_source_sha():
+    """sha256 (16 hex digits) of the kernel sources: a profiles/*_pmc_traffic.json is used for `roofline.traffic` only
+    when it was measured on exactly these kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "crumble_amd", "csrc")
+    for f in ("dev_common.h", "kernels.h", "kcol2.h", "p0_kernels.h", "engine.hip"):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def find_pmc_json():
+    """the newest profiles/*_pmc_traffic.json measured on the current kernel sources, or None"""
+    import glob
+    sha = kernel_source_sha()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            if json.load(open(f)).get("source_sha16") == sha:
+                return f
+        except Exception:            # noqa: BLE001
+            pass
+    return None
+
+
 def prefix_batch(hb, n_reads):
     """First n_reads reads of a HostBatch (same data, bounded CPU-baseline sample)."""
     from crumble_amd import HostBatch
@@ -314,7 +338,8 @@ def main():
     ap.add_argument("--contig-threads", type=int, default=4, help="wgs: host threads that run the contigs' engines "
                     "(one HIP stream each) side by side on the GPU; 1 = one contig at a time")
     ap.add_argument("--pmc-json", default=None, help="profiles/*_pmc_traffic.json measured for THIS build and "
-                    "workload: fills roofline.traffic (null otherwise)")
+                    "workload: fills roofline.traffic (default: the newest one in profiles/ whose source_sha16 equals the "
+                    "current kernel sources' -- null when there is none)")
     ap.add_argument("--kcol", default="auto", help="crumble_hip_set_option kcol (auto|v1|v1perm|v2)")
     ap.add_argument("--pblock", default="auto", help="crumble_hip_set_option pblock (auto|reads|segments|words)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the `other_configs` object (BASELINE configs "
@@ -514,14 +539,16 @@ def main():
     # HBM traffic of that kernel from rocprofv3 PMC counters (FETCH_SIZE + WRITE_SIZE, separate passes): only when a
     # summary measured for THIS build and workload is named on the command line; never a stale constant
     traffic, traffic_src = None, None
-    if args.pmc_json:
+    pmc_json = args.pmc_json or (find_pmc_json() if args.workload == "chr20" and args.scale == 1.0 else None)
+    if pmc_json:
         try:
-            kk = json.load(open(args.pmc_json))["kernels"]
+            kk = json.load(open(pmc_json))["kernels"]
             key = [k for k in kk if k.split("<")[0] == dom[0]]
             if key:
                 t = kk[key[0]]
-                traffic = round((t["FETCH_SIZE_KB_per_launch"] + t["WRITE_SIZE_KB_per_launch"]) * 1024)
-                traffic_src = os.path.basename(args.pmc_json)
+                # bytes moved: FETCH_SIZE counts a 128-byte request as 64 (calibrated: tools/fetch_calib.*), WRITE_SIZE is exact
+                traffic = round((2.0 * t["FETCH_SIZE_KB_per_launch"] + t["WRITE_SIZE_KB_per_launch"]) * 1024)
+                traffic_src = os.path.basename(pmc_json) + " (2 x FETCH_SIZE + WRITE_SIZE, per launch)"
         except Exception:
             traffic = None
     roofline = {

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: everything profiles/<tag>_* is made of -- the default bench line, rocprofv3 kernel stats of the
+# four single-GPU configurations, FETCH_SIZE / WRITE_SIZE of the chr20 step with the calibration kernels, SQ counters of
+# k_columns2 (separate --pmc passes, no trace domains).  Usage: tools/profile_all.sh <tag>; then, in the build
+# container, python tools/summarize_profiles.py <tag>.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+tag=${1:-rXX}
+out=$R/gpurun_out
+bash $R/tools/profile_round.sh $tag > /dev/null 2>&1
+cd /tmp && export TMPDIR=/tmp
+for cfg in "chr20_9 --workload chr20 --preset 9" "panel --workload panel" "hifi_config4 --workload hifi"; do
+  set -- $cfg; name=$1; shift
+  python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-verify "$@" > $out/${tag}_bench_$name.json 2>/dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof_$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-verify "$@" > /dev/null 2>&1
+done
+# SQ counters of the column kernel (chr20 -5)
+n=0
+pass() { n=$((n+1)); rocprofv3 --pmc "$@" --output-format csv -d $out/${tag}_sq_$n -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu --no-verify > /dev/null 2>&1; }
+pass SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES
+pass SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAVES
+pass SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM
+tail -c 600 $out/${tag}_bench.json

@@ -8,6 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
+bash $R/tools/fetch_calib.sh $tag > /dev/null 2>&1
 python3 $R/bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu > $out/${tag}_prof.log 2>&1
 # PMC passes on their own (no trace domains), one counter per pass

@@ -6,6 +6,8 @@ import collections, csv, glob, json, os, re, shutil, sys
 
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+from bench import kernel_source_sha          # the kernels these counters were measured on (bench.py looks for a match)
 go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 
 
@@ -31,8 +33,38 @@ for key, sub, ctr in (("FETCH_SIZE_KB_per_launch", "pmc_fetch", "FETCH_SIZE"), (
         res[k][key] = tot[k] / n[k]
         res[k]["launches"] = n[k]
 if res:
+    calib = None
+    cf = os.path.join(go, f"{tag}_fetch_calib.json")
+    if os.path.exists(cf):
+        calib = json.load(open(cf))
+        shutil.copy(cf, os.path.join(pr, f"{tag}_fetch_calib.json"))
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), chr20 30x full scale, raw counter "
-               "values in KB per launch; MI355X_MICROARCH.md: FETCH_SIZE under-reports wide (16 B/lane) streaming "
-               "reads by 2x, other widths uncalibrated", "kernels": res},
+               "values in KB per launch.  FETCH_SIZE = TCC_EA0_RDREQ x 64 B tallies a 128-byte request as 64 "
+               "(MI355X_MICROARCH.md); tools/fetch_calib.* measured counter / bytes = 0.50 for 16-B streams and for "
+               "32-byte records, 0.70 for the column kernel's 20-byte segment loads (which re-touch half of every line "
+               "one tile later): bytes moved = 2 x FETCH_SIZE; WRITE_SIZE is exact",
+               "source_sha16": kernel_source_sha(), "fetch_calibration": calib["kernels"] if calib else None, "kernels": res},
               open(os.path.join(pr, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+# the other configurations: bench line + rocprofv3 kernel stats each
+for name in ("chr20_9", "panel", "hifi_config4"):
+    bj = os.path.join(go, f"{tag}_bench_{name}.json")
+    if os.path.exists(bj):
+        ls = [l for l in open(bj) if l.startswith("{")]
+        if ls:
+            open(os.path.join(pr, f"{tag}_bench_{name}.json"), "w").write(ls[-1])
+    ks2 = glob.glob(os.path.join(go, f"{tag}_prof_{name}", "*", "*_kernel_stats.csv"))
+    if ks2:
+        shutil.copy(ks2[0], os.path.join(pr, f"{tag}_kernel_stats_{name}.csv"))
+# SQ counters of the column kernel, per launch
+sq = collections.defaultdict(lambda: [0.0, 0])
+for f in glob.glob(os.path.join(go, f"{tag}_sq_*", "*", "*_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        if short(r["Kernel_Name"]).startswith("k_columns2"):
+            a = sq[r["Counter_Name"]]
+            a[0] += float(r["Counter_Value"]); a[1] += 1
+if sq:
+    json.dump({"k_columns2": {k: round(v[0] / v[1]) for k, v in sorted(sq.items())},
+               "note": "rocprofv3 --pmc, chr20 30x -5, per launch (wave-level instruction counts; *_CYCLES summed over SEs)",
+               "source_sha16": kernel_source_sha()},
+              open(os.path.join(pr, f"{tag}_sq_counters.json"), "w"), indent=1)
 print(line.strip()[:400])
