@@ -61,7 +61,7 @@ def write_batches(path, refs, batches, level=1, threads=0):
     L = lib()
     names = (C.c_char_p * len(refs))(*[n.encode() for n, _ in refs])
     lens = (C.c_int64 * len(refs))(*[int(l) for _, l in refs])
-    arr = (Batch * max(1, len(batches)))(*[b.struct() for b in batches])
+    arr = (Batch * max(1, len(batches)))(*[b.struct(packed=False) for b in batches])
     rc = L.crumble_bam_write_batches(os.fsencode(path), len(refs), names, lens, len(batches), arr, level, threads)
     if rc:
         raise _err(rc)

@@ -123,7 +123,9 @@ class HostBatch:
     def _ptr(self, a):
         return a.ctypes.data if a.size else self._pad.ctypes.data
 
-    def struct(self):
+    def struct(self, packed=True):
+        """crumble_batch over these arrays; packed=False always hands over the one-code-per-byte bases (the oracle and the
+        BAM writer read them), packed=True the BAM-packed ones when pack4() attached them."""
         b = Batch()
         b.tid = self.tid
         b.n_reads = self.n_reads
@@ -132,7 +134,7 @@ class HostBatch:
             setattr(b, name, self._ptr(getattr(self, name)))
         b.n_bed = len(self.bed_start)
         b.bases4 = None
-        if getattr(self, "bases4", None) is not None:       # BAM-packed bases instead (crumble_batch.bases4)
+        if packed and getattr(self, "bases4", None) is not None:       # BAM-packed bases instead (crumble_batch.bases4)
             b.bases4 = self.bases4.ctypes.data
             b.bases = None
         return b

@@ -63,7 +63,7 @@ def load():
 def contig(params, hb: HostBatch, trace=False):
     """crumble_oracle_contig -> (quals, flags, stats[, columns])."""
     L = load()
-    b = hb.struct()
+    b = hb.struct(packed=False)
     q = np.empty(max(hb.n_bases, 1), np.uint8)
     f = np.zeros(max(hb.n_reads, 1), np.uint8)
     s = np.zeros(ST_N, np.int64)
@@ -156,17 +156,17 @@ def have_ref():
 
 
 def ref2query_pos(hb, r, pos):
-    b = hb.struct()
+    b = hb.struct(packed=False)
     return load().crumble_oracle_ref2query_pos(C.byref(b), r, pos)
 
 
 def qpos2rpos(hb, r, qpos):
-    b = hb.struct()
+    b = hb.struct(packed=False)
     return load().crumble_oracle_qpos2rpos(C.byref(b), r, qpos)
 
 
 def mask_lc(params, hb, r, is_indel, rpos, min_pos=2**31 - 1, max_pos=0):
-    b = hb.struct()
+    b = hb.struct(packed=False)
     lo, hi = C.c_int(min_pos), C.c_int(max_pos)
     load().crumble_oracle_mask_lc(C.byref(params), C.byref(b), r, int(is_indel), rpos,
                                   C.byref(lo), C.byref(hi))
@@ -180,7 +180,7 @@ def adjust_lut():
 
 
 def pileup(hb, maxn=1 << 20):
-    b = hb.struct()
+    b = hb.struct(packed=False)
     cp = np.zeros(maxn, np.int32); rd = np.zeros(maxn, np.int64)
     qp = np.zeros(maxn, np.int32); ind = np.zeros(maxn, np.int32)
     bits = np.zeros(maxn, np.uint8)
@@ -193,7 +193,7 @@ def pileup(hb, maxn=1 << 20):
 
 
 def indel_only(hb, dist=20, q=37):
-    b = hb.struct()
+    b = hb.struct(packed=False)
     out = np.empty(max(hb.n_bases, 1), np.uint8)
     rc = load().crumble_oracle_indel_only(C.byref(b), dist, q, out.ctypes.data)
     assert rc == 0
