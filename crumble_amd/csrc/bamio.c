@@ -965,7 +965,47 @@ static struct {
     int   (*sam_write1)(void *fp, const void *h, const hts_bam1_t *b);
     hts_bam1_t *(*bam_init1)(void);
     void  (*bam_destroy1)(hts_bam1_t *b);
+    void *(*sam_hdr_parse)(size_t l_text, const char *text);
+    int   (*sam_parse1)(void *kstr, void *h, hts_bam1_t *b);
 } H;
+
+/* The structs above are a private copy of htslib's bam1_core_t / bam1_t.  Before anything is trusted, a record made BY
+ * THE LIBRARY (one SAM line through sam_parse1) is read through the copy: every field this file uses and the layout of
+ * the data block (qname, CIGAR words, packed bases, qualities, aux) must come out as written.  A libhts whose bam1_t
+ * differs is refused (CRUMBLE_BAM_ENOHTS) instead of corrupting records silently. */
+static int hts_layout_check(void)
+{
+    static const char hdr_text[] = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chrT\tLN:100000\n";
+    char line[] = "rd1\t99\tchrT\t1001\t37\t2S5M1I2M\t=\t1201\t210\tACGTNACGTA\t!+5?IIII#~\tNM:i:3\tXS:Z:ab";
+    struct { size_t l, m; char *s; } ks = { sizeof line - 1, sizeof line, line };      /* kstring_t */
+    void *hdr = H.sam_hdr_parse(sizeof hdr_text - 1, hdr_text);
+    hts_bam1_t *b = H.bam_init1();
+    int ok = hdr && b && H.sam_parse1(&ks, hdr, b) >= 0;
+    if (ok) {
+        const hts_core_t *c = &b->core;
+        ok = c->pos == 1000 && c->tid == 0 && c->qual == 37 && c->flag == 99 && c->n_cigar == 4 && c->l_qseq == 10 &&
+             c->mtid == 0 && c->mpos == 1200 && c->isize == 210 && c->l_qname >= 4 && c->l_qname % 4 == 0 &&
+             c->l_extranul == c->l_qname - 4;
+        const size_t fixed = (size_t)c->l_qname + 16 + 5 + 10;                  /* qname, 4 CIGAR words, 5 base bytes, 10 qualities; then the aux fields */
+        ok = ok && b->data && b->l_data >= (int)fixed + 4 + 6 && b->l_data <= (int)fixed + 32 && b->m_data >= (uint32_t)b->l_data;
+        if (ok) {
+            const uint8_t *d = b->data;
+            ok = !memcmp(d, "rd1", 4);
+            const uint8_t *cg = d + c->l_qname;
+            ok = ok && le32(cg) == (2u << 4 | 4u) && le32(cg + 4) == (5u << 4 | 0u) && le32(cg + 8) == (1u << 4 | 1u) && le32(cg + 12) == (2u << 4 | 0u);
+            const uint8_t *sq = cg + 16;                                          /* A C G T N A C G T A -> 1 2 4 8 15 1 2 4 8 1 */
+            ok = ok && sq[0] == 0x12 && sq[1] == 0x48 && sq[2] == 0xf1 && sq[3] == 0x24 && sq[4] == 0x81;
+            const uint8_t *ql = sq + 5;
+            ok = ok && ql[0] == 0 && ql[1] == 10 && ql[2] == 20 && ql[3] == 30 && ql[4] == 40 && ql[8] == 2 && ql[9] == 93;
+            const uint8_t *ax = ql + 10;
+            ok = ok && ax[0] == 'N' && ax[1] == 'M' && !memcmp(d + b->l_data - 6, "XSZab", 6);     /* (NM's integer width is the library's choice) */
+        }
+    }
+    if (b) H.bam_destroy1(b);
+    if (hdr) H.sam_hdr_destroy(hdr);
+    return ok ? 0 : fail(CRUMBLE_BAM_ENOHTS, "this libhts lays bam1_t out differently from the libhts.so.3 ABI this build knows (a record "
+                                             "parsed by the library does not read back through it): refusing to use it");
+}
 
 static int hts_load(void)
 {
@@ -978,12 +1018,13 @@ static int hts_load(void)
     HSYM(hts_version); HSYM(hts_parse_format); HSYM(hts_open_format); HSYM(sam_open_mode); HSYM(hts_close);
     HSYM(hts_set_threads); HSYM(sam_hdr_read); HSYM(sam_hdr_write); HSYM(sam_hdr_destroy); HSYM(sam_hdr_nref);
     HSYM(sam_hdr_tid2name); HSYM(sam_hdr_tid2len); HSYM(sam_hdr_add_pg); HSYM(sam_read1); HSYM(sam_write1);
-    HSYM(bam_init1); HSYM(bam_destroy1);
+    HSYM(bam_init1); HSYM(bam_destroy1); HSYM(sam_hdr_parse); HSYM(sam_parse1);
 #undef HSYM
     const char *v = H.hts_version();
     int maj = 0, min = 0;
     if (!v || sscanf(v, "%d.%d", &maj, &min) < 2 || maj != 1 || min < 10)
         return fail(CRUMBLE_BAM_ENOHTS, "htslib %s: need 1.10 or later (64-bit positions in bam1_core_t)", v ? v : "?");
+    if (hts_layout_check()) return CRUMBLE_BAM_ENOHTS;
     H.ok = 1;
     return 0;
 }
