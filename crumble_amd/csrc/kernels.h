@@ -2327,7 +2327,11 @@ k_restore(DBatch B, const DParams *__restrict__ P, int n_trig, const int32_t *tr
                 resolve_entry(B, r, apos, e);
                 const int64_t so = B.seq_off[r];
                 const int lq = (int)(B.seq_off[r + 1] - so);
-                if (lq && e.qpos < lq) {                       /* snp:1861 / fence */
+                /* the same deferral for a read with several ops: the chain's next trigger column also reports a base of
+                 * this read (its entry's qpos' >= this one's, its min_pos2' <= this one's): its range contains this one */
+                bool later = false;
+                if (lq && nxt_apos < rr.end) { Entry e2; resolve_entry(B, r, nxt_apos, e2); later = e2.qpos < lq; }
+                if (lq && e.qpos < lq && !later) {             /* snp:1861 / fence */
                     const int64_t sgo = B.seg_off[r];
                     start = dev_ref2query_seg(B.segs + sgo, (int)(B.seg_off[r + 1] - sgo), rp, mn2, lq);
                     stop = e.qpos;
