@@ -13,10 +13,13 @@ bad, t0 = 0, time.time()
 for seed in range(s0, s0 + n):
     p, hb, desc = random_case(seed, max_bases=300_000)
     kcol = ("v1", "v1perm", "v2", "v2", "auto")[seed % 5]       # every column kernel, whatever the batch
+    opts = {"kcol": kcol, "pblock": ("auto", "reads", "segments", "words")[(seed // 5) % 4]}   # ... and every P-block decomposition
+    if seed % 2:
+        hb.pack4(ca.lib())                                      # the bases as BAM packs them (crumble_batch.bases4)
     try:
-        assert_parity(lambda q: ca.Engine(q, 0, options={"kcol": kcol}), p, hb)
+        assert_parity(lambda q: ca.Engine(q, 0, options=opts), p, hb)
         if seed % 10 == 0:
-            assert_parity(lambda q: ca.Engine(q, 0, options={"kcol": kcol}), p, tiny_reads_batch(seed, n=2000), check_columns=False)
+            assert_parity(lambda q: ca.Engine(q, 0, options=opts), p, tiny_reads_batch(seed, n=2000), check_columns=False)
         if seed % 3 == 0 and hb.n_reads >= 8 and hb.tid >= 0:          # the same contig cut into windows
             import numpy as np
             import oracle_lib as O
