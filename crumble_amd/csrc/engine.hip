@@ -414,9 +414,6 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
                              h->d_flag.as<uint16_t>(), h->d_seq_off.as<int64_t>(), h->d_cig_off.as<int64_t>(),
                              h->d_cigar.as<uint32_t>(), h->d_inplp.as<uint8_t>(), h->d_end.as<int32_t>(), cnt, d_err, d_minmax, nb, nc);
         CRUMBLE_LAUNCH_INDEP(k_p0_sorted, nblk(n, 256), 256, st, n, h->d_pos.as<int32_t>(), h->d_inplp.as<uint8_t>(), d_err);
-        if (nb > 0 && packed4)
-            CRUMBLE_LAUNCH(k_p0_unpack4, (unsigned)(n < 4 * 8192 ? (n + 3) / 4 : 8192), 256, st, n, h->d_seq_off.as<int64_t>(),
-                           h->d_bases4.as<uint8_t>(), h->d_bases.as<uint8_t>() + BASE_FRONT_PAD);
         if (nb > 0) CRUMBLE_LAUNCH_INDEP(k_p0_basequal, nblk((nb + 15) / 16, 256), 256, st, nb, h->d_bases.as<uint8_t>() + BASE_FRONT_PAD,
                                          h->d_quals.as<uint8_t>() + BASE_FRONT_PAD, d_err, packed4 ? 0 : 1);
         CRUMBLE_LAUNCH_INDEP(k_p0scan_reduce, nblk(nchunks, 64), 64, st, n, cnt, part, nchunks);
@@ -556,6 +553,9 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
                     CRUMBLE_LAUNCH_INDEP(k_p0_chunkread, nblk(nch, 256), 256, st, nch, n, h->d_seq_off.as<int64_t>(),
                                          h->d_blk_read.as<int32_t>(), h->d_chunk_read.as<int32_t>());
             }
+            if (packed4)                                        /* the bases as BAM packs them -> one classed byte per base */
+                CRUMBLE_LAUNCH_INDEP(k_p0_unpack4, nblk(nch, 256), 256, st, nb, n, h->d_seq_off.as<int64_t>(), h->d_blk_read.as<int32_t>(),
+                                     h->d_bases4.as<uint8_t>(), h->d_bases.as<uint8_t>() + BASE_FRONT_PAD);
             h->have_vrec = false;
             if (vrec_path) {
                 /* long reads: one territory per reference-consuming op (+ one per read) and the chunk -> territory

@@ -174,27 +174,61 @@ __global__ void k_p0_basequal(int64_t nb, uint8_t *__restrict__ bases, const uin
     if (bad) atomicMax(err, P0_ERR_QUAL);
 }
 
-/* crumble_batch.bases4 (BAM's two codes per byte, read i from byte (seq_off[i] >> 1) + i) -> one byte per base with the
- * consensus class in its high nibble, i.e. what k_p0_basequal leaves.  A wave per read, a lane per four bases (two
- * packed bytes in, one dword out). */
+/* crumble_batch.bases4 (BAM's two codes per byte, the earlier base in the high nibble; read i from byte
+ * (seq_off[i] >> 1) + i) -> one byte per base with the consensus class in its high nibble, i.e. what k_p0_basequal
+ * leaves.  One lane per 16 output bytes (its owner read from blk_read[], so every lane is independent and the store is
+ * one aligned 16-byte vector): 8 or 9 packed bytes in (three dword loads that need no alignment), the nibbles
+ * interleaved by shifts; a chunk that straddles reads goes byte by byte. */
+typedef uint32_t __attribute__((aligned(1))) p0_u32u;
+#define P0_ILV_LO(X, Y) (((X) & 0xffu) | (((Y) & 0xffu) << 8) | (((X) & 0xff00u) << 8) | (((Y) & 0xff00u) << 16))      /* x0 y0 x1 y1 */
+#define P0_ILV_HI(X, Y) ((((X) >> 16) & 0xffu) | ((((Y) >> 16) & 0xffu) << 8) | ((((X) >> 16) & 0xff00u) << 8) | ((((Y) >> 16) & 0xff00u) << 16))   /* x2 y2 x3 y3 */
 __global__ void __launch_bounds__(256)
-k_p0_unpack4(int64_t n, const int64_t *__restrict__ seq_off, const uint8_t *__restrict__ b4, uint8_t *__restrict__ bases)
+k_p0_unpack4(int64_t nb, int64_t n, const int64_t *__restrict__ seq_off, const int32_t *__restrict__ blk_read,
+             const uint8_t *__restrict__ b4, uint8_t *__restrict__ bases)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t r = wave; r < n; r += nwaves) {
-        const int64_t so = seq_off[r], lq = seq_off[r + 1] - so;
-        const uint8_t *src = b4 + (so >> 1) + r;
-        uint8_t *dst = bases + so;
-        for (int64_t k = 4 * (int64_t)lane; k < lq; k += 256) {
-            const uint32_t p0 = src[k >> 1], p1 = k + 2 < lq ? src[(k >> 1) + 1] : 0u;
-            const uint32_t codes = (p0 >> 4) | ((p0 & 15u) << 8) | ((p1 >> 4) << 16) | ((p1 & 15u) << 24);
-            const uint32_t v = p0_class4(codes);
-            if (k + 4 <= lq) { dst[k] = (uint8_t)v; dst[k + 1] = (uint8_t)(v >> 8); dst[k + 2] = (uint8_t)(v >> 16); dst[k + 3] = (uint8_t)(v >> 24); }
-            else for (int64_t t = k; t < lq; t++) dst[t] = (uint8_t)(v >> (8 * (t - k)));
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (g >= nb) return;
+    int64_t r = blk_read[g >> 6];
+    while (r + 1 < n && seq_off[r + 1] <= g) r++;
+    /* the chunk's bytes belong to one read, or -- at a read boundary -- to two or more: the sixteen bytes are made as if
+     * the whole chunk lay in the read at hand (x may be negative: the bytes before the read are masked away) and merged */
+    const int64_t gend = g + 16 < nb ? g + 16 : nb;
+    uint32_t ow[4] = {0, 0, 0, 0};
+    for (;; r++) {
+        const int64_t so = seq_off[r], e = seq_off[r + 1];
+        const int lo = so > g ? (int)(so - g) : 0, hi = e < gend ? (int)(e - g) : (int)(gend - g);
+        if (lo < hi) {
+            const int64_t x = g - so;                             /* (>> 1 floors, & 1 is the parity, also when negative) */
+            const int64_t sb = (so >> 1) + r + (x >> 1);
+            uint32_t d0, d1, d2;
+            if (sb >= 0) { const uint8_t *src = b4 + sb; d0 = *(const p0_u32u *)src; d1 = *(const p0_u32u *)(src + 4); d2 = *(const p0_u32u *)(src + 8); }
+            else {                                                /* the very first read of the batch, chunk bytes before it */
+                uint32_t t3[3] = {0, 0, 0};
+                for (int k = 0; k < 12; k++) if (sb + k >= 0) t3[k >> 2] |= (uint32_t)b4[sb + k] << (8 * (k & 3));
+                d0 = t3[0]; d1 = t3[1]; d2 = t3[2];
+            }
+            const uint32_t h0 = (d0 >> 4) & 0x0f0f0f0fu, l0 = d0 & 0x0f0f0f0fu, h1 = (d1 >> 4) & 0x0f0f0f0fu, l1 = d1 & 0x0f0f0f0fu;
+            uint32_t xa, ya, xb, yb;                              /* output byte 2j = xa/xb[j], 2j + 1 = ya/yb[j] */
+            if (!(x & 1)) { xa = h0; ya = l0; xb = h1; yb = l1; }
+            else {                                                /* base 2j is the low nibble of byte j, base 2j + 1 the high one of byte j + 1 */
+                const uint32_t h2 = (d2 >> 4) & 0x0f0f0f0fu;
+                xa = l0; ya = (h0 >> 8) | (h1 << 24); xb = l1; yb = (h1 >> 8) | (h2 << 24);
+            }
+            const uint32_t v[4] = {p0_class4(P0_ILV_LO(xa, ya)), p0_class4(P0_ILV_HI(xa, ya)), p0_class4(P0_ILV_LO(xb, yb)), p0_class4(P0_ILV_HI(xb, yb))};
+            const unsigned vb = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+            #pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint32_t M = ((((vb >> (4 * t)) & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;
+                ow[t] = (v[t] & M) | (ow[t] & ~M);
+            }
         }
+        if (e >= gend || r + 1 >= n) break;
     }
+    if (gend - g == 16) { uint4 o; o.x = ow[0]; o.y = ow[1]; o.z = ow[2]; o.w = ow[3]; *(uint4 *)(bases + g) = o; }
+    else for (int64_t t = g; t < gend; t++) bases[t] = (uint8_t)(ow[(t - g) >> 2] >> (8 * ((t - g) & 3)));
 }
+#undef P0_ILV_LO
+#undef P0_ILV_HI
 
 /* chunked exclusive scan of P0Cnt over reads; totals -> partial[nchunks] */
 #define P0_CHUNK 1024
