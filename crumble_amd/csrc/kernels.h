@@ -937,9 +937,17 @@ k_scan_reduce(int L, const uint32_t *colrec, const int32_t *nplp,
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int base = blockIdx.x * SCAN_CHUNK;
     ScanVal acc = {0, 0, 0, 0, 0, 0, 0}, v;
-    for (int k = 0; k < SCAN_CHUNK / 256; k++) {
-        const int i = base + k * 256 + (int)threadIdx.x;
-        if (i < L) { scanval_of(colrec[i], nplp[i], trigcnt[i], v); scanval_add(acc, v); }
+    for (int k = 0; k < SCAN_CHUNK / 1024; k++) {                /* four consecutive columns per thread: 16-byte loads */
+        const int i = base + k * 1024 + 4 * (int)threadIdx.x;
+        if (i + 3 < L) {
+            const uint4 r4 = *(const uint4 *)(colrec + i);
+            const int4 n4 = *(const int4 *)(nplp + i), t4 = *(const int4 *)(trigcnt + i);
+            scanval_of(r4.x, n4.x, t4.x, v); scanval_add(acc, v);
+            scanval_of(r4.y, n4.y, t4.y, v); scanval_add(acc, v);
+            scanval_of(r4.z, n4.z, t4.z, v); scanval_add(acc, v);
+            scanval_of(r4.w, n4.w, t4.w, v); scanval_add(acc, v);
+        } else
+            for (int u = 0; u < 4; u++) if (i + u < L) { scanval_of(colrec[i + u], nplp[i + u], trigcnt[i + u], v); scanval_add(acc, v); }
     }
     acc = scanval_wave_incl(acc, lane);
     if (lane == 63) ws[w] = acc;
@@ -1228,27 +1236,41 @@ k_scan_overdepth(int L, uint32_t *colrec, const int32_t *nplp, const int32_t *tr
     const int nep = *n_ep;
     const double od = P->over_depth;
     ScanVal carry = partial[blockIdx.x];
-    for (int k = 0; k < SCAN_CHUNK / 256; k++) {
-        const int i = base + k * 256 + (int)threadIdx.x;
-        ScanVal v = {0, 0, 0, 0, 0, 0, 0};
-        uint32_t rec = 0;
-        int n = 0;
-        if (i < L) { rec = colrec[i]; n = nplp[i]; scanval_of(rec, n, trigcnt[i], v); }
-        ScanVal inc = scanval_wave_incl01(v, lane);
+    for (int k = 0; k < SCAN_CHUNK / 1024; k++) {
+        /* four consecutive columns per thread (16-byte loads, one wave scan and two barriers per 1024 columns) */
+        const int i0 = base + k * 1024 + 4 * (int)threadIdx.x;
+        uint32_t rec[4] = {0, 0, 0, 0};
+        int n[4] = {0, 0, 0, 0}, tcv[4] = {0, 0, 0, 0};
+        if (i0 + 3 < L) {
+            const uint4 r4 = *(const uint4 *)(colrec + i0);
+            const int4 n4 = *(const int4 *)(nplp + i0), t4 = *(const int4 *)(trigcnt + i0);
+            rec[0] = r4.x; rec[1] = r4.y; rec[2] = r4.z; rec[3] = r4.w;
+            n[0] = n4.x; n[1] = n4.y; n[2] = n4.z; n[3] = n4.w;
+            tcv[0] = t4.x; tcv[1] = t4.y; tcv[2] = t4.z; tcv[3] = t4.w;
+        } else
+            for (int u = 0; u < 4; u++) if (i0 + u < L) { rec[u] = colrec[i0 + u]; n[u] = nplp[i0 + u]; tcv[u] = trigcnt[i0 + u]; }
+        ScanVal v[4], tot = {0, 0, 0, 0, 0, 0, 0};
+        #pragma unroll
+        for (int u = 0; u < 4; u++) { scanval_of(rec[u], n[u], tcv[u], v[u]); if (i0 + u >= L) { const ScanVal z = {0, 0, 0, 0, 0, 0, 0}; v[u] = z; } scanval_add(tot, v[u]); }
+        const ScanVal inc = scanval_wave_incl(tot, lane);
         __syncthreads();                               /* ws reuse */
         if (lane == 63) ws[w] = inc;
         __syncthreads();
         ScanVal run = carry;
         for (int j = 0; j < w; j++) scanval_add(run, ws[j]);
-        if (i < L && (rec & CR_COUNTED) && !(rec & CR_TOODEEP)) {
-            const int64_t ord = run.cols + inc.cols - v.cols, dp = run.depth + inc.depth - v.depth;
-            overdepth_test(i, rec, ord, n, dp, colrec, ep, nep, od, stats, stat_hi);
-            /* the lists are indexed by the exclusive prefixes k_scan_apply would have stored */
-            if (rec & CR_TRIG) {
-                const int t = (int)(run.trigcols + inc.trigcols - v.trigcols);
-                trigcol_pos[t] = i; trigcol_off[t] = (int)(run.items + inc.items - v.items);
+        /* exclusive prefix of the thread's first column: the waves before, the lanes before */
+        run.depth += inc.depth - tot.depth; run.cols += inc.cols - tot.cols; run.trigcols += inc.trigcols - tot.trigcols;
+        run.items += inc.items - tot.items; run.ins += inc.ins - tot.ins;
+        #pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u;
+            if (i < L && (rec[u] & CR_COUNTED) && !(rec[u] & CR_TOODEEP)) {
+                overdepth_test(i, rec[u], run.cols, n[u], run.depth, colrec, ep, nep, od, stats, stat_hi);
+                /* the lists are indexed by the exclusive prefixes k_scan_apply would have stored */
+                if (rec[u] & CR_TRIG) { const int t = (int)run.trigcols; trigcol_pos[t] = i; trigcol_off[t] = (int)run.items; }
+                if (rec[u] & CR_HASINS) inscol_pos[(int)run.ins] = i;
             }
-            if (rec & CR_HASINS) inscol_pos[(int)(run.ins + inc.ins - v.ins)] = i;
+            scanval_add(run, v[u]);
         }
         for (int j = 0; j < (int)(blockDim.x >> 6); j++) scanval_add(carry, ws[j]);
     }
