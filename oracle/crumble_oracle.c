@@ -11,6 +11,10 @@
  * Pinning (see DESIGN.md "Oracle"):
  *   - find_STR/add_rep are checked against the REAL reference str_finder.c,
  *     compiled unmodified into oracle/_ref/ (it needs no external header).
+ *   - the whole transcode() path end to end -- trigger, mask_LC_regions, the STR window and its growth, back-fill,
+ *     qhigh / qlow, and pblock -- against the reference's own published input -> output pair: the mpileup before and
+ *     after `crumble -9p8 -l5 -u40 -i1.0,2` of the man page (crumble.1 EXAMPLES), all 355 printed cells
+ *     (tests/golden/crumble1_example.json, tests/test_manpage_example.py).
  *   - calculate_consensus_pileup, pblock, ref2query_pos, bam_qpos2rpos and
  *     mask_LC_regions are checked against the known answers that the survey
  *     obtained from the compiled reference and against
