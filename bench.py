@@ -481,30 +481,39 @@ def main():
     bases_local = sum(b_.n_bases for b_ in batches)
     stats_via = "none (one rank)"
     if dist is not None:
+        done = False
         if red_dev == "cuda" and len(engines) == 1:
             # the product's own collective: crumble_hip_stats_allreduce (RCCL, in place on the engine's device
-            # vector) over a communicator built from an id that rank 0 hands round
+            # vector) over a communicator built from an id that rank 0 hands round.  Should the communicator fail to
+            # come up on some box, the same sum goes through torch.distributed (RCCL as well) instead of losing the run.
             import ctypes as C
-
-            class UniqueId(C.Structure):
-                _fields_ = [("internal", C.c_char * 128)]
-            rccl = C.CDLL("librccl.so")
-            uid = UniqueId()
-            if rank == 0:
-                assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
-            box = [bytes(uid.internal) if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            C.memmove(C.byref(uid), box[0], 128)
-            comm = C.c_void_p()
-            rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-            assert rccl.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0
-            rc = eng.L.crumble_hip_stats_allreduce(eng.h, comm)
-            assert rc == 0, eng.L.crumble_hip_last_error()
-            stats = eng.stats_read()
-            rccl.ncclCommDestroy.argtypes = [C.c_void_p]
-            rccl.ncclCommDestroy(comm)
-            stats_via = "crumble_hip_stats_allreduce (RCCL)"
-        else:
+            ok = 1
+            try:
+                class UniqueId(C.Structure):
+                    _fields_ = [("internal", C.c_char * 128)]
+                rccl = C.CDLL("librccl.so")
+                uid = UniqueId()
+                if rank == 0:
+                    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+                box = [bytes(uid.internal) if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                C.memmove(C.byref(uid), box[0], 128)
+                comm = C.c_void_p()
+                rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+                ok = 1 if rccl.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0 else 0
+            except Exception:                       # noqa: BLE001
+                ok = 0
+            allok = torch.tensor([ok], dtype=torch.int32, device=red_dev)
+            dist.all_reduce(allok, op=dist.ReduceOp.MIN)            # every rank takes the same path
+            if int(allok.item()) == 1:
+                rc = eng.L.crumble_hip_stats_allreduce(eng.h, comm)
+                assert rc == 0, eng.L.crumble_hip_last_error()
+                stats = eng.stats_read()
+                rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+                rccl.ncclCommDestroy(comm)
+                stats_via = "crumble_hip_stats_allreduce (RCCL)"
+                done = True
+        if not done:
             st = torch.from_numpy(stats.copy()).to(red_dev)
             dist.all_reduce(st, op=dist.ReduceOp.SUM)
             stats = st.cpu().numpy()
