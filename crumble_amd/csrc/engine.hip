@@ -61,7 +61,7 @@ struct crumble_hip {
     DParams hparams;
     DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc, d_mqslot;
     /* batch (inputs) */
-    DevBuf d_genlist, d_vrec, d_pbdirty, d_pbcarry, d_pbhmm, d_bases4, d_ufirst, d_tcum, d_tpart, d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
+    DevBuf d_genlist, d_vrec, d_pbdirty, d_pbcarry, d_pbchg, d_bases4, d_ufirst, d_tcum, d_tpart, d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
            d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax;
     /* per position */
     DevBuf d_colrec, d_nplp, d_score, d_trigcnt, d_dpre, d_col_ord, d_trig_ord, d_item_off,
@@ -275,7 +275,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     DevBuf *all[] = { &h->d_genlist, &h->d_vrec, &h->d_params, &h->d_tables, &h->d_stats, &h->d_batch_stats, &h->d_misc, &h->d_mqslot,
-        &h->d_ufirst, &h->d_tcum, &h->d_tpart, &h->d_pbdirty, &h->d_pbcarry, &h->d_pbhmm, &h->d_bases4, &h->d_pbwmm, &h->d_act, &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
+        &h->d_ufirst, &h->d_tcum, &h->d_tpart, &h->d_pbdirty, &h->d_pbcarry, &h->d_pbchg, &h->d_bases4, &h->d_pbwmm, &h->d_act, &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
         &h->d_slow_g, &h->d_slow_r, &h->d_cix, &h->d_sr, &h->d_stile_lo, &h->d_stile_hi, &h->d_rr, &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
         &h->d_cigar, &h->d_segs, &h->d_bases, &h->d_quals, &h->d_tile_lo, &h->d_tile_hi,
         &h->d_bed_start, &h->d_bed_end, &h->d_bed_pmax, &h->d_colrec, &h->d_nplp, &h->d_score,
@@ -649,25 +649,25 @@ static int launch_pblock(crumble_hip *h, hipStream_t st, int64_t n_reads, int64_
         return e;
     u64 *stop = h->d_pbstop.as<u64>(), *rs = h->d_pbrs.as<u64>(), *runs = h->d_pbruns.as<u64>();
     uint8_t *val = h->d_pbval.as<uint8_t>();
-    HIPCHK(hipMemsetAsync(h->d_pbdirty.p, 0, (size_t)nwords, st));
     if (words) {
-        /* read starts first: k_pb_marks folds them into the stops and knows every word's head */
-        if ((e = h->d_pbhmm.reserve((size_t)(nwords + 1) * 2))) return e;
+        /* read starts, then words (stop masks and every run inside a word), chains (runs that cross words), fill */
+        if ((e = h->d_pbcarry.reserve((size_t)(nwords + 1) * 8)) || (e = h->d_pbchg.reserve((size_t)(nwords + 1) * 8)) ||
+            (e = h->d_pbdirty.reserve((size_t)nwords * 4 + 64)))
+            return e;
+        u64 *carry = h->d_pbcarry.as<u64>(), *chg = h->d_pbchg.as<u64>();
+        uint16_t *mm = h->d_pbwmm.as<uint16_t>();
+        uint32_t *dirty = h->d_pbdirty.as<uint32_t>();
+        HIPCHK(hipMemsetAsync(dirty, 0, (size_t)nwords * 4, st));
         HIPCHK(hipMemsetAsync(rs, 0, (size_t)nwords * 8, st));
         CRUMBLE_LAUNCH_INDEP(k_pb_readstarts, nblk(n_reads, 256), 256, st, n_reads, seq_off, (u64 *)nullptr, rs);
-        CRUMBLE_LAUNCH_INDEP(k_pb_marks, nblk(nwords, 256), 256, st, nb, out, P, stop, rs, runs, h->d_pbwmm.as<uint16_t>(), h->d_pbhmm.as<uint16_t>());
-    } else {
-        CRUMBLE_LAUNCH_INDEP(k_pb_marks, nblk(nwords, 256), 256, st, nb, out, P, stop, rs, runs, h->d_pbwmm.as<uint16_t>(), (uint16_t *)nullptr);
-        CRUMBLE_LAUNCH_INDEP(k_pb_readstarts, nblk(n_reads, 256), 256, st, n_reads, seq_off, stop, rs);
-    }
-    if (words) {
-        if ((e = h->d_pbcarry.reserve((size_t)(nwords + 1) * 8))) return e;
-        u64 *carry = h->d_pbcarry.as<u64>();
-        CRUMBLE_LAUNCH_INDEP(k_pb_words, nblk(nwords, 256), 256, st, nb, n_reads, seq_off, out, rflags, blk_read, stop, rs, runs, val, carry, h->d_pbdirty.as<uint8_t>(), P);
-        CRUMBLE_LAUNCH_INDEP(k_pb_chains, nblk(nwords, 256), 256, st, nb, out, stop, rs, runs, val, carry, h->d_pbwmm.as<uint16_t>(), h->d_pbhmm.as<uint16_t>(), h->d_pbdirty.as<uint8_t>(), P);
-        CRUMBLE_LAUNCH_INDEP(k_pb_fill, nblk((nb + 15) / 16, 256), 256, st, nb, out, stop, runs, val, h->d_pbdirty.as<uint8_t>());
+        CRUMBLE_LAUNCH(k_pb_words, nblk(nwords, 256), 256, st, nb, n_reads, seq_off, out, rflags, blk_read, rs, stop, runs, chg, val, carry, mm, dirty, P);
+        CRUMBLE_LAUNCH_INDEP(k_pb_chains, nblk(nwords, 256), 256, st, nb, out, stop, rs, runs, chg, val, carry, mm, dirty, P);
+        CRUMBLE_LAUNCH(k_pb_fillw, nblk(nwords, 256), 256, st, nb, out, stop, runs, chg, val, dirty);
         return CRUMBLE_OK;
     }
+    HIPCHK(hipMemsetAsync(h->d_pbdirty.p, 0, (size_t)nwords, st));
+    CRUMBLE_LAUNCH_INDEP(k_pb_marks, nblk(nwords, 256), 256, st, nb, out, P, stop, rs, runs, h->d_pbwmm.as<uint16_t>());
+    CRUMBLE_LAUNCH_INDEP(k_pb_readstarts, nblk(n_reads, 256), 256, st, n_reads, seq_off, stop, rs);
     CRUMBLE_LAUNCH_INDEP(k_pb_segments, nblk(nwords, 256), 256, st, nb, n_reads, seq_off, out, rflags, blk_read, stop, rs, runs, val, h->d_pbwmm.as<uint16_t>(), h->d_pbdirty.as<uint8_t>(), P);
     CRUMBLE_LAUNCH_INDEP(k_pb_fill, nblk((nb + 15) / 16, 256), 256, st, nb, out, stop, runs, val, h->d_pbdirty.as<uint8_t>());
     return CRUMBLE_OK;

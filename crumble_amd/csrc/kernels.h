@@ -2566,11 +2566,8 @@ __global__ void k_pblock(int64_t n_reads, const int64_t *seq_off, uint8_t *out,
 
 __global__ void __launch_bounds__(256)
 k_pb_marks(int64_t n_bases, const uint8_t *__restrict__ q, const DParams *__restrict__ P,
-           u64 *__restrict__ stop, u64 *__restrict__ rstart, u64 *__restrict__ runs, uint16_t *__restrict__ wmm,
-           uint16_t *__restrict__ hmm = nullptr)
+           u64 *__restrict__ stop, u64 *__restrict__ rstart, u64 *__restrict__ runs, uint16_t *__restrict__ wmm)
 {
-    /* hmm != nullptr (word-parallel P-block): rstart[] already holds the read starts (k_pb_readstarts ran first); they
-     * are stops too, and the word's head -- the bytes before its first stop of either kind -- gets its (min, max) */
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t g0 = w * 64;
     if (g0 >= n_bases) return;
@@ -2585,10 +2582,7 @@ k_pb_marks(int64_t n_bases, const uint8_t *__restrict__ q, const DParams *__rest
     int prev = g0 > 0 ? (int)q[g0 - 1] : -1000;
     bool prev_pres = g0 > 0 && PB_IS_PRES(prev);
     u64 m = 0;
-    const u64 rsw = hmm ? rstart[w] : 0ull;
     int wmin = 255, wmax = 0;                            /* of the word's bytes: lets a long segment step 64 bases at once */
-    int hmin = 255, hmax = 0;                            /* of the bytes before the word's first stop (k_pb_chains: the tail of a
-                                                          * segment that began in an earlier word) */
     for (int k0 = 0; k0 < nn; k0 += 16) {
         uint32_t wd[4] = {0, 0, 0, 0};
         if (k0 + 16 <= nn) { const uint4 v = *(const uint4 *)(q + g0 + k0); wd[0] = v.x; wd[1] = v.y; wd[2] = v.z; wd[3] = v.w; }
@@ -2600,15 +2594,13 @@ k_pb_marks(int64_t n_bases, const uint8_t *__restrict__ q, const DParams *__rest
             int d = v - prev; d = d < 0 ? -d : d;
             if (k0 + k < nn && (pres || prev_pres || d > level2)) m |= 1ull << (k0 + k);
             if (k0 + k < nn) { wmin = v < wmin ? v : wmin; wmax = v > wmax ? v : wmax; }
-            if (k0 + k < nn && !((m | rsw) & ((2ull << (k0 + k)) - 1ull))) { hmin = v < hmin ? v : hmin; hmax = v > hmax ? v : hmax; }
             prev = v; prev_pres = pres;
         }
     }
 #undef PB_IS_PRES
-    stop[w] = m | rsw;
+    stop[w] = m;
     wmm[w] = (uint16_t)(wmin | (wmax << 8));
-    if (hmm) hmm[w] = (uint16_t)(hmin | (hmax << 8));   /* (no byte before a stop at bit 0: 255 | 0 -- joins any run) */
-    else rstart[w] = 0;
+    rstart[w] = 0;
     runs[w] = 0;
 }
 
@@ -2768,18 +2760,58 @@ k_pb_segments(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_
  * k_pb_segments gives a segment to the lane that owns its first byte and pays a loop trip per segment: a 64-byte word
  * with thirty one-base segments around preserved values is thirty trips for one lane while its wave waits, and a
  * 2000-byte run is thirty dependent loads for another.  Here
- *   k_pb_words    one lane per 64-byte word that holds a stop: ONE pass of the reference's state machine (snp:807-833)
- *                 over the word's bytes from its first stop on, in registers -- every segment and run that starts in the
- *                 word, up to the word's end.  Run starts go to the word's `runs` bits, run values to the word's 64-byte
- *                 row of `runval` (staged in LDS, written as one row).  A segment still open at the word's end, with no
- *                 stop at the next word's first byte, leaves its state in carry[w] (8 bytes).
- *   k_pb_chains   one lane per carried state: walks on word by word -- a word without a stop whose (min, max) keeps the
- *                 run inside 2 * level is one step (wmm[]) -- to the segment's end; bytes are looked at only in the word
- *                 where a run breaks and in the last, partial word.
- * Both record runs exactly as k_pb_segments does; k_pb_fill writes the bytes. */
-#define PBW_ROW 80              /* LDS bytes per lane's runval row (64 used; 16-byte aligned, off the 64-byte bank period) */
+ *   k_pb_words    a wave takes 64 words (4 KiB, loaded coalesced into LDS).  First the bit masks of every word -- stop,
+ *                 preserved, differs-from-its-predecessor, above qcap -- with the wave's lanes as the word's 64 BYTES:
+ *                 a compare per mask and word (the wave's condition mask IS the word's bit mask), handed to the lane
+ *                 that owns the word.  Then one lane per word: ONE pass of the reference's state machine (snp:807-833)
+ *                 over the word's bytes from its first stop on -- every segment and run that starts in the word, up to
+ *                 the word's end.  Run starts go to the word's `runs` bits; a run that changes a byte gets its value in
+ *                 runval[] and its bit in chgrun[].  A segment still open at the word's end, with no stop at the next
+ *                 word's first byte, leaves its state in carry[w] (8 bytes).  mm[w] = (min, max) of the word if it has
+ *                 no stop, else of its head (the bytes before its first stop): what k_pb_chains steps over.
+ *   k_pb_chains   one lane per carried state: walks on word by word -- a whole word or a head whose (min, max) keeps the
+ *                 run inside 2 * level is one step -- to the segment's end; bytes are looked at only where a run breaks.
+ *                 The next word's stop mask and (min, max) are in flight while this word is looked at.
+ *   k_pb_fillw    a wave per 64 words: the words some changing run touches (dirty[]) are gathered, four lanes each;
+ *                 every byte takes the value of the run that holds it.  dirty[w] also tells how far before the word
+ *                 the (changing) run that holds its first byte started: no walk back through the masks.
+ * The bytes are read once by k_pb_words and then only where something changes. */
+#define PBW_ROW 80              /* LDS bytes per word row (64 used; 16-byte aligned, off the 64-byte bank period) */
+#define PBW_TILE (64 * PBW_ROW)
 #define PBW_CARRY_VALID (1ull << 63)
 #define PBW_CARRY(jl, qmin, qmax, lmin, lmax) (PBW_CARRY_VALID | (u64)(jl) | ((u64)(qmin) << 8) | ((u64)(qmax) << 16) | ((u64)(lmin) << 24) | ((u64)(lmax) << 32))
+#define PB_DIRTY 0x80000000u    /* dirty[w]: a run that changes a byte touches word w; low 31 bits: how far before the word's
+                                 * first byte the changing run that holds it starts (0: it starts here, or changes nothing) */
+
+/* |a - b| of two byte values in one operation; a wave-uniform 32-bit value handed to lane I (v_writelane_b32) */
+#ifdef CRUMBLE_EMU
+#define PBW_ABSDIFF(a_, b_) ((a_) > (b_) ? (a_) - (b_) : (b_) - (a_))
+template <int I> __device__ __forceinline__ void pbw_put(uint32_t &dst, uint32_t val) { if ((int)(threadIdx.x & 63) == I) dst = val; }
+#else
+#define PBW_ABSDIFF(a_, b_) __builtin_amdgcn_sad_u8((a_), (b_), 0u)
+template <int I> __device__ __forceinline__ void pbw_put(uint32_t &dst, uint32_t val)
+{ asm("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(__builtin_amdgcn_readfirstlane(val)), "n"(I)); }
+#endif
+
+/* k_pb_words, lane = byte: the bit masks of the tile's words I, I + 1, ... 63 (see the kernel), each handed to the lane
+ * that owns the word.  m[] = stop, keep, chg, big as (low, high) halves. */
+template <int I, bool FULL> __device__ __forceinline__ void
+pbw_masks(const uint8_t *cur, const uint8_t *prv, const uint8_t *ptab, int64_t left, unsigned level2, unsigned qcap,
+          u64 lastpres, uint32_t (&m)[8])
+{
+    /* FULL: all 4096 bytes of the tile are data; else bytes from `left` on are not */
+    const unsigned v = cur[I * PBW_ROW], pv = prv[I * PBW_ROW];
+    const int64_t rem = left - I * 64;
+    const u64 okm = (FULL || rem >= 64) ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+    const u64 bk = __ballot(ptab[v] != 0) & okm;
+    const u64 bs = (__ballot(PBW_ABSDIFF(v, pv) > level2) & okm) | bk | (bk << 1) | lastpres;
+    const u64 bc = __ballot(v != pv), bb = __ballot(v > qcap);
+    pbw_put<I>(m[0], (uint32_t)bs); pbw_put<I>(m[1], (uint32_t)(bs >> 32));
+    pbw_put<I>(m[2], (uint32_t)bk); pbw_put<I>(m[3], (uint32_t)(bk >> 32));
+    pbw_put<I>(m[4], (uint32_t)bc); pbw_put<I>(m[5], (uint32_t)(bc >> 32));
+    pbw_put<I>(m[6], (uint32_t)bb); pbw_put<I>(m[7], (uint32_t)(bb >> 32));
+    if constexpr (I + 1 < 64) pbw_masks<I + 1, FULL>(cur, prv, ptab, left, level2, qcap, bk >> 63, m);
+}
 
 /* one byte q at word position k_ (global g0 + k_) without a stop, inside an open segment: snp:813-829 */
 #define PBW_STEP(q_, k_, ON_BREAK) do { \
@@ -2793,71 +2825,97 @@ k_pb_segments(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_
 
 __global__ void __launch_bounds__(256)
 k_pb_words(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_off, const uint8_t *__restrict__ out,
-           const uint8_t *__restrict__ rflags, const int32_t *__restrict__ blk_read,
-           const u64 *__restrict__ stop, const u64 *__restrict__ rstart, u64 *__restrict__ runs,
-           uint8_t *__restrict__ runval, u64 *__restrict__ carry, uint8_t *__restrict__ dirty,
-           const DParams *__restrict__ P)
+           const uint8_t *__restrict__ rflags, const int32_t *__restrict__ blk_read, const u64 *__restrict__ rstart,
+           u64 *__restrict__ stop, u64 *__restrict__ runs, u64 *__restrict__ chgrun, uint8_t *__restrict__ runval,
+           u64 *__restrict__ carry, uint16_t *__restrict__ mm, uint32_t *__restrict__ dirty, const DParams *__restrict__ P)
 {
-    /* per lane: the word's 64 bytes (a segment's walk indexes them at run time) */
-    __shared__ __attribute__((aligned(16))) uint8_t sbytes[256 * PBW_ROW];
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    /* per wave: 80 bytes ahead of the tile (the byte before it sits at tile[-17], where lane 0 of row 0 looks for its
+     * predecessor), the tile, and the preserved-quality table */
+    __shared__ __attribute__((aligned(16))) uint8_t sbytes[4 * (PBW_ROW + PBW_TILE + 256)];
+    const int lane = threadIdx.x & 63, wv = UNIFORM((int)(threadIdx.x >> 6));
+    uint8_t *const tile = sbytes + wv * (PBW_ROW + PBW_TILE + 256) + PBW_ROW;
+    uint8_t *const ptab = tile + PBW_TILE;
     const int64_t nwords = (n_bases + 63) >> 6;
-    if (w >= nwords) return;
-    const int64_t g0 = w * 64;
+    const int64_t w0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wv) * 64;
+    if (w0 >= nwords) return;                                   /* (the whole wave) */
+    const int64_t gbase = w0 * 64, w = w0 + lane, g0 = w * 64;
+    const bool has = w < nwords;
     /* every load the lane may need goes out before the first one is looked at */
-    u64 st = stop[w];
-    const u64 rs = rstart[w];
-    int64_t r = rflags ? blk_read[w] : 0;
     uint4 v4[4];
-    {
-        const uint4 *src = (const uint4 *)(out + g0);           /* (d_out carries 64 bytes of slack) */
-        #pragma unroll
-        for (int t = 0; t < 4; t++) v4[t] = src[t];
+    #pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int64_t off = gbase + t * 1024 + lane * 16;
+        v4[t].x = v4[t].y = v4[t].z = v4[t].w = 0;
+        if (off < n_bases) v4[t] = *(const uint4 *)(out + off);   /* (d_out carries 64 bytes of slack) */
     }
-    carry[w] = 0;
-    if (!st) return;
-    const int nn = (n_bases - g0 < 64) ? (int)(n_bases - g0) : 64;
+    const u64 rs = has ? rstart[w] : 0ull, rs1 = (w + 1 < nwords) ? rstart[w + 1] : 0ull;
+    int64_t r = (rflags && has) ? blk_read[w] : 0;
+    const int pb0 = gbase > 0 ? (int)out[gbase - 1] : 0;                    /* the byte before the tile */
+    const int nxb = gbase + 4096 < n_bases ? (int)out[gbase + 4096] : -1;   /* and the one behind it */
     const int level2 = P->pblock * 2, qcap = P->qcap;
-    uint32_t wd[16];
-    uint8_t *const byt = sbytes + threadIdx.x * PBW_ROW;
-    uint8_t *const row = runval + g0;                           /* the word's run values: PB_KEEP everywhere (a run that changes
-                                                                 * nothing needs no value), then the walked runs' values */
     {
-        uint4 *dstb = (uint4 *)byt, *dstr = (uint4 *)row;
-        uint4 ff; ff.x = ff.y = ff.z = ff.w = 0xffffffffu;
-        #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const uint4 v = v4[t];
-            wd[4 * t] = v.x; wd[4 * t + 1] = v.y; wd[4 * t + 2] = v.z; wd[4 * t + 3] = v.w;
-            dstb[t] = v; dstr[t] = ff;
-        }
+        uint32_t pt = 0;
+        if (P->any_preserve) pt = *(const uint32_t *)(P->preserve_qual + 4 * lane);
+        *(uint32_t *)(ptab + 4 * lane) = pt;
     }
-    /* bit masks over the word's bytes (packed byte arithmetic, 4 bits per dword):
-     *   keep  the byte's value stays: a preserved quality (snp:817,822; at most four values as scalars, else the
-     *         table) or any byte of a read with flag bit 15 (snp:1098)
+    #pragma unroll
+    for (int t = 0; t < 4; t++) *(uint4 *)(tile + (t * 16 + (lane >> 2)) * PBW_ROW + (lane & 3) * 16) = v4[t];
+    if (lane == 0) tile[-17] = (uint8_t)pb0;
+    WAVE_SYNC();
+    /* bit masks over every word's bytes; lane = byte here, a compare per mask and word:
+     *   stop  a jump of more than 2 * level from the byte before, a preserved value, or the byte behind one (the read
+     *         starts are added from rstart[] below)
+     *   keep  the byte's value stays: a preserved quality (snp:817,822) -- bytes of a read with flag bit 15 (snp:1098)
+     *         are added below
      *   chg   the byte differs from the byte before it: a segment without such a byte (other than at its start) is
      *         one run of one value -- its bytes do not change unless that value is above qcap
      *   big   a byte above qcap */
-#define PBW_BITS4(m_) ((u64)(((((m_) >> 7) * 0x00204081u) >> 21) & 15u))       /* bit 7 of the four bytes -> 4 bits */
-#define PBW_ZERO(x_) (~((((x_) & 0x7f7f7f7fu) + 0x7f7f7f7fu) | (x_)) & 0x80808080u)  /* bit 7 of every zero byte */
-    u64 keep = 0, chg = 0, big = 0;
+    u64 m_stop = 0, keep = 0, chg = 0, big = 0;
     {
-        const int npv = P->any_preserve ? P->n_pv : 0;
-        const uint32_t QC = (uint32_t)qcap * 0x01010101u;
-        uint32_t prevd = 0;
-        #pragma unroll
-        for (int t = 0; t < 16; t++) {
-            uint32_t eq = 0;
-            for (int i = 0; i < npv; i++) eq |= PBW_ZERO(wd[t] ^ ((uint32_t)P->pv_val[i] * 0x01010101u));
-            keep |= PBW_BITS4(eq) << (4 * t);
-            const uint32_t sh = (wd[t] << 8) | (prevd >> 24);                     /* every byte's predecessor */
-            chg |= PBW_BITS4(~PBW_ZERO(wd[t] ^ sh) & 0x80808080u) << (4 * t);
-            big |= PBW_BITS4(~((QC | 0x80808080u) - (wd[t] & 0x7f7f7f7fu)) & 0x80808080u) << (4 * t);   /* QC - q borrows: q > qcap */
-            prevd = wd[t];
-        }
-        if (P->any_preserve && P->n_pv < 0)
-            for (int k = 0; k < nn; k++) if (P->preserve_qual[byt[k]]) keep |= 1ull << k;
+        const uint8_t *const cur = tile + lane, *const prv = tile + (lane ? lane - 1 : -17);
+        uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const u64 pres0 = UNIFORM((int)ptab[pb0]) ? 1ull : 0ull;   /* is the byte before the tile preserved? */
+        if (n_bases - gbase >= 4096) pbw_masks<0, true>(cur, prv, ptab, 4096, (unsigned)level2, (unsigned)qcap, pres0, m);
+        else pbw_masks<0, false>(cur, prv, ptab, n_bases - gbase, (unsigned)level2, (unsigned)qcap, pres0, m);
+        m_stop = ((u64)m[1] << 32) | m[0]; keep = ((u64)m[3] << 32) | m[2];
+        chg = ((u64)m[5] << 32) | m[4]; big = ((u64)m[7] << 32) | m[6];
+        if (w == 0) { m_stop |= 1ull; chg |= 1ull; }            /* (no byte before the first one) */
     }
+#define PBW_IS_PRES(v_) (ptab[v_] != 0)
+    /* is the byte behind the word a stop?  (bit 0 of the next word's mask; the tile's last word looks at the byte) */
+    bool nst0;
+    {
+        const u64 nxt = __shfl_down(m_stop, 1);
+        nst0 = ((nxt | rs1) & 1ull) != 0;
+        if (lane == 63 && nxb >= 0) {
+            const int b63 = (int)tile[63 * PBW_ROW + 63];
+            int d = nxb - b63; d = d < 0 ? -d : d;
+            nst0 = (rs1 & 1ull) || d > level2 || PBW_IS_PRES(nxb) || PBW_IS_PRES(b63);
+        }
+    }
+#undef PBW_IS_PRES
+    if (!has) return;
+    const int nn = (n_bases - g0 < 64) ? (int)(n_bases - g0) : 64;
+    const u64 valid = nn >= 64 ? ~0ull : ((1ull << nn) - 1ull);     /* the end of the data is the last read's end */
+    const u64 st = (m_stop | rs) & valid;
+    const uint8_t *const byt = tile + lane * PBW_ROW;
+    {   /* (min, max) of the word without a stop / of the head before the first stop: the first byte and every byte that
+         * differs from the one before it */
+        const u64 region = (st ? (st & (0ull - st)) - 1ull : ~0ull) & valid;
+        int mn = 255, mx = 0;
+        if (region) {
+            mn = mx = (int)byt[0];
+            u64 c = chg & region & ~1ull;
+            while (c) {
+                const int q = (int)byt[__builtin_ctzll(c)];
+                c &= c - 1;
+                mn = q < mn ? q : mn; mx = q > mx ? q : mx;
+            }
+        }
+        mm[w] = (uint16_t)(mn | (mx << 8));                     /* (no byte before a stop at bit 0: 255 | 0 -- joins any run) */
+    }
+    stop[w] = st;
+    if (!st) { runs[w] = 0; chgrun[w] = 0; carry[w] = 0; return; }
     if (rflags) {
         while (r < n_reads && seq_off[r] < g0 + nn) {
             const int64_t a = seq_off[r], b = seq_off[r + 1];
@@ -2868,9 +2926,6 @@ k_pb_words(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_off
             r++;
         }
     }
-    /* the end of the data is the last read's end */
-    const u64 valid = nn >= 64 ? ~0ull : ((1ull << nn) - 1ull);
-    st &= valid;
     const u64 seg_starts = st & ~keep;                          /* a kept stop ends a segment and starts none */
     /* segments to walk: those with a changing byte inside, all of them if a byte is above qcap (its run is capped) */
     u64 walk = (big & ~keep & valid) ? seg_starts : 0ull;
@@ -2888,8 +2943,11 @@ k_pb_words(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_off
             c &= ~upto;                                         /* the segment's other changing bytes */
         }
     }
-    u64 newruns = 0;
-    bool isdirty = false;
+    uint8_t *const rowv = runval + g0;
+    u64 newruns = 0, chgbits = 0;
+    /* a run [j, .) of the word ends with value mid_: recorded only if it changes a byte */
+#define PBW_CLOSE(j_, mid_, qmin_, qmax_) do { \
+        if (((qmin_) != (qmax_)) | ((mid_) != (qmin_))) { rowv[j_] = (uint8_t)(mid_); chgbits |= 1ull << (j_); } } while (0)
     /* the state the word's last segment is left in (if it is still open at the word's end) */
     const int last_stop = 63 - __builtin_clzll(st);
     int cj = last_stop, cmin = (int)byt[last_stop], cmax = cmin;
@@ -2911,7 +2969,7 @@ k_pb_words(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_off
                     if (nmax - nmin > level2) {                  /* snp:817-826 */
                         int mid = (qmin + qmax) >> 1;
                         mid = mid > qcap ? qcap : mid;
-                        row[j] = (uint8_t)mid; isdirty |= (qmin != qmax) | (mid != qmin);
+                        PBW_CLOSE(j, mid, qmin, qmax);
                         newruns |= 1ull << k; j = k; qmin = qmax = q;
                     } else { qmin = nmin; qmax = nmax; }
                 }
@@ -2921,70 +2979,73 @@ k_pb_words(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_off
             int mid = (qmin + qmax) >> 1;
             const bool at_read_end = nx ? ((rs >> e) & 1ull) != 0 : true;
             if (!at_read_end && mid > qcap) mid = qcap;         /* a read's final run is not capped (snp:832) */
-            row[j] = (uint8_t)mid; isdirty |= (qmin != qmax) | (mid != qmin);
+            PBW_CLOSE(j, mid, qmin, qmax);
         } else { cj = j; cmin = qmin; cmax = qmax; }             /* (the word's last segment) */
     }
+    u64 cy = 0;
     if (last_open && nn == 64) {
         const bool last = w + 1 >= nwords;
-        const u64 nst = last ? 1ull : stop[w + 1];
-        if (nst & 1ull) {                                       /* the next byte is a stop (or there is none): the segment ends here */
-            const bool at_read_end = last ? true : (rstart[w + 1] & 1ull) != 0;
+        if (last || nst0) {                                     /* the next byte is a stop (or there is none): the segment ends here */
+            const bool at_read_end = last ? true : (rs1 & 1ull) != 0;
             int mid = (cmin + cmax) >> 1;
             if (!at_read_end && mid > qcap) mid = qcap;
-            if (cmin != cmax || mid != cmin) { row[cj] = (uint8_t)mid; isdirty = true; }
-        } else carry[w] = PBW_CARRY(cj, cmin, cmax, cmin, cmax);
+            PBW_CLOSE(cj, mid, cmin, cmax);
+        } else cy = PBW_CARRY(cj, cmin, cmax, cmin, cmax);
     }
-    if (newruns) runs[w] = newruns;
-    if (isdirty) dirty[w] = 1;
-#undef PBW_BITS4
-#undef PBW_ZERO
+#undef PBW_CLOSE
+    carry[w] = cy;
+    runs[w] = newruns;
+    chgrun[w] = chgbits;
+    if (chgbits) dirty[w] = PB_DIRTY;
 }
 
 __global__ void __launch_bounds__(256)
 k_pb_chains(int64_t n_bases, const uint8_t *__restrict__ out, const u64 *__restrict__ stop, const u64 *__restrict__ rstart,
-            u64 *__restrict__ runs, uint8_t *__restrict__ runval, const u64 *__restrict__ carry,
-            const uint16_t *__restrict__ wmm, const uint16_t *__restrict__ hmm, uint8_t *__restrict__ dirty,
-            const DParams *__restrict__ P)
+            u64 *__restrict__ runs, u64 *__restrict__ chgrun, uint8_t *__restrict__ runval, const u64 *__restrict__ carry,
+            const uint16_t *__restrict__ mm, uint32_t *__restrict__ dirty, const DParams *__restrict__ P)
 {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nwords = (n_bases + 63) >> 6;
     if (w >= nwords) return;
     const u64 cy = carry[w];
     if (!(cy & PBW_CARRY_VALID)) return;
+    /* (the first word of the walk goes out with the parameters) */
+    u64 s_nx = w + 1 < nwords ? stop[w + 1] : 1ull;
+    unsigned mm_nx = w + 1 < nwords ? mm[w + 1] : 0u;
     const int level2 = P->pblock * 2, qcap = P->qcap;
     int64_t j = w * 64 + (int64_t)(cy & 63u);
     int qmin = (int)((cy >> 8) & 255u), qmax = (int)((cy >> 16) & 255u), lmin = (int)((cy >> 24) & 255u), lmax = (int)((cy >> 32) & 255u);
-    /* a run [j, pos) ends: its value, the words it changes, the next run's start bit */
+    /* a run [j, pos) ends: if it changes a byte, its value, its bit, and the words it touches -- those behind the
+     * run's first one learn where the run that holds their first byte starts (k_pb_fillw) */
 #define PBC_CLOSE(mid_, pos_) do { \
-        runval[j] = (uint8_t)(mid_); \
-        if (lmin != lmax || (mid_) != lmin) for (int64_t dw_ = j >> 6; dw_ <= ((pos_) - 1) >> 6; dw_++) dirty[dw_] = 1; } while (0)
+        if (lmin != lmax || (mid_) != lmin) { \
+            runval[j] = (uint8_t)(mid_); \
+            atomicOr((unsigned long long *)&chgrun[j >> 6], 1ull << (j & 63)); \
+            atomicOr(&dirty[j >> 6], PB_DIRTY); \
+            for (int64_t dw_ = (j >> 6) + 1; dw_ <= ((pos_) - 1) >> 6; dw_++) atomicOr(&dirty[dw_], PB_DIRTY | (uint32_t)(dw_ * 64 - j)); \
+        } } while (0)
 #define PBC_BREAK(mid_, k_) do { const int64_t pos_ = wbase + (k_); PBC_CLOSE(mid_, pos_); \
         atomicOr((unsigned long long *)&runs[pos_ >> 6], 1ull << (pos_ & 63)); j = pos_; } while (0)
     for (int64_t ww = w + 1;; ww++) {
         const bool beyond = ww >= nwords;
-        const u64 s = beyond ? 1ull : stop[ww];
+        const u64 s = s_nx;
+        const unsigned mw = mm_nx;
+        if (ww + 1 < nwords) { s_nx = stop[ww + 1]; mm_nx = mm[ww + 1]; } else { s_nx = 1ull; mm_nx = 0u; }
         const int64_t wbase = ww * 64;
         const int wn = beyond ? 0 : ((n_bases - wbase < 64) ? (int)(n_bases - wbase) : 64);
-        if (!beyond && !s && wn == 64) {
-            const unsigned mm = wmm[ww];
-            const int cmin = (int)(mm & 255u), cmax = (int)(mm >> 8);
-            const int nmin = cmin < qmin ? cmin : qmin, nmax = cmax > qmax ? cmax : qmax;
-            if (nmax - nmin <= level2) { qmin = lmin = nmin; qmax = lmax = nmax; continue; }    /* the whole word joins the run */
-        }
         /* bytes [0, e) of this word belong to the segment: e = the first stop, or all of it */
         const int e = beyond ? 0 : (s ? __builtin_ctzll(s) : wn);
         bool joined = false;
-        if (e > 0 && s) {                                           /* the bytes before the first stop as one step (k_pb_marks' hmm[]) */
-            const unsigned mm = hmm[ww];
-            const int cmin = (int)(mm & 255u), cmax = (int)(mm >> 8);
+        if (e > 0 && (s || wn == 64)) {                             /* the whole word, or its head, as one step (mm[]) */
+            const int cmin = (int)(mw & 255u), cmax = (int)(mw >> 8);
             const int nmin = cmin < qmin ? cmin : qmin, nmax = cmax > qmax ? cmax : qmax;
             if (nmax - nmin <= level2) { qmin = lmin = nmin; qmax = lmax = nmax; joined = true; }
         }
+        if (joined && !s) continue;                                 /* the whole word joins the run */
         if (e > 0 && !joined) {
             const uint4 *src = (const uint4 *)(out + wbase);
-            #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                if (16 * c >= e) continue;
+            #pragma unroll 1
+            for (int c = 0; c < 4 && 16 * c < e; c++) {
                 const uint4 v = src[c];
                 const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
                 #pragma unroll
@@ -3139,6 +3200,73 @@ k_pb_fill(int64_t n_bases, uint8_t *__restrict__ out, const u64 *__restrict__ st
     if (changed) {
         if (g0 + 16 <= n_bases) { uint4 o; o.x = wd[0]; o.y = wd[1]; o.z = wd[2]; o.w = wd[3]; *(uint4 *)(out + g0) = o; }
         else for (int k = 0; g0 + k < n_bases; k++) out[g0 + k] = (uint8_t)((wd[k >> 2] >> (8 * (k & 3))) & 255);
+    }
+}
+
+/* the word-parallel P-block's fill: a wave looks at the dirty[] entries of 64 words, gathers the words some changing run
+ * touches and gives each to four lanes (16 bytes per lane): a byte takes the value of the run that holds it if that
+ * run's chgrun bit is set.  The run that holds a chunk's first byte starts at the last run start at or before it in
+ * the word, else dirty[w] tells how far before the word (0: that run changes nothing). */
+__global__ void __launch_bounds__(256)
+k_pb_fillw(int64_t n_bases, uint8_t *__restrict__ out, const u64 *__restrict__ stop, const u64 *__restrict__ runs,
+           const u64 *__restrict__ chgrun, const uint8_t *__restrict__ runval, const uint32_t *__restrict__ dirty)
+{
+    __shared__ uint8_t slots[4 * 64];
+    const int lane = threadIdx.x & 63;
+    uint8_t *const slot = slots + (threadIdx.x >> 6) * 64;
+    const int64_t nwords = (n_bases + 63) >> 6;
+    const int64_t w0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;
+    if (w0 >= nwords) return;                                   /* (the whole wave) */
+    const uint32_t dz = w0 + lane < nwords ? dirty[w0 + lane] : 0u;
+    const u64 dm = __ballot(dz != 0u);
+    if (!dm) return;
+    const int nd = __popcll(dm);
+    if (dz) slot[__popcll(dm & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+    WAVE_SYNC();
+    for (int p = 0; p * 16 < nd; p++) {
+        const int kq = p * 16 + (lane >> 2);
+        if (kq >= nd) continue;
+        const int64_t w = w0 + (int64_t)slot[kq];
+        const int sh = (lane & 3) * 16;
+        const int64_t g0 = w * 64 + sh;
+        if (g0 >= n_bases) continue;
+        const u64 m = stop[w] | runs[w], cr = chgrun[w];
+        const uint32_t dist = dirty[w] & ~PB_DIRTY;
+        const uint4 v = *(const uint4 *)(out + g0);
+        const uint4 rv4 = *(const uint4 *)(runval + g0);        /* only the bytes at starts of changing runs are meaningful */
+        /* the run that holds the chunk's first byte */
+        uint32_t val = PB_KEEP;
+        {
+            const u64 below = m & ((2ull << sh) - 1ull);
+            if (below) {
+                const int sb = 63 - __builtin_clzll(below);
+                if ((cr >> sb) & 1ull) val = runval[w * 64 + sb];
+            } else if (dist) val = runval[w * 64 - (int64_t)dist];
+        }
+        const unsigned bits = (unsigned)((m >> sh) & 0xffffu), cbits = (unsigned)((cr >> sh) & 0xffffu);
+        if (!(bits & 0xfffeu) && g0 + 16 <= n_bases) {
+            /* no run starts inside the chunk (bit 0 would be its own start, already in val): one value */
+            if (val == PB_KEEP) continue;
+            const uint32_t vv = val * 0x01010101u;
+            if (v.x != vv || v.y != vv || v.z != vv || v.w != vv) { uint4 o; o.x = o.y = o.z = o.w = vv; *(uint4 *)(out + g0) = o; }
+            continue;
+        }
+        uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t rv[4] = {rv4.x, rv4.y, rv4.z, rv4.w};
+        bool changed = false;
+        #pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (k > 0 && ((bits >> k) & 1u)) val = ((cbits >> k) & 1u) ? ((rv[k >> 2] >> (8 * (k & 3))) & 255u) : (uint32_t)PB_KEEP;
+            const uint32_t old = (wd[k >> 2] >> (8 * (k & 3))) & 255u;
+            if (val != PB_KEEP && old != val && g0 + k < n_bases) {
+                wd[k >> 2] = (wd[k >> 2] & ~(255u << (8 * (k & 3)))) | (val << (8 * (k & 3)));
+                changed = true;
+            }
+        }
+        if (changed) {
+            if (g0 + 16 <= n_bases) { uint4 o; o.x = wd[0]; o.y = wd[1]; o.z = wd[2]; o.w = wd[3]; *(uint4 *)(out + g0) = o; }
+            else for (int k = 0; g0 + k < n_bases; k++) out[g0 + k] = (uint8_t)((wd[k >> 2] >> (8 * (k & 3))) & 255u);
+        }
     }
 }
 
