@@ -507,12 +507,19 @@ def main():
             dist.all_reduce(allok, op=dist.ReduceOp.MIN)            # every rank takes the same path
             if int(allok.item()) == 1:
                 rc = eng.L.crumble_hip_stats_allreduce(eng.h, comm)
-                assert rc == 0, eng.L.crumble_hip_last_error()
-                stats = eng.stats_read()
+                # (a refusal -- e.g. the loaded librccl's version against the build's rccl.h -- comes before any
+                # collective is issued and is the same on every rank: agree on it, then take the other path)
+                allok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=red_dev)
+                dist.all_reduce(allok, op=dist.ReduceOp.MIN)
                 rccl.ncclCommDestroy.argtypes = [C.c_void_p]
                 rccl.ncclCommDestroy(comm)
-                stats_via = "crumble_hip_stats_allreduce (RCCL)"
-                done = True
+                if int(allok.item()) == 1:
+                    stats = eng.stats_read()
+                    stats_via = "crumble_hip_stats_allreduce (RCCL)"
+                    done = True
+                elif rank == 0:
+                    print("bench: crumble_hip_stats_allreduce refused (%s); statistics summed by torch.distributed"
+                          % eng.L.crumble_hip_last_error().decode(), file=sys.stderr)
         if not done:
             st = torch.from_numpy(stats.copy()).to(red_dev)
             dist.all_reduce(st, op=dist.ReduceOp.SUM)

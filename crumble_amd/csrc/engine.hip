@@ -970,10 +970,12 @@ extern "C" int crumble_hip_run_finish(crumble_hip *h)
                                      h->d_misc.as<int>() + 11, h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(),
                                      h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(), h->d_b15f.as<uint8_t>());
         }
-        if (L > 0 && h->totals.trigcols > 0)
-            CRUMBLE_LAUNCH(k_restore, h->totals.trigcols, 64, st, B, P, h->totals.trigcols,
+        if (L > 0 && h->totals.trigcols > 0) {
+            const int coop = (h->n_segrec > h->n_reads + h->n_reads / 2) ? 0 : 1;      /* (long reads: two columns per wave) */
+            CRUMBLE_LAUNCH(k_restore, coop ? h->totals.trigcols : (h->totals.trigcols + 7) / 8, 64, st, B, P, h->totals.trigcols,
                                  h->d_trigcol_pos.as<int32_t>(), h->d_pos_mn2.as<int32_t>(), h->d_trig_mx2.as<int32_t>(), h->d_out.as<uint8_t>(),
-                                 (h->n_segrec > h->n_reads + h->n_reads / 2) ? 0 : 1);
+                                 coop);
+        }
         CRUMBLE_LAUNCH_INDEP(k_readfix, nblk(n, 256), 256, st, B, colrec, h->d_keepf.as<uint8_t>(),
                              h->d_b15f.as<uint8_t>(), h->d_rflags.as<uint8_t>(), h->d_kept.as<int32_t>(), d_overflow + 2);
         CRUMBLE_LAUNCH_INDEP(k_keepfix, (nblk(n, 4) < 4096u ? nblk(n, 4) : 4096u), 256, st, B, P, h->d_kept.as<int32_t>(),

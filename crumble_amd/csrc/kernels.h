@@ -2314,9 +2314,12 @@ k_restore(DBatch B, const DParams *__restrict__ P, int n_trig, const int32_t *tr
      * the back-fill in query coordinates).  Step 2: the wave writes the ranges one read at a time,
      * lanes along the bytes, so a range is one or two coalesced stores instead of a byte loop per
      * lane that touches 64 different cache lines per step. */
-    const int t = blockIdx.x;
+    /* long reads (!coop): a column has a few candidates, each lane works alone -- two columns per wave, 32 lanes each
+     * (the kernel waits on chains of dependent loads: half the waves, the same chains) */
+    const int grp = coop ? 64 : 8;
+    const int t = coop ? (int)blockIdx.x : (int)blockIdx.x * 8 + (int)(threadIdx.x >> 3);
     if (t >= n_trig) return;
-    const int lane = threadIdx.x;
+    const int lane = coop ? (int)threadIdx.x : (int)(threadIdx.x & 7);
     const int c = trigcol_pos[t], apos = B.p0 + c, tile = c >> 6;
     const int lo = B.tile_lo[tile], hi = B.tile_hi[tile];
     const int mn2 = pos_mn2[c], qcap = P->qcap;
@@ -2326,7 +2329,7 @@ k_restore(DBatch B, const DParams *__restrict__ P, int n_trig, const int32_t *tr
      * [ref2query_pos(min_pos2'), qpos') contains this one's and writes the same bytes -- this column leaves the read
      * to it (runs of trigger columns over an STR rewrote the same bytes once per column) */
     const int nxt_apos = (t + 1 < n_trig && B.p0 + trigcol_pos[t + 1] <= trig_mx2[t]) ? B.p0 + trigcol_pos[t + 1] : INT_MAX;
-    for (int r0 = lo; r0 < hi; r0 += 64) {
+    for (int r0 = lo; r0 < hi; r0 += grp) {
         const int r = r0 + lane;
         int start = 0, stop = 0;
         unsigned so_lo = 0, so_hi = 0;
@@ -2345,19 +2348,42 @@ k_restore(DBatch B, const DParams *__restrict__ P, int n_trig, const int32_t *tr
                 }
             } else
             if (!(rr.info & RR_SIMPLE) && apos >= rp && apos < rr.end && !(softclip && apos == rp)) {   /* head column with -S: done by the replay pass */
-                Entry e;
-                resolve_entry(B, r, apos, e);
-                const int64_t so = B.seq_off[r];
-                const int lq = (int)(B.seq_off[r + 1] - so);
+                /* qpos of an entry is all that is needed here; the read's ops near the column are found once: the next
+                 * trigger column's op by search, this column's and min_pos2's by walking back from it (they are a few
+                 * ops apart at most -- a search each was three chains of dependent loads per candidate) */
+                const int64_t so = rr.so, sgo = B.seg_off[r];
+                const int lq = rr.lq, ns = (int)(B.seg_off[r + 1] - sgo);
+                const Seg *const sg = B.segs + sgo;
                 /* the same deferral for a read with several ops: the chain's next trigger column also reports a base of
-                 * this read (its entry's qpos' >= this one's, its min_pos2' <= this one's): its range contains this one */
+                 * this read (its entry's qpos' >= this one's, its min_pos2' <= this one's): its range contains this one.
+                 * Looked at first: along a chain every column but the last leaves the read alone. */
+                int si = -1;
                 bool later = false;
-                if (lq && nxt_apos < rr.end) { Entry e2; resolve_entry(B, r, nxt_apos, e2); later = e2.qpos < lq; }
-                if (lq && e.qpos < lq && !later) {             /* snp:1861 / fence */
-                    const int64_t sgo = B.seg_off[r];
-                    start = dev_ref2query_seg(B.segs + sgo, (int)(B.seg_off[r + 1] - sgo), rp, mn2, lq);
-                    stop = e.qpos;
-                    so_lo = (unsigned)(uint64_t)so; so_hi = (unsigned)((uint64_t)so >> 32);
+                if (lq && nxt_apos < rr.end) {
+                    si = seg_find(sg, ns, nxt_apos - rp);
+                    const Seg s2 = sg[si];
+                    later = (seg_type(s2) == SEG_M ? s2.qstart + (nxt_apos - rp - s2.roff) : s2.qstart) < lq;
+                }
+                if (lq && !later) {
+                    const int off = apos - rp;
+                    if (si >= 0) { for (int k = 0; k < 8 && si > 0 && off < sg[si].roff; k++) si--; }
+                    if (si < 0 || off < sg[si].roff) si = seg_find(sg, ns, off);
+                    const Seg s1 = sg[si];
+                    const int qpos = seg_type(s1) == SEG_M ? s1.qstart + (off - s1.roff) : s1.qstart;
+                    if (qpos < lq) {                             /* snp:1861 / fence */
+                        /* ref2query_pos(min_pos2) (dev_ref2query_seg): the first op whose end reaches it */
+                        const int offm = mn2 - rp;
+                        if (offm <= 0) start = 0;
+                        else if (offm > off) start = dev_ref2query_seg(sg, ns, rp, mn2, lq);
+                        else {
+                            int km = si, k = 0;
+                            for (; k < 8 && km > 0 && sg[km - 1].roff + seg_len(sg[km - 1]) >= offm; k++) km--;
+                            if (k == 8) start = dev_ref2query_seg(sg, ns, rp, mn2, lq);
+                            else { const Seg sm = sg[km]; start = seg_type(sm) == SEG_M ? sm.qstart + (offm - sm.roff) : sm.qstart; }
+                        }
+                        stop = qpos;
+                        so_lo = (unsigned)(uint64_t)so; so_hi = (unsigned)((uint64_t)so >> 32);
+                    }
                 }
             }
         }

@@ -147,3 +147,22 @@ def gap_batch(tid=0):
     return HostBatch.from_reads(reads, tid=tid)
 
 
+
+
+_GPU_COUNT = None
+
+
+def gpu_count():
+    """Visible GPUs, asked of torch in a CHILD process: torch brings its own copy of the HIP runtime, and a process
+    that has libcrumble_hip.so's (/opt/rocm) copy loaded as well dies in the runtimes' exit handlers ("double free or
+    corruption", exit code 134, after every test has passed)."""
+    global _GPU_COUNT
+    if _GPU_COUNT is None:
+        import subprocess, sys
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count() if torch.cuda.is_available() else 0)"],
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        try:
+            _GPU_COUNT = int(r.stdout.strip().splitlines()[-1])
+        except (ValueError, IndexError):
+            _GPU_COUNT = 0
+    return _GPU_COUNT

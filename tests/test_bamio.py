@@ -492,8 +492,8 @@ def test_htslib_backend_round_trip_when_present(tmp_path):
 
 def test_cli_has_no_cpu_path(tmp_path):
     """Without a GPU the shipped binary stops with ENODEVICE (exit 2); it never computes on the host."""
-    import torch
-    if torch.cuda.is_available():
+    from parity_util import gpu_count
+    if gpu_count():
         pytest.skip("GPU present")
     exe = os.path.join(ROOT, "crumble_amd", "crumble-hip")
     refs, bs = three_groups()

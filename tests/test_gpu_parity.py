@@ -302,9 +302,9 @@ def test_bench_multi_gpu_rccl(product, workload):
     """The real thing when the box has it: one process per DISTINCT GPU, backend nccl (= RCCL over xGMI), the product's
     own crumble_hip_stats_allreduce.  Skipped on a one-GPU box (the gloo test above covers the control flow there)."""
     import json, os, subprocess, sys
-    import torch
     from crumble_amd.capi import ROOT
-    n = torch.cuda.device_count()
+    from parity_util import gpu_count
+    n = gpu_count()                                   # (asked in a child process: see parity_util.gpu_count)
     if n < 2:
         pytest.skip("one visible GPU")
     n = 2 if n < 4 else 4
