@@ -146,6 +146,7 @@ struct DBatch {
     const uint8_t *bases, *quals;
     const int32_t *tile_lo, *tile_hi;
     const int32_t *bed_start, *bed_end, *bed_pmax;
+    const int32_t *tile_bed;              /* [n_tiles] first keep-region whose prefix-max end reaches the tile (n_bed > 0) */
 };
 
 /* per-position column record */

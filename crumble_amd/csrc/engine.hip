@@ -62,7 +62,7 @@ struct crumble_hip {
     DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc, d_mqslot;
     /* batch (inputs) */
     DevBuf d_genlist, d_vrec, d_pbdirty, d_pbcarry, d_pbchg, d_bases4, d_ufirst, d_tcum, d_tpart, d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
-           d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax;
+           d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax, d_tile_bed;
     /* per position */
     DevBuf d_colrec, d_nplp, d_score, d_trigcnt, d_dpre, d_col_ord, d_trig_ord, d_item_off,
            d_ins_ord, d_pos_mn2, d_partial, d_epochs, d_ht;
@@ -278,7 +278,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
         &h->d_ufirst, &h->d_tcum, &h->d_tpart, &h->d_pbdirty, &h->d_pbcarry, &h->d_pbchg, &h->d_bases4, &h->d_pbwmm, &h->d_act, &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
         &h->d_slow_g, &h->d_slow_r, &h->d_cix, &h->d_sr, &h->d_stile_lo, &h->d_stile_hi, &h->d_rr, &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
         &h->d_cigar, &h->d_segs, &h->d_bases, &h->d_quals, &h->d_tile_lo, &h->d_tile_hi,
-        &h->d_bed_start, &h->d_bed_end, &h->d_bed_pmax, &h->d_colrec, &h->d_nplp, &h->d_score,
+        &h->d_bed_start, &h->d_bed_end, &h->d_bed_pmax, &h->d_tile_bed, &h->d_colrec, &h->d_nplp, &h->d_score,
         &h->d_trigcnt, &h->d_dpre, &h->d_col_ord, &h->d_trig_ord, &h->d_item_off, &h->d_ins_ord,
         &h->d_pos_mn2, &h->d_partial, &h->d_epochs, &h->d_ht, &h->d_trigcol_pos, &h->d_trigcol_off,
         &h->d_inscol_pos, &h->d_items, &h->d_colhi, &h->d_ub, &h->d_pmax_partial, &h->d_trig_mx2,
@@ -521,6 +521,11 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
             CRUMBLE_LAUNCH_INDEP(k_p0_tiles, nblk(B.n_tiles, 256), 256, st, B.n_tiles, B.p0, (int64_t)ns, h->d_sr_ppos.as<int32_t>(),
                                  h->d_sr_pend.as<int32_t>(), h->d_stile_lo.as<int32_t>(), h->d_stile_hi.as<int32_t>());
         }
+        if (B.n_tiles > 0 && n_bed > 0) {                   /* keep-BED cursor of every tile */
+            if ((e = h->d_tile_bed.reserve((size_t)(B.n_tiles + 1) * 4))) return e;
+            CRUMBLE_LAUNCH_INDEP(k_p0_tilebed, nblk(B.n_tiles, 256), 256, st, B.n_tiles, B.p0, n_bed, h->d_bed_pmax.as<int32_t>(),
+                                 h->d_tile_bed.as<int32_t>());
+        }
         if (B.n_tiles > 0) {                                /* cost prefix of the tiles: k_columns' work split */
             const int tch = (int)((B.n_tiles + P0_CHUNK - 1) / P0_CHUNK);
             if ((e = h->d_tcum.reserve((size_t)(B.n_tiles + 2) * 8)) || (e = h->d_tpart.reserve((size_t)(tch + 2) * 8))) return e;
@@ -579,7 +584,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     B.bases = h->d_bases.as<uint8_t>() + BASE_FRONT_PAD; B.quals = h->d_quals.as<uint8_t>() + BASE_FRONT_PAD;
     B.tile_lo = h->d_tile_lo.as<int32_t>(); B.tile_hi = h->d_tile_hi.as<int32_t>();
     B.bed_start = h->d_bed_start.as<int32_t>(); B.bed_end = h->d_bed_end.as<int32_t>();
-    B.bed_pmax = h->d_bed_pmax.as<int32_t>();
+    B.bed_pmax = h->d_bed_pmax.as<int32_t>(); B.tile_bed = h->d_tile_bed.as<int32_t>();
 
     const size_t L = (size_t)(B.L > 0 ? B.L : 1);
     const int nsc = (int)((L + SCAN_CHUNK - 1) / SCAN_CHUNK);

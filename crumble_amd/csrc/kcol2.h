@@ -741,7 +741,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
         continue;
 #endif
         const bool in_win = !WIN || (c >= B.col_lo && c < B.col_hi);
-        const int bed_lo = B.n_bed ? bed_tile(B, c0, lane) : 0;     /* keep-regions: one search per tile, not one per column */
+        const int bed_lo = B.n_bed ? UNIFORM(B.tile_bed[tile]) : 0; /* keep-regions: the tile's cursor (k_p0_tilebed), not a search per column */
 #if KC2_FASTFIN
         {   /* the common tile: in every column that reaches the consensus the ten genotypes without the key base are out
              * of reach (cons_fast_ok, kernels.h) -- the result comes from the five key genotypes in place, no un-permute

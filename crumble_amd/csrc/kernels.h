@@ -171,26 +171,9 @@ __device__ __forceinline__ int bed_preserve(const DBatch &B, int apos)
     return 0;
 }
 /* The same for the 64 columns of a tile at once (k_columns2): the per-column search is ~13 dependent loads with
- * thousands of regions, and nearly every tile lies between two regions.  bed_tile() returns the first region whose
- * prefix-max of `end` reaches the tile's first column c0 -- every column's own cursor position is at or behind it --
- * found by the wave's lanes probing 64 keys per round (three rounds for 5000 regions); bed_preserve_from() walks on
- * from there for one column.  Called by every lane of the wave. */
-__device__ __forceinline__ int bed_tile(const DBatch &B, int c0, int lane)
-{
-    int lo = 0, hi = B.n_bed;                              /* the answer is in [lo, hi]: keys before lo are < c0, key hi is not */
-    while (hi > lo) {
-        const int len = hi - lo, step = (len + 63) >> 6;   /* probes at lo, lo + step, ...: at most 64 of them */
-        const int idx = lo + lane * step;
-        const bool below = idx < hi && B.bed_pmax[idx] < c0;
-        const int nb = __popcll(__ballot(below));          /* the keys do not decrease: the probes below c0 are a prefix */
-        const int nprobes = (len + step - 1) / step;
-        const int nhi = nb < nprobes ? lo + nb * step : hi;
-        lo = nb > 0 ? lo + (nb - 1) * step + 1 : lo;
-        hi = nhi;
-        if (step == 1) { lo = hi; break; }                 /* every key in between was probed */
-    }
-    return lo;
-}
+ * thousands of regions, and nearly every tile lies between two regions.  B.tile_bed[tile] (k_p0_tilebed, once per
+ * batch) is the first region whose prefix-max of `end` reaches the tile's first column -- every column's own cursor
+ * position is at or behind it; bed_preserve_from() walks on from there for one column. */
 __device__ __forceinline__ int bed_preserve_from(const DBatch &B, int apos, int lo)
 {
     while (lo < B.n_bed && B.bed_pmax[lo] < apos) lo++;
@@ -441,7 +424,7 @@ __device__ __forceinline__ void col_decide(ColState &st, const DBatch &B, const 
                                            int32_t *__restrict__ score_out, int32_t *__restrict__ trigcnt, unsigned *stats,
                                            const double *sE = nullptr, const bool cnt = true, const ConsOut *pre = nullptr,
                                            const int bed_lo = -1)
-{   /* bed_lo >= 0: bed_tile()'s answer for the column's tile */
+{   /* bed_lo >= 0: the tile's keep-region cursor (B.tile_bed) */
     const int n_plp = st.n_plp;
     if (n_plp == 0) { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; return; }
 

@@ -395,6 +395,19 @@ __global__ void k_p0_tiles(int n_tiles, int p0, int64_t n, const int32_t *__rest
     tlo[t] = (int32_t)lo; thi[t] = (int32_t)h;
 }
 
+/* keep-BED cursor per tile (k_columns2): the first region whose prefix-max of `end` reaches the tile's first column --
+ * every column's own cursor (bed_preserve, kernels.h) is at or behind it.  Once per batch instead of a search per tile
+ * in every run (three dependent rounds of loads in the tile's epilogue: 9 % of k_columns2 on config 4). */
+__global__ void k_p0_tilebed(int n_tiles, int p0, int n_bed, const int32_t *__restrict__ bed_pmax, int32_t *__restrict__ tbed)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const int64_t c0 = (int64_t)p0 + (int64_t)t * 64;
+    int lo = 0, hi = n_bed;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)bed_pmax[mid] < c0) lo = mid + 1; else hi = mid; }
+    tbed[t] = lo;
+}
+
 __global__ void k_p0_blkread(int64_t nblocks, int64_t n, const int64_t *__restrict__ seq_off, int32_t *__restrict__ blk_read)
 {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

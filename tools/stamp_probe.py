@@ -5,9 +5,9 @@ import synth
 wl = sys.argv[1] if len(sys.argv) > 1 else "chr20"
 cfg = synth.config(wl, scale=float(sys.argv[2]) if len(sys.argv) > 2 else 1.0)
 lvl = sys.argv[3] if len(sys.argv) > 3 else "5"
-if lvl == "pbccs":          # config 4: -y pbccs -R keep.bed
+if lvl in ("pbccs", "pbccs_nobed"):          # config 4: -y pbccs -R keep.bed (pbccs_nobed: without the -R)
     import bench
-    hb = synth.generate(cfg, bed=bench.keep_bed(cfg.contig_len, int(5000 * cfg.contig_len / 248956422 + 0.5)))
+    hb = synth.generate(cfg, bed=bench.keep_bed(cfg.contig_len, int(5000 * cfg.contig_len / 248956422 + 0.5)) if lvl == "pbccs" else None)
     e = ca.Engine(ca.preset_params(None, tech="pbccs"), 0)
 else:
     hb = synth.generate(cfg)
