@@ -139,6 +139,8 @@ struct DBatch {
     int64_t n_vrec;
     const SegRec *sr;
     const int32_t *stile_lo, *stile_hi;   /* candidate SegRec range per 64-column tile */
+    const int64_t *hit_off;               /* long-read batches: [n_tiles+1] the tile's slice of hits[] (k_p0_hitfill) */
+    const int32_t *hits;                  /* SegRec indices of the records that reach a tile, file order */
     const int32_t *unit_first;            /* [n_units+1] first tile of every KCOL_UNIT-sized slice of the tiles' cost prefix */
     int32_t n_units;
     int32_t n_slots;                      /* mapq values (other than hot_mq) with a slot in k_columns2's compact adjustment table */

@@ -62,7 +62,7 @@ struct crumble_hip {
     DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc, d_mqslot;
     /* batch (inputs) */
     DevBuf d_genlist, d_vrec, d_pbdirty, d_pbcarry, d_pbchg, d_bases4, d_ufirst, d_tcum, d_tpart, d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
-           d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax, d_tile_bed;
+           d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax, d_tile_bed, d_hitoff, d_hits;
     /* per position */
     DevBuf d_colrec, d_nplp, d_score, d_trigcnt, d_dpre, d_col_ord, d_trig_ord, d_item_off,
            d_ins_ord, d_pos_mn2, d_partial, d_epochs, d_ht;
@@ -94,6 +94,7 @@ struct crumble_hip {
     crumble_window win;
     int64_t own_b_lo = 0, own_b_hi = 0;     /* byte range of the owned reads */
     int phase = 0;                          /* 0 nothing run; 1 columns; 2 depth; 3 triggers; 4 fold; 5 finished */
+    bool have_hits = false;                 /* long-read batch: hit_off / hits are built (k_p0_hitfill) */
     bool scan_fused = false;                /* no per-column prefix arrays: k_epochs_find + k_scan_overdepth (whole contig, no too-deep column) */
     crumble_carry carry_in;                 /* what phases 2 and 4 started from */
     /* timing */
@@ -278,7 +279,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
         &h->d_ufirst, &h->d_tcum, &h->d_tpart, &h->d_pbdirty, &h->d_pbcarry, &h->d_pbchg, &h->d_bases4, &h->d_pbwmm, &h->d_act, &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
         &h->d_slow_g, &h->d_slow_r, &h->d_cix, &h->d_sr, &h->d_stile_lo, &h->d_stile_hi, &h->d_rr, &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
         &h->d_cigar, &h->d_segs, &h->d_bases, &h->d_quals, &h->d_tile_lo, &h->d_tile_hi,
-        &h->d_bed_start, &h->d_bed_end, &h->d_bed_pmax, &h->d_tile_bed, &h->d_colrec, &h->d_nplp, &h->d_score,
+        &h->d_bed_start, &h->d_bed_end, &h->d_bed_pmax, &h->d_tile_bed, &h->d_hitoff, &h->d_hits, &h->d_colrec, &h->d_nplp, &h->d_score,
         &h->d_trigcnt, &h->d_dpre, &h->d_col_ord, &h->d_trig_ord, &h->d_item_off, &h->d_ins_ord,
         &h->d_pos_mn2, &h->d_partial, &h->d_epochs, &h->d_ht, &h->d_trigcol_pos, &h->d_trigcol_off,
         &h->d_inscol_pos, &h->d_items, &h->d_colhi, &h->d_ub, &h->d_pmax_partial, &h->d_trig_mx2,
@@ -526,12 +527,38 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
             CRUMBLE_LAUNCH_INDEP(k_p0_tilebed, nblk(B.n_tiles, 256), 256, st, B.n_tiles, B.p0, n_bed, h->d_bed_pmax.as<int32_t>(),
                                  h->d_tile_bed.as<int32_t>());
         }
+        const bool multi = tot.nseg > n + n / 2;            /* long reads: many ops per read */
+        h->have_hits = false;
+        if (B.n_tiles > 0 && multi) {                       /* the records that reach each tile, in file order (k_columns2<MULTI>) */
+            const int tch = (int)((B.n_tiles + P0_CHUNK - 1) / P0_CHUNK);
+            if ((e = h->d_hitoff.reserve((size_t)(B.n_tiles + 2) * 8)) || (e = h->d_tpart.reserve((size_t)(tch + 2) * 8))) return e;
+            int64_t *ho = h->d_hitoff.as<int64_t>(), *tp = h->d_tpart.as<int64_t>();
+            HIPCHK(hipMemsetAsync(ho, 0, (size_t)(B.n_tiles + 2) * 8, st));
+            CRUMBLE_LAUNCH_INDEP(k_p0_hitcount, nblk((int64_t)ns, 256), 256, st, (int64_t)ns, B.p0, B.n_tiles, h->d_sr.as<SegRec>(), ho);
+            CRUMBLE_LAUNCH_INDEP(k_i64scan_reduce, nblk(tch, 64), 64, st, (int64_t)B.n_tiles, ho, tp, tch);
+            CRUMBLE_LAUNCH(k_i64scan_partials, 1, 1024, st, tp, tch);
+            CRUMBLE_LAUNCH_INDEP(k_i64scan_apply, nblk(tch, 64), 64, st, (int64_t)B.n_tiles, ho, tp, tch);
+            int64_t nhits = 0;
+            HIPCHK(hipMemcpyAsync(&nhits, ho + B.n_tiles, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (nhits >= INT_MAX) { g_last_error = "more than 2^31 (record, tile) pairs in one batch"; return CRUMBLE_EINVAL; }
+            if ((e = h->d_hits.reserve((size_t)(nhits + 64) * 4))) return e;
+            int *herr = h->d_misc.as<int>() + 15;
+            HIPCHK(hipMemsetAsync(herr, 0, 4, st));
+            CRUMBLE_LAUNCH(k_p0_hitfill, nblk(B.n_tiles, 4), 256, st, B.n_tiles, B.p0, h->d_stile_lo.as<int32_t>(), h->d_stile_hi.as<int32_t>(),
+                           h->d_sr.as<SegRec>(), ho, h->d_hits.as<int32_t>(), herr);
+            int herr_h = 0;
+            HIPCHK(hipMemcpyAsync(&herr_h, herr, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (herr_h) { g_last_error = "internal: tile hit lists inconsistent"; return CRUMBLE_EOVERFLOW; }
+            h->have_hits = true;
+        }
         if (B.n_tiles > 0) {                                /* cost prefix of the tiles: k_columns' work split */
             const int tch = (int)((B.n_tiles + P0_CHUNK - 1) / P0_CHUNK);
             if ((e = h->d_tcum.reserve((size_t)(B.n_tiles + 2) * 8)) || (e = h->d_tpart.reserve((size_t)(tch + 2) * 8))) return e;
             int64_t *cum = h->d_tcum.as<int64_t>(), *tp = h->d_tpart.as<int64_t>();
             CRUMBLE_LAUNCH_INDEP(k_tile_cost, nblk(B.n_tiles, 256), 256, st, B.n_tiles, h->d_stile_lo.as<int32_t>(),
-                                 h->d_stile_hi.as<int32_t>(), h->d_sr.as<SegRec>(), (tot.nseg > n + n / 2) ? 1 : 0, cum);
+                                 h->d_stile_hi.as<int32_t>(), h->d_sr.as<SegRec>(), h->have_hits ? h->d_hitoff.as<int64_t>() : (const int64_t *)nullptr, cum);
             CRUMBLE_LAUNCH_INDEP(k_i64scan_reduce, nblk(tch, 64), 64, st, (int64_t)B.n_tiles, cum, tp, tch);
             CRUMBLE_LAUNCH(k_i64scan_partials, 1, 1024, st, tp, tch);
             CRUMBLE_LAUNCH_INDEP(k_i64scan_apply, nblk(tch, 64), 64, st, (int64_t)B.n_tiles, cum, tp, tch);
@@ -581,6 +608,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     B.vr = h->d_vrec.as<VRec>(); if (!h->have_vrec) B.n_vrec = 0;
     B.sr = h->d_sr.as<SegRec>(); B.stile_lo = h->d_stile_lo.as<int32_t>(); B.stile_hi = h->d_stile_hi.as<int32_t>();
     B.unit_first = h->d_ufirst.as<int32_t>();
+    B.hit_off = h->have_hits ? h->d_hitoff.as<int64_t>() : nullptr; B.hits = h->have_hits ? h->d_hits.as<int32_t>() : nullptr;
     B.bases = h->d_bases.as<uint8_t>() + BASE_FRONT_PAD; B.quals = h->d_quals.as<uint8_t>() + BASE_FRONT_PAD;
     B.tile_lo = h->d_tile_lo.as<int32_t>(); B.tile_hi = h->d_tile_hi.as<int32_t>();
     B.bed_start = h->d_bed_start.as<int32_t>(); B.bed_end = h->d_bed_end.as<int32_t>();
@@ -715,7 +743,7 @@ extern "C" int crumble_hip_set_window(crumble_hip *h, const crumble_window *w)
  * engine per device -- and only the two tiny chained phases in window order: 2 hands the running depth average on
  * (snp:1490-1491,1684-1687), 4 the STR window state (snp:1508-1511,1741-1755). */
 /* what every phase needs from the handle (d_misc: [0] overflow flag, [1] n_epochs, [2] n_kept, [3] k_columns work counter,
- * [8..11] upload, [16..19] depth state out, [24..27] window state out) */
+ * [8..12] upload, [15] hit-list check, [16..19] depth state out, [24..27] window state out) */
 #define RUN_LOCALS \
     HIPCHK(hipSetDevice(h->device)); \
     hipStream_t st = h->stream; \
@@ -757,7 +785,7 @@ extern "C" int crumble_hip_run_columns(crumble_hip *h)
         const unsigned pgrid = (h->persistent_blocks * 4 * (modeB && h->hparams.min_qual_A ? 3 : KCOL_WAVES) / 4 + kw - 1) / kw;
         if (grid > pgrid) grid = pgrid;                 /* persistent: grid-stride over tiles */
         const bool modeA = h->hparams.min_qual_A != 0;
-        const bool multi = h->n_segrec > h->n_reads + h->n_reads / 2;     /* long reads: many ops per read */
+        const bool multi = h->have_hits;                                  /* long reads: many ops per read (the upload listed every tile's records) */
 #define KCOL_LAUNCH2(M, MU, PE) CRUMBLE_LAUNCH((k_columns<M, MU, PE>), grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, ht, stats, (unsigned *)(d_overflow + 3))
 #define KCOL_LAUNCH(M) do { if (multi) { if (h->col_perm) KCOL_LAUNCH2(M, true, true); else KCOL_LAUNCH2(M, true, false); } \
                             else       { if (h->col_perm) KCOL_LAUNCH2(M, false, true); else KCOL_LAUNCH2(M, false, false); } } while (0)

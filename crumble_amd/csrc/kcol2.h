@@ -309,7 +309,7 @@ struct __attribute__((aligned(16))) KC2Lds {
                 }
 
 /* MQ: the active consensus uses CONS_MQUAL (mode B, snp:1535); ANYPRES: -k/-K/-y pbccs set preserve_qual[];
- * MULTI: long reads (many ops per read: candidates are screened by their first 8 bytes); WIN: the batch is a window
+ * MULTI: long reads (many ops per read: a tile's records come from the batch's hit list); WIN: the batch is a window
  * of a contig (crumble_hip_set_window: columns outside [col_lo, col_hi) read as empty, columns from stat_hi on stay
  * out of the statistics) -- its own instances, the whole-contig ones carry none of it */
 template <bool MQ, bool ANYPRES, bool MULTI, bool WIN>
@@ -426,7 +426,8 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
             if (inr) { colrec[c] = 0; nplp_out[c] = 0; score_out[c] = 0; trigcnt[c] = 0; }
             continue;
         }
-        const int lo = UNIFORM(B.stile_lo[tile]), hi = UNIFORM(B.stile_hi[tile]);
+        /* the tile's records: a candidate range of B.sr (short reads), or its slice of the hit list (long reads) */
+        const int lo = UNIFORM(MULTI ? (int)B.hit_off[tile] : B.stile_lo[tile]), hi = UNIFORM(MULTI ? (int)B.hit_off[tile + 1] : B.stile_hi[tile]);
         const int c0 = B.p0 + tile * 64, c1 = c0 + 63;
 
         ColState st;
@@ -449,39 +450,16 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
             if (lane < 4) W.cnt[64 + lane] = 0;
             WAVE_SYNC();
             if (MULTI) {
-                /* long reads: most candidate ops of the overlapping reads miss the tile.  Screen them by their first 8
-                 * bytes, four windows of 64 per round trip, and collect the hits' indices in file order (W.rowinfo
-                 * holds them until the rows' flags are written); then one more round trip brings the hits' records,
+                /* long reads: most ops of the overlapping reads miss the tile; the ones that reach it were listed with
+                 * the batch, in file order (k_p0_hitfill): one round trip for up to KC2_R indices, one for the records,
                  * a lane each */
-                bool full = false;
-                while (wnext < hi && !full) {
-                    int2 pe[4];
-                    #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int idx = wnext + 64 * u + lane;
-                        pe[u].x = 0; pe[u].y = 0;
-                        if (idx < hi) pe[u] = *(const int2 *)&B.sr[idx];
-                    }
-                    #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (full || wnext >= hi) break;
-                        const int idx = wnext + lane;
-                        const bool o = idx < hi && pe[u].y > c0 && pe[u].x <= c1;
-                        const unsigned long long m = __ballot(o);
-                        const int h = __popcll(m);
-                        if (nq + h > KC2_R) { full = true; break; }      /* this window opens the next pass */
-                        if (o) W.rowinfo[nq + __popcll(m & lt)] = (uint32_t)idx;
-                        nq += h;
-                        wnext += 64;
-                    }
-                }
-                WAVE_SYNC();
+                nq = hi - wnext < KC2_R ? hi - wnext : KC2_R;
                 const bool ov = lane < nq;
                 const int slot = lane;
                 uint4 r0, r1;
                 r0.x = r0.y = r0.z = r0.w = 0; r1 = r0;
-                if (ov) { const uint4 *rp = (const uint4 *)&B.sr[W.rowinfo[lane]]; r0 = rp[0]; r1 = rp[1]; }
-                WAVE_SYNC();                                             /* (rowinfo is rewritten below) */
+                if (ov) { const uint4 *rp = (const uint4 *)&B.sr[B.hits[wnext + lane]]; r0 = rp[0]; r1 = rp[1]; }
+                wnext += nq;
                 bool lowrec = false;
                 KC2_STAGE_HIT();
             } else {

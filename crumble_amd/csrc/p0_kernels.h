@@ -395,6 +395,47 @@ __global__ void k_p0_tiles(int n_tiles, int p0, int64_t n, const int32_t *__rest
     tlo[t] = (int32_t)lo; thi[t] = (int32_t)h;
 }
 
+/* Long-read batches (k_columns2<MULTI>): the records (reference-consuming ops) that reach each 64-column tile, listed
+ * once per batch in file order.  A tile's candidate range [stile_lo, stile_hi) holds every op of ~20 overlapping
+ * reads, ~4000 records of which ~25 reach the tile: screening them in every run was 18 % of the kernel on config 4.
+ *   k_p0_hitcount   one lane per record: +1 for every tile it reaches (tile t = columns [c0, c0 + 63], c0 = p0 + 64 t:
+ *                   end > c0 && pos <= c0 + 63)
+ *   (exclusive scan: hit_off[])
+ *   k_p0_hitfill    one wave per tile: the same test over the tile's candidate range, 64 records per round, the hits
+ *                   written in the order they are met -- file order, what the column kernel's sums need */
+__global__ void k_p0_hitcount(int64_t ns, int p0, int n_tiles, const SegRec *__restrict__ sr, int64_t *__restrict__ cnt)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const int2 pe = *(const int2 *)&sr[i];                  /* pos, end */
+    int64_t ta = ((int64_t)pe.x - p0) >> 6, tb = ((int64_t)pe.y - p0 - 1) >> 6;
+    if (ta < 0) ta = 0;
+    if (tb >= n_tiles) tb = n_tiles - 1;
+    for (int64_t t = ta; t <= tb; t++) atomicAdd((unsigned long long *)&cnt[t], 1ull);
+}
+__global__ void __launch_bounds__(256)
+k_p0_hitfill(int n_tiles, int p0, const int32_t *__restrict__ slo, const int32_t *__restrict__ shi,
+             const SegRec *__restrict__ sr, const int64_t *__restrict__ hit_off, int32_t *__restrict__ hits, int *__restrict__ err)
+{
+    const int lane = threadIdx.x & 63;
+    const int tile = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (tile >= n_tiles) return;                            /* (the whole wave) */
+    const int c0 = p0 + tile * 64, c1 = c0 + 63;
+    const int hi = shi[tile];
+    int64_t o = hit_off[tile];
+    const int64_t oe = hit_off[tile + 1];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int w = slo[tile]; w < hi; w += 64) {
+        const int idx = w + lane;
+        bool ov = false;
+        if (idx < hi) { const int2 pe = *(const int2 *)&sr[idx]; ov = pe.y > c0 && pe.x <= c1; }
+        const unsigned long long m = __ballot(ov);
+        if (ov) { const int64_t k = o + __popcll(m & lt); if (k < oe) hits[k] = idx; }
+        o += __popcll(m);
+    }
+    if (lane == 0 && o != oe) *err = 1;                     /* (the two kernels apply one test) */
+}
+
 /* keep-BED cursor per tile (k_columns2): the first region whose prefix-max of `end` reaches the tile's first column --
  * every column's own cursor (bed_preserve, kernels.h) is at or behind it.  Once per batch instead of a search per tile
  * in every run (three dependent rounds of loads in the tile's epilogue: 9 % of k_columns2 on config 4). */
@@ -514,15 +555,13 @@ __global__ void k_p0_vrecs(int64_t n, int64_t nb, int p0, int min_mqual, const R
  * tiles of equal total cost -- no atomics, adjacent tiles (which share their reads) stay in one wave. */
 #define TILE_COST_SPAN (1ll << 56)               /* marks a tile whose reads span too much of the base array */
 __global__ void k_tile_cost(int n_tiles, const int32_t *__restrict__ slo, const int32_t *__restrict__ shi,
-                            const SegRec *__restrict__ sr, int multi, int64_t *__restrict__ cost)
+                            const SegRec *__restrict__ sr, const int64_t *__restrict__ hit_off, int64_t *__restrict__ cost)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
     const int w = shi[t] - slo[t];
-    /* long reads: most candidates are screened out 64 at a time, and a wave that stays on neighbouring tiles keeps
-     * finding the same reads' records and base words in its caches: units of about eight tiles instead of four
-     * (0.1 x config 4: 2.10 -> 1.76 ms; a 128-cost unit: 3.9 ms) */
-    int64_t c = multi ? (w >> 3) + 2 : w + 2;
+    /* long reads (hit_off): the records that reach the tile, not the candidates around them */
+    int64_t c = hit_off ? (hit_off[t + 1] - hit_off[t]) + 2 : w + 2;
     /* k_columns2 addresses the bases of a tile's reads with 32-bit offsets from the first one */
     if (w > 0 && sr[shi[t] - 1].so - sr[slo[t]].so > 0xf0000000ll) c = TILE_COST_SPAN;
     cost[t] = c;
