@@ -335,7 +335,10 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
     for (int i = threadIdx.x; i < KC2_NROWTAB; i += blockDim.x) {
         const int a = i >= 128 ? i - 128 : (MQ ? (int)T->adjc[hot_mq * 256 + i] : (int)T->capc[i]);
         sRow[i * 4] = T->MMd[a]; sRow[i * 4 + 1] = T->_Md[a]; sRow[i * 4 + 2] = T->omq[a];
-        long long pvb = i < 128 ? (long long)T->pvc[i] : 0;
+        /* call_preserve input of the quality (snp:611-623) as the bits an entry of class 0 adds to st.cp: bit 0 for a
+         * preserved quality, bit 8 as well for a really-kept one; the consumer shifts them by the entry's class */
+        const unsigned pvl = i < 128 ? (unsigned)T->pvc[i] : 0u;
+        long long pvb = (long long)((pvl ? 1u : 0u) | (pvl > 1u ? 0x100u : 0u));
         memcpy(&sRow[i * 4 + 3], &pvb, 8);
     }
     if (MQ)
@@ -612,7 +615,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                 /* rows of reads with another mapq than the batch's dominant one: the entries' table row index becomes
                  * 128 + adjusted quality (snp:632-641), one row per step with a lane per column (the lanes sit on
                  * different rows in the steps below, so a row-uniform look-up has no place there); the call_preserve
-                 * input of the raw quality travels in bits 13-14 of the entry */
+                 * input of the raw quality (the new table row carries none) is taken here */
                 unsigned long long nm = __ballot((ri & KC2_NONHOT) != 0u);
                 if (nm) {
                     while (nm) {
@@ -623,8 +626,13 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                         unsigned aq;
                         if (slot < (unsigned)B.n_slots) { aq = sAdjC[slot * 128u + (q & 127u)]; KC2_PIN(aq); }
                         else aq = T->adjc[(rinfo & 255u) * 256u + (q & 255u)];
-                        const unsigned pvb = ANYPRES ? (unsigned)sPv[q & 127u] << 13 : 0u;
-                        if (KC2_CLS(e) != 7u) W.plane[j][lane] = (uint16_t)(((128u + aq) << 5) | pvb | (e & 0x1fu));
+                        if (KC2_CLS(e) != 7u) {
+                            W.plane[j][lane] = (uint16_t)(((128u + aq) << 5) | (e & 0x1fu));
+                            if (ANYPRES) {
+                                const unsigned pv = (unsigned)sPv[q & 127u], cl = KC2_CLS(e);
+                                if (pv) { st.cp |= 1u << cl; if (pv > 1u) st.cp |= (1u << cl) << 8; }
+                            }
+                        }
                     }
                     WAVE_SYNC();
                 }
@@ -677,7 +685,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
 #endif
                 unsigned ve[4];
                 double rMM[4], r_M[4], rom[4];
-                long long rpv[4];
+                unsigned rpv[4];
                 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     ve[u] = vn[u];
@@ -687,7 +695,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                     const double *rw = (const double *)(rowbase + (ve[u] & KC2_ROWMASK));
 #endif
                     rMM[u] = rw[0]; r_M[u] = rw[1]; rom[u] = rw[2];
-                    if (ANYPRES) memcpy(&rpv[u], &rw[3], 8); else rpv[u] = 0;
+                    if (ANYPRES) memcpy(&rpv[u], &rw[3], 4); else rpv[u] = 0;
                 }
                 if (j0 + 4 < steps4) {
                     #pragma unroll
@@ -696,10 +704,10 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     KC2_ROW(ve[u], rMM[u], r_M[u], rom[u]);
-                    if (ANYPRES) {                                        /* call_preserve bits, snp:611-623 */
-                        const unsigned pv = ((unsigned)rpv[u] | (ve[u] >> 13)) & 3u, cl = KC2_CLS(ve[u]);
-                        if (cl != 7u && pv) { st.cp |= 1u << cl; if (pv > 1u) st.cp |= (1u << cl) << 8; }
-                    }
+                    /* call_preserve bits, snp:611-623: the table row's bits at the entry's class.  Class 7 -- no entry,
+                     * its row index may point anywhere, past the table too: hence the mask -- lands on bits 7 and 15,
+                     * dropped after the last pass */
+                    if (ANYPRES) st.cp |= (rpv[u] & 0x101u) << KC2_CLS(ve[u]);
                 }
             }
             WAVE_SYNC();                                                 /* the next group / pass overwrites plane / recs */
@@ -708,6 +716,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
         }
         KC2_DRAIN();
         st.nN = nN;
+        if (ANYPRES) st.cp &= 0x7f7fu;
         if (inr) {
             const uint32_t h = htacc;
             st.depth = st.n_plp - st.nref - n_lq0;       /* entries that reached the sums (snp:685) */
