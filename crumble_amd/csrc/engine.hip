@@ -904,7 +904,10 @@ extern "C" int crumble_hip_run_triggers(crumble_hip *h)
                              trigcol_pos, trigcol_off, inscol_pos, stats, B.stat_hi);
         if (n_ins > 0) {
             STAGE("k_inshist", 0);
-            CRUMBLE_LAUNCH(k_inshist, n_ins, 64, st, B, P, n_ins, inscol_pos, colrec, nplp, stats);
+            {   /* lanes per column: 16 when a column has a few dozen candidate reads, the whole wave on deep pileups */
+                const int gshift = (h->totals.cols > 0 && h->totals.depth / h->totals.cols < 40) ? 4 : 6;     /* (mean depth of the covered columns) */
+                CRUMBLE_LAUNCH(k_inshist, (n_ins + (64 >> gshift) - 1) / (64 >> gshift), 64, st, B, P, n_ins, inscol_pos, colrec, nplp, stats, gshift);
+            }
         }
         if (n_trig > 0) {
             STAGE("k_emit", 0);

@@ -1264,28 +1264,36 @@ k_scan_overdepth(int L, uint32_t *colrec, const int32_t *nplp, const int32_t *tr
  * insertion only.  One thread per such column. */
 __global__ void __launch_bounds__(64)
 k_inshist(DBatch B, const DParams *P, int n_ins, const int32_t *inscol_pos,
-          uint32_t *colrec, const int32_t *nplp, u64 *stats)     /* (statistics: columns < B.stat_hi) */
+          uint32_t *colrec, const int32_t *nplp, u64 *stats, int gshift)     /* (statistics: columns < B.stat_hi) */
 {
-    /* one 64-lane workgroup per column, lanes over its candidate reads */
-    __shared__ int hist[100];
-    __shared__ int s_sz;
-    const int t = blockIdx.x;
-    for (int i = threadIdx.x; i < 100; i += blockDim.x) hist[i] = 0;
-    if (threadIdx.x == 0) s_sz = 0;
+    /* a group of 1 << gshift lanes per column, lanes over its candidate reads: the whole 64-lane workgroup on a deep
+     * pileup; 16 lanes -- four columns per wave -- when a column has a few dozen candidates (the kernel waits on chains
+     * of dependent loads: a quarter of the waves, the same chains) */
+    __shared__ int hist_all[4 * 100];
+    __shared__ int s_sz_all[4];
+    const int glanes = 1 << gshift, grp = (int)threadIdx.x >> gshift, gl = (int)threadIdx.x & (glanes - 1);
+    int *const hist = hist_all + grp * 100;
+    const int t = (int)blockIdx.x * (64 >> gshift) + grp;
+    for (int i = gl; i < 100; i += glanes) hist[i] = 0;
+    if (gl == 0) s_sz_all[grp] = 0;
     __syncthreads();
-    const int c = inscol_pos[t], apos = B.p0 + c, tile = c >> 6;
-    const int lo = B.tile_lo[tile], hi = B.tile_hi[tile];
-    for (int r = lo + (int)threadIdx.x; r < hi; r += blockDim.x) {
-        if (!(apos >= B.pos[r] && apos < B.end[r])) continue;
-        Entry e;
-        resolve_entry(B, r, apos, e);
-        if (e.is_refskip || e.is_head || e.is_tail) continue;
-        if (e.indel > 0) atomicMax(&s_sz, e.indel);
-        if (e.indel >= 0) atomicAdd(&hist[e.indel < 99 ? e.indel : 99], 1);
+    const bool active = t < n_ins;
+    const int c = active ? inscol_pos[t] : 0, apos = B.p0 + c, tile = c >> 6;
+    if (active) {
+        const int lo = B.tile_lo[tile], hi = B.tile_hi[tile];
+        for (int r = lo + gl; r < hi; r += glanes) {
+            if (!(apos >= B.pos[r] && apos < B.end[r])) continue;
+            Entry e;
+            resolve_entry(B, r, apos, e);
+            if (e.is_refskip || e.is_head || e.is_tail) continue;
+            if (e.indel > 0) atomicMax(&s_sz_all[grp], e.indel);
+            if (e.indel >= 0) atomicAdd(&hist[e.indel < 99 ? e.indel : 99], 1);
+        }
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    int indel_sz = s_sz;
+    if (!active || gl != 0) return;
+    int indel_sz = s_sz_all[grp];
+
     if (indel_sz > 100) indel_sz = 100;
     if (!indel_sz) return;
     int qd1 = 0, qd2 = 0, ov = 0;
@@ -2372,8 +2380,13 @@ k_restore(DBatch B, const DParams *__restrict__ P, int n_trig, const int32_t *tr
         }
         if (!coop) {                                       /* long reads: few candidates per column, a lane each */
             const int64_t so = (int64_t)(((uint64_t)so_hi << 32) | so_lo);
-            for (int x = start; x < stop; x++)
-                out[so + x] = cap_q2(P, qcap, any_pres, B.quals[so + x]) & 0x7f;
+            for (int x = start; x < stop; x += 8) {         /* eight loads in flight, then eight stores (a byte per trip waited out a load each) */
+                uint8_t v8[8];
+                #pragma unroll
+                for (int k = 0; k < 8; k++) v8[k] = x + k < stop ? B.quals[so + x + k] : (uint8_t)0;
+                #pragma unroll
+                for (int k = 0; k < 8; k++) if (x + k < stop) out[so + x + k] = cap_q2(P, qcap, any_pres, v8[k]) & 0x7f;
+            }
             continue;
         }
         /* four ranges per step: their loads are in flight together (one range per step left a wave waiting
