@@ -2805,14 +2805,41 @@ k_pb_segments(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_
 #define PB_DIRTY 0x80000000u    /* dirty[w]: a run that changes a byte touches word w; low 31 bits: how far before the word's
                                  * first byte the changing run that holds it starts (0: it starts here, or changes nothing) */
 
-/* |a - b| of two byte values in one operation; a wave-uniform 32-bit value handed to lane I (v_writelane_b32) */
+/* |a - b| of two byte values in one operation; eight wave-uniform 32-bit values handed to lane I (v_writelane_b32).
+ * One asm block for the eight, behind two wait states: on gfx940 / gfx950 a VALU instruction must not read an SGPR
+ * in the two slots after a VALU instruction (here: v_cmp) wrote it, hipcc's hazard pass does not look into an asm
+ * statement's operands, and with one statement per value it scheduled each right behind the compare that made its
+ * operand -- a stale mask bit once in ~10^5 words (found by test_pblock_long_read_shapes on the GPU, never on the
+ * emulator). */
 #ifdef CRUMBLE_EMU
 #define PBW_ABSDIFF(a_, b_) ((a_) > (b_) ? (a_) - (b_) : (b_) - (a_))
-template <int I> __device__ __forceinline__ void pbw_put(uint32_t &dst, uint32_t val) { if ((int)(threadIdx.x & 63) == I) dst = val; }
+template <int I> __device__ __forceinline__ void pbw_put8(uint32_t (&m)[8], u64 a, u64 b, u64 c, u64 d)
+{
+    if ((int)(threadIdx.x & 63) == I) {
+        m[0] = (uint32_t)a; m[1] = (uint32_t)(a >> 32); m[2] = (uint32_t)b; m[3] = (uint32_t)(b >> 32);
+        m[4] = (uint32_t)c; m[5] = (uint32_t)(c >> 32); m[6] = (uint32_t)d; m[7] = (uint32_t)(d >> 32);
+    }
+}
 #else
 #define PBW_ABSDIFF(a_, b_) __builtin_amdgcn_sad_u8((a_), (b_), 0u)
-template <int I> __device__ __forceinline__ void pbw_put(uint32_t &dst, uint32_t val)
-{ asm("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(__builtin_amdgcn_readfirstlane(val)), "n"(I)); }
+template <int I> __device__ __forceinline__ void pbw_put8(uint32_t (&m)[8], u64 a, u64 b, u64 c, u64 d)
+{
+    asm("s_nop 1\n\t"
+        "v_writelane_b32 %0, %8, %16\n\t"
+        "v_writelane_b32 %1, %9, %16\n\t"
+        "v_writelane_b32 %2, %10, %16\n\t"
+        "v_writelane_b32 %3, %11, %16\n\t"
+        "v_writelane_b32 %4, %12, %16\n\t"
+        "v_writelane_b32 %5, %13, %16\n\t"
+        "v_writelane_b32 %6, %14, %16\n\t"
+        "v_writelane_b32 %7, %15, %16"
+        : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7])
+        : "s"(__builtin_amdgcn_readfirstlane((uint32_t)a)), "s"(__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32))),
+          "s"(__builtin_amdgcn_readfirstlane((uint32_t)b)), "s"(__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32))),
+          "s"(__builtin_amdgcn_readfirstlane((uint32_t)c)), "s"(__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32))),
+          "s"(__builtin_amdgcn_readfirstlane((uint32_t)d)), "s"(__builtin_amdgcn_readfirstlane((uint32_t)(d >> 32))),
+          "n"(I));
+}
 #endif
 
 /* k_pb_words, lane = byte: the bit masks of the tile's words I, I + 1, ... 63 (see the kernel), each handed to the lane
@@ -2828,10 +2855,7 @@ pbw_masks(const uint8_t *cur, const uint8_t *prv, const uint8_t *ptab, int64_t l
     const u64 bk = __ballot(ptab[v] != 0) & okm;
     const u64 bs = (__ballot(PBW_ABSDIFF(v, pv) > level2) & okm) | bk | (bk << 1) | lastpres;
     const u64 bc = __ballot(v != pv), bb = __ballot(v > qcap);
-    pbw_put<I>(m[0], (uint32_t)bs); pbw_put<I>(m[1], (uint32_t)(bs >> 32));
-    pbw_put<I>(m[2], (uint32_t)bk); pbw_put<I>(m[3], (uint32_t)(bk >> 32));
-    pbw_put<I>(m[4], (uint32_t)bc); pbw_put<I>(m[5], (uint32_t)(bc >> 32));
-    pbw_put<I>(m[6], (uint32_t)bb); pbw_put<I>(m[7], (uint32_t)(bb >> 32));
+    pbw_put8<I>(m, bs, bk, bc, bb);
     if constexpr (I + 1 < 64) pbw_masks<I + 1, FULL>(cur, prv, ptab, left, level2, qcap, bk >> 63, m);
 }
 

@@ -149,6 +149,50 @@ def gap_batch(tid=0):
 
 
 
+
+def pblock_long_stress(engine_factory, path, seed=1, n_cases=40):
+    """P-block (snp:803-834) on long-read-shaped quality strings: reads of up to 30 kb, one dominant value with sparse
+    preserved / outlying values (HiFi after the replay), slow drifts, noise; -y pbccs, no preserved value, and MORE than
+    four preserved values (the table path); levels 1..70.  Reads longer than the word-parallel kernels' 4 KiB tile,
+    runs that cross hundreds of 64-byte words, data that ends anywhere in a tile."""
+    import oracle_lib as O
+    rng = np.random.default_rng(seed)
+    for it in range(n_cases):
+        tech = int(rng.integers(3))
+        level = int(rng.choice([1, 2, 4, 8, 16, 30, 70]))
+        p = ca.preset_params(9, tech="pbccs", pblock=level) if tech == 0 else ca.preset_params(9, pblock=level)
+        if tech == 2:
+            for v in rng.choice([5, 20, 21, 22, 40, 59, 60, 75, 93], int(rng.integers(1, 8)), replace=False):
+                p.preserve_qual[int(v)] = 1
+        nr = int(rng.integers(1, 12))
+        lens = rng.integers(1, 9000, nr) if rng.random() < 0.7 else rng.integers(1, 200, nr)
+        if rng.random() < 0.3:
+            lens[rng.integers(nr)] = int(rng.integers(4000, 30000))
+        so = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        n = int(so[-1])
+        mode = int(rng.integers(4))
+        if mode == 0:
+            q = rng.choice([60, 93, 5, 56, 40, 59, 70, 90], n, p=[.85, .07, .01, .02, .01, .02, .01, .01])
+        elif mode == 1:
+            q = np.clip(60 + np.cumsum(rng.integers(-3, 4, n)), 0, 93)
+        elif mode == 2:
+            q = rng.integers(0, 94, n)
+        else:
+            q = np.full(n, 60)
+            k = rng.integers(0, n, max(1, n // 50))
+            q[k] = rng.choice([93, 20, 45, 75], len(k))
+        q = q.astype(np.uint8)
+        pq = np.frombuffer(bytes(p.preserve_qual), np.uint8)
+        want = np.concatenate([O.pblock(q[so[i]:so[i + 1]], p.pblock, p.qcap, pq) for i in range(nr)])
+        eng = engine_factory(p)
+        eng.set_option("pblock", path)
+        try:
+            got = eng.pblock(so, q)
+        finally:
+            eng.close()
+        d = np.flatnonzero(got != want)
+        assert len(d) == 0, (it, path, tech, level, mode, lens.tolist(), d[:5].tolist(), got[d[:5]].tolist(), want[d[:5]].tolist())
+
 _GPU_COUNT = None
 
 

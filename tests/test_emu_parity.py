@@ -8,7 +8,7 @@ import pytest
 import crumble_amd as ca
 from crumble_amd import HostBatch
 import emu_lib
-from parity_util import assert_parity, synth_batch, pblock_stress
+from parity_util import assert_parity, synth_batch, pblock_stress, pblock_long_stress
 
 
 @pytest.mark.parametrize("level", [1, 5, 9])
@@ -44,6 +44,20 @@ def test_emu_pblock_paths(product, path):
 def test_emu_pblock_stress(product, path):
     """The pblock operator seam on raw quality strings: jumps, drifts, outliers, every chunk alignment."""
     pblock_stress(emu_lib.engine, path, n_reads=150)
+
+
+@pytest.mark.parametrize("path", ["segments", "words"])
+def test_emu_pblock_long_read_shapes(product, path):
+    """Long-read-shaped quality strings through the two long-read decompositions (see pblock_long_stress)."""
+    pblock_long_stress(emu_lib.engine, path, n_cases=25)
+
+
+def test_emu_long_reads_deep_tiles(product):
+    """Long multi-op reads at 150x: more records reach a 64-column tile than k_columns2 stages in one pass (KC2_R = 64),
+    so a tile's slice of the hit list (k_p0_hitfill) is walked in several passes."""
+    hb = synth_batch("hifi", 0.00004, contig_len=5000, read_len=1500, depth=100.0, err_indel=0.004)
+    assert hb.cig_off[-1] > 3 * hb.n_reads and hb.n_bases > 80 * 5000
+    assert_parity(emu_lib.with_options(kcol="v2"), ca.preset_params(9, tech="pbccs"), hb)
 
 
 def test_emu_empty_and_passthrough(product):

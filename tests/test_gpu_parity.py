@@ -94,6 +94,22 @@ def test_pblock_stress(product, path):
     pblock_stress(gpu_engine, path, n_reads=2000)
 
 
+@pytest.mark.parametrize("path", ["segments", "words"])
+def test_pblock_long_read_shapes(product, path):
+    """Long-read-shaped quality strings through the two long-read decompositions (see pblock_long_stress)."""
+    from parity_util import pblock_long_stress
+    pblock_long_stress(gpu_engine, path, seed=2, n_cases=150)
+
+
+def test_long_reads_deep_tiles(product):
+    """Long multi-op reads at 150x: more records reach a 64-column tile than k_columns2 stages in one pass (KC2_R = 64),
+    so a tile's slice of the hit list (k_p0_hitfill) is walked in several passes."""
+    hb = synth_batch("hifi", 0.0004, read_len=4000, depth=150.0, err_indel=0.002)
+    assert hb.cig_off[-1] > 3 * hb.n_reads and hb.n_bases > 100 * hb.pos.max()
+    assert_parity(gpu_engine, ca.preset_params(9, tech="pbccs"), hb)
+    assert_parity(gpu_engine, ca.preset_params(5), hb)
+
+
 def test_empty_and_passthrough(product):
     p = ca.preset_params(9)
     assert_parity(gpu_engine, p, HostBatch.from_reads([]))
