@@ -62,7 +62,7 @@ struct crumble_hip {
     DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc, d_mqslot;
     /* batch (inputs) */
     DevBuf d_genlist, d_vrec, d_pbdirty, d_pbcarry, d_pbchg, d_bases4, d_ufirst, d_tcum, d_tpart, d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
-           d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax, d_tile_bed, d_hitoff, d_hits;
+           d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax, d_tile_bed, d_hitoff, d_hits, d_rtoff, d_first;
     /* per position */
     DevBuf d_colrec, d_nplp, d_score, d_trigcnt, d_dpre, d_col_ord, d_trig_ord, d_item_off,
            d_ins_ord, d_pos_mn2, d_partial, d_epochs, d_ht;
@@ -279,7 +279,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
         &h->d_ufirst, &h->d_tcum, &h->d_tpart, &h->d_pbdirty, &h->d_pbcarry, &h->d_pbchg, &h->d_bases4, &h->d_pbwmm, &h->d_act, &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
         &h->d_slow_g, &h->d_slow_r, &h->d_cix, &h->d_sr, &h->d_stile_lo, &h->d_stile_hi, &h->d_rr, &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
         &h->d_cigar, &h->d_segs, &h->d_bases, &h->d_quals, &h->d_tile_lo, &h->d_tile_hi,
-        &h->d_bed_start, &h->d_bed_end, &h->d_bed_pmax, &h->d_tile_bed, &h->d_hitoff, &h->d_hits, &h->d_colrec, &h->d_nplp, &h->d_score,
+        &h->d_bed_start, &h->d_bed_end, &h->d_bed_pmax, &h->d_tile_bed, &h->d_hitoff, &h->d_hits, &h->d_rtoff, &h->d_first, &h->d_colrec, &h->d_nplp, &h->d_score,
         &h->d_trigcnt, &h->d_dpre, &h->d_col_ord, &h->d_trig_ord, &h->d_item_off, &h->d_ins_ord,
         &h->d_pos_mn2, &h->d_partial, &h->d_epochs, &h->d_ht, &h->d_trigcol_pos, &h->d_trigcol_off,
         &h->d_inscol_pos, &h->d_items, &h->d_colhi, &h->d_ub, &h->d_pmax_partial, &h->d_trig_mx2,
@@ -530,11 +530,27 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
         const bool multi = tot.nseg > n + n / 2;            /* long reads: many ops per read */
         h->have_hits = false;
         if (B.n_tiles > 0 && multi) {                       /* the records that reach each tile, in file order (k_columns2<MULTI>) */
-            const int tch = (int)((B.n_tiles + P0_CHUNK - 1) / P0_CHUNK);
-            if ((e = h->d_hitoff.reserve((size_t)(B.n_tiles + 2) * 8)) || (e = h->d_tpart.reserve((size_t)(tch + 2) * 8))) return e;
-            int64_t *ho = h->d_hitoff.as<int64_t>(), *tp = h->d_tpart.as<int64_t>();
-            HIPCHK(hipMemsetAsync(ho, 0, (size_t)(B.n_tiles + 2) * 8, st));
-            CRUMBLE_LAUNCH_INDEP(k_p0_hitcount, nblk((int64_t)ns, 256), 256, st, (int64_t)ns, B.p0, B.n_tiles, h->d_sr.as<SegRec>(), ho);
+            const int rch = (int)((n + P0_CHUNK - 1) / P0_CHUNK), tch = (int)((B.n_tiles + P0_CHUNK - 1) / P0_CHUNK);
+            if ((e = h->d_rtoff.reserve((size_t)(n + 2) * 8)) || (e = h->d_tpart.reserve((size_t)((rch > tch ? rch : tch) + 2) * 8)) ||
+                (e = h->d_hitoff.reserve((size_t)(B.n_tiles + 2) * 8)))
+                return e;
+            int64_t *rto = h->d_rtoff.as<int64_t>(), *tp = h->d_tpart.as<int64_t>(), *ho = h->d_hitoff.as<int64_t>();
+            int *herr = h->d_misc.as<int>() + 15;
+            HIPCHK(hipMemsetAsync(herr, 0, 4, st));
+            CRUMBLE_LAUNCH_INDEP(k_p0_rtcount, nblk(n, 256), 256, st, n, B.p0, h->d_rr.as<ReadRec>(), h->d_seg_off.as<int64_t>(), rto);
+            CRUMBLE_LAUNCH_INDEP(k_i64scan_reduce, nblk(rch, 64), 64, st, n, rto, tp, rch);
+            CRUMBLE_LAUNCH(k_i64scan_partials, 1, 1024, st, tp, rch);
+            CRUMBLE_LAUNCH_INDEP(k_i64scan_apply, nblk(rch, 64), 64, st, n, rto, tp, rch);
+            int64_t npairs = 0;
+            HIPCHK(hipMemcpyAsync(&npairs, rto + n, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if ((e = h->d_first.reserve((size_t)(npairs + 64) * 4))) return e;
+            const uint32_t *first = h->d_first.as<uint32_t>();
+            CRUMBLE_LAUNCH_INDEP(k_p0_first, nblk(n, 4), 256, st, n, B.p0, h->d_rr.as<ReadRec>(), h->d_seg_off.as<int64_t>(), h->d_sr.as<SegRec>(),
+                                 rto, h->d_first.as<uint32_t>());
+            const unsigned hgrid = nblk((int64_t)B.n_tiles * P0_HIT_GROUP, 256);
+            CRUMBLE_LAUNCH(k_p0_hitcount, hgrid, 256, st, B.n_tiles, B.p0, h->d_tile_lo.as<int32_t>(), h->d_tile_hi.as<int32_t>(),
+                           h->d_rr.as<ReadRec>(), h->d_seg_off.as<int64_t>(), rto, first, ho);
             CRUMBLE_LAUNCH_INDEP(k_i64scan_reduce, nblk(tch, 64), 64, st, (int64_t)B.n_tiles, ho, tp, tch);
             CRUMBLE_LAUNCH(k_i64scan_partials, 1, 1024, st, tp, tch);
             CRUMBLE_LAUNCH_INDEP(k_i64scan_apply, nblk(tch, 64), 64, st, (int64_t)B.n_tiles, ho, tp, tch);
@@ -543,10 +559,8 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
             HIPCHK(hipStreamSynchronize(st));
             if (nhits >= INT_MAX) { g_last_error = "more than 2^31 (record, tile) pairs in one batch"; return CRUMBLE_EINVAL; }
             if ((e = h->d_hits.reserve((size_t)(nhits + 64) * 4))) return e;
-            int *herr = h->d_misc.as<int>() + 15;
-            HIPCHK(hipMemsetAsync(herr, 0, 4, st));
-            CRUMBLE_LAUNCH(k_p0_hitfill, nblk(B.n_tiles, 4), 256, st, B.n_tiles, B.p0, h->d_stile_lo.as<int32_t>(), h->d_stile_hi.as<int32_t>(),
-                           h->d_sr.as<SegRec>(), ho, h->d_hits.as<int32_t>(), herr);
+            CRUMBLE_LAUNCH(k_p0_hitfill, hgrid, 256, st, B.n_tiles, B.p0, h->d_tile_lo.as<int32_t>(), h->d_tile_hi.as<int32_t>(),
+                           h->d_rr.as<ReadRec>(), h->d_seg_off.as<int64_t>(), rto, first, ho, h->d_hits.as<int32_t>(), herr);
             int herr_h = 0;
             HIPCHK(hipMemcpyAsync(&herr_h, herr, 4, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));

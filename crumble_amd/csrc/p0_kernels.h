@@ -398,43 +398,115 @@ __global__ void k_p0_tiles(int n_tiles, int p0, int64_t n, const int32_t *__rest
 /* Long-read batches (k_columns2<MULTI>): the records (reference-consuming ops) that reach each 64-column tile, listed
  * once per batch in file order.  A tile's candidate range [stile_lo, stile_hi) holds every op of ~20 overlapping
  * reads, ~4000 records of which ~25 reach the tile: screening them in every run was 18 % of the kernel on config 4.
- *   k_p0_hitcount   one lane per record: +1 for every tile it reaches (tile t = columns [c0, c0 + 63], c0 = p0 + 64 t:
- *                   end > c0 && pos <= c0 + 63)
- *   (exclusive scan: hit_off[])
- *   k_p0_hitfill    one wave per tile: the same test over the tile's candidate range, 64 records per round, the hits
- *                   written in the order they are met -- file order, what the column kernel's sums need */
-__global__ void k_p0_hitcount(int64_t ns, int p0, int n_tiles, const SegRec *__restrict__ sr, int64_t *__restrict__ cnt)
+ * Tile t = columns [c0, c0 + 63], c0 = p0 + 64 t; a record reaches it iff end > c0 && pos <= c0 + 63.  A read's ops
+ * are position-sorted and contiguous (end == the next op's pos), so the ops of read r that reach its k-th tile are a
+ * RANGE F_k .. L_k of record indices, and L_k follows from F_(k+1):
+ *   k_p0_rtcount    one lane per read: the number of tiles it reaches (exclusive scan: rt_off[])
+ *   k_p0_first      one wave per read, lanes over its ops: F_k for every tile of the read, a plain store per
+ *                   (read, tile); bit 31 = the op starts on the tile's first column (or the read does): it does not
+ *                   reach the tile before
+ *   k_p0_hitcount   sixteen lanes per tile, a lane per overlapping read: L_k - F_k + 1, summed per tile
+ *                   (exclusive scan: hit_off[])
+ *   k_p0_hitfill    the same walk, the ranges written out read by read: file order, what the column kernel's sums
+ *                   need.  No atomics anywhere, no record is looked at after k_p0_first.
+ * (First version: one atomic add per (record, tile) pair, then a screening pass over the candidate ranges: 6.1 ms per
+ * upload of config 4.  Second: counted and filled in one kernel with one atomic add per tile on ONE cursor -- 4 M
+ * same-address atomics, 11.7 ms.) */
+#define P0_FIRST_STARTS 0x80000000u
+__global__ void k_p0_rtcount(int64_t n, int p0, const ReadRec *__restrict__ rr, const int64_t *__restrict__ seg_off,
+                             int64_t *__restrict__ rt)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ns) return;
-    const int2 pe = *(const int2 *)&sr[i];                  /* pos, end */
-    int64_t ta = ((int64_t)pe.x - p0) >> 6, tb = ((int64_t)pe.y - p0 - 1) >> 6;
-    if (ta < 0) ta = 0;
-    if (tb >= n_tiles) tb = n_tiles - 1;
-    for (int64_t t = ta; t <= tb; t++) atomicAdd((unsigned long long *)&cnt[t], 1ull);
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const ReadRec x = rr[r];
+    rt[r] = (seg_off[r + 1] > seg_off[r] && x.end > x.pos) ? (int64_t)(((x.end - 1 - p0) >> 6) - ((x.pos - p0) >> 6) + 1) : 0;
 }
 __global__ void __launch_bounds__(256)
-k_p0_hitfill(int n_tiles, int p0, const int32_t *__restrict__ slo, const int32_t *__restrict__ shi,
-             const SegRec *__restrict__ sr, const int64_t *__restrict__ hit_off, int32_t *__restrict__ hits, int *__restrict__ err)
+k_p0_first(int64_t n, int p0, const ReadRec *__restrict__ rr, const int64_t *__restrict__ seg_off, const SegRec *__restrict__ sr,
+           const int64_t *__restrict__ rt_off, uint32_t *__restrict__ first)
 {
     const int lane = threadIdx.x & 63;
-    const int tile = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    if (tile >= n_tiles) return;                            /* (the whole wave) */
-    const int c0 = p0 + tile * 64, c1 = c0 + 63;
-    const int hi = shi[tile];
-    int64_t o = hit_off[tile];
-    const int64_t oe = hit_off[tile + 1];
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int w = slo[tile]; w < hi; w += 64) {
-        const int idx = w + lane;
-        bool ov = false;
-        if (idx < hi) { const int2 pe = *(const int2 *)&sr[idx]; ov = pe.y > c0 && pe.x <= c1; }
-        const unsigned long long m = __ballot(ov);
-        if (ov) { const int64_t k = o + __popcll(m & lt); if (k < oe) hits[k] = idx; }
-        o += __popcll(m);
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int64_t s0 = seg_off[r], s1 = seg_off[r + 1];
+    if (s1 <= s0) return;
+    const int t0 = (rr[r].pos - p0) >> 6;
+    const int64_t ro = rt_off[r];
+    for (int64_t i = s0 + lane; i < s1; i += 64) {
+        const int2 pe = *(const int2 *)&sr[i];              /* pos, end */
+        if (pe.y <= pe.x) continue;
+        const int ta = (pe.x - p0) >> 6, tb = (pe.y - 1 - p0) >> 6;
+        /* the op before ends where this one starts: it reaches tile ta too unless this op starts the tile */
+        const bool starts = i == s0 || ((pe.x - p0) & 63) == 0;
+        if (starts) first[ro + (ta - t0)] = (uint32_t)i | P0_FIRST_STARTS;
+        for (int t = ta + 1; t <= tb; t++) first[ro + (t - t0)] = (uint32_t)i;
     }
-    if (lane == 0 && o != oe) *err = 1;                     /* (the two kernels apply one test) */
 }
+#define P0_HIT_GROUP 16         /* lanes per tile in k_p0_hitcount / k_p0_hitfill */
+/* the lane's read of round k_ over tile `tile`: the range [fi_, fi_ + cnt_) of its records that reach the tile */
+#define P0_HIT_READ(k_, fi_, cnt_) do { \
+        const int r_ = lo + (k_) * P0_HIT_GROUP + gl; \
+        (fi_) = 0; (cnt_) = 0; \
+        if (r_ < hi) { \
+            const ReadRec x_ = rr[r_]; \
+            const int64_t s1_ = seg_off[r_ + 1]; \
+            if (s1_ > seg_off[r_] && x_.end > c0 && x_.pos <= c1) { \
+                const int k0_ = tile - ((x_.pos - p0) >> 6); \
+                const int64_t ro_ = rt_off[r_]; \
+                (fi_) = (int)(first[ro_ + k0_] & ~P0_FIRST_STARTS); \
+                if (tile < ((x_.end - 1 - p0) >> 6)) { \
+                    const uint32_t nx_ = first[ro_ + k0_ + 1]; \
+                    (cnt_) = (int)(nx_ & ~P0_FIRST_STARTS) - (fi_) + ((nx_ & P0_FIRST_STARTS) ? 0 : 1); \
+                } else (cnt_) = (int)(s1_ - (fi_)); \
+            } \
+        } } while (0)
+__global__ void __launch_bounds__(256)
+k_p0_hitcount(int n_tiles, int p0, const int32_t *__restrict__ tlo, const int32_t *__restrict__ thi,
+              const ReadRec *__restrict__ rr, const int64_t *__restrict__ seg_off, const int64_t *__restrict__ rt_off,
+              const uint32_t *__restrict__ first, int64_t *__restrict__ cnt_out)
+{
+    const int gl = threadIdx.x & (P0_HIT_GROUP - 1);
+    const int tile = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / P0_HIT_GROUP);
+    const bool live = tile < n_tiles;                       /* (every lane stays for the group's exchanges) */
+    const int c0 = p0 + tile * 64, c1 = c0 + 63;
+    const int lo = live ? tlo[tile] : 0, hi = live ? thi[tile] : 0;
+    int total = 0;
+    for (int k = 0; lo + k * P0_HIT_GROUP < hi; k++) {
+        int fi, cnt;
+        P0_HIT_READ(k, fi, cnt);
+        (void)fi;
+        total += cnt;
+    }
+    for (int d = 1; d < P0_HIT_GROUP; d <<= 1) total += __shfl_xor(total, d);
+    if (live && gl == 0) cnt_out[tile] = total;
+}
+__global__ void __launch_bounds__(256)
+k_p0_hitfill(int n_tiles, int p0, const int32_t *__restrict__ tlo, const int32_t *__restrict__ thi,
+             const ReadRec *__restrict__ rr, const int64_t *__restrict__ seg_off, const int64_t *__restrict__ rt_off,
+             const uint32_t *__restrict__ first, const int64_t *__restrict__ hit_off, int32_t *__restrict__ hits, int *__restrict__ err)
+{
+    const int gl = threadIdx.x & (P0_HIT_GROUP - 1);
+    const int tile = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / P0_HIT_GROUP);
+    const bool live = tile < n_tiles;
+    const int c0 = p0 + tile * 64, c1 = c0 + 63;
+    const int lo = live ? tlo[tile] : 0, hi = live ? thi[tile] : 0;
+    int64_t o = live ? hit_off[tile] : 0;
+    const int64_t oe = live ? hit_off[tile + 1] : 0;
+    int nround = (hi - lo + P0_HIT_GROUP - 1) / P0_HIT_GROUP;
+    for (int d = P0_HIT_GROUP; d < 64; d <<= 1) { const int v = __shfl_xor(nround, d); nround = v > nround ? v : nround; }   /* the wave's tiles in step */
+    const int glast = ((int)(threadIdx.x & 63) & ~(P0_HIT_GROUP - 1)) + P0_HIT_GROUP - 1;
+    for (int k = 0; k < nround; k++) {
+        int fi, cnt;
+        P0_HIT_READ(k, fi, cnt);
+        int inc = cnt;                                      /* inclusive prefix over the group's lanes */
+        for (int d = 1; d < P0_HIT_GROUP; d <<= 1) { const int v = __shfl_up(inc, d, P0_HIT_GROUP); if (gl >= d) inc += v; }
+        const int64_t w = o + (inc - cnt);
+        for (int j = 0; j < cnt; j++) if (w + j < oe) hits[w + j] = fi + j;
+        o += __shfl(inc, glast);
+    }
+    if (live && gl == 0 && o != oe) *err = 1;               /* (the two kernels walk the same ranges) */
+}
+#undef P0_HIT_READ
 
 /* keep-BED cursor per tile (k_columns2): the first region whose prefix-max of `end` reaches the tile's first column --
  * every column's own cursor (bed_preserve, kernels.h) is at or behind it.  Once per batch instead of a search per tile
