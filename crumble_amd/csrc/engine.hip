@@ -660,12 +660,13 @@ static int launch_pblock(crumble_hip *h, hipStream_t st, int64_t n_reads, int64_
 {
     if (nb <= 0 || n_reads <= 0) return CRUMBLE_OK;
     const DParams *P = h->d_params.as<DParams>();
-    /* short reads: one lane per read keeps the lanes of a wave evenly loaded (k_pb_chunkmm / k_pb_reads; measured on the
-     * 300x panel 0.78 ms against 1.3 for the word-parallel kernels, chr20 -9 equal); long reads: word-parallel
-     * (kernels.h, k_pb_words / k_pb_chains; HiFi 0.3 x config 4: 3.7 ms against 5.8 for k_pb_segments, 13.6 per read).
-     * Option "pblock" = reads | segments | words overrides the choice (tuning / tests: all give the same bytes). */
-    const bool per_read = mode ? mode == 1 : nb < 1024 * n_reads;
-    const bool words = mode ? mode == 3 : !per_read;
+    /* The word-parallel kernels (kernels.h: k_pb_words / k_pb_chains / k_pb_fillw) for every batch: in their second form
+     * they beat the per-read walk on short reads too (chr20 -9: 2.26 ms against 4.16 for k_pb_chunkmm / k_pb_reads /
+     * k_pb_fill, the 300x panel 0.73 against 0.78) as they did on long reads (config 4: 5.4 ms against 13.6 per read and
+     * 5.8 for k_pb_segments).  Option "pblock" = reads | segments | words forces one (tuning / tests: all give the same
+     * bytes). */
+    const bool per_read = mode == 1;
+    const bool words = mode == 0 || mode == 3;
     const int64_t nwords = (nb + 63) / 64;
     int e;
     if (per_read && h->hparams.any_preserve) {          /* -k/-K: the byte-wise kernel knows the skip rule */
