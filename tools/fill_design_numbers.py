@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Fills the @TAG@ placeholders of DESIGN.md section 8 from profiles/<tag>_bench_*.json (one-off helper of the
-round-end bookkeeping: the numbers in the text come from the committed bench lines, not from memory).
+"""Regenerates DESIGN.md section 8 from tools/design_section8.tmpl.md and profiles/<tag>_bench_*.json (round-end
+bookkeeping: the numbers in the text come from the committed bench lines, not from memory).
 Usage: python tools/fill_design_numbers.py r03f"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,6 +32,9 @@ r.update(WMS=f(w["ms_per_pass"], 0), WV=f(w["value_incl_pcie"], 1), WS1=f(w["sta
          WS3=f(w["stages_ms"]["d2h"], 0), WOV=f(w["overlap_wall_over_sum_of_stages"], 2))
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
+# section 8 is regenerated from its template (tools/design_section8.tmpl.md) every time
+a, b = s.index("## 8. Measured (MI355X;"), s.index("## 9. Host ingest / egress")
+s = s[:a] + open(os.path.join(ROOT, "tools", "design_section8.tmpl.md")).read().replace("@TAG@", tag) + s[b:]
 for key, val in r.items():
     s = s.replace(f"@{key}@", val)
 open(p, "w").write(s)
