@@ -72,6 +72,12 @@ struct crumble_hip {
     DevBuf d_out, d_rflags, d_keepf, d_b15f, d_blk_read, d_chunk_read, d_kept;
     DBatch B;
     bool have_batch = false, have_run = false;
+    /* what crumble_hip_expand() needs beyond the raw arrays on the device (set by the copy half of an upload) */
+    bool have_raw = false, raw_packed4 = false, raw_lowerr = false;
+    int32_t raw_tid = 0, raw_nbed = 0;
+    int raw_hot_mq = 0, raw_nslots = 0;
+    uint8_t raw_mqtab[256 + 64];
+    std::vector<int32_t> raw_pmax;
     unsigned persistent_blocks = 1024;
     bool col_perm = false;          /* k_columns<.., PERM>: picked per batch in crumble_hip_upload */
     /* crumble_hip_set_option(): kernel choices that never change a result (tests force every variant) */
@@ -360,20 +366,18 @@ static int prefix_max(crumble_hip *h, int32_t *v, int64_t n)
     return CRUMBLE_OK;
 }
 
-/* Copies the raw batch to the device and expands it there (p0_kernels.h): no per-read host work. */
-extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
+/* The copy half of an upload: the raw BAM-shaped arrays go to the device as they are, plus two sampled hints taken
+ * from the host arrays (the batch's mapq histogram, its mean base error): no per-read host work. */
+static int copy_raw(crumble_hip *h, const crumble_batch *b)
 {
-    if (!h || !b || b->n_reads < 0) return CRUMBLE_EINVAL;
-    HIPCHK(hipSetDevice(h->device));
     hipStream_t st = h->stream;
     const int64_t n = b->n_reads;
     const int64_t nb = n ? b->seq_off[n] : 0, nc = n ? b->cig_off[n] : 0;
     if (n >= (int64_t)INT_MAX - 64) { g_last_error = "more than 2^31 reads in one batch"; return CRUMBLE_EINVAL; }
     if (nb < 0 || nc < 0) { g_last_error = "negative total length"; return CRUMBLE_EINVAL; }
-    h->have_batch = false; h->have_run = false;
+    h->have_batch = false; h->have_run = false; h->have_raw = false; h->have_hits = false;
     int e;
 
-    HIPCHK(hipEventRecord(h->ev_up[0], st));
     /* 1. raw arrays */
     if ((e = up(h, h->d_pos, b->pos, n)) || (e = up(h, h->d_mapq, b->mapq, n)) || (e = up(h, h->d_flag, b->flag, n)) ||
         (e = up(h, h->d_seq_off, b->seq_off, n + 1)) || (e = up(h, h->d_cig_off, b->cig_off, n + 1)) ||
@@ -386,17 +390,64 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
         HIPCHK(hipMemsetAsync(h->d_bases.p, 0, BASE_FRONT_PAD, st));
     } else if ((e = up_padded(h, h->d_bases, b->bases, nb))) return e;
     if (n == 0) {                                   /* seq_off[0] may not exist on the host side */
-        const int64_t z = 0;
+        static const int64_t z = 0;
         if ((e = up(h, h->d_seq_off, &z, 1)) || (e = up(h, h->d_cig_off, &z, 1))) return e;
     }
     /* keep-regions: the prefix max of `end` drives the cursor emulation (bed_preserve) */
     const int n_bed = b->n_bed > 0 ? b->n_bed : 0;
-    std::vector<int32_t> pmax(n_bed ? n_bed : 1);
+    std::vector<int32_t> &pmax = h->raw_pmax;           /* (lives in the handle: the copy below is asynchronous) */
+    pmax.resize(n_bed ? n_bed : 1);
     for (int i = 0; i < n_bed; i++) pmax[i] = (i && pmax[i - 1] > b->bed_end[i]) ? pmax[i - 1] : b->bed_end[i];
     if ((e = up(h, h->d_bed_start, b->bed_start, n_bed)) || (e = up(h, h->d_bed_end, b->bed_end, n_bed)) ||
         (e = up(h, h->d_bed_pmax, pmax.data(), n_bed)))
         return e;
+    {   /* the mapq most reads carry: the column kernels keep a composed quality table for it in LDS; the next
+         * KC2_SLOTS most frequent ones get a row of k_columns2's compact adjustment table (their slot travels in
+         * SegRec.info); anything else is looked up in global memory.  Performance hints only. */
+        int64_t hist[256] = {0};
+        const int64_t hstep = n > 65536 ? n / 65536 : 1;     /* a sample: mapq values it misses are looked up in global memory */
+        for (int64_t i = 0; i < n; i += hstep) hist[b->mapq[i]]++;
+        int order[256], best = 0;
+        for (int i = 0; i < 256; i++) { order[i] = i; if (hist[i] > hist[best]) best = i; }
+        h->raw_hot_mq = best;
+        std::sort(order, order + 256, [&](int x, int y) { return hist[x] != hist[y] ? hist[x] > hist[y] : x < y; });
+        uint8_t *tab = h->raw_mqtab;
+        memset(tab, 255, 256); memset(tab + 256, 0, KC2_SLOTS);
+        int ns = 0;
+        for (int k = 0; k < 256 && ns < KC2_SLOTS; k++) {
+            const int m = order[k];
+            if (m == best || hist[m] == 0) continue;
+            tab[m] = (uint8_t)ns; tab[256 + ns] = (uint8_t)m; ns++;
+        }
+        h->raw_nslots = ns;
+    }
+    {   /* k_columns variant (a performance choice only; both give the same bits): per-column base classes pay
+         * when few base calls disagree with their column.  Estimate the batch's error rate from a sample of its
+         * qualities; measured break-even is near 2 % (see kernels.h).  Option "kcol" overrides. */
+        double esum = 0; int64_t cnt = 0;
+        double q2e[128];                                     /* (per call: handles may be used from several threads) */
+        for (int q = 0; q < 128; q++) q2e[q] = pow(10.0, -q / 10.0);
+        const int64_t step = nb > 65536 ? nb / 65536 : 1;
+        for (int64_t i = 0; i < nb; i += step, cnt++) esum += q2e[b->quals[i] & 127];
+        h->raw_lowerr = cnt > 0 && esum < 0.02 * (double)cnt;
+    }
+    h->raw_tid = b->tid; h->raw_nbed = n_bed; h->raw_packed4 = packed4;
+    h->n_reads = n; h->n_bases = nb; h->n_cigar = nc;
+    HIPCHK(hipEventRecord(h->ev_up[1], st));
+    h->have_raw = true;
+    return CRUMBLE_OK;
+}
 
+/* The device half: everything the column engine needs beyond the raw arrays is derived on the device (p0_kernels.h). */
+static int expand(crumble_hip *h)
+{
+    hipStream_t st = h->stream;
+    const int64_t n = h->n_reads, nb = h->n_bases, nc = h->n_cigar;
+    const int n_bed = h->raw_nbed;
+    const bool packed4 = h->raw_packed4;
+    const int32_t tid = h->raw_tid;
+    h->have_batch = false; h->have_run = false;
+    int e;
     HIPCHK(hipEventRecord(h->ev_up[1], st));
     /* 2. classify + validate + count */
     const int nchunks = (int)((n + P0_CHUNK - 1) / P0_CHUNK);
@@ -411,7 +462,7 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     P0Cnt tot = {0, 0, 0};
     int res[4] = {0, INT_MAX, INT_MIN, 0};
     if (n > 0) {
-        CRUMBLE_LAUNCH(k_p0_classify, nblk(n, 1024), 1024, st, n, (int)b->tid, h->d_pos.as<int32_t>(),
+        CRUMBLE_LAUNCH(k_p0_classify, nblk(n, 1024), 1024, st, n, (int)tid, h->d_pos.as<int32_t>(),
                              h->d_flag.as<uint16_t>(), h->d_seq_off.as<int64_t>(), h->d_cig_off.as<int64_t>(),
                              h->d_cigar.as<uint32_t>(), h->d_inplp.as<uint8_t>(), h->d_end.as<int32_t>(), cnt, d_err, d_minmax, nb, nc);
         CRUMBLE_LAUNCH_INDEP(k_p0_sorted, nblk(n, 256), 256, st, n, h->d_pos.as<int32_t>(), h->d_inplp.as<uint8_t>(), d_err);
@@ -444,43 +495,13 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     B.n_tiles = (B.L + 63) / 64;
     B.col_lo = 0; B.col_hi = B.L; B.stat_hi = B.L; B.pad1_ = 0;       /* the whole batch (crumble_hip_set_window narrows it) */
     h->windowed = false; h->phase = 0;
-    {   /* the mapq most reads carry: the column kernels keep a composed quality table for it in LDS; the next
-         * KC2_SLOTS most frequent ones get a row of k_columns2's compact adjustment table (their slot travels in
-         * SegRec.info); anything else is looked up in global memory.  Performance hints only. */
-        int64_t hist[256] = {0};
-        const int64_t hstep = n > 65536 ? n / 65536 : 1;     /* a sample: mapq values it misses are looked up in global memory */
-        for (int64_t i = 0; i < n; i += hstep) hist[b->mapq[i]]++;
-        int order[256], best = 0;
-        for (int i = 0; i < 256; i++) { order[i] = i; if (hist[i] > hist[best]) best = i; }
-        B.hot_mq = best;
-        std::sort(order, order + 256, [&](int x, int y) { return hist[x] != hist[y] ? hist[x] > hist[y] : x < y; });
-        uint8_t tab[256 + KC2_SLOTS];
-        memset(tab, 255, 256); memset(tab + 256, 0, KC2_SLOTS);
-        int ns = 0;
-        for (int k = 0; k < 256 && ns < KC2_SLOTS; k++) {
-            const int m = order[k];
-            if (m == best || hist[m] == 0) continue;
-            tab[m] = (uint8_t)ns; tab[256 + ns] = (uint8_t)m; ns++;
-        }
-        B.n_slots = ns;
-        if ((e = h->d_mqslot.reserve(sizeof tab))) return e;
-        HIPCHK(hipMemcpyAsync(h->d_mqslot.p, tab, sizeof tab, hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));               /* tab is a stack buffer */
-        B.slot_mq = h->d_mqslot.as<uint8_t>() + 256;
-    }
-    {   /* k_columns variant (a performance choice only; both give the same bits): per-column base classes pay
-         * when few base calls disagree with their column.  Estimate the batch's error rate from a sample of its
-         * qualities; measured break-even is near 2 % (see kernels.h).  Option "kcol" overrides. */
-        double esum = 0; int64_t cnt = 0;
-        double q2e[128];                                     /* (per call: handles may be used from several threads) */
-        for (int q = 0; q < 128; q++) q2e[q] = pow(10.0, -q / 10.0);
-        const int64_t step = nb > 65536 ? nb / 65536 : 1;
-        for (int64_t i = 0; i < nb; i += step, cnt++) esum += q2e[b->quals[i] & 127];
-        h->col_perm = cnt > 0 && esum < 0.02 * (double)cnt;
-        if (h->opt_kcol == 1 || h->opt_kcol == 2) h->col_perm = h->opt_kcol == 2;
-    }
+    B.hot_mq = h->raw_hot_mq; B.n_slots = h->raw_nslots;
+    if ((e = h->d_mqslot.reserve(sizeof h->raw_mqtab))) return e;
+    HIPCHK(hipMemcpyAsync(h->d_mqslot.p, h->raw_mqtab, sizeof h->raw_mqtab, hipMemcpyHostToDevice, st));   /* (the table lives in the handle) */
+    B.slot_mq = h->d_mqslot.as<uint8_t>() + 256;
+    h->col_perm = h->raw_lowerr;
+    if (h->opt_kcol == 1 || h->opt_kcol == 2) h->col_perm = h->opt_kcol == 2;
     h->b_kcol = h->opt_kcol; h->b_pblock = h->opt_pblock;
-    h->n_reads = n; h->n_bases = nb; h->n_cigar = nc;
     h->n_segrec = tot.nseg; h->n_slow = tot.nslow;  /* upper bound; the exact count is d_nslow */
     h->n_general_max = tot.ncix / CIX_UNIT;         /* upper bound; the exact count is d_nslow[1] */
 
@@ -645,6 +666,23 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     HIPCHK(hipEventElapsedTime(&h->up_p0_ms, h->ev_up[1], h->ev_up[2]));
     h->have_batch = true;
     return CRUMBLE_OK;
+}
+
+extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
+{
+    if (!h || !b || b->n_reads < 0) return CRUMBLE_EINVAL;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventRecord(h->ev_up[0], h->stream));
+    int e;
+    if ((e = copy_raw(h, b))) return e;
+    return expand(h);
+}
+
+extern "C" int crumble_hip_expand(crumble_hip *h)
+{
+    if (!h || !h->have_raw) { g_last_error = "crumble_hip_expand: no raw batch on the device (crumble_hip_upload first)"; return CRUMBLE_EINVAL; }
+    HIPCHK(hipSetDevice(h->device));
+    return expand(h);
 }
 
 /* -------------------------------------------------------------------- run */

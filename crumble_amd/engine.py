@@ -61,6 +61,7 @@ def load_library(path=None, make_default=True):
         "crumble_hip_set_option": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
         "crumble_hip_contig": (C.c_int, [vp, C.POINTER(Batch), vp, vp, vp]),
         "crumble_hip_upload": (C.c_int, [vp, C.POINTER(Batch)]),
+        "crumble_hip_expand": (C.c_int, [vp]),
         "crumble_hip_run": (C.c_int, [vp]),
         "crumble_hip_set_window": (C.c_int, [vp, vp]),
         "crumble_carry_init": (None, [vp]),
@@ -104,7 +105,7 @@ EXPORTED = [
     "crumble_params_default", "crumble_params_preset", "crumble_params_tech",
     "crumble_params_keep_quals", "crumble_init_bins", "crumble_bed_collapse",
     "crumble_hip_create", "crumble_hip_destroy", "crumble_hip_set_option", "crumble_hip_contig",
-    "crumble_hip_upload", "crumble_hip_run", "crumble_hip_download",
+    "crumble_hip_upload", "crumble_hip_expand", "crumble_hip_run", "crumble_hip_download",
     "crumble_hip_set_window", "crumble_carry_init", "crumble_hip_run_columns", "crumble_hip_run_depth",
     "crumble_hip_run_triggers", "crumble_hip_run_fold", "crumble_hip_run_finish",
     "crumble_hip_kernel_times", "crumble_hip_upload_times", "crumble_hip_stats_devptr", "crumble_hip_stats_reset",
@@ -179,6 +180,10 @@ class Engine:
         self._batch = hb
         self._bstruct = hb.struct()
         self._chk(self.L.crumble_hip_upload(self.h, C.byref(self._bstruct)), "upload")
+
+    def expand(self):
+        """the device half of upload() again, on the raw arrays already on the device"""
+        self._chk(self.L.crumble_hip_expand(self.h), "expand")
 
     def run(self):
         self._chk(self.L.crumble_hip_run(self.h), "run")

@@ -182,6 +182,10 @@ int crumble_hip_contig(crumble_hip *h, const crumble_batch *b,
 /* The three stages separately, so callers (and bench.py) can keep a batch
  * resident in HBM and time only the kernels. */
 int crumble_hip_upload(crumble_hip *h, const crumble_batch *b);
+/* The device half of crumble_hip_upload() once more, on the raw arrays the last upload left on the device: routing and
+ * validation, op tables, tile lists, unpacked bases (what pileup_callback + htslib's bam_plp_auto do per read,
+ * snp_score.c:1113-1153).  bench.py times this together with crumble_hip_run(): a contig pays both, once. */
+int crumble_hip_expand(crumble_hip *h);
 int crumble_hip_run(crumble_hip *h);      /* asynchronous launches + one sync */
 int crumble_hip_download(crumble_hip *h, uint8_t *qual_out,
                          uint8_t *read_flags_out, int64_t *stats);
