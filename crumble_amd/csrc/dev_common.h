@@ -141,8 +141,8 @@ struct DBatch {
     const int32_t *stile_lo, *stile_hi;   /* candidate SegRec range per 64-column tile */
     const int64_t *hit_off;               /* long-read batches: [n_tiles+1] the tile's slice of hits[] (k_p0_hitfill) */
     const int32_t *hits;                  /* SegRec indices of the records that reach a tile, file order */
-    const int32_t *unit_first;            /* [n_units+1] first tile of every KCOL_UNIT-sized slice of the tiles' cost prefix */
-    int32_t n_units;
+    int32_t unit_tiles;                   /* tiles per unit of the column kernels' work counter (set per launch) */
+    int32_t n_units;                      /* ceil(n_tiles / unit_tiles) */
     int32_t n_slots;                      /* mapq values (other than hot_mq) with a slot in k_columns2's compact adjustment table */
     const uint8_t *slot_mq;               /* [n_slots] slot -> mapq, most frequent first; SegRec.info carries the slot */
     const uint8_t *bases, *quals;
@@ -198,8 +198,15 @@ struct Epoch {              /* running-average state of snp:1490-1491,1684   */
 #define MAX_EPOCHS 8192
 
 #define MAX_DEPTH_COL 20000     /* MAX_DEPTH snp:92   */
-#ifndef KCOL_UNIT
-#define KCOL_UNIT     256       /* estimated cost (~candidate records) handed to a wave per grab of k_columns' work counter */
+/* tiles handed out per grab of the column kernels' work counter.  k_columns2's workgroups deal a unit's tiles to their
+ * waves one by one, so the unit only sets how often the global counter is touched and how close together the tiles in
+ * flight on a CU lie; k_columns gives a wave the whole unit.  (Rounds 1-3 cut units of equal estimated cost from a prefix
+ * sum of per-tile costs: three more kernels and a read-back per upload for a balance the per-tile dealing gives anyway.) */
+#ifndef KCOL2_UTILES
+#define KCOL2_UTILES  8
+#endif
+#ifndef KCOL1_UTILES
+#define KCOL1_UTILES  2
 #endif
 #define MASK_WIN_DEV  250       /* MASK_WIN  snp:1229 */
 #define STR_CAP       640       /* live repeats per window   */

@@ -38,7 +38,10 @@ extern "C" const char *crumble_hip_last_error(void) { return g_last_error.c_str(
 /* grow-only device buffer */
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
+    bool owned = true;              /* false: a view into another buffer (the raw arena of an upload) */
+    void view(void *ptr, size_t n) { if (owned && p) (void)hipFree(p); p = ptr; cap = n; owned = false; }
     int reserve(size_t n) {
+        if (!owned) { p = nullptr; cap = 0; owned = true; }
         if (n <= cap && p) return CRUMBLE_OK;
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
@@ -47,7 +50,7 @@ struct DevBuf {
         cap = want;
         return CRUMBLE_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p && owned) (void)hipFree(p); p = nullptr; cap = 0; owned = true; }
     template <class T> T *as() const { return (T *)p; }
 };
 
@@ -60,6 +63,10 @@ struct crumble_hip {
     crumble_params params;
     DParams hparams;
     DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc, d_mqslot;
+    DevBuf d_raw;                   /* arena of the raw arrays of an upload: d_pos, d_mapq, d_flag, d_seq_off, d_cig_off, d_cigar, d_quals,
+                                     * d_bases4 (or d_bases), d_bed_*, d_mqslot are views into it */
+    void *stage = nullptr;          /* page-locked staging buffer of small uploads (RAW_STAGE_MAX bytes) */
+    bool late_pending = false;      /* an expansion is in flight whose late errors (pinned + 128) have not been looked at */
     /* batch (inputs) */
     DevBuf d_genlist, d_vrec, d_pbdirty, d_pbcarry, d_pbchg, d_bases4, d_ufirst, d_tcum, d_tpart, d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
            d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax, d_tile_bed, d_hitoff, d_hits, d_rtoff, d_first;
@@ -293,6 +300,8 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
     for (DevBuf *b : all) b->release();
     if (h->events_ok) { for (int i = 0; i <= MAX_STAGES; i++) (void)hipEventDestroy(h->ev[i]); for (int i = 0; i < 3; i++) (void)hipEventDestroy(h->ev_up[i]); }
     if (h->pinned) (void)hipHostFree(h->pinned);
+    if (h->stage) (void)hipHostFree(h->stage);
+    h->d_raw.release();
     for (auto &l : h->dl) {
         for (int i = 0; i < 2; i++) { if (l.buf[i]) (void)hipHostFree(l.buf[i]); if (l.ev[i]) (void)hipEventDestroy(l.ev[i]); }
         if (l.st) (void)hipStreamDestroy(l.st);
@@ -332,27 +341,7 @@ extern "C" int crumble_hip_set_option(crumble_hip *h, const char *name, const ch
 /* ------------------------------------------------------------- P0 expand */
 static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b > 0 ? (n + b - 1) / b : 1); }
 
-template <class T>
-static int up(crumble_hip *h, DevBuf &d, const T *src, size_t n)
-{
-    int e = d.reserve((n ? n : 1) * sizeof(T) + 64);      /* slack: kernels read whole 16-byte vectors */
-    if (e) return e;
-    if (n) HIPCHK(hipMemcpyAsync(d.p, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
-    return CRUMBLE_OK;
-}
-
-/* bases / qualities: BASE_FRONT_PAD zeroed bytes in front (k_columns2 loads the whole 16-column segment that
- * holds a read's first aligned base) */
-static int up_padded(crumble_hip *h, DevBuf &d, const uint8_t *src, size_t n)
-{
-    int e = d.reserve(n + 2 * BASE_FRONT_PAD + 64);
-    if (e) return e;
-    HIPCHK(hipMemsetAsync(d.p, 0, BASE_FRONT_PAD, h->stream));
-    if (n) HIPCHK(hipMemcpyAsync((uint8_t *)d.p + BASE_FRONT_PAD, src, n, hipMemcpyHostToDevice, h->stream));
-    return CRUMBLE_OK;
-}
-
-/* in-place inclusive prefix max of an int32 device array (chunked; used for the search keys) */
+/* in-place inclusive prefix max of an int32 device array (chunked; the fold's bounds) */
 static int prefix_max(crumble_hip *h, int32_t *v, int64_t n)
 {
     if (n <= 0) return CRUMBLE_OK;
@@ -366,8 +355,12 @@ static int prefix_max(crumble_hip *h, int32_t *v, int64_t n)
     return CRUMBLE_OK;
 }
 
-/* The copy half of an upload: the raw BAM-shaped arrays go to the device as they are, plus two sampled hints taken
- * from the host arrays (the batch's mapq histogram, its mean base error): no per-read host work. */
+/* The copy half of an upload: the raw BAM-shaped arrays go to the device as they are, into ONE device arena
+ * (d_raw; d_pos, d_mapq ... are views into it), plus two sampled hints taken from the host arrays (the batch's mapq
+ * histogram, its mean base error): no per-read host work.  A small batch is packed into a page-locked staging buffer
+ * and crosses in one copy (ten copies of a few kilobytes each were a third of a small contig's fixed cost); a large
+ * one is copied array by array straight from the caller's memory. */
+#define RAW_STAGE_MAX ((size_t)4 << 20)
 static int copy_raw(crumble_hip *h, const crumble_batch *b)
 {
     hipStream_t st = h->stream;
@@ -376,31 +369,10 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
     if (n >= (int64_t)INT_MAX - 64) { g_last_error = "more than 2^31 reads in one batch"; return CRUMBLE_EINVAL; }
     if (nb < 0 || nc < 0) { g_last_error = "negative total length"; return CRUMBLE_EINVAL; }
     h->have_batch = false; h->have_run = false; h->have_raw = false; h->have_hits = false;
-    int e;
-
-    /* 1. raw arrays */
-    if ((e = up(h, h->d_pos, b->pos, n)) || (e = up(h, h->d_mapq, b->mapq, n)) || (e = up(h, h->d_flag, b->flag, n)) ||
-        (e = up(h, h->d_seq_off, b->seq_off, n + 1)) || (e = up(h, h->d_cig_off, b->cig_off, n + 1)) ||
-        (e = up(h, h->d_cigar, b->cigar, nc)) || (e = up_padded(h, h->d_quals, b->quals, nb)))
-        return e;
-    const bool packed4 = b->bases4 != nullptr;      /* BAM-packed bases: half the bytes over PCIe, unpacked by k_p0_unpack4 */
+    const bool packed4 = b->bases4 != nullptr;      /* BAM-packed bases: half the bytes over PCIe, unpacked by k_p0_bases */
     if (!packed4 && !b->bases && nb > 0) { g_last_error = "crumble_batch: neither bases nor bases4"; return CRUMBLE_EINVAL; }
-    if (packed4) {
-        if ((e = up(h, h->d_bases4, b->bases4, (size_t)CRUMBLE_BASES4_SIZE(nb, n))) || (e = h->d_bases.reserve((size_t)nb + 2 * BASE_FRONT_PAD + 64))) return e;
-        HIPCHK(hipMemsetAsync(h->d_bases.p, 0, BASE_FRONT_PAD, st));
-    } else if ((e = up_padded(h, h->d_bases, b->bases, nb))) return e;
-    if (n == 0) {                                   /* seq_off[0] may not exist on the host side */
-        static const int64_t z = 0;
-        if ((e = up(h, h->d_seq_off, &z, 1)) || (e = up(h, h->d_cig_off, &z, 1))) return e;
-    }
-    /* keep-regions: the prefix max of `end` drives the cursor emulation (bed_preserve) */
     const int n_bed = b->n_bed > 0 ? b->n_bed : 0;
-    std::vector<int32_t> &pmax = h->raw_pmax;           /* (lives in the handle: the copy below is asynchronous) */
-    pmax.resize(n_bed ? n_bed : 1);
-    for (int i = 0; i < n_bed; i++) pmax[i] = (i && pmax[i - 1] > b->bed_end[i]) ? pmax[i - 1] : b->bed_end[i];
-    if ((e = up(h, h->d_bed_start, b->bed_start, n_bed)) || (e = up(h, h->d_bed_end, b->bed_end, n_bed)) ||
-        (e = up(h, h->d_bed_pmax, pmax.data(), n_bed)))
-        return e;
+    int e;
     {   /* the mapq most reads carry: the column kernels keep a composed quality table for it in LDS; the next
          * KC2_SLOTS most frequent ones get a row of k_columns2's compact adjustment table (their slot travels in
          * SegRec.info); anything else is looked up in global memory.  Performance hints only. */
@@ -431,6 +403,55 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
         for (int64_t i = 0; i < nb; i += step, cnt++) esum += q2e[b->quals[i] & 127];
         h->raw_lowerr = cnt > 0 && esum < 0.02 * (double)cnt;
     }
+    /* keep-regions: the prefix max of `end` drives the cursor emulation (bed_preserve) */
+    std::vector<int32_t> &pmax = h->raw_pmax;           /* (lives in the handle: the copy below is asynchronous) */
+    pmax.resize(n_bed ? n_bed : 1);
+    for (int i = 0; i < n_bed; i++) pmax[i] = (i && pmax[i - 1] > b->bed_end[i]) ? pmax[i - 1] : b->bed_end[i];
+
+    /* the arena: every array 256-byte aligned with 64 bytes of slack behind it (kernels read whole 16-byte vectors);
+     * qualities (and one-byte-per-base bases) carry BASE_FRONT_PAD zeroed bytes in front: k_columns2 loads the whole
+     * 16-column segment that holds a read's first aligned base */
+    static const int64_t zero64 = 0;
+    struct Item { DevBuf *d; const void *src; size_t bytes, front; size_t off; };
+    const size_t b4bytes = packed4 ? (size_t)CRUMBLE_BASES4_SIZE(nb, n) : 0;
+    Item items[] = {
+        {&h->d_pos, b->pos, (size_t)n * 4, 0, 0}, {&h->d_mapq, b->mapq, (size_t)n, 0, 0}, {&h->d_flag, b->flag, (size_t)n * 2, 0, 0},
+        {&h->d_seq_off, n ? (const void *)b->seq_off : (const void *)&zero64, (size_t)(n + 1) * 8, 0, 0},
+        {&h->d_cig_off, n ? (const void *)b->cig_off : (const void *)&zero64, (size_t)(n + 1) * 8, 0, 0},
+        {&h->d_cigar, b->cigar, (size_t)nc * 4, 0, 0},
+        {&h->d_quals, b->quals, (size_t)nb, BASE_FRONT_PAD, 0},
+        {packed4 ? &h->d_bases4 : &h->d_bases, packed4 ? (const void *)b->bases4 : (const void *)b->bases, packed4 ? b4bytes : (size_t)nb, packed4 ? 0 : (size_t)BASE_FRONT_PAD, 0},
+        {&h->d_bed_start, b->bed_start, (size_t)n_bed * 4, 0, 0}, {&h->d_bed_end, b->bed_end, (size_t)n_bed * 4, 0, 0},
+        {&h->d_bed_pmax, pmax.data(), (size_t)n_bed * 4, 0, 0}, {&h->d_mqslot, h->raw_mqtab, sizeof h->raw_mqtab, 0, 0},
+    };
+    size_t total = 0;
+    for (Item &it : items) { it.off = total; total += (it.front + it.bytes + 2 * BASE_FRONT_PAD + 64 + 255) & ~(size_t)255; }
+    if ((e = h->d_raw.reserve(total))) return e;
+    uint8_t *base = h->d_raw.as<uint8_t>();
+    for (Item &it : items) it.d->view(base + it.off, it.front + it.bytes + 2 * BASE_FRONT_PAD + 64);
+    if (packed4) {                                       /* the one-byte-per-base form is made on the device */
+        if (h->d_bases.owned == false) h->d_bases = DevBuf();
+        if ((e = h->d_bases.reserve((size_t)nb + 2 * BASE_FRONT_PAD + 64))) return e;
+        HIPCHK(hipMemsetAsync(h->d_bases.p, 0, BASE_FRONT_PAD, st));
+    }
+    bool staged = false;
+    if (total <= RAW_STAGE_MAX) {
+        if (!h->stage && hipHostMalloc(&h->stage, RAW_STAGE_MAX, 0) != hipSuccess) h->stage = nullptr;
+        if (h->stage) {
+            uint8_t *sg = (uint8_t *)h->stage;
+            for (Item &it : items) {
+                if (it.front) memset(sg + it.off, 0, it.front);
+                if (it.bytes) memcpy(sg + it.off + it.front, it.src, it.bytes);
+            }
+            HIPCHK(hipMemcpyAsync(base, sg, total, hipMemcpyHostToDevice, st));
+            staged = true;
+        }
+    }
+    if (!staged)
+        for (Item &it : items) {
+            if (it.front) HIPCHK(hipMemsetAsync(base + it.off, 0, it.front, st));
+            if (it.bytes) HIPCHK(hipMemcpyAsync(base + it.off + it.front, it.src, it.bytes, hipMemcpyHostToDevice, st));
+        }
     h->raw_tid = b->tid; h->raw_nbed = n_bed; h->raw_packed4 = packed4;
     h->n_reads = n; h->n_bases = nb; h->n_cigar = nc;
     HIPCHK(hipEventRecord(h->ev_up[1], st));
@@ -438,53 +459,66 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
     return CRUMBLE_OK;
 }
 
-/* The device half: everything the column engine needs beyond the raw arrays is derived on the device (p0_kernels.h). */
-static int expand(crumble_hip *h)
+/* The device half: everything the column engine needs beyond the raw arrays is derived on the device (p0_kernels.h).
+ * One read-back in the middle (the sizes of the expanded tables; the routing / offset / length errors), the rest is
+ * asynchronous; `wait`: also wait for the end and report the late errors (coordinate order, tile span). */
+static int expand_late_errors(crumble_hip *h)
+{
+    const int *res = (const int *)((const char *)h->pinned + 128);
+    switch (res[0]) {
+    case 0: break;
+    case P0_ERR_UNSORTED: return CRUMBLE_EUNSORTED;                      /* snp:1075 */
+    case P0_ERR_SPAN: g_last_error = "the reads over one 64-column tile span more than 3.7 GB of bases"; return CRUMBLE_EINVAL;
+    case P0_ERR_QUAL: g_last_error = "input quality >= 128 (SURVEY.md Q13)"; return CRUMBLE_EINVAL;
+    default: g_last_error = "internal: batch expansion failed"; return CRUMBLE_EOVERFLOW;
+    }
+    if (res[1]) { g_last_error = "internal: tile hit lists inconsistent"; return CRUMBLE_EOVERFLOW; }
+    return CRUMBLE_OK;
+}
+static int expand(crumble_hip *h, bool wait)
 {
     hipStream_t st = h->stream;
     const int64_t n = h->n_reads, nb = h->n_bases, nc = h->n_cigar;
     const int n_bed = h->raw_nbed;
     const bool packed4 = h->raw_packed4;
     const int32_t tid = h->raw_tid;
-    h->have_batch = false; h->have_run = false;
+    h->have_batch = false; h->have_run = false; h->have_hits = false; h->have_vrec = false; h->late_pending = false;
     int e;
     HIPCHK(hipEventRecord(h->ev_up[1], st));
-    /* 2. classify + validate + count */
-    const int nchunks = (int)((n + P0_CHUNK - 1) / P0_CHUNK);
+    /* 1. classify + validate + count */
+    const int nblocks = (int)((n + P0_CHUNK - 1) / P0_CHUNK);
     if ((e = h->d_inplp.reserve((size_t)(n + 1))) || (e = h->d_end.reserve((size_t)(n + 1) * 4)) ||
-        (e = h->d_p0cnt.reserve((size_t)(n + 1) * sizeof(P0Cnt))) ||
-        (e = h->d_p0part.reserve((size_t)(nchunks + 2) * sizeof(P0Cnt))) || (e = h->d_misc.reserve(256)))
+        (e = h->d_p0cnt.reserve((size_t)(n + 1) * sizeof(P0Cnt32))) ||
+        (e = h->d_p0part.reserve((size_t)(nblocks + 2) * sizeof(P0Part))) || (e = h->d_misc.reserve(256)))
         return e;
-    int *d_err = h->d_misc.as<int>() + 8, *d_minmax = d_err + 1, *d_nslow = d_err + 3;
-    const int init[5] = {0, INT_MAX, INT_MIN, 0, 0};        /* error, min pos, max end, n_slow, n_general */
+    int *d_err = h->d_misc.as<int>() + 8, *d_minmax = d_err + 1, *d_nslow = d_err + 3, *d_herr = h->d_misc.as<int>() + 15;
+    static const int init[8] = {0, INT_MAX, INT_MIN, 0, 0, 0, 0, 0};   /* error, min pos, max end, n_slow, n_general, -, -, hit-list check */
     HIPCHK(hipMemcpyAsync(d_err, init, sizeof init, hipMemcpyHostToDevice, st));
-    P0Cnt *cnt = h->d_p0cnt.as<P0Cnt>(), *part = h->d_p0part.as<P0Cnt>();
-    P0Cnt tot = {0, 0, 0};
-    int res[4] = {0, INT_MAX, INT_MIN, 0};
+    P0Cnt32 *cnt = h->d_p0cnt.as<P0Cnt32>();
+    P0Part *part = h->d_p0part.as<P0Part>();
+    P0Part tot;
+    memset(&tot, 0, sizeof tot);
+    int res[3] = {0, INT_MAX, INT_MIN};
     if (n > 0) {
-        CRUMBLE_LAUNCH(k_p0_classify, nblk(n, 1024), 1024, st, n, (int)tid, h->d_pos.as<int32_t>(),
-                             h->d_flag.as<uint16_t>(), h->d_seq_off.as<int64_t>(), h->d_cig_off.as<int64_t>(),
-                             h->d_cigar.as<uint32_t>(), h->d_inplp.as<uint8_t>(), h->d_end.as<int32_t>(), cnt, d_err, d_minmax, nb, nc);
-        CRUMBLE_LAUNCH_INDEP(k_p0_sorted, nblk(n, 256), 256, st, n, h->d_pos.as<int32_t>(), h->d_inplp.as<uint8_t>(), d_err);
-        if (nb > 0) CRUMBLE_LAUNCH_INDEP(k_p0_basequal, nblk((nb + 15) / 16, 256), 256, st, nb, h->d_bases.as<uint8_t>() + BASE_FRONT_PAD,
-                                         h->d_quals.as<uint8_t>() + BASE_FRONT_PAD, d_err, packed4 ? 0 : 1);
-        CRUMBLE_LAUNCH_INDEP(k_p0scan_reduce, nblk(nchunks, 64), 64, st, n, cnt, part, nchunks);
-        CRUMBLE_LAUNCH(k_p0scan_partials, 1, 1024, st, part, nchunks);
-        CRUMBLE_LAUNCH_INDEP(k_p0scan_apply, nblk(nchunks, 64), 64, st, n, cnt, part, nchunks);
-        HIPCHK(hipMemcpyAsync(&tot, part + nchunks, sizeof tot, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(res, d_err, sizeof res, hipMemcpyDeviceToHost, st));
-    }
-    HIPCHK(hipStreamSynchronize(st));               /* sizes of the expanded tables */
+        CRUMBLE_LAUNCH(k_p0_classify, nblk(n, P0_CHUNK), P0_CHUNK, st, n, (int)tid, h->d_pos.as<int32_t>(),
+                       h->d_flag.as<uint16_t>(), h->d_seq_off.as<int64_t>(), h->d_cig_off.as<int64_t>(),
+                       h->d_cigar.as<uint32_t>(), h->d_inplp.as<uint8_t>(), h->d_end.as<int32_t>(), cnt, part, d_err, d_minmax, nb, nc);
+        CRUMBLE_LAUNCH(k_p0_mid, 1, 1024, st, part, nblocks);
+        HIPCHK(hipMemcpyAsync(h->pinned, part + nblocks, sizeof tot, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync((char *)h->pinned + 64, d_err, sizeof res, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));               /* sizes of the expanded tables (and: the caller may free its host buffers) */
+        memcpy(&tot, h->pinned, sizeof tot);
+        memcpy(res, (char *)h->pinned + 64, sizeof res);
+    } else HIPCHK(hipStreamSynchronize(st));
     switch (res[0]) {
     case 0: break;
-    case P0_ERR_UNSORTED: return CRUMBLE_EUNSORTED;                      /* snp:1075 */
-    case P0_ERR_QUAL:  g_last_error = "input quality >= 128 (SURVEY.md Q13)"; return CRUMBLE_EINVAL;
     case P0_ERR_QLEN:  g_last_error = "CIGAR query length differs from l_qseq"; return CRUMBLE_EINVAL;
     case P0_ERR_COORD: g_last_error = "coordinate out of range"; return CRUMBLE_EINVAL;
     default:           g_last_error = "negative or oversized read / cigar length"; return CRUMBLE_EINVAL;
     }
+    const int64_t tot_ncix = tot.ncixu * CIX_UNIT;
     if (tot.nseg >= (int64_t)INT_MAX - 64) { g_last_error = "too many CIGAR segments in one batch"; return CRUMBLE_EINVAL; }
-    if (tot.ncix / CIX_UNIT >= (int64_t)0xfffffff0u) { g_last_error = "base->column table too large"; return CRUMBLE_EINVAL; }
+    if (tot.ncixu >= (int64_t)0xfffffff0u) { g_last_error = "base->column table too large"; return CRUMBLE_EINVAL; }
 
     DBatch &B = h->B;
     memset(&B, 0, sizeof(B));
@@ -496,75 +530,70 @@ static int expand(crumble_hip *h)
     B.col_lo = 0; B.col_hi = B.L; B.stat_hi = B.L; B.pad1_ = 0;       /* the whole batch (crumble_hip_set_window narrows it) */
     h->windowed = false; h->phase = 0;
     B.hot_mq = h->raw_hot_mq; B.n_slots = h->raw_nslots;
-    if ((e = h->d_mqslot.reserve(sizeof h->raw_mqtab))) return e;
-    HIPCHK(hipMemcpyAsync(h->d_mqslot.p, h->raw_mqtab, sizeof h->raw_mqtab, hipMemcpyHostToDevice, st));   /* (the table lives in the handle) */
     B.slot_mq = h->d_mqslot.as<uint8_t>() + 256;
     h->col_perm = h->raw_lowerr;
     if (h->opt_kcol == 1 || h->opt_kcol == 2) h->col_perm = h->opt_kcol == 2;
     h->b_kcol = h->opt_kcol; h->b_pblock = h->opt_pblock;
     h->n_segrec = tot.nseg; h->n_slow = tot.nslow;  /* upper bound; the exact count is d_nslow */
-    h->n_general_max = tot.ncix / CIX_UNIT;         /* upper bound; the exact count is d_nslow[1] */
+    h->n_general_max = tot.ncixu;                   /* upper bound; the exact count is d_nslow[1] */
 
-    /* 3. expanded tables */
+    /* 2. expanded tables */
     const size_t ns = (size_t)tot.nseg;
+    const bool multi = tot.nseg > n + n / 2;        /* long reads: many ops per read */
     /* long reads through the packed replay need no base -> column table (4 B per base of every multi-op read) */
     h->batch_flat = h->opt_replay == 1;
-    const bool vrec_path = tot.nseg > n + n / 2 && h->packed_ok && !h->batch_flat && tot.nseg + n < (int64_t)INT_MAX - 64;
-    const int want_cix = vrec_path ? 0 : 1;
+    const bool vrec_path = multi && h->packed_ok && !h->batch_flat && tot.nseg + n < (int64_t)INT_MAX - 64;
+    const bool want_cix = !vrec_path;
     const size_t nblkb = (size_t)(nb / 64 + 1);
+    const int64_t nch = (nb + 15) / 16;
     if ((e = h->d_segs.reserve((ns + 1) * sizeof(Seg))) || (e = h->d_sr.reserve((ns + 1) * sizeof(SegRec))) ||
-        (e = h->d_sr_ppos.reserve((ns + 1) * 4)) || (e = h->d_sr_pend.reserve((ns + 1) * 4)) ||
         (e = h->d_rr.reserve((size_t)(n + 1) * sizeof(ReadRec))) || (e = h->d_seg_off.reserve((size_t)(n + 2) * 8)) ||
-        (e = h->d_cix.reserve((want_cix ? (size_t)tot.ncix + 1 : 1) * 4)) ||
-        (e = h->d_genlist.reserve(((size_t)(tot.ncix / CIX_UNIT) + 1) * 4)) ||     /* every general read with bases has >= one unit */ (e = h->d_slow_g.reserve(((size_t)tot.nslow + 1) * 8)) ||
+        (e = h->d_cix.reserve((want_cix ? (size_t)tot_ncix + 1 : 1) * 4)) ||
+        (e = h->d_genlist.reserve(((size_t)tot.ncixu + 1) * 4)) ||     /* every general read with bases has >= one unit */
+        (e = h->d_slow_g.reserve(((size_t)tot.nslow + 1) * 8)) ||
         (e = h->d_slow_r.reserve(((size_t)tot.nslow + 1) * 4)) || (e = h->d_kpos.reserve((size_t)(n + 1) * 4)) ||
         (e = h->d_kend.reserve((size_t)(n + 1) * 4)) || (e = h->d_tile_lo.reserve((size_t)(B.n_tiles + 1) * 4)) ||
         (e = h->d_tile_hi.reserve((size_t)(B.n_tiles + 1) * 4)) || (e = h->d_stile_lo.reserve((size_t)(B.n_tiles + 1) * 4)) ||
-        (e = h->d_stile_hi.reserve((size_t)(B.n_tiles + 1) * 4)) || (e = h->d_blk_read.reserve((nblkb + 1) * 4)))
+        (e = h->d_stile_hi.reserve((size_t)(B.n_tiles + 1) * 4)) || (e = h->d_blk_read.reserve((nblkb + 1) * 4)) ||
+        (e = h->d_chunk_read.reserve((size_t)(nch + 2) * 4)) || (e = h->d_tile_bed.reserve((size_t)(n_bed ? B.n_tiles + 1 : 1) * 4)) ||
+        (e = h->d_vrec.reserve((vrec_path ? (size_t)(tot.nseg + n + 1) : 1) * sizeof(VRec))))
         return e;
     if (n == 0) HIPCHK(hipMemsetAsync(h->d_seg_off.p, 0, 16, st));
     if (n > 0) {
-        CRUMBLE_LAUNCH_INDEP(k_p0_fill, nblk(n, 256), 256, st, n, B.p0, h->d_pos.as<int32_t>(), h->d_mapq.as<uint8_t>(),
-                             h->d_seq_off.as<int64_t>(), h->d_cig_off.as<int64_t>(), h->d_cigar.as<uint32_t>(),
-                             h->d_inplp.as<uint8_t>(), h->d_end.as<int32_t>(), cnt, part + nchunks,
-                             h->d_segs.as<Seg>(), h->d_sr.as<SegRec>(), h->d_sr_ppos.as<int32_t>(), h->d_sr_pend.as<int32_t>(),
-                             h->d_rr.as<ReadRec>(), h->d_seg_off.as<int64_t>(), h->d_cix.as<int32_t>(),
-                             h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(), d_nslow, h->d_mqslot.as<uint8_t>(), want_cix);
-        if (tot.ncix > 0 && !vrec_path)                      /* short-read batches: k_replay_reads' list of general-CIGAR reads */
-            CRUMBLE_LAUNCH(k_p0_genlist, nblk(n, 1024), 1024, st, n, h->d_rr.as<ReadRec>(), h->d_genlist.as<int32_t>(), d_nslow + 1);
-        CRUMBLE_LAUNCH_INDEP(k_p0_keys, nblk(n, 256), 256, st, n, h->d_pos.as<int32_t>(), h->d_end.as<int32_t>(),
-                             h->d_inplp.as<uint8_t>(), h->d_kpos.as<int32_t>(), h->d_kend.as<int32_t>());
-        if ((e = prefix_max(h, h->d_kpos.as<int32_t>(), n)) || (e = prefix_max(h, h->d_kend.as<int32_t>(), n)) ||
-            (e = prefix_max(h, h->d_sr_pend.as<int32_t>(), (int64_t)ns)))
-            return e;
-        if (B.n_tiles > 0) {
-            CRUMBLE_LAUNCH_INDEP(k_p0_tiles, nblk(B.n_tiles, 256), 256, st, B.n_tiles, B.p0, n, h->d_kpos.as<int32_t>(),
-                                 h->d_kend.as<int32_t>(), h->d_tile_lo.as<int32_t>(), h->d_tile_hi.as<int32_t>());
-            CRUMBLE_LAUNCH_INDEP(k_p0_tiles, nblk(B.n_tiles, 256), 256, st, B.n_tiles, B.p0, (int64_t)ns, h->d_sr_ppos.as<int32_t>(),
-                                 h->d_sr_pend.as<int32_t>(), h->d_stile_lo.as<int32_t>(), h->d_stile_hi.as<int32_t>());
+        VRec *vrp = vrec_path ? h->d_vrec.as<VRec>() : (VRec *)nullptr;
+        int32_t *gl = (want_cix && tot.ncixu > 0) ? h->d_genlist.as<int32_t>() : (int32_t *)nullptr;
+#define FILL_LAUNCH(GW_) CRUMBLE_LAUNCH((k_p0_fill<GW_>), nblk(n, P0_CHUNK), P0_CHUNK, st, n, nb, B.p0, h->d_pos.as<int32_t>(), h->d_mapq.as<uint8_t>(), \
+                       h->d_seq_off.as<int64_t>(), h->d_cig_off.as<int64_t>(), h->d_cigar.as<uint32_t>(), h->d_inplp.as<uint8_t>(), \
+                       h->d_end.as<int32_t>(), cnt, part, nblocks, h->d_segs.as<Seg>(), h->d_sr.as<SegRec>(), h->d_rr.as<ReadRec>(), \
+                       h->d_seg_off.as<int64_t>(), h->d_kpos.as<int32_t>(), h->d_kend.as<int32_t>(), h->d_slow_g.as<int64_t>(), \
+                       h->d_slow_r.as<int32_t>(), d_nslow, gl, d_nslow + 1, h->d_mqslot.as<uint8_t>(), h->d_blk_read.as<int32_t>(), \
+                       vrp, h->d_chunk_read.as<int32_t>(), h->hparams.min_mqual, d_err)
+        if (multi) FILL_LAUNCH(64); else FILL_LAUNCH(1);
+#undef FILL_LAUNCH
+        if (gl) {                                            /* short-read batches: base -> column table of the general-CIGAR reads */
+            const unsigned g = (unsigned)(tot.ncixu < 4 * 4096 ? (tot.ncixu + 3) / 4 : 4096);
+            CRUMBLE_LAUNCH(k_p0_cix, g, 256, st, B.p0, h->d_genlist.as<int32_t>(), d_nslow + 1, h->d_rr.as<ReadRec>(),
+                           h->d_seg_off.as<int64_t>(), h->d_segs.as<Seg>(), h->d_cix.as<int32_t>());
         }
-        if (B.n_tiles > 0 && n_bed > 0) {                   /* keep-BED cursor of every tile */
-            if ((e = h->d_tile_bed.reserve((size_t)(B.n_tiles + 1) * 4))) return e;
-            CRUMBLE_LAUNCH_INDEP(k_p0_tilebed, nblk(B.n_tiles, 256), 256, st, B.n_tiles, B.p0, n_bed, h->d_bed_pmax.as<int32_t>(),
-                                 h->d_tile_bed.as<int32_t>());
-        }
-        const bool multi = tot.nseg > n + n / 2;            /* long reads: many ops per read */
-        h->have_hits = false;
+        if (B.n_tiles > 0)
+            CRUMBLE_LAUNCH_INDEP(k_p0_tiles, nblk(B.n_tiles, 256), 256, st, B.n_tiles, B.p0, n, h->d_kpos.as<int32_t>(), h->d_kend.as<int32_t>(),
+                                 h->d_seg_off.as<int64_t>(), h->d_sr.as<SegRec>(), h->d_tile_lo.as<int32_t>(), h->d_tile_hi.as<int32_t>(),
+                                 h->d_stile_lo.as<int32_t>(), h->d_stile_hi.as<int32_t>(), n_bed, h->d_bed_pmax.as<int32_t>(),
+                                 h->d_tile_bed.as<int32_t>(), d_err);
         if (B.n_tiles > 0 && multi) {                       /* the records that reach each tile, in file order (k_columns2<MULTI>) */
             const int rch = (int)((n + P0_CHUNK - 1) / P0_CHUNK), tch = (int)((B.n_tiles + P0_CHUNK - 1) / P0_CHUNK);
             if ((e = h->d_rtoff.reserve((size_t)(n + 2) * 8)) || (e = h->d_tpart.reserve((size_t)((rch > tch ? rch : tch) + 2) * 8)) ||
                 (e = h->d_hitoff.reserve((size_t)(B.n_tiles + 2) * 8)))
                 return e;
             int64_t *rto = h->d_rtoff.as<int64_t>(), *tp = h->d_tpart.as<int64_t>(), *ho = h->d_hitoff.as<int64_t>();
-            int *herr = h->d_misc.as<int>() + 15;
-            HIPCHK(hipMemsetAsync(herr, 0, 4, st));
             CRUMBLE_LAUNCH_INDEP(k_p0_rtcount, nblk(n, 256), 256, st, n, B.p0, h->d_rr.as<ReadRec>(), h->d_seg_off.as<int64_t>(), rto);
-            CRUMBLE_LAUNCH_INDEP(k_i64scan_reduce, nblk(rch, 64), 64, st, n, rto, tp, rch);
+            CRUMBLE_LAUNCH(k_i64scan_reduce, rch, 256, st, n, rto, tp, rch);
             CRUMBLE_LAUNCH(k_i64scan_partials, 1, 1024, st, tp, rch);
-            CRUMBLE_LAUNCH_INDEP(k_i64scan_apply, nblk(rch, 64), 64, st, n, rto, tp, rch);
-            int64_t npairs = 0;
-            HIPCHK(hipMemcpyAsync(&npairs, rto + n, 8, hipMemcpyDeviceToHost, st));
+            CRUMBLE_LAUNCH(k_i64scan_apply, rch, 256, st, n, rto, tp, rch);
+            HIPCHK(hipMemcpyAsync(h->pinned, rto + n, 8, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
+            int64_t npairs = 0;
+            memcpy(&npairs, h->pinned, 8);
             if ((e = h->d_first.reserve((size_t)(npairs + 64) * 4))) return e;
             const uint32_t *first = h->d_first.as<uint32_t>();
             CRUMBLE_LAUNCH_INDEP(k_p0_first, nblk(n, 4), 256, st, n, B.p0, h->d_rr.as<ReadRec>(), h->d_seg_off.as<int64_t>(), h->d_sr.as<SegRec>(),
@@ -572,67 +601,28 @@ static int expand(crumble_hip *h)
             const unsigned hgrid = nblk((int64_t)B.n_tiles * P0_HIT_GROUP, 256);
             CRUMBLE_LAUNCH(k_p0_hitcount, hgrid, 256, st, B.n_tiles, B.p0, h->d_tile_lo.as<int32_t>(), h->d_tile_hi.as<int32_t>(),
                            h->d_rr.as<ReadRec>(), h->d_seg_off.as<int64_t>(), rto, first, ho);
-            CRUMBLE_LAUNCH_INDEP(k_i64scan_reduce, nblk(tch, 64), 64, st, (int64_t)B.n_tiles, ho, tp, tch);
+            CRUMBLE_LAUNCH(k_i64scan_reduce, tch, 256, st, (int64_t)B.n_tiles, ho, tp, tch);
             CRUMBLE_LAUNCH(k_i64scan_partials, 1, 1024, st, tp, tch);
-            CRUMBLE_LAUNCH_INDEP(k_i64scan_apply, nblk(tch, 64), 64, st, (int64_t)B.n_tiles, ho, tp, tch);
-            int64_t nhits = 0;
-            HIPCHK(hipMemcpyAsync(&nhits, ho + B.n_tiles, 8, hipMemcpyDeviceToHost, st));
+            CRUMBLE_LAUNCH(k_i64scan_apply, tch, 256, st, (int64_t)B.n_tiles, ho, tp, tch);
+            HIPCHK(hipMemcpyAsync(h->pinned, ho + B.n_tiles, 8, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
+            int64_t nhits = 0;
+            memcpy(&nhits, h->pinned, 8);
             if (nhits >= INT_MAX) { g_last_error = "more than 2^31 (record, tile) pairs in one batch"; return CRUMBLE_EINVAL; }
             if ((e = h->d_hits.reserve((size_t)(nhits + 64) * 4))) return e;
             CRUMBLE_LAUNCH(k_p0_hitfill, hgrid, 256, st, B.n_tiles, B.p0, h->d_tile_lo.as<int32_t>(), h->d_tile_hi.as<int32_t>(),
-                           h->d_rr.as<ReadRec>(), h->d_seg_off.as<int64_t>(), rto, first, ho, h->d_hits.as<int32_t>(), herr);
-            int herr_h = 0;
-            HIPCHK(hipMemcpyAsync(&herr_h, herr, 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            if (herr_h) { g_last_error = "internal: tile hit lists inconsistent"; return CRUMBLE_EOVERFLOW; }
+                           h->d_rr.as<ReadRec>(), h->d_seg_off.as<int64_t>(), rto, first, ho, h->d_hits.as<int32_t>(), d_herr);
             h->have_hits = true;
         }
-        if (B.n_tiles > 0) {                                /* cost prefix of the tiles: k_columns' work split */
-            const int tch = (int)((B.n_tiles + P0_CHUNK - 1) / P0_CHUNK);
-            if ((e = h->d_tcum.reserve((size_t)(B.n_tiles + 2) * 8)) || (e = h->d_tpart.reserve((size_t)(tch + 2) * 8))) return e;
-            int64_t *cum = h->d_tcum.as<int64_t>(), *tp = h->d_tpart.as<int64_t>();
-            CRUMBLE_LAUNCH_INDEP(k_tile_cost, nblk(B.n_tiles, 256), 256, st, B.n_tiles, h->d_stile_lo.as<int32_t>(),
-                                 h->d_stile_hi.as<int32_t>(), h->d_sr.as<SegRec>(), h->have_hits ? h->d_hitoff.as<int64_t>() : (const int64_t *)nullptr, cum);
-            CRUMBLE_LAUNCH_INDEP(k_i64scan_reduce, nblk(tch, 64), 64, st, (int64_t)B.n_tiles, cum, tp, tch);
-            CRUMBLE_LAUNCH(k_i64scan_partials, 1, 1024, st, tp, tch);
-            CRUMBLE_LAUNCH_INDEP(k_i64scan_apply, nblk(tch, 64), 64, st, (int64_t)B.n_tiles, cum, tp, tch);
-            int64_t total = 0;                              /* (one small read-back: sizes the unit table) */
-            HIPCHK(hipMemcpyAsync(&total, cum + B.n_tiles, 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            if (total >= TILE_COST_SPAN) { g_last_error = "the reads over one 64-column tile span more than 3.7 GB of bases"; return CRUMBLE_EINVAL; }
-            if (total >= (int64_t)INT_MAX * (KCOL_UNIT / 2)) { g_last_error = "tile cost overflow"; return CRUMBLE_EINVAL; }
-            B.n_units = (int32_t)((total + KCOL_UNIT - 1) / KCOL_UNIT);
-            if ((e = h->d_ufirst.reserve((size_t)(B.n_units + 2) * 4))) return e;
-            CRUMBLE_LAUNCH_INDEP(k_unit_first, nblk(B.n_units + 1, 256), 256, st, B.n_units, B.n_tiles, cum, h->d_ufirst.as<int32_t>());
-        }
-        if (nb > 0) {
-            const bool shortreads = !(tot.nseg > n + n / 2) && nb < 1024 * n;
-            const int64_t nch = (nb + 15) / 16;
-            if ((e = h->d_chunk_read.reserve((size_t)(nch + 2) * 4))) return e;
-            if (shortreads) {                                   /* both owner tables by scatter from the reads */
-                CRUMBLE_LAUNCH_INDEP(k_p0_owner_scatter, nblk(n, 256), 256, st, n, nb, h->d_seq_off.as<int64_t>(),
-                                     h->d_blk_read.as<int32_t>(), h->d_chunk_read.as<int32_t>());
-            } else {
-                CRUMBLE_LAUNCH_INDEP(k_p0_blkread, nblk((int64_t)nblkb, 256), 256, st, (int64_t)((nb + 63) / 64), n,
-                                     h->d_seq_off.as<int64_t>(), h->d_blk_read.as<int32_t>());
-                if (!(tot.nseg > n + n / 2))                        /* k_replay_fast's per-chunk table */
-                    CRUMBLE_LAUNCH_INDEP(k_p0_chunkread, nblk(nch, 256), 256, st, nch, n, h->d_seq_off.as<int64_t>(),
-                                         h->d_blk_read.as<int32_t>(), h->d_chunk_read.as<int32_t>());
-            }
-            if (packed4)                                        /* the bases as BAM packs them -> one classed byte per base */
-                CRUMBLE_LAUNCH_INDEP(k_p0_unpack4, nblk(nch, 256), 256, st, nb, n, h->d_seq_off.as<int64_t>(), h->d_blk_read.as<int32_t>(),
-                                     h->d_bases4.as<uint8_t>(), h->d_bases.as<uint8_t>() + BASE_FRONT_PAD);
-            h->have_vrec = false;
-            if (vrec_path) {
-                /* long reads: one territory per reference-consuming op (+ one per read) and the chunk -> territory
-                 * table: k_replay_fast<VREC> then treats a match op like a single-match read */
-                const int64_t nv = tot.nseg + n;
-                if ((e = h->d_vrec.reserve((size_t)(nv + 1) * sizeof(VRec)))) return e;
-                CRUMBLE_LAUNCH_INDEP(k_p0_vrecs, nblk(n, 256), 256, st, n, nb, B.p0, h->hparams.min_mqual, h->d_rr.as<ReadRec>(),
-                                     h->d_seg_off.as<int64_t>(), h->d_segs.as<Seg>(), h->d_vrec.as<VRec>(), h->d_chunk_read.as<int32_t>());
-                B.n_vrec = nv; h->have_vrec = true;
-            }
+        if (nb > 0) {                                       /* the bases as the kernels read them; chunk -> read table (k_replay_fast) */
+            const unsigned g = nblk(nb, P0B_BASES);
+#define BASES_LAUNCH(P_, O_) CRUMBLE_LAUNCH((k_p0_bases<P_, O_>), g, P0B_THREADS, st, nb, n, h->d_seq_off.as<int64_t>(), h->d_blk_read.as<int32_t>(), \
+                                            packed4 ? h->d_bases4.as<uint8_t>() : (const uint8_t *)nullptr, h->d_bases.as<uint8_t>() + BASE_FRONT_PAD, \
+                                            h->d_chunk_read.as<int32_t>())
+            if (packed4) { if (vrec_path) BASES_LAUNCH(true, false); else BASES_LAUNCH(true, true); }
+            else         { if (vrec_path) BASES_LAUNCH(false, false); else BASES_LAUNCH(false, true); }
+#undef BASES_LAUNCH
+            if (vrec_path) { B.n_vrec = tot.nseg + n; h->have_vrec = true; }
         }
     }
     B.pos = h->d_pos.as<int32_t>(); B.end = h->d_end.as<int32_t>();
@@ -642,7 +632,7 @@ static int expand(crumble_hip *h)
     B.segs = h->d_segs.as<Seg>(); B.rr = h->d_rr.as<ReadRec>(); B.cix = h->d_cix.as<int32_t>();
     B.vr = h->d_vrec.as<VRec>(); if (!h->have_vrec) B.n_vrec = 0;
     B.sr = h->d_sr.as<SegRec>(); B.stile_lo = h->d_stile_lo.as<int32_t>(); B.stile_hi = h->d_stile_hi.as<int32_t>();
-    B.unit_first = h->d_ufirst.as<int32_t>();
+    B.unit_tiles = KCOL2_UTILES; B.n_units = (B.n_tiles + KCOL2_UTILES - 1) / KCOL2_UTILES;
     B.hit_off = h->have_hits ? h->d_hitoff.as<int64_t>() : nullptr; B.hits = h->have_hits ? h->d_hits.as<int32_t>() : nullptr;
     B.bases = h->d_bases.as<uint8_t>() + BASE_FRONT_PAD; B.quals = h->d_quals.as<uint8_t>() + BASE_FRONT_PAD;
     B.tile_lo = h->d_tile_lo.as<int32_t>(); B.tile_hi = h->d_tile_hi.as<int32_t>();
@@ -659,12 +649,20 @@ static int expand(crumble_hip *h)
         (e = h->d_out.reserve((size_t)nb + 64)) || (e = h->d_rflags.reserve((size_t)(n ? n : 1))) ||
         (e = h->d_keepf.reserve((size_t)(n ? n : 1))) || (e = h->d_kept.reserve((size_t)(n ? n : 1) * 4)) || (e = h->d_b15f.reserve((size_t)(n ? n : 1))))
         return e;
+    /* the late errors: what k_p0_fill / k_p0_tiles / k_p0_hitfill found */
+    HIPCHK(hipMemcpyAsync((char *)h->pinned + 128, d_err, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync((char *)h->pinned + 132, d_herr, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(h->ev_up[2], st));
-    HIPCHK(hipStreamSynchronize(st));               /* the caller may free its host buffers */
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventElapsedTime(&h->up_h2d_ms, h->ev_up[0], h->ev_up[1]));
-    HIPCHK(hipEventElapsedTime(&h->up_p0_ms, h->ev_up[1], h->ev_up[2]));
     h->have_batch = true;
+    h->late_pending = true;
+    if (wait) {
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipGetLastError());
+        h->late_pending = false;
+        HIPCHK(hipEventElapsedTime(&h->up_h2d_ms, h->ev_up[0], h->ev_up[1]));
+        HIPCHK(hipEventElapsedTime(&h->up_p0_ms, h->ev_up[1], h->ev_up[2]));
+        if ((e = expand_late_errors(h))) { h->have_batch = false; return e; }
+    }
     return CRUMBLE_OK;
 }
 
@@ -675,14 +673,15 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     HIPCHK(hipEventRecord(h->ev_up[0], h->stream));
     int e;
     if ((e = copy_raw(h, b))) return e;
-    return expand(h);
+    return expand(h, true);
 }
 
 extern "C" int crumble_hip_expand(crumble_hip *h)
 {
     if (!h || !h->have_raw) { g_last_error = "crumble_hip_expand: no raw batch on the device (crumble_hip_upload first)"; return CRUMBLE_EINVAL; }
     HIPCHK(hipSetDevice(h->device));
-    return expand(h);
+    HIPCHK(hipEventRecord(h->ev_up[0], h->stream));
+    return expand(h, true);
 }
 
 /* -------------------------------------------------------------------- run */
@@ -796,7 +795,7 @@ extern "C" int crumble_hip_set_window(crumble_hip *h, const crumble_window *w)
  * engine per device -- and only the two tiny chained phases in window order: 2 hands the running depth average on
  * (snp:1490-1491,1684-1687), 4 the STR window state (snp:1508-1511,1741-1755). */
 /* what every phase needs from the handle (d_misc: [0] overflow flag, [1] n_epochs, [2] n_kept, [3] k_columns work counter,
- * [8..12] upload, [15] hit-list check, [16..19] depth state out, [24..27] window state out) */
+ * [4] a quality >= 128 was seen (k_stats), [8..12] upload, [15] hit-list check, [16..19] depth state out, [24..27] window state out) */
 #define RUN_LOCALS \
     HIPCHK(hipSetDevice(h->device)); \
     hipStream_t st = h->stream; \
@@ -828,7 +827,7 @@ extern "C" int crumble_hip_run_columns(crumble_hip *h)
     h->n_stages = 0; h->have_run = false;
     memset(&h->totals, 0, sizeof(h->totals));
     HIPCHK(hipMemsetAsync(stats, 0, CRUMBLE_ST_N * 8, st));
-    HIPCHK(hipMemsetAsync(d_overflow, 0, 16, st));      /* [0] overflow, [1] n_epochs, [2] n_kept, [3] k_columns work counter; [8..11] belong to upload */
+    HIPCHK(hipMemsetAsync(d_overflow, 0, 32, st));      /* [0] overflow, [1] n_epochs, [2] n_kept, [3] k_columns work counter, [4] quality >= 128 seen; [8..15] belong to upload */
 
     if (L > 0) {
         uint32_t *ht = h->d_ht.as<uint32_t>();
@@ -839,7 +838,9 @@ extern "C" int crumble_hip_run_columns(crumble_hip *h)
         if (grid > pgrid) grid = pgrid;                 /* persistent: grid-stride over tiles */
         const bool modeA = h->hparams.min_qual_A != 0;
         const bool multi = h->have_hits;                                  /* long reads: many ops per read (the upload listed every tile's records) */
-#define KCOL_LAUNCH2(M, MU, PE) CRUMBLE_LAUNCH((k_columns<M, MU, PE>), grid, KCOL_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, ht, stats, (unsigned *)(d_overflow + 3))
+        DBatch B1 = B;                                  /* k_columns gives a wave a whole unit: smaller ones */
+        B1.unit_tiles = KCOL1_UTILES; B1.n_units = (B.n_tiles + KCOL1_UTILES - 1) / KCOL1_UTILES;
+#define KCOL_LAUNCH2(M, MU, PE) CRUMBLE_LAUNCH((k_columns<M, MU, PE>), grid, KCOL_THREADS, st, B1, P, T, colrec, nplp, score, trigcnt, ht, stats, (unsigned *)(d_overflow + 3))
 #define KCOL_LAUNCH(M) do { if (multi) { if (h->col_perm) KCOL_LAUNCH2(M, true, true); else KCOL_LAUNCH2(M, true, false); } \
                             else       { if (h->col_perm) KCOL_LAUNCH2(M, false, true); else KCOL_LAUNCH2(M, false, false); } } while (0)
         /* k_columns2 (kcol2.h) covers one active consensus; both at once (-q with -Q) and a disabled consensus
@@ -1077,18 +1078,26 @@ extern "C" int crumble_hip_run_finish(crumble_hip *h)
         }
         STAGE("k_stats", 2.0 * nb);
         if (h->windowed)
-            CRUMBLE_LAUNCH(k_stats, 1024, 256, st, h->own_b_lo, h->own_b_hi, h->win.read_end - h->win.read_first, h->d_out.as<uint8_t>(), B.quals, stats);
+            CRUMBLE_LAUNCH(k_stats, 1024, 256, st, h->own_b_lo, h->own_b_hi, h->win.read_end - h->win.read_first, h->d_out.as<uint8_t>(), B.quals, stats, d_overflow + 4);
         else
-            CRUMBLE_LAUNCH(k_stats, 1024, 256, st, (int64_t)0, nb, n, h->d_out.as<uint8_t>(), B.quals, stats);
+            CRUMBLE_LAUNCH(k_stats, 1024, 256, st, (int64_t)0, nb, n, h->d_out.as<uint8_t>(), B.quals, stats, d_overflow + 4);
     }
     HIPCHK(hipEventRecord(h->ev[h->n_stages], st));
     /* fold this batch's counters into the engine's accumulated stats vector, on the device */
     CRUMBLE_LAUNCH_INDEP(k_stats_fold, nblk(CRUMBLE_ST_N, 64), 64, st, h->d_stats.as<u64>(), (const u64 *)stats, CRUMBLE_ST_N, (const int *)d_overflow);
-    int ovf[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(h->pinned, d_overflow, 8, hipMemcpyDeviceToHost, st));
+    int ovf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h->pinned, d_overflow, 32, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    memcpy(ovf, h->pinned, 8);
+    memcpy(ovf, h->pinned, 32);
     HIPCHK(hipGetLastError());
+    if (h->late_pending) {                              /* crumble_hip_contig: the expansion was not waited for */
+        h->late_pending = false;
+        (void)hipEventElapsedTime(&h->up_h2d_ms, h->ev_up[0], h->ev_up[1]);
+        (void)hipEventElapsedTime(&h->up_p0_ms, h->ev_up[1], h->ev_up[2]);
+        const int le = expand_late_errors(h);
+        if (le) { h->have_batch = false; return le; }
+    }
+    if (ovf[4]) { g_last_error = "input quality >= 128 (SURVEY.md Q13)"; return CRUMBLE_EINVAL; }
     for (int i = 0; i < h->n_stages; i++)
         HIPCHK(hipEventElapsedTime(&h->stage_ms[i], h->ev[i], h->ev[i + 1]));
     if (ovf[0]) { g_last_error = "STR repeat list overflow"; return CRUMBLE_EOVERFLOW; }
@@ -1170,7 +1179,11 @@ extern "C" int crumble_hip_contig(crumble_hip *h, const crumble_batch *b, uint8_
                                   uint8_t *read_flags_out, int64_t *stats)
 {
     int e;
-    if ((e = crumble_hip_upload(h, b))) return e;
+    if (!h || !b || b->n_reads < 0) return CRUMBLE_EINVAL;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventRecord(h->ev_up[0], h->stream));
+    /* the expansion's tail runs into the run's first kernels: its late errors are looked at with the run's own read-back */
+    if ((e = copy_raw(h, b)) || (e = expand(h, false))) return e;
     if ((e = crumble_hip_run(h))) return e;
     return crumble_hip_download(h, qual_out, read_flags_out, stats);
 }
@@ -1414,6 +1427,16 @@ extern "C" int crumble_hip_indel_only(crumble_hip *h, int dist, int q, uint8_t *
     HIPCHK(hipSetDevice(h->device));
     const int64_t nb = h->n_bases;
     if (nb == 0) return CRUMBLE_OK;
+    {   /* no run here, so no k_stats: the qualities' input check on its own */
+        int *d_err = h->d_misc.as<int>() + 8;
+        HIPCHK(hipMemsetAsync(d_err, 0, 4, h->stream));
+        CRUMBLE_LAUNCH_INDEP(k_p0_qualcheck, nblk((nb + 15) / 16, 256), 256, h->stream, nb, h->B.quals, d_err);
+        int bad = 0;
+        HIPCHK(hipMemcpyAsync(h->pinned, d_err, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        memcpy(&bad, h->pinned, 4);
+        if (bad) { g_last_error = "input quality >= 128 (SURVEY.md Q13)"; return CRUMBLE_EINVAL; }
+    }
     CRUMBLE_LAUNCH_INDEP(k_indel_only, nblk(nb, 256), 256, h->stream, h->B, h->d_blk_read.as<int32_t>(), dist, q,
                          h->d_out.as<uint8_t>());
     HIPCHK(hipStreamSynchronize(h->stream));

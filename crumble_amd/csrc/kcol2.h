@@ -388,7 +388,8 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                             const int g = (int)atomicAdd(tile_ctr, 1u);
                             if (g >= B.n_units) { L.deal_done = 1u; st = 2u; }
                             else {
-                                const unsigned tb = (unsigned)B.unit_first[g], te = (unsigned)B.unit_first[g + 1];
+                                const unsigned tb = (unsigned)g * (unsigned)B.unit_tiles;
+                                const unsigned te = tb + (unsigned)B.unit_tiles < (unsigned)B.n_tiles ? tb + (unsigned)B.unit_tiles : (unsigned)B.n_tiles;
                                 atomicExch(&L.deal, ((unsigned long long)te << 32) | (tb + 1u));
                                 lo32 = tb; hi32 = te; st = tb < te ? 1u : 3u;
                             }
@@ -417,7 +418,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
         if (lane == 0) g = (int)atomicAdd(tile_ctr, 1u);
         g = READLANE(g, 0);
         if (g >= B.n_units) break;
-        t_begin = UNIFORM(B.unit_first[g]); t_end = UNIFORM(B.unit_first[g + 1]);
+        t_begin = g * B.unit_tiles; t_end = t_begin + B.unit_tiles < B.n_tiles ? t_begin + B.unit_tiles : B.n_tiles;
     }
     KC2_STAMP(0);
     for (int tile = t_begin; tile < t_end; tile++) {

@@ -638,13 +638,9 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
     const bool use_cons = MODE == 0 ? (P->min_qual_A != 0) : (P->min_qual_B != 0);
     const int qcap = P->qcap, min_mqual = P->min_mqual, any_pres = P->any_preserve;
 
-    /* Work split.  The tiles' estimated costs (candidate records + a constant, prefix-summed with the
-     * batch) are cut into units of KCOL_UNIT; a wave takes the next unit from one counter and does the
-     * tiles that start in it: ~5 tiles of a 30x genome, one tile of a 300x target, a whole stretch of
-     * empty tiles between targets, and a 6000x spike tile alone.  Dynamic, because waves do not run
-     * at equal speed (clock, memory channel, neighbours on the CU) -- a fixed split, however well
-     * balanced on paper, left 15 % -- and in order, so that concurrently running waves share reads
-     * through L2.  One atomic per ~KCOL_UNIT record-iterations keeps the counter cool. */
+    /* Work split.  A wave takes the next unit (B.unit_tiles consecutive tiles) from one counter.  Dynamic, because waves
+     * do not run at equal speed (clock, memory channel, neighbours on the CU) -- a fixed split, however well balanced
+     * on paper, left 15 % -- and in order, so that concurrently running waves share reads through L2. */
     (void)wave0; (void)nwaves;
     for (;;) {
     int t_begin, t_end;
@@ -653,7 +649,7 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
         if (lane == 0) g = (int)atomicAdd(tile_ctr, 1u);
         g = READLANE(g, 0);
         if (g >= B.n_units) break;
-        t_begin = UNIFORM(B.unit_first[g]); t_end = UNIFORM(B.unit_first[g + 1]);
+        t_begin = g * B.unit_tiles; t_end = t_begin + B.unit_tiles < B.n_tiles ? t_begin + B.unit_tiles : B.n_tiles;
     }
     for (int tile = t_begin; tile < t_end; tile++) {
         const int c = tile * 64 + lane;
@@ -3323,7 +3319,7 @@ k_pb_fillw(int64_t n_bases, uint8_t *__restrict__ out, const u64 *__restrict__ s
  * serialise the LDS atomics. */
 #define HIST_COPIES 32
 __global__ void __launch_bounds__(256)
-k_stats(int64_t b_lo, int64_t b_hi, int64_t n_reads, const uint8_t *out, const uint8_t *in, u64 *stats)
+k_stats(int64_t b_lo, int64_t b_hi, int64_t n_reads, const uint8_t *out, const uint8_t *in, u64 *stats, int *bad_qual)
 {
     /* bytes [b_lo, b_hi) of the batch (a window of a contig counts the reads it owns): the unaligned head is counted
      * here by workgroup 0, the rest as 16-byte vectors from the next aligned offset */
@@ -3339,10 +3335,12 @@ k_stats(int64_t b_lo, int64_t b_hi, int64_t n_reads, const uint8_t *out, const u
     const int copy = threadIdx.x & (HIST_COPIES - 1);
     const int64_t nvec = n_bases >> 4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    unsigned int changed = 0;
+    unsigned int changed = 0, hibits = 0;                  /* hibits: an INPUT quality >= 128: this is the pass that
+                                                            * looks at every input quality, so the input validation of the qualities is here */
     const uint4 *o4 = (const uint4 *)out, *i4 = (const uint4 *)in;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
         const uint4 a = o4[i], b = i4[i];
+        hibits |= b.x | b.y | b.z | b.w;
         const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
         #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -3360,13 +3358,16 @@ k_stats(int64_t b_lo, int64_t b_hi, int64_t n_reads, const uint8_t *out, const u
             const unsigned o = out[i];
             atomicAdd(&h[o * HIST_COPIES + copy], 1u);
             changed += (o != in[i]);
+            hibits |= in[i];
         }
         for (int64_t i = head_lo - a_lo + threadIdx.x; i < head_hi - a_lo; i += blockDim.x) {   /* (negative offsets) */
             const unsigned o = out[i];
             atomicAdd(&h[o * HIST_COPIES + copy], 1u);
             changed += (o != in[i]);
+            hibits |= in[i];
         }
     }
+    if (hibits & 0x80808080u) *bad_qual = 1;
     if (changed) atomicAdd(&hchg, changed);
     __syncthreads();
     for (int i = threadIdx.x; i < 256; i += blockDim.x) {

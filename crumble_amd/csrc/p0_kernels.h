@@ -1,34 +1,48 @@
 /*
  * p0_kernels.h -- "P0 expand" on the device: everything the column engine needs beyond the raw
  * BAM-shaped arrays of a crumble_batch is derived here, so crumble_hip_upload() is a set of
- * host->device copies plus a few launches (no per-read host loops).
+ * host->device copies plus a few launches (no per-read host loops).  What htslib's bam_plp_auto and
+ * pileup_callback (snp_score.c:1113-1153) do per read, done once per batch:
  *
  *   k_p0_classify   per read: pileup_callback's routing (snp_score.c:1130-1149) + htslib's default
  *                   flag filter, reference length / end, number of reference-consuming CIGAR ops,
- *                   input validation (the reference asserts instead: snp_score.c:1075)
- *   k_p0_basequal   input qualities must be < 128; consensus class of every base into its high nibble
- *   k_p0_sorted     coordinate order of the reads that enter the pileup (snp_score.c:1075)
- *   k_p0scan_*      exclusive prefix sums -> offsets of each read's ops / base->column entries
- *   k_p0_fill       per read: Seg + SegRec tables with htslib's resolve_cigar2 `indel` peek
- *                   (SURVEY.md App. C), ReadRec, base->column table and the list of bases that
- *                   D/N columns report (replay)
- *   k_p0_keys, k_pmax_*, k_p0_tiles   candidate ranges per 64-column tile (reads and ops)
- *   k_p0_blkread    owning read of every 64-base block of the flat base array (k_p0_chunkread: of every 16-base chunk)
+ *                   input validation (the reference asserts instead: snp_score.c:1075); per 1024-read
+ *                   block: the sums of the counts and the largest start / end (the scan's partials)
+ *   k_p0_mid        one workgroup: exclusive scan of the block partials (offsets, prefix maxima), totals
+ *   k_p0_fill       the block's own scan, then per read (a lane each, or a wave each for long reads):
+ *                   Seg + SegRec tables with htslib's resolve_cigar2 `indel` peek,
+ *                   ReadRec, the monotone search keys, coordinate order of the reads that enter the pileup
+ *                   (snp_score.c:1075), the list of bases that D/N columns report (replay), the list of
+ *                   general-CIGAR reads, block -> read table, territories of long reads (VRec)
+ *   k_p0_cix        base -> column table of the general-CIGAR reads of a short-read batch (a wave per read)
+ *   k_p0_tiles      candidate ranges per 64-column tile (reads and ops), keep-BED cursor per tile
+ *   k_p0_bases      the bases as the kernels read them (one byte per base, consensus class in the high
+ *                   nibble) from BAM's packed nibbles, staged through LDS; chunk -> read table
+ *   k_p0_rtcount .. k_p0_hitfill   long reads: the records that reach each tile
+ * (input qualities >= 128, SURVEY.md Q13, are found by the run's last pass over the qualities, k_stats.)
  */
 #ifndef CRUMBLE_P0_KERNELS_H
 #define CRUMBLE_P0_KERNELS_H
 
 #include "dev_common.h"
 
-struct P0Cnt { int64_t nseg, ncix, nslow; };
+/* per-read counts of the classify pass (16 bytes: one vector load in the fill pass) */
+struct P0Cnt32 { int32_t nseg, ncixu /* base -> column entries, in units of CIX_UNIT */, nslow, pad; };
+/* per 1024-read block: the block's sums and maxima from k_p0_classify, turned by k_p0_mid into what lies before the block
+ * (exclusive sums, prefix maxima); entry [nblocks] holds the totals */
+struct P0Part { int64_t nseg, ncixu, nslow; int32_t maxpos, maxend; };
+#define P0_CHUNK 1024
 
 #define P0_ERR_NEG      1
 #define P0_ERR_QLEN     2
 #define P0_ERR_COORD    3
 #define P0_ERR_UNSORTED 4
 #define P0_ERR_QUAL     5
+#define P0_ERR_SPAN     6       /* the reads over one 64-column tile span more than 3.7 GB of bases (k_columns2's 32-bit offsets) */
+#define P0_ERR_HITS     7       /* internal: tile hit lists inconsistent */
 
 __device__ __forceinline__ bool p0_is_mdnx(int op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
+__device__ __forceinline__ bool p0_is_query(int op) { return op == 0 || op == 1 || op == 4 || op == 7 || op == 8; }
 
 /* bam_pileup1_t.indel on the last column of ref-op k (htslib resolve_cigar2's peek at the
  * next op) */
@@ -58,23 +72,23 @@ __device__ __forceinline__ int p0_indel_after(const uint32_t *cig, int n, int k)
     return indel;
 }
 
+/* one read: routing, validation, counts.  mn / mx: its span when it enters the pileup */
 __device__ __forceinline__ void p0_classify_read(int64_t r, int tid, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
                               const int64_t *__restrict__ seq_off, const int64_t *__restrict__ cig_off,
                               const uint32_t *__restrict__ cigar, uint8_t *__restrict__ inplp,
-                              int32_t *__restrict__ end, P0Cnt *__restrict__ cnt, int *err, int &mn, int &mx,
+                              int32_t *__restrict__ end, P0Cnt32 &c, int *err, int &mn, int &mx,
                               int64_t nb, int64_t nc)
 {
     const int64_t co0 = cig_off[r], co1 = cig_off[r + 1], so0 = seq_off[r], so1 = seq_off[r + 1];
     const int64_t ncg64 = co1 - co0, lq = so1 - so0;
-    P0Cnt c = {0, 0, 0};
     inplp[r] = 0; end[r] = pos[r];
     /* offsets must run 0 <= off[r] <= off[r+1] <= total before anything is dereferenced through them */
-    if (lq < 0 || ncg64 < 0 || lq > 0x3fffffff || co0 < 0 || co1 > nc || so0 < 0 || so1 > nb ||
-        (r == 0 && (co0 != 0 || so0 != 0))) { atomicMax(err, P0_ERR_NEG); cnt[r] = c; return; }
+    if (lq < 0 || ncg64 < 0 || lq > 0x3fffffff || ncg64 > 0x3fffffff || co0 < 0 || co1 > nc || so0 < 0 || so1 > nb ||
+        (r == 0 && (co0 != 0 || so0 != 0))) { atomicMax(err, P0_ERR_NEG); return; }
     const uint32_t *cig = cigar + co0;
     const int ncg = (int)ncg64;
     /* pileup_callback routing (snp:1130-1149) + htslib's default filter */
-    if (tid < 0 || (flag[r] & (4 | 256 | 512 | 1024))) { cnt[r] = c; return; }
+    if (tid < 0 || (flag[r] & (4 | 256 | 512 | 1024))) return;
     int64_t x = 0, y = 0;
     int nseg = 0, ndn = 0, first_type = -1, first_ia = 0;
     for (int k = 0; k < ncg; k++) {
@@ -83,63 +97,406 @@ __device__ __forceinline__ void p0_classify_read(int64_t r, int tid, const int32
             if (l > 0) {
                 if (!nseg) { first_type = (op == 2) ? 1 : (op == 3) ? 2 : 0; first_ia = p0_indel_after(cig, ncg, k); }
                 nseg++;
-                if ((op == 2 || op == 3) && y < lq) ndn++;
+                if ((op == 2 || op == 3) && y < lq) ndn++;                 /* (an upper bound: runs of D/N ops report one base) */
             }
             x += l;
             if (op != 2 && op != 3) y += l;
         } else if (op == 1 || op == 4) y += l;
     }
-    if (!nseg || x <= 0) { cnt[r] = c; return; }                      /* no reference-consuming op */
-    if (y != lq && lq != 0) { atomicMax(err, P0_ERR_QLEN); cnt[r] = c; return; }
-    if (pos[r] < 0 || (int64_t)pos[r] + x >= (int64_t)INT_MAX - 64) { atomicMax(err, P0_ERR_COORD); cnt[r] = c; return; }
+    if (!nseg || x <= 0) return;                                       /* no reference-consuming op */
+    if (y != lq && lq != 0) { atomicMax(err, P0_ERR_QLEN); return; }
+    if (pos[r] < 0 || (int64_t)pos[r] + x >= (int64_t)INT_MAX - 64) { atomicMax(err, P0_ERR_COORD); return; }
     inplp[r] = 1;
     end[r] = pos[r] + (int32_t)x;
     const bool simple = nseg == 1 && first_type == 0 && first_ia == 0 && lq > 0;
-    c.nseg = nseg; c.ncix = simple ? 0 : ((lq + CIX_UNIT - 1) & ~(int64_t)(CIX_UNIT - 1)); c.nslow = simple ? 0 : ndn;
-    cnt[r] = c;
+    c.nseg = nseg; c.ncixu = simple ? 0 : (int32_t)((lq + CIX_UNIT - 1) / CIX_UNIT); c.nslow = simple ? 0 : ndn;
     mn = pos[r]; mx = end[r];                              /* extent of the pileup */
 }
 
+/* 1024 reads per workgroup, a lane each; the workgroup's sums / maxima are the partials of the scan that k_p0_fill
+ * finishes (one atomic pair per workgroup for the batch's extent: an atomic pair per read, 12.6 M on two words, was
+ * most of this kernel's time once) */
 __global__ void __launch_bounds__(1024)
 k_p0_classify(int64_t n, int tid, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
-                              const int64_t *__restrict__ seq_off, const int64_t *__restrict__ cig_off,
-                              const uint32_t *__restrict__ cigar, uint8_t *__restrict__ inplp,
-                              int32_t *__restrict__ end, P0Cnt *__restrict__ cnt, int *err, int *minmax,
-                              int64_t nb, int64_t nc)
+              const int64_t *__restrict__ seq_off, const int64_t *__restrict__ cig_off,
+              const uint32_t *__restrict__ cigar, uint8_t *__restrict__ inplp,
+              int32_t *__restrict__ end, P0Cnt32 *__restrict__ cnt, P0Part *__restrict__ part, int *err, int *minmax,
+              int64_t nb, int64_t nc)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int mn = INT_MAX, mx = INT_MIN;
-    if (r < n) p0_classify_read(r, tid, pos, flag, seq_off, cig_off, cigar, inplp, end, cnt, err, mn, mx, nb, nc);
-    /* one atomic pair per 1024-thread workgroup (an atomic pair per read, 12.6 M on two words, was most of this
-     * kernel's time; one per wave still left 4.4 ms of it: a hot word takes ~90 atomics per microsecond) */
-    __shared__ int wmn[16], wmx[16];
+    P0Cnt32 c = {0, 0, 0, 0};
+    if (r < n) {
+        p0_classify_read(r, tid, pos, flag, seq_off, cig_off, cigar, inplp, end, c, err, mn, mx, nb, nc);
+        cnt[r] = c;
+    }
+    __shared__ int wmn[16], wmx[16], wpk[16], wns[16], wsl[16];
+    __shared__ long long wcx[16];
+    int pk = mn == INT_MAX ? INT_MIN : mn;                 /* start of a read in the pileup (the search key's source) */
+    int ns = c.nseg, sl = c.nslow;
+    long long cx = c.ncixu;
     #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
-        const int a = __shfl_xor(mn, d), b = __shfl_xor(mx, d);
-        mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+        const int a = __shfl_xor(mn, d), b = __shfl_xor(mx, d), k2 = __shfl_xor(pk, d);
+        mn = a < mn ? a : mn; mx = b > mx ? b : mx; pk = k2 > pk ? k2 : pk;
+        ns += __shfl_xor(ns, d); sl += __shfl_xor(sl, d); cx += __shfl_xor(cx, d);
     }
-    if ((threadIdx.x & 63) == 0) { wmn[threadIdx.x >> 6] = mn; wmx[threadIdx.x >> 6] = mx; }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { wmn[w] = mn; wmx[w] = mx; wpk[w] = pk; wns[w] = ns; wsl[w] = sl; wcx[w] = cx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < (int)(blockDim.x >> 6); w++) { mn = wmn[w] < mn ? wmn[w] : mn; mx = wmx[w] > mx ? wmx[w] : mx; }
+        P0Part t;
+        t.nseg = 0; t.ncixu = 0; t.nslow = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); k++) {
+            if (k) { mn = wmn[k] < mn ? wmn[k] : mn; mx = wmx[k] > mx ? wmx[k] : mx; pk = wpk[k] > pk ? wpk[k] : pk; }
+            t.nseg += wns[k]; t.ncixu += wcx[k]; t.nslow += wsl[k];
+        }
+        t.maxpos = pk; t.maxend = mx;
+        part[blockIdx.x] = t;
         if (mn != INT_MAX) atomicMin(&minmax[0], mn);
         if (mx != INT_MIN) atomicMax(&minmax[1], mx);
     }
 }
 
-__global__ void k_p0_sorted(int64_t n, const int32_t *__restrict__ pos, const uint8_t *__restrict__ inplp, int *err)
+/* ONE 1024-thread workgroup: the block partials become what lies in front of each block (exclusive sums, prefix
+ * maxima); [nblocks] receives the totals.  A contiguous slice per thread, the thread sums scanned through LDS. */
+__global__ void __launch_bounds__(1024)
+k_p0_mid(P0Part *part, int nblocks)
 {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n || !inplp[r]) return;
-    int64_t q = r - 1;
-    while (q >= 0 && !inplp[q]) q--;
-    if (q >= 0 && pos[r] < pos[q]) atomicMax(err, P0_ERR_UNSORTED);   /* snp:1075 */
+    __shared__ P0Part sh[1024];
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int per = (nblocks + nt - 1) / nt;
+    const int b = t * per, e = b + per < nblocks ? b + per : nblocks;
+    P0Part acc;
+    acc.nseg = acc.ncixu = acc.nslow = 0; acc.maxpos = acc.maxend = INT_MIN;
+    for (int i = b; i < e; i++) {
+        const P0Part v = part[i];
+        acc.nseg += v.nseg; acc.ncixu += v.ncixu; acc.nslow += v.nslow;
+        acc.maxpos = v.maxpos > acc.maxpos ? v.maxpos : acc.maxpos; acc.maxend = v.maxend > acc.maxend ? v.maxend : acc.maxend;
+    }
+    sh[t] = acc;
+    __syncthreads();
+    for (int d = 1; d < nt; d <<= 1) {                    /* Hillis-Steele inclusive scan of the thread sums */
+        P0Part v;
+        v.nseg = v.ncixu = v.nslow = 0; v.maxpos = v.maxend = INT_MIN;
+        if (t >= d) v = sh[t - d];
+        __syncthreads();
+        P0Part x = sh[t];
+        x.nseg += v.nseg; x.ncixu += v.ncixu; x.nslow += v.nslow;
+        x.maxpos = v.maxpos > x.maxpos ? v.maxpos : x.maxpos; x.maxend = v.maxend > x.maxend ? v.maxend : x.maxend;
+        sh[t] = x;
+        __syncthreads();
+    }
+    P0Part run;
+    run.nseg = run.ncixu = run.nslow = 0; run.maxpos = run.maxend = INT_MIN;
+    if (t > 0) run = sh[t - 1];
+    for (int i = b; i < e; i++) {
+        const P0Part v = part[i];
+        part[i] = run;
+        run.nseg += v.nseg; run.ncixu += v.ncixu; run.nslow += v.nslow;
+        run.maxpos = v.maxpos > run.maxpos ? v.maxpos : run.maxpos; run.maxend = v.maxend > run.maxend ? v.maxend : run.maxend;
+    }
+    if (t == nt - 1) part[nblocks] = sh[nt - 1];
 }
 
-/* One pass over the flat base / quality arrays: input qualities must be < 128, and every base
- * byte gets its consensus class in the high nibble next to the nt16 code in the low one (what the reference
- * derives per pileup entry, snp:603-609: A C G T -> 0..3, anything else -> 5 "N"; 4 is '*'), so that k_columns2
- * stages classes with a shift instead of a per-byte decode.  Every reader of `bases` masks with 15. */
+/* ---- k_p0_fill: the tables of every read.
+ * Phase A, a lane per read: the block's own scan of the counts (wave scans + the sixteen wave totals through LDS) on top
+ * of k_p0_mid's block prefixes gives every read its slice of the op tables; the same scan carries the prefix maxima of
+ * start and end over the reads in the pileup -- the monotone search keys of k_p0_tiles (a read outside the pileup
+ * inherits its predecessor's) -- and with them the coordinate-order test of snp:1075: a read in the pileup must not start
+ * before the largest start in front of it.
+ * Phase B, the ops of each read: GW = 1 a lane per read (short reads: one to three ops), GW = 64 the wave takes its 64
+ * reads one after another, 64 CIGAR ops per step with wave scans for the reference / query offsets (long reads: hundreds
+ * of ops; one lane per read left 331 k lanes walking 300 ops each).  Every record is written once and never read back. */
+struct P0Op {            /* one CIGAR op of a read with what lies in front of it */
+    int k, op, l, x0, y0, si;
+};
+template <bool LONG>
+__device__ __forceinline__ void p0_emit_op(const P0Op &o, int64_t r, int ncg, const uint32_t *__restrict__ cig, int rpos, int rend, int64_t so, int lq,
+                                           unsigned mq, unsigned slot, int nseg, int64_t segbase, int64_t cixu, int p0,
+                                           Seg *__restrict__ segs, SegRec *__restrict__ sr, ReadRec *__restrict__ rr,
+                                           int64_t *__restrict__ slow_g, int32_t *__restrict__ slow_r, int *__restrict__ n_slow,
+                                           VRec *__restrict__ vr, int32_t *__restrict__ chunk_vr, int64_t nb, int hcol, bool &general)
+{
+    const uint32_t ty = (o.op == 2) ? SEG_D : (o.op == 3) ? SEG_N : SEG_M;
+    const int ia = p0_indel_after(cig, ncg, o.k);
+    Seg s;
+    s.roff = o.x0; s.qstart = o.y0; s.len_type = (uint32_t)o.l | (ty << 30); s.indel_after = ia;
+    segs[segbase + o.si] = s;
+    SegRec q;
+    q.pos = rpos + o.x0; q.end = q.pos + o.l; q.so = so; q.lq = lq;
+    q.qoff = (ty == SEG_M) ? o.y0 - q.pos : o.y0;
+    q.indel_after = ia;
+    q.info = mq | (ty << 8) | (slot << 16);
+    if (o.si == 0) { q.info |= SR_FIRST; if (o.y0 > 0) q.info |= SR_HEADCLIP; }
+    if (o.si == nseg - 1) {                                /* the last op carries the tail flags */
+        const int qt = (ty == SEG_M) ? o.y0 + o.l - 1 : o.y0;
+        q.info |= SR_LAST;
+        if (qt + 1 < lq) q.info |= SR_TAILCLIP;
+    }
+    sr[segbase + o.si] = q;
+    if (o.si == 0) {                                       /* the read's record goes with its first op */
+        const bool simple = nseg == 1 && ty == SEG_M && ia == 0 && lq > 0;
+        ReadRec x;
+        x.pos = rpos; x.end = rend; x.so = so; x.lq = lq; x.q0 = o.y0;
+        x.info = mq | (simple ? RR_SIMPLE : 0u); x.cix = simple ? 0u : (uint32_t)cixu;
+        rr[r] = x;
+        general = !simple && lq > 0;
+    }
+    /* bases that D/N columns report (htslib shows them the NEXT base): once per base -- a D/N op behind another one
+     * with no query base in between reports the same base */
+    if (ty != SEG_M && o.y0 < lq) {
+        bool dup = false;
+        for (int j = o.k - 1; j >= 0; j--) {
+            const int oj = cig[j] & 15, lj = (int)(cig[j] >> 4);
+            if (lj == 0) continue;
+            if (p0_is_query(oj)) break;
+            if (oj == 2 || oj == 3) { dup = true; break; }
+        }
+        if (!dup) { const int w = atomicAdd(n_slow, 1); slow_g[w] = so + o.y0; slow_r[w] = (int32_t)r; }
+    }
+    if (LONG && vr) {
+        /* the op's territory (VRec, dev_common.h): from its first query base up to the next reference op's */
+        int qn = o.y0 + ((ty == SEG_M) ? o.l : 0);
+        bool last = true;
+        for (int j = o.k + 1; j < ncg; j++) {
+            const int oj = cig[j] & 15, lj = (int)(cig[j] >> 4);
+            if (p0_is_mdnx(oj) && lj > 0) { last = false; break; }
+            if (oj == 1 || oj == 4) qn += lj;
+        }
+        if (last) qn = lq;
+        const int qs = o.y0 < lq ? o.y0 : lq;
+        if (qn > lq) qn = lq;
+        if (qn < qs) qn = qs;
+        VRec v;
+        v.pos = v.end = 0; v.q0 = 0; v.hcol = hcol; v.read = (int32_t)r;
+        if (ty == SEG_M) {
+            const int len = o.l < lq - qs ? o.l : lq - qs;             /* fence: query bases that exist */
+            v.pos = rpos + o.x0; v.end = v.pos + (len > 0 ? len : 0);
+        }
+        v.so = so + qs; v.lq = qn - qs;
+        const int64_t vslot = segbase + r + 1 + o.si;
+        vr[vslot] = v;
+        const int64_t a = v.so, b = v.so + v.lq;
+        for (int64_t k2 = (a + 15) >> 4; k2 * 16 < b; k2++) chunk_vr[k2] = (int32_t)vslot;
+        if (b > a && b == nb) chunk_vr[(nb + 15) >> 4] = (int32_t)vslot;           /* the entry past the last base */
+        if (o.si == 0) {                                   /* the territory in front of the first op */
+            VRec f;
+            f.pos = f.end = 0; f.q0 = 0; f.hcol = hcol; f.read = (int32_t)r; f.so = so; f.lq = qs;
+            vr[vslot - 1] = f;
+            for (int64_t k2 = (so + 15) >> 4; k2 * 16 < so + qs; k2++) chunk_vr[k2] = (int32_t)(vslot - 1);
+            if (qs > 0 && so + qs == nb) chunk_vr[(nb + 15) >> 4] = (int32_t)(vslot - 1);
+        }
+    }
+}
+
+template <int GW>
+__global__ void __launch_bounds__(1024)
+k_p0_fill(int64_t n, int64_t nb, int p0, const int32_t *__restrict__ pos, const uint8_t *__restrict__ mapq,
+          const int64_t *__restrict__ seq_off, const int64_t *__restrict__ cig_off,
+          const uint32_t *__restrict__ cigar, const uint8_t *__restrict__ inplp,
+          const int32_t *__restrict__ end, const P0Cnt32 *__restrict__ cnt, const P0Part *__restrict__ part, int nblocks,
+          Seg *__restrict__ segs, SegRec *__restrict__ sr, ReadRec *__restrict__ rr, int64_t *__restrict__ seg_off,
+          int32_t *__restrict__ kpos, int32_t *__restrict__ kend,
+          int64_t *__restrict__ slow_g, int32_t *__restrict__ slow_r, int *__restrict__ n_slow,
+          int32_t *__restrict__ genlist, int *__restrict__ n_gen, const uint8_t *__restrict__ mq_slot,
+          int32_t *__restrict__ blk_read, VRec *__restrict__ vr, int32_t *__restrict__ chunk_vr, int min_mqual, int *__restrict__ err)
+{
+    __shared__ int w_ns[16], w_ps[16], w_en[16], w_gen[16], w_genbase[16];
+    __shared__ long long w_cx[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = r < n;
+    /* ---- phase A */
+    P0Cnt32 c = {0, 0, 0, 0};
+    if (live) c = cnt[r];
+    const bool in = live && inplp[r] != 0;
+    const int rpos = live ? pos[r] : 0, rend = live ? end[r] : 0;
+    const int ps = in ? rpos : INT_MIN, en = in ? rend : INT_MIN;
+    const int i_ns = kc2_scan_add(c.nseg), i_ps = kc2_scan_max(ps), i_en = kc2_scan_max(en);
+    long long i_cx = c.ncixu;
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const long long o = __shfl_up(i_cx, d); if (lane >= d) i_cx += o; }
+    int x_ps = __shfl_up(i_ps, 1);                         /* the largest start in front of this read, inside the wave */
+    if (lane == 0) x_ps = INT_MIN;
+    if (lane == 63) { w_ns[w] = i_ns; w_ps[w] = i_ps; w_en[w] = i_en; w_cx[w] = i_cx; }
+    __syncthreads();
+    const P0Part pb = part[blockIdx.x];
+    int64_t o_ns = pb.nseg + (i_ns - c.nseg), o_cx = pb.ncixu + (i_cx - c.ncixu);
+    int k_ps = pb.maxpos, k_en = pb.maxend;
+    for (int j = 0; j < w; j++) {
+        o_ns += w_ns[j]; o_cx += w_cx[j];
+        k_ps = w_ps[j] > k_ps ? w_ps[j] : k_ps; k_en = w_en[j] > k_en ? w_en[j] : k_en;
+    }
+    x_ps = x_ps > k_ps ? x_ps : k_ps;
+    k_ps = i_ps > k_ps ? i_ps : k_ps; k_en = i_en > k_en ? i_en : k_en;
+    int64_t so = 0;
+    int lq = 0;
+    if (live) {
+        so = seq_off[r];
+        lq = (int)(seq_off[r + 1] - so);
+        if (in && rpos < x_ps) atomicMax(err, P0_ERR_UNSORTED);            /* snp:1075 */
+        seg_off[r] = o_ns; kpos[r] = k_ps; kend[r] = k_en;
+        if (r == n - 1) seg_off[n] = part[nblocks].nseg;
+        if (!in) {                                         /* never in the pileup: only the epilogue touches it */
+            ReadRec x;
+            x.pos = rpos; x.end = rend; x.so = so; x.lq = lq; x.q0 = 0; x.info = mapq[r]; x.cix = 0;
+            rr[r] = x;
+            if (GW == 64 && vr) {                          /* its one territory: the whole read */
+                VRec f;
+                f.pos = f.end = 0; f.q0 = 0; f.hcol = -1; f.read = (int32_t)r; f.so = so; f.lq = lq;
+                const int64_t vslot = o_ns + r;
+                vr[vslot] = f;
+                for (int64_t k2 = (so + 15) >> 4; k2 * 16 < so + lq; k2++) chunk_vr[k2] = (int32_t)vslot;
+                if (lq > 0 && so + lq == nb) chunk_vr[(nb + 15) >> 4] = (int32_t)vslot;
+            }
+        }
+        if (GW == 1 && blk_read && lq > 0) {               /* the read owns the 64-base blocks whose first base is its own */
+            for (int64_t k2 = (so + 63) >> 6; k2 * 64 < so + lq; k2++) blk_read[k2] = (int32_t)r;
+            if (so + lq == nb) blk_read[(nb + 63) >> 6] = (int32_t)r;       /* the entry past the last base (readers clamp) */
+        }
+    }
+    /* ---- phase B */
+    bool general = false;
+    if (GW == 1) {
+        if (in) {
+            const uint32_t *cig = cigar + cig_off[r];
+            const int ncg = (int)(cig_off[r + 1] - cig_off[r]);
+            const unsigned mq = mapq[r], slot = mq_slot[mq];
+            const int hcol = ((int)mq <= min_mqual) ? rpos - p0 : -1;
+            P0Op o;
+            o.x0 = 0; o.y0 = 0; o.si = 0;
+            for (int k = 0; k < ncg; k++) {
+                o.k = k; o.op = cig[k] & 15; o.l = (int)(cig[k] >> 4);
+                if (p0_is_mdnx(o.op)) {
+                    if (o.l > 0) {
+                        p0_emit_op<false>(o, r, ncg, cig, rpos, rend, so, lq, mq, slot, c.nseg, o_ns, o_cx, p0, segs, sr, rr,
+                                          slow_g, slow_r, n_slow, vr, chunk_vr, nb, hcol, general);
+                        o.si++;
+                    }
+                    o.x0 += o.l;
+                    if (o.op != 2 && o.op != 3) o.y0 += o.l;
+                } else if (o.op == 1 || o.op == 4) o.y0 += o.l;
+            }
+        }
+    } else {
+        for (int i = 0; i < 64; i++) {
+            const int64_t ri = (int64_t)blockIdx.x * blockDim.x + (int64_t)w * 64 + i;
+            if (ri >= n) break;
+            const int in_i = __shfl((int)in, i);
+            const int64_t so_i = __shfl(so, i), ons_i = __shfl(o_ns, i), ocx_i = __shfl(o_cx, i);
+            const int lq_i = __shfl(lq, i), rpos_i = __shfl(rpos, i), rend_i = __shfl(rend, i), nseg_i = __shfl(c.nseg, i);
+            if (lq_i > 0 && blk_read) {                    /* block -> read table, the wave's lanes over the read's blocks */
+                for (int64_t k2 = ((so_i + 63) >> 6) + lane; k2 * 64 < so_i + lq_i; k2 += 64) blk_read[k2] = (int32_t)ri;
+                if (lane == 0 && so_i + lq_i == nb) blk_read[(nb + 63) >> 6] = (int32_t)ri;
+            }
+            if (!in_i) continue;
+            const int64_t co = cig_off[ri];
+            const uint32_t *cig = cigar + co;
+            const int ncg = (int)(cig_off[ri + 1] - co);
+            const unsigned mq = mapq[ri], slot = mq_slot[mq];
+            const int hcol = ((int)mq <= min_mqual) ? rpos_i - p0 : -1;
+            int cx0 = 0, cy0 = 0, cs0 = 0;
+            bool gen_i = false;
+            for (int k0 = 0; k0 < ncg; k0 += 64) {
+                const int k = k0 + lane;
+                P0Op o;
+                o.k = k; o.op = -1; o.l = 0;
+                if (k < ncg) { o.op = cig[k] & 15; o.l = (int)(cig[k] >> 4); }
+                const bool isref = o.op >= 0 && p0_is_mdnx(o.op);
+                const int dx = isref ? o.l : 0;
+                const int dy = (o.op == 0 || o.op == 1 || o.op == 4 || o.op == 7 || o.op == 8) ? o.l : 0;
+                const int ds = (isref && o.l > 0) ? 1 : 0;
+                const int ix = kc2_scan_add(dx), iy = kc2_scan_add(dy), is = kc2_scan_add(ds);
+                o.x0 = cx0 + ix - dx; o.y0 = cy0 + iy - dy; o.si = cs0 + is - ds;
+                if (ds)
+                    p0_emit_op<true>(o, ri, ncg, cig, rpos_i, rend_i, so_i, lq_i, mq, slot, nseg_i, ons_i, ocx_i, p0, segs, sr, rr,
+                                     slow_g, slow_r, n_slow, vr, chunk_vr, nb, hcol, gen_i);
+                cx0 += __shfl(ix, 63); cy0 += __shfl(iy, 63); cs0 += __shfl(is, 63);
+            }
+            if (__ballot(gen_i) != 0ull && lane == i) general = true;
+        }
+    }
+    /* the list of general-CIGAR reads (k_p0_cix, k_replay_reads), any order: one atomic per workgroup */
+    if (genlist) {
+        const unsigned long long m = __ballot(general);
+        if (lane == 0) w_gen[w] = __popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int k = 0; k < (int)(blockDim.x >> 6); k++) { w_genbase[k] = tot; tot += w_gen[k]; }
+            const int base = tot ? atomicAdd(n_gen, tot) : 0;
+            for (int k = 0; k < (int)(blockDim.x >> 6); k++) w_genbase[k] += base;
+        }
+        __syncthreads();
+        if (general) genlist[w_genbase[w] + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)r;
+    }
+}
+
+/* base -> column table of the general-CIGAR reads of a short-read batch (replay): a wave per read of the list, lanes
+ * over its bases; -1 no column, -2 a D/N column reports this base (k_replay_slow) */
+__global__ void __launch_bounds__(256)
+k_p0_cix(int p0, const int32_t *__restrict__ genlist, const int *__restrict__ n_gen, const ReadRec *__restrict__ rr,
+         const int64_t *__restrict__ seg_off, const Seg *__restrict__ segs, int32_t *__restrict__ cix)
+{
+    const int lane = threadIdx.x & 63;
+    const int ng = *n_gen, nw = (int)(gridDim.x * (blockDim.x >> 6));
+    for (int gi = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); gi < ng; gi += nw) {
+        const int64_t r = genlist[gi];
+        const ReadRec x = rr[r];
+        const int64_t s0 = seg_off[r];
+        const int ns = (int)(seg_off[r + 1] - s0);
+        int32_t *cx = cix + (size_t)x.cix * CIX_UNIT;
+        for (int i0 = 0; i0 < x.lq; i0 += 64) {
+            const int i = i0 + lane;
+            int val = -1;
+            bool mark = false;
+            for (int k = 0; k < ns; k++) {
+                const Seg sg = segs[s0 + k];
+                const int off = i - sg.qstart;
+                if (seg_type(sg) == SEG_M) { if (off >= 0 && off < seg_len(sg)) val = (x.pos + sg.roff + off) - p0; }
+                else if (off == 0) mark = true;
+            }
+            if (i < x.lq) cx[i] = mark ? -2 : val;
+        }
+    }
+}
+
+/* For tile t = columns [c0, c0+63]: hi = first read whose (prefix-max) start key > c0+63, lo = min(hi, first read whose
+ * (prefix-max) end key > c0): exactly the two-pointer walk over position-sorted reads (entries between lo and hi that
+ * ended earlier are skipped by the kernels).  The same range in op records is [seg_off[lo], seg_off[hi]): a read's ops
+ * carry its start, and the prefix maximum of `end` over op records is the one over reads.  With keep-regions: the first
+ * region whose prefix-max of `end` reaches the tile's first column -- every column's own cursor (bed_preserve,
+ * kernels.h) is at or behind it. */
+__global__ void k_p0_tiles(int n_tiles, int p0, int64_t n, const int32_t *__restrict__ kpos, const int32_t *__restrict__ kend,
+                           const int64_t *__restrict__ seg_off, const SegRec *__restrict__ sr,
+                           int32_t *__restrict__ tlo, int32_t *__restrict__ thi, int32_t *__restrict__ slo, int32_t *__restrict__ shi,
+                           int n_bed, const int32_t *__restrict__ bed_pmax, int32_t *__restrict__ tbed, int *__restrict__ err)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const int64_t c0 = (int64_t)p0 + (int64_t)t * 64, c1 = c0 + 63;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)kpos[mid] <= c1) lo = mid + 1; else hi = mid; }
+    const int64_t h = lo;
+    lo = 0; hi = h;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)kend[mid] <= c0) lo = mid + 1; else hi = mid; }
+    tlo[t] = (int32_t)lo; thi[t] = (int32_t)h;
+    const int64_t s0 = seg_off[lo], s1 = seg_off[h];
+    slo[t] = (int32_t)s0; shi[t] = (int32_t)s1;
+    /* k_columns2 addresses the bases of a tile's reads with 32-bit offsets from the first one */
+    if (s1 > s0 && sr[s1 - 1].so - sr[s0].so > 0xf0000000ll) atomicMax(err, P0_ERR_SPAN);
+    if (n_bed > 0) {
+        int a = 0, b = n_bed;
+        while (a < b) { const int mid = (a + b) >> 1; if ((int64_t)bed_pmax[mid] < c0) a = mid + 1; else b = mid; }
+        tbed[t] = a;
+    }
+}
+
+/* The bases as the kernels read them: one byte per base, the nt16 code in the low nibble and the consensus class in the
+ * high one (what the reference derives per pileup entry, snp:603-609: A C G T -> 0..3, anything else -> 5 "N"; 4 is
+ * '*'), so that k_columns2 stages classes with a shift instead of a per-byte decode.  Every reader of `bases` masks
+ * with 15. */
 __device__ __forceinline__ uint32_t p0_class4(uint32_t w)
 {
     const uint32_t c = w & 0x0f0f0f0fu;
@@ -151,70 +508,123 @@ __device__ __forceinline__ uint32_t p0_class4(uint32_t w)
     const uint32_t cls = (idx & ~bad) | (0x05050505u & bad);
     return c | (cls << 4);
 }
-/* (do_bases == 0: the base bytes already carry their class, k_p0_unpack4 wrote them) */
-__global__ void k_p0_basequal(int64_t nb, uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals, int *err, int do_bases)
+/* qualities >= 128 of a batch that is not run (crumble_hip_indel_only): the run's own check is k_stats */
+__global__ void k_p0_qualcheck(int64_t nb, const uint8_t *__restrict__ quals, int *err)
 {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
     if (i >= nb) return;
     bool bad = false;
-    if (i + 16 <= nb) {
-        const uint4 v = *(const uint4 *)(quals + i);
-        bad = ((v.x | v.y | v.z | v.w) & 0x80808080u) != 0;
-        if (do_bases) {
-            uint4 b = *(const uint4 *)(bases + i);
-            b.x = p0_class4(b.x); b.y = p0_class4(b.y); b.z = p0_class4(b.z); b.w = p0_class4(b.w);
-            *(uint4 *)(bases + i) = b;
-        }
-    } else {
-        for (int64_t k = i; k < nb; k++) {
-            bad = bad || (quals[k] & 0x80);
-            if (do_bases) bases[k] = (uint8_t)(p0_class4(bases[k]) & 0xffu);
-        }
-    }
+    if (i + 16 <= nb) { const uint4 v = *(const uint4 *)(quals + i); bad = ((v.x | v.y | v.z | v.w) & 0x80808080u) != 0; }
+    else for (int64_t k = i; k < nb; k++) bad = bad || (quals[k] & 0x80);
     if (bad) atomicMax(err, P0_ERR_QUAL);
 }
 
-/* crumble_batch.bases4 (BAM's two codes per byte, the earlier base in the high nibble; read i from byte
- * (seq_off[i] >> 1) + i) -> one byte per base with the consensus class in its high nibble, i.e. what k_p0_basequal
- * leaves.  One lane per 16 output bytes (its owner read from blk_read[], so every lane is independent and the store is
- * one aligned 16-byte vector): 8 or 9 packed bytes in (three dword loads that need no alignment), the nibbles
- * interleaved by shifts; a chunk that straddles reads goes byte by byte. */
-typedef uint32_t __attribute__((aligned(1))) p0_u32u;
+/* k_p0_bases.  PACKED: crumble_batch.bases4 (BAM's two codes per byte, the earlier base in the high nibble; read i from
+ * byte (seq_off[i] >> 1) + i) -> one classed byte per base; otherwise the class is added to the one-code-per-byte
+ * input in place.  OWNER: chunk_read[] (the read that owns the first base of every 16-base chunk: k_replay_fast starts
+ * there) is written on the way.  A 256-lane workgroup takes 4096 consecutive bases, a lane 16 of them (one aligned
+ * 16-byte store).  The reads that own them are consecutive and so are their packed bytes: their offsets and the ~2 KB
+ * of packed bytes are staged in LDS with coalesced loads (first / last read from the block table: wave-uniform
+ * look-ups), a chunk's owner comes from a scatter over the staged reads, and a lane's 8 or 9 packed bytes are three
+ * LDS words and a byte funnel -- no per-lane chain of dependent global loads (block table -> offsets -> bytes: 1.66 ms
+ * for chr20's 1.9 G bases, now bound by the 0.5 + 1 bytes per base it moves).  A chunk that straddles reads is made once
+ * per read as if the whole chunk lay in that read and merged by byte mask.  Workgroups whose bases belong to more than
+ * P0B_MAXR reads (reads of a few bases) take the same steps from global memory. */
+#define P0B_THREADS 256
+#define P0B_BASES   (P0B_THREADS * 16)
+#define P0B_MAXR    1024
 #define P0_ILV_LO(X, Y) (((X) & 0xffu) | (((Y) & 0xffu) << 8) | (((X) & 0xff00u) << 8) | (((Y) & 0xff00u) << 16))      /* x0 y0 x1 y1 */
 #define P0_ILV_HI(X, Y) ((((X) >> 16) & 0xffu) | ((((Y) >> 16) & 0xffu) << 8) | ((((X) >> 16) & 0xff00u) << 8) | ((((Y) >> 16) & 0xff00u) << 16))   /* x2 y2 x3 y3 */
-__global__ void __launch_bounds__(256)
-k_p0_unpack4(int64_t nb, int64_t n, const int64_t *__restrict__ seq_off, const int32_t *__restrict__ blk_read,
-             const uint8_t *__restrict__ b4, uint8_t *__restrict__ bases)
+/* sixteen classed bytes from the packed bytes d0 d1 d2 (twelve bytes from the one that holds the chunk's first base);
+ * odd: the first base is that byte's low nibble */
+__device__ __forceinline__ void p0_unpack16(uint32_t d0, uint32_t d1, uint32_t d2, bool odd, uint32_t (&v)[4])
 {
-    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    const uint32_t h0 = (d0 >> 4) & 0x0f0f0f0fu, l0 = d0 & 0x0f0f0f0fu, h1 = (d1 >> 4) & 0x0f0f0f0fu, l1 = d1 & 0x0f0f0f0fu;
+    uint32_t xa, ya, xb, yb;                              /* output byte 2j = xa/xb[j], 2j + 1 = ya/yb[j] */
+    if (!odd) { xa = h0; ya = l0; xb = h1; yb = l1; }
+    else {                                                /* base 2j is the low nibble of byte j, base 2j + 1 the high one of byte j + 1 */
+        const uint32_t h2 = (d2 >> 4) & 0x0f0f0f0fu;
+        xa = l0; ya = (h0 >> 8) | (h1 << 24); xb = l1; yb = (h1 >> 8) | (h2 << 24);
+    }
+    v[0] = p0_class4(P0_ILV_LO(xa, ya)); v[1] = p0_class4(P0_ILV_HI(xa, ya));
+    v[2] = p0_class4(P0_ILV_LO(xb, yb)); v[3] = p0_class4(P0_ILV_HI(xb, yb));
+}
+template <bool PACKED, bool OWNER>
+__global__ void __launch_bounds__(P0B_THREADS)
+k_p0_bases(int64_t nb, int64_t n, const int64_t *__restrict__ seq_off, const int32_t *__restrict__ blk_read,
+           const uint8_t *__restrict__ b4, uint8_t *__restrict__ bases, int32_t *__restrict__ chunk_read)
+{
+    __shared__ long long s_so[P0B_MAXR + 2];
+    __shared__ uint32_t s_b4[(P0B_BASES / 2 + P0B_MAXR + 64) / 4];
+    __shared__ int s_owner[P0B_THREADS];
+    const int64_t G0 = (int64_t)blockIdx.x * P0B_BASES;
+    if (G0 >= nb) return;
+    const int64_t G1 = G0 + P0B_BASES < nb ? G0 + P0B_BASES : nb;
+    /* first and last owner: wave-uniform walks from the block table */
+    int64_t r0 = blk_read[G0 >> 6], r1 = blk_read[(G1 - 1) >> 6];
+    while (r0 + 1 < n && seq_off[r0 + 1] <= G0) r0++;
+    while (r1 + 1 < n && seq_off[r1 + 1] <= G1 - 1) r1++;
+    const int nr = (int)(r1 - r0 + 1);
+    const bool staged = nr <= P0B_MAXR;
+    const int64_t g = G0 + (int64_t)threadIdx.x * 16;
+    int64_t B0 = 0;
+    if (staged) {
+        for (int j = threadIdx.x; j <= nr; j += P0B_THREADS) s_so[j] = seq_off[r0 + j];
+        if (PACKED) {
+            const int64_t so0 = seq_off[r0];
+            B0 = ((so0 >> 1) + r0 + ((G0 - so0) >> 1)) & ~(int64_t)3;
+            const int64_t so1 = seq_off[r1];
+            const int64_t B1 = (so1 >> 1) + r1 + ((G1 - 1 - so1) >> 1) + 1 + 12;       /* a lane looks at twelve bytes */
+            const int nw4 = (int)((B1 - B0 + 3) >> 2);
+            const uint32_t *src = (const uint32_t *)(b4 + B0);                           /* (b4 is 4-byte aligned, B0 a multiple of 4) */
+            for (int j = threadIdx.x; j < nw4; j += P0B_THREADS) s_b4[j] = src[j];
+        }
+        __syncthreads();
+        /* owner of every chunk: the read that holds its first base */
+        for (int j = threadIdx.x; j < nr; j += P0B_THREADS) {
+            const int64_t a = s_so[j] > G0 ? s_so[j] : G0, b = s_so[j + 1] < G1 ? s_so[j + 1] : G1;
+            for (int64_t k = (a + 15) >> 4; k * 16 < b; k++) s_owner[(int)(k - (G0 >> 4))] = j;
+        }
+        __syncthreads();
+    }
     if (g >= nb) return;
-    int64_t r = blk_read[g >> 6];
-    while (r + 1 < n && seq_off[r + 1] <= g) r++;
-    /* the chunk's bytes belong to one read, or -- at a read boundary -- to two or more: the sixteen bytes are made as if
-     * the whole chunk lay in the read at hand (x may be negative: the bytes before the read are masked away) and merged */
     const int64_t gend = g + 16 < nb ? g + 16 : nb;
+    int64_t r;
+    if (staged) r = r0 + s_owner[threadIdx.x];
+    else { r = blk_read[g >> 6]; while (r + 1 < n && seq_off[r + 1] <= g) r++; }
+    if (OWNER) {
+        chunk_read[g >> 4] = (int32_t)r;
+        if (gend == nb) chunk_read[(nb + 15) >> 4] = (int32_t)r1;                     /* the entry past the last base (readers clamp) */
+    }
+    if (!PACKED) {
+        if (gend - g == 16) {
+            uint4 b = *(const uint4 *)(bases + g);
+            b.x = p0_class4(b.x); b.y = p0_class4(b.y); b.z = p0_class4(b.z); b.w = p0_class4(b.w);
+            *(uint4 *)(bases + g) = b;
+        } else for (int64_t k = g; k < gend; k++) bases[k] = (uint8_t)(p0_class4(bases[k]) & 0xffu);
+        return;
+    }
     uint32_t ow[4] = {0, 0, 0, 0};
     for (;; r++) {
-        const int64_t so = seq_off[r], e = seq_off[r + 1];
+        const int64_t so = staged ? (int64_t)s_so[r - r0] : seq_off[r], e = staged ? (int64_t)s_so[r - r0 + 1] : seq_off[r + 1];
         const int lo = so > g ? (int)(so - g) : 0, hi = e < gend ? (int)(e - g) : (int)(gend - g);
         if (lo < hi) {
+            /* as if the whole chunk lay in this read (x may be negative: the bytes before the read are masked away) */
             const int64_t x = g - so;                             /* (>> 1 floors, & 1 is the parity, also when negative) */
             const int64_t sb = (so >> 1) + r + (x >> 1);
             uint32_t d0, d1, d2;
-            if (sb >= 0) { const uint8_t *src = b4 + sb; d0 = *(const p0_u32u *)src; d1 = *(const p0_u32u *)(src + 4); d2 = *(const p0_u32u *)(src + 8); }
-            else {                                                /* the very first read of the batch, chunk bytes before it */
+            if (staged && sb >= B0) {
+                const int o = (int)(sb - B0), wi = o >> 2;
+                const unsigned sh = (unsigned)o & 3u;
+                const uint32_t w0 = s_b4[wi], w1 = s_b4[wi + 1], w2 = s_b4[wi + 2], w3 = s_b4[wi + 3];
+                d0 = kc2_alignbyte(w1, w0, sh); d1 = kc2_alignbyte(w2, w1, sh); d2 = kc2_alignbyte(w3, w2, sh);
+            } else {                                              /* bytes in front of the staged range (a chunk's bytes before its read), or no staging */
                 uint32_t t3[3] = {0, 0, 0};
                 for (int k = 0; k < 12; k++) if (sb + k >= 0) t3[k >> 2] |= (uint32_t)b4[sb + k] << (8 * (k & 3));
                 d0 = t3[0]; d1 = t3[1]; d2 = t3[2];
             }
-            const uint32_t h0 = (d0 >> 4) & 0x0f0f0f0fu, l0 = d0 & 0x0f0f0f0fu, h1 = (d1 >> 4) & 0x0f0f0f0fu, l1 = d1 & 0x0f0f0f0fu;
-            uint32_t xa, ya, xb, yb;                              /* output byte 2j = xa/xb[j], 2j + 1 = ya/yb[j] */
-            if (!(x & 1)) { xa = h0; ya = l0; xb = h1; yb = l1; }
-            else {                                                /* base 2j is the low nibble of byte j, base 2j + 1 the high one of byte j + 1 */
-                const uint32_t h2 = (d2 >> 4) & 0x0f0f0f0fu;
-                xa = l0; ya = (h0 >> 8) | (h1 << 24); xb = l1; yb = (h1 >> 8) | (h2 << 24);
-            }
-            const uint32_t v[4] = {p0_class4(P0_ILV_LO(xa, ya)), p0_class4(P0_ILV_HI(xa, ya)), p0_class4(P0_ILV_LO(xb, yb)), p0_class4(P0_ILV_HI(xb, yb))};
+            uint32_t v[4];
+            p0_unpack16(d0, d1, d2, (x & 1) != 0, v);
             const unsigned vb = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
             #pragma unroll
             for (int t = 0; t < 4; t++) {
@@ -229,171 +639,6 @@ k_p0_unpack4(int64_t nb, int64_t n, const int64_t *__restrict__ seq_off, const i
 }
 #undef P0_ILV_LO
 #undef P0_ILV_HI
-
-/* chunked exclusive scan of P0Cnt over reads; totals -> partial[nchunks] */
-#define P0_CHUNK 1024
-__device__ __forceinline__ void p0cnt_add(P0Cnt &a, const P0Cnt &b) { a.nseg += b.nseg; a.ncix += b.ncix; a.nslow += b.nslow; }
-__global__ void k_p0scan_reduce(int64_t n, const P0Cnt *__restrict__ cnt, P0Cnt *__restrict__ partial, int nchunks)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nchunks) return;
-    P0Cnt acc = {0, 0, 0};
-    const int64_t b = (int64_t)t * P0_CHUNK, e = b + P0_CHUNK < n ? b + P0_CHUNK : n;
-    for (int64_t i = b; i < e; i++) p0cnt_add(acc, cnt[i]);
-    partial[t] = acc;
-}
-/* exclusive scan of the chunk sums by ONE 1024-thread workgroup: a contiguous slice per thread, the thread sums
- * scanned through LDS (it was one thread walking 12 000 chunks: 1.7 ms per upload) */
-__global__ void __launch_bounds__(1024)
-k_p0scan_partials(P0Cnt *partial, int nchunks)
-{
-    __shared__ P0Cnt sh[1024];
-    const int t = threadIdx.x, nt = blockDim.x;
-    const int per = (nchunks + nt - 1) / nt;
-    const int b = t * per, e = b + per < nchunks ? b + per : nchunks;
-    P0Cnt acc = {0, 0, 0};
-    for (int i = b; i < e; i++) p0cnt_add(acc, partial[i]);
-    sh[t] = acc;
-    __syncthreads();
-    for (int d = 1; d < nt; d <<= 1) {                    /* Hillis-Steele inclusive scan of the thread sums */
-        P0Cnt v = {0, 0, 0};
-        if (t >= d) v = sh[t - d];
-        __syncthreads();
-        p0cnt_add(sh[t], v);
-        __syncthreads();
-    }
-    P0Cnt run = {0, 0, 0};
-    if (t > 0) run = sh[t - 1];
-    for (int i = b; i < e; i++) { const P0Cnt v = partial[i]; partial[i] = run; p0cnt_add(run, v); }
-    if (t == nt - 1) partial[nchunks] = sh[nt - 1];
-}
-__global__ void k_p0scan_apply(int64_t n, P0Cnt *__restrict__ cnt, const P0Cnt *__restrict__ partial, int nchunks)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nchunks) return;
-    P0Cnt run = partial[t];
-    const int64_t b = (int64_t)t * P0_CHUNK, e = b + P0_CHUNK < n ? b + P0_CHUNK : n;
-    for (int64_t i = b; i < e; i++) { const P0Cnt v = cnt[i]; cnt[i] = run; p0cnt_add(run, v); }
-}
-
-__global__ void k_p0_fill(int64_t n, int p0, const int32_t *__restrict__ pos, const uint8_t *__restrict__ mapq,
-                          const int64_t *__restrict__ seq_off, const int64_t *__restrict__ cig_off,
-                          const uint32_t *__restrict__ cigar, const uint8_t *__restrict__ inplp,
-                          const int32_t *__restrict__ end, const P0Cnt *__restrict__ off, const P0Cnt *__restrict__ total,
-                          Seg *__restrict__ segs, SegRec *__restrict__ sr, int32_t *__restrict__ sr_ppos,
-                          int32_t *__restrict__ sr_pend, ReadRec *__restrict__ rr, int64_t *__restrict__ seg_off,
-                          int32_t *__restrict__ cix, int64_t *__restrict__ slow_g, int32_t *__restrict__ slow_r,
-                          int *n_slow, const uint8_t *__restrict__ mq_slot, int want_cix)
-{
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const P0Cnt o = off[r];
-    seg_off[r] = o.nseg;
-    if (r == n - 1) seg_off[n] = total->nseg;
-    const int64_t so = seq_off[r];
-    const int lq = (int)(seq_off[r + 1] - so);
-    ReadRec x;
-    x.pos = pos[r]; x.end = end[r]; x.so = so; x.lq = lq; x.q0 = 0; x.info = mapq[r]; x.cix = 0;
-    if (!inplp[r]) { rr[r] = x; return; }
-    const uint32_t *cig = cigar + cig_off[r];
-    const int ncg = (int)(cig_off[r + 1] - cig_off[r]);
-    /* pass 1: the op table (Seg) and the self-contained records (SegRec) */
-    int64_t si = o.nseg;
-    const int64_t s_first = si;
-    int xr = 0, y = 0, nseg = 0;
-    for (int k = 0; k < ncg; k++) {
-        const int op = cig[k] & 15, l = (int)(cig[k] >> 4);
-        if (p0_is_mdnx(op)) {
-            if (l > 0) {
-                const uint32_t ty = (op == 2) ? SEG_D : (op == 3) ? SEG_N : SEG_M;
-                Seg s;
-                s.roff = xr; s.qstart = y; s.len_type = (uint32_t)l | (ty << 30);
-                s.indel_after = p0_indel_after(cig, ncg, k);
-                segs[si] = s;
-                SegRec q;
-                q.pos = x.pos + xr; q.end = q.pos + l; q.so = so; q.lq = lq;
-                q.qoff = (ty == SEG_M) ? y - q.pos : y;
-                q.indel_after = s.indel_after;
-                q.info = (uint32_t)mapq[r] | (ty << 8) | ((uint32_t)mq_slot[mapq[r]] << 16);
-                if (si == s_first) { q.info |= SR_FIRST; if (y > 0) q.info |= SR_HEADCLIP; x.q0 = y; }
-                sr[si] = q; sr_ppos[si] = x.pos; sr_pend[si] = x.end;
-                si++; nseg++;
-            }
-            xr += l;
-            if (op != 2 && op != 3) y += l;
-        } else if (op == 1 || op == 4) y += l;
-    }
-    {   /* the last op carries the tail flags */
-        SegRec q = sr[si - 1];
-        const Seg sl = segs[si - 1];
-        const int qt = (seg_type(sl) == SEG_M) ? sl.qstart + seg_len(sl) - 1 : sl.qstart;
-        q.info |= SR_LAST;
-        if (qt + 1 < lq) q.info |= SR_TAILCLIP;
-        sr[si - 1] = q;
-    }
-    const Seg s0 = segs[s_first];
-    const bool simple = nseg == 1 && seg_type(s0) == SEG_M && s0.indel_after == 0 && lq > 0;
-    if (simple) { x.info |= RR_SIMPLE; rr[r] = x; return; }
-    /* pass 2: base -> column table of a general CIGAR (replay).  Long-read batches that go through the packed replay
-     * (territories, k_p0_vrecs) never look a base up: only the list of bases that D/N columns report is made -- a
-     * base is reported by a run of consecutive D/N ops, so equal qstart of consecutive ops is the duplicate test */
-    x.cix = (uint32_t)(o.ncix / CIX_UNIT);
-    rr[r] = x;
-    if (!want_cix) {
-        int last = -1;
-        for (int64_t k = s_first; k < si; k++) {
-            const Seg sg = segs[k];
-            if (seg_type(sg) != SEG_M && sg.qstart < lq && sg.qstart != last) {
-                last = sg.qstart;
-                const int w = atomicAdd(n_slow, 1);
-                slow_g[w] = so + sg.qstart; slow_r[w] = (int32_t)r;
-            }
-        }
-        return;
-    }
-    int32_t *cx = cix + o.ncix;
-    for (int i = 0; i < lq; i++) cx[i] = -1;
-    for (int64_t k = s_first; k < si; k++) {
-        const Seg sg = segs[k];
-        if (seg_type(sg) != SEG_M) continue;
-        for (int i = 0; i < seg_len(sg) && sg.qstart + i < lq; i++) cx[sg.qstart + i] = (x.pos + sg.roff + i) - p0;
-    }
-    for (int64_t k = s_first; k < si; k++) {               /* bases that D/N columns report */
-        const Seg sg = segs[k];
-        if (seg_type(sg) != SEG_M && sg.qstart < lq && cx[sg.qstart] != -2) {
-            cx[sg.qstart] = -2;
-            const int w = atomicAdd(n_slow, 1);
-            slow_g[w] = so + sg.qstart; slow_r[w] = (int32_t)r;
-        }
-    }
-}
-
-/* monotone search keys for the per-tile candidate ranges of reads */
-__global__ void k_p0_keys(int64_t n, const int32_t *__restrict__ pos, const int32_t *__restrict__ end,
-                          const uint8_t *__restrict__ inplp, int32_t *__restrict__ kpos, int32_t *__restrict__ kend)
-{
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    kpos[r] = inplp[r] ? pos[r] : INT_MIN;
-    kend[r] = inplp[r] ? end[r] : INT_MIN;
-}
-
-/* For tile t = columns [c0, c0+63]: hi = first index whose (prefix-max) start key > c0+63,
- * lo = min(hi, first index whose (prefix-max) end key > c0): exactly the two-pointer walk over
- * position-sorted reads (entries between lo and hi that ended earlier are skipped by the kernels). */
-__global__ void k_p0_tiles(int n_tiles, int p0, int64_t n, const int32_t *__restrict__ kpos,
-                           const int32_t *__restrict__ kend, int32_t *__restrict__ tlo, int32_t *__restrict__ thi)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tiles) return;
-    const int64_t c0 = (int64_t)p0 + (int64_t)t * 64, c1 = c0 + 63;
-    int64_t lo = 0, hi = n;
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)kpos[mid] <= c1) lo = mid + 1; else hi = mid; }
-    const int64_t h = lo;
-    lo = 0; hi = h;
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)kend[mid] <= c0) lo = mid + 1; else hi = mid; }
-    tlo[t] = (int32_t)lo; thi[t] = (int32_t)h;
-}
 
 /* Long-read batches (k_columns2<MULTI>): the records (reference-consuming ops) that reach each 64-column tile, listed
  * once per batch in file order.  A tile's candidate range [stile_lo, stile_hi) holds every op of ~20 overlapping
@@ -508,144 +753,21 @@ k_p0_hitfill(int n_tiles, int p0, const int32_t *__restrict__ tlo, const int32_t
 }
 #undef P0_HIT_READ
 
-/* keep-BED cursor per tile (k_columns2): the first region whose prefix-max of `end` reaches the tile's first column --
- * every column's own cursor (bed_preserve, kernels.h) is at or behind it.  Once per batch instead of a search per tile
- * in every run (three dependent rounds of loads in the tile's epilogue: 9 % of k_columns2 on config 4). */
-__global__ void k_p0_tilebed(int n_tiles, int p0, int n_bed, const int32_t *__restrict__ bed_pmax, int32_t *__restrict__ tbed)
+/* chunked exclusive scan over int64 (the hit lists' offsets): a 256-thread workgroup per chunk of P0_CHUNK values,
+ * coalesced (a thread per chunk walking its 1024 values touched 64 cache lines per load instruction) */
+__global__ void __launch_bounds__(256)
+k_i64scan_reduce(int64_t n, const int64_t *__restrict__ v, int64_t *__restrict__ partial, int nchunks)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tiles) return;
-    const int64_t c0 = (int64_t)p0 + (int64_t)t * 64;
-    int lo = 0, hi = n_bed;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)bed_pmax[mid] < c0) lo = mid + 1; else hi = mid; }
-    tbed[t] = lo;
-}
-
-__global__ void k_p0_blkread(int64_t nblocks, int64_t n, const int64_t *__restrict__ seq_off, int32_t *__restrict__ blk_read)
-{
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nblocks) return;
-    const int64_t g0 = b * 64;
-    int64_t lo = 0, hi = n;                                /* first r with seq_off[r + 1] > g0 */
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (seq_off[mid + 1] <= g0) lo = mid + 1; else hi = mid; }
-    blk_read[b] = (int32_t)(lo < n ? lo : n - 1);
-}
-
-/* the same per 16-base chunk, from the block table (short-read batches: k_replay_fast starts its chunk
- * without walking forward from the block's read -- one dependent load less for every wave) */
-__global__ void k_p0_chunkread(int64_t nchunks, int64_t n, const int64_t *__restrict__ seq_off,
-                               const int32_t *__restrict__ blk_read, int32_t *__restrict__ chunk_read)
-{
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nchunks) return;
-    const int64_t g0 = c * 16;
-    int64_t r = blk_read[c >> 2];
-    while (r + 1 < n && seq_off[r + 1] <= g0) r++;
-    chunk_read[c] = (int32_t)r;
-}
-
-/* The same two tables for short-read batches, by scatter: read r owns the blocks / chunks whose first base lies in
- * [seq_off[r], seq_off[r+1]) -- a couple of blocks and ~10 chunks per 150-base read, instead of a 24-step binary
- * search per block (0.64 + 0.44 ms per upload) */
-__global__ void k_p0_owner_scatter(int64_t n, int64_t nb, const int64_t *__restrict__ seq_off,
-                                   int32_t *__restrict__ blk_read, int32_t *__restrict__ chunk_read)
-{
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const int64_t a = seq_off[r], b = seq_off[r + 1];
-    if (b <= a) return;
-    for (int64_t k = (a + 63) >> 6; k * 64 < b; k++) blk_read[k] = (int32_t)r;
-    for (int64_t k = (a + 15) >> 4; k * 16 < b; k++) chunk_read[k] = (int32_t)r;
-    if (b == nb) {                                         /* the entries past the last base (readers clamp) */
-        blk_read[(nb + 63) >> 6] = (int32_t)r;
-        chunk_read[(nb + 15) >> 4] = (int32_t)r;
-    }
-}
-
-/* k_replay_reads' work list: the reads with a general CIGAR and bases, in any order.  One atomic per 1024-thread
- * workgroup (ballot + prefix popcount inside the waves, the wave totals through LDS): an atomic per read or per wave
- * on the one counter costs more than the rest of the upload's kernels together. */
-__global__ void __launch_bounds__(1024)
-k_p0_genlist(int64_t n, const ReadRec *__restrict__ rr, int32_t *__restrict__ list, int *__restrict__ count)
-{
-    __shared__ int wcnt[16], wbase[16];
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    bool gen = false;
-    if (r < n) { const ReadRec x = rr[r]; gen = x.lq > 0 && x.end > x.pos && !(x.info & RR_SIMPLE); }
-    const unsigned long long m = __ballot(gen);
-    if (lane == 0) wcnt[w] = __popcll(m);
+    __shared__ long long ws[4];
+    const int64_t b = (int64_t)blockIdx.x * P0_CHUNK;
+    long long acc = 0;
+    #pragma unroll
+    for (int k = 0; k < P0_CHUNK / 256; k++) { const int64_t i = b + k * 256 + threadIdx.x; if (i < n) acc += v[i]; }
+    #pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int tot = 0;
-        for (int k = 0; k < (int)(blockDim.x >> 6); k++) { wbase[k] = tot; tot += wcnt[k]; }
-        const int base = tot ? atomicAdd(count, tot) : 0;
-        for (int k = 0; k < (int)(blockDim.x >> 6); k++) wbase[k] += base;
-    }
-    __syncthreads();
-    if (gen) list[wbase[w] + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)r;
-}
-
-/* Long-read batches: the territories of every read (VRec, dev_common.h) and the chunk -> territory table, by scatter
- * like k_p0_owner_scatter.  One thread per read. */
-__global__ void k_p0_vrecs(int64_t n, int64_t nb, int p0, int min_mqual, const ReadRec *__restrict__ rr,
-                           const int64_t *__restrict__ seg_off, const Seg *__restrict__ segs,
-                           VRec *__restrict__ vr, int32_t *__restrict__ chunk_vr)
-{
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const ReadRec x = rr[r];
-    const int64_t s0 = seg_off[r], base = s0 + r;
-    const int ns = (int)(seg_off[r + 1] - s0);
-    const int lq = x.lq;
-    const int hcol = (x.end > x.pos && (int)(x.info & 255u) <= min_mqual) ? x.pos - p0 : -1;
-    for (int j = -1; j < ns; j++) {
-        int qs = 0, qn = lq;
-        VRec v;
-        v.pos = v.end = 0; v.q0 = 0; v.hcol = hcol; v.read = (int32_t)r;
-        if (j >= 0) {
-            const Seg sg = segs[s0 + j];
-            qs = sg.qstart < lq ? sg.qstart : lq;
-            if (seg_type(sg) == SEG_M) {
-                const int len = seg_len(sg) < lq - qs ? seg_len(sg) : lq - qs;     /* fence: query bases that exist */
-                v.pos = x.pos + sg.roff; v.end = v.pos + (len > 0 ? len : 0);
-            }
-        }
-        if (j + 1 < ns) { const int q2 = segs[s0 + j + 1].qstart; qn = q2 < lq ? q2 : lq; }
-        if (qn < qs) qn = qs;
-        v.so = x.so + qs; v.lq = qn - qs;
-        const int64_t slot = base + 1 + j;
-        vr[slot] = v;
-        const int64_t a = v.so, b = v.so + v.lq;
-        for (int64_t k = (a + 15) >> 4; k * 16 < b; k++) chunk_vr[k] = (int32_t)slot;
-        if (b > a && b == nb) chunk_vr[(nb + 15) >> 4] = (int32_t)slot;           /* the entry past the last base */
-    }
-}
-
-/* Work split of k_columns: an estimated cost per 64-column tile (its candidate records plus a constant
- * for the per-tile prologue/epilogue), prefix-summed, so that every wave can take a CONTIGUOUS run of
- * tiles of equal total cost -- no atomics, adjacent tiles (which share their reads) stay in one wave. */
-#define TILE_COST_SPAN (1ll << 56)               /* marks a tile whose reads span too much of the base array */
-__global__ void k_tile_cost(int n_tiles, const int32_t *__restrict__ slo, const int32_t *__restrict__ shi,
-                            const SegRec *__restrict__ sr, const int64_t *__restrict__ hit_off, int64_t *__restrict__ cost)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tiles) return;
-    const int w = shi[t] - slo[t];
-    /* long reads (hit_off): the records that reach the tile, not the candidates around them */
-    int64_t c = hit_off ? (hit_off[t + 1] - hit_off[t]) + 2 : w + 2;
-    /* k_columns2 addresses the bases of a tile's reads with 32-bit offsets from the first one */
-    if (w > 0 && sr[shi[t] - 1].so - sr[slo[t]].so > 0xf0000000ll) c = TILE_COST_SPAN;
-    cost[t] = c;
-}
-__global__ void k_i64scan_reduce(int64_t n, const int64_t *__restrict__ v, int64_t *__restrict__ partial, int nchunks)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nchunks) return;
-    int64_t acc = 0;
-    const int64_t b = (int64_t)t * P0_CHUNK, e = b + P0_CHUNK < n ? b + P0_CHUNK : n;
-    for (int64_t i = b; i < e; i++) acc += v[i];
-    partial[t] = acc;
+    if (threadIdx.x == 0) partial[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 __global__ void __launch_bounds__(1024)
 k_i64scan_partials(int64_t *partial, int nchunks)
@@ -670,25 +792,25 @@ k_i64scan_partials(int64_t *partial, int nchunks)
     if (t == nt - 1) partial[nchunks] = sh[nt - 1];
 }
 /* exclusive scan in place; v[n] receives the total */
-__global__ void k_i64scan_apply(int64_t n, int64_t *__restrict__ v, const int64_t *__restrict__ partial, int nchunks)
+__global__ void __launch_bounds__(256)
+k_i64scan_apply(int64_t n, int64_t *__restrict__ v, const int64_t *__restrict__ partial, int nchunks)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nchunks) return;
-    int64_t run = partial[t];
-    const int64_t b = (int64_t)t * P0_CHUNK, e = b + P0_CHUNK < n ? b + P0_CHUNK : n;
-    for (int64_t i = b; i < e; i++) { const int64_t x = v[i]; v[i] = run; run += x; }
-    if (t == nchunks - 1) v[n] = run;
-}
-
-/* unit g of the cost prefix starts at tile unit_first[g] = first t with cum[t] >= g*KCOL_UNIT */
-__global__ void k_unit_first(int n_units, int n_tiles, const int64_t *__restrict__ cum, int32_t *__restrict__ unit_first)
-{
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g > n_units) return;
-    const int64_t c = (int64_t)g * KCOL_UNIT;
-    int lo = 0, hi = n_tiles;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (cum[mid] < c) lo = mid + 1; else hi = mid; }
-    unit_first[g] = g == n_units ? n_tiles : lo;
+    __shared__ long long ws[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i0 = (int64_t)blockIdx.x * P0_CHUNK + (int64_t)threadIdx.x * 4;      /* four consecutive values per thread */
+    long long x[4], tot = 0;
+    #pragma unroll
+    for (int k = 0; k < 4; k++) { x[k] = i0 + k < n ? v[i0 + k] : 0; tot += x[k]; }
+    long long inc = tot;
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const long long o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+    if (lane == 63) ws[w] = inc;
+    __syncthreads();
+    long long run = partial[blockIdx.x] + inc - tot;
+    for (int j = 0; j < w; j++) run += ws[j];
+    #pragma unroll
+    for (int k = 0; k < 4; k++) { if (i0 + k < n) v[i0 + k] = run; run += x[k]; }
+    if (blockIdx.x == (unsigned)(nchunks - 1) && threadIdx.x == 255) v[n] = partial[blockIdx.x] + ws[0] + ws[1] + ws[2] + (w == 3 ? inc : 0);
 }
 
 #endif
