@@ -535,7 +535,7 @@ static int expand(crumble_hip *h, bool wait)
     if (h->opt_kcol == 1 || h->opt_kcol == 2) h->col_perm = h->opt_kcol == 2;
     h->b_kcol = h->opt_kcol; h->b_pblock = h->opt_pblock;
     h->n_segrec = tot.nseg; h->n_slow = tot.nslow;  /* upper bound; the exact count is d_nslow */
-    h->n_general_max = tot.ncixu;                   /* upper bound; the exact count is d_nslow[1] */
+    h->n_general_max = tot.ngen;                    /* general-CIGAR reads with bases (d_nslow[1] on the device) */
 
     /* 2. expanded tables */
     const size_t ns = (size_t)tot.nseg;
@@ -543,13 +543,16 @@ static int expand(crumble_hip *h, bool wait)
     /* long reads through the packed replay need no base -> column table (4 B per base of every multi-op read) */
     h->batch_flat = h->opt_replay == 1;
     const bool vrec_path = multi && h->packed_ok && !h->batch_flat && tot.nseg + n < (int64_t)INT_MAX - 64;
-    const bool want_cix = !vrec_path;
+    /* which replay the run will take (crumble_hip_run_finish): the packed kernels find a general read's columns in its op
+     * table; only k_replay_flat looks them up in the base -> column table */
+    const bool packed_path = h->packed_ok && !h->batch_flat && (!multi || vrec_path);
+    const bool want_cix = !packed_path && !h->hparams.softclip;
     const size_t nblkb = (size_t)(nb / 64 + 1);
     const int64_t nch = (nb + 15) / 16;
     if ((e = h->d_segs.reserve((ns + 1) * sizeof(Seg))) || (e = h->d_sr.reserve((ns + 1) * sizeof(SegRec))) ||
         (e = h->d_rr.reserve((size_t)(n + 1) * sizeof(ReadRec))) || (e = h->d_seg_off.reserve((size_t)(n + 2) * 8)) ||
         (e = h->d_cix.reserve((want_cix ? (size_t)tot_ncix + 1 : 1) * 4)) ||
-        (e = h->d_genlist.reserve(((size_t)tot.ncixu + 1) * 4)) ||     /* every general read with bases has >= one unit */
+        (e = h->d_genlist.reserve(((size_t)tot.ngen + 1) * 4)) ||
         (e = h->d_slow_g.reserve(((size_t)tot.nslow + 1) * 8)) ||
         (e = h->d_slow_r.reserve(((size_t)tot.nslow + 1) * 4)) || (e = h->d_kpos.reserve((size_t)(n + 1) * 4)) ||
         (e = h->d_kend.reserve((size_t)(n + 1) * 4)) || (e = h->d_tile_lo.reserve((size_t)(B.n_tiles + 1) * 4)) ||
@@ -561,17 +564,24 @@ static int expand(crumble_hip *h, bool wait)
     if (n == 0) HIPCHK(hipMemsetAsync(h->d_seg_off.p, 0, 16, st));
     if (n > 0) {
         VRec *vrp = vrec_path ? h->d_vrec.as<VRec>() : (VRec *)nullptr;
-        int32_t *gl = (want_cix && tot.ncixu > 0) ? h->d_genlist.as<int32_t>() : (int32_t *)nullptr;
+        int32_t *gl = (tot.ngen > 0 && !vrec_path) ? h->d_genlist.as<int32_t>() : (int32_t *)nullptr;     /* k_p0_cix, k_replay_reads */
 #define FILL_LAUNCH(GW_) CRUMBLE_LAUNCH((k_p0_fill<GW_>), nblk(n, P0_CHUNK), P0_CHUNK, st, n, nb, B.p0, h->d_pos.as<int32_t>(), h->d_mapq.as<uint8_t>(), \
                        h->d_seq_off.as<int64_t>(), h->d_cig_off.as<int64_t>(), h->d_cigar.as<uint32_t>(), h->d_inplp.as<uint8_t>(), \
                        h->d_end.as<int32_t>(), cnt, part, nblocks, h->d_segs.as<Seg>(), h->d_sr.as<SegRec>(), h->d_rr.as<ReadRec>(), \
                        h->d_seg_off.as<int64_t>(), h->d_kpos.as<int32_t>(), h->d_kend.as<int32_t>(), h->d_slow_g.as<int64_t>(), \
                        h->d_slow_r.as<int32_t>(), d_nslow, gl, d_nslow + 1, h->d_mqslot.as<uint8_t>(), h->d_blk_read.as<int32_t>(), \
                        vrp, h->d_chunk_read.as<int32_t>(), h->hparams.min_mqual, d_err)
-        if (multi) FILL_LAUNCH(64); else FILL_LAUNCH(1);
+        if (multi) {
+            FILL_LAUNCH(0);
+            CRUMBLE_LAUNCH(k_p0_fill_long, nblk(n, 4), 256, st, n, nb, B.p0, h->d_pos.as<int32_t>(), h->d_mapq.as<uint8_t>(),
+                           h->d_seq_off.as<int64_t>(), h->d_cig_off.as<int64_t>(), h->d_cigar.as<uint32_t>(), h->d_inplp.as<uint8_t>(),
+                           h->d_end.as<int32_t>(), cnt, h->d_segs.as<Seg>(), h->d_sr.as<SegRec>(), h->d_rr.as<ReadRec>(),
+                           h->d_seg_off.as<int64_t>(), h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(), d_nslow,
+                           h->d_mqslot.as<uint8_t>(), h->d_blk_read.as<int32_t>(), vrp, h->d_chunk_read.as<int32_t>(), h->hparams.min_mqual);
+        } else FILL_LAUNCH(1);
 #undef FILL_LAUNCH
-        if (gl) {                                            /* short-read batches: base -> column table of the general-CIGAR reads */
-            const unsigned g = (unsigned)(tot.ncixu < 4 * 4096 ? (tot.ncixu + 3) / 4 : 4096);
+        if (gl && want_cix) {                                /* k_replay_flat: base -> column table of the general-CIGAR reads */
+            const unsigned g = (unsigned)(tot.ngen < 4 * 4096 ? (tot.ngen + 3) / 4 : 4096);
             CRUMBLE_LAUNCH(k_p0_cix, g, 256, st, B.p0, h->d_genlist.as<int32_t>(), d_nslow + 1, h->d_rr.as<ReadRec>(),
                            h->d_seg_off.as<int64_t>(), h->d_segs.as<Seg>(), h->d_cix.as<int32_t>());
         }

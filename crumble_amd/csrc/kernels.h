@@ -2225,19 +2225,34 @@ k_replay_reads(DBatch B, const DParams *__restrict__ P, const uint32_t *__restri
         if (!(rr.lq > 0 && rr.end > rr.pos && !(rr.info & RR_SIMPLE))) continue;
         const int n = rr.lq;
         const int hms = ((int)(rr.info & 255) <= P->min_mqual && !(colrec[rr.pos - B.p0] & CR_SKIP)) ? 1 : 0;
-        const unsigned cx = rr.cix;
         const int64_t s0 = rr.so;
+        const int64_t sg0 = B.seg_off[rs];
+        const int nsg = (int)(B.seg_off[rs + 1] - sg0);
         for (int x0 = lane; x0 < n; x0 += 256) {               /* four bases per lane: the gathers of all four in flight */
-            /* base -> column table of the read (built with the batch): -1 no column, -2 a D/N column
-             * reports this base (k_replay_slow, afterwards) */
+            /* the column of every base from the read's op table (a few ops, wave-uniform look-ups): -1 no column, -2 a
+             * D/N column reports this base (k_replay_slow, afterwards).  (Rounds 1-3 read this from a base -> column
+             * table written at upload: 4 bytes per base of every general read and a kernel of its own.) */
             int c4[4];
             uint32_t q4[4], b4[4], r4[4];
             #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int x = x0 + 64 * u;
                 c4[u] = -1; q4[u] = 0; b4[u] = 0;
-                if (x < n) { c4[u] = B.cix[(size_t)cx * CIX_UNIT + (size_t)x]; q4[u] = B.quals[s0 + x]; b4[u] = B.bases[s0 + x]; }
+                if (x < n) { q4[u] = B.quals[s0 + x]; b4[u] = B.bases[s0 + x]; }
             }
+            for (int k = 0; k < nsg; k++) {
+                const Seg sg = B.segs[sg0 + k];
+                const bool isM = seg_type(sg) == SEG_M;
+                const int col0 = rr.pos + sg.roff - B.p0;
+                #pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int off = x0 + 64 * u - sg.qstart;
+                    if (isM) { if (off >= 0 && off < seg_len(sg) && c4[u] != -2) c4[u] = col0 + off; }
+                    else if (off == 0) c4[u] = -2;
+                }
+            }
+            #pragma unroll
+            for (int u = 0; u < 4; u++) if (x0 + 64 * u >= n) c4[u] = -1;
             #pragma unroll
             for (int u = 0; u < 4; u++) r4[u] = c4[u] >= 0 ? colrec[c4[u]] : 0u;
             #pragma unroll

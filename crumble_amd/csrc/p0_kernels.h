@@ -30,7 +30,7 @@
 struct P0Cnt32 { int32_t nseg, ncixu /* base -> column entries, in units of CIX_UNIT */, nslow, pad; };
 /* per 1024-read block: the block's sums and maxima from k_p0_classify, turned by k_p0_mid into what lies before the block
  * (exclusive sums, prefix maxima); entry [nblocks] holds the totals */
-struct P0Part { int64_t nseg, ncixu, nslow; int32_t maxpos, maxend; };
+struct P0Part { int64_t nseg, ncixu, nslow, ngen /* general-CIGAR reads with bases */; int32_t maxpos, maxend; };
 #define P0_CHUNK 1024
 
 #define P0_ERR_NEG      1
@@ -130,11 +130,12 @@ k_p0_classify(int64_t n, int tid, const int32_t *__restrict__ pos, const uint16_
         p0_classify_read(r, tid, pos, flag, seq_off, cig_off, cigar, inplp, end, c, err, mn, mx, nb, nc);
         cnt[r] = c;
     }
-    __shared__ int wmn[16], wmx[16], wpk[16], wns[16], wsl[16];
+    __shared__ int wmn[16], wmx[16], wpk[16], wns[16], wsl[16], wgn[16];
     __shared__ long long wcx[16];
     int pk = mn == INT_MAX ? INT_MIN : mn;                 /* start of a read in the pileup (the search key's source) */
     int ns = c.nseg, sl = c.nslow;
     long long cx = c.ncixu;
+    const int gn = __popcll(__ballot(c.ncixu > 0));        /* general-CIGAR reads with bases: the ones with table entries */
     #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         const int a = __shfl_xor(mn, d), b = __shfl_xor(mx, d), k2 = __shfl_xor(pk, d);
@@ -142,14 +143,14 @@ k_p0_classify(int64_t n, int tid, const int32_t *__restrict__ pos, const uint16_
         ns += __shfl_xor(ns, d); sl += __shfl_xor(sl, d); cx += __shfl_xor(cx, d);
     }
     const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { wmn[w] = mn; wmx[w] = mx; wpk[w] = pk; wns[w] = ns; wsl[w] = sl; wcx[w] = cx; }
+    if ((threadIdx.x & 63) == 0) { wmn[w] = mn; wmx[w] = mx; wpk[w] = pk; wns[w] = ns; wsl[w] = sl; wcx[w] = cx; wgn[w] = gn; }
     __syncthreads();
     if (threadIdx.x == 0) {
         P0Part t;
-        t.nseg = 0; t.ncixu = 0; t.nslow = 0;
+        t.nseg = 0; t.ncixu = 0; t.nslow = 0; t.ngen = 0;
         for (int k = 0; k < (int)(blockDim.x >> 6); k++) {
             if (k) { mn = wmn[k] < mn ? wmn[k] : mn; mx = wmx[k] > mx ? wmx[k] : mx; pk = wpk[k] > pk ? wpk[k] : pk; }
-            t.nseg += wns[k]; t.ncixu += wcx[k]; t.nslow += wsl[k];
+            t.nseg += wns[k]; t.ncixu += wcx[k]; t.nslow += wsl[k]; t.ngen += wgn[k];
         }
         t.maxpos = pk; t.maxend = mx;
         part[blockIdx.x] = t;
@@ -168,32 +169,32 @@ k_p0_mid(P0Part *part, int nblocks)
     const int per = (nblocks + nt - 1) / nt;
     const int b = t * per, e = b + per < nblocks ? b + per : nblocks;
     P0Part acc;
-    acc.nseg = acc.ncixu = acc.nslow = 0; acc.maxpos = acc.maxend = INT_MIN;
+    acc.nseg = acc.ncixu = acc.nslow = acc.ngen = 0; acc.maxpos = acc.maxend = INT_MIN;
     for (int i = b; i < e; i++) {
         const P0Part v = part[i];
-        acc.nseg += v.nseg; acc.ncixu += v.ncixu; acc.nslow += v.nslow;
+        acc.nseg += v.nseg; acc.ncixu += v.ncixu; acc.nslow += v.nslow; acc.ngen += v.ngen;
         acc.maxpos = v.maxpos > acc.maxpos ? v.maxpos : acc.maxpos; acc.maxend = v.maxend > acc.maxend ? v.maxend : acc.maxend;
     }
     sh[t] = acc;
     __syncthreads();
     for (int d = 1; d < nt; d <<= 1) {                    /* Hillis-Steele inclusive scan of the thread sums */
         P0Part v;
-        v.nseg = v.ncixu = v.nslow = 0; v.maxpos = v.maxend = INT_MIN;
+        v.nseg = v.ncixu = v.nslow = v.ngen = 0; v.maxpos = v.maxend = INT_MIN;
         if (t >= d) v = sh[t - d];
         __syncthreads();
         P0Part x = sh[t];
-        x.nseg += v.nseg; x.ncixu += v.ncixu; x.nslow += v.nslow;
+        x.nseg += v.nseg; x.ncixu += v.ncixu; x.nslow += v.nslow; x.ngen += v.ngen;
         x.maxpos = v.maxpos > x.maxpos ? v.maxpos : x.maxpos; x.maxend = v.maxend > x.maxend ? v.maxend : x.maxend;
         sh[t] = x;
         __syncthreads();
     }
     P0Part run;
-    run.nseg = run.ncixu = run.nslow = 0; run.maxpos = run.maxend = INT_MIN;
+    run.nseg = run.ncixu = run.nslow = run.ngen = 0; run.maxpos = run.maxend = INT_MIN;
     if (t > 0) run = sh[t - 1];
     for (int i = b; i < e; i++) {
         const P0Part v = part[i];
         part[i] = run;
-        run.nseg += v.nseg; run.ncixu += v.ncixu; run.nslow += v.nslow;
+        run.nseg += v.nseg; run.ncixu += v.ncixu; run.nslow += v.nslow; run.ngen += v.ngen;
         run.maxpos = v.maxpos > run.maxpos ? v.maxpos : run.maxpos; run.maxend = v.maxend > run.maxend ? v.maxend : run.maxend;
     }
     if (t == nt - 1) part[nblocks] = sh[nt - 1];
@@ -205,9 +206,8 @@ k_p0_mid(P0Part *part, int nblocks)
  * start and end over the reads in the pileup -- the monotone search keys of k_p0_tiles (a read outside the pileup
  * inherits its predecessor's) -- and with them the coordinate-order test of snp:1075: a read in the pileup must not start
  * before the largest start in front of it.
- * Phase B, the ops of each read: GW = 1 a lane per read (short reads: one to three ops), GW = 64 the wave takes its 64
- * reads one after another, 64 CIGAR ops per step with wave scans for the reference / query offsets (long reads: hundreds
- * of ops; one lane per read left 331 k lanes walking 300 ops each).  Every record is written once and never read back. */
+ * Phase B, the ops of each read: GW = 1 here, a lane per read (short reads: one to three ops); GW = 0 leaves them to
+ * k_p0_fill_long, a wave per read (long reads: hundreds of ops).  Every record is written once and never read back. */
 struct P0Op {            /* one CIGAR op of a read with what lies in front of it */
     int k, op, l, x0, y0, si;
 };
@@ -216,7 +216,7 @@ __device__ __forceinline__ void p0_emit_op(const P0Op &o, int64_t r, int ncg, co
                                            unsigned mq, unsigned slot, int nseg, int64_t segbase, int64_t cixu, int p0,
                                            Seg *__restrict__ segs, SegRec *__restrict__ sr, ReadRec *__restrict__ rr,
                                            int64_t *__restrict__ slow_g, int32_t *__restrict__ slow_r, int *__restrict__ n_slow,
-                                           VRec *__restrict__ vr, int32_t *__restrict__ chunk_vr, int64_t nb, int hcol, bool &general)
+                                           VRec *__restrict__ vr, int32_t *__restrict__ chunk_vr, int64_t nb, int hcol)
 {
     const uint32_t ty = (o.op == 2) ? SEG_D : (o.op == 3) ? SEG_N : SEG_M;
     const int ia = p0_indel_after(cig, ncg, o.k);
@@ -241,7 +241,6 @@ __device__ __forceinline__ void p0_emit_op(const P0Op &o, int64_t r, int ncg, co
         x.pos = rpos; x.end = rend; x.so = so; x.lq = lq; x.q0 = o.y0;
         x.info = mq | (simple ? RR_SIMPLE : 0u); x.cix = simple ? 0u : (uint32_t)cixu;
         rr[r] = x;
-        general = !simple && lq > 0;
     }
     /* bases that D/N columns report (htslib shows them the NEXT base): once per base -- a D/N op behind another one
      * with no query base in between reports the same base */
@@ -295,14 +294,14 @@ __global__ void __launch_bounds__(1024)
 k_p0_fill(int64_t n, int64_t nb, int p0, const int32_t *__restrict__ pos, const uint8_t *__restrict__ mapq,
           const int64_t *__restrict__ seq_off, const int64_t *__restrict__ cig_off,
           const uint32_t *__restrict__ cigar, const uint8_t *__restrict__ inplp,
-          const int32_t *__restrict__ end, const P0Cnt32 *__restrict__ cnt, const P0Part *__restrict__ part, int nblocks,
+          const int32_t *__restrict__ end, P0Cnt32 *__restrict__ cnt, const P0Part *__restrict__ part, int nblocks,
           Seg *__restrict__ segs, SegRec *__restrict__ sr, ReadRec *__restrict__ rr, int64_t *__restrict__ seg_off,
           int32_t *__restrict__ kpos, int32_t *__restrict__ kend,
           int64_t *__restrict__ slow_g, int32_t *__restrict__ slow_r, int *__restrict__ n_slow,
           int32_t *__restrict__ genlist, int *__restrict__ n_gen, const uint8_t *__restrict__ mq_slot,
           int32_t *__restrict__ blk_read, VRec *__restrict__ vr, int32_t *__restrict__ chunk_vr, int min_mqual, int *__restrict__ err)
 {
-    __shared__ int w_ns[16], w_ps[16], w_en[16], w_gen[16], w_genbase[16];
+    __shared__ int w_ns[16], w_ps[16], w_en[16], w_gn[16];
     __shared__ long long w_cx[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -319,13 +318,17 @@ k_p0_fill(int64_t n, int64_t nb, int p0, const int32_t *__restrict__ pos, const 
     for (int d = 1; d < 64; d <<= 1) { const long long o = __shfl_up(i_cx, d); if (lane >= d) i_cx += o; }
     int x_ps = __shfl_up(i_ps, 1);                         /* the largest start in front of this read, inside the wave */
     if (lane == 0) x_ps = INT_MIN;
-    if (lane == 63) { w_ns[w] = i_ns; w_ps[w] = i_ps; w_en[w] = i_en; w_cx[w] = i_cx; }
+    /* general-CIGAR reads with bases are the ones with table entries: their list (k_p0_cix, k_replay_reads) in file order */
+    const bool general = c.ncixu > 0;
+    const unsigned long long gm = __ballot(general);
+    if (lane == 63) { w_ns[w] = i_ns; w_ps[w] = i_ps; w_en[w] = i_en; w_cx[w] = i_cx; w_gn[w] = __popcll(gm); }
     __syncthreads();
     const P0Part pb = part[blockIdx.x];
     int64_t o_ns = pb.nseg + (i_ns - c.nseg), o_cx = pb.ncixu + (i_cx - c.ncixu);
+    int64_t o_gn = pb.ngen + __popcll(gm & ((1ull << lane) - 1ull));
     int k_ps = pb.maxpos, k_en = pb.maxend;
     for (int j = 0; j < w; j++) {
-        o_ns += w_ns[j]; o_cx += w_cx[j];
+        o_ns += w_ns[j]; o_cx += w_cx[j]; o_gn += w_gn[j];
         k_ps = w_ps[j] > k_ps ? w_ps[j] : k_ps; k_en = w_en[j] > k_en ? w_en[j] : k_en;
     }
     x_ps = x_ps > k_ps ? x_ps : k_ps;
@@ -337,12 +340,14 @@ k_p0_fill(int64_t n, int64_t nb, int p0, const int32_t *__restrict__ pos, const 
         lq = (int)(seq_off[r + 1] - so);
         if (in && rpos < x_ps) atomicMax(err, P0_ERR_UNSORTED);            /* snp:1075 */
         seg_off[r] = o_ns; kpos[r] = k_ps; kend[r] = k_en;
-        if (r == n - 1) seg_off[n] = part[nblocks].nseg;
+        if (r == n - 1) { seg_off[n] = part[nblocks].nseg; *n_gen = (int)part[nblocks].ngen; }
+        if (GW == 0) cnt[r].pad = (int32_t)(uint32_t)o_cx;                    /* k_p0_fill_long takes it from there */
+        if (general && genlist) genlist[o_gn] = (int32_t)r;
         if (!in) {                                         /* never in the pileup: only the epilogue touches it */
             ReadRec x;
             x.pos = rpos; x.end = rend; x.so = so; x.lq = lq; x.q0 = 0; x.info = mapq[r]; x.cix = 0;
             rr[r] = x;
-            if (GW == 64 && vr) {                          /* its one territory: the whole read */
+            if (GW == 0 && vr) {                           /* its one territory: the whole read */
                 VRec f;
                 f.pos = f.end = 0; f.q0 = 0; f.hcol = -1; f.read = (int32_t)r; f.so = so; f.lq = lq;
                 const int64_t vslot = o_ns + r;
@@ -356,8 +361,7 @@ k_p0_fill(int64_t n, int64_t nb, int p0, const int32_t *__restrict__ pos, const 
             if (so + lq == nb) blk_read[(nb + 63) >> 6] = (int32_t)r;       /* the entry past the last base (readers clamp) */
         }
     }
-    /* ---- phase B */
-    bool general = false;
+    /* ---- phase B (GW == 0: k_p0_fill_long does it, a wave per read) */
     if (GW == 1) {
         if (in) {
             const uint32_t *cig = cigar + cig_off[r];
@@ -371,7 +375,7 @@ k_p0_fill(int64_t n, int64_t nb, int p0, const int32_t *__restrict__ pos, const 
                 if (p0_is_mdnx(o.op)) {
                     if (o.l > 0) {
                         p0_emit_op<false>(o, r, ncg, cig, rpos, rend, so, lq, mq, slot, c.nseg, o_ns, o_cx, p0, segs, sr, rr,
-                                          slow_g, slow_r, n_slow, vr, chunk_vr, nb, hcol, general);
+                                          slow_g, slow_r, n_slow, vr, chunk_vr, nb, hcol);
                         o.si++;
                     }
                     o.x0 += o.l;
@@ -379,57 +383,57 @@ k_p0_fill(int64_t n, int64_t nb, int p0, const int32_t *__restrict__ pos, const 
                 } else if (o.op == 1 || o.op == 4) o.y0 += o.l;
             }
         }
-    } else {
-        for (int i = 0; i < 64; i++) {
-            const int64_t ri = (int64_t)blockIdx.x * blockDim.x + (int64_t)w * 64 + i;
-            if (ri >= n) break;
-            const int in_i = __shfl((int)in, i);
-            const int64_t so_i = __shfl(so, i), ons_i = __shfl(o_ns, i), ocx_i = __shfl(o_cx, i);
-            const int lq_i = __shfl(lq, i), rpos_i = __shfl(rpos, i), rend_i = __shfl(rend, i), nseg_i = __shfl(c.nseg, i);
-            if (lq_i > 0 && blk_read) {                    /* block -> read table, the wave's lanes over the read's blocks */
-                for (int64_t k2 = ((so_i + 63) >> 6) + lane; k2 * 64 < so_i + lq_i; k2 += 64) blk_read[k2] = (int32_t)ri;
-                if (lane == 0 && so_i + lq_i == nb) blk_read[(nb + 63) >> 6] = (int32_t)ri;
-            }
-            if (!in_i) continue;
-            const int64_t co = cig_off[ri];
-            const uint32_t *cig = cigar + co;
-            const int ncg = (int)(cig_off[ri + 1] - co);
-            const unsigned mq = mapq[ri], slot = mq_slot[mq];
-            const int hcol = ((int)mq <= min_mqual) ? rpos_i - p0 : -1;
-            int cx0 = 0, cy0 = 0, cs0 = 0;
-            bool gen_i = false;
-            for (int k0 = 0; k0 < ncg; k0 += 64) {
-                const int k = k0 + lane;
-                P0Op o;
-                o.k = k; o.op = -1; o.l = 0;
-                if (k < ncg) { o.op = cig[k] & 15; o.l = (int)(cig[k] >> 4); }
-                const bool isref = o.op >= 0 && p0_is_mdnx(o.op);
-                const int dx = isref ? o.l : 0;
-                const int dy = (o.op == 0 || o.op == 1 || o.op == 4 || o.op == 7 || o.op == 8) ? o.l : 0;
-                const int ds = (isref && o.l > 0) ? 1 : 0;
-                const int ix = kc2_scan_add(dx), iy = kc2_scan_add(dy), is = kc2_scan_add(ds);
-                o.x0 = cx0 + ix - dx; o.y0 = cy0 + iy - dy; o.si = cs0 + is - ds;
-                if (ds)
-                    p0_emit_op<true>(o, ri, ncg, cig, rpos_i, rend_i, so_i, lq_i, mq, slot, nseg_i, ons_i, ocx_i, p0, segs, sr, rr,
-                                     slow_g, slow_r, n_slow, vr, chunk_vr, nb, hcol, gen_i);
-                cx0 += __shfl(ix, 63); cy0 += __shfl(iy, 63); cs0 += __shfl(is, 63);
-            }
-            if (__ballot(gen_i) != 0ull && lane == i) general = true;
-        }
     }
-    /* the list of general-CIGAR reads (k_p0_cix, k_replay_reads), any order: one atomic per workgroup */
-    if (genlist) {
-        const unsigned long long m = __ballot(general);
-        if (lane == 0) w_gen[w] = __popcll(m);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int tot = 0;
-            for (int k = 0; k < (int)(blockDim.x >> 6); k++) { w_genbase[k] = tot; tot += w_gen[k]; }
-            const int base = tot ? atomicAdd(n_gen, tot) : 0;
-            for (int k = 0; k < (int)(blockDim.x >> 6); k++) w_genbase[k] += base;
-        }
-        __syncthreads();
-        if (general) genlist[w_genbase[w] + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)r;
+}
+
+/* Phase B for long reads: ONE WAVE PER READ, 64 CIGAR ops per step with wave scans for the reference / query offsets
+ * (hundreds of ops per read; a lane per read left 331 k lanes walking 300 ops each, and the waves of a 1024-read
+ * workgroup taking their 64 reads one after another left the chip a few hundred workgroups).  k_p0_fill<0> has
+ * written every read's slice of the tables (seg_off, the base -> column offset in cnt[r].pad) before. */
+__global__ void __launch_bounds__(256)
+k_p0_fill_long(int64_t n, int64_t nb, int p0, const int32_t *__restrict__ pos, const uint8_t *__restrict__ mapq,
+               const int64_t *__restrict__ seq_off, const int64_t *__restrict__ cig_off,
+               const uint32_t *__restrict__ cigar, const uint8_t *__restrict__ inplp,
+               const int32_t *__restrict__ end, const P0Cnt32 *__restrict__ cnt,
+               Seg *__restrict__ segs, SegRec *__restrict__ sr, ReadRec *__restrict__ rr, const int64_t *__restrict__ seg_off,
+               int64_t *__restrict__ slow_g, int32_t *__restrict__ slow_r, int *__restrict__ n_slow,
+               const uint8_t *__restrict__ mq_slot, int32_t *__restrict__ blk_read, VRec *__restrict__ vr,
+               int32_t *__restrict__ chunk_vr, int min_mqual)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t ri = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ri >= n) return;                                   /* (the whole wave) */
+    const int64_t so_i = seq_off[ri];
+    const int lq_i = (int)(seq_off[ri + 1] - so_i);
+    if (lq_i > 0 && blk_read) {                            /* block -> read table, the wave's lanes over the read's blocks */
+        for (int64_t k2 = ((so_i + 63) >> 6) + lane; k2 * 64 < so_i + lq_i; k2 += 64) blk_read[k2] = (int32_t)ri;
+        if (lane == 0 && so_i + lq_i == nb) blk_read[(nb + 63) >> 6] = (int32_t)ri;
+    }
+    if (!inplp[ri]) return;
+    const P0Cnt32 c = cnt[ri];
+    const int rpos_i = pos[ri], rend_i = end[ri], nseg_i = c.nseg;
+    const int64_t ons_i = seg_off[ri], ocx_i = (int64_t)(uint32_t)c.pad;
+    const int64_t co = cig_off[ri];
+    const uint32_t *cig = cigar + co;
+    const int ncg = (int)(cig_off[ri + 1] - co);
+    const unsigned mq = mapq[ri], slot = mq_slot[mq];
+    const int hcol = ((int)mq <= min_mqual) ? rpos_i - p0 : -1;
+    int cx0 = 0, cy0 = 0, cs0 = 0;
+    for (int k0 = 0; k0 < ncg; k0 += 64) {
+        const int k = k0 + lane;
+        P0Op o;
+        o.k = k; o.op = -1; o.l = 0;
+        if (k < ncg) { o.op = cig[k] & 15; o.l = (int)(cig[k] >> 4); }
+        const bool isref = o.op >= 0 && p0_is_mdnx(o.op);
+        const int dx = isref ? o.l : 0;
+        const int dy = (o.op == 0 || o.op == 1 || o.op == 4 || o.op == 7 || o.op == 8) ? o.l : 0;
+        const int ds = (isref && o.l > 0) ? 1 : 0;
+        const int ix = kc2_scan_add(dx), iy = kc2_scan_add(dy), is = kc2_scan_add(ds);
+        o.x0 = cx0 + ix - dx; o.y0 = cy0 + iy - dy; o.si = cs0 + is - ds;
+        if (ds)
+            p0_emit_op<true>(o, ri, ncg, cig, rpos_i, rend_i, so_i, lq_i, mq, slot, nseg_i, ons_i, ocx_i, p0, segs, sr, rr,
+                             slow_g, slow_r, n_slow, vr, chunk_vr, nb, hcol);
+        cx0 += __shfl(ix, 63); cy0 += __shfl(iy, 63); cs0 += __shfl(is, 63);
     }
 }
 
@@ -531,8 +535,11 @@ __global__ void k_p0_qualcheck(int64_t nb, const uint8_t *__restrict__ quals, in
  * per read as if the whole chunk lay in that read and merged by byte mask.  Workgroups whose bases belong to more than
  * P0B_MAXR reads (reads of a few bases) take the same steps from global memory. */
 #define P0B_THREADS 256
-#define P0B_BASES   (P0B_THREADS * 16)
-#define P0B_MAXR    1024
+#define P0B_CPL     4                                  /* 16-base chunks per lane, P0B_THREADS chunks apart (coalesced stores) */
+#define P0B_CHUNKS  (P0B_THREADS * P0B_CPL)
+#define P0B_BASES   (P0B_CHUNKS * 16)
+#define P0B_MAXR    512
+#define P0B_SEARCH  32                                 /* at most this many reads over a workgroup's bases: chunk owners by search */
 #define P0_ILV_LO(X, Y) (((X) & 0xffu) | (((Y) & 0xffu) << 8) | (((X) & 0xff00u) << 8) | (((Y) & 0xff00u) << 16))      /* x0 y0 x1 y1 */
 #define P0_ILV_HI(X, Y) ((((X) >> 16) & 0xffu) | ((((Y) >> 16) & 0xffu) << 8) | ((((X) >> 16) & 0xff00u) << 8) | ((((Y) >> 16) & 0xff00u) << 16))   /* x2 y2 x3 y3 */
 /* sixteen classed bytes from the packed bytes d0 d1 d2 (twelve bytes from the one that holds the chunk's first base);
@@ -555,8 +562,8 @@ k_p0_bases(int64_t nb, int64_t n, const int64_t *__restrict__ seq_off, const int
            const uint8_t *__restrict__ b4, uint8_t *__restrict__ bases, int32_t *__restrict__ chunk_read)
 {
     __shared__ long long s_so[P0B_MAXR + 2];
-    __shared__ uint32_t s_b4[(P0B_BASES / 2 + P0B_MAXR + 64) / 4];
-    __shared__ int s_owner[P0B_THREADS];
+    __shared__ uint32_t s_b4[PACKED ? (P0B_BASES / 2 + P0B_MAXR + 64) / 4 : 4];
+    __shared__ uint16_t s_owner[P0B_CHUNKS];
     const int64_t G0 = (int64_t)blockIdx.x * P0B_BASES;
     if (G0 >= nb) return;
     const int64_t G1 = G0 + P0B_BASES < nb ? G0 + P0B_BASES : nb;
@@ -566,7 +573,6 @@ k_p0_bases(int64_t nb, int64_t n, const int64_t *__restrict__ seq_off, const int
     while (r1 + 1 < n && seq_off[r1 + 1] <= G1 - 1) r1++;
     const int nr = (int)(r1 - r0 + 1);
     const bool staged = nr <= P0B_MAXR;
-    const int64_t g = G0 + (int64_t)threadIdx.x * 16;
     int64_t B0 = 0;
     if (staged) {
         for (int j = threadIdx.x; j <= nr; j += P0B_THREADS) s_so[j] = seq_off[r0 + j];
@@ -575,67 +581,90 @@ k_p0_bases(int64_t nb, int64_t n, const int64_t *__restrict__ seq_off, const int
             B0 = ((so0 >> 1) + r0 + ((G0 - so0) >> 1)) & ~(int64_t)3;
             const int64_t so1 = seq_off[r1];
             const int64_t B1 = (so1 >> 1) + r1 + ((G1 - 1 - so1) >> 1) + 1 + 12;       /* a lane looks at twelve bytes */
-            const int nw4 = (int)((B1 - B0 + 3) >> 2);
-            const uint32_t *src = (const uint32_t *)(b4 + B0);                           /* (b4 is 4-byte aligned, B0 a multiple of 4) */
-            for (int j = threadIdx.x; j < nw4; j += P0B_THREADS) s_b4[j] = src[j];
-        }
-        __syncthreads();
-        /* owner of every chunk: the read that holds its first base */
-        for (int j = threadIdx.x; j < nr; j += P0B_THREADS) {
-            const int64_t a = s_so[j] > G0 ? s_so[j] : G0, b = s_so[j + 1] < G1 ? s_so[j + 1] : G1;
-            for (int64_t k = (a + 15) >> 4; k * 16 < b; k++) s_owner[(int)(k - (G0 >> 4))] = j;
-        }
-        __syncthreads();
-    }
-    if (g >= nb) return;
-    const int64_t gend = g + 16 < nb ? g + 16 : nb;
-    int64_t r;
-    if (staged) r = r0 + s_owner[threadIdx.x];
-    else { r = blk_read[g >> 6]; while (r + 1 < n && seq_off[r + 1] <= g) r++; }
-    if (OWNER) {
-        chunk_read[g >> 4] = (int32_t)r;
-        if (gend == nb) chunk_read[(nb + 15) >> 4] = (int32_t)r1;                     /* the entry past the last base (readers clamp) */
-    }
-    if (!PACKED) {
-        if (gend - g == 16) {
-            uint4 b = *(const uint4 *)(bases + g);
-            b.x = p0_class4(b.x); b.y = p0_class4(b.y); b.z = p0_class4(b.z); b.w = p0_class4(b.w);
-            *(uint4 *)(bases + g) = b;
-        } else for (int64_t k = g; k < gend; k++) bases[k] = (uint8_t)(p0_class4(bases[k]) & 0xffu);
-        return;
-    }
-    uint32_t ow[4] = {0, 0, 0, 0};
-    for (;; r++) {
-        const int64_t so = staged ? (int64_t)s_so[r - r0] : seq_off[r], e = staged ? (int64_t)s_so[r - r0 + 1] : seq_off[r + 1];
-        const int lo = so > g ? (int)(so - g) : 0, hi = e < gend ? (int)(e - g) : (int)(gend - g);
-        if (lo < hi) {
-            /* as if the whole chunk lay in this read (x may be negative: the bytes before the read are masked away) */
-            const int64_t x = g - so;                             /* (>> 1 floors, & 1 is the parity, also when negative) */
-            const int64_t sb = (so >> 1) + r + (x >> 1);
-            uint32_t d0, d1, d2;
-            if (staged && sb >= B0) {
-                const int o = (int)(sb - B0), wi = o >> 2;
-                const unsigned sh = (unsigned)o & 3u;
-                const uint32_t w0 = s_b4[wi], w1 = s_b4[wi + 1], w2 = s_b4[wi + 2], w3 = s_b4[wi + 3];
-                d0 = kc2_alignbyte(w1, w0, sh); d1 = kc2_alignbyte(w2, w1, sh); d2 = kc2_alignbyte(w3, w2, sh);
-            } else {                                              /* bytes in front of the staged range (a chunk's bytes before its read), or no staging */
-                uint32_t t3[3] = {0, 0, 0};
-                for (int k = 0; k < 12; k++) if (sb + k >= 0) t3[k >> 2] |= (uint32_t)b4[sb + k] << (8 * (k & 3));
-                d0 = t3[0]; d1 = t3[1]; d2 = t3[2];
-            }
-            uint32_t v[4];
-            p0_unpack16(d0, d1, d2, (x & 1) != 0, v);
-            const unsigned vb = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-            #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const uint32_t M = ((((vb >> (4 * t)) & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;
-                ow[t] = (v[t] & M) | (ow[t] & ~M);
+            const int nw16 = (int)((B1 - B0 + 15) >> 4);
+            const uint4 *src = (const uint4 *)(b4 + (B0 & ~(int64_t)15));               /* (b4 is 16-byte aligned; the array carries slack) */
+            const int sh = (int)(B0 & 15) >> 2;                                           /* B0 is a multiple of 4 */
+            for (int j = threadIdx.x; j <= nw16; j += P0B_THREADS) {
+                const uint4 v = src[j];
+                const int o = 4 * j - sh;
+                if (o >= 0) s_b4[o] = v.x;
+                if (o + 1 >= 0) s_b4[o + 1] = v.y;
+                if (o + 2 >= 0) s_b4[o + 2] = v.z;
+                if (o + 3 >= 0) s_b4[o + 3] = v.w;
             }
         }
-        if (e >= gend || r + 1 >= n) break;
+        __syncthreads();
+        /* owner of every chunk, the read that holds its first base: by scatter from the reads when they are many and
+         * short (a few chunks each); a lane searches the staged offsets for its own chunks when they are few and long
+         * (one lane writing a long read's thousand entries kept the workgroup waiting) */
+        if (nr > P0B_SEARCH) {
+            for (int j = threadIdx.x; j < nr; j += P0B_THREADS) {
+                const int64_t a = s_so[j] > G0 ? s_so[j] : G0, b = s_so[j + 1] < G1 ? s_so[j + 1] : G1;
+                for (int64_t k = (a + 15) >> 4; k * 16 < b; k++) s_owner[(int)(k - (G0 >> 4))] = (uint16_t)j;
+            }
+            __syncthreads();
+        }
     }
-    if (gend - g == 16) { uint4 o; o.x = ow[0]; o.y = ow[1]; o.z = ow[2]; o.w = ow[3]; *(uint4 *)(bases + g) = o; }
-    else for (int64_t t = g; t < gend; t++) bases[t] = (uint8_t)(ow[(t - g) >> 2] >> (8 * ((t - g) & 3)));
+    #pragma unroll
+    for (int u = 0; u < P0B_CPL; u++) {
+        const int ci = u * P0B_THREADS + (int)threadIdx.x;
+        const int64_t g = G0 + (int64_t)ci * 16;
+        if (g >= nb) continue;
+        const int64_t gend = g + 16 < nb ? g + 16 : nb;
+        int64_t r;
+        if (staged && nr > P0B_SEARCH) r = r0 + s_owner[ci];
+        else if (staged) {                                        /* last staged read whose first base is at or before g */
+            int lo = 0, hi = nr - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_so[mid] <= g) lo = mid; else hi = mid - 1; }
+            while (lo + 1 < nr && s_so[lo + 1] <= g) lo++;        /* (zero-length reads share an offset: the owner is the last of them) */
+            r = r0 + lo;
+        }
+        else { r = blk_read[g >> 6]; while (r + 1 < n && seq_off[r + 1] <= g) r++; }
+        if (OWNER) {
+            chunk_read[g >> 4] = (int32_t)r;
+            if (gend == nb) chunk_read[(nb + 15) >> 4] = (int32_t)r1;                 /* the entry past the last base (readers clamp) */
+        }
+        if (!PACKED) {
+            if (gend - g == 16) {
+                uint4 b = *(const uint4 *)(bases + g);
+                b.x = p0_class4(b.x); b.y = p0_class4(b.y); b.z = p0_class4(b.z); b.w = p0_class4(b.w);
+                *(uint4 *)(bases + g) = b;
+            } else for (int64_t k = g; k < gend; k++) bases[k] = (uint8_t)(p0_class4(bases[k]) & 0xffu);
+            continue;
+        }
+        uint32_t ow[4] = {0, 0, 0, 0};
+        for (;; r++) {
+            const int64_t so = staged ? (int64_t)s_so[r - r0] : seq_off[r], e = staged ? (int64_t)s_so[r - r0 + 1] : seq_off[r + 1];
+            const int lo = so > g ? (int)(so - g) : 0, hi = e < gend ? (int)(e - g) : (int)(gend - g);
+            if (lo < hi) {
+                /* as if the whole chunk lay in this read (x may be negative: the bytes before the read are masked away) */
+                const int64_t x = g - so;                         /* (>> 1 floors, & 1 is the parity, also when negative) */
+                const int64_t sb = (so >> 1) + r + (x >> 1);
+                uint32_t d0, d1, d2;
+                if (staged && sb >= B0) {
+                    const int o = (int)(sb - B0), wi = o >> 2;
+                    const unsigned sh = (unsigned)o & 3u;
+                    const uint32_t w0 = s_b4[wi], w1 = s_b4[wi + 1], w2 = s_b4[wi + 2], w3 = s_b4[wi + 3];
+                    d0 = kc2_alignbyte(w1, w0, sh); d1 = kc2_alignbyte(w2, w1, sh); d2 = kc2_alignbyte(w3, w2, sh);
+                } else {                                          /* bytes in front of the staged range (a chunk's bytes before its read), or no staging */
+                    uint32_t t3[3] = {0, 0, 0};
+                    for (int k = 0; k < 12; k++) if (sb + k >= 0) t3[k >> 2] |= (uint32_t)b4[sb + k] << (8 * (k & 3));
+                    d0 = t3[0]; d1 = t3[1]; d2 = t3[2];
+                }
+                uint32_t v[4];
+                p0_unpack16(d0, d1, d2, (x & 1) != 0, v);
+                const unsigned vb = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+                #pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const uint32_t M = ((((vb >> (4 * t)) & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;
+                    ow[t] = (v[t] & M) | (ow[t] & ~M);
+                }
+            }
+            if (e >= gend || r + 1 >= n) break;
+        }
+        if (gend - g == 16) { uint4 o; o.x = ow[0]; o.y = ow[1]; o.z = ow[2]; o.w = ow[3]; *(uint4 *)(bases + g) = o; }
+        else for (int64_t t = g; t < gend; t++) bases[t] = (uint8_t)(ow[(t - g) >> 2] >> (8 * ((t - g) & 3)));
+    }
 }
 #undef P0_ILV_LO
 #undef P0_ILV_HI
