@@ -182,7 +182,7 @@ def measure_config(ca, synth, workload, scale, device, steps=3, warmup=1, verify
     if hasattr(ca, "lib"):
         hb.pack4(ca.lib())
     params = ca.preset_params(d_preset, tech=d_tech)
-    eng = ca.Engine(params, device)
+    eng = ca.Engine(params, device, options={"stages": "on"})
     try:
         eng.upload(hb)
         for _ in range(warmup):
@@ -228,6 +228,32 @@ def measure_config(ca, synth, workload, scale, device, steps=3, warmup=1, verify
         return out
     finally:
         eng.close()
+
+
+def measure_small_contig(ca, synth, device, preset=5, contig_len=5000, reps=200):
+    """What a contig costs beyond its bases (snp_score.c:1478-1488: all a contig boundary costs the reference is a reset):
+    crumble_hip_contig() -- copy in, device-side expansion, run, copy out -- on a 5 kb contig at 30x, repeated; and
+    the run alone.  Wall clock per call."""
+    cfg = synth.config("chr20", scale=1.0)
+    cfg.contig_len = contig_len
+    hb = synth.generate(cfg)
+    eng = ca.Engine(ca.preset_params(preset), device)
+    try:
+        for _ in range(5):
+            eng.contig(hb)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.contig(hb)
+        t_contig = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.run()
+        t_run = (time.perf_counter() - t0) / reps
+    finally:
+        eng.close()
+    return {"contig_bp": contig_len, "reads": hb.n_reads, "bases": hb.n_bases, "contig_ms": round(t_contig * 1e3, 4),
+            "run_ms": round(t_run * 1e3, 4), "reps": reps,
+            "note": "crumble_hip_contig() per call on a 5 kb contig (host -> device, expansion, run, device -> host), and crumble_hip_run() alone"}
 
 
 def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=3):
@@ -419,7 +445,9 @@ def main():
         b_.pack4(ca.lib())          # the bases cross PCIe as BAM packs them (crumble_batch.bases4), as crumble-hip sends them
     hb = batches[0]
     params = ca.preset_params(args.preset, tech=tech)
-    opts = {} if args.kcol == "auto" else {"kcol": args.kcol}
+    opts = {"stages": "on"}                     # HIP events around the run's stages: roofline.kernels_ms
+    if args.kcol != "auto":
+        opts["kcol"] = args.kcol
     if args.pblock != "auto":
         opts["pblock"] = args.pblock
 
@@ -694,6 +722,11 @@ def main():
                     "sample": f"{cores} independent windows of {per} reads of the same contig, one process per core "
                               f"(contigs / windows are the independent unit), {wall:.1f} s wall",
                 }
+        if world == 1:
+            try:
+                out["small_contig"] = measure_small_contig(ca, synth, local_rank, preset=args.preset or 5)
+            except Exception as ex:                # noqa: BLE001
+                out["small_contig"] = {"error": repr(ex)[:300]}
         if args.e2e:
             out["end_to_end"] = file_to_file(hb, args, local_rank)
         if world == 1 and args.workload == "chr20" and args.scale == 1.0 and not args.no_other_configs and not args.no_cpu:

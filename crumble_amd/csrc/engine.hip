@@ -55,6 +55,7 @@ struct DevBuf {
 };
 
 #define MAX_STAGES 16
+#define FOLD_SMALL_MAX 8192         /* trigger columns (or capacity) up to which one workgroup does the whole fold */
 #define DL_LANES 8
 #define DL_CHUNK ((size_t)8 << 20)
 struct crumble_hip {
@@ -66,7 +67,17 @@ struct crumble_hip {
     DevBuf d_raw;                   /* arena of the raw arrays of an upload: d_pos, d_mapq, d_flag, d_seq_off, d_cig_off, d_cigar, d_quals,
                                      * d_bases4 (or d_bases), d_bed_*, d_mqslot are views into it */
     void *stage = nullptr;          /* page-locked staging buffer of small uploads (RAW_STAGE_MAX bytes) */
-    bool late_pending = false;      /* an expansion is in flight whose late errors (pinned + 128) have not been looked at */
+    bool late_pending = false;      /* an expansion is in flight whose late errors (pinned + 256) have not been looked at */
+    /* crumble_hip_run's fast path: the work lists are reserved with capacities guessed from the batch's shape and every
+     * kernel takes the lists' true lengths from device memory, so the launches need no size read-back in the middle;
+     * the scan sets an abort flag when a list would not fit (or a column is too deep) and the run is repeated the
+     * careful way with exact sizes (what a window of a contig always does). */
+    bool spec = false, spec_aborted = false;
+    bool fold_small = false;        /* the last fold took k_fold_small (it marks the windows too) */
+    int cap_trig = 0, cap_items = 0, cap_ins = 0;       /* capacities the lists hold (grow-only, remembered across batches) */
+    int opt_spec = 1;               /* "run" = fast | careful: crumble_hip_run's first attempt (tests force the second way) */
+    int opt_caps = 0;               /* "caps" = n: the fast path's capacities forced to n (tests: a forced abort) */
+    int opt_stages = 0;             /* "stages" = on: HIP events around every stage of a run (crumble_hip_kernel_times; bench.py) */
     /* batch (inputs) */
     DevBuf d_genlist, d_vrec, d_pbdirty, d_pbcarry, d_pbchg, d_bases4, d_ufirst, d_tcum, d_tpart, d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
            d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax, d_tile_bed, d_hitoff, d_hits, d_rtoff, d_first;
@@ -248,7 +259,7 @@ extern "C" crumble_hip *crumble_hip_create(const crumble_params *p, int device, 
     }
     if (hipSetDevice(device) != hipSuccess) { g_last_error = "hipSetDevice failed"; return fail(CRUMBLE_EHIP); }
     if (hipStreamCreate(&h->stream) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(CRUMBLE_EHIP); }
-    if (hipHostMalloc(&h->pinned, 256, 0) != hipSuccess) { h->pinned = nullptr; g_last_error = "hipHostMalloc failed"; return fail(CRUMBLE_ENOMEM); }
+    if (hipHostMalloc(&h->pinned, 512, 0) != hipSuccess) { h->pinned = nullptr; g_last_error = "hipHostMalloc failed"; return fail(CRUMBLE_ENOMEM); }
     for (int i = 0; i <= MAX_STAGES; i++)
         if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(CRUMBLE_EHIP); }
     for (int i = 0; i < 3; i++)
@@ -269,7 +280,7 @@ extern "C" crumble_hip *crumble_hip_create(const crumble_params *p, int device, 
     if (!tab) return fail(CRUMBLE_ENOMEM);
     build_tables(tab, &h->hparams);
     if ((e = h->d_params.reserve(sizeof(DParams))) || (e = h->d_tables.reserve(sizeof(DTables))) ||
-        (e = h->d_stats.reserve(CRUMBLE_ST_N * 8)) || (e = h->d_batch_stats.reserve(CRUMBLE_ST_N * 8)) ||
+        (e = h->d_stats.reserve(CRUMBLE_ST_N * 8)) || (e = h->d_batch_stats.reserve(CRUMBLE_ST_N * 8 + 256)) ||
         (e = h->d_misc.reserve(256)))
         return fail(e);
     if (hipMemcpy(h->d_params.p, &h->hparams, sizeof(DParams), hipMemcpyHostToDevice) != hipSuccess ||
@@ -330,6 +341,18 @@ extern "C" int crumble_hip_set_option(crumble_hip *h, const char *name, const ch
         static const char *const nm[] = {"auto", "flat"};
         if ((v = pick(nm, 2)) < 0) return CRUMBLE_EINVAL;
         h->opt_replay = v;
+    } else if (!strcmp(name, "run")) {
+        static const char *const nm[] = {"careful", "fast"};
+        if ((v = pick(nm, 2)) < 0) return CRUMBLE_EINVAL;
+        h->opt_spec = v;
+    } else if (!strcmp(name, "caps")) {                     /* tests: the fast path's list capacities (0: guessed from the batch) */
+        const long long c = atoll(value);
+        if (c < 0 || c > INT_MAX / 2) return CRUMBLE_EINVAL;
+        h->opt_caps = (int)c;
+    } else if (!strcmp(name, "stages")) {                   /* HIP events around the stages of a run (crumble_hip_kernel_times) */
+        static const char *const nm[] = {"off", "on"};
+        if ((v = pick(nm, 2)) < 0) return CRUMBLE_EINVAL;
+        h->opt_stages = v;
     } else if (!strcmp(name, "dl_chunk")) {                 /* bytes per staged download copy (tests shrink it) */
         const long long c = atoll(value);
         if (c < 256 || c > (long long)DL_CHUNK) return CRUMBLE_EINVAL;
@@ -342,16 +365,17 @@ extern "C" int crumble_hip_set_option(crumble_hip *h, const char *name, const ch
 static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b > 0 ? (n + b - 1) / b : 1); }
 
 /* in-place inclusive prefix max of an int32 device array (chunked; the fold's bounds) */
-static int prefix_max(crumble_hip *h, int32_t *v, int64_t n)
+/* (n_dev: the true length is on the device, n its capacity -- workgroups beyond the length leave at once) */
+static int prefix_max(crumble_hip *h, int32_t *v, int64_t n, const int *n_dev = nullptr)
 {
     if (n <= 0) return CRUMBLE_OK;
     const int nch = (int)((n + PMAX_CHUNK - 1) / PMAX_CHUNK);
     int e = h->d_pmax_partial.reserve((size_t)(nch + 2) * 4);
     if (e) return e;
     int32_t *pp = h->d_pmax_partial.as<int32_t>();
-    CRUMBLE_LAUNCH(k_pmax_reduce, nch, 256, h->stream, (int)n, v, pp);
-    CRUMBLE_LAUNCH(k_pmax_partials, 1, 64, h->stream, pp, nch);
-    CRUMBLE_LAUNCH(k_pmax_apply, nch, 256, h->stream, (int)n, v, pp);
+    CRUMBLE_LAUNCH(k_pmax_reduce, nch, 256, h->stream, (int)n, n_dev, v, pp);
+    CRUMBLE_LAUNCH(k_pmax_partials, 1, 64, h->stream, pp, nch, (int)n, n_dev);
+    CRUMBLE_LAUNCH(k_pmax_apply, nch, 256, h->stream, (int)n, n_dev, v, pp);
     return CRUMBLE_OK;
 }
 
@@ -464,7 +488,7 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
  * asynchronous; `wait`: also wait for the end and report the late errors (coordinate order, tile span). */
 static int expand_late_errors(crumble_hip *h)
 {
-    const int *res = (const int *)((const char *)h->pinned + 128);
+    const int *res = (const int *)((const char *)h->pinned + 256);
     switch (res[0]) {
     case 0: break;
     case P0_ERR_UNSORTED: return CRUMBLE_EUNSORTED;                      /* snp:1075 */
@@ -650,18 +674,19 @@ static int expand(crumble_hip *h, bool wait)
     B.bed_pmax = h->d_bed_pmax.as<int32_t>(); B.tile_bed = h->d_tile_bed.as<int32_t>();
 
     const size_t L = (size_t)(B.L > 0 ? B.L : 1);
-    const int nsc = (int)((L + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    const int nsc = (int)((L + SCAN_CHUNK_OF(L) - 1) / SCAN_CHUNK_OF(L));
     if ((e = h->d_colrec.reserve(L * 4)) || (e = h->d_nplp.reserve(L * 4)) || (e = h->d_score.reserve(L * 4)) ||
         (e = h->d_trigcnt.reserve(L * 4)) || (e = h->d_dpre.reserve(L * 8)) || (e = h->d_col_ord.reserve(L * 4)) ||
         (e = h->d_trig_ord.reserve(L * 4)) || (e = h->d_item_off.reserve(L * 4)) || (e = h->d_ins_ord.reserve(L * 4)) ||
         (e = h->d_pos_mn2.reserve(L * 4)) || (e = h->d_ht.reserve(L * 4)) || (e = h->d_partial.reserve((size_t)(nsc + 2) * sizeof(ScanVal))) ||
         (e = h->d_epochs.reserve(MAX_EPOCHS * sizeof(Epoch))) ||
         (e = h->d_out.reserve((size_t)nb + 64)) || (e = h->d_rflags.reserve((size_t)(n ? n : 1))) ||
-        (e = h->d_keepf.reserve((size_t)(n ? n : 1))) || (e = h->d_kept.reserve((size_t)(n ? n : 1) * 4)) || (e = h->d_b15f.reserve((size_t)(n ? n : 1))))
+        (e = h->d_keepf.reserve((size_t)(n ? n : 1) * 2)) || (e = h->d_kept.reserve((size_t)(n ? n : 1) * 4)))
         return e;
+    h->d_b15f.view(h->d_keepf.as<uint8_t>() + (n ? n : 1), (size_t)(n ? n : 1));      /* (one memset clears both) */
     /* the late errors: what k_p0_fill / k_p0_tiles / k_p0_hitfill found */
-    HIPCHK(hipMemcpyAsync((char *)h->pinned + 128, d_err, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync((char *)h->pinned + 132, d_herr, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync((char *)h->pinned + 256, d_err, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync((char *)h->pinned + 260, d_herr, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(h->ev_up[2], st));
     h->have_batch = true;
     h->late_pending = true;
@@ -696,7 +721,7 @@ extern "C" int crumble_hip_expand(crumble_hip *h)
 
 /* -------------------------------------------------------------------- run */
 
-#define STAGE(name_, bytes_) do { if (h->n_stages < MAX_STAGES) { \
+#define STAGE(name_, bytes_) do { if (h->opt_stages && h->n_stages < MAX_STAGES) { \
     HIPCHK(hipEventRecord(h->ev[h->n_stages], st)); \
     h->stage_name[h->n_stages] = name_; h->stage_bytes[h->n_stages] = (double)(bytes_); h->n_stages++; } } while (0)
 
@@ -804,8 +829,10 @@ extern "C" int crumble_hip_set_window(crumble_hip *h, const crumble_window *w)
  * windows (include/crumble_hip.h, crumble_hip_set_window) runs phases 1, 3 and 5 of all its windows in parallel -- one
  * engine per device -- and only the two tiny chained phases in window order: 2 hands the running depth average on
  * (snp:1490-1491,1684-1687), 4 the STR window state (snp:1508-1511,1741-1755). */
-/* what every phase needs from the handle (d_misc: [0] overflow flag, [1] n_epochs, [2] n_kept, [3] k_columns work counter,
- * [4] a quality >= 128 was seen (k_stats), [8..12] upload, [15] hit-list check, [16..19] depth state out, [24..27] window state out) */
+/* what every phase needs from the handle.  Run flags, behind the batch statistics (d_overflow): [0] overflow flag,
+ * [1] n_epochs, [2] n_kept, [3] k_columns work counter, [4] a quality >= 128 was seen (k_stats), [5] fast path aborted,
+ * [8..15] the scan's totals (fast path).  d_misc: [8..12] upload, [15] hit-list check, [16..19] depth state out,
+ * [24..27] window state out */
 #define RUN_LOCALS \
     HIPCHK(hipSetDevice(h->device)); \
     hipStream_t st = h->stream; \
@@ -813,31 +840,36 @@ extern "C" int crumble_hip_set_window(crumble_hip *h, const crumble_window *w)
     const DParams *P = h->d_params.as<DParams>(); \
     const DTables *T = h->d_tables.as<DTables>(); \
     u64 *stats = h->d_batch_stats.as<u64>(); \
-    int *d_overflow = h->d_misc.as<int>(); \
+    int *d_overflow = (int *)(stats + CRUMBLE_ST_N);        /* the run's flags live behind the batch statistics: one memset */ \
     int *d_nep = d_overflow + 1; \
+    const bool spec = h->spec; \
+    const int *spec_abort = spec ? d_overflow + 5 : (const int *)nullptr; \
     const int L = B.L; \
     const int64_t n = B.n_reads, nb = B.n_bases; \
     uint32_t *colrec = h->d_colrec.as<uint32_t>(); \
     int32_t *nplp = h->d_nplp.as<int32_t>(), *score = h->d_score.as<int32_t>(); \
     int32_t *trigcnt = h->d_trigcnt.as<int32_t>(); \
-    const int nchunks = (L + SCAN_CHUNK - 1) / SCAN_CHUNK; \
+    const int scan_chunk = SCAN_CHUNK_OF(L); \
+    const int nchunks = (L + scan_chunk - 1) / scan_chunk; \
     ScanVal *partial = h->d_partial.as<ScanVal>(); \
-    const int n_trig = h->totals.trigcols, n_items = h->totals.items, n_ins = h->totals.ins; \
+    const int n_trig = spec ? h->cap_trig : h->totals.trigcols, n_items = spec ? h->cap_items : h->totals.items, n_ins = spec ? h->cap_ins : h->totals.ins; \
+    const int *nd_trig = spec ? &partial[nchunks].trigcols : (const int *)nullptr, *nd_items = spec ? &partial[nchunks].items : (const int *)nullptr, \
+              *nd_ins = spec ? &partial[nchunks].ins : (const int *)nullptr; \
     int32_t *trigcol_pos = h->d_trigcol_pos.as<int32_t>(), *trigcol_off = h->d_trigcol_off.as<int32_t>(); \
     int32_t *inscol_pos = h->d_inscol_pos.as<int32_t>(); \
     TrigItem *items = h->d_items.as<TrigItem>(); \
     (void)P; (void)T; (void)stats; (void)d_nep; (void)L; (void)n; (void)nb; (void)colrec; (void)nplp; (void)score; (void)trigcnt; \
-    (void)nchunks; (void)partial; (void)n_trig; (void)n_items; (void)n_ins; (void)trigcol_pos; (void)trigcol_off; (void)inscol_pos; (void)items;
+    (void)nchunks; (void)scan_chunk; (void)partial; (void)n_trig; (void)n_items; (void)n_ins; (void)trigcol_pos; (void)trigcol_off; (void)inscol_pos; (void)items; \
+    (void)spec_abort; (void)nd_trig; (void)nd_items; (void)nd_ins;
 static const crumble_carry CARRY0 = {0, 0, INT_MAX, 0, INT_MAX, 0};
 
 extern "C" int crumble_hip_run_columns(crumble_hip *h)
 {
     if (!h || !h->have_batch) { g_last_error = "no batch uploaded"; return CRUMBLE_EINVAL; }
     RUN_LOCALS
-    h->n_stages = 0; h->have_run = false;
+    h->n_stages = 0; h->have_run = false; h->fold_small = false;
     memset(&h->totals, 0, sizeof(h->totals));
-    HIPCHK(hipMemsetAsync(stats, 0, CRUMBLE_ST_N * 8, st));
-    HIPCHK(hipMemsetAsync(d_overflow, 0, 32, st));      /* [0] overflow, [1] n_epochs, [2] n_kept, [3] k_columns work counter, [4] quality >= 128 seen; [8..15] belong to upload */
+    HIPCHK(hipMemsetAsync(stats, 0, CRUMBLE_ST_N * 8 + 64, st));      /* the counters and the run flags */
 
     if (L > 0) {
         uint32_t *ht = h->d_ht.as<uint32_t>();
@@ -882,18 +914,30 @@ extern "C" int crumble_hip_run_columns(crumble_hip *h)
 #undef KCOL_LAUNCH2
 
         STAGE("scan", 0);
-        CRUMBLE_LAUNCH(k_scan_reduce, nchunks, 256, st, L, colrec, nplp, trigcnt, partial, nchunks);
-        CRUMBLE_LAUNCH(k_scan_partials, 1, 1024, st, partial, nchunks);
-        HIPCHK(hipMemcpyAsync(h->pinned, partial + nchunks, sizeof(ScanVal), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));           /* sizes of the work lists */
-        memcpy(&h->totals, h->pinned, sizeof(ScanVal));
-        /* a whole contig without a too-deep column needs no per-column prefix arrays (kernels.h, k_scan_overdepth) */
-        h->scan_fused = !h->windowed && h->totals.toodeep == 0;
-        if (!h->scan_fused)
-            CRUMBLE_LAUNCH(k_scan_apply, nchunks, 256, st, L, colrec, nplp, trigcnt, partial, nchunks,
-                                 h->d_dpre.as<int64_t>(), h->d_col_ord.as<int32_t>(), h->d_trig_ord.as<int32_t>(),
-                                 h->d_item_off.as<int32_t>(), h->d_ins_ord.as<int32_t>());
-        const int nt = h->totals.trigcols, nit = h->totals.items, ni = h->totals.ins;
+        CRUMBLE_LAUNCH(k_scan_reduce, nchunks, 256, st, L, colrec, nplp, trigcnt, partial, nchunks, scan_chunk);
+        if (spec) {
+            /* capacities from the batch's shape (measured: trigger columns 0.03-1 % of the columns, triggers 0.003-0.07 %
+             * of the bases over the four BASELINE configurations), never below what an earlier batch needed */
+            const int64_t ct = std::max<int64_t>(4096, (int64_t)L / 32), ci = std::max<int64_t>(16384, nb / 128);
+            if (h->cap_trig < ct) h->cap_trig = (int)std::min<int64_t>(ct, INT_MAX / 2);
+            if (h->cap_items < ci) h->cap_items = (int)std::min<int64_t>(ci, INT_MAX / 2);
+            if (h->cap_ins < h->cap_trig) h->cap_ins = h->cap_trig;
+            if (h->opt_caps) h->cap_trig = h->cap_items = h->cap_ins = h->opt_caps;
+            CRUMBLE_LAUNCH(k_scan_partials, 1, 1024, st, partial, nchunks, h->cap_trig, h->cap_items, h->cap_ins, d_overflow + 5, (ScanVal *)(d_overflow + 8));
+            h->scan_fused = true;                   /* (a too-deep column aborts the fast path) */
+        } else {
+            CRUMBLE_LAUNCH(k_scan_partials, 1, 1024, st, partial, nchunks, 0, 0, 0, (int *)nullptr, (ScanVal *)nullptr);
+            HIPCHK(hipMemcpyAsync(h->pinned, partial + nchunks, sizeof(ScanVal), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));           /* sizes of the work lists */
+            memcpy(&h->totals, h->pinned, sizeof(ScanVal));
+            /* a whole contig without a too-deep column needs no per-column prefix arrays (kernels.h, k_scan_overdepth) */
+            h->scan_fused = !h->windowed && h->totals.toodeep == 0;
+            if (!h->scan_fused)
+                CRUMBLE_LAUNCH(k_scan_apply, nchunks, 256, st, L, colrec, nplp, trigcnt, partial, nchunks,
+                                     h->d_dpre.as<int64_t>(), h->d_col_ord.as<int32_t>(), h->d_trig_ord.as<int32_t>(),
+                                     h->d_item_off.as<int32_t>(), h->d_ins_ord.as<int32_t>(), scan_chunk);
+        }
+        const int nt = spec ? h->cap_trig : h->totals.trigcols, nit = spec ? h->cap_items : h->totals.items, ni = spec ? h->cap_ins : h->totals.ins;
         int e;
         if ((e = h->d_trigcol_pos.reserve((size_t)(nt + 1) * 4)) || (e = h->d_trigcol_off.reserve((size_t)(nt + 1) * 4)) ||
             (e = h->d_inscol_pos.reserve((size_t)(ni + 1) * 4)) || (e = h->d_items.reserve((size_t)(nit + 1) * sizeof(TrigItem))) ||
@@ -919,17 +963,19 @@ extern "C" int crumble_hip_run_depth(crumble_hip *h, const crumble_carry *in, cr
     if (L > 0 && h->scan_fused && (out || late)) {    /* the state at a cut is read from the prefix arrays */
         CRUMBLE_LAUNCH(k_scan_apply, nchunks, 256, st, L, colrec, nplp, trigcnt, partial, nchunks,
                              h->d_dpre.as<int64_t>(), h->d_col_ord.as<int32_t>(), h->d_trig_ord.as<int32_t>(),
-                             h->d_item_off.as<int32_t>(), h->d_ins_ord.as<int32_t>());
+                             h->d_item_off.as<int32_t>(), h->d_ins_ord.as<int32_t>(), scan_chunk);
         h->scan_fused = false;
     }
     if (L > 0 && h->scan_fused) {
-        const int64_t ncols = h->totals.cols, first = 1048577 - cin.total_col;
+        /* (fast path: the number of counted columns is on the device; at most L of them) */
+        const int64_t ncols = spec ? (int64_t)L : h->totals.cols, first = 1048577 - cin.total_col;
         int n = 0;
         if (ncols > 0) n = 1 + (int)((ncols > first) ? (ncols - first + 524288) / 524289 : 0);
         if (n > MAX_EPOCHS - 1) n = MAX_EPOCHS - 1;
         if (n > 1)
-            CRUMBLE_LAUNCH(k_epochs_find, n - 1, 64, st, L, colrec, nplp, partial, nchunks, h->d_epochs.as<Epoch>(), (int64_t)cin.total_col);
-        CRUMBLE_LAUNCH_INDEP(k_epochs_td, 1, 1, st, h->d_epochs.as<Epoch>(), n, d_nep, (int64_t)cin.total_col, (int64_t)cin.total_depth);
+            CRUMBLE_LAUNCH(k_epochs_find, n - 1, 64, st, L, colrec, nplp, partial, nchunks, h->d_epochs.as<Epoch>(), (int64_t)cin.total_col, scan_chunk);
+        CRUMBLE_LAUNCH_INDEP(k_epochs_td, 1, 1, st, h->d_epochs.as<Epoch>(), n, d_nep, (int64_t)cin.total_col, (int64_t)cin.total_depth,
+                             spec ? partial + nchunks : (const ScanVal *)nullptr);
     } else
     if (L > 0) {
         if (h->totals.toodeep == 0 && !late)
@@ -960,27 +1006,32 @@ extern "C" int crumble_hip_run_triggers(crumble_hip *h)
         STAGE("k_overdepth", 0);
         if (h->scan_fused)
             CRUMBLE_LAUNCH(k_scan_overdepth, nchunks, 256, st, L, colrec, nplp, trigcnt, partial, h->d_epochs.as<Epoch>(), d_nep, P,
-                           trigcol_pos, trigcol_off, inscol_pos, stats, B.stat_hi);
+                           trigcol_pos, trigcol_off, inscol_pos, stats, B.stat_hi, spec_abort, scan_chunk);
         else
         CRUMBLE_LAUNCH_INDEP(k_overdepth, nblk((L + 3) / 4, 256), 256, st, L, colrec, nplp, h->d_col_ord.as<int32_t>(),
                              h->d_dpre.as<int64_t>(), h->d_trig_ord.as<int32_t>(), h->d_item_off.as<int32_t>(),
                              h->d_ins_ord.as<int32_t>(), h->d_epochs.as<Epoch>(), d_nep, P,
                              trigcol_pos, trigcol_off, inscol_pos, stats, B.stat_hi);
+        /* (fast path: the lists' lengths are on the device; grids sized for the capacities, bounded, striding) */
         if (n_ins > 0) {
             STAGE("k_inshist", 0);
-            {   /* lanes per column: 16 when a column has a few dozen candidate reads, the whole wave on deep pileups */
-                const int gshift = (h->totals.cols > 0 && h->totals.depth / h->totals.cols < 40) ? 4 : 6;     /* (mean depth of the covered columns) */
-                CRUMBLE_LAUNCH(k_inshist, (n_ins + (64 >> gshift) - 1) / (64 >> gshift), 64, st, B, P, n_ins, inscol_pos, colrec, nplp, stats, gshift);
+            {   /* lanes per column: 16 when a column has a few dozen candidate reads, the whole wave on deep pileups
+                 * (mean depth of the covered columns; fast path: bases per column of the batch's extent, an upper bound of it) */
+                const int64_t mean_depth = spec ? nb / (L > 0 ? L : 1) : (h->totals.cols > 0 ? h->totals.depth / h->totals.cols : 0);
+                const int gshift = mean_depth < 40 ? 4 : 6;
+                unsigned g = (unsigned)((n_ins + (64 >> gshift) - 1) / (64 >> gshift));
+                if (spec && g > 4096u) g = 4096u;
+                CRUMBLE_LAUNCH(k_inshist, g, 64, st, B, P, n_ins, nd_ins, spec_abort, inscol_pos, colrec, nplp, stats, gshift);
             }
         }
         if (n_trig > 0) {
             STAGE("k_emit", 0);
             if (h->n_segrec > h->n_reads + h->n_reads / 2)       /* long reads: few candidates per column */
-                CRUMBLE_LAUNCH_INDEP(k_emit_lanes, nblk(n_trig, 64), 64, st, B, P, n_trig, trigcol_pos, trigcol_off, colrec, items);
+                CRUMBLE_LAUNCH_INDEP(k_emit_lanes, (spec && nblk(n_trig, 64) > 4096u) ? 4096u : nblk(n_trig, 64), 64, st, B, P, n_trig, nd_trig, spec_abort, trigcol_pos, trigcol_off, colrec, items);
             else
-                CRUMBLE_LAUNCH(k_emit, nblk(n_trig, 4), 256, st, B, P, n_trig, trigcol_pos, trigcol_off, colrec, items);
+                CRUMBLE_LAUNCH(k_emit, (spec && nblk(n_trig, 4) > 8192u) ? 8192u : nblk(n_trig, 4), 256, st, B, P, n_trig, nd_trig, spec_abort, trigcol_pos, trigcol_off, colrec, items);
             STAGE("k_str", 0);
-            CRUMBLE_LAUNCH_INDEP(k_str, nblk(n_items, 64), 64, st, B, P, n_items, items, d_overflow);
+            CRUMBLE_LAUNCH_INDEP(k_str, (spec && nblk(n_items, 64) > 16384u) ? 16384u : nblk(n_items, 64), 64, st, B, P, n_items, nd_items, spec_abort, items, d_overflow);
         }
     }
     h->phase = 3;
@@ -1001,13 +1052,20 @@ extern "C" int crumble_hip_run_fold(crumble_hip *h, const crumble_carry *in, cru
             STAGE("k_fold", 0);
             int32_t *colhi = h->d_colhi.as<int32_t>(), *ub = h->d_ub.as<int32_t>();
             int pe;
-            CRUMBLE_LAUNCH_INDEP(k_fold_bounds, nblk(n_trig, 64), 64, st, B, P, n_trig, trigcol_pos, trigcol_off, trigcnt, items, colhi, cin.max_pos);
-            if ((pe = prefix_max(h, colhi, n_trig))) return pe;
-            CRUMBLE_LAUNCH_INDEP(k_fold_ub, nblk(n_trig, 64), 64, st, B, P, n_trig, trigcol_pos, colhi, ub, cin.max_pos2);
-            if ((pe = prefix_max(h, ub, n_trig))) return pe;
-            CRUMBLE_LAUNCH_INDEP(k_fold, nblk(n_trig, 64), 64, st, B, P, n_trig, trigcol_pos, trigcol_off, trigcnt, items, ub,
+            h->fold_small = !h->windowed && !in && !out && n_trig <= FOLD_SMALL_MAX;
+            if (h->fold_small)                          /* a short list (a small contig): all of it, and the window marks, in one launch */
+                CRUMBLE_LAUNCH(k_fold_small, 1, 1024, st, B, P, n_trig, nd_trig, spec_abort, trigcol_pos, trigcol_off, trigcnt, items, colhi, ub,
+                               colrec, h->d_pos_mn2.as<int32_t>(), h->d_trig_mx2.as<int32_t>(), d_carry);
+            else {
+            const unsigned gt = (spec && nblk(n_trig, 64) > 4096u) ? 4096u : nblk(n_trig, 64);
+            CRUMBLE_LAUNCH_INDEP(k_fold_bounds, gt, 64, st, B, P, n_trig, nd_trig, spec_abort, trigcol_pos, trigcol_off, trigcnt, items, colhi, cin.max_pos);
+            if ((pe = prefix_max(h, colhi, n_trig, nd_trig))) return pe;
+            CRUMBLE_LAUNCH_INDEP(k_fold_ub, gt, 64, st, B, P, n_trig, nd_trig, spec_abort, trigcol_pos, colhi, ub, cin.max_pos2);
+            if ((pe = prefix_max(h, ub, n_trig, nd_trig))) return pe;
+            CRUMBLE_LAUNCH_INDEP(k_fold, gt, 64, st, B, P, n_trig, nd_trig, spec_abort, trigcol_pos, trigcol_off, trigcnt, items, ub,
                                  colrec, h->d_pos_mn2.as<int32_t>(), h->d_trig_mx2.as<int32_t>(),
                                  cin.min_pos, cin.max_pos, cin.min_pos2, cin.max_pos2, B.p0 + B.stat_hi, d_carry);
+            }
         }
         /* the window's first columns are "in window" while the carried state is live: snp:1880 tests
          * min_pos != INT_MAX, after the reset of every column with pos > max_pos2 (snp:1508) */
@@ -1027,13 +1085,12 @@ extern "C" int crumble_hip_run_finish(crumble_hip *h)
 {
     if (!h || !h->have_batch || h->phase != 4) { g_last_error = "crumble_hip_run_finish: run the fold phase first"; return CRUMBLE_EINVAL; }
     RUN_LOCALS
-    if (L > 0 && n_trig > 0) {
-        CRUMBLE_LAUNCH_INDEP(k_window, nblk(n_trig, 64), 64, st, B, n_trig, trigcol_pos, h->d_trig_mx2.as<int32_t>(), colrec);
+    if (L > 0 && n_trig > 0 && !h->fold_small) {
+        CRUMBLE_LAUNCH_INDEP(k_window, (spec && nblk(n_trig, 64) > 4096u) ? 4096u : nblk(n_trig, 64), 64, st, B, n_trig, nd_trig, spec_abort, trigcol_pos, h->d_trig_mx2.as<int32_t>(), colrec);
     }
     if (n > 0) {
         STAGE("k_replay", 3.0 * nb);
-        HIPCHK(hipMemsetAsync(h->d_keepf.p, 0, (size_t)n, st));
-        HIPCHK(hipMemsetAsync(h->d_b15f.p, 0, (size_t)n, st));
+        HIPCHK(hipMemsetAsync(h->d_keepf.p, 0, (size_t)n * 2, st));      /* keepf and, behind it, b15f */
         if (nb > 0 && h->hparams.softclip)
             CRUMBLE_LAUNCH_INDEP(k_replay_general, nblk(nb, 256), 256, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
                                  h->d_blk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(),
@@ -1070,9 +1127,11 @@ extern "C" int crumble_hip_run_finish(crumble_hip *h)
                                      h->d_misc.as<int>() + 11, h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(),
                                      h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(), h->d_b15f.as<uint8_t>());
         }
-        if (L > 0 && h->totals.trigcols > 0) {
-            const int coop = (h->n_segrec > h->n_reads + h->n_reads / 2) ? 0 : 1;      /* (long reads: two columns per wave) */
-            CRUMBLE_LAUNCH(k_restore, coop ? h->totals.trigcols : (h->totals.trigcols + 7) / 8, 64, st, B, P, h->totals.trigcols,
+        if (L > 0 && n_trig > 0) {
+            const int coop = (h->n_segrec > h->n_reads + h->n_reads / 2) ? 0 : 1;      /* (long reads: eight columns per wave) */
+            unsigned g = (unsigned)(coop ? n_trig : (n_trig + 7) / 8);
+            if (spec && g > 32768u) g = 32768u;
+            CRUMBLE_LAUNCH(k_restore, g, 64, st, B, P, n_trig, nd_trig, spec_abort,
                                  h->d_trigcol_pos.as<int32_t>(), h->d_pos_mn2.as<int32_t>(), h->d_trig_mx2.as<int32_t>(), h->d_out.as<uint8_t>(),
                                  coop);
         }
@@ -1092,14 +1151,15 @@ extern "C" int crumble_hip_run_finish(crumble_hip *h)
         else
             CRUMBLE_LAUNCH(k_stats, 1024, 256, st, (int64_t)0, nb, n, h->d_out.as<uint8_t>(), B.quals, stats, d_overflow + 4);
     }
-    HIPCHK(hipEventRecord(h->ev[h->n_stages], st));
+    if (h->opt_stages) HIPCHK(hipEventRecord(h->ev[h->n_stages], st));
     /* fold this batch's counters into the engine's accumulated stats vector, on the device */
-    CRUMBLE_LAUNCH_INDEP(k_stats_fold, nblk(CRUMBLE_ST_N, 64), 64, st, h->d_stats.as<u64>(), (const u64 *)stats, CRUMBLE_ST_N, (const int *)d_overflow);
-    int ovf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(h->pinned, d_overflow, 32, hipMemcpyDeviceToHost, st));
+    CRUMBLE_LAUNCH_INDEP(k_stats_fold, nblk(CRUMBLE_ST_N, 64), 64, st, h->d_stats.as<u64>(), (const u64 *)stats, CRUMBLE_ST_N, (const int *)d_overflow, spec_abort);
+    int ovf[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h->pinned, d_overflow, 64, hipMemcpyDeviceToHost, st));      /* the flags and (fast path) the scan's totals */
     HIPCHK(hipStreamSynchronize(st));
-    memcpy(ovf, h->pinned, 32);
+    memcpy(ovf, h->pinned, 64);
     HIPCHK(hipGetLastError());
+    if (spec) memcpy(&h->totals, ovf + 8, sizeof(ScanVal));
     if (h->late_pending) {                              /* crumble_hip_contig: the expansion was not waited for */
         h->late_pending = false;
         (void)hipEventElapsedTime(&h->up_h2d_ms, h->ev_up[0], h->ev_up[1]);
@@ -1110,6 +1170,13 @@ extern "C" int crumble_hip_run_finish(crumble_hip *h)
     if (ovf[4]) { g_last_error = "input quality >= 128 (SURVEY.md Q13)"; return CRUMBLE_EINVAL; }
     for (int i = 0; i < h->n_stages; i++)
         HIPCHK(hipEventElapsedTime(&h->stage_ms[i], h->ev[i], h->ev[i + 1]));
+    if (spec && ovf[5]) {                               /* the lists did not fit (or a column is too deep): the careful way, with exact sizes */
+        h->cap_trig = (int)std::min<int64_t>(INT_MAX / 2, std::max<int64_t>(h->cap_trig, (int64_t)h->totals.trigcols + h->totals.trigcols / 4));
+        h->cap_items = (int)std::min<int64_t>(INT_MAX / 2, std::max<int64_t>(h->cap_items, (int64_t)h->totals.items + h->totals.items / 4));
+        h->cap_ins = (int)std::min<int64_t>(INT_MAX / 2, std::max<int64_t>(h->cap_ins, (int64_t)h->totals.ins + h->totals.ins / 4));
+        h->spec_aborted = true;
+        return CRUMBLE_OK;
+    }
     if (ovf[0]) { g_last_error = "STR repeat list overflow"; return CRUMBLE_EOVERFLOW; }
     h->have_run = true; h->phase = 5;
     return CRUMBLE_OK;
@@ -1119,9 +1186,22 @@ extern "C" int crumble_hip_run_finish(crumble_hip *h)
 extern "C" int crumble_hip_run(crumble_hip *h)
 {
     int e;
+    if (!h) return CRUMBLE_EINVAL;
+    /* a whole contig: first the fast way (no size read-back in the middle: capacities guessed from the batch's shape,
+     * lengths read on the device); should the scan find a list too small or a column deeper than MAX_DEPTH, once more
+     * with the read-back.  A window of a contig always takes the second way (its phases hand state on through the host). */
+    h->spec = !h->windowed && h->opt_spec;
+    h->spec_aborted = false;
+    e = CRUMBLE_OK;
     if ((e = crumble_hip_run_columns(h)) || (e = crumble_hip_run_depth(h, nullptr, nullptr)) || (e = crumble_hip_run_triggers(h)) ||
-        (e = crumble_hip_run_fold(h, nullptr, nullptr)) || (e = crumble_hip_run_finish(h)))
-        return e;
+        (e = crumble_hip_run_fold(h, nullptr, nullptr)) || (e = crumble_hip_run_finish(h))) { h->spec = false; return e; }
+    if (h->spec && h->spec_aborted) {
+        h->spec = false;
+        if ((e = crumble_hip_run_columns(h)) || (e = crumble_hip_run_depth(h, nullptr, nullptr)) || (e = crumble_hip_run_triggers(h)) ||
+            (e = crumble_hip_run_fold(h, nullptr, nullptr)) || (e = crumble_hip_run_finish(h)))
+            return e;
+    }
+    h->spec = false;
     return CRUMBLE_OK;
 }
 
@@ -1175,6 +1255,17 @@ extern "C" int crumble_hip_download(crumble_hip *h, uint8_t *qual_out, uint8_t *
 {
     if (!h || !h->have_run) { g_last_error = "nothing to download: call crumble_hip_run first"; return CRUMBLE_EINVAL; }
     HIPCHK(hipSetDevice(h->device));
+    if ((size_t)h->n_bases < 4 * h->dl_chunk) {
+        /* a small batch: the three copies queued behind one another, one wait (three blocking copies of a few
+         * kilobytes each were a tenth of a small contig's fixed cost) */
+        int64_t s[CRUMBLE_ST_N];
+        if (qual_out && h->n_bases) HIPCHK(hipMemcpyAsync(qual_out, h->d_out.p, (size_t)h->n_bases, hipMemcpyDeviceToHost, h->stream));
+        if (read_flags_out && h->n_reads) HIPCHK(hipMemcpyAsync(read_flags_out, h->d_rflags.p, (size_t)h->n_reads, hipMemcpyDeviceToHost, h->stream));
+        if (stats) HIPCHK(hipMemcpyAsync(s, h->d_batch_stats.p, sizeof s, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (stats) for (int i = 0; i < CRUMBLE_ST_N; i++) stats[i] += s[i];
+        return CRUMBLE_OK;
+    }
     if (qual_out && h->n_bases) { const int e = staged_d2h(h, qual_out, h->d_out.as<uint8_t>(), (size_t)h->n_bases); if (e) return e; }
     if (read_flags_out && h->n_reads) { const int e = staged_d2h(h, read_flags_out, h->d_rflags.as<uint8_t>(), (size_t)h->n_reads); if (e) return e; }
     if (stats) {
@@ -1399,7 +1490,7 @@ extern "C" int crumble_hip_mask_lc(crumble_hip *h, int64_t nq, const int64_t *re
     int *d_overflow = h->d_misc.as<int>();
     HIPCHK(hipMemset(d_overflow, 0, 4));
     HIPCHK(hipMemcpy(d.p, it.data(), (size_t)nq * sizeof(TrigItem), hipMemcpyHostToDevice));
-    CRUMBLE_LAUNCH_INDEP(k_str, nblk(nq, 64), 64, h->stream, h->B, h->d_params.as<DParams>(), (int)nq, d.as<TrigItem>(), d_overflow);
+    CRUMBLE_LAUNCH_INDEP(k_str, nblk(nq, 64), 64, h->stream, h->B, h->d_params.as<DParams>(), (int)nq, (const int *)nullptr, (const int *)nullptr, d.as<TrigItem>(), d_overflow);
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(it.data(), d.p, (size_t)nq * sizeof(TrigItem), hipMemcpyDeviceToHost));
     int ovf = 0;

@@ -858,10 +858,19 @@ k_columns(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ T
 
 #include "kcol2.h"
 
+/* Work-list kernels take their length either from the host (n, `dev` null) or from device memory (the scan's totals,
+ * clamped to the capacity n the lists were reserved with) and stride over it with whatever grid they were given: the
+ * run's launches then need no size read-back in the middle (crumble_hip_run's fast path, engine.hip).  `abort_`: the
+ * scan found the speculative capacities too small (or a too-deep column): the lists are incomplete, do nothing. */
+#define LIST_N(n_, dev_) ((dev_) ? ((*(dev_) < (n_)) ? *(dev_) : (n_)) : (n_))
+#define LIST_ABORTED(abort_) ((abort_) && *(abort_))
+
 /* ------------------------------------------------------------------------ */
 /* Chunked device-wide exclusive scan of ScanVal over positions.            */
 #ifndef SCAN_CHUNK
 #define SCAN_CHUNK 8192               /* (2048: scan stage 0.69 ms on the chr20 set, 4096: 0.63, 8192: 0.59) */
+#define SCAN_CHUNK_SMALL 1024         /* small contigs: one workgroup walking 8192 columns in eight dependent rounds was a tenth of a 5 kb contig's run */
+#define SCAN_CHUNK_OF(L_) ((L_) <= (1 << 18) ? SCAN_CHUNK_SMALL : SCAN_CHUNK)
 #endif
 
 __device__ __forceinline__ void scanval_of(uint32_t rec, int32_t nplp, int32_t tc, ScanVal &v)
@@ -910,13 +919,13 @@ __device__ __forceinline__ ScanVal scanval_wave_incl01(ScanVal v, int lane)
 /* one workgroup reduces one chunk of SCAN_CHUNK consecutive positions (coalesced) */
 __global__ void __launch_bounds__(256)
 k_scan_reduce(int L, const uint32_t *colrec, const int32_t *nplp,
-              const int32_t *trigcnt, ScanVal *partial, int nchunks)
+              const int32_t *trigcnt, ScanVal *partial, int nchunks, int chunk)
 {
     __shared__ ScanVal ws[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int base = blockIdx.x * SCAN_CHUNK;
+    const int base = blockIdx.x * chunk;
     ScanVal acc = {0, 0, 0, 0, 0, 0, 0}, v;
-    for (int k = 0; k < SCAN_CHUNK / 1024; k++) {                /* four consecutive columns per thread: 16-byte loads */
+    for (int k = 0; k < chunk / 1024; k++) {                /* four consecutive columns per thread: 16-byte loads */
         const int i = base + k * 1024 + 4 * (int)threadIdx.x;
         if (i + 3 < L) {
             const uint4 r4 = *(const uint4 *)(colrec + i);
@@ -942,8 +951,9 @@ k_scan_reduce(int L, const uint32_t *colrec, const int32_t *nplp,
  * in tiles of 1024 (thread t <- entry base + t: coalesced), each tile scanned by the workgroup (wave shuffles
  * + the 16 wave totals in LDS), the carry running from tile to tile. */
 __global__ void __launch_bounds__(1024)
-k_scan_partials(ScanVal *partial, int nchunks)
-{
+k_scan_partials(ScanVal *partial, int nchunks, int cap_trig, int cap_items, int cap_ins, int *spec_abort, ScanVal *totals_copy)
+{   /* the fast path (null otherwise): *spec_abort <- 1 when a total exceeds its capacity or a column is too deep;
+     * *totals_copy <- the totals, next to the run's flags for the host's one read-back at the end of the run */
     __shared__ ScanVal ws[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
     ScanVal carry = {0, 0, 0, 0, 0, 0, 0};
@@ -963,20 +973,26 @@ k_scan_partials(ScanVal *partial, int nchunks)
         for (int j = 0; j < nw; j++) scanval_add(carry, ws[j]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) partial[nchunks] = carry;           /* the grand total */
+    if (threadIdx.x == 0) {
+        partial[nchunks] = carry;                             /* the grand total */
+        if (spec_abort) {
+            if (carry.trigcols > cap_trig || carry.items > cap_items || carry.ins > cap_ins || carry.toodeep != 0) *spec_abort = 1;
+            *totals_copy = carry;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256)
 k_scan_apply(int L, const uint32_t *colrec, const int32_t *nplp,
              const int32_t *trigcnt, const ScanVal *partial, int nchunks,
              int64_t *dpre, int32_t *col_ord, int32_t *trig_ord,
-             int32_t *item_off, int32_t *ins_ord)
+             int32_t *item_off, int32_t *ins_ord, int chunk)
 {
     __shared__ ScanVal ws[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int base = blockIdx.x * SCAN_CHUNK;
+    const int base = blockIdx.x * chunk;
     ScanVal carry = partial[blockIdx.x];
-    for (int k = 0; k < SCAN_CHUNK / 256; k++) {
+    for (int k = 0; k < chunk / 256; k++) {
         const int i = base + k * 256 + (int)threadIdx.x;
         ScanVal v = {0, 0, 0, 0, 0, 0, 0};
         if (i < L) scanval_of(colrec[i], nplp[i], trigcnt[i], v);
@@ -1154,15 +1170,24 @@ k_overdepth(int L, uint32_t *colrec, const int32_t *nplp, const int32_t *col_ord
  * every column's prefixes applies the over-depth test and fills the trigger / insertion column lists itself. */
 
 /* one wave per epoch k >= 1: the counted column with ordinal ord_k and the depth prefix in front of it */
+/* number of epochs of a whole contig with `ncols` counted columns that starts from total_col tc0 (no too-deep column) */
+__device__ __forceinline__ int epochs_count(int64_t ncols, int64_t tc0)
+{
+    const int64_t first = 1048577 - tc0;
+    int n = 0;
+    if (ncols > 0) n = 1 + (int)((ncols > first) ? (ncols - first + 524288) / 524289 : 0);
+    return n > MAX_EPOCHS - 1 ? MAX_EPOCHS - 1 : n;
+}
 __global__ void __launch_bounds__(64)
 k_epochs_find(int L, const uint32_t *__restrict__ colrec, const int32_t *__restrict__ nplp,
-              const ScanVal *__restrict__ partial, int nchunks, Epoch *__restrict__ ep, int64_t tc0)
+              const ScanVal *__restrict__ partial, int nchunks, Epoch *__restrict__ ep, int64_t tc0, int chunk)
 {
     const int k = blockIdx.x + 1, lane = threadIdx.x;
+    if (k >= epochs_count(partial[nchunks].cols, tc0)) return;   /* (the grid may be sized for the most epochs L columns can have) */
     const int64_t ord = (1048577 - tc0) + (int64_t)(k - 1) * 524289;
     int lo = 0, hi = nchunks;                              /* last chunk whose exclusive column count is <= ord */
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int64_t)partial[mid].cols <= ord) lo = mid; else hi = mid; }
-    const int base = lo * SCAN_CHUNK, per = SCAN_CHUNK / 64;
+    const int base = lo * chunk, per = chunk / 64;
     /* lane l takes `per` consecutive columns: its sums, the wave's exclusive prefix, then the lane that holds the
      * ordinal walks its slice */
     int cnt = 0;
@@ -1191,9 +1216,10 @@ k_epochs_find(int L, const uint32_t *__restrict__ colrec, const int32_t *__restr
         }
     }
 }
-__global__ void k_epochs_td(Epoch *ep, int n, int *n_ep, int64_t tc0, int64_t td0)
+__global__ void k_epochs_td(Epoch *ep, int n, int *n_ep, int64_t tc0, int64_t td0, const ScanVal *totals)
 {
     if (blockIdx.x || threadIdx.x) return;
+    if (totals) n = epochs_count(totals->cols, tc0);           /* (fast path: the count is on the device) */
     ep[0].ord_start = 0; ep[0].tc_start = tc0; ep[0].dpre_start = 0; ep[0].td_start = td0;
     int64_t td = td0;
     for (int k = 0; k + 1 < n; k++) {
@@ -1207,15 +1233,16 @@ __global__ void k_epochs_td(Epoch *ep, int n, int *n_ep, int64_t tc0, int64_t td
 __global__ void __launch_bounds__(256)
 k_scan_overdepth(int L, uint32_t *colrec, const int32_t *nplp, const int32_t *trigcnt, const ScanVal *partial,
                  const Epoch *ep, const int *n_ep, const DParams *P, int32_t *trigcol_pos, int32_t *trigcol_off,
-                 int32_t *inscol_pos, u64 *stats, int stat_hi)
+                 int32_t *inscol_pos, u64 *stats, int stat_hi, const int *spec_abort, int chunk)
 {
     __shared__ ScanVal ws[4];
+    if (LIST_ABORTED(spec_abort)) return;                  /* (the lists would not hold the columns: the run is repeated with exact sizes) */
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int base = blockIdx.x * SCAN_CHUNK;
+    const int base = blockIdx.x * chunk;
     const int nep = *n_ep;
     const double od = P->over_depth;
     ScanVal carry = partial[blockIdx.x];
-    for (int k = 0; k < SCAN_CHUNK / 1024; k++) {
+    for (int k = 0; k < chunk / 1024; k++) {
         /* four consecutive columns per thread (16-byte loads, one wave scan and two barriers per 1024 columns) */
         const int i0 = base + k * 1024 + 4 * (int)threadIdx.x;
         uint32_t rec[4] = {0, 0, 0, 0};
@@ -1259,9 +1286,11 @@ k_scan_overdepth(int L, uint32_t *colrec, const int32_t *nplp, const int32_t *tr
 /* Indel-length histogram test (snp:1708-1713, 1777-1819), columns with an
  * insertion only.  One thread per such column. */
 __global__ void __launch_bounds__(64)
-k_inshist(DBatch B, const DParams *P, int n_ins, const int32_t *inscol_pos,
+k_inshist(DBatch B, const DParams *P, int n_ins_, const int *n_dev, const int *spec_abort, const int32_t *inscol_pos,
           uint32_t *colrec, const int32_t *nplp, u64 *stats, int gshift)     /* (statistics: columns < B.stat_hi) */
 {
+    if (LIST_ABORTED(spec_abort)) return;
+    const int n_ins = LIST_N(n_ins_, n_dev);
     /* a group of 1 << gshift lanes per column, lanes over its candidate reads: the whole 64-lane workgroup on a deep
      * pileup; 16 lanes -- four columns per wave -- when a column has a few dozen candidates (the kernel waits on chains
      * of dependent loads: a quarter of the waves, the same chains) */
@@ -1269,7 +1298,9 @@ k_inshist(DBatch B, const DParams *P, int n_ins, const int32_t *inscol_pos,
     __shared__ int s_sz_all[4];
     const int glanes = 1 << gshift, grp = (int)threadIdx.x >> gshift, gl = (int)threadIdx.x & (glanes - 1);
     int *const hist = hist_all + grp * 100;
-    const int t = (int)blockIdx.x * (64 >> gshift) + grp;
+    for (int tb = (int)blockIdx.x; tb * (64 >> gshift) < n_ins; tb += (int)gridDim.x) {     /* (uniform over the workgroup) */
+    const int t = tb * (64 >> gshift) + grp;
+    __syncthreads();                                       /* the previous round's histograms are done with */
     for (int i = gl; i < 100; i += glanes) hist[i] = 0;
     if (gl == 0) s_sz_all[grp] = 0;
     __syncthreads();
@@ -1287,11 +1318,11 @@ k_inshist(DBatch B, const DParams *P, int n_ins, const int32_t *inscol_pos,
         }
     }
     __syncthreads();
-    if (!active || gl != 0) return;
+    if (!active || gl != 0) continue;
     int indel_sz = s_sz_all[grp];
 
     if (indel_sz > 100) indel_sz = 100;
-    if (!indel_sz) return;
+    if (!indel_sz) continue;
     int qd1 = 0, qd2 = 0, ov = 0;
     for (int i = 0; i <= indel_sz && i < 100; i++) {
         if (!hist[i]) continue;
@@ -1303,17 +1334,19 @@ k_inshist(DBatch B, const DParams *P, int n_ins, const int32_t *inscol_pos,
     if ((double)(ov - qd1 - qd2) > P->ins_len_perc * (ov + .1)) { why |= CR_KEEP | CR_R_INSLEN; stat_inc(stats, ST_INS_LEN_PERC, c < B.stat_hi); }
     if ((double)ov < P->indel_ov_perc * nplp[c]) { why |= CR_KEEP | CR_R_INDELOV; stat_inc(stats, ST_INDEL_OV_PERC, c < B.stat_hi); }
     if (why) colrec[c] |= why;
+    }
 }
 
 /* ------------------------------------------------------------------------ */
 /* Ordered trigger list of each trigger column (snp:1695-1730).  One wave per trigger column: the lanes
  * test 64 candidate reads at a time and the hits are written in file order (ballot + prefix popcount). */
 __global__ void __launch_bounds__(256)
-k_emit(DBatch B, const DParams *P, int n_trig, const int32_t *trigcol_pos,
+k_emit(DBatch B, const DParams *P, int n_trig_, const int *n_dev, const int *spec_abort, const int32_t *trigcol_pos,
        const int32_t *trigcol_off, const uint32_t *colrec, TrigItem *items)
 {
-    const int t = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    if (t >= n_trig) return;                                     /* (the whole wave) */
+    if (LIST_ABORTED(spec_abort)) return;
+    const int n_trig = LIST_N(n_trig_, n_dev), lane = threadIdx.x & 63;
+    for (int t = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); t < n_trig; t += (int)(gridDim.x * (blockDim.x >> 6))) {   /* (the whole wave) */
     const int c = trigcol_pos[t], apos = B.p0 + c, tile = c >> 6;
     const int lo = B.tile_lo[tile], hi = B.tile_hi[tile];
     const uint32_t rec = colrec[c];
@@ -1337,14 +1370,16 @@ k_emit(DBatch B, const DParams *P, int n_trig, const int32_t *trigcol_pos,
         if (emit) items[o + __popcll(m & ((1ull << lane) - 1ull))] = it;
         o += __popcll(m);
     }
+    }
 }
 
 /* the same with one lane per trigger column: long-read batches, where a column has only a few candidates */
-__global__ void k_emit_lanes(DBatch B, const DParams *P, int n_trig, const int32_t *trigcol_pos,
+__global__ void k_emit_lanes(DBatch B, const DParams *P, int n_trig_, const int *n_dev, const int *spec_abort, const int32_t *trigcol_pos,
                              const int32_t *trigcol_off, const uint32_t *colrec, TrigItem *items)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_trig) return;
+    if (LIST_ABORTED(spec_abort)) return;
+    const int n_trig = LIST_N(n_trig_, n_dev);
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_trig; t += (int)(gridDim.x * blockDim.x)) {
     const int c = trigcol_pos[t], apos = B.p0 + c, tile = c >> 6;
     const int lo = B.tile_lo[tile], hi = B.tile_hi[tile];
     const uint32_t rec = colrec[c];
@@ -1361,6 +1396,7 @@ __global__ void k_emit_lanes(DBatch B, const DParams *P, int n_trig, const int32
         it.read = r; it.qpos1_kind = (e.qpos + 1) | (is_indel << 30) | ((rec & CR_SCAN) ? 0 : (1 << 29));
         it.lo = INT_MAX; it.hi = 0;
         items[o++] = it;
+    }
     }
 }
 
@@ -1599,17 +1635,19 @@ __device__ inline void dev_mask_lc(const DBatch &B, const DParams *P, int r, int
 }
 
 __global__ void __launch_bounds__(64)
-k_str(DBatch B, const DParams *P, int n_items, TrigItem *items, int *overflow)
+k_str(DBatch B, const DParams *P, int n_items_, const int *n_dev, const int *spec_abort, TrigItem *items, int *overflow)
 {
     __shared__ unsigned win[STR_WORDS * 64];           /* lane t owns win[k*64 + t] */
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_items) return;
-    const TrigItem it = items[t];
-    if (it.qpos1_kind & (1 << 29)) return;            /* indel_cnt < n_plp*indel_fract: snp:1732 */
-    int lo = INT_MAX, hi = 0;
-    dev_mask_lc(B, P, it.read, it.qpos1_kind & 0x1fffffff, (it.qpos1_kind >> 30) & 1, &lo, &hi, overflow,
-                &win[threadIdx.x & 63]);
-    items[t].lo = lo; items[t].hi = hi;
+    if (LIST_ABORTED(spec_abort)) return;
+    const int n_items = LIST_N(n_items_, n_dev);
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_items; t += (int)(gridDim.x * blockDim.x)) {
+        const TrigItem it = items[t];
+        if (it.qpos1_kind & (1 << 29)) continue;       /* indel_cnt < n_plp*indel_fract: snp:1732 */
+        int lo = INT_MAX, hi = 0;
+        dev_mask_lc(B, P, it.read, it.qpos1_kind & 0x1fffffff, (it.qpos1_kind >> 30) & 1, &lo, &hi, overflow,
+                    &win[threadIdx.x & 63]);
+        items[t].lo = lo; items[t].hi = hi;
+    }
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1618,18 +1656,24 @@ k_str(DBatch B, const DParams *P, int n_items, TrigItem *items, int *overflow)
  * (pos > max_pos2).  ubound[k] is a sound upper bound of max_pos2 after
  * column k under ANY incoming state, so pos[k+1] > ubound[k] proves a reset:
  * those are independent segments, folded sequentially by one thread each. */
-__global__ void k_fold_bounds(DBatch B, const DParams *P, int n_trig, const int32_t *trigcol_pos,
-                              const int32_t *trigcol_off, const int32_t *trigcnt,
-                              const TrigItem *items, int32_t *colhi, int in_max_pos)
+__device__ __forceinline__ int fold_bound_of(const DBatch &B, int k, const int32_t *trigcol_pos, const int32_t *trigcol_off,
+                                             const int32_t *trigcnt, const TrigItem *items, int in_max_pos)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_trig) return;
     const int c = trigcol_pos[k], pos = B.p0 + c;
     const int o = trigcol_off[k], n = trigcnt[c];
     int h = pos;
     for (int i = 0; i < n; i++) if (items[o + i].hi > h) h = items[o + i].hi;
     if (k == 0 && in_max_pos > h) h = in_max_pos;            /* the state the window starts from */
-    colhi[k] = h;
+    return h;
+}
+__global__ void k_fold_bounds(DBatch B, const DParams *P, int n_trig_, const int *n_dev, const int *spec_abort, const int32_t *trigcol_pos,
+                              const int32_t *trigcol_off, const int32_t *trigcnt,
+                              const TrigItem *items, int32_t *colhi, int in_max_pos)
+{
+    if (LIST_ABORTED(spec_abort)) return;
+    const int n_trig = LIST_N(n_trig_, n_dev);
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_trig; k += (int)(gridDim.x * blockDim.x))
+        colhi[k] = fold_bound_of(B, k, trigcol_pos, trigcol_off, trigcnt, items, in_max_pos);
 }
 
 /* generic chunked inclusive prefix-max over int32: one 256-thread workgroup per chunk of PMAX_CHUNK
@@ -1642,9 +1686,11 @@ __device__ __forceinline__ int pmax_wave_max(int m)
     return m;
 }
 __global__ void __launch_bounds__(256)
-k_pmax_reduce(int n, const int32_t *__restrict__ v, int32_t *__restrict__ partial)
+k_pmax_reduce(int n_, const int *n_dev, const int32_t *__restrict__ v, int32_t *__restrict__ partial)
 {
     __shared__ int wm[4];
+    const int n = LIST_N(n_, n_dev);
+    if ((int)blockIdx.x * PMAX_CHUNK >= n) return;
     const int b = blockIdx.x * PMAX_CHUNK + threadIdx.x * 8;
     int m = INT_MIN;
     #pragma unroll
@@ -1661,9 +1707,10 @@ k_pmax_reduce(int n, const int32_t *__restrict__ v, int32_t *__restrict__ partia
 }
 /* exclusive prefix-max of the chunk maxima, in place: one wave, 64 chunks per step */
 __global__ void __launch_bounds__(64)
-k_pmax_partials(int32_t *partial, int nchunks)
+k_pmax_partials(int32_t *partial, int nchunks_, int n_, const int *n_dev)
 {
     const int lane = threadIdx.x;
+    const int nchunks = n_dev ? (LIST_N(n_, n_dev) + PMAX_CHUNK - 1) / PMAX_CHUNK : nchunks_;
     int run = INT_MIN;
     for (int base = 0; base < nchunks; base += 64) {
         const int x = base + lane < nchunks ? partial[base + lane] : INT_MIN;
@@ -1678,9 +1725,11 @@ k_pmax_partials(int32_t *partial, int nchunks)
     }
 }
 __global__ void __launch_bounds__(256)
-k_pmax_apply(int n, int32_t *__restrict__ v, const int32_t *__restrict__ partial)
+k_pmax_apply(int n_, const int *n_dev, int32_t *__restrict__ v, const int32_t *__restrict__ partial)
 {
     __shared__ int wm[4];
+    const int n = LIST_N(n_, n_dev);
+    if ((int)blockIdx.x * PMAX_CHUNK >= n) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int b = blockIdx.x * PMAX_CHUNK + threadIdx.x * 8;
     int x[8], m = INT_MIN;
@@ -1701,31 +1750,35 @@ k_pmax_apply(int n, int32_t *__restrict__ v, const int32_t *__restrict__ partial
 }
 
 /* colhi (already prefix-maxed = bound on max_pos) -> per-column bound on max_pos2 */
-__global__ void k_fold_ub(DBatch B, const DParams *P, int n_trig, const int32_t *trigcol_pos,
-                          const int32_t *colhi, int32_t *ub, int in_max_pos2)
+__device__ __forceinline__ int fold_ub_of(const DBatch &B, const DParams *P, int k, const int32_t *trigcol_pos, int colhi_k, int in_max_pos2)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_trig) return;
-    const double pos = B.p0 + trigcol_pos[k], h = colhi[k];
+    const double pos = B.p0 + trigcol_pos[k], h = colhi_k;
     double a = pos + (h - pos) * P->iSTR_mul + P->iSTR_add;
     double b = pos + (h - pos) * P->sSTR_mul + P->sSTR_add;
     double m = a > b ? a : b;
     if (m < pos) m = pos;
     m += 2;                                         /* slack over the truncations */
     if (k == 0 && (double)in_max_pos2 > m) m = in_max_pos2;
-    ub[k] = m > 2147483000.0 ? 2147483000 : (int)m;
+    return m > 2147483000.0 ? 2147483000 : (int)m;
+}
+__global__ void k_fold_ub(DBatch B, const DParams *P, int n_trig_, const int *n_dev, const int *spec_abort, const int32_t *trigcol_pos,
+                          const int32_t *colhi, int32_t *ub, int in_max_pos2)
+{
+    if (LIST_ABORTED(spec_abort)) return;
+    const int n_trig = LIST_N(n_trig_, n_dev);
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_trig; k += (int)(gridDim.x * blockDim.x))
+        ub[k] = fold_ub_of(B, P, k, trigcol_pos, colhi[k], in_max_pos2);
 }
 
-__global__ void k_fold(DBatch B, const DParams *P, int n_trig, const int32_t *trigcol_pos,
+/* one segment of trigger columns from its start k0 (no-op when k0 is not a segment start) */
+__device__ __forceinline__ void fold_chain(const DBatch &B, const DParams *P, int n_trig, int k0, const int32_t *trigcol_pos,
                        const int32_t *trigcol_off, const int32_t *trigcnt, const TrigItem *items,
                        const int32_t *ubmax /* inclusive prefix max of ub */,
-                       uint32_t *colrec, int32_t *pos_mn2, int32_t *trig_mx2,
+                       int32_t *pos_mn2, int32_t *trig_mx2,
                        int in_min_pos, int in_max_pos, int in_min_pos2, int in_max_pos2, int cut_pos, int32_t *carry_out)
 {
     /* (in_*: the state the first column starts from -- INT_MAX 0 INT_MAX 0 for a whole contig; carry_out: the
      * state after the last trigger column before cut_pos, for the next window of the contig) */
-    const int k0 = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k0 >= n_trig) return;
     if (k0 > 0 && !(B.p0 + trigcol_pos[k0] > ubmax[k0 - 1])) return;   /* not a segment start */
     int min_pos = INT_MAX, max_pos = 0, min_pos2 = INT_MAX, max_pos2 = 0;
     if (k0 == 0) { min_pos = in_min_pos; max_pos = in_max_pos; min_pos2 = in_min_pos2; max_pos2 = in_max_pos2; }
@@ -1760,6 +1813,18 @@ __global__ void k_fold(DBatch B, const DParams *P, int n_trig, const int32_t *tr
         }
     }
 }
+__global__ void k_fold(DBatch B, const DParams *P, int n_trig_, const int *n_dev, const int *spec_abort, const int32_t *trigcol_pos,
+                       const int32_t *trigcol_off, const int32_t *trigcnt, const TrigItem *items,
+                       const int32_t *ubmax /* inclusive prefix max of ub */,
+                       uint32_t *colrec, int32_t *pos_mn2, int32_t *trig_mx2,
+                       int in_min_pos, int in_max_pos, int in_min_pos2, int in_max_pos2, int cut_pos, int32_t *carry_out)
+{
+    if (LIST_ABORTED(spec_abort)) return;
+    const int n_trig = LIST_N(n_trig_, n_dev);
+    for (int k0 = blockIdx.x * blockDim.x + threadIdx.x; k0 < n_trig; k0 += (int)(gridDim.x * blockDim.x))
+        fold_chain(B, P, n_trig, k0, trigcol_pos, trigcol_off, trigcnt, items, ubmax, pos_mn2, trig_mx2,
+                   in_min_pos, in_max_pos, in_min_pos2, in_max_pos2, cut_pos, carry_out);
+}
 
 /* the columns from the window's first one up to the first trigger column are "in window" while pos <= the
  * max_pos2 the window starts from (snp:1880) */
@@ -1773,16 +1838,63 @@ __global__ void k_window_head(DBatch B, int n_trig, const int32_t *trigcol_pos, 
 }
 
 /* columns after a trigger column stay "in window" while pos <= max_pos2 (snp:1880) */
-__global__ void k_window(DBatch B, int n_trig, const int32_t *trigcol_pos, const int32_t *trig_mx2,
-                         uint32_t *colrec)
+__device__ __forceinline__ void window_of(const DBatch &B, int n_trig, int k, const int32_t *trigcol_pos, const int32_t *trig_mx2, uint32_t *colrec)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_trig) return;
     const int c = trigcol_pos[k];
     int64_t last = (int64_t)trig_mx2[k] - B.p0;
     const int next = (k + 1 < n_trig) ? trigcol_pos[k + 1] : B.L;
     if (last > next - 1) last = next - 1;
     for (int64_t i = c + 1; i <= last; i++) colrec[i] |= CR_WIN;
+}
+__global__ void k_window(DBatch B, int n_trig_, const int *n_dev, const int *spec_abort, const int32_t *trigcol_pos, const int32_t *trig_mx2,
+                         uint32_t *colrec)
+{
+    if (LIST_ABORTED(spec_abort)) return;
+    const int n_trig = LIST_N(n_trig_, n_dev);
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_trig; k += (int)(gridDim.x * blockDim.x))
+        window_of(B, n_trig, k, trigcol_pos, trig_mx2, colrec);
+}
+
+/* Short trigger lists (a small contig): bounds, both prefix maxima, the fold and the window marks by ONE 1024-thread
+ * workgroup in one launch -- ten dependent launches of a few microseconds each were a fifth of a 5 kb contig's run.
+ * Whole contigs only (the windows' phases hand state on between the steps). */
+__device__ __forceinline__ void block_prefix_max(int32_t *v, int n, int *wm /* [17] */)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+    int carry = INT_MIN;
+    for (int base = 0; base < n; base += (int)blockDim.x) {
+        const int i = base + (int)threadIdx.x;
+        int incl = i < n ? v[i] : INT_MIN;
+        #pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d && o > incl) incl = o; }
+        if (lane == 63) wm[w] = incl;
+        __syncthreads();
+        int run = carry;
+        for (int j = 0; j < w; j++) run = wm[j] > run ? wm[j] : run;
+        if (i < n) v[i] = incl > run ? incl : run;
+        for (int j = 0; j < nw; j++) carry = wm[j] > carry ? wm[j] : carry;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(1024)
+k_fold_small(DBatch B, const DParams *P, int n_trig_, const int *n_dev, const int *spec_abort, const int32_t *trigcol_pos,
+             const int32_t *trigcol_off, const int32_t *trigcnt, const TrigItem *items, int32_t *colhi, int32_t *ub,
+             uint32_t *colrec, int32_t *pos_mn2, int32_t *trig_mx2, int32_t *carry_out)
+{
+    __shared__ int wm[17];
+    if (LIST_ABORTED(spec_abort)) return;
+    const int n_trig = LIST_N(n_trig_, n_dev);
+    for (int k = threadIdx.x; k < n_trig; k += (int)blockDim.x) colhi[k] = fold_bound_of(B, k, trigcol_pos, trigcol_off, trigcnt, items, 0);
+    __syncthreads();
+    block_prefix_max(colhi, n_trig, wm);
+    for (int k = threadIdx.x; k < n_trig; k += (int)blockDim.x) ub[k] = fold_ub_of(B, P, k, trigcol_pos, colhi[k], 0);
+    __syncthreads();
+    block_prefix_max(ub, n_trig, wm);
+    for (int k0 = threadIdx.x; k0 < n_trig; k0 += (int)blockDim.x)
+        fold_chain(B, P, n_trig, k0, trigcol_pos, trigcol_off, trigcnt, items, ub, pos_mn2, trig_mx2,
+                   INT_MAX, 0, INT_MAX, 0, B.p0 + B.stat_hi, carry_out);
+    __syncthreads();
+    for (int k = threadIdx.x; k < n_trig; k += (int)blockDim.x) window_of(B, n_trig, k, trigcol_pos, trig_mx2, colrec);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -2309,9 +2421,11 @@ __global__ void k_replay_general(DBatch B, const DParams *__restrict__ P, const 
 /* (c): back-fill of every read under a trigger column (snp:1870-1879), bases before
  * the entry's own qpos (the entry's own byte is handled by apply_col). */
 __global__ void __launch_bounds__(64)
-k_restore(DBatch B, const DParams *__restrict__ P, int n_trig, const int32_t *trigcol_pos,
+k_restore(DBatch B, const DParams *__restrict__ P, int n_trig_, const int *n_dev, const int *spec_abort, const int32_t *trigcol_pos,
           const int32_t *__restrict__ pos_mn2, const int32_t *__restrict__ trig_mx2, uint8_t *__restrict__ out, int coop)
 {
+    if (LIST_ABORTED(spec_abort)) return;
+    const int n_trig = LIST_N(n_trig_, n_dev);
     /* one wave per trigger column.  Step 1: every lane resolves one candidate read (entry, start of
      * the back-fill in query coordinates).  Step 2: the wave writes the ranges one read at a time,
      * lanes along the bytes, so a range is one or two coalesced stores instead of a byte loop per
@@ -2319,8 +2433,9 @@ k_restore(DBatch B, const DParams *__restrict__ P, int n_trig, const int32_t *tr
     /* long reads (!coop): a column has a few candidates, each lane works alone -- two columns per wave, 32 lanes each
      * (the kernel waits on chains of dependent loads: half the waves, the same chains) */
     const int grp = coop ? 64 : 8;
-    const int t = coop ? (int)blockIdx.x : (int)blockIdx.x * 8 + (int)(threadIdx.x >> 3);
-    if (t >= n_trig) return;
+    for (int tb = (int)blockIdx.x; (coop ? tb : tb * 8) < n_trig; tb += (int)gridDim.x) {
+    const int t = coop ? tb : tb * 8 + (int)(threadIdx.x >> 3);
+    if (t >= n_trig) continue;
     const int lane = coop ? (int)threadIdx.x : (int)(threadIdx.x & 7);
     const int c = trigcol_pos[t], apos = B.p0 + c, tile = c >> 6;
     const int lo = B.tile_lo[tile], hi = B.tile_hi[tile];
@@ -2426,6 +2541,7 @@ k_restore(DBatch B, const DParams *__restrict__ P, int n_trig, const int32_t *tr
                 for (int x = s4[u] + lane + 64; x < e4[u]; x += 64)
                     out[so4[u] + x] = cap_q2(P, qcap, any_pres, B.quals[so4[u] + x]) & 0x7f;
         }
+    }
     }
 }
 
@@ -3401,10 +3517,11 @@ k_stats(int64_t b_lo, int64_t b_hi, int64_t n_reads, const uint8_t *out, const u
 
 /* this batch's counters into the engine's accumulated vector (what the multi-GPU all-reduce sums) */
 /* (a run that ends in CRUMBLE_EOVERFLOW adds nothing: its partial counters must not reach the all-reduced vector) */
-__global__ void k_stats_fold(u64 *__restrict__ total, const u64 *__restrict__ batch, int n, const int *__restrict__ overflow)
+__global__ void k_stats_fold(u64 *__restrict__ total, const u64 *__restrict__ batch, int n, const int *__restrict__ overflow,
+                             const int *__restrict__ spec_abort)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && !*overflow) total[i] += batch[i];
+    if (i < n && !*overflow && !LIST_ABORTED(spec_abort)) total[i] += batch[i];      /* (an aborted fast run is repeated) */
 }
 
 #endif /* CRUMBLE_KERNELS_H */

@@ -166,9 +166,15 @@ void         crumble_hip_destroy(crumble_hip *h);
  *   "kcol"   = auto | v1 | v1perm | v2      column kernel (k_columns, its per-column-class form, k_columns2)
  *   "pblock" = auto | reads | segments | words   P-block decomposition
  *   "replay" = auto | flat                  per-base replay kernel
+ *   "run"    = fast | careful               crumble_hip_run's first attempt: work lists sized by guess and measured on
+ *                                           the device (no read-back in the middle; repeated the careful way when a
+ *                                           guess was too small), or sized from a read-back as the windows' phases are
+ *   "caps"   = <n>                          the fast attempt's list capacities (0: guessed; tests force the repeat)
+ *   "stages" = off | on                     HIP events around the stages of a run (crumble_hip_kernel_times)
  *   "dl_chunk" = <bytes>                    size of one staged device -> host copy (256 .. 8 MiB; crumble_hip_download
  *                                           of >= 4 chunks goes through page-locked staging buffers on 8 streams)
- * Takes effect at the next crumble_hip_upload().  Unknown names / values -> CRUMBLE_EINVAL. */
+ * kcol / pblock / replay take effect at the next crumble_hip_upload(), the others at once.  Unknown names / values ->
+ * CRUMBLE_EINVAL. */
 int crumble_hip_set_option(crumble_hip *h, const char *name, const char *value);
 
 /* Replaces one contig's worth of transcode() loop iterations + flush:
@@ -227,7 +233,7 @@ int crumble_hip_run_triggers(crumble_hip *h);
 int crumble_hip_run_fold(crumble_hip *h, const crumble_carry *in, crumble_carry *out);
 int crumble_hip_run_finish(crumble_hip *h);
 
-/* HIP-event timings of the last crumble_hip_run(): names[i] / ms[i] for up to
+/* HIP-event timings of the last crumble_hip_run() (option "stages" = on; 0 stages otherwise): names[i] / ms[i] for up to
  * `max` kernels (returns the number filled).  bytes[i] (may be NULL) receives
  * the algorithmic bytes that launch is charged with. */
 int crumble_hip_kernel_times(crumble_hip *h, const char **names, float *ms,

@@ -234,3 +234,23 @@ def test_emu_long_sparse_contig(product):
     hb = HostBatch.from_reads(reads)
     for level in (5, 9):
         assert_parity(emu_lib.engine, ca.preset_params(level), hb)
+
+
+def test_emu_run_paths(product):
+    """crumble_hip_run's fast way (lists sized by guess, lengths on the device), the careful way (sized from a
+    read-back) and the fast way with capacities too small for the batch (aborted by the scan, repeated carefully)
+    give the oracle's bytes, flags, statistics and column records."""
+    cases = ((ca.preset_params(5), synth_batch("chr20", 0.0004, err_indel=2e-3)),
+             (ca.preset_params(9, tech="pbccs"), synth_batch("hifi", 0.0001, read_len=3000)),
+             (ca.preset_params(1), synth_batch("ce", 0.2)))
+    for p, hb in cases:
+        for opts in ({"run": "careful"}, {"run": "fast"}, {"run": "fast", "caps": 3}, {"run": "fast", "caps": 3, "kcol": "v2"}):
+            assert_parity(emu_lib.with_options(**opts), p, hb)
+    # one engine: an aborted fast run, then batches that fit
+    eng = emu_lib.engine(ca.preset_params(5), caps=2)
+    import oracle_lib as O
+    for hb in (cases[0][1], cases[2][1], cases[0][1]):
+        q, f, s = eng.contig(hb)
+        wq, wf, ws = O.contig(ca.preset_params(5), hb)
+        assert np.array_equal(q, wq) and np.array_equal(f, wf) and np.array_equal(s, ws)
+    eng.close()

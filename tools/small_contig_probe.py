@@ -7,7 +7,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import crumble_amd as ca
 import synth
 eng = ca.Engine(ca.preset_params(5), 0)
-for clen in (5000, 50000, 500000, 5000000):
+sizes = [int(a) for a in sys.argv[1:]] or [5000, 50000, 500000, 5000000]
+for clen in sizes:
     cfg = synth.config("chr20", scale=1.0); cfg.contig_len = clen
     hb = synth.generate(cfg)
     eng.contig(hb)
