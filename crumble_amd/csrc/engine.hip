@@ -87,7 +87,7 @@ struct crumble_hip {
     /* work lists */
     DevBuf d_trigcol_pos, d_trigcol_off, d_inscol_pos, d_items, d_colhi, d_ub, d_pmax_partial, d_trig_mx2;
     /* outputs */
-    DevBuf d_out, d_rflags, d_keepf, d_b15f, d_blk_read, d_chunk_read, d_kept;
+    DevBuf d_out, d_rflags, d_keepf, d_b15f, d_blk_read, d_chunk_read, d_kept, d_marks;
     DBatch B;
     bool have_batch = false, have_run = false;
     /* what crumble_hip_expand() needs beyond the raw arrays on the device (set by the copy half of an upload) */
@@ -307,7 +307,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
         &h->d_trigcnt, &h->d_dpre, &h->d_col_ord, &h->d_trig_ord, &h->d_item_off, &h->d_ins_ord,
         &h->d_pos_mn2, &h->d_partial, &h->d_epochs, &h->d_ht, &h->d_trigcol_pos, &h->d_trigcol_off,
         &h->d_inscol_pos, &h->d_items, &h->d_colhi, &h->d_ub, &h->d_pmax_partial, &h->d_trig_mx2,
-        &h->d_out, &h->d_rflags, &h->d_keepf, &h->d_b15f, &h->d_blk_read, &h->d_chunk_read, &h->d_kept };
+        &h->d_out, &h->d_rflags, &h->d_keepf, &h->d_b15f, &h->d_blk_read, &h->d_chunk_read, &h->d_kept, &h->d_marks };
     for (DevBuf *b : all) b->release();
     if (h->events_ok) { for (int i = 0; i <= MAX_STAGES; i++) (void)hipEventDestroy(h->ev[i]); for (int i = 0; i < 3; i++) (void)hipEventDestroy(h->ev_up[i]); }
     if (h->pinned) (void)hipHostFree(h->pinned);
@@ -1090,66 +1090,109 @@ extern "C" int crumble_hip_run_finish(crumble_hip *h)
     }
     if (n > 0) {
         STAGE("k_replay", 3.0 * nb);
-        HIPCHK(hipMemsetAsync(h->d_keepf.p, 0, (size_t)n * 2, st));      /* keepf and, behind it, b15f */
-        if (nb > 0 && h->hparams.softclip)
-            CRUMBLE_LAUNCH_INDEP(k_replay_general, nblk(nb, 256), 256, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
-                                 h->d_blk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(),
-                                 h->d_b15f.as<uint8_t>());
-        else if (nb > 0 && h->packed_ok && !h->batch_flat && (!(h->n_segrec > h->n_reads + h->n_reads / 2) || h->have_vrec)) {
-            /* action bytes + packed 16-base chunks (kernels.h): per read for short reads (+ the general-CIGAR reads
-             * one at a time), per reference-consuming op for long reads */
+        const bool multi = h->n_segrec > h->n_reads + h->n_reads / 2;
+        const bool packed = nb > 0 && !h->hparams.softclip && h->packed_ok && !h->batch_flat && (!multi || h->have_vrec);
+        /* the statistics come out of the replay when it is the last writer (no P-block) and counts every byte (a window
+         * of a contig counts its owned reads only: k_stats) */
+        const bool fused_stats = packed && !h->hparams.pblock && !h->windowed;
+        if (packed) {
+            /* The packed replay.  First what a byte needs to know beyond its own column: the per-read flags
+             * (k_readflags, from the columns k_actions marks) and the back-fill ranges of the trigger columns (k_restore's
+             * marks, a bit per base).  Then ONE writer per byte: k_replay_fast over 16-base chunks (per read for short
+             * reads, per reference-consuming op for long reads), k_replay_reads for the general-CIGAR reads of a
+             * short-read batch, k_replay_slow for the bases D/N columns report. */
             int ea;
-            if ((ea = h->d_act.reserve((size_t)L + 2 * ACT_PAD))) return ea;
+            const size_t nfw = (size_t)(L > 0 ? L : 0) / 32 + 2, nbw = (size_t)nb / 32 + 4;
+            if ((ea = h->d_act.reserve((size_t)L + 2 * ACT_PAD)) || (ea = h->d_marks.reserve((nfw + nbw) * 4 + 64))) return ea;
             uint8_t *act = h->d_act.as<uint8_t>() + ACT_PAD;
-            if (L > 0) CRUMBLE_LAUNCH_INDEP(k_actions, nblk((L + 3) / 4, 256), 256, st, L, colrec, act);
-#define RFAST_LAUNCH(V_, PV_) CRUMBLE_LAUNCH_INDEP((k_replay_fast<V_, PV_>), nblk((nb + 15) / 16, 256), 256, st, B, P, colrec, act, \
-                                     h->d_chunk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(), h->d_b15f.as<uint8_t>())
-            const bool pv = h->hparams.n_pv > 0;
-            if (h->have_vrec) { if (pv) RFAST_LAUNCH(true, true); else RFAST_LAUNCH(true, false); }
-            else {
-                if (pv) RFAST_LAUNCH(false, true); else RFAST_LAUNCH(false, false);
-                if (h->n_general_max > 0)
-                    CRUMBLE_LAUNCH_INDEP(k_replay_reads, (unsigned)(h->n_general_max < 16384 ? h->n_general_max : 16384), 64, st, B, P, colrec,
-                                         h->d_genlist.as<int32_t>(), h->d_misc.as<int>() + 12,
-                                         h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(), h->d_b15f.as<uint8_t>());
+            uint32_t *flagbits = h->d_marks.as<uint32_t>(), *forcebits = flagbits + nfw;
+            uint8_t *rfl = h->d_rflags.as<uint8_t>();
+            HIPCHK(hipMemsetAsync(flagbits, 0, (nfw + nbw) * 4, st));
+            if (L > 0) CRUMBLE_LAUNCH_INDEP(k_actions, nblk((L + 3) / 4, 256), 256, st, L, colrec, act, flagbits);
+            CRUMBLE_LAUNCH_INDEP(k_readflags, nblk(n, 256), 256, st, B, colrec, flagbits, rfl, forcebits);
+            if (L > 0 && n_trig > 0) {
+                const int coop = multi ? 0 : 1;                 /* (long reads: eight columns per wave) */
+                unsigned g = (unsigned)(coop ? n_trig : (n_trig + 7) / 8);
+                if (spec && g > 32768u) g = 32768u;
+                CRUMBLE_LAUNCH(k_restore, g, 64, st, B, P, n_trig, nd_trig, spec_abort, h->d_trigcol_pos.as<int32_t>(), h->d_pos_mn2.as<int32_t>(),
+                               h->d_trig_mx2.as<int32_t>(), h->d_out.as<uint8_t>(), coop, forcebits);
             }
+            /* with the statistics inside, a workgroup flushes its histogram at its end: few enough of them for that, many
+             * enough (several rounds of what the chip holds at once) for an even finish */
+            const unsigned gfull = nblk((nb + 15) / 16, 256);
+            const unsigned gf = (!fused_stats || gfull < h->persistent_blocks * 8) ? gfull : h->persistent_blocks * 8;
+#define RFAST_LAUNCH(V_, PV_, S_) CRUMBLE_LAUNCH((k_replay_fast<V_, PV_, S_>), gf, 256, st, B, P, colrec, act, \
+                                     h->d_chunk_read.as<int32_t>(), h->d_out.as<uint8_t>(), forcebits, stats, d_overflow + 4)
+#define RFAST_LAUNCH2(V_, PV_) do { if (fused_stats) RFAST_LAUNCH(V_, PV_, true); else RFAST_LAUNCH(V_, PV_, false); } while (0)
+            const bool pv = h->hparams.n_pv > 0;
+            if (h->have_vrec) { if (pv) RFAST_LAUNCH2(true, true); else RFAST_LAUNCH2(true, false); }
+            else {
+                if (pv) RFAST_LAUNCH2(false, true); else RFAST_LAUNCH2(false, false);
+                if (h->n_general_max > 0) {
+                    /* four waves per workgroup, a read per wave at a time; no more workgroups than the chip holds at once */
+                    const unsigned gmax = h->persistent_blocks / 4 * 6 > 0 ? h->persistent_blocks / 4 * 6 : 1u;
+                    const unsigned gg = (unsigned)((h->n_general_max + 3) / 4 < (int64_t)gmax ? (h->n_general_max + 3) / 4 : gmax);
+                    if (fused_stats) CRUMBLE_LAUNCH(k_replay_reads<true>, gg, 256, st, B, P, colrec, h->d_genlist.as<int32_t>(), h->d_misc.as<int>() + 12,
+                                                    h->d_out.as<uint8_t>(), forcebits, stats);
+                    else             CRUMBLE_LAUNCH(k_replay_reads<false>, gg, 256, st, B, P, colrec, h->d_genlist.as<int32_t>(), h->d_misc.as<int>() + 12,
+                                                    h->d_out.as<uint8_t>(), forcebits, stats);
+                }
+            }
+#undef RFAST_LAUNCH2
 #undef RFAST_LAUNCH
-            if (h->n_slow > 0)
-                CRUMBLE_LAUNCH_INDEP(k_replay_slow, nblk(h->n_slow, 64), 64, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
-                                     h->d_misc.as<int>() + 11, h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(),
-                                     h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(), h->d_b15f.as<uint8_t>());
-        } else if (nb > 0) {
-            CRUMBLE_LAUNCH_INDEP(k_replay_flat, nblk((nb + RPL_NB - 1) / RPL_NB, 256), 256, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
-                                 h->d_blk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(),
-                                 h->d_b15f.as<uint8_t>());
-            if (h->n_slow > 0)
-                CRUMBLE_LAUNCH_INDEP(k_replay_slow, nblk(h->n_slow, 64), 64, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
-                                     h->d_misc.as<int>() + 11, h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(),
-                                     h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(), h->d_b15f.as<uint8_t>());
+            if (h->n_slow > 0) {
+                if (fused_stats) CRUMBLE_LAUNCH(k_replay_slow<true>, nblk(h->n_slow, 64), 64, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
+                                                h->d_misc.as<int>() + 11, h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(),
+                                                h->d_out.as<uint8_t>(), (uint8_t *)nullptr, (uint8_t *)nullptr, forcebits, stats);
+                else             CRUMBLE_LAUNCH(k_replay_slow<false>, nblk(h->n_slow, 64), 64, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
+                                                h->d_misc.as<int>() + 11, h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(),
+                                                h->d_out.as<uint8_t>(), (uint8_t *)nullptr, (uint8_t *)nullptr, forcebits, stats);
+            }
+            if (fused_stats) CRUMBLE_LAUNCH_INDEP(k_stats_totals, 1, 64, st, n, nb, stats);
+        } else {
+            /* the byte-wise replays (-S, parameter sets outside the packed formulas, "replay" = flat): the flags are
+             * raised on the way, the back-fill and the kept reads are written afterwards */
+            HIPCHK(hipMemsetAsync(h->d_keepf.p, 0, (size_t)n * 2, st));      /* keepf and, behind it, b15f */
+            if (nb > 0 && h->hparams.softclip)
+                CRUMBLE_LAUNCH_INDEP(k_replay_general, nblk(nb, 256), 256, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
+                                     h->d_blk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(),
+                                     h->d_b15f.as<uint8_t>());
+            else if (nb > 0) {
+                CRUMBLE_LAUNCH_INDEP(k_replay_flat, nblk((nb + RPL_NB - 1) / RPL_NB, 256), 256, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
+                                     h->d_blk_read.as<int32_t>(), h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(),
+                                     h->d_b15f.as<uint8_t>());
+                if (h->n_slow > 0)
+                    CRUMBLE_LAUNCH(k_replay_slow<false>, nblk(h->n_slow, 64), 64, st, B, P, colrec, h->d_pos_mn2.as<int32_t>(),
+                                   h->d_misc.as<int>() + 11, h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(),
+                                   h->d_out.as<uint8_t>(), h->d_keepf.as<uint8_t>(), h->d_b15f.as<uint8_t>(),
+                                   (const uint32_t *)nullptr, stats);
+            }
+            if (L > 0 && n_trig > 0) {
+                const int coop = multi ? 0 : 1;
+                unsigned g = (unsigned)(coop ? n_trig : (n_trig + 7) / 8);
+                if (spec && g > 32768u) g = 32768u;
+                CRUMBLE_LAUNCH(k_restore, g, 64, st, B, P, n_trig, nd_trig, spec_abort,
+                                     h->d_trigcol_pos.as<int32_t>(), h->d_pos_mn2.as<int32_t>(), h->d_trig_mx2.as<int32_t>(), h->d_out.as<uint8_t>(),
+                                     coop, (uint32_t *)nullptr);
+            }
+            CRUMBLE_LAUNCH_INDEP(k_readfix, nblk(n, 256), 256, st, B, colrec, h->d_keepf.as<uint8_t>(),
+                                 h->d_b15f.as<uint8_t>(), h->d_rflags.as<uint8_t>(), h->d_kept.as<int32_t>(), d_overflow + 2);
+            CRUMBLE_LAUNCH_INDEP(k_keepfix, (nblk(n, 4) < 4096u ? nblk(n, 4) : 4096u), 256, st, B, P, h->d_kept.as<int32_t>(),
+                                 d_overflow + 2, h->d_out.as<uint8_t>());
         }
-        if (L > 0 && n_trig > 0) {
-            const int coop = (h->n_segrec > h->n_reads + h->n_reads / 2) ? 0 : 1;      /* (long reads: eight columns per wave) */
-            unsigned g = (unsigned)(coop ? n_trig : (n_trig + 7) / 8);
-            if (spec && g > 32768u) g = 32768u;
-            CRUMBLE_LAUNCH(k_restore, g, 64, st, B, P, n_trig, nd_trig, spec_abort,
-                                 h->d_trigcol_pos.as<int32_t>(), h->d_pos_mn2.as<int32_t>(), h->d_trig_mx2.as<int32_t>(), h->d_out.as<uint8_t>(),
-                                 coop);
-        }
-        CRUMBLE_LAUNCH_INDEP(k_readfix, nblk(n, 256), 256, st, B, colrec, h->d_keepf.as<uint8_t>(),
-                             h->d_b15f.as<uint8_t>(), h->d_rflags.as<uint8_t>(), h->d_kept.as<int32_t>(), d_overflow + 2);
-        CRUMBLE_LAUNCH_INDEP(k_keepfix, (nblk(n, 4) < 4096u ? nblk(n, 4) : 4096u), 256, st, B, P, h->d_kept.as<int32_t>(),
-                             d_overflow + 2, h->d_out.as<uint8_t>());
         if (h->hparams.pblock) {
             STAGE("k_pblock", 2.0 * nb);
             const int pe = launch_pblock(h, st, n, nb, B.seq_off, h->d_out.as<uint8_t>(), h->d_rflags.as<uint8_t>(),
                                          h->d_blk_read.as<int32_t>(), h->b_pblock);
             if (pe) return pe;
         }
-        STAGE("k_stats", 2.0 * nb);
-        if (h->windowed)
-            CRUMBLE_LAUNCH(k_stats, 1024, 256, st, h->own_b_lo, h->own_b_hi, h->win.read_end - h->win.read_first, h->d_out.as<uint8_t>(), B.quals, stats, d_overflow + 4);
-        else
-            CRUMBLE_LAUNCH(k_stats, 1024, 256, st, (int64_t)0, nb, n, h->d_out.as<uint8_t>(), B.quals, stats, d_overflow + 4);
+        if (!fused_stats) {
+            STAGE("k_stats", 2.0 * nb);
+            if (h->windowed)
+                CRUMBLE_LAUNCH(k_stats, 1024, 256, st, h->own_b_lo, h->own_b_hi, h->win.read_end - h->win.read_first, h->d_out.as<uint8_t>(), B.quals, stats, d_overflow + 4);
+            else
+                CRUMBLE_LAUNCH(k_stats, 1024, 256, st, (int64_t)0, nb, n, h->d_out.as<uint8_t>(), B.quals, stats, d_overflow + 4);
+        }
     }
     if (h->opt_stages) HIPCHK(hipEventRecord(h->ev[h->n_stages], st));
     /* fold this batch's counters into the engine's accumulated stats vector, on the device */

@@ -2026,8 +2026,8 @@ __device__ __forceinline__ uint8_t replay_base(const DBatch &B, const DParams *_
         }
     }
     if (sc_tail) o.v = P->bin2[o.v];
-    if (o.keep) keepf[r] = 1;                              /* same value from every lane: benign */
-    if (o.b15) b15f[r] = 1;
+    if (o.keep && keepf) keepf[r] = 1;                     /* same value from every lane: benign */
+    if (o.b15 && b15f) b15f[r] = 1;
     return o.v & 0x7f;                                     /* snp:1093 */
 }
 
@@ -2173,15 +2173,94 @@ __device__ __forceinline__ unsigned action_of(uint32_t r)
     return a;
 }
 /* four columns per thread: one 16-byte load, one 4-byte store (the arrays start 16-byte aligned) */
-__global__ void k_actions(int L, const uint32_t *__restrict__ colrec, uint8_t *__restrict__ act)
+/* flagbits (may be null; zeroed by the caller): one bit per column = action bit 6, "the column raises a per-read flag":
+ * k_readflags looks only at those columns */
+__global__ void k_actions(int L, const uint32_t *__restrict__ colrec, uint8_t *__restrict__ act, uint32_t *__restrict__ flagbits)
 {
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (c >= L) return;
+    unsigned f = 0;
     if (c + 3 < L) {
         const uint4 r = *(const uint4 *)(colrec + c);
-        *(uint32_t *)(act + c) = action_of(r.x) | (action_of(r.y) << 8) | (action_of(r.z) << 16) | (action_of(r.w) << 24);
+        const unsigned a0 = action_of(r.x), a1 = action_of(r.y), a2 = action_of(r.z), a3 = action_of(r.w);
+        *(uint32_t *)(act + c) = a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
+        f = ((a0 >> 6) & 1u) | (((a1 >> 6) & 1u) << 1) | (((a2 >> 6) & 1u) << 2) | (((a3 >> 6) & 1u) << 3);
     } else
-        for (int i = c; i < L; i++) act[i] = (uint8_t)action_of(colrec[i]);
+        for (int i = c; i < L; i++) { const unsigned a = action_of(colrec[i]); act[i] = (uint8_t)a; f |= ((a >> 6) & 1u) << (i - c); }
+    if (flagbits && f) atomicOr(&flagbits[c >> 5], f << (c & 31));       /* (c is a multiple of four: the bits stay in the word) */
+}
+
+/* bits [a, b) of a zeroed bit array */
+__device__ __forceinline__ void mark_bits(uint32_t *__restrict__ bitsarr, int64_t a, int64_t b)
+{
+    for (int64_t w = a >> 5; w <= (b - 1) >> 5; w++) {
+        const int lo = a > w * 32 ? (int)(a - w * 32) : 0, hi = b < w * 32 + 32 ? (int)(b - w * 32) : 32;
+        const uint32_t m = (hi == 32 ? ~0u : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+        if (m) atomicOr(&bitsarr[w], m);
+    }
+}
+
+/* The per-read flags BEFORE the replay (packed replay; the byte-wise replays raise them on the way, k_readfix):
+ * keep_qual (snp:1847: any column of the read's span sets it -- every column holds an entry of the read, a base, a
+ * deletion or a reference skip) and flag bit 15 (snp:1890: columns whose entry comes after the l_qseq test, i.e. not
+ * the D/N columns behind the last query base, not a read without SEQ).  Only columns with their bit in flagbits are
+ * looked at.  One lane per read. */
+__global__ void k_readflags(DBatch B, const uint32_t *__restrict__ colrec, const uint32_t *__restrict__ flagbits,
+                            uint8_t *__restrict__ rflags, uint32_t *__restrict__ forcebits)
+{   /* a kept read's bytes are marked in forcebits like a back-fill range: the replay pass puts the capped original there
+     * (snp:1939) and needs no flag look-up per read */
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B.n_reads) return;
+    const ReadRec rr = B.rr[r];
+    if (rr.end <= rr.pos) { rflags[r] = 4; return; }
+    const int c0 = rr.pos - B.p0, c1 = rr.end - B.p0;
+    int cb = c1;                                            /* columns [c0, cb) can raise bit 15 */
+    if (rr.lq == 0) cb = c0;
+    else if (!(rr.info & RR_SIMPLE)) {
+        const Seg *segs = B.segs + B.seg_off[r];
+        const int ns = (int)(B.seg_off[r + 1] - B.seg_off[r]);
+        for (int i = ns - 1; i >= 0 && segs[i].qstart >= rr.lq; i--) cb = c0 + segs[i].roff;
+    }
+    int keep = 0, b15 = 0;
+    const int w0 = c0 >> 5, w1 = (c1 - 1) >> 5;
+    if (w1 - w0 < 8) {                                      /* the usual read: does any of its columns raise a flag at all? (independent loads) */
+        uint32_t any = 0;
+        #pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint32_t bits = (w0 + k <= w1) ? flagbits[w0 + k] : 0u;
+            if (k == 0) bits &= ~0u << (c0 & 31);
+            if (w0 + k == w1 && ((c1 - 1) & 31) != 31) bits &= (2u << ((c1 - 1) & 31)) - 1u;
+            any |= bits;
+        }
+        if (!any) { rflags[r] = 0; return; }
+    }
+    for (int w = w0; w <= w1; w++) {
+        uint32_t bits = flagbits[w];
+        if (w == (c0 >> 5)) bits &= ~0u << (c0 & 31);
+        if (w == ((c1 - 1) >> 5) && ((c1 - 1) & 31) != 31) bits &= (2u << ((c1 - 1) & 31)) - 1u;
+        while (bits) {
+            const int c = w * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            const uint32_t rec = colrec[c];
+            if (rec & CR_SKIP) continue;
+            if (rec & CR_KEEP) keep = 1;
+            if (CR_PRESERVE(rec) > 1 && c < cb) b15 = 1;
+        }
+    }
+    rflags[r] = (uint8_t)(keep | (b15 << 1));
+    if (keep && rr.lq > 0) mark_bits(forcebits, rr.so, rr.so + rr.lq);
+}
+
+/* per-workgroup histogram of output qualities in LDS (signed counts: a corrected byte takes one out and puts one in);
+ * flushed into the statistics vector at the end */
+__device__ __forceinline__ void hist_flush(unsigned *h, u64 *stats, unsigned changed_net)
+{
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        const int v = (int)h[i];
+        if (v) atomicAdd(&stats[ST_HIST0 + i], (u64)(long long)v);
+    }
+    if (changed_net) atomicAdd(&stats[ST_BASES_CHANGED], (u64)(long long)(int)changed_net);
 }
 
 #define PB4(x)       ((uint32_t)(x) * 0x01010101u)
@@ -2203,26 +2282,43 @@ __device__ __forceinline__ int64_t rf_read(const VRec &x, int64_t) { return x.re
 template <bool VREC> struct RfSel { typedef ReadRec T; static __device__ __forceinline__ const T *tab(const DBatch &B) { return B.rr; } };
 template <> struct RfSel<true> { typedef VRec T; static __device__ __forceinline__ const T *tab(const DBatch &B) { return B.vr; } };
 
-template <bool VREC, bool PV>
+/* forcebits: the bytes of the kept reads (keep_qual, k_readflags) and the back-fill ranges of the trigger columns
+ * (k_restore's marks) are known BEFORE this pass, so it is the one writer of every byte it owns: the marked bytes are
+ * the capped original (snp:1939, 1875).  STATS: the histogram of the output and the changed count are taken
+ * here, from registers, instead of by a pass of their own over output and input (k_stats: 2 B per base): bytes of
+ * general-CIGAR reads are left to k_replay_reads (short reads), the bases D/N columns report are corrected by
+ * k_replay_slow.  The two values nearly every output byte has (qhigh, qlow) are counted with packed compares and
+ * popcounts into registers; only the other bytes go through LDS atomics.  It is also the pass that looks at every
+ * INPUT quality: a value >= 128 raises *bad_qual.  Persistent: the grid strides over the chunks. */
+template <bool VREC, bool PV, bool STATS>
 __global__ void __launch_bounds__(256)
 k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restrict__ colrec,
               const uint8_t *__restrict__ act, const int32_t *__restrict__ chunk_read,
-              uint8_t *__restrict__ out, uint8_t *__restrict__ keepf, uint8_t *__restrict__ b15f)
+              uint8_t *__restrict__ out, const uint32_t *__restrict__ forcebits,
+              u64 *__restrict__ stats, int *__restrict__ bad_qual)
 {
-    const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
-    if (g0 >= B.n_bases) return;
-    const int64_t gend = (g0 + 16 < B.n_bases) ? g0 + 16 : B.n_bases;
-    const uint4 q4 = *(const uint4 *)(B.quals + g0), b4 = *(const uint4 *)(B.bases + g0);   /* buffers carry slack */
-    const uint32_t qw[4] = {q4.x, q4.y, q4.z, q4.w}, bw[4] = {b4.x, b4.y, b4.z, b4.w};
-    uint32_t ow[4] = {qw[0] & 0x7f7f7f7fu, qw[1] & 0x7f7f7f7fu, qw[2] & 0x7f7f7f7fu, qw[3] & 0x7f7f7f7fu};
+    __shared__ unsigned hist[STATS ? 256 : 1];
+    unsigned cnt_h = 0, cnt_l = 0, cnt_chg = 0, hibits = 0;
+    if (STATS) { for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0; __syncthreads(); }
     const uint32_t QC = PB4(P->qcap), QH = PB4(P->qhigh), QL = PB4(P->qlow), CUT = PB4(P->qcutoff);
     const bool reduce = P->reduce_qual != 0, binary = P->binary_qual != 0;
     const int min_mqual = P->min_mqual, npv = PV ? P->n_pv : 0;
     const int64_t n_owner = VREC ? B.n_vrec : B.n_reads;
-    int64_t r = chunk_read[g0 >> 4];                          /* the owner of byte g0 (table built with the batch) */
     typedef typename RfSel<VREC>::T Rec;
     const Rec *const recs = RfSel<VREC>::tab(B);
+    const int64_t nchunks = (B.n_bases + 15) >> 4;
+    for (int64_t ch = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunks; ch += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t g0 = ch * 16;
+    const int64_t gend = (g0 + 16 < B.n_bases) ? g0 + 16 : B.n_bases;
+    const uint4 q4 = *(const uint4 *)(B.quals + g0), b4 = *(const uint4 *)(B.bases + g0);   /* buffers carry slack */
+    const unsigned fb16 = *(const uint16_t *)((const uint8_t *)forcebits + (g0 >> 3));      /* the chunk's back-fill marks */
+    const uint32_t qw[4] = {q4.x, q4.y, q4.z, q4.w}, bw[4] = {b4.x, b4.y, b4.z, b4.w};
+    if (gend - g0 == 16) hibits |= q4.x | q4.y | q4.z | q4.w;
+    else for (int k = 0; k < (int)(gend - g0); k++) hibits |= qw[k >> 2] & (0xffu << (8 * (k & 3)));     /* (the slack behind the last base is not input) */
+    uint32_t ow[4] = {qw[0] & 0x7f7f7f7fu, qw[1] & 0x7f7f7f7fu, qw[2] & 0x7f7f7f7fu, qw[3] & 0x7f7f7f7fu};
+    int64_t r = chunk_read[g0 >> 4];                          /* the owner of byte g0 (table built with the batch) */
     Rec rr = recs[r];
+    unsigned genb = 0;                                        /* bytes of general-CIGAR reads (k_replay_reads') */
     /* The chunk's bytes belong to one read, or -- at a read boundary, i.e. in some lane of nearly every
      * wave -- to two: up to two reads are gathered into slots and done in ONE pass of the packed body
      * (per-byte merge of their action bytes); only chunks that touch more than two single-match reads
@@ -2231,10 +2327,14 @@ k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
         unsigned vb[2] = {0, 0};
         int c0s[2] = {0, 0};
         uint32_t hms[2] = {0, 0};
-        int64_t rid[2] = {r, r};
         int ns = 0;
         bool more = false;
         for (;;) {
+            if (!VREC && STATS && rr.end > rr.pos && !rf_aligned(rr)) {       /* a general-CIGAR read's bytes: k_replay_reads counts them */
+                const int64_t o0 = rr.so, o1 = rr.so + rr.lq;
+                const int lo = (o0 > g0) ? (int)(o0 - g0) : 0, hi = (o1 < gend) ? (int)(o1 - g0) : (int)(gend - g0);
+                if (lo < hi) genb |= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+            }
             if (rf_aligned(rr)) {
                 /* bytes of this chunk that are aligned bases of this read */
                 const int64_t a0 = rr.so + rr.q0, a1 = a0 + (rr.end - rr.pos);
@@ -2245,8 +2345,8 @@ k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
                     const int c0 = rr.pos + (int)(g0 - a0) - B.p0; /* column of byte 0 (may be < 0: padded) */
                     uint32_t hm = 0;                               /* low-mapq read whose head column is live: snp:1852 */
                     if (rf_headmark(rr, B, min_mqual, colrec)) hm = 0xffffffffu;
-                    if (ns == 0) { vb[0] = m; c0s[0] = c0; hms[0] = hm; rid[0] = rf_read(rr, r); }
-                    else         { vb[1] = m; c0s[1] = c0; hms[1] = hm; rid[1] = rf_read(rr, r); }
+                    if (ns == 0) { vb[0] = m; c0s[0] = c0; hms[0] = hm; }
+                    else         { vb[1] = m; c0s[1] = c0; hms[1] = hm; }
                     ns++;
                 }
             }
@@ -2267,7 +2367,6 @@ k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
             LOAD_ACT16(a, c0s[0]);
             if (ns > 1) LOAD_ACT16(a2, c0s[1]);
             #undef LOAD_ACT16
-            uint32_t se = 0, se2 = 0;
             #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t q = qw[k], b = bw[k];
@@ -2298,40 +2397,82 @@ k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
                 const uint32_t W = ((ac >> 5) & 0x01010101u) * 0xffu;
                 const uint32_t v = ((capq & W) | (~W & ((q & U) | (qz & ~U)))) & 0x7f7f7f7fu;
                 ow[k] = (v & V) | (ow[k] & ~V);
-                se |= ac & V1 & 0x40404040u;
-                se2 |= ac & V2 & 0x40404040u;
-            }
-            if (se | se2) {                                        /* rare: a column raises a per-read flag */
-                for (int s2 = 0; s2 < 2; s2++) {
-                    if (!(s2 ? se2 : se)) continue;
-                    for (int k = 0; k < 16; k++) {
-                        if (!((vb[s2] >> k) & 1)) continue;
-                        const uint32_t rc = colrec[c0s[s2] + k];
-                        if (rc & CR_SKIP) continue;
-                        if (rc & CR_KEEP) keepf[rid[s2]] = 1;
-                        if (CR_PRESERVE(rc) > 1) b15f[rid[s2]] = 1;
-                    }
-                }
             }
         }
         if (!more) break;
     }
+    const unsigned cq = fb16;                                  /* kept read or back-fill: the capped original, whatever the columns said */
+    if (cq) {
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t C = ((((cq >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;
+            if (!C) continue;
+            const uint32_t q = qw[k];
+            uint32_t PV1 = 0;
+            if (PV) for (int i = 0; i < npv; i++) PV1 |= ~PB_NZ(q ^ PB4(P->pv_val[i]));
+            const uint32_t geq = PB_GE(q, QC) & ~PV1;
+            const uint32_t capq = ((QC & geq) | (q & ~geq)) & 0x7f7f7f7fu;
+            ow[k] = (capq & C) | (ow[k] & ~C);
+        }
+    }
     if (gend - g0 == 16) { uint4 o4; o4.x = ow[0]; o4.y = ow[1]; o4.z = ow[2]; o4.w = ow[3]; *(uint4 *)(out + g0) = o4; }
     else for (int k = 0; k < (int)(gend - g0); k++) out[g0 + k] = (uint8_t)((ow[k >> 2] >> (8 * (k & 3))) & 255);
+    if (STATS) {
+        unsigned valid = (gend - g0 == 16) ? 0xffffu : ((1u << (int)(gend - g0)) - 1u);
+        valid &= ~genb;
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t Vm = ((((valid >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u) * 0x80u;       /* bit 7 of the bytes counted here */
+            const uint32_t o = ow[k], q = qw[k] & 0x7f7f7f7fu;
+            const uint32_t eh = ~((o ^ QH) + 0x7f7f7f7fu) & Vm;                                             /* bytes equal to qhigh: (x + 0x7f) has bit 7 clear iff x == 0 */
+            const uint32_t el = ~((o ^ QL) + 0x7f7f7f7fu) & Vm & ~eh;
+            const uint32_t ne = ((o ^ q) + 0x7f7f7f7fu) & Vm;                                               /* bytes that differ from the input */
+            cnt_h += __popc(eh); cnt_l += __popc(el); cnt_chg += __popc(ne);
+            const uint32_t other = Vm & ~eh & ~el;                   /* the rest (original values, bin2 levels): LDS atomics, no loop */
+            if (other & 0x00000080u) atomicAdd(&hist[o & 255u], 1u);
+            if (other & 0x00008000u) atomicAdd(&hist[(o >> 8) & 255u], 1u);
+            if (other & 0x00800000u) atomicAdd(&hist[(o >> 16) & 255u], 1u);
+            if (other & 0x80000000u) atomicAdd(&hist[o >> 24], 1u);
+        }
+    }
+    }
+    if ((hibits & 0x80808080u) && bad_qual) *bad_qual = 1;
+    if (STATS) {
+        /* the three register counters: one LDS add per wave */
+        #pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { cnt_h += __shfl_xor(cnt_h, d); cnt_l += __shfl_xor(cnt_l, d); cnt_chg += __shfl_xor(cnt_chg, d); }
+        __shared__ unsigned chg_all;
+        if (threadIdx.x == 0) chg_all = 0;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) {
+            if (cnt_h) atomicAdd(&hist[P->qhigh & 255], cnt_h);
+            if (cnt_l) atomicAdd(&hist[P->qlow & 255], cnt_l);
+            if (cnt_chg) atomicAdd(&chg_all, cnt_chg);
+        }
+        __syncthreads();
+        hist_flush(hist, stats, threadIdx.x == 0 ? chg_all : 0u);
+    }
 }
 
+/* STATS: this pass is the one writer of the general-CIGAR reads' bytes (k_replay_fast leaves them out of its count) */
+template <bool STATS>
 __global__ void __launch_bounds__(256)
 k_replay_reads(DBatch B, const DParams *__restrict__ P, const uint32_t *__restrict__ colrec,
                const int32_t *__restrict__ gen_list, const int *__restrict__ n_gen,
-               uint8_t *__restrict__ out, uint8_t *__restrict__ keepf, uint8_t *__restrict__ b15f)
+               uint8_t *__restrict__ out, const uint32_t *__restrict__ forcebits,
+               u64 *__restrict__ stats)
 {
     /* one wave per general-CIGAR read of the list the upload made (k_p0_fill; it used to find them by scanning
      * every read record: 0.34 ms on the chr20 set for 3 % of the reads) */
+    __shared__ unsigned hist[STATS ? 256 : 1];
+    unsigned cnt_chg = 0;
+    if (STATS) { for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0; __syncthreads(); }
     const int lane = threadIdx.x & 63;
     const int qcap = P->qcap, qhigh = P->qhigh, qlow = P->qlow;
     const bool reduce = P->reduce_qual != 0, binary = P->binary_qual != 0, any_pres = P->any_preserve != 0;
     const int ng = *n_gen;
-    for (int gi = blockIdx.x; gi < ng; gi += gridDim.x) {
+    const int nw = (int)(gridDim.x * (blockDim.x >> 6));
+    for (int gi = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); gi < ng; gi += nw) {
         const int64_t rs = gen_list[gi];
         const ReadRec rr = B.rr[rs];
         if (!(rr.lq > 0 && rr.end > rr.pos && !(rr.info & RR_SIMPLE))) continue;
@@ -2346,11 +2487,15 @@ k_replay_reads(DBatch B, const DParams *__restrict__ P, const uint32_t *__restri
              * table written at upload: 4 bytes per base of every general read and a kernel of its own.) */
             int c4[4];
             uint32_t q4[4], b4[4], r4[4];
+            bool f4[4];
             #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int x = x0 + 64 * u;
-                c4[u] = -1; q4[u] = 0; b4[u] = 0;
-                if (x < n) { q4[u] = B.quals[s0 + x]; b4[u] = B.bases[s0 + x]; }
+                c4[u] = -1; q4[u] = 0; b4[u] = 0; f4[u] = false;
+                if (x < n) {
+                    q4[u] = B.quals[s0 + x]; b4[u] = B.bases[s0 + x];
+                    f4[u] = ((forcebits[(s0 + x) >> 5] >> ((s0 + x) & 31)) & 1u) != 0;      /* a kept read, or a trigger column's back-fill reaches it */
+                }
             }
             for (int k = 0; k < nsg; k++) {
                 const Seg sg = B.segs[sg0 + k];
@@ -2372,38 +2517,68 @@ k_replay_reads(DBatch B, const DParams *__restrict__ P, const uint32_t *__restri
                 const int x = x0 + 64 * u;
                 if (x >= n) continue;
                 const uint32_t q0 = q4[u];
+                const uint32_t capq = any_pres ? (uint32_t)cap_q2(P, qcap, true, (uint8_t)q0) : (q0 > (uint32_t)qcap ? (uint32_t)qcap : q0);
                 uint32_t v = q0;
                 if (c4[u] >= 0) {
                     const uint32_t rcd = r4[u];
                     const bool skip = (rcd & CR_SKIP) != 0;
                     const int pres = CR_PRESERVE(rcd), base = (int)(b4[u] & 15);
                     const bool match = base == (1 << CR_A1(rcd)) || base == (1 << CR_A2(rcd));
-                    const uint32_t capq = any_pres ? (uint32_t)cap_q2(P, qcap, true, (uint8_t)q0) : (q0 > (uint32_t)qcap ? (uint32_t)qcap : q0);
                     const uint32_t qz = match ? (uint32_t)qhigh : (reduce ? (binary ? (uint32_t)P->bin2[q0] : (uint32_t)qlow) : q0);
                     bool keepv = hms || skip || pres;
                     if (any_pres) keepv = keepv || P->preserve_qual[q0 & 0x7f] >= 1 + ((rcd & CR_PERFECT) ? 1 : 0);   /* snp:1885 */
                     v = (!skip && (rcd & CR_WIN)) ? capq : (keepv ? q0 : qz);
-                    if (!skip && (rcd & CR_KEEP)) keepf[rs] = 1;
-                    if (!skip && pres > 1) b15f[rs] = 1;
                 }
-                out[s0 + x] = (uint8_t)(v & 0x7f);
+                if (f4[u]) v = capq;
+                v &= 0x7f;
+                out[s0 + x] = (uint8_t)v;
+                if (STATS) { atomicAdd(&hist[v], 1u); cnt_chg += (v != (q0 & 0x7fu)) ? 1u : 0u; }
             }
         }
+    }
+    if (STATS) {
+        #pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cnt_chg += __shfl_xor(cnt_chg, d);
+        __shared__ unsigned chg_all;
+        if (threadIdx.x == 0) chg_all = 0;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0 && cnt_chg) atomicAdd(&chg_all, cnt_chg);
+        __syncthreads();
+        hist_flush(hist, stats, threadIdx.x == 0 ? chg_all : 0u);
     }
 }
 #undef PB4
 #undef PB_GE
 #undef PB_NZ
 
-/* the bases that D/N columns report (list built with the batch), after the chunk kernels */
+/* the bases that D/N columns report (list built with the batch), after the chunk kernels.  forcebits (packed replay):
+ * a kept read's byte and a back-fill's are the capped original whatever the columns say; STATS: the byte was
+ * counted with the value the pass before left -- one out, one in. */
+template <bool STATS>
 __global__ void k_replay_slow(DBatch B, const DParams *__restrict__ P, const uint32_t *__restrict__ colrec,
                               const int32_t *__restrict__ pos_mn2, const int *__restrict__ n_slow, const int64_t *__restrict__ slow_g,
                               const int32_t *__restrict__ slow_r, uint8_t *__restrict__ out,
-                              uint8_t *__restrict__ keepf, uint8_t *__restrict__ b15f)
+                              uint8_t *__restrict__ keepf, uint8_t *__restrict__ b15f,
+                              const uint32_t *__restrict__ forcebits, u64 *__restrict__ stats)
 {
+    __shared__ unsigned hist[STATS ? 256 : 1];
+    __shared__ unsigned chg_all;
+    if (STATS) { for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0; if (threadIdx.x == 0) chg_all = 0; __syncthreads(); }
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= *n_slow) return;
-    out[slow_g[t]] = replay_base(B, P, colrec, pos_mn2, slow_g[t], slow_r[t], keepf, b15f);
+    if (t < *n_slow) {
+        const int64_t g = slow_g[t];
+        uint8_t v = replay_base(B, P, colrec, pos_mn2, g, slow_r[t], keepf, b15f);
+        if (forcebits && ((forcebits[g >> 5] >> (g & 31)) & 1u)) v = cap_q2(P, P->qcap, P->any_preserve != 0, B.quals[g]) & 0x7f;
+        if (STATS) {
+            const unsigned old = out[g], qin = B.quals[g] & 0x7fu;
+            if (old != v) {
+                atomicAdd(&hist[old], 0xffffffffu); atomicAdd(&hist[v], 1u);
+                atomicAdd(&chg_all, (unsigned)((v != qin) ? 1 : 0) - (unsigned)((old != qin) ? 1 : 0));
+            }
+        }
+        out[g] = v;
+    }
+    if (STATS) { __syncthreads(); hist_flush(hist, stats, threadIdx.x == 0 ? chg_all : 0u); }
 }
 
 /* every base through the general routine (used when -S is on) */
@@ -2422,8 +2597,10 @@ __global__ void k_replay_general(DBatch B, const DParams *__restrict__ P, const 
  * the entry's own qpos (the entry's own byte is handled by apply_col). */
 __global__ void __launch_bounds__(64)
 k_restore(DBatch B, const DParams *__restrict__ P, int n_trig_, const int *n_dev, const int *spec_abort, const int32_t *trigcol_pos,
-          const int32_t *__restrict__ pos_mn2, const int32_t *__restrict__ trig_mx2, uint8_t *__restrict__ out, int coop)
-{
+          const int32_t *__restrict__ pos_mn2, const int32_t *__restrict__ trig_mx2, uint8_t *__restrict__ out, int coop,
+          uint32_t *__restrict__ forcebits)
+{   /* forcebits (packed replay; zeroed by the caller): the ranges are MARKED, one bit per base, and the replay pass --
+     * the one writer of every byte then -- puts the capped original there; otherwise they are written here */
     if (LIST_ABORTED(spec_abort)) return;
     const int n_trig = LIST_N(n_trig_, n_dev);
     /* one wave per trigger column.  Step 1: every lane resolves one candidate read (entry, start of
@@ -2503,6 +2680,11 @@ k_restore(DBatch B, const DParams *__restrict__ P, int n_trig_, const int *n_dev
                     }
                 }
             }
+        }
+        if (forcebits) {
+            const int64_t so = (int64_t)(((uint64_t)so_hi << 32) | so_lo);
+            if (start < stop) mark_bits(forcebits, so + start, so + stop);
+            continue;
         }
         if (!coop) {                                       /* long reads: few candidates per column, a lane each */
             const int64_t so = (int64_t)(((uint64_t)so_hi << 32) | so_lo);
@@ -3513,6 +3695,12 @@ k_stats(int64_t b_lo, int64_t b_hi, int64_t n_reads, const uint8_t *out, const u
             atomicAdd(&stats[ST_BASES], (u64)bases_total);
         }
     }
+}
+
+/* reads / bases of a batch whose histogram the replay kernels took */
+__global__ void k_stats_totals(int64_t n_reads, int64_t n_bases, u64 *stats)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) { atomicAdd(&stats[ST_READS], (u64)n_reads); atomicAdd(&stats[ST_BASES], (u64)n_bases); }
 }
 
 /* this batch's counters into the engine's accumulated vector (what the multi-GPU all-reduce sums) */
