@@ -20,6 +20,7 @@
 #include <zlib.h>
 #include <omp.h>
 #include <sys/mman.h>
+#include <pthread.h>
 #include "../../include/crumble_bamio.h"
 
 static char g_err[512];          /* process-wide: the record scan may run on any thread of the team */
@@ -42,6 +43,43 @@ int crumble_bam_timing(char *buf, size_t len)
     return snprintf(buf, len, "bamio: fread %.3f inflate %.3f record-scan %.3f prefix %.3f unpack %.3f | scatter %.3f deflate %.3f fwrite %.3f s",
                     T_fread, T_inflate, T_scan, T_prefix, T_unpack, T_scatter, T_deflate, T_fwrite);
 }
+
+/* ---- libdeflate, when the host has it (resolved at run time like htslib below; zlib otherwise) ----------------
+ * BGZF blocks are whole raw-deflate streams of known size: exactly libdeflate's one-shot interface, two to three times
+ * zlib's speed in both directions, and its crc32 uses the carry-less multiply.  Only entry points whose signatures
+ * have not changed since libdeflate 1.0 are used; the prototypes are declared here, as the htslib backend declares its
+ * own.  CRUMBLE_BAM_ZLIB=1 keeps zlib (the tests run both). */
+#include <dlfcn.h>
+static struct {
+    void *lib;
+    void *(*alloc_decompressor)(void);
+    int (*deflate_decompress)(void *, const void *, size_t, void *, size_t, size_t *);
+    void (*free_decompressor)(void *);
+    void *(*alloc_compressor)(int);
+    size_t (*deflate_compress)(void *, const void *, size_t, void *, size_t);
+    void (*free_compressor)(void *);
+    uint32_t (*crc32)(uint32_t, const void *, size_t);
+    int ok;
+} LD;
+static pthread_once_t ld_once = PTHREAD_ONCE_INIT;
+static void ld_load(void)
+{
+    const char *z = getenv("CRUMBLE_BAM_ZLIB");
+    if (z && *z && *z != '0') return;
+    LD.lib = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+    if (!LD.lib) LD.lib = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+    if (!LD.lib) return;
+#define LDSYM(field, name) do { *(void **)&LD.field = dlsym(LD.lib, name); if (!LD.field) return; } while (0)
+    LDSYM(alloc_decompressor, "libdeflate_alloc_decompressor"); LDSYM(deflate_decompress, "libdeflate_deflate_decompress");
+    LDSYM(free_decompressor, "libdeflate_free_decompressor"); LDSYM(alloc_compressor, "libdeflate_alloc_compressor");
+    LDSYM(deflate_compress, "libdeflate_deflate_compress"); LDSYM(free_compressor, "libdeflate_free_compressor");
+    LDSYM(crc32, "libdeflate_crc32");
+#undef LDSYM
+    LD.ok = 1;
+}
+static int ld_ready(void) { pthread_once(&ld_once, ld_load); return LD.ok; }
+/* "libdeflate" or "zlib": what inflates and deflates the BGZF blocks of this process */
+const char *crumble_bam_codec(void) { return ld_ready() ? "libdeflate" : "zlib"; }
 
 static inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
 static inline uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | p[1] << 8); }
@@ -236,10 +274,12 @@ static int refill(crumble_bam_reader *r, int side)
         uint8_t *dst = r->raw + r->raw_len;
         int bad = 0;
         const double ti = now_s();
+        const int use_ld = ld_ready();
         #pragma omp parallel num_threads(r->threads) reduction(|:bad)
         {
             z_stream zs; memset(&zs, 0, sizeof zs);            /* one inflate state per thread, reset per block */
-            const int zok = inflateInit2(&zs, -15) == Z_OK;
+            void *ldd = use_ld ? LD.alloc_decompressor() : NULL;
+            const int zok = ldd ? 1 : inflateInit2(&zs, -15) == Z_OK;
             if (side) {
                 /* the sequential walk over the records inflated so far costs about as much as one
                  * round of inflate: one thread does it while the others start on the blocks */
@@ -249,6 +289,13 @@ static int refill(crumble_bam_reader *r, int side)
             #pragma omp for schedule(dynamic, 4)
             for (size_t i = 0; i < nb; i++) {
                 if (blk[i].ulen == 0) continue;
+                if (ldd) {
+                    size_t got = 0;
+                    if (LD.deflate_decompress(ldd, r->cbuf + blk[i].coff, blk[i].clen, dst + blk[i].uoff, blk[i].ulen, &got) != 0 ||
+                        got != blk[i].ulen) bad |= 2;
+                    if (LD.crc32(0, dst + blk[i].uoff, blk[i].ulen) != blk[i].crc) bad |= 4;
+                    continue;
+                }
                 if (!zok || inflateReset(&zs) != Z_OK) { bad |= 1; continue; }
                 zs.next_in = r->cbuf + blk[i].coff; zs.avail_in = (uInt)blk[i].clen;
                 zs.next_out = dst + blk[i].uoff;    zs.avail_out = (uInt)blk[i].ulen;
@@ -256,7 +303,8 @@ static int refill(crumble_bam_reader *r, int side)
                 if (zr != Z_STREAM_END || zs.avail_out != 0) bad |= 2;
                 if (crc32(crc32(0L, Z_NULL, 0), dst + blk[i].uoff, (uInt)blk[i].ulen) != blk[i].crc) bad |= 4;
             }
-            if (zok) inflateEnd(&zs);
+            if (ldd) LD.free_decompressor(ldd);
+            else if (zok) inflateEnd(&zs);
         }
         free(blk);
         T_inflate += now_s() - ti;
@@ -583,27 +631,35 @@ static int bgzf_write(crumble_bam_writer *w, const uint8_t *data, size_t len)
         const size_t nb = nblk - b0 < BATCH ? nblk - b0 : BATCH;
         int bad = 0;
         const double td = now_s();
+        const int use_ld = ld_ready();
         #pragma omp parallel num_threads(w->threads) reduction(|:bad)
         {
             z_stream zs; memset(&zs, 0, sizeof zs);            /* one deflate state per thread, reset per block */
-            const int zok = deflateInit2(&zs, w->level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK;
+            /* (zlib level 0 = stored blocks: libdeflate's level 0 is the same; the levels above it mean about the same effort) */
+            void *ldc = use_ld ? LD.alloc_compressor(w->level < 0 ? 6 : w->level > 12 ? 12 : w->level) : NULL;
+            int zok = 0;
             #pragma omp for schedule(dynamic, 4)
             for (size_t i = 0; i < nb; i++) {
                 const size_t off = (b0 + i) * BLK_IN, ul = len - off < BLK_IN ? len - off : BLK_IN;
                 uint8_t *o = w->obuf + i * SLOT;
                 osz[i] = 0;
-                if (!zok || deflateReset(&zs) != Z_OK) { bad = 1; continue; }
-                zs.next_in = (Bytef *)(data + off); zs.avail_in = (uInt)ul;
-                zs.next_out = o + 18; zs.avail_out = (uInt)(SLOT - 18 - 8);
-                if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { bad = 1; continue; }
-                const size_t cl = zs.total_out;
+                size_t cl = ldc ? LD.deflate_compress(ldc, data + off, ul, o + 18, SLOT - 18 - 8) : 0;
+                if (!cl) {                                      /* zlib (no libdeflate, or the one block it could not fit) */
+                    if (!zok) { if (deflateInit2(&zs, w->level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = 1; continue; } zok = 1; }
+                    if (deflateReset(&zs) != Z_OK) { bad = 1; continue; }
+                    zs.next_in = (Bytef *)(data + off); zs.avail_in = (uInt)ul;
+                    zs.next_out = o + 18; zs.avail_out = (uInt)(SLOT - 18 - 8);
+                    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { bad = 1; continue; }
+                    cl = zs.total_out;
+                }
                 static const uint8_t hdr[16] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0 };
                 memcpy(o, hdr, 16);
                 put16(o + 16, (uint16_t)(18 + cl + 8 - 1));
-                put32(o + 18 + cl, (uint32_t)crc32(crc32(0L, Z_NULL, 0), data + off, (uInt)ul));
+                put32(o + 18 + cl, ldc ? LD.crc32(0, data + off, ul) : (uint32_t)crc32(crc32(0L, Z_NULL, 0), data + off, (uInt)ul));
                 put32(o + 18 + cl + 4, (uint32_t)ul);
                 osz[i] = 18 + cl + 8;
             }
+            if (ldc) LD.free_compressor(ldc);
             if (zok) deflateEnd(&zs);
         }
         T_deflate += now_s() - td;

@@ -115,6 +115,9 @@ void  crumble_bam_big_free(void *p, size_t n);
 
 /* Where the host time went so far (process-wide phase timers), as one line of text. */
 int crumble_bam_timing(char *buf, size_t len);
+/* "libdeflate" (found on the host at run time) or "zlib": what inflates / deflates BGZF blocks in this process;
+ * CRUMBLE_BAM_ZLIB=1 in the environment keeps zlib */
+const char *crumble_bam_codec(void);
 
 const char *crumble_bam_last_error(void);
 

@@ -119,6 +119,54 @@ def test_write_batches_then_read_back(tmp_path):
         batches_equal(a, b)
 
 
+def test_both_codecs_cross_read(tmp_path):
+    """BGZF blocks go through libdeflate when the host has it (dlopen) and through zlib otherwise (CRUMBLE_BAM_ZLIB=1
+    forces it): a file written by either is valid gzip (Python's decoder checks every member's CRC32 and ISIZE) and is
+    read back identically by the other.  The codec is a process-wide choice, so each side is its own process."""
+    import subprocess
+    import sys
+    code = '''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import ctypes as C
+from crumble_amd import bamio
+import synth
+L = bamio.lib(); L.crumble_bam_codec.restype = C.c_char_p
+mode, path, want = sys.argv[1], sys.argv[2], sys.argv[3]
+assert L.crumble_bam_codec().decode() == want, L.crumble_bam_codec()
+b0 = synth.generate(synth.config("ce", scale=0.5))
+if mode == "write":
+    bamio.write_batches(path, [("chrI", 60000)], [b0], level=int(sys.argv[4]))
+else:
+    got = list(bamio.Reader(path, threads=3))
+    assert len(got) == 1
+    for nm in ("pos", "mapq", "flag", "seq_off", "cig_off", "cigar", "bases", "quals"):
+        assert np.array_equal(getattr(got[0], nm), getattr(b0, nm)), nm
+print("ok")
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    def run(env_zlib, *args):
+        env = dict(os.environ)
+        env.pop("CRUMBLE_BAM_ZLIB", None)
+        if env_zlib:
+            env["CRUMBLE_BAM_ZLIB"] = "1"
+        r = subprocess.run([sys.executable, "-c", code, *args], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-800:]
+    have_ld = bamio.lib().crumble_bam_codec is not None
+    import ctypes as C
+    bamio.lib().crumble_bam_codec.restype = C.c_char_p
+    here = bamio.lib().crumble_bam_codec().decode()
+    run(True, "write", str(tmp_path / "z.bam"), "zlib", "1")
+    walk_bam(tmp_path / "z.bam")
+    run(True, "read", str(tmp_path / "z.bam"), "zlib")
+    if here == "libdeflate" or "CRUMBLE_BAM_ZLIB" in os.environ:
+        for lvl in ("0", "1", "6"):
+            run(False, "write", str(tmp_path / f"d{lvl}.bam"), "libdeflate", lvl)
+            walk_bam(tmp_path / f"d{lvl}.bam")                    # an independent inflate + CRC check of every block
+            run(True, "read", str(tmp_path / f"d{lvl}.bam"), "zlib")
+            run(False, "read", str(tmp_path / f"d{lvl}.bam"), "libdeflate")
+        run(False, "read", str(tmp_path / "z.bam"), "libdeflate")
+
+
 def test_reader_against_python_encoder(tmp_path):
     rng = np.random.default_rng(11)
     refs = [("a", 5000), ("b", 9000), ("c", 100)]
