@@ -324,7 +324,27 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=3)
     t_gen = time.time() - t0
     params = ca.preset_params(preset)
     engines = [ca.Engine(params, device) for _ in range(n_engines)]
-    outs = [None] * len(batches)
+    # what crosses PCIe lives in page-locked host memory (crumble_hip_host_alloc), as a host that keeps its buffers would
+    # hold it: the batches' arrays (copied there once, before the clock) and one output buffer pair per engine
+    pins = []
+
+    def pin(a):
+        b, p_ = ca.pinned_array(len(a), a.dtype)
+        b[:] = a
+        pins.append(p_)
+        return b
+    originals = []
+    for b_ in batches:
+        originals.append((b_.quals, b_.bases))
+        for nm in ("pos", "mapq", "flag", "seq_off", "cig_off", "cigar", "quals"):
+            setattr(b_, nm, pin(getattr(b_, nm)))
+        if getattr(b_, "bases4", None) is not None:
+            b_.bases4 = pin(b_.bases4)
+    max_nb, max_n = max(b_.n_bases for b_ in batches), max(b_.n_reads for b_ in batches)
+    out_bufs = {id(e): (pin(np.zeros(max(1, max_nb), np.uint8)), pin(np.zeros(max(1, max_n), np.uint8))) for e in engines}
+    k_small = int(np.argmin([b_.n_bases for b_ in batches]))
+    kept = {}
+    lens_ok = [False] * len(batches)
     try:
         def one_pass(keep):
             free_q, run_q, dl_q = queue.Queue(), queue.Queue(), queue.Queue()
@@ -361,9 +381,11 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=3)
                         it = dl_q.get()
                         if it is None:
                             break
-                        t = time.perf_counter(); q, f, _ = it[1].download(want_stats=False); t_stage[2] += time.perf_counter() - t
+                        t = time.perf_counter(); q, f, _ = it[1].download(want_stats=False, out=out_bufs[id(it[1])]); t_stage[2] += time.perf_counter() - t
                         if keep:
-                            outs[it[0]] = (q, f)
+                            lens_ok[it[0]] = len(q) == batches[it[0]].n_bases
+                            if it[0] == k_small:
+                                kept["q"], kept["f"] = q.copy(), f.copy()
                         free_q.put(it[1])
                 except Exception as ex:            # noqa: BLE001
                     err.append(ex)
@@ -382,10 +404,8 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=3)
         total = sum(b.n_bases for b in batches)
         # the smallest contig's bytes and flags against the oracle (bounded CPU time), everything else by properties
         import oracle_lib as O
-        k = int(np.argmin([b.n_bases for b in batches]))
-        wq, wf, _ = O.contig(params, batches[k])
-        ok = bool(np.array_equal(outs[k][0], wq) and np.array_equal(outs[k][1], wf))
-        ok = ok and all(o is not None and len(o[0]) == b.n_bases for o, b in zip(outs, batches))
+        wq, wf, _ = O.contig(params, batches[k_small])
+        ok = bool(np.array_equal(kept["q"], wq) and np.array_equal(kept["f"], wf)) and all(lens_ok)
         return {
             "workload": f"wgs-30x: 24 synthetic contigs (GRCh38 lengths x {scale}), {total} bases, -{preset}, streamed through "
                         f"{n_engines} engines on one GPU (upload || kernels || download)",
@@ -393,11 +413,13 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=3)
             "stages_ms": {"h2d_and_p0": round(st[0] * 1e3, 2), "kernels": round(st[1] * 1e3, 2), "d2h": round(st[2] * 1e3, 2)},
             "overlap_wall_over_sum_of_stages": round(wall / max(1e-9, sum(st)), 3),
             "verified_smallest_contig": ok, "gen_s": round(t_gen, 1),
-            "note": "host buffers are pageable numpy memory; this is a PCIe-inclusive rate and never `value`",
+            "note": "batches and output buffers in page-locked host memory (crumble_hip_host_alloc); a PCIe-inclusive rate, never `value`",
         }
     finally:
         for e in engines:
             e.close()
+        for p_ in pins:
+            ca.pinned_free(p_)
 
 
 def main():
@@ -576,22 +598,32 @@ def main():
             # vector) over a communicator built from an id that rank 0 hands round.  Should the communicator fail to
             # come up on some box, the same sum goes through torch.distributed (RCCL as well) instead of losing the run.
             import ctypes as C
-            ok = 1
+            ok, comm, rccl = 1, None, None
+
+            class UniqueId(C.Structure):
+                _fields_ = [("internal", C.c_char * 128)]
+            uid = UniqueId()
             try:
-                class UniqueId(C.Structure):
-                    _fields_ = [("internal", C.c_char * 128)]
                 rccl = C.CDLL("librccl.so")
-                uid = UniqueId()
-                if rank == 0:
-                    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
-                box = [bytes(uid.internal) if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                C.memmove(C.byref(uid), box[0], 128)
-                comm = C.c_void_p()
-                rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-                ok = 1 if rccl.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0 else 0
+                if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+                    ok = 0
             except Exception:                       # noqa: BLE001
                 ok = 0
+            # rank 0 ALWAYS broadcasts (the id, or None when it has none): no rank is left waiting in the broadcast
+            box = [bytes(uid.internal) if (rank == 0 and ok) else None]
+            dist.broadcast_object_list(box, src=0)
+            if box[0] is None:
+                ok = 0
+            if ok:
+                try:
+                    C.memmove(C.byref(uid), box[0], 128)
+                    comm = C.c_void_p()
+                    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+                    ok = 1 if rccl.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0 else 0
+                    if not ok:
+                        comm = None
+                except Exception:                   # noqa: BLE001
+                    ok, comm = 0, None
             allok = torch.tensor([ok], dtype=torch.int32, device=red_dev)
             dist.all_reduce(allok, op=dist.ReduceOp.MIN)            # every rank takes the same path
             if int(allok.item()) == 1:
@@ -600,8 +632,6 @@ def main():
                 # collective is issued and is the same on every rank: agree on it, then take the other path)
                 allok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=red_dev)
                 dist.all_reduce(allok, op=dist.ReduceOp.MIN)
-                rccl.ncclCommDestroy.argtypes = [C.c_void_p]
-                rccl.ncclCommDestroy(comm)
                 if int(allok.item()) == 1:
                     stats = eng.stats_read()
                     stats_via = "crumble_hip_stats_allreduce (RCCL)"
@@ -609,6 +639,9 @@ def main():
                 elif rank == 0:
                     print("bench: crumble_hip_stats_allreduce refused (%s); statistics summed by torch.distributed"
                           % eng.L.crumble_hip_last_error().decode(), file=sys.stderr)
+            if comm is not None and rccl is not None:           # (also on the ranks whose communicator came up while another's did not)
+                rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+                rccl.ncclCommDestroy(comm)
         if not done:
             st = torch.from_numpy(stats.copy()).to(red_dev)
             dist.all_reduce(st, op=dist.ReduceOp.SUM)

@@ -9,4 +9,4 @@ from .capi import (Params, Batch, Column, HostBatch, COLUMN_DTYPE, ST_N, ST_HIST
                    ST_NAMES, RF_KEEP, RF_NOPBLOCK, RF_PASSTHRU, stats_dict, parse_cigar)
 from . import shard
 from .engine import (lib, load_library, build_library, default_params, preset_params,
-                     Engine, CrumbleError, LIB_PATH)
+                     Engine, CrumbleError, LIB_PATH, pinned_array, pinned_free)

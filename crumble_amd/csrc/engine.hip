@@ -108,6 +108,7 @@ struct crumble_hip {
     /* download staging (staged_d2h): DL_LANES host threads, each with its own stream and two page-locked buffers */
     struct DlLane { void *buf[2] = {nullptr, nullptr}; hipStream_t st = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; } dl[8];
     bool dl_ok = false;
+    size_t dl_bufsz = 0;            /* size of each staging buffer */
     size_t dl_chunk = (size_t)8 << 20;
     bool packed_ok = false;         /* the packed replay's value formulas hold for these parameters (set at create) */
     bool have_vrec = false;         /* long-read batch: territories + chunk table built (k_p0_vrecs) */
@@ -1109,7 +1110,8 @@ extern "C" int crumble_hip_run_finish(crumble_hip *h)
             uint8_t *rfl = h->d_rflags.as<uint8_t>();
             HIPCHK(hipMemsetAsync(flagbits, 0, (nfw + nbw) * 4, st));
             if (L > 0) CRUMBLE_LAUNCH_INDEP(k_actions, nblk((L + 3) / 4, 256), 256, st, L, colrec, act, flagbits);
-            CRUMBLE_LAUNCH_INDEP(k_readflags, nblk(n, 256), 256, st, B, colrec, flagbits, rfl, forcebits);
+            if (multi) CRUMBLE_LAUNCH(k_readflags_wave, nblk(n, 4), 256, st, B, colrec, flagbits, rfl, forcebits);
+            else       CRUMBLE_LAUNCH_INDEP(k_readflags, nblk(n, 256), 256, st, B, colrec, flagbits, rfl, forcebits);
             if (L > 0 && n_trig > 0) {
                 const int coop = multi ? 0 : 1;                 /* (long reads: eight columns per wave) */
                 unsigned g = (unsigned)(coop ? n_trig : (n_trig + 7) / 8);
@@ -1256,15 +1258,37 @@ static int staged_d2h(crumble_hip *h, uint8_t *dst, const uint8_t *src, size_t b
 {
     const size_t CH = h->dl_chunk;
     if (bytes < 4 * CH) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return CRUMBLE_OK; }
-    if (!h->dl_ok) {
-        for (auto &l : h->dl) {
-            if (!l.st) HIPCHK(hipStreamCreate(&l.st));
-            for (int i = 0; i < 2; i++) {
-                if (!l.buf[i] && hipHostMalloc(&l.buf[i], DL_CHUNK, 0) != hipSuccess) { l.buf[i] = nullptr; g_last_error = "hipHostMalloc failed"; return CRUMBLE_ENOMEM; }
-                if (!l.ev[i]) HIPCHK(hipEventCreate(&l.ev[i]));
-            }
+#ifndef CRUMBLE_EMU
+    {   /* a destination that is page-locked already (crumble_hip_host_alloc, hipHostRegister) needs no staging */
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, dst) == hipSuccess && at.type == hipMemoryTypeHost) {
+            HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+            return CRUMBLE_OK;
         }
-        h->dl_ok = true;
+        (void)hipGetLastError();                        /* (an ordinary pointer: the query's error is not ours) */
+    }
+#endif
+    if (!h->dl_ok || h->dl_bufsz < CH) {
+        /* two page-locked buffers of ONE chunk per lane (16 buffers of the configured chunk size, not of the largest one);
+         * should the page-locked memory not be there, what was taken is given back and the copy goes the plain way */
+        bool ok = true;
+        for (auto &l : h->dl) {
+            if (!l.st && hipStreamCreate(&l.st) != hipSuccess) { l.st = nullptr; ok = false; break; }
+            for (int i = 0; i < 2 && ok; i++) {
+                if (l.buf[i] && h->dl_bufsz < CH) { (void)hipHostFree(l.buf[i]); l.buf[i] = nullptr; }
+                if (!l.buf[i] && hipHostMalloc(&l.buf[i], CH, 0) != hipSuccess) { l.buf[i] = nullptr; ok = false; }
+                if (ok && !l.ev[i] && hipEventCreate(&l.ev[i]) != hipSuccess) { l.ev[i] = nullptr; ok = false; }
+            }
+            if (!ok) break;
+        }
+        if (!ok) {
+            for (auto &l : h->dl) for (int i = 0; i < 2; i++) if (l.buf[i]) { (void)hipHostFree(l.buf[i]); l.buf[i] = nullptr; }
+            h->dl_ok = false; h->dl_bufsz = 0;
+            (void)hipGetLastError();
+            HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+            return CRUMBLE_OK;
+        }
+        h->dl_ok = true; h->dl_bufsz = CH;
     }
     std::atomic<int> failed(0);
     auto lane = [&](int t) {
@@ -1287,9 +1311,16 @@ static int staged_d2h(crumble_hip *h, uint8_t *dst, const uint8_t *src, size_t b
         (void)hipStreamSynchronize(l.st);
     };
     std::thread th[DL_LANES];
-    for (int t = 1; t < DL_LANES; t++) th[t] = std::thread(lane, t);
+    int started = 1;
+    try { for (int t = 1; t < DL_LANES; t++) { th[t] = std::thread(lane, t); started = t + 1; } }
+    catch (...) { failed = 2; }                         /* (no thread to be had: the slices nobody took are copied below) */
     lane(0);
-    for (int t = 1; t < DL_LANES; t++) th[t].join();
+    for (int t = 1; t < started; t++) th[t].join();
+    if (failed == 2) {
+        g_last_error = "staged device -> host copy: could not start a host thread";
+        HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+        return CRUMBLE_OK;
+    }
     if (failed) { g_last_error = "staged device -> host copy failed"; return CRUMBLE_EHIP; }
     return CRUMBLE_OK;
 }
@@ -1352,6 +1383,14 @@ extern "C" int crumble_hip_upload_times(crumble_hip *h, float *h2d_ms, float *p0
     return CRUMBLE_OK;
 }
 
+extern "C" void *crumble_hip_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, 0) != hipSuccess) { g_last_error = "hipHostMalloc failed"; return nullptr; }
+    return p;
+}
+extern "C" void crumble_hip_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
 /* ------------------------------------------------------------------ stats */
 extern "C" void *crumble_hip_stats_devptr(crumble_hip *h) { return h ? h->d_stats.p : nullptr; }
 extern "C" int crumble_hip_stats_reset(crumble_hip *h)
@@ -1381,27 +1420,31 @@ struct RcclApi {
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
     bool ok = false;
 };
+static bool rccl_load(RcclApi &api);
 static const RcclApi *rccl_api()
 {
+    /* (a function-local static: initialised once, by whichever thread comes first; the others wait) */
     static RcclApi api;
-    static bool tried = false;
-    if (tried) return api.ok ? &api : nullptr;
-    tried = true;
+    static const bool ok = rccl_load(api);
+    return ok ? &api : nullptr;
+}
+static bool rccl_load(RcclApi &api)
+{
     void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) { g_last_error = "librccl.so not found"; return nullptr; }
+    if (!lib) { g_last_error = "librccl.so not found"; return false; }
     auto get_version = (decltype(&ncclGetVersion))dlsym(lib, "ncclGetVersion");
     int v = 0;
     if (!get_version || get_version(&v) != ncclSuccess || v / 10000 != NCCL_VERSION_CODE / 10000) {
         g_last_error = "librccl.so: version " + std::to_string(v) + " does not match the build's rccl.h (" + std::to_string(NCCL_VERSION_CODE) + ")";
-        return nullptr;
+        return false;
     }
     api.all_reduce = (decltype(&ncclAllReduce))dlsym(lib, "ncclAllReduce");
     api.comm_init_all = (decltype(&ncclCommInitAll))dlsym(lib, "ncclCommInitAll");
     api.comm_destroy = (decltype(&ncclCommDestroy))dlsym(lib, "ncclCommDestroy");
-    if (!api.all_reduce || !api.comm_init_all || !api.comm_destroy) { g_last_error = "librccl.so: entry points missing"; return nullptr; }
+    if (!api.all_reduce || !api.comm_init_all || !api.comm_destroy) { g_last_error = "librccl.so: entry points missing"; return false; }
     api.ok = true;
-    return &api;
+    return true;
 }
 #endif
 

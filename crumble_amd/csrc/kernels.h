@@ -2191,6 +2191,14 @@ __global__ void k_actions(int L, const uint32_t *__restrict__ colrec, uint8_t *_
 }
 
 /* bits [a, b) of a zeroed bit array */
+#define RF_TRAILING_CB() \
+    int cb = c1;                                            /* columns [c0, cb) can raise bit 15 */ \
+    if (rr.lq == 0) cb = c0; \
+    else if (!(rr.info & RR_SIMPLE)) { \
+        const Seg *segs = B.segs + B.seg_off[r]; \
+        const int ns = (int)(B.seg_off[r + 1] - B.seg_off[r]); \
+        for (int i = ns - 1; i >= 0 && segs[i].qstart >= rr.lq; i--) cb = c0 + segs[i].roff; \
+    }
 __device__ __forceinline__ void mark_bits(uint32_t *__restrict__ bitsarr, int64_t a, int64_t b)
 {
     for (int64_t w = a >> 5; w <= (b - 1) >> 5; w++) {
@@ -2214,13 +2222,7 @@ __global__ void k_readflags(DBatch B, const uint32_t *__restrict__ colrec, const
     const ReadRec rr = B.rr[r];
     if (rr.end <= rr.pos) { rflags[r] = 4; return; }
     const int c0 = rr.pos - B.p0, c1 = rr.end - B.p0;
-    int cb = c1;                                            /* columns [c0, cb) can raise bit 15 */
-    if (rr.lq == 0) cb = c0;
-    else if (!(rr.info & RR_SIMPLE)) {
-        const Seg *segs = B.segs + B.seg_off[r];
-        const int ns = (int)(B.seg_off[r + 1] - B.seg_off[r]);
-        for (int i = ns - 1; i >= 0 && segs[i].qstart >= rr.lq; i--) cb = c0 + segs[i].roff;
-    }
+    RF_TRAILING_CB();
     int keep = 0, b15 = 0;
     const int w0 = c0 >> 5, w1 = (c1 - 1) >> 5;
     if (w1 - w0 < 8) {                                      /* the usual read: does any of its columns raise a flag at all? (independent loads) */
@@ -2249,6 +2251,44 @@ __global__ void k_readflags(DBatch B, const uint32_t *__restrict__ colrec, const
     }
     rflags[r] = (uint8_t)(keep | (b15 << 1));
     if (keep && rr.lq > 0) mark_bits(forcebits, rr.so, rr.so + rr.lq);
+}
+/* the same with a wave per read (long reads: hundreds of words of column flags and of byte marks per read) */
+__global__ void __launch_bounds__(256)
+k_readflags_wave(DBatch B, const uint32_t *__restrict__ colrec, const uint32_t *__restrict__ flagbits,
+                 uint8_t *__restrict__ rflags, uint32_t *__restrict__ forcebits)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= B.n_reads) return;                            /* (the whole wave) */
+    const ReadRec rr = B.rr[r];
+    if (rr.end <= rr.pos) { if (lane == 0) rflags[r] = 4; return; }
+    const int c0 = rr.pos - B.p0, c1 = rr.end - B.p0;
+    RF_TRAILING_CB();
+    int keep = 0, b15 = 0;
+    const int w0 = c0 >> 5, w1 = (c1 - 1) >> 5;
+    for (int w = w0 + lane; w <= w1; w += 64) {
+        uint32_t bits = flagbits[w];
+        if (w == w0) bits &= ~0u << (c0 & 31);
+        if (w == w1 && ((c1 - 1) & 31) != 31) bits &= (2u << ((c1 - 1) & 31)) - 1u;
+        while (bits) {
+            const int c = w * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            const uint32_t rec = colrec[c];
+            if (rec & CR_SKIP) continue;
+            if (rec & CR_KEEP) keep = 1;
+            if (CR_PRESERVE(rec) > 1 && c < cb) b15 = 1;
+        }
+    }
+    keep = __ballot(keep) != 0ull; b15 = __ballot(b15) != 0ull;
+    if (lane == 0) rflags[r] = (uint8_t)(keep | (b15 << 1));
+    if (keep && rr.lq > 0) {
+        const int64_t a = rr.so, b = rr.so + rr.lq;
+        for (int64_t w = (a >> 5) + lane; w <= (b - 1) >> 5; w += 64) {
+            const int lo = a > w * 32 ? (int)(a - w * 32) : 0, hi = b < w * 32 + 32 ? (int)(b - w * 32) : 32;
+            const uint32_t m = (hi == 32 ? ~0u : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+            if (m) atomicOr(&forcebits[w], m);
+        }
+    }
 }
 
 /* per-workgroup histogram of output qualities in LDS (signed counts: a corrected byte takes one out and puts one in);
@@ -2316,6 +2356,23 @@ k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
     if (gend - g0 == 16) hibits |= q4.x | q4.y | q4.z | q4.w;
     else for (int k = 0; k < (int)(gend - g0); k++) hibits |= qw[k >> 2] & (0xffu << (8 * (k & 3)));     /* (the slack behind the last base is not input) */
     uint32_t ow[4] = {qw[0] & 0x7f7f7f7fu, qw[1] & 0x7f7f7f7fu, qw[2] & 0x7f7f7f7fu, qw[3] & 0x7f7f7f7fu};
+    /* the capped original of every byte (cap_quality snp:1325; -k / -K: a preserved quality is not capped): window columns,
+     * back-fill ranges and kept reads take it */
+    uint32_t capw[4], pv1w[4], pv2w[4];
+    #pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t q = qw[k];
+        uint32_t PV1 = 0, PV2 = 0;
+        if (PV)
+            for (int i = 0; i < npv; i++) {
+                const uint32_t eq = ~PB_NZ(q ^ PB4(P->pv_val[i]));
+                PV1 |= eq;
+                if (P->pv_lvl[i] > 1) PV2 |= eq;
+            }
+        const uint32_t geq = PB_GE(q, QC) & ~PV1;
+        capw[k] = (QC & geq) | (q & ~geq);
+        pv1w[k] = PV1; pv2w[k] = PV2;
+    }
     int64_t r = chunk_read[g0 >> 4];                          /* the owner of byte g0 (table built with the batch) */
     Rec rr = recs[r];
     unsigned genb = 0;                                        /* bytes of general-CIGAR reads (k_replay_reads') */
@@ -2375,15 +2432,7 @@ k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
                 const uint32_t V = V1 | V2;
                 const uint32_t ac = (a[k] & V1) | (a2[k] & V2);
                 const uint32_t hm = (hms[0] & V1) | (hms[1] & V2);
-                uint32_t PV1 = 0, PV2 = 0;                                           /* -k / -K: bytes of a preserved quality */
-                if (PV)
-                    for (int i = 0; i < npv; i++) {
-                        const uint32_t eq = ~PB_NZ(q ^ PB4(P->pv_val[i]));
-                        PV1 |= eq;
-                        if (P->pv_lvl[i] > 1) PV2 |= eq;
-                    }
-                const uint32_t geq = PB_GE(q, QC) & ~PV1;
-                const uint32_t capq = (QC & geq) | (q & ~geq);                       /* cap_quality snp:1325 */
+                const uint32_t PV1 = pv1w[k], PV2 = pv2w[k], capq = capw[k];      /* -k / -K: bytes of a preserved quality; cap_quality */
                 const uint32_t hit = b & ac & 0x0f0f0f0fu;                          /* base shares a bit with a called allele */
                 const uint32_t many = b & ((b | 0x80808080u) - 0x01010101u) & 0x0f0f0f0fu;   /* >= 2 bits: never equals a call */
                 const uint32_t M = PB_NZ(hit) & ~PB_NZ(many);                       /* base == call1 || base == call2 (snp:1908) */
@@ -2406,13 +2455,7 @@ k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
         #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t C = ((((cq >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;
-            if (!C) continue;
-            const uint32_t q = qw[k];
-            uint32_t PV1 = 0;
-            if (PV) for (int i = 0; i < npv; i++) PV1 |= ~PB_NZ(q ^ PB4(P->pv_val[i]));
-            const uint32_t geq = PB_GE(q, QC) & ~PV1;
-            const uint32_t capq = ((QC & geq) | (q & ~geq)) & 0x7f7f7f7fu;
-            ow[k] = (capq & C) | (ow[k] & ~C);
+            ow[k] = (capw[k] & 0x7f7f7f7fu & C) | (ow[k] & ~C);
         }
     }
     if (gend - g0 == 16) { uint4 o4; o4.x = ow[0]; o4.y = ow[1]; o4.z = ow[2]; o4.w = ow[3]; *(uint4 *)(out + g0) = o4; }

@@ -83,6 +83,8 @@ def load_library(path=None, make_default=True):
         "crumble_hip_mask_lc": (C.c_int, [vp, i64, vp, vp, vp, vp, vp]),
         "crumble_hip_pblock": (C.c_int, [vp, i64, vp, vp]),
         "crumble_hip_indel_only": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+        "crumble_hip_host_alloc": (vp, [C.c_size_t]),
+        "crumble_hip_host_free": (None, [vp]),
         "crumble_hip_strerror": (C.c_char_p, [C.c_int]),
         "crumble_hip_last_error": (C.c_char_p, []),
     }
@@ -111,9 +113,27 @@ EXPORTED = [
     "crumble_hip_kernel_times", "crumble_hip_upload_times", "crumble_hip_stats_devptr", "crumble_hip_stats_reset",
     "crumble_hip_stats_read", "crumble_hip_stats_allreduce", "crumble_hip_comm_init_all",
     "crumble_hip_comm_destroy", "crumble_hip_columns",
-    "crumble_hip_mask_lc", "crumble_hip_pblock", "crumble_hip_indel_only", "crumble_hip_strerror",
+    "crumble_hip_mask_lc", "crumble_hip_pblock", "crumble_hip_indel_only", "crumble_hip_host_alloc", "crumble_hip_host_free",
+    "crumble_hip_strerror",
     "crumble_hip_last_error",
 ]
+
+
+def pinned_array(n, dtype, library=None):
+    """numpy array of n items in page-locked host memory (crumble_hip_host_alloc); keep the returned array alive and
+    hand it to pinned_free() when done."""
+    L = library if library is not None else lib()
+    dt = np.dtype(dtype)
+    nbytes = max(1, int(n) * dt.itemsize)
+    p = L.crumble_hip_host_alloc(nbytes)
+    if not p:
+        raise MemoryError("crumble_hip_host_alloc")
+    a = np.frombuffer((C.c_uint8 * nbytes).from_address(p), dtype=dt, count=int(n))
+    return a, p
+
+
+def pinned_free(p, library=None):
+    (library if library is not None else lib()).crumble_hip_host_free(p)
 
 
 def default_params():

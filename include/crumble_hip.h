@@ -303,6 +303,12 @@ int crumble_hip_pblock(crumble_hip *h, int64_t n_reads, const int64_t *seq_off,
  * Q = 37).  Uses the batch of the last crumble_hip_upload(). */
 int crumble_hip_indel_only(crumble_hip *h, int dist, int q, uint8_t *qual_out);
 
+/* Page-locked host memory (hipHostMalloc) for a caller's batch arrays and output buffers: copies to and from it cross
+ * PCIe at the link's rate without the runtime's staging through its own buffers (pageable memory: about half).  Any host
+ * memory works with every entry point; this is an option for callers that keep their buffers.  NULL on failure. */
+void *crumble_hip_host_alloc(size_t bytes);
+void  crumble_hip_host_free(void *p);
+
 const char *crumble_hip_strerror(int err);
 /* Text of the last HIP/RCCL runtime error seen by this thread. */
 const char *crumble_hip_last_error(void);

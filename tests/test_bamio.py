@@ -418,7 +418,7 @@ def test_cli_multi_device_emulated(tmp_path):
     bs.append(HostBatch.from_reads([dict(pos=0, cigar="*", seq="ACGTAC", qual=[9, 30, 31, 12, 40, 2], flag=4)], tid=-1))
     bamio.write_batches(tmp_path / "in.bam", refs, bs)
     outs = {}
-    for j in ("1", "2", "3"):
+    for j in ("1", "2", "3", "8"):
         env = dict(os.environ, CRUMBLE_HIP_DEVICES=",".join("0" * int(j)))
         r = subprocess.run([exe, "-v", "-v", "-5", "-j", j, "-b", str(tmp_path / f"s{j}.bed"), str(tmp_path / "in.bam"), str(tmp_path / f"out{j}.bam")],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
@@ -428,7 +428,7 @@ def test_cli_multi_device_emulated(tmp_path):
         if j != "1":
             assert f"{j} device(s)" in r.stderr
     text1 = walk_bam(tmp_path / "out1.bam")
-    for j in ("2", "3"):
+    for j in ("2", "3", "8"):
         t = walk_bam(tmp_path / f"out{j}.bam")
         assert t[1] == text1[1] and [x["qual"] for x in t[2]] == [x["qual"] for x in text1[2]] and len(t[2]) == len(text1[2])
         assert outs[j][1] == outs["1"][1] and outs[j][2] == outs["1"][2]
@@ -538,6 +538,85 @@ def test_htslib_backend_round_trip_when_present(tmp_path):
         assert {k: v for k, v in x.items() if k != "qual"} == {k: v for k, v in y.items() if k != "qual"}
 
 
+# ---------------------------------------------------------------- the htslib backend, executed through a test double
+FAKEHTS = os.path.join(ROOT, "tests", "fakehts")
+
+
+def _fakehts(kind):
+    r = subprocess.run(["make", "-C", FAKEHTS], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    d = os.path.join(FAKEHTS, kind)
+    return dict(os.environ, LD_LIBRARY_PATH=d + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+
+
+def _sam_text(refs, batches):
+    """SAM text of HostBatches (names r<i>; mate fields empty)."""
+    out = ["@HD\tVN:1.6\tSO:coordinate"] + [f"@SQ\tSN:{n}\tLN:{l}" for n, l in refs]
+    k = 0
+    for hb in batches:
+        for i in range(hb.n_reads):
+            ops = hb.cigar[hb.cig_off[i]:hb.cig_off[i + 1]]
+            cg = "".join(f"{int(o) >> 4}{'MIDNSHP=X'[int(o) & 15]}" for o in ops) or "*"
+            sq = "".join("=ACMGRSVTWYHKDBN"[int(b)] for b in hb.bases[hb.seq_off[i]:hb.seq_off[i + 1]]) or "*"
+            ql = "".join(chr(int(q) + 33) for q in hb.quals[hb.seq_off[i]:hb.seq_off[i + 1]]) or "*"
+            rn = refs[hb.tid][0] if hb.tid >= 0 else "*"
+            out.append(f"r{k}\t{int(hb.flag[i])}\t{rn}\t{int(hb.pos[i]) + 1}\t{int(hb.mapq[i])}\t{cg}\t*\t0\t0\t{sq}\t{ql}\tNM:i:{k % 300}\tXT:Z:t{k}")
+            k += 1
+    return "\n".join(out) + "\n"
+
+
+def _sam_quals(path):
+    return [l.split("\t")[10] for l in open(path) if not l.startswith("@")]
+
+
+def _run_fakehts_round_trip(exe, tmp_path):
+    """in.sam -> crumble-hip -5 -> out.sam through the htslib backend with the test double on LD_LIBRARY_PATH: hts_load(),
+    hts_layout_check(), the bam1_t -> SoA conversion, the quality write-back, -I / -O parsing, purge_tags and the @PG
+    line all execute, and the output qualities are the oracle's.  This pins NO parity with a real htslib (there is
+    none here, and the double was written from the same reading of the headers as the backend): it turns "never
+    executed" into "executed".  A double that lays bam1_core_t out differently must be refused."""
+    import oracle_lib as O
+    refs, bs = three_groups()
+    (tmp_path / "in.sam").write_text(_sam_text(refs, bs))
+    env = _fakehts("ok")
+    r = subprocess.run([exe, "-5", "-I", "sam", "-O", "sam", "-T", "XT", str(tmp_path / "in.sam"), str(tmp_path / "out.sam")],
+                       env=env, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    got = _sam_quals(tmp_path / "out.sam")
+    p = ca.preset_params(5)
+    want = []
+    for hb in bs:
+        wq, _, _ = O.contig(p, hb)
+        want += ["".join(chr(int(q) + 33) for q in wq[hb.seq_off[i]:hb.seq_off[i + 1]]) or "*" for i in range(hb.n_reads)]
+    assert got == want
+    lines = [l for l in open(tmp_path / "out.sam")]
+    assert any(l.startswith("@PG") and "crumble-hip" in l for l in lines)
+    body = [l for l in lines if not l.startswith("@")]
+    assert all("NM:i:" in l and "XT:Z:" not in l for l in body)                    # -T XT: the black list is applied on this path too
+    assert [l.split("\t")[:10] for l in body] == [l.split("\t")[:10] for l in _sam_text(refs, bs).splitlines() if not l.startswith("@")]
+    # by file name alone (snp_score.c:2569), and BAM input refused by the double (SAM text only): a clean error
+    r = subprocess.run([exe, "-5", str(tmp_path / "in.sam"), str(tmp_path / "o2.sam")], env=env, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and _sam_quals(tmp_path / "o2.sam") == want, r.stderr
+    r = subprocess.run([exe, "-5", "-O", "cram", str(tmp_path / "in.sam"), str(tmp_path / "o.cram")], env=env, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "format" in r.stderr
+    # another ABI: refused by the layout self-check, nothing written
+    r = subprocess.run([exe, "-5", str(tmp_path / "in.sam"), str(tmp_path / "o3.sam")], env=_fakehts("shifted"), stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "lays bam1_t out differently" in r.stderr, r.stderr
+    assert not os.path.exists(tmp_path / "o3.sam")
+
+
+def test_htslib_backend_through_a_test_double_emulated(tmp_path):
+    import emu_lib
+    emu_lib.load()
+    _run_fakehts_round_trip(os.path.join(ROOT, "tests", "emu", "crumble-hip-emu"), tmp_path)
+
+
+@pytest.mark.gpu
+def test_htslib_backend_through_a_test_double_gpu(tmp_path):
+    _run_fakehts_round_trip(os.path.join(ROOT, "crumble_amd", "crumble-hip"), tmp_path)
+
+
+
 def test_cli_has_no_cpu_path(tmp_path):
     """Without a GPU the shipped binary stops with ENODEVICE (exit 2); it never computes on the host."""
     from parity_util import gpu_count
@@ -587,7 +666,7 @@ def test_cli_multi_device_and_options_gpu(tmp_path):
     ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(nd))
     ndev = nd.value
     outs = {}
-    for j in (1, 2, 3):
+    for j in (1, 2, 3, 8):                       # (8: the device count the target names; more engines than contigs)
         devs = ",".join(str(k if ndev >= j else 0) for k in range(j))
         env = dict(os.environ, CRUMBLE_HIP_DEVICES=devs)
         r = subprocess.run([exe, "-v", "-5", "-j", str(j), "-b", str(tmp_path / f"s{j}.bed"), str(tmp_path / "in.bam"), str(tmp_path / f"out{j}.bam")],
@@ -600,11 +679,11 @@ def test_cli_multi_device_and_options_gpu(tmp_path):
             assert "RCCL all-reduce" in r.stderr
     want = _oracle_file(ca.preset_params(5), tmp_path / "in.bam", None)
     assert np.array_equal(outs[1][0], want)
-    for j in (2, 3):
+    for j in (2, 3, 8):
         assert np.array_equal(outs[j][0], outs[1][0]) and outs[j][1] == outs[1][1] and outs[j][2] == outs[1][2]
     assert outs[1][1] == "".join(_oracle_bed(ca.preset_params(5), tmp_path / "in.bam"))
     # (1b) -w: every contig cut into windows over the engines
-    for j in (2, 3):
+    for j in (2, 3, 8):
         devs = ",".join(str(k if ndev >= j else 0) for k in range(j))
         r = subprocess.run([exe, "-v", "-5", "-j", str(j), "-w", "-b", str(tmp_path / "sw.bed"), str(tmp_path / "in.bam"), str(tmp_path / "outw.bam")],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=dict(os.environ, CRUMBLE_HIP_DEVICES=devs))

@@ -293,24 +293,27 @@ def test_upload_validation_errors(product):
     eng.close()
 
 
-@pytest.mark.parametrize("workload", ["chr20", "wgs"])
-def test_bench_two_ranks(product, workload):
-    """bench.py's N>1 control flow (barriers, max-over-ranks timing, stats / base-count all-reduce, one JSON
-    line from rank 0) with two processes sharing this box's one GPU; gloo stands in for RCCL here."""
+@pytest.mark.parametrize("workload,ranks", [("chr20", 2), ("wgs", 2), ("wgs", 8)])
+def test_bench_two_ranks(product, workload, ranks):
+    """bench.py's N>1 control flow (LPT packing of the 24 contigs onto the ranks, barriers, max-over-ranks timing,
+    stats / base-count all-reduce, one JSON line from rank 0) with 2 -- and, at the world size the target names, 8 --
+    processes sharing this box's one GPU; gloo stands in for RCCL here."""
     import json, os, subprocess, sys
     from crumble_amd.capi import ROOT
     env = dict(os.environ, CRUMBLE_BENCH_BACKEND="gloo", CRUMBLE_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     scale = "0.01" if workload == "chr20" else "0.0005"
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload, "--scale", scale],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+                        "--master-addr", "127.0.0.1", "--master-port", str(29533 + ranks), os.path.join(ROOT, "bench.py"),
+                        "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--workload", workload, "--scale", scale],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == ("weak" if workload == "chr20" else "strong")
+    assert d["n_gpus"] == ranks and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == ("weak" if workload == "chr20" else "strong")
     assert "roofline" in d and "cpu_baseline" not in d
+    if workload == "wgs":
+        assert d["config"]["contigs"] == 24 and 1.0 <= d["config"]["lpt_max_over_mean_load"] < 1.35
 
 
 @pytest.mark.parametrize("workload", ["chr20", "wgs"])
