@@ -856,12 +856,18 @@ extern "C" int crumble_hip_set_window(crumble_hip *h, const crumble_window *w)
     const int n_trig = spec ? h->cap_trig : h->totals.trigcols, n_items = spec ? h->cap_items : h->totals.items, n_ins = spec ? h->cap_ins : h->totals.ins; \
     const int *nd_trig = spec ? &partial[nchunks].trigcols : (const int *)nullptr, *nd_items = spec ? &partial[nchunks].items : (const int *)nullptr, \
               *nd_ins = spec ? &partial[nchunks].ins : (const int *)nullptr; \
+    /* what the list kernels' grids are sized for: the exact lengths, or (fast path) the capacities bounded by what a \
+     * batch of this size can produce -- blocks beyond the real length leave at once, and a small contig behind a large \
+     * one does not launch the large one's grids */ \
+    const int gn_trig = spec ? (int)std::min<int64_t>(n_trig, L) : n_trig, gn_ins = spec ? (int)std::min<int64_t>(n_ins, L) : n_ins, \
+              gn_items = spec ? (int)std::min<int64_t>(n_items, nb + L) : n_items; \
+    const unsigned gcap = spec ? 65536u : 0x7fffffffu;      /* (fast path: a workgroup that finds nothing costs ~0.2 ns; the kernels stride) */ \
     int32_t *trigcol_pos = h->d_trigcol_pos.as<int32_t>(), *trigcol_off = h->d_trigcol_off.as<int32_t>(); \
     int32_t *inscol_pos = h->d_inscol_pos.as<int32_t>(); \
     TrigItem *items = h->d_items.as<TrigItem>(); \
     (void)P; (void)T; (void)stats; (void)d_nep; (void)L; (void)n; (void)nb; (void)colrec; (void)nplp; (void)score; (void)trigcnt; \
     (void)nchunks; (void)scan_chunk; (void)partial; (void)n_trig; (void)n_items; (void)n_ins; (void)trigcol_pos; (void)trigcol_off; (void)inscol_pos; (void)items; \
-    (void)spec_abort; (void)nd_trig; (void)nd_items; (void)nd_ins;
+    (void)spec_abort; (void)nd_trig; (void)nd_items; (void)nd_ins; (void)gn_trig; (void)gn_ins; (void)gn_items; (void)gcap;
 static const crumble_carry CARRY0 = {0, 0, INT_MAX, 0, INT_MAX, 0};
 
 extern "C" int crumble_hip_run_columns(crumble_hip *h)
@@ -1017,22 +1023,22 @@ extern "C" int crumble_hip_run_triggers(crumble_hip *h)
         if (n_ins > 0) {
             STAGE("k_inshist", 0);
             {   /* lanes per column: 16 when a column has a few dozen candidate reads, the whole wave on deep pileups
-                 * (mean depth of the covered columns; fast path: bases per column of the batch's extent, an upper bound of it) */
-                const int64_t mean_depth = spec ? nb / (L > 0 ? L : 1) : (h->totals.cols > 0 ? h->totals.depth / h->totals.cols : 0);
+                 * (mean depth of the covered columns; fast path: the kernel takes it from the scan's totals on the device) */
+                const int64_t mean_depth = spec ? 0 : (h->totals.cols > 0 ? h->totals.depth / h->totals.cols : 0);
                 const int gshift = mean_depth < 40 ? 4 : 6;
-                unsigned g = (unsigned)((n_ins + (64 >> gshift) - 1) / (64 >> gshift));
-                if (spec && g > 4096u) g = 4096u;
-                CRUMBLE_LAUNCH(k_inshist, g, 64, st, B, P, n_ins, nd_ins, spec_abort, inscol_pos, colrec, nplp, stats, gshift);
+                const unsigned g = std::min(gcap, (unsigned)((gn_ins + (64 >> gshift) - 1) / (64 >> gshift)));
+                CRUMBLE_LAUNCH(k_inshist, g, 64, st, B, P, n_ins, nd_ins, spec_abort, inscol_pos, colrec, nplp, stats, gshift,
+                               spec ? (const ScanVal *)&partial[nchunks] : (const ScanVal *)nullptr);
             }
         }
         if (n_trig > 0) {
             STAGE("k_emit", 0);
             if (h->n_segrec > h->n_reads + h->n_reads / 2)       /* long reads: few candidates per column */
-                CRUMBLE_LAUNCH_INDEP(k_emit_lanes, (spec && nblk(n_trig, 64) > 4096u) ? 4096u : nblk(n_trig, 64), 64, st, B, P, n_trig, nd_trig, spec_abort, trigcol_pos, trigcol_off, colrec, items);
+                CRUMBLE_LAUNCH_INDEP(k_emit_lanes, std::min(gcap, nblk(gn_trig, 64)), 64, st, B, P, n_trig, nd_trig, spec_abort, trigcol_pos, trigcol_off, colrec, items);
             else
-                CRUMBLE_LAUNCH(k_emit, (spec && nblk(n_trig, 4) > 8192u) ? 8192u : nblk(n_trig, 4), 256, st, B, P, n_trig, nd_trig, spec_abort, trigcol_pos, trigcol_off, colrec, items);
+                CRUMBLE_LAUNCH(k_emit, std::min(gcap / 4, nblk(gn_trig, 4)), 256, st, B, P, n_trig, nd_trig, spec_abort, trigcol_pos, trigcol_off, colrec, items);
             STAGE("k_str", 0);
-            CRUMBLE_LAUNCH_INDEP(k_str, (spec && nblk(n_items, 64) > 16384u) ? 16384u : nblk(n_items, 64), 64, st, B, P, n_items, nd_items, spec_abort, items, d_overflow);
+            CRUMBLE_LAUNCH_INDEP(k_str, std::min(gcap, nblk(gn_items, 64)), 64, st, B, P, n_items, nd_items, spec_abort, items, d_overflow);
         }
     }
     h->phase = 3;
@@ -1058,11 +1064,11 @@ extern "C" int crumble_hip_run_fold(crumble_hip *h, const crumble_carry *in, cru
                 CRUMBLE_LAUNCH(k_fold_small, 1, 1024, st, B, P, n_trig, nd_trig, spec_abort, trigcol_pos, trigcol_off, trigcnt, items, colhi, ub,
                                colrec, h->d_pos_mn2.as<int32_t>(), h->d_trig_mx2.as<int32_t>(), d_carry);
             else {
-            const unsigned gt = (spec && nblk(n_trig, 64) > 4096u) ? 4096u : nblk(n_trig, 64);
+            const unsigned gt = std::min(gcap, nblk(gn_trig, 64));
             CRUMBLE_LAUNCH_INDEP(k_fold_bounds, gt, 64, st, B, P, n_trig, nd_trig, spec_abort, trigcol_pos, trigcol_off, trigcnt, items, colhi, cin.max_pos);
-            if ((pe = prefix_max(h, colhi, n_trig, nd_trig))) return pe;
+            if ((pe = prefix_max(h, colhi, gn_trig, nd_trig))) return pe;
             CRUMBLE_LAUNCH_INDEP(k_fold_ub, gt, 64, st, B, P, n_trig, nd_trig, spec_abort, trigcol_pos, colhi, ub, cin.max_pos2);
-            if ((pe = prefix_max(h, ub, n_trig, nd_trig))) return pe;
+            if ((pe = prefix_max(h, ub, gn_trig, nd_trig))) return pe;
             CRUMBLE_LAUNCH_INDEP(k_fold, gt, 64, st, B, P, n_trig, nd_trig, spec_abort, trigcol_pos, trigcol_off, trigcnt, items, ub,
                                  colrec, h->d_pos_mn2.as<int32_t>(), h->d_trig_mx2.as<int32_t>(),
                                  cin.min_pos, cin.max_pos, cin.min_pos2, cin.max_pos2, B.p0 + B.stat_hi, d_carry);
@@ -1087,7 +1093,7 @@ extern "C" int crumble_hip_run_finish(crumble_hip *h)
     if (!h || !h->have_batch || h->phase != 4) { g_last_error = "crumble_hip_run_finish: run the fold phase first"; return CRUMBLE_EINVAL; }
     RUN_LOCALS
     if (L > 0 && n_trig > 0 && !h->fold_small) {
-        CRUMBLE_LAUNCH_INDEP(k_window, (spec && nblk(n_trig, 64) > 4096u) ? 4096u : nblk(n_trig, 64), 64, st, B, n_trig, nd_trig, spec_abort, trigcol_pos, h->d_trig_mx2.as<int32_t>(), colrec);
+        CRUMBLE_LAUNCH_INDEP(k_window, std::min(gcap, nblk(gn_trig, 64)), 64, st, B, n_trig, nd_trig, spec_abort, trigcol_pos, h->d_trig_mx2.as<int32_t>(), colrec);
     }
     if (n > 0) {
         STAGE("k_replay", 3.0 * nb);
@@ -1114,8 +1120,7 @@ extern "C" int crumble_hip_run_finish(crumble_hip *h)
             else       CRUMBLE_LAUNCH_INDEP(k_readflags, nblk(n, 256), 256, st, B, colrec, flagbits, rfl, forcebits);
             if (L > 0 && n_trig > 0) {
                 const int coop = multi ? 0 : 1;                 /* (long reads: eight columns per wave) */
-                unsigned g = (unsigned)(coop ? n_trig : (n_trig + 7) / 8);
-                if (spec && g > 32768u) g = 32768u;
+                const unsigned g = std::min(gcap, (unsigned)(coop ? gn_trig : (gn_trig + 7) / 8));
                 CRUMBLE_LAUNCH(k_restore, g, 64, st, B, P, n_trig, nd_trig, spec_abort, h->d_trigcol_pos.as<int32_t>(), h->d_pos_mn2.as<int32_t>(),
                                h->d_trig_mx2.as<int32_t>(), h->d_out.as<uint8_t>(), coop, forcebits);
             }
@@ -1171,8 +1176,7 @@ extern "C" int crumble_hip_run_finish(crumble_hip *h)
             }
             if (L > 0 && n_trig > 0) {
                 const int coop = multi ? 0 : 1;
-                unsigned g = (unsigned)(coop ? n_trig : (n_trig + 7) / 8);
-                if (spec && g > 32768u) g = 32768u;
+                const unsigned g = std::min(gcap, (unsigned)(coop ? gn_trig : (gn_trig + 7) / 8));
                 CRUMBLE_LAUNCH(k_restore, g, 64, st, B, P, n_trig, nd_trig, spec_abort,
                                      h->d_trigcol_pos.as<int32_t>(), h->d_pos_mn2.as<int32_t>(), h->d_trig_mx2.as<int32_t>(), h->d_out.as<uint8_t>(),
                                      coop, (uint32_t *)nullptr);

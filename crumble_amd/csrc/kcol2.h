@@ -58,11 +58,6 @@
 #define KC2_WGDEAL   1             /* the waves of a workgroup take the tiles of ONE unit between them, tile by tile: tiles in
                                     * flight on a CU are neighbours, their reads' cache lines are shared while they are hot */
 #endif
-#ifndef KC2_TWO_LOOPS
-#define KC2_TWO_LOOPS 0            /* a second instance of the consumer's row loop for passes without a '*' / N entry (12 VALU + 8 SALU per
-                                    * row instead of 13 + 10): measured SLOWER on the chr20 set (4.80 against 4.62 ms) -- the two instances'
-                                    * accumulators get different registers and every pass pays the moves -- so it stays an option */
-#endif
 #ifndef KC2_FASTFIN
 #define KC2_FASTFIN  1             /* tiles whose columns are all "common" take cons_finalize_fast (needs KC2_LDS_EXP) */
 #endif
@@ -74,17 +69,10 @@
 #define KC2_FULL     0x40000u      /* a match op spanning the whole tile: takes part in the key vote */
 #define KC2_NONHOT   0x80000u      /* mapq != the batch's dominant one (CONS_MQUAL only) */
 #define KC2_NROWTAB  (128 + 101)
-/* matrix entry (16 bits): low byte = table row (a raw quality, or 128 + adjusted quality), high byte = class << 4 | 8
- * (class 7 = the record does not reach the column; the 8 keeps an entry from being zero).  Each half is a whole byte so
- * that the consumer's compares and its table address read them with sub-dword addressing (SDWA) -- no extract, no mask */
-#define KC2_CLS(v_)     (((v_) >> 12) & 7u)
-#define KC2_ROWOFF(v_)  (((v_) & 0xffu) << 5)
-#define KC2_CLSBYTE(c_) ((((unsigned)(c_)) << 4) | 8u)
-#ifdef CRUMBLE_EMU
-#define KC2_K(c_) (c_)             /* the C row routine compares class numbers, the GPU one the entry's class byte */
-#else
-#define KC2_K(c_) KC2_CLSBYTE(c_)
-#endif
+#define KC2_ROWMASK  0x1fe0u       /* matrix entry: table row byte offset (bits 5-12) | class (bits 1-3; 7 = the record does
+                                    * not reach the column) | bit 0 set (never zero) | call_preserve input of a translated
+                                    * row (bits 13-14) */
+#define KC2_CLS(v_)  (((v_) >> 1) & 7u)
 
 #ifdef CRUMBLE_EMU
 static unsigned long long kc2_emu_fin[2];      /* test hook (emulator only): tiles through cons_finalize_fast / the general finalize */
@@ -192,7 +180,7 @@ struct __attribute__((aligned(16))) KC2Lds {
 #define KC2_DRAIN_V(x_) do { \
     const unsigned pe_ = (x_); \
     if (pe_) { \
-        const double *rw_ = (const double *)(rowbase + KC2_ROWOFF(pe_)); \
+        const double *rw_ = (const double *)(rowbase + (pe_ & KC2_ROWMASK)); \
         const double pMM = rw_[0], p_M = rw_[1], pom = rw_[2]; \
         const unsigned rc_ = KC2_CLS(pe_); \
         const unsigned k_ = rc_ < 4u ? (rc_ ^ key) : rc_; \
@@ -232,17 +220,18 @@ struct __attribute__((aligned(16))) KC2Lds {
         if (ml_) pend = (pend << 16) | (v_); \
         if (__ballot(ml_ && pend > 0xffffu)) KC2_DRAIN(); \
     } } while (0)
-#define KC2_ROW_PLAIN(v_, MM_, _M_, om_) KC2_ROW(v_, MM_, _M_, om_)
 #else
-/* (EXEC is all ones in the consumer: the workgroup is whole waves and nothing before the row loop is lane-divergent) */
 #define KC2_ROW(v_, MM_, _M_, om_) do { \
-    unsigned long long mis_, odd_, coll_, rare_, m0_, m1_, m2_, m3_, t_; \
+    unsigned long long mis_, odd_, coll_, rare_, m0_, m1_, m2_, m3_, t_, sv_; \
+    unsigned cls_; \
     asm volatile( \
-        "v_cmp_eq_u32_sdwa %[m0], %[v], %[k0] src0_sel:BYTE_1 src1_sel:DWORD\n\t" \
-        "v_cmp_eq_u32_sdwa %[m1], %[v], %[k1] src0_sel:BYTE_1 src1_sel:DWORD\n\t" \
-        "v_cmp_eq_u32_sdwa %[m2], %[v], %[k2] src0_sel:BYTE_1 src1_sel:DWORD\n\t" \
-        "v_cmp_eq_u32_sdwa %[m3], %[v], %[k3] src0_sel:BYTE_1 src1_sel:DWORD\n\t" \
-        "v_cmp_ne_u32_sdwa %[t], %[none], %[v] src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+        "v_bfe_u32 %[cls], %[v], 1, 3\n\t" \
+        "v_cmp_eq_u32_e64 %[m0], %[cls], %[k0]\n\t" \
+        "v_cmp_eq_u32_e64 %[m1], %[cls], %[k1]\n\t" \
+        "v_cmp_eq_u32_e64 %[m2], %[cls], %[k2]\n\t" \
+        "v_cmp_eq_u32_e64 %[m3], %[cls], %[k3]\n\t" \
+        "v_cmp_ne_u32_e64 %[t], 7, %[cls]\n\t" \
+        "s_mov_b64 %[sv], exec\n\t" \
         "s_andn2_b64 %[mis], %[t], %[m0]\n\t" \
         "s_or_b64 %[t], %[m1], %[m2]\n\t" \
         "s_or_b64 %[t], %[t], %[m3]\n\t" \
@@ -261,55 +250,21 @@ struct __attribute__((aligned(16))) KC2Lds {
         "v_lshl_or_b32 %[pend], %[pend], 16, %[v]\n\t"          /* park this entry behind the lane's older one */ \
         "v_cmp_lt_u32_e64 %[coll], %[ffff], %[pend]\n\t"        /* a lane with two parked entries: drain */ \
         "s_or_b64 %[rare], %[odd], %[coll]\n\t" \
-        "s_mov_b64 exec, -1" \
-        : [m0] "=&s"(m0_), [m1] "=&s"(m1_), [m2] "=&s"(m2_), [m3] "=&s"(m3_), \
-          [t] "=&s"(t_), [mis] "=&s"(mis_), [odd] "=&s"(odd_), [coll] "=&s"(coll_), [rare] "=&s"(rare_), \
-          [s00] "+v"(s00), [s01] "+v"(s01), [s02] "+v"(s02), [s03] "+v"(s03), [s04] "+v"(s04), [d0] "+v"(d0), \
-          [pend] "+v"(pend) \
-        : [v] "v"(v_), [k0] "v"(k0), [k1] "v"(k1), [k2] "v"(k2), [k3] "v"(k3), [MM] "v"(MM_), [_M] "v"(_M_), [om] "v"(om_), \
-          [ffff] "s"(0xffffu), [none] "s"(KC2_CLSBYTE(7)) \
-        : "scc"); \
-    if (__builtin_expect(rare_ != 0ull, 0)) { \
-        if (odd_ != 0ull) {                               /* a '*' or an N somewhere in the row */ \
-            const unsigned cls_ = KC2_CLS(v_); \
-            if (cls_ == 4u) { KC2_MASKED; s04 += (_M_); } \
-            if (cls_ == 5u) { KC2_MASKED; s00 += (MM_); s01 += (MM_); s02 += (MM_); s03 += (MM_); s04 += (_M_); } \
-        } \
-        if (coll_ != 0ull) KC2_DRAIN(); \
-    } } while (0)
-/* The same for a pass that holds no '*' and no N entry (the producer looks: three passes in four on the chr20 set): an
- * entry that is not of the key class is then of one of the three other base classes, so the parked lanes are m1 | m2 | m3
- * and neither the "does the row reach the column" compare nor the odd-class mask is needed: 12 VALU + 8 SALU. */
-#define KC2_ROW_PLAIN(v_, MM_, _M_, om_) do { \
-    unsigned long long mis_, coll_, m0_, m1_, m2_, m3_; \
-    asm volatile( \
-        "v_cmp_eq_u32_sdwa %[m0], %[v], %[k0] src0_sel:BYTE_1 src1_sel:DWORD\n\t" \
-        "v_cmp_eq_u32_sdwa %[m1], %[v], %[k1] src0_sel:BYTE_1 src1_sel:DWORD\n\t" \
-        "v_cmp_eq_u32_sdwa %[m2], %[v], %[k2] src0_sel:BYTE_1 src1_sel:DWORD\n\t" \
-        "v_cmp_eq_u32_sdwa %[m3], %[v], %[k3] src0_sel:BYTE_1 src1_sel:DWORD\n\t" \
-        "s_or_b64 %[mis], %[m1], %[m2]\n\t" \
-        "s_mov_b64 exec, %[m0]\n\t" \
-        "v_add_f64 %[s00], %[s00], %[MM]\n\t" \
-        "v_add_f64 %[d0], %[d0], %[om]\n\t" \
-        "v_add_f64 %[s04], %[s04], %[_M]\n\t" \
-        "s_or_b64 exec, %[m0], %[m1]\n\t" \
-        "v_add_f64 %[s01], %[s01], %[_M]\n\t" \
-        "s_or_b64 exec, %[m0], %[m2]\n\t" \
-        "v_add_f64 %[s02], %[s02], %[_M]\n\t" \
-        "s_or_b64 exec, %[m0], %[m3]\n\t" \
-        "v_add_f64 %[s03], %[s03], %[_M]\n\t" \
-        "s_or_b64 exec, %[mis], %[m3]\n\t" \
-        "v_lshl_or_b32 %[pend], %[pend], 16, %[v]\n\t"          /* park this entry behind the lane's older one */ \
-        "v_cmp_lt_u32_e64 %[coll], %[ffff], %[pend]\n\t"        /* a lane with two parked entries: drain */ \
-        "s_mov_b64 exec, -1" \
-        : [m0] "=&s"(m0_), [m1] "=&s"(m1_), [m2] "=&s"(m2_), [m3] "=&s"(m3_), [mis] "=&s"(mis_), [coll] "=&s"(coll_), \
+        "s_mov_b64 exec, %[sv]" \
+        : [cls] "=&v"(cls_), [m0] "=&s"(m0_), [m1] "=&s"(m1_), [m2] "=&s"(m2_), [m3] "=&s"(m3_), \
+          [t] "=&s"(t_), [sv] "=&s"(sv_), [mis] "=&s"(mis_), [odd] "=&s"(odd_), [coll] "=&s"(coll_), [rare] "=&s"(rare_), \
           [s00] "+v"(s00), [s01] "+v"(s01), [s02] "+v"(s02), [s03] "+v"(s03), [s04] "+v"(s04), [d0] "+v"(d0), \
           [pend] "+v"(pend) \
         : [v] "v"(v_), [k0] "v"(k0), [k1] "v"(k1), [k2] "v"(k2), [k3] "v"(k3), [MM] "v"(MM_), [_M] "v"(_M_), [om] "v"(om_), \
           [ffff] "s"(0xffffu) \
         : "scc"); \
-    if (__builtin_expect(coll_ != 0ull, 0)) KC2_DRAIN(); \
-    } while (0)
+    if (__builtin_expect(rare_ != 0ull, 0)) { \
+        if (odd_ != 0ull) {                               /* a '*' or an N somewhere in the row */ \
+            if (cls_ == 4u) { KC2_MASKED; s04 += (_M_); } \
+            if (cls_ == 5u) { KC2_MASKED; s00 += (MM_); s01 += (MM_); s02 += (MM_); s03 += (MM_); s04 += (_M_); } \
+        } \
+        if (coll_ != 0ull) KC2_DRAIN(); \
+    } } while (0)
 #endif
 
 #ifdef KC2_EXP_STAMP      /* diagnostic build: cycles per phase, summed over waves, into the unused stats slots 24..29 */
@@ -352,54 +307,6 @@ struct __attribute__((aligned(16))) KC2Lds {
                         } \
                     } \
                 }
-
-/* the consumer's row loop: four rows per trip, their matrix entries read a trip ahead, their table rows at the top */
-#ifdef KC2_EXP_NOCONSUME
-#define KC2_LOOP_END(steps4_) ((steps4_) < 4 ? (steps4_) : 4)
-#else
-#define KC2_LOOP_END(steps4_) (steps4_)
-#endif
-#ifdef KC2_EXP_NOCONFLICT    /* diagnostic build (wrong results): every lane reads ONE table row -- no LDS bank conflicts */
-#define KC2_ROWADDR(v_) (rowbase + (((v_) & 0u) | (37u << 5)))
-#else
-#ifdef CRUMBLE_EMU
-#define KC2_ROWADDR(v_) (rowbase + KC2_ROWOFF(v_))
-#else
-/* the entry's low byte times 32 in one instruction (sub-dword source select); the table is the first thing in LDS */
-__device__ __forceinline__ const char *kc2_rowaddr(const char *rowbase, unsigned v)
-{
-    unsigned off;
-    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "s"(5u), "v"(v));
-    return rowbase + off;
-}
-#define KC2_ROWADDR(v_) kc2_rowaddr(rowbase, (v_))
-#endif
-#endif
-#define KC2_CONSUME_LOOP(ROWFN) \
-            for (int j0 = 0; j0 < KC2_LOOP_END(steps4); j0 += 4) { \
-                unsigned ve[4]; \
-                double rMM[4], r_M[4], rom[4]; \
-                unsigned rpv[4]; \
-                _Pragma("unroll") \
-                for (int u = 0; u < 4; u++) { \
-                    ve[u] = vn[u]; \
-                    const double *rw = (const double *)KC2_ROWADDR(ve[u]); \
-                    rMM[u] = rw[0]; r_M[u] = rw[1]; rom[u] = rw[2]; \
-                    if (ANYPRES) memcpy(&rpv[u], &rw[3], 4); else rpv[u] = 0; \
-                } \
-                if (j0 + 4 < steps4) { \
-                    _Pragma("unroll") \
-                    for (int u = 0; u < 4; u++) vn[u] = basep[(j0 + 4 + u) * 64]; \
-                } \
-                _Pragma("unroll") \
-                for (int u = 0; u < 4; u++) { \
-                    ROWFN(ve[u], rMM[u], r_M[u], rom[u]); \
-                    /* call_preserve bits, snp:611-623: the table row's bits at the entry's class.  Class 7 -- no entry, \
-                     * its row index may point anywhere, past the table too: hence the mask -- lands on bits 7 and 15, \
-                     * dropped after the last pass */ \
-                    if (ANYPRES) st.cp |= (rpv[u] & 0x101u) << KC2_CLS(ve[u]); \
-                } \
-            }
 
 /* MQ: the active consensus uses CONS_MQUAL (mode B, snp:1535); ANYPRES: -k/-K/-y pbccs set preserve_qual[];
  * MULTI: long reads (many ops per read: a tile's records come from the batch's hit list); WIN: the batch is a window
@@ -609,7 +516,6 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
             const uint64_t so_first = ((uint64_t)(uint32_t)UNIFORM(sof.y) << 32) | so_lo;
             const uint8_t *const pbase = B.bases + so_first - BASE_FRONT_PAD, *const qbase = B.quals + so_first - BASE_FRONT_PAD;
             const unsigned phase = (unsigned)(uintptr_t)pbase & 3u;          /* bases and quals share the byte phase */
-            uint32_t oddacc = 0;                                             /* does the pass hold a '*' or an N entry at all? */
             for (int s0 = 0; s0 < rows; s0 += 32) {
                 const int ne = rows - s0 > 16 ? 2 : 1;
                 uint32_t bwr[2][5], qwr[2][5];
@@ -669,11 +575,10 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                     #pragma unroll
                     for (int t = 0; t < 4; t++) {
                         /* class byte: class << 4 | 0x08 (the mask's), 0x78 where the record does not reach the column;
-                         * u16 = class byte << 8 | quality: the two bytes interleaved, no shift */
+                         * u16 = quality << 8 | class byte, shifted down 3: quality << 5 | class << 1 | 1 */
                         const uint32_t cm = cb[t] | ma[t] | mb[t];
-                        out[2 * t]     = kc2_perm(qw[t], cm, 0x01050004u);
-                        out[2 * t + 1] = kc2_perm(qw[t], cm, 0x03070206u);
-                        if (KC2_TWO_LOOPS) oddacc |= cm & 0x40404040u & ~((cm & 0x20202020u) << 1);      /* a '*' (4) or an N (5): bit 6 without bit 5 */
+                        out[2 * t]     = kc2_perm(qw[t], cm, 0x05010400u) >> 3;
+                        out[2 * t + 1] = kc2_perm(qw[t], cm, 0x07030602u) >> 3;
                     }
                     uint4 *dst = (uint4 *)&W.plane[row][16 * seg];
                     uint4 o0, o1;
@@ -706,8 +611,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                 }
                 key = (unsigned)cand;
             }
-            const unsigned k0 = KC2_K(key), k1 = KC2_K(key ^ 1u), k2 = KC2_K(key ^ 2u), k3 = KC2_K(key ^ 3u);
-            const bool pass_odd = __ballot(oddacc != 0u) != 0ull;
+            const unsigned k0 = key, k1 = key ^ 1u, k2 = key ^ 2u, k3 = key ^ 3u;
             if (MQ) {
                 /* rows of reads with another mapq than the batch's dominant one: the entries' table row index becomes
                  * 128 + adjusted quality (snp:632-641), one row per step with a lane per column (the lanes sit on
@@ -719,12 +623,12 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                         const int j = __builtin_ctzll(nm);
                         nm &= nm - 1;
                         const unsigned rinfo = READLANE(ri, j), slot = (rinfo >> 8) & 255u;
-                        const unsigned e = W.plane[j][lane], q = e & 255u;
+                        const unsigned e = W.plane[j][lane], q = (e >> 5) & 255u;
                         unsigned aq;
                         if (slot < (unsigned)B.n_slots) { aq = sAdjC[slot * 128u + (q & 127u)]; KC2_PIN(aq); }
                         else aq = T->adjc[(rinfo & 255u) * 256u + (q & 255u)];
                         if (KC2_CLS(e) != 7u) {
-                            W.plane[j][lane] = (uint16_t)((128u + aq) | (e & 0xff00u));
+                            W.plane[j][lane] = (uint16_t)(((128u + aq) << 5) | (e & 0x1fu));
                             if (ANYPRES) {
                                 const unsigned pv = (unsigned)sPv[q & 127u], cl = KC2_CLS(e);
                                 if (pv) { st.cp |= 1u << cl; if (pv > 1u) st.cp |= (1u << cl) << 8; }
@@ -775,13 +679,38 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
             unsigned vn[4];
             #pragma unroll
             for (int u = 0; u < 4; u++) vn[u] = basep[u * 64];
-            /* (two instances of the row loop: a pass without a '*' / N entry takes the shorter row routine) */
-#if KC2_TWO_LOOPS
-            if (pass_odd) { KC2_CONSUME_LOOP(KC2_ROW); } else { KC2_CONSUME_LOOP(KC2_ROW_PLAIN); }
+#ifdef KC2_EXP_NOCONSUME
+            for (int j0 = 0; j0 < 4 && j0 < steps4; j0 += 4) {
 #else
-            (void)pass_odd;
-            KC2_CONSUME_LOOP(KC2_ROW);
+            for (int j0 = 0; j0 < steps4; j0 += 4) {
 #endif
+                unsigned ve[4];
+                double rMM[4], r_M[4], rom[4];
+                unsigned rpv[4];
+                #pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    ve[u] = vn[u];
+#ifdef KC2_EXP_NOCONFLICT    /* diagnostic build (wrong results): every lane reads ONE table row -- no LDS bank conflicts */
+                    const double *rw = (const double *)(rowbase + ((ve[u] & 0u) | (37u << 5)));
+#else
+                    const double *rw = (const double *)(rowbase + (ve[u] & KC2_ROWMASK));
+#endif
+                    rMM[u] = rw[0]; r_M[u] = rw[1]; rom[u] = rw[2];
+                    if (ANYPRES) memcpy(&rpv[u], &rw[3], 4); else rpv[u] = 0;
+                }
+                if (j0 + 4 < steps4) {
+                    #pragma unroll
+                    for (int u = 0; u < 4; u++) vn[u] = basep[(j0 + 4 + u) * 64];
+                }
+                #pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    KC2_ROW(ve[u], rMM[u], r_M[u], rom[u]);
+                    /* call_preserve bits, snp:611-623: the table row's bits at the entry's class.  Class 7 -- no entry,
+                     * its row index may point anywhere, past the table too: hence the mask -- lands on bits 7 and 15,
+                     * dropped after the last pass */
+                    if (ANYPRES) st.cp |= (rpv[u] & 0x101u) << KC2_CLS(ve[u]);
+                }
+            }
             WAVE_SYNC();                                                 /* the next group / pass overwrites plane / recs */
             KC2_STAMP(3);
             }

@@ -1242,19 +1242,25 @@ k_scan_overdepth(int L, uint32_t *colrec, const int32_t *nplp, const int32_t *tr
     const int nep = *n_ep;
     const double od = P->over_depth;
     ScanVal carry = partial[blockIdx.x];
+    /* four consecutive columns per thread (16-byte loads, one wave scan and two barriers per 1024 columns); the next
+     * round's loads are issued before this round's barriers */
+    uint4 r4n = {0, 0, 0, 0};
+    int4 n4n = {0, 0, 0, 0}, t4n = {0, 0, 0, 0};
+#define KSO_LOAD(i0_) do { \
+        const int j0_ = (i0_); \
+        r4n.x = r4n.y = r4n.z = r4n.w = 0u; n4n.x = n4n.y = n4n.z = n4n.w = 0; t4n = n4n; \
+        if (j0_ + 3 < L) { r4n = *(const uint4 *)(colrec + j0_); n4n = *(const int4 *)(nplp + j0_); t4n = *(const int4 *)(trigcnt + j0_); } \
+        else if (j0_ < L) { \
+            r4n.x = colrec[j0_]; n4n.x = nplp[j0_]; t4n.x = trigcnt[j0_]; \
+            if (j0_ + 1 < L) { r4n.y = colrec[j0_ + 1]; n4n.y = nplp[j0_ + 1]; t4n.y = trigcnt[j0_ + 1]; } \
+            if (j0_ + 2 < L) { r4n.z = colrec[j0_ + 2]; n4n.z = nplp[j0_ + 2]; t4n.z = trigcnt[j0_ + 2]; } \
+        } } while (0)
+    KSO_LOAD(base + 4 * (int)threadIdx.x);
     for (int k = 0; k < chunk / 1024; k++) {
-        /* four consecutive columns per thread (16-byte loads, one wave scan and two barriers per 1024 columns) */
         const int i0 = base + k * 1024 + 4 * (int)threadIdx.x;
-        uint32_t rec[4] = {0, 0, 0, 0};
-        int n[4] = {0, 0, 0, 0}, tcv[4] = {0, 0, 0, 0};
-        if (i0 + 3 < L) {
-            const uint4 r4 = *(const uint4 *)(colrec + i0);
-            const int4 n4 = *(const int4 *)(nplp + i0), t4 = *(const int4 *)(trigcnt + i0);
-            rec[0] = r4.x; rec[1] = r4.y; rec[2] = r4.z; rec[3] = r4.w;
-            n[0] = n4.x; n[1] = n4.y; n[2] = n4.z; n[3] = n4.w;
-            tcv[0] = t4.x; tcv[1] = t4.y; tcv[2] = t4.z; tcv[3] = t4.w;
-        } else
-            for (int u = 0; u < 4; u++) if (i0 + u < L) { rec[u] = colrec[i0 + u]; n[u] = nplp[i0 + u]; tcv[u] = trigcnt[i0 + u]; }
+        const uint32_t rec[4] = {r4n.x, r4n.y, r4n.z, r4n.w};
+        const int n[4] = {n4n.x, n4n.y, n4n.z, n4n.w}, tcv[4] = {t4n.x, t4n.y, t4n.z, t4n.w};
+        if (k + 1 < chunk / 1024) KSO_LOAD(i0 + 1024);
         ScanVal v[4], tot = {0, 0, 0, 0, 0, 0, 0};
         #pragma unroll
         for (int u = 0; u < 4; u++) { scanval_of(rec[u], n[u], tcv[u], v[u]); if (i0 + u >= L) { const ScanVal z = {0, 0, 0, 0, 0, 0, 0}; v[u] = z; } scanval_add(tot, v[u]); }
@@ -1280,6 +1286,7 @@ k_scan_overdepth(int L, uint32_t *colrec, const int32_t *nplp, const int32_t *tr
         }
         for (int j = 0; j < (int)(blockDim.x >> 6); j++) scanval_add(carry, ws[j]);
     }
+#undef KSO_LOAD
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1287,10 +1294,14 @@ k_scan_overdepth(int L, uint32_t *colrec, const int32_t *nplp, const int32_t *tr
  * insertion only.  One thread per such column. */
 __global__ void __launch_bounds__(64)
 k_inshist(DBatch B, const DParams *P, int n_ins_, const int *n_dev, const int *spec_abort, const int32_t *inscol_pos,
-          uint32_t *colrec, const int32_t *nplp, u64 *stats, int gshift)     /* (statistics: columns < B.stat_hi) */
+          uint32_t *colrec, const int32_t *nplp, u64 *stats, int gshift, const ScanVal *totals)     /* (statistics: columns < B.stat_hi) */
 {
     if (LIST_ABORTED(spec_abort)) return;
     const int n_ins = LIST_N(n_ins_, n_dev);
+    if (totals) {                                          /* fast path: the host has not seen the scan's totals */
+        const int64_t mean_depth = totals->cols > 0 ? totals->depth / totals->cols : 0;
+        gshift = mean_depth < 40 ? 4 : 6;
+    }
     /* a group of 1 << gshift lanes per column, lanes over its candidate reads: the whole 64-lane workgroup on a deep
      * pileup; 16 lanes -- four columns per wave -- when a column has a few dozen candidates (the kernel waits on chains
      * of dependent loads: a quarter of the waves, the same chains) */
