@@ -1136,9 +1136,10 @@ extern "C" int crumble_hip_run_finish(crumble_hip *h)
             else {
                 if (pv) RFAST_LAUNCH2(false, true); else RFAST_LAUNCH2(false, false);
                 if (h->n_general_max > 0) {
-                    /* four waves per workgroup, a read per wave at a time; no more workgroups than the chip holds at once */
+                    /* sixteen reads per workgroup at a time (RR_GL lanes each); no more workgroups than the chip holds at once */
                     const unsigned gmax = h->persistent_blocks / 4 * 6 > 0 ? h->persistent_blocks / 4 * 6 : 1u;
-                    const unsigned gg = (unsigned)((h->n_general_max + 3) / 4 < (int64_t)gmax ? (h->n_general_max + 3) / 4 : gmax);
+                    const int64_t rpb = 256 / RR_GL;
+                    const unsigned gg = (unsigned)((h->n_general_max + rpb - 1) / rpb < (int64_t)gmax ? (h->n_general_max + rpb - 1) / rpb : gmax);
                     if (fused_stats) CRUMBLE_LAUNCH(k_replay_reads<true>, gg, 256, st, B, P, colrec, h->d_genlist.as<int32_t>(), h->d_misc.as<int>() + 12,
                                                     h->d_out.as<uint8_t>(), forcebits, stats);
                     else             CRUMBLE_LAUNCH(k_replay_reads<false>, gg, 256, st, B, P, colrec, h->d_genlist.as<int32_t>(), h->d_misc.as<int>() + 12,

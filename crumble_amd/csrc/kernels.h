@@ -1431,36 +1431,50 @@ __device__ __forceinline__ unsigned nt16_to_str2(unsigned c16)
     return (c16 == 2) ? 1u : (c16 == 4) ? 2u : (c16 == 8) ? 3u : 0u;
 }
 
-/* add_rep (str_finder.c:34-127) without pads; the utlist list is an ordered array whose
- * tail element is mirrored in registers (ts, te): most calls end at the "already covered by
- * the tail" test or append without touching older elements */
-__device__ __forceinline__ int dev_add_rep(const StrWin &w, int len, int pos, int rlen,
-                                           short *st, short *en, int n, int &ts, int &te, int *overflow)
+/* add_rep (str_finder.c:34-127) without pads; the utlist list is an ordered array (entry = start | end << 16) whose
+ * tail element is mirrored in registers (ts, te): most calls end at the "already covered by the tail" test or append
+ * without touching older elements.  Three parts: the covered test, the extension of the repeat to the right
+ * (str_finder.c:62-75; by bytes here, by whole words of the equality masks in dev_find_STR), the list update. */
+#define STR_ENT(st_, en_) ((unsigned)(st_) | ((unsigned)(en_) << 16))
+#define STR_ENT_ST(e_)    ((int)((e_) & 0xffffu))
+#define STR_ENT_EN(e_)    ((int)((e_) >> 16))
+__device__ __forceinline__ bool str_rep_covered(int n, int ts, int te, int pos, int rlen)
 {
-    if (n && ts <= pos - rlen * 2 + 1 && te >= pos) return n;                /* :41-45 */
-    int cp1 = pos + 1 - rlen, cp2 = pos + 1;
-    while (cp2 < len && str_code(w, cp1) == str_code(w, cp2)) { cp1++; cp2++; }  /* :62-75 */
-    const int el_end = cp2 - 1, el_start = pos + 1 - 2 * rlen;
+    return n && ts <= pos - rlen * 2 + 1 && te >= pos;                       /* :41-45 */
+}
+__device__ __forceinline__ int str_rep_insert(unsigned *lst, int n, int &ts, int &te, int el_start, int el_end, int *overflow)
+{
     if (n && te >= el_start) {                          /* :106-122 (the walk stops at once otherwise) */
         int cur = n - 1;
+        int cs = ts, ce = te;                           /* the tail's entry is in registers */
         for (;;) {
             const bool was_head = (cur == 0);
             int prev = was_head ? n - 1 : cur - 1;      /* head->prev is the tail */
             bool deleted = false;
-            if (en[cur] < el_start) break;
-            if (st[cur] >= el_start) {
-                for (int k = cur; k < n - 1; k++) { st[k] = st[k + 1]; en[k] = en[k + 1]; }
+            if (ce < el_start) break;
+            if (cs >= el_start) {
+                for (int k = cur; k < n - 1; k++) lst[k] = lst[k + 1];
                 n--; deleted = true;
             }
             if (was_head && !deleted) break;
             if (!n) break;
             if (was_head) prev = n - 1;
             cur = prev;
+            const unsigned e = lst[cur];
+            cs = STR_ENT_ST(e); ce = STR_ENT_EN(e);
         }
     }
-    if (n < STR_CAP) { st[n] = (short)el_start; en[n] = (short)el_end; n++; ts = el_start; te = el_end; }
+    if (n < STR_CAP) { lst[n] = STR_ENT(el_start, el_end); n++; ts = el_start; te = el_end; }
     else *overflow = 1;
     return n;
+}
+__device__ __forceinline__ int dev_add_rep(const StrWin &w, int len, int pos, int rlen,
+                                           unsigned *lst, int n, int &ts, int &te, int *overflow)
+{
+    if (str_rep_covered(n, ts, te, pos, rlen)) return n;
+    int cp1 = pos + 1 - rlen, cp2 = pos + 1;
+    while (cp2 < len && str_code(w, cp1) == str_code(w, cp2)) { cp1++; cp2++; }  /* :62-75 */
+    return str_rep_insert(lst, n, ts, te, pos + 1 - 2 * rlen, cp2 - 1, overflow);
 }
 
 /* find_STR (str_finder.c:135-189).  From position 15 on, the reference asks at every position i for
@@ -1474,7 +1488,7 @@ __device__ __forceinline__ int dev_add_rep(const StrWin &w, int len, int pos, in
  * repeats that start at or after its own start, so what is found more than 15 positions to the right of that zone
  * neither is kept nor evicts anything that is (the extension of a repeat to the right still reads the whole
  * window). */
-__device__ __forceinline__ int dev_find_STR(const StrWin &w, int len, short *st, short *en, int *overflow, int pos_limit)
+__device__ __forceinline__ int dev_find_STR(const StrWin &w, int len, unsigned *lst, int *overflow, int pos_limit)
 {
     int n = 0, ts = 0, te = -1;
     uint32_t word = 0;
@@ -1484,14 +1498,15 @@ __device__ __forceinline__ int dev_find_STR(const StrWin &w, int len, short *st,
             if (i < 2 * rlen - 1) break;
             const uint32_t mask = (1u << (2 * rlen)) - 1;
             if ((word & mask) == ((word >> (2 * rlen)) & mask))
-                n = dev_add_rep(w, len, i, rlen, st, en, n, ts, te, overflow);
+                n = dev_add_rep(w, len, i, rlen, lst, n, ts, te, overflow);
         }
     }
     /* D[p-1]: equality with the code p positions back, for the previous word (needed for runs that
      * cross the word boundary) */
     uint32_t Dp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t x0p = 0, x1p = 0;                              /* planes of the previous word */
-    int nw = (len + 31) >> 5;
+    const int nwords = (len + 31) >> 5;
+    int nw = nwords;
     if (pos_limit < 0) nw = 0;
     else if ((pos_limit >> 5) + 1 < nw) nw = (pos_limit >> 5) + 1;
     for (int wi = 0; wi < nw; wi++) {
@@ -1516,10 +1531,9 @@ __device__ __forceinline__ int dev_find_STR(const StrWin &w, int len, short *st,
             E[p - 1] = r;
             Dp[p - 1] = D;
         }
-        x0p = x0; x1p = x1;
         uint32_t any = E[0] | E[1] | E[2] | E[3] | E[4] | E[5] | E[6] | E[7];
         if (wi == 0) any &= ~0x7fffu;                       /* positions 0..14 were handled above */
-        if (wi == ((len + 31) >> 5) - 1 && (len & 31)) any &= (1u << (len & 31)) - 1u;
+        if (wi == nwords - 1 && (len & 31)) any &= (1u << (len & 31)) - 1u;
         if (wi == (pos_limit >> 5) && (pos_limit & 31) != 31) any &= (2u << (pos_limit & 31)) - 1u;
         while (any) {
             const int b = __builtin_ctz(any);
@@ -1527,8 +1541,37 @@ __device__ __forceinline__ int dev_find_STR(const StrWin &w, int len, short *st,
             const uint32_t bit = 1u << b;
             const int rl = (E[7] & bit) ? 8 : (E[6] & bit) ? 7 : (E[5] & bit) ? 6 : (E[4] & bit) ? 5
                          : (E[3] & bit) ? 4 : (E[2] & bit) ? 3 : (E[1] & bit) ? 2 : 1;
-            n = dev_add_rep(w, len, wi * 32 + b, rl, st, en, n, ts, te, overflow);
+            const int pos = wi * 32 + b;
+            if (str_rep_covered(n, ts, te, pos, rl)) continue;
+            /* the repeat runs on to the right while x[i] == x[i - rl] (str_finder.c:62-75): the ones of this period's
+             * equality mask behind bit b, word by word (a byte loop through LDS before: two dependent reads per
+             * position).  Codes behind the window's end read as 0: the count is cut at len. */
+            int ext;
+            {
+                const uint32_t s0 = (x0 << rl) | (x0p >> (32 - rl)), s1 = (x1 << rl) | (x1p >> (32 - rl));
+                const uint32_t D = ~((x0 ^ s0) | (x1 ^ s1));
+                const int room = 31 - b;
+                const uint32_t m = room ? (D >> (b + 1)) : 0u;
+                const uint32_t z = ~m;
+                ext = z ? __builtin_ctz(z) : 32;
+                if (ext >= room) {
+                    ext = room;
+                    uint32_t y0 = x0, y1 = x1;
+                    for (int wj = wi + 1; wj < nwords; wj++) {
+                        const uint32_t n0 = w.w[wj * 64], n1 = w.w[(STR_PW + wj) * 64];
+                        const uint32_t t0 = (n0 << rl) | (y0 >> (32 - rl)), t1 = (n1 << rl) | (y1 >> (32 - rl));
+                        const uint32_t zn = (n0 ^ t0) | (n1 ^ t1);                      /* ~D of the next word */
+                        const int c = zn ? __builtin_ctz(zn) : 32;
+                        ext += c;
+                        if (c < 32) break;
+                        y0 = n0; y1 = n1;
+                    }
+                }
+                if (ext > len - 1 - pos) ext = len - 1 - pos;
+            }
+            n = str_rep_insert(lst, n, ts, te, pos + 1 - 2 * rl, pos + ext, overflow);
         }
+        x0p = x0; x1p = x1;
     }
     return n;
 }
@@ -1584,7 +1627,7 @@ __device__ __forceinline__ int dev_ref2query_seg(const Seg *__restrict__ segs, i
 __device__ inline void dev_mask_lc(const DBatch &B, const DParams *P, int r, int rpos, int is_indel,
                                    int *min_pos, int *max_pos, int *overflow, unsigned *lds_lane)
 {
-    short st[STR_CAP], en[STR_CAP];
+    unsigned lst[STR_CAP];                                 /* start | end << 16 */
     const int64_t so = B.seq_off[r];
     const int lq = (int)(B.seq_off[r + 1] - so);
     const uint8_t *bases = B.bases + so;
@@ -1632,16 +1675,26 @@ __device__ inline void dev_mask_lc(const DBatch &B, const DParams *P, int r, int
     StrWin w; w.w = lds_lane;
     const int add = is_indel ? P->iSTR_add : P->sSTR_add;
     const int64_t lim = (int64_t)rpos + (add > 0 ? add : 0) - start + 15;
-    const int n = dev_find_STR(w, len, st, en, overflow, lim > len ? len : (int)lim);
+#ifdef KSTR_EXP_NOFIND       /* diagnostic build (wrong results): the window staging alone */
+    const int n = (lds_lane[0] == 0x12345u) ? 1 : 0; lst[0] = 0;
+#else
+    const int n = dev_find_STR(w, len, lst, overflow, lim > len ? len : (int)lim);
+#endif
     const uint32_t *cig = B.cigar + B.cig_off[r];
     const int nc = (int)(B.cig_off[r + 1] - B.cig_off[r]);
-    for (int i = 0; i < n; i++) {
-        int s = st[i] + start, e = en[i] + start;
-        if (!(rpos + add >= s && rpos - add <= e)) continue;
-        s = dev_qpos2rpos(cig, nc, B.pos[r], s);
-        e = dev_qpos2rpos(cig, nc, B.pos[r], e);
-        if (*min_pos > s) *min_pos = s;
-        if (*max_pos < e) *max_pos = e;
+    for (int i0 = 0; i0 < n; i0 += 4) {                    /* (four entries' loads in flight) */
+        unsigned e4[4];
+        #pragma unroll
+        for (int u = 0; u < 4; u++) e4[u] = i0 + u < n ? lst[i0 + u] : 0xffffu;       /* (start 65535: never kept) */
+        #pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int s = STR_ENT_ST(e4[u]) + start, e = STR_ENT_EN(e4[u]) + start;
+            if (i0 + u >= n || !(rpos + add >= s && rpos - add <= e)) continue;
+            s = dev_qpos2rpos(cig, nc, B.pos[r], s);
+            e = dev_qpos2rpos(cig, nc, B.pos[r], e);
+            if (*min_pos > s) *min_pos = s;
+            if (*max_pos < e) *max_pos = e;
+        }
     }
 }
 
@@ -2508,6 +2561,7 @@ k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
     }
 }
 
+#define RR_GL 16
 /* STATS: this pass is the one writer of the general-CIGAR reads' bytes (k_replay_fast leaves them out of its count) */
 template <bool STATS>
 __global__ void __launch_bounds__(256)
@@ -2516,17 +2570,19 @@ k_replay_reads(DBatch B, const DParams *__restrict__ P, const uint32_t *__restri
                uint8_t *__restrict__ out, const uint32_t *__restrict__ forcebits,
                u64 *__restrict__ stats)
 {
-    /* one wave per general-CIGAR read of the list the upload made (k_p0_fill; it used to find them by scanning
-     * every read record: 0.34 ms on the chr20 set for 3 % of the reads) */
+    /* RR_GL lanes per general-CIGAR read of the list the upload made (k_p0_fill; it used to find them by scanning
+     * every read record: 0.34 ms on the chr20 set for 3 % of the reads).  A read is a chain of dependent look-ups
+     * (list -> record -> op table -> column records) in front of a few dozen bytes of work: four reads share a wave
+     * so that four chains run side by side (a wave per read: 0.46 ms on the chr20 set) */
     __shared__ unsigned hist[STATS ? 256 : 1];
     unsigned cnt_chg = 0;
     if (STATS) { for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0; __syncthreads(); }
-    const int lane = threadIdx.x & 63;
+    const int gl = threadIdx.x & (RR_GL - 1);
     const int qcap = P->qcap, qhigh = P->qhigh, qlow = P->qlow;
     const bool reduce = P->reduce_qual != 0, binary = P->binary_qual != 0, any_pres = P->any_preserve != 0;
     const int ng = *n_gen;
-    const int nw = (int)(gridDim.x * (blockDim.x >> 6));
-    for (int gi = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); gi < ng; gi += nw) {
+    const int nw = (int)(gridDim.x * (blockDim.x / RR_GL));
+    for (int gi = (int)(blockIdx.x * (blockDim.x / RR_GL) + (threadIdx.x / RR_GL)); gi < ng; gi += nw) {
         const int64_t rs = gen_list[gi];
         const ReadRec rr = B.rr[rs];
         if (!(rr.lq > 0 && rr.end > rr.pos && !(rr.info & RR_SIMPLE))) continue;
@@ -2535,7 +2591,7 @@ k_replay_reads(DBatch B, const DParams *__restrict__ P, const uint32_t *__restri
         const int64_t s0 = rr.so;
         const int64_t sg0 = B.seg_off[rs];
         const int nsg = (int)(B.seg_off[rs + 1] - sg0);
-        for (int x0 = lane; x0 < n; x0 += 256) {               /* four bases per lane: the gathers of all four in flight */
+        for (int x0 = gl; x0 < n; x0 += 4 * RR_GL) {           /* four bases per lane: the gathers of all four in flight */
             /* the column of every base from the read's op table (a few ops, wave-uniform look-ups): -1 no column, -2 a
              * D/N column reports this base (k_replay_slow, afterwards).  (Rounds 1-3 read this from a base -> column
              * table written at upload: 4 bytes per base of every general read and a kernel of its own.) */
@@ -2544,7 +2600,7 @@ k_replay_reads(DBatch B, const DParams *__restrict__ P, const uint32_t *__restri
             bool f4[4];
             #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int x = x0 + 64 * u;
+                const int x = x0 + RR_GL * u;
                 c4[u] = -1; q4[u] = 0; b4[u] = 0; f4[u] = false;
                 if (x < n) {
                     q4[u] = B.quals[s0 + x]; b4[u] = B.bases[s0 + x];
@@ -2557,18 +2613,18 @@ k_replay_reads(DBatch B, const DParams *__restrict__ P, const uint32_t *__restri
                 const int col0 = rr.pos + sg.roff - B.p0;
                 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const int off = x0 + 64 * u - sg.qstart;
+                    const int off = x0 + RR_GL * u - sg.qstart;
                     if (isM) { if (off >= 0 && off < seg_len(sg) && c4[u] != -2) c4[u] = col0 + off; }
                     else if (off == 0) c4[u] = -2;
                 }
             }
             #pragma unroll
-            for (int u = 0; u < 4; u++) if (x0 + 64 * u >= n) c4[u] = -1;
+            for (int u = 0; u < 4; u++) if (x0 + RR_GL * u >= n) c4[u] = -1;
             #pragma unroll
             for (int u = 0; u < 4; u++) r4[u] = c4[u] >= 0 ? colrec[c4[u]] : 0u;
             #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int x = x0 + 64 * u;
+                const int x = x0 + RR_GL * u;
                 if (x >= n) continue;
                 const uint32_t q0 = q4[u];
                 const uint32_t capq = any_pres ? (uint32_t)cap_q2(P, qcap, true, (uint8_t)q0) : (q0 > (uint32_t)qcap ? (uint32_t)qcap : q0);
