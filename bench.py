@@ -452,7 +452,11 @@ def main():
                     help="metric (ii), BAM file -> crumble-hip -> BAM file (SURVEY.md 8d), on the WHOLE contig (the default line "
                          "runs it on a quarter of it); an extra 'end_to_end' object, never part of 'value'")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end leg")
+    ap.add_argument("--profile", action="store_true", help="the timed steps and nothing else (rocprofv3 runs: no CPU legs, no "
+                    "verification, no small-contig probe, no end_to_end, no other_configs -- every launch in the trace is a step's)")
     args = ap.parse_args()
+    if args.profile:
+        args.no_cpu = args.no_verify = args.no_e2e = args.no_other_configs = True
     label, d_preset, d_tech, d_bed = WORKLOADS[args.workload]
     preset = args.preset if args.preset is not None else d_preset
     tech = (None if args.tech == "none" else args.tech) if args.tech is not None else d_tech
@@ -802,7 +806,7 @@ def main():
                     "sample": f"{cores} independent windows of {per} reads of the same contig, one process per core "
                               f"(contigs / windows are the independent unit), {wall:.1f} s wall",
                 }
-        if world == 1:
+        if world == 1 and not args.profile:
             try:
                 out["small_contig"] = measure_small_contig(ca, synth, local_rank, preset=args.preset or 5)
             except Exception as ex:                # noqa: BLE001

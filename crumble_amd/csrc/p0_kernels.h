@@ -535,7 +535,9 @@ __global__ void k_p0_qualcheck(int64_t nb, const uint8_t *__restrict__ quals, in
  * per read as if the whole chunk lay in that read and merged by byte mask.  Workgroups whose bases belong to more than
  * P0B_MAXR reads (reads of a few bases) take the same steps from global memory. */
 #define P0B_THREADS 256
+#ifndef P0B_CPL
 #define P0B_CPL     4                                  /* 16-base chunks per lane, P0B_THREADS chunks apart (coalesced stores) */
+#endif
 #define P0B_CHUNKS  (P0B_THREADS * P0B_CPL)
 #define P0B_BASES   (P0B_CHUNKS * 16)
 #define P0B_MAXR    512

@@ -10,8 +10,8 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 bash $R/tools/fetch_calib.sh $tag > /dev/null 2>&1
 python3 $R/bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu > $out/${tag}_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -- python3 $R/bench.py --steps 5 --warmup 1 --profile > $out/${tag}_prof.log 2>&1
 # PMC passes on their own (no trace domains), one counter per pass
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --profile > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 --profile > /dev/null 2>&1
 tail -1 $out/${tag}_bench.json

@@ -21,17 +21,26 @@ open(os.path.join(pr, f"{tag}_bench_chr20_full.json"), "w").write(line)
 ks = glob.glob(os.path.join(go, f"{tag}_prof", "*", "*_kernel_stats.csv"))
 if ks:
     shutil.copy(ks[0], os.path.join(pr, f"{tag}_kernel_stats_chr20_full.csv"))
-res = collections.defaultdict(dict)
-for key, sub, ctr in (("FETCH_SIZE_KB_per_launch", "pmc_fetch", "FETCH_SIZE"), ("WRITE_SIZE_KB_per_launch", "pmc_write", "WRITE_SIZE")):
-    tot, n = collections.defaultdict(float), collections.defaultdict(int)
-    for f in glob.glob(os.path.join(go, f"{tag}_{sub}", "*", "*_counter_collection.csv")):
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == ctr:
-                k = short(r["Kernel_Name"])
-                tot[k] += float(r["Counter_Value"]); n[k] += 1
-    for k in tot:
-        res[k][key] = tot[k] / n[k]
-        res[k]["launches"] = n[k]
+def traffic(suffix):
+    """FETCH_SIZE / WRITE_SIZE per launch and kernel from the two --pmc passes gpurun_out/<tag>_pmc_{fetch,write}<suffix>"""
+    res = collections.defaultdict(dict)
+    for key, sub, ctr in (("FETCH_SIZE_KB_per_launch", "pmc_fetch", "FETCH_SIZE"), ("WRITE_SIZE_KB_per_launch", "pmc_write", "WRITE_SIZE")):
+        tot, n = collections.defaultdict(float), collections.defaultdict(int)
+        for f in glob.glob(os.path.join(go, f"{tag}_{sub}{suffix}", "*", "*_counter_collection.csv")):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == ctr:
+                    k = short(r["Kernel_Name"])
+                    tot[k] += float(r["Counter_Value"]); n[k] += 1
+        for k in tot:
+            res[k][key] = tot[k] / n[k]
+            res[k]["launches"] = n[k]
+    return res
+
+
+res = traffic("")
+other = {name: {k: v for k, v in traffic("_" + name).items() if k.startswith("k_columns2") or k.startswith("k_replay_fast")}
+         for name in ("panel", "hifi")}
+other = {k: v for k, v in other.items() if v}
 if res:
     calib = None
     cf = os.path.join(go, f"{tag}_fetch_calib.json")
@@ -43,7 +52,8 @@ if res:
                "(MI355X_MICROARCH.md); tools/fetch_calib.* measured counter / bytes = 0.50 for 16-B streams and for "
                "32-byte records, 0.70 for the column kernel's 20-byte segment loads (which re-touch half of every line "
                "one tile later): bytes moved = 2 x FETCH_SIZE; WRITE_SIZE is exact",
-               "source_sha16": kernel_source_sha(), "fetch_calibration": calib["kernels"] if calib else None, "kernels": res},
+               "source_sha16": kernel_source_sha(), "fetch_calibration": calib["kernels"] if calib else None, "kernels": res,
+               "other_configs": other},
               open(os.path.join(pr, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 # the other configurations: bench line + rocprofv3 kernel stats each
 for name in ("chr20_9", "panel", "hifi_config4"):
@@ -55,16 +65,20 @@ for name in ("chr20_9", "panel", "hifi_config4"):
     ks2 = glob.glob(os.path.join(go, f"{tag}_prof_{name}", "*", "*_kernel_stats.csv"))
     if ks2:
         shutil.copy(ks2[0], os.path.join(pr, f"{tag}_kernel_stats_{name}.csv"))
-# SQ counters of the column kernel, per launch
-sq = collections.defaultdict(lambda: [0.0, 0])
-for f in glob.glob(os.path.join(go, f"{tag}_sq_*", "*", "*_counter_collection.csv")):
-    for r in csv.DictReader(open(f)):
-        if short(r["Kernel_Name"]).startswith("k_columns2"):
-            a = sq[r["Counter_Name"]]
-            a[0] += float(r["Counter_Value"]); a[1] += 1
-if sq:
-    json.dump({"k_columns2": {k: round(v[0] / v[1]) for k, v in sorted(sq.items())},
-               "note": "rocprofv3 --pmc, chr20 30x -5, per launch (wave-level instruction counts; *_CYCLES summed over SEs)",
-               "source_sha16": kernel_source_sha()},
-              open(os.path.join(pr, f"{tag}_sq_counters.json"), "w"), indent=1)
+# SQ counters of the column kernel, per launch: chr20 -5, the 300x panel, config 4
+sqall = {}
+for name in ("chr20", "panel", "hifi"):
+    sq = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(os.path.join(go, f"{tag}_sq_{name}_*", "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if short(r["Kernel_Name"]).startswith("k_columns2"):
+                a = sq[r["Counter_Name"]]
+                a[0] += float(r["Counter_Value"]); a[1] += 1
+    if sq:
+        sqall["k_columns2" if name == "chr20" else "k_columns2_" + name] = {k: round(v[0] / v[1]) for k, v in sorted(sq.items())}
+if sqall:
+    sqall["note"] = ("rocprofv3 --pmc, per launch (wave-level instruction counts; *_CYCLES summed over SEs): k_columns2 = chr20 30x -5, "
+                     "k_columns2_panel = 300x panel -9, k_columns2_hifi = config 4 (HiFi 20x, -y pbccs -R)")
+    sqall["source_sha16"] = kernel_source_sha()
+    json.dump(sqall, open(os.path.join(pr, f"{tag}_sq_counters.json"), "w"), indent=1)
 print(line.strip()[:400])
