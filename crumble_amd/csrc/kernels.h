@@ -2216,15 +2216,20 @@ k_replay_flat(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
  *                     bit  5    window column: capped original (snp:1880)
  *                     bit  6    the column sets a per-read flag (keep_qual / bit 15): rare follow-up
  *                     bit  7    perfect column (a quality preserved at level 1 is not kept there, snp:1885)
+ *   k_readflags     (round 4) the per-read flags BEFORE the pass: keep_qual / flag bit 15 from the columns k_actions
+ *                   marked; a kept read's bytes are marked in forcebits (a bit per base), as k_restore marks the
+ *                   back-fill ranges of the trigger columns there -- so every byte has ONE writer below
  *   k_replay_fast   one lane per 16-byte chunk of the flat base array.  For every single-match read
  *                   that overlaps the chunk, 16 qualities, 16 bases and the 16 action bytes of the
  *                   columns they would sit on are combined with packed byte arithmetic (values < 128
  *                   leave bit 7 free as a guard), ~9 VALU per base instead of ~80, and the bytes of
- *                   that read's aligned part are taken from the result; clips, reads outside the
- *                   pileup and (for now) reads with a general CIGAR keep the input byte.  All loads
- *                   and the store are 16 bytes wide and coalesced.
- *   k_replay_reads  the reads with a general CIGAR (a few %): the wave takes them one at a time,
- *                   one lane per base, through replay_base(). */
+ *                   that read's aligned part are taken from the result; marked bytes (forcebits) take the
+ *                   capped original; clips and reads outside the pileup keep the input byte, reads with a
+ *                   general CIGAR are left alone.  All loads and the store are 16 bytes wide and coalesced.
+ *                   STATS: the output histogram, the changed count and the quality check (input >= 128)
+ *                   are taken on the way -- no separate pass over the bytes (k_stats) when nothing writes later.
+ *   k_replay_reads  the reads with a general CIGAR (a few %): RR_GL lanes per read, four reads per wave,
+ *                   the column of every base from the read's op table. */
 __device__ __forceinline__ unsigned action_of(uint32_t r)
 {
     const bool skip = (r & CR_SKIP) != 0;
