@@ -40,7 +40,9 @@
 #ifndef CRUMBLE_KCOL2_H
 #define CRUMBLE_KCOL2_H
 
-#define KC2_R        64            /* candidates screened per pass = records staged in LDS */
+#ifndef KC2_R
+#define KC2_R        64            /* candidates screened per pass = records staged in LDS (56 with 14 waves: see profiles/NOTES_r04.md) */
+#endif
 #ifndef KC2_PR
 #define KC2_PR       64            /* rows of the matrix (a pass with more hits is produced / consumed in groups) */
 #endif
@@ -477,14 +479,22 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                         r0 = rp[0]; r1 = rp[1];
                         ov = (int)r0.y > c0 && (int)r0.x <= c1;
                     }
-                    const unsigned long long m = __ballot(ov);
-                    const int h = __popcll(m);
-                    if (nq + h > KC2_R) break;
+                    unsigned long long m = __ballot(ov);
+                    int h = __popcll(m), adv = 64;
+                    if (KC2_R < 64 && h > KC2_R) {
+                        /* more hits in the window than the matrix has rows: the first KC2_R of them now, the window
+                         * resumes at the first one left out */
+                        const unsigned long long over = __ballot(ov && __popcll(m & lt) == KC2_R);
+                        adv = __builtin_ctzll(over);
+                        ov = ov && lane < adv;
+                        m &= (1ull << adv) - 1ull;
+                        h = KC2_R;
+                    }
                     const int slot = nq + __popcll(m & lt);
                     bool lowrec = false;
                     KC2_STAGE_HIT();
                     nq += h;
-                    wnext += 64;
+                    wnext += adv;
                     break;
                 }
             }
@@ -584,7 +594,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                     uint4 o0, o1;
                     o0.x = out[0]; o0.y = out[1]; o0.z = out[2]; o0.w = out[3];
                     o1.x = out[4]; o1.y = out[5]; o1.z = out[6]; o1.w = out[7];
-                    dst[0] = o0; dst[1] = o1;
+                    if (KC2_PR % 16 == 0 || row < KC2_PR) { dst[0] = o0; dst[1] = o1; }      /* (a step is sixteen rows) */
                 }
             }
             WAVE_SYNC();

@@ -5,6 +5,6 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 tags=$1; shift
 for tag in $tags; do
   echo "== $tag $*"
-  CRUMBLE_HIP_LIB=$R/build/libcrumble_$tag.so python3 $R/bench.py --steps 5 --warmup 2 --no-cpu --no-verify --no-other-configs --no-e2e "$@" 2>/dev/null | python3 -c "
+  CRUMBLE_HIP_LIB=$R/build/libcrumble_$tag.so timeout 150 python3 $R/bench.py --steps 5 --warmup 2 --no-cpu --no-verify --no-other-configs --no-e2e "$@" 2>/dev/null | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['kernels_ms'])"
 done
