@@ -86,19 +86,20 @@ def test_emu_column_kernel_variants(product, kcol):
     LDS, inline / parked split of the FP64 adds)."""
     eng = emu_lib.with_options(kcol=kcol)
     slow = kcol == "v2"        # k_columns2 under the emulator: a fiber rendezvous per matrix row (emu_lib.engine)
-    hb = synth_batch("chr20", 0.00016 if slow else 0.0004)
+    hb = synth_batch("chr20", 0.0001 if slow else 0.0004)
     emu_lib.fin_counts()
     assert_parity(eng, ca.preset_params(5), hb)
     if slow:                   # k_columns2 finishes a tile one of two ways (cons_finalize_fast / the general path): both ran
         fast, general = emu_lib.fin_counts()
-        assert fast > 20 and general > 5, (fast, general)
+        assert fast > 10 and general > 3, (fast, general)
     if not slow:               # both consensus modes at once: k_columns whatever the option says
         assert_parity(eng, ca.preset_params(5, min_qual_A=30, min_indel_A=60), hb)
-    assert_parity(eng, ca.preset_params(5, min_qual_A=30, min_qual_B=0), hb)
+    if not slow:               # (mode A through k_columns2: test_emu_consensus_modes)
+        assert_parity(eng, ca.preset_params(5, min_qual_A=30, min_qual_B=0), hb)
     assert_parity(eng, ca.preset_params(9, keep="37", perfect_col=1), hb)
-    assert_parity(eng, ca.preset_params(9), synth_batch("panel", 0.001 if kcol != "v2" else 0.0003))
-    assert_parity(eng, ca.preset_params(9, tech="pbccs"), synth_batch("hifi", 0.0001 if slow else 0.0002, read_len=3000))
-    assert_parity(eng, ca.preset_params(1), synth_batch("ce", 0.12 if slow else 0.3))
+    assert_parity(eng, ca.preset_params(9), synth_batch("panel", 0.001 if kcol != "v2" else 0.0002))
+    assert_parity(eng, ca.preset_params(9, tech="pbccs"), synth_batch("hifi", 0.00007 if slow else 0.0002, read_len=3000))
+    assert_parity(eng, ca.preset_params(1), synth_batch("ce", 0.08 if slow else 0.3))
 
 
 def test_emu_indel_only(product):
@@ -240,11 +241,11 @@ def test_emu_run_paths(product):
     """crumble_hip_run's fast way (lists sized by guess, lengths on the device), the careful way (sized from a
     read-back) and the fast way with capacities too small for the batch (aborted by the scan, repeated carefully)
     give the oracle's bytes, flags, statistics and column records."""
-    cases = ((ca.preset_params(5), synth_batch("chr20", 0.0004, err_indel=2e-3)),
-             (ca.preset_params(9, tech="pbccs"), synth_batch("hifi", 0.0001, read_len=3000)),
-             (ca.preset_params(1), synth_batch("ce", 0.2)))
-    for p, hb in cases:
-        for opts in ({"run": "careful"}, {"run": "fast"}, {"run": "fast", "caps": 3}, {"run": "fast", "caps": 3, "kcol": "v2"}):
+    cases = ((ca.preset_params(5), synth_batch("chr20", 0.0002, err_indel=2e-3)),
+             (ca.preset_params(9, tech="pbccs"), synth_batch("hifi", 0.00007, read_len=3000)),
+             (ca.preset_params(1), synth_batch("ce", 0.1)))
+    for i, (p, hb) in enumerate(cases):
+        for opts in ({"run": "careful"}, {"run": "fast"}, {"run": "fast", "caps": 3}) + (({"run": "fast", "caps": 3, "kcol": "v2"},) if i == 0 else ()):
             assert_parity(emu_lib.with_options(**opts), p, hb)
     # one engine: an aborted fast run, then batches that fit
     eng = emu_lib.engine(ca.preset_params(5), caps=2)
