@@ -163,6 +163,38 @@ def test_emu_rerun_and_engine_reuse(product):
     eng.close()
 
 
+def _expand_and_host_buffers(make_engine, library, hb, p):
+    """crumble_hip_expand() re-runs the device-side pileup construction on the raw arrays an upload left on the device
+    (what bench.py times per step): any number of times, same result; crumble_hip_host_alloc() buffers are ordinary
+    destinations of a download; expand without a batch is an error, not a crash."""
+    import oracle_lib as O
+    eng = make_engine(p)
+    want = O.contig(p, hb)
+    eng.upload(hb); eng.run()
+    got = eng.download()
+    assert all(np.array_equal(x, y) for x, y in zip(got, want))
+    eng.expand(); eng.run()
+    assert all(np.array_equal(x, y) for x, y in zip(eng.download(), want))
+    eng.expand(); eng.expand(); eng.run(); eng.run()
+    qa, qp = ca.pinned_array(max(hb.n_bases, 1), np.uint8, library=library)
+    fa, fp = ca.pinned_array(max(hb.n_reads, 1), np.uint8, library=library)
+    try:
+        qa[:] = 0xEE; fa[:] = 0xEE
+        q, f, s = eng.download(out=(qa, fa))
+        assert np.array_equal(q, want[0]) and np.array_equal(f, want[1]) and np.array_equal(s, want[2])
+    finally:
+        ca.pinned_free(qp, library=library); ca.pinned_free(fp, library=library)
+    eng.close()
+    fresh = make_engine(p)
+    with pytest.raises(Exception):
+        fresh.expand()
+    fresh.close()
+
+
+def test_emu_expand_and_host_buffers(product):
+    _expand_and_host_buffers(emu_lib.engine, emu_lib.load(), synth_batch("chr20", 0.00012), ca.preset_params(5))
+
+
 def test_emu_packed_bases(product):
     """crumble_batch.bases4 (BAM's two codes per byte, unpacked on the device by k_p0_unpack4) gives what the
     one-code-per-byte form gives: short and long reads, odd lengths, tiny and empty reads, the unmapped tail."""

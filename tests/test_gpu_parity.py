@@ -392,3 +392,10 @@ def test_rerun_and_engine_reuse(product):
         want = O.contig(p, hb)
         assert all(np.array_equal(x, y) for x, y in zip(got, want))
     eng.close()
+
+
+def test_expand_and_host_buffers(product):
+    """crumble_hip_expand (the step bench.py times = expand + run) and crumble_hip_host_alloc through the HIP build"""
+    from test_emu_parity import _expand_and_host_buffers
+    _expand_and_host_buffers(lambda q: ca.Engine(q, 0), None, synth_batch("chr20", 0.01), ca.preset_params(5))
+    _expand_and_host_buffers(lambda q: ca.Engine(q, 0), None, synth_batch("hifi", 0.002), ca.preset_params(9, tech="pbccs"))
