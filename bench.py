@@ -431,7 +431,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="contig length scale (1.0 = BASELINE config)")
     ap.add_argument("--preset", type=int, default=None, help="crumble -[1-9] (default: the workload's)")
     ap.add_argument("--tech", default=None, help="crumble -y (default: the workload's; 'none' disables)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--cpu-all", action="store_true", help="(default now) also time the CPU restatement on all host "
@@ -761,7 +761,7 @@ def main():
     if rank == 0:
         # ---- parity of the TIMED result + CPU baseline on a bounded prefix of the same workload ----
         import oracle_lib as O
-        ns_per_base = 60e-9
+        ns_per_base = 20e-9                      # (the restatement runs at ~0.05 Gbases/s on the GPU boxes' hosts)
         n_sample_bases = args.cpu_seconds / ns_per_base
         n_sample = int(min(hb.n_reads, max(1000, n_sample_bases / max(1, hb.n_bases / max(1, hb.n_reads)))))
         sample = prefix_batch(hb, n_sample)
