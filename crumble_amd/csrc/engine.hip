@@ -559,7 +559,8 @@ static int expand(crumble_hip *h, bool wait)
     h->col_perm = h->raw_lowerr;
     if (h->opt_kcol == 1 || h->opt_kcol == 2) h->col_perm = h->opt_kcol == 2;
     h->b_kcol = h->opt_kcol; h->b_pblock = h->opt_pblock;
-    h->n_segrec = tot.nseg; h->n_slow = tot.nslow;  /* upper bound; the exact count is d_nslow */
+    if (tot.nslow > 0x7fffffffll) { g_last_error = "crumble_hip_upload: more than 2^31 bases under D/N ops"; return CRUMBLE_EINVAL; }
+    h->n_segrec = tot.nseg; h->n_slow = tot.nslow;  /* the list's length: a slot per D/N op with a base to report (empty slots: read -1) */
     h->n_general_max = tot.ngen;                    /* general-CIGAR reads with bases (d_nslow[1] on the device) */
 
     /* 2. expanded tables */
@@ -601,7 +602,7 @@ static int expand(crumble_hip *h, bool wait)
             CRUMBLE_LAUNCH(k_p0_fill_long, nblk(n, 4), 256, st, n, nb, B.p0, h->d_pos.as<int32_t>(), h->d_mapq.as<uint8_t>(),
                            h->d_seq_off.as<int64_t>(), h->d_cig_off.as<int64_t>(), h->d_cigar.as<uint32_t>(), h->d_inplp.as<uint8_t>(),
                            h->d_end.as<int32_t>(), cnt, h->d_segs.as<Seg>(), h->d_sr.as<SegRec>(), h->d_rr.as<ReadRec>(),
-                           h->d_seg_off.as<int64_t>(), h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(), d_nslow,
+                           h->d_seg_off.as<int64_t>(), h->d_slow_g.as<int64_t>(), h->d_slow_r.as<int32_t>(),
                            h->d_mqslot.as<uint8_t>(), h->d_blk_read.as<int32_t>(), vrp, h->d_chunk_read.as<int32_t>(), h->hparams.min_mqual);
         } else FILL_LAUNCH(1);
 #undef FILL_LAUNCH

@@ -2680,7 +2680,7 @@ __global__ void k_replay_slow(DBatch B, const DParams *__restrict__ P, const uin
     __shared__ unsigned chg_all;
     if (STATS) { for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0; if (threadIdx.x == 0) chg_all = 0; __syncthreads(); }
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < *n_slow) {
+    if (t < *n_slow && slow_r[t] >= 0) {                   /* (-1: a slot whose base another D/N op reports) */
         const int64_t g = slow_g[t];
         uint8_t v = replay_base(B, P, colrec, pos_mn2, g, slow_r[t], keepf, b15f);
         if (forcebits && ((forcebits[g >> 5] >> (g & 31)) & 1u)) v = cap_q2(P, P->qcap, P->any_preserve != 0, B.quals[g]) & 0x7f;

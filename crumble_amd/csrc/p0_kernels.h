@@ -215,7 +215,7 @@ template <bool LONG>
 __device__ __forceinline__ void p0_emit_op(const P0Op &o, int64_t r, int ncg, const uint32_t *__restrict__ cig, int rpos, int rend, int64_t so, int lq,
                                            unsigned mq, unsigned slot, int nseg, int64_t segbase, int64_t cixu, int p0,
                                            Seg *__restrict__ segs, SegRec *__restrict__ sr, ReadRec *__restrict__ rr,
-                                           int64_t *__restrict__ slow_g, int32_t *__restrict__ slow_r, int *__restrict__ n_slow,
+                                           int64_t *__restrict__ slow_g, int32_t *__restrict__ slow_r, int64_t slow_slot,
                                            VRec *__restrict__ vr, int32_t *__restrict__ chunk_vr, int64_t nb, int hcol)
 {
     const uint32_t ty = (o.op == 2) ? SEG_D : (o.op == 3) ? SEG_N : SEG_M;
@@ -243,7 +243,10 @@ __device__ __forceinline__ void p0_emit_op(const P0Op &o, int64_t r, int ncg, co
         rr[r] = x;
     }
     /* bases that D/N columns report (htslib shows them the NEXT base): once per base -- a D/N op behind another one
-     * with no query base in between reports the same base */
+     * with no query base in between reports the same base.  Every such op owns ONE slot of the list (slow_slot: the
+     * read's slice from the scan of k_p0_classify's counts + the op's ordinal among the read's D/N ops), a repeated
+     * base leaves its slot empty (read -1): no counter shared by all reads -- an atomic add per entry on one word was
+     * 0.4 ms of the chr20 expansion and 2.3 ms of config 4's */
     if (ty != SEG_M && o.y0 < lq) {
         bool dup = false;
         for (int j = o.k - 1; j >= 0; j--) {
@@ -252,7 +255,7 @@ __device__ __forceinline__ void p0_emit_op(const P0Op &o, int64_t r, int ncg, co
             if (p0_is_query(oj)) break;
             if (oj == 2 || oj == 3) { dup = true; break; }
         }
-        if (!dup) { const int w = atomicAdd(n_slow, 1); slow_g[w] = so + o.y0; slow_r[w] = (int32_t)r; }
+        slow_g[slow_slot] = so + o.y0; slow_r[slow_slot] = dup ? -1 : (int32_t)r;
     }
     if (LONG && vr) {
         /* the op's territory (VRec, dev_common.h): from its first query base up to the next reference op's */
@@ -301,7 +304,7 @@ k_p0_fill(int64_t n, int64_t nb, int p0, const int32_t *__restrict__ pos, const 
           int32_t *__restrict__ genlist, int *__restrict__ n_gen, const uint8_t *__restrict__ mq_slot,
           int32_t *__restrict__ blk_read, VRec *__restrict__ vr, int32_t *__restrict__ chunk_vr, int min_mqual, int *__restrict__ err)
 {
-    __shared__ int w_ns[16], w_ps[16], w_en[16], w_gn[16];
+    __shared__ int w_ns[16], w_ps[16], w_en[16], w_gn[16], w_sl[16];
     __shared__ long long w_cx[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -312,7 +315,7 @@ k_p0_fill(int64_t n, int64_t nb, int p0, const int32_t *__restrict__ pos, const 
     const bool in = live && inplp[r] != 0;
     const int rpos = live ? pos[r] : 0, rend = live ? end[r] : 0;
     const int ps = in ? rpos : INT_MIN, en = in ? rend : INT_MIN;
-    const int i_ns = kc2_scan_add(c.nseg), i_ps = kc2_scan_max(ps), i_en = kc2_scan_max(en);
+    const int i_ns = kc2_scan_add(c.nseg), i_ps = kc2_scan_max(ps), i_en = kc2_scan_max(en), i_sl = kc2_scan_add(c.nslow);
     long long i_cx = c.ncixu;
     #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const long long o = __shfl_up(i_cx, d); if (lane >= d) i_cx += o; }
@@ -321,14 +324,15 @@ k_p0_fill(int64_t n, int64_t nb, int p0, const int32_t *__restrict__ pos, const 
     /* general-CIGAR reads with bases are the ones with table entries: their list (k_p0_cix, k_replay_reads) in file order */
     const bool general = c.ncixu > 0;
     const unsigned long long gm = __ballot(general);
-    if (lane == 63) { w_ns[w] = i_ns; w_ps[w] = i_ps; w_en[w] = i_en; w_cx[w] = i_cx; w_gn[w] = __popcll(gm); }
+    if (lane == 63) { w_ns[w] = i_ns; w_ps[w] = i_ps; w_en[w] = i_en; w_cx[w] = i_cx; w_gn[w] = __popcll(gm); w_sl[w] = i_sl; }
     __syncthreads();
     const P0Part pb = part[blockIdx.x];
     int64_t o_ns = pb.nseg + (i_ns - c.nseg), o_cx = pb.ncixu + (i_cx - c.ncixu);
     int64_t o_gn = pb.ngen + __popcll(gm & ((1ull << lane) - 1ull));
+    int64_t o_sl = pb.nslow + (i_sl - c.nslow);             /* the read's slice of the list of bases under D/N ops */
     int k_ps = pb.maxpos, k_en = pb.maxend;
     for (int j = 0; j < w; j++) {
-        o_ns += w_ns[j]; o_cx += w_cx[j]; o_gn += w_gn[j];
+        o_ns += w_ns[j]; o_cx += w_cx[j]; o_gn += w_gn[j]; o_sl += w_sl[j];
         k_ps = w_ps[j] > k_ps ? w_ps[j] : k_ps; k_en = w_en[j] > k_en ? w_en[j] : k_en;
     }
     x_ps = x_ps > k_ps ? x_ps : k_ps;
@@ -340,8 +344,8 @@ k_p0_fill(int64_t n, int64_t nb, int p0, const int32_t *__restrict__ pos, const 
         lq = (int)(seq_off[r + 1] - so);
         if (in && rpos < x_ps) atomicMax(err, P0_ERR_UNSORTED);            /* snp:1075 */
         seg_off[r] = o_ns; kpos[r] = k_ps; kend[r] = k_en;
-        if (r == n - 1) { seg_off[n] = part[nblocks].nseg; *n_gen = (int)part[nblocks].ngen; }
-        if (GW == 0) cnt[r].pad = (int32_t)(uint32_t)o_cx;                    /* k_p0_fill_long takes it from there */
+        if (r == n - 1) { seg_off[n] = part[nblocks].nseg; *n_gen = (int)part[nblocks].ngen; *n_slow = (int)part[nblocks].nslow; }
+        if (GW == 0) { cnt[r].pad = (int32_t)(uint32_t)o_cx; cnt[r].nslow = (int32_t)o_sl; }   /* k_p0_fill_long takes them from there */
         if (general && genlist) genlist[o_gn] = (int32_t)r;
         if (!in) {                                         /* never in the pileup: only the epilogue touches it */
             ReadRec x;
@@ -370,12 +374,14 @@ k_p0_fill(int64_t n, int64_t nb, int p0, const int32_t *__restrict__ pos, const 
             const int hcol = ((int)mq <= min_mqual) ? rpos - p0 : -1;
             P0Op o;
             o.x0 = 0; o.y0 = 0; o.si = 0;
+            int dn = 0;                                    /* D/N ops with a base to report so far (k_p0_classify's count) */
             for (int k = 0; k < ncg; k++) {
                 o.k = k; o.op = cig[k] & 15; o.l = (int)(cig[k] >> 4);
                 if (p0_is_mdnx(o.op)) {
                     if (o.l > 0) {
                         p0_emit_op<false>(o, r, ncg, cig, rpos, rend, so, lq, mq, slot, c.nseg, o_ns, o_cx, p0, segs, sr, rr,
-                                          slow_g, slow_r, n_slow, vr, chunk_vr, nb, hcol);
+                                          slow_g, slow_r, o_sl + dn, vr, chunk_vr, nb, hcol);
+                        if ((o.op == 2 || o.op == 3) && o.y0 < lq) dn++;
                         o.si++;
                     }
                     o.x0 += o.l;
@@ -396,7 +402,7 @@ k_p0_fill_long(int64_t n, int64_t nb, int p0, const int32_t *__restrict__ pos, c
                const uint32_t *__restrict__ cigar, const uint8_t *__restrict__ inplp,
                const int32_t *__restrict__ end, const P0Cnt32 *__restrict__ cnt,
                Seg *__restrict__ segs, SegRec *__restrict__ sr, ReadRec *__restrict__ rr, const int64_t *__restrict__ seg_off,
-               int64_t *__restrict__ slow_g, int32_t *__restrict__ slow_r, int *__restrict__ n_slow,
+               int64_t *__restrict__ slow_g, int32_t *__restrict__ slow_r,
                const uint8_t *__restrict__ mq_slot, int32_t *__restrict__ blk_read, VRec *__restrict__ vr,
                int32_t *__restrict__ chunk_vr, int min_mqual)
 {
@@ -412,13 +418,13 @@ k_p0_fill_long(int64_t n, int64_t nb, int p0, const int32_t *__restrict__ pos, c
     if (!inplp[ri]) return;
     const P0Cnt32 c = cnt[ri];
     const int rpos_i = pos[ri], rend_i = end[ri], nseg_i = c.nseg;
-    const int64_t ons_i = seg_off[ri], ocx_i = (int64_t)(uint32_t)c.pad;
+    const int64_t ons_i = seg_off[ri], ocx_i = (int64_t)(uint32_t)c.pad, osl_i = (int64_t)(uint32_t)c.nslow;
     const int64_t co = cig_off[ri];
     const uint32_t *cig = cigar + co;
     const int ncg = (int)(cig_off[ri + 1] - co);
     const unsigned mq = mapq[ri], slot = mq_slot[mq];
     const int hcol = ((int)mq <= min_mqual) ? rpos_i - p0 : -1;
-    int cx0 = 0, cy0 = 0, cs0 = 0;
+    int cx0 = 0, cy0 = 0, cs0 = 0, cd0 = 0;
     for (int k0 = 0; k0 < ncg; k0 += 64) {
         const int k = k0 + lane;
         P0Op o;
@@ -430,10 +436,12 @@ k_p0_fill_long(int64_t n, int64_t nb, int p0, const int32_t *__restrict__ pos, c
         const int ds = (isref && o.l > 0) ? 1 : 0;
         const int ix = kc2_scan_add(dx), iy = kc2_scan_add(dy), is = kc2_scan_add(ds);
         o.x0 = cx0 + ix - dx; o.y0 = cy0 + iy - dy; o.si = cs0 + is - ds;
+        const int dd = (ds && (o.op == 2 || o.op == 3) && o.y0 < lq_i) ? 1 : 0;      /* a D/N op with a base to report */
+        const int id = kc2_scan_add(dd);
         if (ds)
             p0_emit_op<true>(o, ri, ncg, cig, rpos_i, rend_i, so_i, lq_i, mq, slot, nseg_i, ons_i, ocx_i, p0, segs, sr, rr,
-                             slow_g, slow_r, n_slow, vr, chunk_vr, nb, hcol);
-        cx0 += __shfl(ix, 63); cy0 += __shfl(iy, 63); cs0 += __shfl(is, 63);
+                             slow_g, slow_r, osl_i + cd0 + id - dd, vr, chunk_vr, nb, hcol);
+        cx0 += __shfl(ix, 63); cy0 += __shfl(iy, 63); cs0 += __shfl(is, 63); cd0 += __shfl(id, 63);
     }
 }
 
