@@ -516,7 +516,7 @@ static int expand(crumble_hip *h, bool wait)
         (e = h->d_p0cnt.reserve((size_t)(n + 1) * sizeof(P0Cnt32))) ||
         (e = h->d_p0part.reserve((size_t)(nblocks + 2) * sizeof(P0Part))) || (e = h->d_misc.reserve(256)))
         return e;
-    int *d_err = h->d_misc.as<int>() + 8, *d_minmax = d_err + 1, *d_nslow = d_err + 3, *d_herr = h->d_misc.as<int>() + 15;
+    int *d_err = h->d_misc.as<int>() + 8, *d_nslow = d_err + 3, *d_herr = h->d_misc.as<int>() + 15;
     static const int init[8] = {0, INT_MAX, INT_MIN, 0, 0, 0, 0, 0};   /* error, min pos, max end, n_slow, n_general, -, -, hit-list check */
     HIPCHK(hipMemcpyAsync(d_err, init, sizeof init, hipMemcpyHostToDevice, st));
     P0Cnt32 *cnt = h->d_p0cnt.as<P0Cnt32>();
@@ -527,13 +527,14 @@ static int expand(crumble_hip *h, bool wait)
     if (n > 0) {
         CRUMBLE_LAUNCH(k_p0_classify, nblk(n, P0_CHUNK), P0_CHUNK, st, n, (int)tid, h->d_pos.as<int32_t>(),
                        h->d_flag.as<uint16_t>(), h->d_seq_off.as<int64_t>(), h->d_cig_off.as<int64_t>(),
-                       h->d_cigar.as<uint32_t>(), h->d_inplp.as<uint8_t>(), h->d_end.as<int32_t>(), cnt, part, d_err, d_minmax, nb, nc);
+                       h->d_cigar.as<uint32_t>(), h->d_inplp.as<uint8_t>(), h->d_end.as<int32_t>(), cnt, part, d_err, nb, nc);
         CRUMBLE_LAUNCH(k_p0_mid, 1, 1024, st, part, nblocks);
         HIPCHK(hipMemcpyAsync(h->pinned, part + nblocks, sizeof tot, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync((char *)h->pinned + 64, d_err, sizeof res, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));               /* sizes of the expanded tables (and: the caller may free its host buffers) */
         memcpy(&tot, h->pinned, sizeof tot);
         memcpy(res, (char *)h->pinned + 64, sizeof res);
+        res[1] = tot.minpos; res[2] = tot.maxend;      /* the batch's extent: the scan's totals (no atomics) */
     } else HIPCHK(hipStreamSynchronize(st));
     switch (res[0]) {
     case 0: break;

@@ -30,7 +30,8 @@
 struct P0Cnt32 { int32_t nseg, ncixu /* base -> column entries, in units of CIX_UNIT */, nslow, pad; };
 /* per 1024-read block: the block's sums and maxima from k_p0_classify, turned by k_p0_mid into what lies before the block
  * (exclusive sums, prefix maxima); entry [nblocks] holds the totals */
-struct P0Part { int64_t nseg, ncixu, nslow, ngen /* general-CIGAR reads with bases */; int32_t maxpos, maxend; };
+struct P0Part { int64_t nseg, ncixu, nslow, ngen /* general-CIGAR reads with bases */; int32_t maxpos, maxend;
+                int32_t minpos /* smallest start of a read in the pileup: with the totals' maxend, the batch's extent */, pad_; };
 #define P0_CHUNK 1024
 
 #define P0_ERR_NEG      1
@@ -120,7 +121,7 @@ __global__ void __launch_bounds__(1024)
 k_p0_classify(int64_t n, int tid, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
               const int64_t *__restrict__ seq_off, const int64_t *__restrict__ cig_off,
               const uint32_t *__restrict__ cigar, uint8_t *__restrict__ inplp,
-              int32_t *__restrict__ end, P0Cnt32 *__restrict__ cnt, P0Part *__restrict__ part, int *err, int *minmax,
+              int32_t *__restrict__ end, P0Cnt32 *__restrict__ cnt, P0Part *__restrict__ part, int *err,
               int64_t nb, int64_t nc)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -152,10 +153,9 @@ k_p0_classify(int64_t n, int tid, const int32_t *__restrict__ pos, const uint16_
             if (k) { mn = wmn[k] < mn ? wmn[k] : mn; mx = wmx[k] > mx ? wmx[k] : mx; pk = wpk[k] > pk ? wpk[k] : pk; }
             t.nseg += wns[k]; t.ncixu += wcx[k]; t.nslow += wsl[k]; t.ngen += wgn[k];
         }
-        t.maxpos = pk; t.maxend = mx;
-        part[blockIdx.x] = t;
-        if (mn != INT_MAX) atomicMin(&minmax[0], mn);
-        if (mx != INT_MIN) atomicMax(&minmax[1], mx);
+        t.maxpos = pk; t.maxend = mx; t.minpos = mn; t.pad_ = 0;
+        part[blockIdx.x] = t;                              /* (the extent comes out of k_p0_mid's totals: an atomic pair per
+                                                            * workgroup on two words was still most of this kernel's 0.33 ms) */
     }
 }
 
@@ -169,33 +169,36 @@ k_p0_mid(P0Part *part, int nblocks)
     const int per = (nblocks + nt - 1) / nt;
     const int b = t * per, e = b + per < nblocks ? b + per : nblocks;
     P0Part acc;
-    acc.nseg = acc.ncixu = acc.nslow = acc.ngen = 0; acc.maxpos = acc.maxend = INT_MIN;
+    acc.nseg = acc.ncixu = acc.nslow = acc.ngen = 0; acc.maxpos = acc.maxend = INT_MIN; acc.minpos = INT_MAX; acc.pad_ = 0;
     for (int i = b; i < e; i++) {
         const P0Part v = part[i];
         acc.nseg += v.nseg; acc.ncixu += v.ncixu; acc.nslow += v.nslow; acc.ngen += v.ngen;
         acc.maxpos = v.maxpos > acc.maxpos ? v.maxpos : acc.maxpos; acc.maxend = v.maxend > acc.maxend ? v.maxend : acc.maxend;
+        acc.minpos = v.minpos < acc.minpos ? v.minpos : acc.minpos;
     }
     sh[t] = acc;
     __syncthreads();
     for (int d = 1; d < nt; d <<= 1) {                    /* Hillis-Steele inclusive scan of the thread sums */
         P0Part v;
-        v.nseg = v.ncixu = v.nslow = v.ngen = 0; v.maxpos = v.maxend = INT_MIN;
+        v.nseg = v.ncixu = v.nslow = v.ngen = 0; v.maxpos = v.maxend = INT_MIN; v.minpos = INT_MAX; v.pad_ = 0;
         if (t >= d) v = sh[t - d];
         __syncthreads();
         P0Part x = sh[t];
         x.nseg += v.nseg; x.ncixu += v.ncixu; x.nslow += v.nslow; x.ngen += v.ngen;
         x.maxpos = v.maxpos > x.maxpos ? v.maxpos : x.maxpos; x.maxend = v.maxend > x.maxend ? v.maxend : x.maxend;
+        x.minpos = v.minpos < x.minpos ? v.minpos : x.minpos;
         sh[t] = x;
         __syncthreads();
     }
     P0Part run;
-    run.nseg = run.ncixu = run.nslow = run.ngen = 0; run.maxpos = run.maxend = INT_MIN;
+    run.nseg = run.ncixu = run.nslow = run.ngen = 0; run.maxpos = run.maxend = INT_MIN; run.minpos = INT_MAX; run.pad_ = 0;
     if (t > 0) run = sh[t - 1];
     for (int i = b; i < e; i++) {
         const P0Part v = part[i];
         part[i] = run;
         run.nseg += v.nseg; run.ncixu += v.ncixu; run.nslow += v.nslow; run.ngen += v.ngen;
         run.maxpos = v.maxpos > run.maxpos ? v.maxpos : run.maxpos; run.maxend = v.maxend > run.maxend ? v.maxend : run.maxend;
+        run.minpos = v.minpos < run.minpos ? v.minpos : run.minpos;
     }
     if (t == nt - 1) part[nblocks] = sh[nt - 1];
 }
