@@ -333,13 +333,16 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=3)
         b[:] = a
         pins.append(p_)
         return b
-    originals = []
+    originals = []                                  # (restored before the page-locked blocks are freed)
     for b_ in batches:
-        originals.append((b_.quals, b_.bases))
+        saved = {}
         for nm in ("pos", "mapq", "flag", "seq_off", "cig_off", "cigar", "quals"):
-            setattr(b_, nm, pin(getattr(b_, nm)))
+            saved[nm] = getattr(b_, nm)
+            setattr(b_, nm, pin(saved[nm]))
         if getattr(b_, "bases4", None) is not None:
+            saved["bases4"] = b_.bases4
             b_.bases4 = pin(b_.bases4)
+        originals.append(saved)
     max_nb, max_n = max(b_.n_bases for b_ in batches), max(b_.n_reads for b_ in batches)
     out_bufs = {id(e): (pin(np.zeros(max(1, max_nb), np.uint8)), pin(np.zeros(max(1, max_n), np.uint8))) for e in engines}
     k_small = int(np.argmin([b_.n_bases for b_ in batches]))
@@ -418,6 +421,11 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=3)
     finally:
         for e in engines:
             e.close()
+        for b_, saved in zip(batches, originals):   # no array of a batch may point into freed page-locked memory
+            for nm, a in saved.items():
+                setattr(b_, nm, a)
+        out_bufs.clear()
+        kept.clear()
         for p_ in pins:
             ca.pinned_free(p_)
 
@@ -455,6 +463,10 @@ def main():
     ap.add_argument("--profile", action="store_true", help="the timed steps and nothing else (rocprofv3 runs: no CPU legs, no "
                     "verification, no small-contig probe, no end_to_end, no other_configs -- every launch in the trace is a step's)")
     args = ap.parse_args()
+    if not args.profile and any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        # under a profiler every launch should be a timed step's, and no child process should inherit the preload
+        print("bench: profiler preload detected: running as --profile (timed steps only)", file=sys.stderr)
+        args.profile = True
     if args.profile:
         args.no_cpu = args.no_verify = args.no_e2e = args.no_other_configs = True
     label, d_preset, d_tech, d_bed = WORKLOADS[args.workload]

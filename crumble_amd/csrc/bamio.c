@@ -6,7 +6,7 @@
  *
  * Layout decisions (host side of an HBM-resident engine):
  *  - a contig's records are inflated straight into ONE growing byte buffer (`raw`), never copied
- *    again: the SoA views handed to the engine are built from it by an OpenMP team, the engine's
+ *    again: the SoA views handed to the engine are built from it by a team of host threads (team.h), the engine's
  *    quality bytes are scattered back into it, and the same buffer is deflated for output;
  *  - BGZF blocks are independent deflate streams, so both directions are a parallel-for over blocks
  *    with a prefix sum over the (known) block sizes; file reads/writes stay sequential.
@@ -18,10 +18,11 @@
 #include <errno.h>
 #include <stdarg.h>
 #include <zlib.h>
-#include <omp.h>
+#include <unistd.h>
 #include <sys/mman.h>
 #include <pthread.h>
 #include "../../include/crumble_bamio.h"
+#include "team.h"
 
 static char g_err[512];          /* process-wide: the record scan may run on any thread of the team */
 const char *crumble_bam_last_error(void) { return g_err; }
@@ -151,7 +152,7 @@ void  crumble_bam_big_free(void *p, size_t n) { big_free(p, n); }
 #include <sched.h>
 static int default_threads(void)
 {
-    int n = omp_get_max_threads();
+    int n = (int)sysconf(_SC_NPROCESSORS_ONLN);
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0 && c < n) n = c; }
     FILE *fp = fopen("/sys/fs/cgroup/cpu.max", "r");
@@ -176,6 +177,7 @@ static int default_threads(void)
 struct crumble_bam_reader {
     FILE *fp;
     int threads;
+    team *tm;                                 /* the reader's own team (idle workers sleep: team.h); NULL in a detached group */
     uint8_t *cbuf; size_t clen, ccap;        /* compressed bytes not yet inflated  */
     int eof_file;
     /* the uncompressed stream window: [0, raw_len) valid, scan = parse position     */
@@ -214,6 +216,61 @@ static int raw_reserve(crumble_bam_reader *r, size_t need)
 
 /* Appends more uncompressed bytes to raw.  Returns 1 if bytes were added, 0 at EOF, < 0 on error. */
 static void scan_records(crumble_bam_reader *r);
+
+/* one piece of a refill: BGZF blocks [lo, hi) inflated and CRC-checked into the record buffer.  Every thread of the
+ * team keeps one inflate state (team slot), reset per block. */
+typedef struct { z_stream zs; int zok; void *ldd; } inflate_tls;
+static void inflate_tls_free(void *p_)
+{
+    inflate_tls *p = p_;
+    if (p->ldd) LD.free_decompressor(p->ldd);
+    if (p->zok) inflateEnd(&p->zs);
+    free(p);
+}
+typedef struct {
+    crumble_bam_reader *r; const blk_t *blk; uint8_t *dst; int use_ld, side;
+    atomic_int side_taken_done;     /* `side`: the first thread to arrive walks the records that are already there */
+    atomic_int bad;
+} inflate_job;
+static void inflate_blocks(void *ctx, int64_t lo, int64_t hi, int tid)
+{
+    inflate_job *j = ctx;
+    crumble_bam_reader *r = j->r;
+    const blk_t *blk = j->blk;
+    uint8_t *dst = j->dst;
+    int bad = 0;
+    if (j->side && !atomic_exchange(&j->side_taken_done, 1)) {
+        /* the sequential walk over the records inflated so far costs about as much as one round of inflate: one
+         * thread does it while the others start on the blocks */
+        scan_records(r);
+    }
+    team *t = r->tm;                                    /* (every reader has one) */
+    inflate_tls *tl = t->slot[tid];
+    if (!tl) {
+        tl = calloc(1, sizeof *tl);
+        if (!tl) { atomic_fetch_or(&j->bad, 1); return; }
+        tl->ldd = j->use_ld ? LD.alloc_decompressor() : NULL;
+        tl->zok = tl->ldd ? 0 : inflateInit2(&tl->zs, -15) == Z_OK;
+        t->slot[tid] = tl;
+    }
+    for (int64_t i = lo; i < hi; i++) {
+        if (blk[i].ulen == 0) continue;
+        if (tl->ldd) {
+            size_t got = 0;
+            if (LD.deflate_decompress(tl->ldd, r->cbuf + blk[i].coff, blk[i].clen, dst + blk[i].uoff, blk[i].ulen, &got) != 0 ||
+                got != blk[i].ulen) bad |= 2;
+            if (LD.crc32(0, dst + blk[i].uoff, blk[i].ulen) != blk[i].crc) bad |= 4;
+            continue;
+        }
+        if (!tl->zok || inflateReset(&tl->zs) != Z_OK) { bad |= 1; continue; }
+        tl->zs.next_in = r->cbuf + blk[i].coff; tl->zs.avail_in = (uInt)blk[i].clen;
+        tl->zs.next_out = dst + blk[i].uoff;    tl->zs.avail_out = (uInt)blk[i].ulen;
+        const int zr = inflate(&tl->zs, Z_FINISH);
+        if (zr != Z_STREAM_END || tl->zs.avail_out != 0) bad |= 2;
+        if (crc32(crc32(0L, Z_NULL, 0), dst + blk[i].uoff, (uInt)blk[i].ulen) != blk[i].crc) bad |= 4;
+    }
+    if (bad) atomic_fetch_or(&j->bad, bad);
+}
 
 /* `side`: run scan_records() on the bytes that are already there while the team inflates the new chunk */
 static int refill(crumble_bam_reader *r, int side)
@@ -275,37 +332,11 @@ static int refill(crumble_bam_reader *r, int side)
         int bad = 0;
         const double ti = now_s();
         const int use_ld = ld_ready();
-        #pragma omp parallel num_threads(r->threads) reduction(|:bad)
-        {
-            z_stream zs; memset(&zs, 0, sizeof zs);            /* one inflate state per thread, reset per block */
-            void *ldd = use_ld ? LD.alloc_decompressor() : NULL;
-            const int zok = ldd ? 1 : inflateInit2(&zs, -15) == Z_OK;
-            if (side) {
-                /* the sequential walk over the records inflated so far costs about as much as one
-                 * round of inflate: one thread does it while the others start on the blocks */
-                #pragma omp single nowait
-                scan_records(r);
-            }
-            #pragma omp for schedule(dynamic, 4)
-            for (size_t i = 0; i < nb; i++) {
-                if (blk[i].ulen == 0) continue;
-                if (ldd) {
-                    size_t got = 0;
-                    if (LD.deflate_decompress(ldd, r->cbuf + blk[i].coff, blk[i].clen, dst + blk[i].uoff, blk[i].ulen, &got) != 0 ||
-                        got != blk[i].ulen) bad |= 2;
-                    if (LD.crc32(0, dst + blk[i].uoff, blk[i].ulen) != blk[i].crc) bad |= 4;
-                    continue;
-                }
-                if (!zok || inflateReset(&zs) != Z_OK) { bad |= 1; continue; }
-                zs.next_in = r->cbuf + blk[i].coff; zs.avail_in = (uInt)blk[i].clen;
-                zs.next_out = dst + blk[i].uoff;    zs.avail_out = (uInt)blk[i].ulen;
-                const int zr = inflate(&zs, Z_FINISH);
-                if (zr != Z_STREAM_END || zs.avail_out != 0) bad |= 2;
-                if (crc32(crc32(0L, Z_NULL, 0), dst + blk[i].uoff, (uInt)blk[i].ulen) != blk[i].crc) bad |= 4;
-            }
-            if (ldd) LD.free_decompressor(ldd);
-            else if (zok) inflateEnd(&zs);
-        }
+        inflate_job job = { r, blk, dst, use_ld, side, 0 };
+        atomic_init(&job.bad, 0);
+        team_run(r->tm, (int64_t)nb, 4, inflate_blocks, &job);
+        if (side && !atomic_load(&job.side_taken_done)) scan_records(r);     /* (no block at all: nobody took the walk) */
+        bad = atomic_load(&job.bad);
         free(blk);
         T_inflate += now_s() - ti;
         if (bad) return fail(CRUMBLE_BAM_EFORMAT, "BGZF inflate/CRC failure (mask %d)", bad);
@@ -338,6 +369,9 @@ crumble_bam_reader *crumble_bam_open(const char *path, int threads, int *err)
     crumble_bam_reader *r = calloc(1, sizeof *r);
     if (!r) { e = fail(CRUMBLE_BAM_ENOMEM, "out of memory"); goto bad; }
     r->threads = threads > 0 ? threads : default_threads();
+    r->tm = team_create(r->threads);
+    if (!r->tm) { e = fail(CRUMBLE_BAM_ENOMEM, "out of memory"); goto bad; }
+    r->tm->slot_free = inflate_tls_free;
     r->fp = fopen(path, "rb");
     if (!r->fp) { e = fail(CRUMBLE_BAM_EIO, "%s: %s", path, strerror(errno)); goto bad; }
     int rc;
@@ -381,6 +415,7 @@ void crumble_bam_close(crumble_bam_reader *r)
 {
     if (!r) return;
     if (r->fp) fclose(r->fp);
+    team_destroy(r->tm);
     free(r->cbuf); big_free(r->raw, r->raw_cap); free(r->text);
     if (r->ref_name) for (int32_t i = 0; i < r->n_ref; i++) free(r->ref_name[i]);
     free(r->ref_name); free(r->ref_len); free(r->rec_off);
@@ -460,6 +495,42 @@ static void scan_records(crumble_bam_reader *r)
     T_scan += now_s() - t0;
 }
 
+/* records [lo, hi) of the current group -> the SoA arrays */
+typedef struct { crumble_bam_reader *r; atomic_int unsupported; } unpack_job;
+static void unpack_records(void *ctx, int64_t lo, int64_t hi, int tid)
+{
+    unpack_job *uj = ctx;
+    crumble_bam_reader *r = uj->r;
+    int unsupported = 0;
+    (void)tid;
+    for (int64_t i = lo; i < hi; i++) {
+        const uint8_t *p = r->raw + r->rec_off[i];
+        const uint32_t lname = p[F_LNAME], ncig = le16(p + F_NCIG);
+        const int32_t lseq = (int32_t)le32(p + F_LSEQ);
+        r->pos[i] = (int32_t)le32(p + F_POS);
+        r->mapq[i] = p[F_MAPQ];
+        r->flag[i] = le16(p + F_FLAG);
+        const uint8_t *cg = p + F_FIXED + lname;
+        uint32_t *co = r->cigar + r->cig_off[i];
+        uint32_t nlong = 0;
+        const uint8_t *lc = ncig == 2 ? long_cigar(p, &nlong) : NULL;
+        if (lc) { if ((int64_t)nlong != r->cig_off[i + 1] - r->cig_off[i]) unsupported |= 1; else for (uint32_t k = 0; k < nlong; k++) co[k] = le32(lc + 4 * k); }
+        else for (uint32_t k = 0; k < ncig; k++) co[k] = le32(cg + 4 * k);
+        const uint8_t *sq = cg + 4 * (size_t)ncig;
+        if (r->packed4) memcpy(r->bases + CRUMBLE_BASES4_OFF(r->seq_off[i], i), sq, ((size_t)lseq + 1) / 2);   /* as they are */
+        else {
+            uint8_t *bo = r->bases + r->seq_off[i];
+            for (int32_t k = 0; k + 1 < lseq; k += 2) { const uint8_t v = sq[k >> 1]; bo[k] = v >> 4; bo[k + 1] = v & 15; }
+            if (lseq & 1) bo[lseq - 1] = sq[lseq >> 1] >> 4;
+        }
+        const uint8_t *ql = sq + ((size_t)lseq + 1) / 2;
+        uint8_t *qo = r->quals + r->seq_off[i];
+        if (lseq > 0 && ql[0] == 0xff) memset(qo, 0, (size_t)lseq);     /* absent qualities */
+        else memcpy(qo, ql, (size_t)lseq);
+    }
+    if (unsupported) atomic_fetch_or(&uj->unsupported, unsupported);
+}
+
 int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
 {
     /* drop the previous group (or the header) from the window: only the offset moves; the bytes are
@@ -521,32 +592,10 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
     int unsupported = 0;
     const double tu0 = now_s();
     T_prefix += tu0 - tp0;
-    #pragma omp parallel for schedule(static) num_threads(r->threads) reduction(|:unsupported)
-    for (int64_t i = 0; i < n; i++) {
-        const uint8_t *p = r->raw + r->rec_off[i];
-        const uint32_t lname = p[F_LNAME], ncig = le16(p + F_NCIG);
-        const int32_t lseq = (int32_t)le32(p + F_LSEQ);
-        r->pos[i] = (int32_t)le32(p + F_POS);
-        r->mapq[i] = p[F_MAPQ];
-        r->flag[i] = le16(p + F_FLAG);
-        const uint8_t *cg = p + F_FIXED + lname;
-        uint32_t *co = r->cigar + r->cig_off[i];
-        uint32_t nlong = 0;
-        const uint8_t *lc = ncig == 2 ? long_cigar(p, &nlong) : NULL;
-        if (lc) { if ((int64_t)nlong != r->cig_off[i + 1] - r->cig_off[i]) unsupported |= 1; else for (uint32_t k = 0; k < nlong; k++) co[k] = le32(lc + 4 * k); }
-        else for (uint32_t k = 0; k < ncig; k++) co[k] = le32(cg + 4 * k);
-        const uint8_t *sq = cg + 4 * (size_t)ncig;
-        if (r->packed4) memcpy(r->bases + CRUMBLE_BASES4_OFF(r->seq_off[i], i), sq, ((size_t)lseq + 1) / 2);   /* as they are */
-        else {
-            uint8_t *bo = r->bases + r->seq_off[i];
-            for (int32_t k = 0; k + 1 < lseq; k += 2) { const uint8_t v = sq[k >> 1]; bo[k] = v >> 4; bo[k + 1] = v & 15; }
-            if (lseq & 1) bo[lseq - 1] = sq[lseq >> 1] >> 4;
-        }
-        const uint8_t *ql = sq + ((size_t)lseq + 1) / 2;
-        uint8_t *qo = r->quals + r->seq_off[i];
-        if (lseq > 0 && ql[0] == 0xff) memset(qo, 0, (size_t)lseq);     /* absent qualities */
-        else memcpy(qo, ql, (size_t)lseq);
-    }
+    unpack_job uj = { r, 0 };
+    atomic_init(&uj.unsupported, 0);
+    team_run(r->tm, n, 0, unpack_records, &uj);
+    unsupported = atomic_load(&uj.unsupported);
     T_unpack += now_s() - tu0;
     if (unsupported) return fail(CRUMBLE_BAM_EFORMAT, "inconsistent CG tag");
     memset(b, 0, sizeof *b);
@@ -604,6 +653,7 @@ void crumble_bam_group_free(crumble_bam_group *gg)
 #define BLK_IN 0xff00u                       /* uncompressed bytes per block (htslib's choice too) */
 struct crumble_bam_writer {
     FILE *fp; int level, threads; uint8_t *obuf; size_t ocap;
+    team *tm;                          /* the writer's own team (team.h); NULL inside a crumble_hts (purge settings only) */
     /* purge_tags (snp_score.c:989-1054) */
     int aux_mode;                      /* 0 none, 1 whitelist (-t), 2 blacklist (-T) */
     uint8_t *aux_set;                  /* 65536-bit set of two-character tags */
@@ -613,6 +663,53 @@ struct crumble_bam_writer {
 };
 
 static const uint8_t BGZF_EOF[28] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+
+/* one piece of a round of output: blocks [lo, hi) of the round deflated into their slots.  Every thread of the team
+ * keeps one compressor (team slot). */
+typedef struct { z_stream zs; int zok; void *ldc; } deflate_tls;
+static void deflate_tls_free(void *p_)
+{
+    deflate_tls *p = p_;
+    if (p->ldc) LD.free_compressor(p->ldc);
+    if (p->zok) deflateEnd(&p->zs);
+    free(p);
+}
+typedef struct { crumble_bam_writer *w; const uint8_t *data; size_t len, b0; size_t *osz; int use_ld; atomic_int bad; } deflate_job;
+static void deflate_blocks(void *ctx, int64_t lo, int64_t hi, int tid)
+{
+    deflate_job *j = ctx;
+    crumble_bam_writer *w = j->w;
+    const uint8_t *data = j->data;
+    const size_t len = j->len, SLOT = 65536;
+    deflate_tls *tl = w->tm->slot[tid];
+    if (!tl) {
+        tl = calloc(1, sizeof *tl);
+        if (!tl) { atomic_store(&j->bad, 1); for (int64_t i = lo; i < hi; i++) j->osz[i] = 0; return; }
+        /* (zlib level 0 = stored blocks: libdeflate's level 0 is the same; the levels above it mean about the same effort) */
+        tl->ldc = j->use_ld ? LD.alloc_compressor(w->level < 0 ? 6 : w->level > 12 ? 12 : w->level) : NULL;
+        w->tm->slot[tid] = tl;
+    }
+    for (int64_t i = lo; i < hi; i++) {
+        const size_t off = (j->b0 + (size_t)i) * BLK_IN, ul = len - off < BLK_IN ? len - off : BLK_IN;
+        uint8_t *o = w->obuf + (size_t)i * SLOT;
+        j->osz[i] = 0;
+        size_t cl = tl->ldc ? LD.deflate_compress(tl->ldc, data + off, ul, o + 18, SLOT - 18 - 8) : 0;
+        if (!cl) {                                      /* zlib (no libdeflate, or the one block it could not fit) */
+            if (!tl->zok) { if (deflateInit2(&tl->zs, w->level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { atomic_store(&j->bad, 1); continue; } tl->zok = 1; }
+            if (deflateReset(&tl->zs) != Z_OK) { atomic_store(&j->bad, 1); continue; }
+            tl->zs.next_in = (Bytef *)(data + off); tl->zs.avail_in = (uInt)ul;
+            tl->zs.next_out = o + 18; tl->zs.avail_out = (uInt)(SLOT - 18 - 8);
+            if (deflate(&tl->zs, Z_FINISH) != Z_STREAM_END) { atomic_store(&j->bad, 1); continue; }
+            cl = tl->zs.total_out;
+        }
+        static const uint8_t hdr[16] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0 };
+        memcpy(o, hdr, 16);
+        put16(o + 16, (uint16_t)(18 + cl + 8 - 1));
+        put32(o + 18 + cl, tl->ldc ? LD.crc32(0, data + off, ul) : (uint32_t)crc32(crc32(0L, Z_NULL, 0), data + off, (uInt)ul));
+        put32(o + 18 + cl + 4, (uint32_t)ul);
+        j->osz[i] = 18 + cl + 8;
+    }
+}
 
 /* deflates data[0..len) as consecutive BGZF blocks and writes them */
 static int bgzf_write(crumble_bam_writer *w, const uint8_t *data, size_t len)
@@ -632,36 +729,10 @@ static int bgzf_write(crumble_bam_writer *w, const uint8_t *data, size_t len)
         int bad = 0;
         const double td = now_s();
         const int use_ld = ld_ready();
-        #pragma omp parallel num_threads(w->threads) reduction(|:bad)
-        {
-            z_stream zs; memset(&zs, 0, sizeof zs);            /* one deflate state per thread, reset per block */
-            /* (zlib level 0 = stored blocks: libdeflate's level 0 is the same; the levels above it mean about the same effort) */
-            void *ldc = use_ld ? LD.alloc_compressor(w->level < 0 ? 6 : w->level > 12 ? 12 : w->level) : NULL;
-            int zok = 0;
-            #pragma omp for schedule(dynamic, 4)
-            for (size_t i = 0; i < nb; i++) {
-                const size_t off = (b0 + i) * BLK_IN, ul = len - off < BLK_IN ? len - off : BLK_IN;
-                uint8_t *o = w->obuf + i * SLOT;
-                osz[i] = 0;
-                size_t cl = ldc ? LD.deflate_compress(ldc, data + off, ul, o + 18, SLOT - 18 - 8) : 0;
-                if (!cl) {                                      /* zlib (no libdeflate, or the one block it could not fit) */
-                    if (!zok) { if (deflateInit2(&zs, w->level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = 1; continue; } zok = 1; }
-                    if (deflateReset(&zs) != Z_OK) { bad = 1; continue; }
-                    zs.next_in = (Bytef *)(data + off); zs.avail_in = (uInt)ul;
-                    zs.next_out = o + 18; zs.avail_out = (uInt)(SLOT - 18 - 8);
-                    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { bad = 1; continue; }
-                    cl = zs.total_out;
-                }
-                static const uint8_t hdr[16] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0 };
-                memcpy(o, hdr, 16);
-                put16(o + 16, (uint16_t)(18 + cl + 8 - 1));
-                put32(o + 18 + cl, ldc ? LD.crc32(0, data + off, ul) : (uint32_t)crc32(crc32(0L, Z_NULL, 0), data + off, (uInt)ul));
-                put32(o + 18 + cl + 4, (uint32_t)ul);
-                osz[i] = 18 + cl + 8;
-            }
-            if (ldc) LD.free_compressor(ldc);
-            if (zok) deflateEnd(&zs);
-        }
+        deflate_job job = { w, data, len, b0, osz, use_ld };
+        atomic_init(&job.bad, 0);
+        team_run(w->tm, (int64_t)nb, 4, deflate_blocks, &job);
+        bad = atomic_load(&job.bad);
         T_deflate += now_s() - td;
         if (bad) { free(osz); return fail(CRUMBLE_BAM_EIO, "deflate failed"); }
         const double tw = now_s();
@@ -706,8 +777,11 @@ static crumble_bam_writer *writer_open(const char *path, int level, int threads,
     if (!w) { if (err) *err = fail(CRUMBLE_BAM_ENOMEM, "out of memory"); return NULL; }
     w->level = level < 0 ? Z_DEFAULT_COMPRESSION : (level > 9 ? 9 : level);
     w->threads = threads > 0 ? threads : default_threads();
+    w->tm = team_create(w->threads);
+    if (!w->tm) { if (err) *err = fail(CRUMBLE_BAM_ENOMEM, "out of memory"); free(w); return NULL; }
+    w->tm->slot_free = deflate_tls_free;
     w->fp = fopen(path, "wb");
-    if (!w->fp) { if (err) *err = fail(CRUMBLE_BAM_EIO, "%s: %s", path, strerror(errno)); free(w); return NULL; }
+    if (!w->fp) { if (err) *err = fail(CRUMBLE_BAM_EIO, "%s: %s", path, strerror(errno)); team_destroy(w->tm); free(w); return NULL; }
     return w;
 }
 
@@ -717,7 +791,7 @@ crumble_bam_writer *crumble_bam_create(const char *path, const crumble_bam_reade
     crumble_bam_writer *w = writer_open(path, level, threads, err);
     if (!w) return NULL;
     const int rc = write_header(w, r->text, r->l_text, pg_line, r->n_ref, (const char *const *)r->ref_name, r->ref_len);
-    if (rc) { if (err) *err = rc; fclose(w->fp); big_free(w->obuf, w->ocap); free(w); return NULL; }
+    if (rc) { if (err) *err = rc; fclose(w->fp); team_destroy(w->tm); big_free(w->obuf, w->ocap); free(w); return NULL; }
     if (err) *err = 0;
     return w;
 }
@@ -801,21 +875,69 @@ static inline void aux_bin(const crumble_bam_writer *w, uint8_t *t)
     for (uint8_t *c = t + 3; *c; c++) *c = (uint8_t)((*c >= b[1]) ? b[2] : b[0]);
 }
 
+/* the pieces of crumble_bam_write_group(), records [lo, hi) each */
+typedef struct { crumble_bam_writer *w; crumble_bam_reader *r; const uint8_t *qual_out; int binning; atomic_int bad; } wg_job;
+static void wg_scatter(void *ctx, int64_t lo, int64_t hi, int tid)
+{
+    wg_job *j = ctx; crumble_bam_reader *r = j->r;
+    (void)tid;
+    for (int64_t i = lo; i < hi; i++) {
+        uint8_t *p = r->raw + r->rec_off[i];
+        const int32_t lseq = (int32_t)le32(p + F_LSEQ);
+        uint8_t *ql = p + F_FIXED + p[F_LNAME] + 4 * (size_t)le16(p + F_NCIG) + ((size_t)lseq + 1) / 2;
+        if (lseq > 0 && ql[0] != 0xff) memcpy(ql, j->qual_out + r->seq_off[i], (size_t)lseq);
+    }
+}
+static void wg_aux_sizes(void *ctx, int64_t lo, int64_t hi, int tid)
+{
+    wg_job *j = ctx; crumble_bam_reader *r = j->r; crumble_bam_writer *w = j->w;
+    (void)tid;
+    for (int64_t i = lo; i < hi; i++) {
+        const uint8_t *p = r->raw + r->rec_off[i];
+        const uint32_t bs = le32(p);
+        const int32_t lseq = (int32_t)le32(p + F_LSEQ);
+        const uint8_t *aux = p + F_FIXED + p[F_LNAME] + 4 * (size_t)le16(p + F_NCIG) + ((size_t)lseq + 1) / 2 + (size_t)lseq;
+        const uint8_t *lim = p + 4 + bs;
+        size_t keep = (size_t)(aux - p);
+        for (const uint8_t *t = aux; t < lim; ) {
+            const uint8_t *e = (t + 3 <= lim) ? aux_end(t + 2, lim) : NULL;
+            if (!e) { atomic_store(&j->bad, 1); break; }
+            if (aux_keep(w, t)) keep += (size_t)(e - t);
+            t = e;
+        }
+        w->noff[i] = keep;
+    }
+}
+static void wg_aux_copy(void *ctx, int64_t lo, int64_t hi, int tid)
+{
+    wg_job *j = ctx; crumble_bam_reader *r = j->r; crumble_bam_writer *w = j->w;
+    (void)tid;
+    for (int64_t i = lo; i < hi; i++) {
+        const uint8_t *p = r->raw + r->rec_off[i];
+        const uint32_t bs = le32(p);
+        const int32_t lseq = (int32_t)le32(p + F_LSEQ);
+        const uint8_t *aux = p + F_FIXED + p[F_LNAME] + 4 * (size_t)le16(p + F_NCIG) + ((size_t)lseq + 1) / 2 + (size_t)lseq;
+        const uint8_t *lim = p + 4 + bs;
+        uint8_t *o = w->raw2 + w->noff[i], *q = o;
+        memcpy(q, p, (size_t)(aux - p)); q += aux - p;
+        for (const uint8_t *t = aux; t < lim; ) {
+            const uint8_t *e = aux_end(t + 2, lim);
+            if (aux_keep(w, t)) { memcpy(q, t, (size_t)(e - t)); if (j->binning) aux_bin(w, q); q += e - t; }
+            t = e;
+        }
+        put32(o, (uint32_t)(q - o - 4));
+    }
+}
+
 int crumble_bam_write_group(crumble_bam_writer *w, crumble_bam_reader *r, const uint8_t *qual_out)
 {
     if (r->n == 0) return 0;
     const double tsc = now_s();
-    if (qual_out) {
-        #pragma omp parallel for schedule(static) num_threads(w->threads)
-        for (int64_t i = 0; i < r->n; i++) {
-            uint8_t *p = r->raw + r->rec_off[i];
-            const int32_t lseq = (int32_t)le32(p + F_LSEQ);
-            uint8_t *ql = p + F_FIXED + p[F_LNAME] + 4 * (size_t)le16(p + F_NCIG) + ((size_t)lseq + 1) / 2;
-            if (lseq > 0 && ql[0] != 0xff) memcpy(ql, qual_out + r->seq_off[i], (size_t)lseq);
-        }
-    }
-    const size_t first = r->rec_off[0];
     const int binning = w->bd[0] | w->bd[1] | w->bd[2] | w->bi[0] | w->bi[1] | w->bi[2];
+    wg_job job = { w, r, qual_out, binning, 0 };
+    atomic_init(&job.bad, 0);
+    if (qual_out) team_run(w->tm, r->n, 0, wg_scatter, &job);
+    const size_t first = r->rec_off[0];
     if (!w->aux_mode && !binning) {
         T_scatter += now_s() - tsc;
         return bgzf_write(w, r->raw + first, r->group_end - first);
@@ -829,24 +951,8 @@ int crumble_bam_write_group(crumble_bam_writer *w, crumble_bam_reader *r, const 
         w->noff_cap = w->noff ? (size_t)n + 1 : 0;
         if (!w->noff) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
     }
-    int bad = 0;
-    #pragma omp parallel for schedule(static) num_threads(w->threads) reduction(|:bad)
-    for (int64_t i = 0; i < n; i++) {
-        const uint8_t *p = r->raw + r->rec_off[i];
-        const uint32_t bs = le32(p);
-        const int32_t lseq = (int32_t)le32(p + F_LSEQ);
-        const uint8_t *aux = p + F_FIXED + p[F_LNAME] + 4 * (size_t)le16(p + F_NCIG) + ((size_t)lseq + 1) / 2 + (size_t)lseq;
-        const uint8_t *lim = p + 4 + bs;
-        size_t keep = (size_t)(aux - p);
-        for (const uint8_t *t = aux; t < lim; ) {
-            const uint8_t *e = (t + 3 <= lim) ? aux_end(t + 2, lim) : NULL;
-            if (!e) { bad = 1; break; }
-            if (aux_keep(w, t)) keep += (size_t)(e - t);
-            t = e;
-        }
-        w->noff[i] = keep;
-    }
-    if (bad) return fail(CRUMBLE_BAM_EFORMAT, "malformed auxiliary field");
+    team_run(w->tm, n, 0, wg_aux_sizes, &job);
+    if (atomic_load(&job.bad)) return fail(CRUMBLE_BAM_EFORMAT, "malformed auxiliary field");
     size_t tot = 0;
     for (int64_t i = 0; i < n; i++) { const size_t k = w->noff[i]; w->noff[i] = tot; tot += k; }
     w->noff[n] = tot;
@@ -857,22 +963,7 @@ int crumble_bam_write_group(crumble_bam_writer *w, crumble_bam_reader *r, const 
         w->raw2_cap = w->raw2 ? c : 0;
         if (!w->raw2) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
     }
-    #pragma omp parallel for schedule(static) num_threads(w->threads)
-    for (int64_t i = 0; i < n; i++) {
-        const uint8_t *p = r->raw + r->rec_off[i];
-        const uint32_t bs = le32(p);
-        const int32_t lseq = (int32_t)le32(p + F_LSEQ);
-        const uint8_t *aux = p + F_FIXED + p[F_LNAME] + 4 * (size_t)le16(p + F_NCIG) + ((size_t)lseq + 1) / 2 + (size_t)lseq;
-        const uint8_t *lim = p + 4 + bs;
-        uint8_t *o = w->raw2 + w->noff[i], *q = o;
-        memcpy(q, p, (size_t)(aux - p)); q += aux - p;
-        for (const uint8_t *t = aux; t < lim; ) {
-            const uint8_t *e = aux_end(t + 2, lim);
-            if (aux_keep(w, t)) { memcpy(q, t, (size_t)(e - t)); if (binning) aux_bin(w, q); q += e - t; }
-            t = e;
-        }
-        put32(o, (uint32_t)(q - o - 4));
-    }
+    team_run(w->tm, n, 0, wg_aux_copy, &job);
     T_scatter += now_s() - tsc;
     return bgzf_write(w, w->raw2, tot);
 }
@@ -883,6 +974,7 @@ int crumble_bam_writer_close(crumble_bam_writer *w)
     int rc = 0;
     if (fwrite(BGZF_EOF, 1, 28, w->fp) != 28) rc = fail(CRUMBLE_BAM_EIO, "write error: %s", strerror(errno));
     if (fclose(w->fp) != 0 && !rc) rc = fail(CRUMBLE_BAM_EIO, "close: %s", strerror(errno));
+    team_destroy(w->tm);
     big_free(w->obuf, w->ocap); big_free(w->raw2, w->raw2_cap); free(w->noff); free(w->aux_set); free(w);
     return rc;
 }
@@ -897,6 +989,39 @@ static int reg2bin(int64_t beg, int64_t end)
     if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
     if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
     return 0;
+}
+
+/* records [lo, hi) of one batch -> BAM records (test helper below) */
+typedef struct { const crumble_batch *b; uint8_t *buf; const size_t *off; int64_t serial; } wb_job;
+static void wb_pack(void *ctx, int64_t lo, int64_t hi, int tid)
+{
+    wb_job *j = ctx;
+    const crumble_batch *b = j->b; uint8_t *buf = j->buf; const size_t *off = j->off; const int64_t serial = j->serial;
+    (void)tid;
+    for (int64_t i = lo; i < hi; i++) {
+        uint8_t *p = buf + off[i];
+        char nm[32];
+        const int ln = snprintf(nm, sizeof nm, "r%lld", (long long)(serial + i)) + 1;
+        const int64_t lq = b->seq_off[i + 1] - b->seq_off[i], ncg = b->cig_off[i + 1] - b->cig_off[i];
+        const uint32_t *cg = b->cigar + b->cig_off[i];
+        int64_t rlen = 0;
+        for (int64_t k = 0; k < ncg; k++) { const unsigned op = cg[k] & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += cg[k] >> 4; }
+        put32(p, (uint32_t)(off[i + 1] - off[i] - 4));
+        put32(p + F_REFID, (uint32_t)b->tid);
+        put32(p + F_POS, (uint32_t)b->pos[i]);
+        p[F_LNAME] = (uint8_t)ln; p[F_MAPQ] = b->mapq[i];
+        put16(p + 14, (uint16_t)reg2bin(b->pos[i] < 0 ? 0 : b->pos[i], (b->pos[i] < 0 ? 0 : b->pos[i]) + (rlen ? rlen : 1)));
+        put16(p + F_NCIG, (uint16_t)ncg); put16(p + F_FLAG, b->flag[i]);
+        put32(p + F_LSEQ, (uint32_t)lq);
+        put32(p + 24, (uint32_t)-1); put32(p + 28, (uint32_t)-1); put32(p + 32, 0);
+        uint8_t *q = p + F_FIXED;
+        memcpy(q, nm, (size_t)ln); q += ln;
+        for (int64_t k = 0; k < ncg; k++) { put32(q, cg[k]); q += 4; }
+        const uint8_t *bs = b->bases + b->seq_off[i];
+        for (int64_t k = 0; k + 1 < lq; k += 2) *q++ = (uint8_t)((bs[k] & 15) << 4 | (bs[k + 1] & 15));
+        if (lq & 1) *q++ = (uint8_t)((bs[lq - 1] & 15) << 4);
+        memcpy(q, b->quals + b->seq_off[i], (size_t)lq);
+    }
 }
 
 int crumble_bam_write_batches(const char *path, int32_t n_ref, const char *const *names, const int64_t *lens,
@@ -924,31 +1049,8 @@ int crumble_bam_write_batches(const char *path, int32_t n_ref, const char *const
         off[n] = tot;
         uint8_t *buf = malloc(tot + 1);
         if (!buf) { free(off); rc = fail(CRUMBLE_BAM_ENOMEM, "out of memory"); break; }
-        #pragma omp parallel for schedule(static) num_threads(w->threads)
-        for (int64_t i = 0; i < n; i++) {
-            uint8_t *p = buf + off[i];
-            char nm[32];
-            const int ln = snprintf(nm, sizeof nm, "r%lld", (long long)(serial + i)) + 1;
-            const int64_t lq = b->seq_off[i + 1] - b->seq_off[i], ncg = b->cig_off[i + 1] - b->cig_off[i];
-            const uint32_t *cg = b->cigar + b->cig_off[i];
-            int64_t rlen = 0;
-            for (int64_t k = 0; k < ncg; k++) { const unsigned op = cg[k] & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += cg[k] >> 4; }
-            put32(p, (uint32_t)(off[i + 1] - off[i] - 4));
-            put32(p + F_REFID, (uint32_t)b->tid);
-            put32(p + F_POS, (uint32_t)b->pos[i]);
-            p[F_LNAME] = (uint8_t)ln; p[F_MAPQ] = b->mapq[i];
-            put16(p + 14, (uint16_t)reg2bin(b->pos[i] < 0 ? 0 : b->pos[i], (b->pos[i] < 0 ? 0 : b->pos[i]) + (rlen ? rlen : 1)));
-            put16(p + F_NCIG, (uint16_t)ncg); put16(p + F_FLAG, b->flag[i]);
-            put32(p + F_LSEQ, (uint32_t)lq);
-            put32(p + 24, (uint32_t)-1); put32(p + 28, (uint32_t)-1); put32(p + 32, 0);
-            uint8_t *q = p + F_FIXED;
-            memcpy(q, nm, (size_t)ln); q += ln;
-            for (int64_t k = 0; k < ncg; k++) { put32(q, cg[k]); q += 4; }
-            const uint8_t *bs = b->bases + b->seq_off[i];
-            for (int64_t k = 0; k + 1 < lq; k += 2) *q++ = (uint8_t)((bs[k] & 15) << 4 | (bs[k + 1] & 15));
-            if (lq & 1) *q++ = (uint8_t)((bs[lq - 1] & 15) << 4);
-            memcpy(q, b->quals + b->seq_off[i], (size_t)lq);
-        }
+        wb_job wj = { b, buf, off, serial };
+        team_run(w->tm, n, 0, wb_pack, &wj);
         rc = bgzf_write(w, buf, tot);
         serial += n;
         free(buf); free(off);
@@ -1099,6 +1201,7 @@ struct crumble_hts {
     hts_bam1_t *ahead;                       /* first record of the next group */
     hts_bam1_t **pool; int64_t npool, cappool;
     int eof;
+    team *tm;                                /* host threads of the SoA unpack (team.h) */
     crumble_bam_writer filt;                 /* purge_tags settings only */
     /* SoA views */
     int32_t *pos; uint8_t *mapq; uint16_t *flag; int64_t *seq_off, *cig_off; uint32_t *cigar; uint8_t *bases, *quals;
@@ -1156,6 +1259,28 @@ int crumble_hts_load_bed(const crumble_hts *h, const char *path, int32_t **tid, 
 }
 int crumble_hts_set_aux_filter(crumble_hts *h, const char *whitelist, const char *blacklist, const int bd[3], const int bi[3])
 { return crumble_bam_set_aux_filter(&h->filt, whitelist, blacklist, bd, bi); }
+
+/* records [lo, hi) of the current group -> the SoA arrays */
+static void hts_unpack(void *ctx, int64_t lo, int64_t hi, int tid)
+{
+    crumble_hts *h = ctx;
+    (void)tid;
+    for (int64_t i = lo; i < hi; i++) {
+        const hts_bam1_t *r = h->rec[i];
+        const int32_t lseq = r->core.l_qseq;
+        h->pos[i] = (int32_t)r->core.pos; h->mapq[i] = r->core.qual; h->flag[i] = r->core.flag;
+        const uint8_t *cg = r->data + r->core.l_qname;
+        memcpy(h->cigar + h->cig_off[i], cg, 4 * (size_t)r->core.n_cigar);
+        const uint8_t *sq = cg + 4 * (size_t)r->core.n_cigar;
+        uint8_t *bo = h->bases + h->seq_off[i];
+        for (int32_t k = 0; k + 1 < lseq; k += 2) { const uint8_t v = sq[k >> 1]; bo[k] = v >> 4; bo[k + 1] = v & 15; }
+        if (lseq & 1) bo[lseq - 1] = sq[lseq >> 1] >> 4;
+        const uint8_t *ql = sq + ((size_t)lseq + 1) / 2;
+        uint8_t *qo = h->quals + h->seq_off[i];
+        if (lseq > 0 && ql[0] == 0xff) memset(qo, 0, (size_t)lseq);     /* absent qualities */
+        else memcpy(qo, ql, (size_t)lseq);
+    }
+}
 
 /* the next run of records sharing one refID -> SoA views (same contract as crumble_bam_next_contig) */
 int crumble_hts_next_contig(crumble_hts *h, crumble_batch *b)
@@ -1221,22 +1346,8 @@ int crumble_hts_next_contig(crumble_hts *h, crumble_batch *b)
     int64_t ab = 0, ac = 0;
     for (int64_t i = 0; i < n; i++) { h->seq_off[i] = ab; h->cig_off[i] = ac; ab += h->rec[i]->core.l_qseq; ac += h->rec[i]->core.n_cigar; }
     h->seq_off[n] = ab; h->cig_off[n] = ac;
-    #pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < n; i++) {
-        const hts_bam1_t *r = h->rec[i];
-        const int32_t lseq = r->core.l_qseq;
-        h->pos[i] = (int32_t)r->core.pos; h->mapq[i] = r->core.qual; h->flag[i] = r->core.flag;
-        const uint8_t *cg = r->data + r->core.l_qname;
-        memcpy(h->cigar + h->cig_off[i], cg, 4 * (size_t)r->core.n_cigar);
-        const uint8_t *sq = cg + 4 * (size_t)r->core.n_cigar;
-        uint8_t *bo = h->bases + h->seq_off[i];
-        for (int32_t k = 0; k + 1 < lseq; k += 2) { const uint8_t v = sq[k >> 1]; bo[k] = v >> 4; bo[k + 1] = v & 15; }
-        if (lseq & 1) bo[lseq - 1] = sq[lseq >> 1] >> 4;
-        const uint8_t *ql = sq + ((size_t)lseq + 1) / 2;
-        uint8_t *qo = h->quals + h->seq_off[i];
-        if (lseq > 0 && ql[0] == 0xff) memset(qo, 0, (size_t)lseq);     /* absent qualities */
-        else memcpy(qo, ql, (size_t)lseq);
-    }
+    if (!h->tm) h->tm = team_create(default_threads());
+    team_run(h->tm, n, 0, hts_unpack, h);               /* (no team: team_run does the loop itself) */
     memset(b, 0, sizeof *b);
     b->tid = tid; b->n_reads = n;
     b->pos = h->pos; b->mapq = h->mapq; b->flag = h->flag; b->seq_off = h->seq_off; b->cig_off = h->cig_off;
@@ -1282,6 +1393,7 @@ int crumble_hts_close(crumble_hts *h)
         if (h->in && H.hts_close(h->in) != 0) rc = fail(CRUMBLE_BAM_EIO, "error while closing the input");
         if (h->out && H.hts_close(h->out) != 0) rc = fail(CRUMBLE_BAM_EIO, "error while closing the output");
     }
+    team_destroy(h->tm);
     free(h->rec); free(h->pool); free(h->pos); free(h->mapq); free(h->flag); free(h->seq_off); free(h->cig_off); free(h->cigar);
     big_free(h->bases, h->cap_bases); big_free(h->quals, h->cap_bases); free(h->filt.aux_set);
     free(h);

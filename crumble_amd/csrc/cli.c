@@ -365,15 +365,6 @@ static void lpt_assign(const crumble_bam_reader *rd, int ndev, int *dev_of)
 
 int main(int argc, char **argv)
 {
-    /* The reader's and the writer's OpenMP teams run side by side (read / GPU / write of consecutive contigs overlap):
-     * threads of one team spinning at a barrier take the cores the other team needs.  libgomp reads its wait policy
-     * when it is loaded, so the process starts itself again with the policy set -- before anything touches the GPU. */
-    if (!getenv("OMP_WAIT_POLICY") && !getenv("GOMP_SPINCOUNT") && !getenv("CRUMBLE_NO_REEXEC")) {
-        setenv("OMP_WAIT_POLICY", "passive", 1);
-        setenv("CRUMBLE_NO_REEXEC", "1", 1);
-        execv("/proc/self/exe", argv);
-        /* (no /proc: go on as we are) */
-    }
     crumble_params P;
     crumble_params_default(&P);
     int opt, verbose = 0, threads = 0, no_pg = 0, ngpu = 1, windowed = 0;

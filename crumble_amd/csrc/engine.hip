@@ -1205,7 +1205,8 @@ extern "C" int crumble_hip_run_finish(crumble_hip *h)
     }
     if (h->opt_stages) HIPCHK(hipEventRecord(h->ev[h->n_stages], st));
     /* fold this batch's counters into the engine's accumulated stats vector, on the device */
-    CRUMBLE_LAUNCH_INDEP(k_stats_fold, nblk(CRUMBLE_ST_N, 64), 64, st, h->d_stats.as<u64>(), (const u64 *)stats, CRUMBLE_ST_N, (const int *)d_overflow, spec_abort);
+    CRUMBLE_LAUNCH_INDEP(k_stats_fold, nblk(CRUMBLE_ST_N, 64), 64, st, h->d_stats.as<u64>(), (const u64 *)stats, CRUMBLE_ST_N, (const int *)d_overflow, spec_abort,
+                         (const int *)(h->d_misc.as<int>() + 8), (const int *)(h->d_misc.as<int>() + 15));
     int ovf[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(h->pinned, d_overflow, 64, hipMemcpyDeviceToHost, st));      /* the flags and (fast path) the scan's totals */
     HIPCHK(hipStreamSynchronize(st));

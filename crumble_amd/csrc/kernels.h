@@ -3819,12 +3819,15 @@ __global__ void k_stats_totals(int64_t n_reads, int64_t n_bases, u64 *stats)
 }
 
 /* this batch's counters into the engine's accumulated vector (what the multi-GPU all-reduce sums) */
-/* (a run that ends in CRUMBLE_EOVERFLOW adds nothing: its partial counters must not reach the all-reduced vector) */
+/* (a run that ends in an error adds nothing: the partial counters of a batch that is rejected -- CRUMBLE_EOVERFLOW, an
+ * input quality >= 128 seen by the replay / k_stats (overflow[4]), the expansion's late errors: unsorted input, tile
+ * span, hit lists (p0_err, hit_err) -- must not reach the all-reduced vector) */
 __global__ void k_stats_fold(u64 *__restrict__ total, const u64 *__restrict__ batch, int n, const int *__restrict__ overflow,
-                             const int *__restrict__ spec_abort)
+                             const int *__restrict__ spec_abort, const int *__restrict__ p0_err, const int *__restrict__ hit_err)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && !*overflow && !LIST_ABORTED(spec_abort)) total[i] += batch[i];      /* (an aborted fast run is repeated) */
+    if (i < n && !overflow[0] && !overflow[4] && !*p0_err && !*hit_err && !LIST_ABORTED(spec_abort))
+        total[i] += batch[i];                                                        /* (an aborted fast run is repeated) */
 }
 
 #endif /* CRUMBLE_KERNELS_H */

@@ -5,10 +5,14 @@
  * (/root/reference/snp_score.c:2144-2542) and bed.c:20-40 so that a caller who
  * switches from crumble's getopt loop to this ABI gets identical settings.
  */
+#define _GNU_SOURCE
 #include <stdlib.h>
 #include <string.h>
 #include <strings.h>
+#include <unistd.h>
+#include <sched.h>
 #include "../../include/crumble_hip.h"
+#include "team.h"
 
 /* main()'s initialiser, snp_score.c:2152-2192 (== preset -9) */
 void crumble_params_default(crumble_params *p)
@@ -164,15 +168,25 @@ const char *crumble_hip_strerror(int err)
 }
 
 /* one nt16 code per byte -> BAM's packing in the crumble_batch.bases4 layout (include/crumble_hip.h) */
-void crumble_pack_bases4(int64_t n_reads, const int64_t *seq_off, const uint8_t *bases, uint8_t *out)
+typedef struct { const int64_t *seq_off; const uint8_t *bases; uint8_t *out; } pack4_job;
+static void pack4_reads(void *ctx, int64_t lo, int64_t hi, int tid)
 {
-    #pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < n_reads; i++) {
-        const uint8_t *b = bases + seq_off[i];
-        const int64_t lq = seq_off[i + 1] - seq_off[i];
-        uint8_t *o = out + CRUMBLE_BASES4_OFF(seq_off[i], i);
+    const pack4_job *j = ctx;
+    (void)tid;
+    for (int64_t i = lo; i < hi; i++) {
+        const uint8_t *b = j->bases + j->seq_off[i];
+        const int64_t lq = j->seq_off[i + 1] - j->seq_off[i];
+        uint8_t *o = j->out + CRUMBLE_BASES4_OFF(j->seq_off[i], i);
         int64_t k = 0;
         for (; k + 1 < lq; k += 2) *o++ = (uint8_t)((b[k] & 15) << 4 | (b[k + 1] & 15));
         if (k < lq) *o = (uint8_t)((b[k] & 15) << 4);
     }
+}
+void crumble_pack_bases4(int64_t n_reads, const int64_t *seq_off, const uint8_t *bases, uint8_t *out)
+{
+    pack4_job j = { seq_off, bases, out };
+    long nt = sysconf(_SC_NPROCESSORS_ONLN);
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0 && CPU_COUNT(&set) < nt) nt = CPU_COUNT(&set);
+    team_run_once((int)(nt > 32 ? 32 : nt), n_reads, 0, pack4_reads, &j);
 }

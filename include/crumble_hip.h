@@ -108,7 +108,12 @@ typedef struct crumble_batch {
     const uint32_t *cigar;    /* BAM encoding: len<<4 | op (MIDNSHP=X)          */
     const uint8_t  *bases;    /* one nt16 code (0..15, "=ACMGRSVTWYHKDBN") per  */
                               /* base; l_qseq(i) = seq_off[i+1]-seq_off[i]      */
-    const uint8_t  *quals;    /* phred, one byte per base (must be < 128)       */
+    const uint8_t  *quals;    /* phred, one byte per base; must be < 128: a    */
+                              /* larger value is found by the kernels that     */
+                              /* read the qualities, i.e. reported (EINVAL) by */
+                              /* crumble_hip_run / _run_finish / _contig, not  */
+                              /* by crumble_hip_upload; such a batch adds      */
+                              /* nothing to the accumulated statistics         */
     int32_t  n_bed;           /* keep-regions of THIS contig, after             */
     const int32_t *bed_start; /* crumble_bed_collapse() (bed.c:20-40)           */
     const int32_t *bed_end;

@@ -143,6 +143,58 @@ def test_emu_upload_validation(product):
     eng.close()
 
 
+def _rejected_batches_leave_the_statistics(make_engine):
+    """A batch that ends in CRUMBLE_EINVAL / CRUMBLE_EUNSORTED adds nothing to the engine's accumulated statistics vector
+    (what crumble_hip_stats_allreduce sums), whichever way it is driven: crumble_hip_contig, crumble_hip_upload +
+    crumble_hip_run (a quality >= 128 is seen by the replay, i.e. reported by the RUN: include/crumble_hip.h), or the
+    five phases of a window."""
+    from crumble_amd import windows as W
+    p = ca.preset_params(5)
+    eng = make_engine(p)
+    ok = [dict(pos=100 + 3 * i, cigar="10M", seq="ACGTACGTAC", qual=30) for i in range(40)]
+    hb_ok = HostBatch.from_reads(ok)
+    badq = [dict(r) for r in ok]
+    badq[17] = dict(badq[17], qual=[30, 30, 30, 200, 30, 30, 30, 30, 30, 30])
+    hb_badq = HostBatch.from_reads(badq)
+    hb_unsorted = HostBatch.from_reads(ok[:20] + ok[5:6] + ok[20:])
+    eng.contig(hb_ok)
+    base = eng.stats_read()
+    assert base[ca.capi.ST_NAMES.index("reads")] == 40
+    for hb, code in ((hb_badq, -1), (hb_unsorted, -4)):
+        with pytest.raises(ca.CrumbleError) as ei:
+            eng.contig(hb)
+        assert ei.value.code == code
+        assert np.array_equal(eng.stats_read(), base), "a rejected batch reached the accumulated statistics (contig)"
+    # upload + run: the bad quality is the run's to report
+    eng.upload(hb_badq)
+    with pytest.raises(ca.CrumbleError) as ei:
+        eng.run()
+    assert ei.value.code == -1
+    assert np.array_equal(eng.stats_read(), base), "a rejected batch reached the accumulated statistics (upload + run)"
+    with pytest.raises(ca.CrumbleError) as ei:      # the unsorted batch is refused by the upload itself
+        eng.upload(hb_unsorted)
+    assert ei.value.code == -4
+    # the phases of a window
+    eng.upload(hb_badq)
+    w = W.Window()
+    w.col_start, w.col_end, w.stat_end, w.read_first, w.read_end = 100, 100 + 3 * 39 + 10, 100 + 3 * 39 + 10, 0, 40
+    eng.set_window(w)
+    cout = W.Carry()
+    cin = W.Carry.start()
+    eng.run_columns(); eng.run_depth(cin, cout); eng.run_triggers(); eng.run_fold(cin, cout)
+    with pytest.raises(ca.CrumbleError) as ei:
+        eng.run_finish()
+    assert ei.value.code == -1
+    assert np.array_equal(eng.stats_read(), base), "a rejected batch reached the accumulated statistics (window phases)"
+    eng.contig(hb_ok)                               # still usable, and counting again
+    assert np.array_equal(eng.stats_read(), 2 * base)
+    eng.close()
+
+
+def test_emu_rejected_batches_leave_the_statistics(product):
+    _rejected_batches_leave_the_statistics(emu_lib.engine)
+
+
 def test_emu_rerun_and_engine_reuse(product):
     """run(); download == run(); run(); download (grow-only buffers, partially written arrays), and one engine
     reused for batches of different shapes gives what a fresh engine gives."""
@@ -278,6 +330,12 @@ def test_emu_run_paths(product):
              (ca.preset_params(1), synth_batch("ce", 0.1)))
     for i, (p, hb) in enumerate(cases):
         for opts in ({"run": "careful"}, {"run": "fast"}, {"run": "fast", "caps": 3}) + (({"run": "fast", "caps": 3, "kcol": "v2"},) if i == 0 else ()):
+            assert_parity(emu_lib.with_options(**opts), p, hb)
+    # the byte-wise replay ("replay" = flat: k_replay_flat, then k_restore's byte writes, k_readfix, k_keepfix) on a
+    # long-read (multi-op) batch, a short-read one, and -S (k_replay_general) -- the paths the packed replay bypasses
+    for p, hb in (cases[1], cases[0], (ca.preset_params(9, softclip=1), synth_batch("chr20", 0.0002, softclip_frac=0.3)),
+                  (ca.preset_params(9, tech="pbccs", softclip=1), cases[1][1])):
+        for opts in ({"replay": "flat"}, {"replay": "flat", "run": "fast", "caps": 3}):
             assert_parity(emu_lib.with_options(**opts), p, hb)
     # one engine: an aborted fast run, then batches that fit
     eng = emu_lib.engine(ca.preset_params(5), caps=2)

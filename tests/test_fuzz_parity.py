@@ -15,7 +15,9 @@ def test_fuzz_emulated(product, seed):
     p, hb, desc = random_case(seed, max_bases=120_000)
     print(desc)
     # every column kernel, whatever the batch; the run's fast way, the careful one, and an aborted fast attempt
-    assert_parity(emu_lib.with_options(kcol=KCOL_VARIANTS[seed % 3], run=("fast", "careful")[(seed // 3) % 2], caps=(0, 0, 2)[seed % 3]), p, hb)
+    # ... and, on every fourth seed, the byte-wise replay (k_replay_flat + k_restore / k_readfix / k_keepfix behind it)
+    assert_parity(emu_lib.with_options(kcol=KCOL_VARIANTS[seed % 3], run=("fast", "careful")[(seed // 3) % 2], caps=(0, 0, 2)[seed % 3],
+                                       replay=("auto", "auto", "auto", "flat")[seed % 4]), p, hb)
 
 
 @pytest.mark.gpu
@@ -26,7 +28,8 @@ def test_fuzz_gpu(product, block):
         p, hb, desc = random_case(seed, max_bases=400_000)
         kcol = KCOL_VARIANTS[seed % 3] if seed % 4 else "auto"      # every column kernel, whatever the batch
         try:
-            opts = {"kcol": kcol, "run": ("fast", "fast", "careful")[seed % 3], "caps": (0, 0, 0, 0, 5)[seed % 5]}
+            opts = {"kcol": kcol, "run": ("fast", "fast", "careful")[seed % 3], "caps": (0, 0, 0, 0, 5)[seed % 5],
+                    "replay": ("auto", "auto", "auto", "flat")[(seed // 2) % 4]}
             assert_parity(lambda q: ca.Engine(q, 0, options=opts), p, hb)
         except AssertionError as e:
             raise AssertionError(f"{desc}: {e}") from e

@@ -293,6 +293,13 @@ def test_upload_validation_errors(product):
     eng.close()
 
 
+def test_rejected_batches_leave_the_statistics(product):
+    """upload + run and the windowed phases report a bad quality through the run, and no rejected batch reaches the
+    accumulated statistics vector"""
+    from test_emu_parity import _rejected_batches_leave_the_statistics
+    _rejected_batches_leave_the_statistics(gpu_engine)
+
+
 @pytest.mark.parametrize("workload,ranks", [("chr20", 2), ("wgs", 2), ("wgs", 8)])
 def test_bench_two_ranks(product, workload, ranks):
     """bench.py's N>1 control flow (LPT packing of the 24 contigs onto the ranks, barriers, max-over-ranks timing,

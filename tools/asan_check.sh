@@ -8,11 +8,11 @@ W=${1:-/tmp/crumble_asan}; mkdir -p $W; cd $W
 SRC=$R/crumble_amd/csrc; EMU=$R/tests/emu
 FL="-fsanitize=address,undefined -fno-omit-frame-pointer -g -O1"
 gcc $FL -fPIC -c $SRC/params.c -o params.o
-gcc $FL -fPIC -fopenmp -c $SRC/bamio.c -o bamio.o
+gcc $FL -fPIC -pthread -c $SRC/bamio.c -o bamio.o
 g++ $FL -std=c++17 -fPIC -ffp-contract=off -DCRUMBLE_EMU -include $EMU/hip_emu.h -Wno-unknown-pragmas -x c++ -c $SRC/engine.hip -o engine.o
 g++ $FL -std=c++17 -fPIC -c $EMU/hip_emu.cpp -o hip_emu.o
 gcc $FL -c $SRC/cli.c -o cli.o
-g++ $FL -o crumble-hip-asan cli.o engine.o hip_emu.o params.o bamio.o -lz -lgomp -lpthread -lm
+g++ $FL -o crumble-hip-asan cli.o engine.o hip_emu.o params.o bamio.o -lz -ldl -lpthread -lm
 python3 - <<PY
 import sys; sys.path.insert(0, "$R"); sys.path.insert(0, "$R/tests")
 import numpy as np

@@ -14,7 +14,8 @@ for seed in range(s0, s0 + n):
     p, hb, desc = random_case(seed, max_bases=300_000)
     kcol = ("v1", "v1perm", "v2", "v2", "auto")[seed % 5]       # every column kernel, whatever the batch
     opts = {"kcol": kcol, "pblock": ("auto", "reads", "segments", "words")[(seed // 5) % 4],   # ... and every P-block decomposition
-            "run": ("fast", "fast", "careful")[seed % 3], "caps": (0, 0, 0, 0, 0, 0, 4)[seed % 7]}   # ... and the run's fast way, the careful one, an aborted attempt
+            "run": ("fast", "fast", "careful")[seed % 3], "caps": (0, 0, 0, 0, 0, 0, 4)[seed % 7],   # ... and the run's fast way, the careful one, an aborted attempt
+            "replay": ("auto", "auto", "auto", "flat")[(seed // 3) % 4]}                          # ... and the byte-wise replay
     if seed % 2:
         hb.pack4(ca.lib())                                      # the bases as BAM packs them (crumble_batch.bases4)
     try:

@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_prof -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu "$@" > $R/gpurun_out/${tag}_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_prof -- python3 $R/bench.py --steps 3 --warmup 1 --profile "$@" > $R/gpurun_out/${tag}_prof.log 2>&1
 f=$(ls $R/gpurun_out/${tag}_prof/*/*kernel_stats.csv | head -1)
 python3 - "$f" <<'PY'
 import csv, sys

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 tag=${1:-diag}; kern=${2:-k_columns}; shift; shift
 cd /tmp && export TMPDIR=/tmp
 n=0
-pass() { n=$((n+1)); rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/${tag}_diag_$n -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu $EXTRA > /dev/null 2>&1; }
+pass() { n=$((n+1)); rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/${tag}_diag_$n -- python3 $R/bench.py --steps 1 --warmup 0 --profile $EXTRA > /dev/null 2>&1; }
 EXTRA="$*"
 pass SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 pass SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY

@@ -7,7 +7,7 @@ for tag in "$@"; do
   if [ "$tag" = default ]; then unset CRUMBLE_HIP_LIB; else export CRUMBLE_HIP_LIB=$R/build/libcrumble_$tag.so; fi
   rm -rf $R/gpurun_out/insts_$tag
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES \
-      --output-format csv -d $R/gpurun_out/insts_$tag -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu --no-verify > /dev/null 2>&1
+      --output-format csv -d $R/gpurun_out/insts_$tag -- python3 $R/bench.py --steps 1 --warmup 0 --profile > /dev/null 2>&1
   python3 - "$R/gpurun_out/insts_$tag" "$tag" <<'PY'
 import csv, glob, sys, collections
 tot = collections.defaultdict(float)
