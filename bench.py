@@ -226,7 +226,7 @@ def measure_config(ca, synth, workload, scale, device, steps=3, warmup=1, verify
     hb = synth.generate(cfg, bed=bed)
     t_gen = time.time() - t0
     if hasattr(ca, "lib"):
-        hb.pack4(ca.lib())
+        hb.pack4(ca.lib()).lens()
     params = ca.preset_params(d_preset, tech=d_tech)
     eng = ca.Engine(params, device, options={"stages": "on"})
     try:
@@ -302,12 +302,12 @@ def measure_small_contig(ca, synth, device, preset=5, contig_len=5000, reps=200)
             "note": "crumble_hip_contig() per call on a 5 kb contig (host -> device, expansion, run, device -> host), and crumble_hip_run() alone"}
 
 
-def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=3):
+def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=4, coded=True, n_uploaders=1):
     """BASELINE config 5 on ONE GPU as the stream it is (snp_score.c:1437: contigs one after another): the 24 contigs
-    sit in host memory; contig k+1's host -> device copy + device-side expansion, contig k's kernels and contig k-1's
-    download (page-locked staging, engine.hip staged_d2h) run side by side -- three host threads, a ring of engines
-    (each its own HIP stream).  Reports the wall time per pass, the three stages' summed times and wall / sum
-    (1.0 = nothing overlaps, 1/3 = perfect overlap of three equal stages)."""
+    sit in host memory; contig k+1's host -> device copy + device-side expansion, contig k's kernels, contig k-1's
+    coded download and contig k-2's expansion on the host run side by side -- four host threads, a ring of engines
+    (each its own HIP stream).  Reports the wall time per pass, the stages' summed times and wall / sum
+    (1.0 = nothing overlaps)."""
     import queue
     import threading
     sizes = [int(l * scale) for l in shard.GRCH38]
@@ -320,7 +320,7 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=3)
         cfg.tid = tid
         batches.append(synth.generate(cfg))
         if hasattr(ca, "lib"):
-            batches[-1].pack4(ca.lib())
+            batches[-1].pack4(ca.lib()).lens()      # bases as BAM packs them, BAM's per-read lengths: what crumble-hip sends
     t_gen = time.time() - t0
     params = ca.preset_params(preset)
     engines = [ca.Engine(params, device) for _ in range(n_engines)]
@@ -336,7 +336,7 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=3)
     originals = []                                  # (restored before the page-locked blocks are freed)
     for b_ in batches:
         saved = {}
-        for nm in ("pos", "mapq", "flag", "seq_off", "cig_off", "cigar", "quals"):
+        for nm in ("pos", "mapq", "flag", "seq_off", "cig_off", "cigar", "quals") + (("l_qseq", "n_cigar") if getattr(b_, "l_qseq", None) is not None else ()):
             saved[nm] = getattr(b_, nm)
             setattr(b_, nm, pin(saved[nm]))
         if getattr(b_, "bases4", None) is not None:
@@ -345,26 +345,45 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=3)
         originals.append(saved)
     max_nb, max_n = max(b_.n_bases for b_ in batches), max(b_.n_reads for b_ in batches)
     out_bufs = {id(e): (pin(np.zeros(max(1, max_nb), np.uint8)), pin(np.zeros(max(1, max_n), np.uint8))) for e in engines}
+    # the coded download's three streams (2 bits per base, a block table, the escape bytes) land in page-locked memory too
+    coded_bufs = {id(e): (pin(np.zeros(max_nb // 16 + 2, np.uint32)), pin(np.zeros(max_nb // 4096 + 2, np.int64)),
+                          pin(np.zeros(max(1, max_nb // 8), np.uint8))) for e in engines} if coded else {}
+    xfer = [0, 0]
     k_small = int(np.argmin([b_.n_bases for b_ in batches]))
     kept = {}
     lens_ok = [False] * len(batches)
     try:
         def one_pass(keep):
-            free_q, run_q, dl_q = queue.Queue(), queue.Queue(), queue.Queue()
+            free_q, run_q, dl_q, dec_q = queue.Queue(), queue.Queue(), queue.Queue(), queue.Queue()
             for e in engines:
                 free_q.put(e)
-            t_stage = [0.0, 0.0, 0.0]
+            t_stage = [0.0, 0.0, 0.0, 0.0]
             err = []
 
+            up_lock = threading.Lock()
+            up_state = {"next": 0, "live": n_uploaders}
+
             def uploader():
+                # n_uploaders threads take the contigs in turn: while one engine's expansion (a few small kernels and their
+                # size read-back) runs, the other's copies keep the link busy
                 try:
-                    for i, b in enumerate(batches):
+                    while True:
+                        with up_lock:
+                            i = up_state["next"]; up_state["next"] += 1
+                        if i >= len(batches):
+                            break
                         e = free_q.get()
-                        t = time.perf_counter(); e.upload(b); t_stage[0] += time.perf_counter() - t
+                        t = time.perf_counter(); e.upload(batches[i]); dt = time.perf_counter() - t
+                        with up_lock:
+                            t_stage[0] += dt
                         run_q.put((i, e))
                 except Exception as ex:            # noqa: BLE001
                     err.append(ex)
-                run_q.put(None)
+                with up_lock:
+                    up_state["live"] -= 1
+                    last = up_state["live"] == 0
+                if last:
+                    run_q.put(None)
 
             def runner():
                 try:
@@ -384,7 +403,20 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=3)
                         it = dl_q.get()
                         if it is None:
                             break
-                        t = time.perf_counter(); q, f, _ = it[1].download(want_stats=False, out=out_bufs[id(it[1])]); t_stage[2] += time.perf_counter() - t
+                        t = time.perf_counter()
+                        if coded:
+                            # 2 bits per base + escapes over the link; the expansion is the next stage's
+                            c_, f, _ = it[1].download_coded(want_stats=False, bufs=coded_bufs[id(it[1])])
+                            q = None
+                        else:
+                            q, f, _ = it[1].download(want_stats=False, out=out_bufs[id(it[1])])
+                        t_stage[2] += time.perf_counter() - t
+                        if keep:
+                            u_, d_ = it[1].transfer_bytes()
+                            xfer[0] += u_; xfer[1] += d_
+                        if coded:
+                            dec_q.put((it[0], it[1], c_, f))
+                            continue
                         if keep:
                             lens_ok[it[0]] = len(q) == batches[it[0]].n_bases
                             if it[0] == k_small:
@@ -392,7 +424,28 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=3)
                         free_q.put(it[1])
                 except Exception as ex:            # noqa: BLE001
                     err.append(ex)
-            th = [threading.Thread(target=f) for f in (uploader, runner, downloader)]
+                dec_q.put(None)
+
+            def decoder():
+                # the coded result expanded on the host against the input qualities it still holds (crumble_decode_quals
+                # on the host's threads): the bytes a plain download gives
+                try:
+                    while True:
+                        it = dec_q.get()
+                        if it is None:
+                            break
+                        t = time.perf_counter()
+                        q = (it[1].decode(it[2], batches[it[0]].quals, out=out_bufs[id(it[1])][0], threads=int(os.environ.get("CRUMBLE_BENCH_DECODE_THREADS", "0")))
+                             if not os.environ.get("CRUMBLE_BENCH_STREAM_NODECODE") else out_bufs[id(it[1])][0][:batches[it[0]].n_bases])
+                        t_stage[3] += time.perf_counter() - t
+                        if keep:
+                            lens_ok[it[0]] = len(q) == batches[it[0]].n_bases
+                            if it[0] == k_small:
+                                kept["q"], kept["f"] = q.copy(), it[3].copy()
+                        free_q.put(it[1])
+                except Exception as ex:            # noqa: BLE001
+                    err.append(ex)
+            th = [threading.Thread(target=f) for f in (uploader,) * n_uploaders + (runner, downloader) + ((decoder,) if coded else ())]
             t0 = time.perf_counter()
             for t in th:
                 t.start()
@@ -411,9 +464,12 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=3)
         ok = bool(np.array_equal(kept["q"], wq) and np.array_equal(kept["f"], wf)) and all(lens_ok)
         return {
             "workload": f"wgs-30x: 24 synthetic contigs (GRCh38 lengths x {scale}), {total} bases, -{preset}, streamed through "
-                        f"{n_engines} engines on one GPU (upload || kernels || download)",
+                        f"{n_engines} engines on one GPU ({n_uploaders} uploads || kernels || download || host expansion)",
             "value_incl_pcie": round(total / wall / 1e9, 3), "unit": "Gbases/s", "ms_per_pass": round(wall * 1e3, 2),
-            "stages_ms": {"h2d_and_p0": round(st[0] * 1e3, 2), "kernels": round(st[1] * 1e3, 2), "d2h": round(st[2] * 1e3, 2)},
+            "stages_ms": {"h2d_and_p0": round(st[0] * 1e3, 2), "kernels": round(st[1] * 1e3, 2), "d2h": round(st[2] * 1e3, 2),
+                          **({"host_decode": round(st[3] * 1e3, 2)} if coded else {})},
+            "download": "coded: 2 bits per base + escape bytes (crumble_hip_encode / _download_coded), expanded by crumble_decode_quals on the host's threads as a fourth stage" if coded else "plain: one byte per base",
+            "pcie_bytes_per_base": {"in": round(xfer[0] / max(1, total), 4), "out": round(xfer[1] / max(1, total), 4)},
             "overlap_wall_over_sum_of_stages": round(wall / max(1e-9, sum(st)), 3),
             "verified_smallest_contig": ok, "gen_s": round(t_gen, 1),
             "note": "batches and output buffers in page-locked host memory (crumble_hip_host_alloc); a PCIe-inclusive rate, never `value`",
@@ -425,9 +481,144 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=3)
             for nm, a in saved.items():
                 setattr(b_, nm, a)
         out_bufs.clear()
+        coded_bufs.clear()
         kept.clear()
         for p_ in pins:
             ca.pinned_free(p_)
+
+
+def allreduce_stats(ca, engines, dist, rank, world, red_dev):
+    """The one collective of the path: the statistics / quality-histogram vector summed over the ranks.  A rank that ran
+    several engines (one per contig) first folds their vectors into its first engine (crumble_hip_stats_add), then the
+    product's own collective runs on that engine: crumble_hip_stats_allreduce (RCCL, in place on the device vector)
+    over a communicator built from an id that rank 0 hands round.  Should the communicator fail to come up on some box
+    (or the ranks share one device: the gloo test), the same sum goes through torch.distributed instead of losing the
+    run.  -> (summed vector, how it was summed)"""
+    import torch
+    eng = engines[0]
+    if len(engines) > 1:
+        rest = sum(e_.stats_read() for e_ in engines[1:])
+        eng.stats_add(rest)
+        for e_ in engines[1:]:
+            e_.stats_reset()
+    stats = eng.stats_read()
+    if dist is None:
+        return stats, "none (one rank)"
+    done = False
+    stats_via = None
+    if red_dev == "cuda":
+        import ctypes as C
+        ok, comm, rccl = 1, None, None
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        uid = UniqueId()
+        try:
+            rccl = C.CDLL("librccl.so")
+            if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+                ok = 0
+        except Exception:                       # noqa: BLE001
+            ok = 0
+        # rank 0 ALWAYS broadcasts (the id, or None when it has none): no rank is left waiting in the broadcast
+        box = [bytes(uid.internal) if (rank == 0 and ok) else None]
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            ok = 0
+        if ok:
+            try:
+                C.memmove(C.byref(uid), box[0], 128)
+                comm = C.c_void_p()
+                rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+                ok = 1 if rccl.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0 else 0
+                if not ok:
+                    comm = None
+            except Exception:                   # noqa: BLE001
+                ok, comm = 0, None
+        allok = torch.tensor([ok], dtype=torch.int32, device=red_dev)
+        dist.all_reduce(allok, op=dist.ReduceOp.MIN)            # every rank takes the same path
+        if int(allok.item()) == 1:
+            rc = eng.L.crumble_hip_stats_allreduce(eng.h, comm)
+            # (a refusal -- e.g. the loaded librccl's version against the build's rccl.h -- comes before any
+            # collective is issued and is the same on every rank: agree on it, then take the other path)
+            allok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=red_dev)
+            dist.all_reduce(allok, op=dist.ReduceOp.MIN)
+            if int(allok.item()) == 1:
+                stats = eng.stats_read()
+                stats_via = "crumble_hip_stats_allreduce (RCCL)"
+                done = True
+            elif rank == 0:
+                print("bench: crumble_hip_stats_allreduce refused (%s); statistics summed by torch.distributed"
+                      % eng.L.crumble_hip_last_error().decode(), file=sys.stderr)
+        if comm is not None and rccl is not None:           # (also on the ranks whose communicator came up while another's did not)
+            rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+            rccl.ncclCommDestroy(comm)
+    if not done:
+        st = torch.from_numpy(stats.copy()).to(red_dev)
+        dist.all_reduce(st, op=dist.ReduceOp.SUM)
+        stats = st.cpu().numpy()
+        stats_via = f"torch.distributed all_reduce ({'RCCL' if red_dev == 'cuda' else 'gloo'})"
+    return stats, stats_via
+
+
+def measure_wgs_strong(ca, synth, shard, dist, rank, world, local_rank, red_dev, scale, preset=5, steps=2, warmup=1):
+    """BASELINE config 5 at N > 1 (what the metric is named after): 24 synthetic contigs with GRCh38's proportions,
+    LPT-packed onto the ranks by length (contigs are the independent unit: every cross-column state resets on a tid change,
+    snp_score.c:1478-1488) -- strong scaling, no data-path collective -- resident in HBM, `steps` passes of expansion + run
+    over each rank's share, max over ranks; then ONE all-reduce of the statistics vector through the product's
+    crumble_hip_stats_allreduce, and the summed histogram checked against the job's base count."""
+    import torch
+    sizes = [int(l * scale) for l in shard.GRCH38]
+    assign, loads = shard.lpt_pack(sizes, world)
+    batches = []
+    for tid in assign[rank]:
+        cfg = synth.config("chr20", scale=1.0)
+        cfg.contig_len = max(sizes[tid], 4 * cfg.read_len + 4096)
+        cfg.seed = 5000 + tid
+        cfg.tid = tid
+        batches.append(synth.generate(cfg).pack4(ca.lib()).lens())
+    params = ca.preset_params(preset)
+    engines = []
+    try:
+        for b_ in batches:
+            e_ = ca.Engine(params, local_rank)
+            e_.upload(b_)
+            engines.append(e_)
+        if not engines:                                  # (more ranks than contigs: this rank only takes part in the collectives)
+            engines.append(ca.Engine(params, local_rank))
+
+        def sync_all():
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        for _ in range(warmup):
+            for e_ in engines[:len(batches)]:
+                e_.expand(); e_.run()
+        for e_ in engines:
+            e_.stats_reset()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for e_ in engines[:len(batches)]:
+                e_.expand(); e_.run()
+        sync_all()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        stats, via = allreduce_stats(ca, engines, dist, rank, world, red_dev)
+        tb = torch.tensor([sum(b_.n_bases for b_ in batches), sum(b_.n_reads for b_ in batches)], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        total_bases, total_reads = int(tb[0].item()), int(tb[1].item())
+        names = ca.capi.ST_NAMES
+        hist_ok = (int(stats[ca.capi.ST_HIST0:ca.capi.ST_HIST0 + 256].sum()) == total_bases * steps and
+                   int(stats[names.index("bases")]) == total_bases * steps and int(stats[names.index("reads")]) == total_reads * steps)
+        return {
+            "workload": f"wgs-30x: 24 synthetic contigs (GRCh38 lengths x {scale}), {total_bases} bases, -{preset}, LPT-packed on {world} GPUs",
+            "value": round(total_bases * steps / elapsed / 1e9, 4), "unit": "Gbases/s", "scaling": "strong", "n_gpus": world,
+            "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "lpt_max_over_mean_load": round(max(loads) / (sum(loads) / len(loads)), 4),
+            "contigs_per_rank": [len(a_) for a_ in assign], "stats_allreduce": via, "summed_histogram_ok": bool(hist_ok),
+        }
+    finally:
+        for e_ in engines:
+            e_.close()
 
 
 def main():
@@ -455,11 +646,14 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the `other_configs` object (BASELINE configs "
                     "3, 4 and 5 measured after the headline config; default line, one GPU only; --no-cpu skips it too: its "
                     "legs check themselves against the CPU oracle)")
+    ap.add_argument("--wgs-strong-scale", type=float, default=0.05, help="N > 1: the `wgs_strong` object's contig length scale "
+                    "(24 GRCh38-proportioned contigs, LPT-packed over the ranks, resident in HBM; times --scale)")
     ap.add_argument("--wgs-stream-scale", type=float, default=0.05, help="other_configs.wgs_streamed: contig length scale")
     ap.add_argument("--e2e", action="store_true",
                     help="metric (ii), BAM file -> crumble-hip -> BAM file (SURVEY.md 8d), on the WHOLE contig (the default line "
                          "runs it on a quarter of it); an extra 'end_to_end' object, never part of 'value'")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end leg")
+    ap.add_argument("--only-streamed", action="store_true", help="tuning: run the config-5 streamed leg alone and print its object")
     ap.add_argument("--profile", action="store_true", help="the timed steps and nothing else (rocprofv3 runs: no CPU legs, no "
                     "verification, no small-contig probe, no end_to_end, no other_configs -- every launch in the trace is a step's)")
     args = ap.parse_args()
@@ -469,6 +663,12 @@ def main():
         args.profile = True
     if args.profile:
         args.no_cpu = args.no_verify = args.no_e2e = args.no_other_configs = True
+    if args.only_streamed:
+        import crumble_amd as ca
+        import synth
+        from crumble_amd import shard
+        print(json.dumps(measure_wgs_streamed(ca, synth, shard, args.wgs_stream_scale, 0)))
+        return
     label, d_preset, d_tech, d_bed = WORKLOADS[args.workload]
     preset = args.preset if args.preset is not None else d_preset
     tech = (None if args.tech == "none" else args.tech) if args.tech is not None else d_tech
@@ -527,7 +727,8 @@ def main():
         scaling = "weak"
     t_gen = time.time() - t0
     for b_ in batches:
-        b_.pack4(ca.lib())          # the bases cross PCIe as BAM packs them (crumble_batch.bases4), as crumble-hip sends them
+        b_.pack4(ca.lib()).lens()   # the bases cross PCIe as BAM packs them (crumble_batch.bases4) and the offset tables as BAM's own
+                                    # per-read lengths (l_qseq / n_cigar), as crumble-hip sends them
     hb = batches[0]
     params = ca.preset_params(args.preset, tech=tech)
     opts = {"stages": "on"}                     # HIP events around the run's stages: roofline.kernels_ms
@@ -604,65 +805,9 @@ def main():
         elapsed = float(t.item())
 
     # ---- the one collective of the path: statistics / quality histogram ----
-    stats = sum(e_.stats_read() for e_ in engines)
+    stats, stats_via = allreduce_stats(ca, engines, dist, rank, world, red_dev)
     bases_local = sum(b_.n_bases for b_ in batches)
-    stats_via = "none (one rank)"
     if dist is not None:
-        done = False
-        if red_dev == "cuda" and len(engines) == 1:
-            # the product's own collective: crumble_hip_stats_allreduce (RCCL, in place on the engine's device
-            # vector) over a communicator built from an id that rank 0 hands round.  Should the communicator fail to
-            # come up on some box, the same sum goes through torch.distributed (RCCL as well) instead of losing the run.
-            import ctypes as C
-            ok, comm, rccl = 1, None, None
-
-            class UniqueId(C.Structure):
-                _fields_ = [("internal", C.c_char * 128)]
-            uid = UniqueId()
-            try:
-                rccl = C.CDLL("librccl.so")
-                if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
-                    ok = 0
-            except Exception:                       # noqa: BLE001
-                ok = 0
-            # rank 0 ALWAYS broadcasts (the id, or None when it has none): no rank is left waiting in the broadcast
-            box = [bytes(uid.internal) if (rank == 0 and ok) else None]
-            dist.broadcast_object_list(box, src=0)
-            if box[0] is None:
-                ok = 0
-            if ok:
-                try:
-                    C.memmove(C.byref(uid), box[0], 128)
-                    comm = C.c_void_p()
-                    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-                    ok = 1 if rccl.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0 else 0
-                    if not ok:
-                        comm = None
-                except Exception:                   # noqa: BLE001
-                    ok, comm = 0, None
-            allok = torch.tensor([ok], dtype=torch.int32, device=red_dev)
-            dist.all_reduce(allok, op=dist.ReduceOp.MIN)            # every rank takes the same path
-            if int(allok.item()) == 1:
-                rc = eng.L.crumble_hip_stats_allreduce(eng.h, comm)
-                # (a refusal -- e.g. the loaded librccl's version against the build's rccl.h -- comes before any
-                # collective is issued and is the same on every rank: agree on it, then take the other path)
-                allok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=red_dev)
-                dist.all_reduce(allok, op=dist.ReduceOp.MIN)
-                if int(allok.item()) == 1:
-                    stats = eng.stats_read()
-                    stats_via = "crumble_hip_stats_allreduce (RCCL)"
-                    done = True
-                elif rank == 0:
-                    print("bench: crumble_hip_stats_allreduce refused (%s); statistics summed by torch.distributed"
-                          % eng.L.crumble_hip_last_error().decode(), file=sys.stderr)
-            if comm is not None and rccl is not None:           # (also on the ranks whose communicator came up while another's did not)
-                rccl.ncclCommDestroy.argtypes = [C.c_void_p]
-                rccl.ncclCommDestroy(comm)
-        if not done:
-            st = torch.from_numpy(stats.copy()).to(red_dev)
-            dist.all_reduce(st, op=dist.ReduceOp.SUM)
-            stats = st.cpu().numpy()
-            stats_via = f"torch.distributed all_reduce ({'RCCL' if red_dev == 'cuda' else 'gloo'})"
         tb = torch.tensor([bases_local], dtype=torch.int64, device=red_dev)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         total_bases = int(tb.item())
@@ -674,14 +819,32 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
 
     # ---- download of the TIMED engine's result (what the verification below looks at) ----
+    up_bytes = sum(e_.transfer_bytes()[0] for e_ in engines)
     t0 = time.perf_counter()
     tq, tf, _ = eng.download(want_stats=False)
     t_down_first = time.perf_counter() - t0
-    t_down = 1e9
+    t_down_plain = 1e9
     for _ in range(3):                                             # steady state: the caller's buffers are already mapped
         t0 = time.perf_counter()
         tq, tf, _ = eng.download(want_stats=False, out=(tq, tf))
-        t_down = min(t_down, time.perf_counter() - t0)
+        t_down_plain = min(t_down_plain, time.perf_counter() - t0)
+    down_plain_bytes = eng.transfer_bytes()[1]
+    # the coded download (2 bits per base + escape bytes, include/crumble_hip.h) and its expansion on the host against the
+    # input qualities: the same bytes (checked), a quarter of the link traffic
+    t_down, t_dec, cbufs, cq = 1e9, 1e9, None, np.empty(max(1, hb.n_bases), np.uint8)
+    for _ in range(3):
+        t0 = time.perf_counter()
+        c_, _, _ = eng.download_coded(want_flags=True, want_stats=False, bufs=cbufs)
+        t1 = time.perf_counter()
+        cq = eng.decode(c_, hb.quals, out=cq if len(cq) >= hb.n_bases else None)
+        t2 = time.perf_counter()
+        cbufs = c_._keep
+        if t2 - t0 < t_down + t_dec:
+            t_down, t_dec = t1 - t0, t2 - t1
+    down_coded_bytes = eng.transfer_bytes()[1]
+    coded_ok = bool(np.array_equal(cq[:hb.n_bases], tq))
+    coded_escapes = int(c_.n_escapes)
+    del cq, cbufs, c_
 
     # ---- roofline of the dominant kernel (HIP events on the engine's stream) ----
     dom = max(ktimes.items(), key=lambda kv: kv[1][0])
@@ -720,15 +883,29 @@ def main():
     step_s = elapsed / args.steps
     h2d_s = h2d_ms * 1e-3
     extra = {
-        "p0_ms": round(p0_step_ms, 3), "h2d_ms": round(h2d_ms, 3), "d2h_ms": round(t_down * 1e3 * len(batches), 3),
+        "p0_ms": round(p0_step_ms, 3), "h2d_ms": round(h2d_ms, 3),
+        "d2h_ms": round((t_down + t_dec) * 1e3 * len(batches), 3), "d2h_coded_copy_ms": round(t_down * 1e3 * len(batches), 3),
+        "d2h_host_decode_ms": round(t_dec * 1e3 * len(batches), 3), "d2h_plain_ms": round(t_down_plain * 1e3 * len(batches), 3),
         "d2h_first_ms": round(t_down_first * 1e3 * len(batches), 3),
+        "coded_download_equals_plain": coded_ok, "coded_escape_bytes": coded_escapes,
+        "pcie_bytes_per_base": {"in": round(up_bytes / max(1, bases_local), 4), "out": round(down_coded_bytes / max(1, hb.n_bases), 4),
+                                "out_plain": round(down_plain_bytes / max(1, hb.n_bases), 4)},
         "value_kernels_only": round(bases_local / (kernel_ms_total * 1e-3) / 1e9, 3) if kernel_ms_total > 0 else None,
-        "value_incl_pcie": round(bases_local / (step_s + h2d_s + t_down * len(batches)) / 1e9, 3),
+        "value_incl_pcie": round(bases_local / (step_s + h2d_s + min(t_down + t_dec, t_down_plain) * len(batches)) / 1e9, 3),
+        "value_incl_pcie_download": "coded" if t_down + t_dec < t_down_plain else "plain",
+        "value_incl_pcie_coded_download": round(bases_local / (step_s + h2d_s + (t_down + t_dec) * len(batches)) / 1e9, 3),
+        "value_incl_pcie_coded_copy_only": round(bases_local / (step_s + h2d_s + t_down * len(batches)) / 1e9, 3),
+        "value_incl_pcie_plain_download": round(bases_local / (step_s + h2d_s + t_down_plain * len(batches)) / 1e9, 3),
         "note": "value = device-side expansion (P0) + every kernel of the run, raw arrays resident in HBM (a contig pays both, "
                 "once); value_kernels_only = the run's kernels alone (sum of HIP-event stage times; rounds 1-3 reported this as "
-                "`value`); value_incl_pcie adds the host->device copy (pageable numpy memory, bases as BAM packs them: "
-                "crumble_batch.bases4) and the download (second download into the same pageable buffers: a "
-                "first download into fresh memory also pays the page faults, d2h_first_ms)",
+                "`value`); value_incl_pcie adds the host->device copy (pageable numpy memory; bases as BAM packs them, "
+                "crumble_batch.bases4, and BAM's per-read lengths instead of offset tables) and the CODED download "
+                "(crumble_hip_encode + crumble_hip_download_coded: 2 bits per base + escape bytes, then crumble_decode_quals on "
+                "the host's threads -- byte for byte the plain download, checked: coded_download_equals_plain); d2h_plain_ms "
+                "is the one-byte-per-base download (steady state into mapped pageable buffers; d2h_first_ms also pays the page faults); "
+                "value_incl_pcie takes whichever of the two is faster on this host for a FLAT output array (the coded form is "
+                "made for callers that expand it into their records while they write them, crumble-hip's writer: "
+                "value_incl_pcie_coded_copy_only leaves the expansion to that pass)",
     }
 
     out = {
@@ -754,6 +931,19 @@ def main():
         "around_the_step": extra,
     }
 
+    if world > 1 and args.workload == "chr20" and not args.profile:
+        # BASELINE config 5 is the configuration that names N GPUs: the driver's `--gpus N` line keeps the chr20 weak-scaling
+        # headline and measures config 5 beside it (every rank takes part: collectives inside)
+        for e_ in engines:
+            e_.close()
+        engines = []
+        del tq, tf
+        try:
+            ws = measure_wgs_strong(ca, synth, shard, dist, rank, world, local_rank, red_dev, args.wgs_strong_scale * args.scale,
+                                    preset=args.preset or 5)
+        except Exception as ex:                    # noqa: BLE001
+            ws = {"error": repr(ex)[:300]}
+        out["wgs_strong"] = ws
     if rank == 0 and args.workload != "wgs":
         # compression proxy (no CRAM writer offline): share of the quality bytes the pass
         # rewrote and the order-0 entropy of the quality bytes before / after, from the engine's own statistics

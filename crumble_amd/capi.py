@@ -52,7 +52,21 @@ class Batch(C.Structure):
         ("bases", C.c_void_p), ("quals", C.c_void_p),
         ("n_bed", C.c_int32), ("bed_start", C.c_void_p), ("bed_end", C.c_void_p),
         ("bases4", C.c_void_p),
+        ("l_qseq", C.c_void_p), ("n_cigar", C.c_void_p), ("n_bases", C.c_int64), ("n_cigar_ops", C.c_int64),
     ]
+
+
+class Coded(C.Structure):
+    """crumble_coded: the result as 2 bits per base + escape bytes (include/crumble_hip.h, "coded download")."""
+    _fields_ = [
+        ("n_bases", C.c_int64), ("n_words", C.c_int64), ("n_blocks", C.c_int64), ("n_escapes", C.c_int64),
+        ("value", C.c_uint8 * 2), ("pad_", C.c_uint8 * 6), ("cap", C.c_uint8 * 256),
+        ("codes", C.c_void_p), ("esc_off", C.c_void_p), ("esc", C.c_void_p),
+    ]
+
+
+class DecodeCursor(C.Structure):
+    _fields_ = [("base", C.c_int64), ("esc_pos", C.c_int64)]
 
 
 class Column(C.Structure):
@@ -137,7 +151,21 @@ class HostBatch:
         if packed and getattr(self, "bases4", None) is not None:       # BAM-packed bases instead (crumble_batch.bases4)
             b.bases4 = self.bases4.ctypes.data
             b.bases = None
+        if packed and getattr(self, "l_qseq", None) is not None:       # BAM's per-read lengths instead of the offset tables
+            b.l_qseq, b.n_cigar = self._ptr(self.l_qseq), self._ptr(self.n_cigar)
+            b.n_bases, b.n_cigar_ops = self.n_bases, int(self.cig_off[-1]) if len(self.cig_off) else 0
+            b.seq_off = b.cig_off = None
         return b
+
+    def lens(self):
+        """Attach BAM's own per-read lengths (crumble_batch.l_qseq / n_cigar): struct() then hands the engine those (6 bytes
+        per read over PCIe) and no offset tables.  Batches with a read of more than 65535 CIGAR ops keep the offsets."""
+        nc = np.diff(self.cig_off)
+        if len(nc) and nc.max() > 65535:
+            return self
+        self.l_qseq = np.ascontiguousarray(np.diff(self.seq_off), np.int32)
+        self.n_cigar = np.ascontiguousarray(nc, np.uint16)
+        return self
 
     def pack4(self, lib):
         """Attach the bases in BAM's packing (crumble_pack_bases4): struct() then hands the engine bases4 and no bases."""

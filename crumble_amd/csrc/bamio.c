@@ -192,6 +192,8 @@ struct crumble_bam_reader {
     size_t *rec_off;                          /* [n] offset of block_size field      */
     int32_t tid;
     int32_t *pos; uint8_t *mapq; uint16_t *flag; int64_t *seq_off, *cig_off;
+    int32_t *lq; uint16_t *ncg;               /* BAM's own l_seq / n_cigar_op per read (crumble_batch.l_qseq / n_cigar) */
+    int long_cig;                             /* the group holds a CG-tag CIGAR (> 65535 ops): no n_cigar form */
     uint32_t *cigar; uint8_t *bases, *quals;
     int packed4;                    /* bases[] holds BAM's packing in the crumble_batch.bases4 layout (crumble_bam_set_packed_bases) */
     size_t cap_reads, cap_bases, cap_cig;
@@ -419,7 +421,7 @@ void crumble_bam_close(crumble_bam_reader *r)
     free(r->cbuf); big_free(r->raw, r->raw_cap); free(r->text);
     if (r->ref_name) for (int32_t i = 0; i < r->n_ref; i++) free(r->ref_name[i]);
     free(r->ref_name); free(r->ref_len); free(r->rec_off);
-    free(r->pos); free(r->mapq); free(r->flag); free(r->seq_off); free(r->cig_off);
+    free(r->pos); free(r->mapq); free(r->flag); free(r->seq_off); free(r->cig_off); free(r->lq); free(r->ncg);
     free(r->cigar); big_free(r->bases, r->cap_bases); big_free(r->quals, r->cap_bases);
     free(r);
 }
@@ -488,6 +490,7 @@ static void scan_records(crumble_bam_reader *r)
         r->seq_off[r->n] = r->acc_nb; r->cig_off[r->n] = r->acc_nc;
         uint32_t nops = ncig;
         if (ncig == 2) (void)long_cigar(p, &nops);            /* real op count of a CG-tag CIGAR */
+        if (nops > 65535) r->long_cig = 1;
         r->acc_nb += lseq; r->acc_nc += nops;
         r->n++;
         r->scan += 4 + (size_t)bs;
@@ -510,6 +513,8 @@ static void unpack_records(void *ctx, int64_t lo, int64_t hi, int tid)
         r->pos[i] = (int32_t)le32(p + F_POS);
         r->mapq[i] = p[F_MAPQ];
         r->flag[i] = le16(p + F_FLAG);
+        r->lq[i] = lseq;
+        r->ncg[i] = (uint16_t)(r->cig_off[i + 1] - r->cig_off[i]);      /* (a CG-tag CIGAR: the group keeps the offset form) */
         const uint8_t *cg = p + F_FIXED + lname;
         uint32_t *co = r->cigar + r->cig_off[i];
         uint32_t nlong = 0;
@@ -541,7 +546,7 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
         memmove(r->raw, r->raw + r->head, r->raw_len - r->head);
         r->raw_len -= r->head; r->scan -= r->head; r->head = 0;
     }
-    r->n = 0; r->have_tid = 0; r->group_done = 0; r->scan_err = 0; r->acc_nb = r->acc_nc = 0;
+    r->n = 0; r->have_tid = 0; r->group_done = 0; r->scan_err = 0; r->acc_nb = r->acc_nc = 0; r->long_cig = 0;
     /* the resident bytes may already hold the whole next group: walk them before reading ahead */
     scan_records(r);
     if (r->scan_err) return r->scan_err;
@@ -565,9 +570,10 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
     const int64_t n = r->n;
     if (r->cap_reads < (size_t)n + 1) {
         const size_t c = (size_t)n + (size_t)n / 4 + 64;
-        free(r->pos); free(r->mapq); free(r->flag);
+        free(r->pos); free(r->mapq); free(r->flag); free(r->lq); free(r->ncg);
         r->pos = malloc(c * sizeof *r->pos); r->mapq = malloc(c); r->flag = malloc(c * sizeof *r->flag);
-        r->cap_reads = (r->pos && r->mapq && r->flag) ? c : 0;
+        r->lq = malloc(c * sizeof *r->lq); r->ncg = malloc(c * sizeof *r->ncg);
+        r->cap_reads = (r->pos && r->mapq && r->flag && r->lq && r->ncg) ? c : 0;
         if (!r->cap_reads) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
     }
     const int64_t nb = r->acc_nb, nc = r->acc_nc;
@@ -604,6 +610,7 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
     b->seq_off = r->seq_off; b->cig_off = r->cig_off; b->cigar = r->cigar;
     b->quals = r->quals;
     if (r->packed4) b->bases4 = r->bases; else b->bases = r->bases;
+    if (!r->long_cig) { b->l_qseq = r->lq; b->n_cigar = r->ncg; b->n_bases = nb; b->n_cigar_ops = nc; }   /* 6 bytes per read to the device instead of 16 */
     return 1;
 }
 
@@ -627,11 +634,12 @@ crumble_bam_group *crumble_bam_detach_group(crumble_bam_reader *r)
     g->raw = r->raw; g->raw_cap = r->raw_cap; g->raw_len = r->group_end; g->group_end = r->group_end; g->head = r->head;
     g->n = r->n; g->cap_n = r->cap_n; g->rec_off = r->rec_off; g->tid = r->tid;
     g->pos = r->pos; g->mapq = r->mapq; g->flag = r->flag; g->seq_off = r->seq_off; g->cig_off = r->cig_off;
+    g->lq = r->lq; g->ncg = r->ncg;
     g->cigar = r->cigar; g->bases = r->bases; g->quals = r->quals;
     g->cap_reads = r->cap_reads; g->cap_bases = r->cap_bases; g->cap_cig = r->cap_cig;
     r->raw = nraw; r->raw_cap = ncap; r->raw_len = tail; r->scan -= r->group_end; r->group_end = 0; r->head = 0;
     r->n = 0; r->cap_n = 0; r->rec_off = NULL; r->seq_off = NULL; r->cig_off = NULL;
-    r->pos = NULL; r->mapq = NULL; r->flag = NULL; r->cigar = NULL; r->bases = NULL; r->quals = NULL;
+    r->pos = NULL; r->mapq = NULL; r->flag = NULL; r->cigar = NULL; r->bases = NULL; r->quals = NULL; r->lq = NULL; r->ncg = NULL;
     r->cap_reads = r->cap_bases = r->cap_cig = 0;
     return (crumble_bam_group *)g;
 }
@@ -644,7 +652,7 @@ void crumble_bam_group_free(crumble_bam_group *gg)
     crumble_bam_reader *g = (crumble_bam_reader *)gg;
     if (!g) return;
     big_free(g->raw, g->raw_cap); free(g->rec_off); free(g->seq_off); free(g->cig_off);
-    free(g->pos); free(g->mapq); free(g->flag); free(g->cigar);
+    free(g->pos); free(g->mapq); free(g->flag); free(g->cigar); free(g->lq); free(g->ncg);
     big_free(g->bases, g->cap_bases); big_free(g->quals, g->cap_bases);
     free(g);
 }
@@ -876,11 +884,24 @@ static inline void aux_bin(const crumble_bam_writer *w, uint8_t *t)
 }
 
 /* the pieces of crumble_bam_write_group(), records [lo, hi) each */
-typedef struct { crumble_bam_writer *w; crumble_bam_reader *r; const uint8_t *qual_out; int binning; atomic_int bad; } wg_job;
+typedef struct { crumble_bam_writer *w; crumble_bam_reader *r; const uint8_t *qual_out; int binning; atomic_int bad; const crumble_coded *coded; } wg_job;
 static void wg_scatter(void *ctx, int64_t lo, int64_t hi, int tid)
 {
     wg_job *j = ctx; crumble_bam_reader *r = j->r;
     (void)tid;
+    if (j->coded) {
+        /* the coded result (include/crumble_hip.h): expanded straight into the records.  A record's quality field still
+         * holds the input qualities, which is what code 2 refers to; the cursor walks the reads of this piece in base order */
+        crumble_decode_cursor cur;
+        crumble_decode_seek(j->coded, r->seq_off[lo], &cur);
+        for (int64_t i = lo; i < hi; i++) {
+            uint8_t *p = r->raw + r->rec_off[i];
+            const int32_t lseq = (int32_t)le32(p + F_LSEQ);
+            uint8_t *ql = p + F_FIXED + p[F_LNAME] + 4 * (size_t)le16(p + F_NCIG) + ((size_t)lseq + 1) / 2;
+            if (lseq > 0) crumble_decode_run(j->coded, &cur, lseq, ql, ql[0] != 0xff ? ql : NULL);
+        }
+        return;
+    }
     for (int64_t i = lo; i < hi; i++) {
         uint8_t *p = r->raw + r->rec_off[i];
         const int32_t lseq = (int32_t)le32(p + F_LSEQ);
@@ -929,14 +950,26 @@ static void wg_aux_copy(void *ctx, int64_t lo, int64_t hi, int tid)
     }
 }
 
-int crumble_bam_write_group(crumble_bam_writer *w, crumble_bam_reader *r, const uint8_t *qual_out)
+static int write_group(crumble_bam_writer *w, crumble_bam_reader *r, const uint8_t *qual_out, const crumble_coded *coded);
+int crumble_bam_write_group(crumble_bam_writer *w, crumble_bam_reader *r, const uint8_t *qual_out) { return write_group(w, r, qual_out, NULL); }
+int crumble_bam_write_group_coded(crumble_bam_writer *w, crumble_bam_reader *r, const crumble_coded *c)
+{
+    if (r->n && (!c || c->n_bases != r->seq_off[r->n])) return fail(CRUMBLE_EINVAL, "crumble_bam_write_group_coded: the coded result is not this group's");
+    return write_group(w, r, NULL, c);
+}
+int crumble_bam_write_detached_coded(crumble_bam_writer *w, crumble_bam_group *g, const crumble_coded *c)
+{
+    return crumble_bam_write_group_coded(w, (crumble_bam_reader *)g, c);
+}
+
+static int write_group(crumble_bam_writer *w, crumble_bam_reader *r, const uint8_t *qual_out, const crumble_coded *coded)
 {
     if (r->n == 0) return 0;
     const double tsc = now_s();
     const int binning = w->bd[0] | w->bd[1] | w->bd[2] | w->bi[0] | w->bi[1] | w->bi[2];
-    wg_job job = { w, r, qual_out, binning, 0 };
+    wg_job job = { w, r, qual_out, binning, 0, coded };
     atomic_init(&job.bad, 0);
-    if (qual_out) team_run(w->tm, r->n, 0, wg_scatter, &job);
+    if (qual_out || coded) team_run(w->tm, r->n, 0, wg_scatter, &job);
     const size_t first = r->rec_off[0];
     if (!w->aux_mode && !binning) {
         T_scatter += now_s() - tsc;

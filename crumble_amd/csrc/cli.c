@@ -71,6 +71,7 @@ typedef struct job {
     int64_t seq; int dev, done, err;
     crumble_bam_group *g; crumble_batch B;
     uint8_t *qout; size_t qcap;
+    crumble_coded coded; int is_coded;     /* the result as 2 bits per base + escapes (buffers inside qout) */
     int32_t *sus_pos; uint8_t *sus_why; int64_t n_sus;     /* -b */
     char errtxt[256];
 } job;
@@ -81,6 +82,7 @@ typedef struct {
     int64_t next_write; int closing, failed;
     int ndev, devices[MAX_DEV]; crumble_hip *eng[MAX_DEV]; void *comm[MAX_DEV];
     int want_suspect, use_rccl;
+    int plain_download;             /* CRUMBLE_HIP_PLAIN_DOWNLOAD=1: one byte per base back from the device (tests compare both ways) */
     crumble_bam_writer *wr; crumble_bam_reader *rd; FILE *bed_fp;
     double t_gpu[MAX_DEV], t_write; int verbose;
     int64_t stats[CRUMBLE_ST_N];
@@ -99,11 +101,26 @@ static void *gpu_worker(void *a_)
         pthread_mutex_unlock(&p->mu);
         const double t0 = now();
         const size_t nb = (size_t)j->B.seq_off[j->B.n_reads];
-        j->qcap = nb + 64; j->qout = crumble_bam_big_alloc(j->qcap);
-        if (!j->qout) { j->err = CRUMBLE_ENOMEM; snprintf(j->errtxt, sizeof j->errtxt, "out of memory"); }
+        /* upload + run, then the result in coded form (2 bits per base + the escape bytes: a quarter of the bytes over
+         * PCIe; the writer expands it into the records, which still hold the input qualities).  A batch with many escapes
+         * (long reads with P-block) comes back as plain bytes. */
+        crumble_hip *eng = p->eng[d];
+        if ((j->err = crumble_hip_contig_run(eng, &j->B)) || (j->err = crumble_hip_encode(eng, &j->coded)))
+            snprintf(j->errtxt, sizeof j->errtxt, "%s (%s)", crumble_hip_strerror(j->err), crumble_hip_last_error());
         else {
-            j->err = crumble_hip_contig(p->eng[d], &j->B, j->qout, NULL, NULL);   /* stats stay on the device */
-            if (j->err) snprintf(j->errtxt, sizeof j->errtxt, "%s (%s)", crumble_hip_strerror(j->err), crumble_hip_last_error());
+            crumble_coded *c = &j->coded;
+            j->is_coded = !p->plain_download && (size_t)c->n_escapes <= nb / 8;
+            const size_t o1 = ((size_t)c->n_words * 4 + 63) & ~(size_t)63, o2 = o1 + (((size_t)c->n_blocks * 8 + 63) & ~(size_t)63);
+            j->qcap = (j->is_coded ? o2 + (size_t)c->n_escapes : nb) + 64;
+            j->qout = crumble_bam_big_alloc(j->qcap);
+            if (!j->qout) { j->err = CRUMBLE_ENOMEM; snprintf(j->errtxt, sizeof j->errtxt, "out of memory"); }
+            else {
+                if (j->is_coded) {
+                    c->codes = (uint32_t *)j->qout; c->esc_off = (int64_t *)(j->qout + o1); c->esc = j->qout + o2;
+                    j->err = crumble_hip_download_coded(eng, c, NULL, NULL);            /* stats stay on the device */
+                } else j->err = crumble_hip_download(eng, j->qout, NULL, NULL);
+                if (j->err) snprintf(j->errtxt, sizeof j->errtxt, "%s (%s)", crumble_hip_strerror(j->err), crumble_hip_last_error());
+            }
         }
         if (!j->err && p->want_suspect && j->B.tid >= 0) {        /* -b: snp_score.c:1496,1676,1768,1802,1810 */
             const int64_t ns = crumble_hip_suspect(p->eng[d], NULL, NULL, 0);
@@ -164,7 +181,9 @@ static void *writer_thread(void *p_)
         }
         if (!p->failed) {
             if (j->n_sus) print_suspects(p->bed_fp, crumble_bam_ref_name(p->rd, j->B.tid), j->sus_pos, j->sus_why, j->n_sus);
-            if (crumble_bam_write_detached(p->wr, j->g, j->qout)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); p->failed = 1; }
+            if (j->is_coded ? crumble_bam_write_detached_coded(p->wr, j->g, &j->coded) : crumble_bam_write_detached(p->wr, j->g, j->qout)) {
+                fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); p->failed = 1;
+            }
         }
         if (p->verbose > 1) fprintf(stderr, "  %s: %lld reads on device %d\n", crumble_bam_ref_name(p->rd, j->B.tid), (long long)j->B.n_reads, p->devices[j->dev]);
         crumble_bam_group_free(j->g); crumble_bam_big_free(j->qout, j->qcap); free(j->sus_pos); free(j->sus_why);
@@ -291,6 +310,7 @@ static void run_windowed(pipe_t *p, job *j)
         w->vb.n_reads = m; w->vb.pos = B->pos + lo; w->vb.mapq = B->mapq + lo; w->vb.flag = B->flag + lo;
         w->vb.seq_off = w->seq_off; w->vb.cig_off = w->cig_off; w->vb.cigar = B->cigar + c0;
         w->vb.bases = B->bases + b0; w->vb.quals = B->quals + b0;
+        if (B->l_qseq && B->n_cigar) { w->vb.l_qseq = B->l_qseq + lo; w->vb.n_cigar = B->n_cigar + lo; w->vb.n_bases = B->seq_off[hi] - b0; w->vb.n_cigar_ops = B->cig_off[hi] - c0; }
     }
     {
         crumble_carry carry, nxt;
@@ -489,6 +509,7 @@ int main(int argc, char **argv)
     memset(&p, 0, sizeof p);
     pthread_mutex_init(&p.mu, NULL); pthread_cond_init(&p.cv, NULL);
     p.verbose = verbose; p.bed_fp = bed_fp; p.want_suspect = bed_fp != NULL;
+    p.plain_download = getenv("CRUMBLE_HIP_PLAIN_DOWNLOAD") && atoi(getenv("CRUMBLE_HIP_PLAIN_DOWNLOAD"));
     if (ngpu < 1 || ngpu > MAX_DEV) { fprintf(stderr, "crumble-hip: -j must be 1..%d\n", MAX_DEV); return 1; }
     p.ndev = ngpu;
     {   /* device list: CRUMBLE_HIP_DEVICES="a,b,.." (tests may name one device twice), else CRUMBLE_HIP_DEVICE + k */

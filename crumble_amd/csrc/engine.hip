@@ -35,6 +35,19 @@ extern "C" const char *crumble_hip_last_error(void) { return g_last_error.c_str(
     char buf_[512]; snprintf(buf_, sizeof buf_, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
     g_last_error = buf_; return CRUMBLE_EHIP; } } while (0)
 
+/* blocking copies / fills ON THE ENGINE'S STREAM (a non-blocking stream: the null stream's implicit ordering does not
+ * reach it, so nothing in this file uses the null stream) */
+static inline hipError_t copy_sync(hipStream_t st, void *dst, const void *src, size_t n, hipMemcpyKind kind)
+{
+    hipError_t e = hipMemcpyAsync(dst, src, n, kind, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+static inline hipError_t fill_sync(hipStream_t st, void *dst, int v, size_t n)
+{
+    hipError_t e = hipMemsetAsync(dst, v, n, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+
 /* grow-only device buffer */
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
@@ -64,6 +77,8 @@ struct crumble_hip {
     crumble_params params;
     DParams hparams;
     DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc, d_mqslot;
+    DevBuf d_lq, d_ncg;             /* BAM's own per-read lengths, when the batch carries them instead of the offset tables (views into d_raw) */
+    size_t up_bytes = 0, down_bytes = 0;    /* bytes the last upload copied from the host / the last download copied to it */
     DevBuf d_raw;                   /* arena of the raw arrays of an upload: d_pos, d_mapq, d_flag, d_seq_off, d_cig_off, d_cigar, d_quals,
                                      * d_bases4 (or d_bases), d_bed_*, d_mqslot are views into it */
     void *stage = nullptr;          /* page-locked staging buffer of small uploads (RAW_STAGE_MAX bytes) */
@@ -88,6 +103,8 @@ struct crumble_hip {
     DevBuf d_trigcol_pos, d_trigcol_off, d_inscol_pos, d_items, d_colhi, d_ub, d_pmax_partial, d_trig_mx2;
     /* outputs */
     DevBuf d_out, d_rflags, d_keepf, d_b15f, d_blk_read, d_chunk_read, d_kept, d_marks;
+    DevBuf d_codes, d_escoff, d_esc;        /* the result in coded form (crumble_hip_encode) */
+    bool have_coded = false;
     DBatch B;
     bool have_batch = false, have_run = false;
     /* what crumble_hip_expand() needs beyond the raw arrays on the device (set by the copy half of an upload) */
@@ -259,7 +276,9 @@ extern "C" crumble_hip *crumble_hip_create(const crumble_params *p, int device, 
         h->packed_ok = ok;
     }
     if (hipSetDevice(device) != hipSuccess) { g_last_error = "hipSetDevice failed"; return fail(CRUMBLE_EHIP); }
-    if (hipStreamCreate(&h->stream) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(CRUMBLE_EHIP); }
+    /* a non-blocking stream: nothing this engine does waits for (or holds up) the null stream -- several engines on one
+     * device (crumble-hip's pipeline, windows) overlap their copies and kernels */
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(CRUMBLE_EHIP); }
     if (hipHostMalloc(&h->pinned, 512, 0) != hipSuccess) { h->pinned = nullptr; g_last_error = "hipHostMalloc failed"; return fail(CRUMBLE_ENOMEM); }
     for (int i = 0; i <= MAX_STAGES; i++)
         if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(CRUMBLE_EHIP); }
@@ -284,10 +303,10 @@ extern "C" crumble_hip *crumble_hip_create(const crumble_params *p, int device, 
         (e = h->d_stats.reserve(CRUMBLE_ST_N * 8)) || (e = h->d_batch_stats.reserve(CRUMBLE_ST_N * 8 + 256)) ||
         (e = h->d_misc.reserve(256)))
         return fail(e);
-    if (hipMemcpy(h->d_params.p, &h->hparams, sizeof(DParams), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(h->d_tables.p, tab, sizeof(DTables), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(h->d_stats.p, 0, CRUMBLE_ST_N * 8) != hipSuccess ||
-        hipMemset(h->d_batch_stats.p, 0, CRUMBLE_ST_N * 8) != hipSuccess) {
+    if (copy_sync(h->stream, h->d_params.p, &h->hparams, sizeof(DParams), hipMemcpyHostToDevice) != hipSuccess ||
+        copy_sync(h->stream, h->d_tables.p, tab, sizeof(DTables), hipMemcpyHostToDevice) != hipSuccess ||
+        fill_sync(h->stream, h->d_stats.p, 0, CRUMBLE_ST_N * 8) != hipSuccess ||
+        fill_sync(h->stream, h->d_batch_stats.p, 0, CRUMBLE_ST_N * 8) != hipSuccess) {
         g_last_error = "uploading tables failed";
         return fail(CRUMBLE_EHIP);
     }
@@ -308,7 +327,8 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
         &h->d_trigcnt, &h->d_dpre, &h->d_col_ord, &h->d_trig_ord, &h->d_item_off, &h->d_ins_ord,
         &h->d_pos_mn2, &h->d_partial, &h->d_epochs, &h->d_ht, &h->d_trigcol_pos, &h->d_trigcol_off,
         &h->d_inscol_pos, &h->d_items, &h->d_colhi, &h->d_ub, &h->d_pmax_partial, &h->d_trig_mx2,
-        &h->d_out, &h->d_rflags, &h->d_keepf, &h->d_b15f, &h->d_blk_read, &h->d_chunk_read, &h->d_kept, &h->d_marks };
+        &h->d_out, &h->d_rflags, &h->d_keepf, &h->d_b15f, &h->d_blk_read, &h->d_chunk_read, &h->d_kept, &h->d_marks,
+        &h->d_codes, &h->d_escoff, &h->d_esc, &h->d_lq, &h->d_ncg };
     for (DevBuf *b : all) b->release();
     if (h->events_ok) { for (int i = 0; i <= MAX_STAGES; i++) (void)hipEventDestroy(h->ev[i]); for (int i = 0; i < 3; i++) (void)hipEventDestroy(h->ev_up[i]); }
     if (h->pinned) (void)hipHostFree(h->pinned);
@@ -390,7 +410,10 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
 {
     hipStream_t st = h->stream;
     const int64_t n = b->n_reads;
-    const int64_t nb = n ? b->seq_off[n] : 0, nc = n ? b->cig_off[n] : 0;
+    /* the offset tables, or BAM's own per-read lengths (6 bytes per read over PCIe instead of 16; offsets made on the device) */
+    const bool lens = b->l_qseq != nullptr && b->n_cigar != nullptr;
+    if (!lens && n && (!b->seq_off || !b->cig_off)) { g_last_error = "crumble_batch: neither seq_off / cig_off nor l_qseq / n_cigar"; return CRUMBLE_EINVAL; }
+    const int64_t nb = !n ? 0 : lens ? b->n_bases : b->seq_off[n], nc = !n ? 0 : lens ? b->n_cigar_ops : b->cig_off[n];
     if (n >= (int64_t)INT_MAX - 64) { g_last_error = "more than 2^31 reads in one batch"; return CRUMBLE_EINVAL; }
     if (nb < 0 || nc < 0) { g_last_error = "negative total length"; return CRUMBLE_EINVAL; }
     h->have_batch = false; h->have_run = false; h->have_raw = false; h->have_hits = false;
@@ -437,12 +460,14 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
      * qualities (and one-byte-per-base bases) carry BASE_FRONT_PAD zeroed bytes in front: k_columns2 loads the whole
      * 16-column segment that holds a read's first aligned base */
     static const int64_t zero64 = 0;
-    struct Item { DevBuf *d; const void *src; size_t bytes, front; size_t off; };
+    struct Item { DevBuf *d; const void *src; size_t bytes, front; size_t off; size_t room; };
     const size_t b4bytes = packed4 ? (size_t)CRUMBLE_BASES4_SIZE(nb, n) : 0;
+    const bool dev_offsets = lens && n > 0;               /* (room: bytes the view holds; bytes: what is copied from the host) */
     Item items[] = {
         {&h->d_pos, b->pos, (size_t)n * 4, 0, 0}, {&h->d_mapq, b->mapq, (size_t)n, 0, 0}, {&h->d_flag, b->flag, (size_t)n * 2, 0, 0},
-        {&h->d_seq_off, n ? (const void *)b->seq_off : (const void *)&zero64, (size_t)(n + 1) * 8, 0, 0},
-        {&h->d_cig_off, n ? (const void *)b->cig_off : (const void *)&zero64, (size_t)(n + 1) * 8, 0, 0},
+        {&h->d_seq_off, dev_offsets ? nullptr : n ? (const void *)b->seq_off : (const void *)&zero64, dev_offsets ? 0 : (size_t)(n + 1) * 8, 0, 0, (size_t)(n + 1) * 8},
+        {&h->d_cig_off, dev_offsets ? nullptr : n ? (const void *)b->cig_off : (const void *)&zero64, dev_offsets ? 0 : (size_t)(n + 1) * 8, 0, 0, (size_t)(n + 1) * 8},
+        {&h->d_lq, b->l_qseq, dev_offsets ? (size_t)n * 4 : 0, 0, 0}, {&h->d_ncg, b->n_cigar, dev_offsets ? (size_t)n * 2 : 0, 0, 0},
         {&h->d_cigar, b->cigar, (size_t)nc * 4, 0, 0},
         {&h->d_quals, b->quals, (size_t)nb, BASE_FRONT_PAD, 0},
         {packed4 ? &h->d_bases4 : &h->d_bases, packed4 ? (const void *)b->bases4 : (const void *)b->bases, packed4 ? b4bytes : (size_t)nb, packed4 ? 0 : (size_t)BASE_FRONT_PAD, 0},
@@ -450,10 +475,10 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
         {&h->d_bed_pmax, pmax.data(), (size_t)n_bed * 4, 0, 0}, {&h->d_mqslot, h->raw_mqtab, sizeof h->raw_mqtab, 0, 0},
     };
     size_t total = 0;
-    for (Item &it : items) { it.off = total; total += (it.front + it.bytes + 2 * BASE_FRONT_PAD + 64 + 255) & ~(size_t)255; }
+    for (Item &it : items) { if (it.room < it.bytes) it.room = it.bytes; it.off = total; total += (it.front + it.room + 2 * BASE_FRONT_PAD + 64 + 255) & ~(size_t)255; }
     if ((e = h->d_raw.reserve(total))) return e;
     uint8_t *base = h->d_raw.as<uint8_t>();
-    for (Item &it : items) it.d->view(base + it.off, it.front + it.bytes + 2 * BASE_FRONT_PAD + 64);
+    for (Item &it : items) it.d->view(base + it.off, it.front + it.room + 2 * BASE_FRONT_PAD + 64);
     if (packed4) {                                       /* the one-byte-per-base form is made on the device */
         if (h->d_bases.owned == false) h->d_bases = DevBuf();
         if ((e = h->d_bases.reserve((size_t)nb + 2 * BASE_FRONT_PAD + 64))) return e;
@@ -477,8 +502,19 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
             if (it.front) HIPCHK(hipMemsetAsync(base + it.off, 0, it.front, st));
             if (it.bytes) HIPCHK(hipMemcpyAsync(base + it.off + it.front, it.src, it.bytes, hipMemcpyHostToDevice, st));
         }
+    if (dev_offsets) {                                  /* seq_off[n + 1], cig_off[n + 1] from the lengths, on the device */
+        const int nch = (int)((n + P0_CHUNK - 1) / P0_CHUNK);
+        if ((e = h->d_tpart.reserve((size_t)(2 * (nch + 1) + 2) * 8))) return e;
+        int64_t *tp = h->d_tpart.as<int64_t>();
+        CRUMBLE_LAUNCH(k_p0_len_reduce, nch, 256, st, n, h->d_lq.as<int32_t>(), h->d_ncg.as<uint16_t>(), tp, nch);
+        CRUMBLE_LAUNCH(k_i64scan_partials, 2, 1024, st, tp, nch);
+        CRUMBLE_LAUNCH(k_p0_len_apply, nch, 256, st, n, h->d_lq.as<int32_t>(), h->d_ncg.as<uint16_t>(), (const int64_t *)tp, nch,
+                       h->d_seq_off.as<int64_t>(), h->d_cig_off.as<int64_t>());
+    }
     h->raw_tid = b->tid; h->raw_nbed = n_bed; h->raw_packed4 = packed4;
     h->n_reads = n; h->n_bases = nb; h->n_cigar = nc;
+    h->up_bytes = 0;
+    for (const Item &it : items) h->up_bytes += it.bytes;
     HIPCHK(hipEventRecord(h->ev_up[1], st));
     h->have_raw = true;
     return CRUMBLE_OK;
@@ -821,8 +857,8 @@ extern "C" int crumble_hip_set_window(crumble_hip *h, const crumble_window *w)
     int64_t o2[2] = {0, 0};
     HIPCHK(hipSetDevice(h->device));
     if (h->n_reads > 0) {
-        HIPCHK(hipMemcpy(&o2[0], h->d_seq_off.as<int64_t>() + w->read_first, 8, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(&o2[1], h->d_seq_off.as<int64_t>() + w->read_end, 8, hipMemcpyDeviceToHost));
+        HIPCHK(copy_sync(h->stream, &o2[0], h->d_seq_off.as<int64_t>() + w->read_first, 8, hipMemcpyDeviceToHost));
+        HIPCHK(copy_sync(h->stream, &o2[1], h->d_seq_off.as<int64_t>() + w->read_end, 8, hipMemcpyDeviceToHost));
     }
     h->own_b_lo = o2[0]; h->own_b_hi = o2[1];
     return CRUMBLE_OK;
@@ -876,7 +912,7 @@ extern "C" int crumble_hip_run_columns(crumble_hip *h)
 {
     if (!h || !h->have_batch) { g_last_error = "no batch uploaded"; return CRUMBLE_EINVAL; }
     RUN_LOCALS
-    h->n_stages = 0; h->have_run = false; h->fold_small = false;
+    h->n_stages = 0; h->have_run = false; h->fold_small = false; h->have_coded = false;
     memset(&h->totals, 0, sizeof(h->totals));
     HIPCHK(hipMemsetAsync(stats, 0, CRUMBLE_ST_N * 8 + 64, st));      /* the counters and the run flags */
 
@@ -1265,12 +1301,14 @@ extern "C" int crumble_hip_run(crumble_hip *h)
 static int staged_d2h(crumble_hip *h, uint8_t *dst, const uint8_t *src, size_t bytes)
 {
     const size_t CH = h->dl_chunk;
-    if (bytes < 4 * CH) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return CRUMBLE_OK; }
+    /* (never the null stream: a copy there would wait for, and hold up, every blocking stream of the device) */
+#define D2H_PLAIN() do { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream)); } while (0)
+    if (bytes < 4 * CH) { D2H_PLAIN(); return CRUMBLE_OK; }
 #ifndef CRUMBLE_EMU
     {   /* a destination that is page-locked already (crumble_hip_host_alloc, hipHostRegister) needs no staging */
         hipPointerAttribute_t at;
         if (hipPointerGetAttributes(&at, dst) == hipSuccess && at.type == hipMemoryTypeHost) {
-            HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+            D2H_PLAIN();
             return CRUMBLE_OK;
         }
         (void)hipGetLastError();                        /* (an ordinary pointer: the query's error is not ours) */
@@ -1281,7 +1319,7 @@ static int staged_d2h(crumble_hip *h, uint8_t *dst, const uint8_t *src, size_t b
          * should the page-locked memory not be there, what was taken is given back and the copy goes the plain way */
         bool ok = true;
         for (auto &l : h->dl) {
-            if (!l.st && hipStreamCreate(&l.st) != hipSuccess) { l.st = nullptr; ok = false; break; }
+            if (!l.st && hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) != hipSuccess) { l.st = nullptr; ok = false; break; }
             for (int i = 0; i < 2 && ok; i++) {
                 if (l.buf[i] && h->dl_bufsz < CH) { (void)hipHostFree(l.buf[i]); l.buf[i] = nullptr; }
                 if (!l.buf[i] && hipHostMalloc(&l.buf[i], CH, 0) != hipSuccess) { l.buf[i] = nullptr; ok = false; }
@@ -1293,7 +1331,7 @@ static int staged_d2h(crumble_hip *h, uint8_t *dst, const uint8_t *src, size_t b
             for (auto &l : h->dl) for (int i = 0; i < 2; i++) if (l.buf[i]) { (void)hipHostFree(l.buf[i]); l.buf[i] = nullptr; }
             h->dl_ok = false; h->dl_bufsz = 0;
             (void)hipGetLastError();
-            HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+            D2H_PLAIN();
             return CRUMBLE_OK;
         }
         h->dl_ok = true; h->dl_bufsz = CH;
@@ -1326,17 +1364,19 @@ static int staged_d2h(crumble_hip *h, uint8_t *dst, const uint8_t *src, size_t b
     for (int t = 1; t < started; t++) th[t].join();
     if (failed == 2) {
         g_last_error = "staged device -> host copy: could not start a host thread";
-        HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+        D2H_PLAIN();
         return CRUMBLE_OK;
     }
     if (failed) { g_last_error = "staged device -> host copy failed"; return CRUMBLE_EHIP; }
     return CRUMBLE_OK;
+#undef D2H_PLAIN
 }
 
 extern "C" int crumble_hip_download(crumble_hip *h, uint8_t *qual_out, uint8_t *read_flags_out, int64_t *stats)
 {
     if (!h || !h->have_run) { g_last_error = "nothing to download: call crumble_hip_run first"; return CRUMBLE_EINVAL; }
     HIPCHK(hipSetDevice(h->device));
+    h->down_bytes = (qual_out ? (size_t)h->n_bases : 0) + (read_flags_out ? (size_t)h->n_reads : 0) + (stats ? sizeof(int64_t) * CRUMBLE_ST_N : 0);
     if ((size_t)h->n_bases < 4 * h->dl_chunk) {
         /* a small batch: the three copies queued behind one another, one wait (three blocking copies of a few
          * kilobytes each were a tenth of a small contig's fixed cost) */
@@ -1352,14 +1392,74 @@ extern "C" int crumble_hip_download(crumble_hip *h, uint8_t *qual_out, uint8_t *
     if (read_flags_out && h->n_reads) { const int e = staged_d2h(h, read_flags_out, h->d_rflags.as<uint8_t>(), (size_t)h->n_reads); if (e) return e; }
     if (stats) {
         int64_t s[CRUMBLE_ST_N];
-        HIPCHK(hipMemcpy(s, h->d_batch_stats.p, sizeof s, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(s, h->d_batch_stats.p, sizeof s, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
         for (int i = 0; i < CRUMBLE_ST_N; i++) stats[i] += s[i];
     }
     return CRUMBLE_OK;
 }
 
-extern "C" int crumble_hip_contig(crumble_hip *h, const crumble_batch *b, uint8_t *qual_out,
-                                  uint8_t *read_flags_out, int64_t *stats)
+/* ---- coded download (include/crumble_hip.h): 2 bits per base + the escape bytes ---------------------------------- */
+extern "C" int crumble_hip_encode(crumble_hip *h, crumble_coded *c)
+{
+    if (!h || !c || !h->have_run) { g_last_error = "nothing to encode: call crumble_hip_run first"; return CRUMBLE_EINVAL; }
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const int64_t nb = h->n_bases;
+    const int64_t nwords = (nb + 15) / 16, nblocks = (nb + ENC_BLOCK - 1) / ENC_BLOCK;
+    static_assert(ENC_BLOCK == CRUMBLE_CODED_BLOCK, "the device's and the header's block size");
+    int e;
+    if ((e = h->d_codes.reserve((size_t)nwords * 4 + 64)) || (e = h->d_escoff.reserve((size_t)(nblocks + 1) * 8)) ||
+        (e = h->d_esc.reserve((size_t)nb + 64)) || (e = h->d_misc.reserve(256)))
+        return e;
+    /* d_misc [32..33]: the escape total (64 bits), [34]: the two values (bytes) */
+    unsigned long long *d_tot = (unsigned long long *)(h->d_misc.as<int>() + 32);
+    uint8_t *d_pick = (uint8_t *)(h->d_misc.as<int>() + 34);
+    CRUMBLE_LAUNCH(k_encode_pick, 1, 256, st, nb, (const uint8_t *)h->d_out.as<uint8_t>(), h->B.quals, h->d_params.as<DParams>(), d_pick, d_tot);
+    if (nb > 0) {
+        const unsigned g = (unsigned)std::min<int64_t>(nblocks, (int64_t)h->persistent_blocks * 8);
+        CRUMBLE_LAUNCH(k_encode, g, 256, st, nb, (const uint8_t *)h->d_out.as<uint8_t>(), h->B.quals, h->d_params.as<DParams>(),
+                       (const uint8_t *)d_pick, h->d_codes.as<uint32_t>(), h->d_escoff.as<int64_t>(), h->d_esc.as<uint8_t>(), d_tot);
+    }
+    HIPCHK(hipMemcpyAsync((char *)h->pinned + 320, d_tot, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    unsigned long long tot = 0;
+    memcpy(&tot, (char *)h->pinned + 320, 8);
+    memset(c, 0, sizeof *c);
+    c->n_bases = nb; c->n_words = nwords; c->n_blocks = nblocks; c->n_escapes = (int64_t)tot;
+    memcpy(c->value, (char *)h->pinned + 328, 2);
+    for (int q = 0; q < 256; q++)
+        c->cap[q] = (uint8_t)((q > h->hparams.qcap && !h->hparams.preserve_qual[q]) ? h->hparams.qcap : q);   /* cap_quality snp:1325-1332 */
+    h->have_coded = true;
+    return CRUMBLE_OK;
+}
+
+extern "C" int crumble_hip_download_coded(crumble_hip *h, const crumble_coded *c, uint8_t *read_flags_out, int64_t *stats)
+{
+    if (!h || !c || !h->have_run || !h->have_coded) { g_last_error = "crumble_hip_download_coded: call crumble_hip_encode first"; return CRUMBLE_EINVAL; }
+    if (c->n_bases != h->n_bases || (c->n_words && !c->codes) || (c->n_blocks && !c->esc_off) || (c->n_escapes && !c->esc)) {
+        g_last_error = "crumble_hip_download_coded: the coded result's buffers are not set"; return CRUMBLE_EINVAL;
+    }
+    HIPCHK(hipSetDevice(h->device));
+    int e;
+    h->down_bytes = (size_t)c->n_words * 4 + (size_t)c->n_blocks * 8 + (size_t)c->n_escapes + (read_flags_out ? (size_t)h->n_reads : 0) + (stats ? sizeof(int64_t) * CRUMBLE_ST_N : 0);
+    if (c->n_words && (e = staged_d2h(h, (uint8_t *)c->codes, h->d_codes.as<uint8_t>(), (size_t)c->n_words * 4))) return e;
+    hipStream_t st = h->stream;
+    int64_t s[CRUMBLE_ST_N];
+    if (c->n_blocks) HIPCHK(hipMemcpyAsync(c->esc_off, h->d_escoff.p, (size_t)c->n_blocks * 8, hipMemcpyDeviceToHost, st));
+    if (c->n_escapes) {
+        if ((size_t)c->n_escapes >= 4 * h->dl_chunk) { if ((e = staged_d2h(h, c->esc, h->d_esc.as<uint8_t>(), (size_t)c->n_escapes))) return e; }
+        else HIPCHK(hipMemcpyAsync(c->esc, h->d_esc.p, (size_t)c->n_escapes, hipMemcpyDeviceToHost, st));
+    }
+    if (read_flags_out && h->n_reads) HIPCHK(hipMemcpyAsync(read_flags_out, h->d_rflags.p, (size_t)h->n_reads, hipMemcpyDeviceToHost, st));
+    if (stats) HIPCHK(hipMemcpyAsync(s, h->d_batch_stats.p, sizeof s, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (stats) for (int i = 0; i < CRUMBLE_ST_N; i++) stats[i] += s[i];
+    return CRUMBLE_OK;
+}
+
+extern "C" int crumble_hip_contig_run(crumble_hip *h, const crumble_batch *b)
 {
     int e;
     if (!h || !b || b->n_reads < 0) return CRUMBLE_EINVAL;
@@ -1367,7 +1467,14 @@ extern "C" int crumble_hip_contig(crumble_hip *h, const crumble_batch *b, uint8_
     HIPCHK(hipEventRecord(h->ev_up[0], h->stream));
     /* the expansion's tail runs into the run's first kernels: its late errors are looked at with the run's own read-back */
     if ((e = copy_raw(h, b)) || (e = expand(h, false))) return e;
-    if ((e = crumble_hip_run(h))) return e;
+    return crumble_hip_run(h);
+}
+
+extern "C" int crumble_hip_contig(crumble_hip *h, const crumble_batch *b, uint8_t *qual_out,
+                                  uint8_t *read_flags_out, int64_t *stats)
+{
+    const int e = crumble_hip_contig_run(h, b);
+    if (e) return e;
     return crumble_hip_download(h, qual_out, read_flags_out, stats);
 }
 
@@ -1391,6 +1498,14 @@ extern "C" int crumble_hip_upload_times(crumble_hip *h, float *h2d_ms, float *p0
     return CRUMBLE_OK;
 }
 
+extern "C" int crumble_hip_transfer_bytes(crumble_hip *h, int64_t *up, int64_t *down)
+{
+    if (!h) return CRUMBLE_EINVAL;
+    if (up) *up = (int64_t)h->up_bytes;
+    if (down) *down = (int64_t)h->down_bytes;
+    return CRUMBLE_OK;
+}
+
 extern "C" void *crumble_hip_host_alloc(size_t bytes)
 {
     void *p = nullptr;
@@ -1405,14 +1520,24 @@ extern "C" int crumble_hip_stats_reset(crumble_hip *h)
 {
     if (!h) return CRUMBLE_EINVAL;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipMemset(h->d_stats.p, 0, CRUMBLE_ST_N * 8));
+    HIPCHK(fill_sync(h->stream, h->d_stats.p, 0, CRUMBLE_ST_N * 8));
+    return CRUMBLE_OK;
+}
+extern "C" int crumble_hip_stats_add(crumble_hip *h, const int64_t *stats)
+{
+    if (!h || !stats) return CRUMBLE_EINVAL;
+    HIPCHK(hipSetDevice(h->device));
+    int64_t cur[CRUMBLE_ST_N];
+    HIPCHK(copy_sync(h->stream, cur, h->d_stats.p, sizeof cur, hipMemcpyDeviceToHost));
+    for (int i = 0; i < CRUMBLE_ST_N; i++) cur[i] += stats[i];
+    HIPCHK(copy_sync(h->stream, h->d_stats.p, cur, sizeof cur, hipMemcpyHostToDevice));
     return CRUMBLE_OK;
 }
 extern "C" int crumble_hip_stats_read(crumble_hip *h, int64_t *stats)
 {
     if (!h || !stats) return CRUMBLE_EINVAL;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipMemcpy(stats, h->d_stats.p, CRUMBLE_ST_N * 8, hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(h->stream, stats, h->d_stats.p, CRUMBLE_ST_N * 8, hipMemcpyDeviceToHost));
     return CRUMBLE_OK;
 }
 
@@ -1511,10 +1636,10 @@ extern "C" int64_t crumble_hip_columns(crumble_hip *h, crumble_column *cols, int
     std::vector<uint32_t> rec(L > 0 ? L : 1);
     std::vector<int32_t> np(L > 0 ? L : 1), sc(L > 0 ? L : 1), mn2(L > 0 ? L : 1);
     if (L > 0) {
-        if (hipMemcpy(rec.data(), h->d_colrec.p, (size_t)L * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(np.data(), h->d_nplp.p, (size_t)L * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(sc.data(), h->d_score.p, (size_t)L * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(mn2.data(), h->d_pos_mn2.p, (size_t)L * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        if (copy_sync(h->stream, rec.data(), h->d_colrec.p, (size_t)L * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            copy_sync(h->stream, np.data(), h->d_nplp.p, (size_t)L * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            copy_sync(h->stream, sc.data(), h->d_score.p, (size_t)L * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            copy_sync(h->stream, mn2.data(), h->d_pos_mn2.p, (size_t)L * 4, hipMemcpyDeviceToHost) != hipSuccess)
             return CRUMBLE_EHIP;
     }
     int64_t k = 0;
@@ -1550,7 +1675,7 @@ extern "C" int64_t crumble_hip_suspect(crumble_hip *h, int32_t *pos, uint8_t *wh
     const int L = h->B.L;
     if (L <= 0) return 0;
     std::vector<uint32_t> rec((size_t)L);
-    if (hipMemcpy(rec.data(), h->d_colrec.p, (size_t)L * 4, hipMemcpyDeviceToHost) != hipSuccess) return CRUMBLE_EHIP;
+    if (copy_sync(h->stream, rec.data(), h->d_colrec.p, (size_t)L * 4, hipMemcpyDeviceToHost) != hipSuccess) return CRUMBLE_EHIP;
     int64_t k = 0;
     for (int i = 0; i < L; i++) {
         const uint32_t r = rec[i];
@@ -1582,13 +1707,13 @@ extern "C" int crumble_hip_mask_lc(crumble_hip *h, int64_t nq, const int64_t *re
     int e = d.reserve((size_t)nq * sizeof(TrigItem));
     if (e) return e;
     int *d_overflow = h->d_misc.as<int>();
-    HIPCHK(hipMemset(d_overflow, 0, 4));
-    HIPCHK(hipMemcpy(d.p, it.data(), (size_t)nq * sizeof(TrigItem), hipMemcpyHostToDevice));
+    HIPCHK(fill_sync(h->stream, d_overflow, 0, 4));
+    HIPCHK(copy_sync(h->stream, d.p, it.data(), (size_t)nq * sizeof(TrigItem), hipMemcpyHostToDevice));
     CRUMBLE_LAUNCH_INDEP(k_str, nblk(nq, 64), 64, h->stream, h->B, h->d_params.as<DParams>(), (int)nq, (const int *)nullptr, (const int *)nullptr, d.as<TrigItem>(), d_overflow);
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(it.data(), d.p, (size_t)nq * sizeof(TrigItem), hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(h->stream, it.data(), d.p, (size_t)nq * sizeof(TrigItem), hipMemcpyDeviceToHost));
     int ovf = 0;
-    HIPCHK(hipMemcpy(&ovf, d_overflow, 4, hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(h->stream, &ovf, d_overflow, 4, hipMemcpyDeviceToHost));
     d.release();
     if (ovf) return CRUMBLE_EOVERFLOW;
     for (int64_t i = 0; i < nq; i++) { lo[i] = it[i].lo; hi[i] = it[i].hi; }
@@ -1606,12 +1731,12 @@ extern "C" int crumble_hip_pblock(crumble_hip *h, int64_t n_reads, const int64_t
     DevBuf dq, ds;
     int e;
     if ((e = dq.reserve((size_t)nb + 64)) || (e = ds.reserve((size_t)(n_reads + 1) * 8))) return e;
-    if (nb) HIPCHK(hipMemcpy(dq.p, quals, (size_t)nb, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ds.p, seq_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice));
+    if (nb) HIPCHK(copy_sync(h->stream, dq.p, quals, (size_t)nb, hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(h->stream, ds.p, seq_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice));
     if (h->hparams.pblock && nb > 0 && (e = launch_pblock(h, h->stream, n_reads, nb, ds.as<int64_t>(), dq.as<uint8_t>(), nullptr, nullptr, h->opt_pblock)))
         return e;
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (nb) HIPCHK(hipMemcpy(quals, dq.p, (size_t)nb, hipMemcpyDeviceToHost));
+    if (nb) HIPCHK(copy_sync(h->stream, quals, dq.p, (size_t)nb, hipMemcpyDeviceToHost));
     dq.release(); ds.release();
     return CRUMBLE_OK;
 }
@@ -1635,7 +1760,7 @@ extern "C" int crumble_hip_indel_only(crumble_hip *h, int dist, int q, uint8_t *
     CRUMBLE_LAUNCH_INDEP(k_indel_only, nblk(nb, 256), 256, h->stream, h->B, h->d_blk_read.as<int32_t>(), dist, q,
                          h->d_out.as<uint8_t>());
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(qual_out, h->d_out.p, (size_t)nb, hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(h->stream, qual_out, h->d_out.p, (size_t)nb, hipMemcpyDeviceToHost));
     h->have_run = false;                 /* d_out no longer holds crumble_hip_run's result */
     return CRUMBLE_OK;
 }

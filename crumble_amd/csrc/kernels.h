@@ -3812,6 +3812,120 @@ k_stats(int64_t b_lo, int64_t b_hi, int64_t n_reads, const uint8_t *out, const u
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/* The result in coded form (crumble_hip_encode; include/crumble_hip.h "coded download"): what crosses PCIe on the way
+ * out.  After the pass almost every quality byte is one of two values (qhigh / qlow at the numeric presets: the two
+ * fullest bins among the bytes the pass changed are taken, k_encode_pick) or the read's own input quality after cap_quality
+ * (snp:1325-1332: kept reads, STR windows, back-fill ranges, preserved values) -- which the host still holds.  So the
+ * device hands back 2 bits per base, 16 bases to a 32-bit word (base i in bits 2*(i & 15)):
+ *   0 = value[0], 1 = value[1], 2 = cap[input quality], 3 = the next byte of the escape stream
+ * plus the escape bytes themselves (P-block averages, bin2[] levels that are neither of the two values), in base order
+ * inside every 4096-base block; esc_off[block] is where the block's escapes start (blocks reserve their slice with
+ * ONE atomic each, and only blocks that have escapes do).  The host expands it while it writes the records
+ * (bamio.c) -- a quarter of the bytes over the link, the same bytes in the file. */
+#define ENC_BLOCK 4096
+/* the two values of codes 0 and 1: the two fullest bins among the bytes the pass CHANGED (a byte that still equals its
+ * capped input is code 2 whatever its value), from a sample of 16-byte chunks spread over the batch */
+__global__ void __launch_bounds__(256)
+k_encode_pick(int64_t nb, const uint8_t *__restrict__ out, const uint8_t *__restrict__ in, const DParams *__restrict__ P,
+              uint8_t *__restrict__ pick, unsigned long long *__restrict__ esc_total)
+{
+    __shared__ unsigned hist[128];
+    __shared__ uint8_t cap[256];
+    if (threadIdx.x < 128) hist[threadIdx.x] = 0;
+    {
+        const int qcap = P->qcap, i = threadIdx.x;
+        cap[i] = (uint8_t)((i > qcap && !P->preserve_qual[i]) ? qcap : i);
+    }
+    __syncthreads();
+    const int64_t nch = nb >> 4;
+    const int64_t want = 8192, step = nch > want ? nch / want : 1;
+    for (int64_t k = threadIdx.x; k * step < nch && k < want; k += blockDim.x) {
+        const int64_t b0 = (k * step) << 4;
+        const uint4 o4 = *(const uint4 *)(out + b0), q4 = *(const uint4 *)(in + b0);
+        const uint32_t ow[4] = {o4.x, o4.y, o4.z, o4.w}, qw[4] = {q4.x, q4.y, q4.z, q4.w};
+        #pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const unsigned o = (ow[j >> 2] >> (8 * (j & 3))) & 255, q = (qw[j >> 2] >> (8 * (j & 3))) & 255;
+            if (o != cap[q] && o < 128) atomicAdd(&hist[o], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x) return;
+    int a = -1, b = -1;
+    unsigned ca = 0, cb = 0;
+    for (int i = 0; i < 128; i++) {
+        const unsigned c = hist[i];
+        if (c > ca) { b = a; cb = ca; a = i; ca = c; }
+        else if (c > cb) { b = i; cb = c; }
+    }
+    if (a < 0) a = P->qhigh;
+    if (b < 0) b = (P->qlow != a) ? P->qlow : ((a + 1) & 127);
+    pick[0] = (uint8_t)a; pick[1] = (uint8_t)b;
+    *esc_total = 0;
+}
+
+__global__ void __launch_bounds__(256)
+k_encode(int64_t nb, const uint8_t *__restrict__ out, const uint8_t *__restrict__ in, const DParams *__restrict__ P,
+         const uint8_t *__restrict__ pick, uint32_t *__restrict__ codes, int64_t *__restrict__ esc_off,
+         uint8_t *__restrict__ esc, unsigned long long *__restrict__ esc_total)
+{
+    __shared__ uint8_t cap[256];
+    __shared__ unsigned wtot[4];
+    __shared__ unsigned long long base_s;
+    {
+        const int qcap = P->qcap;
+        const int i = threadIdx.x;
+        cap[i] = (uint8_t)((i > qcap && !P->preserve_qual[i]) ? qcap : i);      /* cap_quality snp:1325-1332 */
+    }
+    const unsigned va = pick[0], vb = pick[1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t nblk = (nb + ENC_BLOCK - 1) / ENC_BLOCK;
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        __syncthreads();                                    /* cap[] filled; wtot / base_s of the last round read */
+        const int64_t b0 = blk * ENC_BLOCK + (int64_t)threadIdx.x * 16;
+        uint32_t code = 0, emask = 0;
+        uint32_t ow[4] = {0, 0, 0, 0};
+        if (b0 < nb) {
+            /* (both arrays carry at least 64 bytes of slack behind their last byte; bytes beyond nb are masked out) */
+            const uint4 o4 = *(const uint4 *)(out + b0), q4 = *(const uint4 *)(in + b0);
+            ow[0] = o4.x; ow[1] = o4.y; ow[2] = o4.z; ow[3] = o4.w;
+            const uint32_t qw[4] = {q4.x, q4.y, q4.z, q4.w};
+            const int nv = nb - b0 < 16 ? (int)(nb - b0) : 16;
+            #pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const unsigned o = (ow[k >> 2] >> (8 * (k & 3))) & 255, q = (qw[k >> 2] >> (8 * (k & 3))) & 255;
+                unsigned c = o == va ? 0u : o == vb ? 1u : o == cap[q] ? 2u : 3u;
+                if (k >= nv) c = 0;
+                code |= c << (2 * k);
+                emask |= (c == 3u ? 1u : 0u) << k;
+            }
+        }
+        const unsigned ne = (unsigned)__popc(emask);
+        unsigned incl = ne;                                 /* inclusive prefix of the escape counts over the wave */
+        #pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        unsigned before = incl - ne, total = 0;
+        #pragma unroll
+        for (int w = 0; w < 4; w++) { if (w < wave) before += wtot[w]; total += wtot[w]; }
+        if (threadIdx.x == 0) {
+            const unsigned long long base = total ? atomicAdd(esc_total, (unsigned long long)total) : 0ull;
+            base_s = base;
+            esc_off[blk] = (int64_t)base;
+        }
+        if (b0 < nb) codes[b0 >> 4] = code;
+        if (total) {                                        /* (uniform over the workgroup) */
+            __syncthreads();
+            uint8_t *e = esc + base_s + before;
+            #pragma unroll
+            for (int k = 0; k < 16; k++)
+                if ((emask >> k) & 1u) *e++ = (uint8_t)((ow[k >> 2] >> (8 * (k & 3))) & 255);
+        }
+    }
+}
+
 /* reads / bases of a batch whose histogram the replay kernels took */
 __global__ void k_stats_totals(int64_t n_reads, int64_t n_bases, u64 *stats)
 {

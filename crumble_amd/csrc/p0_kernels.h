@@ -815,6 +815,7 @@ __global__ void __launch_bounds__(1024)
 k_i64scan_partials(int64_t *partial, int nchunks)
 {
     __shared__ int64_t sh[1024];
+    partial += (size_t)blockIdx.x * ((size_t)nchunks + 1);      /* (grid > 1: several arrays of nchunks + 1 values, one workgroup each) */
     const int t = threadIdx.x, nt = blockDim.x;
     const int per = (nchunks + nt - 1) / nt;
     const int b = t * per, e = b + per < nchunks ? b + per : nchunks;
@@ -853,6 +854,54 @@ k_i64scan_apply(int64_t n, int64_t *__restrict__ v, const int64_t *__restrict__ 
     #pragma unroll
     for (int k = 0; k < 4; k++) { if (i0 + k < n) v[i0 + k] = run; run += x[k]; }
     if (blockIdx.x == (unsigned)(nchunks - 1) && threadIdx.x == 255) v[n] = partial[blockIdx.x] + ws[0] + ws[1] + ws[2] + (w == 3 ? inc : 0);
+}
+
+
+/* The offset arrays from BAM's own per-read fields (crumble_batch.l_qseq / .n_cigar): a read's 32-bit l_seq and 16-bit
+ * n_cigar_op cross PCIe (6 bytes per read) instead of two 64-bit offsets (16), and the exclusive prefix sums
+ * seq_off[n + 1] / cig_off[n + 1] every later kernel reads are made here.  Three launches: chunk sums of both
+ * lengths, k_i64scan_partials over the two partial arrays (grid 2), the offsets.  A negative l_qseq gives offsets
+ * that run backwards, which k_p0_classify reports like any other bad offset table. */
+__global__ void __launch_bounds__(256)
+k_p0_len_reduce(int64_t n, const int32_t *__restrict__ lq, const uint16_t *__restrict__ ncg, int64_t *__restrict__ partial, int nchunks)
+{
+    __shared__ long long ws[8];
+    const int64_t b = (int64_t)blockIdx.x * P0_CHUNK;
+    long long aq = 0, ac = 0;
+    #pragma unroll
+    for (int k = 0; k < P0_CHUNK / 256; k++) { const int64_t i = b + k * 256 + threadIdx.x; if (i < n) { aq += lq[i]; ac += ncg[i]; } }
+    #pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { aq += __shfl_xor(aq, d); ac += __shfl_xor(ac, d); }
+    if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6] = aq; ws[4 + (threadIdx.x >> 6)] = ac; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+        partial[(size_t)nchunks + 1 + blockIdx.x] = ws[4] + ws[5] + ws[6] + ws[7];
+    }
+}
+__global__ void __launch_bounds__(256)
+k_p0_len_apply(int64_t n, const int32_t *__restrict__ lq, const uint16_t *__restrict__ ncg, const int64_t *__restrict__ partial, int nchunks,
+               int64_t *__restrict__ seq_off, int64_t *__restrict__ cig_off)
+{
+    __shared__ long long ws[8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i0 = (int64_t)blockIdx.x * P0_CHUNK + (int64_t)threadIdx.x * 4;      /* four consecutive reads per thread */
+    long long xq[4], xc[4], tq = 0, tc = 0;
+    #pragma unroll
+    for (int k = 0; k < 4; k++) { xq[k] = i0 + k < n ? lq[i0 + k] : 0; xc[k] = i0 + k < n ? ncg[i0 + k] : 0; tq += xq[k]; tc += xc[k]; }
+    long long iq = tq, ic = tc;
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const long long oq = __shfl_up(iq, d), oc = __shfl_up(ic, d); if (lane >= d) { iq += oq; ic += oc; } }
+    if (lane == 63) { ws[w] = iq; ws[4 + w] = ic; }
+    __syncthreads();
+    long long rq = partial[blockIdx.x] + iq - tq, rc = partial[(size_t)nchunks + 1 + blockIdx.x] + ic - tc;
+    for (int j = 0; j < w; j++) { rq += ws[j]; rc += ws[4 + j]; }
+    #pragma unroll
+    for (int k = 0; k < 4; k++) { if (i0 + k < n) { seq_off[i0 + k] = rq; cig_off[i0 + k] = rc; } rq += xq[k]; rc += xc[k]; }
+    if (blockIdx.x == (unsigned)(nchunks - 1) && threadIdx.x == 255) {
+        seq_off[n] = partial[blockIdx.x] + ws[0] + ws[1] + ws[2] + iq;
+        cig_off[n] = partial[(size_t)nchunks + 1 + blockIdx.x] + ws[4] + ws[5] + ws[6] + ic;
+    }
 }
 
 #endif

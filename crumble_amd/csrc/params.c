@@ -167,6 +167,7 @@ const char *crumble_hip_strerror(int err)
     }
 }
 
+static int host_threads_(void);
 /* one nt16 code per byte -> BAM's packing in the crumble_batch.bases4 layout (include/crumble_hip.h) */
 typedef struct { const int64_t *seq_off; const uint8_t *bases; uint8_t *out; } pack4_job;
 static void pack4_reads(void *ctx, int64_t lo, int64_t hi, int tid)
@@ -185,8 +186,82 @@ static void pack4_reads(void *ctx, int64_t lo, int64_t hi, int tid)
 void crumble_pack_bases4(int64_t n_reads, const int64_t *seq_off, const uint8_t *bases, uint8_t *out)
 {
     pack4_job j = { seq_off, bases, out };
+    team_run_once(host_threads_(), n_reads, 4096, 0, pack4_reads, &j);
+}
+
+/* ---- coded download, host side (include/crumble_hip.h): 2 bits per base -> quality bytes -------------------- */
+void crumble_decode_seek(const crumble_coded *c, int64_t base, crumble_decode_cursor *cur)
+{
+    cur->base = base;
+    cur->esc_pos = 0;
+    if (base >= c->n_bases) return;
+    const int64_t blk = base / CRUMBLE_CODED_BLOCK, b0 = blk * CRUMBLE_CODED_BLOCK;
+    int64_t e = c->esc_off[blk];
+    const uint32_t *w = c->codes + (b0 >> 4);
+    const int64_t nfull = (base - b0) >> 4;
+    for (int64_t k = 0; k < nfull; k++) e += __builtin_popcount(w[k] & (w[k] >> 1) & 0x55555555u);
+    const int rem = (int)((base - b0) & 15);
+    if (rem) { const uint32_t x = w[nfull] & ((1u << (2 * rem)) - 1u); e += __builtin_popcount(x & (x >> 1) & 0x55555555u); }
+    cur->esc_pos = e;
+}
+
+void crumble_decode_run(const crumble_coded *c, crumble_decode_cursor *cur, int64_t n, const uint8_t *qin, uint8_t *qout)
+{
+    int64_t b = cur->base, e = cur->esc_pos;
+    const int64_t end = b + n;
+    const uint8_t va = c->value[0], vb = c->value[1];
+    /* a byte of codes (four bases, none of them code 2 or 3) -> four quality bytes */
+    const uint32_t va4 = va * 0x01010101u, d4 = (uint32_t)(va ^ vb);
+    int64_t k = 0;                                          /* index into qin / qout */
+    while (b < end) {
+        if ((b & (CRUMBLE_CODED_BLOCK - 1)) == 0) e = c->esc_off[b / CRUMBLE_CODED_BLOCK];   /* a block's escapes start where it says */
+        const int sh = (int)(b & 15);
+        uint32_t w = c->codes[b >> 4] >> (2 * sh);
+        int m = 16 - sh;
+        if ((int64_t)m > end - b) m = (int)(end - b);
+        if (!qout) {                                        /* skipped bases: only the escape cursor moves */
+            const uint32_t x = m < 16 ? (w & ((1u << (2 * m)) - 1u)) : w;
+            e += __builtin_popcount(x & (x >> 1) & 0x55555555u);
+        } else if (m == 16 && !(w & 0xaaaaaaaau)) {         /* sixteen bases of the two values: the bulk of every batch */
+            uint32_t o[4] = { va4, va4, va4, va4 };
+            if (w)
+                for (int i = 0; i < 4; i++, w >>= 8) {
+                    /* bits 0, 2, 4, 6 of the code byte -> 0x00 / 0x01 in bytes 0..3, times (va ^ vb), xor va */
+                    const uint32_t s = (w & 1u) | ((w & 4u) << 6) | ((w & 16u) << 12) | ((w & 64u) << 18);
+                    o[i] = va4 ^ (s * d4);
+                }
+            memcpy(qout + k, o, 16);
+        } else
+            for (int i = 0; i < m; i++, w >>= 2) {
+                const unsigned code = w & 3u;
+                qout[k + i] = code == 0 ? va : code == 1 ? vb : code == 2 ? c->cap[qin[k + i]] : c->esc[e++];
+            }
+        b += m; k += m;
+    }
+    cur->base = b; cur->esc_pos = e;
+}
+
+typedef struct { const crumble_coded *c; const uint8_t *qin; uint8_t *qout; } decode_job;
+static void decode_blocks(void *ctx, int64_t lo, int64_t hi, int tid)
+{
+    const decode_job *j = ctx;
+    (void)tid;
+    crumble_decode_cursor cur;
+    const int64_t b0 = lo * CRUMBLE_CODED_BLOCK;
+    int64_t b1 = hi * CRUMBLE_CODED_BLOCK;
+    if (b1 > j->c->n_bases) b1 = j->c->n_bases;
+    crumble_decode_seek(j->c, b0, &cur);
+    crumble_decode_run(j->c, &cur, b1 - b0, j->qin + b0, j->qout + b0);
+}
+static int host_threads_(void)
+{
     long nt = sysconf(_SC_NPROCESSORS_ONLN);
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0 && CPU_COUNT(&set) < nt) nt = CPU_COUNT(&set);
-    team_run_once((int)(nt > 32 ? 32 : nt), n_reads, 0, pack4_reads, &j);
+    return (int)(nt > 32 ? 32 : nt < 1 ? 1 : nt);
+}
+void crumble_decode_quals(const crumble_coded *c, const uint8_t *quals_in, uint8_t *qual_out, int threads)
+{
+    decode_job j = { c, quals_in, qual_out };
+    team_run_once(threads > 0 ? threads : host_threads_(), c->n_blocks, 64, 16, decode_blocks, &j);
 }

@@ -118,11 +118,12 @@ static void team_run(team *t, int64_t total, int64_t chunk, team_fn fn, void *ct
     pthread_mutex_unlock(&t->mu);
 }
 
-/* a one-off fan-out for callers without a team of their own (crumble_pack_bases4): n threads for one loop */
-__attribute__((unused)) static void team_run_once(int n, int64_t total, int64_t chunk, team_fn fn, void *ctx)
+/* a one-off fan-out for callers without a team of their own (crumble_pack_bases4, crumble_decode_quals): n threads for
+ * one loop; fewer than min_total items are not worth the threads */
+__attribute__((unused)) static void team_run_once(int n, int64_t total, int64_t min_total, int64_t chunk, team_fn fn, void *ctx)
 {
     if (total <= 0) return;
-    if (n <= 1 || total < 4096) { fn(ctx, 0, total, 0); return; }
+    if (n <= 1 || total < min_total) { fn(ctx, 0, total, 0); return; }
     team *t = team_create(n);
     team_run(t, total, chunk, fn, ctx);
     team_destroy(t);

@@ -10,7 +10,7 @@ import subprocess
 
 import numpy as np
 
-from .capi import (Params, Batch, Column, HostBatch, COLUMN_DTYPE, ST_N, ROOT, HERE)
+from .capi import (Params, Batch, Column, Coded, DecodeCursor, HostBatch, COLUMN_DTYPE, ST_N, ROOT, HERE)
 
 LIB_PATH = os.environ.get("CRUMBLE_HIP_LIB", os.path.join(HERE, "libcrumble_hip.so"))
 _lib = None
@@ -60,6 +60,7 @@ def load_library(path=None, make_default=True):
         "crumble_hip_destroy": (None, [vp]),
         "crumble_hip_set_option": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
         "crumble_hip_contig": (C.c_int, [vp, C.POINTER(Batch), vp, vp, vp]),
+        "crumble_hip_contig_run": (C.c_int, [vp, C.POINTER(Batch)]),
         "crumble_hip_upload": (C.c_int, [vp, C.POINTER(Batch)]),
         "crumble_hip_expand": (C.c_int, [vp]),
         "crumble_hip_run": (C.c_int, [vp]),
@@ -71,11 +72,18 @@ def load_library(path=None, make_default=True):
         "crumble_hip_run_fold": (C.c_int, [vp, vp, vp]),
         "crumble_hip_run_finish": (C.c_int, [vp]),
         "crumble_hip_download": (C.c_int, [vp, vp, vp, vp]),
+        "crumble_hip_encode": (C.c_int, [vp, C.POINTER(Coded)]),
+        "crumble_hip_download_coded": (C.c_int, [vp, C.POINTER(Coded), vp, vp]),
+        "crumble_decode_seek": (None, [C.POINTER(Coded), i64, C.POINTER(DecodeCursor)]),
+        "crumble_decode_run": (None, [C.POINTER(Coded), C.POINTER(DecodeCursor), i64, vp, vp]),
+        "crumble_decode_quals": (None, [C.POINTER(Coded), vp, vp, C.c_int]),
         "crumble_hip_kernel_times": (C.c_int, [vp, vp, vp, vp, C.c_int]),
         "crumble_hip_upload_times": (C.c_int, [vp, vp, vp]),
+        "crumble_hip_transfer_bytes": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
         "crumble_hip_stats_devptr": (vp, [vp]),
         "crumble_hip_stats_reset": (C.c_int, [vp]),
         "crumble_hip_stats_read": (C.c_int, [vp, vp]),
+        "crumble_hip_stats_add": (C.c_int, [vp, vp]),
         "crumble_hip_stats_allreduce": (C.c_int, [vp, vp]),
         "crumble_hip_comm_init_all": (C.c_int, [C.c_int, vp, vp]),
         "crumble_hip_comm_destroy": (None, [vp]),
@@ -106,12 +114,13 @@ def lib():
 EXPORTED = [
     "crumble_params_default", "crumble_params_preset", "crumble_params_tech",
     "crumble_params_keep_quals", "crumble_init_bins", "crumble_bed_collapse",
-    "crumble_hip_create", "crumble_hip_destroy", "crumble_hip_set_option", "crumble_hip_contig",
+    "crumble_hip_create", "crumble_hip_destroy", "crumble_hip_set_option", "crumble_hip_contig", "crumble_hip_contig_run",
     "crumble_hip_upload", "crumble_hip_expand", "crumble_hip_run", "crumble_hip_download",
+    "crumble_hip_encode", "crumble_hip_download_coded", "crumble_decode_seek", "crumble_decode_run", "crumble_decode_quals",
     "crumble_hip_set_window", "crumble_carry_init", "crumble_hip_run_columns", "crumble_hip_run_depth",
     "crumble_hip_run_triggers", "crumble_hip_run_fold", "crumble_hip_run_finish",
-    "crumble_hip_kernel_times", "crumble_hip_upload_times", "crumble_hip_stats_devptr", "crumble_hip_stats_reset",
-    "crumble_hip_stats_read", "crumble_hip_stats_allreduce", "crumble_hip_comm_init_all",
+    "crumble_hip_kernel_times", "crumble_hip_upload_times", "crumble_hip_transfer_bytes", "crumble_hip_stats_devptr", "crumble_hip_stats_reset",
+    "crumble_hip_stats_read", "crumble_hip_stats_add", "crumble_hip_stats_allreduce", "crumble_hip_comm_init_all",
     "crumble_hip_comm_destroy", "crumble_hip_columns",
     "crumble_hip_mask_lc", "crumble_hip_pblock", "crumble_hip_indel_only", "crumble_hip_host_alloc", "crumble_hip_host_free",
     "crumble_hip_strerror",
@@ -237,6 +246,34 @@ class Engine:
         self._chk(self.L.crumble_hip_download(self.h, _vp(q), _vp(f), _vp(s)), "download")
         return q[:hb.n_bases], (f[:hb.n_reads] if f is not None else None), s
 
+    def download_coded(self, want_flags=True, want_stats=True, bufs=None):
+        """crumble_hip_encode + crumble_hip_download_coded: (Coded, flags, stats).  The three streams land in numpy
+        arrays kept alive on the returned struct (`_keep`); bufs = (codes, esc_off, esc) arrays of an earlier call (or
+        page-locked ones) to write into again."""
+        hb = self._batch
+        c = Coded()
+        self._chk(self.L.crumble_hip_encode(self.h, C.byref(c)), "encode")
+        if bufs is not None and len(bufs[0]) >= c.n_words and len(bufs[1]) >= c.n_blocks and len(bufs[2]) >= c.n_escapes:
+            codes, eo, esc = bufs
+        else:
+            codes = np.empty(max(1, c.n_words), np.uint32)
+            eo = np.empty(max(1, c.n_blocks), np.int64)
+            esc = np.empty(max(1, c.n_escapes), np.uint8)
+        c.codes, c.esc_off, c.esc = codes.ctypes.data, eo.ctypes.data, esc.ctypes.data
+        c._keep = (codes, eo, esc)
+        f = np.zeros(max(hb.n_reads, 1), np.uint8) if want_flags else None
+        s = np.zeros(ST_N, np.int64) if want_stats else None
+        self._chk(self.L.crumble_hip_download_coded(self.h, C.byref(c), _vp(f), _vp(s)), "download_coded")
+        return c, (f[:hb.n_reads] if f is not None else None), s
+
+    def decode(self, c, quals_in, out=None, threads=0):
+        """crumble_decode_quals: the coded result + the batch's input qualities -> the output qualities (host only)."""
+        qin = np.ascontiguousarray(quals_in, np.uint8)
+        q = out if out is not None else np.empty(max(1, c.n_bases), np.uint8)
+        if c.n_bases:
+            self.L.crumble_decode_quals(C.byref(c), qin.ctypes.data, q.ctypes.data, int(threads))
+        return q[:c.n_bases]
+
     def contig(self, hb: HostBatch):
         """crumble_hip_contig: qualities, per-read flags, stats."""
         b = hb.struct()
@@ -270,6 +307,12 @@ class Engine:
         self._chk(self.L.crumble_hip_upload_times(self.h, C.byref(a), C.byref(b)), "upload_times")
         return float(a.value), float(b.value)
 
+    def transfer_bytes(self):
+        """(bytes the last upload copied from the host, bytes the last download copied back)"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._chk(self.L.crumble_hip_transfer_bytes(self.h, C.byref(a), C.byref(b)), "transfer_bytes")
+        return int(a.value), int(b.value)
+
     def mask_lc(self, read_idx, qpos1, is_indel):
         r = np.ascontiguousarray(read_idx, np.int64)
         q = np.ascontiguousarray(qpos1, np.int32)
@@ -298,6 +341,11 @@ class Engine:
 
     def stats_reset(self):
         self._chk(self.L.crumble_hip_stats_reset(self.h), "stats_reset")
+
+    def stats_add(self, stats):
+        s = np.ascontiguousarray(stats, np.int64)
+        assert len(s) == ST_N
+        self._chk(self.L.crumble_hip_stats_add(self.h, _vp(s)), "stats_add")
 
     def stats_read(self):
         s = np.zeros(ST_N, np.int64)

@@ -75,6 +75,11 @@ int crumble_bam_set_aux_filter(crumble_bam_writer *w, const char *whitelist, con
 /* Writes the reader's current group with qual_out (same layout as crumble_hip_contig's output;
  * NULL = qualities unchanged) replacing the quality bytes: flush_bam_list(), snp_score.c:1081-1105. */
 int crumble_bam_write_group(crumble_bam_writer *w, crumble_bam_reader *r, const uint8_t *qual_out);
+/* The same with the engine's result in coded form (crumble_hip_encode / crumble_hip_download_coded, include/crumble_hip.h):
+ * 2 bits per base are expanded straight into the records' quality fields, which still hold the input qualities the
+ * codes refer to -- no intermediate quality array on the host, a quarter of the bytes over PCIe. */
+int crumble_bam_write_group_coded(crumble_bam_writer *w, crumble_bam_reader *r, const crumble_coded *c);
+int crumble_bam_write_detached_coded(crumble_bam_writer *w, crumble_bam_group *g, const crumble_coded *c);
 /* Writes the BGZF EOF block and closes. */
 int crumble_bam_writer_close(crumble_bam_writer *w);
 

@@ -123,6 +123,14 @@ typedef struct crumble_batch {
      * n_reads) bytes.  Half the host -> device bytes of the one-code-per-byte form and no expansion pass on the host:
      * the device unpacks while it rewrites the base bytes anyway (k_p0_unpack4). */
     const uint8_t  *bases4;
+    /* Optional, the compact form of the two offset tables: BAM's own per-read fields, l_qseq[i] = l_seq of read i
+     * (int32) and n_cigar[i] = its n_cigar_op (uint16), with the totals n_bases = seq_off[n_reads] and n_cigar_ops =
+     * cig_off[n_reads].  When BOTH arrays are given the engine sends these 6 bytes per read to the device instead of the
+     * 16 of seq_off / cig_off (which may then be NULL) and derives the offsets there (k_p0_len_*).  A batch that holds a
+     * read of more than 65535 CIGAR ops (SAMv1 4.2.2, CG tag) uses cig_off. */
+    const int32_t  *l_qseq;
+    const uint16_t *n_cigar;
+    int64_t  n_bases, n_cigar_ops;
 } crumble_batch;
 #define CRUMBLE_BASES4_OFF(seq_off_i, i)      (((int64_t)(seq_off_i) >> 1) + (int64_t)(i))
 #define CRUMBLE_BASES4_SIZE(n_bases, n_reads) (((int64_t)(n_bases) >> 1) + (int64_t)(n_reads) + 1)
@@ -190,6 +198,11 @@ int crumble_hip_set_option(crumble_hip *h, const char *name, const char *value);
 int crumble_hip_contig(crumble_hip *h, const crumble_batch *b,
                        uint8_t *qual_out, uint8_t *read_flags_out, int64_t *stats);
 
+/* crumble_hip_contig() without its download: host -> device, expansion, run (the expansion's tail overlaps the run's
+ * first kernels, one wait less than crumble_hip_upload + crumble_hip_run).  Follow with crumble_hip_download(), or
+ * crumble_hip_encode() + crumble_hip_download_coded(). */
+int crumble_hip_contig_run(crumble_hip *h, const crumble_batch *b);
+
 /* The three stages separately, so callers (and bench.py) can keep a batch
  * resident in HBM and time only the kernels. */
 int crumble_hip_upload(crumble_hip *h, const crumble_batch *b);
@@ -200,6 +213,48 @@ int crumble_hip_expand(crumble_hip *h);
 int crumble_hip_run(crumble_hip *h);      /* asynchronous launches + one sync */
 int crumble_hip_download(crumble_hip *h, uint8_t *qual_out,
                          uint8_t *read_flags_out, int64_t *stats);
+
+/* ---- coded download: a quarter of the bytes over PCIe ---------------------------------------------------------
+ * What the host does with the result is flush_bam_list()'s "replace the record's qualities" (snp_score.c:1081-1105),
+ * and it still holds the input qualities.  After the pass almost every output byte is one of two values (qhigh / qlow
+ * at the numeric presets) or the read's own input quality after cap_quality (snp_score.c:1325-1332).  So instead of one
+ * byte per base the device can hand back 2 bits per base,
+ *     0 = value[0]   1 = value[1]   2 = cap[input quality]   3 = the next byte of the escape stream,
+ * 16 bases to a 32-bit word (base i of the flat base array in bits 2 * (i & 15) of codes[i >> 4]), plus the escape
+ * bytes (P-block averages, bin2[] levels) in base order inside every block of CRUMBLE_CODED_BLOCK bases, block b's
+ * starting at esc[esc_off[b]].  Expanded on the host it is byte for byte what crumble_hip_download() returns.
+ *
+ *   crumble_hip_encode(h, &c)            after crumble_hip_run(): encodes on the device, fills the sizes and tables of c
+ *   (caller provides c.codes[c.n_words], c.esc_off[c.n_blocks], c.esc[c.n_escapes] -- any host memory)
+ *   crumble_hip_download_coded(h, &c, flags, stats)       the three streams, the per-read flags, the statistics
+ *   crumble_decode_seek / crumble_decode_run              the host-side expansion (plain C, no device), or
+ *   crumble_decode_quals(&c, quals_in, qual_out, threads) the whole batch at once
+ * A batch whose escapes are many (c.n_escapes above n_bases / 8, say: long reads with P-block) is better served by
+ * crumble_hip_download(); both stay valid after crumble_hip_encode(). */
+#define CRUMBLE_CODED_BLOCK 4096
+typedef struct crumble_coded {
+    int64_t n_bases;
+    int64_t n_words;            /* (n_bases + 15) / 16 code words                                   */
+    int64_t n_blocks;           /* (n_bases + CRUMBLE_CODED_BLOCK - 1) / CRUMBLE_CODED_BLOCK        */
+    int64_t n_escapes;          /* bytes of the escape stream                                        */
+    uint8_t value[2];           /* the bytes codes 0 and 1 stand for                                 */
+    uint8_t pad_[6];
+    uint8_t cap[256];           /* code 2: cap[input quality] (cap_quality with this engine's -U / -k / -K) */
+    uint32_t *codes;            /* caller's buffers, filled by crumble_hip_download_coded            */
+    int64_t  *esc_off;
+    uint8_t  *esc;
+} crumble_coded;
+int crumble_hip_encode(crumble_hip *h, crumble_coded *c);
+int crumble_hip_download_coded(crumble_hip *h, const crumble_coded *c, uint8_t *read_flags_out, int64_t *stats);
+/* Host-side expansion.  A cursor walks the flat base array: seek to any base (counts the escapes of the block in
+ * front of it: at most CRUMBLE_CODED_BLOCK / 16 words), then run over consecutive bases.  quals_in / qual_out point at
+ * the FIRST base of the run (they may be the same memory: a record's quality field is rewritten in place);
+ * qual_out == NULL skips the run (a record without qualities). */
+typedef struct crumble_decode_cursor { int64_t base, esc_pos; } crumble_decode_cursor;
+void crumble_decode_seek(const crumble_coded *c, int64_t base, crumble_decode_cursor *cur);
+void crumble_decode_run(const crumble_coded *c, crumble_decode_cursor *cur, int64_t n, const uint8_t *quals_in, uint8_t *qual_out);
+/* the whole batch: qual_out[n_bases] from quals_in[n_bases] on `threads` host threads (0: all the process may use) */
+void crumble_decode_quals(const crumble_coded *c, const uint8_t *quals_in, uint8_t *qual_out, int threads);
 
 /* ---- one contig over several devices: windows ------------------------------------------------
  * transcode() carries three pieces of state from column to column: the running depth average total_col / total_depth
@@ -248,11 +303,18 @@ int crumble_hip_kernel_times(crumble_hip *h, const char **names, float *ms,
  * expansion (P0: routing, validation, op tables, tile ranges) including its two small size read-backs. */
 int crumble_hip_upload_times(crumble_hip *h, float *h2d_ms, float *p0_ms);
 
+/* Bytes that crossed PCIe: what the last crumble_hip_upload / _contig copied from the host, and what the last
+ * crumble_hip_download / _download_coded copied back. */
+int crumble_hip_transfer_bytes(crumble_hip *h, int64_t *up, int64_t *down);
+
 /* Accumulated device-side stats vector (int64[CRUMBLE_ST_N]) of this engine:
  * a raw device pointer so torch.distributed / RCCL can all-reduce it in place. */
 void *crumble_hip_stats_devptr(crumble_hip *h);
 int   crumble_hip_stats_reset(crumble_hip *h);
 int   crumble_hip_stats_read(crumble_hip *h, int64_t *stats);
+/* Adds a host vector (int64[CRUMBLE_ST_N]) to the accumulated one: a host that runs several engines on one device folds
+ * their vectors into one engine before that device's single crumble_hip_stats_allreduce(). */
+int   crumble_hip_stats_add(crumble_hip *h, const int64_t *stats);
 /* Sums the stats vector over all ranks of an RCCL communicator (ncclComm_t
  * passed as void*). The only collective on the path. */
 int   crumble_hip_stats_allreduce(crumble_hip *h, void *nccl_comm);

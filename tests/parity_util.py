@@ -34,9 +34,38 @@ def assert_parity(make_engine, params, hb, check_columns=True):
         assert np.array_equal(f, f2), "per-read flags differ"
         d = np.nonzero(s != s2)[0]
         assert len(d) == 0, ("stats differ", d, s[d], s2[d])
+        assert_coded_download(eng, hb, q2, f2, s2)
     finally:
         eng.close()
     return q, f, s
+
+
+def assert_coded_download(eng, hb, q, f, s):
+    """The coded download (crumble_hip_encode / _download_coded + the host-side expansion) of the run that `eng` holds is
+    byte for byte the plain download (q, f, s): whole batch on several threads, and through the cursor from arbitrary
+    starts (as the BAM writer walks it read by read, skipping some)."""
+    import ctypes as C
+    c, f3, s3 = eng.download_coded()
+    assert c.n_bases == hb.n_bases and c.n_words == (hb.n_bases + 15) // 16 and c.n_blocks == (hb.n_bases + 4095) // 4096
+    assert np.array_equal(f, f3) and np.array_equal(s, s3), "coded download: flags / statistics differ"
+    got = eng.decode(c, hb.quals, threads=3)
+    bad = np.nonzero(got != q)[0]
+    assert len(bad) == 0, ("coded download differs from the plain one", len(bad), bad[:10], got[bad[:10]], q[bad[:10]], list(c.value), c.n_escapes)
+    if hb.n_reads:
+        # read by read from a random start, in place (input bytes overwritten), every third read skipped
+        rng = np.random.default_rng(hb.n_bases)
+        r0 = int(rng.integers(0, hb.n_reads))
+        r1 = min(hb.n_reads, r0 + 300)
+        buf = hb.quals.copy()
+        cur = ca.DecodeCursor()
+        eng.L.crumble_decode_seek(C.byref(c), int(hb.seq_off[r0]), C.byref(cur))
+        for r in range(r0, r1):
+            a, b = int(hb.seq_off[r]), int(hb.seq_off[r + 1])
+            skip = (r % 3) == 1
+            eng.L.crumble_decode_run(C.byref(c), C.byref(cur), b - a, buf.ctypes.data + a, None if skip else buf.ctypes.data + a)
+            want = hb.quals[a:b] if skip else q[a:b]
+            assert np.array_equal(buf[a:b], want), ("cursor decode differs", r, skip)
+        assert cur.base == int(hb.seq_off[r1])
 
 
 def cigar_zoo(cases, reps=60, seed=7):

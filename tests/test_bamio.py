@@ -385,6 +385,23 @@ def test_cli_end_to_end_emulated(tmp_path):
         assert np.array_equal(got, want), np.nonzero(got != want)[0][:10]
         text, wrefs, recs = walk_bam(tmp_path / "out.bam")
         assert wrefs == refs and "@PG\tID:crumble-hip" in text and len(recs) == sum(b.n_reads for b in bs)
+        # the default run took the coded download (2 bits per base + escapes, expanded into the records by the writer);
+        # one byte per base back from the device gives the same file
+        r = subprocess.run([exe, *args, str(tmp_path / "in.bam"), str(tmp_path / "out_plain.bam")], env=dict(os.environ, CRUMBLE_HIP_PLAIN_DOWNLOAD="1"),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        assert np.array_equal(_file_quals(tmp_path / "out_plain.bam"), want)
+    # records without qualities (0xff, SAMv1 4.2.3) between ordinary ones: the coded expansion skips exactly their bases
+    raw = py_bam(refs, [dict(tid=0, pos=100 + 2 * i, cigar=[(40 << 4)], seq=[(1, 2, 4, 8)[(k * 5 + k // 7) % 4] for k in range(40)],
+                             qual=(None if i % 4 == 1 else [20 + (i * 7 + k) % 21 for k in range(40)]), name=f"m{i}") for i in range(300)])
+    (tmp_path / "noq.bam").write_bytes(py_bgzf(raw))
+    outs = []
+    for env in ({}, {"CRUMBLE_HIP_PLAIN_DOWNLOAD": "1"}):
+        r = subprocess.run([exe, "-9", str(tmp_path / "noq.bam"), str(tmp_path / "noq_out.bam")], env=dict(os.environ, **env), stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append([bytes(x["qual"]) for x in walk_bam(tmp_path / "noq_out.bam")[2]])
+    assert outs[0] == outs[1] and all(q == b"\xff" * 40 for i, q in enumerate(outs[0]) if i % 4 == 1)
+    assert any(q != bytes(20 + (i * 7 + k) % 21 for k in range(40)) for i, q in enumerate(outs[0]) if i % 4 != 1)
     # purge_tags through the command line (-T drops, -e/-f/-g bins BD) leaves names and qualities alone
     raw = py_bam(refs, [dict(tid=0, pos=100 + i, cigar=[(50 << 4)], seq=[1] * 50, qual=[30] * 50, name=f"t{i}",
                              aux=b"NMC\x01BDZ" + bytes([40 + i, 70]) + b"\0XSZab\0") for i in range(5)])

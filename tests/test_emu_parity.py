@@ -262,8 +262,25 @@ def test_emu_packed_bases(product):
         hb4 = copy.copy(hb).pack4(L)
         assert hb4.struct().bases is None and hb4.struct().bases4
         got = e.contig(hb4)
-        e.close()
         assert all(np.array_equal(x, y) for x, y in zip(got, want))
+        up_off = e.transfer_bytes()[0]
+        # ... and BAM's own per-read lengths (crumble_batch.l_qseq / n_cigar: the offsets are made on the device)
+        hbl = copy.copy(hb4).lens()
+        st = hbl.struct()
+        assert st.l_qseq and st.n_cigar and not st.seq_off and not st.cig_off and st.n_bases == hb.n_bases
+        got = e.contig(hbl)
+        assert all(np.array_equal(x, y) for x, y in zip(got, want))
+        up, down = e.transfer_bytes()
+        assert up == up_off - 16 * (hb.n_reads + 1) + 6 * hb.n_reads and down >= hb.n_bases      # 6 bytes per read instead of 16
+        e.close()
+    # a bad length is an error code like a bad offset (a negative l_qseq makes the device-made offsets run backwards)
+    hbl = copy.copy(tiny).lens()
+    hbl.l_qseq = hbl.l_qseq.copy(); hbl.l_qseq[2] = -3
+    e = emu_lib.engine(p)
+    with pytest.raises(ca.CrumbleError) as ei:
+        e.contig(hbl)
+    assert ei.value.code == -1
+    e.close()
 
 
 def test_emu_staged_download(product):

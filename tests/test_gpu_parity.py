@@ -198,6 +198,10 @@ def test_packed_bases(product):
         eng = gpu_engine(p)
         hb4 = copy.copy(hb).pack4(eng.L)
         got = eng.contig(hb4)
+        assert all(np.array_equal(x, y) for x, y in zip(got, want))
+        hbl = copy.copy(hb4).lens()                      # BAM's per-read lengths instead of the offset tables
+        assert hbl.struct().l_qseq and not hbl.struct().seq_off
+        got = eng.contig(hbl)
         eng.close()
         assert all(np.array_equal(x, y) for x, y in zip(got, want))
 
@@ -321,6 +325,13 @@ def test_bench_two_ranks(product, workload, ranks):
     assert "roofline" in d and "cpu_baseline" not in d
     if workload == "wgs":
         assert d["config"]["contigs"] == 24 and 1.0 <= d["config"]["lpt_max_over_mean_load"] < 1.35
+    else:
+        # the driver's `--gpus N` line measures BASELINE config 5 beside the chr20 headline: 24 contigs LPT-packed over the
+        # ranks (strong scaling), the statistics summed over the ranks, the summed histogram checked
+        ws = d["wgs_strong"]
+        assert "error" not in ws, ws
+        assert ws["scaling"] == "strong" and ws["n_gpus"] == ranks and ws["value"] > 0 and ws["summed_histogram_ok"] is True
+        assert sum(ws["contigs_per_rank"]) == 24 and 1.0 <= ws["lpt_max_over_mean_load"] < 1.35
 
 
 @pytest.mark.parametrize("workload", ["chr20", "wgs"])
@@ -345,6 +356,8 @@ def test_bench_multi_gpu_rccl(product, workload):
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == n and d["value"] > 0
     assert "RCCL" in d["config"]["stats_allreduce"]
+    if workload == "chr20":
+        assert d["wgs_strong"]["summed_histogram_ok"] is True and "crumble_hip_stats_allreduce" in d["wgs_strong"]["stats_allreduce"]
     if workload == "wgs":
         assert 1.0 <= d["config"]["lpt_max_over_mean_load"] < 1.5
 

@@ -18,6 +18,8 @@ for seed in range(s0, s0 + n):
             "replay": ("auto", "auto", "auto", "flat")[(seed // 3) % 4]}                          # ... and the byte-wise replay
     if seed % 2:
         hb.pack4(ca.lib())                                      # the bases as BAM packs them (crumble_batch.bases4)
+    if seed % 4 >= 2:
+        hb.lens()                                               # BAM's per-read lengths instead of the offset tables
     try:
         assert_parity(lambda q: ca.Engine(q, 0, options=opts), p, hb)
         if seed % 10 == 0:
