@@ -54,6 +54,68 @@ def find_pmc_json():
     return None
 
 
+def find_profile_json(suffix):
+    """the newest profiles/*_<suffix>.json measured on the current kernel sources, or None"""
+    import glob
+    sha = kernel_source_sha()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{suffix}.json")), reverse=True):
+        try:
+            if json.load(open(f)).get("source_sha16") == sha:
+                return f
+        except Exception:            # noqa: BLE001
+            pass
+    return None
+
+
+GPU_CLOCK_GHZ = 2.4         # MI355X_MICROARCH.md: peak engine clock
+GPU_SIMDS = 256 * 4
+
+
+def secondary_roofline(kernel_key, kernel_ms, n_bases):
+    """The roof the column kernel actually sits under ("secondary limiter to report honestly"): instruction
+    issue.  floor_ms = SQ_INSTS_VALU wave-instructions x 4 cycles (a wave64 VALU / FP64 instruction occupies its SIMD's
+    issue slot for four) / (1024 SIMDs x the peak clock), from the rocprofv3 --pmc summary in profiles/ measured on these
+    kernel sources (null otherwise: never a stale constant)."""
+    f = find_profile_json("sq_counters")
+    if not f:
+        return None
+    try:
+        c = json.load(open(f)).get(kernel_key)
+        if not c:
+            return None
+        floor_ms = c["SQ_INSTS_VALU"] * 4.0 / (GPU_SIMDS * GPU_CLOCK_GHZ * 1e9) * 1e3
+        out = {"bound": "valu_issue", "floor_ms": round(floor_ms, 3), "frac": round(floor_ms / kernel_ms, 4) if kernel_ms > 0 else None,
+               "valu_wave_insts": int(c["SQ_INSTS_VALU"]), "salu_wave_insts": int(c.get("SQ_INSTS_SALU", 0)),
+               "valu_busy": round(c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"] * (c["SQ_WAVES"] / GPU_SIMDS), 4) if c.get("SQ_WAVE_CYCLES") else None,
+               "wait_any": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4) if c.get("SQ_WAVE_CYCLES") else None,
+               "lds_bank_conflict_share": round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 4) if c.get("SQ_LDS_IDX_ACTIVE") else None,
+               # the consensus sums (kcol2.h): six FP64 adds per pileup entry in file order, five more for an entry that
+               # disagrees with its column's key base (the reference: 5 per entry on 15 sums + 1, snp_score.c:656-683, 651)
+               "fp64_adds_per_base": 6,
+               "source": os.path.basename(f)}
+        return out
+    except Exception:                # noqa: BLE001
+        return None
+
+
+def counter_traffic(kernel_prefix, config=None):
+    """HBM bytes per launch of a kernel from the PMC summary of these sources: 2 x FETCH_SIZE + WRITE_SIZE (the FETCH
+    calibration of tools/fetch_calib.*), for the headline config (config None) or profiles' other_configs[config]."""
+    f = find_profile_json("pmc_traffic")
+    if not f:
+        return None, None
+    try:
+        d = json.load(open(f))
+        kk = d["kernels"] if config is None else d.get("other_configs", {}).get(config, {})
+        key = [k for k in kk if k.split("<")[0] == kernel_prefix]
+        if not key:
+            return None, None
+        t = kk[key[0]]
+        return round((2.0 * t["FETCH_SIZE_KB_per_launch"] + t["WRITE_SIZE_KB_per_launch"]) * 1024), os.path.basename(f) + " (2 x FETCH_SIZE + WRITE_SIZE, per launch)"
+    except Exception:                # noqa: BLE001
+        return None, None
+
+
 def prefix_batch(hb, n_reads):
     """First n_reads reads of a HostBatch (same data, bounded CPU-baseline sample)."""
     from crumble_amd import HostBatch
@@ -254,8 +316,13 @@ def measure_config(ca, synth, workload, scale, device, steps=3, warmup=1, verify
                         f"{'-' + str(d_preset) if d_preset else 'default level'}{' -y ' + d_tech if d_tech else ''}"
                         f"{' -R keep.bed (' + str(len(hb.bed_start)) + ' regions)' if len(hb.bed_start) else ''}",
             "value": round(hb.n_bases / step_s / 1e9, 3), "unit": "Gbases/s", "ms_per_step": round(step_s * 1e3, 3),
-            "roofline": {"kernel": dom[0], "kernel_ms": round(dom_ms, 3),
-                         "frac": round(dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if dom_ms > 0 else 0.0},
+            "roofline": {"bound": "hbm", "kernel": dom[0], "kernel_ms": round(dom_ms, 3),
+                         "achieved": round(dom_bytes / (dom_ms * 1e-3) / 1e9, 2) if dom_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if dom_ms > 0 else 0.0,
+                         "traffic": counter_traffic(dom[0], workload)[0] if scale == 1.0 else None,
+                         "traffic_source": counter_traffic(dom[0], workload)[1] if scale == 1.0 else None,
+                         "secondary": secondary_roofline({"panel": "k_columns2_panel", "hifi": "k_columns2_hifi"}.get(workload, ""), dom_ms, hb.n_bases)
+                                      if (scale == 1.0 and dom[0] == "k_columns2") else None},
             "pipeline_frac": round(_algo_bytes(hb) / ((kernels_ms + p0_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             "value_kernels_only": round(hb.n_bases / (kernels_ms * 1e-3) / 1e9, 3), "p0_ms": round(p0_ms, 3),
             "kernels_ms": {k: round(v[0] / v[2], 3) for k, v in kt.items()}, "gen_s": round(t_gen, 1),
@@ -877,6 +944,8 @@ def main():
         "pipeline_frac": round(algo_total / ((kernel_ms_total + p0_step_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
         "pipeline_note": "SURVEY 8(d) bytes of the whole path / HIP-event time of expansion (P0) + run kernels",
         "kernels_ms": {"p0_expand": round(p0_step_ms, 3), **{k: round(v[0] / v[2], 3) for k, v in ktimes.items()}},
+        "secondary": secondary_roofline("k_columns2", dom_ms, hb.n_bases)
+                     if (dom[0] == "k_columns2" and args.workload == "chr20" and args.scale == 1.0 and args.preset == 5) else None,
     }
 
     # what a real contig pays around the timed step: PCIe in and out

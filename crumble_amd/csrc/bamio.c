@@ -171,7 +171,8 @@ static int default_threads(void)
 }
 
 /* ------------------------------------------------------------------ BGZF in */
-#define CHUNK_IN   (32u << 20)      /* compressed bytes read per refill           */
+#define CHUNK_IN   (8u << 20)       /* compressed bytes read per refill: what is inflated beyond a contig's last record is
+                                     * carried over to the next window (crumble_bam_detach_group copies it), so not too much at once */
 #define MAX_BLOCKS 16384            /* per refill (>= CHUNK_IN / smallest sane block, grown on demand) */
 
 struct crumble_bam_reader {

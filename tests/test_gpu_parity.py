@@ -374,7 +374,10 @@ def test_bench_other_configs_small(product):
     assert oc4["verified_timed_output_leading_reads"] and "keep.bed" in oc4["workload"]
     w = bench.measure_wgs_streamed(ca, synth, shard, 0.0008, 0)
     assert w["verified_smallest_contig"] and 0 < w["overlap_wall_over_sum_of_stages"] <= 1.05
-    assert set(w["stages_ms"]) == {"h2d_and_p0", "kernels", "d2h"}
+    assert set(w["stages_ms"]) == {"h2d_and_p0", "kernels", "d2h", "host_decode"}
+    assert w["pcie_bytes_per_base"]["out"] < 0.5 < w["pcie_bytes_per_base"]["in"] < 2.0      # the coded download, the packed upload
+    w = bench.measure_wgs_streamed(ca, synth, shard, 0.0008, 0, coded=False)
+    assert w["verified_smallest_contig"] and set(w["stages_ms"]) == {"h2d_and_p0", "kernels", "d2h"} and w["pcie_bytes_per_base"]["out"] >= 1.0
 
 
 def test_find_str_stress(product):
