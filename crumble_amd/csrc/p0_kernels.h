@@ -577,8 +577,11 @@ k_p0_bases(int64_t nb, int64_t n, const int64_t *__restrict__ seq_off, const int
     __shared__ long long s_so[P0B_MAXR + 2];
     __shared__ uint32_t s_b4[PACKED ? (P0B_BASES / 2 + P0B_MAXR + 64) / 4 : 4];
     __shared__ uint16_t s_owner[P0B_CHUNKS];
+    __shared__ uint16_t s_rest[PACKED ? P0B_CHUNKS : 1];   /* the chunks that do not lie inside one read: done after the others */
+    __shared__ unsigned s_nrest;
     const int64_t G0 = (int64_t)blockIdx.x * P0B_BASES;
     if (G0 >= nb) return;
+    if (threadIdx.x == 0) s_nrest = 0;
     const int64_t G1 = G0 + P0B_BASES < nb ? G0 + P0B_BASES : nb;
     /* first and last owner: wave-uniform walks from the block table */
     int64_t r0 = blk_read[G0 >> 6], r1 = blk_read[(G1 - 1) >> 6];
@@ -617,7 +620,12 @@ k_p0_bases(int64_t nb, int64_t n, const int64_t *__restrict__ seq_off, const int
             }
             __syncthreads();
         }
-    }
+    } else __syncthreads();                                       /* (s_nrest = 0 is seen by every lane) */
+    /* Round 5: the chunks that lie inside ONE read (nine in ten on 150-base reads) take a straight path here -- owner, its
+     * packed bytes from LDS, one unpack, one 16-byte store; the others (a read boundary inside the chunk, bytes in front of
+     * the staged range, the batch's last partial chunk, workgroups of tiny reads) are listed and done afterwards by as
+     * many lanes as there are such chunks.  Before, every wave ran the general per-owner loop twice for each of its four
+     * chunks because SOME lane's chunk straddled two reads: 1296 VALU per lane, the kernel's bound (VALU 96 % busy). */
     #pragma unroll
     for (int u = 0; u < P0B_CPL; u++) {
         const int ci = u * P0B_THREADS + (int)threadIdx.x;
@@ -645,6 +653,38 @@ k_p0_bases(int64_t nb, int64_t n, const int64_t *__restrict__ seq_off, const int
             } else for (int64_t k = g; k < gend; k++) bases[k] = (uint8_t)(p0_class4(bases[k]) & 0xffu);
             continue;
         }
+        bool fast = staged && gend - g == 16;
+        if (fast) {
+            const int64_t so = (int64_t)s_so[r - r0], e = (int64_t)s_so[r - r0 + 1];
+            const int64_t x = g - so, sb = (so >> 1) + r + (x >> 1);
+            fast = so <= g && e >= gend && sb >= B0;
+            if (fast) {
+                const int o = (int)(sb - B0), wi = o >> 2;
+                const unsigned sh = (unsigned)o & 3u;
+                const uint32_t w0 = s_b4[wi], w1 = s_b4[wi + 1], w2 = s_b4[wi + 2], w3 = s_b4[wi + 3];
+                uint32_t v[4];
+                p0_unpack16(kc2_alignbyte(w1, w0, sh), kc2_alignbyte(w2, w1, sh), kc2_alignbyte(w3, w2, sh), (x & 1) != 0, v);
+                uint4 o4; o4.x = v[0]; o4.y = v[1]; o4.z = v[2]; o4.w = v[3];
+                *(uint4 *)(bases + g) = o4;
+            }
+        }
+        if (!fast) s_rest[atomicAdd(&s_nrest, 1u)] = (uint16_t)ci;
+    }
+    if (!PACKED) return;
+    __syncthreads();
+    const int nrest = (int)s_nrest;
+    for (int i = (int)threadIdx.x; i < nrest; i += P0B_THREADS) {
+        const int ci = (int)s_rest[i];
+        const int64_t g = G0 + (int64_t)ci * 16;
+        const int64_t gend = g + 16 < nb ? g + 16 : nb;
+        int64_t r;                                                /* the chunk's owner once more */
+        if (staged && nr > P0B_SEARCH) r = r0 + s_owner[ci];
+        else if (staged) {
+            int lo = 0, hi = nr - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_so[mid] <= g) lo = mid; else hi = mid - 1; }
+            while (lo + 1 < nr && s_so[lo + 1] <= g) lo++;
+            r = r0 + lo;
+        } else { r = blk_read[g >> 6]; while (r + 1 < n && seq_off[r + 1] <= g) r++; }
         uint32_t ow[4] = {0, 0, 0, 0};
         for (;; r++) {
             const int64_t so = staged ? (int64_t)s_so[r - r0] : seq_off[r], e = staged ? (int64_t)s_so[r - r0 + 1] : seq_off[r + 1];

@@ -14,6 +14,10 @@ def test_fuzz_emulated(product, seed):
     from parity_util import KCOL_VARIANTS
     p, hb, desc = random_case(seed, max_bases=120_000)
     print(desc)
+    if seed % 2:
+        hb.pack4(emu_lib.load())                 # the bases as BAM packs them (k_p0_bases<PACKED>) ...
+    if seed % 4 >= 2:
+        hb.lens()                                # ... BAM's per-read lengths instead of the offset tables
     # every column kernel, whatever the batch; the run's fast way, the careful one, and an aborted fast attempt
     # ... and, on every fourth seed, the byte-wise replay (k_replay_flat + k_restore / k_readfix / k_keepfix behind it)
     assert_parity(emu_lib.with_options(kcol=KCOL_VARIANTS[seed % 3], run=("fast", "careful")[(seed // 3) % 2], caps=(0, 0, 2)[seed % 3],
@@ -26,6 +30,10 @@ def test_fuzz_gpu(product, block):
     from parity_util import KCOL_VARIANTS
     for seed in range(1000 + 25 * block, 1000 + 25 * (block + 1)):
         p, hb, desc = random_case(seed, max_bases=400_000)
+        if seed % 2:
+            hb.pack4(ca.lib())                   # the bases as BAM packs them (k_p0_bases<PACKED>) ...
+        if seed % 4 >= 2:
+            hb.lens()                            # ... BAM's per-read lengths instead of the offset tables
         kcol = KCOL_VARIANTS[seed % 3] if seed % 4 else "auto"      # every column kernel, whatever the batch
         try:
             opts = {"kcol": kcol, "run": ("fast", "fast", "careful")[seed % 3], "caps": (0, 0, 0, 0, 5)[seed % 5],
