@@ -899,7 +899,7 @@ def main():
     # the coded download (2 bits per base + escape bytes, include/crumble_hip.h) and its expansion on the host against the
     # input qualities: the same bytes (checked), a quarter of the link traffic
     t_down, t_dec, cbufs, cq = 1e9, 1e9, None, np.empty(max(1, hb.n_bases), np.uint8)
-    for _ in range(3):
+    for _ in range(1 if args.profile else 3):                      # (--profile: once, so that the object below exists; its launches are not a step's)
         t0 = time.perf_counter()
         c_, _, _ = eng.download_coded(want_flags=True, want_stats=False, bufs=cbufs)
         t1 = time.perf_counter()

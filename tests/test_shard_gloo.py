@@ -34,16 +34,31 @@ def _worker(rank, world, port, scales, q):
     sizes = [int(1e6 * s) for s in scales]
     assign, _ = shard.lpt_pack(sizes, world)
     p = ca.preset_params(5)
-    eng = emu_lib.engine(p, kcol=("v1", "v2")[rank & 1])   # one engine per rank, reused for all its contigs
+    # rank 0: one engine reused for all its contigs; rank 1: an engine per contig (several engines on one device), their
+    # vectors folded into the first with crumble_hip_stats_add before the rank's one all-reduce (bench.py's wgs_strong),
+    # the batches in the form crumble-hip sends them (packed bases, per-read lengths), the result taken in coded form
+    engs = [emu_lib.engine(p, kcol=("v1", "v2")[rank & 1])]
     ok = True
-    for tid in assign[rank]:
+    for k, tid in enumerate(assign[rank]):
         cfg = synth.config("chr20", scale=scales[tid] * 0.001, seed=100 + tid, tid=tid)
         hb = synth.generate(cfg, threads=2)
-        q1, f1, _ = eng.contig(hb)
+        if rank == 1 and k > 0:
+            engs.append(emu_lib.engine(p, kcol="v1"))
+        eng = engs[-1]
+        if rank == 1:
+            import copy
+            eng.upload(copy.copy(hb).pack4(emu_lib.load()).lens()); eng.run()
+            c, f1, _ = eng.download_coded(want_stats=False)
+            q1 = eng.decode(c, hb.quals)
+        else:
+            q1, f1, _ = eng.contig(hb)
         wq, wf, _ = O.contig(p, hb)
         ok = ok and np.array_equal(q1, wq) and np.array_equal(f1, wf)
-    local = eng.stats_read()                                # what crumble_hip_stats_allreduce sums on the GPU
-    eng.close()
+    if len(engs) > 1:
+        engs[0].stats_add(sum(e.stats_read() for e in engs[1:]))
+    local = engs[0].stats_read()                            # what crumble_hip_stats_allreduce sums on the GPU
+    for e in engs:
+        e.close()
     assert ok, "engine output differs from the oracle"
     total = shard.allreduce_stats(local, dist)
     dist.barrier()
