@@ -103,3 +103,55 @@ def test_no_exec_in_the_product():
         if os.path.exists(path):
             out = subprocess.run(["ldd", path], stdout=subprocess.PIPE, text=True).stdout
             assert "libgomp" not in out and "libomp" not in out, (so, out)
+
+
+def test_coded_expansion_host_side(product):
+    """crumble_decode_seek / _run / _quals (plain C, no device): a hand-made coded result -- every code, escapes on both
+    sides of the 4096-base block borders, a last partial word -- expands to what numpy computes; through the cursor from
+    arbitrary starts, in place, with skipped runs (records without qualities)."""
+    import numpy as np
+    from crumble_amd import Coded, DecodeCursor
+    L = crumble_amd.lib()
+    rng = np.random.default_rng(5)
+    for nb in (0, 1, 15, 16, 17, 4095, 4096, 4097, 3 * 4096 + 5, 70001):
+        codes_b = rng.choice(4, nb, p=[0.6, 0.15, 0.2, 0.05]).astype(np.uint32)
+        if nb > 4100:
+            codes_b[4090:4102] = 3                                     # escapes across a block border
+            codes_b[8192 - 16:8192 + 16] = [0, 1] * 16                 # whole words of the two values
+        qin = rng.integers(0, 94, nb).astype(np.uint8)
+        cap = np.minimum(np.arange(256), 60).astype(np.uint8)
+        cap[70] = 70                                                   # a preserved value above the cap
+        esc_vals = rng.integers(0, 100, int((codes_b == 3).sum())).astype(np.uint8)
+        want = np.where(codes_b == 0, 40, np.where(codes_b == 1, 5, cap[qin])).astype(np.uint8)
+        want[codes_b == 3] = esc_vals
+        nw, nblk = (nb + 15) // 16, (nb + 4095) // 4096
+        words = np.zeros(max(1, nw), np.uint32)
+        for i in range(16):
+            part = codes_b[i::16]
+            words[:len(part)] |= part << np.uint32(2 * i)
+        ne_before = np.concatenate([[0], np.cumsum(codes_b == 3)])
+        esc_off = np.array([ne_before[min(nb, b * 4096)] for b in range(max(1, nblk))], np.int64)
+        c = Coded()
+        c.n_bases, c.n_words, c.n_blocks, c.n_escapes = nb, nw, nblk, len(esc_vals)
+        c.value[0], c.value[1] = 40, 5
+        for q in range(256):
+            c.cap[q] = int(cap[q])
+        esc = np.concatenate([esc_vals, np.zeros(1, np.uint8)])
+        c.codes, c.esc_off, c.esc = words.ctypes.data, esc_off.ctypes.data, esc.ctypes.data
+        out = np.full(max(1, nb), 0xEE, np.uint8)
+        if nb:
+            L.crumble_decode_quals(C.byref(c), qin.ctypes.data, out.ctypes.data, 3)
+            assert np.array_equal(out[:nb], want), (nb, np.nonzero(out[:nb] != want)[0][:10])
+        # the cursor: runs of random lengths from a random start, in place, some skipped
+        buf = qin.copy()
+        start = int(rng.integers(0, nb + 1))
+        cur = DecodeCursor()
+        L.crumble_decode_seek(C.byref(c), start, C.byref(cur))
+        b = start
+        while b < nb:
+            n = int(min(nb - b, rng.integers(0, 300)))
+            skip = bool(rng.integers(0, 4) == 0)
+            L.crumble_decode_run(C.byref(c), C.byref(cur), n, buf.ctypes.data + b, None if skip else buf.ctypes.data + b)
+            assert np.array_equal(buf[b:b + n], qin[b:b + n] if skip else want[b:b + n]), (nb, b, n, skip)
+            b += n
+        assert cur.base == max(start, nb) or nb == 0
