@@ -105,6 +105,7 @@ struct crumble_hip {
     DevBuf d_out, d_rflags, d_keepf, d_b15f, d_blk_read, d_chunk_read, d_kept, d_marks;
     DevBuf d_codes, d_escoff, d_esc;        /* the result in coded form (crumble_hip_encode) */
     bool have_coded = false;
+    int64_t coded_escapes = 0;              /* what the last crumble_hip_encode reported (crumble_hip_download_coded copies exactly that) */
     DBatch B;
     bool have_batch = false, have_run = false;
     /* what crumble_hip_expand() needs beyond the raw arrays on the device (set by the copy half of an upload) */
@@ -1431,14 +1432,19 @@ extern "C" int crumble_hip_encode(crumble_hip *h, crumble_coded *c)
     memcpy(c->value, (char *)h->pinned + 328, 2);
     for (int q = 0; q < 256; q++)
         c->cap[q] = (uint8_t)((q > h->hparams.qcap && !h->hparams.preserve_qual[q]) ? h->hparams.qcap : q);   /* cap_quality snp:1325-1332 */
-    h->have_coded = true;
+    h->have_coded = true; h->coded_escapes = (int64_t)tot;
     return CRUMBLE_OK;
 }
 
 extern "C" int crumble_hip_download_coded(crumble_hip *h, const crumble_coded *c, uint8_t *read_flags_out, int64_t *stats)
 {
     if (!h || !c || !h->have_run || !h->have_coded) { g_last_error = "crumble_hip_download_coded: call crumble_hip_encode first"; return CRUMBLE_EINVAL; }
-    if (c->n_bases != h->n_bases || (c->n_words && !c->codes) || (c->n_blocks && !c->esc_off) || (c->n_escapes && !c->esc)) {
+    /* the sizes are the engine's own: a struct whose counts were changed since crumble_hip_encode() is refused, not trusted */
+    if (c->n_bases != h->n_bases || c->n_words != (h->n_bases + 15) / 16 || c->n_blocks != (h->n_bases + ENC_BLOCK - 1) / ENC_BLOCK ||
+        c->n_escapes != h->coded_escapes) {
+        g_last_error = "crumble_hip_download_coded: the crumble_coded is not the one crumble_hip_encode() filled for this run"; return CRUMBLE_EINVAL;
+    }
+    if ((c->n_words && !c->codes) || (c->n_blocks && !c->esc_off) || (c->n_escapes && !c->esc)) {
         g_last_error = "crumble_hip_download_coded: the coded result's buffers are not set"; return CRUMBLE_EINVAL;
     }
     HIPCHK(hipSetDevice(h->device));

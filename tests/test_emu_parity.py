@@ -195,6 +195,33 @@ def test_emu_rejected_batches_leave_the_statistics(product):
     _rejected_batches_leave_the_statistics(emu_lib.engine)
 
 
+def test_emu_coded_download_contract(product):
+    """crumble_hip_encode / _download_coded: nothing to encode before a run, a crumble_coded whose counts were changed since the
+    encode is refused (the engine copies its own sizes, never the caller's), the plain download stays valid beside the coded
+    one, a new run invalidates the coded result."""
+    import ctypes as C
+    p = ca.preset_params(9)
+    hb = synth_batch("chr20", 0.0002)
+    eng = emu_lib.engine(p)
+    c = ca.Coded()
+    assert eng.L.crumble_hip_encode(eng.h, C.byref(c)) == -1            # no run yet
+    eng.upload(hb); eng.run()
+    q, f, s = eng.download()
+    c, f2, s2 = eng.download_coded()
+    assert np.array_equal(eng.decode(c, hb.quals), q) and np.array_equal(f, f2) and np.array_equal(s, s2)
+    q3, _, _ = eng.download()                                            # still there
+    assert np.array_equal(q3, q)
+    for field, val in (("n_escapes", c.n_escapes + 1), ("n_words", c.n_words - 1), ("n_blocks", c.n_blocks + 1), ("n_bases", c.n_bases - 16)):
+        bad = ca.Coded.from_buffer_copy(c)
+        setattr(bad, field, val)
+        assert eng.L.crumble_hip_download_coded(eng.h, C.byref(bad), None, None) == -1, field
+    eng.run()                                                            # a new run: encode again first
+    assert eng.L.crumble_hip_download_coded(eng.h, C.byref(c), None, None) == -1
+    c2, _, _ = eng.download_coded()
+    assert np.array_equal(eng.decode(c2, hb.quals), q)
+    eng.close()
+
+
 def test_emu_rerun_and_engine_reuse(product):
     """run(); download == run(); run(); download (grow-only buffers, partially written arrays), and one engine
     reused for batches of different shapes gives what a fresh engine gives."""
