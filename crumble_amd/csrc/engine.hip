@@ -114,6 +114,7 @@ struct crumble_hip {
     int raw_hot_mq = 0, raw_nslots = 0;
     uint8_t raw_mqtab[256 + 64];
     std::vector<int32_t> raw_pmax;
+    std::vector<int64_t> raw_so, raw_co;    /* a small batch's offset tables made from its per-read lengths on the host */
     unsigned persistent_blocks = 1024;
     bool col_perm = false;          /* k_columns<.., PERM>: picked per batch in crumble_hip_upload */
     /* crumble_hip_set_option(): kernel choices that never change a result (tests force every variant) */
@@ -407,6 +408,7 @@ static int prefix_max(crumble_hip *h, int32_t *v, int64_t n, const int *n_dev = 
  * and crosses in one copy (ten copies of a few kilobytes each were a third of a small contig's fixed cost); a large
  * one is copied array by array straight from the caller's memory. */
 #define RAW_STAGE_MAX ((size_t)4 << 20)
+#define LENS_ON_DEVICE_MIN 65536    /* reads from which on the offset tables are made on the device from the uploaded lengths */
 static int copy_raw(crumble_hip *h, const crumble_batch *b)
 {
     hipStream_t st = h->stream;
@@ -463,11 +465,22 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
     static const int64_t zero64 = 0;
     struct Item { DevBuf *d; const void *src; size_t bytes, front; size_t off; size_t room; };
     const size_t b4bytes = packed4 ? (size_t)CRUMBLE_BASES4_SIZE(nb, n) : 0;
-    const bool dev_offsets = lens && n > 0;               /* (room: bytes the view holds; bytes: what is copied from the host) */
+    /* a small batch's offsets are made right here (three more launches would cost a 5 kb contig more than its 6 bytes per
+     * read save); a large one's by a scan on the device from the lengths it uploads instead */
+    const bool dev_offsets = lens && n > LENS_ON_DEVICE_MIN;
+    const int64_t *h_so = b->seq_off, *h_co = b->cig_off;
+    if (lens && !dev_offsets && n > 0) {
+        h->raw_so.resize((size_t)n + 1); h->raw_co.resize((size_t)n + 1);      /* (live in the handle: the copy below is asynchronous) */
+        int64_t a = 0, c = 0;
+        for (int64_t i = 0; i < n; i++) { h->raw_so[i] = a; h->raw_co[i] = c; a += b->l_qseq[i]; c += b->n_cigar[i]; }
+        h->raw_so[n] = a; h->raw_co[n] = c;
+        if (a != nb || c != nc) { g_last_error = "crumble_batch: n_bases / n_cigar_ops do not match the per-read lengths"; return CRUMBLE_EINVAL; }
+        h_so = h->raw_so.data(); h_co = h->raw_co.data();
+    }                                                     /* (room: bytes the view holds; bytes: what is copied from the host) */
     Item items[] = {
         {&h->d_pos, b->pos, (size_t)n * 4, 0, 0}, {&h->d_mapq, b->mapq, (size_t)n, 0, 0}, {&h->d_flag, b->flag, (size_t)n * 2, 0, 0},
-        {&h->d_seq_off, dev_offsets ? nullptr : n ? (const void *)b->seq_off : (const void *)&zero64, dev_offsets ? 0 : (size_t)(n + 1) * 8, 0, 0, (size_t)(n + 1) * 8},
-        {&h->d_cig_off, dev_offsets ? nullptr : n ? (const void *)b->cig_off : (const void *)&zero64, dev_offsets ? 0 : (size_t)(n + 1) * 8, 0, 0, (size_t)(n + 1) * 8},
+        {&h->d_seq_off, dev_offsets ? nullptr : n ? (const void *)h_so : (const void *)&zero64, dev_offsets ? 0 : (size_t)(n + 1) * 8, 0, 0, (size_t)(n + 1) * 8},
+        {&h->d_cig_off, dev_offsets ? nullptr : n ? (const void *)h_co : (const void *)&zero64, dev_offsets ? 0 : (size_t)(n + 1) * 8, 0, 0, (size_t)(n + 1) * 8},
         {&h->d_lq, b->l_qseq, dev_offsets ? (size_t)n * 4 : 0, 0, 0}, {&h->d_ncg, b->n_cigar, dev_offsets ? (size_t)n * 2 : 0, 0, 0},
         {&h->d_cigar, b->cigar, (size_t)nc * 4, 0, 0},
         {&h->d_quals, b->quals, (size_t)nb, BASE_FRONT_PAD, 0},
