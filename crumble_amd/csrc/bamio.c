@@ -88,7 +88,7 @@ static inline void put32(uint8_t *p, uint32_t v) { p[0] = v; p[1] = v >> 8; p[2]
 static inline void put16(uint8_t *p, uint16_t v) { p[0] = v; p[1] = v >> 8; }
 
 /* Multi-GB buffers come straight from mmap with MADV_HUGEPAGE: first touch of 4 KiB pages by a
- * large OpenMP team is otherwise the dominant host cost (one page fault per 4 KiB, serialised on
+ * large team of threads is otherwise the dominant host cost (one page fault per 4 KiB, serialised on
  * the address-space lock).  Growing keeps the contents through mremap (no copy). */
 /* Sizes are rounded up to size classes (2^k and 1.5 * 2^k, at least 2 MiB) and freed buffers of a class wait in a
  * small pool: a contig pipeline (crumble-hip: several groups in flight, a quality buffer per group) would otherwise

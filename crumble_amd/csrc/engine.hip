@@ -928,7 +928,7 @@ extern "C" int crumble_hip_run_columns(crumble_hip *h)
     RUN_LOCALS
     h->n_stages = 0; h->have_run = false; h->fold_small = false; h->have_coded = false;
     memset(&h->totals, 0, sizeof(h->totals));
-    HIPCHK(hipMemsetAsync(stats, 0, CRUMBLE_ST_N * 8 + 64, st));      /* the counters and the run flags */
+    HIPCHK(hipMemsetAsync(stats, 0, CRUMBLE_ST_N * 8 + 128, st));     /* the counters, the run flags, k_columns2's eight unit counters */
 
     if (L > 0) {
         uint32_t *ht = h->d_ht.as<uint32_t>();
@@ -957,7 +957,7 @@ extern "C" int crumble_hip_run_columns(crumble_hip *h)
         if (v2) {
             unsigned g2 = (h->persistent_blocks + 3) / 4;       /* one workgroup of KC2_WAVES waves per CU */
             if (g2 > nblk(B.n_tiles, KC2_WAVES)) g2 = nblk(B.n_tiles, KC2_WAVES);
-#define KCOL2_LAUNCH4(MQ_, AP_, MU_, W_) CRUMBLE_LAUNCH((k_columns2<MQ_, AP_, MU_, W_>), g2, KC2_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, ht, stats, (unsigned *)(d_overflow + 3))
+#define KCOL2_LAUNCH4(MQ_, AP_, MU_, W_) CRUMBLE_LAUNCH((k_columns2<MQ_, AP_, MU_, W_>), g2, KC2_THREADS, st, B, P, T, colrec, nplp, score, trigcnt, ht, stats, (unsigned *)(d_overflow + 16))
 #define KCOL2_LAUNCH3(MQ_, AP_, MU_) do { if (h->windowed) KCOL2_LAUNCH4(MQ_, AP_, MU_, true); else KCOL2_LAUNCH4(MQ_, AP_, MU_, false); } while (0)
 #define KCOL2_LAUNCH(MQ_, AP_) do { if (multi) KCOL2_LAUNCH3(MQ_, AP_, true); else KCOL2_LAUNCH3(MQ_, AP_, false); } while (0)
             if (modeB) { if (h->hparams.any_preserve) KCOL2_LAUNCH(true, true); else KCOL2_LAUNCH(true, false); }

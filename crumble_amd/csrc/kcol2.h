@@ -310,6 +310,31 @@ struct __attribute__((aligned(16))) KC2Lds {
                     } \
                 }
 
+/* The next unit for a workgroup (round 5, XCD-aware): the units are cut into eight contiguous ranges, one per group of
+ * workgroups that share an XCD (blockIdx % 8 under the round-robin placement: which blocks share one, never which XCD --
+ * speed only), each range with its own counter.  The 32 workgroups of an XCD then work on neighbouring units at the same
+ * time, and the reads that straddle a unit border (three in ten at 150 bases and 512-column units) are in THEIR L2 when the
+ * neighbour asks for them, instead of being fetched once per XCD.  A group whose range is used up takes from the others'. */
+#ifndef KC2_XCD
+#define KC2_XCD 1
+#endif
+__device__ __forceinline__ int kc2_next_unit(unsigned *__restrict__ ctr, int n_units)
+{
+#if KC2_XCD
+    const int grp = (int)(blockIdx.x & 7u);
+    for (int j = 0; j < 8; j++) {
+        const int y = (grp + j) & 7;
+        const int s0 = (int)((long long)n_units * y / 8), e0 = (int)((long long)n_units * (y + 1) / 8);
+        if (s0 >= e0 || *(volatile unsigned *)&ctr[y] >= (unsigned)(e0 - s0)) continue;
+        const unsigned k = atomicAdd(&ctr[y], 1u);
+        if (k < (unsigned)(e0 - s0)) return s0 + (int)k;
+    }
+    return n_units;
+#else
+    return (int)atomicAdd(ctr, 1u);
+#endif
+}
+
 /* MQ: the active consensus uses CONS_MQUAL (mode B, snp:1535); ANYPRES: -k/-K/-y pbccs set preserve_qual[];
  * MULTI: long reads (many ops per read: a tile's records come from the batch's hit list); WIN: the batch is a window
  * of a contig (crumble_hip_set_window: columns outside [col_lo, col_hi) read as empty, columns from stat_hi on stay
@@ -387,7 +412,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                         const unsigned long long d2 = *(volatile unsigned long long *)&L.deal;     /* refilled meanwhile? */
                         if ((unsigned)d2 < (unsigned)(d2 >> 32)) st = 3u;
                         else {
-                            const int g = (int)atomicAdd(tile_ctr, 1u);
+                            const int g = kc2_next_unit(tile_ctr, B.n_units);
                             if (g >= B.n_units) { L.deal_done = 1u; st = 2u; }
                             else {
                                 const unsigned tb = (unsigned)g * (unsigned)B.unit_tiles;
@@ -417,7 +442,7 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
     int t_begin, t_end;
     {
         int g = 0;
-        if (lane == 0) g = (int)atomicAdd(tile_ctr, 1u);
+        if (lane == 0) g = kc2_next_unit(tile_ctr, B.n_units);
         g = READLANE(g, 0);
         if (g >= B.n_units) break;
         t_begin = g * B.unit_tiles; t_end = t_begin + B.unit_tiles < B.n_tiles ? t_begin + B.unit_tiles : B.n_tiles;

@@ -887,16 +887,28 @@ __device__ __forceinline__ void scanval_of(uint32_t rec, int32_t nplp, int32_t t
 __device__ __forceinline__ void scanval_add(ScanVal &a, const ScanVal &b)
 { a.depth += b.depth; a.cols += b.cols; a.trigcols += b.trigcols; a.items += b.items; a.ins += b.ins; a.toodeep += b.toodeep; }
 
-/* wave-level inclusive scan of a ScanVal (shuffles), then block-level via LDS */
+/* wave-level inclusive scan of a ScanVal, then block-level via LDS.  Round 5: the six fields go through the DPP scans of
+ * kcol2.h (VALU only, six dependent steps of a few cycles) instead of __shfl_up ladders -- 36 ds_bpermute round trips per
+ * scan, six of them dependent -- in kernels that do one such scan per 1024 columns between two barriers */
+#ifdef CRUMBLE_EMU
+__device__ __forceinline__ long long kc2_scan_add64(long long v)
+{ const int ln = threadIdx.x & 63; for (int d = 1; d < 64; d <<= 1) { const long long o = __shfl_up(v, d); if (ln >= d) v += o; } return v; }
+#else
+__device__ __forceinline__ long long kc2_scan_add64(long long v)
+{
+#define KC2_STEP64(ctrl_, rows_) { const int lo_ = KC2_DPP(0, (int)v, ctrl_, rows_), hi_ = KC2_DPP(0, (int)(v >> 32), ctrl_, rows_); \
+                                   v += (long long)(((unsigned long long)(unsigned)hi_ << 32) | (unsigned)lo_); }
+    KC2_STEP64(0x111, 0xf) KC2_STEP64(0x112, 0xf) KC2_STEP64(0x114, 0xf) KC2_STEP64(0x118, 0xf) KC2_STEP64(0x142, 0xa) KC2_STEP64(0x143, 0xc)
+#undef KC2_STEP64
+    return v;
+}
+#endif
 __device__ __forceinline__ ScanVal scanval_wave_incl(ScanVal v, int lane)
 {
-    #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        ScanVal o;
-        o.depth = __shfl_up(v.depth, d); o.cols = __shfl_up(v.cols, d); o.trigcols = __shfl_up(v.trigcols, d);
-        o.items = __shfl_up(v.items, d); o.ins = __shfl_up(v.ins, d); o.toodeep = __shfl_up(v.toodeep, d); o.pad = 0;
-        if (lane >= d) scanval_add(v, o);
-    }
+    (void)lane;
+    v.depth = kc2_scan_add64(v.depth);
+    v.cols = kc2_scan_add(v.cols); v.trigcols = kc2_scan_add(v.trigcols); v.items = kc2_scan_add(v.items);
+    v.ins = kc2_scan_add(v.ins); v.toodeep = kc2_scan_add(v.toodeep);
     return v;
 }
 /* the same for per-position values, whose four flag fields are 0/1: their prefix is a popcount of
@@ -908,11 +920,7 @@ __device__ __forceinline__ ScanVal scanval_wave_incl01(ScanVal v, int lane)
     v.trigcols = __popcll(__ballot(v.trigcols != 0) & le);
     v.ins = __popcll(__ballot(v.ins != 0) & le);
     v.toodeep = __popcll(__ballot(v.toodeep != 0) & le);
-    #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int64_t od = __shfl_up(v.depth, d); const int oi = __shfl_up(v.items, d);
-        if (lane >= d) { v.depth += od; v.items += oi; }
-    }
+    v.depth = kc2_scan_add64(v.depth); v.items = kc2_scan_add(v.items);
     return v;
 }
 

@@ -5,7 +5,7 @@
  * (snp_score.c:1116-1117) and sam_write1() inside flush_bam_list() (snp_score.c:1101).  htslib is
  * not part of /root/reference, so this is a from-the-spec BGZF + BAM (SAMv1 section 4) reader and
  * writer that produces exactly the SoA `crumble_batch` the engine consumes and writes the records
- * back with the engine's quality bytes.  BGZF blocks are inflated / deflated by an OpenMP team
+ * back with the engine's quality bytes.  BGZF blocks are inflated / deflated by a team of host threads (csrc/team.h)
  * (zlib per block), record fields are unpacked per read in parallel.
  *
  * Plain C ABI, no HIP.  Lives in libcrumble_bamio.so so that hosts which already have htslib need

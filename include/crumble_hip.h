@@ -134,7 +134,7 @@ typedef struct crumble_batch {
 } crumble_batch;
 #define CRUMBLE_BASES4_OFF(seq_off_i, i)      (((int64_t)(seq_off_i) >> 1) + (int64_t)(i))
 #define CRUMBLE_BASES4_SIZE(n_bases, n_reads) (((int64_t)(n_bases) >> 1) + (int64_t)(n_reads) + 1)
-/* bases (one code per byte) -> the bases4 layout above; out has CRUMBLE_BASES4_SIZE bytes.  Host helper (OpenMP). */
+/* bases (one code per byte) -> the bases4 layout above; out has CRUMBLE_BASES4_SIZE bytes.  Host helper (a team of host threads). */
 void crumble_pack_bases4(int64_t n_reads, const int64_t *seq_off, const uint8_t *bases, uint8_t *out);
 
 /* per-read output flags */
