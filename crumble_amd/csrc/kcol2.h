@@ -310,24 +310,32 @@ struct __attribute__((aligned(16))) KC2Lds {
                     } \
                 }
 
-/* The next unit for a workgroup (round 5, XCD-aware): the units are cut into eight contiguous ranges, one per group of
- * workgroups that share an XCD (blockIdx % 8 under the round-robin placement: which blocks share one, never which XCD --
- * speed only), each range with its own counter.  The 32 workgroups of an XCD then work on neighbouring units at the same
- * time, and the reads that straddle a unit border (three in ten at 150 bases and 512-column units) are in THEIR L2 when the
- * neighbour asks for them, instead of being fetched once per XCD.  A group whose range is used up takes from the others'. */
+/* The next unit for a workgroup.  KC2_XCD = 1 (round-5 experiment, off): chunks of KC2_XCD_CHUNK consecutive units are dealt
+ * round-robin to eight groups of workgroups (blockIdx % 8: the blocks that share an XCD under round-robin placement), each
+ * group with its own counter, so that the 32 workgroups of an XCD work on neighbouring units and the reads that straddle a
+ * unit border are in THEIR L2.  Measured on one box: chr20 4.531 (one counter) / 4.536 (this) / 4.549 (groups of blockIdx / 32)
+ * -- the re-fetch across XCDs is not what the kernel waits for.  Two things learnt on the way: eight contiguous eighths of the
+ * contig instead of interleaved chunks, and ANY look at the counter before the add (a volatile global load under the
+ * workgroup's lock), each cost 2.7-3.2 ms of 4.5. */
 #ifndef KC2_XCD
-#define KC2_XCD 1
+#define KC2_XCD 0
+#endif
+#ifndef KC2_XCD_CHUNK
+#define KC2_XCD_CHUNK 32
 #endif
 __device__ __forceinline__ int kc2_next_unit(unsigned *__restrict__ ctr, int n_units)
 {
 #if KC2_XCD
     const int grp = (int)(blockIdx.x & 7u);
+    const int C = KC2_XCD_CHUNK, full = n_units / (8 * C), rem = n_units % (8 * C);
     for (int j = 0; j < 8; j++) {
         const int y = (grp + j) & 7;
-        const int s0 = (int)((long long)n_units * y / 8), e0 = (int)((long long)n_units * (y + 1) / 8);
-        if (s0 >= e0 || *(volatile unsigned *)&ctr[y] >= (unsigned)(e0 - s0)) continue;
+        int extra = rem - y * C;
+        extra = extra < 0 ? 0 : extra > C ? C : extra;
+        const unsigned len = (unsigned)(full * C + extra);                   /* units u with (u / C) % 8 == y */
+        if (len == 0u) continue;
         const unsigned k = atomicAdd(&ctr[y], 1u);
-        if (k < (unsigned)(e0 - s0)) return s0 + (int)k;
+        if (k < len) return (int)(((k / (unsigned)C) * 8u + (unsigned)y) * (unsigned)C + k % (unsigned)C);
     }
     return n_units;
 #else
