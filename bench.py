@@ -369,11 +369,12 @@ def measure_small_contig(ca, synth, device, preset=5, contig_len=5000, reps=200)
             "note": "crumble_hip_contig() per call on a 5 kb contig (host -> device, expansion, run, device -> host), and crumble_hip_run() alone"}
 
 
-def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=4, coded=True, n_uploaders=1):
+def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=4, coded=True, n_uploaders=1, coded_in=None):
     """BASELINE config 5 on ONE GPU as the stream it is (snp_score.c:1437: contigs one after another): the 24 contigs
     sit in host memory; contig k+1's host -> device copy + device-side expansion, contig k's kernels, contig k-1's
     coded download and contig k-2's expansion on the host run side by side -- four host threads, a ring of engines
-    (each its own HIP stream).  Reports the wall time per pass, the stages' summed times and wall / sum
+    (each its own HIP stream).  coded_in: a fifth stage in front packs contig k+2's qualities into 2- / 4-bit codes
+    (crumble_pack_quals on the host's threads, inside the clock) and the upload sends those (crumble_batch.qualsp).  Reports the wall time per pass, the stages' summed times and wall / sum
     (1.0 = nothing overlaps)."""
     import queue
     import threading
@@ -415,6 +416,15 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=4,
     # the coded download's three streams (2 bits per base, a block table, the escape bytes) land in page-locked memory too
     coded_bufs = {id(e): (pin(np.zeros(max_nb // 16 + 2, np.uint32)), pin(np.zeros(max_nb // 4096 + 2, np.int64)),
                           pin(np.zeros(max(1, max_nb // 8), np.uint8))) for e in engines} if coded else {}
+    # the coded qualities are made INSIDE the pass (a stage of its own); their page-locked landing buffers are made here
+    import ctypes as C_
+    if coded_in is None:        # off by default: on a 16-core host the packing costs more CPU than the link saves (profiles/NOTES_r05.md)
+        coded_in = os.environ.get("CRUMBLE_BENCH_STREAM_CODED_IN") == "1"
+    coded_in = bool(coded_in and hasattr(ca, "lib") and hasattr(ca.lib(), "crumble_pack_quals"))
+    qp_bufs = [pin(np.zeros((b_.n_bases * 4 + 7) // 8 + 16, np.uint8)) for b_ in batches] if coded_in else []
+    if coded_in:
+        ca.lib().crumble_pack_quals.restype = C_.c_int
+        ca.lib().crumble_pack_quals.argtypes = [C_.c_int64, C_.c_void_p, C_.c_void_p, C_.c_void_p]
     xfer = [0, 0]
     k_small = int(np.argmin([b_.n_bases for b_ in batches]))
     kept = {}
@@ -424,20 +434,39 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=4,
             free_q, run_q, dl_q, dec_q = queue.Queue(), queue.Queue(), queue.Queue(), queue.Queue()
             for e in engines:
                 free_q.put(e)
-            t_stage = [0.0, 0.0, 0.0, 0.0]
+            t_stage = [0.0, 0.0, 0.0, 0.0, 0.0]
             err = []
+            up_q = queue.Queue()
 
             up_lock = threading.Lock()
-            up_state = {"next": 0, "live": n_uploaders}
+            up_state = {"live": n_uploaders}
+
+            def packer():
+                # the qualities as 2- / 4-bit codes (crumble_pack_quals, the host's threads): what the upload then sends
+                try:
+                    for i, b_ in enumerate(batches):
+                        if coded_in:
+                            t = time.perf_counter()
+                            lut = np.zeros(16, np.uint8)
+                            bits = ca.lib().crumble_pack_quals(b_.n_bases, b_.quals.ctypes.data, qp_bufs[i].ctypes.data, lut.ctypes.data)
+                            if bits:
+                                b_.qualsp, b_.qual_bits, b_.qual_lut = qp_bufs[i][:(b_.n_bases * bits + 7) // 8 + 16], bits, lut
+                            else:
+                                b_.qualsp = None
+                            t_stage[4] += time.perf_counter() - t
+                        up_q.put(i)
+                except Exception as ex:            # noqa: BLE001
+                    err.append(ex)
+                for _ in range(n_uploaders):
+                    up_q.put(None)
 
             def uploader():
                 # n_uploaders threads take the contigs in turn: while one engine's expansion (a few small kernels and their
                 # size read-back) runs, the other's copies keep the link busy
                 try:
                     while True:
-                        with up_lock:
-                            i = up_state["next"]; up_state["next"] += 1
-                        if i >= len(batches):
+                        i = up_q.get()
+                        if i is None:
                             break
                         e = free_q.get()
                         t = time.perf_counter(); e.upload(batches[i]); dt = time.perf_counter() - t
@@ -512,7 +541,7 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=4,
                         free_q.put(it[1])
                 except Exception as ex:            # noqa: BLE001
                     err.append(ex)
-            th = [threading.Thread(target=f) for f in (uploader,) * n_uploaders + (runner, downloader) + ((decoder,) if coded else ())]
+            th = [threading.Thread(target=f) for f in (packer,) + (uploader,) * n_uploaders + (runner, downloader) + ((decoder,) if coded else ())]
             t0 = time.perf_counter()
             for t in th:
                 t.start()
@@ -531,10 +560,13 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=4,
         ok = bool(np.array_equal(kept["q"], wq) and np.array_equal(kept["f"], wf)) and all(lens_ok)
         return {
             "workload": f"wgs-30x: 24 synthetic contigs (GRCh38 lengths x {scale}), {total} bases, -{preset}, streamed through "
-                        f"{n_engines} engines on one GPU ({n_uploaders} uploads || kernels || download || host expansion)",
+                        f"{n_engines} engines on one GPU ({'host packing || ' if coded_in else ''}{n_uploaders} uploads || kernels || download || host expansion)",
             "value_incl_pcie": round(total / wall / 1e9, 3), "unit": "Gbases/s", "ms_per_pass": round(wall * 1e3, 2),
             "stages_ms": {"h2d_and_p0": round(st[0] * 1e3, 2), "kernels": round(st[1] * 1e3, 2), "d2h": round(st[2] * 1e3, 2),
-                          **({"host_decode": round(st[3] * 1e3, 2)} if coded else {})},
+                          **({"host_decode": round(st[3] * 1e3, 2)} if coded else {}), **({"host_pack": round(st[4] * 1e3, 2)} if coded_in else {})},
+            "upload": ("coded qualities: 2 / 4 bits per base into a table of the batch's values (crumble_pack_quals on the host's threads, "
+                       "a stage inside the clock; expanded on the device by k_p0_quals), BAM-packed bases, per-read lengths"
+                       if coded_in else "one byte per quality, BAM-packed bases, per-read lengths"),
             "download": "coded: 2 bits per base + escape bytes (crumble_hip_encode / _download_coded), expanded by crumble_decode_quals on the host's threads as a fourth stage" if coded else "plain: one byte per base",
             "pcie_bytes_per_base": {"in": round(xfer[0] / max(1, total), 4), "out": round(xfer[1] / max(1, total), 4)},
             "overlap_wall_over_sum_of_stages": round(wall / max(1e-9, sum(st)), 3),
@@ -547,6 +579,8 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=4,
         for b_, saved in zip(batches, originals):   # no array of a batch may point into freed page-locked memory
             for nm, a in saved.items():
                 setattr(b_, nm, a)
+            b_.qualsp = None
+        qp_bufs.clear()
         out_bufs.clear()
         coded_bufs.clear()
         kept.clear()
@@ -885,8 +919,40 @@ def main():
     value = total_bases * args.steps / elapsed / 1e9
     ms_per_step = elapsed / args.steps * 1e3
 
-    # ---- download of the TIMED engine's result (what the verification below looks at) ----
     up_bytes = sum(e_.transfer_bytes()[0] for e_ in engines)
+    # ---- the same contig with its qualities sent as codes (crumble_batch.qualsp: 2 / 4 bits per base into a table of the
+    # batch's values, made by crumble_pack_quals on the host's threads, expanded on the device by k_p0_quals inside the
+    # expansion): what the PCIe-inclusive rates below use when it is the faster way in.  Never `value`: the headline keeps
+    # one byte per quality in HBM, as rounds 1-4 measured it.
+    coded_q = None
+    if len(batches) == 1 and world == 1 and hasattr(ca.lib(), "crumble_pack_quals"):
+        import copy
+        t_pack = 1e9
+        for _ in range(1 if args.profile else 2):
+            t0 = time.perf_counter()
+            hq = copy.copy(hb).packq(ca.lib())
+            t_pack = min(t_pack, time.perf_counter() - t0)
+        if getattr(hq, "qualsp", None) is not None:
+            eng.upload(hq)
+            eng.upload(hq)
+            hq_h2d_ms, _ = eng.upload_times()
+            hq_up_bytes = eng.transfer_bytes()[0]
+            step_one(eng)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            hq_p0 = 0.0
+            for _ in range(args.steps):
+                step_one(eng)
+                hq_p0 += eng.upload_times()[1]
+            torch.cuda.synchronize()
+            hq_step_s = (time.perf_counter() - t0) / args.steps
+            coded_q = {"bits": int(hq.qual_bits), "distinct_values_in_first_4M": int(len(np.unique(hb.quals[:4000000]))),
+                       "host_pack_ms": round(t_pack * 1e3, 3), "h2d_ms": round(hq_h2d_ms, 3), "p0_ms": round(hq_p0 / args.steps, 3),
+                       "ms_per_step": round(hq_step_s * 1e3, 3), "value": round(hb.n_bases / hq_step_s / 1e9, 3),
+                       "pcie_in_bytes_per_base": round(hq_up_bytes / max(1, hb.n_bases), 4)}
+        del hq
+
+    # ---- download of the TIMED engine's result (what the verification below looks at) ----
     t0 = time.perf_counter()
     tq, tf, _ = eng.download(want_stats=False)
     t_down_first = time.perf_counter() - t0
@@ -951,6 +1017,8 @@ def main():
     # what a real contig pays around the timed step: PCIe in and out
     step_s = elapsed / args.steps
     h2d_s = h2d_ms * 1e-3
+    # the way in with coded qualities, everything counted: packing on the host + the smaller copy + the step with k_p0_quals inside
+    in_coded_s = (coded_q["host_pack_ms"] + coded_q["h2d_ms"] + coded_q["ms_per_step"]) * 1e-3 if coded_q else 1e9
     extra = {
         "p0_ms": round(p0_step_ms, 3), "h2d_ms": round(h2d_ms, 3),
         "d2h_ms": round((t_down + t_dec) * 1e3 * len(batches), 3), "d2h_coded_copy_ms": round(t_down * 1e3 * len(batches), 3),
@@ -960,8 +1028,12 @@ def main():
         "pcie_bytes_per_base": {"in": round(up_bytes / max(1, bases_local), 4), "out": round(down_coded_bytes / max(1, hb.n_bases), 4),
                                 "out_plain": round(down_plain_bytes / max(1, hb.n_bases), 4)},
         "value_kernels_only": round(bases_local / (kernel_ms_total * 1e-3) / 1e9, 3) if kernel_ms_total > 0 else None,
-        "value_incl_pcie": round(bases_local / (step_s + h2d_s + min(t_down + t_dec, t_down_plain) * len(batches)) / 1e9, 3),
+        "value_incl_pcie": round(bases_local / (min(step_s + h2d_s, in_coded_s) + min(t_down + t_dec, t_down_plain) * len(batches)) / 1e9, 3),
+        "value_incl_pcie_upload": "coded qualities (host packing inside)" if in_coded_s < step_s + h2d_s else "plain",
         "value_incl_pcie_download": "coded" if t_down + t_dec < t_down_plain else "plain",
+        "coded_qualities": coded_q,
+        "value_incl_pcie_coded_both_copies_only": (round(bases_local / (coded_q["ms_per_step"] * 1e-3 + coded_q["h2d_ms"] * 1e-3 + t_down) / 1e9, 3)
+                                                   if coded_q else None),
         "value_incl_pcie_coded_download": round(bases_local / (step_s + h2d_s + (t_down + t_dec) * len(batches)) / 1e9, 3),
         "value_incl_pcie_coded_copy_only": round(bases_local / (step_s + h2d_s + t_down * len(batches)) / 1e9, 3),
         "value_incl_pcie_plain_download": round(bases_local / (step_s + h2d_s + t_down_plain * len(batches)) / 1e9, 3),
@@ -974,7 +1046,10 @@ def main():
                 "is the one-byte-per-base download (steady state into mapped pageable buffers; d2h_first_ms also pays the page faults); "
                 "value_incl_pcie takes whichever of the two is faster on this host for a FLAT output array (the coded form is "
                 "made for callers that expand it into their records while they write them, crumble-hip's writer: "
-                "value_incl_pcie_coded_copy_only leaves the expansion to that pass)",
+                "value_incl_pcie_coded_copy_only leaves the expansion to that pass); coded_qualities: the same contig uploaded with its "
+                "qualities as 2- / 4-bit codes (crumble_pack_quals + crumble_batch.qualsp, k_p0_quals inside the step): value_incl_pcie "
+                "takes that way in when packing + copy + step beat the plain copy + step; value_incl_pcie_coded_both_copies_only = "
+                "coded in and out with the host-side packing / expansion left to the reader's and writer's record passes",
     }
 
     out = {

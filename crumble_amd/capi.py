@@ -53,6 +53,7 @@ class Batch(C.Structure):
         ("n_bed", C.c_int32), ("bed_start", C.c_void_p), ("bed_end", C.c_void_p),
         ("bases4", C.c_void_p),
         ("l_qseq", C.c_void_p), ("n_cigar", C.c_void_p), ("n_bases", C.c_int64), ("n_cigar_ops", C.c_int64),
+        ("qualsp", C.c_void_p), ("qual_bits", C.c_int32), ("qual_lut", C.c_uint8 * 16),
     ]
 
 
@@ -155,6 +156,12 @@ class HostBatch:
             b.l_qseq, b.n_cigar = self._ptr(self.l_qseq), self._ptr(self.n_cigar)
             b.n_bases, b.n_cigar_ops = self.n_bases, int(self.cig_off[-1]) if len(self.cig_off) else 0
             b.seq_off = b.cig_off = None
+        b.qualsp, b.qual_bits = None, 0
+        if packed and getattr(self, "qualsp", None) is not None:       # coded qualities instead (crumble_batch.qualsp)
+            b.qualsp, b.qual_bits = self.qualsp.ctypes.data, self.qual_bits
+            for i in range(16):
+                b.qual_lut[i] = int(self.qual_lut[i])
+            b.quals = None
         return b
 
     def lens(self):
@@ -174,6 +181,18 @@ class HostBatch:
         lib.crumble_pack_bases4.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.crumble_pack_bases4(self.n_reads, self.seq_off.ctypes.data, self._ptr(self.bases), out.ctypes.data)
         self.bases4 = out
+        return self
+
+    def packq(self, lib):
+        """Attach the qualities as 2- or 4-bit codes (crumble_pack_quals): struct() then hands the engine qualsp and no quals.
+        A batch with more than sixteen distinct qualities keeps the bytes."""
+        out = np.zeros((self.n_bases * 4 + 7) // 8 + 16, np.uint8)
+        lut = np.zeros(16, np.uint8)
+        lib.crumble_pack_quals.restype = C.c_int
+        lib.crumble_pack_quals.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        bits = lib.crumble_pack_quals(self.n_bases, self._ptr(self.quals), out.ctypes.data, lut.ctypes.data)
+        if bits:
+            self.qualsp, self.qual_bits, self.qual_lut = out[:(self.n_bases * bits + 7) // 8 + 16], bits, lut
         return self
 
     @classmethod

@@ -77,6 +77,8 @@ struct crumble_hip {
     crumble_params params;
     DParams hparams;
     DevBuf d_params, d_tables, d_stats, d_batch_stats, d_misc, d_mqslot;
+    DevBuf d_qualsp;                /* the coded qualities of an upload (crumble_batch.qualsp; a view into d_raw): k_p0_quals makes d_quals from them */
+    int raw_qbits = 0; uint8_t raw_qlut[16] = {0};
     DevBuf d_lq, d_ncg;             /* BAM's own per-read lengths, when the batch carries them instead of the offset tables (views into d_raw) */
     size_t up_bytes = 0, down_bytes = 0;    /* bytes the last upload copied from the host / the last download copied to it */
     DevBuf d_raw;                   /* arena of the raw arrays of an upload: d_pos, d_mapq, d_flag, d_seq_off, d_cig_off, d_cigar, d_quals,
@@ -422,6 +424,9 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
     h->have_batch = false; h->have_run = false; h->have_raw = false; h->have_hits = false;
     const bool packed4 = b->bases4 != nullptr;      /* BAM-packed bases: half the bytes over PCIe, unpacked by k_p0_bases */
     if (!packed4 && !b->bases && nb > 0) { g_last_error = "crumble_batch: neither bases nor bases4"; return CRUMBLE_EINVAL; }
+    const int qbits = b->qualsp ? b->qual_bits : 0;   /* coded qualities: a quarter / half of the bytes over PCIe, expanded by k_p0_quals */
+    if (qbits != 0 && qbits != 2 && qbits != 4) { g_last_error = "crumble_batch: qual_bits must be 0, 2 or 4"; return CRUMBLE_EINVAL; }
+    if (!qbits && !b->quals && nb > 0) { g_last_error = "crumble_batch: neither quals nor qualsp"; return CRUMBLE_EINVAL; }
     const int n_bed = b->n_bed > 0 ? b->n_bed : 0;
     int e;
     {   /* the mapq most reads carry: the column kernels keep a composed quality table for it in LDS; the next
@@ -451,7 +456,10 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
         double q2e[128];                                     /* (per call: handles may be used from several threads) */
         for (int q = 0; q < 128; q++) q2e[q] = pow(10.0, -q / 10.0);
         const int64_t step = nb > 65536 ? nb / 65536 : 1;
-        for (int64_t i = 0; i < nb; i += step, cnt++) esum += q2e[b->quals[i] & 127];
+        for (int64_t i = 0; i < nb; i += step, cnt++) {
+            const int q = !qbits ? b->quals[i] : b->qual_lut[(b->qualsp[(i * qbits) >> 3] >> ((i * qbits) & 7)) & ((1 << qbits) - 1)];
+            esum += q2e[q & 127];
+        }
         h->raw_lowerr = cnt > 0 && esum < 0.02 * (double)cnt;
     }
     /* keep-regions: the prefix max of `end` drives the cursor emulation (bed_preserve) */
@@ -483,7 +491,8 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
         {&h->d_cig_off, dev_offsets ? nullptr : n ? (const void *)h_co : (const void *)&zero64, dev_offsets ? 0 : (size_t)(n + 1) * 8, 0, 0, (size_t)(n + 1) * 8},
         {&h->d_lq, b->l_qseq, dev_offsets ? (size_t)n * 4 : 0, 0, 0}, {&h->d_ncg, b->n_cigar, dev_offsets ? (size_t)n * 2 : 0, 0, 0},
         {&h->d_cigar, b->cigar, (size_t)nc * 4, 0, 0},
-        {&h->d_quals, b->quals, (size_t)nb, BASE_FRONT_PAD, 0},
+        {qbits ? &h->d_qualsp : &h->d_quals, qbits ? (const void *)b->qualsp : (const void *)b->quals,
+         qbits ? (size_t)CRUMBLE_QUALSP_SIZE(nb, qbits) - 16 : (size_t)nb, qbits ? 0 : (size_t)BASE_FRONT_PAD, 0},
         {packed4 ? &h->d_bases4 : &h->d_bases, packed4 ? (const void *)b->bases4 : (const void *)b->bases, packed4 ? b4bytes : (size_t)nb, packed4 ? 0 : (size_t)BASE_FRONT_PAD, 0},
         {&h->d_bed_start, b->bed_start, (size_t)n_bed * 4, 0, 0}, {&h->d_bed_end, b->bed_end, (size_t)n_bed * 4, 0, 0},
         {&h->d_bed_pmax, pmax.data(), (size_t)n_bed * 4, 0, 0}, {&h->d_mqslot, h->raw_mqtab, sizeof h->raw_mqtab, 0, 0},
@@ -497,6 +506,11 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
         if (h->d_bases.owned == false) h->d_bases = DevBuf();
         if ((e = h->d_bases.reserve((size_t)nb + 2 * BASE_FRONT_PAD + 64))) return e;
         HIPCHK(hipMemsetAsync(h->d_bases.p, 0, BASE_FRONT_PAD, st));
+    }
+    if (qbits) {                                         /* likewise the one-byte-per-quality form (k_p0_quals, with the expansion) */
+        if (h->d_quals.owned == false) h->d_quals = DevBuf();
+        if ((e = h->d_quals.reserve((size_t)nb + 2 * BASE_FRONT_PAD + 64))) return e;
+        HIPCHK(hipMemsetAsync(h->d_quals.p, 0, BASE_FRONT_PAD, st));
     }
     bool staged = false;
     if (total <= RAW_STAGE_MAX) {
@@ -526,6 +540,7 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
                        h->d_seq_off.as<int64_t>(), h->d_cig_off.as<int64_t>());
     }
     h->raw_tid = b->tid; h->raw_nbed = n_bed; h->raw_packed4 = packed4;
+    h->raw_qbits = qbits; memcpy(h->raw_qlut, b->qual_lut, 16);
     h->n_reads = n; h->n_bases = nb; h->n_cigar = nc;
     h->up_bytes = 0;
     for (const Item &it : items) h->up_bytes += it.bytes;
@@ -560,6 +575,15 @@ static int expand(crumble_hip *h, bool wait)
     h->have_batch = false; h->have_run = false; h->have_hits = false; h->have_vrec = false; h->late_pending = false;
     int e;
     HIPCHK(hipEventRecord(h->ev_up[1], st));
+    if (h->raw_qbits && nb > 0) {                        /* 0. the qualities, one byte each, from their codes */
+        uint32_t l[4];
+        memcpy(l, h->raw_qlut, 16);
+        const int64_t nch = (nb + 15) >> 4;
+        const int g = (int)std::min<int64_t>((nch + 255) / 256, 256 * 32);
+        uint8_t *qd = h->d_quals.as<uint8_t>() + BASE_FRONT_PAD;
+        if (h->raw_qbits == 2) CRUMBLE_LAUNCH_INDEP((k_p0_quals<2>), g, 256, st, nb, h->d_qualsp.as<uint8_t>(), l[0], l[1], l[2], l[3], qd);
+        else                   CRUMBLE_LAUNCH_INDEP((k_p0_quals<4>), g, 256, st, nb, h->d_qualsp.as<uint8_t>(), l[0], l[1], l[2], l[3], qd);
+    }
     /* 1. classify + validate + count */
     const int nblocks = (int)((n + P0_CHUNK - 1) / P0_CHUNK);
     if ((e = h->d_inplp.reserve((size_t)(n + 1))) || (e = h->d_end.reserve((size_t)(n + 1) * 4)) ||

@@ -2381,8 +2381,17 @@ __device__ __forceinline__ void hist_flush(unsigned *h, u64 *stats, unsigned cha
 }
 
 #define PB4(x)       ((uint32_t)(x) * 0x01010101u)
-#define PB_GE(a, b)  ((((((a) | 0x80808080u) - (b)) & 0x80808080u) >> 7) * 0xffu)    /* bytes where a >= b (a, b < 128) */
-#define PB_NZ(x)     (((((x) + 0x7f7f7f7fu) & 0x80808080u) >> 7) * 0xffu)             /* bytes where x != 0 (x < 128)    */
+/* Packed-byte flags live in bit 7 of each byte; a full 0x00 / 0xff byte mask is made from them by ONE v_perm_b32 whose
+ * selector bytes are 0x0c (constant 0x00) or 0x0d (constant 0xff), and a per-byte choice between two words by one v_perm_b32
+ * whose selector bytes are i (byte i of b) or 4 + i (byte i of a).  (Round 5: the `* 0xff` of the rounds before is a
+ * v_mul_lo_u32 -- quarter rate -- and k_replay_fast issued forty of them per sixteen bases.) */
+__device__ __forceinline__ uint32_t pb_full7(uint32_t f) { return kc2_perm(0u, 0u, ((f >> 7) & 0x01010101u) | 0x0c0c0c0cu); }
+__device__ __forceinline__ uint32_t pb_sel7(uint32_t f, uint32_t a, uint32_t b) { return kc2_perm(a, b, ((f >> 5) & 0x04040404u) | 0x03020100u); }
+#define PB_GE(a, b)  pb_full7(((a) | 0x80808080u) - (b))     /* bytes where a >= b (a, b < 128) */
+#define PB_NZ(x)     pb_full7((x) + 0x7f7f7f7fu)             /* bytes where x != 0 (x < 128)    */
+/* the four-byte mask of the four bits of x: the bits spread to bit 0 of each byte (24-bit multiply: full rate), then the
+ * 0x0c / 0x0d selector */
+__device__ __forceinline__ uint32_t pb_nib(uint32_t x) { return kc2_perm(0u, 0u, (((x & 15u) * 0x00204081u) & 0x01010101u) | 0x0c0c0c0cu); }
 #define ACT_PAD 64   /* bytes in front of act[0]: a chunk may start up to 15 columns before the read */
 
 /* the owner of a byte range: a read (short-read batches: ReadRec) or a territory of a read (long-read batches:
@@ -2407,8 +2416,13 @@ template <> struct RfSel<true> { typedef VRec T; static __device__ __forceinline
  * k_replay_slow.  The two values nearly every output byte has (qhigh, qlow) are counted with packed compares and
  * popcounts into registers; only the other bytes go through LDS atomics.  It is also the pass that looks at every
  * INPUT quality: a value >= 128 raises *bad_qual.  Persistent: the grid strides over the chunks. */
+#ifndef RF_WAVES
+#define RF_ATTR
+#else
+#define RF_ATTR __attribute__((amdgpu_waves_per_eu(RF_WAVES, RF_WAVES)))
+#endif
 template <bool VREC, bool PV, bool STATS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) RF_ATTR
 k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restrict__ colrec,
               const uint8_t *__restrict__ act, const int32_t *__restrict__ chunk_read,
               uint8_t *__restrict__ out, const uint32_t *__restrict__ forcebits,
@@ -2446,8 +2460,7 @@ k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
                 PV1 |= eq;
                 if (P->pv_lvl[i] > 1) PV2 |= eq;
             }
-        const uint32_t geq = PB_GE(q, QC) & ~PV1;
-        capw[k] = (QC & geq) | (q & ~geq);
+        capw[k] = pb_sel7((((q | 0x80808080u) - QC) & ~PV1), QC, q);
         pv1w[k] = PV1; pv2w[k] = PV2;
     }
     int64_t r = chunk_read[g0 >> 4];                          /* the owner of byte g0 (table built with the batch) */
@@ -2489,39 +2502,36 @@ k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
         }
         if (ns) {
             uint32_t a[4], a2[4] = {0, 0, 0, 0};
-            #define LOAD_ACT16(dst, col) do {   /* 16 action bytes from an arbitrary byte address: aligned dwords + byte funnel */ \
+            #define LOAD_ACT16(dst, col) do {   /* 16 action bytes from an arbitrary byte address: aligned dwords + v_alignbyte */ \
                 const uint8_t *ap_ = act + (col); \
-                const unsigned sh_ = (unsigned)((uintptr_t)ap_ & 3u), s8_ = sh_ * 8u; \
+                const unsigned sh_ = (unsigned)((uintptr_t)ap_ & 3u); \
                 const uint32_t *aw_ = (const uint32_t *)(ap_ - sh_); \
                 const uint32_t w0_ = aw_[0], w1_ = aw_[1], w2_ = aw_[2], w3_ = aw_[3], w4_ = aw_[4]; \
-                dst[0] = sh_ ? (w0_ >> s8_) | (w1_ << (32u - s8_)) : w0_; \
-                dst[1] = sh_ ? (w1_ >> s8_) | (w2_ << (32u - s8_)) : w1_; \
-                dst[2] = sh_ ? (w2_ >> s8_) | (w3_ << (32u - s8_)) : w2_; \
-                dst[3] = sh_ ? (w3_ >> s8_) | (w4_ << (32u - s8_)) : w3_; } while (0)
+                dst[0] = kc2_alignbyte(w1_, w0_, sh_); dst[1] = kc2_alignbyte(w2_, w1_, sh_); \
+                dst[2] = kc2_alignbyte(w3_, w2_, sh_); dst[3] = kc2_alignbyte(w4_, w3_, sh_); } while (0)
             LOAD_ACT16(a, c0s[0]);
             if (ns > 1) LOAD_ACT16(a2, c0s[1]);
             #undef LOAD_ACT16
             #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t q = qw[k], b = bw[k];
-                const uint32_t V1 = ((((vb[0] >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;   /* first read's bytes  */
-                const uint32_t V2 = ((((vb[1] >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;   /* second read's bytes */
-                const uint32_t V = V1 | V2;
+                const uint32_t V1 = pb_nib(vb[0] >> (4 * k)), V2 = pb_nib(vb[1] >> (4 * k)), V = V1 | V2;   /* the first / second read's bytes */
                 const uint32_t ac = (a[k] & V1) | (a2[k] & V2);
                 const uint32_t hm = (hms[0] & V1) | (hms[1] & V2);
                 const uint32_t PV1 = pv1w[k], PV2 = pv2w[k], capq = capw[k];      /* -k / -K: bytes of a preserved quality; cap_quality */
+                /* (flags: bit 7 of each byte) */
                 const uint32_t hit = b & ac & 0x0f0f0f0fu;                          /* base shares a bit with a called allele */
                 const uint32_t many = b & ((b | 0x80808080u) - 0x01010101u) & 0x0f0f0f0fu;   /* >= 2 bits: never equals a call */
-                const uint32_t M = PB_NZ(hit) & ~PB_NZ(many);                       /* base == call1 || base == call2 (snp:1908) */
+                const uint32_t fM = (hit + 0x7f7f7f7fu) & ~(many + 0x7f7f7f7fu);   /* base == call1 || base == call2 (snp:1908) */
                 uint32_t nm = q;
                 if (reduce) {
-                    if (binary) { const uint32_t gc = PB_GE(q, CUT); nm = (QH & gc) | (QL & ~gc); }   /* bin2[], no -K here */
+                    if (binary) nm = pb_sel7((q | 0x80808080u) - CUT, QH, QL);     /* bin2[], no -K here */
                     else nm = QL;
                 }
-                const uint32_t qz = (QH & M) | (nm & ~M);
-                const uint32_t U = (((ac >> 4) & 0x01010101u) * 0xffu) | hm | PV2 | (PV1 & ~(((ac >> 7) & 0x01010101u) * 0xffu));   /* snp:1885 */
-                const uint32_t W = ((ac >> 5) & 0x01010101u) * 0xffu;
-                const uint32_t v = ((capq & W) | (~W & ((q & U) | (qz & ~U)))) & 0x7f7f7f7fu;
+                const uint32_t qz = pb_sel7(fM, QH, nm);
+                uint32_t fU = (ac << 3) | hm;                                       /* snp:1885 */
+                if (PV) fU |= PV2 | (PV1 & ~ac);
+                const uint32_t v = pb_sel7(ac << 2, capq, pb_sel7(fU, q, qz)) & 0x7f7f7f7fu;      /* window columns: the capped original */
                 ow[k] = (v & V) | (ow[k] & ~V);
             }
         }
@@ -2531,7 +2541,7 @@ k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
     if (cq) {
         #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t C = ((((cq >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;
+            const uint32_t C = pb_nib(cq >> (4 * k));
             ow[k] = (capw[k] & 0x7f7f7f7fu & C) | (ow[k] & ~C);
         }
     }
@@ -2542,7 +2552,7 @@ k_replay_fast(DBatch B, const DParams *__restrict__ P, const uint32_t *__restric
         valid &= ~genb;
         #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t Vm = ((((valid >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u) * 0x80u;       /* bit 7 of the bytes counted here */
+            const uint32_t Vm = ((((valid >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u) << 7;            /* bit 7 of the bytes counted here */
             const uint32_t o = ow[k], q = qw[k] & 0x7f7f7f7fu;
             const uint32_t eh = ~((o ^ QH) + 0x7f7f7f7fu) & Vm;                                             /* bytes equal to qhigh: (x + 0x7f) has bit 7 clear iff x == 0 */
             const uint32_t el = ~((o ^ QL) + 0x7f7f7f7fu) & Vm & ~eh;
@@ -2671,8 +2681,6 @@ k_replay_reads(DBatch B, const DParams *__restrict__ P, const uint32_t *__restri
     }
 }
 #undef PB4
-#undef PB_GE
-#undef PB_NZ
 
 /* the bases that D/N columns report (list built with the batch), after the chunk kernels.  forcebits (packed replay):
  * a kept read's byte and a back-fill's are the capped original whatever the columns say; STATS: the byte was
@@ -3144,7 +3152,6 @@ k_pb_segments(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_
                     mn[t] = (wd[t] & M) | (~M & 0x7f7f7f7fu);
                     mx[t] = wd[t] & M;
                 }
-                #define PB_GE(a, b) (((((a) | 0x80808080u) - (b)) & 0x80808080u) >> 7) * 0xffu
                 #define PB_MIN(a, b, m) (((b) & (m)) | ((a) & ~(m)))       /* m = bytes where a >= b */
                 #define PB_MAX(a, b, m) (((a) & (m)) | ((b) & ~(m)))
                 uint32_t g01 = PB_GE(mn[0], mn[1]), g23 = PB_GE(mn[2], mn[3]);
@@ -3155,7 +3162,6 @@ k_pb_segments(int64_t n_bases, int64_t n_reads, const int64_t *__restrict__ seq_
                 a = PB_MAX(mx[0], mx[1], g01); b2 = PB_MAX(mx[2], mx[3], g23);
                 gab = PB_GE(a, b2);
                 const uint32_t x4 = PB_MAX(a, b2, gab);
-                #undef PB_GE
                 #undef PB_MIN
                 #undef PB_MAX
                 int cmin = (int)(m4 & 255), cmax = (int)(x4 & 255);

@@ -944,4 +944,39 @@ k_p0_len_apply(int64_t n, const int32_t *__restrict__ lq, const uint16_t *__rest
     }
 }
 
+/* ---- k_p0_quals: the coded qualities of an upload (crumble_batch.qualsp: 2 or 4 bits per base into a table of up to
+ * sixteen values) -> one byte per base, the form every other kernel reads.  Sixteen bases per thread: 4 or 8 bytes in, 16 out
+ * (1.25-1.5 B per base of HBM traffic for 0.5-0.75 B per base less over PCIe).  The table lives in four registers and a
+ * v_perm_b32 whose selector IS the codes picks four values at once. */
+template <int BITS>
+__global__ void __launch_bounds__(256)
+k_p0_quals(int64_t nb, const uint8_t *__restrict__ qp, uint32_t l0, uint32_t l1, uint32_t l2, uint32_t l3, uint8_t *__restrict__ quals)
+{
+    const int64_t nch = (nb + 15) >> 4;
+    for (int64_t ch = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ch < nch; ch += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t o[4];
+        if (BITS == 2) {
+            const uint32_t w = *(const uint32_t *)(qp + ch * 4);             /* (the array carries slack) */
+            #pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t t = (w >> (8 * k)) & 255u;                     /* four codes: one per byte, 0..3 = bytes of l0 */
+                o[k] = kc2_perm(0u, l0, (t | (t << 6) | (t << 12) | (t << 18)) & 0x03030303u);
+            }
+        } else {
+            const uint2 w2 = *(const uint2 *)(qp + ch * 8);
+            #pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t t = ((k < 2 ? w2.x : w2.y) >> (16 * (k & 1))) & 0xffffu;      /* four codes of four bits */
+                const uint32_t x = (t | (t << 8)) & 0x00ff00ffu;
+                const uint32_t c = (x | (x << 4)) & 0x0f0f0f0fu;                             /* one per byte */
+                const uint32_t sel = c & 0x07070707u;
+                const uint32_t lo = kc2_perm(l1, l0, sel), hi = kc2_perm(l3, l2, sel);
+                o[k] = kc2_perm(hi, lo, ((c >> 1) & 0x04040404u) | 0x03020100u);           /* code >= 8: the upper half of the table */
+            }
+        }
+        uint4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
+        *(uint4 *)(quals + ch * 16) = v;                                      /* (up to 15 bytes of slack behind the last base) */
+    }
+}
+
 #endif

@@ -189,6 +189,77 @@ void crumble_pack_bases4(int64_t n_reads, const int64_t *seq_off, const uint8_t 
     team_run_once(host_threads_(), n_reads, 4096, 0, pack4_reads, &j);
 }
 
+/* ---- coded upload, host side (include/crumble_hip.h, crumble_batch.qualsp): quality bytes -> 2- or 4-bit codes --- */
+typedef struct { const uint8_t *q; int64_t n; unsigned char (*seen)[256]; } qseen_job;
+static void qseen_piece(void *ctx, int64_t lo, int64_t hi, int tid)
+{
+    qseen_job *j = (qseen_job *)ctx;
+    unsigned char *s = j->seen[tid];
+    const uint8_t *q = j->q;
+    int64_t i = lo;
+    for (; i + 8 <= hi; i += 8) {                                      /* which byte values occur: a store per byte, no branch */
+        s[q[i]] = 1; s[q[i + 1]] = 1; s[q[i + 2]] = 1; s[q[i + 3]] = 1;
+        s[q[i + 4]] = 1; s[q[i + 5]] = 1; s[q[i + 6]] = 1; s[q[i + 7]] = 1;
+    }
+    for (; i < hi; i++) s[q[i]] = 1;
+}
+/* two quality bytes -> their two codes (code of the first | code of the second << bits): one look-up per pair */
+typedef struct { const uint8_t *q; uint8_t *out; int64_t n; int bits; uint8_t map[256]; uint8_t *pair; } qpack_job;
+static void qpack_piece(void *ctx, int64_t lo, int64_t hi, int tid)      /* [lo, hi): output BYTES */
+{
+    qpack_job *j = (qpack_job *)ctx;
+    (void)tid;
+    const uint8_t *q = j->q, *pair = j->pair;
+    const int per = 8 / j->bits;                                          /* bases per output byte */
+    int64_t full = j->n / per;
+    if (full > hi) full = hi;
+    if (j->bits == 2)
+        for (int64_t o = lo; o < full; o++) {
+            const uint8_t *x = q + 4 * o;
+            j->out[o] = (uint8_t)(pair[x[0] | ((unsigned)x[1] << 8)] | (pair[x[2] | ((unsigned)x[3] << 8)] << 4));
+        }
+    else
+        for (int64_t o = lo; o < full; o++) {
+            const uint8_t *x = q + 2 * o;
+            j->out[o] = pair[x[0] | ((unsigned)x[1] << 8)];
+        }
+    for (int64_t o = full > lo ? full : lo; o < hi; o++) {                /* the last, partial byte */
+        unsigned b = 0;
+        for (int k = 0; k < per && per * o + k < j->n; k++) b |= (unsigned)j->map[q[per * o + k]] << (j->bits * k);
+        j->out[o] = (uint8_t)b;
+    }
+}
+int crumble_pack_quals(int64_t n_bases, const uint8_t *quals, uint8_t *out, uint8_t lut[16])
+{
+    memset(lut, 0, 16);
+    if (n_bases <= 0) { memset(out, 0, 16); return 2; }
+    const int nt = host_threads_();
+    unsigned char (*seen)[256] = calloc((size_t)(nt > 0 ? nt : 1) + 1, 256);
+    if (!seen) return 0;
+    qseen_job sj = { quals, n_bases, seen };
+    team_run_once(nt, n_bases, 1 << 16, 1 << 20, qseen_piece, &sj);
+    int nv = 0;
+    qpack_job pj;
+    memset(pj.map, 0, sizeof pj.map);
+    for (int v = 0; v < 256; v++) {
+        int any = 0;
+        for (int t = 0; t <= (nt > 0 ? nt : 1); t++) any |= seen[t][v];
+        if (any) { if (nv < 16) { lut[nv] = (uint8_t)v; pj.map[v] = (uint8_t)nv; } nv++; }
+    }
+    free(seen);
+    if (nv > 16) return 0;
+    pj.q = quals; pj.out = out; pj.n = n_bases; pj.bits = nv <= 4 ? 2 : 4;
+    pj.pair = malloc(65536);
+    if (!pj.pair) return 0;
+    for (int b1 = 0; b1 < nv; b1++)                                    /* (only pairs of values that occur are ever looked up) */
+        for (int b0 = 0; b0 < nv; b0++) pj.pair[lut[b0] | ((unsigned)lut[b1] << 8)] = (uint8_t)(b0 | (b1 << pj.bits));
+    const int64_t nbytes = (n_bases * pj.bits + 7) / 8;
+    team_run_once(nt, nbytes, 1 << 16, 1 << 20, qpack_piece, &pj);
+    free(pj.pair);
+    memset(out + nbytes, 0, 16);
+    return pj.bits;
+}
+
 /* ---- coded download, host side (include/crumble_hip.h): 2 bits per base -> quality bytes -------------------- */
 void crumble_decode_seek(const crumble_coded *c, int64_t base, crumble_decode_cursor *cur)
 {

@@ -116,7 +116,7 @@ EXPORTED = [
     "crumble_params_keep_quals", "crumble_init_bins", "crumble_bed_collapse",
     "crumble_hip_create", "crumble_hip_destroy", "crumble_hip_set_option", "crumble_hip_contig", "crumble_hip_contig_run",
     "crumble_hip_upload", "crumble_hip_expand", "crumble_hip_run", "crumble_hip_download",
-    "crumble_hip_encode", "crumble_hip_download_coded", "crumble_decode_seek", "crumble_decode_run", "crumble_decode_quals",
+    "crumble_pack_bases4", "crumble_pack_quals", "crumble_hip_encode", "crumble_hip_download_coded", "crumble_decode_seek", "crumble_decode_run", "crumble_decode_quals",
     "crumble_hip_set_window", "crumble_carry_init", "crumble_hip_run_columns", "crumble_hip_run_depth",
     "crumble_hip_run_triggers", "crumble_hip_run_fold", "crumble_hip_run_finish",
     "crumble_hip_kernel_times", "crumble_hip_upload_times", "crumble_hip_transfer_bytes", "crumble_hip_stats_devptr", "crumble_hip_stats_reset",

@@ -131,7 +131,21 @@ typedef struct crumble_batch {
     const int32_t  *l_qseq;
     const uint16_t *n_cigar;
     int64_t  n_bases, n_cigar_ops;
+    /* Optional, INSTEAD of quals (then quals may be NULL): the qualities as codes of qual_bits (2 or 4) bits each into
+     * qual_lut (quality of base i = qual_lut[code i]; code i sits in byte i * qual_bits / 8 of qualsp at bit
+     * (i * qual_bits) % 8, counted over ALL bases of the batch, not per read; CRUMBLE_QUALSP_SIZE bytes).  What binned
+     * instruments write (four or eight distinct values) then crosses PCIe as 0.25 / 0.5 bytes per base instead of 1;
+     * the device makes the one-byte form while it expands the batch (k_p0_quals).  crumble_pack_quals() makes the codes
+     * and says when a batch has too many distinct values for them.  qual_bits == 0: quals is used. */
+    const uint8_t  *qualsp;
+    int32_t  qual_bits;
+    uint8_t  qual_lut[16];
 } crumble_batch;
+#define CRUMBLE_QUALSP_SIZE(n_bases, bits)    (((int64_t)(n_bases) * (bits) + 7) / 8 + 16)
+/* quals (one byte per base) -> the coded form above.  Returns 2 or 4 (the code width; lut filled, out written:
+ * CRUMBLE_QUALSP_SIZE(n_bases, 4) bytes are enough for either) or 0 when the batch holds more than sixteen distinct
+ * values (out unspecified: hand over quals).  Host helper (a team of host threads). */
+int crumble_pack_quals(int64_t n_bases, const uint8_t *quals, uint8_t *out, uint8_t lut[16]);
 #define CRUMBLE_BASES4_OFF(seq_off_i, i)      (((int64_t)(seq_off_i) >> 1) + (int64_t)(i))
 #define CRUMBLE_BASES4_SIZE(n_bases, n_reads) (((int64_t)(n_bases) >> 1) + (int64_t)(n_reads) + 1)
 /* bases (one code per byte) -> the bases4 layout above; out has CRUMBLE_BASES4_SIZE bytes.  Host helper (a team of host threads). */

@@ -312,6 +312,62 @@ def test_emu_packed_bases(product):
     e.close()
 
 
+def test_emu_coded_qualities(product):
+    """crumble_batch.qualsp (2- or 4-bit codes into a table of at most sixteen qualities, made by crumble_pack_quals, expanded on
+    the device by k_p0_quals) gives what the one-byte-per-quality form gives: four values (2 bits), eight and sixteen (4 bits),
+    one value, lengths that are not a multiple of four / sixteen, an empty batch; seventeen values keep the bytes; the bytes
+    that cross shrink accordingly; a table entry >= 128 is the same error as such a byte."""
+    import copy
+    L = emu_lib.load()
+    rng = np.random.default_rng(5)
+    def with_values(hb, vals):
+        hb = copy.copy(hb)
+        hb.quals = np.asarray(vals, np.uint8)[rng.integers(0, len(vals), hb.n_bases)]
+        return hb
+    base = synth_batch("chr20", 0.0002)
+    tiny = HostBatch.from_reads([dict(pos=10, cigar="1M", seq="A", qual=[30]), dict(pos=10, cigar="*", seq="", qual=[]),
+                                 dict(pos=11, cigar="3M", seq="ACG", qual=[30, 31, 2]), dict(pos=12, cigar="2M1I2M", seq="NACGT", qual=20),
+                                 dict(pos=12, cigar="7M", seq="ACGTACG", qual=33)])
+    empty = HostBatch.from_reads([])
+    cases = [(base, 2), (with_values(base, [3, 9, 17, 22, 27, 33, 38, 41]), 4), (with_values(base, list(range(20, 36))), 4),
+             (with_values(base, [30]), 2), (with_values(base, [0, 93]), 2), (tiny, 4), (empty, 2),
+             (synth_batch("hifi", 0.0001, read_len=3001), 0), (with_values(base, list(range(20, 37))), 0)]
+    for preset in (5, 9):
+        p = ca.preset_params(preset)
+        for hb, bits in cases:
+            e = emu_lib.engine(p)
+            want = e.contig(hb)
+            up_plain = e.transfer_bytes()[0]
+            hq = copy.copy(hb).packq(L)
+            st = hq.struct()
+            if bits == 0:
+                assert getattr(hq, "qualsp", None) is None and st.quals and not st.qualsp
+                e.close()
+                continue
+            assert st.quals is None and st.qualsp and st.qual_bits == bits, (st.qual_bits, bits)
+            assert sorted(set(hq.qual_lut[:len(set(hb.quals.tolist()))].tolist())) == sorted(set(hb.quals.tolist()))
+            got = e.contig(hq)
+            assert all(np.array_equal(x, y) for x, y in zip(got, want))
+            assert e.transfer_bytes()[0] == up_plain - hb.n_bases + (hb.n_bases * bits + 7) // 8
+            # ... together with BAM's packed bases and per-read lengths: what a reader hands over
+            got = e.contig(copy.copy(hq).pack4(L).lens())
+            assert all(np.array_equal(x, y) for x, y in zip(got, want))
+            e.close()
+    # a table entry >= 128: reported like a quality byte >= 128 (SURVEY.md Q13), by the run
+    hq = copy.copy(base).packq(L)
+    hq.qual_lut = hq.qual_lut.copy(); hq.qual_lut[1] = 200
+    e = emu_lib.engine(ca.preset_params(5))
+    with pytest.raises(ca.CrumbleError) as ei:
+        e.contig(hq)
+    assert ei.value.code == -1
+    # a code width other than 2 / 4 is refused at upload
+    hq = copy.copy(base).packq(L)
+    hq.qual_bits = 3
+    with pytest.raises(ca.CrumbleError):
+        e.contig(hq)
+    e.close()
+
+
 def test_emu_staged_download(product):
     """crumble_hip_download through the page-locked staging lanes (8 host threads, double-buffered chunks): with the
     chunk shrunk so that this batch is hundreds of chunks -- whole chunks, a ragged last one, more lanes than chunks --

@@ -1,6 +1,7 @@
 """Randomised parity: random option sets x random synthetic alignments, engine == oracle bit for bit
 (quality bytes, per-read flags, statistics, column records).  CPU tier: the emulated kernels on a
 few seeds; GPU tier: the real build on many."""
+import numpy as np
 import pytest
 
 import crumble_amd as ca
@@ -18,6 +19,11 @@ def test_fuzz_emulated(product, seed):
         hb.pack4(emu_lib.load())                 # the bases as BAM packs them (k_p0_bases<PACKED>) ...
     if seed % 4 >= 2:
         hb.lens()                                # ... BAM's per-read lengths instead of the offset tables
+    if seed % 3 == 1:                            # ... qualities of a binned instrument, sent as 2- / 4-bit codes (k_p0_quals)
+        import numpy as np
+        vals = np.array([2, 11, 25, 37, 6, 15, 22, 27, 33, 40, 41, 8, 30, 19, 35, 39], np.uint8)[:(4, 8, 16, 3)[(seed // 3) % 4]]
+        hb.quals = vals[hb.quals % len(vals)]
+        hb.packq(emu_lib.load())
     # every column kernel, whatever the batch; the run's fast way, the careful one, and an aborted fast attempt
     # ... and, on every fourth seed, the byte-wise replay (k_replay_flat + k_restore / k_readfix / k_keepfix behind it)
     assert_parity(emu_lib.with_options(kcol=KCOL_VARIANTS[seed % 3], run=("fast", "careful")[(seed // 3) % 2], caps=(0, 0, 2)[seed % 3],
@@ -34,6 +40,10 @@ def test_fuzz_gpu(product, block):
             hb.pack4(ca.lib())                   # the bases as BAM packs them (k_p0_bases<PACKED>) ...
         if seed % 4 >= 2:
             hb.lens()                            # ... BAM's per-read lengths instead of the offset tables
+        if seed % 3 == 1:                        # ... qualities of a binned instrument, sent as 2- / 4-bit codes (k_p0_quals)
+            vals = np.array([2, 11, 25, 37, 6, 15, 22, 27, 33, 40, 41, 8, 30, 19, 35, 39], np.uint8)[:(4, 8, 16, 3)[(seed // 3) % 4]]
+            hb.quals = vals[hb.quals % len(vals)]
+            hb.packq(ca.lib())
         kcol = KCOL_VARIANTS[seed % 3] if seed % 4 else "auto"      # every column kernel, whatever the batch
         try:
             opts = {"kcol": kcol, "run": ("fast", "fast", "careful")[seed % 3], "caps": (0, 0, 0, 0, 5)[seed % 5],

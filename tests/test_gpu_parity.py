@@ -376,8 +376,33 @@ def test_bench_other_configs_small(product):
     assert w["verified_smallest_contig"] and 0 < w["overlap_wall_over_sum_of_stages"] <= 1.05
     assert set(w["stages_ms"]) == {"h2d_and_p0", "kernels", "d2h", "host_decode"}
     assert w["pcie_bytes_per_base"]["out"] < 0.5 < w["pcie_bytes_per_base"]["in"] < 2.0      # the coded download, the packed upload
-    w = bench.measure_wgs_streamed(ca, synth, shard, 0.0008, 0, coded=False)
+    w = bench.measure_wgs_streamed(ca, synth, shard, 0.0008, 0, coded_in=True)                # ... and the qualities as codes, packed inside the clock
+    assert w["verified_smallest_contig"] and set(w["stages_ms"]) == {"h2d_and_p0", "kernels", "d2h", "host_decode", "host_pack"}
+    assert w["pcie_bytes_per_base"]["out"] < 0.5 < w["pcie_bytes_per_base"]["in"] < 1.0
+    w = bench.measure_wgs_streamed(ca, synth, shard, 0.0008, 0, coded=False, coded_in=False)
     assert w["verified_smallest_contig"] and set(w["stages_ms"]) == {"h2d_and_p0", "kernels", "d2h"} and w["pcie_bytes_per_base"]["out"] >= 1.0
+    assert 1.5 < w["pcie_bytes_per_base"]["in"] < 2.0                                          # one byte per quality
+
+
+def test_coded_qualities_gpu(product):
+    """crumble_batch.qualsp on the GPU (k_p0_quals<2> / <4>): the oracle's bytes, flags and statistics, as for the byte form."""
+    import copy
+    import oracle_lib as O
+    rng = np.random.default_rng(11)
+    a = synth_batch("chr20", 0.01)
+    b = copy.copy(a)
+    b.quals = np.array([3, 9, 17, 22, 27, 33, 38, 41, 12, 13], np.uint8)[rng.integers(0, 10, a.n_bases)]
+    for preset, hb, bits in ((5, a, 2), (9, a, 2), (5, b, 4), (9, b, 4)):
+        p = ca.preset_params(preset)
+        want = O.contig(p, hb)
+        hq = copy.copy(hb).pack4(ca.lib()).lens().packq(ca.lib())
+        assert hq.qual_bits == bits and hq.struct().quals is None
+        eng = gpu_engine(p)
+        got = eng.contig(hq)
+        assert all(np.array_equal(x, y) for x, y in zip(got, want))
+        up = eng.transfer_bytes()[0]
+        assert up < hb.n_bases * (0.5 + bits / 8.0 + 0.2)
+        eng.close()
 
 
 def test_find_str_stress(product):

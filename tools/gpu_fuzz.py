@@ -20,6 +20,11 @@ for seed in range(s0, s0 + n):
         hb.pack4(ca.lib())                                      # the bases as BAM packs them (crumble_batch.bases4)
     if seed % 4 >= 2:
         hb.lens()                                               # BAM's per-read lengths instead of the offset tables
+    if seed % 3 == 1:                                           # qualities of a binned instrument, sent as 2- / 4-bit codes (k_p0_quals)
+        import numpy as np
+        vals = np.array([2, 11, 25, 37, 6, 15, 22, 27, 33, 40, 41, 8, 30, 19, 35, 39], np.uint8)[:(4, 8, 16, 3)[(seed // 3) % 4]]
+        hb.quals = vals[hb.quals % len(vals)]
+        hb.packq(ca.lib())
     try:
         assert_parity(lambda q: ca.Engine(q, 0, options=opts), p, hb)
         if seed % 10 == 0:
