@@ -391,7 +391,9 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=4,
             batches[-1].pack4(ca.lib()).lens()      # bases as BAM packs them, BAM's per-read lengths: what crumble-hip sends
     t_gen = time.time() - t0
     params = ca.preset_params(preset)
-    engines = [ca.Engine(params, device) for _ in range(n_engines)]
+    n_engines = int(os.environ.get("CRUMBLE_BENCH_STREAM_ENGINES", n_engines))
+    eopts = {"dl_kernel": os.environ["CRUMBLE_BENCH_DL_KERNEL"]} if os.environ.get("CRUMBLE_BENCH_DL_KERNEL") else None
+    engines = [ca.Engine(params, device, options=eopts) for _ in range(n_engines)]
     # what crosses PCIe lives in page-locked host memory (crumble_hip_host_alloc), as a host that keeps its buffers would
     # hold it: the batches' arrays (copied there once, before the clock) and one output buffer pair per engine
     pins = []
@@ -425,6 +427,7 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=4,
     if coded_in:
         ca.lib().crumble_pack_quals.restype = C_.c_int
         ca.lib().crumble_pack_quals.argtypes = [C_.c_int64, C_.c_void_p, C_.c_void_p, C_.c_void_p]
+    split_upload = hasattr(engines[0], "upload_raw") and os.environ.get("CRUMBLE_BENCH_STREAM_SPLIT", "1") == "1"
     xfer = [0, 0]
     k_small = int(np.argmin([b_.n_bases for b_ in batches]))
     kept = {}
@@ -469,7 +472,9 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=4,
                         if i is None:
                             break
                         e = free_q.get()
-                        t = time.perf_counter(); e.upload(batches[i]); dt = time.perf_counter() - t
+                        # the copy alone (crumble_hip_upload_raw returns when the arrays are on the device): the expansion is
+                        # the next stage's, so that the link goes straight on with the next contig
+                        t = time.perf_counter(); (e.upload_raw if split_upload else e.upload)(batches[i]); dt = time.perf_counter() - t
                         with up_lock:
                             t_stage[0] += dt
                         run_q.put((i, e))
@@ -487,7 +492,11 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=4,
                         it = run_q.get()
                         if it is None:
                             break
-                        t = time.perf_counter(); it[1].run(); t_stage[1] += time.perf_counter() - t
+                        t = time.perf_counter()
+                        if split_upload:
+                            it[1].expand()
+                        it[1].run()
+                        t_stage[1] += time.perf_counter() - t
                         dl_q.put(it)
                 except Exception as ex:            # noqa: BLE001
                     err.append(ex)
@@ -562,7 +571,7 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=4,
             "workload": f"wgs-30x: 24 synthetic contigs (GRCh38 lengths x {scale}), {total} bases, -{preset}, streamed through "
                         f"{n_engines} engines on one GPU ({'host packing || ' if coded_in else ''}{n_uploaders} uploads || kernels || download || host expansion)",
             "value_incl_pcie": round(total / wall / 1e9, 3), "unit": "Gbases/s", "ms_per_pass": round(wall * 1e3, 2),
-            "stages_ms": {"h2d_and_p0": round(st[0] * 1e3, 2), "kernels": round(st[1] * 1e3, 2), "d2h": round(st[2] * 1e3, 2),
+            "stages_ms": {("h2d" if split_upload else "h2d_and_p0"): round(st[0] * 1e3, 2), ("p0_and_kernels" if split_upload else "kernels"): round(st[1] * 1e3, 2), "d2h": round(st[2] * 1e3, 2),
                           **({"host_decode": round(st[3] * 1e3, 2)} if coded else {}), **({"host_pack": round(st[4] * 1e3, 2)} if coded_in else {})},
             "upload": ("coded qualities: 2 / 4 bits per base into a table of the batch's values (crumble_pack_quals on the host's threads, "
                        "a stage inside the clock; expanded on the device by k_p0_quals), BAM-packed bases, per-read lengths"

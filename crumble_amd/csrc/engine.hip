@@ -131,6 +131,8 @@ struct crumble_hip {
     bool dl_ok = false;
     size_t dl_bufsz = 0;            /* size of each staging buffer */
     size_t dl_chunk = (size_t)8 << 20;
+    int opt_dl_kernel = 1;          /* "dl_kernel": a page-locked destination is written by k_d2h_store (the GPU's own stores over the link)
+                                     * instead of a copy-engine transfer that queues behind the uploads of the other handles */
     bool packed_ok = false;         /* the packed replay's value formulas hold for these parameters (set at create) */
     bool have_vrec = false;         /* long-read batch: territories + chunk table built (k_p0_vrecs) */
     bool batch_flat = false;        /* "replay" = flat as it stood when the batch was uploaded (decides which tables exist) */
@@ -378,6 +380,10 @@ extern "C" int crumble_hip_set_option(crumble_hip *h, const char *name, const ch
         static const char *const nm[] = {"off", "on"};
         if ((v = pick(nm, 2)) < 0) return CRUMBLE_EINVAL;
         h->opt_stages = v;
+    } else if (!strcmp(name, "dl_kernel")) {                /* page-locked destinations: written by a kernel instead of the copy engine */
+        static const char *const nm[] = {"off", "on"};
+        if ((v = pick(nm, 2)) < 0) return CRUMBLE_EINVAL;
+        h->opt_dl_kernel = v;
     } else if (!strcmp(name, "dl_chunk")) {                 /* bytes per staged download copy (tests shrink it) */
         const long long c = atoll(value);
         if (c < 256 || c > (long long)DL_CHUNK) return CRUMBLE_EINVAL;
@@ -786,6 +792,21 @@ extern "C" int crumble_hip_upload(crumble_hip *h, const crumble_batch *b)
     int e;
     if ((e = copy_raw(h, b))) return e;
     return expand(h, true);
+}
+
+/* the copy half alone: returns when the raw arrays are on the device (the link is free for the next batch's copy while
+ * this one's expansion -- crumble_hip_expand -- and run wait their turn on the GPU) */
+extern "C" int crumble_hip_upload_raw(crumble_hip *h, const crumble_batch *b)
+{
+    if (!h || !b || b->n_reads < 0) return CRUMBLE_EINVAL;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventRecord(h->ev_up[0], h->stream));
+    int e;
+    if ((e = copy_raw(h, b))) return e;
+    HIPCHK(hipEventSynchronize(h->ev_up[1]));
+    HIPCHK(hipEventElapsedTime(&h->up_h2d_ms, h->ev_up[0], h->ev_up[1]));
+    h->up_p0_ms = 0;
+    return CRUMBLE_OK;
 }
 
 extern "C" int crumble_hip_expand(crumble_hip *h)
@@ -1336,6 +1357,14 @@ extern "C" int crumble_hip_run(crumble_hip *h)
  * staging path (measured 14-15 GB/s on the MI355X box: 134 ms for chr20's 1.9 GB).  Here DL_LANES host threads take a
  * slice of the range each: asynchronous copies into the thread's two page-locked buffers on its own stream (several
  * SDMA engines at once), and while a chunk is in flight the thread copies the previous one on to the caller's memory. */
+#ifndef CRUMBLE_EMU
+/* device -> page-locked host memory by the GPU's own stores (posted writes over the link): sixteen bytes per lane */
+__global__ void __launch_bounds__(256) k_d2h_store(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+#endif
 static int staged_d2h(crumble_hip *h, uint8_t *dst, const uint8_t *src, size_t bytes)
 {
     const size_t CH = h->dl_chunk;
@@ -1346,6 +1375,15 @@ static int staged_d2h(crumble_hip *h, uint8_t *dst, const uint8_t *src, size_t b
     {   /* a destination that is page-locked already (crumble_hip_host_alloc, hipHostRegister) needs no staging */
         hipPointerAttribute_t at;
         if (hipPointerGetAttributes(&at, dst) == hipSuccess && at.type == hipMemoryTypeHost) {
+            void *dd = nullptr;
+            if (h->opt_dl_kernel && !(((uintptr_t)dst | (uintptr_t)src) & 15) && hipHostGetDevicePointer(&dd, dst, 0) == hipSuccess && dd) {
+                const size_t n16 = bytes >> 4, tail = bytes & 15;
+                if (n16) CRUMBLE_LAUNCH(k_d2h_store, 64, 256, h->stream, (uint4 *)dd, (const uint4 *)src, n16);
+                if (tail) HIPCHK(hipMemcpyAsync(dst + (n16 << 4), src + (n16 << 4), tail, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                return CRUMBLE_OK;
+            }
+            (void)hipGetLastError();
             D2H_PLAIN();
             return CRUMBLE_OK;
         }

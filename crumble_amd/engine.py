@@ -62,6 +62,7 @@ def load_library(path=None, make_default=True):
         "crumble_hip_contig": (C.c_int, [vp, C.POINTER(Batch), vp, vp, vp]),
         "crumble_hip_contig_run": (C.c_int, [vp, C.POINTER(Batch)]),
         "crumble_hip_upload": (C.c_int, [vp, C.POINTER(Batch)]),
+        "crumble_hip_upload_raw": (C.c_int, [vp, C.POINTER(Batch)]),
         "crumble_hip_expand": (C.c_int, [vp]),
         "crumble_hip_run": (C.c_int, [vp]),
         "crumble_hip_set_window": (C.c_int, [vp, vp]),
@@ -115,7 +116,7 @@ EXPORTED = [
     "crumble_params_default", "crumble_params_preset", "crumble_params_tech",
     "crumble_params_keep_quals", "crumble_init_bins", "crumble_bed_collapse",
     "crumble_hip_create", "crumble_hip_destroy", "crumble_hip_set_option", "crumble_hip_contig", "crumble_hip_contig_run",
-    "crumble_hip_upload", "crumble_hip_expand", "crumble_hip_run", "crumble_hip_download",
+    "crumble_hip_upload", "crumble_hip_upload_raw", "crumble_hip_expand", "crumble_hip_run", "crumble_hip_download",
     "crumble_pack_bases4", "crumble_pack_quals", "crumble_hip_encode", "crumble_hip_download_coded", "crumble_decode_seek", "crumble_decode_run", "crumble_decode_quals",
     "crumble_hip_set_window", "crumble_carry_init", "crumble_hip_run_columns", "crumble_hip_run_depth",
     "crumble_hip_run_triggers", "crumble_hip_run_fold", "crumble_hip_run_finish",
@@ -209,6 +210,12 @@ class Engine:
         self._batch = hb
         self._bstruct = hb.struct()
         self._chk(self.L.crumble_hip_upload(self.h, C.byref(self._bstruct)), "upload")
+
+    def upload_raw(self, hb: HostBatch):
+        """the copy half of upload() alone (crumble_hip_upload_raw): expand() + run() follow"""
+        self._batch = hb
+        self._bstruct = hb.struct()
+        self._chk(self.L.crumble_hip_upload_raw(self.h, C.byref(self._bstruct)), "upload_raw")
 
     def expand(self):
         """the device half of upload() again, on the raw arrays already on the device"""

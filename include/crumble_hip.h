@@ -220,6 +220,10 @@ int crumble_hip_contig_run(crumble_hip *h, const crumble_batch *b);
 /* The three stages separately, so callers (and bench.py) can keep a batch
  * resident in HBM and time only the kernels. */
 int crumble_hip_upload(crumble_hip *h, const crumble_batch *b);
+/* The copy half of crumble_hip_upload() alone: returns when the batch's raw arrays are on the device.  Follow with
+ * crumble_hip_expand() (+ crumble_hip_run()): a caller that streams contigs through several handles keeps the link busy
+ * with the next contig's copy while this one's expansion waits for its turn on the GPU (bench.py's streamed leg). */
+int crumble_hip_upload_raw(crumble_hip *h, const crumble_batch *b);
 /* The device half of crumble_hip_upload() once more, on the raw arrays the last upload left on the device: routing and
  * validation, op tables, tile lists, unpacked bases (what pileup_callback + htslib's bam_plp_auto do per read,
  * snp_score.c:1113-1153).  bench.py times this together with crumble_hip_run(): a contig pays both, once. */

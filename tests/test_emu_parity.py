@@ -267,6 +267,15 @@ def _expand_and_host_buffers(make_engine, library, hb, p):
     fresh = make_engine(p)
     with pytest.raises(Exception):
         fresh.expand()
+    # the copy half alone (crumble_hip_upload_raw), then expansion and run as separate calls: the streamed leg's split
+    with pytest.raises(Exception):
+        fresh.run()
+    fresh.upload_raw(hb)
+    with pytest.raises(Exception):
+        fresh.run()                                     # raw arrays only: nothing to run yet
+    fresh.expand(); fresh.run()
+    assert all(np.array_equal(x, y) for x, y in zip(fresh.download(), want))
+    assert fresh.upload_times()[0] >= 0.0
     fresh.close()
 
 
