@@ -427,6 +427,9 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=4,
     if coded_in:
         ca.lib().crumble_pack_quals.restype = C_.c_int
         ca.lib().crumble_pack_quals.argtypes = [C_.c_int64, C_.c_void_p, C_.c_void_p, C_.c_void_p]
+    # largest contig first: what is left when the last copy has landed (that contig's expansion, run, download, host expansion)
+    # is then the smallest contig's
+    order = sorted(range(len(batches)), key=lambda i: -batches[i].n_bases)
     split_upload = hasattr(engines[0], "upload_raw") and os.environ.get("CRUMBLE_BENCH_STREAM_SPLIT", "1") == "1"
     xfer = [0, 0]
     k_small = int(np.argmin([b_.n_bases for b_ in batches]))
@@ -447,7 +450,8 @@ def measure_wgs_streamed(ca, synth, shard, scale, device, preset=5, n_engines=4,
             def packer():
                 # the qualities as 2- / 4-bit codes (crumble_pack_quals, the host's threads): what the upload then sends
                 try:
-                    for i, b_ in enumerate(batches):
+                    for i in order:
+                        b_ = batches[i]
                         if coded_in:
                             t = time.perf_counter()
                             lut = np.zeros(16, np.uint8)
@@ -934,10 +938,10 @@ def main():
     # expansion): what the PCIe-inclusive rates below use when it is the faster way in.  Never `value`: the headline keeps
     # one byte per quality in HBM, as rounds 1-4 measured it.
     coded_q = None
-    if len(batches) == 1 and world == 1 and hasattr(ca.lib(), "crumble_pack_quals"):
+    if len(batches) == 1 and world == 1 and not args.profile and hasattr(ca.lib(), "crumble_pack_quals"):
         import copy
         t_pack = 1e9
-        for _ in range(1 if args.profile else 2):
+        for _ in range(2):
             t0 = time.perf_counter()
             hq = copy.copy(hb).packq(ca.lib())
             t_pack = min(t_pack, time.perf_counter() - t0)
