@@ -83,6 +83,7 @@ typedef struct {
     int ndev, devices[MAX_DEV]; crumble_hip *eng[MAX_DEV]; void *comm[MAX_DEV];
     int want_suspect, use_rccl;
     int plain_download;             /* CRUMBLE_HIP_PLAIN_DOWNLOAD=1: one byte per base back from the device (tests compare both ways) */
+    int coded_quals;                /* CRUMBLE_HIP_CODED_QUALS=1: qualities to the device as 2- / 4-bit codes when a contig has at most sixteen values */
     crumble_bam_writer *wr; crumble_bam_reader *rd; FILE *bed_fp;
     double t_gpu[MAX_DEV], t_write; int verbose;
     int64_t stats[CRUMBLE_ST_N];
@@ -105,7 +106,17 @@ static void *gpu_worker(void *a_)
          * PCIe; the writer expands it into the records, which still hold the input qualities).  A batch with many escapes
          * (long reads with P-block) comes back as plain bytes. */
         crumble_hip *eng = p->eng[d];
-        if ((j->err = crumble_hip_contig_run(eng, &j->B)) || (j->err = crumble_hip_encode(eng, &j->coded)))
+        uint8_t *qp = NULL;
+        const size_t qpcap = (size_t)CRUMBLE_QUALSP_SIZE(nb, 4) + 64;
+        if (p->coded_quals && nb > 0 && j->B.quals && (qp = crumble_bam_big_alloc(qpcap))) {
+            /* binned qualities (four or eight values) cross PCIe as codes: crumble_batch.qualsp (include/crumble_hip.h) */
+            const int bits = crumble_pack_quals((int64_t)nb, j->B.quals, qp, j->B.qual_lut);
+            if (bits) { j->B.qualsp = qp; j->B.qual_bits = bits; }
+        }
+        j->err = crumble_hip_contig_run(eng, &j->B);
+        j->B.qualsp = NULL; j->B.qual_bits = 0;
+        if (qp) crumble_bam_big_free(qp, qpcap);
+        if (j->err || (j->err = crumble_hip_encode(eng, &j->coded)))
             snprintf(j->errtxt, sizeof j->errtxt, "%s (%s)", crumble_hip_strerror(j->err), crumble_hip_last_error());
         else {
             crumble_coded *c = &j->coded;
@@ -510,6 +521,7 @@ int main(int argc, char **argv)
     pthread_mutex_init(&p.mu, NULL); pthread_cond_init(&p.cv, NULL);
     p.verbose = verbose; p.bed_fp = bed_fp; p.want_suspect = bed_fp != NULL;
     p.plain_download = getenv("CRUMBLE_HIP_PLAIN_DOWNLOAD") && atoi(getenv("CRUMBLE_HIP_PLAIN_DOWNLOAD"));
+    p.coded_quals = getenv("CRUMBLE_HIP_CODED_QUALS") && atoi(getenv("CRUMBLE_HIP_CODED_QUALS"));
     if (ngpu < 1 || ngpu > MAX_DEV) { fprintf(stderr, "crumble-hip: -j must be 1..%d\n", MAX_DEV); return 1; }
     p.ndev = ngpu;
     {   /* device list: CRUMBLE_HIP_DEVICES="a,b,.." (tests may name one device twice), else CRUMBLE_HIP_DEVICE + k */

@@ -367,6 +367,9 @@ def test_cli_end_to_end_emulated(tmp_path):
     emu_lib.load()
     exe = os.path.join(ROOT, "tests", "emu", "crumble-hip-emu")
     refs, bs = three_groups()
+    # the second contig's qualities as a binned instrument writes them (eight values; the first keeps its 22: CRUMBLE_HIP_CODED_QUALS
+    # below then sends one contig as codes and one as bytes)
+    bs[1].quals = np.array([2, 11, 17, 22, 27, 33, 37, 40], np.uint8)[bs[1].quals % 8]
     bamio.write_batches(tmp_path / "in.bam", refs, bs)
     (tmp_path / "keep.bed").write_text("chrI\t1000\t3000\nchrII\t500\t800\n")
     for args, params, bed in (
@@ -391,6 +394,12 @@ def test_cli_end_to_end_emulated(tmp_path):
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         assert r.returncode == 0, r.stderr
         assert np.array_equal(_file_quals(tmp_path / "out_plain.bam"), want)
+        # ... and so do the qualities sent to the device as 2- / 4-bit codes where a contig has at most sixteen values
+        # (CRUMBLE_HIP_CODED_QUALS=1: crumble_pack_quals + crumble_batch.qualsp; contigs with more values send bytes)
+        r = subprocess.run([exe, *args, str(tmp_path / "in.bam"), str(tmp_path / "out_cq.bam")], env=dict(os.environ, CRUMBLE_HIP_CODED_QUALS="1"),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        assert np.array_equal(_file_quals(tmp_path / "out_cq.bam"), want)
     # records without qualities (0xff, SAMv1 4.2.3) between ordinary ones: the coded expansion skips exactly their bases
     raw = py_bam(refs, [dict(tid=0, pos=100 + 2 * i, cigar=[(40 << 4)], seq=[(1, 2, 4, 8)[(k * 5 + k // 7) % 4] for k in range(40)],
                              qual=(None if i % 4 == 1 else [20 + (i * 7 + k) % 21 for k in range(40)]), name=f"m{i}") for i in range(300)])

@@ -361,6 +361,9 @@ def test_emu_coded_qualities(product):
             # ... together with BAM's packed bases and per-read lengths: what a reader hands over
             got = e.contig(copy.copy(hq).pack4(L).lens())
             assert all(np.array_equal(x, y) for x, y in zip(got, want))
+            # ... and the same engine goes back to the byte form (its quality array changes owner: arena view <-> own buffer)
+            assert all(np.array_equal(x, y) for x, y in zip(e.contig(hb), want))
+            assert all(np.array_equal(x, y) for x, y in zip(e.contig(hq), want))
             e.close()
     # a table entry >= 128: reported like a quality byte >= 128, by the run
     hq = copy.copy(base).packq(L)

@@ -21,6 +21,7 @@ import synth
 b0 = synth.generate(synth.config("ce", scale=0.5))
 b1 = synth.generate(synth.config("hifi", scale=0.0002, read_len=3000, tid=1))
 b2 = synth.generate(synth.config("panel", scale=0.0008, tid=2))
+b0.quals = np.array([2, 11, 25, 37], np.uint8)[b0.quals % 4]      # a binned instrument's four values: CRUMBLE_HIP_CODED_QUALS sends them as codes
 rng = np.random.default_rng(3); n, L = 30, 100
 un = HostBatch(-1, np.full(n, -1), np.zeros(n), np.full(n, 4), np.arange(n + 1) * L, np.zeros(n + 1), np.zeros(0, np.uint32),
                rng.choice([1, 2, 4, 8, 15], n * L), rng.integers(2, 42, n * L))
@@ -34,4 +35,10 @@ for args in "-5" "-9 -R k.bed -b s.bed" "-1 -S -k 30-35" "-9 -y pbccs -T XS" "-3
   ./crumble-hip-asan $args in.bam out.bam > run.log 2>&1 || { echo "FAILED: $args"; tail -20 run.log; exit 1; }
   if grep -q "runtime error\|AddressSanitizer" run.log; then echo "SANITIZER REPORT: $args"; grep -m5 "runtime error\|AddressSanitizer" run.log; exit 1; fi
   echo "clean: $args"
+done
+# the qualities as 2-bit codes (crumble_pack_quals on the host's threads, k_p0_quals): contig a; b and c keep their bytes
+for args in "-5" "-9 -j 3"; do
+  CRUMBLE_HIP_CODED_QUALS=1 ./crumble-hip-asan $args in.bam out.bam > run.log 2>&1 || { echo "FAILED (coded qualities): $args"; tail -20 run.log; exit 1; }
+  if grep -q "runtime error\|AddressSanitizer" run.log; then echo "SANITIZER REPORT (coded qualities): $args"; grep -m5 "runtime error\|AddressSanitizer" run.log; exit 1; fi
+  echo "clean (coded qualities): $args"
 done
