@@ -1238,7 +1238,13 @@ __global__ void k_epochs_td(Epoch *ep, int n, int *n_ep, int64_t tc0, int64_t td
 }
 
 /* k_scan_apply + k_overdepth in one pass over the columns */
+/* (six waves per SIMD: left alone the compiler takes 120 VGPRs -- four waves -- for a kernel that waits on its per-column epoch
+ * look-ups; at 79, without a spill, chr20 0.318 -> 0.276 ms, config 4 1.23 -> 1.04) */
+#ifndef CRUMBLE_EMU
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6)))
+#else
 __global__ void __launch_bounds__(256)
+#endif
 k_scan_overdepth(int L, uint32_t *colrec, const int32_t *nplp, const int32_t *trigcnt, const ScanVal *partial,
                  const Epoch *ep, const int *n_ep, const DParams *P, int32_t *trigcol_pos, int32_t *trigcol_off,
                  int32_t *inscol_pos, u64 *stats, int stat_hi, const int *spec_abort, int chunk)
