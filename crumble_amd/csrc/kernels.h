@@ -2305,7 +2305,6 @@ __global__ void k_readflags(DBatch B, const uint32_t *__restrict__ colrec, const
     const ReadRec rr = B.rr[r];
     if (rr.end <= rr.pos) { rflags[r] = 4; return; }
     const int c0 = rr.pos - B.p0, c1 = rr.end - B.p0;
-    RF_TRAILING_CB();
     int keep = 0, b15 = 0;
     const int w0 = c0 >> 5, w1 = (c1 - 1) >> 5;
     if (w1 - w0 < 8) {                                      /* the usual read: does any of its columns raise a flag at all? (independent loads) */
@@ -2319,6 +2318,8 @@ __global__ void k_readflags(DBatch B, const uint32_t *__restrict__ colrec, const
         }
         if (!any) { rflags[r] = 0; return; }
     }
+    RF_TRAILING_CB();                                       /* (after the early exit: a general-CIGAR read's op walk is a chain of dependent
+                                                             * loads that every wave with such a read waited for, flags or not) */
     for (int w = w0; w <= w1; w++) {
         uint32_t bits = flagbits[w];
         if (w == (c0 >> 5)) bits &= ~0u << (c0 & 31);
