@@ -155,3 +155,37 @@ def test_coded_expansion_host_side(product):
             assert np.array_equal(buf[b:b + n], qin[b:b + n] if skip else want[b:b + n]), (nb, b, n, skip)
             b += n
         assert cur.base == max(start, nb) or nb == 0
+
+
+def test_pack_quals_host_side(product):
+    """crumble_pack_quals (plain C, no device): 2-bit codes for up to four distinct qualities, 4-bit codes for up to sixteen,
+    0 (hand over the bytes) for more; every length around the byte and thread-piece borders; the table holds exactly the
+    values that occur, and table[code(i)] is quality i -- what k_p0_quals computes on the device."""
+    import numpy as np
+    L = crumble_amd.lib()
+    L.crumble_pack_quals.restype = C.c_int
+    L.crumble_pack_quals.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(9)
+    pools = {1: [37], 2: [0, 255], 3: [2, 11, 40], 4: [2, 11, 25, 37], 5: [2, 11, 25, 37, 40], 8: list(range(20, 28)),
+             16: list(range(0, 64, 4)), 17: list(range(17)), 40: list(range(2, 42))}
+    for nv, vals in pools.items():
+        for nb in (0, 1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 4099, (1 << 16) + 3, (1 << 20) + 5, 3 * (1 << 20) + 1):
+            if nb and nb < nv:
+                continue
+            q = np.asarray(vals, np.uint8)[rng.integers(0, len(vals), nb)]
+            if nb:
+                q[rng.permutation(nb)[:len(vals)]] = vals              # every value of the pool occurs
+            out = np.full((nb * 4 + 7) // 8 + 16, 0xEE, np.uint8)
+            lut = np.full(16, 0xEE, np.uint8)
+            bits = L.crumble_pack_quals(nb, q.ctypes.data if nb else None, out.ctypes.data, lut.ctypes.data)
+            if nv > 16 and nb:
+                assert bits == 0, (nv, nb)
+                continue
+            assert bits == (2 if (nv <= 4 or nb == 0) else 4), (nv, nb, bits)
+            if not nb:
+                continue
+            assert sorted(lut[:nv].tolist()) == sorted(vals) and not lut[nv:].any(), (nv, nb, lut)
+            idx = np.arange(nb, dtype=np.int64)
+            codes = (out[(idx * bits) >> 3] >> ((idx * bits) & 7).astype(np.uint8)) & ((1 << bits) - 1)
+            assert np.array_equal(lut[codes], q), (nv, nb)
+            assert not out[(nb * bits + 7) // 8:(nb * bits + 7) // 8 + 16].any()      # the slack behind the codes is zeroed
