@@ -24,6 +24,9 @@ ST_NAMES = [
 RF_KEEP, RF_NOPBLOCK, RF_PASSTHRU = 1, 2, 4
 
 
+ABI = 6          # CRUMBLE_HIP_ABI of include/crumble_hip.h: the struct layouts below are that version's
+
+
 class Params(C.Structure):
     """crumble_params (snp_score.c:185-226 hot-path fields)."""
     _fields_ = [

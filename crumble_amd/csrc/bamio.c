@@ -1236,6 +1236,7 @@ struct crumble_hts {
     hts_bam1_t **pool; int64_t npool, cappool;
     int eof;
     team *tm;                                /* host threads of the SoA unpack (team.h) */
+    int threads;                             /* what crumble_hts_open was given (-@): the unpack team's size too */
     crumble_bam_writer filt;                 /* purge_tags settings only */
     /* SoA views */
     int32_t *pos; uint8_t *mapq; uint16_t *flag; int64_t *seq_off, *cig_off; uint32_t *cigar; uint8_t *bases, *quals;
@@ -1263,6 +1264,7 @@ crumble_hts *crumble_hts_open(const char *in_fn, const char *in_fmt, const char 
     char mode[8] = "w";
     H.sam_open_mode(mode + 1, out_fn, NULL);                 /* format by file name, snp_score.c:2569 */
     if (!(h->out = H.hts_open_format(out_fn, mode, out_fmt ? h->out_fmt : NULL))) { e = fail(CRUMBLE_BAM_EIO, "cannot open %s", out_fn); goto bad; }
+    h->threads = threads;
     if (threads > 1) { H.hts_set_threads(h->in, threads); H.hts_set_threads(h->out, threads); }
     if (!(h->hdr = H.sam_hdr_read(h->in))) { e = fail(CRUMBLE_BAM_EFORMAT, "failed to read the file header"); goto bad; }
     if (pg_name && H.sam_hdr_add_pg(h->hdr, pg_name, "VN", pg_version ? pg_version : "0", pg_cmdline ? "CL" : NULL, pg_cmdline, NULL) != 0) {
@@ -1380,7 +1382,7 @@ int crumble_hts_next_contig(crumble_hts *h, crumble_batch *b)
     int64_t ab = 0, ac = 0;
     for (int64_t i = 0; i < n; i++) { h->seq_off[i] = ab; h->cig_off[i] = ac; ab += h->rec[i]->core.l_qseq; ac += h->rec[i]->core.n_cigar; }
     h->seq_off[n] = ab; h->cig_off[n] = ac;
-    if (!h->tm) h->tm = team_create(default_threads());
+    if (!h->tm) h->tm = team_create(h->threads > 0 ? h->threads : default_threads());
     team_run(h->tm, n, 0, hts_unpack, h);               /* (no team: team_run does the loop itself) */
     memset(b, 0, sizeof *b);
     b->tid = tid; b->n_reads = n;

@@ -108,8 +108,10 @@ static void *gpu_worker(void *a_)
         crumble_hip *eng = p->eng[d];
         uint8_t *qp = NULL;
         const size_t qpcap = (size_t)CRUMBLE_QUALSP_SIZE(nb, 4) + 64;
-        if (p->coded_quals && nb > 0 && j->B.quals && (qp = crumble_bam_big_alloc(qpcap))) {
-            /* binned qualities (four or eight values) cross PCIe as codes: crumble_batch.qualsp (include/crumble_hip.h) */
+        /* binned qualities (four or eight values) cross PCIe as codes: crumble_batch.qualsp (include/crumble_hip.h).  The
+         * cheap look (which values occur) comes first: a contig with more than sixteen values allocates nothing. */
+        if (p->coded_quals && nb > 0 && j->B.quals && crumble_pack_quals((int64_t)nb, j->B.quals, NULL, j->B.qual_lut) &&
+            (qp = crumble_bam_big_alloc(qpcap))) {
             const int bits = crumble_pack_quals((int64_t)nb, j->B.quals, qp, j->B.qual_lut);
             if (bits) { j->B.qualsp = qp; j->B.qual_bits = bits; }
         }
@@ -458,8 +460,17 @@ int main(int argc, char **argv)
         }
     }
     if (argc - optind != 2) { usage(stderr); return 1; }
+    if (crumble_hip_abi_version() != CRUMBLE_HIP_ABI || crumble_hip_struct_size(0) != sizeof(crumble_batch) ||
+        crumble_hip_struct_size(1) != sizeof(crumble_params) || crumble_hip_struct_size(2) != sizeof(crumble_coded)) {
+        fprintf(stderr, "crumble-hip: libcrumble_hip.so was built from another version of crumble_hip.h (ABI %d, this driver %d)\n",
+                crumble_hip_abi_version(), CRUMBLE_HIP_ABI);
+        return 1;
+    }
     const char *in_fn = argv[optind], *out_fn = argv[optind + 1];
     const int level = getenv("CRUMBLE_BAM_LEVEL") ? atoi(getenv("CRUMBLE_BAM_LEVEL")) : -1;
+    /* -@ also bounds the engine library's host helpers (crumble_pack_quals / crumble_decode_quals run per GPU worker:
+     * each gets its share of the budget, not the whole of it beside the reader's and the writer's teams) */
+    if (threads > 0) crumble_set_host_threads(threads / (ngpu > 0 ? ngpu : 1) > 0 ? threads / (ngpu > 0 ? ngpu : 1) : 1);
 
     {   /* SAM / CRAM / explicit formats: the htslib backend, one contig at a time on one device */
         unsigned char magic[4] = {0, 0, 0, 0};

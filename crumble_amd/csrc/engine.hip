@@ -97,7 +97,7 @@ struct crumble_hip {
     int opt_stages = 0;             /* "stages" = on: HIP events around every stage of a run (crumble_hip_kernel_times; bench.py) */
     /* batch (inputs) */
     DevBuf d_genlist, d_vrec, d_pbdirty, d_pbcarry, d_pbchg, d_bases4, d_ufirst, d_tcum, d_tpart, d_pbwmm, d_act, d_pbstop, d_pbrs, d_pbruns, d_pbval, d_flag, d_p0cnt, d_p0part, d_sr_ppos, d_sr_pend, d_kpos, d_kend, d_slow_g, d_slow_r, d_cix, d_sr, d_stile_lo, d_stile_hi, d_rr, d_pos, d_end, d_mapq, d_inplp, d_seq_off, d_cig_off, d_seg_off, d_cigar, d_segs,
-           d_bases, d_quals, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax, d_tile_bed, d_hitoff, d_hits, d_rtoff, d_first;
+           d_bases, d_quals, d_bases_x, d_quals_x, d_tile_lo, d_tile_hi, d_bed_start, d_bed_end, d_bed_pmax, d_tile_bed, d_hitoff, d_hits, d_rtoff, d_first;
     /* per position */
     DevBuf d_colrec, d_nplp, d_score, d_trigcnt, d_dpre, d_col_ord, d_trig_ord, d_item_off,
            d_ins_ord, d_pos_mn2, d_partial, d_epochs, d_ht;
@@ -328,7 +328,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
     DevBuf *all[] = { &h->d_genlist, &h->d_vrec, &h->d_params, &h->d_tables, &h->d_stats, &h->d_batch_stats, &h->d_misc, &h->d_mqslot,
         &h->d_ufirst, &h->d_tcum, &h->d_tpart, &h->d_pbdirty, &h->d_pbcarry, &h->d_pbchg, &h->d_bases4, &h->d_pbwmm, &h->d_act, &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
         &h->d_slow_g, &h->d_slow_r, &h->d_cix, &h->d_sr, &h->d_stile_lo, &h->d_stile_hi, &h->d_rr, &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
-        &h->d_cigar, &h->d_segs, &h->d_bases, &h->d_quals, &h->d_tile_lo, &h->d_tile_hi,
+        &h->d_cigar, &h->d_segs, &h->d_bases, &h->d_quals, &h->d_bases_x, &h->d_quals_x, &h->d_tile_lo, &h->d_tile_hi,
         &h->d_bed_start, &h->d_bed_end, &h->d_bed_pmax, &h->d_tile_bed, &h->d_hitoff, &h->d_hits, &h->d_rtoff, &h->d_first, &h->d_colrec, &h->d_nplp, &h->d_score,
         &h->d_trigcnt, &h->d_dpre, &h->d_col_ord, &h->d_trig_ord, &h->d_item_off, &h->d_ins_ord,
         &h->d_pos_mn2, &h->d_partial, &h->d_epochs, &h->d_ht, &h->d_trigcol_pos, &h->d_trigcol_off,
@@ -508,14 +508,17 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
     if ((e = h->d_raw.reserve(total))) return e;
     uint8_t *base = h->d_raw.as<uint8_t>();
     for (Item &it : items) it.d->view(base + it.off, it.front + it.room + 2 * BASE_FRONT_PAD + 64);
+    /* d_bases / d_quals are always VIEWS: into the arena when the batch carries the one-byte form, into a grow-only buffer
+     * of their own (d_bases_x / d_quals_x) when the device makes it.  Batches that alternate between the two forms (coded
+     * and plain qualities from one contig to the next) neither free nor allocate: hipFree synchronises the whole device. */
     if (packed4) {                                       /* the one-byte-per-base form is made on the device */
-        if (h->d_bases.owned == false) h->d_bases = DevBuf();
-        if ((e = h->d_bases.reserve((size_t)nb + 2 * BASE_FRONT_PAD + 64))) return e;
+        if ((e = h->d_bases_x.reserve((size_t)nb + 2 * BASE_FRONT_PAD + 64))) return e;
+        h->d_bases.view(h->d_bases_x.p, h->d_bases_x.cap);
         HIPCHK(hipMemsetAsync(h->d_bases.p, 0, BASE_FRONT_PAD, st));
     }
     if (qbits) {                                         /* likewise the one-byte-per-quality form (k_p0_quals, with the expansion) */
-        if (h->d_quals.owned == false) h->d_quals = DevBuf();
-        if ((e = h->d_quals.reserve((size_t)nb + 2 * BASE_FRONT_PAD + 64))) return e;
+        if ((e = h->d_quals_x.reserve((size_t)nb + 2 * BASE_FRONT_PAD + 64))) return e;
+        h->d_quals.view(h->d_quals_x.p, h->d_quals_x.cap);
         HIPCHK(hipMemsetAsync(h->d_quals.p, 0, BASE_FRONT_PAD, st));
     }
     bool staged = false;
@@ -620,6 +623,7 @@ static int expand(crumble_hip *h, bool wait)
     case 0: break;
     case P0_ERR_QLEN:  g_last_error = "CIGAR query length differs from l_qseq"; return CRUMBLE_EINVAL;
     case P0_ERR_COORD: g_last_error = "coordinate out of range"; return CRUMBLE_EINVAL;
+    case P0_ERR_TOTALS: g_last_error = "crumble_batch: n_bases / n_cigar_ops do not match the per-read lengths"; return CRUMBLE_EINVAL;
     default:           g_last_error = "negative or oversized read / cigar length"; return CRUMBLE_EINVAL;
     }
     const int64_t tot_ncix = tot.ncixu * CIX_UNIT;

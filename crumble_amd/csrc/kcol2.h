@@ -634,6 +634,9 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
             KC2_STAMP(2);
 
             /* ---- consume */
+#if !defined(CRUMBLE_EMU) && defined(KC2_PRIO)
+            __builtin_amdgcn_s_setprio(KC2_PRIO);                         /* diagnostic: the row walk ahead of the waves that wait on memory */
+#endif
             const unsigned ri = lane < rows ? W.rowinfo[lane] : 0u;
             if (first) {
                 /* class 0 of each column: Boyer-Moore majority over a few rows, preferably rows that span the tile
@@ -754,6 +757,9 @@ k_columns2(DBatch B, const DParams *__restrict__ P, const DTables *__restrict__ 
                     if (ANYPRES) st.cp |= (rpv[u] & 0x101u) << KC2_CLS(ve[u]);
                 }
             }
+#if !defined(CRUMBLE_EMU) && defined(KC2_PRIO)
+            __builtin_amdgcn_s_setprio(0);
+#endif
             WAVE_SYNC();                                                 /* the next group / pass overwrites plane / recs */
             KC2_STAMP(3);
             }

@@ -41,6 +41,7 @@ struct P0Part { int64_t nseg, ncixu, nslow, ngen /* general-CIGAR reads with bas
 #define P0_ERR_QUAL     5
 #define P0_ERR_SPAN     6       /* the reads over one 64-column tile span more than 3.7 GB of bases (k_columns2's 32-bit offsets) */
 #define P0_ERR_HITS     7       /* internal: tile hit lists inconsistent */
+#define P0_ERR_TOTALS   8       /* n_bases / n_cigar_ops differ from the sums of the per-read lengths (the device-scan path: the host path checks them before the copy) */
 
 __device__ __forceinline__ bool p0_is_mdnx(int op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
 __device__ __forceinline__ bool p0_is_query(int op) { return op == 0 || op == 1 || op == 4 || op == 7 || op == 8; }
@@ -78,7 +79,7 @@ __device__ __forceinline__ void p0_classify_read(int64_t r, int tid, const int32
                               const int64_t *__restrict__ seq_off, const int64_t *__restrict__ cig_off,
                               const uint32_t *__restrict__ cigar, uint8_t *__restrict__ inplp,
                               int32_t *__restrict__ end, P0Cnt32 &c, int *err, int &mn, int &mx,
-                              int64_t nb, int64_t nc)
+                              int64_t nb, int64_t nc, int64_t n)
 {
     const int64_t co0 = cig_off[r], co1 = cig_off[r + 1], so0 = seq_off[r], so1 = seq_off[r + 1];
     const int64_t ncg64 = co1 - co0, lq = so1 - so0;
@@ -86,6 +87,8 @@ __device__ __forceinline__ void p0_classify_read(int64_t r, int tid, const int32
     /* offsets must run 0 <= off[r] <= off[r+1] <= total before anything is dereferenced through them */
     if (lq < 0 || ncg64 < 0 || lq > 0x3fffffff || ncg64 > 0x3fffffff || co0 < 0 || co1 > nc || so0 < 0 || so1 > nb ||
         (r == 0 && (co0 != 0 || so0 != 0))) { atomicMax(err, P0_ERR_NEG); return; }
+    /* the caller's totals size every buffer: an overstated one would have the host and the kernels read past the arrays */
+    if (r == n - 1 && (co1 != nc || so1 != nb)) { atomicMax(err, P0_ERR_TOTALS); return; }
     const uint32_t *cig = cigar + co0;
     const int ncg = (int)ncg64;
     /* pileup_callback routing (snp:1130-1149) + htslib's default filter */
@@ -128,7 +131,7 @@ k_p0_classify(int64_t n, int tid, const int32_t *__restrict__ pos, const uint16_
     int mn = INT_MAX, mx = INT_MIN;
     P0Cnt32 c = {0, 0, 0, 0};
     if (r < n) {
-        p0_classify_read(r, tid, pos, flag, seq_off, cig_off, cigar, inplp, end, c, err, mn, mx, nb, nc);
+        p0_classify_read(r, tid, pos, flag, seq_off, cig_off, cigar, inplp, end, c, err, mn, mx, nb, nc, n);
         cnt[r] = c;
     }
     __shared__ int wmn[16], wmx[16], wpk[16], wns[16], wsl[16], wgn[16];

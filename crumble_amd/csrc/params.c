@@ -168,6 +168,20 @@ const char *crumble_hip_strerror(int err)
     }
 }
 
+int crumble_hip_abi_version(void) { return CRUMBLE_HIP_ABI; }
+size_t crumble_hip_struct_size(int which)
+{
+    switch (which) {
+    case 0: return sizeof(crumble_batch);
+    case 1: return sizeof(crumble_params);
+    case 2: return sizeof(crumble_coded);
+    case 3: return sizeof(crumble_window);
+    case 4: return sizeof(crumble_carry);
+    case 5: return sizeof(crumble_column);
+    default: return 0;
+    }
+}
+
 static int host_threads_(void);
 /* one nt16 code per byte -> BAM's packing in the crumble_batch.bases4 layout (include/crumble_hip.h) */
 typedef struct { const int64_t *seq_off; const uint8_t *bases; uint8_t *out; } pack4_job;
@@ -233,7 +247,7 @@ static void qpack_piece(void *ctx, int64_t lo, int64_t hi, int tid)      /* [lo,
 int crumble_pack_quals(int64_t n_bases, const uint8_t *quals, uint8_t *out, uint8_t lut[16])
 {
     memset(lut, 0, 16);
-    if (n_bases <= 0) { memset(out, 0, 16); return 2; }
+    if (n_bases <= 0) { if (out) memset(out, 0, 16); return 2; }
     const int nt = host_threads_();
     unsigned char (*seen)[256] = calloc((size_t)(nt > 0 ? nt : 1) + 1, 256);
     if (!seen) return 0;
@@ -249,6 +263,7 @@ int crumble_pack_quals(int64_t n_bases, const uint8_t *quals, uint8_t *out, uint
     }
     free(seen);
     if (nv > 16) return 0;
+    if (!out) return nv <= 4 ? 2 : 4;                                  /* the probe: would this batch take codes, and how wide */
     pj.q = quals; pj.out = out; pj.n = n_bases; pj.bits = nv <= 4 ? 2 : 4;
     pj.pair = malloc(65536);
     if (!pj.pair) return 0;
@@ -328,8 +343,12 @@ static void decode_blocks(void *ctx, int64_t lo, int64_t hi, int tid)
 /* threads for the host helpers: the CPUs this process may use -- on line, in its affinity mask, within its cgroup's cpu.max
  * quota (a container that sees 256 CPUs and may use 16 runs 32 threads slower than 16: the streamed leg's uploader thread was
  * the one that paid, 160 -> 186 ms of copies) -- the rule of bamio.c's default_threads() */
+static int g_host_threads;      /* crumble_set_host_threads(): the caller's budget (-@), 0 = all the process may use */
+void crumble_set_host_threads(int n) { __atomic_store_n(&g_host_threads, n > 0 ? n : 0, __ATOMIC_RELAXED); }
 static int host_threads_(void)
 {
+    const int budget = __atomic_load_n(&g_host_threads, __ATOMIC_RELAXED);
+    if (budget > 0) return budget > 32 ? 32 : budget;
     long nt = sysconf(_SC_NPROCESSORS_ONLN);
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0 && CPU_COUNT(&set) < nt) nt = CPU_COUNT(&set);

@@ -10,7 +10,7 @@ import subprocess
 
 import numpy as np
 
-from .capi import (Params, Batch, Column, Coded, DecodeCursor, HostBatch, COLUMN_DTYPE, ST_N, ROOT, HERE)
+from .capi import (ABI, Params, Batch, Column, Coded, DecodeCursor, HostBatch, COLUMN_DTYPE, ST_N, ROOT, HERE)
 
 LIB_PATH = os.environ.get("CRUMBLE_HIP_LIB", os.path.join(HERE, "libcrumble_hip.so"))
 _lib = None
@@ -96,6 +96,9 @@ def load_library(path=None, make_default=True):
         "crumble_hip_host_free": (None, [vp]),
         "crumble_hip_strerror": (C.c_char_p, [C.c_int]),
         "crumble_hip_last_error": (C.c_char_p, []),
+        "crumble_hip_abi_version": (C.c_int, []),
+        "crumble_hip_struct_size": (C.c_size_t, [C.c_int]),
+        "crumble_set_host_threads": (None, [C.c_int]),
     }
     for name, (res, args) in sig.items():
         try:
@@ -103,6 +106,13 @@ def load_library(path=None, make_default=True):
         except AttributeError:        # tests/test_abi.py checks completeness
             continue
         f.restype, f.argtypes = res, args
+    # the ABI handshake of include/crumble_hip.h: the structs declared in capi.py are the library's, field for field
+    if hasattr(L, "crumble_hip_abi_version"):
+        sizes = [C.sizeof(Batch), C.sizeof(Params), C.sizeof(Coded)]
+        if L.crumble_hip_abi_version() != ABI or [L.crumble_hip_struct_size(i) for i in range(3)] != sizes:
+            raise RuntimeError(f"{path}: built from another version of include/crumble_hip.h than crumble_amd/capi.py (ABI "
+                               f"{L.crumble_hip_abi_version()} vs {ABI}; struct sizes "
+                               f"{[L.crumble_hip_struct_size(i) for i in range(3)]} vs {sizes})")
     if make_default:
         _lib = L
     return L
@@ -126,6 +136,7 @@ EXPORTED = [
     "crumble_hip_mask_lc", "crumble_hip_pblock", "crumble_hip_indel_only", "crumble_hip_host_alloc", "crumble_hip_host_free",
     "crumble_hip_strerror",
     "crumble_hip_last_error",
+    "crumble_hip_abi_version", "crumble_hip_struct_size", "crumble_set_host_threads",
 ]
 
 

@@ -24,6 +24,18 @@
 extern "C" {
 #endif
 
+/* ------------------------------------------------------------- ABI version */
+/* The structs below are passed by pointer and read in full by the library: a host built against an older header would
+ * hand over a shorter crumble_batch / crumble_params.  Check once at start-up:
+ *     crumble_hip_abi_version() == CRUMBLE_HIP_ABI  &&  crumble_hip_struct_size(0) == sizeof(crumble_batch)  && ...
+ * and zero every struct (memset) before filling it in: fields added by later versions then read as "not given".
+ * CRUMBLE_HIP_ABI changes whenever a struct of this header gains, loses or re-orders a field. */
+#define CRUMBLE_HIP_ABI 6
+int    crumble_hip_abi_version(void);
+/* sizeof, as the LIBRARY was built: which = 0 crumble_batch, 1 crumble_params, 2 crumble_coded, 3 crumble_window,
+ * 4 crumble_carry, 5 crumble_column; 0 for any other value */
+size_t crumble_hip_struct_size(int which);
+
 /* ------------------------------------------------------------------ errors */
 #define CRUMBLE_OK            0
 #define CRUMBLE_EINVAL       -1   /* bad argument / unsupported parameter     */
@@ -146,6 +158,12 @@ typedef struct crumble_batch {
  * CRUMBLE_QUALSP_SIZE(n_bases, 4) bytes are enough for either) or 0 when the batch holds more than sixteen distinct
  * values (out unspecified: hand over quals).  Host helper (a team of host threads). */
 int crumble_pack_quals(int64_t n_bases, const uint8_t *quals, uint8_t *out, uint8_t lut[16]);
+/* (out == NULL: the look alone -- which values occur -- so that a caller can decide before it allocates: returns the width
+ * the batch would take, or 0) */
+/* Host threads the library's host helpers (crumble_pack_quals, crumble_pack_bases4, crumble_decode_quals with threads == 0) may
+ * use from now on; n <= 0: all the process may use (affinity mask, cgroup quota; at most 32).  A driver with one worker
+ * per device hands each its share of the user's -@. */
+void crumble_set_host_threads(int n);
 #define CRUMBLE_BASES4_OFF(seq_off_i, i)      (((int64_t)(seq_off_i) >> 1) + (int64_t)(i))
 #define CRUMBLE_BASES4_SIZE(n_bases, n_reads) (((int64_t)(n_bases) >> 1) + (int64_t)(n_reads) + 1)
 /* bases (one code per byte) -> the bases4 layout above; out has CRUMBLE_BASES4_SIZE bytes.  Host helper (a team of host threads). */

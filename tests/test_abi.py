@@ -21,6 +21,19 @@ def test_exports_every_declared_symbol(product):
         assert hasattr(L, n), f"{n} declared in include/ but not exported"
 
 
+def test_abi_version_handshake(product):
+    """crumble_hip_abi_version() is the header's CRUMBLE_HIP_ABI, crumble_hip_struct_size() the sizes the ctypes mirrors have
+    (a host built against an older header must be able to notice), and crumble_set_host_threads exists."""
+    from crumble_amd import capi
+    L = crumble_amd.lib()
+    txt = open(os.path.join(ROOT, "include", "crumble_hip.h")).read()
+    abi = int(re.search(r"#define\s+CRUMBLE_HIP_ABI\s+(\d+)", txt).group(1))
+    assert L.crumble_hip_abi_version() == abi == capi.ABI
+    want = [C.sizeof(capi.Batch), C.sizeof(capi.Params), C.sizeof(capi.Coded), 32, 32, C.sizeof(capi.Column)]
+    assert [L.crumble_hip_struct_size(i) for i in range(6)] == want and L.crumble_hip_struct_size(6) == 0
+    L.crumble_set_host_threads(3); L.crumble_set_host_threads(0)
+
+
 def test_bamio_exports_every_declared_symbol(product):
     L = C.CDLL(os.path.join(ROOT, "crumble_amd", "libcrumble_bamio.so"))
     names = [n for n in _declared("crumble_bamio.h") if n.startswith("crumble_bam_")]
@@ -178,6 +191,8 @@ def test_pack_quals_host_side(product):
             out = np.full((nb * 4 + 7) // 8 + 16, 0xEE, np.uint8)
             lut = np.full(16, 0xEE, np.uint8)
             bits = L.crumble_pack_quals(nb, q.ctypes.data if nb else None, out.ctypes.data, lut.ctypes.data)
+            # out == NULL is the look alone (a caller decides before it allocates): the same width, nothing written
+            assert L.crumble_pack_quals(nb, q.ctypes.data if nb else None, None, np.zeros(16, np.uint8).ctypes.data) == bits
             if nv > 16 and nb:
                 assert bits == 0, (nv, nb)
                 continue

@@ -318,6 +318,14 @@ def test_emu_packed_bases(product):
     with pytest.raises(ca.CrumbleError) as ei:
         e.contig(hbl)
     assert ei.value.code == -1
+    # totals that do not match the lengths: refused on the host for a small batch, by the device scan's check for a large one
+    # (the same bad batch must not behave differently by read count)
+    for hb in (tiny, synth_batch("chr20", 0.0035, read_len=36, depth=40.0)):
+        hbl = copy.copy(hb).lens()
+        hbl.l_qseq = hbl.l_qseq.copy(); hbl.l_qseq[-1] -= 1          # n_bases now overstates the sum of the lengths
+        with pytest.raises(ca.CrumbleError) as ei:
+            e.contig(hbl)
+        assert ei.value.code == -1 and "do not match" in str(ei.value)
     e.close()
 
 
