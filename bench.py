@@ -142,7 +142,7 @@ def _host_threads():
     return n
 
 
-def file_to_file(ca, synth, refs, batches, preset, device, label, verify_seconds=2.0):
+def file_to_file(ca, synth, refs, batches, preset, device, label, verify_seconds=2.0, codec=None, src_keep=None):
     """Metric (ii) of SURVEY.md 8(d): contigs as a BAM file through the crumble-hip driver (BGZF inflate + BAM parse +
     H2D + expansion + kernels + D2H + BGZF deflate).  `value` is over the driver's own clock from the first byte read
     to the last byte written (the figure crumble-hip -v prints: reader, GPU worker and writer threads overlap across
@@ -160,6 +160,8 @@ def file_to_file(ca, synth, refs, batches, preset, device, label, verify_seconds
     try:
         bamio.write_batches(src, refs, batches, level=1)
         env = dict(os.environ, CRUMBLE_HIP_DEVICE=str(device), CRUMBLE_BAM_LEVEL="1")
+        if codec:
+            env["CRUMBLE_HIP_CODEC"] = codec          # gpu (crumble-hip's default: BGZF members inflated / deflated on the device) | host
         t0 = time.perf_counter()
         lvl = [f"-{preset}"] if preset else []
         r = subprocess.run([os.path.join(ROOT, "crumble_amd", "crumble-hip"), "-v"] + lvl + [src, dst],
@@ -174,8 +176,10 @@ def file_to_file(ca, synth, refs, batches, preset, device, label, verify_seconds
         out = {"workload": label, "value": round(total / st[0] / 1e9, 4) if st[0] else None, "unit": "Gbases/s",
                "loop_s": st[0], "read_parse_s": st[1], "gpu_incl_pcie_s": st[2], "deflate_write_s": st[3],
                "value_process": round(total / wall / 1e9, 4), "process_wall_s": round(wall, 2), "contigs": len(batches), "bases": total,
-               "host_threads": _host_threads(), "host_cpus_visible": os.cpu_count(), "codec": L.crumble_bam_codec().decode(),
-               "in_bytes": os.path.getsize(src), "out_bytes": os.path.getsize(dst)}
+               "host_threads": _host_threads(), "host_cpus_visible": os.cpu_count(),
+               "codec": (re.search(r"BGZF codec: (.*)", r.stderr) or [None, L.crumble_bam_codec().decode()])[1],
+               "in_bytes": os.path.getsize(src), "out_bytes": os.path.getsize(dst),
+               "host_stage_s": (re.search(r"bamio: (.*)", r.stderr) or [None, None])[1]}
         if verify_seconds > 0:
             got = list(bamio.Reader(dst))
             params = ca.preset_params(preset)
@@ -213,6 +217,10 @@ def end_to_end_legs(ca, synth, shard, args, hb_full, label, device):
         batches.append(synth.generate(cfg))
     refs = [(f"chr{t + 1}", max(s_, 4 * 150 + 4096) + 1000) for t, s_ in enumerate(sizes)]
     out = file_to_file(ca, synth, refs, batches, args.preset, device, f"wgs-30x: 24 contigs (GRCh38 lengths x {0.005 * args.scale:g})")
+    # the same file with the BGZF members inflated / deflated by the host's threads (libdeflate level 1 where the box has it):
+    # what the driver did before the device codec, and what the device codec is measured against
+    hc = file_to_file(ca, synth, refs, batches, args.preset, device, "the same, CRUMBLE_HIP_CODEC=host", verify_seconds=0, codec="host")
+    out["host_codec"] = {k: hc.get(k) for k in ("value", "loop_s", "read_parse_s", "gpu_incl_pcie_s", "deflate_write_s", "codec", "out_bytes", "host_stage_s", "error") if k in hc}
     cfg_e = synth.config("chr20", scale=0.25 * args.scale)
     cfg_e.seed += 77
     out["one_contig"] = file_to_file(ca, synth, [("chr20", 64444167)], [synth.generate(cfg_e)], args.preset, device,

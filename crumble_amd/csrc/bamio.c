@@ -175,9 +175,29 @@ static int default_threads(void)
                                      * carried over to the next window (crumble_bam_detach_group copies it), so not too much at once */
 #define MAX_BLOCKS 16384            /* per refill (>= CHUNK_IN / smallest sane block, grown on demand) */
 
+/* the record buffer is shared between the reader and the groups detached from it (crumble_bam_detach_group): a group
+ * owns the bytes of its records, the reader goes on behind them in the same mapping -- nothing is copied at a detach */
+typedef struct { atomic_int refs; uint8_t *p; size_t cap; } rawbuf;
+static rawbuf *rawbuf_new(size_t cap)
+{
+    rawbuf *b = malloc(sizeof *b);
+    if (!b) return NULL;
+    b->p = big_alloc(cap);
+    if (!b->p) { free(b); return NULL; }
+    b->cap = cap; atomic_init(&b->refs, 1);
+    return b;
+}
+static void rawbuf_release(rawbuf *b)
+{
+    if (b && atomic_fetch_sub(&b->refs, 1) == 1) { big_free(b->p, b->cap); free(b); }
+}
+
 struct crumble_bam_reader {
     FILE *fp;
     int threads;
+    rawbuf *rb;                               /* raw / raw_cap below are its p / cap */
+    crumble_bam_coder codec; int has_codec;   /* crumble_bam_reader_set_codec: BGZF members inflated by the caller's codec (the device) */
+    size_t chunk_in;                          /* compressed bytes read per refill */
     team *tm;                                 /* the reader's own team (idle workers sleep: team.h); NULL in a detached group */
     uint8_t *cbuf; size_t clen, ccap;        /* compressed bytes not yet inflated  */
     int eof_file;
@@ -211,9 +231,19 @@ static int raw_reserve(crumble_bam_reader *r, size_t need)
     size_t nc = r->raw_cap ? r->raw_cap : (64u << 20);
     while (nc < need) nc += nc / 2 + (16u << 20);
     nc = (nc + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
-    uint8_t *p = big_grow(r->raw, r->raw_cap, nc);
-    if (!p) return fail(CRUMBLE_BAM_ENOMEM, "out of memory growing record buffer to %zu bytes", nc);
-    r->raw = p; r->raw_cap = nc;
+    if (r->rb && atomic_load(&r->rb->refs) == 1) {          /* nobody else looks at it: grow in place (may move) */
+        uint8_t *p = big_grow(r->raw, r->raw_cap, nc);
+        if (!p) return fail(CRUMBLE_BAM_ENOMEM, "out of memory growing record buffer to %zu bytes", nc);
+        r->rb->p = p; r->rb->cap = nc;
+        r->raw = p; r->raw_cap = nc;
+        return 0;
+    }
+    /* detached groups still read the front of it: a new mapping, the live bytes at the SAME offsets (the pages in front of
+     * them are never touched), the old one left to its groups */
+    rawbuf *nb = rawbuf_new(nc);
+    if (!nb) return fail(CRUMBLE_BAM_ENOMEM, "out of memory growing record buffer to %zu bytes", nc);
+    if (r->rb) { memcpy(nb->p + r->head, r->raw + r->head, r->raw_len - r->head); rawbuf_release(r->rb); }
+    r->rb = nb; r->raw = nb->p; r->raw_cap = nb->cap;
     return 0;
 }
 
@@ -280,15 +310,16 @@ static int refill(crumble_bam_reader *r, int side)
 {
     for (;;) {
         if (!r->eof_file) {
-            if (r->ccap < r->clen + CHUNK_IN) {
-                uint8_t *p = realloc(r->cbuf, r->clen + CHUNK_IN);
+            const size_t chunk = r->chunk_in ? r->chunk_in : CHUNK_IN;
+            if (r->ccap < r->clen + chunk) {
+                uint8_t *p = realloc(r->cbuf, r->clen + chunk);
                 if (!p) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
-                r->cbuf = p; r->ccap = r->clen + CHUNK_IN;
+                r->cbuf = p; r->ccap = r->clen + chunk;
             }
             const double tf = now_s();
-            size_t got = fread(r->cbuf + r->clen, 1, CHUNK_IN, r->fp);
+            size_t got = fread(r->cbuf + r->clen, 1, chunk, r->fp);
             T_fread += now_s() - tf;
-            if (got < CHUNK_IN) {
+            if (got < chunk) {
                 if (ferror(r->fp)) return fail(CRUMBLE_BAM_EIO, "read error: %s", strerror(errno));
                 r->eof_file = 1;
             }
@@ -334,6 +365,20 @@ static int refill(crumble_bam_reader *r, int side)
         uint8_t *dst = r->raw + r->raw_len;
         int bad = 0;
         const double ti = now_s();
+        if (r->has_codec) {
+            /* the caller's codec (crumble-hip: the device, crumble_gz_inflate) takes the whole round */
+            crumble_bam_block *gb = malloc(nb * sizeof *gb);
+            if (!gb) { free(blk); return fail(CRUMBLE_BAM_ENOMEM, "out of memory"); }
+            for (size_t i = 0; i < nb; i++) {
+                gb[i].coff = (int64_t)blk[i].coff; gb[i].uoff = (int64_t)blk[i].uoff;
+                gb[i].clen = (uint32_t)blk[i].clen; gb[i].ulen = (uint32_t)blk[i].ulen; gb[i].crc = blk[i].crc; gb[i].pad_ = 0;
+            }
+            const int crc = r->codec.inflate(r->codec.ctx, r->cbuf, (int64_t)off, gb, (int64_t)nb, dst, (int64_t)utot);
+            free(gb); free(blk);
+            T_inflate += now_s() - ti;
+            if (crc) return fail(CRUMBLE_BAM_EFORMAT, "BGZF inflate/CRC failure in the codec (code %d)", crc);
+            if (side) scan_records(r);
+        } else {
         const int use_ld = ld_ready();
         inflate_job job = { r, blk, dst, use_ld, side, 0 };
         atomic_init(&job.bad, 0);
@@ -343,6 +388,7 @@ static int refill(crumble_bam_reader *r, int side)
         free(blk);
         T_inflate += now_s() - ti;
         if (bad) return fail(CRUMBLE_BAM_EFORMAT, "BGZF inflate/CRC failure (mask %d)", bad);
+        }
         memmove(r->cbuf, r->cbuf + off, r->clen - off);
         r->clen -= off;
         r->raw_len += utot;
@@ -419,7 +465,7 @@ void crumble_bam_close(crumble_bam_reader *r)
     if (!r) return;
     if (r->fp) fclose(r->fp);
     team_destroy(r->tm);
-    free(r->cbuf); big_free(r->raw, r->raw_cap); free(r->text);
+    free(r->cbuf); rawbuf_release(r->rb); free(r->text);
     if (r->ref_name) for (int32_t i = 0; i < r->n_ref; i++) free(r->ref_name[i]);
     free(r->ref_name); free(r->ref_len); free(r->rec_off);
     free(r->pos); free(r->mapq); free(r->flag); free(r->seq_off); free(r->cig_off); free(r->lq); free(r->ncg);
@@ -544,7 +590,17 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
      * small contigs used to memmove the whole read-ahead window per contig) */
     if (r->group_end) { r->head = r->group_end; r->group_end = 0; }
     if (r->head > ((size_t)64 << 20) && r->head * 2 > r->raw_len) {
-        memmove(r->raw, r->raw + r->head, r->raw_len - r->head);
+        if (atomic_load(&r->rb->refs) == 1) memmove(r->raw, r->raw + r->head, r->raw_len - r->head);
+        else {                                              /* groups in flight hold the front: the live rest into a mapping of its own */
+            const size_t live = r->raw_len - r->head;
+            size_t nc = (size_t)64 << 20;
+            while (nc < live + ((size_t)16 << 20)) nc += nc / 2;
+            rawbuf *nb = rawbuf_new(nc);
+            if (!nb) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+            memcpy(nb->p, r->raw + r->head, live);
+            rawbuf_release(r->rb);
+            r->rb = nb; r->raw = nb->p; r->raw_cap = nb->cap;
+        }
         r->raw_len -= r->head; r->scan -= r->head; r->head = 0;
     }
     r->n = 0; r->have_tid = 0; r->group_done = 0; r->scan_err = 0; r->acc_nb = r->acc_nc = 0; r->long_cig = 0;
@@ -617,6 +673,13 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
 
 /* The reader hands the bases on as BAM packs them (crumble_batch.bases4, bases == NULL): no nibble expansion on the
  * host, half the bytes to the device.  Takes effect at the next crumble_bam_next_contig(). */
+void crumble_bam_reader_set_codec(crumble_bam_reader *r, const crumble_bam_coder *c)
+{
+    if (!r) return;
+    r->has_codec = c && c->inflate;
+    if (r->has_codec) { r->codec = *c; r->chunk_in = (size_t)64 << 20; }     /* a device wants thousands of members per call */
+    else r->chunk_in = 0;
+}
 void crumble_bam_set_packed_bases(crumble_bam_reader *r, int on) { if (r) r->packed4 = on ? 1 : 0; }
 
 /* A detached group: the reader-shaped shell that owns one contig's record bytes and SoA arrays, so that the
@@ -625,12 +688,9 @@ crumble_bam_group *crumble_bam_detach_group(crumble_bam_reader *r)
 {
     crumble_bam_reader *g = calloc(1, sizeof *g);
     if (!g) { fail(CRUMBLE_BAM_ENOMEM, "out of memory"); return NULL; }
-    const size_t tail = r->raw_len - r->group_end;
-    size_t ncap = (size_t)64 << 20;
-    while (ncap < tail + ((size_t)1 << 20)) ncap *= 2;
-    uint8_t *nraw = big_alloc(ncap);
-    if (!nraw) { free(g); fail(CRUMBLE_BAM_ENOMEM, "out of memory"); return NULL; }
-    memcpy(nraw, r->raw + r->group_end, tail);
+    /* the group shares the reader's record buffer (its records lie in front of group_end, the reader goes on behind them) */
+    atomic_fetch_add(&r->rb->refs, 1);
+    g->rb = r->rb;
     g->threads = r->threads;
     g->raw = r->raw; g->raw_cap = r->raw_cap; g->raw_len = r->group_end; g->group_end = r->group_end; g->head = r->head;
     g->n = r->n; g->cap_n = r->cap_n; g->rec_off = r->rec_off; g->tid = r->tid;
@@ -638,7 +698,7 @@ crumble_bam_group *crumble_bam_detach_group(crumble_bam_reader *r)
     g->lq = r->lq; g->ncg = r->ncg;
     g->cigar = r->cigar; g->bases = r->bases; g->quals = r->quals;
     g->cap_reads = r->cap_reads; g->cap_bases = r->cap_bases; g->cap_cig = r->cap_cig;
-    r->raw = nraw; r->raw_cap = ncap; r->raw_len = tail; r->scan -= r->group_end; r->group_end = 0; r->head = 0;
+    r->head = r->group_end; r->group_end = 0;
     r->n = 0; r->cap_n = 0; r->rec_off = NULL; r->seq_off = NULL; r->cig_off = NULL;
     r->pos = NULL; r->mapq = NULL; r->flag = NULL; r->cigar = NULL; r->bases = NULL; r->quals = NULL; r->lq = NULL; r->ncg = NULL;
     r->cap_reads = r->cap_bases = r->cap_cig = 0;
@@ -652,7 +712,7 @@ void crumble_bam_group_free(crumble_bam_group *gg)
 {
     crumble_bam_reader *g = (crumble_bam_reader *)gg;
     if (!g) return;
-    big_free(g->raw, g->raw_cap); free(g->rec_off); free(g->seq_off); free(g->cig_off);
+    rawbuf_release(g->rb); free(g->rec_off); free(g->seq_off); free(g->cig_off);
     free(g->pos); free(g->mapq); free(g->flag); free(g->cigar); free(g->lq); free(g->ncg);
     big_free(g->bases, g->cap_bases); big_free(g->quals, g->cap_bases);
     free(g);
@@ -662,6 +722,7 @@ void crumble_bam_group_free(crumble_bam_group *gg)
 #define BLK_IN 0xff00u                       /* uncompressed bytes per block (htslib's choice too) */
 struct crumble_bam_writer {
     FILE *fp; int level, threads; uint8_t *obuf; size_t ocap;
+    crumble_bam_coder codec; int has_codec;   /* crumble_bam_writer_set_codec: blocks deflated by the caller's codec (the device) */
     team *tm;                          /* the writer's own team (team.h); NULL inside a crumble_hts (purge settings only) */
     /* purge_tags (snp_score.c:989-1054) */
     int aux_mode;                      /* 0 none, 1 whitelist (-t), 2 blacklist (-T) */
@@ -670,6 +731,13 @@ struct crumble_bam_writer {
     uint8_t *raw2; size_t raw2_cap;    /* compacted records when tags are dropped */
     size_t *noff; size_t noff_cap;
 };
+
+void crumble_bam_writer_set_codec(crumble_bam_writer *w, const crumble_bam_coder *c)
+{
+    if (!w) return;
+    w->has_codec = c && c->deflate && c->deflate_bound;
+    if (w->has_codec) w->codec = *c;
+}
 
 static const uint8_t BGZF_EOF[28] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 
@@ -724,6 +792,29 @@ static void deflate_blocks(void *ctx, int64_t lo, int64_t hi, int tid)
 static int bgzf_write(crumble_bam_writer *w, const uint8_t *data, size_t len)
 {
     const size_t SLOT = 65536, BATCH = 4096;                 /* 256 MiB of input per round */
+    if (w->has_codec && len > 0) {
+        /* the caller's codec (crumble-hip: the device, crumble_gz_deflate): rounds of whole blocks, one write each */
+        const size_t round = (size_t)BATCH * BLK_IN;
+        for (size_t o = 0; o < len; o += round) {
+            const size_t n = len - o < round ? len - o : round;
+            const size_t cap = (size_t)w->codec.deflate_bound((int64_t)n);
+            if (w->ocap < cap) {
+                big_free(w->obuf, w->ocap);
+                w->obuf = big_alloc(cap);
+                w->ocap = w->obuf ? cap : 0;
+                if (!w->obuf) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
+            }
+            const double td = now_s();
+            int64_t got = 0;
+            const int rc = w->codec.deflate(w->codec.ctx, data + o, (int64_t)n, w->level, w->obuf, (int64_t)w->ocap, &got);
+            T_deflate += now_s() - td;
+            if (rc || got <= 0) return fail(CRUMBLE_BAM_EIO, "deflate failed in the codec (code %d)", rc);
+            const double tw = now_s();
+            if (fwrite(w->obuf, 1, (size_t)got, w->fp) != (size_t)got) return fail(CRUMBLE_BAM_EIO, "write error: %s", strerror(errno));
+            T_fwrite += now_s() - tw;
+        }
+        return 0;
+    }
     if (w->ocap < SLOT * BATCH) {
         big_free(w->obuf, w->ocap);
         uint8_t *p = big_alloc(SLOT * BATCH);

@@ -90,6 +90,18 @@ typedef struct {
 } pipe_t;
 typedef struct { pipe_t *p; int d; } worker_arg;
 
+/* the device BGZF codec (crumble_gz_* of crumble_hip.h) behind libcrumble_bamio's codec hooks */
+static int gz_inflate_cb(void *ctx, const uint8_t *comp, int64_t comp_len, const crumble_bam_block *blk, int64_t n_blocks,
+                         uint8_t *raw, int64_t raw_len)
+{
+    return crumble_gz_inflate((crumble_gz *)ctx, comp, comp_len, (const crumble_gz_block *)blk, n_blocks, raw, raw_len, 1);
+}
+static int gz_deflate_cb(void *ctx, const uint8_t *raw, int64_t raw_len, int level, uint8_t *out, int64_t out_cap, int64_t *out_len)
+{
+    return crumble_gz_deflate((crumble_gz *)ctx, raw, raw_len, level, out, out_cap, out_len);
+}
+typedef char gz_block_layout_check[sizeof(crumble_bam_block) == sizeof(crumble_gz_block) ? 1 : -1];
+
 static void *gpu_worker(void *a_)
 {
     worker_arg *a = a_; pipe_t *p = a->p; const int d = a->d;
@@ -575,6 +587,26 @@ int main(int argc, char **argv)
     if (!wr) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
     if (crumble_bam_set_aux_filter(wr, wl, bl, bd, bi)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
     p.wr = wr;
+    /* BGZF members inflated and deflated on the device (CRUMBLE_HIP_CODEC = gpu | gpu-inflate | gpu-deflate | host; default
+     * gpu; a compression level of 7 or more asks for the host's deflate, whose higher levels search harder than the device's one) */
+    crumble_gz *gz_in = NULL, *gz_out = NULL;
+    {
+        const char *cm = getenv("CRUMBLE_HIP_CODEC");
+        const int want_in = !cm || !strcmp(cm, "gpu") || !strcmp(cm, "gpu-inflate");
+        const int want_out = (!cm || !strcmp(cm, "gpu") || !strcmp(cm, "gpu-deflate")) && level < 7;
+        if (cm && strcmp(cm, "gpu") && strcmp(cm, "gpu-inflate") && strcmp(cm, "gpu-deflate") && strcmp(cm, "host")) {
+            fprintf(stderr, "crumble-hip: CRUMBLE_HIP_CODEC must be gpu, gpu-inflate, gpu-deflate or host\n"); return 1;
+        }
+        int ge = 0;
+        if (want_in && !(gz_in = crumble_gz_create(p.devices[0], &ge)))
+            fprintf(stderr, "crumble-hip: device inflate unavailable (%s): host threads inflate\n", crumble_hip_last_error());
+        if (want_out && !(gz_out = crumble_gz_create(p.devices[ngpu - 1], &ge)))
+            fprintf(stderr, "crumble-hip: device deflate unavailable (%s): host threads deflate\n", crumble_hip_last_error());
+        crumble_bam_coder cin = { gz_in, gz_inflate_cb, NULL, NULL }, cout = { gz_out, NULL, gz_deflate_cb, crumble_gz_deflate_bound };
+        if (gz_in) crumble_bam_reader_set_codec(rd, &cin);
+        if (gz_out) crumble_bam_writer_set_codec(wr, &cout);
+        if (verbose) fprintf(stderr, "BGZF codec: inflate %s, deflate %s\n", gz_in ? "device" : crumble_bam_codec(), gz_out ? "device" : crumble_bam_codec());
+    }
 
     const int32_t nref = crumble_bam_n_ref(rd);
     int *dev_of = calloc((size_t)(nref > 0 ? nref : 1), sizeof *dev_of);
@@ -665,6 +697,7 @@ int main(int argc, char **argv)
         fprintf(stderr, "%s\n", tb);
     }
     crumble_bam_close(rd);
+    crumble_gz_destroy(gz_in); crumble_gz_destroy(gz_out);
     for (int d = 0; d < ngpu; d++) { if (p.use_rccl) crumble_hip_comm_destroy(p.comm[d]); crumble_hip_destroy(p.eng[d]); }
     free(bt); free(bs); free(be); free(pg); free(dev_of);
     return rc_main;

@@ -1850,6 +1850,9 @@ extern "C" int crumble_hip_indel_only(crumble_hip *h, int dist, int q, uint8_t *
     return CRUMBLE_OK;
 }
 
+/* ------------------------------------------------------------------ BGZF codec on the device (include/crumble_hip.h) */
+#include "gz_host.h"
+
 #ifdef CRUMBLE_EMU
 /* test hook of the emulated build (tests/emu): how many tiles took k_columns2's two finalize paths since the last call */
 extern "C" void crumble_emu_fin_counts(unsigned long long *out) { out[0] = kc2_emu_fin[0]; out[1] = kc2_emu_fin[1]; kc2_emu_fin[0] = kc2_emu_fin[1] = 0; }

@@ -1,0 +1,243 @@
+/*
+ * gz_host.h -- host side of the device BGZF codec (gz_kernels.h): crumble_gz_* of include/crumble_hip.h.
+ * Included by engine.hip (one translation unit: the CPU test emulator builds exactly that file).
+ *
+ * A crumble_gz is independent of any engine: its own non-blocking stream and device buffers (grow-only), so a driver's
+ * reader and writer threads can each own one beside the engines that run the contigs.  Calls on one handle are serial.
+ */
+#ifndef CRUMBLE_GZ_HOST_H
+#define CRUMBLE_GZ_HOST_H
+
+#include "gz_kernels.h"
+
+#define GZ_BATCH_RAW ((int64_t)256 << 20)      /* uncompressed bytes per round of launches (the token buffer is 4 x that) */
+#define GZ_IN_PAD    4096                       /* bytes behind the compressed buffer: k_gz_tokens stages whole 256-byte chunks ahead */
+
+struct crumble_gz {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevBuf d_comp, d_blk, d_tokoff, d_tok, d_ntok, d_status, d_raw, d_slots, d_sizes, d_off, d_out, d_tabs;
+    void *pinned = nullptr;                     /* 4 KiB page-locked: sizes and totals read back */
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float ms_h2d = 0, ms_kernels = 0, ms_d2h = 0;
+    int64_t last_in = 0, last_out = 0;
+};
+
+static void gz_make_tables(uint32_t *tab /* 256 + 32 */)
+{
+    for (uint32_t i = 0; i < 256; i++) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ GZ_POLY : c >> 1;
+        tab[i] = c;
+    }
+    uint32_t p = 1u << 30;                       /* x^1 */
+    tab[256] = p;
+    for (int n = 1; n < 32; n++) tab[256 + n] = p = gz_multmodp(p, p);
+}
+
+extern "C" crumble_gz *crumble_gz_create(int device, int *err)
+{
+    int dummy; if (!err) err = &dummy;
+    *err = CRUMBLE_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        g_last_error = "no usable HIP device for the BGZF codec"; *err = CRUMBLE_ENODEVICE; return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) { *err = CRUMBLE_EHIP; return nullptr; }
+    crumble_gz *g = new (std::nothrow) crumble_gz();
+    if (!g) { *err = CRUMBLE_ENOMEM; return nullptr; }
+    g->device = device;
+    bool ok = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) == hipSuccess;
+    for (auto &e : g->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    ok = ok && hipHostMalloc(&g->pinned, 4096, 0) == hipSuccess;
+    uint32_t tabs[288];
+    gz_make_tables(tabs);
+    ok = ok && g->d_tabs.reserve(sizeof tabs) == CRUMBLE_OK && copy_sync(g->stream, g->d_tabs.p, tabs, sizeof tabs, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { g_last_error = "BGZF codec: device set-up failed"; *err = CRUMBLE_EHIP; crumble_gz_destroy(g); return nullptr; }
+    return g;
+}
+
+extern "C" void crumble_gz_destroy(crumble_gz *g)
+{
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    DevBuf *all[] = { &g->d_comp, &g->d_blk, &g->d_tokoff, &g->d_tok, &g->d_ntok, &g->d_status, &g->d_raw, &g->d_slots, &g->d_sizes,
+                      &g->d_off, &g->d_out, &g->d_tabs };
+    for (DevBuf *b : all) b->release();
+    for (auto &e : g->ev) if (e) (void)hipEventDestroy(e);
+    if (g->pinned) (void)hipHostFree(g->pinned);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+}
+
+extern "C" int64_t crumble_gz_deflate_bound(int64_t raw_len)
+{
+    const int64_t nb = raw_len > 0 ? (raw_len + GZ_MAXBLK - 1) / GZ_MAXBLK : 0;
+    return raw_len + nb * (18 + 5 + 8);
+}
+
+static const char *gz_status_text(unsigned s)
+{
+    if (s & GZ_E_CRC) return "CRC-32 mismatch";
+    if (s & GZ_E_SIZE) return "inflated size differs from ISIZE";
+    if (s & GZ_E_INPUT) return "DEFLATE stream runs past the member";
+    if (s & GZ_E_DIST) return "distance beyond the start of the member or output beyond ISIZE";
+    if (s & GZ_E_SYMBOL) return "unassigned Huffman code";
+    if (s & GZ_E_CODES) return "invalid code lengths";
+    return "invalid block header";
+}
+
+/* Inflates n_blocks BGZF members: blk[i].coff / clen = where member i's DEFLATE payload sits in comp[0, comp_len) (behind
+ * its gzip header, in front of its CRC-32 / ISIZE trailer), ulen / crc = that trailer, uoff = where its bytes go in
+ * raw[0, raw_len).  uoff must not decrease and the members must not overlap in raw.  check_crc = 0 skips the CRC-32. */
+extern "C" int crumble_gz_inflate(crumble_gz *g, const uint8_t *comp, int64_t comp_len, const crumble_gz_block *blk, int64_t n_blocks,
+                                  uint8_t *raw, int64_t raw_len, int check_crc)
+{
+    if (!g || n_blocks < 0 || comp_len < 0 || raw_len < 0 || (n_blocks && (!comp || !blk || !raw))) return CRUMBLE_EINVAL;
+    static_assert(sizeof(crumble_gz_block) == sizeof(GzBlock), "crumble_gz_block layout");
+    HIPCHK(hipSetDevice(g->device));
+    hipStream_t st = g->stream;
+    g->ms_h2d = g->ms_kernels = g->ms_d2h = 0; g->last_in = comp_len; g->last_out = 0;
+    if (!n_blocks) return CRUMBLE_OK;
+    int64_t prev_end = 0;
+    for (int64_t i = 0; i < n_blocks; i++) {
+        const crumble_gz_block &b = blk[i];
+        if (b.coff < 0 || b.coff + (int64_t)b.clen > comp_len || b.ulen > 65536u || b.uoff < prev_end || b.uoff + (int64_t)b.ulen > raw_len) {
+            g_last_error = "crumble_gz_inflate: block table out of range"; return CRUMBLE_EINVAL;
+        }
+        prev_end = b.uoff + (int64_t)b.ulen;
+    }
+    int e;
+    int ncu = 256;
+#ifndef CRUMBLE_EMU
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, g->device) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
+#endif
+    if ((e = g->d_comp.reserve((size_t)comp_len + GZ_IN_PAD))) return e;
+    HIPCHK(hipEventRecord(g->ev[0], st));
+    HIPCHK(hipMemcpyAsync(g->d_comp.p, comp, (size_t)comp_len, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync((uint8_t *)g->d_comp.p + comp_len, 0, GZ_IN_PAD, st));
+    HIPCHK(hipEventRecord(g->ev[1], st));
+    float acc_k = 0, acc_d = 0, ms = 0;
+    HIPCHK(hipEventSynchronize(g->ev[1]));
+    HIPCHK(hipEventElapsedTime(&ms, g->ev[0], g->ev[1])); g->ms_h2d = ms;
+    std::vector<int64_t> tokoff;
+    std::vector<uint32_t> stat;
+    for (int64_t i0 = 0; i0 < n_blocks; ) {
+        /* a round: members [i0, i1) with at most GZ_BATCH_RAW bytes of output */
+        int64_t i1 = i0, sum = 0;
+        while (i1 < n_blocks && (i1 == i0 || sum + (int64_t)blk[i1].ulen <= GZ_BATCH_RAW)) { sum += blk[i1].ulen; i1++; }
+        const int64_t n = i1 - i0;
+        const int64_t u0 = blk[i0].uoff, u1 = blk[i1 - 1].uoff + (int64_t)blk[i1 - 1].ulen;
+        tokoff.resize((size_t)n + 1);
+        int64_t t = 0;
+        for (int64_t i = 0; i < n; i++) { tokoff[(size_t)i] = t; t += blk[i0 + i].ulen; }
+        tokoff[(size_t)n] = t;
+        if ((e = g->d_blk.reserve((size_t)n * sizeof(GzBlock))) || (e = g->d_tokoff.reserve((size_t)(n + 1) * 8)) ||
+            (e = g->d_tok.reserve((size_t)(t + 64) * 4)) || (e = g->d_ntok.reserve((size_t)n * 4)) || (e = g->d_status.reserve((size_t)n * 4)) ||
+            (e = g->d_raw.reserve((size_t)(u1 - u0) + 64)))
+            return e;
+        HIPCHK(hipMemsetAsync(g->d_status.p, 0xff, (size_t)n * 4, st));      /* (k_gz_tokens writes every member's word) */
+        HIPCHK(hipMemcpyAsync(g->d_blk.p, blk + i0, (size_t)n * sizeof(GzBlock), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(g->d_tokoff.p, tokoff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipEventRecord(g->ev[0], st));
+        CRUMBLE_LAUNCH(k_gz_tokens, (unsigned)((n + GZ_WAVES - 1) / GZ_WAVES), GZ_WAVES * 64, st, (int)n, g->d_blk.as<GzBlock>(),
+                       g->d_comp.as<uint8_t>(), g->d_tok.as<uint32_t>(), g->d_tokoff.as<int64_t>(), g->d_ntok.as<uint32_t>(), g->d_status.as<uint32_t>());
+        /* (uoff is relative to the caller's raw: the round's image starts at u0) */
+        CRUMBLE_LAUNCH(k_gz_resolve, (unsigned)(n < 4 * ncu ? n : 4 * ncu), GZ_RT, st, (int)n, g->d_blk.as<GzBlock>(), g->d_tok.as<uint32_t>(), g->d_tokoff.as<int64_t>(),
+                       g->d_ntok.as<uint32_t>(), g->d_status.as<uint32_t>(), g->d_tabs.as<uint32_t>(), g->d_tabs.as<uint32_t>() + 256,
+                       g->d_raw.as<uint8_t>() - u0, check_crc);
+        HIPCHK(hipGetLastError());                           /* (a launch that the device refuses must not pass as an empty result) */
+        HIPCHK(hipEventRecord(g->ev[1], st));
+        stat.resize((size_t)n);
+        HIPCHK(hipMemcpyAsync(stat.data(), g->d_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(raw + u0, g->d_raw.p, (size_t)(u1 - u0), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(g->ev[2], st));
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipEventElapsedTime(&ms, g->ev[0], g->ev[1])); acc_k += ms;
+        HIPCHK(hipEventElapsedTime(&ms, g->ev[1], g->ev[2])); acc_d += ms;
+        for (int64_t i = 0; i < n; i++)
+            if (stat[(size_t)i]) {
+                char buf[160];
+                snprintf(buf, sizeof buf, "BGZF member %lld: %s (status %u)", (long long)(i0 + i), gz_status_text(stat[(size_t)i]), stat[(size_t)i]);
+                g_last_error = buf;
+                return CRUMBLE_EINVAL;
+            }
+        g->last_out += u1 - u0;
+        i0 = i1;
+    }
+    g->ms_kernels = acc_k; g->ms_d2h = acc_d;
+    return CRUMBLE_OK;
+}
+
+/* Deflates raw[0, raw_len) into BGZF members of 0xff00 input bytes each (the last one shorter), side by side in out; no
+ * end-of-file member.  level 0: stored blocks; any other value: the one compression level the device has. */
+extern "C" int crumble_gz_deflate(crumble_gz *g, const uint8_t *raw, int64_t raw_len, int level, uint8_t *out, int64_t out_cap, int64_t *out_len)
+{
+    if (!g || raw_len < 0 || !out_len || (raw_len && (!raw || !out))) return CRUMBLE_EINVAL;
+    *out_len = 0;
+    HIPCHK(hipSetDevice(g->device));
+    hipStream_t st = g->stream;
+    g->ms_h2d = g->ms_kernels = g->ms_d2h = 0; g->last_in = raw_len; g->last_out = 0;
+    if (!raw_len) return CRUMBLE_OK;
+    if (out_cap < crumble_gz_deflate_bound(raw_len)) { g_last_error = "crumble_gz_deflate: output buffer below crumble_gz_deflate_bound()"; return CRUMBLE_EINVAL; }
+    int e;
+    int ncu = 256;
+#ifndef CRUMBLE_EMU
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, g->device) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
+#endif
+    const int64_t per_round = (GZ_BATCH_RAW / GZ_MAXBLK) * GZ_MAXBLK;
+    float ms = 0;
+    int64_t produced = 0;
+    for (int64_t r0 = 0; r0 < raw_len; r0 += per_round) {
+        const int64_t len = raw_len - r0 < per_round ? raw_len - r0 : per_round;
+        const int nb = (int)((len + GZ_MAXBLK - 1) / GZ_MAXBLK);
+        if ((e = g->d_raw.reserve((size_t)len + 64)) || (e = g->d_tok.reserve((size_t)nb * 65536 * 4)) || (e = g->d_slots.reserve((size_t)nb * GZ_SLOT)) ||
+            (e = g->d_sizes.reserve((size_t)nb * 4)) || (e = g->d_off.reserve((size_t)(nb + 1) * 8)) || (e = g->d_out.reserve((size_t)nb * GZ_SLOT)))
+            return e;
+        HIPCHK(hipEventRecord(g->ev[0], st));
+        HIPCHK(hipMemcpyAsync(g->d_raw.p, raw + r0, (size_t)len, hipMemcpyHostToDevice, st));
+        HIPCHK(hipEventRecord(g->ev[1], st));
+        CRUMBLE_LAUNCH(k_gz_deflate, (unsigned)(nb < ncu ? nb : ncu), GZ_DT, st, nb, g->d_raw.as<uint8_t>(), len, level, g->d_tok.as<uint32_t>(),
+                       g->d_slots.as<uint8_t>(), g->d_sizes.as<uint32_t>(), g->d_tabs.as<uint32_t>(), g->d_tabs.as<uint32_t>() + 256);
+        CRUMBLE_LAUNCH(k_gz_offsets, 1, 1024, st, nb, g->d_sizes.as<uint32_t>(), g->d_off.as<int64_t>());
+        CRUMBLE_LAUNCH(k_gz_gather, (unsigned)nb, 256, st, nb, g->d_slots.as<uint8_t>(), g->d_sizes.as<uint32_t>(), g->d_off.as<int64_t>(), g->d_out.as<uint8_t>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(g->ev[2], st));
+        HIPCHK(hipMemcpyAsync(g->pinned, g->d_off.as<int64_t>() + nb, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        int64_t total = 0;
+        memcpy(&total, g->pinned, 8);
+        if (total <= 0 || produced + total > out_cap) { g_last_error = "crumble_gz_deflate: internal size error"; return CRUMBLE_EOVERFLOW; }
+        HIPCHK(hipMemcpyAsync(out + produced, g->d_out.p, (size_t)total, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(g->ev[3], st));
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipEventElapsedTime(&ms, g->ev[0], g->ev[1])); g->ms_h2d += ms;
+        HIPCHK(hipEventElapsedTime(&ms, g->ev[1], g->ev[2])); g->ms_kernels += ms;
+        HIPCHK(hipEventElapsedTime(&ms, g->ev[2], g->ev[3])); g->ms_d2h += ms;
+        produced += total;
+    }
+    *out_len = produced; g->last_out = produced;
+    return CRUMBLE_OK;
+}
+
+/* stream time of the last crumble_gz_inflate / _deflate: host -> device copies, kernels, device -> host copies */
+extern "C" int crumble_gz_times(crumble_gz *g, float *h2d_ms, float *kernels_ms, float *d2h_ms)
+{
+    if (!g) return CRUMBLE_EINVAL;
+    if (h2d_ms) *h2d_ms = g->ms_h2d;
+    if (kernels_ms) *kernels_ms = g->ms_kernels;
+    if (d2h_ms) *d2h_ms = g->ms_d2h;
+    return CRUMBLE_OK;
+}
+
+#if defined(GZ_STAMP) && !defined(CRUMBLE_EMU)
+extern "C" int crumble_gz_debug_stamps(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gz_stamp), sizeof(unsigned long long) * 16) != hipSuccess) return CRUMBLE_EHIP;
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(gz_stamp), z, sizeof z); }
+    return CRUMBLE_OK;
+}
+#endif
+
+#endif /* CRUMBLE_GZ_HOST_H */

@@ -182,6 +182,42 @@ size_t crumble_hip_struct_size(int which)
     }
 }
 
+/* ---- BGZF member walk (SAMv1 4.1; RFC 1952 header with the BC extra subfield): host side of crumble_gz_inflate ---- */
+int64_t crumble_bgzf_scan(const uint8_t *comp, int64_t comp_len, crumble_gz_block *blk, int64_t max_blocks,
+                          int64_t *consumed, int64_t *raw_total)
+{
+    int64_t off = 0, nb = 0, utot = 0;
+    while (off + 18 <= comp_len && (!blk || nb < max_blocks)) {
+        const uint8_t *h = comp + off;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return -1;
+        const unsigned xlen = (unsigned)h[10] | (unsigned)h[11] << 8;
+        if (off + 12 + (int64_t)xlen > comp_len) break;
+        int bsize = -1;
+        for (unsigned x = 0; x + 4 <= xlen; ) {
+            const uint8_t *sf = h + 12 + x;
+            const unsigned slen = (unsigned)sf[2] | (unsigned)sf[3] << 8;
+            if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = sf[4] | sf[5] << 8;
+            x += 4 + slen;
+        }
+        if (bsize < 0) return -1;
+        const int64_t total = (int64_t)bsize + 1;
+        if (total < 12 + (int64_t)xlen + 8) return -1;
+        if (off + total > comp_len) break;
+        const uint8_t *t = h + total - 8;
+        const uint32_t crc = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+        const uint32_t isz = (uint32_t)t[4] | (uint32_t)t[5] << 8 | (uint32_t)t[6] << 16 | (uint32_t)t[7] << 24;
+        if (isz > 65536u) return -1;
+        if (blk) {
+            blk[nb].coff = off + 12 + xlen; blk[nb].clen = (uint32_t)(total - 12 - xlen - 8);
+            blk[nb].uoff = utot; blk[nb].ulen = isz; blk[nb].crc = crc; blk[nb].pad_ = 0;
+        }
+        utot += isz; nb++; off += total;
+    }
+    if (consumed) *consumed = off;
+    if (raw_total) *raw_total = utot;
+    return nb;
+}
+
 static int host_threads_(void);
 /* one nt16 code per byte -> BAM's packing in the crumble_batch.bases4 layout (include/crumble_hip.h) */
 typedef struct { const int64_t *seq_off; const uint8_t *bases; uint8_t *out; } pack4_job;

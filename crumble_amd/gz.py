@@ -1,0 +1,100 @@
+"""ctypes view of the device BGZF codec (crumble_gz_* of include/crumble_hip.h): what the tests and bench.py call.
+The product's users are crumble-hip's reader and writer (csrc/cli.c installs it into libcrumble_bamio's codec hooks)."""
+import ctypes as C
+
+import numpy as np
+
+from .engine import CrumbleError, lib
+
+
+class GzBlock(C.Structure):
+    _fields_ = [("coff", C.c_int64), ("uoff", C.c_int64), ("clen", C.c_uint32), ("ulen", C.c_uint32),
+                ("crc", C.c_uint32), ("pad_", C.c_uint32)]
+
+
+BLOCK_DTYPE = np.dtype([("coff", "<i8"), ("uoff", "<i8"), ("clen", "<u4"), ("ulen", "<u4"), ("crc", "<u4"), ("pad_", "<u4")])
+
+
+def _sig(L):
+    vp, i64 = C.c_void_p, C.c_int64
+    L.crumble_gz_create.restype = vp
+    L.crumble_gz_create.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    L.crumble_gz_destroy.restype = None
+    L.crumble_gz_destroy.argtypes = [vp]
+    L.crumble_bgzf_scan.restype = i64
+    L.crumble_bgzf_scan.argtypes = [vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64)]
+    L.crumble_gz_inflate.restype = C.c_int
+    L.crumble_gz_inflate.argtypes = [vp, vp, i64, vp, i64, vp, i64, C.c_int]
+    L.crumble_gz_deflate_bound.restype = i64
+    L.crumble_gz_deflate_bound.argtypes = [i64]
+    L.crumble_gz_deflate.restype = C.c_int
+    L.crumble_gz_deflate.argtypes = [vp, vp, i64, C.c_int, vp, i64, C.POINTER(i64)]
+    L.crumble_gz_times.restype = C.c_int
+    L.crumble_gz_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    return L
+
+
+def bgzf_scan(data, library=None):
+    """(blocks as a numpy record array, bytes of whole members walked, total ISIZE) of a BGZF byte string / uint8 array"""
+    L = _sig(library if library is not None else lib())
+    a = np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else data
+    consumed, total = C.c_int64(0), C.c_int64(0)
+    n = L.crumble_bgzf_scan(a.ctypes.data, a.size, None, 0, C.byref(consumed), C.byref(total))
+    if n < 0:
+        raise ValueError("not BGZF")
+    blk = np.zeros(max(int(n), 1), BLOCK_DTYPE)
+    n2 = L.crumble_bgzf_scan(a.ctypes.data, a.size, blk.ctypes.data, n, C.byref(consumed), C.byref(total))
+    assert n2 == n
+    return blk[:n], int(consumed.value), int(total.value)
+
+
+class GzCodec:
+    def __init__(self, device=0, library=None):
+        self.L = _sig(library if library is not None else lib())
+        err = C.c_int(0)
+        self.h = self.L.crumble_gz_create(device, C.byref(err))
+        if not self.h:
+            raise CrumbleError(err.value, "crumble_gz_create", self.L)
+
+    def close(self):
+        if self.h:
+            self.L.crumble_gz_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def inflate(self, data, check_crc=True, blocks=None):
+        """the concatenated members of a BGZF byte string inflated on the device -> uint8 array"""
+        a = np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else data
+        if blocks is None:
+            blocks, consumed, total = bgzf_scan(a, self.L)
+            if consumed != a.size:
+                raise ValueError("trailing bytes behind the last whole BGZF member")
+        else:
+            total = int(blocks["uoff"][-1] + blocks["ulen"][-1]) if len(blocks) else 0
+        out = np.empty(max(total, 1), np.uint8)
+        blocks = np.ascontiguousarray(blocks)
+        rc = self.L.crumble_gz_inflate(self.h, a.ctypes.data, a.size, blocks.ctypes.data, len(blocks), out.ctypes.data, total,
+                                       1 if check_crc else 0)
+        if rc:
+            raise CrumbleError(rc, "crumble_gz_inflate", self.L)
+        return out[:total]
+
+    def deflate(self, data, level=6):
+        a = np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else data
+        cap = int(self.L.crumble_gz_deflate_bound(a.size))
+        out = np.empty(max(cap, 1), np.uint8)
+        n = C.c_int64(0)
+        rc = self.L.crumble_gz_deflate(self.h, a.ctypes.data, a.size, level, out.ctypes.data, cap, C.byref(n))
+        if rc:
+            raise CrumbleError(rc, "crumble_gz_deflate", self.L)
+        return out[:n.value]
+
+    def times(self):
+        a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
+        self.L.crumble_gz_times(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return {"h2d_ms": a.value, "kernels_ms": b.value, "d2h_ms": c.value}

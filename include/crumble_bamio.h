@@ -41,6 +41,24 @@ const char *crumble_bam_ref_name(const crumble_bam_reader *r, int32_t tid);
 int64_t     crumble_bam_ref_len(const crumble_bam_reader *r, int32_t tid);
 const char *crumble_bam_header_text(const crumble_bam_reader *r, int64_t *len);
 
+/* BGZF members inflated / deflated by the caller instead of the library's host threads: crumble-hip hands the device codec
+ * in (crumble_gz_inflate / crumble_gz_deflate of crumble_hip.h; this library itself stays free of HIP).  crumble_bam_block is
+ * crumble_gz_block field for field.  inflate: blk[i].coff / clen locate member i's DEFLATE payload in comp[0, comp_len),
+ * its ulen bytes go to raw[blk[i].uoff ...], crc is the member's CRC-32 (to be checked); deflate: raw[0, raw_len) as
+ * members of 0xff00 input bytes side by side in out (out_cap >= deflate_bound(raw_len)), their total size in *out_len.
+ * Both return 0 or a negative code.  Set before the first read / write; NULL = back to the host threads.  With a codec the
+ * reader reads 64 MiB of compressed bytes per round. */
+typedef struct crumble_bam_block { int64_t coff, uoff; uint32_t clen, ulen, crc, pad_; } crumble_bam_block;
+typedef struct crumble_bam_coder {
+    void *ctx;
+    int (*inflate)(void *ctx, const uint8_t *comp, int64_t comp_len, const crumble_bam_block *blk, int64_t n_blocks,
+                   uint8_t *raw, int64_t raw_len);
+    int (*deflate)(void *ctx, const uint8_t *raw, int64_t raw_len, int level, uint8_t *out, int64_t out_cap, int64_t *out_len);
+    int64_t (*deflate_bound)(int64_t raw_len);
+} crumble_bam_coder;
+void crumble_bam_reader_set_codec(crumble_bam_reader *r, const crumble_bam_coder *c);
+void crumble_bam_writer_set_codec(crumble_bam_writer *w, const crumble_bam_coder *c);
+
 /* Reads the next run of records sharing one refID (a contig, or the trailing tid -1 block: the
  * unit transcode() resets its state on, snp_score.c:1478-1488) and fills *b with SoA views owned
  * by the reader, valid until the next call.  b->n_bed is 0 (the caller attaches keep regions).

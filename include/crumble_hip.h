@@ -406,6 +406,39 @@ int crumble_hip_pblock(crumble_hip *h, int64_t n_reads, const int64_t *seq_off,
  * Q = 37).  Uses the batch of the last crumble_hip_upload(). */
 int crumble_hip_indel_only(crumble_hip *h, int dist, int q, uint8_t *qual_out);
 
+/* ---- BGZF members inflated / deflated on the device ----------------------------------------------
+ * What htslib's bgzf layer does on host threads under sam_read1 (snp_score.c:1116-1117) and sam_write1
+ * (snp_score.c:1101): every 64 KiB member is an independent DEFLATE stream (RFC 1951/1952, SAMv1 4.1).  A crumble_gz is a
+ * codec context on one device (its own stream and buffers, independent of any engine; calls on one handle are serial).
+ *
+ *   crumble_bgzf_scan(comp, n, blk, max, &consumed, &raw_total)   host only: walks the gzip headers of the whole members in
+ *       comp[0, n), fills blk[] (payload position, ISIZE, CRC-32, uoff = running sum of ISIZE); returns their number (may
+ *       stop at max), < 0 for a malformed header; consumed = bytes of whole members walked
+ *   crumble_gz_inflate(g, comp, n, blk, n_blocks, raw, raw_len, check_crc)   raw[blk[i].uoff ...] = member i inflated;
+ *       a corrupt member (bad code lengths, distance too far back, wrong size, CRC-32) -> CRUMBLE_EINVAL, text in
+ *       crumble_hip_last_error()
+ *   crumble_gz_deflate(g, raw, n, level, out, out_cap, &out_len)   raw cut into members of 0xff00 bytes (htslib's block
+ *       size), each a complete gzip member with the BC extra field; out_cap >= crumble_gz_deflate_bound(n); no EOF member;
+ *       level 0 = stored, anything else = the device's one level (hash + run + repeat-distance candidates, greedy parse,
+ *       dynamic Huffman codes).  Any inflater reads the result; the bytes differ from zlib's (as zlib's do from libdeflate's). */
+typedef struct crumble_gz crumble_gz;
+typedef struct crumble_gz_block {
+    int64_t  coff;              /* first byte of the member's DEFLATE payload in the compressed buffer */
+    int64_t  uoff;              /* where its bytes go in the uncompressed buffer                     */
+    uint32_t clen, ulen, crc;   /* payload bytes; ISIZE; CRC-32 of the uncompressed bytes            */
+    uint32_t pad_;
+} crumble_gz_block;
+crumble_gz *crumble_gz_create(int device, int *err);
+void    crumble_gz_destroy(crumble_gz *g);
+int64_t crumble_bgzf_scan(const uint8_t *comp, int64_t comp_len, crumble_gz_block *blk, int64_t max_blocks,
+                          int64_t *consumed, int64_t *raw_total);
+int     crumble_gz_inflate(crumble_gz *g, const uint8_t *comp, int64_t comp_len, const crumble_gz_block *blk, int64_t n_blocks,
+                           uint8_t *raw, int64_t raw_len, int check_crc);
+int64_t crumble_gz_deflate_bound(int64_t raw_len);
+int     crumble_gz_deflate(crumble_gz *g, const uint8_t *raw, int64_t raw_len, int level, uint8_t *out, int64_t out_cap, int64_t *out_len);
+/* stream time of the last inflate / deflate call on g: host -> device copies, kernels, device -> host copies (ms) */
+int     crumble_gz_times(crumble_gz *g, float *h2d_ms, float *kernels_ms, float *d2h_ms);
+
 /* Page-locked host memory (hipHostMalloc) for a caller's batch arrays and output buffers: copies to and from it cross
  * PCIe at the link's rate without the runtime's staging through its own buffers (pageable memory: about half).  Any host
  * memory works with every entry point; this is an option for callers that keep their buffers.  NULL on failure. */

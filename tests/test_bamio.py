@@ -101,6 +101,15 @@ def three_groups():
 
 
 # ------------------------------------------------------------------------------- tests
+@pytest.fixture(autouse=True)
+def _host_codec_under_emulation(request, monkeypatch):
+    """crumble-hip inflates and deflates BGZF members on the device by default; emulated, a full block costs 1024 fibers some
+    fifteen seconds, so the emulated driver tests keep the host codec (test_cli_device_codec_emulated below runs the device
+    one on a small file; the GPU tests take the default)"""
+    if "emulated" in request.node.name and "device_codec" not in request.node.name:
+        monkeypatch.setenv("CRUMBLE_HIP_CODEC", "host")
+
+
 def test_write_batches_then_read_back(tmp_path):
     refs, bs = three_groups()
     path = tmp_path / "t.bam"
@@ -423,6 +432,35 @@ def test_cli_end_to_end_emulated(tmp_path):
     # options that were not rebuilt are refused loudly
     r = subprocess.run([exe, "-r", "chrI", str(tmp_path / "in.bam"), str(tmp_path / "o2.bam")], stderr=subprocess.PIPE, text=True)
     assert r.returncode == 1 and "does not provide" in r.stderr
+
+
+def test_cli_device_codec_emulated(tmp_path):
+    """crumble-hip with its default codec -- BGZF members inflated (crumble_gz_inflate behind the reader's hook) and deflated
+    (crumble_gz_deflate behind the writer's) by the device kernels, emulated here -- writes the records the host codec writes:
+    same uncompressed stream, valid gzip members; each direction alone as well"""
+    import emu_lib
+    emu_lib.load()
+    exe = os.path.join(ROOT, "tests", "emu", "crumble-hip-emu")
+    refs = [("chrI", 60000), ("chrII", 25000)]
+    bs = [synth.generate(synth.config("ce", scale=0.06)), synth.generate(synth.config("ce", scale=0.03, seed=78, tid=1))]
+    bamio.write_batches(tmp_path / "in.bam", refs, bs, level=6)
+    streams = {}
+    for mode in ("host", "gpu", "gpu-inflate", "gpu-deflate"):
+        out = tmp_path / f"out_{mode}.bam"
+        r = subprocess.run([exe, "-v", "-5", "-z", str(tmp_path / "in.bam"), str(out)], env=dict(os.environ, CRUMBLE_HIP_CODEC=mode),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr
+        want_dev = {"host": (False, False), "gpu": (True, True), "gpu-inflate": (True, False), "gpu-deflate": (False, True)}[mode]
+        line = [l for l in r.stderr.splitlines() if l.startswith("BGZF codec:")][0]
+        assert ("inflate device" in line) == want_dev[0] and ("deflate device" in line) == want_dev[1], line
+        streams[mode] = gzip.decompress(open(out, "rb").read())           # every member's CRC-32 and ISIZE checked
+        assert open(out, "rb").read()[-28:] == BGZF_EOF
+    assert streams["gpu"] == streams["host"] == streams["gpu-inflate"] == streams["gpu-deflate"]
+    want = _oracle_file(ca.preset_params(5), tmp_path / "in.bam")
+    assert np.array_equal(_file_quals(tmp_path / "out_gpu.bam"), want)
+    r = subprocess.run([exe, "-5", str(tmp_path / "in.bam"), str(tmp_path / "o.bam")], env=dict(os.environ, CRUMBLE_HIP_CODEC="zlib"),
+                       stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "CRUMBLE_HIP_CODEC" in r.stderr
 
 
 def test_cli_multi_device_emulated(tmp_path):
