@@ -142,7 +142,7 @@ def _host_threads():
     return n
 
 
-def file_to_file(ca, synth, refs, batches, preset, device, label, verify_seconds=2.0, codec=None, src_keep=None):
+def file_to_file(ca, synth, refs, batches, preset, device, label, verify_seconds=2.0, codec=None, level="1"):
     """Metric (ii) of SURVEY.md 8(d): contigs as a BAM file through the crumble-hip driver (BGZF inflate + BAM parse +
     H2D + expansion + kernels + D2H + BGZF deflate).  `value` is over the driver's own clock from the first byte read
     to the last byte written (the figure crumble-hip -v prints: reader, GPU worker and writer threads overlap across
@@ -159,7 +159,11 @@ def file_to_file(ca, synth, refs, batches, preset, device, label, verify_seconds
     total = sum(b_.n_bases for b_ in batches)
     try:
         bamio.write_batches(src, refs, batches, level=1)
-        env = dict(os.environ, CRUMBLE_HIP_DEVICE=str(device), CRUMBLE_BAM_LEVEL="1")
+        env = dict(os.environ, CRUMBLE_HIP_DEVICE=str(device))
+        if level is not None:
+            env["CRUMBLE_BAM_LEVEL"] = level          # "1": the fastest host deflate (the legs of rounds 4 and 5); None: the default level (6)
+        else:
+            env.pop("CRUMBLE_BAM_LEVEL", None)
         if codec:
             env["CRUMBLE_HIP_CODEC"] = codec          # gpu (crumble-hip's default: BGZF members inflated / deflated on the device) | host
         t0 = time.perf_counter()
@@ -217,10 +221,16 @@ def end_to_end_legs(ca, synth, shard, args, hb_full, label, device):
         batches.append(synth.generate(cfg))
     refs = [(f"chr{t + 1}", max(s_, 4 * 150 + 4096) + 1000) for t, s_ in enumerate(sizes)]
     out = file_to_file(ca, synth, refs, batches, args.preset, device, f"wgs-30x: 24 contigs (GRCh38 lengths x {0.005 * args.scale:g})")
-    # the same file with the BGZF members inflated / deflated by the host's threads (libdeflate level 1 where the box has it):
-    # what the driver did before the device codec, and what the device codec is measured against
-    hc = file_to_file(ca, synth, refs, batches, args.preset, device, "the same, CRUMBLE_HIP_CODEC=host", verify_seconds=0, codec="host")
-    out["host_codec"] = {k: hc.get(k) for k in ("value", "loop_s", "read_parse_s", "gpu_incl_pcie_s", "deflate_write_s", "codec", "out_bytes", "host_stage_s", "error") if k in hc}
+    # crumble-hip's codec policy (CRUMBLE_HIP_CODEC=auto) takes the host's threads at level 1 on a sixteen-thread host: the leg above is
+    # the host codec.  The same file with every member inflated AND deflated on the device (crumble_gz_*):
+    keys = ("value", "loop_s", "read_parse_s", "gpu_incl_pcie_s", "deflate_write_s", "codec", "out_bytes", "host_stage_s", "error")
+    dv = file_to_file(ca, synth, refs, batches, args.preset, device, "the same, CRUMBLE_HIP_CODEC=gpu", verify_seconds=0, codec="gpu")
+    out["device_codec"] = {k: dv.get(k) for k in keys if k in dv}
+    # ... and at the DEFAULT compression level (what htslib and reference crumble write: zlib 6), where auto = host inflate +
+    # device deflate, against the host's threads doing both
+    da = file_to_file(ca, synth, refs, batches, args.preset, device, "the same at the default level, auto", verify_seconds=0, level=None)
+    dh = file_to_file(ca, synth, refs, batches, args.preset, device, "the same at the default level, host", verify_seconds=0, codec="host", level=None)
+    out["default_level"] = {"auto": {k: da.get(k) for k in keys if k in da}, "host_codec": {k: dh.get(k) for k in keys if k in dh}}
     cfg_e = synth.config("chr20", scale=0.25 * args.scale)
     cfg_e.seed += 77
     out["one_contig"] = file_to_file(ca, synth, [("chr20", 64444167)], [synth.generate(cfg_e)], args.preset, device,

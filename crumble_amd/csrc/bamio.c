@@ -170,6 +170,8 @@ static int default_threads(void)
     return n < 1 ? 1 : n;
 }
 
+int crumble_bam_default_threads(void) { return default_threads(); }
+
 /* ------------------------------------------------------------------ BGZF in */
 #define CHUNK_IN   (8u << 20)       /* compressed bytes read per refill: what is inflated beyond a contig's last record is
                                      * carried over to the next window (crumble_bam_detach_group copies it), so not too much at once */
@@ -677,7 +679,7 @@ void crumble_bam_reader_set_codec(crumble_bam_reader *r, const crumble_bam_coder
 {
     if (!r) return;
     r->has_codec = c && c->inflate;
-    if (r->has_codec) { r->codec = *c; r->chunk_in = (size_t)64 << 20; }     /* a device wants thousands of members per call */
+    if (r->has_codec) { r->codec = *c; r->chunk_in = (size_t)256 << 20; }    /* a device wants tens of thousands of members per call */
     else r->chunk_in = 0;
 }
 void crumble_bam_set_packed_bases(crumble_bam_reader *r, int on) { if (r) r->packed4 = on ? 1 : 0; }

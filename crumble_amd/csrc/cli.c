@@ -587,15 +587,24 @@ int main(int argc, char **argv)
     if (!wr) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
     if (crumble_bam_set_aux_filter(wr, wl, bl, bd, bi)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
     p.wr = wr;
-    /* BGZF members inflated and deflated on the device (CRUMBLE_HIP_CODEC = gpu | gpu-inflate | gpu-deflate | host; default
-     * gpu; a compression level of 7 or more asks for the host's deflate, whose higher levels search harder than the device's one) */
+    /* BGZF members inflated / deflated on the device: CRUMBLE_HIP_CODEC = auto | gpu | gpu-inflate | gpu-deflate | host.
+     * auto (the default) goes by what was measured on MI355X boxes: the device deflates a gigabyte of
+     * records in ~0.1 s whatever the level, sixteen host threads need 0.17 s at level 1 and three times that at the default
+     * level, so the device deflates unless the caller asked for level 0 / 1 with eight or more host threads or for level 7
+     * and up (the host's slow levels search harder than the device's one); the host's threads inflate (a gigabyte in 0.1 s
+     * on sixteen of them, as long as the device needs with the bytes' way back over PCIe) unless there are fewer than eight. */
     crumble_gz *gz_in = NULL, *gz_out = NULL;
     {
         const char *cm = getenv("CRUMBLE_HIP_CODEC");
-        const int want_in = !cm || !strcmp(cm, "gpu") || !strcmp(cm, "gpu-inflate");
-        const int want_out = (!cm || !strcmp(cm, "gpu") || !strcmp(cm, "gpu-deflate")) && level < 7;
-        if (cm && strcmp(cm, "gpu") && strcmp(cm, "gpu-inflate") && strcmp(cm, "gpu-deflate") && strcmp(cm, "host")) {
-            fprintf(stderr, "crumble-hip: CRUMBLE_HIP_CODEC must be gpu, gpu-inflate, gpu-deflate or host\n"); return 1;
+        if (!cm) cm = "auto";
+        if (strcmp(cm, "auto") && strcmp(cm, "gpu") && strcmp(cm, "gpu-inflate") && strcmp(cm, "gpu-deflate") && strcmp(cm, "host")) {
+            fprintf(stderr, "crumble-hip: CRUMBLE_HIP_CODEC must be auto, gpu, gpu-inflate, gpu-deflate or host\n"); return 1;
+        }
+        const int ht = threads > 0 ? threads : crumble_bam_default_threads();
+        int want_in = !strcmp(cm, "gpu") || !strcmp(cm, "gpu-inflate"), want_out = !strcmp(cm, "gpu") || !strcmp(cm, "gpu-deflate");
+        if (!strcmp(cm, "auto")) {
+            want_in = ht < 8;
+            want_out = level < 7 && !(level >= 0 && level <= 1 && ht >= 8);
         }
         int ge = 0;
         if (want_in && !(gz_in = crumble_gz_create(p.devices[0], &ge)))

@@ -16,7 +16,8 @@
 struct crumble_gz {
     int device = 0;
     hipStream_t stream = nullptr;
-    DevBuf d_comp, d_blk, d_tokoff, d_tok, d_ntok, d_status, d_raw, d_slots, d_sizes, d_off, d_out, d_tabs;
+    DevBuf d_comp, d_blk, d_tokoff, d_tok, d_ntok, d_status, d_raw, d_slots, d_sizes, d_off, d_out, d_tabs, d_scratch, d_cand;
+    int opt_lanes = -1;                         /* crumble_gz_set_option("tokens", ...): -1 by member count, 0 a wave per member, 1 a lane per member */
     void *pinned = nullptr;                     /* 4 KiB page-locked: sizes and totals read back */
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float ms_h2d = 0, ms_kernels = 0, ms_d2h = 0;
@@ -63,7 +64,7 @@ extern "C" void crumble_gz_destroy(crumble_gz *g)
     (void)hipSetDevice(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     DevBuf *all[] = { &g->d_comp, &g->d_blk, &g->d_tokoff, &g->d_tok, &g->d_ntok, &g->d_status, &g->d_raw, &g->d_slots, &g->d_sizes,
-                      &g->d_off, &g->d_out, &g->d_tabs };
+                      &g->d_off, &g->d_out, &g->d_tabs, &g->d_scratch, &g->d_cand };
     for (DevBuf *b : all) b->release();
     for (auto &e : g->ev) if (e) (void)hipEventDestroy(e);
     if (g->pinned) (void)hipHostFree(g->pinned);
@@ -125,8 +126,10 @@ extern "C" int crumble_gz_inflate(crumble_gz *g, const uint8_t *comp, int64_t co
     std::vector<uint32_t> stat;
     for (int64_t i0 = 0; i0 < n_blocks; ) {
         /* a round: members [i0, i1) with at most GZ_BATCH_RAW bytes of output */
+        /* (a lane per member wants every member of the call in flight at once: its time hardly depends on their number) */
+        const int64_t round_raw = (g->opt_lanes < 0 ? n_blocks - i0 > (int64_t)16 * ncu : g->opt_lanes != 0) ? 16 * GZ_BATCH_RAW : GZ_BATCH_RAW;
         int64_t i1 = i0, sum = 0;
-        while (i1 < n_blocks && (i1 == i0 || sum + (int64_t)blk[i1].ulen <= GZ_BATCH_RAW)) { sum += blk[i1].ulen; i1++; }
+        while (i1 < n_blocks && (i1 == i0 || sum + (int64_t)blk[i1].ulen <= round_raw)) { sum += blk[i1].ulen; i1++; }
         const int64_t n = i1 - i0;
         const int64_t u0 = blk[i0].uoff, u1 = blk[i1 - 1].uoff + (int64_t)blk[i1 - 1].ulen;
         tokoff.resize((size_t)n + 1);
@@ -141,6 +144,13 @@ extern "C" int crumble_gz_inflate(crumble_gz *g, const uint8_t *comp, int64_t co
         HIPCHK(hipMemcpyAsync(g->d_blk.p, blk + i0, (size_t)n * sizeof(GzBlock), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(g->d_tokoff.p, tokoff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
         HIPCHK(hipEventRecord(g->ev[0], st));
+        /* the walk: a wave per member while they all fit the chip at once (sixteen per CU), a lane per member beyond that */
+        const bool lanes = g->opt_lanes < 0 ? n > (int64_t)16 * ncu : g->opt_lanes != 0;
+        if (lanes) {
+            if ((e = g->d_scratch.reserve((size_t)((n + 63) / 64 * 64) * GZ2_WORDS * 4))) return e;
+            CRUMBLE_LAUNCH(k_gz_tokens_lanes, (unsigned)((n + 63) / 64), 64, st, (int)n, g->d_blk.as<GzBlock>(), g->d_comp.as<uint8_t>(),
+                           g->d_tok.as<uint32_t>(), g->d_tokoff.as<int64_t>(), g->d_ntok.as<uint32_t>(), g->d_status.as<uint32_t>(), g->d_scratch.as<uint32_t>());
+        } else
         CRUMBLE_LAUNCH(k_gz_tokens, (unsigned)((n + GZ_WAVES - 1) / GZ_WAVES), GZ_WAVES * 64, st, (int)n, g->d_blk.as<GzBlock>(),
                        g->d_comp.as<uint8_t>(), g->d_tok.as<uint32_t>(), g->d_tokoff.as<int64_t>(), g->d_ntok.as<uint32_t>(), g->d_status.as<uint32_t>());
         /* (uoff is relative to the caller's raw: the round's image starts at u0) */
@@ -180,6 +190,7 @@ extern "C" int crumble_gz_deflate(crumble_gz *g, const uint8_t *raw, int64_t raw
     hipStream_t st = g->stream;
     g->ms_h2d = g->ms_kernels = g->ms_d2h = 0; g->last_in = raw_len; g->last_out = 0;
     if (!raw_len) return CRUMBLE_OK;
+    level = level == 0 ? 0 : 1;                          /* 0: stored; anything else, zlib's -1 "default" included: the device's one level */
     if (out_cap < crumble_gz_deflate_bound(raw_len)) { g_last_error = "crumble_gz_deflate: output buffer below crumble_gz_deflate_bound()"; return CRUMBLE_EINVAL; }
     int e;
     int ncu = 256;
@@ -192,13 +203,13 @@ extern "C" int crumble_gz_deflate(crumble_gz *g, const uint8_t *raw, int64_t raw
     for (int64_t r0 = 0; r0 < raw_len; r0 += per_round) {
         const int64_t len = raw_len - r0 < per_round ? raw_len - r0 : per_round;
         const int nb = (int)((len + GZ_MAXBLK - 1) / GZ_MAXBLK);
-        if ((e = g->d_raw.reserve((size_t)len + 64)) || (e = g->d_tok.reserve((size_t)nb * 65536 * 4)) || (e = g->d_slots.reserve((size_t)nb * GZ_SLOT)) ||
+        if ((e = g->d_raw.reserve((size_t)len + 64)) || (e = g->d_tok.reserve((size_t)nb * 65536 * 4)) || (e = g->d_cand.reserve((size_t)nb * 65536 * 4)) || (e = g->d_slots.reserve((size_t)nb * GZ_SLOT)) ||
             (e = g->d_sizes.reserve((size_t)nb * 4)) || (e = g->d_off.reserve((size_t)(nb + 1) * 8)) || (e = g->d_out.reserve((size_t)nb * GZ_SLOT)))
             return e;
         HIPCHK(hipEventRecord(g->ev[0], st));
         HIPCHK(hipMemcpyAsync(g->d_raw.p, raw + r0, (size_t)len, hipMemcpyHostToDevice, st));
         HIPCHK(hipEventRecord(g->ev[1], st));
-        CRUMBLE_LAUNCH(k_gz_deflate, (unsigned)(nb < ncu ? nb : ncu), GZ_DT, st, nb, g->d_raw.as<uint8_t>(), len, level, g->d_tok.as<uint32_t>(),
+        CRUMBLE_LAUNCH(k_gz_deflate, (unsigned)(nb < ncu ? nb : ncu), GZ_DT, st, nb, g->d_raw.as<uint8_t>(), len, level, g->d_tok.as<uint32_t>(), g->d_cand.as<uint32_t>(),
                        g->d_slots.as<uint8_t>(), g->d_sizes.as<uint32_t>(), g->d_tabs.as<uint32_t>(), g->d_tabs.as<uint32_t>() + 256);
         CRUMBLE_LAUNCH(k_gz_offsets, 1, 1024, st, nb, g->d_sizes.as<uint32_t>(), g->d_off.as<int64_t>());
         CRUMBLE_LAUNCH(k_gz_gather, (unsigned)nb, 256, st, nb, g->d_slots.as<uint8_t>(), g->d_sizes.as<uint32_t>(), g->d_off.as<int64_t>(), g->d_out.as<uint8_t>());
@@ -219,6 +230,18 @@ extern "C" int crumble_gz_deflate(crumble_gz *g, const uint8_t *raw, int64_t raw
     }
     *out_len = produced; g->last_out = produced;
     return CRUMBLE_OK;
+}
+
+/* implementation choices that never change a result (the tests force both): "tokens" = auto | wave | lane */
+extern "C" int crumble_gz_set_option(crumble_gz *g, const char *name, const char *value)
+{
+    if (!g || !name || !value) return CRUMBLE_EINVAL;
+    if (!strcmp(name, "tokens")) {
+        if (!strcmp(value, "auto")) g->opt_lanes = -1; else if (!strcmp(value, "wave")) g->opt_lanes = 0; else if (!strcmp(value, "lane")) g->opt_lanes = 1;
+        else return CRUMBLE_EINVAL;
+        return CRUMBLE_OK;
+    }
+    return CRUMBLE_EINVAL;
 }
 
 /* stream time of the last crumble_gz_inflate / _deflate: host -> device copies, kernels, device -> host copies */

@@ -338,6 +338,276 @@ k_gz_tokens(int n_members, const GzBlock *__restrict__ blk, const uint8_t *__res
     if (lane == 0) { ntok_out[mi] = (uint32_t)tokpos; status[mi] = err; }
 }
 
+/* ---- k_gz_tokens_lanes: a LANE per member --------------------------------------------------------------------------
+ * The wave-per-member walk above keeps one lane of sixty-four busy; with thousands of members in a call the other way
+ * round pays: every lane walks its own member (bit buffer, position and state in its registers), the 64 walks advance in
+ * lockstep one symbol per loop iteration whatever each lane's symbol is (literal, match, a header field), and the decode
+ * tables live in a per-member scratch area in global memory (6.3 KiB each: served by the L2 / the Infinity Cache).  A
+ * lane that reaches a block header reads its code lengths one symbol per iteration like everybody else's symbols; the
+ * table fill is done for one lane at a time by the whole wave.  Same tokens, same status words as k_gz_tokens. */
+#define GZ2_WORDS    1600          /* scratch words per member */
+#define GZ2_LIT      0             /* [1024] literal/length table */
+#define GZ2_DST      1024          /* [256]  distance table */
+#define GZ2_LSYM     1280          /* u16[288] literal/length symbols in canonical order */
+#define GZ2_DSYM     1424          /* u16[32] */
+#define GZ2_CNT      1440          /* u16[6][16]: lcnt lfirst loffs dcnt dfirst doffs */
+#define GZ2_LENS     1488          /* u8[320] code lengths as read */
+
+/* the decode table of one member's block, by the whole wave (uniform arguments): lens[0, n) -> tab, sym, cnt / first / offs */
+__device__ __forceinline__ unsigned gz2_build(const uint8_t *lens, int n, int tb, uint32_t *tab, uint16_t *sym, uint16_t *cfo, bool is_dist, int lane)
+{
+    for (int i = lane; i < (1 << tb); i += 64) tab[i] = 0u;
+    int cnt[16];
+    #pragma unroll
+    for (int q = 0; q < 16; q++) cnt[q] = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int l = i0 + lane < n ? lens[i0 + lane] : 0;
+        #pragma unroll
+        for (int q = 1; q < 16; q++) cnt[q] += __popcll(__ballot(l == q));
+    }
+    int first[16], offs[16], left = 1, code = 0, o = 0;
+    bool over = false;
+    first[0] = 0; offs[0] = 0;
+    #pragma unroll
+    for (int l = 1; l < 16; l++) {
+        left <<= 1; left -= cnt[l];
+        if (left < 0) over = true;
+        code = (code + (l > 1 ? cnt[l - 1] : 0)) << 1;
+        first[l] = code; offs[l] = o; o += cnt[l];
+    }
+    if (over) return GZ_E_CODES;
+    if (lane < 16) {
+        int c = 0, f = 0, of = 0;
+        #pragma unroll
+        for (int q = 0; q < 16; q++) if (lane == q) { c = cnt[q]; f = first[q]; of = offs[q]; }
+        cfo[lane] = (uint16_t)c; cfo[16 + lane] = (uint16_t)f; cfo[32 + lane] = (uint16_t)of;
+    }
+    int seen[16];
+    #pragma unroll
+    for (int q = 0; q < 16; q++) seen[q] = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int s = i0 + lane, l = s < n ? lens[s] : 0;
+        int rank = 0, f = 0, of = 0;
+        #pragma unroll
+        for (int q = 1; q < 16; q++) {
+            const unsigned long long bm = __ballot(l == q);
+            if (l == q) { rank = seen[q] + __popcll(bm & ((1ull << lane) - 1ull)); f = first[q]; of = offs[q]; }
+            seen[q] += __popcll(bm);
+        }
+        if (l) {
+            const uint32_t rev = gz_bitrev((uint32_t)(f + rank), l);
+            sym[of + rank] = (uint16_t)s;
+            if (l <= tb) {
+                const uint32_t e = is_dist ? gz_dist_entry(s, l) : gz_lit_entry(s, l);
+                for (uint32_t j = rev; j < (1u << tb); j += 1u << l) tab[j] = e;
+            } else tab[rev & ((1u << tb) - 1u)] = GZ_ENTRY(0, GZ_K_LONG, 0, 0);
+        }
+    }
+    return 0;
+}
+
+__global__ void __launch_bounds__(64)
+k_gz_tokens_lanes(int n_members, const GzBlock *__restrict__ blk, const uint8_t *__restrict__ comp, uint32_t *__restrict__ gtok,
+                  const int64_t *__restrict__ tok_off, uint32_t *__restrict__ ntok_out, uint32_t *__restrict__ status,
+                  uint32_t *__restrict__ scratch)
+{
+    const int lane = threadIdx.x & 63;
+    const int mi = (int)blockIdx.x * 64 + lane;
+    const bool valid = mi < n_members;
+    GzBlock m;
+    m.coff = 0; m.uoff = 0; m.clen = 0; m.ulen = 0; m.crc = 0; m.pad_ = 0;
+    if (valid) m = blk[mi];
+    const uint8_t *src = comp + m.coff;
+    uint32_t *S = scratch + (size_t)(valid ? mi : 0) * GZ2_WORDS;
+    uint32_t *tout = gtok + (valid ? tok_off[mi] : 0);
+    enum { S_HDR = 0, S_CLEN = 1, S_LENS = 2, S_BUILD = 3, S_DECODE = 4, S_STORED = 5, S_DONE = 6 };
+    int state = valid ? S_HDR : S_DONE;
+    uint64_t bb = 0; int bc = 0, ip = 0;
+    int bfinal = 0, stored_left = 0, k = 0, need = 0, hlit = 0, hdist = 0, hclen = 0, prev = 0;
+    uint64_t clpack = 0, cnt7 = 0, first7 = 0, sortlo = 0, sorthi = 0;
+    uint32_t litacc = 0; int litn = 0, ntok = 0;
+    int outpos = 0;
+    unsigned err = 0;
+    const int ulen = (int)m.ulen, clen = (int)m.clen;
+    uint8_t *lens = (uint8_t *)(S + GZ2_LENS);
+
+#define G2_TAKE(n_) do { bb >>= (n_); bc -= (n_); } while (0)
+#define G2_EMIT(t_) do { tout[ntok++] = (t_); } while (0)
+#define G2_FLUSH_LIT() do { if (litn) { G2_EMIT(litacc | ((uint32_t)litn << 24)); litacc = 0; litn = 0; } } while (0)
+#define G2_FAIL(e_) do { err |= (e_); state = S_DONE; } while (0)
+    for (;;) {
+        if (__ballot(state != S_DONE) == 0ull) break;
+        if (state != S_DONE) {
+            if (bc <= 32) { bb |= (uint64_t)((const GzU32u *)(src + ip))->v << bc; bc += 32; ip += 4; }
+            if (ip > clen + 12) G2_FAIL(GZ_E_INPUT);
+        }
+        if (state == S_DECODE) {
+            uint32_t e = S[GZ2_LIT + (uint32_t)(bb & ((1u << GZ_TB) - 1u))];
+            if (((e >> 5) & 7u) == GZ_K_LONG) {
+                const uint16_t *cfo = (const uint16_t *)(S + GZ2_CNT);
+                e = gz_decode_long(bb, cfo, cfo + 16, cfo + 32, (const uint16_t *)(S + GZ2_LSYM), false);
+            }
+            const uint32_t kind = (e >> 5) & 7u;
+            if (kind == 0u) G2_FAIL(GZ_E_SYMBOL);
+            else {
+                G2_TAKE((int)(e & 31u));
+                if (kind == GZ_K_LIT) {
+                    if (outpos >= ulen) G2_FAIL(GZ_E_DIST);
+                    else { litacc |= ((e >> 16) & 0xffu) << (8 * litn); litn++; outpos++; if (litn == 3) G2_FLUSH_LIT(); }
+                } else if (kind == GZ_K_EOB) state = bfinal ? S_DONE : S_HDR;
+                else {
+                    const int xb = (int)((e >> 8) & 31u);
+                    const int len = (int)(e >> 16) + (int)(bb & ((1u << xb) - 1u));
+                    G2_TAKE(xb);
+                    if (bc <= 32) { bb |= (uint64_t)((const GzU32u *)(src + ip))->v << bc; bc += 32; ip += 4; }
+                    uint32_t d = S[GZ2_DST + (uint32_t)(bb & ((1u << GZ_DB) - 1u))];
+                    if (((d >> 5) & 7u) == GZ_K_LONG) {
+                        const uint16_t *cfo = (const uint16_t *)(S + GZ2_CNT) + 48;
+                        d = gz_decode_long(bb, cfo, cfo + 16, cfo + 32, (const uint16_t *)(S + GZ2_DSYM), true);
+                    }
+                    if (((d >> 5) & 7u) != GZ_K_LEN) G2_FAIL(GZ_E_SYMBOL);
+                    else {
+                        G2_TAKE((int)(d & 31u));
+                        const int dxb = (int)((d >> 8) & 31u);
+                        const int dist = (int)(d >> 16) + (int)(bb & ((1u << dxb) - 1u));
+                        G2_TAKE(dxb);
+                        if (dist > outpos || outpos + len > ulen) G2_FAIL(GZ_E_DIST);
+                        else { G2_FLUSH_LIT(); G2_EMIT(GZ_TOK_MATCH(len, dist)); outpos += len; }
+                    }
+                }
+            }
+        } else if (state == S_STORED) {
+            if (stored_left == 0) state = bfinal ? S_DONE : S_HDR;
+            else if (outpos >= ulen) G2_FAIL(GZ_E_DIST);
+            else {
+                litacc |= (uint32_t)(bb & 0xffu) << (8 * litn); litn++;
+                G2_TAKE(8); stored_left--; outpos++;
+                if (litn == 3) G2_FLUSH_LIT();
+            }
+        } else if (state == S_HDR) {
+            bfinal = (int)(bb & 1u);
+            const int bt = (int)((bb >> 1) & 3u);
+            G2_TAKE(3);
+            if (bt == 0) {
+                G2_TAKE(bc & 7);
+                if (bc < 32) { bb |= (uint64_t)((const GzU32u *)(src + ip))->v << bc; bc += 32; ip += 4; }
+                const uint32_t ln = (uint32_t)(bb & 0xffffu), nl = (uint32_t)((bb >> 16) & 0xffffu);
+                G2_TAKE(32);
+                if ((ln ^ nl) != 0xffffu) G2_FAIL(GZ_E_BTYPE);
+                else { stored_left = (int)ln; state = S_STORED; }
+            } else if (bt == 1) {
+                for (int sy = 0; sy < 288; sy++) lens[sy] = (uint8_t)(sy < 144 ? 8 : sy < 256 ? 9 : sy < 280 ? 7 : 8);
+                for (int sy = 0; sy < 30; sy++) lens[288 + sy] = 5;
+                hlit = 288; hdist = 30;
+                state = S_BUILD;
+            } else if (bt == 2) {
+                hlit = (int)(bb & 31u) + 257; hdist = (int)((bb >> 5) & 31u) + 1; hclen = (int)((bb >> 10) & 15u) + 4;
+                G2_TAKE(14);
+                if (hlit > 286 || hdist > 30) G2_FAIL(GZ_E_CODES);
+                else { clpack = 0; k = 0; state = S_CLEN; }
+            } else G2_FAIL(GZ_E_BTYPE);
+        } else if (state == S_CLEN) {
+            /* one 3-bit length of the code-length code per iteration, packed by symbol into 57 bits */
+            const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            int sy = 0;
+            #pragma unroll
+            for (int q = 0; q < 19; q++) if (k == q) sy = order[q];
+            clpack |= (uint64_t)(bb & 7u) << (3 * sy);
+            G2_TAKE(3);
+            if (++k == hclen) {
+                /* the canonical decoder of this code in registers: counts (5 bits each), first codes (8 bits each), the
+                 * symbols in canonical order (5 bits each, nineteen of them over two words) */
+                cnt7 = 0; first7 = 0; sortlo = 0; sorthi = 0;
+                int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < 19; i++) { const int l = (int)((clpack >> (3 * i)) & 7u);
+                    #pragma unroll
+                    for (int q = 1; q < 8; q++) c[q] += l == q; }
+                int left = 1, code = 0, nx[8];
+                nx[0] = 0;
+                {
+                    int o = 0;
+                    #pragma unroll
+                    for (int l = 1; l < 8; l++) {
+                        left <<= 1; left -= c[l];
+                        code = (code + (l > 1 ? c[l - 1] : 0)) << 1;
+                        cnt7 |= (uint64_t)c[l] << (5 * (l - 1)); first7 |= (uint64_t)(code & 255) << (8 * (l - 1));
+                        nx[l] = o; o += c[l];
+                    }
+                }
+                if (left < 0) G2_FAIL(GZ_E_CODES);
+                else {
+                    for (int i = 0; i < 19; i++) {
+                        const int l = (int)((clpack >> (3 * i)) & 7u);
+                        if (!l) continue;
+                        int pos = 0;
+                        #pragma unroll
+                        for (int q = 1; q < 8; q++) if (l == q) pos = nx[q]++;
+                        if (pos < 12) sortlo |= (uint64_t)i << (5 * pos); else sorthi |= (uint64_t)i << (5 * (pos - 12));
+                    }
+                    k = 0; prev = 0; need = hlit + hdist;
+                    state = S_LENS;
+                }
+            }
+        } else if (state == S_LENS) {
+            /* one code-length symbol per iteration */
+            int sy = -1; uint32_t code = 0; uint64_t t = bb; int offs = 0;
+            #pragma unroll
+            for (int l = 1; l <= 7; l++) {
+                code = (code << 1) | (uint32_t)(t & 1u); t >>= 1;
+                const int cn = (int)((cnt7 >> (5 * (l - 1))) & 31u), cf = (int)((first7 >> (8 * (l - 1))) & 255u);
+                if (sy < 0 && cn && (int)code >= cf && (int)code - cf < cn) {
+                    const int pos = offs + (int)code - cf;
+                    sy = (int)((pos < 12 ? sortlo >> (5 * pos) : sorthi >> (5 * (pos - 12))) & 31u);
+                    G2_TAKE(l);
+                }
+                offs += cn;
+            }
+            if (sy < 0) G2_FAIL(GZ_E_SYMBOL);
+            else if (sy < 16) { lens[k++] = (uint8_t)sy; prev = sy; }
+            else {
+                int rep, val = 0;
+                bool bad = false;
+                if (sy == 16) { bad = k == 0; val = prev; rep = 3 + (int)(bb & 3u); G2_TAKE(2); }
+                else if (sy == 17) { rep = 3 + (int)(bb & 7u); G2_TAKE(3); }
+                else { rep = 11 + (int)(bb & 127u); G2_TAKE(7); }
+                if (bad || k + rep > need) G2_FAIL(GZ_E_CODES);
+                else { for (int r = 0; r < rep; r++) lens[k++] = (uint8_t)val; if (sy != 16) prev = 0; }
+            }
+            if (state == S_LENS && k >= need) {
+                if (lens[256] == 0) G2_FAIL(GZ_E_CODES);
+                else state = S_BUILD;
+            }
+        }
+        /* ---- the table fills: one requesting lane at a time, by all sixty-four */
+        unsigned long long bm = __ballot(state == S_BUILD);
+        if (bm) {
+            KC2_FENCE_WG();                                  /* the lanes' code lengths are in memory */
+            while (bm) {
+                const int L = __builtin_ctzll(bm);
+                bm &= bm - 1ull;
+                const int mL = (int)blockIdx.x * 64 + L;
+                uint32_t *SL = scratch + (size_t)mL * GZ2_WORDS;
+                const int nl = READLANE(hlit, L), nd = READLANE(hdist, L);
+                const uint8_t *lensL = (const uint8_t *)(SL + GZ2_LENS);
+                unsigned e = gz2_build(lensL, nl, GZ_TB, SL + GZ2_LIT, (uint16_t *)(SL + GZ2_LSYM), (uint16_t *)(SL + GZ2_CNT), false, lane);
+                e |= gz2_build(lensL + nl, nd, GZ_DB, SL + GZ2_DST, (uint16_t *)(SL + GZ2_DSYM), (uint16_t *)(SL + GZ2_CNT) + 48, true, lane);
+                if (lane == L) { if (e) G2_FAIL(e); else state = S_DECODE; }
+            }
+            KC2_FENCE_WG();                                  /* the tables are in memory before anybody looks something up */
+        }
+    }
+    if (valid) {
+        G2_FLUSH_LIT();
+        if (!err && outpos != ulen) err |= GZ_E_SIZE;
+        if (!err && (int64_t)ip * 8 - bc > (int64_t)clen * 8) err |= GZ_E_INPUT;
+        ntok_out[mi] = (uint32_t)ntok; status[mi] = err;
+    }
+#undef G2_TAKE
+#undef G2_EMIT
+#undef G2_FLUSH_LIT
+#undef G2_FAIL
+}
+
 /* ---- CRC-32 (the gzip one: reflected 0xEDB88320), slices combined the way zlib's crc32_combine does ----------------- */
 #define GZ_POLY 0xedb88320u
 HD uint32_t gz_multmodp(uint32_t a, uint32_t b)
@@ -382,6 +652,16 @@ __device__ __forceinline__ uint32_t gz_crc_block(const uint8_t *img, int n, cons
     __syncthreads();
     return r;
 }
+
+/* a workgroup barrier for what went through LDS only: __syncthreads() also waits for the wave's outstanding GLOBAL stores
+ * (vmcnt(0): a microsecond per barrier when every step of a loop leaves a store behind), this one for LDS traffic alone.
+ * Whatever was stored to global memory in front of it is NOT ordered by it: a __syncthreads() must follow before another
+ * wave reads those bytes. */
+#ifdef CRUMBLE_EMU
+#define GZ_LDS_BARRIER() __syncthreads()
+#else
+#define GZ_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 
 /* does any thread of the workgroup say so?  (flag: a word of LDS) */
 __device__ __forceinline__ bool gz_any(bool p, int32_t *flag, int tid)
@@ -504,6 +784,10 @@ k_gz_resolve(int n_members, const GzBlock *__restrict__ blk, const uint32_t *__r
 #define GZ_HB        13            /* bits of each of the two hash tables */
 #define GZ_MAXBLK    65280         /* 0xff00: bytes per block (htslib's BGZF_BLOCK_SIZE) */
 #define GZ_SLOT      65536         /* bytes of a member's output slot (header + payload + trailer never exceed it) */
+#define GZ_RANGE     4096          /* positions parsed by one wave (sixteen ranges per block) */
+#ifndef GZ_CMPMAX
+#define GZ_CMPMAX    258           /* bytes a hash / repeat-distance candidate is compared over */
+#endif
 #define GZ_NICE      16            /* a run at least this long: the hash candidates are not looked at */
 
 struct GzHuff {                    /* scratch of one code construction (a wave each) */
@@ -517,7 +801,6 @@ struct GzDeflate {
     uint32_t h4[1 << GZ_HB];       /* position + 1 of the latest 4-byte / 6-byte context with this hash (0: none) */
     uint32_t h6[1 << GZ_HB];       /* (both become the output bit buffer once the tokens are made) */
     uint32_t eq[2048 + 8];         /* bit p: data[p] == data[p - 1] */
-    uint16_t mlen[GZ_SUB], mdist[GZ_SUB];
     uint16_t hk[2 * GZ_SUB];       /* the sub-block's hash keys: 4-byte contexts, then 6-byte ones */
     uint32_t hist_l[288], hist_d[32], hist_b[19];
     uint8_t  len_l[288], len_d[32], len_b[19];
@@ -526,7 +809,8 @@ struct GzDeflate {
     GzHuff   hf[2];
     uint32_t crc_tab[256], x2n[32], red[GZ_DT];
     int32_t  scan[GZ_DT / 64 + 1];
-    int32_t  s_next, lastm, ntok, anyflag, n_rl, hlit, hdist, hclen, use_stored;
+    int32_t  lastm[2], anyflag, n_rl, hlit, hdist, hclen, use_stored;
+    int32_t  rcount[GZ_DT / 64];   /* tokens of each range */
     uint32_t bitpos;               /* bits written so far (header, by lane 0) */
 };
 
@@ -674,6 +958,79 @@ __device__ __forceinline__ void gz_putbits(uint32_t *buf, uint32_t &bitpos, uint
     bitpos += (uint32_t)nb;
 }
 
+/* Pass B: the greedy parse, sixteen ranges of 4096 positions at once, a wave each.  A match is cut at the end of its
+ * range, so every range's parse starts at its first position and needs nothing from its neighbour (the price: at most
+ * fifteen shortened matches per block).  Inside a range the wave goes sub-block by sub-block: lane l holds the four
+ * positions l, l + 64, l + 128, l + 192; which of them have a match is four 64-bit ballots; the walk -- literals up to
+ * the next position with a match, that match, on to its end -- is scalar code, a match's length fetched by readlane.
+ * Tokens go to the range's own 4096 slots of tk[], their number to D.rcount[]. */
+__device__ __noinline__ void gz_parse_ranges(GzDeflate &D, uint32_t *__restrict__ tk, const uint32_t *__restrict__ cand, int N, int level, int lane, int wv)
+{   /* (a function of its own, not inlined: its sixty-four-bit masks and per-word loops would otherwise raise the register
+     * pressure of the candidate loop in front of it, which runs 255 times per block) */
+    if (level > 0 && N > 0) {
+        const int r0 = wv * GZ_RANGE, r1 = r0 + GZ_RANGE < N ? r0 + GZ_RANGE : N;
+        int sp_abs = r0, nt = 0;                            /* next uncovered position, tokens of the range so far (uniform) */
+        uint32_t *rtk = tk + r0;
+        for (int base = r0; base < r1; base += GZ_SUB) {
+            int ml[4], md[4];
+            unsigned long long mm[4], sel[4] = {0ull, 0ull, 0ull, 0ull};
+            const int nend = r1 - base < GZ_SUB ? r1 - base : GZ_SUB;
+            #pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int p = base + lane + 64 * q;
+                const uint32_t c = p < r1 ? cand[p] : 0u;
+                int l = (int)(c >> 16);
+                if (l > r1 - p) l = r1 - p;                  /* cut at the end of the range */
+                ml[q] = l >= 3 ? l : 0; md[q] = (int)(c & 0xffffu);
+                mm[q] = __ballot(ml[q] >= 3);
+            }
+            int sp = sp_abs - base;
+            if (sp < 0) sp = 0;
+            #pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int wend = nend - 64 * w < 64 ? nend - 64 * w : 64;        /* valid positions of this word */
+                int lo = sp - 64 * w;
+                if (lo < 0) lo = 0;
+                while (lo < wend) {
+                    const unsigned long long m = mm[w] & (~0ull << lo);
+                    if (m == 0ull) {                                               /* literals to the end of the word */
+                        sel[w] |= (wend == 64 ? ~0ull : ((1ull << wend) - 1ull)) & (~0ull << lo);
+                        lo = wend;
+                        break;
+                    }
+                    const int b = __builtin_ctzll(m);
+                    sel[w] |= ((2ull << b) - 1ull) & (~0ull << lo);              /* the literals in front of it, and the match */
+                    lo = b + READLANE(ml[w], b);
+                }
+                if (64 * w + lo > sp) sp = 64 * w + lo;
+            }
+            if (base + sp > sp_abs) sp_abs = base + sp;
+            /* the tokens in position order: word 0's positions, then word 1's ... (position = 64 * word + lane) */
+            const unsigned long long below = (1ull << lane) - 1ull;
+            #pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if ((sel[q] >> lane) & 1ull) {
+                    const int p = base + lane + 64 * q;
+                    uint32_t tokv;
+                    if (ml[q] >= 3) {
+                        const int d = md[q] + 1;
+                        tokv = 0x80000000u | ((uint32_t)(ml[q] - 3) << 16) | (uint32_t)(d - 1);
+                        int xb, xv;
+                        atomicAdd(&D.hist_l[gz_len_sym(ml[q], &xb, &xv)], 1u);
+                        atomicAdd(&D.hist_d[gz_dist_sym(d, &xb, &xv)], 1u);
+                    } else {
+                        tokv = D.data[p];
+                        atomicAdd(&D.hist_l[tokv], 1u);
+                    }
+                    rtk[nt + __popcll(sel[q] & below)] = tokv;
+                }
+                nt += __popcll(sel[q]);
+            }
+        }
+        if (lane == 0) D.rcount[wv] = r0 < N ? nt : 0;
+    } else if (lane == 0) D.rcount[wv] = 0;
+}
+
 #if defined(GZ_STAMP) && !defined(CRUMBLE_EMU)      /* diagnostic build: shader cycles per phase of k_gz_deflate, summed over workgroups */
 __device__ unsigned long long gz_stamp[16];
 #define GZ_STAMP_AT(k_) do { if (tid == 0) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); atomicAdd(&gz_stamp[k_], (unsigned long long)(t_ - tlast)); tlast = t_; } } while (0)
@@ -683,7 +1040,7 @@ __device__ unsigned long long gz_stamp[16];
 #define GZ_STAMP_DECL do { } while (0)
 #endif
 __global__ void __launch_bounds__(GZ_DT)
-k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int level, uint32_t *__restrict__ gtok,
+k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int level, uint32_t *__restrict__ gtok, uint32_t *__restrict__ gcand,
              uint8_t *__restrict__ slots, uint32_t *__restrict__ sizes, const uint32_t *__restrict__ crc_tab, const uint32_t *__restrict__ x2n)
 {
     __shared__ GzDeflate D;
@@ -693,6 +1050,7 @@ k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int
     const int N = (int)(raw_len - b0 < GZ_MAXBLK ? raw_len - b0 : GZ_MAXBLK);
     const uint8_t *src = raw + b0;
     uint32_t *tk = gtok + (size_t)bi * 65536;
+    uint32_t *cand = gcand + (size_t)bi * 65536;            /* per position: best match length << 16 | distance - 1 */
     uint8_t *slot = slots + (size_t)bi * GZ_SLOT;
     __syncthreads();                                          /* (the previous block's stores out of LDS are done) */
     GZ_STAMP_DECL;
@@ -710,7 +1068,7 @@ k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int
     if (tid < 19) D.hist_b[tid] = 0u;
     if (tid < 256) D.crc_tab[tid] = crc_tab[tid];
     if (tid < 32) D.x2n[tid] = x2n[tid];
-    if (tid == 0) { D.s_next = 0; D.ntok = 0; D.bitpos = 0; D.use_stored = 0; }
+    if (tid == 0) { D.lastm[0] = -1; D.lastm[1] = -1; D.bitpos = 0; D.use_stored = 0; }
     __syncthreads();
     const uint32_t crc = gz_crc_block(D.data, N, D.crc_tab, D.x2n, D.red, tid, GZ_DT);
     /* eq[]: bit p set when byte p repeats byte p - 1 */
@@ -721,11 +1079,10 @@ k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int
     }
     __syncthreads();
     GZ_STAMP_AT(0);
-    int last_dist = 0;                                        /* the distance of the latest match taken (uniform) */
-    /* Two workgroup barriers per sub-block of 256 positions:
-     *   1  every thread: one candidate of one position (four lanes per position), the best of the four to LDS
-     *   2  wave 0: the greedy parse of the sub-block, its tokens and histograms, the carry into the next sub-block; waves
-     *      1..15 meanwhile put the sub-block's positions into the hash tables */
+    int last_dist = 0;                                        /* the distance of a recent match (uniform): the "same distance again" candidate */
+    /* Pass A, two workgroup barriers per sub-block of 256 positions: every thread one candidate of one position (four lanes per
+     * position), the best of the four into cand[] (global: 256 KiB per block, read again by pass B); then the sub-block's
+     * positions into the hash tables.  Nothing here depends on which matches the parse will take. */
     if (level > 0 && N > 0)
     for (int base = 0; base < N; base += GZ_SUB) {
         const int j = tid >> 2, cnd = tid & 3;               /* position of the sub-block, candidate kind */
@@ -760,13 +1117,18 @@ k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int
             else if (run < GZ_NICE) {
                 if (cnd == 0 && maxl >= 4) cand = (int)D.h4[k4] - 1;
                 if (cnd == 1 && maxl >= 6) cand = (int)D.h6[k6] - 1;
+#ifndef GZ_EXP_NOREP
                 if (cnd == 3 && last_dist > 1 && P - last_dist >= 0) cand = P - last_dist;
+#endif
                 if (cand >= 0 && P - cand <= 32768) {
                     /* common prefix of the bytes at cand and at P, eight at a time (aligned words, shifted into place) */
                     const int cw = cand >> 2, csh = 8 * (cand & 3);
+                    /* (at most GZ_CMPMAX bytes: one lane's long compare holds its whole workgroup at the barrier, and a longer
+                     * match is simply taken in pieces) */
+                    const int cmax = maxl < GZ_CMPMAX ? maxl : GZ_CMPMAX;
                     int l = 0;
                     uint64_t pv = b8;
-                    for (int it = 0; l < maxl; it++) {
+                    for (int it = 0; l < cmax; it++) {
                         const uint32_t c0 = dw[cw + 2 * it], c1 = dw[cw + 2 * it + 1], c2 = dw[cw + 2 * it + 2];
                         const uint64_t ct = ((uint64_t)c1 << 32) | c0;
                         const uint64_t cv = csh ? (ct >> csh) | ((uint64_t)c2 << (64 - csh)) : ct;
@@ -779,7 +1141,7 @@ k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int
                         if (x) { l += __builtin_ctzll(x) >> 3; break; }
                         l += 8;
                     }
-                    if (l > maxl) l = maxl;
+                    if (l > cmax) l = cmax;
                     if (l >= 4) { blen = l; bdist = P - cand; }
                 }
             }
@@ -790,90 +1152,31 @@ k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int
             if (ol > blen || (ol == blen && ol > 0 && od < bdist)) { blen = ol; bdist = od; }
         }
         if (cnd == 0) {
-            D.mlen[j] = (uint16_t)blen; D.mdist[j] = (uint16_t)(bdist ? bdist - 1 : 0);
+#ifndef GZ_EXP_NOCAND
+            if (P < N) cand[P] = ((uint32_t)blen << 16) | (uint32_t)(bdist ? bdist - 1 : 0);
+#endif
+#ifndef GZ_EXP_NOLASTM
+            if (blen >= 3) atomicMax(&D.lastm[(base / GZ_SUB) & 1], (j << 16) | (bdist - 1));
+#endif
         }
-        __syncthreads();                                                                    /* ---- 1 */
+        GZ_LDS_BARRIER();                                                                   /* ---- 1 */
         GZ_STAMP_AT(1);
-        const int s0 = D.s_next;
-        if (wv == 0) {
-            /* The greedy parse and the tokens, by wave 0 alone and without a trip through LDS per token: lane l holds the
-             * four positions l, l + 64, l + 128, l + 192; which positions have a match is four 64-bit ballots; the walk --
-             * literals up to the next position with a match, that match, on to its end -- is the same scalar code in every
-             * lane (one step per MATCH taken, not per token), a match's length fetched from its lane by readlane. */
-            int ml[4], md[4];
-            unsigned long long mm[4], sel[4] = {0ull, 0ull, 0ull, 0ull};
-            const int nend = N - base < GZ_SUB ? N - base : GZ_SUB;
-            const int ntok0 = UNIFORM(D.ntok);                   /* (read by every lane in front of the ballots: lane 0 writes it at the end) */
-            #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                ml[q] = D.mlen[lane + 64 * q]; md[q] = D.mdist[lane + 64 * q];
-                mm[q] = __ballot(ml[q] >= 3 && lane + 64 * q < nend);
+        {   /* the hash tables take the sub-block's positions (the largest position wins: deterministic) */
+            if (tid < 2 * GZ_SUB) {
+                const int jj = tid >> 1, PP = base + jj;
+                if (tid & 1) { if (PP + 6 <= N) atomicMax(&D.h6[D.hk[GZ_SUB + jj]], (uint32_t)PP + 1u); }
+                else         { if (PP + 4 <= N) atomicMax(&D.h4[D.hk[jj]], (uint32_t)PP + 1u); }
             }
-            /* (values read from LDS are wave-uniform here but not known to be: said so, the walk below stays in scalar
-             * registers -- otherwise every readlane becomes a loop over the lanes) */
-            int sp = UNIFORM(s0) - base, lastd = -1;
-            if (sp < 0) sp = 0;
-            /* word by word (static indices: no selects between the four masks), inside a word from match to match */
-            #pragma unroll
-            for (int w = 0; w < 4; w++) {
-                const int wend = nend - 64 * w < 64 ? nend - 64 * w : 64;        /* valid positions of this word */
-                int lo = sp - 64 * w;
-                if (lo < 0) lo = 0;
-                while (lo < wend) {
-                    const unsigned long long m = mm[w] & (~0ull << lo);
-                    if (m == 0ull) {                                               /* literals to the end of the word */
-                        sel[w] |= (wend == 64 ? ~0ull : ((1ull << wend) - 1ull)) & (~0ull << lo);
-                        lo = wend;
-                        break;
-                    }
-                    const int b = __builtin_ctzll(m);
-                    sel[w] |= ((2ull << b) - 1ull) & (~0ull << lo);              /* the literals in front of it, and the match */
-                    lastd = READLANE(md[w], b);
-                    lo = b + READLANE(ml[w], b);
-                }
-                if (64 * w + lo > sp) sp = 64 * w + lo;
-            }
-            /* the tokens in position order: word 0's positions, then word 1's ... (position = 64 * word + lane) */
-            int before = ntok0;
-            const unsigned long long below = (1ull << lane) - 1ull;
-            #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if ((sel[q] >> lane) & 1ull) {
-                    const int p = base + lane + 64 * q;
-                    uint32_t tokv;
-                    if (ml[q] >= 3) {
-                        const int d = md[q] + 1;
-                        tokv = 0x80000000u | ((uint32_t)(ml[q] - 3) << 16) | (uint32_t)(d - 1);
-                        int xb, xv;
-                        atomicAdd(&D.hist_l[gz_len_sym(ml[q], &xb, &xv)], 1u);
-                        atomicAdd(&D.hist_d[gz_dist_sym(d, &xb, &xv)], 1u);
-                    } else {
-                        tokv = D.data[p];
-                        atomicAdd(&D.hist_l[tokv], 1u);
-                    }
-                    tk[before + __popcll(sel[q] & below)] = tokv;
-                }
-                before += __popcll(sel[q]);
-            }
-            WAVE_SYNC();
-            if (lane == 0) { D.ntok = before; D.lastm = lastd; if (s0 < base + GZ_SUB) D.s_next = base + sp; }
-        } else {
-            /* the hash tables take the sub-block's positions (the largest position wins: deterministic) */
-            const int t = tid - 64;
-            if (t < 2 * GZ_SUB) {
-                const int jj = t >> 1, PP = base + jj;
-                if (t & 1) { if (PP + 6 <= N) atomicMax(&D.h6[D.hk[GZ_SUB + jj]], (uint32_t)PP + 1u); }
-                else       { if (PP + 4 <= N) atomicMax(&D.h4[D.hk[jj]], (uint32_t)PP + 1u); }
-            }
+            const int lm = D.lastm[(base / GZ_SUB) & 1];
+            if (lm >= 0) last_dist = (lm & 0xffff) + 1;
+            if (tid == 0) D.lastm[((base / GZ_SUB) + 1) & 1] = -1;      /* (the other one: the next sub-block's, untouched since its readers two barriers ago) */
         }
-        __syncthreads();                                                                    /* ---- 2 */
+        GZ_LDS_BARRIER();                                                                   /* ---- 2 */
         GZ_STAMP_AT(2);
-        const int lm = D.lastm;
-        if (lm >= 0) last_dist = lm + 1;
-        /* (D.lastm, D.ntok and D.s_next are next written behind barrier 1 of the next sub-block: every thread has read them by then) */
     }
     __syncthreads();
-    const int ntok = (level > 0) ? D.ntok : 0;
+    gz_parse_ranges(D, tk, cand, N, level, lane, wv);
+    __syncthreads();
     /* ---- the codes */
     if (tid == 0) D.hist_l[256] = 1u;                        /* end of block */
     __syncthreads();
@@ -999,37 +1302,43 @@ k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int
     } else {
         /* ---- every token's bits at its place: prefix sum of the bit counts, OR into the buffer */
         uint32_t bitbase = D.bitpos;
-        for (int c = 0; c <= ntok; c += GZ_DT) {              /* (<=: the end-of-block code is token number ntok) */
-            const int i = c + tid;
-            uint64_t v = 0; int nb = 0;
-            if (i < ntok) {
-                const uint32_t t = tk[i];
-                if (t >> 31) {
-                    const int l = (int)((t >> 16) & 0xffu) + 3, d = (int)(t & 0x7fffu) + 1;
-                    int xb, xv;
-                    const int ls = gz_len_sym(l, &xb, &xv);
-                    v = D.code_l[ls]; nb = D.len_l[ls];
-                    v |= (uint64_t)xv << nb; nb += xb;
-                    const int ds = gz_dist_sym(d, &xb, &xv);
-                    v |= (uint64_t)D.code_d[ds] << nb; nb += D.len_d[ds];
-                    v |= (uint64_t)xv << nb; nb += xb;
-                } else { v = D.code_l[t & 0xffu]; nb = D.len_l[t & 0xffu]; }
-            } else if (i == ntok) { v = D.code_l[256]; nb = D.len_l[256]; }
-            int incl = nb;
-            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-            if (lane == 63) D.scan[wv] = incl;
-            __syncthreads();
-            uint32_t wbase = 0, total = 0;
-            for (int w = 0; w < GZ_DT / 64; w++) { const uint32_t s = (uint32_t)D.scan[w]; if (w < wv) wbase += s; total += s; }
-            if (nb) {
-                const uint32_t bp = bitbase + wbase + (uint32_t)(incl - nb);
-                const uint32_t w = bp >> 5, sh = bp & 31u;
-                atomicOr(&obuf[w], (uint32_t)(v << sh));
-                if (sh + (uint32_t)nb > 32u) atomicOr(&obuf[w + 1], (uint32_t)(v >> (32u - sh)));
-                if (sh + (uint32_t)nb > 64u) atomicOr(&obuf[w + 2], (uint32_t)(v >> (64u - sh)));
+        for (int rg = 0; rg <= GZ_DT / 64; rg++) {           /* the ranges in order; one more round for the end-of-block code */
+            const bool last = rg == GZ_DT / 64;
+            const int rn = last ? 1 : D.rcount[rg];
+            const uint32_t *rtk = tk + (last ? 0 : rg * GZ_RANGE);
+            for (int c = 0; c < rn; c += GZ_DT) {
+                const int i = c + tid;
+                uint64_t v = 0; int nb = 0;
+                if (last) { if (tid == 0) { v = D.code_l[256]; nb = D.len_l[256]; } }
+                else if (i < rn) {
+                    const uint32_t t = rtk[i];
+                    if (t >> 31) {
+                        const int l = (int)((t >> 16) & 0xffu) + 3, d = (int)(t & 0x7fffu) + 1;
+                        int xb, xv;
+                        const int ls = gz_len_sym(l, &xb, &xv);
+                        v = D.code_l[ls]; nb = D.len_l[ls];
+                        v |= (uint64_t)xv << nb; nb += xb;
+                        const int ds = gz_dist_sym(d, &xb, &xv);
+                        v |= (uint64_t)D.code_d[ds] << nb; nb += D.len_d[ds];
+                        v |= (uint64_t)xv << nb; nb += xb;
+                    } else { v = D.code_l[t & 0xffu]; nb = D.len_l[t & 0xffu]; }
+                }
+                int incl = nb;
+                for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+                if (lane == 63) D.scan[wv] = incl;
+                __syncthreads();
+                uint32_t wbase = 0, total = 0;
+                for (int w = 0; w < GZ_DT / 64; w++) { const uint32_t sc = (uint32_t)D.scan[w]; if (w < wv) wbase += sc; total += sc; }
+                if (nb) {
+                    const uint32_t bp = bitbase + wbase + (uint32_t)(incl - nb);
+                    const uint32_t w = bp >> 5, sh = bp & 31u;
+                    atomicOr(&obuf[w], (uint32_t)(v << sh));
+                    if (sh + (uint32_t)nb > 32u) atomicOr(&obuf[w + 1], (uint32_t)(v >> (32u - sh)));
+                    if (sh + (uint32_t)nb > 64u) atomicOr(&obuf[w + 2], (uint32_t)(v >> (64u - sh)));
+                }
+                bitbase += total;
+                __syncthreads();
             }
-            bitbase += total;
-            __syncthreads();
         }
         payload = (bitbase + 7u) >> 3;
         for (uint32_t i = tid; i < payload; i += GZ_DT) slot[18 + i] = ((const uint8_t *)obuf)[i];

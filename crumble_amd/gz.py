@@ -29,6 +29,8 @@ def _sig(L):
     L.crumble_gz_deflate_bound.argtypes = [i64]
     L.crumble_gz_deflate.restype = C.c_int
     L.crumble_gz_deflate.argtypes = [vp, vp, i64, C.c_int, vp, i64, C.POINTER(i64)]
+    L.crumble_gz_set_option.restype = C.c_int
+    L.crumble_gz_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.crumble_gz_times.restype = C.c_int
     L.crumble_gz_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     return L
@@ -55,6 +57,11 @@ class GzCodec:
         self.h = self.L.crumble_gz_create(device, C.byref(err))
         if not self.h:
             raise CrumbleError(err.value, "crumble_gz_create", self.L)
+
+    def set_option(self, name, value):
+        rc = self.L.crumble_gz_set_option(self.h, name.encode(), value.encode())
+        if rc:
+            raise CrumbleError(rc, "crumble_gz_set_option", self.L)
 
     def close(self):
         if self.h:

@@ -47,7 +47,7 @@ const char *crumble_bam_header_text(const crumble_bam_reader *r, int64_t *len);
  * its ulen bytes go to raw[blk[i].uoff ...], crc is the member's CRC-32 (to be checked); deflate: raw[0, raw_len) as
  * members of 0xff00 input bytes side by side in out (out_cap >= deflate_bound(raw_len)), their total size in *out_len.
  * Both return 0 or a negative code.  Set before the first read / write; NULL = back to the host threads.  With a codec the
- * reader reads 64 MiB of compressed bytes per round. */
+ * reader reads 256 MiB of compressed bytes per round. */
 typedef struct crumble_bam_block { int64_t coff, uoff; uint32_t clen, ulen, crc, pad_; } crumble_bam_block;
 typedef struct crumble_bam_coder {
     void *ctx;
@@ -141,6 +141,8 @@ int crumble_bam_timing(char *buf, size_t len);
 /* "libdeflate" (found on the host at run time) or "zlib": what inflates / deflates BGZF blocks in this process;
  * CRUMBLE_BAM_ZLIB=1 in the environment keeps zlib */
 const char *crumble_bam_codec(void);
+/* the team size `threads <= 0` stands for: the CPUs this process may use (affinity mask, cgroup quota), at most 64 */
+int crumble_bam_default_threads(void);
 
 const char *crumble_bam_last_error(void);
 

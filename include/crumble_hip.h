@@ -436,6 +436,9 @@ int     crumble_gz_inflate(crumble_gz *g, const uint8_t *comp, int64_t comp_len,
                            uint8_t *raw, int64_t raw_len, int check_crc);
 int64_t crumble_gz_deflate_bound(int64_t raw_len);
 int     crumble_gz_deflate(crumble_gz *g, const uint8_t *raw, int64_t raw_len, int level, uint8_t *out, int64_t out_cap, int64_t *out_len);
+/* implementation choices that never change a result: "tokens" = auto | wave | lane (k_gz_tokens: a wave per member, the
+ * right thing for a few thousand members; k_gz_tokens_lanes: a lane per member, for tens of thousands and more) */
+int     crumble_gz_set_option(crumble_gz *g, const char *name, const char *value);
 /* stream time of the last inflate / deflate call on g: host -> device copies, kernels, device -> host copies (ms) */
 int     crumble_gz_times(crumble_gz *g, float *h2d_ms, float *kernels_ms, float *d2h_ms);
 

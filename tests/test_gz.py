@@ -77,7 +77,7 @@ def _inflate_cases(codec, sizes, levels, kinds=None):
     rng = np.random.default_rng(11)
     for n in sizes:
         for kind, data in samples(rng, n).items():
-            if kinds and kind not in kinds:
+            if kinds and n > 1000 and kind not in kinds:         # (the emulated tier: the large sizes on the kinds that differ there)
                 continue
             for level in levels:
                 comp = bgzf(data, level)
@@ -145,6 +145,8 @@ def _deflate_cases(codec, sizes):
                     assert len(comp) <= n + 31 * nm                         # stored when nothing is gained
                 assert codec.deflate(data, level).tobytes() == comp           # deterministic
     assert codec.deflate(b"", 6).size == 0
+    data = samples(rng, 3000)["records"]                                 # zlib's "default" level (-1) compresses, 0 alone stores
+    assert codec.deflate(data, -1).tobytes() == codec.deflate(data, 6).tobytes() and len(codec.deflate(data, 0)) > len(data)
 
 
 # ------------------------------------------------------------------------------------------ emulated tier (no GPU)
@@ -156,12 +158,19 @@ def emu_codec():
     c.close()
 
 
-def test_emu_inflate_zlib_members(emu_codec):
-    _inflate_cases(emu_codec, (1, 7, 700, 70000), (0, 1, 6, 9))
+@pytest.mark.parametrize("tokens", ["wave", "lane"])
+def test_emu_inflate_zlib_members(emu_codec, tokens):
+    """both walks: a wave per member (k_gz_tokens) and a lane per member (k_gz_tokens_lanes)"""
+    emu_codec.set_option("tokens", tokens)
+    _inflate_cases(emu_codec, (1, 7, 700, 70000), (0, 1, 6), kinds=("records", "runs"))
+    emu_codec.set_option("tokens", "auto")
 
 
-def test_emu_inflate_refuses_corrupt_members(emu_codec):
+@pytest.mark.parametrize("tokens", ["wave", "lane"])
+def test_emu_inflate_refuses_corrupt_members(emu_codec, tokens):
+    emu_codec.set_option("tokens", tokens)
     _corrupt_cases(emu_codec)
+    emu_codec.set_option("tokens", "auto")
 
 
 def test_emu_deflate_round_trip(emu_codec):
@@ -198,13 +207,19 @@ def gpu_codec(product):
 
 
 @pytest.mark.gpu
-def test_gpu_inflate_zlib_members(gpu_codec):
+@pytest.mark.parametrize("tokens", ["wave", "lane"])
+def test_gpu_inflate_zlib_members(gpu_codec, tokens):
+    gpu_codec.set_option("tokens", tokens)
     _inflate_cases(gpu_codec, (1, 7, 700, 70000, 1 << 20), (0, 1, 6, 9))
+    gpu_codec.set_option("tokens", "auto")
 
 
 @pytest.mark.gpu
-def test_gpu_inflate_refuses_corrupt_members(gpu_codec):
+@pytest.mark.parametrize("tokens", ["wave", "lane"])
+def test_gpu_inflate_refuses_corrupt_members(gpu_codec, tokens):
+    gpu_codec.set_option("tokens", tokens)
     _corrupt_cases(gpu_codec)
+    gpu_codec.set_option("tokens", "auto")
 
 
 @pytest.mark.gpu
