@@ -589,10 +589,10 @@ int main(int argc, char **argv)
     p.wr = wr;
     /* BGZF members inflated / deflated on the device: CRUMBLE_HIP_CODEC = auto | gpu | gpu-inflate | gpu-deflate | host.
      * auto (the default) goes by what was measured on MI355X boxes: the device deflates a gigabyte of
-     * records in ~0.1 s whatever the level, sixteen host threads need 0.17 s at level 1 and three times that at the default
-     * level, so the device deflates unless the caller asked for level 0 / 1 with eight or more host threads or for level 7
-     * and up (the host's slow levels search harder than the device's one); the host's threads inflate (a gigabyte in 0.1 s
-     * on sixteen of them, as long as the device needs with the bytes' way back over PCIe) unless there are fewer than eight. */
+     * records in ~0.1 s whatever the level (copies included), sixteen host threads need 0.15-0.17 s at level 1 and twice that
+     * at the default level, so the device deflates unless the caller asked for level 0 (stored) or for level 7 and up (the
+     * host's slow levels search harder than the device's one); the host's threads inflate (a gigabyte in 0.08-0.1 s on
+     * sixteen of them, less than the device needs with the bytes' way back over PCIe) unless there are fewer than eight. */
     crumble_gz *gz_in = NULL, *gz_out = NULL;
     {
         const char *cm = getenv("CRUMBLE_HIP_CODEC");
@@ -604,7 +604,7 @@ int main(int argc, char **argv)
         int want_in = !strcmp(cm, "gpu") || !strcmp(cm, "gpu-inflate"), want_out = !strcmp(cm, "gpu") || !strcmp(cm, "gpu-deflate");
         if (!strcmp(cm, "auto")) {
             want_in = ht < 8;
-            want_out = level < 7 && !(level >= 0 && level <= 1 && ht >= 8);
+            want_out = level != 0 && level < 7;
         }
         int ge = 0;
         if (want_in && !(gz_in = crumble_gz_create(p.devices[0], &ge)))

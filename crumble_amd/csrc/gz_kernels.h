@@ -802,6 +802,7 @@ struct GzDeflate {
     uint32_t h6[1 << GZ_HB];       /* (both become the output bit buffer once the tokens are made) */
     uint32_t eq[2048 + 8];         /* bit p: data[p] == data[p - 1] */
     uint16_t hk[2 * GZ_SUB];       /* the sub-block's hash keys: 4-byte contexts, then 6-byte ones */
+    uint32_t best[GZ_SUB];         /* per position of the sub-block: the best candidate, length << 16 | ~(distance - 1) */
     uint32_t hist_l[288], hist_d[32], hist_b[19];
     uint8_t  len_l[288], len_d[32], len_b[19];
     uint16_t code_l[288], code_d[32], code_b[19];
@@ -1066,6 +1067,7 @@ k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int
     for (int i = tid; i < 288; i += GZ_DT) D.hist_l[i] = 0u;
     if (tid < 32) D.hist_d[tid] = 0u;
     if (tid < 19) D.hist_b[tid] = 0u;
+    if (tid < GZ_SUB) D.best[tid] = 0u;
     if (tid < 256) D.crc_tab[tid] = crc_tab[tid];
     if (tid < 32) D.x2n[tid] = x2n[tid];
     if (tid == 0) { D.lastm[0] = -1; D.lastm[1] = -1; D.bitpos = 0; D.use_stored = 0; }
@@ -1085,15 +1087,17 @@ k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int
      * positions into the hash tables.  Nothing here depends on which matches the parse will take. */
     if (level > 0 && N > 0)
     for (int base = 0; base < N; base += GZ_SUB) {
-        const int j = tid >> 2, cnd = tid & 3;               /* position of the sub-block, candidate kind */
+        /* a WAVE per candidate kind and 64 positions (wave w: kind w & 3, positions 64 * (w >> 2) + lane): no lane computes
+         * what only another kind needs; the four kinds of a position meet in an LDS word by atomicMax on
+         * length << 16 | ~(distance - 1) -- the longest wins, then the nearest */
+        const int cnd = wv & 3, j = ((wv >> 2) << 6) + lane;
         const int P = base + j;
         const int maxl = N - P < 258 ? N - P : 258;
-        int blen = 0, bdist = 0;
         if (P < N) {
-            /* how far the byte in front of P repeats from P on: the consecutive ones of eq[] from bit P */
-            int run = 0;
-            {
-                int p = P;
+            const uint32_t *dw = (const uint32_t *)D.data;
+            if (cnd == 2) {
+                /* how far the byte in front of P repeats from P on: the consecutive ones of eq[] from bit P */
+                int run = 0, p = P;
                 while (run < maxl) {
                     const uint32_t w = ~(D.eq[p >> 5] >> (p & 31));         /* first zero = end of the run */
                     const int avail = 32 - (p & 31);
@@ -1102,29 +1106,29 @@ k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int
                     run += avail; p += avail;
                 }
                 if (run > maxl) run = maxl;
-            }
-            const uint32_t *dw = (const uint32_t *)D.data;
-            const int pw = P >> 2, psh = 8 * (P & 3);
-            const uint32_t w0 = dw[pw], w1 = dw[pw + 1], w2 = dw[pw + 2];
-            const uint64_t two = ((uint64_t)w1 << 32) | w0;
-            const uint64_t b8 = psh ? (two >> psh) | ((uint64_t)w2 << (64 - psh)) : two;      /* the eight bytes from P on */
-            const uint32_t k4 = ((uint32_t)b8 * 2654435761u) >> (32 - GZ_HB);
-            const uint32_t k6 = (uint32_t)(((b8 & 0xffffffffffffull) * 0x9E3779B97F4A7C15ull) >> (64 - GZ_HB));
-            if (cnd == 0) D.hk[j] = (uint16_t)k4;
-            if (cnd == 1) D.hk[GZ_SUB + j] = (uint16_t)k6;
-            int cand = -1;
-            if (cnd == 2) { if (run >= 3 && P >= 1) { blen = run; bdist = 1; } }
-            else if (run < GZ_NICE) {
-                if (cnd == 0 && maxl >= 4) cand = (int)D.h4[k4] - 1;
-                if (cnd == 1 && maxl >= 6) cand = (int)D.h6[k6] - 1;
-#ifndef GZ_EXP_NOREP
-                if (cnd == 3 && last_dist > 1 && P - last_dist >= 0) cand = P - last_dist;
-#endif
-                if (cand >= 0 && P - cand <= 32768) {
-                    /* common prefix of the bytes at cand and at P, eight at a time (aligned words, shifted into place) */
-                    const int cw = cand >> 2, csh = 8 * (cand & 3);
-                    /* (at most GZ_CMPMAX bytes: one lane's long compare holds its whole workgroup at the barrier, and a longer
-                     * match is simply taken in pieces) */
+                if (run >= 3 && P >= 1) atomicMax(&D.best[j], ((uint32_t)run << 16) | 0xffffu);
+            } else {
+                /* inside a run of GZ_NICE or more the run's own match is good enough: sixteen one bits of eq[] from bit P */
+                const uint32_t e0 = D.eq[P >> 5], e1 = D.eq[(P >> 5) + 1];
+                const uint64_t eqw = (((uint64_t)e1 << 32) | e0) >> (P & 31);
+                const bool inrun = ((uint32_t)eqw & ((1u << GZ_NICE) - 1u)) == ((1u << GZ_NICE) - 1u);
+                const int pw = P >> 2, psh = 8 * (P & 3);
+                const uint32_t w0 = dw[pw], w1 = dw[pw + 1], w2 = dw[pw + 2];
+                const uint64_t two = ((uint64_t)w1 << 32) | w0;
+                const uint64_t b8 = psh ? (two >> psh) | ((uint64_t)w2 << (64 - psh)) : two;      /* the eight bytes from P on */
+                int cand_p = -1;
+                if (cnd == 0) {
+                    const uint32_t k4 = ((uint32_t)b8 * 2654435761u) >> (32 - GZ_HB);
+                    D.hk[j] = (uint16_t)(k4 | (inrun ? 0x8000u : 0u));
+                    if (!inrun && maxl >= 4) cand_p = (int)D.h4[k4] - 1;
+                } else if (cnd == 1) {
+                    const uint32_t k6 = (uint32_t)(((b8 & 0xffffffffffffull) * 0x9E3779B97F4A7C15ull) >> (64 - GZ_HB));
+                    D.hk[GZ_SUB + j] = (uint16_t)(k6 | (inrun ? 0x8000u : 0u));
+                    if (!inrun && maxl >= 6) cand_p = (int)D.h6[k6] - 1;
+                } else if (!inrun && last_dist > 1 && P - last_dist >= 0) cand_p = P - last_dist;
+                if (cand_p >= 0 && P - cand_p <= 32768) {
+                    /* common prefix of the bytes at cand_p and at P, eight at a time (aligned words, shifted into place) */
+                    const int cw = cand_p >> 2, csh = 8 * (cand_p & 3);
                     const int cmax = maxl < GZ_CMPMAX ? maxl : GZ_CMPMAX;
                     int l = 0;
                     uint64_t pv = b8;
@@ -1142,37 +1146,41 @@ k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int
                         l += 8;
                     }
                     if (l > cmax) l = cmax;
-                    if (l >= 4) { blen = l; bdist = P - cand; }
+                    if (l >= 4) atomicMax(&D.best[j], ((uint32_t)l << 16) | (0xffffu - (uint32_t)(P - cand_p - 1)));
                 }
             }
         }
-        /* the best of the four: the longest, then the nearest */
-        for (int x = 1; x <= 2; x <<= 1) {
-            const int ol = __shfl_xor(blen, x), od = __shfl_xor(bdist, x);
-            if (ol > blen || (ol == blen && ol > 0 && od < bdist)) { blen = ol; bdist = od; }
-        }
-        if (cnd == 0) {
-#ifndef GZ_EXP_NOCAND
-            if (P < N) cand[P] = ((uint32_t)blen << 16) | (uint32_t)(bdist ? bdist - 1 : 0);
-#endif
-#ifndef GZ_EXP_NOLASTM
-            if (blen >= 3) atomicMax(&D.lastm[(base / GZ_SUB) & 1], (j << 16) | (bdist - 1));
-#endif
-        }
         GZ_LDS_BARRIER();                                                                   /* ---- 1 */
         GZ_STAMP_AT(1);
-        {   /* the hash tables take the sub-block's positions (the largest position wins: deterministic) */
-            if (tid < 2 * GZ_SUB) {
-                const int jj = tid >> 1, PP = base + jj;
-                if (tid & 1) { if (PP + 6 <= N) atomicMax(&D.h6[D.hk[GZ_SUB + jj]], (uint32_t)PP + 1u); }
-                else         { if (PP + 4 <= N) atomicMax(&D.h4[D.hk[jj]], (uint32_t)PP + 1u); }
+        {
+            if (tid < GZ_SUB) {                              /* the winners: to cand[] (pass B reads them), the latest one's distance on */
+                const uint32_t v = D.best[tid];
+                D.best[tid] = 0u;
+                const int bl = (int)(v >> 16), bd1 = (int)(0xffffu - (v & 0xffffu));        /* length, distance - 1 */
+                if (base + tid < N) cand[base + tid] = bl >= 3 ? ((uint32_t)bl << 16) | (uint32_t)bd1 : 0u;
+                /* the latest position with a match, and its distance: one atomic per wave (its highest such lane), not one per
+                 * lane on one word */
+                const unsigned long long hm = __ballot(bl >= 3);
+                if (hm && lane == 63 - __builtin_clzll(hm)) atomicMax(&D.lastm[(base / GZ_SUB) & 1], (tid << 16) | bd1);
+            } else if (tid < 3 * GZ_SUB) {
+                /* the hash tables take the sub-block's positions (the largest position wins: deterministic) */
+                const int t = tid - GZ_SUB, jj = t >> 1, PP = base + jj;
+                /* (not the positions inside a run: they all hash alike -- sixty-four atomics on one word -- and nothing looks
+                 * a run's inside up: bit 15 of the key) */
+                const uint32_t hkv = D.hk[(t & 1) ? GZ_SUB + jj : jj];
+                if (!(hkv & 0x8000u)) {
+                    if (t & 1) { if (PP + 6 <= N) atomicMax(&D.h6[hkv], (uint32_t)PP + 1u); }
+                    else       { if (PP + 4 <= N) atomicMax(&D.h4[hkv], (uint32_t)PP + 1u); }
+                }
             }
-            const int lm = D.lastm[(base / GZ_SUB) & 1];
-            if (lm >= 0) last_dist = (lm & 0xffff) + 1;
             if (tid == 0) D.lastm[((base / GZ_SUB) + 1) & 1] = -1;      /* (the other one: the next sub-block's, untouched since its readers two barriers ago) */
         }
         GZ_LDS_BARRIER();                                                                   /* ---- 2 */
         GZ_STAMP_AT(2);
+        {
+            const int lm = D.lastm[(base / GZ_SUB) & 1];
+            if (lm >= 0) last_dist = (lm & 0xffff) + 1;
+        }
     }
     __syncthreads();
     gz_parse_ranges(D, tk, cand, N, level, lane, wv);
