@@ -142,7 +142,39 @@ def _host_threads():
     return n
 
 
-def file_to_file(ca, synth, refs, batches, preset, device, label, verify_seconds=2.0, codec=None, level="1"):
+def codec_kernels(path, device):
+    """The device BGZF codec (crumble_gz_*, csrc/gz_kernels.h) alone on a BAM file's bytes: members inflated, the records deflated
+    again; HIP-event time of the kernels and of the copies, sizes against the host codec's.  Algorithmic bytes of a pass =
+    compressed + uncompressed (each crosses HBM once at least); the kernels are bound by latency and instruction issue, not by
+    bytes."""
+    import gzip
+    from crumble_amd import gz
+    comp = np.fromfile(path, np.uint8)
+    c = gz.GzCodec(device)
+    try:
+        raw = c.inflate(comp)                                   # (first call: allocations)
+        t0 = time.perf_counter(); raw = c.inflate(comp); w_in = time.perf_counter() - t0
+        ti = c.times()
+        ok_in = bool(np.array_equal(raw[:1 << 20], np.frombuffer(gzip.decompress(comp.tobytes())[:1 << 20], np.uint8)))
+        out = c.deflate(raw, 6)
+        t0 = time.perf_counter(); out = c.deflate(raw, 6); w_out = time.perf_counter() - t0
+        td = c.times()
+        back = c.inflate(out)
+        ok_out = bool(np.array_equal(back, raw))
+        n_members = int(len(gz.bgzf_scan(comp)[0]))
+        return {"raw_bytes": int(raw.size), "members": n_members,
+                "inflate": {"kernels_ms": round(ti["kernels_ms"], 2), "GB_per_s_kernels": round(raw.size / ti["kernels_ms"] / 1e6, 2),
+                            "wall_ms_incl_copies": round(w_in * 1e3, 1), "h2d_ms": round(ti["h2d_ms"], 2), "d2h_ms": round(ti["d2h_ms"], 2),
+                            "hbm_frac": round((raw.size + comp.size) / (ti["kernels_ms"] * 1e-3) / 8e12, 5), "equals_gzip": ok_in},
+                "deflate": {"kernels_ms": round(td["kernels_ms"], 2), "GB_per_s_kernels": round(raw.size / td["kernels_ms"] / 1e6, 2),
+                            "wall_ms_incl_copies": round(w_out * 1e3, 1), "h2d_ms": round(td["h2d_ms"], 2), "d2h_ms": round(td["d2h_ms"], 2),
+                            "hbm_frac": round((raw.size + out.size) / (td["kernels_ms"] * 1e-3) / 8e12, 5),
+                            "bytes": int(out.size), "bytes_host_level1": int(comp.size), "round_trip_ok": ok_out}}
+    finally:
+        c.close()
+
+
+def file_to_file(ca, synth, refs, batches, preset, device, label, verify_seconds=2.0, codec=None, level="1", codec_probe=False):
     """Metric (ii) of SURVEY.md 8(d): contigs as a BAM file through the crumble-hip driver (BGZF inflate + BAM parse +
     H2D + expansion + kernels + D2H + BGZF deflate).  `value` is over the driver's own clock from the first byte read
     to the last byte written (the figure crumble-hip -v prints: reader, GPU worker and writer threads overlap across
@@ -159,6 +191,9 @@ def file_to_file(ca, synth, refs, batches, preset, device, label, verify_seconds
     total = sum(b_.n_bases for b_ in batches)
     try:
         bamio.write_batches(src, refs, batches, level=1)
+        probe = None
+        if codec_probe:
+            probe = codec_kernels(src, device)
         env = dict(os.environ, CRUMBLE_HIP_DEVICE=str(device))
         if level is not None:
             env["CRUMBLE_BAM_LEVEL"] = level          # "1": the fastest host deflate (the legs of rounds 4 and 5); None: the default level (6)
@@ -184,6 +219,8 @@ def file_to_file(ca, synth, refs, batches, preset, device, label, verify_seconds
                "codec": (re.search(r"BGZF codec: (.*)", r.stderr) or [None, L.crumble_bam_codec().decode()])[1],
                "in_bytes": os.path.getsize(src), "out_bytes": os.path.getsize(dst),
                "host_stage_s": (re.search(r"bamio: (.*)", r.stderr) or [None, None])[1]}
+        if probe:
+            out["codec_kernels"] = probe
         if verify_seconds > 0:
             got = list(bamio.Reader(dst))
             params = ca.preset_params(preset)
@@ -220,14 +257,16 @@ def end_to_end_legs(ca, synth, shard, args, hb_full, label, device):
         cfg.tid = tid
         batches.append(synth.generate(cfg))
     refs = [(f"chr{t + 1}", max(s_, 4 * 150 + 4096) + 1000) for t, s_ in enumerate(sizes)]
-    out = file_to_file(ca, synth, refs, batches, args.preset, device, f"wgs-30x: 24 contigs (GRCh38 lengths x {0.005 * args.scale:g})")
-    # crumble-hip's codec policy (CRUMBLE_HIP_CODEC=auto) takes the host's threads at level 1 on a sixteen-thread host: the leg above is
-    # the host codec.  The same file with every member inflated AND deflated on the device (crumble_gz_*):
+    out = file_to_file(ca, synth, refs, batches, args.preset, device, f"wgs-30x: 24 contigs (GRCh38 lengths x {0.005 * args.scale:g})", codec_probe=True)
+    # crumble-hip's codec policy (CRUMBLE_HIP_CODEC=auto): the host's threads inflate, the device deflates (crumble_gz_deflate) -- the
+    # leg above.  The same file with the host's threads doing both (libdeflate level 1 where the box has it: the legs of rounds 4
+    # and 5), and with every member inflated AND deflated on the device:
     keys = ("value", "loop_s", "read_parse_s", "gpu_incl_pcie_s", "deflate_write_s", "codec", "out_bytes", "host_stage_s", "error")
+    hc = file_to_file(ca, synth, refs, batches, args.preset, device, "the same, CRUMBLE_HIP_CODEC=host", verify_seconds=0, codec="host")
+    out["host_codec"] = {k: hc.get(k) for k in keys if k in hc}
     dv = file_to_file(ca, synth, refs, batches, args.preset, device, "the same, CRUMBLE_HIP_CODEC=gpu", verify_seconds=0, codec="gpu")
     out["device_codec"] = {k: dv.get(k) for k in keys if k in dv}
-    # ... and at the DEFAULT compression level (what htslib and reference crumble write: zlib 6), where auto = host inflate +
-    # device deflate, against the host's threads doing both
+    # ... and at the DEFAULT compression level (what htslib and reference crumble write: zlib 6): auto against the host's threads
     da = file_to_file(ca, synth, refs, batches, args.preset, device, "the same at the default level, auto", verify_seconds=0, level=None)
     dh = file_to_file(ca, synth, refs, batches, args.preset, device, "the same at the default level, host", verify_seconds=0, codec="host", level=None)
     out["default_level"] = {"auto": {k: da.get(k) for k in keys if k in da}, "host_codec": {k: dh.get(k) for k in keys if k in dh}}

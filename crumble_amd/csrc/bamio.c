@@ -175,6 +175,7 @@ int crumble_bam_default_threads(void) { return default_threads(); }
 /* ------------------------------------------------------------------ BGZF in */
 #define CHUNK_IN   (8u << 20)       /* compressed bytes read per refill: what is inflated beyond a contig's last record is
                                      * carried over to the next window (crumble_bam_detach_group copies it), so not too much at once */
+#define RAW_MIN_CAP ((size_t)1 << 30) /* address space of a record buffer (see raw_reserve) */
 #define MAX_BLOCKS 16384            /* per refill (>= CHUNK_IN / smallest sane block, grown on demand) */
 
 /* the record buffer is shared between the reader and the groups detached from it (crumble_bam_detach_group): a group
@@ -230,7 +231,9 @@ typedef struct { size_t coff, clen, uoff, ulen; uint32_t crc; } blk_t;
 static int raw_reserve(crumble_bam_reader *r, size_t need)
 {
     if (need <= r->raw_cap) return 0;
-    size_t nc = r->raw_cap ? r->raw_cap : (64u << 20);
+    /* (address space, not memory: pages that are never touched cost nothing, and a mapping that need not grow while detached
+     * groups still read its front is never copied) */
+    size_t nc = r->raw_cap ? r->raw_cap : RAW_MIN_CAP;
     while (nc < need) nc += nc / 2 + (16u << 20);
     nc = (nc + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
     if (r->rb && atomic_load(&r->rb->refs) == 1) {          /* nobody else looks at it: grow in place (may move) */
@@ -595,8 +598,8 @@ int crumble_bam_next_contig(crumble_bam_reader *r, crumble_batch *b)
         if (atomic_load(&r->rb->refs) == 1) memmove(r->raw, r->raw + r->head, r->raw_len - r->head);
         else {                                              /* groups in flight hold the front: the live rest into a mapping of its own */
             const size_t live = r->raw_len - r->head;
-            size_t nc = (size_t)64 << 20;
-            while (nc < live + ((size_t)16 << 20)) nc += nc / 2;
+            size_t nc = RAW_MIN_CAP;
+            while (nc < live + ((size_t)256 << 20)) nc += nc / 2;
             rawbuf *nb = rawbuf_new(nc);
             if (!nb) return fail(CRUMBLE_BAM_ENOMEM, "out of memory");
             memcpy(nb->p, r->raw + r->head, live);

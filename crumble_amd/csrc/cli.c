@@ -546,12 +546,24 @@ int main(int argc, char **argv)
     p.plain_download = getenv("CRUMBLE_HIP_PLAIN_DOWNLOAD") && atoi(getenv("CRUMBLE_HIP_PLAIN_DOWNLOAD"));
     p.coded_quals = getenv("CRUMBLE_HIP_CODED_QUALS") && atoi(getenv("CRUMBLE_HIP_CODED_QUALS"));
     if (ngpu < 1 || ngpu > MAX_DEV) { fprintf(stderr, "crumble-hip: -j must be 1..%d\n", MAX_DEV); return 1; }
+    /* One device: several engines on it (CRUMBLE_HIP_ENGINES=n, default 2), a worker thread each -- while one contig's bytes
+     * cross PCIe another one's kernels run, and a file of thousands of small contigs (hs38DH's decoys) pays their fixed cost
+     * n at a time.  The engines' statistics are added up on the host (as for a device named twice in CRUMBLE_HIP_DEVICES);
+     * with -j N > 1 every device has one engine and RCCL sums. */
+    int engines_one = 0;
+    if (ngpu == 1 && !windowed && !getenv("CRUMBLE_HIP_DEVICES")) {
+        const char *ev = getenv("CRUMBLE_HIP_ENGINES");
+        int n = ev ? atoi(ev) : 2;
+        if (n < 1) n = 1;
+        if (n > 8) n = 8;
+        if (n > 1) { engines_one = 1; ngpu = n; }
+    }
     p.ndev = ngpu;
     {   /* device list: CRUMBLE_HIP_DEVICES="a,b,.." (tests may name one device twice), else CRUMBLE_HIP_DEVICE + k */
         const char *dl = getenv("CRUMBLE_HIP_DEVICES");
         const int base = getenv("CRUMBLE_HIP_DEVICE") ? atoi(getenv("CRUMBLE_HIP_DEVICE")) : 0;
         for (int d = 0; d < ngpu; d++) {
-            p.devices[d] = base + d;
+            p.devices[d] = engines_one ? base : base + d;
             if (dl && *dl) { p.devices[d] = atoi(dl); dl = strchr(dl, ','); dl = dl ? dl + 1 : ""; }
         }
     }
@@ -699,7 +711,8 @@ int main(int argc, char **argv)
         for (int d = 0; d < ngpu; d++) tg += p.t_gpu[d];
         fprintf(stderr, "end-to-end %.3f s (read+parse %.3f, upload+kernels+download %.3f, write %.3f): %.4f Gbases/s file to file\n",
                 wall, t_read, tg, p.t_write, wall > 0 ? gb / wall : 0.0);
-        fprintf(stderr, "%d device(s)%s, reader / GPU workers / writer overlapped; %lld reads, %lld bases\n", ngpu,
+        if (engines_one) fprintf(stderr, "1 device, %d engines on it, ", ngpu);
+        fprintf(stderr, "%d device(s)%s, reader / GPU workers / writer overlapped; %lld reads, %lld bases\n", engines_one ? 1 : ngpu,
                 p.use_rccl ? ", statistics summed by RCCL all-reduce" : "", (long long)total_reads, (long long)total_bases);
         char tb[512];
         crumble_bam_timing(tb, sizeof tb);
