@@ -201,6 +201,7 @@ struct crumble_bam_reader {
     rawbuf *rb;                               /* raw / raw_cap below are its p / cap */
     crumble_bam_coder codec; int has_codec;   /* crumble_bam_reader_set_codec: BGZF members inflated by the caller's codec (the device) */
     size_t chunk_in;                          /* compressed bytes read per refill */
+    int64_t hdr_bytes;                        /* size of the BAM header in the inflated stream */
     team *tm;                                 /* the reader's own team (idle workers sleep: team.h); NULL in a detached group */
     uint8_t *cbuf; size_t clen, ccap;        /* compressed bytes not yet inflated  */
     int eof_file;
@@ -457,6 +458,7 @@ crumble_bam_reader *crumble_bam_open(const char *path, int threads, int *err)
         r->scan += (size_t)ln + 8;
     }
     r->group_end = r->scan;                                 /* header bytes are dropped on the first call */
+    r->hdr_bytes = (int64_t)r->scan;
     if (err) *err = 0;
     return r;
 bad:
@@ -482,6 +484,7 @@ int32_t crumble_bam_n_ref(const crumble_bam_reader *r) { return r->n_ref; }
 const char *crumble_bam_ref_name(const crumble_bam_reader *r, int32_t tid) { return tid >= 0 && tid < r->n_ref ? r->ref_name[tid] : "*"; }
 int64_t crumble_bam_ref_len(const crumble_bam_reader *r, int32_t tid) { return tid >= 0 && tid < r->n_ref ? r->ref_len[tid] : 0; }
 const char *crumble_bam_header_text(const crumble_bam_reader *r, int64_t *len) { if (len) *len = r->l_text; return r->text; }
+int64_t crumble_bam_header_bytes(const crumble_bam_reader *r) { return r->hdr_bytes; }
 
 /* fixed part of a BAM alignment record, offsets from the block_size field */
 enum { F_REFID = 4, F_POS = 8, F_LNAME = 12, F_MAPQ = 13, F_NCIG = 16, F_FLAG = 18, F_LSEQ = 20, F_FIXED = 36 };
@@ -1096,6 +1099,16 @@ static int write_group(crumble_bam_writer *w, crumble_bam_reader *r, const uint8
     team_run(w->tm, n, 0, wg_aux_copy, &job);
     T_scatter += now_s() - tsc;
     return bgzf_write(w, w->raw2, tot);
+}
+
+/* members that are BGZF already (the device pipeline's output: crumble_stream_drain) */
+int crumble_bam_write_members(crumble_bam_writer *w, const uint8_t *members, size_t n)
+{
+    if (!w) return CRUMBLE_BAM_EIO;
+    const double tw = now_s();
+    if (n && fwrite(members, 1, n, w->fp) != n) return fail(CRUMBLE_BAM_EIO, "write error: %s", strerror(errno));
+    T_fwrite += now_s() - tw;
+    return 0;
 }
 
 int crumble_bam_writer_close(crumble_bam_writer *w)

@@ -102,6 +102,101 @@ static int gz_deflate_cb(void *ctx, const uint8_t *raw, int64_t raw_len, int lev
 }
 typedef char gz_block_layout_check[sizeof(crumble_bam_block) == sizeof(crumble_gz_block) ? 1 : -1];
 
+/* ---- the device pipeline: the file's records never leave the GPU (crumble_stream, include/crumble_hip.h).  The host reads
+ * compressed bytes, walks the BGZF member headers and writes compressed bytes; inflate, record delimiting, the engine's input,
+ * its output back into the records and deflate happen in HBM.  One device, no tag filters, no -b: everything else takes
+ * the host pipeline below.  Returns 0 done, 1 failed (message printed), -1 "not for this file": the caller starts over the
+ * host way (a CG-tag CIGAR, a record stream the device could not delimit). */
+#ifndef PIPELINE_AUTO_DEVICE
+#define PIPELINE_AUTO_DEVICE 0
+#endif
+static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_bam_writer *wr, crumble_hip *eng, int device, int level,
+                           int nbed, const int32_t *bt, const int32_t *bs, const int32_t *be, int verbose, int64_t *reads_out, int64_t *bases_out,
+                           double times[3])
+{
+    int err = 0;
+    const int32_t nref = crumble_bam_n_ref(rd);
+    crumble_stream *s = crumble_stream_create(device, nref, crumble_bam_header_bytes(rd), &err);
+    if (!s) { fprintf(stderr, "crumble-hip: device pipeline unavailable (%s)\n", crumble_hip_last_error()); return -1; }
+    FILE *fp = fopen(in_fn, "rb");
+    if (!fp) { crumble_stream_destroy(s); return -1; }
+    const size_t CH = (size_t)256 << 20;
+    size_t cap = CH + ((size_t)1 << 20), have = 0, ocap = 0;
+    uint8_t *buf = crumble_bam_big_alloc(cap), *obuf = NULL;
+    size_t bcap = 8192;
+    crumble_gz_block *blk = malloc(bcap * sizeof *blk);
+    int rc = 0, eof = 0, bed_i = 0;
+    double t_read = 0, t_gpu = 0, t_write = 0;
+    int64_t n_reads = 0, n_bases = 0;
+    while (!eof && !rc) {
+        double t0 = now();
+        if (!buf || !blk) { fprintf(stderr, "crumble-hip: out of memory\n"); rc = 1; break; }
+        const size_t got = fread(buf + have, 1, cap - have, fp);
+        if (got < cap - have) { if (ferror(fp)) { fprintf(stderr, "crumble-hip: read error\n"); rc = 1; break; } eof = 1; }
+        have += got;
+        int64_t used = 0, raw_total = 0, nb;
+        for (;;) {
+            nb = crumble_bgzf_scan(buf, (int64_t)have, blk, (int64_t)bcap, &used, &raw_total);
+            if (nb < 0) { fprintf(stderr, "crumble-hip: not a BGZF block (bad gzip header)\n"); rc = 1; break; }
+            if ((size_t)nb < bcap) break;
+            bcap *= 2; free(blk); blk = malloc(bcap * sizeof *blk);
+            if (!blk) { rc = 1; break; }
+        }
+        if (rc) break;
+        if (eof && (size_t)used != have) { fprintf(stderr, "crumble-hip: truncated BGZF block at end of file\n"); rc = 1; break; }
+        t_read += now() - t0;
+        t0 = now();
+        int e = crumble_stream_feed(s, buf, used, blk, nb, eof);
+        if (e) { if (verbose) fprintf(stderr, "crumble-hip: device pipeline: %s\n", crumble_hip_last_error()); rc = -1; break; }
+        memmove(buf, buf + used, have - (size_t)used);
+        have -= (size_t)used;
+        crumble_stream_group g[1024];
+        for (;;) {
+            const int ng = crumble_stream_groups(s, g, 1024);
+            int k = 0;
+            int64_t bytes = 0;
+            for (int i = 0; i < ng && i < 1024 && g[i].complete; i++) {
+                while (bed_i < nbed && g[i].tid >= 0 && bt[bed_i] < g[i].tid) bed_i++;
+                int j2 = bed_i;
+                while (j2 < nbed && bt[j2] == g[i].tid) j2++;
+                e = crumble_stream_process(s, eng, i, j2 - bed_i, bs + bed_i, be + bed_i);
+                if (e) { fprintf(stderr, "crumble-hip: contig %s: %s (%s)\n", crumble_bam_ref_name(rd, g[i].tid), crumble_hip_strerror(e), crumble_hip_last_error()); rc = strstr(crumble_hip_last_error(), "CG tag") ? -1 : 2; break; }
+                n_reads += g[i].n_reads; bytes = g[i].byte_end - g[0].byte_start; k++;
+            }
+            if (rc || !k) break;
+            {   /* bases: the engines' statistics have them; per run, filled by process */
+                crumble_stream_group g2[1024];
+                crumble_stream_groups(s, g2, 1024);
+                for (int i = 0; i < k; i++) n_bases += g2[i].n_bases;
+            }
+            const size_t need = (size_t)crumble_gz_deflate_bound(bytes) + 64;
+            if (ocap < need) { crumble_bam_big_free(obuf, ocap); obuf = crumble_bam_big_alloc(need); ocap = obuf ? need : 0; if (!obuf) { rc = 1; break; } }
+            int64_t olen = 0;
+            e = crumble_stream_drain(s, k, level, obuf, (int64_t)ocap, &olen);
+            if (e) { fprintf(stderr, "crumble-hip: %s (%s)\n", crumble_hip_strerror(e), crumble_hip_last_error()); rc = 1; break; }
+            t_gpu += now() - t0;
+            t0 = now();
+            if (crumble_bam_write_members(wr, obuf, (size_t)olen)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); rc = 1; break; }
+            t_write += now() - t0;
+            t0 = now();
+            if (k < 1024) break;
+        }
+        t_gpu += now() - t0;
+    }
+    if (!rc && have) { fprintf(stderr, "crumble-hip: trailing bytes behind the last BGZF member\n"); rc = 1; }
+    if (!rc && verbose) {
+        float mi = 0, md = 0; int64_t bi = 0, bo = 0;
+        crumble_stream_times(s, &mi, &md, &bi, &bo);
+        fprintf(stderr, "pipeline: device (records inflated, delimited, run and deflated in HBM; %.1f MB in, %.1f MB out over PCIe; inflate %.3f s, deflate %.3f s of the GPU stage)\n",
+                bi / 1e6, bo / 1e6, mi / 1e3, md / 1e3);
+    }
+    times[0] = t_read; times[1] = t_gpu; times[2] = t_write;
+    *reads_out = n_reads; *bases_out = n_bases;
+    fclose(fp); free(blk); crumble_bam_big_free(buf, cap); crumble_bam_big_free(obuf, ocap);
+    crumble_stream_destroy(s);
+    return rc == 2 ? 1 : rc;
+}
+
 static void *gpu_worker(void *a_)
 {
     worker_arg *a = a_; pipe_t *p = a->p; const int d = a->d;
@@ -550,8 +645,20 @@ int main(int argc, char **argv)
      * cross PCIe another one's kernels run, and a file of thousands of small contigs (hs38DH's decoys) pays their fixed cost
      * n at a time.  The engines' statistics are added up on the host (as for a device named twice in CRUMBLE_HIP_DEVICES);
      * with -j N > 1 every device has one engine and RCCL sums. */
+    /* CRUMBLE_HIP_PIPELINE = device | host | auto: the device pipeline (device_pipeline() above) for BAM -> BAM on one
+     * device without tag filters and without -b */
+    int dev_mode = 0;
+    {
+        const char *pm = getenv("CRUMBLE_HIP_PIPELINE");
+        if (!pm) pm = "auto";
+        if (strcmp(pm, "auto") && strcmp(pm, "device") && strcmp(pm, "host")) { fprintf(stderr, "crumble-hip: CRUMBLE_HIP_PIPELINE must be auto, device or host\n"); return 1; }
+        const int can = ngpu == 1 && !windowed && !getenv("CRUMBLE_HIP_DEVICES") && !wl && !bl && !bed_fp &&
+                        !bd[0] && !bd[1] && !bd[2] && !bi[0] && !bi[1] && !bi[2] && !p.plain_download && !p.coded_quals;
+        if (!strcmp(pm, "device") && !can) fprintf(stderr, "crumble-hip: CRUMBLE_HIP_PIPELINE=device needs one device and none of -w -t -T -b -e..-G: the host pipeline runs\n");
+        dev_mode = can && (!strcmp(pm, "device") || (!strcmp(pm, "auto") && PIPELINE_AUTO_DEVICE));
+    }
     int engines_one = 0;
-    if (ngpu == 1 && !windowed && !getenv("CRUMBLE_HIP_DEVICES")) {
+    if (ngpu == 1 && !windowed && !dev_mode && !getenv("CRUMBLE_HIP_DEVICES")) {
         const char *ev = getenv("CRUMBLE_HIP_ENGINES");
         int n = ev ? atoi(ev) : 2;
         if (n < 1) n = 1;
@@ -606,7 +713,23 @@ int main(int argc, char **argv)
      * host's slow levels search harder than the device's one); the host's threads inflate (a gigabyte in 0.08-0.1 s on
      * sixteen of them, less than the device needs with the bytes' way back over PCIe) unless there are fewer than eight. */
     crumble_gz *gz_in = NULL, *gz_out = NULL;
-    {
+    double dev_times[3] = {0, 0, 0};
+    int64_t dev_reads = 0, dev_bases = 0;
+    int dev_done = 0;
+    const double t_all = now();
+    if (dev_mode) {
+        const int rcd = device_pipeline(in_fn, rd, wr, p.eng[0], p.devices[0], level, nbed, bt, bs, be, verbose, &dev_reads, &dev_bases, dev_times);
+        if (rcd > 0) return rcd;
+        if (rcd == 0) dev_done = 1;
+        else {                                                  /* not for this file: from the top, the host way */
+            if (verbose) fprintf(stderr, "pipeline: the device pipeline does not take this file; the host pipeline runs\n");
+            crumble_bam_writer_close(wr);
+            if (!(wr = crumble_bam_create(out_fn, rd, pg, level, threads, &err))) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
+            p.wr = wr;
+            (void)crumble_hip_stats_reset(p.eng[0]);
+        }
+    }
+    if (!dev_done) {
         const char *cm = getenv("CRUMBLE_HIP_CODEC");
         if (!cm) cm = "auto";
         if (strcmp(cm, "auto") && strcmp(cm, "gpu") && strcmp(cm, "gpu-inflate") && strcmp(cm, "gpu-deflate") && strcmp(cm, "host")) {
@@ -629,19 +752,19 @@ int main(int argc, char **argv)
         if (verbose) fprintf(stderr, "BGZF codec: inflate %s, deflate %s\n", gz_in ? "device" : crumble_bam_codec(), gz_out ? "device" : crumble_bam_codec());
     }
 
+    double t_read = 0;
+    int bed_i = 0, rc_main = 0;
+    int64_t seq = 0, total_reads = 0, total_bases = 0;
     const int32_t nref = crumble_bam_n_ref(rd);
     int *dev_of = calloc((size_t)(nref > 0 ? nref : 1), sizeof *dev_of);
     lpt_assign(rd, ngpu, dev_of);
 
     pthread_t wt, gt[MAX_DEV]; worker_arg wa[MAX_DEV];
+    if (dev_done) goto finish;
     pthread_create(&wt, NULL, writer_thread, &p);
     if (!windowed)
         for (int d = 0; d < ngpu; d++) { wa[d].p = &p; wa[d].d = d; pthread_create(&gt[d], NULL, gpu_worker, &wa[d]); }
 
-    double t_read = 0;
-    const double t_all = now();
-    int bed_i = 0, rc_main = 0;
-    int64_t seq = 0, total_reads = 0, total_bases = 0;
     for (;;) {
         crumble_batch B;
         double t0 = now();
@@ -695,6 +818,8 @@ int main(int argc, char **argv)
     }
     pthread_join(wt, NULL);
     if (p.failed) rc_main = p.failed == 2 ? 2 : 1;
+finish:
+    if (dev_done) { t_read = dev_times[0]; p.t_gpu[0] = dev_times[1]; p.t_write = dev_times[2]; total_reads = dev_reads; total_bases = dev_bases; }
     if (bed_fp && fclose(bed_fp)) { perror("-b"); rc_main = 1; }
     if (crumble_bam_writer_close(wr)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); rc_main = 1; }
     /* statistics: after the all-reduce every engine holds the sum; without RCCL (one device, or one device named
@@ -712,7 +837,8 @@ int main(int argc, char **argv)
         fprintf(stderr, "end-to-end %.3f s (read+parse %.3f, upload+kernels+download %.3f, write %.3f): %.4f Gbases/s file to file\n",
                 wall, t_read, tg, p.t_write, wall > 0 ? gb / wall : 0.0);
         if (engines_one) fprintf(stderr, "1 device, %d engines on it, ", ngpu);
-        fprintf(stderr, "%d device(s)%s, reader / GPU workers / writer overlapped; %lld reads, %lld bases\n", engines_one ? 1 : ngpu,
+        if (dev_done) fprintf(stderr, "1 device, records resident; %lld reads, %lld bases\n", (long long)total_reads, (long long)total_bases);
+        else fprintf(stderr, "%d device(s)%s, reader / GPU workers / writer overlapped; %lld reads, %lld bases\n", engines_one ? 1 : ngpu,
                 p.use_rccl ? ", statistics summed by RCCL all-reduce" : "", (long long)total_reads, (long long)total_bases);
         char tb[512];
         crumble_bam_timing(tb, sizeof tb);

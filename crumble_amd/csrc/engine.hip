@@ -27,6 +27,8 @@
 #include "dev_common.h"
 #include "kernels.h"
 #include "p0_kernels.h"
+#include "gz_kernels.h"
+#include "stream_kernels.h"
 
 static thread_local std::string g_last_error;
 extern "C" const char *crumble_hip_last_error(void) { return g_last_error.c_str(); }
@@ -417,22 +419,30 @@ static int prefix_max(crumble_hip *h, int32_t *v, int64_t n, const int *n_dev = 
  * one is copied array by array straight from the caller's memory. */
 #define RAW_STAGE_MAX ((size_t)4 << 20)
 #define LENS_ON_DEVICE_MIN 65536    /* reads from which on the offset tables are made on the device from the uploaded lengths */
-static int copy_raw(crumble_hip *h, const crumble_batch *b)
+/* the batch's per-read and per-base arrays are ON THE DEVICE already, inside BAM records (crumble_stream, stream_host.h):
+ * where the records are, what k_st_fields found in them, and the hints copy_raw otherwise samples from host arrays */
+struct DevSrc {
+    const uint8_t *rec; const int64_t *rec_off;          /* device: the record bytes, record i at rec[rec_off[i]] */
+    const int32_t *pos; const uint8_t *mapq; const uint16_t *flag; const int32_t *lq; const uint16_t *ncg; const uint8_t *noq;   /* device, [n] */
+    int64_t mq_hist[256];                                /* host: sampled mapq histogram */
+    bool lowerr;                                         /* host: mean base error below 2 % */
+};
+static int copy_raw(crumble_hip *h, const crumble_batch *b, const DevSrc *ds = nullptr)
 {
     hipStream_t st = h->stream;
     const int64_t n = b->n_reads;
     /* the offset tables, or BAM's own per-read lengths (6 bytes per read over PCIe instead of 16; offsets made on the device) */
-    const bool lens = b->l_qseq != nullptr && b->n_cigar != nullptr;
+    const bool lens = ds || (b->l_qseq != nullptr && b->n_cigar != nullptr);
     if (!lens && n && (!b->seq_off || !b->cig_off)) { g_last_error = "crumble_batch: neither seq_off / cig_off nor l_qseq / n_cigar"; return CRUMBLE_EINVAL; }
     const int64_t nb = !n ? 0 : lens ? b->n_bases : b->seq_off[n], nc = !n ? 0 : lens ? b->n_cigar_ops : b->cig_off[n];
     if (n >= (int64_t)INT_MAX - 64) { g_last_error = "more than 2^31 reads in one batch"; return CRUMBLE_EINVAL; }
     if (nb < 0 || nc < 0) { g_last_error = "negative total length"; return CRUMBLE_EINVAL; }
     h->have_batch = false; h->have_run = false; h->have_raw = false; h->have_hits = false;
-    const bool packed4 = b->bases4 != nullptr;      /* BAM-packed bases: half the bytes over PCIe, unpacked by k_p0_bases */
+    const bool packed4 = ds || b->bases4 != nullptr;      /* BAM-packed bases: half the bytes over PCIe, unpacked by k_p0_bases */
     if (!packed4 && !b->bases && nb > 0) { g_last_error = "crumble_batch: neither bases nor bases4"; return CRUMBLE_EINVAL; }
-    const int qbits = b->qualsp ? b->qual_bits : 0;   /* coded qualities: a quarter / half of the bytes over PCIe, expanded by k_p0_quals */
+    const int qbits = (!ds && b->qualsp) ? b->qual_bits : 0;   /* coded qualities: a quarter / half of the bytes over PCIe, expanded by k_p0_quals */
     if (qbits != 0 && qbits != 2 && qbits != 4) { g_last_error = "crumble_batch: qual_bits must be 0, 2 or 4"; return CRUMBLE_EINVAL; }
-    if (!qbits && !b->quals && nb > 0) { g_last_error = "crumble_batch: neither quals nor qualsp"; return CRUMBLE_EINVAL; }
+    if (!ds && !qbits && !b->quals && nb > 0) { g_last_error = "crumble_batch: neither quals nor qualsp"; return CRUMBLE_EINVAL; }
     const int n_bed = b->n_bed > 0 ? b->n_bed : 0;
     int e;
     {   /* the mapq most reads carry: the column kernels keep a composed quality table for it in LDS; the next
@@ -440,7 +450,8 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
          * SegRec.info); anything else is looked up in global memory.  Performance hints only. */
         int64_t hist[256] = {0};
         const int64_t hstep = n > 65536 ? n / 65536 : 1;     /* a sample: mapq values it misses are looked up in global memory */
-        for (int64_t i = 0; i < n; i += hstep) hist[b->mapq[i]]++;
+        if (ds) memcpy(hist, ds->mq_hist, sizeof hist);
+        else for (int64_t i = 0; i < n; i += hstep) hist[b->mapq[i]]++;
         int order[256], best = 0;
         for (int i = 0; i < 256; i++) { order[i] = i; if (hist[i] > hist[best]) best = i; }
         h->raw_hot_mq = best;
@@ -462,11 +473,11 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
         double q2e[128];                                     /* (per call: handles may be used from several threads) */
         for (int q = 0; q < 128; q++) q2e[q] = pow(10.0, -q / 10.0);
         const int64_t step = nb > 65536 ? nb / 65536 : 1;
-        for (int64_t i = 0; i < nb; i += step, cnt++) {
+        for (int64_t i = 0; !ds && i < nb; i += step, cnt++) {
             const int q = !qbits ? b->quals[i] : b->qual_lut[(b->qualsp[(i * qbits) >> 3] >> ((i * qbits) & 7)) & ((1 << qbits) - 1)];
             esum += q2e[q & 127];
         }
-        h->raw_lowerr = cnt > 0 && esum < 0.02 * (double)cnt;
+        h->raw_lowerr = ds ? ds->lowerr : (cnt > 0 && esum < 0.02 * (double)cnt);
     }
     /* keep-regions: the prefix max of `end` drives the cursor emulation (bed_preserve) */
     std::vector<int32_t> &pmax = h->raw_pmax;           /* (lives in the handle: the copy below is asynchronous) */
@@ -481,7 +492,7 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
     const size_t b4bytes = packed4 ? (size_t)CRUMBLE_BASES4_SIZE(nb, n) : 0;
     /* a small batch's offsets are made right here (three more launches would cost a 5 kb contig more than its 6 bytes per
      * read save); a large one's by a scan on the device from the lengths it uploads instead */
-    const bool dev_offsets = lens && n > LENS_ON_DEVICE_MIN;
+    const bool dev_offsets = lens && (ds || n > LENS_ON_DEVICE_MIN);
     const int64_t *h_so = b->seq_off, *h_co = b->cig_off;
     if (lens && !dev_offsets && n > 0) {
         h->raw_so.resize((size_t)n + 1); h->raw_co.resize((size_t)n + 1);      /* (live in the handle: the copy below is asynchronous) */
@@ -491,15 +502,18 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
         if (a != nb || c != nc) { g_last_error = "crumble_batch: n_bases / n_cigar_ops do not match the per-read lengths"; return CRUMBLE_EINVAL; }
         h_so = h->raw_so.data(); h_co = h->raw_co.data();
     }                                                     /* (room: bytes the view holds; bytes: what is copied from the host) */
+    /* (a device source: nothing is copied from the host for the per-read / per-base arrays -- bytes 0, room = their size --,
+     * k_st_gather fills them below) */
+#define HB(x_) (ds ? (size_t)0 : (size_t)(x_))
     Item items[] = {
-        {&h->d_pos, b->pos, (size_t)n * 4, 0, 0}, {&h->d_mapq, b->mapq, (size_t)n, 0, 0}, {&h->d_flag, b->flag, (size_t)n * 2, 0, 0},
+        {&h->d_pos, b->pos, HB(n * 4), 0, 0, (size_t)n * 4}, {&h->d_mapq, b->mapq, HB(n), 0, 0, (size_t)n}, {&h->d_flag, b->flag, HB(n * 2), 0, 0, (size_t)n * 2},
         {&h->d_seq_off, dev_offsets ? nullptr : n ? (const void *)h_so : (const void *)&zero64, dev_offsets ? 0 : (size_t)(n + 1) * 8, 0, 0, (size_t)(n + 1) * 8},
         {&h->d_cig_off, dev_offsets ? nullptr : n ? (const void *)h_co : (const void *)&zero64, dev_offsets ? 0 : (size_t)(n + 1) * 8, 0, 0, (size_t)(n + 1) * 8},
-        {&h->d_lq, b->l_qseq, dev_offsets ? (size_t)n * 4 : 0, 0, 0}, {&h->d_ncg, b->n_cigar, dev_offsets ? (size_t)n * 2 : 0, 0, 0},
-        {&h->d_cigar, b->cigar, (size_t)nc * 4, 0, 0},
+        {&h->d_lq, b->l_qseq, HB(dev_offsets ? n * 4 : 0), 0, 0, dev_offsets ? (size_t)n * 4 : 0}, {&h->d_ncg, b->n_cigar, HB(dev_offsets ? n * 2 : 0), 0, 0, dev_offsets ? (size_t)n * 2 : 0},
+        {&h->d_cigar, b->cigar, HB(nc * 4), 0, 0, (size_t)nc * 4},
         {qbits ? &h->d_qualsp : &h->d_quals, qbits ? (const void *)b->qualsp : (const void *)b->quals,
-         qbits ? (size_t)CRUMBLE_QUALSP_SIZE(nb, qbits) - 16 : (size_t)nb, qbits ? 0 : (size_t)BASE_FRONT_PAD, 0},
-        {packed4 ? &h->d_bases4 : &h->d_bases, packed4 ? (const void *)b->bases4 : (const void *)b->bases, packed4 ? b4bytes : (size_t)nb, packed4 ? 0 : (size_t)BASE_FRONT_PAD, 0},
+         HB(qbits ? (size_t)CRUMBLE_QUALSP_SIZE(nb, qbits) - 16 : (size_t)nb), qbits ? 0 : (size_t)BASE_FRONT_PAD, 0, qbits ? (size_t)CRUMBLE_QUALSP_SIZE(nb, qbits) - 16 : (size_t)nb},
+        {packed4 ? &h->d_bases4 : &h->d_bases, packed4 ? (const void *)b->bases4 : (const void *)b->bases, HB(packed4 ? b4bytes : (size_t)nb), packed4 ? 0 : (size_t)BASE_FRONT_PAD, 0, packed4 ? b4bytes : (size_t)nb},
         {&h->d_bed_start, b->bed_start, (size_t)n_bed * 4, 0, 0}, {&h->d_bed_end, b->bed_end, (size_t)n_bed * 4, 0, 0},
         {&h->d_bed_pmax, pmax.data(), (size_t)n_bed * 4, 0, 0}, {&h->d_mqslot, h->raw_mqtab, sizeof h->raw_mqtab, 0, 0},
     };
@@ -539,7 +553,15 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
             if (it.front) HIPCHK(hipMemsetAsync(base + it.off, 0, it.front, st));
             if (it.bytes) HIPCHK(hipMemcpyAsync(base + it.off + it.front, it.src, it.bytes, hipMemcpyHostToDevice, st));
         }
-    if (dev_offsets) {                                  /* seq_off[n + 1], cig_off[n + 1] from the lengths, on the device */
+    if (ds && n > 0) {                                  /* the per-read fields: device to device (k_st_fields left them in the stream's arrays) */
+        HIPCHK(hipMemcpyAsync(h->d_pos.p, ds->pos, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(h->d_mapq.p, ds->mapq, (size_t)n, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(h->d_flag.p, ds->flag, (size_t)n * 2, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(h->d_lq.p, ds->lq, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(h->d_ncg.p, ds->ncg, (size_t)n * 2, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemsetAsync(h->d_quals.p, 0, BASE_FRONT_PAD, st));
+    }
+    if (dev_offsets && n > 0) {                         /* seq_off[n + 1], cig_off[n + 1] from the lengths, on the device */
         const int nch = (int)((n + P0_CHUNK - 1) / P0_CHUNK);
         if ((e = h->d_tpart.reserve((size_t)(2 * (nch + 1) + 2) * 8))) return e;
         int64_t *tp = h->d_tpart.as<int64_t>();
@@ -548,6 +570,10 @@ static int copy_raw(crumble_hip *h, const crumble_batch *b)
         CRUMBLE_LAUNCH(k_p0_len_apply, nch, 256, st, n, h->d_lq.as<int32_t>(), h->d_ncg.as<uint16_t>(), (const int64_t *)tp, nch,
                        h->d_seq_off.as<int64_t>(), h->d_cig_off.as<int64_t>());
     }
+    if (dev_offsets && n == 0) { static const int64_t z2[1] = {0}; HIPCHK(hipMemcpyAsync(h->d_seq_off.p, z2, 8, hipMemcpyHostToDevice, st)); HIPCHK(hipMemcpyAsync(h->d_cig_off.p, z2, 8, hipMemcpyHostToDevice, st)); }
+    if (ds && n > 0)                                    /* CIGAR words, packed bases, qualities out of the records */
+        CRUMBLE_LAUNCH(k_st_gather, (unsigned)((n + 63) / 64), 256, st, ds->rec, ds->rec_off, n, h->d_seq_off.as<int64_t>(), h->d_cig_off.as<int64_t>(),
+                       ds->noq, h->d_cigar.as<uint32_t>(), h->d_bases4.as<uint8_t>(), h->d_quals.as<uint8_t>() + BASE_FRONT_PAD);
     h->raw_tid = b->tid; h->raw_nbed = n_bed; h->raw_packed4 = packed4;
     h->raw_qbits = qbits; memcpy(h->raw_qlut, b->qual_lut, 16);
     h->n_reads = n; h->n_bases = nb; h->n_cigar = nc;
@@ -1852,6 +1878,7 @@ extern "C" int crumble_hip_indel_only(crumble_hip *h, int dist, int q, uint8_t *
 
 /* ------------------------------------------------------------------ BGZF codec on the device (include/crumble_hip.h) */
 #include "gz_host.h"
+#include "stream_host.h"
 
 #ifdef CRUMBLE_EMU
 /* test hook of the emulated build (tests/emu): how many tiles took k_columns2's two finalize paths since the last call */

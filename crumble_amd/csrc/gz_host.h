@@ -92,10 +92,12 @@ static const char *gz_status_text(unsigned s)
 /* Inflates n_blocks BGZF members: blk[i].coff / clen = where member i's DEFLATE payload sits in comp[0, comp_len) (behind
  * its gzip header, in front of its CRC-32 / ISIZE trailer), ulen / crc = that trailer, uoff = where its bytes go in
  * raw[0, raw_len).  uoff must not decrease and the members must not overlap in raw.  check_crc = 0 skips the CRC-32. */
-extern "C" int crumble_gz_inflate(crumble_gz *g, const uint8_t *comp, int64_t comp_len, const crumble_gz_block *blk, int64_t n_blocks,
-                                  uint8_t *raw, int64_t raw_len, int check_crc)
+/* raw: host destination (copied back round by round), or NULL with raw_dev: a DEVICE destination -- member i's bytes go to
+ * raw_dev[blk[i].uoff ...] and stay there (crumble_stream, section 9c) */
+static int gz_inflate_impl(crumble_gz *g, const uint8_t *comp, int64_t comp_len, const crumble_gz_block *blk, int64_t n_blocks,
+                           uint8_t *raw, uint8_t *raw_dev, int64_t raw_len, int check_crc)
 {
-    if (!g || n_blocks < 0 || comp_len < 0 || raw_len < 0 || (n_blocks && (!comp || !blk || !raw))) return CRUMBLE_EINVAL;
+    if (!g || n_blocks < 0 || comp_len < 0 || raw_len < 0 || (n_blocks && (!comp || !blk || (!raw && !raw_dev)))) return CRUMBLE_EINVAL;
     static_assert(sizeof(crumble_gz_block) == sizeof(GzBlock), "crumble_gz_block layout");
     HIPCHK(hipSetDevice(g->device));
     hipStream_t st = g->stream;
@@ -127,7 +129,7 @@ extern "C" int crumble_gz_inflate(crumble_gz *g, const uint8_t *comp, int64_t co
     for (int64_t i0 = 0; i0 < n_blocks; ) {
         /* a round: members [i0, i1) with at most GZ_BATCH_RAW bytes of output */
         /* (a lane per member wants every member of the call in flight at once: its time hardly depends on their number) */
-        const int64_t round_raw = (g->opt_lanes < 0 ? n_blocks - i0 > (int64_t)16 * ncu : g->opt_lanes != 0) ? 16 * GZ_BATCH_RAW : GZ_BATCH_RAW;
+        const int64_t round_raw = (g->opt_lanes < 0 ? n_blocks - i0 > (int64_t)16 * ncu : g->opt_lanes != 0) ? 8 * GZ_BATCH_RAW : GZ_BATCH_RAW;      /* (2 GiB of records = 8 GiB of token slots at most) */
         int64_t i1 = i0, sum = 0;
         while (i1 < n_blocks && (i1 == i0 || sum + (int64_t)blk[i1].ulen <= round_raw)) { sum += blk[i1].ulen; i1++; }
         const int64_t n = i1 - i0;
@@ -138,7 +140,7 @@ extern "C" int crumble_gz_inflate(crumble_gz *g, const uint8_t *comp, int64_t co
         tokoff[(size_t)n] = t;
         if ((e = g->d_blk.reserve((size_t)n * sizeof(GzBlock))) || (e = g->d_tokoff.reserve((size_t)(n + 1) * 8)) ||
             (e = g->d_tok.reserve((size_t)(t + 64) * 4)) || (e = g->d_ntok.reserve((size_t)n * 4)) || (e = g->d_status.reserve((size_t)n * 4)) ||
-            (e = g->d_raw.reserve((size_t)(u1 - u0) + 64)))
+            (!raw_dev && (e = g->d_raw.reserve((size_t)(u1 - u0) + 64))))
             return e;
         HIPCHK(hipMemsetAsync(g->d_status.p, 0xff, (size_t)n * 4, st));      /* (k_gz_tokens writes every member's word) */
         HIPCHK(hipMemcpyAsync(g->d_blk.p, blk + i0, (size_t)n * sizeof(GzBlock), hipMemcpyHostToDevice, st));
@@ -156,12 +158,12 @@ extern "C" int crumble_gz_inflate(crumble_gz *g, const uint8_t *comp, int64_t co
         /* (uoff is relative to the caller's raw: the round's image starts at u0) */
         CRUMBLE_LAUNCH(k_gz_resolve, (unsigned)(n < 4 * ncu ? n : 4 * ncu), GZ_RT, st, (int)n, g->d_blk.as<GzBlock>(), g->d_tok.as<uint32_t>(), g->d_tokoff.as<int64_t>(),
                        g->d_ntok.as<uint32_t>(), g->d_status.as<uint32_t>(), g->d_tabs.as<uint32_t>(), g->d_tabs.as<uint32_t>() + 256,
-                       g->d_raw.as<uint8_t>() - u0, check_crc);
+                       raw_dev ? raw_dev : g->d_raw.as<uint8_t>() - u0, check_crc);
         HIPCHK(hipGetLastError());                           /* (a launch that the device refuses must not pass as an empty result) */
         HIPCHK(hipEventRecord(g->ev[1], st));
         stat.resize((size_t)n);
         HIPCHK(hipMemcpyAsync(stat.data(), g->d_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(raw + u0, g->d_raw.p, (size_t)(u1 - u0), hipMemcpyDeviceToHost, st));
+        if (!raw_dev) HIPCHK(hipMemcpyAsync(raw + u0, g->d_raw.p, (size_t)(u1 - u0), hipMemcpyDeviceToHost, st));
         HIPCHK(hipEventRecord(g->ev[2], st));
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipEventElapsedTime(&ms, g->ev[0], g->ev[1])); acc_k += ms;
@@ -180,11 +182,19 @@ extern "C" int crumble_gz_inflate(crumble_gz *g, const uint8_t *comp, int64_t co
     return CRUMBLE_OK;
 }
 
-/* Deflates raw[0, raw_len) into BGZF members of 0xff00 input bytes each (the last one shorter), side by side in out; no
- * end-of-file member.  level 0: stored blocks; any other value: the one compression level the device has. */
-extern "C" int crumble_gz_deflate(crumble_gz *g, const uint8_t *raw, int64_t raw_len, int level, uint8_t *out, int64_t out_cap, int64_t *out_len)
+extern "C" int crumble_gz_inflate(crumble_gz *g, const uint8_t *comp, int64_t comp_len, const crumble_gz_block *blk, int64_t n_blocks,
+                                  uint8_t *raw, int64_t raw_len, int check_crc)
 {
-    if (!g || raw_len < 0 || !out_len || (raw_len && (!raw || !out))) return CRUMBLE_EINVAL;
+    if (n_blocks && !raw) return CRUMBLE_EINVAL;
+    return gz_inflate_impl(g, comp, comp_len, blk, n_blocks, raw, nullptr, raw_len, check_crc);
+}
+
+/* Deflates raw[0, raw_len) into BGZF members of 0xff00 input bytes each (the last one shorter), side by side in out; no
+ * end-of-file member.  level 0: stored blocks; any other value: the one compression level the device has.
+ * (raw: host source, or NULL with raw_dev: the bytes are on the device already) */
+static int gz_deflate_impl(crumble_gz *g, const uint8_t *raw, const uint8_t *raw_dev, int64_t raw_len, int level, uint8_t *out, int64_t out_cap, int64_t *out_len)
+{
+    if (!g || raw_len < 0 || !out_len || (raw_len && ((!raw && !raw_dev) || !out))) return CRUMBLE_EINVAL;
     *out_len = 0;
     HIPCHK(hipSetDevice(g->device));
     hipStream_t st = g->stream;
@@ -203,13 +213,13 @@ extern "C" int crumble_gz_deflate(crumble_gz *g, const uint8_t *raw, int64_t raw
     for (int64_t r0 = 0; r0 < raw_len; r0 += per_round) {
         const int64_t len = raw_len - r0 < per_round ? raw_len - r0 : per_round;
         const int nb = (int)((len + GZ_MAXBLK - 1) / GZ_MAXBLK);
-        if ((e = g->d_raw.reserve((size_t)len + 64)) || (e = g->d_tok.reserve((size_t)nb * 65536 * 4)) || (e = g->d_cand.reserve((size_t)nb * 65536 * 4)) || (e = g->d_slots.reserve((size_t)nb * GZ_SLOT)) ||
+        if ((!raw_dev && (e = g->d_raw.reserve((size_t)len + 64))) || (e = g->d_tok.reserve((size_t)nb * 65536 * 4)) || (e = g->d_cand.reserve((size_t)nb * 65536 * 4)) || (e = g->d_slots.reserve((size_t)nb * GZ_SLOT)) ||
             (e = g->d_sizes.reserve((size_t)nb * 4)) || (e = g->d_off.reserve((size_t)(nb + 1) * 8)) || (e = g->d_out.reserve((size_t)nb * GZ_SLOT)))
             return e;
         HIPCHK(hipEventRecord(g->ev[0], st));
-        HIPCHK(hipMemcpyAsync(g->d_raw.p, raw + r0, (size_t)len, hipMemcpyHostToDevice, st));
+        if (!raw_dev) HIPCHK(hipMemcpyAsync(g->d_raw.p, raw + r0, (size_t)len, hipMemcpyHostToDevice, st));
         HIPCHK(hipEventRecord(g->ev[1], st));
-        CRUMBLE_LAUNCH(k_gz_deflate, (unsigned)(nb < ncu ? nb : ncu), GZ_DT, st, nb, g->d_raw.as<uint8_t>(), len, level, g->d_tok.as<uint32_t>(), g->d_cand.as<uint32_t>(),
+        CRUMBLE_LAUNCH(k_gz_deflate, (unsigned)(nb < ncu ? nb : ncu), GZ_DT, st, nb, raw_dev ? raw_dev + r0 : g->d_raw.as<const uint8_t>(), len, level, g->d_tok.as<uint32_t>(), g->d_cand.as<uint32_t>(),
                        g->d_slots.as<uint8_t>(), g->d_sizes.as<uint32_t>(), g->d_tabs.as<uint32_t>(), g->d_tabs.as<uint32_t>() + 256);
         CRUMBLE_LAUNCH(k_gz_offsets, 1, 1024, st, nb, g->d_sizes.as<uint32_t>(), g->d_off.as<int64_t>());
         CRUMBLE_LAUNCH(k_gz_gather, (unsigned)nb, 256, st, nb, g->d_slots.as<uint8_t>(), g->d_sizes.as<uint32_t>(), g->d_off.as<int64_t>(), g->d_out.as<uint8_t>());
@@ -230,6 +240,12 @@ extern "C" int crumble_gz_deflate(crumble_gz *g, const uint8_t *raw, int64_t raw
     }
     *out_len = produced; g->last_out = produced;
     return CRUMBLE_OK;
+}
+
+extern "C" int crumble_gz_deflate(crumble_gz *g, const uint8_t *raw, int64_t raw_len, int level, uint8_t *out, int64_t out_cap, int64_t *out_len)
+{
+    if (raw_len && !raw) return CRUMBLE_EINVAL;
+    return gz_deflate_impl(g, raw, nullptr, raw_len, level, out, out_cap, out_len);
 }
 
 /* implementation choices that never change a result (the tests force both): "tokens" = auto | wave | lane */

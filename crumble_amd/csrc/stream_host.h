@@ -1,0 +1,290 @@
+/*
+ * stream_host.h -- crumble_stream: a BAM file's records on the device from inflate to deflate (include/crumble_hip.h).
+ * Included by engine.hip behind gz_host.h (one translation unit: it reaches into crumble_hip and crumble_gz).
+ *
+ *   feed     whole BGZF members (host bytes) -> inflated behind what the device buffer holds (crumble_gz, CRC-32 checked),
+ *            record starts found (stream_kernels.h: guess / walk / verify), contig runs found
+ *   process  one contig's records -> an engine (k_st_fields, the engine's own expansion and run, k_st_scatter): the
+ *            engine's input never exists on the host, its output qualities go straight back into the records
+ *   drain    the records of the first k contigs deflated into BGZF members (crumble_gz), host bytes out; the rest moves
+ *            to the front of the buffer
+ * What crosses PCIe is the compressed file, once in each direction, plus a few words per contig.
+ */
+#ifndef CRUMBLE_STREAM_HOST_H
+#define CRUMBLE_STREAM_HOST_H
+
+#include "stream_kernels.h"
+
+struct crumble_stream {
+    int device = 0;
+    crumble_gz *gz = nullptr;                    /* codec context (its stream carries this object's kernels too) */
+    int n_ref = 0;
+    DevBuf d_rec[2];                             /* the record bytes: [0, len) of d_rec[cur] */
+    int cur = 0;
+    int64_t len = 0;                             /* bytes in the buffer */
+    int64_t start = 0;                           /* first record (behind the BAM header on the first feed) */
+    int64_t tail = 0;                            /* where the incomplete last record starts (== len when there is none) */
+    int64_t n_rec = 0;
+    DevBuf d_guess, d_exit, d_count, d_slots, d_coff, d_recoff, d_list, d_misc, d_err;
+    DevBuf d_pos, d_mapq, d_flag, d_lq, d_ncg, d_noq, d_tot;
+    std::vector<crumble_stream_group> groups;    /* in record order; the last one may go on in the next feed */
+    bool eof = false;
+    void *pinned = nullptr;
+    int64_t bytes_in = 0, bytes_out = 0;         /* compressed bytes fed / drained so far */
+    float ms_inflate = 0, ms_sync = 0, ms_engine = 0, ms_deflate = 0;
+};
+
+extern "C" crumble_stream *crumble_stream_create(int device, int32_t n_ref, int64_t header_bytes, int *err)
+{
+    int dummy; if (!err) err = &dummy;
+    *err = CRUMBLE_OK;
+    crumble_gz *gz = crumble_gz_create(device, err);
+    if (!gz) return nullptr;
+    crumble_stream *s = new (std::nothrow) crumble_stream();
+    if (!s) { crumble_gz_destroy(gz); *err = CRUMBLE_ENOMEM; return nullptr; }
+    s->device = device; s->gz = gz; s->n_ref = n_ref; s->start = header_bytes > 0 ? header_bytes : 0;
+    bool ok = hipHostMalloc(&s->pinned, 4096, 0) == hipSuccess;
+    uint32_t ppm[128];
+    for (int q = 0; q < 128; q++) ppm[q] = (uint32_t)(1e6 * pow(10.0, -q / 10.0) + 0.5);
+    ok = ok && s->d_err.reserve(sizeof ppm) == CRUMBLE_OK && copy_sync(gz->stream, s->d_err.p, ppm, sizeof ppm, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && s->d_misc.reserve(256) == CRUMBLE_OK && s->d_tot.reserve(sizeof(StTotals)) == CRUMBLE_OK;
+    if (!ok) { g_last_error = "crumble_stream: device set-up failed"; *err = CRUMBLE_EHIP; crumble_stream_destroy(s); return nullptr; }
+    return s;
+}
+
+extern "C" void crumble_stream_destroy(crumble_stream *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->gz && s->gz->stream) (void)hipStreamSynchronize(s->gz->stream);
+    DevBuf *all[] = { &s->d_rec[0], &s->d_rec[1], &s->d_guess, &s->d_exit, &s->d_count, &s->d_slots, &s->d_coff, &s->d_recoff, &s->d_list,
+                      &s->d_misc, &s->d_err, &s->d_pos, &s->d_mapq, &s->d_flag, &s->d_lq, &s->d_ncg, &s->d_noq, &s->d_tot };
+    for (DevBuf *b : all) b->release();
+    if (s->pinned) (void)hipHostFree(s->pinned);
+    crumble_gz_destroy(s->gz);
+    delete s;
+}
+
+/* record starts and contig runs of d_rec[cur][start, len) */
+static int stream_sync(crumble_stream *s)
+{
+    hipStream_t st = s->gz->stream;
+    const uint8_t *R = s->d_rec[s->cur].as<uint8_t>();
+    s->groups.clear(); s->n_rec = 0; s->tail = s->start;
+    if (s->len <= s->start) return CRUMBLE_OK;
+    const int nch = (int)((s->len - s->start + ST_CHUNK - 1) / ST_CHUNK);
+    int e;
+    if ((e = s->d_guess.reserve((size_t)nch * 8)) || (e = s->d_exit.reserve((size_t)nch * 8)) || (e = s->d_count.reserve((size_t)nch * 4)) ||
+        (e = s->d_slots.reserve((size_t)nch * ST_MAXREC * 8)) || (e = s->d_coff.reserve((size_t)(nch + 1) * 8)))
+        return e;
+    int *bad = s->d_misc.as<int>();
+    int64_t *tailp = (int64_t *)(s->d_misc.as<char>() + 16);
+    int *nlist = (int *)(s->d_misc.as<char>() + 32);
+    HIPCHK(hipMemsetAsync(s->d_misc.p, 0, 64, st));
+    CRUMBLE_LAUNCH(k_st_guess, nch, 64, st, R, s->start, s->len, s->n_ref, nch, s->d_guess.as<int64_t>());
+    CRUMBLE_LAUNCH(k_st_walk, (nch + 63) / 64, 64, st, R, s->start, s->len, nch, s->d_guess.as<int64_t>(), s->d_slots.as<int64_t>(),
+                   s->d_count.as<int32_t>(), s->d_exit.as<int64_t>());
+    CRUMBLE_LAUNCH(k_st_verify, (nch + 255) / 256, 256, st, nch, s->d_guess.as<int64_t>(), s->d_exit.as<int64_t>(), s->d_count.as<int32_t>(), bad);
+    CRUMBLE_LAUNCH(k_st_tail, 1, 1, st, nch, s->d_guess.as<int64_t>(), s->d_exit.as<int64_t>(), s->len, tailp, bad);
+    CRUMBLE_LAUNCH(k_st_offsets, 1, 1024, st, nch, s->d_count.as<int32_t>(), s->d_coff.as<int64_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(s->pinned, s->d_misc.p, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync((char *)s->pinned + 64, s->d_coff.as<int64_t>() + nch, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    int hbad; int64_t htail, nrec;
+    memcpy(&hbad, s->pinned, 4); memcpy(&htail, (char *)s->pinned + 16, 8); memcpy(&nrec, (char *)s->pinned + 64, 8);
+    if (hbad) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "crumble_stream: the BAM records could not be delimited (check %d): not a BAM record stream, or corrupt", hbad);
+        g_last_error = buf;
+        return CRUMBLE_EINVAL;
+    }
+    s->tail = htail; s->n_rec = nrec;
+    if (!nrec) return CRUMBLE_OK;
+    const int max_list = 1 << 20;
+    if ((e = s->d_recoff.reserve((size_t)(nrec + 1) * 8)) || (e = s->d_list.reserve((size_t)max_list * 16))) return e;
+    CRUMBLE_LAUNCH(k_st_compact, nch, 256, st, nch, s->d_slots.as<int64_t>(), s->d_count.as<int32_t>(), s->d_coff.as<int64_t>(), s->d_recoff.as<int64_t>());
+    CRUMBLE_LAUNCH(k_st_groups, (unsigned)((nrec + 255) / 256), 256, st, R, s->len, s->n_ref, nrec, s->d_recoff.as<int64_t>(), s->d_list.as<int64_t>(),
+                   nlist, max_list, bad);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(s->pinned, s->d_misc.p, 48, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    int nl;
+    memcpy(&hbad, s->pinned, 4); memcpy(&nl, (char *)s->pinned + 32, 4);
+    if (hbad || nl > max_list) { g_last_error = "crumble_stream: implausible BAM record (or more than a million contig runs in one feed)"; return CRUMBLE_EINVAL; }
+    std::vector<int64_t> list((size_t)nl * 2);
+    HIPCHK(copy_sync(st, list.data(), s->d_list.p, (size_t)nl * 16, hipMemcpyDeviceToHost));
+    std::vector<std::pair<int64_t, int64_t>> runs((size_t)nl);
+    for (int i = 0; i < nl; i++) runs[(size_t)i] = { list[2 * (size_t)i], list[2 * (size_t)i + 1] };
+    std::sort(runs.begin(), runs.end());
+    /* the byte range of a run: from its first record to the next run's first record (the last one: to the tail) */
+    std::vector<int64_t> first((size_t)nl + 1);
+    {
+        std::vector<int64_t> idx((size_t)nl);
+        for (int i = 0; i < nl; i++) idx[(size_t)i] = runs[(size_t)i].first;
+        /* rec_off of the runs' first records: gathered one by one (a handful per feed) */
+        for (int i = 0; i < nl; i++) HIPCHK(hipMemcpyAsync(&first[(size_t)i], s->d_recoff.as<int64_t>() + idx[(size_t)i], 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        first[(size_t)nl] = s->tail;
+    }
+    for (int i = 0; i < nl; i++) {
+        crumble_stream_group g;
+        memset(&g, 0, sizeof g);
+        g.tid = (int32_t)runs[(size_t)i].second;
+        g.first_read = runs[(size_t)i].first;
+        g.n_reads = (i + 1 < nl ? runs[(size_t)i + 1].first : nrec) - g.first_read;
+        g.byte_start = first[(size_t)i]; g.byte_end = first[(size_t)i + 1];
+        g.complete = (i + 1 < nl || s->eof) ? 1 : 0;
+        if (i && g.tid >= 0 && runs[(size_t)i - 1].second >= 0 && g.tid < runs[(size_t)i - 1].second) { g_last_error = "crumble_stream: contigs out of header order"; return CRUMBLE_EUNSORTED; }
+        s->groups.push_back(g);
+    }
+    return CRUMBLE_OK;
+}
+
+/* More of the file: whole BGZF members (crumble_bgzf_scan's table; uoff is ignored -- the members' bytes go behind what the
+ * buffer holds, in order).  eof: nothing follows (the last contig run is then complete, and an incomplete record an error). */
+extern "C" int crumble_stream_feed(crumble_stream *s, const uint8_t *comp, int64_t comp_len, const crumble_gz_block *blk, int64_t n_blocks, int eof)
+{
+    if (!s || comp_len < 0 || n_blocks < 0 || (n_blocks && (!comp || !blk))) return CRUMBLE_EINVAL;
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = s->gz->stream;
+    int64_t add = 0;
+    for (int64_t i = 0; i < n_blocks; i++) add += blk[i].ulen;
+    DevBuf &B = s->d_rec[s->cur];
+    const size_t need = (size_t)(s->len + add) + 4096;
+    int e;
+    if (need > B.cap) {                                     /* grow: into the other buffer, the bytes so far copied over */
+        DevBuf &N = s->d_rec[s->cur ^ 1];
+        size_t want = B.cap ? B.cap : ((size_t)1 << 30);
+        while (want < need) want += want / 2;
+        if ((e = N.reserve(want))) return e;
+        if (s->len) CRUMBLE_LAUNCH(k_st_copy, 1024, 256, st, B.as<const uint8_t>(), N.as<uint8_t>(), s->len);
+        HIPCHK(hipStreamSynchronize(st));
+        s->cur ^= 1;
+    }
+    uint8_t *R = s->d_rec[s->cur].as<uint8_t>();
+    std::vector<crumble_gz_block> b2((size_t)n_blocks);
+    int64_t u = s->len;
+    for (int64_t i = 0; i < n_blocks; i++) { b2[(size_t)i] = blk[i]; b2[(size_t)i].uoff = u; u += blk[i].ulen; }
+    if (n_blocks && (e = gz_inflate_impl(s->gz, comp, comp_len, b2.data(), n_blocks, nullptr, R, u, 1))) return e;
+    s->ms_inflate += s->gz->ms_h2d + s->gz->ms_kernels;
+    s->len = u; s->eof = eof != 0; s->bytes_in += comp_len;
+    HIPCHK(hipMemsetAsync(R + s->len, 0, 4096, st));
+    if ((e = stream_sync(s))) return e;
+    if (s->eof && s->tail != s->len) { g_last_error = "crumble_stream: truncated BAM record at the end of the file"; return CRUMBLE_EINVAL; }
+    return CRUMBLE_OK;
+}
+
+/* the contig runs the buffer holds, in order (valid until the next feed / drain); returns their number */
+extern "C" int crumble_stream_groups(crumble_stream *s, crumble_stream_group *out, int max)
+{
+    if (!s) return CRUMBLE_EINVAL;
+    const int n = (int)s->groups.size();
+    for (int i = 0; i < n && i < max; i++) out[i] = s->groups[(size_t)i];
+    return n;
+}
+
+/* One contig run through an engine of the same device: the engine's batch is made from the records on the device
+ * (crumble_hip_upload's work without a host array), run, and the output qualities written back into the records.
+ * bed_*: this contig's keep regions (host, after crumble_bed_collapse), n_bed 0 for none.  The engine's statistics
+ * accumulate as with crumble_hip_contig().  CRUMBLE_EUNSUPP-like cases (a CG-tag CIGAR) return CRUMBLE_EINVAL with a
+ * message: the caller falls back to the host path for the file. */
+extern "C" int crumble_stream_process(crumble_stream *s, crumble_hip *h, int group, int32_t n_bed, const int32_t *bed_start, const int32_t *bed_end)
+{
+    if (!s || !h || group < 0 || group >= (int)s->groups.size() || h->device != s->device) return CRUMBLE_EINVAL;
+    const crumble_stream_group &g = s->groups[(size_t)group];
+    if (!g.complete) { g_last_error = "crumble_stream_process: the contig run is not complete yet"; return CRUMBLE_EINVAL; }
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = s->gz->stream;
+    const int64_t n = g.n_reads;
+    int e;
+    if ((e = s->d_pos.reserve((size_t)n * 4 + 64)) || (e = s->d_mapq.reserve((size_t)n + 64)) || (e = s->d_flag.reserve((size_t)n * 2 + 64)) ||
+        (e = s->d_lq.reserve((size_t)n * 4 + 64)) || (e = s->d_ncg.reserve((size_t)n * 2 + 64)) || (e = s->d_noq.reserve((size_t)n + 64)))
+        return e;
+    uint8_t *R = s->d_rec[s->cur].as<uint8_t>();
+    const int64_t *ro = s->d_recoff.as<int64_t>() + g.first_read;
+    HIPCHK(hipMemsetAsync(s->d_tot.p, 0, sizeof(StTotals), st));
+    const int64_t step = n > 65536 ? n / 65536 : 1;
+    if (n) CRUMBLE_LAUNCH(k_st_fields, (unsigned)((n + 255) / 256), 256, st, R, ro, n, s->d_pos.as<int32_t>(), s->d_mapq.as<uint8_t>(), s->d_flag.as<uint16_t>(),
+                          s->d_lq.as<int32_t>(), s->d_ncg.as<uint16_t>(), s->d_noq.as<uint8_t>(), s->d_tot.as<StTotals>(), s->d_err.as<uint32_t>(), step);
+    HIPCHK(hipGetLastError());
+    StTotals tot;
+    HIPCHK(copy_sync(st, &tot, s->d_tot.p, sizeof tot, hipMemcpyDeviceToHost));
+    if (tot.unsupported) { g_last_error = "crumble_stream: a CIGAR of more than 65535 operations (CG tag): not taken on the device path"; return CRUMBLE_EINVAL; }
+    crumble_batch b;
+    memset(&b, 0, sizeof b);
+    b.tid = g.tid; b.n_reads = n; b.n_bases = (int64_t)tot.n_bases; b.n_cigar_ops = (int64_t)tot.n_cigar;
+    b.n_bed = g.tid >= 0 ? n_bed : 0; b.bed_start = bed_start; b.bed_end = bed_end;
+    DevSrc ds;
+    memset(&ds, 0, sizeof ds);
+    ds.rec = R; ds.rec_off = ro;
+    ds.pos = s->d_pos.as<int32_t>(); ds.mapq = s->d_mapq.as<uint8_t>(); ds.flag = s->d_flag.as<uint16_t>();
+    ds.lq = s->d_lq.as<int32_t>(); ds.ncg = s->d_ncg.as<uint16_t>(); ds.noq = s->d_noq.as<uint8_t>();
+    for (int i = 0; i < 256; i++) ds.mq_hist[i] = tot.mq_hist[i];
+    ds.lowerr = tot.err_cnt > 0 && (double)tot.err_ppm < 20000.0 * (double)tot.err_cnt;
+    /* the engine's own stream from here on: what this object's stream wrote is complete (the read-back above) */
+    HIPCHK(hipEventRecord(h->ev_up[0], h->stream));
+    if ((e = copy_raw(h, &b, &ds))) return e;
+    if ((e = expand(h, true))) return e;
+    if ((e = crumble_hip_run(h))) return e;
+    if (n && b.n_bases)
+        CRUMBLE_LAUNCH(k_st_scatter, (unsigned)((n + 63) / 64), 256, h->stream, R, ro, n, h->d_seq_off.as<int64_t>(), s->d_noq.as<uint8_t>(), h->d_out.as<uint8_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    s->groups[(size_t)group].n_bases = b.n_bases;
+    return CRUMBLE_OK;
+}
+
+/* The records of the first k contig runs (all of them processed, or meant to pass unchanged) as BGZF members into out;
+ * they leave the buffer, what lies behind them moves to its front.  out_cap >= crumble_gz_deflate_bound(their bytes). */
+extern "C" int crumble_stream_drain(crumble_stream *s, int k, int level, uint8_t *out, int64_t out_cap, int64_t *out_len)
+{
+    if (!s || k < 0 || k > (int)s->groups.size() || !out_len) return CRUMBLE_EINVAL;
+    *out_len = 0;
+    if (!k) return CRUMBLE_OK;
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = s->gz->stream;
+    const int64_t b0 = s->groups[0].byte_start, b1 = s->groups[(size_t)k - 1].byte_end;
+    uint8_t *R = s->d_rec[s->cur].as<uint8_t>();
+    int e;
+    if (b1 > b0 && (e = gz_deflate_impl(s->gz, nullptr, R + b0, b1 - b0, level, out, out_cap, out_len))) return e;
+    s->ms_deflate += s->gz->ms_kernels + s->gz->ms_d2h;
+    s->bytes_out += *out_len;
+    /* what is left: [b1, len) to the front of the other buffer */
+    const int64_t rest = s->len - b1;
+    DevBuf &N = s->d_rec[s->cur ^ 1];
+    {
+        const size_t keep = (size_t)(rest > 0 ? rest : 0) + 4096, capc = s->d_rec[s->cur].cap;
+        if (N.cap < keep && (e = N.reserve(keep > capc ? keep : capc))) return e;      /* (as large as its twin: the next feed appends) */
+    }
+    if (rest > 0) CRUMBLE_LAUNCH(k_st_copy, 1024, 256, st, R + b1, N.as<uint8_t>(), rest);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    s->cur ^= 1; s->len = rest > 0 ? rest : 0; s->start = 0;
+    if ((e = stream_sync(s))) return e;
+    return CRUMBLE_OK;
+}
+
+/* the bytes of the buffer (tests): d_rec[cur][from, from + n) -> host */
+extern "C" int crumble_stream_peek(crumble_stream *s, int64_t from, int64_t n, uint8_t *out, int64_t *len, int64_t *n_rec, int64_t *rec_off, int64_t max_rec)
+{
+    if (!s) return CRUMBLE_EINVAL;
+    HIPCHK(hipSetDevice(s->device));
+    if (len) *len = s->len;
+    if (n_rec) *n_rec = s->n_rec;
+    if (out && n > 0) { if (from < 0 || from + n > s->len) return CRUMBLE_EINVAL; HIPCHK(copy_sync(s->gz->stream, out, s->d_rec[s->cur].as<uint8_t>() + from, (size_t)n, hipMemcpyDeviceToHost)); }
+    if (rec_off && max_rec > 0 && s->n_rec) HIPCHK(copy_sync(s->gz->stream, rec_off, s->d_recoff.p, (size_t)(s->n_rec < max_rec ? s->n_rec : max_rec) * 8, hipMemcpyDeviceToHost));
+    return CRUMBLE_OK;
+}
+
+extern "C" int crumble_stream_times(crumble_stream *s, float *inflate_ms, float *deflate_ms, int64_t *bytes_in, int64_t *bytes_out)
+{
+    if (!s) return CRUMBLE_EINVAL;
+    if (inflate_ms) *inflate_ms = s->ms_inflate;
+    if (deflate_ms) *deflate_ms = s->ms_deflate;
+    if (bytes_in) *bytes_in = s->bytes_in;
+    if (bytes_out) *bytes_out = s->bytes_out;
+    return CRUMBLE_OK;
+}
+
+#endif /* CRUMBLE_STREAM_HOST_H */

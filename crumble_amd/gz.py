@@ -105,3 +105,84 @@ class GzCodec:
         a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
         self.L.crumble_gz_times(self.h, C.byref(a), C.byref(b), C.byref(c))
         return {"h2d_ms": a.value, "kernels_ms": b.value, "d2h_ms": c.value}
+
+
+class StreamGroup(C.Structure):
+    _fields_ = [("tid", C.c_int32), ("complete", C.c_int32), ("first_read", C.c_int64), ("n_reads", C.c_int64),
+                ("n_bases", C.c_int64), ("byte_start", C.c_int64), ("byte_end", C.c_int64)]
+
+
+class Stream:
+    """crumble_stream (include/crumble_hip.h): a BAM file's records on the device from inflate to deflate"""
+
+    def __init__(self, n_ref, header_bytes, device=0, library=None):
+        L = self.L = _sig(library if library is not None else lib())
+        vp, i64 = C.c_void_p, C.c_int64
+        L.crumble_stream_create.restype = vp
+        L.crumble_stream_create.argtypes = [C.c_int, C.c_int32, i64, C.POINTER(C.c_int)]
+        L.crumble_stream_destroy.restype = None
+        L.crumble_stream_destroy.argtypes = [vp]
+        L.crumble_stream_feed.restype = C.c_int
+        L.crumble_stream_feed.argtypes = [vp, vp, i64, vp, i64, C.c_int]
+        L.crumble_stream_groups.restype = C.c_int
+        L.crumble_stream_groups.argtypes = [vp, vp, C.c_int]
+        L.crumble_stream_process.restype = C.c_int
+        L.crumble_stream_process.argtypes = [vp, vp, C.c_int, C.c_int32, vp, vp]
+        L.crumble_stream_drain.restype = C.c_int
+        L.crumble_stream_drain.argtypes = [vp, C.c_int, C.c_int, vp, i64, C.POINTER(i64)]
+        L.crumble_stream_peek.restype = C.c_int
+        L.crumble_stream_peek.argtypes = [vp, i64, i64, vp, C.POINTER(i64), C.POINTER(i64), vp, i64]
+        err = C.c_int(0)
+        self.h = L.crumble_stream_create(device, n_ref, header_bytes, C.byref(err))
+        if not self.h:
+            raise CrumbleError(err.value, "crumble_stream_create", L)
+
+    def close(self):
+        if self.h:
+            self.L.crumble_stream_destroy(self.h)
+            self.h = None
+
+    def feed(self, comp, eof):
+        a = np.frombuffer(comp, np.uint8) if not isinstance(comp, np.ndarray) else comp
+        blocks, consumed, total = bgzf_scan(a, self.L) if a.size else (np.zeros(0, BLOCK_DTYPE), 0, 0)
+        blocks = np.ascontiguousarray(blocks)
+        rc = self.L.crumble_stream_feed(self.h, a.ctypes.data if a.size else None, consumed, blocks.ctypes.data if len(blocks) else None, len(blocks), 1 if eof else 0)
+        if rc:
+            raise CrumbleError(rc, "crumble_stream_feed", self.L)
+        return consumed
+
+    def groups(self):
+        g = (StreamGroup * 4096)()
+        n = self.L.crumble_stream_groups(self.h, g, 4096)
+        return [g[i] for i in range(min(n, 4096))]
+
+    def process(self, engine, i, bed=None):
+        if bed is not None and len(bed):
+            bs = np.ascontiguousarray(bed[:, 0], np.int32); be = np.ascontiguousarray(bed[:, 1], np.int32)
+            rc = self.L.crumble_stream_process(self.h, engine.h, i, len(bs), bs.ctypes.data, be.ctypes.data)
+        else:
+            rc = self.L.crumble_stream_process(self.h, engine.h, i, 0, None, None)
+        if rc:
+            raise CrumbleError(rc, "crumble_stream_process", self.L)
+
+    def drain(self, k, level=6):
+        gs = self.groups()
+        nbytes = (gs[k - 1].byte_end - gs[0].byte_start) if k else 0
+        cap = int(self.L.crumble_gz_deflate_bound(nbytes)) + 64
+        out = np.empty(cap, np.uint8)
+        n = C.c_int64(0)
+        rc = self.L.crumble_stream_drain(self.h, k, level, out.ctypes.data, cap, C.byref(n))
+        if rc:
+            raise CrumbleError(rc, "crumble_stream_drain", self.L)
+        return out[:n.value]
+
+    def peek(self):
+        """(buffer bytes, record offsets)"""
+        ln, nr = C.c_int64(0), C.c_int64(0)
+        self.L.crumble_stream_peek(self.h, 0, 0, None, C.byref(ln), C.byref(nr), None, 0)
+        buf = np.empty(max(ln.value, 1), np.uint8)
+        ro = np.empty(max(nr.value, 1), np.int64)
+        rc = self.L.crumble_stream_peek(self.h, 0, ln.value, buf.ctypes.data, C.byref(ln), C.byref(nr), ro.ctypes.data, nr.value)
+        if rc:
+            raise CrumbleError(rc, "crumble_stream_peek", self.L)
+        return buf[:ln.value], ro[:nr.value]

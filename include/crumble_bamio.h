@@ -98,6 +98,10 @@ int crumble_bam_write_group(crumble_bam_writer *w, crumble_bam_reader *r, const 
  * codes refer to -- no intermediate quality array on the host, a quarter of the bytes over PCIe. */
 int crumble_bam_write_group_coded(crumble_bam_writer *w, crumble_bam_reader *r, const crumble_coded *c);
 int crumble_bam_write_detached_coded(crumble_bam_writer *w, crumble_bam_group *g, const crumble_coded *c);
+/* bytes of the BAM header (magic, text, reference list) in the inflated stream: where the first record starts */
+int64_t crumble_bam_header_bytes(const crumble_bam_reader *r);
+/* appends bytes that are whole BGZF members already (crumble_stream_drain's output) */
+int crumble_bam_write_members(crumble_bam_writer *w, const uint8_t *members, size_t n);
 /* Writes the BGZF EOF block and closes. */
 int crumble_bam_writer_close(crumble_bam_writer *w);
 

@@ -442,6 +442,41 @@ int     crumble_gz_set_option(crumble_gz *g, const char *name, const char *value
 /* stream time of the last inflate / deflate call on g: host -> device copies, kernels, device -> host copies (ms) */
 int     crumble_gz_times(crumble_gz *g, float *h2d_ms, float *kernels_ms, float *d2h_ms);
 
+/* ---- a BAM file's records on the device from inflate to deflate (round 6) --------------------------
+ * What sam_read1 / pileup_callback (snp_score.c:1113-1153) and flush_bam_list / sam_write1 (snp_score.c:1081-1105) do on
+ * the host around transcode()'s loop, with the records never leaving the device: the host reads compressed bytes, walks the
+ * BGZF member headers (crumble_bgzf_scan) and writes compressed bytes; inflate, finding the records, the engine's input, its
+ * output back into the records and deflate all happen in HBM.
+ *
+ *   s = crumble_stream_create(device, n_ref, header_bytes, &err)   header_bytes = size of the BAM header in the inflated
+ *       stream (magic, text, references: the host parses it from the first members and writes the output's own)
+ *   crumble_stream_feed(s, comp, n, blk, n_blocks, eof)            whole members, in file order
+ *   n = crumble_stream_groups(s, g, max)                           the contig runs in the buffer (refID, reads, bytes); all but
+ *       the last are complete, the last one too once eof was fed
+ *   crumble_stream_process(s, engine, i, n_bed, bed_start, bed_end)   run i through an engine of the same device
+ *   crumble_stream_drain(s, k, level, out, cap, &len)              the first k runs as BGZF members (then gone from the buffer)
+ * Files with a CIGAR of more than 65535 operations (CG tag) are refused by process (CRUMBLE_EINVAL): the caller takes the
+ * host path.  A record stream that cannot be delimited (the chain of block_size fields is checked) is refused by feed. */
+typedef struct crumble_stream crumble_stream;
+typedef struct crumble_stream_group {
+    int32_t tid;            /* refID of the run (-1: the unmapped tail)                           */
+    int32_t complete;       /* 1: every record of the run is in the buffer                         */
+    int64_t first_read;     /* index of its first record among the buffer's records                */
+    int64_t n_reads;
+    int64_t n_bases;        /* filled by crumble_stream_process                                    */
+    int64_t byte_start, byte_end;   /* its records' bytes in the inflated stream held by the buffer */
+} crumble_stream_group;
+crumble_stream *crumble_stream_create(int device, int32_t n_ref, int64_t header_bytes, int *err);
+void crumble_stream_destroy(crumble_stream *s);
+int  crumble_stream_feed(crumble_stream *s, const uint8_t *comp, int64_t comp_len, const crumble_gz_block *blk, int64_t n_blocks, int eof);
+int  crumble_stream_groups(crumble_stream *s, crumble_stream_group *out, int max);
+int  crumble_stream_process(crumble_stream *s, crumble_hip *h, int group, int32_t n_bed, const int32_t *bed_start, const int32_t *bed_end);
+int  crumble_stream_drain(crumble_stream *s, int k, int level, uint8_t *out, int64_t out_cap, int64_t *out_len);
+/* tests: bytes [from, from + n) of the buffer, its length, its record count and record offsets */
+int  crumble_stream_peek(crumble_stream *s, int64_t from, int64_t n, uint8_t *out, int64_t *len, int64_t *n_rec, int64_t *rec_off, int64_t max_rec);
+/* stream time spent inflating / deflating so far (ms), compressed bytes in / out */
+int  crumble_stream_times(crumble_stream *s, float *inflate_ms, float *deflate_ms, int64_t *bytes_in, int64_t *bytes_out);
+
 /* Page-locked host memory (hipHostMalloc) for a caller's batch arrays and output buffers: copies to and from it cross
  * PCIe at the link's rate without the runtime's staging through its own buffers (pageable memory: about half).  Any host
  * memory works with every entry point; this is an option for callers that keep their buffers.  NULL on failure. */

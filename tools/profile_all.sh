@@ -28,4 +28,8 @@ for cfg in "chr20 --workload chr20" "panel --workload panel" "hifi --workload hi
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmc_write_$name -- python3 $R/bench.py --steps 1 --warmup 0 --profile $BARGS > /dev/null 2>&1
   fi
 done
+# the device BGZF codec on a gigabyte of records (tools/gz_probe.py closes its handle before the interpreter exits: a destructor
+# at exit hangs under the profiler)
+python3 $R/tools/gz_probe.py 0.3 6 > $out/${tag}_codec_probe.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof_codec -- python3 $R/tools/gz_probe.py 0.3 6 > /dev/null 2>&1
 tail -c 600 $out/${tag}_bench.json

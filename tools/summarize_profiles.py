@@ -65,6 +65,15 @@ for name in ("chr20_9", "panel", "hifi_config4"):
     ks2 = glob.glob(os.path.join(go, f"{tag}_prof_{name}", "*", "*_kernel_stats.csv"))
     if ks2:
         shutil.copy(ks2[0], os.path.join(pr, f"{tag}_kernel_stats_{name}.csv"))
+# the device BGZF codec on a gigabyte of records: the probe's line and the kernel stats of the same command
+cj = os.path.join(go, f"{tag}_codec_probe.json")
+if os.path.exists(cj):
+    ls = [l for l in open(cj) if l.startswith("{")]
+    if ls:
+        open(os.path.join(pr, f"{tag}_codec_probe.json"), "w").write(ls[-1])
+ks3 = glob.glob(os.path.join(go, f"{tag}_prof_codec", "*", "*_kernel_stats.csv"))
+if ks3:
+    shutil.copy(ks3[0], os.path.join(pr, f"{tag}_kernel_stats_codec.csv"))
 # SQ counters of the column kernel, per launch: chr20 -5, the 300x panel, config 4
 sqall = {}
 for name in ("chr20", "panel", "hifi"):
