@@ -104,97 +104,215 @@ typedef char gz_block_layout_check[sizeof(crumble_bam_block) == sizeof(crumble_g
 
 /* ---- the device pipeline: the file's records never leave the GPU (crumble_stream, include/crumble_hip.h).  The host reads
  * compressed bytes, walks the BGZF member headers and writes compressed bytes; inflate, record delimiting, the engine's input,
- * its output back into the records and deflate happen in HBM.  One device, no tag filters, no -b: everything else takes
- * the host pipeline below.  Returns 0 done, 1 failed (message printed), -1 "not for this file": the caller starts over the
- * host way (a CG-tag CIGAR, a record stream the device could not delimit). */
+ * its output back into the records and deflate happen in HBM.  Three threads: a reader (fread + crumble_bgzf_scan into one
+ * of two page-locked chunk buffers), this one (feed / process / drain), a writer (fwrite out of one of two page-locked
+ * output buffers).  One device, no tag filters, no -b: everything else takes the host pipeline below.  Returns 0 done,
+ * 1 / 2 failed (message printed), -1 "not for this file": the caller starts over the host way (a CG-tag CIGAR). */
 #ifndef PIPELINE_AUTO_DEVICE
 #define PIPELINE_AUTO_DEVICE 0
 #endif
+/* compressed bytes per feed (the inflate kernel's time hardly depends on the members' number) and record bytes per drain, at
+ * least (whole contig runs); CRUMBLE_HIP_DP_CHUNK / CRUMBLE_HIP_DP_PIECE (bytes) let the tests cut a small file many times */
+static size_t DP_CHUNK = (size_t)256 << 20;
+static int64_t DP_PIECE = (int64_t)192 << 20;
+typedef struct { uint8_t *buf; size_t cap; int pinned; crumble_gz_block *blk; size_t bcap; int64_t nb, used; int eof, full; } dp_in;
+typedef struct { uint8_t *buf; size_t cap; int pinned; int64_t len; int full; } dp_out;
+typedef struct {
+    pthread_mutex_t mu; pthread_cond_t cv;
+    FILE *fp; crumble_bam_writer *wr;
+    dp_in in[2]; dp_out out[2];
+    int fail, stop, in_done;             /* fail: 1 error (message printed); stop: everybody leaves */
+    double t_read, t_write;
+} dp_t;
+
+static uint8_t *dp_alloc(size_t n, int *pinned)
+{
+    uint8_t *p = crumble_hip_host_alloc(n);
+    *pinned = p != NULL;
+    return p ? p : crumble_bam_big_alloc(n);
+}
+static void dp_free(uint8_t *p, size_t n, int pinned) { if (!p) return; if (pinned) crumble_hip_host_free(p); else crumble_bam_big_free(p, n); }
+static void dp_fail(dp_t *d, int code) { pthread_mutex_lock(&d->mu); if (!d->fail) d->fail = code; d->stop = 1; pthread_cond_broadcast(&d->cv); pthread_mutex_unlock(&d->mu); }
+
+static void *dp_reader(void *a)
+{
+    dp_t *d = a;
+    size_t carry = 0; const uint8_t *carry_src = NULL;
+    for (int slot = 0;; slot ^= 1) {
+        dp_in *c = &d->in[slot];
+        pthread_mutex_lock(&d->mu);
+        while (c->full && !d->stop) pthread_cond_wait(&d->cv, &d->mu);
+        const int stop = d->stop;
+        pthread_mutex_unlock(&d->mu);
+        if (stop) break;
+        const double t0 = now();
+        if (!c->buf && !(c->buf = dp_alloc(c->cap, &c->pinned))) { fprintf(stderr, "crumble-hip: out of memory\n"); dp_fail(d, 1); break; }
+        if (carry) memmove(c->buf, carry_src, carry);           /* the member cut by the end of the chunk before */
+        size_t have = carry;
+        const size_t got = fread(c->buf + have, 1, c->cap - have, d->fp);
+        c->eof = 0;
+        if (got < c->cap - have) { if (ferror(d->fp)) { fprintf(stderr, "crumble-hip: read error\n"); dp_fail(d, 1); break; } c->eof = 1; }
+        have += got;
+        int64_t used = 0, raw_total = 0, nb = 0;
+        for (;;) {
+            nb = crumble_bgzf_scan(c->buf, (int64_t)have, c->blk, (int64_t)c->bcap, &used, &raw_total);
+            if (nb < 0 || (size_t)nb < c->bcap) break;
+            c->bcap *= 2; free(c->blk);
+            if (!(c->blk = malloc(c->bcap * sizeof *c->blk))) { nb = -2; break; }
+        }
+        if (nb < 0) { fprintf(stderr, nb == -2 ? "crumble-hip: out of memory\n" : "crumble-hip: not a BGZF block (bad gzip header)\n"); dp_fail(d, 1); break; }
+        if (c->eof && (size_t)used != have) { fprintf(stderr, "crumble-hip: truncated BGZF block at the end of the file\n"); dp_fail(d, 1); break; }
+        if (!c->eof && !used) { fprintf(stderr, "crumble-hip: a BGZF block larger than the read buffer\n"); dp_fail(d, 1); break; }
+        c->nb = nb; c->used = used;
+        carry = have - (size_t)used; carry_src = c->buf + used;
+        const int eof = c->eof;
+        pthread_mutex_lock(&d->mu);
+        d->t_read += now() - t0;
+        c->full = 1;
+        pthread_cond_broadcast(&d->cv);
+        pthread_mutex_unlock(&d->mu);
+        if (eof) break;
+    }
+    return NULL;
+}
+
+static void *dp_writer(void *a)
+{
+    dp_t *d = a;
+    for (int slot = 0;; slot ^= 1) {
+        dp_out *o = &d->out[slot];
+        pthread_mutex_lock(&d->mu);
+        while (!o->full && !d->stop && !d->in_done) pthread_cond_wait(&d->cv, &d->mu);
+        const int go = o->full;
+        pthread_mutex_unlock(&d->mu);
+        if (!go) break;                                         /* (in_done with nothing queued, or a failure) */
+        const double t0 = now();
+        if (crumble_bam_write_members(d->wr, o->buf, (size_t)o->len)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); dp_fail(d, 1); break; }
+        pthread_mutex_lock(&d->mu);
+        d->t_write += now() - t0;
+        o->full = 0;
+        pthread_cond_broadcast(&d->cv);
+        pthread_mutex_unlock(&d->mu);
+    }
+    return NULL;
+}
+
 static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_bam_writer *wr, crumble_hip *eng, int device, int level,
                            int nbed, const int32_t *bt, const int32_t *bs, const int32_t *be, int verbose, int64_t *reads_out, int64_t *bases_out,
-                           double times[3])
+                           double times[4])
 {
     int err = 0;
     const int32_t nref = crumble_bam_n_ref(rd);
     crumble_stream *s = crumble_stream_create(device, nref, crumble_bam_header_bytes(rd), &err);
     if (!s) { fprintf(stderr, "crumble-hip: device pipeline unavailable (%s)\n", crumble_hip_last_error()); return -1; }
-    FILE *fp = fopen(in_fn, "rb");
-    if (!fp) { crumble_stream_destroy(s); return -1; }
-    const size_t CH = (size_t)256 << 20;
-    size_t cap = CH + ((size_t)1 << 20), have = 0, ocap = 0;
-    uint8_t *buf = crumble_bam_big_alloc(cap), *obuf = NULL;
-    size_t bcap = 8192;
-    crumble_gz_block *blk = malloc(bcap * sizeof *blk);
-    int rc = 0, eof = 0, bed_i = 0;
-    double t_read = 0, t_gpu = 0, t_write = 0;
+    static dp_t d;
+    memset(&d, 0, sizeof d);
+    pthread_mutex_init(&d.mu, NULL); pthread_cond_init(&d.cv, NULL);
+    d.wr = wr;
+    if (!(d.fp = fopen(in_fn, "rb"))) { crumble_stream_destroy(s); return -1; }
+    if (getenv("CRUMBLE_HIP_DP_CHUNK") && atoll(getenv("CRUMBLE_HIP_DP_CHUNK")) >= 66000) DP_CHUNK = (size_t)atoll(getenv("CRUMBLE_HIP_DP_CHUNK"));
+    if (getenv("CRUMBLE_HIP_DP_PIECE") && atoll(getenv("CRUMBLE_HIP_DP_PIECE")) > 0) DP_PIECE = atoll(getenv("CRUMBLE_HIP_DP_PIECE"));
+    size_t fsize = DP_CHUNK;
+    if (!fseek(d.fp, 0, SEEK_END)) { const long fl = ftell(d.fp); if (fl >= 0) fsize = (size_t)fl; }
+    rewind(d.fp);
+    for (int i = 0; i < 2; i++) {
+        d.in[i].cap = (fsize < DP_CHUNK ? fsize : DP_CHUNK) + ((size_t)1 << 16);
+        d.in[i].bcap = d.in[i].cap / 4096 + 64;
+        d.in[i].blk = malloc(d.in[i].bcap * sizeof(crumble_gz_block));
+        d.out[i].cap = (size_t)crumble_gz_deflate_bound(DP_PIECE + (DP_PIECE >> 2)) + 64;
+    }
+    /* the first buffer of each kind before the clock starts (like the engines: set-up); the second ones when they are needed */
+    d.in[0].buf = dp_alloc(d.in[0].cap, &d.in[0].pinned);
+    d.out[0].buf = dp_alloc(d.out[0].cap, &d.out[0].pinned);
+    int rc = (!d.in[0].buf || !d.out[0].buf || !d.in[0].blk || !d.in[1].blk) ? 1 : 0;
+    if (rc) fprintf(stderr, "crumble-hip: out of memory\n");
+    const double t_all = now();
+    double t_gpu = 0;
     int64_t n_reads = 0, n_bases = 0;
-    while (!eof && !rc) {
+    pthread_t rt, wt;
+    int threads_up = 0;
+    if (!rc) { pthread_create(&rt, NULL, dp_reader, &d); pthread_create(&wt, NULL, dp_writer, &d); threads_up = 1; }
+    int bed_i = 0, oslot = 0, eof = 0;
+    for (int slot = 0; !rc && !eof; slot ^= 1) {
+        dp_in *c = &d.in[slot];
+        pthread_mutex_lock(&d.mu);
+        while (!c->full && !d.stop) pthread_cond_wait(&d.cv, &d.mu);
+        const int stop = d.stop;
+        pthread_mutex_unlock(&d.mu);
+        if (stop) break;
         double t0 = now();
-        if (!buf || !blk) { fprintf(stderr, "crumble-hip: out of memory\n"); rc = 1; break; }
-        const size_t got = fread(buf + have, 1, cap - have, fp);
-        if (got < cap - have) { if (ferror(fp)) { fprintf(stderr, "crumble-hip: read error\n"); rc = 1; break; } eof = 1; }
-        have += got;
-        int64_t used = 0, raw_total = 0, nb;
-        for (;;) {
-            nb = crumble_bgzf_scan(buf, (int64_t)have, blk, (int64_t)bcap, &used, &raw_total);
-            if (nb < 0) { fprintf(stderr, "crumble-hip: not a BGZF block (bad gzip header)\n"); rc = 1; break; }
-            if ((size_t)nb < bcap) break;
-            bcap *= 2; free(blk); blk = malloc(bcap * sizeof *blk);
-            if (!blk) { rc = 1; break; }
+        eof = c->eof;
+        int e = crumble_stream_feed(s, c->buf, c->used, c->blk, c->nb, eof);
+        pthread_mutex_lock(&d.mu); c->full = 0; pthread_cond_broadcast(&d.cv); pthread_mutex_unlock(&d.mu);
+        if (e) {
+            fprintf(stderr, "crumble-hip: %s (%s)\n", crumble_hip_strerror(e), crumble_hip_last_error());
+            rc = e == CRUMBLE_EUNSORTED ? 2 : 1;
+            break;
         }
-        if (rc) break;
-        if (eof && (size_t)used != have) { fprintf(stderr, "crumble-hip: truncated BGZF block at end of file\n"); rc = 1; break; }
-        t_read += now() - t0;
-        t0 = now();
-        int e = crumble_stream_feed(s, buf, used, blk, nb, eof);
-        if (e) { if (verbose) fprintf(stderr, "crumble-hip: device pipeline: %s\n", crumble_hip_last_error()); rc = -1; break; }
-        memmove(buf, buf + used, have - (size_t)used);
-        have -= (size_t)used;
-        crumble_stream_group g[1024];
-        for (;;) {
-            const int ng = crumble_stream_groups(s, g, 1024);
+        for (;;) {                                              /* whole contig runs, DP_PIECE bytes of records or more per drain */
+            crumble_stream_group g[256];
+            const int ng = crumble_stream_groups(s, g, 256);
             int k = 0;
             int64_t bytes = 0;
-            for (int i = 0; i < ng && i < 1024 && g[i].complete; i++) {
+            for (int i = 0; i < ng && i < 256 && g[i].complete && bytes < DP_PIECE; i++) {
                 while (bed_i < nbed && g[i].tid >= 0 && bt[bed_i] < g[i].tid) bed_i++;
                 int j2 = bed_i;
                 while (j2 < nbed && bt[j2] == g[i].tid) j2++;
                 e = crumble_stream_process(s, eng, i, j2 - bed_i, bs + bed_i, be + bed_i);
-                if (e) { fprintf(stderr, "crumble-hip: contig %s: %s (%s)\n", crumble_bam_ref_name(rd, g[i].tid), crumble_hip_strerror(e), crumble_hip_last_error()); rc = strstr(crumble_hip_last_error(), "CG tag") ? -1 : 2; break; }
+                if (e) {
+                    if (strstr(crumble_hip_last_error(), "CG tag")) rc = -1;
+                    else { fprintf(stderr, "crumble-hip: contig %s: %s (%s)\n", g[i].tid >= 0 ? crumble_bam_ref_name(rd, g[i].tid) : "*", crumble_hip_strerror(e), crumble_hip_last_error()); rc = 2; }
+                    break;
+                }
                 n_reads += g[i].n_reads; bytes = g[i].byte_end - g[0].byte_start; k++;
             }
             if (rc || !k) break;
-            {   /* bases: the engines' statistics have them; per run, filled by process */
-                crumble_stream_group g2[1024];
-                crumble_stream_groups(s, g2, 1024);
-                for (int i = 0; i < k; i++) n_bases += g2[i].n_bases;
-            }
-            const size_t need = (size_t)crumble_gz_deflate_bound(bytes) + 64;
-            if (ocap < need) { crumble_bam_big_free(obuf, ocap); obuf = crumble_bam_big_alloc(need); ocap = obuf ? need : 0; if (!obuf) { rc = 1; break; } }
-            int64_t olen = 0;
-            e = crumble_stream_drain(s, k, level, obuf, (int64_t)ocap, &olen);
-            if (e) { fprintf(stderr, "crumble-hip: %s (%s)\n", crumble_hip_strerror(e), crumble_hip_last_error()); rc = 1; break; }
+            crumble_stream_groups(s, g, 256);                   /* (n_bases of the runs just processed) */
+            for (int i = 0; i < k; i++) n_bases += g[i].n_bases;
+            dp_out *o = &d.out[oslot];
+            pthread_mutex_lock(&d.mu);
             t_gpu += now() - t0;
+            while (o->full && !d.stop) pthread_cond_wait(&d.cv, &d.mu);
+            const int stop2 = d.stop;
+            pthread_mutex_unlock(&d.mu);
+            if (stop2) break;
             t0 = now();
-            if (crumble_bam_write_members(wr, obuf, (size_t)olen)) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); rc = 1; break; }
-            t_write += now() - t0;
-            t0 = now();
-            if (k < 1024) break;
+            const size_t need = (size_t)crumble_gz_deflate_bound(bytes) + 64;
+            if (!o->buf || o->cap < need) {
+                dp_free(o->buf, o->cap, o->pinned);
+                if (o->cap < need) o->cap = need;
+                if (!(o->buf = dp_alloc(o->cap, &o->pinned))) { fprintf(stderr, "crumble-hip: out of memory\n"); rc = 1; break; }
+            }
+            e = crumble_stream_drain(s, k, level, o->buf, (int64_t)o->cap, &o->len);
+            if (e) { fprintf(stderr, "crumble-hip: %s (%s)\n", crumble_hip_strerror(e), crumble_hip_last_error()); rc = 1; break; }
+            pthread_mutex_lock(&d.mu); o->full = 1; pthread_cond_broadcast(&d.cv); pthread_mutex_unlock(&d.mu);
+            oslot ^= 1;
         }
         t_gpu += now() - t0;
     }
-    if (!rc && have) { fprintf(stderr, "crumble-hip: trailing bytes behind the last BGZF member\n"); rc = 1; }
-    if (!rc && verbose) {
-        float mi = 0, md = 0; int64_t bi = 0, bo = 0;
-        crumble_stream_times(s, &mi, &md, &bi, &bo);
-        fprintf(stderr, "pipeline: device (records inflated, delimited, run and deflated in HBM; %.1f MB in, %.1f MB out over PCIe; inflate %.3f s, deflate %.3f s of the GPU stage)\n",
-                bi / 1e6, bo / 1e6, mi / 1e3, md / 1e3);
+    pthread_mutex_lock(&d.mu);
+    if (rc) d.stop = 1;
+    d.in_done = 1;
+    pthread_cond_broadcast(&d.cv);
+    pthread_mutex_unlock(&d.mu);
+    if (threads_up) {
+        pthread_join(wt, NULL);                                 /* (writes what is queued, unless something failed) */
+        pthread_mutex_lock(&d.mu); d.stop = 1; pthread_cond_broadcast(&d.cv); pthread_mutex_unlock(&d.mu);
+        pthread_join(rt, NULL);
     }
-    times[0] = t_read; times[1] = t_gpu; times[2] = t_write;
+    if (!rc && d.fail) rc = d.fail;
+    times[0] = d.t_read; times[1] = t_gpu; times[2] = d.t_write; times[3] = now() - t_all;
+    if (!rc && verbose) {
+        float ms[5] = {0}; int64_t bi = 0, bo = 0;
+        crumble_stream_times(s, ms, &bi, &bo);
+        fprintf(stderr, "pipeline: device (records inflated, delimited, run and deflated in HBM; %.1f MB in, %.1f MB out over PCIe; GPU stage: inflate %.3f s, "
+                "delimit %.3f, engine %.3f, deflate %.3f, move %.3f)\n", bi / 1e6, bo / 1e6, ms[0] / 1e3, ms[1] / 1e3, ms[2] / 1e3, ms[3] / 1e3, ms[4] / 1e3);
+    }
     *reads_out = n_reads; *bases_out = n_bases;
-    fclose(fp); free(blk); crumble_bam_big_free(buf, cap); crumble_bam_big_free(obuf, ocap);
+    fclose(d.fp);
+    for (int i = 0; i < 2; i++) { dp_free(d.in[i].buf, d.in[i].cap, d.in[i].pinned); dp_free(d.out[i].buf, d.out[i].cap, d.out[i].pinned); free(d.in[i].blk); }
     crumble_stream_destroy(s);
-    return rc == 2 ? 1 : rc;
+    return rc;
 }
 
 static void *gpu_worker(void *a_)
@@ -713,7 +831,7 @@ int main(int argc, char **argv)
      * host's slow levels search harder than the device's one); the host's threads inflate (a gigabyte in 0.08-0.1 s on
      * sixteen of them, less than the device needs with the bytes' way back over PCIe) unless there are fewer than eight. */
     crumble_gz *gz_in = NULL, *gz_out = NULL;
-    double dev_times[3] = {0, 0, 0};
+    double dev_times[4] = {0, 0, 0, 0};
     int64_t dev_reads = 0, dev_bases = 0;
     int dev_done = 0;
     const double t_all = now();
@@ -828,7 +946,7 @@ finish:
         int64_t s1[CRUMBLE_ST_N];
         if (crumble_hip_stats_read(p.eng[d], s1) == 0) for (int i = 0; i < CRUMBLE_ST_N; i++) p.stats[i] += s1[i];
     }
-    const double wall = now() - t_all;
+    const double wall = dev_done ? dev_times[3] : now() - t_all;
     if (verbose && !rc_main) {
         for (int i = 0; i < (int)(sizeof ST_NAME / sizeof *ST_NAME); i++) fprintf(stderr, "%-16s %lld\n", ST_NAME[i], (long long)p.stats[i]);
         const double gb = p.stats[CRUMBLE_ST_BASES] / 1e9;

@@ -31,7 +31,7 @@ struct crumble_stream {
     bool eof = false;
     void *pinned = nullptr;
     int64_t bytes_in = 0, bytes_out = 0;         /* compressed bytes fed / drained so far */
-    float ms_inflate = 0, ms_sync = 0, ms_engine = 0, ms_deflate = 0;
+    float ms_inflate = 0, ms_sync = 0, ms_engine = 0, ms_deflate = 0, ms_move = 0;   /* host clock around each part */
 };
 
 extern "C" crumble_stream *crumble_stream_create(int device, int32_t n_ref, int64_t header_bytes, int *err)
@@ -66,8 +66,12 @@ extern "C" void crumble_stream_destroy(crumble_stream *s)
 }
 
 /* record starts and contig runs of d_rec[cur][start, len) */
+static double st_now() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + 1e-6 * t.tv_nsec; }
+struct StClock { float *acc; double t0; StClock(float *a) : acc(a), t0(st_now()) {} ~StClock() { *acc += (float)(st_now() - t0); } };
+
 static int stream_sync(crumble_stream *s)
 {
+    StClock clk(&s->ms_sync);
     hipStream_t st = s->gz->stream;
     const uint8_t *R = s->d_rec[s->cur].as<uint8_t>();
     s->groups.clear(); s->n_rec = 0; s->tail = s->start;
@@ -166,8 +170,7 @@ extern "C" int crumble_stream_feed(crumble_stream *s, const uint8_t *comp, int64
     std::vector<crumble_gz_block> b2((size_t)n_blocks);
     int64_t u = s->len;
     for (int64_t i = 0; i < n_blocks; i++) { b2[(size_t)i] = blk[i]; b2[(size_t)i].uoff = u; u += blk[i].ulen; }
-    if (n_blocks && (e = gz_inflate_impl(s->gz, comp, comp_len, b2.data(), n_blocks, nullptr, R, u, 1))) return e;
-    s->ms_inflate += s->gz->ms_h2d + s->gz->ms_kernels;
+    { StClock clk(&s->ms_inflate); if (n_blocks && (e = gz_inflate_impl(s->gz, comp, comp_len, b2.data(), n_blocks, nullptr, R, u, 1))) return e; }
     s->len = u; s->eof = eof != 0; s->bytes_in += comp_len;
     HIPCHK(hipMemsetAsync(R + s->len, 0, 4096, st));
     if ((e = stream_sync(s))) return e;
@@ -198,6 +201,7 @@ extern "C" int crumble_stream_process(crumble_stream *s, crumble_hip *h, int gro
     hipStream_t st = s->gz->stream;
     const int64_t n = g.n_reads;
     int e;
+    StClock clk(&s->ms_engine);
     if ((e = s->d_pos.reserve((size_t)n * 4 + 64)) || (e = s->d_mapq.reserve((size_t)n + 64)) || (e = s->d_flag.reserve((size_t)n * 2 + 64)) ||
         (e = s->d_lq.reserve((size_t)n * 4 + 64)) || (e = s->d_ncg.reserve((size_t)n * 2 + 64)) || (e = s->d_noq.reserve((size_t)n + 64)))
         return e;
@@ -247,8 +251,8 @@ extern "C" int crumble_stream_drain(crumble_stream *s, int k, int level, uint8_t
     const int64_t b0 = s->groups[0].byte_start, b1 = s->groups[(size_t)k - 1].byte_end;
     uint8_t *R = s->d_rec[s->cur].as<uint8_t>();
     int e;
-    if (b1 > b0 && (e = gz_deflate_impl(s->gz, nullptr, R + b0, b1 - b0, level, out, out_cap, out_len))) return e;
-    s->ms_deflate += s->gz->ms_kernels + s->gz->ms_d2h;
+    { StClock clk(&s->ms_deflate); if (b1 > b0 && (e = gz_deflate_impl(s->gz, nullptr, R + b0, b1 - b0, level, out, out_cap, out_len))) return e; }
+    const double t_move = st_now();
     s->bytes_out += *out_len;
     /* what is left: [b1, len) to the front of the other buffer */
     const int64_t rest = s->len - b1;
@@ -261,6 +265,7 @@ extern "C" int crumble_stream_drain(crumble_stream *s, int k, int level, uint8_t
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     s->cur ^= 1; s->len = rest > 0 ? rest : 0; s->start = 0;
+    s->ms_move += (float)(st_now() - t_move);
     if ((e = stream_sync(s))) return e;
     return CRUMBLE_OK;
 }
@@ -277,11 +282,12 @@ extern "C" int crumble_stream_peek(crumble_stream *s, int64_t from, int64_t n, u
     return CRUMBLE_OK;
 }
 
-extern "C" int crumble_stream_times(crumble_stream *s, float *inflate_ms, float *deflate_ms, int64_t *bytes_in, int64_t *bytes_out)
+/* host-clock milliseconds so far: ms[0..4] = inflate (H2D + kernels), record delimiting, engine (fields + expansion + run +
+ * scatter), deflate (kernels + D2H), moving the rest of the buffer */
+extern "C" int crumble_stream_times(crumble_stream *s, float ms[5], int64_t *bytes_in, int64_t *bytes_out)
 {
     if (!s) return CRUMBLE_EINVAL;
-    if (inflate_ms) *inflate_ms = s->ms_inflate;
-    if (deflate_ms) *deflate_ms = s->ms_deflate;
+    if (ms) { ms[0] = s->ms_inflate; ms[1] = s->ms_sync; ms[2] = s->ms_engine; ms[3] = s->ms_deflate; ms[4] = s->ms_move; }
     if (bytes_in) *bytes_in = s->bytes_in;
     if (bytes_out) *bytes_out = s->bytes_out;
     return CRUMBLE_OK;

@@ -178,8 +178,13 @@ k_st_fields(const uint8_t *__restrict__ R, const int64_t *__restrict__ rec_off, 
             uint8_t *__restrict__ mapq, uint16_t *__restrict__ flag, int32_t *__restrict__ lq, uint16_t *__restrict__ ncg,
             uint8_t *__restrict__ noq, StTotals *__restrict__ tot, const uint32_t *__restrict__ err_ppm, int64_t sample_step)
 {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned flags;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    unsigned long long nb = 0, nc = 0;
+    unsigned long long nb = 0, nc = 0, ep = 0, ec = 0;
+    hist[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) flags = 0u;
+    __syncthreads();
     if (i < n) {
         const uint8_t *r = R + rec_off[i];
         const uint32_t lname = r[12], nco = st_u16(r + 16);
@@ -192,16 +197,25 @@ k_st_fields(const uint8_t *__restrict__ R, const int64_t *__restrict__ rec_off, 
         /* a CIGAR of more than 65535 operations lives in the CG tag behind a kSmN placeholder (SAMv1 4.2.2): not taken here */
         if (nco == 2u && ls > 0) {
             const uint32_t c0 = st_u32(cg), c1 = st_u32(cg + 4);
-            if ((c0 & 15u) == 4u && (int32_t)(c0 >> 4) == ls && (c1 & 15u) == 3u) atomicOr(&tot->unsupported, 1u);
+            if ((c0 & 15u) == 4u && (int32_t)(c0 >> 4) == ls && (c1 & 15u) == 3u) atomicOr(&flags, 1u);
         }
         if (i % sample_step == 0) {
-            atomicAdd(&tot->mq_hist[r[13]], 1u);
-            if (ls > 0) { atomicAdd(&tot->err_ppm, (unsigned long long)err_ppm[absent ? 0 : (q[0] & 127)]); atomicAdd(&tot->err_cnt, 1ull); }
+            atomicAdd(&hist[r[13]], 1u);
+            if (ls > 0) { ep = err_ppm[absent ? 0 : (q[0] & 127)]; ec = 1ull; }
         }
     }
-    /* the two sums: wave, then one atomic pair per wave */
-    for (int d = 32; d > 0; d >>= 1) { nb += (unsigned long long)__shfl_xor((long long)nb, d); nc += (unsigned long long)__shfl_xor((long long)nc, d); }
-    if ((threadIdx.x & 63) == 0 && (nb | nc)) { atomicAdd(&tot->n_bases, nb); atomicAdd(&tot->n_cigar, nc); }
+    /* the sums: wave, then one atomic each per wave; the histogram and the flag: one atomic per bin the workgroup touched */
+    for (int d = 32; d > 0; d >>= 1) {
+        nb += (unsigned long long)__shfl_xor((long long)nb, d); nc += (unsigned long long)__shfl_xor((long long)nc, d);
+        ep += (unsigned long long)__shfl_xor((long long)ep, d); ec += (unsigned long long)__shfl_xor((long long)ec, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (nb | nc) { atomicAdd(&tot->n_bases, nb); atomicAdd(&tot->n_cigar, nc); }
+        if (ec) { atomicAdd(&tot->err_ppm, ep); atomicAdd(&tot->err_cnt, ec); }
+    }
+    __syncthreads();
+    if (hist[threadIdx.x]) atomicAdd(&tot->mq_hist[threadIdx.x], hist[threadIdx.x]);
+    if (threadIdx.x == 0 && flags) atomicOr(&tot->unsupported, 1u);
 }
 
 /* a wave per read (sixteen reads per wave in turn): CIGAR words, the packed bases into the bases4 layout (read i at byte

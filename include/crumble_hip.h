@@ -474,8 +474,9 @@ int  crumble_stream_process(crumble_stream *s, crumble_hip *h, int group, int32_
 int  crumble_stream_drain(crumble_stream *s, int k, int level, uint8_t *out, int64_t out_cap, int64_t *out_len);
 /* tests: bytes [from, from + n) of the buffer, its length, its record count and record offsets */
 int  crumble_stream_peek(crumble_stream *s, int64_t from, int64_t n, uint8_t *out, int64_t *len, int64_t *n_rec, int64_t *rec_off, int64_t max_rec);
-/* stream time spent inflating / deflating so far (ms), compressed bytes in / out */
-int  crumble_stream_times(crumble_stream *s, float *inflate_ms, float *deflate_ms, int64_t *bytes_in, int64_t *bytes_out);
+/* host-clock milliseconds so far -- ms[0..4] = inflate (H2D + kernels), record delimiting, engine (fields, expansion, run,
+ * scatter), deflate (kernels + D2H), moving what is left of the buffer -- and the compressed bytes in / out */
+int  crumble_stream_times(crumble_stream *s, float ms[5], int64_t *bytes_in, int64_t *bytes_out);
 
 /* Page-locked host memory (hipHostMalloc) for a caller's batch arrays and output buffers: copies to and from it cross
  * PCIe at the link's rate without the runtime's staging through its own buffers (pageable memory: about half).  Any host

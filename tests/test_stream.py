@@ -171,10 +171,10 @@ def _refusals(library, make_engine, tmp_path):
     eng.close(); s.close()
 
 
-def _cli(exe, tmp_path, scale, env=None, timeout=1800):
+def _cli(exe, tmp_path, scale, env=None, timeout=1800, chunk=66000, level=6):
     refs = [("chrI", 60000), ("chrII", 25000)]
     bs = [synth.generate(synth.config("ce", scale=scale)), synth.generate(synth.config("ce", scale=scale / 2, seed=78, tid=1)), three_groups()[1][2]]
-    bamio.write_batches(tmp_path / "in.bam", refs, bs, level=6)
+    bamio.write_batches(tmp_path / "in.bam", refs, bs, level=level)
     (tmp_path / "keep.bed").write_text("chrI\t1000\t3000\nchrII\t500\t800\n")
     rd = bamio.Reader(tmp_path / "in.bam"); bed = rd.load_bed(tmp_path / "keep.bed"); rd.close()
     for args, params, b in ((["-5"], ca.preset_params(5), None), (["-1", "-R", str(tmp_path / "keep.bed")], ca.preset_params(1), bed)):
@@ -191,6 +191,12 @@ def _cli(exe, tmp_path, scale, env=None, timeout=1800):
             err[mode] = [l for l in r.stderr.splitlines() if l[:1].islower() and l.split()[-1].isdigit() and len(l.split()) == 2]
         assert st["device"] == st["host"]
         assert err["device"] == err["host"] and len(err["host"]) >= 20          # the statistics block
+        # the same with the file cut into many feeds and drains (members carried from one read buffer to the next, contig runs
+        # that end in a later feed, both buffers of each kind in use)
+        r = subprocess.run([exe, "-z", *args, str(tmp_path / "in.bam"), str(tmp_path / "out_cut.bam")], timeout=timeout, stderr=subprocess.PIPE, text=True,
+                           env=dict(os.environ, CRUMBLE_HIP_PIPELINE="device", CRUMBLE_HIP_DP_CHUNK=str(chunk), CRUMBLE_HIP_DP_PIECE="20000", **(env or {})))
+        assert r.returncode == 0, r.stderr
+        assert gzip.decompress(open(tmp_path / "out_cut.bam", "rb").read()) == st["host"]
         assert np.array_equal(_file_quals(tmp_path / "out_device.bam"), _oracle_file(params, tmp_path / "in.bam", b))
     # a CIGAR behind a CG tag (SAMv1 4.2.2: placeholder kSmN + CG:B,I): the device pipeline hands the file to the host pipeline
     real = [(2 << 4) | 0, (1 << 4) | 1, (3 << 4) | 2, (1 << 4) | 0]
@@ -222,7 +228,7 @@ def test_emu_stream_refusals(tmp_path):
 def test_cli_device_pipeline_emulated(tmp_path):
     import emu_lib
     emu_lib.load()
-    _cli(os.path.join(ROOT, "tests", "emu", "crumble-hip-emu"), tmp_path, 0.06, env={"CRUMBLE_HIP_CODEC": "host"})
+    _cli(os.path.join(ROOT, "tests", "emu", "crumble-hip-emu"), tmp_path, 0.25, env={"CRUMBLE_HIP_CODEC": "host"}, level=0)
 
 
 def test_cli_pipeline_option_checked(tmp_path):
@@ -268,11 +274,12 @@ def test_cli_device_pipeline_many_contigs_gpu(tmp_path):
     bs.append(three_groups()[1][2])
     bamio.write_batches(tmp_path / "in.bam", refs, bs, level=1)
     st = {}
-    for mode, level in (("host", "1"), ("device", "1"), ("device", "-1")):
+    for mode, level in (("host", "1"), ("device", "1"), ("device", "-1"), ("device", "6")):
         out = tmp_path / f"out_{mode}{level}.bam"
-        r = subprocess.run([exe, "-v", "-z", "-9", str(tmp_path / "in.bam"), str(out)], env=dict(os.environ, CRUMBLE_HIP_PIPELINE=mode, CRUMBLE_BAM_LEVEL=level),
+        cut = {"CRUMBLE_HIP_DP_CHUNK": "200000", "CRUMBLE_HIP_DP_PIECE": "300000"} if level == "6" else {}      # many feeds, many drains
+        r = subprocess.run([exe, "-v", "-z", "-9", str(tmp_path / "in.bam"), str(out)], env=dict(os.environ, CRUMBLE_HIP_PIPELINE=mode, CRUMBLE_BAM_LEVEL=level, **cut),
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         assert r.returncode == 0, r.stderr
         st[(mode, level)] = gzip.decompress(open(out, "rb").read())
-    assert st[("host", "1")] == st[("device", "1")] == st[("device", "-1")]
+    assert st[("host", "1")] == st[("device", "1")] == st[("device", "-1")] == st[("device", "6")]
     assert np.array_equal(_file_quals(tmp_path / "out_device1.bam"), _oracle_file(ca.preset_params(9), tmp_path / "in.bam"))
