@@ -12,6 +12,7 @@
  * program stops with CRUMBLE_ENODEVICE.
  */
 #define _GNU_SOURCE
+#include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -114,7 +115,7 @@ typedef char gz_block_layout_check[sizeof(crumble_bam_block) == sizeof(crumble_g
 /* compressed bytes per feed (the inflate kernel's time hardly depends on the members' number) and record bytes per drain, at
  * least (whole contig runs); CRUMBLE_HIP_DP_CHUNK / CRUMBLE_HIP_DP_PIECE (bytes) let the tests cut a small file many times */
 static size_t DP_CHUNK = (size_t)256 << 20;
-static int64_t DP_PIECE = (int64_t)192 << 20;
+static int64_t DP_PIECE = (int64_t)128 << 20;
 typedef struct { uint8_t *buf; size_t cap; int pinned; crumble_gz_block *blk; size_t bcap; int64_t nb, used; int eof, full; } dp_in;
 typedef struct { uint8_t *buf; size_t cap; int pinned; int64_t len; int full; } dp_out;
 typedef struct {
@@ -134,10 +135,49 @@ static uint8_t *dp_alloc(size_t n, int *pinned)
 static void dp_free(uint8_t *p, size_t n, int pinned) { if (!p) return; if (pinned) crumble_hip_host_free(p); else crumble_bam_big_free(p, n); }
 static void dp_fail(dp_t *d, int code) { pthread_mutex_lock(&d->mu); if (!d->fail) d->fail = code; d->stop = 1; pthread_cond_broadcast(&d->cv); pthread_mutex_unlock(&d->mu); }
 
+/* n bytes at offset off, by four threads when there are many (a cached file comes at the speed of one core's memcpy otherwise);
+ * returns the bytes read (short at the end of the file), -1 on an error */
+typedef struct { int fd; uint8_t *buf; size_t n; off_t off; ssize_t got; } pr_job;
+static void *pr_run(void *a)
+{
+    pr_job *j = a;
+    size_t done = 0;
+    while (done < j->n) {
+        const ssize_t r = pread(j->fd, j->buf + done, j->n - done, j->off + (off_t)done);
+        if (r < 0) { j->got = -1; return NULL; }
+        if (r == 0) break;
+        done += (size_t)r;
+    }
+    j->got = (ssize_t)done;
+    return NULL;
+}
+static ssize_t par_pread(int fd, uint8_t *buf, size_t n, off_t off)
+{
+    const int nt = n >= ((size_t)16 << 20) ? 4 : 1;
+    pr_job j[4]; pthread_t t[4];
+    const size_t per = (n / (size_t)nt + 4095) & ~(size_t)4095;
+    for (int i = 0; i < nt; i++) {
+        const size_t lo = per * (size_t)i, hi = i == nt - 1 ? n : (per * (size_t)(i + 1) < n ? per * (size_t)(i + 1) : n);
+        j[i].fd = fd; j[i].buf = buf + lo; j[i].n = hi > lo ? hi - lo : 0; j[i].off = off + (off_t)lo; j[i].got = 0;
+        if (i) pthread_create(&t[i], NULL, pr_run, &j[i]);
+    }
+    pr_run(&j[0]);
+    for (int i = 1; i < nt; i++) pthread_join(t[i], NULL);
+    ssize_t total = 0;
+    for (int i = 0; i < nt; i++) {
+        if (j[i].got < 0) return -1;
+        total += j[i].got;
+        if ((size_t)j[i].got < j[i].n) break;                   /* the end of the file lies in this part */
+    }
+    return total;
+}
+
 static void *dp_reader(void *a)
 {
     dp_t *d = a;
     size_t carry = 0; const uint8_t *carry_src = NULL;
+    off_t foff = 0;
+    const int fd = fileno(d->fp);
     for (int slot = 0;; slot ^= 1) {
         dp_in *c = &d->in[slot];
         pthread_mutex_lock(&d->mu);
@@ -149,10 +189,11 @@ static void *dp_reader(void *a)
         if (!c->buf && !(c->buf = dp_alloc(c->cap, &c->pinned))) { fprintf(stderr, "crumble-hip: out of memory\n"); dp_fail(d, 1); break; }
         if (carry) memmove(c->buf, carry_src, carry);           /* the member cut by the end of the chunk before */
         size_t have = carry;
-        const size_t got = fread(c->buf + have, 1, c->cap - have, d->fp);
-        c->eof = 0;
-        if (got < c->cap - have) { if (ferror(d->fp)) { fprintf(stderr, "crumble-hip: read error\n"); dp_fail(d, 1); break; } c->eof = 1; }
-        have += got;
+        const ssize_t got = par_pread(fd, c->buf + have, c->cap - have, foff);
+        if (got < 0) { fprintf(stderr, "crumble-hip: read error: %s\n", strerror(errno)); dp_fail(d, 1); break; }
+        c->eof = (size_t)got < c->cap - have;
+        foff += got;
+        have += (size_t)got;
         int64_t used = 0, raw_total = 0, nb = 0;
         for (;;) {
             nb = crumble_bgzf_scan(c->buf, (int64_t)have, c->blk, (int64_t)c->bcap, &used, &raw_total);
@@ -224,7 +265,9 @@ static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_ba
     /* the first buffer of each kind before the clock starts (like the engines: set-up); the second ones when they are needed */
     d.in[0].buf = dp_alloc(d.in[0].cap, &d.in[0].pinned);
     d.out[0].buf = dp_alloc(d.out[0].cap, &d.out[0].pinned);
-    int rc = (!d.in[0].buf || !d.out[0].buf || !d.in[0].blk || !d.in[1].blk) ? 1 : 0;
+    d.out[1].buf = dp_alloc(d.out[1].cap, &d.out[1].pinned);
+    int rc = (!d.in[0].buf || !d.out[0].buf || !d.out[1].buf || !d.in[0].blk || !d.in[1].blk) ? 1 : 0;
+    if (!rc) (void)crumble_stream_reserve(s, (int64_t)d.in[0].cap, (int64_t)d.in[0].cap * 5);   /* (a hint: what it cannot get now it asks for again later) */
     if (rc) fprintf(stderr, "crumble-hip: out of memory\n");
     const double t_all = now();
     double t_gpu = 0;

@@ -65,6 +65,32 @@ extern "C" void crumble_stream_destroy(crumble_stream *s)
     delete s;
 }
 
+/* Set-up before the first feed (optional): device memory for feeds of up to comp_bytes of members that inflate to about
+ * raw_bytes -- the record buffers, the codec's token and slot arrays -- so that no feed / drain stops to allocate. */
+extern "C" int crumble_stream_reserve(crumble_stream *s, int64_t comp_bytes, int64_t raw_bytes)
+{
+    if (!s || comp_bytes < 0 || raw_bytes < 0) return CRUMBLE_EINVAL;
+    HIPCHK(hipSetDevice(s->device));
+    crumble_gz *g = s->gz;
+    int e;
+    const size_t raw = (size_t)raw_bytes + 4096, nmem = (size_t)(raw_bytes / 32768 + comp_bytes / 16384 + 64);
+    const size_t in_round = raw < (size_t)8 * GZ_BATCH_RAW ? raw : (size_t)8 * GZ_BATCH_RAW;
+    const size_t out_round = raw < (size_t)GZ_BATCH_RAW ? raw : (size_t)GZ_BATCH_RAW, nb = out_round / GZ_MAXBLK + 1;
+    const size_t tok = (in_round + 64) * 4 > nb * 65536 * 4 ? (in_round + 64) * 4 : nb * 65536 * 4;
+    if ((e = s->d_rec[0].reserve(raw)) || (e = s->d_rec[1].reserve(raw)) || (e = g->d_comp.reserve((size_t)comp_bytes + GZ_IN_PAD)) ||
+        (e = g->d_blk.reserve(nmem * sizeof(GzBlock))) || (e = g->d_tokoff.reserve((nmem + 1) * 8)) || (e = g->d_tok.reserve(tok)) ||
+        (e = g->d_ntok.reserve(nmem * 4)) || (e = g->d_status.reserve(nmem * 4)) || (e = g->d_scratch.reserve((nmem + 64) * GZ2_WORDS * 4)) ||
+        (e = g->d_cand.reserve(nb * 65536 * 4)) || (e = g->d_slots.reserve(nb * GZ_SLOT)) || (e = g->d_sizes.reserve(nb * 4)) ||
+        (e = g->d_off.reserve((nb + 1) * 8)) || (e = g->d_out.reserve(nb * GZ_SLOT)))
+        return e;
+    const size_t nch = raw / ST_CHUNK + 2;
+    if ((e = s->d_guess.reserve(nch * 8)) || (e = s->d_exit.reserve(nch * 8)) || (e = s->d_count.reserve(nch * 4)) ||
+        (e = s->d_slots.reserve(nch * ST_MAXREC * 8)) || (e = s->d_coff.reserve((nch + 1) * 8)) || (e = s->d_recoff.reserve(raw / 36 * 8 / 4 + 64)) ||
+        (e = s->d_list.reserve((size_t)(1 << 20) * 16)))
+        return e;
+    return CRUMBLE_OK;
+}
+
 /* record starts and contig runs of d_rec[cur][start, len) */
 static double st_now() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + 1e-6 * t.tv_nsec; }
 struct StClock { float *acc; double t0; StClock(float *a) : acc(a), t0(st_now()) {} ~StClock() { *acc += (float)(st_now() - t0); } };

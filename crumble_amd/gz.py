@@ -137,6 +137,13 @@ class Stream:
         if not self.h:
             raise CrumbleError(err.value, "crumble_stream_create", L)
 
+    def reserve(self, comp_bytes, raw_bytes):
+        self.L.crumble_stream_reserve.restype = C.c_int
+        self.L.crumble_stream_reserve.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        rc = self.L.crumble_stream_reserve(self.h, comp_bytes, raw_bytes)
+        if rc:
+            raise CrumbleError(rc, "crumble_stream_reserve", self.L)
+
     def close(self):
         if self.h:
             self.L.crumble_stream_destroy(self.h)

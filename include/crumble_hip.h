@@ -472,6 +472,9 @@ int  crumble_stream_feed(crumble_stream *s, const uint8_t *comp, int64_t comp_le
 int  crumble_stream_groups(crumble_stream *s, crumble_stream_group *out, int max);
 int  crumble_stream_process(crumble_stream *s, crumble_hip *h, int group, int32_t n_bed, const int32_t *bed_start, const int32_t *bed_end);
 int  crumble_stream_drain(crumble_stream *s, int k, int level, uint8_t *out, int64_t out_cap, int64_t *out_len);
+/* optional set-up before the first feed: device memory for feeds of up to comp_bytes that inflate to about raw_bytes (record
+ * buffers, token and slot arrays), so that no feed / drain stops to allocate; larger feeds still work (they grow the buffers) */
+int  crumble_stream_reserve(crumble_stream *s, int64_t comp_bytes, int64_t raw_bytes);
 /* tests: bytes [from, from + n) of the buffer, its length, its record count and record offsets */
 int  crumble_stream_peek(crumble_stream *s, int64_t from, int64_t n, uint8_t *out, int64_t *len, int64_t *n_rec, int64_t *rec_off, int64_t max_rec);
 /* host-clock milliseconds so far -- ms[0..4] = inflate (H2D + kernels), record delimiting, engine (fields, expansion, run,

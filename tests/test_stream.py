@@ -67,6 +67,8 @@ def run_stream(library, engine, path, cuts, level=6, bed=None):
     assert consumed == len(comp) and total == len(raw)
     edges = [0] + [int(blk["coff"][c]) - 18 for c in cuts] + [len(comp)]
     s = gz.Stream(n_ref, hdr, 0, library)
+    if cuts:
+        s.reserve(len(comp) // 2, len(raw) // 3)         # a hint that is too small: the buffers grow
     out, seen_groups, done_bytes = b"", [], hdr
     try:
         for i in range(len(edges) - 1):
