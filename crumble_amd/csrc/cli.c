@@ -260,7 +260,7 @@ static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_ba
         d.in[i].cap = (fsize < DP_CHUNK ? fsize : DP_CHUNK) + ((size_t)1 << 16);
         d.in[i].bcap = d.in[i].cap / 4096 + 64;
         d.in[i].blk = malloc(d.in[i].bcap * sizeof(crumble_gz_block));
-        d.out[i].cap = (size_t)crumble_gz_deflate_bound(DP_PIECE + (DP_PIECE >> 2)) + 64;
+        d.out[i].cap = (size_t)crumble_gz_deflate_bound(DP_PIECE > 2 * 65280 ? DP_PIECE : 2 * 65280) + 64;    /* (two members at least) */
     }
     /* the first buffer of each kind before the clock starts (like the engines: set-up); the second ones when they are needed */
     d.in[0].buf = dp_alloc(d.in[0].cap, &d.in[0].pinned);
@@ -292,11 +292,11 @@ static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_ba
             rc = e == CRUMBLE_EUNSORTED ? 2 : 1;
             break;
         }
-        for (;;) {                                              /* whole contig runs, DP_PIECE bytes of records or more per drain */
+        for (;;) {                                              /* whole contig runs, DP_PIECE bytes of records or more, then drains */
             crumble_stream_group g[256];
             const int ng = crumble_stream_groups(s, g, 256);
             int k = 0;
-            int64_t bytes = 0;
+            int64_t bytes = crumble_stream_pending(s);
             for (int i = 0; i < ng && i < 256 && g[i].complete && bytes < DP_PIECE; i++) {
                 while (bed_i < nbed && g[i].tid >= 0 && bt[bed_i] < g[i].tid) bed_i++;
                 int j2 = bed_i;
@@ -307,29 +307,30 @@ static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_ba
                     else { fprintf(stderr, "crumble-hip: contig %s: %s (%s)\n", g[i].tid >= 0 ? crumble_bam_ref_name(rd, g[i].tid) : "*", crumble_hip_strerror(e), crumble_hip_last_error()); rc = 2; }
                     break;
                 }
-                n_reads += g[i].n_reads; bytes = g[i].byte_end - g[0].byte_start; k++;
+                n_reads += g[i].n_reads; bytes = g[i].byte_end; k++;
             }
-            if (rc || !k) break;
-            crumble_stream_groups(s, g, 256);                   /* (n_bases of the runs just processed) */
-            for (int i = 0; i < k; i++) n_bases += g[i].n_bases;
-            dp_out *o = &d.out[oslot];
-            pthread_mutex_lock(&d.mu);
-            t_gpu += now() - t0;
-            while (o->full && !d.stop) pthread_cond_wait(&d.cv, &d.mu);
-            const int stop2 = d.stop;
-            pthread_mutex_unlock(&d.mu);
-            if (stop2) break;
-            t0 = now();
-            const size_t need = (size_t)crumble_gz_deflate_bound(bytes) + 64;
-            if (!o->buf || o->cap < need) {
-                dp_free(o->buf, o->cap, o->pinned);
-                if (o->cap < need) o->cap = need;
-                if (!(o->buf = dp_alloc(o->cap, &o->pinned))) { fprintf(stderr, "crumble-hip: out of memory\n"); rc = 1; break; }
+            if (rc || !bytes) break;
+            if (k) {
+                crumble_stream_groups(s, g, 256);               /* (n_bases of the runs just processed) */
+                for (int i = 0; i < k; i++) n_bases += g[i].n_bases;
             }
-            e = crumble_stream_drain(s, k, level, o->buf, (int64_t)o->cap, &o->len);
-            if (e) { fprintf(stderr, "crumble-hip: %s (%s)\n", crumble_hip_strerror(e), crumble_hip_last_error()); rc = 1; break; }
-            pthread_mutex_lock(&d.mu); o->full = 1; pthread_cond_broadcast(&d.cv); pthread_mutex_unlock(&d.mu);
-            oslot ^= 1;
+            /* what was processed leaves through the two fixed output buffers, a buffer's worth of whole members at a time */
+            do {
+                dp_out *o = &d.out[oslot];
+                pthread_mutex_lock(&d.mu);
+                t_gpu += now() - t0;
+                while (o->full && !d.stop) pthread_cond_wait(&d.cv, &d.mu);
+                const int stop2 = d.stop;
+                pthread_mutex_unlock(&d.mu);
+                t0 = now();
+                if (stop2) { rc = rc ? rc : 1; break; }
+                e = crumble_stream_drain(s, k, level, o->buf, (int64_t)o->cap, &o->len);
+                k = 0;
+                if (e) { fprintf(stderr, "crumble-hip: %s (%s)\n", crumble_hip_strerror(e), crumble_hip_last_error()); rc = 1; break; }
+                pthread_mutex_lock(&d.mu); o->full = 1; pthread_cond_broadcast(&d.cv); pthread_mutex_unlock(&d.mu);
+                oslot ^= 1;
+            } while (crumble_stream_pending(s) > 0);
+            if (rc) break;
         }
         t_gpu += now() - t0;
     }

@@ -21,6 +21,7 @@ struct crumble_gz {
     void *pinned = nullptr;                     /* 4 KiB page-locked: sizes and totals read back */
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float ms_h2d = 0, ms_kernels = 0, ms_d2h = 0;
+    int ncu = 256;                              /* compute units (hipGetDeviceProperties once: the call costs milliseconds) */
     int64_t last_in = 0, last_out = 0;
 };
 
@@ -51,6 +52,9 @@ extern "C" crumble_gz *crumble_gz_create(int device, int *err)
     bool ok = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) == hipSuccess;
     for (auto &e : g->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     ok = ok && hipHostMalloc(&g->pinned, 4096, 0) == hipSuccess;
+#ifndef CRUMBLE_EMU
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) g->ncu = pr.multiProcessorCount; }
+#endif
     uint32_t tabs[288];
     gz_make_tables(tabs);
     ok = ok && g->d_tabs.reserve(sizeof tabs) == CRUMBLE_OK && copy_sync(g->stream, g->d_tabs.p, tabs, sizeof tabs, hipMemcpyHostToDevice) == hipSuccess;
@@ -112,10 +116,7 @@ static int gz_inflate_impl(crumble_gz *g, const uint8_t *comp, int64_t comp_len,
         prev_end = b.uoff + (int64_t)b.ulen;
     }
     int e;
-    int ncu = 256;
-#ifndef CRUMBLE_EMU
-    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, g->device) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
-#endif
+    const int ncu = g->ncu;
     if ((e = g->d_comp.reserve((size_t)comp_len + GZ_IN_PAD))) return e;
     HIPCHK(hipEventRecord(g->ev[0], st));
     HIPCHK(hipMemcpyAsync(g->d_comp.p, comp, (size_t)comp_len, hipMemcpyHostToDevice, st));
@@ -203,10 +204,7 @@ static int gz_deflate_impl(crumble_gz *g, const uint8_t *raw, const uint8_t *raw
     level = level == 0 ? 0 : 1;                          /* 0: stored; anything else, zlib's -1 "default" included: the device's one level */
     if (out_cap < crumble_gz_deflate_bound(raw_len)) { g_last_error = "crumble_gz_deflate: output buffer below crumble_gz_deflate_bound()"; return CRUMBLE_EINVAL; }
     int e;
-    int ncu = 256;
-#ifndef CRUMBLE_EMU
-    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, g->device) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
-#endif
+    const int ncu = g->ncu;
     const int64_t per_round = (GZ_BATCH_RAW / GZ_MAXBLK) * GZ_MAXBLK;
     float ms = 0;
     int64_t produced = 0;

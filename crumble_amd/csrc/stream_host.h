@@ -19,10 +19,12 @@ struct crumble_stream {
     int device = 0;
     crumble_gz *gz = nullptr;                    /* codec context (its stream carries this object's kernels too) */
     int n_ref = 0;
-    DevBuf d_rec[2];                             /* the record bytes: [0, len) of d_rec[cur] */
+    DevBuf d_rec[2];                             /* the live bytes: [base, base + len) of d_rec[cur]; offsets below count from base */
     int cur = 0;
-    int64_t len = 0;                             /* bytes in the buffer */
-    int64_t start = 0;                           /* first record (behind the BAM header on the first feed) */
+    int64_t base = 0;                            /* (advanced by drain; back to 0 when a feed moves the live bytes to the other buffer) */
+    int64_t len = 0;                             /* live bytes */
+    int64_t hdr = 0;                             /* bytes of the BAM header still to be dropped at the front (first feeds) */
+    int64_t start = 0;                           /* first record not yet processed: what lies in front of it was processed and waits for a drain */
     int64_t tail = 0;                            /* where the incomplete last record starts (== len when there is none) */
     int64_t n_rec = 0;
     DevBuf d_guess, d_exit, d_count, d_slots, d_coff, d_recoff, d_list, d_misc, d_err;
@@ -42,7 +44,7 @@ extern "C" crumble_stream *crumble_stream_create(int device, int32_t n_ref, int6
     if (!gz) return nullptr;
     crumble_stream *s = new (std::nothrow) crumble_stream();
     if (!s) { crumble_gz_destroy(gz); *err = CRUMBLE_ENOMEM; return nullptr; }
-    s->device = device; s->gz = gz; s->n_ref = n_ref; s->start = header_bytes > 0 ? header_bytes : 0;
+    s->device = device; s->gz = gz; s->n_ref = n_ref; s->hdr = header_bytes > 0 ? header_bytes : 0;
     bool ok = hipHostMalloc(&s->pinned, 4096, 0) == hipSuccess;
     uint32_t ppm[128];
     for (int q = 0; q < 128; q++) ppm[q] = (uint32_t)(1e6 * pow(10.0, -q / 10.0) + 0.5);
@@ -99,7 +101,7 @@ static int stream_sync(crumble_stream *s)
 {
     StClock clk(&s->ms_sync);
     hipStream_t st = s->gz->stream;
-    const uint8_t *R = s->d_rec[s->cur].as<uint8_t>();
+    const uint8_t *R = s->d_rec[s->cur].as<uint8_t>() + s->base;
     s->groups.clear(); s->n_rec = 0; s->tail = s->start;
     if (s->len <= s->start) return CRUMBLE_OK;
     const int nch = (int)((s->len - s->start + ST_CHUNK - 1) / ST_CHUNK);
@@ -183,22 +185,29 @@ extern "C" int crumble_stream_feed(crumble_stream *s, const uint8_t *comp, int64
     DevBuf &B = s->d_rec[s->cur];
     const size_t need = (size_t)(s->len + add) + 4096;
     int e;
-    if (need > B.cap) {                                     /* grow: into the other buffer, the bytes so far copied over */
+    if ((size_t)s->base + need > B.cap) {                   /* no room behind the live bytes: they move to the front of the other buffer */
         DevBuf &N = s->d_rec[s->cur ^ 1];
-        size_t want = B.cap ? B.cap : ((size_t)1 << 30);
+        size_t want = B.cap > N.cap ? B.cap : N.cap;
+        if (!want) want = (size_t)1 << 30;
         while (want < need) want += want / 2;
-        if ((e = N.reserve(want))) return e;
-        if (s->len) CRUMBLE_LAUNCH(k_st_copy, 1024, 256, st, B.as<const uint8_t>(), N.as<uint8_t>(), s->len);
+        if (N.cap < want) {
+            if (N.cap >= need) want = N.cap;
+            else if ((e = N.reserve(want))) return e;
+        }
+        if (s->len) CRUMBLE_LAUNCH(k_st_copy, 1024, 256, st, B.as<const uint8_t>() + s->base, N.as<uint8_t>(), s->len);
+        HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st));
-        s->cur ^= 1;
+        s->cur ^= 1; s->base = 0;
     }
-    uint8_t *R = s->d_rec[s->cur].as<uint8_t>();
+    uint8_t *R = s->d_rec[s->cur].as<uint8_t>() + s->base;
     std::vector<crumble_gz_block> b2((size_t)n_blocks);
     int64_t u = s->len;
     for (int64_t i = 0; i < n_blocks; i++) { b2[(size_t)i] = blk[i]; b2[(size_t)i].uoff = u; u += blk[i].ulen; }
     { StClock clk(&s->ms_inflate); if (n_blocks && (e = gz_inflate_impl(s->gz, comp, comp_len, b2.data(), n_blocks, nullptr, R, u, 1))) return e; }
     s->len = u; s->eof = eof != 0; s->bytes_in += comp_len;
+    if (s->hdr && s->len >= s->hdr) { s->base += s->hdr; s->len -= s->hdr; s->hdr = 0; R = s->d_rec[s->cur].as<uint8_t>() + s->base; }   /* the header goes */
     HIPCHK(hipMemsetAsync(R + s->len, 0, 4096, st));
+    if (s->hdr) { if (s->eof) { g_last_error = "crumble_stream: the file ends inside the BAM header"; return CRUMBLE_EINVAL; } return CRUMBLE_OK; }
     if ((e = stream_sync(s))) return e;
     if (s->eof && s->tail != s->len) { g_last_error = "crumble_stream: truncated BAM record at the end of the file"; return CRUMBLE_EINVAL; }
     return CRUMBLE_OK;
@@ -231,7 +240,7 @@ extern "C" int crumble_stream_process(crumble_stream *s, crumble_hip *h, int gro
     if ((e = s->d_pos.reserve((size_t)n * 4 + 64)) || (e = s->d_mapq.reserve((size_t)n + 64)) || (e = s->d_flag.reserve((size_t)n * 2 + 64)) ||
         (e = s->d_lq.reserve((size_t)n * 4 + 64)) || (e = s->d_ncg.reserve((size_t)n * 2 + 64)) || (e = s->d_noq.reserve((size_t)n + 64)))
         return e;
-    uint8_t *R = s->d_rec[s->cur].as<uint8_t>();
+    uint8_t *R = s->d_rec[s->cur].as<uint8_t>() + s->base;
     const int64_t *ro = s->d_recoff.as<int64_t>() + g.first_read;
     HIPCHK(hipMemsetAsync(s->d_tot.p, 0, sizeof(StTotals), st));
     const int64_t step = n > 65536 ? n / 65536 : 1;
@@ -265,36 +274,34 @@ extern "C" int crumble_stream_process(crumble_stream *s, crumble_hip *h, int gro
     return CRUMBLE_OK;
 }
 
-/* The records of the first k contig runs (all of them processed, or meant to pass unchanged) as BGZF members into out;
- * they leave the buffer, what lies behind them moves to its front.  out_cap >= crumble_gz_deflate_bound(their bytes). */
+/* The records of the first k contig runs (all of them processed, or meant to pass unchanged), behind whatever an earlier
+ * call left over, as BGZF members into out: everything if crumble_gz_deflate_bound(their bytes) <= out_cap, else as many
+ * whole members of 0xff00 bytes as out_cap holds -- the rest stays at the front of the buffer for the next call (k = 0
+ * then drains it; crumble_stream_pending() tells how much there is).  The contig runs are numbered anew afterwards. */
 extern "C" int crumble_stream_drain(crumble_stream *s, int k, int level, uint8_t *out, int64_t out_cap, int64_t *out_len)
 {
     if (!s || k < 0 || k > (int)s->groups.size() || !out_len) return CRUMBLE_EINVAL;
     *out_len = 0;
-    if (!k) return CRUMBLE_OK;
+    if (s->hdr) return k ? CRUMBLE_EINVAL : CRUMBLE_OK;
+    const int64_t avail = k ? s->groups[(size_t)k - 1].byte_end : s->start;
+    if (!avail) return CRUMBLE_OK;
     HIPCHK(hipSetDevice(s->device));
-    hipStream_t st = s->gz->stream;
-    const int64_t b0 = s->groups[0].byte_start, b1 = s->groups[(size_t)k - 1].byte_end;
-    uint8_t *R = s->d_rec[s->cur].as<uint8_t>();
-    int e;
-    { StClock clk(&s->ms_deflate); if (b1 > b0 && (e = gz_deflate_impl(s->gz, nullptr, R + b0, b1 - b0, level, out, out_cap, out_len))) return e; }
-    const double t_move = st_now();
-    s->bytes_out += *out_len;
-    /* what is left: [b1, len) to the front of the other buffer */
-    const int64_t rest = s->len - b1;
-    DevBuf &N = s->d_rec[s->cur ^ 1];
-    {
-        const size_t keep = (size_t)(rest > 0 ? rest : 0) + 4096, capc = s->d_rec[s->cur].cap;
-        if (N.cap < keep && (e = N.reserve(keep > capc ? keep : capc))) return e;      /* (as large as its twin: the next feed appends) */
+    int64_t take = avail;
+    if (crumble_gz_deflate_bound(avail) > out_cap) {
+        take = out_cap / (GZ_MAXBLK + 31) * GZ_MAXBLK;
+        if (take <= 0) { g_last_error = "crumble_stream_drain: the output buffer does not hold one BGZF member"; return CRUMBLE_EINVAL; }
     }
-    if (rest > 0) CRUMBLE_LAUNCH(k_st_copy, 1024, 256, st, R + b1, N.as<uint8_t>(), rest);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));
-    s->cur ^= 1; s->len = rest > 0 ? rest : 0; s->start = 0;
-    s->ms_move += (float)(st_now() - t_move);
+    uint8_t *R = s->d_rec[s->cur].as<uint8_t>() + s->base;
+    int e;
+    { StClock clk(&s->ms_deflate); if ((e = gz_deflate_impl(s->gz, nullptr, R, take, level, out, out_cap, out_len))) return e; }
+    s->bytes_out += *out_len;
+    s->base += take; s->len -= take; s->start = avail - take;
     if ((e = stream_sync(s))) return e;
     return CRUMBLE_OK;
 }
+
+/* bytes that were processed (or skipped) and not drained yet: the front of the buffer */
+extern "C" int64_t crumble_stream_pending(crumble_stream *s) { return s && !s->hdr ? s->start : 0; }
 
 /* the bytes of the buffer (tests): d_rec[cur][from, from + n) -> host */
 extern "C" int crumble_stream_peek(crumble_stream *s, int64_t from, int64_t n, uint8_t *out, int64_t *len, int64_t *n_rec, int64_t *rec_off, int64_t max_rec)
@@ -303,7 +310,7 @@ extern "C" int crumble_stream_peek(crumble_stream *s, int64_t from, int64_t n, u
     HIPCHK(hipSetDevice(s->device));
     if (len) *len = s->len;
     if (n_rec) *n_rec = s->n_rec;
-    if (out && n > 0) { if (from < 0 || from + n > s->len) return CRUMBLE_EINVAL; HIPCHK(copy_sync(s->gz->stream, out, s->d_rec[s->cur].as<uint8_t>() + from, (size_t)n, hipMemcpyDeviceToHost)); }
+    if (out && n > 0) { if (from < 0 || from + n > s->len) return CRUMBLE_EINVAL; HIPCHK(copy_sync(s->gz->stream, out, s->d_rec[s->cur].as<uint8_t>() + s->base + from, (size_t)n, hipMemcpyDeviceToHost)); }
     if (rec_off && max_rec > 0 && s->n_rec) HIPCHK(copy_sync(s->gz->stream, rec_off, s->d_recoff.p, (size_t)(s->n_rec < max_rec ? s->n_rec : max_rec) * 8, hipMemcpyDeviceToHost));
     return CRUMBLE_OK;
 }

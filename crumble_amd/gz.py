@@ -172,11 +172,19 @@ class Stream:
         if rc:
             raise CrumbleError(rc, "crumble_stream_process", self.L)
 
-    def drain(self, k, level=6):
+    def pending(self):
+        self.L.crumble_stream_pending.restype = C.c_int64
+        self.L.crumble_stream_pending.argtypes = [C.c_void_p]
+        return int(self.L.crumble_stream_pending(self.h))
+
+    def drain(self, k, level=6, cap=None):
+        """BGZF members of the first k contig runs (behind what an earlier call left); cap: bytes of the output buffer -- when
+        that is less than crumble_gz_deflate_bound() of the bytes, whole members only, the rest stays (pending())"""
         gs = self.groups()
-        nbytes = (gs[k - 1].byte_end - gs[0].byte_start) if k else 0
-        cap = int(self.L.crumble_gz_deflate_bound(nbytes)) + 64
-        out = np.empty(cap, np.uint8)
+        nbytes = gs[k - 1].byte_end if k else self.pending()
+        if cap is None:
+            cap = int(self.L.crumble_gz_deflate_bound(nbytes)) + 64
+        out = np.empty(max(cap, 1), np.uint8)
         n = C.c_int64(0)
         rc = self.L.crumble_stream_drain(self.h, k, level, out.ctypes.data, cap, C.byref(n))
         if rc:
