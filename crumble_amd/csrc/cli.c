@@ -115,7 +115,7 @@ typedef char gz_block_layout_check[sizeof(crumble_bam_block) == sizeof(crumble_g
 /* compressed bytes per feed (the inflate kernel's time hardly depends on the members' number) and record bytes per drain, at
  * least (whole contig runs); CRUMBLE_HIP_DP_CHUNK / CRUMBLE_HIP_DP_PIECE (bytes) let the tests cut a small file many times */
 static size_t DP_CHUNK = (size_t)256 << 20;
-static int64_t DP_PIECE = (int64_t)128 << 20;
+static int64_t DP_PIECE = (int64_t)2048 * 65280;      /* (2048 members: eight per CU) */
 typedef struct { uint8_t *buf; size_t cap; int pinned; crumble_gz_block *blk; size_t bcap; int64_t nb, used; int eof, full; } dp_in;
 typedef struct { uint8_t *buf; size_t cap; int pinned; int64_t len; int full; } dp_out;
 typedef struct {
@@ -292,12 +292,12 @@ static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_ba
             rc = e == CRUMBLE_EUNSORTED ? 2 : 1;
             break;
         }
-        for (;;) {                                              /* whole contig runs, DP_PIECE bytes of records or more, then drains */
+        for (;;) {                                              /* whole contig runs until DP_PIECE bytes of records wait, then a drain */
             crumble_stream_group g[256];
             const int ng = crumble_stream_groups(s, g, 256);
             int k = 0;
             int64_t bytes = crumble_stream_pending(s);
-            for (int i = 0; i < ng && i < 256 && g[i].complete && bytes < DP_PIECE; i++) {
+            for (int i = 0; i < ng && i < 256 && g[i].complete && crumble_gz_deflate_bound(bytes) <= (int64_t)d.out[oslot].cap; i++) {
                 while (bed_i < nbed && g[i].tid >= 0 && bt[bed_i] < g[i].tid) bed_i++;
                 int j2 = bed_i;
                 while (j2 < nbed && bt[j2] == g[i].tid) j2++;
@@ -309,13 +309,17 @@ static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_ba
                 }
                 n_reads += g[i].n_reads; bytes = g[i].byte_end; k++;
             }
-            if (rc || !bytes) break;
+            if (rc) break;
             if (k) {
                 crumble_stream_groups(s, g, 256);               /* (n_bases of the runs just processed) */
                 for (int i = 0; i < k; i++) n_bases += g[i].n_bases;
             }
-            /* what was processed leaves through the two fixed output buffers, a buffer's worth of whole members at a time */
-            do {
+            /* the last bytes of the file: the short last member too; otherwise whole members, a buffer's worth at a time, and
+             * what is less than that waits for the next runs */
+            const int last = eof && k == ng && ng <= 256;
+            if (!k && !(last && bytes)) break;
+            int first = 1;
+            while (first || (last ? crumble_stream_pending(s) > 0 : crumble_gz_deflate_bound(crumble_stream_pending(s)) > (int64_t)d.out[oslot].cap)) {
                 dp_out *o = &d.out[oslot];
                 pthread_mutex_lock(&d.mu);
                 t_gpu += now() - t0;
@@ -324,12 +328,15 @@ static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_ba
                 pthread_mutex_unlock(&d.mu);
                 t0 = now();
                 if (stop2) { rc = rc ? rc : 1; break; }
-                e = crumble_stream_drain(s, k, level, o->buf, (int64_t)o->cap, &o->len);
-                k = 0;
+                const int whole = !last && crumble_gz_deflate_bound(bytes) <= (int64_t)o->cap && first;   /* less than a buffer waits: only mark the runs */
+                e = crumble_stream_drain(s, k, level, last, o->buf, whole ? 0 : (int64_t)o->cap, &o->len);
+                k = 0; first = 0;
                 if (e) { fprintf(stderr, "crumble-hip: %s (%s)\n", crumble_hip_strerror(e), crumble_hip_last_error()); rc = 1; break; }
-                pthread_mutex_lock(&d.mu); o->full = 1; pthread_cond_broadcast(&d.cv); pthread_mutex_unlock(&d.mu);
-                oslot ^= 1;
-            } while (crumble_stream_pending(s) > 0);
+                if (o->len) {
+                    pthread_mutex_lock(&d.mu); o->full = 1; pthread_cond_broadcast(&d.cv); pthread_mutex_unlock(&d.mu);
+                    oslot ^= 1;
+                }
+            }
             if (rc) break;
         }
         t_gpu += now() - t0;

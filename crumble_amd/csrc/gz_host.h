@@ -59,6 +59,22 @@ extern "C" crumble_gz *crumble_gz_create(int device, int *err)
     gz_make_tables(tabs);
     ok = ok && g->d_tabs.reserve(sizeof tabs) == CRUMBLE_OK && copy_sync(g->stream, g->d_tabs.p, tabs, sizeof tabs, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { g_last_error = "BGZF codec: device set-up failed"; *err = CRUMBLE_EHIP; crumble_gz_destroy(g); return nullptr; }
+#ifndef CRUMBLE_EMU
+    {   /* every kernel once over nothing: a kernel's first launch costs milliseconds (measured: 6.5 ms in front of the first
+         * k_gz_tokens_lanes of a run), which belongs to the set-up and not to the first file's first members */
+        hipStream_t st = g->stream;
+        const uint32_t *tb = g->d_tabs.as<uint32_t>();
+        hipLaunchKernelGGL(k_gz_tokens_lanes, dim3(1), dim3(64), 0, st, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL(k_gz_tokens, dim3(1), dim3(GZ_WAVES * 64), 0, st, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL(k_gz_resolve, dim3(1), dim3(GZ_RT), 0, st, 0, nullptr, nullptr, nullptr, nullptr, nullptr, tb, tb + 256, nullptr, 0);
+        hipLaunchKernelGGL(k_gz_deflate, dim3(1), dim3(GZ_DT), 0, st, 0, nullptr, (int64_t)0, 1, nullptr, nullptr, nullptr, nullptr, tb, tb + 256);
+        if (g->d_off.reserve(64) == CRUMBLE_OK) hipLaunchKernelGGL(k_gz_offsets, dim3(1), dim3(1024), 0, st, 0, nullptr, g->d_off.as<int64_t>());
+        hipLaunchKernelGGL(k_gz_gather, dim3(1), dim3(256), 0, st, 0, nullptr, nullptr, nullptr, nullptr);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            g_last_error = "BGZF codec: kernel warm-up failed"; *err = CRUMBLE_EHIP; crumble_gz_destroy(g); return nullptr;
+        }
+    }
+#endif
     return g;
 }
 

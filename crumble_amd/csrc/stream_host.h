@@ -22,6 +22,7 @@ struct crumble_stream {
     DevBuf d_rec[2];                             /* the live bytes: [base, base + len) of d_rec[cur]; offsets below count from base */
     int cur = 0;
     int64_t base = 0;                            /* (advanced by drain; back to 0 when a feed moves the live bytes to the other buffer) */
+    int64_t sync_base = 0;                       /* base when the records were last delimited: d_recoff and the groups' bytes count from there */
     int64_t len = 0;                             /* live bytes */
     int64_t hdr = 0;                             /* bytes of the BAM header still to be dropped at the front (first feeds) */
     int64_t start = 0;                           /* first record not yet processed: what lies in front of it was processed and waits for a drain */
@@ -102,6 +103,7 @@ static int stream_sync(crumble_stream *s)
     StClock clk(&s->ms_sync);
     hipStream_t st = s->gz->stream;
     const uint8_t *R = s->d_rec[s->cur].as<uint8_t>() + s->base;
+    s->sync_base = s->base;
     s->groups.clear(); s->n_rec = 0; s->tail = s->start;
     if (s->len <= s->start) return CRUMBLE_OK;
     const int nch = (int)((s->len - s->start + ST_CHUNK - 1) / ST_CHUNK);
@@ -218,7 +220,8 @@ extern "C" int crumble_stream_groups(crumble_stream *s, crumble_stream_group *ou
 {
     if (!s) return CRUMBLE_EINVAL;
     const int n = (int)s->groups.size();
-    for (int i = 0; i < n && i < max; i++) out[i] = s->groups[(size_t)i];
+    const int64_t shift = s->base - s->sync_base;           /* (a drain since the records were delimited moved the origin) */
+    for (int i = 0; i < n && i < max; i++) { out[i] = s->groups[(size_t)i]; out[i].byte_start -= shift; out[i].byte_end -= shift; }
     return n;
 }
 
@@ -240,7 +243,7 @@ extern "C" int crumble_stream_process(crumble_stream *s, crumble_hip *h, int gro
     if ((e = s->d_pos.reserve((size_t)n * 4 + 64)) || (e = s->d_mapq.reserve((size_t)n + 64)) || (e = s->d_flag.reserve((size_t)n * 2 + 64)) ||
         (e = s->d_lq.reserve((size_t)n * 4 + 64)) || (e = s->d_ncg.reserve((size_t)n * 2 + 64)) || (e = s->d_noq.reserve((size_t)n + 64)))
         return e;
-    uint8_t *R = s->d_rec[s->cur].as<uint8_t>() + s->base;
+    uint8_t *R = s->d_rec[s->cur].as<uint8_t>() + s->sync_base;
     const int64_t *ro = s->d_recoff.as<int64_t>() + g.first_read;
     HIPCHK(hipMemsetAsync(s->d_tot.p, 0, sizeof(StTotals), st));
     const int64_t step = n > 65536 ? n / 65536 : 1;
@@ -274,29 +277,35 @@ extern "C" int crumble_stream_process(crumble_stream *s, crumble_hip *h, int gro
     return CRUMBLE_OK;
 }
 
-/* The records of the first k contig runs (all of them processed, or meant to pass unchanged), behind whatever an earlier
- * call left over, as BGZF members into out: everything if crumble_gz_deflate_bound(their bytes) <= out_cap, else as many
- * whole members of 0xff00 bytes as out_cap holds -- the rest stays at the front of the buffer for the next call (k = 0
- * then drains it; crumble_stream_pending() tells how much there is).  The contig runs are numbered anew afterwards. */
-extern "C" int crumble_stream_drain(crumble_stream *s, int k, int level, uint8_t *out, int64_t out_cap, int64_t *out_len)
+/* The first k contig runs are done (processed, or meant to pass unchanged): they join what waits at the front of the buffer
+ * (crumble_stream_pending), and as much of that as out_cap holds leaves as BGZF members of 0xff00 bytes -- whole members
+ * only, unless flush is set and everything fits: then the last, shorter member too (the end of the file, or of a piece the
+ * caller wants closed).  out_cap 0: nothing is written, the runs are only marked.  The remaining runs keep their order and
+ * are numbered from 0 again. */
+extern "C" int crumble_stream_drain(crumble_stream *s, int k, int level, int flush, uint8_t *out, int64_t out_cap, int64_t *out_len)
 {
-    if (!s || k < 0 || k > (int)s->groups.size() || !out_len) return CRUMBLE_EINVAL;
+    if (!s || k < 0 || k > (int)s->groups.size() || !out_len || out_cap < 0 || (out_cap && !out)) return CRUMBLE_EINVAL;
     *out_len = 0;
     if (s->hdr) return k ? CRUMBLE_EINVAL : CRUMBLE_OK;
-    const int64_t avail = k ? s->groups[(size_t)k - 1].byte_end : s->start;
-    if (!avail) return CRUMBLE_OK;
-    HIPCHK(hipSetDevice(s->device));
-    int64_t take = avail;
-    if (crumble_gz_deflate_bound(avail) > out_cap) {
-        take = out_cap / (GZ_MAXBLK + 31) * GZ_MAXBLK;
-        if (take <= 0) { g_last_error = "crumble_stream_drain: the output buffer does not hold one BGZF member"; return CRUMBLE_EINVAL; }
+    if (k) {
+        s->start = s->groups[(size_t)k - 1].byte_end - (s->base - s->sync_base);
+        s->groups.erase(s->groups.begin(), s->groups.begin() + k);
     }
+    const int64_t avail = s->start;
+    if (!avail || !out_cap) return CRUMBLE_OK;
+    int64_t take = avail;
+    if (crumble_gz_deflate_bound(avail) > out_cap) take = out_cap / (GZ_MAXBLK + 31) * GZ_MAXBLK;
+    else if (!flush) take = avail / GZ_MAXBLK * GZ_MAXBLK;
+    if (take <= 0) {
+        if (crumble_gz_deflate_bound(avail) > out_cap) { g_last_error = "crumble_stream_drain: the output buffer does not hold one BGZF member"; return CRUMBLE_EINVAL; }
+        return CRUMBLE_OK;                                  /* (less than a member waits, and no flush) */
+    }
+    HIPCHK(hipSetDevice(s->device));
     uint8_t *R = s->d_rec[s->cur].as<uint8_t>() + s->base;
     int e;
     { StClock clk(&s->ms_deflate); if ((e = gz_deflate_impl(s->gz, nullptr, R, take, level, out, out_cap, out_len))) return e; }
     s->bytes_out += *out_len;
-    s->base += take; s->len -= take; s->start = avail - take;
-    if ((e = stream_sync(s))) return e;
+    s->base += take; s->len -= take; s->start -= take; s->tail -= take;
     return CRUMBLE_OK;
 }
 

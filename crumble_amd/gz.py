@@ -129,7 +129,7 @@ class Stream:
         L.crumble_stream_process.restype = C.c_int
         L.crumble_stream_process.argtypes = [vp, vp, C.c_int, C.c_int32, vp, vp]
         L.crumble_stream_drain.restype = C.c_int
-        L.crumble_stream_drain.argtypes = [vp, C.c_int, C.c_int, vp, i64, C.POINTER(i64)]
+        L.crumble_stream_drain.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, i64, C.POINTER(i64)]
         L.crumble_stream_peek.restype = C.c_int
         L.crumble_stream_peek.argtypes = [vp, i64, i64, vp, C.POINTER(i64), C.POINTER(i64), vp, i64]
         err = C.c_int(0)
@@ -177,16 +177,17 @@ class Stream:
         self.L.crumble_stream_pending.argtypes = [C.c_void_p]
         return int(self.L.crumble_stream_pending(self.h))
 
-    def drain(self, k, level=6, cap=None):
-        """BGZF members of the first k contig runs (behind what an earlier call left); cap: bytes of the output buffer -- when
-        that is less than crumble_gz_deflate_bound() of the bytes, whole members only, the rest stays (pending())"""
+    def drain(self, k, level=6, cap=None, flush=True):
+        """the first k contig runs are done; BGZF members of what waits at the front of the buffer: whole members of 0xff00
+        bytes as far as cap (bytes of the output buffer; default: enough for everything) allows, with flush the last, shorter
+        one too when everything fits; the rest stays (pending())"""
         gs = self.groups()
         nbytes = gs[k - 1].byte_end if k else self.pending()
         if cap is None:
             cap = int(self.L.crumble_gz_deflate_bound(nbytes)) + 64
         out = np.empty(max(cap, 1), np.uint8)
         n = C.c_int64(0)
-        rc = self.L.crumble_stream_drain(self.h, k, level, out.ctypes.data, cap, C.byref(n))
+        rc = self.L.crumble_stream_drain(self.h, k, level, 1 if flush else 0, out.ctypes.data, cap, C.byref(n))
         if rc:
             raise CrumbleError(rc, "crumble_stream_drain", self.L)
         return out[:n.value]

@@ -454,9 +454,9 @@ int     crumble_gz_times(crumble_gz *g, float *h2d_ms, float *kernels_ms, float 
  *   n = crumble_stream_groups(s, g, max)                           the contig runs in the buffer (refID, reads, bytes); all but
  *       the last are complete, the last one too once eof was fed
  *   crumble_stream_process(s, engine, i, n_bed, bed_start, bed_end)   run i through an engine of the same device
- *   crumble_stream_drain(s, k, level, out, cap, &len)              the first k runs as BGZF members (then gone from the buffer);
- *       with cap below crumble_gz_deflate_bound(their bytes): as many whole members as fit, the rest waits at the front of the
- *       buffer (crumble_stream_pending) for the next call -- a contig of any size through a fixed output buffer
+ *   crumble_stream_drain(s, k, level, flush, out, cap, &len)       the first k runs are done: they join what waits at the front of
+ *       the buffer (crumble_stream_pending), and as many whole BGZF members of 0xff00 bytes as cap holds leave; with flush the
+ *       last, shorter one too when everything fits -- a contig of any size through a fixed output buffer
  * Files with a CIGAR of more than 65535 operations (CG tag) are refused by process (CRUMBLE_EINVAL): the caller takes the
  * host path.  A record stream that cannot be delimited (the chain of block_size fields is checked) is refused by feed. */
 typedef struct crumble_stream crumble_stream;
@@ -473,7 +473,7 @@ void crumble_stream_destroy(crumble_stream *s);
 int  crumble_stream_feed(crumble_stream *s, const uint8_t *comp, int64_t comp_len, const crumble_gz_block *blk, int64_t n_blocks, int eof);
 int  crumble_stream_groups(crumble_stream *s, crumble_stream_group *out, int max);
 int  crumble_stream_process(crumble_stream *s, crumble_hip *h, int group, int32_t n_bed, const int32_t *bed_start, const int32_t *bed_end);
-int  crumble_stream_drain(crumble_stream *s, int k, int level, uint8_t *out, int64_t out_cap, int64_t *out_len);
+int  crumble_stream_drain(crumble_stream *s, int k, int level, int flush, uint8_t *out, int64_t out_cap, int64_t *out_len);
 int64_t crumble_stream_pending(crumble_stream *s);   /* bytes processed and not drained yet */
 /* optional set-up before the first feed: device memory for feeds of up to comp_bytes that inflate to about raw_bytes (record
  * buffers, token and slot arrays), so that no feed / drain stops to allocate; larger feeds still work (they grow the buffers) */

@@ -99,6 +99,9 @@ def run_stream(library, engine, path, cuts, level=6, bed=None, small_out=False):
                 assert gs[0].byte_start == 0
                 if small_out:                        # an output buffer of two members: the rest waits at the front of the buffer
                     cap, kk, back = 2 * (0xff00 + 31) + 5, k, b""
+                    m = s.drain(kk, level, cap, flush=False).tobytes() if nbytes < 0xff00 else b"x"
+                    assert nbytes >= 0xff00 or (m == b"" and s.pending() == nbytes)        # less than a member and no flush: it waits
+                    kk = 0 if nbytes < 0xff00 else kk
                     while True:
                         m = s.drain(kk, level, cap).tobytes()
                         kk = 0
@@ -107,6 +110,7 @@ def run_stream(library, engine, path, cuts, level=6, bed=None, small_out=False):
                         if not s.pending():
                             break
                         assert len(gzip.decompress(m)) == 2 * 0xff00
+                    assert [(g.tid, g.byte_start) for g in s.groups()[:1]] in ([], [(gs[k].tid, 0)] if k < len(gs) else [])
                 else:
                     m = s.drain(k, level).tobytes()
                     back = gzip.decompress(m) if m else b""
