@@ -341,22 +341,34 @@ k_gz_tokens(int n_members, const GzBlock *__restrict__ blk, const uint8_t *__res
 /* ---- k_gz_tokens_lanes: a LANE per member --------------------------------------------------------------------------
  * The wave-per-member walk above keeps one lane of sixty-four busy; with thousands of members in a call the other way
  * round pays: every lane walks its own member (bit buffer, position and state in its registers), the 64 walks advance in
- * lockstep one symbol per loop iteration whatever each lane's symbol is (literal, match, a header field), and the decode
- * tables live in a per-member scratch area in global memory (6.3 KiB each: served by the L2 / the Infinity Cache).  A
- * lane that reaches a block header reads its code lengths one symbol per iteration like everybody else's symbols; the
- * table fill is done for one lane at a time by the whole wave.  Same tokens, same status words as k_gz_tokens. */
-#define GZ2_WORDS    1600          /* scratch words per member */
-#define GZ2_LIT      0             /* [1024] literal/length table */
-#define GZ2_DST      1024          /* [256]  distance table */
-#define GZ2_LSYM     1280          /* u16[288] literal/length symbols in canonical order */
-#define GZ2_DSYM     1424          /* u16[32] */
-#define GZ2_CNT      1440          /* u16[6][16]: lcnt lfirst loffs dcnt dfirst doffs */
-#define GZ2_LENS     1488          /* u8[320] code lengths as read */
+ * lockstep one symbol per loop iteration whatever each lane's symbol is (literal, match, a header field).  The primary
+ * decode tables of the 64 members live in LDS as 16-bit entries, interleaved by lane (entry j of lane L at half-word
+ * j * 64 + L: two lanes per bank at most whatever they look up): 2^9 literal/length entries and 2^7 distance entries per
+ * lane, 80 KiB per wave.  Codes longer than that (rare symbols by construction) are decoded the canonical way from a small
+ * per-member area in global memory, where the code lengths of a dynamic header also wait for the table fill.  The next
+ * input word is always in flight one refill ahead.  A lane that reaches a block header reads its code lengths one symbol
+ * per iteration like everybody else's symbols; the table fill is done for one lane at a time by the whole wave.  Same
+ * tokens, same status words as k_gz_tokens. */
+#define GZ2_TB       9             /* bits of the literal/length look-up in LDS */
+#define GZ2_DB       7             /* of the distance look-up */
+#define GZ2_WORDS    288           /* scratch words per member (global memory) */
+#define GZ2_LSYM     0             /* u16[288] literal/length symbols in canonical order */
+#define GZ2_DSYM     144           /* u16[32] */
+#define GZ2_CNT      160           /* u16[6][16]: lcnt lfirst loffs dcnt dfirst doffs */
+#define GZ2_LENS     208           /* u8[320] code lengths as read */
+/* 16-bit entry: code length (bits 0-3; 0: not a code), kind (bits 4-5), value (bits 6-15: the literal, or the index of the
+ * length / distance symbol -- base and extra bits follow from it by arithmetic, RFC 1951 3.2.5) */
+#define GZ2_LIT      0u
+#define GZ2_LEN      1u
+#define GZ2_EOB      2u
+#define GZ2_LONG     3u
+#define GZ2_E(len_, kind_, val_) ((uint16_t)((uint32_t)(len_) | ((uint32_t)(kind_) << 4) | ((uint32_t)(val_) << 6)))
 
-/* the decode table of one member's block, by the whole wave (uniform arguments): lens[0, n) -> tab, sym, cnt / first / offs */
-__device__ __forceinline__ unsigned gz2_build(const uint8_t *lens, int n, int tb, uint32_t *tab, uint16_t *sym, uint16_t *cfo, bool is_dist, int lane)
+/* the decode table of one member's block, by the whole wave (uniform arguments): lens[0, n) -> tab (LDS, stride 64
+ * half-words), sym, cnt / first / offs (global) */
+__device__ __forceinline__ unsigned gz2_build(const uint8_t *lens, int n, int tb, uint16_t *tab, uint16_t *sym, uint16_t *cfo, bool is_dist, int lane)
 {
-    for (int i = lane; i < (1 << tb); i += 64) tab[i] = 0u;
+    for (int i = lane; i < (1 << tb); i += 64) tab[i * 64] = 0;
     int cnt[16];
     #pragma unroll
     for (int q = 0; q < 16; q++) cnt[q] = 0;
@@ -382,6 +394,7 @@ __device__ __forceinline__ unsigned gz2_build(const uint8_t *lens, int n, int tb
         for (int q = 0; q < 16; q++) if (lane == q) { c = cnt[q]; f = first[q]; of = offs[q]; }
         cfo[lane] = (uint16_t)c; cfo[16 + lane] = (uint16_t)f; cfo[32 + lane] = (uint16_t)of;
     }
+    WAVE_SYNC();                                             /* (the cleared entries are in LDS before the codes go in) */
     int seen[16];
     #pragma unroll
     for (int q = 0; q < 16; q++) seen[q] = 0;
@@ -398,9 +411,11 @@ __device__ __forceinline__ unsigned gz2_build(const uint8_t *lens, int n, int tb
             const uint32_t rev = gz_bitrev((uint32_t)(f + rank), l);
             sym[of + rank] = (uint16_t)s;
             if (l <= tb) {
-                const uint32_t e = is_dist ? gz_dist_entry(s, l) : gz_lit_entry(s, l);
-                for (uint32_t j = rev; j < (1u << tb); j += 1u << l) tab[j] = e;
-            } else tab[rev & ((1u << tb) - 1u)] = GZ_ENTRY(0, GZ_K_LONG, 0, 0);
+                uint16_t e;
+                if (is_dist) e = s > 29 ? (uint16_t)0 : GZ2_E(l, GZ2_LEN, s);
+                else e = s < 256 ? GZ2_E(l, GZ2_LIT, s) : s == 256 ? GZ2_E(l, GZ2_EOB, 0) : s > 285 ? (uint16_t)0 : GZ2_E(l, GZ2_LEN, s - 257);
+                for (uint32_t j = rev; j < (1u << tb); j += 1u << l) tab[j * 64] = e;
+            } else tab[(rev & ((1u << tb) - 1u)) * 64] = GZ2_E(0, GZ2_LONG, 0);
         }
     }
     return 0;
@@ -411,6 +426,7 @@ k_gz_tokens_lanes(int n_members, const GzBlock *__restrict__ blk, const uint8_t 
                   const int64_t *__restrict__ tok_off, uint32_t *__restrict__ ntok_out, uint32_t *__restrict__ status,
                   uint32_t *__restrict__ scratch)
 {
+    __shared__ uint16_t T[((1 << GZ2_TB) + (1 << GZ2_DB)) * 64];
     const int lane = threadIdx.x & 63;
     const int mi = (int)blockIdx.x * 64 + lane;
     const bool valid = mi < n_members;
@@ -420,6 +436,7 @@ k_gz_tokens_lanes(int n_members, const GzBlock *__restrict__ blk, const uint8_t 
     const uint8_t *src = comp + m.coff;
     uint32_t *S = scratch + (size_t)(valid ? mi : 0) * GZ2_WORDS;
     uint32_t *tout = gtok + (valid ? tok_off[mi] : 0);
+    const uint16_t *TL = T + lane, *TD = T + (1 << GZ2_TB) * 64 + lane;
     enum { S_HDR = 0, S_CLEN = 1, S_LENS = 2, S_BUILD = 3, S_DECODE = 4, S_STORED = 5, S_DONE = 6 };
     int state = valid ? S_HDR : S_DONE;
     uint64_t bb = 0; int bc = 0, ip = 0;
@@ -430,7 +447,10 @@ k_gz_tokens_lanes(int n_members, const GzBlock *__restrict__ blk, const uint8_t 
     unsigned err = 0;
     const int ulen = (int)m.ulen, clen = (int)m.clen;
     uint8_t *lens = (uint8_t *)(S + GZ2_LENS);
+    /* the word behind the bit buffer, loaded one refill ahead (the buffer behind the last member is padded: GZ_IN_PAD) */
+    uint32_t nxt = valid ? ((const GzU32u *)src)->v : 0u;
 
+#define G2_REFILL() do { bb |= (uint64_t)nxt << bc; bc += 32; ip += 4; nxt = ((const GzU32u *)(src + ip))->v; } while (0)
 #define G2_TAKE(n_) do { bb >>= (n_); bc -= (n_); } while (0)
 #define G2_EMIT(t_) do { tout[ntok++] = (t_); } while (0)
 #define G2_FLUSH_LIT() do { if (litn) { G2_EMIT(litacc | ((uint32_t)litn << 24)); litacc = 0; litn = 0; } } while (0)
@@ -438,38 +458,51 @@ k_gz_tokens_lanes(int n_members, const GzBlock *__restrict__ blk, const uint8_t 
     for (;;) {
         if (__ballot(state != S_DONE) == 0ull) break;
         if (state != S_DONE) {
-            if (bc <= 32) { bb |= (uint64_t)((const GzU32u *)(src + ip))->v << bc; bc += 32; ip += 4; }
+            if (bc <= 32) G2_REFILL();
             if (ip > clen + 12) G2_FAIL(GZ_E_INPUT);
         }
         if (state == S_DECODE) {
-            uint32_t e = S[GZ2_LIT + (uint32_t)(bb & ((1u << GZ_TB) - 1u))];
-            if (((e >> 5) & 7u) == GZ_K_LONG) {
+            const uint32_t e = TL[((uint32_t)bb & ((1u << GZ2_TB) - 1u)) * 64];
+            int cl = (int)(e & 15u), xb = 0, val = (int)(e >> 6);
+            uint32_t kind = (e >> 4) & 3u;
+            bool bad = e == 0u;
+            if (kind == GZ2_LEN) {                           /* length symbol -> base, extra bits (RFC 1951 3.2.5) */
+                if (val < 8) val += 3;
+                else if (val == 28) val = 258;
+                else { xb = (val - 4) >> 2; val = 3 + ((4 + (val & 3)) << xb); }
+            } else if (kind == GZ2_LONG) {
                 const uint16_t *cfo = (const uint16_t *)(S + GZ2_CNT);
-                e = gz_decode_long(bb, cfo, cfo + 16, cfo + 32, (const uint16_t *)(S + GZ2_LSYM), false);
+                const uint32_t e2 = gz_decode_long(bb, cfo, cfo + 16, cfo + 32, (const uint16_t *)(S + GZ2_LSYM), false);
+                const uint32_t k2 = (e2 >> 5) & 7u;
+                bad = k2 == 0u;
+                cl = (int)(e2 & 31u); xb = (int)((e2 >> 8) & 31u); val = (int)(e2 >> 16);
+                kind = k2 == GZ_K_LIT ? GZ2_LIT : k2 == GZ_K_EOB ? GZ2_EOB : GZ2_LEN;
             }
-            const uint32_t kind = (e >> 5) & 7u;
-            if (kind == 0u) G2_FAIL(GZ_E_SYMBOL);
+            if (bad) G2_FAIL(GZ_E_SYMBOL);
             else {
-                G2_TAKE((int)(e & 31u));
-                if (kind == GZ_K_LIT) {
+                G2_TAKE(cl);
+                if (kind == GZ2_LIT) {
                     if (outpos >= ulen) G2_FAIL(GZ_E_DIST);
-                    else { litacc |= ((e >> 16) & 0xffu) << (8 * litn); litn++; outpos++; if (litn == 3) G2_FLUSH_LIT(); }
-                } else if (kind == GZ_K_EOB) state = bfinal ? S_DONE : S_HDR;
+                    else { litacc |= ((uint32_t)val & 0xffu) << (8 * litn); litn++; outpos++; if (litn == 3) G2_FLUSH_LIT(); }
+                } else if (kind == GZ2_EOB) state = bfinal ? S_DONE : S_HDR;
                 else {
-                    const int xb = (int)((e >> 8) & 31u);
-                    const int len = (int)(e >> 16) + (int)(bb & ((1u << xb) - 1u));
+                    const int len = val + (int)(bb & ((1u << xb) - 1u));
                     G2_TAKE(xb);
-                    if (bc <= 32) { bb |= (uint64_t)((const GzU32u *)(src + ip))->v << bc; bc += 32; ip += 4; }
-                    uint32_t d = S[GZ2_DST + (uint32_t)(bb & ((1u << GZ_DB) - 1u))];
-                    if (((d >> 5) & 7u) == GZ_K_LONG) {
+                    if (bc <= 32) G2_REFILL();
+                    const uint32_t d = TD[((uint32_t)bb & ((1u << GZ2_DB) - 1u)) * 64];
+                    int dl = (int)(d & 15u), dxb = 0, dv = (int)(d >> 6);
+                    bool dbad = ((d >> 4) & 3u) != GZ2_LEN;
+                    if (((d >> 4) & 3u) == GZ2_LONG) {
                         const uint16_t *cfo = (const uint16_t *)(S + GZ2_CNT) + 48;
-                        d = gz_decode_long(bb, cfo, cfo + 16, cfo + 32, (const uint16_t *)(S + GZ2_DSYM), true);
-                    }
-                    if (((d >> 5) & 7u) != GZ_K_LEN) G2_FAIL(GZ_E_SYMBOL);
+                        const uint32_t d2 = gz_decode_long(bb, cfo, cfo + 16, cfo + 32, (const uint16_t *)(S + GZ2_DSYM), true);
+                        dbad = ((d2 >> 5) & 7u) != GZ_K_LEN;
+                        dl = (int)(d2 & 31u); dxb = (int)((d2 >> 8) & 31u); dv = (int)(d2 >> 16);
+                    } else if (dv < 4) dv += 1;
+                    else { dxb = (dv - 2) >> 1; dv = 1 + ((2 + (dv & 1)) << dxb); }
+                    if (dbad) G2_FAIL(GZ_E_SYMBOL);
                     else {
-                        G2_TAKE((int)(d & 31u));
-                        const int dxb = (int)((d >> 8) & 31u);
-                        const int dist = (int)(d >> 16) + (int)(bb & ((1u << dxb) - 1u));
+                        G2_TAKE(dl);
+                        const int dist = dv + (int)(bb & ((1u << dxb) - 1u));
                         G2_TAKE(dxb);
                         if (dist > outpos || outpos + len > ulen) G2_FAIL(GZ_E_DIST);
                         else { G2_FLUSH_LIT(); G2_EMIT(GZ_TOK_MATCH(len, dist)); outpos += len; }
@@ -490,7 +523,7 @@ k_gz_tokens_lanes(int n_members, const GzBlock *__restrict__ blk, const uint8_t 
             G2_TAKE(3);
             if (bt == 0) {
                 G2_TAKE(bc & 7);
-                if (bc < 32) { bb |= (uint64_t)((const GzU32u *)(src + ip))->v << bc; bc += 32; ip += 4; }
+                if (bc < 32) G2_REFILL();
                 const uint32_t ln = (uint32_t)(bb & 0xffffu), nl = (uint32_t)((bb >> 16) & 0xffffu);
                 G2_TAKE(32);
                 if ((ln ^ nl) != 0xffffu) G2_FAIL(GZ_E_BTYPE);
@@ -589,11 +622,12 @@ k_gz_tokens_lanes(int n_members, const GzBlock *__restrict__ blk, const uint8_t 
                 uint32_t *SL = scratch + (size_t)mL * GZ2_WORDS;
                 const int nl = READLANE(hlit, L), nd = READLANE(hdist, L);
                 const uint8_t *lensL = (const uint8_t *)(SL + GZ2_LENS);
-                unsigned e = gz2_build(lensL, nl, GZ_TB, SL + GZ2_LIT, (uint16_t *)(SL + GZ2_LSYM), (uint16_t *)(SL + GZ2_CNT), false, lane);
-                e |= gz2_build(lensL + nl, nd, GZ_DB, SL + GZ2_DST, (uint16_t *)(SL + GZ2_DSYM), (uint16_t *)(SL + GZ2_CNT) + 48, true, lane);
+                unsigned e = gz2_build(lensL, nl, GZ2_TB, T + L, (uint16_t *)(SL + GZ2_LSYM), (uint16_t *)(SL + GZ2_CNT), false, lane);
+                e |= gz2_build(lensL + nl, nd, GZ2_DB, T + (1 << GZ2_TB) * 64 + L, (uint16_t *)(SL + GZ2_DSYM), (uint16_t *)(SL + GZ2_CNT) + 48, true, lane);
                 if (lane == L) { if (e) G2_FAIL(e); else state = S_DECODE; }
             }
             KC2_FENCE_WG();                                  /* the tables are in memory before anybody looks something up */
+            WAVE_SYNC();
         }
     }
     if (valid) {
@@ -602,6 +636,7 @@ k_gz_tokens_lanes(int n_members, const GzBlock *__restrict__ blk, const uint8_t 
         if (!err && (int64_t)ip * 8 - bc > (int64_t)clen * 8) err |= GZ_E_INPUT;
         ntok_out[mi] = (uint32_t)ntok; status[mi] = err;
     }
+#undef G2_REFILL
 #undef G2_TAKE
 #undef G2_EMIT
 #undef G2_FLUSH_LIT
