@@ -21,6 +21,7 @@ struct crumble_gz {
     void *pinned = nullptr;                     /* 4 KiB page-locked: sizes and totals read back */
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float ms_h2d = 0, ms_kernels = 0, ms_d2h = 0;
+    int opt_lpw = 0;                            /* walking lanes per wave of k_gz_tokens_lanes: 0 = by the number of members, 8 / 16 / 64 */
     int ncu = 256;                              /* compute units (hipGetDeviceProperties once: the call costs milliseconds) */
     int64_t last_in = 0, last_out = 0;
 };
@@ -64,7 +65,8 @@ extern "C" crumble_gz *crumble_gz_create(int device, int *err)
          * k_gz_tokens_lanes of a run), which belongs to the set-up and not to the first file's first members */
         hipStream_t st = g->stream;
         const uint32_t *tb = g->d_tabs.as<uint32_t>();
-        hipLaunchKernelGGL(k_gz_tokens_lanes, dim3(1), dim3(64), 0, st, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL(k_gz_tokens_lanes<8>, dim3(1), dim3(64), 0, st, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL(k_gz_tokens_lanes<16>, dim3(1), dim3(64), 0, st, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
         hipLaunchKernelGGL(k_gz_tokens, dim3(1), dim3(GZ_WAVES * 64), 0, st, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
         hipLaunchKernelGGL(k_gz_resolve, dim3(1), dim3(GZ_RT), 0, st, 0, nullptr, nullptr, nullptr, nullptr, nullptr, tb, tb + 256, nullptr, 0);
         hipLaunchKernelGGL(k_gz_deflate, dim3(1), dim3(GZ_DT), 0, st, 0, nullptr, (int64_t)0, 1, nullptr, nullptr, nullptr, nullptr, tb, tb + 256);
@@ -166,9 +168,12 @@ static int gz_inflate_impl(crumble_gz *g, const uint8_t *comp, int64_t comp_len,
         /* the walk: a wave per member while they all fit the chip at once (sixteen per CU), a lane per member beyond that */
         const bool lanes = g->opt_lanes < 0 ? n > (int64_t)16 * ncu : g->opt_lanes != 0;
         if (lanes) {
-            if ((e = g->d_scratch.reserve((size_t)((n + 63) / 64 * 64) * GZ2_WORDS * 4))) return e;
-            CRUMBLE_LAUNCH(k_gz_tokens_lanes, (unsigned)((n + 63) / 64), 64, st, (int)n, g->d_blk.as<GzBlock>(), g->d_comp.as<uint8_t>(),
-                           g->d_tok.as<uint32_t>(), g->d_tokoff.as<int64_t>(), g->d_ntok.as<uint32_t>(), g->d_status.as<uint32_t>(), g->d_scratch.as<uint32_t>());
+            /* walking lanes per wave: eight while that keeps every member of the round in flight (eight waves per CU), sixteen beyond */
+            const int lpw = g->opt_lpw ? g->opt_lpw : n <= (int64_t)64 * ncu ? 8 : 16;
+#define GZ_LANES_LAUNCH(LPW_) CRUMBLE_LAUNCH(k_gz_tokens_lanes<LPW_>, (unsigned)((n + LPW_ - 1) / LPW_), 64, st, (int)n, g->d_blk.as<GzBlock>(), g->d_comp.as<uint8_t>(), \
+                           g->d_tok.as<uint32_t>(), g->d_tokoff.as<int64_t>(), g->d_ntok.as<uint32_t>(), g->d_status.as<uint32_t>())
+            if (lpw == 8) GZ_LANES_LAUNCH(8); else if (lpw == 16) GZ_LANES_LAUNCH(16); else GZ_LANES_LAUNCH(64);
+#undef GZ_LANES_LAUNCH
         } else
         CRUMBLE_LAUNCH(k_gz_tokens, (unsigned)((n + GZ_WAVES - 1) / GZ_WAVES), GZ_WAVES * 64, st, (int)n, g->d_blk.as<GzBlock>(),
                        g->d_comp.as<uint8_t>(), g->d_tok.as<uint32_t>(), g->d_tokoff.as<int64_t>(), g->d_ntok.as<uint32_t>(), g->d_status.as<uint32_t>());
@@ -269,6 +274,12 @@ extern "C" int crumble_gz_set_option(crumble_gz *g, const char *name, const char
     if (!strcmp(name, "tokens")) {
         if (!strcmp(value, "auto")) g->opt_lanes = -1; else if (!strcmp(value, "wave")) g->opt_lanes = 0; else if (!strcmp(value, "lane")) g->opt_lanes = 1;
         else return CRUMBLE_EINVAL;
+        return CRUMBLE_OK;
+    }
+    if (!strcmp(name, "lanes_per_wave")) {
+        const int v = !strcmp(value, "auto") ? 0 : atoi(value);
+        if (v != 0 && v != 8 && v != 16 && v != 64) return CRUMBLE_EINVAL;
+        g->opt_lpw = v;
         return CRUMBLE_OK;
     }
     return CRUMBLE_EINVAL;

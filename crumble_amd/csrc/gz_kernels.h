@@ -340,22 +340,22 @@ k_gz_tokens(int n_members, const GzBlock *__restrict__ blk, const uint8_t *__res
 
 /* ---- k_gz_tokens_lanes: a LANE per member --------------------------------------------------------------------------
  * The wave-per-member walk above keeps one lane of sixty-four busy; with thousands of members in a call the other way
- * round pays: every lane walks its own member (bit buffer, position and state in its registers), the 64 walks advance in
- * lockstep one symbol per loop iteration whatever each lane's symbol is (literal, match, a header field).  The primary
- * decode tables of the 64 members live in LDS as 16-bit entries, interleaved by lane (entry j of lane L at half-word
- * j * 64 + L: two lanes per bank at most whatever they look up): 2^9 literal/length entries and 2^7 distance entries per
- * lane, 80 KiB per wave.  Codes longer than that (rare symbols by construction) are decoded the canonical way from a small
- * per-member area in global memory, where the code lengths of a dynamic header also wait for the table fill.  The next
- * input word is always in flight one refill ahead.  A lane that reaches a block header reads its code lengths one symbol
- * per iteration like everybody else's symbols; the table fill is done for one lane at a time by the whole wave.  Same
- * tokens, same status words as k_gz_tokens. */
+ * round pays: a lane walks its own member (bit buffer, position and state in its registers), the walks of a wave advance
+ * in lockstep one step per loop iteration whatever each lane's step is (a literal, a match, a header field).
+ *
+ * What bounds such a walk is instruction issue, not memory: a wave alone on its SIMD issues an instruction every four to
+ * five cycles, and every iteration executes every path that ANY of its lanes takes.  So (1) only LPW lanes of a wave walk
+ * (8 or 16: eight or four waves per CU instead of one, fewer lanes to diverge in each), (2) an iteration takes up to two
+ * more literals after its first symbol, (3) nothing on a path goes to global memory except the input word (always loaded
+ * one refill ahead) and the tokens: the decode tables of a member live in LDS as 16-bit entries interleaved by lane
+ * (entry j of lane L at half-word j * LPW + L) -- 2^9 literal/length and 2^7 distance entries, behind them the canonical
+ * decoder's counts / first codes / offsets and sorted symbols for the codes longer than that, and the code lengths of a
+ * dynamic header (zeroed when the header starts, so that the zero runs, most of a header, cost no stores): 2432 bytes per
+ * member.  A lane that reaches a block header reads its code lengths one symbol per iteration like everybody else's
+ * symbols; the table fill is done for one lane at a time by the whole wave.  Same tokens, same status words as
+ * k_gz_tokens. */
 #define GZ2_TB       9             /* bits of the literal/length look-up in LDS */
 #define GZ2_DB       7             /* of the distance look-up */
-#define GZ2_WORDS    288           /* scratch words per member (global memory) */
-#define GZ2_LSYM     0             /* u16[288] literal/length symbols in canonical order */
-#define GZ2_DSYM     144           /* u16[32] */
-#define GZ2_CNT      160           /* u16[6][16]: lcnt lfirst loffs dcnt dfirst doffs */
-#define GZ2_LENS     208           /* u8[320] code lengths as read */
 /* 16-bit entry: code length (bits 0-3; 0: not a code), kind (bits 4-5), value (bits 6-15: the literal, or the index of the
  * length / distance symbol -- base and extra bits follow from it by arithmetic, RFC 1951 3.2.5) */
 #define GZ2_LIT      0u
@@ -364,16 +364,25 @@ k_gz_tokens(int n_members, const GzBlock *__restrict__ blk, const uint8_t *__res
 #define GZ2_LONG     3u
 #define GZ2_E(len_, kind_, val_) ((uint16_t)((uint32_t)(len_) | ((uint32_t)(kind_) << 4) | ((uint32_t)(val_) << 6)))
 
-/* the decode table of one member's block, by the whole wave (uniform arguments): lens[0, n) -> tab (LDS, stride 64
- * half-words), sym, cnt / first / offs (global) */
-__device__ __forceinline__ unsigned gz2_build(const uint8_t *lens, int n, int tb, uint16_t *tab, uint16_t *sym, uint16_t *cfo, bool is_dist, int lane)
+__device__ __forceinline__ uint32_t gz_brev15(uint32_t v)
+{   /* the low fifteen bits, first bit of the stream on top */
+#ifdef CRUMBLE_EMU
+    return gz_bitrev(v & 0x7fffu, 15);
+#else
+    return __builtin_bitreverse32(v) >> 17;
+#endif
+}
+
+/* the decode table of one member's block, by the whole wave (uniform arguments): n code lengths at lens[0], lens[st], ..
+ * -> tab, sym, cnt / first / offs (all LDS, stride st) */
+__device__ __forceinline__ unsigned gz2_build(const uint8_t *lens, int n, int tb, uint16_t *tab, uint16_t *sym, uint16_t *cfo, bool is_dist, int lane, int st)
 {
-    for (int i = lane; i < (1 << tb); i += 64) tab[i * 64] = 0;
+    for (int i = lane; i < (1 << tb); i += 64) tab[i * st] = 0;
     int cnt[16];
     #pragma unroll
     for (int q = 0; q < 16; q++) cnt[q] = 0;
     for (int i0 = 0; i0 < n; i0 += 64) {
-        const int l = i0 + lane < n ? lens[i0 + lane] : 0;
+        const int l = i0 + lane < n ? lens[(i0 + lane) * st] : 0;
         #pragma unroll
         for (int q = 1; q < 16; q++) cnt[q] += __popcll(__ballot(l == q));
     }
@@ -392,14 +401,14 @@ __device__ __forceinline__ unsigned gz2_build(const uint8_t *lens, int n, int tb
         int c = 0, f = 0, of = 0;
         #pragma unroll
         for (int q = 0; q < 16; q++) if (lane == q) { c = cnt[q]; f = first[q]; of = offs[q]; }
-        cfo[lane] = (uint16_t)c; cfo[16 + lane] = (uint16_t)f; cfo[32 + lane] = (uint16_t)of;
+        cfo[lane * st] = (uint16_t)c; cfo[(16 + lane) * st] = (uint16_t)f; cfo[(32 + lane) * st] = (uint16_t)of;
     }
     WAVE_SYNC();                                             /* (the cleared entries are in LDS before the codes go in) */
     int seen[16];
     #pragma unroll
     for (int q = 0; q < 16; q++) seen[q] = 0;
     for (int i0 = 0; i0 < n; i0 += 64) {
-        const int s = i0 + lane, l = s < n ? lens[s] : 0;
+        const int s = i0 + lane, l = s < n ? lens[s * st] : 0;
         int rank = 0, f = 0, of = 0;
         #pragma unroll
         for (int q = 1; q < 16; q++) {
@@ -409,34 +418,51 @@ __device__ __forceinline__ unsigned gz2_build(const uint8_t *lens, int n, int tb
         }
         if (l) {
             const uint32_t rev = gz_bitrev((uint32_t)(f + rank), l);
-            sym[of + rank] = (uint16_t)s;
+            sym[(of + rank) * st] = (uint16_t)s;
             if (l <= tb) {
                 uint16_t e;
                 if (is_dist) e = s > 29 ? (uint16_t)0 : GZ2_E(l, GZ2_LEN, s);
                 else e = s < 256 ? GZ2_E(l, GZ2_LIT, s) : s == 256 ? GZ2_E(l, GZ2_EOB, 0) : s > 285 ? (uint16_t)0 : GZ2_E(l, GZ2_LEN, s - 257);
-                for (uint32_t j = rev; j < (1u << tb); j += 1u << l) tab[j * 64] = e;
-            } else tab[(rev & ((1u << tb) - 1u)) * 64] = GZ2_E(0, GZ2_LONG, 0);
+                for (uint32_t j = rev; j < (1u << tb); j += 1u << l) tab[j * st] = e;
+            } else tab[(rev & ((1u << tb) - 1u)) * st] = GZ2_E(0, GZ2_LONG, 0);
         }
     }
     return 0;
 }
 
+/* a code longer than the look-up's bits, against the canonical first codes of the lengths tb + 1 .. 15: the symbol (its
+ * length in *cl), or -1 */
+__device__ __forceinline__ int gz2_long(uint64_t bb, const uint16_t *cfo, const uint16_t *sym, int tb, int st, int *cl)
+{
+    const uint32_t v = gz_brev15((uint32_t)bb);
+    int s = -1;
+    for (int l = tb + 1; l <= 15; l++) {
+        const uint32_t c = v >> (15 - l), n = cfo[l * st], f = cfo[(16 + l) * st];
+        if (s < 0 && c - f < n) { s = (int)sym[(cfo[(32 + l) * st] + (c - f)) * st]; *cl = l; }
+    }
+    return s;
+}
+
+template <int LPW>
 __global__ void __launch_bounds__(64)
 k_gz_tokens_lanes(int n_members, const GzBlock *__restrict__ blk, const uint8_t *__restrict__ comp, uint32_t *__restrict__ gtok,
-                  const int64_t *__restrict__ tok_off, uint32_t *__restrict__ ntok_out, uint32_t *__restrict__ status,
-                  uint32_t *__restrict__ scratch)
+                  const int64_t *__restrict__ tok_off, uint32_t *__restrict__ ntok_out, uint32_t *__restrict__ status)
 {
-    __shared__ uint16_t T[((1 << GZ2_TB) + (1 << GZ2_DB)) * 64];
+    __shared__ uint16_t TLs[(1 << GZ2_TB) * LPW], TDs[(1 << GZ2_DB) * LPW];
+    __shared__ uint16_t SYs[320 * LPW];                       /* literal/length symbols in canonical order [288], distance symbols [32] */
+    __shared__ uint16_t CFs[96 * LPW];                        /* lcnt lfirst loffs dcnt dfirst doffs, sixteen each */
+    __shared__ uint8_t LNs[320 * LPW];                        /* code lengths as read */
     const int lane = threadIdx.x & 63;
-    const int mi = (int)blockIdx.x * 64 + lane;
-    const bool valid = mi < n_members;
+    const int mi = (int)blockIdx.x * LPW + lane;
+    const bool valid = lane < LPW && mi < n_members;
+    const int ml = valid ? lane : 0;                          /* (the idle lanes' addresses stay inside the arrays) */
     GzBlock m;
     m.coff = 0; m.uoff = 0; m.clen = 0; m.ulen = 0; m.crc = 0; m.pad_ = 0;
     if (valid) m = blk[mi];
     const uint8_t *src = comp + m.coff;
-    uint32_t *S = scratch + (size_t)(valid ? mi : 0) * GZ2_WORDS;
     uint32_t *tout = gtok + (valid ? tok_off[mi] : 0);
-    const uint16_t *TL = T + lane, *TD = T + (1 << GZ2_TB) * 64 + lane;
+    const uint16_t *TL = TLs + ml, *TD = TDs + ml, *SY = SYs + ml, *CF = CFs + ml;
+    uint8_t *lens = LNs + ml;
     enum { S_HDR = 0, S_CLEN = 1, S_LENS = 2, S_BUILD = 3, S_DECODE = 4, S_STORED = 5, S_DONE = 6 };
     int state = valid ? S_HDR : S_DONE;
     uint64_t bb = 0; int bc = 0, ip = 0;
@@ -446,7 +472,6 @@ k_gz_tokens_lanes(int n_members, const GzBlock *__restrict__ blk, const uint8_t 
     int outpos = 0;
     unsigned err = 0;
     const int ulen = (int)m.ulen, clen = (int)m.clen;
-    uint8_t *lens = (uint8_t *)(S + GZ2_LENS);
     /* the word behind the bit buffer, loaded one refill ahead (the buffer behind the last member is padded: GZ_IN_PAD) */
     uint32_t nxt = valid ? ((const GzU32u *)src)->v : 0u;
 
@@ -462,21 +487,20 @@ k_gz_tokens_lanes(int n_members, const GzBlock *__restrict__ blk, const uint8_t 
             if (ip > clen + 12) G2_FAIL(GZ_E_INPUT);
         }
         if (state == S_DECODE) {
-            const uint32_t e = TL[((uint32_t)bb & ((1u << GZ2_TB) - 1u)) * 64];
+            const uint32_t e = TL[((uint32_t)bb & ((1u << GZ2_TB) - 1u)) * LPW];
             int cl = (int)(e & 15u), xb = 0, val = (int)(e >> 6);
             uint32_t kind = (e >> 4) & 3u;
             bool bad = e == 0u;
+            if (kind == GZ2_LONG) {
+                const int sy = gz2_long(bb, CF, SY, GZ2_TB, LPW, &cl);
+                bad = sy < 0 || sy > 285;
+                kind = sy < 256 ? GZ2_LIT : sy == 256 ? GZ2_EOB : GZ2_LEN;
+                val = sy < 256 ? sy : sy - 257;
+            }
             if (kind == GZ2_LEN) {                           /* length symbol -> base, extra bits (RFC 1951 3.2.5) */
                 if (val < 8) val += 3;
                 else if (val == 28) val = 258;
                 else { xb = (val - 4) >> 2; val = 3 + ((4 + (val & 3)) << xb); }
-            } else if (kind == GZ2_LONG) {
-                const uint16_t *cfo = (const uint16_t *)(S + GZ2_CNT);
-                const uint32_t e2 = gz_decode_long(bb, cfo, cfo + 16, cfo + 32, (const uint16_t *)(S + GZ2_LSYM), false);
-                const uint32_t k2 = (e2 >> 5) & 7u;
-                bad = k2 == 0u;
-                cl = (int)(e2 & 31u); xb = (int)((e2 >> 8) & 31u); val = (int)(e2 >> 16);
-                kind = k2 == GZ_K_LIT ? GZ2_LIT : k2 == GZ_K_EOB ? GZ2_EOB : GZ2_LEN;
             }
             if (bad) G2_FAIL(GZ_E_SYMBOL);
             else {
@@ -489,15 +513,14 @@ k_gz_tokens_lanes(int n_members, const GzBlock *__restrict__ blk, const uint8_t 
                     const int len = val + (int)(bb & ((1u << xb) - 1u));
                     G2_TAKE(xb);
                     if (bc <= 32) G2_REFILL();
-                    const uint32_t d = TD[((uint32_t)bb & ((1u << GZ2_DB) - 1u)) * 64];
+                    const uint32_t d = TD[((uint32_t)bb & ((1u << GZ2_DB) - 1u)) * LPW];
                     int dl = (int)(d & 15u), dxb = 0, dv = (int)(d >> 6);
                     bool dbad = ((d >> 4) & 3u) != GZ2_LEN;
                     if (((d >> 4) & 3u) == GZ2_LONG) {
-                        const uint16_t *cfo = (const uint16_t *)(S + GZ2_CNT) + 48;
-                        const uint32_t d2 = gz_decode_long(bb, cfo, cfo + 16, cfo + 32, (const uint16_t *)(S + GZ2_DSYM), true);
-                        dbad = ((d2 >> 5) & 7u) != GZ_K_LEN;
-                        dl = (int)(d2 & 31u); dxb = (int)((d2 >> 8) & 31u); dv = (int)(d2 >> 16);
-                    } else if (dv < 4) dv += 1;
+                        dv = gz2_long(bb, CF + 48 * LPW, SY + 288 * LPW, GZ2_DB, LPW, &dl);
+                        dbad = dv < 0 || dv > 29;
+                    }
+                    if (dv < 4) dv += 1;
                     else { dxb = (dv - 2) >> 1; dv = 1 + ((2 + (dv & 1)) << dxb); }
                     if (dbad) G2_FAIL(GZ_E_SYMBOL);
                     else {
@@ -506,6 +529,20 @@ k_gz_tokens_lanes(int n_members, const GzBlock *__restrict__ blk, const uint8_t 
                         G2_TAKE(dxb);
                         if (dist > outpos || outpos + len > ulen) G2_FAIL(GZ_E_DIST);
                         else { G2_FLUSH_LIT(); G2_EMIT(GZ_TOK_MATCH(len, dist)); outpos += len; }
+                    }
+                }
+            }
+            /* up to two more symbols while they are literals whose bits are all in the buffer (anything else waits for the
+             * next iteration's full path) */
+            #pragma unroll
+            for (int r = 0; r < 2; r++) {
+                if (state == S_DECODE) {
+                    const uint32_t e2 = TL[((uint32_t)bb & ((1u << GZ2_TB) - 1u)) * LPW];
+                    const int c2 = (int)(e2 & 15u);
+                    if ((e2 & 0x30u) == (GZ2_LIT << 4) && c2 != 0 && c2 <= bc && outpos < ulen) {
+                        G2_TAKE(c2);
+                        litacc |= (e2 >> 6) << (8 * litn); litn++; outpos++;
+                        if (litn == 3) G2_FLUSH_LIT();
                     }
                 }
             }
@@ -529,15 +566,18 @@ k_gz_tokens_lanes(int n_members, const GzBlock *__restrict__ blk, const uint8_t 
                 if ((ln ^ nl) != 0xffffu) G2_FAIL(GZ_E_BTYPE);
                 else { stored_left = (int)ln; state = S_STORED; }
             } else if (bt == 1) {
-                for (int sy = 0; sy < 288; sy++) lens[sy] = (uint8_t)(sy < 144 ? 8 : sy < 256 ? 9 : sy < 280 ? 7 : 8);
-                for (int sy = 0; sy < 30; sy++) lens[288 + sy] = 5;
+                for (int sy = 0; sy < 288; sy++) lens[sy * LPW] = (uint8_t)(sy < 144 ? 8 : sy < 256 ? 9 : sy < 280 ? 7 : 8);
+                for (int sy = 0; sy < 30; sy++) lens[(288 + sy) * LPW] = 5;
                 hlit = 288; hdist = 30;
                 state = S_BUILD;
             } else if (bt == 2) {
                 hlit = (int)(bb & 31u) + 257; hdist = (int)((bb >> 5) & 31u) + 1; hclen = (int)((bb >> 10) & 15u) + 4;
                 G2_TAKE(14);
                 if (hlit > 286 || hdist > 30) G2_FAIL(GZ_E_CODES);
-                else { clpack = 0; k = 0; state = S_CLEN; }
+                else {
+                    clpack = 0; k = 0; state = S_CLEN;
+                    for (int sy = 0; sy < 316; sy++) lens[sy * LPW] = 0;      /* (the zero runs of the header then only move k) */
+                }
             } else G2_FAIL(GZ_E_BTYPE);
         } else if (state == S_CLEN) {
             /* one 3-bit length of the code-length code per iteration, packed by symbol into 57 bits */
@@ -596,38 +636,35 @@ k_gz_tokens_lanes(int n_members, const GzBlock *__restrict__ blk, const uint8_t 
                 offs += cn;
             }
             if (sy < 0) G2_FAIL(GZ_E_SYMBOL);
-            else if (sy < 16) { lens[k++] = (uint8_t)sy; prev = sy; }
+            else if (sy < 16) { lens[k * LPW] = (uint8_t)sy; k++; prev = sy; }
             else {
-                int rep, val = 0;
+                int rep;
                 bool bad = false;
-                if (sy == 16) { bad = k == 0; val = prev; rep = 3 + (int)(bb & 3u); G2_TAKE(2); }
+                if (sy == 16) { bad = k == 0; rep = 3 + (int)(bb & 3u); G2_TAKE(2); }
                 else if (sy == 17) { rep = 3 + (int)(bb & 7u); G2_TAKE(3); }
                 else { rep = 11 + (int)(bb & 127u); G2_TAKE(7); }
                 if (bad || k + rep > need) G2_FAIL(GZ_E_CODES);
-                else { for (int r = 0; r < rep; r++) lens[k++] = (uint8_t)val; if (sy != 16) prev = 0; }
+                else if (sy == 16) { for (int r = 0; r < rep; r++) lens[(k + r) * LPW] = (uint8_t)prev; k += rep; }
+                else { k += rep; prev = 0; }                 /* (zeros are there already) */
             }
             if (state == S_LENS && k >= need) {
-                if (lens[256] == 0) G2_FAIL(GZ_E_CODES);
+                if (lens[256 * LPW] == 0) G2_FAIL(GZ_E_CODES);
                 else state = S_BUILD;
             }
         }
         /* ---- the table fills: one requesting lane at a time, by all sixty-four */
         unsigned long long bm = __ballot(state == S_BUILD);
         if (bm) {
-            KC2_FENCE_WG();                                  /* the lanes' code lengths are in memory */
+            WAVE_SYNC();                                     /* the lanes' code lengths are in LDS */
             while (bm) {
                 const int L = __builtin_ctzll(bm);
                 bm &= bm - 1ull;
-                const int mL = (int)blockIdx.x * 64 + L;
-                uint32_t *SL = scratch + (size_t)mL * GZ2_WORDS;
                 const int nl = READLANE(hlit, L), nd = READLANE(hdist, L);
-                const uint8_t *lensL = (const uint8_t *)(SL + GZ2_LENS);
-                unsigned e = gz2_build(lensL, nl, GZ2_TB, T + L, (uint16_t *)(SL + GZ2_LSYM), (uint16_t *)(SL + GZ2_CNT), false, lane);
-                e |= gz2_build(lensL + nl, nd, GZ2_DB, T + (1 << GZ2_TB) * 64 + L, (uint16_t *)(SL + GZ2_DSYM), (uint16_t *)(SL + GZ2_CNT) + 48, true, lane);
+                unsigned e = gz2_build(LNs + L, nl, GZ2_TB, TLs + L, SYs + L, CFs + L, false, lane, LPW);
+                e |= gz2_build(LNs + L + nl * LPW, nd, GZ2_DB, TDs + L, SYs + L + 288 * LPW, CFs + L + 48 * LPW, true, lane, LPW);
                 if (lane == L) { if (e) G2_FAIL(e); else state = S_DECODE; }
             }
-            KC2_FENCE_WG();                                  /* the tables are in memory before anybody looks something up */
-            WAVE_SYNC();
+            WAVE_SYNC();                                     /* the tables are in LDS before anybody looks something up */
         }
     }
     if (valid) {

@@ -82,7 +82,7 @@ extern "C" int crumble_stream_reserve(crumble_stream *s, int64_t comp_bytes, int
     const size_t tok = (in_round + 64) * 4 > nb * 65536 * 4 ? (in_round + 64) * 4 : nb * 65536 * 4;
     if ((e = s->d_rec[0].reserve(raw)) || (e = s->d_rec[1].reserve(raw)) || (e = g->d_comp.reserve((size_t)comp_bytes + GZ_IN_PAD)) ||
         (e = g->d_blk.reserve(nmem * sizeof(GzBlock))) || (e = g->d_tokoff.reserve((nmem + 1) * 8)) || (e = g->d_tok.reserve(tok)) ||
-        (e = g->d_ntok.reserve(nmem * 4)) || (e = g->d_status.reserve(nmem * 4)) || (e = g->d_scratch.reserve((nmem + 64) * GZ2_WORDS * 4)) ||
+        (e = g->d_ntok.reserve(nmem * 4)) || (e = g->d_status.reserve(nmem * 4)) ||
         (e = g->d_cand.reserve(nb * 65536 * 4)) || (e = g->d_slots.reserve(nb * GZ_SLOT)) || (e = g->d_sizes.reserve(nb * 4)) ||
         (e = g->d_off.reserve((nb + 1) * 8)) || (e = g->d_out.reserve(nb * GZ_SLOT)))
         return e;

@@ -159,19 +159,25 @@ def emu_codec():
     c.close()
 
 
-@pytest.mark.parametrize("tokens", ["wave", "lane"])
+def _walk(codec, tokens):
+    """tokens: wave | lane | lane16 | lane64 (the lane walk with 8 -- its choice for few members --, 16 or 64 walking lanes per wave)"""
+    codec.set_option("tokens", tokens[:4])
+    codec.set_option("lanes_per_wave", tokens[4:] or "auto")
+
+
+@pytest.mark.parametrize("tokens", ["wave", "lane", "lane16", "lane64"])
 def test_emu_inflate_zlib_members(emu_codec, tokens):
     """both walks: a wave per member (k_gz_tokens) and a lane per member (k_gz_tokens_lanes)"""
-    emu_codec.set_option("tokens", tokens)
+    _walk(emu_codec, tokens)
     _inflate_cases(emu_codec, (1, 7, 700, 70000), (0, 1, 6), kinds=("records", "runs"))
-    emu_codec.set_option("tokens", "auto")
+    _walk(emu_codec, "auto")
 
 
-@pytest.mark.parametrize("tokens", ["wave", "lane"])
+@pytest.mark.parametrize("tokens", ["wave", "lane", "lane64"])
 def test_emu_inflate_refuses_corrupt_members(emu_codec, tokens):
-    emu_codec.set_option("tokens", tokens)
+    _walk(emu_codec, tokens)
     _corrupt_cases(emu_codec)
-    emu_codec.set_option("tokens", "auto")
+    _walk(emu_codec, "auto")
 
 
 def test_emu_deflate_round_trip(emu_codec):
@@ -208,19 +214,19 @@ def gpu_codec(product):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tokens", ["wave", "lane"])
+@pytest.mark.parametrize("tokens", ["wave", "lane", "lane16", "lane64"])
 def test_gpu_inflate_zlib_members(gpu_codec, tokens):
-    gpu_codec.set_option("tokens", tokens)
+    _walk(gpu_codec, tokens)
     _inflate_cases(gpu_codec, (1, 7, 700, 70000, 1 << 20), (0, 1, 6, 9))
-    gpu_codec.set_option("tokens", "auto")
+    _walk(gpu_codec, "auto")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tokens", ["wave", "lane"])
+@pytest.mark.parametrize("tokens", ["wave", "lane", "lane16", "lane64"])
 def test_gpu_inflate_refuses_corrupt_members(gpu_codec, tokens):
-    gpu_codec.set_option("tokens", tokens)
+    _walk(gpu_codec, tokens)
     _corrupt_cases(gpu_codec)
-    gpu_codec.set_option("tokens", "auto")
+    _walk(gpu_codec, "auto")
 
 
 @pytest.mark.gpu

@@ -70,10 +70,12 @@ while time.time() - t0 < budget:
         zc = T.bgzf(data, level, blk=blk, strategy=strategy)
     except AssertionError:                                  # (a member that zlib could not fit into 64 KiB: noise at a large block size)
         zc = T.bgzf(data, level, blk=30000, strategy=strategy)
-    for tokens in ("wave", "lane"):
+    for tokens, lpw in (("wave", "auto"), ("lane", str(rng.choice([8, 16, 64])))):
         c.set_option("tokens", tokens)
-        assert c.inflate(zc).tobytes() == data, ("inflate", seed, cases, size, level, strategy, blk, tokens)
+        c.set_option("lanes_per_wave", lpw)
+        assert c.inflate(zc).tobytes() == data, ("inflate", seed, cases, size, level, strategy, blk, tokens, lpw)
     c.set_option("tokens", "auto")
+    c.set_option("lanes_per_wave", "auto")
     cases += 1
     total += size
 c.close()

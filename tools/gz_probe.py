@@ -29,6 +29,8 @@ t_py_inflate = time.time() - t0
 c = gz.GzCodec(0)
 if os.environ.get('GZ_TOKENS'):
     c.set_option('tokens', os.environ['GZ_TOKENS'])
+if os.environ.get('GZ_LPW'):
+    c.set_option('lanes_per_wave', os.environ['GZ_LPW'])
 out = {"bases": int(hb.n_bases), "raw_bytes": int(want.size), "comp_bytes_host": int(comp.size), "host_codec": bamio.codec() if hasattr(bamio, "codec") else "?",
        "host_write_s": round(t_host_deflate, 3), "python_gunzip_s": round(t_py_inflate, 3)}
 for rep in range(3):
