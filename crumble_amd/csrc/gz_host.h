@@ -148,7 +148,7 @@ static int gz_inflate_impl(crumble_gz *g, const uint8_t *comp, int64_t comp_len,
     for (int64_t i0 = 0; i0 < n_blocks; ) {
         /* a round: members [i0, i1) with at most GZ_BATCH_RAW bytes of output */
         /* (a lane per member wants every member of the call in flight at once: its time hardly depends on their number) */
-        const int64_t round_raw = (g->opt_lanes < 0 ? n_blocks - i0 > (int64_t)16 * ncu : g->opt_lanes != 0) ? 8 * GZ_BATCH_RAW : GZ_BATCH_RAW;      /* (2 GiB of records = 8 GiB of token slots at most) */
+        const int64_t round_raw = g->opt_lanes != 0 ? 8 * GZ_BATCH_RAW : GZ_BATCH_RAW;      /* (2 GiB of records = 8 GiB of token slots at most) */
         int64_t i1 = i0, sum = 0;
         while (i1 < n_blocks && (i1 == i0 || sum + (int64_t)blk[i1].ulen <= round_raw)) { sum += blk[i1].ulen; i1++; }
         const int64_t n = i1 - i0;
@@ -165,11 +165,12 @@ static int gz_inflate_impl(crumble_gz *g, const uint8_t *comp, int64_t comp_len,
         HIPCHK(hipMemcpyAsync(g->d_blk.p, blk + i0, (size_t)n * sizeof(GzBlock), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(g->d_tokoff.p, tokoff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
         HIPCHK(hipEventRecord(g->ev[0], st));
-        /* the walk: a wave per member while they all fit the chip at once (sixteen per CU), a lane per member beyond that */
-        const bool lanes = g->opt_lanes < 0 ? n > (int64_t)16 * ncu : g->opt_lanes != 0;
+        /* the walk: a lane per member (measured on MI355X, tools/inflate_sweep.py: 11 ms against the wave walk's 23 for 500 members,
+         * 19 against 108 for 10 000); the wave per member stays as an option (crumble_gz_set_option) */
+        const bool lanes = g->opt_lanes != 0;
         if (lanes) {
-            /* walking lanes per wave: eight while that keeps every member of the round in flight (eight waves per CU), sixteen beyond */
-            const int lpw = g->opt_lpw ? g->opt_lpw : n <= (int64_t)64 * ncu ? 8 : 16;
+            /* walking lanes per wave: eight (eight waves per CU) was the fastest at every size measured, 500 to 32 000 members */
+            const int lpw = g->opt_lpw ? g->opt_lpw : 8;
 #define GZ_LANES_LAUNCH(LPW_) CRUMBLE_LAUNCH(k_gz_tokens_lanes<LPW_>, (unsigned)((n + LPW_ - 1) / LPW_), 64, st, (int)n, g->d_blk.as<GzBlock>(), g->d_comp.as<uint8_t>(), \
                            g->d_tok.as<uint32_t>(), g->d_tokoff.as<int64_t>(), g->d_ntok.as<uint32_t>(), g->d_status.as<uint32_t>())
             if (lpw == 8) GZ_LANES_LAUNCH(8); else if (lpw == 16) GZ_LANES_LAUNCH(16); else GZ_LANES_LAUNCH(64);

@@ -247,7 +247,7 @@ extern "C" int crumble_stream_process(crumble_stream *s, crumble_hip *h, int gro
     const int64_t *ro = s->d_recoff.as<int64_t>() + g.first_read;
     HIPCHK(hipMemsetAsync(s->d_tot.p, 0, sizeof(StTotals), st));
     const int64_t step = n > 65536 ? n / 65536 : 1;
-    if (n) CRUMBLE_LAUNCH(k_st_fields, (unsigned)((n + 255) / 256), 256, st, R, ro, n, s->d_pos.as<int32_t>(), s->d_mapq.as<uint8_t>(), s->d_flag.as<uint16_t>(),
+    if (n) CRUMBLE_LAUNCH(k_st_fields, (unsigned)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512), 256, st, R, ro, n, s->d_pos.as<int32_t>(), s->d_mapq.as<uint8_t>(), s->d_flag.as<uint16_t>(),
                           s->d_lq.as<int32_t>(), s->d_ncg.as<uint16_t>(), s->d_noq.as<uint8_t>(), s->d_tot.as<StTotals>(), s->d_err.as<uint32_t>(), step);
     HIPCHK(hipGetLastError());
     StTotals tot;

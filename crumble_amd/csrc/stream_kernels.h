@@ -180,12 +180,12 @@ k_st_fields(const uint8_t *__restrict__ R, const int64_t *__restrict__ rec_off, 
 {
     __shared__ unsigned hist[256];
     __shared__ unsigned flags;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    __shared__ unsigned long long sums[4][4];                /* per wave: bases, cigar operations, error ppm, error samples */
     unsigned long long nb = 0, nc = 0, ep = 0, ec = 0;
     hist[threadIdx.x] = 0u;
     if (threadIdx.x == 0) flags = 0u;
     __syncthreads();
-    if (i < n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const uint8_t *r = R + rec_off[i];
         const uint32_t lname = r[12], nco = st_u16(r + 16);
         const int32_t ls = (int32_t)st_u32(r + 20);
@@ -193,7 +193,7 @@ k_st_fields(const uint8_t *__restrict__ R, const int64_t *__restrict__ rec_off, 
         const uint8_t *cg = r + 36 + lname, *q = cg + 4 * nco + (ls + 1) / 2;
         const bool absent = ls > 0 && q[0] == 0xff;
         noq[i] = absent ? 1 : 0;
-        nb = (unsigned long long)ls; nc = nco;
+        nb += (unsigned long long)ls; nc += nco;
         /* a CIGAR of more than 65535 operations lives in the CG tag behind a kSmN placeholder (SAMv1 4.2.2): not taken here */
         if (nco == 2u && ls > 0) {
             const uint32_t c0 = st_u32(cg), c1 = st_u32(cg + 4);
@@ -201,21 +201,34 @@ k_st_fields(const uint8_t *__restrict__ R, const int64_t *__restrict__ rec_off, 
         }
         if (i % sample_step == 0) {
             atomicAdd(&hist[r[13]], 1u);
-            if (ls > 0) { ep = err_ppm[absent ? 0 : (q[0] & 127)]; ec = 1ull; }
+            if (ls > 0) { ep += err_ppm[absent ? 0 : (q[0] & 127)]; ec += 1ull; }
         }
     }
-    /* the sums: wave, then one atomic each per wave; the histogram and the flag: one atomic per bin the workgroup touched */
+    /* the sums: wave, workgroup, then one atomic each per workgroup (a few hundred per launch: atomics on one address take
+     * their turns in the L2); the histogram and the flag: one atomic per bin the workgroup touched */
     for (int d = 32; d > 0; d >>= 1) {
         nb += (unsigned long long)__shfl_xor((long long)nb, d); nc += (unsigned long long)__shfl_xor((long long)nc, d);
         ep += (unsigned long long)__shfl_xor((long long)ep, d); ec += (unsigned long long)__shfl_xor((long long)ec, d);
     }
-    if ((threadIdx.x & 63) == 0) {
-        if (nb | nc) { atomicAdd(&tot->n_bases, nb); atomicAdd(&tot->n_cigar, nc); }
-        if (ec) { atomicAdd(&tot->err_ppm, ep); atomicAdd(&tot->err_cnt, ec); }
-    }
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; sums[w][0] = nb; sums[w][1] = nc; sums[w][2] = ep; sums[w][3] = ec; }
     __syncthreads();
+    if (threadIdx.x < 4) {
+        const unsigned long long v = sums[0][threadIdx.x] + sums[1][threadIdx.x] + sums[2][threadIdx.x] + sums[3][threadIdx.x];
+        if (v) atomicAdd(threadIdx.x == 0 ? &tot->n_bases : threadIdx.x == 1 ? &tot->n_cigar : threadIdx.x == 2 ? &tot->err_ppm : &tot->err_cnt, v);
+    }
     if (hist[threadIdx.x]) atomicAdd(&tot->mq_hist[threadIdx.x], hist[threadIdx.x]);
     if (threadIdx.x == 0 && flags) atomicOr(&tot->unsupported, 1u);
+}
+
+/* n bytes by one wave, four per lane and step (both sides at any byte address: the device takes unaligned words), the last
+ * one to three bytes singly */
+struct __attribute__((packed, aligned(1))) StU32u { uint32_t v; };
+__device__ __forceinline__ void st_copy_wave(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int n, int lane)
+{
+    const int n4 = n >> 2;
+    for (int j = lane; j < n4; j += 64) ((StU32u *)dst)[j].v = ((const StU32u *)src)[j].v;
+    const int rest = n & 3;
+    if (lane < rest) dst[4 * n4 + lane] = src[4 * n4 + lane];
 }
 
 /* a wave per read (sixteen reads per wave in turn): CIGAR words, the packed bases into the bases4 layout (read i at byte
@@ -237,9 +250,9 @@ k_st_gather(const uint8_t *__restrict__ R, const int64_t *__restrict__ rec_off, 
         const int64_t so = seq_off[i], co = cig_off[i];
         for (uint32_t j = lane; j < nco; j += 64) cigar[co + j] = st_u32(cg + 4 * j);
         uint8_t *b4 = bases4 + (so >> 1) + i;
-        for (int j = lane; j < (ls + 1) / 2; j += 64) b4[j] = sq[j];
-        const bool absent = noq[i] != 0;
-        for (int j = lane; j < ls; j += 64) quals[so + j] = absent ? 0 : q[j];
+        st_copy_wave(b4, sq, (ls + 1) / 2, lane);
+        if (noq[i] != 0) { for (int j = lane; j < ls; j += 64) quals[so + j] = 0; }
+        else st_copy_wave(quals + so, q, ls, lane);
     }
 }
 
@@ -259,8 +272,7 @@ k_st_scatter(uint8_t *__restrict__ R, const int64_t *__restrict__ rec_off, int64
         const uint32_t lname = r[12], nco = st_u16(r + 16);
         const int32_t ls = (int32_t)st_u32(r + 20);
         uint8_t *q = r + 36 + lname + 4 * nco + (ls + 1) / 2;
-        const uint8_t *o = out + seq_off[i];
-        for (int j = lane; j < ls; j += 64) q[j] = o[j];
+        st_copy_wave(q, out + seq_off[i], ls, lane);
     }
 }
 
