@@ -174,7 +174,7 @@ def codec_kernels(path, device):
         c.close()
 
 
-def file_to_file(ca, synth, refs, batches, preset, device, label, verify_seconds=2.0, codec=None, level="1", codec_probe=False):
+def file_to_file(ca, synth, refs, batches, preset, device, label, verify_seconds=2.0, codec=None, level="1", codec_probe=False, pipeline=None):
     """Metric (ii) of SURVEY.md 8(d): contigs as a BAM file through the crumble-hip driver (BGZF inflate + BAM parse +
     H2D + expansion + kernels + D2H + BGZF deflate).  `value` is over the driver's own clock from the first byte read
     to the last byte written (the figure crumble-hip -v prints: reader, GPU worker and writer threads overlap across
@@ -200,7 +200,9 @@ def file_to_file(ca, synth, refs, batches, preset, device, label, verify_seconds
         else:
             env.pop("CRUMBLE_BAM_LEVEL", None)
         if codec:
-            env["CRUMBLE_HIP_CODEC"] = codec          # gpu (crumble-hip's default: BGZF members inflated / deflated on the device) | host
+            env["CRUMBLE_HIP_CODEC"] = codec          # (host pipeline only) gpu: BGZF members inflated / deflated on the device | host
+        if pipeline:
+            env["CRUMBLE_HIP_PIPELINE"] = pipeline    # device (crumble-hip's default: the records stay in HBM from inflate to deflate) | host
         t0 = time.perf_counter()
         lvl = [f"-{preset}"] if preset else []
         r = subprocess.run([os.path.join(ROOT, "crumble_amd", "crumble-hip"), "-v"] + lvl + [src, dst],
@@ -218,7 +220,11 @@ def file_to_file(ca, synth, refs, batches, preset, device, label, verify_seconds
                "host_threads": _host_threads(), "host_cpus_visible": os.cpu_count(),
                "codec": (re.search(r"BGZF codec: (.*)", r.stderr) or [None, L.crumble_bam_codec().decode()])[1],
                "in_bytes": os.path.getsize(src), "out_bytes": os.path.getsize(dst),
-               "host_stage_s": (re.search(r"bamio: (.*)", r.stderr) or [None, None])[1]}
+               "host_stage_s": (re.search(r"bamio: (.*)", r.stderr) or [None, None])[1],
+               "pipeline": (re.search(r"pipeline: (device) \((.*)\)", r.stderr) or [None, "host", None])[1]}
+        m2 = re.search(r"pipeline: device \(.*GPU stage: (.*)\)", r.stderr)
+        if m2:
+            out["gpu_stage_s"] = m2.group(1)
         if probe:
             out["codec_kernels"] = probe
         if verify_seconds > 0:
@@ -258,17 +264,22 @@ def end_to_end_legs(ca, synth, shard, args, hb_full, label, device):
         batches.append(synth.generate(cfg))
     refs = [(f"chr{t + 1}", max(s_, 4 * 150 + 4096) + 1000) for t, s_ in enumerate(sizes)]
     out = file_to_file(ca, synth, refs, batches, args.preset, device, f"wgs-30x: 24 contigs (GRCh38 lengths x {0.005 * args.scale:g})", codec_probe=True)
-    # crumble-hip's codec policy (CRUMBLE_HIP_CODEC=auto): the host's threads inflate, the device deflates (crumble_gz_deflate) -- the
-    # leg above.  The same file with the host's threads doing both (libdeflate level 1 where the box has it: the legs of rounds 4
-    # and 5), and with every member inflated AND deflated on the device:
-    keys = ("value", "loop_s", "read_parse_s", "gpu_incl_pcie_s", "deflate_write_s", "codec", "out_bytes", "host_stage_s", "error")
-    hc = file_to_file(ca, synth, refs, batches, args.preset, device, "the same, CRUMBLE_HIP_CODEC=host", verify_seconds=0, codec="host")
+    # crumble-hip's default is the device pipeline (CRUMBLE_HIP_PIPELINE=auto: the records stay in HBM from inflate to deflate,
+    # csrc/stream_host.h) -- the leg above.  The same file through the host pipeline (reader / GPU workers / writer threads, the
+    # records parsed and written on the host) with its codec policy (the host's threads inflate, the device deflates: round 6's
+    # first figure), with the host's threads doing both (libdeflate level 1 where the box has it: the legs of rounds 4 and 5), and
+    # with every member inflated AND deflated on the device:
+    keys = ("value", "loop_s", "read_parse_s", "gpu_incl_pcie_s", "deflate_write_s", "codec", "pipeline", "gpu_stage_s", "out_bytes", "host_stage_s", "error")
+    hp = file_to_file(ca, synth, refs, batches, args.preset, device, "the same, CRUMBLE_HIP_PIPELINE=host", verify_seconds=0, pipeline="host")
+    out["host_pipeline"] = {k: hp.get(k) for k in keys if k in hp}
+    hc = file_to_file(ca, synth, refs, batches, args.preset, device, "the same, host pipeline, CRUMBLE_HIP_CODEC=host", verify_seconds=0, codec="host", pipeline="host")
     out["host_codec"] = {k: hc.get(k) for k in keys if k in hc}
-    dv = file_to_file(ca, synth, refs, batches, args.preset, device, "the same, CRUMBLE_HIP_CODEC=gpu", verify_seconds=0, codec="gpu")
+    dv = file_to_file(ca, synth, refs, batches, args.preset, device, "the same, host pipeline, CRUMBLE_HIP_CODEC=gpu", verify_seconds=0, codec="gpu", pipeline="host")
     out["device_codec"] = {k: dv.get(k) for k in keys if k in dv}
-    # ... and at the DEFAULT compression level (what htslib and reference crumble write: zlib 6): auto against the host's threads
+    # ... and at the DEFAULT compression level (what htslib and reference crumble write: zlib 6): the default driver against the
+    # host pipeline with the host's threads as the codec
     da = file_to_file(ca, synth, refs, batches, args.preset, device, "the same at the default level, auto", verify_seconds=0, level=None)
-    dh = file_to_file(ca, synth, refs, batches, args.preset, device, "the same at the default level, host", verify_seconds=0, codec="host", level=None)
+    dh = file_to_file(ca, synth, refs, batches, args.preset, device, "the same at the default level, host", verify_seconds=0, codec="host", level=None, pipeline="host")
     out["default_level"] = {"auto": {k: da.get(k) for k in keys if k in da}, "host_codec": {k: dh.get(k) for k in keys if k in dh}}
     cfg_e = synth.config("chr20", scale=0.25 * args.scale)
     cfg_e.seed += 77

@@ -110,7 +110,7 @@ typedef char gz_block_layout_check[sizeof(crumble_bam_block) == sizeof(crumble_g
  * output buffers).  One device, no tag filters, no -b: everything else takes the host pipeline below.  Returns 0 done,
  * 1 / 2 failed (message printed), -1 "not for this file": the caller starts over the host way (a CG-tag CIGAR). */
 #ifndef PIPELINE_AUTO_DEVICE
-#define PIPELINE_AUTO_DEVICE 0
+#define PIPELINE_AUTO_DEVICE 1
 #endif
 /* compressed bytes per feed (the inflate kernel's time hardly depends on the members' number) and record bytes per drain, at
  * least (whole contig runs); CRUMBLE_HIP_DP_CHUNK / CRUMBLE_HIP_DP_PIECE (bytes) let the tests cut a small file many times */
@@ -287,9 +287,9 @@ static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_ba
         eof = c->eof;
         int e = crumble_stream_feed(s, c->buf, c->used, c->blk, c->nb, eof);
         pthread_mutex_lock(&d.mu); c->full = 0; pthread_cond_broadcast(&d.cv); pthread_mutex_unlock(&d.mu);
-        if (e) {
-            fprintf(stderr, "crumble-hip: %s (%s)\n", crumble_hip_strerror(e), crumble_hip_last_error());
-            rc = e == CRUMBLE_EUNSORTED ? 2 : 1;
+        if (e) {                                                /* (a file the device cannot take apart: the host reader has the better diagnostics) */
+            if (e == CRUMBLE_ENOMEM || e == CRUMBLE_EHIP) { fprintf(stderr, "crumble-hip: %s (%s)\n", crumble_hip_strerror(e), crumble_hip_last_error()); rc = 1; }
+            else { if (verbose) fprintf(stderr, "crumble-hip: device pipeline: %s\n", crumble_hip_last_error()); rc = -1; }
             break;
         }
         for (;;) {                                              /* whole contig runs until DP_PIECE bytes of records wait, then a drain */
@@ -356,6 +356,7 @@ static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_ba
     if (!rc && verbose) {
         float ms[5] = {0}; int64_t bi = 0, bo = 0;
         crumble_stream_times(s, ms, &bi, &bo);
+        fprintf(stderr, "BGZF codec: inflate device, deflate device\n");
         fprintf(stderr, "pipeline: device (records inflated, delimited, run and deflated in HBM; %.1f MB in, %.1f MB out over PCIe; GPU stage: inflate %.3f s, "
                 "delimit %.3f, engine %.3f, deflate %.3f, move %.3f)\n", bi / 1e6, bo / 1e6, ms[0] / 1e3, ms[1] / 1e3, ms[2] / 1e3, ms[3] / 1e3, ms[4] / 1e3);
     }
@@ -824,7 +825,10 @@ int main(int argc, char **argv)
         const int can = ngpu == 1 && !windowed && !getenv("CRUMBLE_HIP_DEVICES") && !wl && !bl && !bed_fp &&
                         !bd[0] && !bd[1] && !bd[2] && !bi[0] && !bi[1] && !bi[2] && !p.plain_download && !p.coded_quals;
         if (!strcmp(pm, "device") && !can) fprintf(stderr, "crumble-hip: CRUMBLE_HIP_PIPELINE=device needs one device and none of -w -t -T -b -e..-G: the host pipeline runs\n");
-        dev_mode = can && (!strcmp(pm, "device") || (!strcmp(pm, "auto") && PIPELINE_AUTO_DEVICE));
+        /* auto: the device pipeline whenever it applies (measured on MI355X boxes, profiles/NOTES_r06.md: 4.3-4.7 Gbases/s file to
+         * file against the host pipeline's 1.8-2.3), unless the caller asks for the slow levels 7-9, which search harder than
+         * the device's one level does */
+        dev_mode = can && (!strcmp(pm, "device") || (!strcmp(pm, "auto") && PIPELINE_AUTO_DEVICE && level < 7));
     }
     int engines_one = 0;
     if (ngpu == 1 && !windowed && !dev_mode && !getenv("CRUMBLE_HIP_DEVICES")) {

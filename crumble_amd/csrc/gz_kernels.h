@@ -1157,7 +1157,12 @@ k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int
     /* Pass A, two workgroup barriers per sub-block of 256 positions: every thread one candidate of one position (four lanes per
      * position), the best of the four into cand[] (global: 256 KiB per block, read again by pass B); then the sub-block's
      * positions into the hash tables.  Nothing here depends on which matches the parse will take. */
+#ifdef GZ_EXP_NOA                                             /* (diagnostic builds, tools/build_variant.sh: what a phase costs is what the kernel gains without it) */
+    for (int i = tid; i < N; i += GZ_DT) cand[i] = 0u;
+    if (false)
+#else
     if (level > 0 && N > 0)
+#endif
     for (int base = 0; base < N; base += GZ_SUB) {
         /* a WAVE per candidate kind and 64 positions (wave w: kind w & 3, positions 64 * (w >> 2) + lane): no lane computes
          * what only another kind needs; the four kinds of a position meet in an LDS word by atomicMax on
@@ -1198,6 +1203,9 @@ k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int
                     D.hk[GZ_SUB + j] = (uint16_t)(k6 | (inrun ? 0x8000u : 0u));
                     if (!inrun && maxl >= 6) cand_p = (int)D.h6[k6] - 1;
                 } else if (!inrun && last_dist > 1 && P - last_dist >= 0) cand_p = P - last_dist;
+#ifdef GZ_EXP_NOCMP
+                cand_p = -1;
+#endif
                 if (cand_p >= 0 && P - cand_p <= 32768) {
                     /* common prefix of the bytes at cand_p and at P, eight at a time (aligned words, shifted into place) */
                     const int cw = cand_p >> 2, csh = 8 * (cand_p & 3);

@@ -106,8 +106,10 @@ def _host_codec_under_emulation(request, monkeypatch):
     """crumble-hip inflates and deflates BGZF members on the device by default; emulated, a full block costs 1024 fibers some
     fifteen seconds, so the emulated driver tests keep the host codec (test_cli_device_codec_emulated below runs the device
     one on a small file; the GPU tests take the default)"""
-    if "emulated" in request.node.name and "device_codec" not in request.node.name:
-        monkeypatch.setenv("CRUMBLE_HIP_CODEC", "host")
+    if "emulated" in request.node.name:
+        monkeypatch.setenv("CRUMBLE_HIP_PIPELINE", "host")    # (the device pipeline, crumble-hip's default: tests/test_stream.py)
+        if "device_codec" not in request.node.name:
+            monkeypatch.setenv("CRUMBLE_HIP_CODEC", "host")
 
 
 def test_write_batches_then_read_back(tmp_path):
