@@ -238,7 +238,32 @@ static void *dp_writer(void *a)
     return NULL;
 }
 
-static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_bam_writer *wr, crumble_hip *eng, int device, int level,
+/* the complete contig runs [0, k) of the stream through the engines, a thread each: whoever is free takes the next run */
+typedef struct {
+    crumble_stream *s; crumble_hip *eng; int k; int *next; pthread_mutex_t *mu;
+    const int *bed_lo, *bed_n; const int32_t *bs, *be;
+    int *err, *err_group; char *err_text;
+} dp_proc;
+static void *dp_process(void *a)
+{
+    dp_proc *w = a;
+    for (;;) {
+        pthread_mutex_lock(w->mu);
+        const int i = *w->err ? w->k : (*w->next)++;
+        pthread_mutex_unlock(w->mu);
+        if (i >= w->k) break;
+        const int e = crumble_stream_process(w->s, w->eng, i, w->bed_n[i], w->bs + w->bed_lo[i], w->be + w->bed_lo[i]);
+        if (e) {
+            pthread_mutex_lock(w->mu);
+            if (!*w->err) { *w->err = e; *w->err_group = i; snprintf(w->err_text, 256, "%s", crumble_hip_last_error()); }
+            pthread_mutex_unlock(w->mu);
+            break;
+        }
+    }
+    return NULL;
+}
+
+static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_bam_writer *wr, crumble_hip **engs, int n_eng, int device, int level,
                            int nbed, const int32_t *bt, const int32_t *bs, const int32_t *be, int verbose, int64_t *reads_out, int64_t *bases_out,
                            double times[4])
 {
@@ -297,17 +322,30 @@ static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_ba
             const int ng = crumble_stream_groups(s, g, 256);
             int k = 0;
             int64_t bytes = crumble_stream_pending(s);
+            int bed_lo[256], bed_n[256];
             for (int i = 0; i < ng && i < 256 && g[i].complete && crumble_gz_deflate_bound(bytes) <= (int64_t)d.out[oslot].cap; i++) {
                 while (bed_i < nbed && g[i].tid >= 0 && bt[bed_i] < g[i].tid) bed_i++;
                 int j2 = bed_i;
                 while (j2 < nbed && bt[j2] == g[i].tid) j2++;
-                e = crumble_stream_process(s, eng, i, j2 - bed_i, bs + bed_i, be + bed_i);
-                if (e) {
-                    if (strstr(crumble_hip_last_error(), "CG tag")) rc = -1;
-                    else { fprintf(stderr, "crumble-hip: contig %s: %s (%s)\n", g[i].tid >= 0 ? crumble_bam_ref_name(rd, g[i].tid) : "*", crumble_hip_strerror(e), crumble_hip_last_error()); rc = 2; }
-                    break;
-                }
+                bed_lo[i] = bed_i; bed_n[i] = j2 - bed_i;
                 n_reads += g[i].n_reads; bytes = g[i].byte_end; k++;
+            }
+            if (k) {
+                int next = 0, perr = 0, pgrp = 0;
+                char ptext[256] = "";
+                pthread_mutex_t pmu = PTHREAD_MUTEX_INITIALIZER;
+                dp_proc w[4]; pthread_t pt[4];
+                const int nw = k < n_eng ? k : n_eng;
+                for (int q = 0; q < nw; q++) {
+                    w[q] = (dp_proc){ s, engs[q], k, &next, &pmu, bed_lo, bed_n, bs, be, &perr, &pgrp, ptext };
+                    if (q) pthread_create(&pt[q], NULL, dp_process, &w[q]);
+                }
+                dp_process(&w[0]);
+                for (int q = 1; q < nw; q++) pthread_join(pt[q], NULL);
+                if (perr) {
+                    if (strstr(ptext, "CG tag")) rc = -1;
+                    else { fprintf(stderr, "crumble-hip: contig %s: %s (%s)\n", g[pgrp].tid >= 0 ? crumble_bam_ref_name(rd, g[pgrp].tid) : "*", crumble_hip_strerror(perr), ptext); rc = 2; }
+                }
             }
             if (rc) break;
             if (k) {
@@ -831,11 +869,11 @@ int main(int argc, char **argv)
         dev_mode = can && (!strcmp(pm, "device") || (!strcmp(pm, "auto") && PIPELINE_AUTO_DEVICE && level < 7));
     }
     int engines_one = 0;
-    if (ngpu == 1 && !windowed && !dev_mode && !getenv("CRUMBLE_HIP_DEVICES")) {
+    if (ngpu == 1 && !windowed && !getenv("CRUMBLE_HIP_DEVICES")) {      /* (the device pipeline too: its contig runs go to whichever engine is free) */
         const char *ev = getenv("CRUMBLE_HIP_ENGINES");
         int n = ev ? atoi(ev) : 2;
         if (n < 1) n = 1;
-        if (n > 8) n = 8;
+        if (n > (dev_mode ? 4 : 8)) n = dev_mode ? 4 : 8;
         if (n > 1) { engines_one = 1; ngpu = n; }
     }
     p.ndev = ngpu;
@@ -891,7 +929,7 @@ int main(int argc, char **argv)
     int dev_done = 0;
     const double t_all = now();
     if (dev_mode) {
-        const int rcd = device_pipeline(in_fn, rd, wr, p.eng[0], p.devices[0], level, nbed, bt, bs, be, verbose, &dev_reads, &dev_bases, dev_times);
+        const int rcd = device_pipeline(in_fn, rd, wr, p.eng, ngpu, p.devices[0], level, nbed, bt, bs, be, verbose, &dev_reads, &dev_bases, dev_times);
         if (rcd > 0) return rcd;
         if (rcd == 0) dev_done = 1;
         else {                                                  /* not for this file: from the top, the host way */
@@ -899,7 +937,7 @@ int main(int argc, char **argv)
             crumble_bam_writer_close(wr);
             if (!(wr = crumble_bam_create(out_fn, rd, pg, level, threads, &err))) { fprintf(stderr, "crumble-hip: %s\n", crumble_bam_last_error()); return 1; }
             p.wr = wr;
-            (void)crumble_hip_stats_reset(p.eng[0]);
+            for (int d2 = 0; d2 < ngpu; d2++) (void)crumble_hip_stats_reset(p.eng[d2]);
         }
     }
     if (!dev_done) {

@@ -805,7 +805,11 @@ k_gz_resolve(int n_members, const GzBlock *__restrict__ blk, const uint32_t *__r
             const int pos = outbase + wbase + incl - len;
             const int dist = (int)(t & 0x7fffu) + 1;
             if (valid && (pos + len > ulen || (is_match && dist > pos) || (!is_match && len == 0))) err |= GZ_E_DIST;
+#ifdef GZ_EXP_NOTOKW
+            else if (false) {
+#else
             else if (valid && pos < hi && pos + len > lo) {
+#endif
                 if (!is_match) {
                     for (int k = 0; k < len; k++) { const int p = pos + k; if (p >= lo && p < hi) { R.img[p] = (uint8_t)(t >> (8 * k)); R.ref[p - lo] = (uint16_t)p; } }
                 } else {
@@ -823,7 +827,11 @@ k_gz_resolve(int n_members, const GzBlock *__restrict__ blk, const uint32_t *__r
         if (half == 1 || hi == ulen) total_out = outbase;
         if (gz_any(err != 0u, &R.anyflag, tid)) { err |= GZ_E_DIST; break; }
         /* ---- pointer jumping: until every reference names a literal of this half (ref[a] == a) or a byte below lo */
+#ifdef GZ_EXP_NOJUMP                                          /* (diagnostic builds: wrong bytes, the kernel's time without this part) */
+        for (int round = 0; round < 0; round++) {
+#else
         for (int round = 0; round < 17; round++) {
+#endif
             bool changed = false;
             for (int p = lo + tid; p < hi; p += GZ_RT) {
                 const int a = R.ref[p - lo];

@@ -14,6 +14,8 @@
 #define CRUMBLE_STREAM_HOST_H
 
 #include "stream_kernels.h"
+#include <mutex>
+#define ST_SLOTS 4
 
 struct crumble_stream {
     int device = 0;
@@ -29,7 +31,11 @@ struct crumble_stream {
     int64_t tail = 0;                            /* where the incomplete last record starts (== len when there is none) */
     int64_t n_rec = 0;
     DevBuf d_guess, d_exit, d_count, d_slots, d_coff, d_recoff, d_list, d_misc, d_err;
-    DevBuf d_pos, d_mapq, d_flag, d_lq, d_ncg, d_noq, d_tot;
+    /* per engine that processes runs of this stream (up to ST_SLOTS at once, a host thread each): the per-read fields, the
+     * totals, a stream for them */
+    struct Slot { crumble_hip *owner = nullptr; hipStream_t st = nullptr; DevBuf d_pos, d_mapq, d_flag, d_lq, d_ncg, d_noq, d_tot; float ms = 0; };
+    Slot slot[ST_SLOTS];
+    std::mutex slot_mu;
     std::vector<crumble_stream_group> groups;    /* in record order; the last one may go on in the next feed */
     bool eof = false;
     void *pinned = nullptr;
@@ -50,7 +56,7 @@ extern "C" crumble_stream *crumble_stream_create(int device, int32_t n_ref, int6
     uint32_t ppm[128];
     for (int q = 0; q < 128; q++) ppm[q] = (uint32_t)(1e6 * pow(10.0, -q / 10.0) + 0.5);
     ok = ok && s->d_err.reserve(sizeof ppm) == CRUMBLE_OK && copy_sync(gz->stream, s->d_err.p, ppm, sizeof ppm, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && s->d_misc.reserve(256) == CRUMBLE_OK && s->d_tot.reserve(sizeof(StTotals)) == CRUMBLE_OK;
+    ok = ok && s->d_misc.reserve(256) == CRUMBLE_OK;
     if (!ok) { g_last_error = "crumble_stream: device set-up failed"; *err = CRUMBLE_EHIP; crumble_stream_destroy(s); return nullptr; }
     return s;
 }
@@ -61,8 +67,13 @@ extern "C" void crumble_stream_destroy(crumble_stream *s)
     (void)hipSetDevice(s->device);
     if (s->gz && s->gz->stream) (void)hipStreamSynchronize(s->gz->stream);
     DevBuf *all[] = { &s->d_rec[0], &s->d_rec[1], &s->d_guess, &s->d_exit, &s->d_count, &s->d_slots, &s->d_coff, &s->d_recoff, &s->d_list,
-                      &s->d_misc, &s->d_err, &s->d_pos, &s->d_mapq, &s->d_flag, &s->d_lq, &s->d_ncg, &s->d_noq, &s->d_tot };
+                      &s->d_misc, &s->d_err };
     for (DevBuf *b : all) b->release();
+    for (auto &sl : s->slot) {
+        if (sl.st) { (void)hipStreamSynchronize(sl.st); (void)hipStreamDestroy(sl.st); }
+        DevBuf *sb[] = { &sl.d_pos, &sl.d_mapq, &sl.d_flag, &sl.d_lq, &sl.d_ncg, &sl.d_noq, &sl.d_tot };
+        for (DevBuf *b : sb) b->release();
+    }
     if (s->pinned) (void)hipHostFree(s->pinned);
     crumble_gz_destroy(s->gz);
     delete s;
@@ -236,22 +247,31 @@ extern "C" int crumble_stream_process(crumble_stream *s, crumble_hip *h, int gro
     const crumble_stream_group &g = s->groups[(size_t)group];
     if (!g.complete) { g_last_error = "crumble_stream_process: the contig run is not complete yet"; return CRUMBLE_EINVAL; }
     HIPCHK(hipSetDevice(s->device));
-    hipStream_t st = s->gz->stream;
+    crumble_stream::Slot *sl = nullptr;
+    {   /* this engine's slot (several engines, a host thread each, may process different runs of one stream at once) */
+        std::lock_guard<std::mutex> lk(s->slot_mu);
+        for (auto &c : s->slot) if (c.owner == h) { sl = &c; break; }
+        if (!sl) for (auto &c : s->slot) if (!c.owner) { c.owner = h; sl = &c; break; }
+        if (!sl) { g_last_error = "crumble_stream_process: more than ST_SLOTS engines on one stream"; return CRUMBLE_EINVAL; }
+        if (!sl->st && hipStreamCreateWithFlags(&sl->st, hipStreamNonBlocking) != hipSuccess) { sl->st = nullptr; g_last_error = "hipStreamCreate failed"; return CRUMBLE_EHIP; }
+    }
+    hipStream_t st = sl->st;
     const int64_t n = g.n_reads;
     int e;
-    StClock clk(&s->ms_engine);
-    if ((e = s->d_pos.reserve((size_t)n * 4 + 64)) || (e = s->d_mapq.reserve((size_t)n + 64)) || (e = s->d_flag.reserve((size_t)n * 2 + 64)) ||
-        (e = s->d_lq.reserve((size_t)n * 4 + 64)) || (e = s->d_ncg.reserve((size_t)n * 2 + 64)) || (e = s->d_noq.reserve((size_t)n + 64)))
+    StClock clk(&sl->ms);
+    if ((e = sl->d_pos.reserve((size_t)n * 4 + 64)) || (e = sl->d_mapq.reserve((size_t)n + 64)) || (e = sl->d_flag.reserve((size_t)n * 2 + 64)) ||
+        (e = sl->d_lq.reserve((size_t)n * 4 + 64)) || (e = sl->d_ncg.reserve((size_t)n * 2 + 64)) || (e = sl->d_noq.reserve((size_t)n + 64)) ||
+        (e = sl->d_tot.reserve(sizeof(StTotals))))
         return e;
     uint8_t *R = s->d_rec[s->cur].as<uint8_t>() + s->sync_base;
     const int64_t *ro = s->d_recoff.as<int64_t>() + g.first_read;
-    HIPCHK(hipMemsetAsync(s->d_tot.p, 0, sizeof(StTotals), st));
+    HIPCHK(hipMemsetAsync(sl->d_tot.p, 0, sizeof(StTotals), st));
     const int64_t step = n > 65536 ? n / 65536 : 1;
-    if (n) CRUMBLE_LAUNCH(k_st_fields, (unsigned)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512), 256, st, R, ro, n, s->d_pos.as<int32_t>(), s->d_mapq.as<uint8_t>(), s->d_flag.as<uint16_t>(),
-                          s->d_lq.as<int32_t>(), s->d_ncg.as<uint16_t>(), s->d_noq.as<uint8_t>(), s->d_tot.as<StTotals>(), s->d_err.as<uint32_t>(), step);
+    if (n) CRUMBLE_LAUNCH(k_st_fields, (unsigned)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512), 256, st, R, ro, n, sl->d_pos.as<int32_t>(), sl->d_mapq.as<uint8_t>(), sl->d_flag.as<uint16_t>(),
+                          sl->d_lq.as<int32_t>(), sl->d_ncg.as<uint16_t>(), sl->d_noq.as<uint8_t>(), sl->d_tot.as<StTotals>(), s->d_err.as<uint32_t>(), step);
     HIPCHK(hipGetLastError());
     StTotals tot;
-    HIPCHK(copy_sync(st, &tot, s->d_tot.p, sizeof tot, hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(st, &tot, sl->d_tot.p, sizeof tot, hipMemcpyDeviceToHost));
     if (tot.unsupported) { g_last_error = "crumble_stream: a CIGAR of more than 65535 operations (CG tag): not taken on the device path"; return CRUMBLE_EINVAL; }
     crumble_batch b;
     memset(&b, 0, sizeof b);
@@ -260,17 +280,17 @@ extern "C" int crumble_stream_process(crumble_stream *s, crumble_hip *h, int gro
     DevSrc ds;
     memset(&ds, 0, sizeof ds);
     ds.rec = R; ds.rec_off = ro;
-    ds.pos = s->d_pos.as<int32_t>(); ds.mapq = s->d_mapq.as<uint8_t>(); ds.flag = s->d_flag.as<uint16_t>();
-    ds.lq = s->d_lq.as<int32_t>(); ds.ncg = s->d_ncg.as<uint16_t>(); ds.noq = s->d_noq.as<uint8_t>();
+    ds.pos = sl->d_pos.as<int32_t>(); ds.mapq = sl->d_mapq.as<uint8_t>(); ds.flag = sl->d_flag.as<uint16_t>();
+    ds.lq = sl->d_lq.as<int32_t>(); ds.ncg = sl->d_ncg.as<uint16_t>(); ds.noq = sl->d_noq.as<uint8_t>();
     for (int i = 0; i < 256; i++) ds.mq_hist[i] = tot.mq_hist[i];
     ds.lowerr = tot.err_cnt > 0 && (double)tot.err_ppm < 20000.0 * (double)tot.err_cnt;
-    /* the engine's own stream from here on: what this object's stream wrote is complete (the read-back above) */
+    /* the engine's own stream from here on: what the slot's stream wrote is complete (the read-back above) */
     HIPCHK(hipEventRecord(h->ev_up[0], h->stream));
     if ((e = copy_raw(h, &b, &ds))) return e;
     if ((e = expand(h, true))) return e;
     if ((e = crumble_hip_run(h))) return e;
     if (n && b.n_bases)
-        CRUMBLE_LAUNCH(k_st_scatter, (unsigned)((n + 63) / 64), 256, h->stream, R, ro, n, h->d_seq_off.as<int64_t>(), s->d_noq.as<uint8_t>(), h->d_out.as<uint8_t>());
+        CRUMBLE_LAUNCH(k_st_scatter, (unsigned)((n + 63) / 64), 256, h->stream, R, ro, n, h->d_seq_off.as<int64_t>(), sl->d_noq.as<uint8_t>(), h->d_out.as<uint8_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     s->groups[(size_t)group].n_bases = b.n_bases;
@@ -329,7 +349,7 @@ extern "C" int crumble_stream_peek(crumble_stream *s, int64_t from, int64_t n, u
 extern "C" int crumble_stream_times(crumble_stream *s, float ms[5], int64_t *bytes_in, int64_t *bytes_out)
 {
     if (!s) return CRUMBLE_EINVAL;
-    if (ms) { ms[0] = s->ms_inflate; ms[1] = s->ms_sync; ms[2] = s->ms_engine; ms[3] = s->ms_deflate; ms[4] = s->ms_move; }
+    if (ms) { ms[0] = s->ms_inflate; ms[1] = s->ms_sync; ms[2] = 0; for (auto &c : s->slot) ms[2] += c.ms; ms[3] = s->ms_deflate; ms[4] = s->ms_move; }
     if (bytes_in) *bytes_in = s->bytes_in;
     if (bytes_out) *bytes_out = s->bytes_out;
     return CRUMBLE_OK;

@@ -453,7 +453,8 @@ int     crumble_gz_times(crumble_gz *g, float *h2d_ms, float *kernels_ms, float 
  *   crumble_stream_feed(s, comp, n, blk, n_blocks, eof)            whole members, in file order
  *   n = crumble_stream_groups(s, g, max)                           the contig runs in the buffer (refID, reads, bytes); all but
  *       the last are complete, the last one too once eof was fed
- *   crumble_stream_process(s, engine, i, n_bed, bed_start, bed_end)   run i through an engine of the same device
+ *   crumble_stream_process(s, engine, i, n_bed, bed_start, bed_end)   run i through an engine of the same device (up to four
+ *       engines, a host thread each, may process different runs at once; feed / drain / groups: one thread, nothing beside them)
  *   crumble_stream_drain(s, k, level, flush, out, cap, &len)       the first k runs are done: they join what waits at the front of
  *       the buffer (crumble_stream_pending), and as many whole BGZF members of 0xff00 bytes as cap holds leave; with flush the
  *       last, shorter one too when everything fits -- a contig of any size through a fixed output buffer
