@@ -46,6 +46,11 @@
 struct GzBlock { int64_t coff, uoff; uint32_t clen, ulen, crc, pad_; };
 
 struct __attribute__((packed, aligned(1))) GzU32u { uint32_t v; };      /* a 32-bit word at any byte address (global memory) */
+#ifdef CRUMBLE_EMU
+#define GZ_GLOBAL(T) T
+#else
+#define GZ_GLOBAL(T) __attribute__((address_space(1))) T
+#endif
 
 struct GzWave {
     uint32_t lit[1 << GZ_TB];
@@ -699,28 +704,36 @@ HD uint32_t gz_x2nmodp(uint64_t n, unsigned k, const uint32_t *x2n)
     while (n) { if (n & 1u) p = gz_multmodp(x2n[k & 31u], p); n >>= 1; k++; }
     return p;
 }
-/* CRC-32 of n bytes of `img` (LDS) by a workgroup of nthr threads: a slice per thread, slices folded with the shift
- * operator.  tab / x2n: LDS copies of the byte table and the powers; red: nthr words of LDS.  Returns the CRC in every thread. */
+/* CRC-32 of n <= 64 * nthr bytes of `img` (LDS) by a workgroup of nthr threads (a power of two).  Thread t takes the 64 bytes
+ * that END (nthr - 1 - t) * 64 bytes in front of the end of the data (the first threads' slices are empty or short when n is
+ * not 64 * nthr): every slice then sits a whole number of slices in front of the end, and two neighbouring partial results
+ * combine by ONE shift that is the same for the whole level -- state(A || B) = state(A) * x^(8 |B|) + state0(B) (the register is
+ * linear in state and data; zlib's crc32_combine is this identity on finished CRCs), |B| = 64 * 2^k bytes at level k, and
+ * x^(2^(9 + k)) mod p is x2n[9 + k].  Ten levels with 8, 4, 2, 1, 1 .. waves at work; the version before shifted every
+ * slice to the end by its own amount (up to sixteen polynomial products per thread, every wave, diverging): 95 k cycles per
+ * block against ~15 k.  tab / x2n: LDS copies of the byte table and the powers; red: nthr words of LDS.  Returns the CRC
+ * in every thread. */
 __device__ __forceinline__ uint32_t gz_crc_block(const uint8_t *img, int n, const uint32_t *tab, const uint32_t *x2n, uint32_t *red,
                                                  int tid, int nthr)
 {
-    int per = (n + nthr - 1) / nthr;
-    per = (per + 3) & ~3;
-    const int lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
+    const int s0 = n - (nthr - tid) * 64;
+    const int lo = s0 > 0 ? s0 : 0, hi = s0 + 64 > 0 ? s0 + 64 : 0;
     uint32_t c = 0;
     if (hi > lo) {
-        c = 0xffffffffu;
+        if (lo == 0) c = 0xffffffffu;                        /* (the register's start value, where the data starts) */
         for (int i = lo; i < hi; i++) c = tab[(c ^ img[i]) & 0xffu] ^ (c >> 8);
-        c ^= 0xffffffffu;
-        if (n - hi > 0) c = gz_multmodp(gz_x2nmodp((uint64_t)(n - hi), 3, x2n), c);
     }
     red[tid] = c;
     __syncthreads();
-    for (int s = nthr >> 1; s > 0; s >>= 1) {
-        if (tid < s) red[tid] ^= red[tid + s];
+    int k = 0;
+    for (int half = nthr >> 1; half > 0; half >>= 1, k++) {
+        uint32_t v = 0;
+        if (tid < half) v = gz_multmodp(x2n[(9 + k) & 31], red[2 * tid]) ^ red[2 * tid + 1];
+        __syncthreads();
+        if (tid < half) red[tid] = v;
         __syncthreads();
     }
-    const uint32_t r = red[0];
+    const uint32_t r = n > 0 ? red[0] ^ 0xffffffffu : 0u;
     __syncthreads();
     return r;
 }
@@ -1039,6 +1052,18 @@ __device__ __forceinline__ void gz_putbits(uint32_t *buf, uint32_t &bitpos, uint
     bitpos += (uint32_t)nb;
 }
 
+#if defined(GZ_STAMP) && !defined(CRUMBLE_EMU)      /* diagnostic build: shader cycles per phase of k_gz_deflate, summed over workgroups */
+__device__ unsigned long long gz_stamp[16];
+#define GZ_STAMP_AT(k_) do { if (tid == 0) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); atomicAdd(&gz_stamp[k_], (unsigned long long)(t_ - tlast)); tlast = t_; } } while (0)
+#define GZ_STAMP_DECL long long tlast = (long long)__builtin_amdgcn_s_memtime()
+#define GZ_STAMP_PB(k_) do { if (wv == 0 && lane == 0) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); atomicAdd(&gz_stamp[k_], (unsigned long long)(t_ - tpb)); tpb = t_; } } while (0)
+#define GZ_STAMP_PB_DECL long long tpb = (long long)__builtin_amdgcn_s_memtime()
+#else
+#define GZ_STAMP_AT(k_) do { } while (0)
+#define GZ_STAMP_DECL do { } while (0)
+#define GZ_STAMP_PB(k_) do { } while (0)
+#define GZ_STAMP_PB_DECL do { } while (0)
+#endif
 /* Pass B: the greedy parse, sixteen ranges of 4096 positions at once, a wave each.  A match is cut at the end of its
  * range, so every range's parse starts at its first position and needs nothing from its neighbour (the price: at most
  * fifteen shortened matches per block).  Inside a range the wave goes sub-block by sub-block: lane l holds the four
@@ -1051,20 +1076,35 @@ __device__ __noinline__ void gz_parse_ranges(GzDeflate &D, uint32_t *__restrict_
     if (level > 0 && N > 0) {
         const int r0 = wv * GZ_RANGE, r1 = r0 + GZ_RANGE < N ? r0 + GZ_RANGE : N;
         int sp_abs = r0, nt = 0;                            /* next uncovered position, tokens of the range so far (uniform) */
-        uint32_t *rtk = tk + r0;
+        /* (global pointers by their address space: a function that is not inlined would go through flat instructions, which
+         * wait on the LDS counter as well) */
+        GZ_GLOBAL(uint32_t) *rtk = (GZ_GLOBAL(uint32_t) *)(tk + r0);
+        GZ_GLOBAL(const uint32_t) *gcand = (GZ_GLOBAL(const uint32_t) *)cand;
+        GZ_STAMP_PB_DECL;
+        /* the candidates of the next sub-block are loaded while this one is walked (they come from HBM: pass A wrote 256 KiB
+         * per block and CU; measured 12 k cycles per sub-block waiting for them, more than the walk takes) */
+        uint32_t cn[4];
+        #pragma unroll
+        for (int q = 0; q < 4; q++) { const int p = r0 + lane + 64 * q; cn[q] = p < r1 ? gcand[p] : 0u; }
         for (int base = r0; base < r1; base += GZ_SUB) {
             int ml[4], md[4];
             unsigned long long mm[4], sel[4] = {0ull, 0ull, 0ull, 0ull};
             const int nend = r1 - base < GZ_SUB ? r1 - base : GZ_SUB;
+            uint32_t cc[4];
+            #pragma unroll
+            for (int q = 0; q < 4; q++) cc[q] = cn[q];
+            #pragma unroll
+            for (int q = 0; q < 4; q++) { const int p = base + GZ_SUB + lane + 64 * q; cn[q] = p < r1 ? gcand[p] : 0u; }
             #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int p = base + lane + 64 * q;
-                const uint32_t c = p < r1 ? cand[p] : 0u;
+                const uint32_t c = cc[q];
                 int l = (int)(c >> 16);
                 if (l > r1 - p) l = r1 - p;                  /* cut at the end of the range */
                 ml[q] = l >= 3 ? l : 0; md[q] = (int)(c & 0xffffu);
                 mm[q] = __ballot(ml[q] >= 3);
             }
+            GZ_STAMP_PB(8);
             int sp = sp_abs - base;
             if (sp < 0) sp = 0;
             #pragma unroll
@@ -1086,6 +1126,7 @@ __device__ __noinline__ void gz_parse_ranges(GzDeflate &D, uint32_t *__restrict_
                 if (64 * w + lo > sp) sp = 64 * w + lo;
             }
             if (base + sp > sp_abs) sp_abs = base + sp;
+            GZ_STAMP_PB(9);
             /* the tokens in position order: word 0's positions, then word 1's ... (position = 64 * word + lane) */
             const unsigned long long below = (1ull << lane) - 1ull;
             #pragma unroll
@@ -1107,19 +1148,12 @@ __device__ __noinline__ void gz_parse_ranges(GzDeflate &D, uint32_t *__restrict_
                 }
                 nt += __popcll(sel[q]);
             }
+            GZ_STAMP_PB(10);
         }
         if (lane == 0) D.rcount[wv] = r0 < N ? nt : 0;
     } else if (lane == 0) D.rcount[wv] = 0;
 }
 
-#if defined(GZ_STAMP) && !defined(CRUMBLE_EMU)      /* diagnostic build: shader cycles per phase of k_gz_deflate, summed over workgroups */
-__device__ unsigned long long gz_stamp[16];
-#define GZ_STAMP_AT(k_) do { if (tid == 0) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); atomicAdd(&gz_stamp[k_], (unsigned long long)(t_ - tlast)); tlast = t_; } } while (0)
-#define GZ_STAMP_DECL long long tlast = (long long)__builtin_amdgcn_s_memtime()
-#else
-#define GZ_STAMP_AT(k_) do { } while (0)
-#define GZ_STAMP_DECL do { } while (0)
-#endif
 __global__ void __launch_bounds__(GZ_DT)
 k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int level, uint32_t *__restrict__ gtok, uint32_t *__restrict__ gcand,
              uint8_t *__restrict__ slots, uint32_t *__restrict__ sizes, const uint32_t *__restrict__ crc_tab, const uint32_t *__restrict__ x2n)
@@ -1271,7 +1305,11 @@ k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int
         }
     }
     __syncthreads();
+#ifdef GZ_EXP_NOPARSE
+    if (lane == 0) D.rcount[wv] = 0;
+#else
     gz_parse_ranges(D, tk, cand, N, level, lane, wv);
+#endif
     __syncthreads();
     /* ---- the codes */
     if (tid == 0) D.hist_l[256] = 1u;                        /* end of block */
@@ -1281,10 +1319,17 @@ k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int
         else if (tid >= 320 && tid < 350) gz_huff_rank(D.hist_d, 30, tid - 320, D.hf[1]);
     }
     __syncthreads();
+#ifdef GZ_EXP_NOHUFF                                          /* (diagnostic: flat 9- and 5-bit codes instead of the two trees) */
+    if (level > 0) {
+        for (int i = tid; i < 286; i += GZ_DT) { D.len_l[i] = 9; D.code_l[i] = (uint16_t)gz_bitrev((uint32_t)i, 9); }
+        if (tid < 30) { D.len_d[tid] = 5; D.code_d[tid] = (uint16_t)gz_bitrev((uint32_t)tid, 5); }
+    }
+#else
     if (level > 0) {
         if (wv == 0) gz_huff_build(D.hist_l, 286, 15, D.len_l, D.code_l, D.hf[0], lane, true);
         if (wv == 1) gz_huff_build(D.hist_d, 30, 15, D.len_d, D.code_d, D.hf[1], lane, true);
     }
+#endif
     __syncthreads();
     GZ_STAMP_AT(4);
     /* the output bit buffer: the hash tables' 64 KiB */
@@ -1292,42 +1337,69 @@ k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int
     for (int i = tid; i < 2 * (1 << GZ_HB); i += GZ_DT) obuf[i] = 0u;
     __syncthreads();
     if (level > 0 && wv == 0) {
-        if (lane == 0) {
-            int hlit = 286, hdist = 30;
-            while (hlit > 257 && D.len_l[hlit - 1] == 0) hlit--;
-            while (hdist > 1 && D.len_d[hdist - 1] == 0) hdist--;
+        {   /* HLIT / HDIST: the last used length and distance symbol (257 and 1 at least) */
+            const unsigned long long ul = __ballot(lane < 29 && D.len_l[257 + (lane < 29 ? lane : 0)] != 0);
+            const unsigned long long ud = __ballot(lane < 30 && D.len_d[lane < 30 ? lane : 0] != 0);
+            const int hlit = 257 + (ul ? 64 - __builtin_clzll(ul) : 0);
+            int hdist = ud ? 64 - __builtin_clzll(ud) : 1;
             /* at least one distance code must be given a length (zlib refuses a block that has matches and none; one unused
              * code of one bit is what zlib itself writes for a block without matches) */
-            if (hdist == 1 && D.len_d[0] == 0) { D.len_d[0] = 1; D.code_d[0] = 0; }
-            D.hlit = hlit; D.hdist = hdist;
-            /* the lengths as runs: 16 = repeat the previous length 3-6 times, 17 = 3-10 zeros, 18 = 11-138 zeros */
-            int n_rl = 0, i = 0;
-            const int tot = hlit + hdist;
-            while (i < tot) {
-                const int v = i < hlit ? D.len_l[i] : D.len_d[i - hlit];
-                int r = 1;
-                while (i + r < tot && (i + r < hlit ? D.len_l[i + r] : D.len_d[i + r - hlit]) == v) r++;
-                if (v == 0 && r >= 3) {
-                    int left = r;
-                    while (left >= 3) {
-                        const int take = left > 138 ? 138 : left;
-                        if (take >= 11) { D.rl_sym[n_rl] = 18; D.rl_ext[n_rl] = (uint8_t)(take - 11); }
-                        else { D.rl_sym[n_rl] = 17; D.rl_ext[n_rl] = (uint8_t)(take - 3); }
-                        n_rl++; left -= take;
-                    }
-                    while (left-- > 0) { D.rl_sym[n_rl] = 0; D.rl_ext[n_rl] = 0; n_rl++; }
-                } else if (v != 0 && r >= 4) {
-                    D.rl_sym[n_rl] = (uint8_t)v; D.rl_ext[n_rl] = 0; n_rl++;
-                    int left = r - 1;
-                    while (left >= 3) { const int take = left > 6 ? 6 : left; D.rl_sym[n_rl] = 16; D.rl_ext[n_rl] = (uint8_t)(take - 3); n_rl++; left -= take; }
-                    while (left-- > 0) { D.rl_sym[n_rl] = (uint8_t)v; D.rl_ext[n_rl] = 0; n_rl++; }
-                } else {
-                    for (int k = 0; k < r; k++) { D.rl_sym[n_rl] = (uint8_t)v; D.rl_ext[n_rl] = 0; n_rl++; }
-                }
-                i += r;
+            if (lane == 0) {
+                if (!ud) { D.len_d[0] = 1; D.code_d[0] = 0; hdist = 1; }
+                D.hlit = hlit; D.hdist = hdist;
             }
-            D.n_rl = n_rl;
-            for (int k = 0; k < n_rl; k++) D.hist_b[D.rl_sym[k]]++;
+            WAVE_SYNC();
+        }
+        {   /* the lengths as runs: 16 = repeat the previous length 3-6 times, 17 = 3-10 zeros, 18 = 11-138 zeros.  Every lane
+             * looks at five of the (at most 316) lengths; a lane whose length differs from the one in front of it starts a run,
+             * learns the run's length from the next start, counts the symbols the run becomes and writes them at the prefix sum
+             * of the counts (the serial loop this replaces took as long as pass B) */
+            const int hlit = D.hlit, tot = D.hlit + D.hdist;
+            uint16_t *spos = (uint16_t *)D.red;              /* run starts in order (scratch: the CRC's reduction words) */
+            uint8_t *sval = (uint8_t *)(spos + 320);
+            int before = 0;
+            for (int c = 0; c < 5; c++) {
+                const int i = 64 * c + lane;
+                const int v = i < tot ? (i < hlit ? D.len_l[i] : D.len_d[i - hlit]) : -1;
+                const int pv = i == 0 || i >= tot ? -2 : (i - 1 < hlit ? D.len_l[i - 1] : D.len_d[i - 1 - hlit]);
+                const bool st = i < tot && v != pv;
+                const unsigned long long sm = __ballot(st);
+                if (st) { const int k = before + __popcll(sm & ((1ull << lane) - 1ull)); spos[k] = (uint16_t)i; sval[k] = (uint8_t)v; }
+                before += __popcll(sm);
+            }
+            const int ns = before;
+            WAVE_SYNC();
+            int obase = 0;
+            for (int k0 = 0; k0 < ns; k0 += 64) {
+                const int k = k0 + lane;
+                int v = 0, r = 0, cnt = 0;
+                if (k < ns) {
+                    v = sval[k];
+                    r = (k + 1 < ns ? (int)spos[k + 1] : tot) - (int)spos[k];
+                    if (v == 0 && r >= 3) { int left = r; while (left >= 3) { left -= left > 138 ? 138 : left; cnt++; } cnt += left; }
+                    else if (v != 0 && r >= 4) { int left = r - 1; cnt = 1; while (left >= 3) { left -= left > 6 ? 6 : left; cnt++; } cnt += left; }
+                    else cnt = r;
+                }
+                int incl = cnt;
+                for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+                int o = obase + incl - cnt;
+#define GZ_RL(sym_, ext_) do { D.rl_sym[o] = (uint8_t)(sym_); D.rl_ext[o] = (uint8_t)(ext_); atomicAdd(&D.hist_b[sym_], 1u); o++; } while (0)
+                if (k < ns) {
+                    if (v == 0 && r >= 3) {
+                        int left = r;
+                        while (left >= 3) { const int take = left > 138 ? 138 : left; if (take >= 11) GZ_RL(18, take - 11); else GZ_RL(17, take - 3); left -= take; }
+                        while (left-- > 0) GZ_RL(0, 0);
+                    } else if (v != 0 && r >= 4) {
+                        GZ_RL(v, 0);
+                        int left = r - 1;
+                        while (left >= 3) { const int take = left > 6 ? 6 : left; GZ_RL(16, take - 3); left -= take; }
+                        while (left-- > 0) GZ_RL(v, 0);
+                    } else for (int q = 0; q < r; q++) GZ_RL(v, 0);
+                }
+#undef GZ_RL
+                obase += READLANE(incl, 63);
+            }
+            if (lane == 0) D.n_rl = obase;
         }
         WAVE_SYNC();
         gz_huff_build(D.hist_b, 19, 7, D.len_b, D.code_b, D.hf[0], lane);
@@ -1398,7 +1470,11 @@ k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int
     } else {
         /* ---- every token's bits at its place: prefix sum of the bit counts, OR into the buffer */
         uint32_t bitbase = D.bitpos;
+#ifdef GZ_EXP_NOENC
+        for (int rg = GZ_DT / 64; rg <= GZ_DT / 64; rg++) {
+#else
         for (int rg = 0; rg <= GZ_DT / 64; rg++) {           /* the ranges in order; one more round for the end-of-block code */
+#endif
             const bool last = rg == GZ_DT / 64;
             const int rn = last ? 1 : D.rcount[rg];
             const uint32_t *rtk = tk + (last ? 0 : rg * GZ_RANGE);

@@ -47,7 +47,7 @@ for rep in range(3):
     comp2 = c.deflate(want, 6)
     wall = time.time() - t0
     tm = c.times()
-    if rep == 0:
+    if rep == 0 and not os.environ.get('GZ_PROBE_NOCHECK'):
         assert gzip.decompress(comp2.tobytes()) == want.tobytes()
     out[f"deflate_{rep}"] = {"wall_s": round(wall, 4), **{k: round(v, 3) for k, v in tm.items()}, "comp_bytes": int(comp2.size),
                              "ratio_vs_host": round(comp2.size / comp.size, 4),

@@ -22,5 +22,7 @@ tot = sum(out[i] for i in range(8))
 nb = (want.size + 65279) // 65280
 for i in range(7):
     print(f"{names[i]:22s} {out[i] / nb:12.0f} cycles/block  {100.0 * out[i] / tot:5.1f} %")
+for i, nm in ((8, "pass B: candidates loaded"), (9, "pass B: walk"), (10, "pass B: tokens, histogram")):
+    print(f"{nm:28s} {out[i] / nb:12.0f} cycles/block (wave 0 of 16)")
 print("blocks", nb, "cycles/block", tot / nb, c.times())
 c.close()
