@@ -276,7 +276,7 @@ static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_ba
     pthread_mutex_init(&d.mu, NULL); pthread_cond_init(&d.cv, NULL);
     d.wr = wr;
     if (!(d.fp = fopen(in_fn, "rb"))) { crumble_stream_destroy(s); return -1; }
-    if (getenv("CRUMBLE_HIP_DP_CHUNK") && atoll(getenv("CRUMBLE_HIP_DP_CHUNK")) >= 66000) DP_CHUNK = (size_t)atoll(getenv("CRUMBLE_HIP_DP_CHUNK"));
+    if (getenv("CRUMBLE_HIP_DP_CHUNK") && atoll(getenv("CRUMBLE_HIP_DP_CHUNK")) >= 4096) DP_CHUNK = (size_t)atoll(getenv("CRUMBLE_HIP_DP_CHUNK"));
     if (getenv("CRUMBLE_HIP_DP_PIECE") && atoll(getenv("CRUMBLE_HIP_DP_PIECE")) > 0) DP_PIECE = atoll(getenv("CRUMBLE_HIP_DP_PIECE"));
     size_t fsize = DP_CHUNK;
     if (!fseek(d.fp, 0, SEEK_END)) { const long fl = ftell(d.fp); if (fl >= 0) fsize = (size_t)fl; }

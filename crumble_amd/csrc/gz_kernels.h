@@ -846,16 +846,29 @@ k_gz_resolve(int n_members, const GzBlock *__restrict__ blk, const uint32_t *__r
         for (int round = 0; round < 17; round++) {
 #endif
             bool changed = false;
-            for (int p = lo + tid; p < hi; p += GZ_RT) {
-                const int a = R.ref[p - lo];
-                if (a != p && a >= lo) {
-                    const int b = R.ref[a - lo];
-                    if (b != a) { R.ref[p - lo] = (uint16_t)b; changed = true; }
-                }
+            /* eight positions at a time: their references first, then the references' references (two dependent LDS round
+             * trips per eight positions instead of per position; a stale or a fresh value of another thread's reference is an
+             * ancestor either way) */
+            for (int p0 = lo + tid; p0 < hi; p0 += 8 * GZ_RT) {
+                int a[8], b[8];
+                #pragma unroll
+                for (int u = 0; u < 8; u++) { const int p = p0 + u * GZ_RT; a[u] = p < hi ? (int)R.ref[p - lo] : p; }
+                #pragma unroll
+                for (int u = 0; u < 8; u++) { const int p = p0 + u * GZ_RT; b[u] = (a[u] != p && a[u] >= lo) ? (int)R.ref[a[u] - lo] : a[u]; }
+                #pragma unroll
+                for (int u = 0; u < 8; u++) { const int p = p0 + u * GZ_RT; if (b[u] != a[u]) { R.ref[p - lo] = (uint16_t)b[u]; changed = true; } }
             }
             if (!gz_any(changed, &R.anyflag, tid)) break;
         }
-        for (int p = lo + tid; p < hi; p += GZ_RT) { const int a = R.ref[p - lo]; if (a != p) R.img[p] = R.img[a]; }
+        for (int p0 = lo + tid; p0 < hi; p0 += 8 * GZ_RT) {
+            int a[8]; uint8_t v[8];
+            #pragma unroll
+            for (int u = 0; u < 8; u++) { const int p = p0 + u * GZ_RT; a[u] = p < hi ? (int)R.ref[p - lo] : p; }
+            #pragma unroll
+            for (int u = 0; u < 8; u++) { const int p = p0 + u * GZ_RT; v[u] = a[u] != p ? R.img[a[u]] : (uint8_t)0; }
+            #pragma unroll
+            for (int u = 0; u < 8; u++) { const int p = p0 + u * GZ_RT; if (a[u] != p) R.img[p] = v[u]; }
+        }
         __syncthreads();
     }
     if (!err && total_out != ulen) err |= GZ_E_SIZE;

@@ -169,11 +169,14 @@ def _walk(codec, tokens):
 def test_emu_inflate_zlib_members(emu_codec, tokens):
     """both walks: a wave per member (k_gz_tokens) and a lane per member (k_gz_tokens_lanes)"""
     _walk(emu_codec, tokens)
-    _inflate_cases(emu_codec, (1, 7, 700, 70000), (0, 1, 6), kinds=("records", "runs"))
+    if tokens in ("lane16", "lane64"):                       # (the same kernel source as "lane", another stride: a shorter list)
+        _inflate_cases(emu_codec, (7, 20000), (1, 6), kinds=("records",))
+    else:
+        _inflate_cases(emu_codec, (1, 7, 700, 70000), (0, 1, 6), kinds=("records", "runs"))
     _walk(emu_codec, "auto")
 
 
-@pytest.mark.parametrize("tokens", ["wave", "lane", "lane64"])
+@pytest.mark.parametrize("tokens", ["wave", "lane"])
 def test_emu_inflate_refuses_corrupt_members(emu_codec, tokens):
     _walk(emu_codec, tokens)
     _corrupt_cases(emu_codec)

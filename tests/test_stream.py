@@ -140,7 +140,7 @@ def _cases(library, make_engine, tmp_path, scale):
     p5 = ca.preset_params(5)
     eng = make_engine(p5)
     try:
-        for cuts in ([], [nblk // 2], sorted({1, nblk // 3, 2 * nblk // 3} - {0})) if nblk > 3 else ([],):
+        for cuts in ([nblk // 2], sorted({1, nblk // 3, 2 * nblk // 3} - {0})) if nblk > 3 else ([],):     # (one feed: the keep-region case below)
             rin, rout, groups = run_stream(library, eng, path, cuts, small_out=len(cuts) == 1)
             assert groups == [(0, bs[0].n_reads), (1, bs[1].n_reads), (-1, bs[2].n_reads)]
             check_against_oracle(p5, path, rin, rout)
@@ -189,10 +189,12 @@ def _refusals(library, make_engine, tmp_path):
     eng.close(); s.close()
 
 
-def _cli(exe, tmp_path, scale, env=None, timeout=1800, chunk=66000, level=6):
+def _cli(exe, tmp_path, scale, env=None, timeout=1800, chunk=66000, level=6, quick=False, reblock=0):
     refs = [("chrI", 60000), ("chrII", 25000)]
     bs = [synth.generate(synth.config("ce", scale=scale)), synth.generate(synth.config("ce", scale=scale / 2, seed=78, tid=1)), three_groups()[1][2]]
     bamio.write_batches(tmp_path / "in.bam", refs, bs, level=level)
+    if reblock:                                              # small members: a small read buffer then cuts the file many times
+        (tmp_path / "in.bam").write_bytes(py_bgzf(gzip.decompress(open(tmp_path / "in.bam", "rb").read()), block=reblock))
     (tmp_path / "keep.bed").write_text("chrI\t1000\t3000\nchrII\t500\t800\n")
     rd = bamio.Reader(tmp_path / "in.bam"); bed = rd.load_bed(tmp_path / "keep.bed"); rd.close()
     for args, params, b in ((["-5"], ca.preset_params(5), None), (["-1", "-R", str(tmp_path / "keep.bed")], ca.preset_params(1), bed)):
@@ -211,11 +213,27 @@ def _cli(exe, tmp_path, scale, env=None, timeout=1800, chunk=66000, level=6):
         assert err["device"] == err["host"] and len(err["host"]) >= 20          # the statistics block
         # the same with the file cut into many feeds and drains (members carried from one read buffer to the next, contig runs
         # that end in a later feed, both buffers of each kind in use)
+        if b is not None and quick:
+            continue
         r = subprocess.run([exe, "-z", *args, str(tmp_path / "in.bam"), str(tmp_path / "out_cut.bam")], timeout=timeout, stderr=subprocess.PIPE, text=True,
                            env=dict(os.environ, CRUMBLE_HIP_PIPELINE="device", CRUMBLE_HIP_DP_CHUNK=str(chunk), CRUMBLE_HIP_DP_PIECE="20000", **(env or {})))
         assert r.returncode == 0, r.stderr
         assert gzip.decompress(open(tmp_path / "out_cut.bam", "rb").read()) == st["host"]
         assert np.array_equal(_file_quals(tmp_path / "out_device.bam"), _oracle_file(params, tmp_path / "in.bam", b))
+    # records without qualities (0xff, SAMv1 4.2.3) between ordinary ones, the @PG line of the default run
+    raw = py_bam(refs, [dict(tid=0, pos=100 + 2 * i, cigar=[(40 << 4)], seq=[(1, 2, 4, 8)[(k * 5 + k // 7) % 4] for k in range(40)],
+                             qual=(None if i % 4 == 1 else [20 + (i * 7 + k) % 21 for k in range(40)]), name=f"m{i}") for i in range(300)])
+    (tmp_path / "noq.bam").write_bytes(py_bgzf(raw))
+    outs = {}
+    for mode in ("host", "device"):
+        r = subprocess.run([exe, "-9", str(tmp_path / "noq.bam"), str(tmp_path / "noq_out.bam")], env=dict(os.environ, CRUMBLE_HIP_PIPELINE=mode, **(env or {})),
+                           stderr=subprocess.PIPE, text=True, timeout=timeout)
+        assert r.returncode == 0, r.stderr
+        text, _, recs = walk_bam(tmp_path / "noq_out.bam")
+        assert "@PG\tID:crumble-hip" in text
+        outs[mode] = [bytes(x["qual"]) for x in recs]
+    assert outs["host"] == outs["device"] and all(q == b"\xff" * 40 for i, q in enumerate(outs["device"]) if i % 4 == 1)
+    assert any(q != bytes(20 + (i * 7 + k) % 21 for k in range(40)) for i, q in enumerate(outs["device"]) if i % 4 != 1)
     # a CIGAR behind a CG tag (SAMv1 4.2.2: placeholder kSmN + CG:B,I): the device pipeline hands the file to the host pipeline
     real = [(2 << 4) | 0, (1 << 4) | 1, (3 << 4) | 2, (1 << 4) | 0]
     cgtag = b"NMC\x01CGBI" + struct.pack("<I4I", 4, *real) + b"XSZz\0"
@@ -246,7 +264,7 @@ def test_emu_stream_refusals(tmp_path):
 def test_cli_device_pipeline_emulated(tmp_path):
     import emu_lib
     emu_lib.load()
-    _cli(os.path.join(ROOT, "tests", "emu", "crumble-hip-emu"), tmp_path, 0.25, env={"CRUMBLE_HIP_CODEC": "host"}, level=0)
+    _cli(os.path.join(ROOT, "tests", "emu", "crumble-hip-emu"), tmp_path, 0.15, env={"CRUMBLE_HIP_CODEC": "host"}, quick=True, reblock=3000, chunk=5000)
 
 
 def test_cli_pipeline_option_checked(tmp_path):

@@ -32,4 +32,12 @@ done
 # at exit hangs under the profiler)
 python3 $R/tools/gz_probe.py 0.3 6 > $out/${tag}_codec_probe.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof_codec -- python3 $R/tools/gz_probe.py 0.3 6 > /dev/null 2>&1
+# the device pipeline (crumble-hip's default): its own clock over three runs beside the host pipeline's, then the kernel and copy
+# trace of one run (the binary itself behind --), the inflate sweep
+export TMPDIR=/tmp
+PQ_KEEP=1 python3 $R/tools/pipe_quick.py 1 3 device1:CRUMBLE_BAM_LEVEL=1 device6: host1:CRUMBLE_HIP_PIPELINE=host,CRUMBLE_BAM_LEVEL=1 > $out/${tag}_pipeline.txt 2>&1
+CRUMBLE_BAM_LEVEL=1 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $out/${tag}_prof_pipeline -- $R/crumble_amd/crumble-hip -5 -z /tmp/pq_in.bam /tmp/pq_out.bam > /dev/null 2>&1
+python3 $R/tools/timeline.py $out/${tag}_prof_pipeline 0.8 0.4 > $out/${tag}_pipeline_timeline.txt 2>&1
+rm -f /tmp/pq_in.bam /tmp/pq_out.bam
+python3 $R/tools/inflate_sweep.py 0.01 0.05 0.2 0.6 > $out/${tag}_inflate_sweep.txt 2>&1
 tail -c 600 $out/${tag}_bench.json

@@ -74,6 +74,14 @@ if os.path.exists(cj):
 ks3 = glob.glob(os.path.join(go, f"{tag}_prof_codec", "*", "*_kernel_stats.csv"))
 if ks3:
     shutil.copy(ks3[0], os.path.join(pr, f"{tag}_kernel_stats_codec.csv"))
+# the device pipeline: the driver's own lines, kernel stats and timeline of one traced run, the inflate sweep
+for name in ("pipeline.txt", "pipeline_timeline.txt", "inflate_sweep.txt"):
+    f = os.path.join(go, f"{tag}_{name}")
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(pr, f"{tag}_{name}"))
+ks4 = glob.glob(os.path.join(go, f"{tag}_prof_pipeline", "*", "*_kernel_stats.csv"))
+if ks4:
+    shutil.copy(ks4[0], os.path.join(pr, f"{tag}_kernel_stats_pipeline.csv"))
 # SQ counters of the column kernel, per launch: chr20 -5, the 300x panel, config 4
 sqall = {}
 for name in ("chr20", "panel", "hifi"):
