@@ -863,7 +863,7 @@ int main(int argc, char **argv)
         const int can = ngpu == 1 && !windowed && !getenv("CRUMBLE_HIP_DEVICES") && !wl && !bl && !bed_fp &&
                         !bd[0] && !bd[1] && !bd[2] && !bi[0] && !bi[1] && !bi[2] && !p.plain_download && !p.coded_quals;
         if (!strcmp(pm, "device") && !can) fprintf(stderr, "crumble-hip: CRUMBLE_HIP_PIPELINE=device needs one device and none of -w -t -T -b -e..-G: the host pipeline runs\n");
-        /* auto: the device pipeline whenever it applies (measured on MI355X boxes, profiles/NOTES_r06.md: 4.3-4.7 Gbases/s file to
+        /* auto: the device pipeline whenever it applies (measured on MI355X boxes, profiles/NOTES_r06.md: 4.7-5.0 Gbases/s file to
          * file against the host pipeline's 1.8-2.3), unless the caller asks for the slow levels 7-9, which search harder than
          * the device's one level does */
         dev_mode = can && (!strcmp(pm, "device") || (!strcmp(pm, "auto") && PIPELINE_AUTO_DEVICE && level < 7));
