@@ -1285,7 +1285,9 @@ k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int
                 }
             }
         }
+#ifndef GZ_EXP_NOBAR1
         GZ_LDS_BARRIER();                                                                   /* ---- 1 */
+#endif
         GZ_STAMP_AT(1);
         {
             if (tid < GZ_SUB) {                              /* the winners: to cand[] (pass B reads them), the latest one's distance on */
@@ -1310,7 +1312,9 @@ k_gz_deflate(int n_blocks, const uint8_t *__restrict__ raw, int64_t raw_len, int
             }
             if (tid == 0) D.lastm[((base / GZ_SUB) + 1) & 1] = -1;      /* (the other one: the next sub-block's, untouched since its readers two barriers ago) */
         }
+#ifndef GZ_EXP_NOBAR2
         GZ_LDS_BARRIER();                                                                   /* ---- 2 */
+#endif
         GZ_STAMP_AT(2);
         {
             const int lm = D.lastm[(base / GZ_SUB) & 1];
