@@ -350,8 +350,8 @@ k_gz_tokens(int n_members, const GzBlock *__restrict__ blk, const uint8_t *__res
  *
  * What bounds such a walk is instruction issue, not memory: a wave alone on its SIMD issues an instruction every four to
  * five cycles, and every iteration executes every path that ANY of its lanes takes.  So (1) only LPW lanes of a wave walk
- * (8 or 16: eight or four waves per CU instead of one, fewer lanes to diverge in each), (2) an iteration takes up to two
- * more literals after its first symbol, (3) nothing on a path goes to global memory except the input word (always loaded
+ * (8 or 16: eight or four waves per CU instead of one, fewer lanes to diverge in each), (2) an iteration takes one more
+ * literal after its first symbol when that is what comes next, (3) nothing on a path goes to global memory except the input word (always loaded
  * one refill ahead) and the tokens: the decode tables of a member live in LDS as 16-bit entries interleaved by lane
  * (entry j of lane L at half-word j * LPW + L) -- 2^9 literal/length and 2^7 distance entries, behind them the canonical
  * decoder's counts / first codes / offsets and sorted symbols for the codes longer than that, and the code lengths of a
@@ -361,6 +361,10 @@ k_gz_tokens(int n_members, const GzBlock *__restrict__ blk, const uint8_t *__res
  * k_gz_tokens. */
 #define GZ2_TB       9             /* bits of the literal/length look-up in LDS */
 #define GZ2_DB       7             /* of the distance look-up */
+#ifndef GZ2_MORE
+#define GZ2_MORE     1             /* literals an iteration takes beyond its first symbol (measured, 10.5 k members, walk + copy: 17.0 / 16.4 / 16.8 /
+                                    * 18.0 / 19.2 ms for 0 / 1 / 2 / 3 / 5: every lane pays for a path that any lane takes) */
+#endif
 /* 16-bit entry: code length (bits 0-3; 0: not a code), kind (bits 4-5), value (bits 6-15: the literal, or the index of the
  * length / distance symbol -- base and extra bits follow from it by arithmetic, RFC 1951 3.2.5) */
 #define GZ2_LIT      0u
@@ -537,10 +541,11 @@ k_gz_tokens_lanes(int n_members, const GzBlock *__restrict__ blk, const uint8_t 
                     }
                 }
             }
-            /* up to two more symbols while they are literals whose bits are all in the buffer (anything else waits for the
+            /* up to GZ2_MORE more symbols while they are literals whose bits are all in the buffer (anything else waits for the
              * next iteration's full path) */
             #pragma unroll
-            for (int r = 0; r < 2; r++) {
+            for (int r = 0; r < GZ2_MORE; r++) {
+                if (r == 2 && state == S_DECODE && bc <= 32) G2_REFILL();      /* (the word was asked for at the top of the iteration) */
                 if (state == S_DECODE) {
                     const uint32_t e2 = TL[((uint32_t)bb & ((1u << GZ2_TB) - 1u)) * LPW];
                     const int c2 = (int)(e2 & 15u);
