@@ -319,3 +319,31 @@ def test_cli_device_pipeline_many_contigs_gpu(tmp_path):
         st[(mode, level)] = gzip.decompress(open(out, "rb").read())
     assert st[("host", "1")] == st[("device", "1")] == st[("device", "-1")] == st[("device", "6")]
     assert np.array_equal(_file_quals(tmp_path / "out_device1.bam"), _oracle_file(ca.preset_params(9), tmp_path / "in.bam"))
+
+
+@pytest.mark.gpu
+def test_cli_device_pipeline_a_thousand_contigs_gpu(tmp_path):
+    """more contig runs in one feed than crumble_stream_groups hands out at a time (256), most of them a handful of reads
+    (hs38DH has 3171 decoys and alts of a few kb), contigs without reads between them"""
+    exe = os.path.join(ROOT, "crumble_amd", "crumble-hip")
+    rng = np.random.default_rng(9)
+    refs = [(f"d{t}", 9000) for t in range(1000)]
+    recs = []
+    for t in range(1000):
+        if t % 13 == 5:
+            continue
+        for i in range(int(rng.integers(1, 12))):
+            L = int(rng.integers(30, 120))
+            recs.append(dict(tid=t, pos=100 + 40 * i + int(rng.integers(0, 30)), cigar=[(L << 4)], seq=rng.choice([1, 2, 4, 8], L).tolist(),
+                             qual=rng.integers(2, 42, L).tolist(), name=f"r{t}_{i}", mapq=int(rng.choice([0, 20, 60]))))
+    recs.sort(key=lambda r: (r["tid"], r["pos"]))
+    (tmp_path / "in.bam").write_bytes(py_bgzf(py_bam(refs, recs)))
+    st = {}
+    for mode in ("host", "device"):
+        r = subprocess.run([exe, "-v", "-z", "-9", str(tmp_path / "in.bam"), str(tmp_path / f"out_{mode}.bam")], env=dict(os.environ, CRUMBLE_HIP_PIPELINE=mode),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        assert ("pipeline: device" in r.stderr) == (mode == "device")
+        st[mode] = gzip.decompress(open(tmp_path / f"out_{mode}.bam", "rb").read())
+    assert st["host"] == st["device"] and len(walk_bam(tmp_path / "out_device.bam")[2]) == len(recs)
+    assert np.array_equal(_file_quals(tmp_path / "out_device.bam"), _oracle_file(ca.preset_params(9), tmp_path / "in.bam"))
