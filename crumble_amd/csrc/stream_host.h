@@ -127,9 +127,20 @@ static int stream_sync(crumble_stream *s)
     int *nlist = (int *)(s->d_misc.as<char>() + 32);
     HIPCHK(hipMemsetAsync(s->d_misc.p, 0, 64, st));
     CRUMBLE_LAUNCH(k_st_guess, nch, 64, st, R, s->start, s->len, s->n_ref, nch, s->d_guess.as<int64_t>());
-    CRUMBLE_LAUNCH(k_st_walk, (nch + 63) / 64, 64, st, R, s->start, s->len, nch, s->d_guess.as<int64_t>(), s->d_slots.as<int64_t>(),
-                   s->d_count.as<int32_t>(), s->d_exit.as<int64_t>());
-    CRUMBLE_LAUNCH(k_st_verify, (nch + 255) / 256, 256, st, nch, s->d_guess.as<int64_t>(), s->d_exit.as<int64_t>(), s->d_count.as<int32_t>(), bad);
+    int *changed = (int *)(s->d_misc.as<char>() + 48);
+    for (int round = 0;; round++) {                         /* (one round when every guess was right: the usual case) */
+        CRUMBLE_LAUNCH(k_st_walk, (nch + 63) / 64, 64, st, R, s->start, s->len, nch, s->d_guess.as<int64_t>(), s->d_slots.as<int64_t>(),
+                       s->d_count.as<int32_t>(), s->d_exit.as<int64_t>());
+        HIPCHK(hipMemsetAsync(changed, 0, 4, st));
+        CRUMBLE_LAUNCH(k_st_fix, (nch + 255) / 256, 256, st, nch, s->start, s->d_guess.as<int64_t>(), s->d_exit.as<int64_t>(), s->d_count.as<int32_t>(), changed, bad);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync((char *)s->pinned + 128, changed, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        int hchanged;
+        memcpy(&hchanged, (char *)s->pinned + 128, 4);
+        if (!hchanged) break;
+        if (round >= nch || round > 4096) { g_last_error = "crumble_stream: the record chain did not settle"; return CRUMBLE_EINVAL; }
+    }
     CRUMBLE_LAUNCH(k_st_tail, 1, 1, st, nch, s->d_guess.as<int64_t>(), s->d_exit.as<int64_t>(), s->len, tailp, bad);
     CRUMBLE_LAUNCH(k_st_offsets, 1, 1024, st, nch, s->d_count.as<int32_t>(), s->d_coff.as<int64_t>());
     HIPCHK(hipGetLastError());

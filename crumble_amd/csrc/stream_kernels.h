@@ -93,22 +93,25 @@ k_st_walk(const uint8_t *__restrict__ R, int64_t start, int64_t n, int n_chunks,
     count[c] = cnt; exitp[c] = o;
 }
 
-/* the chain: chunk c's guess must be where the walk of the last chunk in front of it that had a guess left off; every
- * record must be plausible where it was counted (its refID / lengths are used next).  bad: a word that stays 0 */
+/* the chain, checked and REPAIRED: chunk c's first record start must be where the walk of the last chunk in front of it that
+ * has one left off (if that lies inside chunk c; if it lies behind, chunk c lies inside a record and has none).  A guess can
+ * be wrong -- with a few hundred reference sequences a record's own block_size passes for a refID four bytes early -- so a
+ * chunk whose guess differs takes the chain's value and is walked again; chunk 0 starts at a known record, so every round
+ * makes at least the first wrong chunk right, and what stands when nothing changes any more is the sequential walk's result.
+ * changed: set when a guess was replaced; bad: a chunk with more records than it can hold (cannot happen: 36 bytes each). */
 __global__ void __launch_bounds__(256)
-k_st_verify(int n_chunks, const int64_t *__restrict__ guess, const int64_t *__restrict__ exitp, const int32_t *__restrict__ count, int *bad)
+k_st_fix(int n_chunks, int64_t start, int64_t *__restrict__ guess, const int64_t *__restrict__ exitp, const int32_t *__restrict__ count,
+         int *changed, int *bad)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= n_chunks) return;
     if (count[c] > ST_MAXREC) atomicOr(bad, 4);
-    if (c == 0 || guess[c] == ST_NONE) {
-        /* (a chunk without a guess must lie inside a record: its predecessor's walk must have passed it -- checked from the
-         * next chunk that has one) */
-        return;
-    }
+    if (c == 0) return;
     int p = c - 1;
     while (p > 0 && guess[p] == ST_NONE) p--;
-    if (exitp[p] != guess[c]) atomicOr(bad, 1);
+    const int64_t e = exitp[p], lo = start + (int64_t)c * ST_CHUNK, hi = lo + ST_CHUNK;
+    const int64_t want = e < hi ? (e >= lo ? e : ST_NONE) : ST_NONE;      /* (e < lo: chunk p's walk stopped at a record the buffer ends in) */
+    if (guess[c] != want) { guess[c] = want; atomicOr(changed, 1); }
 }
 /* the walk's end must be the buffer's end or an incomplete record; *tail = where the unconsumed bytes start */
 __global__ void k_st_tail(int n_chunks, const int64_t *__restrict__ guess, const int64_t *__restrict__ exitp, int64_t n, int64_t *tail, int *bad)

@@ -189,6 +189,35 @@ def _refusals(library, make_engine, tmp_path):
     eng.close(); s.close()
 
 
+def _wrong_guesses(library, make_engine, tmp_path):
+    """records built so that FOUR BYTES IN FRONT of every record start there is a plausible header too (the last quality bytes
+    as a block_size below 2^29, the record's own block_size as a refID below the reference count, its pos -- 1 mod 256 -- as a
+    one-byte name ...): every chunk's speculative guess is wrong, the chain check repairs it, the result is the sequential
+    walk's (found with 300 and 1500 real contigs: a refID test is weak once there are hundreds of references)"""
+    refs = [(f"c{t}", 3000000) for t in range(200)]
+    recs = [dict(tid=7, pos=1 + 256 * i, cigar=[(50 << 4)], seq=[(1, 2, 4, 8)[(i + k) % 4] for k in range(50)], qual=[20] * 50, name=f"q{i % 10}xyz")
+            for i in range(3000)]
+    raw = py_bam(refs, recs)
+    n_ref, hdr, offs = host_walk(raw)
+    assert len(raw) - hdr > 4 * 65536
+    comp = np.frombuffer(py_bgzf(raw)[:-28], np.uint8)
+    s = gz.Stream(n_ref, hdr, 0, library)
+    p9 = ca.preset_params(9)
+    eng = make_engine(p9)
+    try:
+        s.feed(comp, True)
+        buf, ro = s.peek()
+        assert list(ro) == [o - hdr for o in offs]
+        gs = s.groups()
+        assert [(g.tid, g.n_reads) for g in gs] == [(7, 3000)]
+        s.process(eng, 0)
+        out = gzip.decompress(s.drain(1, 1).tobytes())
+    finally:
+        eng.close(); s.close()
+    (tmp_path / "fp.bam").write_bytes(py_bgzf(raw))
+    check_against_oracle(p9, tmp_path / "fp.bam", raw[hdr:], out)
+
+
 def _cli(exe, tmp_path, scale, env=None, timeout=1800, chunk=66000, level=6, quick=False, reblock=0):
     refs = [("chrI", 60000), ("chrII", 25000)]
     bs = [synth.generate(synth.config("ce", scale=scale)), synth.generate(synth.config("ce", scale=scale / 2, seed=78, tid=1)), three_groups()[1][2]]
@@ -261,6 +290,11 @@ def test_emu_stream_refusals(tmp_path):
     _refusals(emu_lib.load(), emu_lib.engine, tmp_path)
 
 
+def test_emu_stream_wrong_guesses_repaired(tmp_path):
+    import emu_lib
+    _wrong_guesses(emu_lib.load(), emu_lib.engine, tmp_path)
+
+
 def test_cli_device_pipeline_emulated(tmp_path):
     import emu_lib
     emu_lib.load()
@@ -281,6 +315,11 @@ def test_cli_pipeline_option_checked(tmp_path):
 @pytest.mark.gpu
 def test_gpu_stream_records_stay_on_the_device(product, tmp_path):
     _cases(product, lambda p: ca.Engine(p, 0), tmp_path, 1.0)
+
+
+@pytest.mark.gpu
+def test_gpu_stream_wrong_guesses_repaired(product, tmp_path):
+    _wrong_guesses(product, lambda p: ca.Engine(p, 0), tmp_path)
 
 
 @pytest.mark.gpu
