@@ -30,7 +30,7 @@ struct crumble_stream {
     int64_t start = 0;                           /* first record not yet processed: what lies in front of it was processed and waits for a drain */
     int64_t tail = 0;                            /* where the incomplete last record starts (== len when there is none) */
     int64_t n_rec = 0;
-    DevBuf d_guess, d_exit, d_count, d_slots, d_coff, d_recoff, d_list, d_misc, d_err;
+    DevBuf d_guess, d_exit, d_count, d_slots, d_coff, d_recoff, d_list, d_misc, d_err, d_pred;
     /* per engine that processes runs of this stream (up to ST_SLOTS at once, a host thread each): the per-read fields, the
      * totals, a stream for them */
     struct Slot { crumble_hip *owner = nullptr; hipStream_t st = nullptr; DevBuf d_pos, d_mapq, d_flag, d_lq, d_ncg, d_noq, d_tot; float ms = 0; };
@@ -67,7 +67,7 @@ extern "C" void crumble_stream_destroy(crumble_stream *s)
     (void)hipSetDevice(s->device);
     if (s->gz && s->gz->stream) (void)hipStreamSynchronize(s->gz->stream);
     DevBuf *all[] = { &s->d_rec[0], &s->d_rec[1], &s->d_guess, &s->d_exit, &s->d_count, &s->d_slots, &s->d_coff, &s->d_recoff, &s->d_list,
-                      &s->d_misc, &s->d_err };
+                      &s->d_misc, &s->d_err, &s->d_pred };
     for (DevBuf *b : all) b->release();
     for (auto &sl : s->slot) {
         if (sl.st) { (void)hipStreamSynchronize(sl.st); (void)hipStreamDestroy(sl.st); }
@@ -120,7 +120,7 @@ static int stream_sync(crumble_stream *s)
     const int nch = (int)((s->len - s->start + ST_CHUNK - 1) / ST_CHUNK);
     int e;
     if ((e = s->d_guess.reserve((size_t)nch * 8)) || (e = s->d_exit.reserve((size_t)nch * 8)) || (e = s->d_count.reserve((size_t)nch * 4)) ||
-        (e = s->d_slots.reserve((size_t)nch * ST_MAXREC * 8)) || (e = s->d_coff.reserve((size_t)(nch + 1) * 8)))
+        (e = s->d_slots.reserve((size_t)nch * ST_MAXREC * 8)) || (e = s->d_coff.reserve((size_t)(nch + 1) * 8)) || (e = s->d_pred.reserve((size_t)nch * 4)))
         return e;
     int *bad = s->d_misc.as<int>();
     int64_t *tailp = (int64_t *)(s->d_misc.as<char>() + 16);
@@ -132,14 +132,16 @@ static int stream_sync(crumble_stream *s)
         CRUMBLE_LAUNCH(k_st_walk, (nch + 63) / 64, 64, st, R, s->start, s->len, nch, s->d_guess.as<int64_t>(), s->d_slots.as<int64_t>(),
                        s->d_count.as<int32_t>(), s->d_exit.as<int64_t>());
         HIPCHK(hipMemsetAsync(changed, 0, 4, st));
-        CRUMBLE_LAUNCH(k_st_fix, (nch + 255) / 256, 256, st, nch, s->start, s->d_guess.as<int64_t>(), s->d_exit.as<int64_t>(), s->d_count.as<int32_t>(), changed, bad);
+        CRUMBLE_LAUNCH(k_st_check, (nch + 255) / 256, 256, st, nch, s->start, s->d_guess.as<int64_t>(), s->d_exit.as<int64_t>(), s->d_count.as<int32_t>(),
+                       s->d_coff.as<int64_t>(), s->d_pred.as<int32_t>(), bad);             /* (d_coff: free until k_st_offsets below) */
+        CRUMBLE_LAUNCH(k_st_fix, (nch + 255) / 256, 256, st, nch, s->d_guess.as<int64_t>(), s->d_coff.as<int64_t>(), s->d_pred.as<int32_t>(), changed);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync((char *)s->pinned + 128, changed, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         int hchanged;
         memcpy(&hchanged, (char *)s->pinned + 128, 4);
         if (!hchanged) break;
-        if (round >= nch || round > 4096) { g_last_error = "crumble_stream: the record chain did not settle"; return CRUMBLE_EINVAL; }
+        if (round > nch || round > 4096) { g_last_error = "crumble_stream: the record chain did not settle"; return CRUMBLE_EINVAL; }
     }
     CRUMBLE_LAUNCH(k_st_tail, 1, 1, st, nch, s->d_guess.as<int64_t>(), s->d_exit.as<int64_t>(), s->len, tailp, bad);
     CRUMBLE_LAUNCH(k_st_offsets, 1, 1024, st, nch, s->d_count.as<int32_t>(), s->d_coff.as<int64_t>());

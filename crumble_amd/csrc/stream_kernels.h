@@ -95,23 +95,38 @@ k_st_walk(const uint8_t *__restrict__ R, int64_t start, int64_t n, int n_chunks,
 
 /* the chain, checked and REPAIRED: chunk c's first record start must be where the walk of the last chunk in front of it that
  * has one left off (if that lies inside chunk c; if it lies behind, chunk c lies inside a record and has none).  A guess can
- * be wrong -- with a few hundred reference sequences a record's own block_size passes for a refID four bytes early -- so a
- * chunk whose guess differs takes the chain's value and is walked again; chunk 0 starts at a known record, so every round
- * makes at least the first wrong chunk right, and what stands when nothing changes any more is the sequential walk's result.
- * changed: set when a guess was replaced; bad: a chunk with more records than it can hold (cannot happen: 36 bytes each). */
+ * be wrong -- with a few hundred reference sequences a record's own block_size passes for a refID four bytes early -- so:
+ * k_st_check notes for every chunk whether its guess is what the chain says (want[c] = ST_OK) or what the chain says instead,
+ * and k_st_fix replaces the guess of every inconsistent chunk WHOSE PREDECESSORS (the last chunk with a start and the ones
+ * without between it and this one) ARE CONSISTENT -- a chunk behind a wrong one is inconsistent only because that one's walk
+ * went astray or never happened: it is left alone and is consistent again once its predecessor is repaired.  Chunk 0 starts at a known record, so the first inconsistent chunk is always repaired; every round of walk /
+ * check / fix removes at least one wrong guess and all isolated ones, and what stands when a round changes nothing is the
+ * sequential walk's result.  bad: a chunk with more records than it can hold (cannot happen: 36 bytes each). */
+#define ST_OK (-2ll)
 __global__ void __launch_bounds__(256)
-k_st_fix(int n_chunks, int64_t start, int64_t *__restrict__ guess, const int64_t *__restrict__ exitp, const int32_t *__restrict__ count,
-         int *changed, int *bad)
+k_st_check(int n_chunks, int64_t start, const int64_t *__restrict__ guess, const int64_t *__restrict__ exitp, const int32_t *__restrict__ count,
+           int64_t *__restrict__ want, int32_t *__restrict__ pred, int *bad)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= n_chunks) return;
     if (count[c] > ST_MAXREC) atomicOr(bad, 4);
-    if (c == 0) return;
+    if (c == 0) { want[0] = ST_OK; pred[0] = 0; return; }
     int p = c - 1;
     while (p > 0 && guess[p] == ST_NONE) p--;
     const int64_t e = exitp[p], lo = start + (int64_t)c * ST_CHUNK, hi = lo + ST_CHUNK;
-    const int64_t want = e < hi ? (e >= lo ? e : ST_NONE) : ST_NONE;      /* (e < lo: chunk p's walk stopped at a record the buffer ends in) */
-    if (guess[c] != want) { guess[c] = want; atomicOr(changed, 1); }
+    const int64_t w = e < hi ? (e >= lo ? e : ST_NONE) : ST_NONE;      /* (e < lo: chunk p's walk stopped at a record the buffer ends in) */
+    want[c] = guess[c] == w ? ST_OK : w;
+    pred[c] = p;
+}
+__global__ void __launch_bounds__(256)
+k_st_fix(int n_chunks, int64_t *__restrict__ guess, const int64_t *__restrict__ want, const int32_t *__restrict__ pred, int *changed)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_chunks || c == 0) return;
+    if (want[c] == ST_OK) return;
+    for (int q = pred[c]; q < c; q++) if (want[q] != ST_OK) return;      /* (the chunks without a start in between count: their "none" is a claim too) */
+    guess[c] = want[c];
+    atomicOr(changed, 1);
 }
 /* the walk's end must be the buffer's end or an incomplete record; *tail = where the unconsumed bytes start */
 __global__ void k_st_tail(int n_chunks, const int64_t *__restrict__ guess, const int64_t *__restrict__ exitp, int64_t n, int64_t *tail, int *bad)
