@@ -44,6 +44,8 @@ while time.time() - t0 < budget:
         if rng.random() < 0.15:
             continue                                            # a contig without reads
         bs.append(hb)
+    if rng.random() < 0.35:                                     # a long reference list (hs38DH has 3366): a refID test alone is weak then
+        refs += [(f"x{t}", 5000) for t in range(int(rng.choice([300, 1000, 3500])))]
     if rng.random() < 0.5:
         bs.append(TB.three_groups()[1][2])                      # unmapped tail
     bamio.write_batches(src, refs, bs, level=int(rng.choice([0, 1, 6])))
