@@ -29,7 +29,7 @@ src, bedf = os.path.join(tmp, "pf_in.bam"), os.path.join(tmp, "pf_keep.bed")
 OPTS = [(["-5"], dict(level=5)), (["-1"], dict(level=1)), (["-9"], dict(level=9)), (["-9", "-p", "8"], dict(level=9, pblock=8)),
         (["-7", "-k", "2,11"], dict(level=7, keep="2,11")), (["-8", "-K", "37"], dict(level=8, really_keep="37")),
         (["-3", "-y", "pbccs"], dict(level=3, tech="pbccs")), (["-5", "-u", "35", "-c", "25"], dict(level=5, qhigh=35, qcutoff=25))]
-t0, cases, bad = time.time(), 0, 0
+t0, cases, bad, fell_back = time.time(), 0, 0, 0
 seed = seed0
 while time.time() - t0 < budget:
     rng = np.random.default_rng(seed)
@@ -76,10 +76,13 @@ while time.time() - t0 < budget:
         data = open(dst, "rb").read()
         out[mode] = gzip.decompress(data) if data[-28:] == TB.BGZF_EOF else b"no EOF member"
         stats[mode] = [l for l in r.stderr.splitlines() if len(l.split()) == 2 and l.split()[1].isdigit()]
+        if mode == "device" and "host pipeline runs" in r.stderr:
+            fell_back += 1
+            print("seed", seed, "fell back:", [l for l in r.stderr.splitlines() if "device pipeline" in l][:1], flush=True)
         if mode == "device" and "pipeline: device" not in r.stderr and "host pipeline runs" not in r.stderr:
             out[mode] = "the device pipeline did not run"
     ok = out["host"] == out["device"] and stats.get("host") == stats.get("device") and not isinstance(out["host"], tuple)
-    if ok and cases % 5 == 0:
+    if ok and cases % 5 == 0 and bs:
         kw = dict(pk)
         want = TB._oracle_file(ca.preset_params(kw.pop("level"), **kw), src, bed)
         ok = np.array_equal(TB._file_quals(os.path.join(tmp, "pf_device.bam")), want)
@@ -88,5 +91,5 @@ while time.time() - t0 < budget:
         print("FAIL seed", seed, args, [type(v).__name__ if isinstance(v, bytes) else v for v in out.values()], flush=True)
     cases += 1
     seed += 1
-print(f"pipe_fuzz seeds {seed0}..{seed - 1}: {cases} cases, {bad} failures, {time.time() - t0:.0f} s")
+print(f"pipe_fuzz seeds {seed0}..{seed - 1}: {cases} cases, {bad} failures, {fell_back} taken by the host pipeline instead, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
