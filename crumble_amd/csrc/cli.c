@@ -871,7 +871,7 @@ int main(int argc, char **argv)
     int engines_one = 0;
     if (ngpu == 1 && !windowed && !getenv("CRUMBLE_HIP_DEVICES")) {      /* (the device pipeline too: its contig runs go to whichever engine is free) */
         const char *ev = getenv("CRUMBLE_HIP_ENGINES");
-        int n = ev ? atoi(ev) : dev_mode ? 3 : 2;               /* (measured, 24 contigs through the device pipeline: 107 / 103 / 99 / 100 ms with 1 / 2 / 3 / 4) */
+        int n = ev ? atoi(ev) : dev_mode ? 4 : 2;               /* (measured through the device pipeline with 1 / 2 / 3 / 4: 24 contigs 107 / 103 / 99 / 100 ms, 1500 contigs of 5 kb 775 / 494 / 397 / 344 ms) */
         if (n < 1) n = 1;
         if (n > (dev_mode ? 4 : 8)) n = dev_mode ? 4 : 8;
         if (n > 1) { engines_one = 1; ngpu = n; }
