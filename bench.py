@@ -225,6 +225,8 @@ def file_to_file(ca, synth, refs, batches, preset, device, label, verify_seconds
         m2 = re.search(r"pipeline: device \(.*GPU stage: (.*)\)", r.stderr)
         if m2:
             out["gpu_stage_s"] = m2.group(1)
+            # the device pipeline moves the compressed file over PCIe, once each way, and nothing else of size
+            out["pcie_bytes_per_base"] = {"in": round(out["in_bytes"] / total, 4), "out": round(out["out_bytes"] / total, 4)}
         if probe:
             out["codec_kernels"] = probe
         if verify_seconds > 0:
@@ -281,6 +283,29 @@ def end_to_end_legs(ca, synth, shard, args, hb_full, label, device):
     da = file_to_file(ca, synth, refs, batches, args.preset, device, "the same at the default level, auto", verify_seconds=0, level=None)
     dh = file_to_file(ca, synth, refs, batches, args.preset, device, "the same at the default level, host", verify_seconds=0, codec="host", level=None, pipeline="host")
     out["default_level"] = {"auto": {k: da.get(k) for k in keys if k in da}, "host_codec": {k: dh.get(k) for k in keys if k in dh}}
+    # many small contigs (hs38DH: 3171 decoys and alts of a few kb): 600 contigs of 5 kb through both pipelines
+    try:
+        import copy
+        pool = []
+        for k in range(8):
+            cfg_s = synth.config("chr20", scale=1.0)
+            cfg_s.contig_len = 5000
+            cfg_s.seed = 9000 + k
+            pool.append(synth.generate(cfg_s))
+        sb, srefs = [], []
+        for tid in range(600):
+            b_ = copy.copy(pool[tid % 8])
+            b_.tid = tid
+            sb.append(b_)
+            srefs.append((f"d{tid}", 6000))
+        sc = {}
+        for name, pl in (("device", None), ("host", "host")):
+            r_ = file_to_file(ca, synth, srefs, sb, args.preset, device, "600 contigs of 5 kb", verify_seconds=0, pipeline=pl)
+            sc[name] = {"value": r_.get("value"), "loop_s": r_.get("loop_s"), "pipeline": r_.get("pipeline"),
+                        "ms_per_contig": round(r_["loop_s"] / 600 * 1e3, 3) if r_.get("loop_s") else None, "error": r_.get("error")}
+        out["small_contigs"] = {"workload": "600 contigs of 5 kb at 30x (8 different ones in turn)", "unit": "Gbases/s", **sc}
+    except Exception as ex:
+        out["small_contigs"] = {"error": repr(ex)[:300]}
     cfg_e = synth.config("chr20", scale=0.25 * args.scale)
     cfg_e.seed += 77
     out["one_contig"] = file_to_file(ca, synth, [("chr20", 64444167)], [synth.generate(cfg_e)], args.preset, device,
