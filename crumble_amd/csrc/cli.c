@@ -285,7 +285,10 @@ static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_ba
         d.in[i].cap = (fsize < DP_CHUNK ? fsize : DP_CHUNK) + ((size_t)1 << 16);
         d.in[i].bcap = d.in[i].cap / 4096 + 64;
         d.in[i].blk = malloc(d.in[i].bcap * sizeof(crumble_gz_block));
-        d.out[i].cap = (size_t)crumble_gz_deflate_bound(DP_PIECE > 2 * 65280 ? DP_PIECE : 2 * 65280) + 64;    /* (two members at least) */
+        /* (a buffer's worth of members, less for a small file -- page-locked memory costs ~0.3 ms per MB to get --, two members at least) */
+        int64_t piece = DP_PIECE;
+        if ((int64_t)fsize * 6 < piece) piece = ((int64_t)fsize * 6 / 65280 + 1) * 65280;
+        d.out[i].cap = (size_t)crumble_gz_deflate_bound(piece > 2 * 65280 ? piece : 2 * 65280) + 64;
     }
     /* the first buffer of each kind before the clock starts (like the engines: set-up); the second ones when they are needed */
     d.in[0].buf = dp_alloc(d.in[0].cap, &d.in[0].pinned);

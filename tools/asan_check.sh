@@ -42,3 +42,14 @@ for args in "-5" "-9 -j 3"; do
   if grep -q "runtime error\|AddressSanitizer" run.log; then echo "SANITIZER REPORT (coded qualities): $args"; grep -m5 "runtime error\|AddressSanitizer" run.log; exit 1; fi
   echo "clean (coded qualities): $args"
 done
+# the device pipeline (crumble_stream: device inflate, record starts, engines fed from the records, device deflate; reader /
+# writer threads of cli.c) -- with the file cut into small feeds and drains, and whole
+unset CRUMBLE_HIP_DEVICES
+for env in "CRUMBLE_HIP_DP_CHUNK=70000 CRUMBLE_HIP_DP_PIECE=30000" "CRUMBLE_HIP_ENGINES=1"; do
+  for args in "-5" "-9 -R k.bed"; do
+    env CRUMBLE_HIP_PIPELINE=device $env ./crumble-hip-asan -v $args in.bam out.bam > run.log 2>&1 || { echo "FAILED (device pipeline, $env): $args"; tail -20 run.log; exit 1; }
+    if grep -q "runtime error\|AddressSanitizer" run.log; then echo "SANITIZER REPORT (device pipeline): $args"; grep -m5 "runtime error\|AddressSanitizer" run.log; exit 1; fi
+    grep -q "pipeline: device" run.log || { echo "the device pipeline did not run: $args"; tail -5 run.log; exit 1; }
+    echo "clean (device pipeline, $env): $args"
+  done
+done
