@@ -308,6 +308,8 @@ static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_ba
     int threads_up = 0;
     if (!rc) { pthread_create(&rt, NULL, dp_reader, &d); pthread_create(&wt, NULL, dp_writer, &d); threads_up = 1; }
     int bed_i = 0, oslot = 0, eof = 0;
+    dp_out *inflight = NULL;                                  /* the output buffer of a drain that was begun and not yet collected */
+    const int async_drain = !(getenv("CRUMBLE_HIP_ASYNC_DRAIN") && !atoi(getenv("CRUMBLE_HIP_ASYNC_DRAIN")));
     for (int slot = 0; !rc && !eof; slot ^= 1) {
         dp_in *c = &d.in[slot];
         pthread_mutex_lock(&d.mu);
@@ -317,7 +319,14 @@ static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_ba
         if (stop) break;
         double t0 = now();
         eof = c->eof;
-        int e = crumble_stream_feed(s, c->buf, c->used, c->blk, c->nb, eof);
+        int e = 0;
+        if (inflight) {                                         /* (a feed may move the buffer: the drain in flight first) */
+            e = crumble_stream_drain_end(s, inflight->buf, (int64_t)inflight->cap, &inflight->len);
+            if (e) { fprintf(stderr, "crumble-hip: %s (%s)\n", crumble_hip_strerror(e), crumble_hip_last_error()); rc = 1; break; }
+            pthread_mutex_lock(&d.mu); inflight->full = 1; pthread_cond_broadcast(&d.cv); pthread_mutex_unlock(&d.mu);
+            inflight = NULL;
+        }
+        e = crumble_stream_feed(s, c->buf, c->used, c->blk, c->nb, eof);
         pthread_mutex_lock(&d.mu); c->full = 0; pthread_cond_broadcast(&d.cv); pthread_mutex_unlock(&d.mu);
         if (e) {                                                /* (a file the device cannot take apart: the host reader has the better diagnostics) */
             if (e == CRUMBLE_ENOMEM || e == CRUMBLE_EHIP) { fprintf(stderr, "crumble-hip: %s (%s)\n", crumble_hip_strerror(e), crumble_hip_last_error()); rc = 1; }
@@ -360,9 +369,16 @@ static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_ba
                 for (int i = 0; i < k; i++) n_bases += g[i].n_bases;
             }
             /* the last bytes of the file: the short last member too; otherwise whole members, a buffer's worth at a time, and
-             * what is less than that waits for the next runs */
+             * what is less than that waits for the next runs.  A drain is begun and left in flight: its members are made while
+             * the next runs are processed (other streams), and collected before the next one starts */
             const int last = eof && k == ng && ng <= 256;
             if (!k && !(last && bytes)) break;
+            if (inflight) {                                     /* the drain begun before these runs were processed */
+                e = crumble_stream_drain_end(s, inflight->buf, (int64_t)inflight->cap, &inflight->len);
+                if (e) { fprintf(stderr, "crumble-hip: %s (%s)\n", crumble_hip_strerror(e), crumble_hip_last_error()); rc = 1; break; }
+                pthread_mutex_lock(&d.mu); inflight->full = 1; pthread_cond_broadcast(&d.cv); pthread_mutex_unlock(&d.mu);
+                inflight = NULL;
+            }
             int first = 1;
             while (first || (last ? crumble_stream_pending(s) > 0 : crumble_gz_deflate_bound(crumble_stream_pending(s)) > (int64_t)d.out[oslot].cap)) {
                 dp_out *o = &d.out[oslot];
@@ -374,17 +390,26 @@ static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_ba
                 t0 = now();
                 if (stop2) { rc = rc ? rc : 1; break; }
                 const int whole = !last && crumble_gz_deflate_bound(bytes) <= (int64_t)o->cap && first;   /* less than a buffer waits: only mark the runs */
-                e = crumble_stream_drain(s, k, level, last, o->buf, whole ? 0 : (int64_t)o->cap, &o->len);
+                int64_t taken = 0;
+                e = crumble_stream_drain_begin(s, k, level, last, whole ? 0 : (int64_t)o->cap, &taken);
                 k = 0; first = 0;
                 if (e) { fprintf(stderr, "crumble-hip: %s (%s)\n", crumble_hip_strerror(e), crumble_hip_last_error()); rc = 1; break; }
-                if (o->len) {
-                    pthread_mutex_lock(&d.mu); o->full = 1; pthread_cond_broadcast(&d.cv); pthread_mutex_unlock(&d.mu);
-                    oslot ^= 1;
-                }
+                if (!taken) continue;
+                oslot ^= 1;
+                const int more = last ? crumble_stream_pending(s) > 0 : crumble_gz_deflate_bound(crumble_stream_pending(s)) > (int64_t)d.out[oslot].cap;
+                if (!more && async_drain && !last) { inflight = o; break; }      /* (collected after the next runs, or in front of the next feed) */
+                e = crumble_stream_drain_end(s, o->buf, (int64_t)o->cap, &o->len);
+                if (e) { fprintf(stderr, "crumble-hip: %s (%s)\n", crumble_hip_strerror(e), crumble_hip_last_error()); rc = 1; break; }
+                pthread_mutex_lock(&d.mu); o->full = 1; pthread_cond_broadcast(&d.cv); pthread_mutex_unlock(&d.mu);
             }
             if (rc) break;
         }
         t_gpu += now() - t0;
+    }
+    if (inflight && !rc) {                                    /* (cannot be: the file's last drain is not left in flight) */
+        const int e = crumble_stream_drain_end(s, inflight->buf, (int64_t)inflight->cap, &inflight->len);
+        if (e) { fprintf(stderr, "crumble-hip: %s (%s)\n", crumble_hip_strerror(e), crumble_hip_last_error()); rc = 1; }
+        else { pthread_mutex_lock(&d.mu); inflight->full = 1; pthread_cond_broadcast(&d.cv); pthread_mutex_unlock(&d.mu); }
     }
     pthread_mutex_lock(&d.mu);
     if (rc) d.stop = 1;

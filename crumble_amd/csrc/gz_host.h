@@ -272,6 +272,51 @@ static int gz_deflate_impl(crumble_gz *g, const uint8_t *raw, const uint8_t *raw
     return CRUMBLE_OK;
 }
 
+/* The same in two halves for a device source of at most one round (crumble_stream's drains): begin enqueues the kernels and
+ * returns; end waits, checks and copies the members out.  Between the two the caller may do other work on other streams; it
+ * must not use this codec object, and the source bytes must stay as they are. */
+static int gz_deflate_begin(crumble_gz *g, const uint8_t *raw_dev, int64_t raw_len, int level)
+{
+    if (!g || !raw_dev || raw_len <= 0 || raw_len > (GZ_BATCH_RAW / GZ_MAXBLK) * GZ_MAXBLK) return CRUMBLE_EINVAL;
+    HIPCHK(hipSetDevice(g->device));
+    hipStream_t st = g->stream;
+    g->ms_h2d = g->ms_kernels = g->ms_d2h = 0; g->last_in = raw_len; g->last_out = 0;
+    level = level == 0 ? 0 : 1;
+    const int ncu = g->ncu;
+    const int nb = (int)((raw_len + GZ_MAXBLK - 1) / GZ_MAXBLK);
+    int e;
+    if ((e = g->d_tok.reserve((size_t)nb * 65536 * 4)) || (e = g->d_cand.reserve((size_t)nb * 65536 * 4)) || (e = g->d_slots.reserve((size_t)nb * GZ_SLOT)) ||
+        (e = g->d_sizes.reserve((size_t)nb * 4)) || (e = g->d_off.reserve((size_t)(nb + 1) * 8)) || (e = g->d_out.reserve((size_t)nb * GZ_SLOT)))
+        return e;
+    HIPCHK(hipEventRecord(g->ev[1], st));
+    CRUMBLE_LAUNCH(k_gz_deflate, (unsigned)(nb < ncu ? nb : ncu), GZ_DT, st, nb, raw_dev, raw_len, level, g->d_tok.as<uint32_t>(), g->d_cand.as<uint32_t>(),
+                   g->d_slots.as<uint8_t>(), g->d_sizes.as<uint32_t>(), g->d_tabs.as<uint32_t>(), g->d_tabs.as<uint32_t>() + 256);
+    CRUMBLE_LAUNCH(k_gz_offsets, 1, 1024, st, nb, g->d_sizes.as<uint32_t>(), g->d_off.as<int64_t>());
+    CRUMBLE_LAUNCH(k_gz_gather, (unsigned)nb, 256, st, nb, g->d_slots.as<uint8_t>(), g->d_sizes.as<uint32_t>(), g->d_off.as<int64_t>(), g->d_out.as<uint8_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(g->ev[2], st));
+    HIPCHK(hipMemcpyAsync(g->pinned, g->d_off.as<int64_t>() + nb, 8, hipMemcpyDeviceToHost, st));
+    return CRUMBLE_OK;
+}
+static int gz_deflate_end(crumble_gz *g, uint8_t *out, int64_t out_cap, int64_t *out_len)
+{
+    *out_len = 0;
+    HIPCHK(hipSetDevice(g->device));
+    hipStream_t st = g->stream;
+    HIPCHK(hipStreamSynchronize(st));
+    int64_t total = 0;
+    memcpy(&total, g->pinned, 8);
+    if (total <= 0 || total > out_cap) { g_last_error = "crumble_gz_deflate: internal size error"; return CRUMBLE_EOVERFLOW; }
+    HIPCHK(hipMemcpyAsync(out, g->d_out.p, (size_t)total, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(g->ev[3], st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, g->ev[1], g->ev[2])); g->ms_kernels = ms;
+    HIPCHK(hipEventElapsedTime(&ms, g->ev[2], g->ev[3])); g->ms_d2h = ms;
+    *out_len = total; g->last_out = total;
+    return CRUMBLE_OK;
+}
+
 extern "C" int crumble_gz_deflate(crumble_gz *g, const uint8_t *raw, int64_t raw_len, int level, uint8_t *out, int64_t out_cap, int64_t *out_len)
 {
     if (raw_len && !raw) return CRUMBLE_EINVAL;

@@ -38,6 +38,8 @@ struct crumble_stream {
     std::mutex slot_mu;
     std::vector<crumble_stream_group> groups;    /* in record order; the last one may go on in the next feed */
     bool eof = false;
+    double t_begin = 0;
+    bool inflight = false;                       /* a drain was begun and not ended: its members are being made */
     void *pinned = nullptr;
     int64_t bytes_in = 0, bytes_out = 0;         /* compressed bytes fed / drained so far */
     float ms_inflate = 0, ms_sync = 0, ms_engine = 0, ms_deflate = 0, ms_move = 0;   /* host clock around each part */
@@ -204,6 +206,7 @@ static int stream_sync(crumble_stream *s)
 extern "C" int crumble_stream_feed(crumble_stream *s, const uint8_t *comp, int64_t comp_len, const crumble_gz_block *blk, int64_t n_blocks, int eof)
 {
     if (!s || comp_len < 0 || n_blocks < 0 || (n_blocks && (!comp || !blk))) return CRUMBLE_EINVAL;
+    if (s->inflight) { g_last_error = "crumble_stream_feed: a drain is in flight (crumble_stream_drain_end first)"; return CRUMBLE_EINVAL; }
     HIPCHK(hipSetDevice(s->device));
     hipStream_t st = s->gz->stream;
     int64_t add = 0;
@@ -315,10 +318,11 @@ extern "C" int crumble_stream_process(crumble_stream *s, crumble_hip *h, int gro
  * only, unless flush is set and everything fits: then the last, shorter member too (the end of the file, or of a piece the
  * caller wants closed).  out_cap 0: nothing is written, the runs are only marked.  The remaining runs keep their order and
  * are numbered from 0 again. */
-extern "C" int crumble_stream_drain(crumble_stream *s, int k, int level, int flush, uint8_t *out, int64_t out_cap, int64_t *out_len)
+/* marks the first k runs done and says how many bytes of the front of the buffer a drain into out_cap bytes takes (0: none) */
+static int stream_drain_plan(crumble_stream *s, int k, int flush, int64_t out_cap, int64_t *take_out)
 {
-    if (!s || k < 0 || k > (int)s->groups.size() || !out_len || out_cap < 0 || (out_cap && !out)) return CRUMBLE_EINVAL;
-    *out_len = 0;
+    *take_out = 0;
+    if (s->inflight) { g_last_error = "crumble_stream_drain: a drain is in flight (crumble_stream_drain_end first)"; return CRUMBLE_EINVAL; }
     if (s->hdr) return k ? CRUMBLE_EINVAL : CRUMBLE_OK;
     if (k) {
         s->start = s->groups[(size_t)k - 1].byte_end - (s->base - s->sync_base);
@@ -333,12 +337,55 @@ extern "C" int crumble_stream_drain(crumble_stream *s, int k, int level, int flu
         if (crumble_gz_deflate_bound(avail) > out_cap) { g_last_error = "crumble_stream_drain: the output buffer does not hold one BGZF member"; return CRUMBLE_EINVAL; }
         return CRUMBLE_OK;                                  /* (less than a member waits, and no flush) */
     }
+    *take_out = take;
+    return CRUMBLE_OK;
+}
+
+extern "C" int crumble_stream_drain(crumble_stream *s, int k, int level, int flush, uint8_t *out, int64_t out_cap, int64_t *out_len)
+{
+    if (!s || k < 0 || k > (int)s->groups.size() || !out_len || out_cap < 0 || (out_cap && !out)) return CRUMBLE_EINVAL;
+    *out_len = 0;
+    int64_t take = 0;
+    int e;
+    if ((e = stream_drain_plan(s, k, flush, out_cap, &take)) || !take) return e;
     HIPCHK(hipSetDevice(s->device));
     uint8_t *R = s->d_rec[s->cur].as<uint8_t>() + s->base;
-    int e;
     { StClock clk(&s->ms_deflate); if ((e = gz_deflate_impl(s->gz, nullptr, R, take, level, out, out_cap, out_len))) return e; }
     s->bytes_out += *out_len;
     s->base += take; s->len -= take; s->start -= take; s->tail -= take;
+    return CRUMBLE_OK;
+}
+
+/* The same drain in two halves: begin marks the runs, enqueues the deflate of what a buffer of out_cap bytes will take
+ * (*taken: that many record bytes; 0: nothing to do, no end needed) and returns; crumble_stream_drain_end waits and copies
+ * the members out.  In between the caller may process further runs (crumble_stream_process works on other streams and
+ * other bytes) -- not feed, not drain.  out_cap: at most a codec round (256 MB of records). */
+extern "C" int crumble_stream_drain_begin(crumble_stream *s, int k, int level, int flush, int64_t out_cap, int64_t *taken)
+{
+    if (!s || k < 0 || k > (int)s->groups.size() || !taken || out_cap < 0) return CRUMBLE_EINVAL;
+    *taken = 0;
+    int64_t take = 0;
+    int e;
+    if ((e = stream_drain_plan(s, k, flush, out_cap, &take)) || !take) return e;
+    HIPCHK(hipSetDevice(s->device));
+    uint8_t *R = s->d_rec[s->cur].as<uint8_t>() + s->base;
+    s->t_begin = st_now();
+    if ((e = gz_deflate_begin(s->gz, R, take, level))) return e;
+    s->base += take; s->len -= take; s->start -= take; s->tail -= take;
+    s->inflight = true;
+    *taken = take;
+    return CRUMBLE_OK;
+}
+extern "C" int crumble_stream_drain_end(crumble_stream *s, uint8_t *out, int64_t out_cap, int64_t *out_len)
+{
+    if (!s || !out || !out_len) return CRUMBLE_EINVAL;
+    *out_len = 0;
+    if (!s->inflight) return CRUMBLE_OK;
+    s->inflight = false;
+    const int e = gz_deflate_end(s->gz, out, out_cap, out_len);
+    s->ms_deflate += (float)(st_now() - s->t_begin);         /* (wall time from begin: includes what the caller did in between) */
+    if (e) return e;
+    s->bytes_out += *out_len;
     return CRUMBLE_OK;
 }
 

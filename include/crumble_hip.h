@@ -476,6 +476,11 @@ int  crumble_stream_groups(crumble_stream *s, crumble_stream_group *out, int max
 int  crumble_stream_process(crumble_stream *s, crumble_hip *h, int group, int32_t n_bed, const int32_t *bed_start, const int32_t *bed_end);
 int  crumble_stream_drain(crumble_stream *s, int k, int level, int flush, uint8_t *out, int64_t out_cap, int64_t *out_len);
 int64_t crumble_stream_pending(crumble_stream *s);   /* bytes processed and not drained yet */
+/* the drain in two halves: _begin marks the runs, enqueues the deflate of what a buffer of out_cap bytes will take (*taken
+ * record bytes; 0: nothing to do and no _end needed; out_cap at most a codec round, 256 MB of records) and returns; _end waits
+ * and copies the members out.  In between further runs may be processed (other streams, other bytes) -- no feed, no drain. */
+int  crumble_stream_drain_begin(crumble_stream *s, int k, int level, int flush, int64_t out_cap, int64_t *taken);
+int  crumble_stream_drain_end(crumble_stream *s, uint8_t *out, int64_t out_cap, int64_t *out_len);
 /* optional set-up before the first feed: device memory for feeds of up to comp_bytes that inflate to about raw_bytes (record
  * buffers, token and slot arrays), so that no feed / drain stops to allocate; larger feeds still work (they grow the buffers) */
 int  crumble_stream_reserve(crumble_stream *s, int64_t comp_bytes, int64_t raw_bytes);
