@@ -32,7 +32,7 @@ bamio.write_batches(src, refs, batches, level=1)
 total = sum(b.n_bases for b in batches)
 print(f"{n} contigs of {bp} bp: {total / 1e6:.1f} Mbases, {os.path.getsize(src) / 1e6:.1f} MB", flush=True)
 for name, env in (("host, 2 engines", {"CRUMBLE_HIP_PIPELINE": "host"}), ("host, 4 engines", {"CRUMBLE_HIP_PIPELINE": "host", "CRUMBLE_HIP_ENGINES": "4"}),
-                  ("device, 1 engine", {"CRUMBLE_HIP_ENGINES": "1"}), ("device, 2", {"CRUMBLE_HIP_ENGINES": "2"}), ("device, 3 (default)", {}), ("device, 4", {"CRUMBLE_HIP_ENGINES": "4"})):
+                  ("device, 1 engine", {"CRUMBLE_HIP_ENGINES": "1"}), ("device, 2", {"CRUMBLE_HIP_ENGINES": "2"}), ("device, 3", {"CRUMBLE_HIP_ENGINES": "3"}), ("device, 4 (default)", {})):
     best = None
     for rep in range(2):
         r = subprocess.run([os.path.join(ROOT, "crumble_amd", "crumble-hip"), "-v", "-5", "-z", src, dst], env=dict(os.environ, CRUMBLE_BAM_LEVEL="1", **env),
