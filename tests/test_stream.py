@@ -351,7 +351,7 @@ def test_cli_device_pipeline_many_contigs_gpu(tmp_path):
     st = {}
     for mode, level in (("host", "1"), ("device", "1"), ("device", "-1"), ("device", "6")):
         out = tmp_path / f"out_{mode}{level}.bam"
-        cut = {"CRUMBLE_HIP_DP_CHUNK": "200000", "CRUMBLE_HIP_DP_PIECE": "300000"} if level == "6" else {}      # many feeds, many drains
+        cut = {"CRUMBLE_HIP_DP_CHUNK": "200000", "CRUMBLE_HIP_DP_PIECE": "300000", "CRUMBLE_HIP_ASYNC_DRAIN": "1"} if level == "6" else {}      # many feeds, many drains (left in flight)
         r = subprocess.run([exe, "-v", "-z", "-9", str(tmp_path / "in.bam"), str(out)], env=dict(os.environ, CRUMBLE_HIP_PIPELINE=mode, CRUMBLE_BAM_LEVEL=level, **cut),
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         assert r.returncode == 0, r.stderr

@@ -65,6 +65,7 @@ while time.time() - t0 < budget:
         env = dict(os.environ, CRUMBLE_HIP_PIPELINE=mode, CRUMBLE_BAM_LEVEL=str(rng.choice([0, 1, -1])))
         if mode == "device":
             env["CRUMBLE_HIP_ENGINES"] = str(rng.integers(1, 5))
+            env["CRUMBLE_HIP_ASYNC_DRAIN"] = str(rng.integers(0, 2))
             if rng.random() < 0.7:
                 env["CRUMBLE_HIP_DP_CHUNK"] = str(int(rng.choice([70000, 200000, 3000000])))
                 env["CRUMBLE_HIP_DP_PIECE"] = str(int(rng.choice([20000, 400000, 5000000])))
