@@ -245,7 +245,7 @@ def _cli(exe, tmp_path, scale, env=None, timeout=1800, chunk=66000, level=6, qui
         if b is not None and quick:
             continue
         r = subprocess.run([exe, "-z", *args, str(tmp_path / "in.bam"), str(tmp_path / "out_cut.bam")], timeout=timeout, stderr=subprocess.PIPE, text=True,
-                           env=dict(os.environ, CRUMBLE_HIP_PIPELINE="device", CRUMBLE_HIP_DP_CHUNK=str(chunk), CRUMBLE_HIP_DP_PIECE="20000", **(env or {})))
+                           env=dict(os.environ, CRUMBLE_HIP_PIPELINE="device", CRUMBLE_HIP_DP_CHUNK=str(chunk), CRUMBLE_HIP_DP_PIECE="20000", CRUMBLE_HIP_ASYNC_DRAIN="1", **(env or {})))
         assert r.returncode == 0, r.stderr
         assert gzip.decompress(open(tmp_path / "out_cut.bam", "rb").read()) == st["host"]
         assert np.array_equal(_file_quals(tmp_path / "out_device.bam"), _oracle_file(params, tmp_path / "in.bam", b))
