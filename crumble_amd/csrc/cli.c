@@ -301,6 +301,8 @@ static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_ba
     for (int i = 0; i < 3; i++) pthread_join(pth[i], NULL);
     int rc = (!d.in[0].buf || !d.out[0].buf || !d.out[1].buf || !d.in[0].blk || !d.in[1].blk) ? 1 : 0;
     if (rc) fprintf(stderr, "crumble-hip: out of memory\n");
+    int64_t ac0 = 0; double am0 = 0;
+    crumble_hip_alloc_stats(&ac0, &am0);
     const double t_all = now();
     double t_gpu = 0;
     int64_t n_reads = 0, n_bases = 0;
@@ -428,9 +430,12 @@ static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_ba
     if (!rc && verbose) {
         float ms[5] = {0}; int64_t bi = 0, bo = 0;
         crumble_stream_times(s, ms, &bi, &bo);
+        int64_t ac1 = 0; double am1 = 0;
+        crumble_hip_alloc_stats(&ac1, &am1);
         fprintf(stderr, "BGZF codec: inflate device, deflate device\n");
         fprintf(stderr, "pipeline: device (records inflated, delimited, run and deflated in HBM; %.1f MB in, %.1f MB out over PCIe; GPU stage: inflate %.3f s, "
-                "delimit %.3f, engine %.3f, deflate %.3f, move %.3f)\n", bi / 1e6, bo / 1e6, ms[0] / 1e3, ms[1] / 1e3, ms[2] / 1e3, ms[3] / 1e3, ms[4] / 1e3);
+                "delimit %.3f, engine %.3f, deflate %.3f, move %.3f; device allocations inside: %lld, %.3f s)\n", bi / 1e6, bo / 1e6, ms[0] / 1e3, ms[1] / 1e3, ms[2] / 1e3, ms[3] / 1e3, ms[4] / 1e3,
+                (long long)(ac1 - ac0), (am1 - am0) / 1e3);
     }
     *reads_out = n_reads; *bases_out = n_bases;
     fclose(d.fp);

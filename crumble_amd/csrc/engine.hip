@@ -51,6 +51,9 @@ static inline hipError_t fill_sync(hipStream_t st, void *dst, int v, size_t n)
 }
 
 /* grow-only device buffer */
+/* device allocations of this process: how many, and the host time they took (crumble_hip_alloc_stats: a diagnostic -- a first
+ * contig's seventy-odd buffers are allocated inside a driver's timed loop) */
+static std::atomic<long long> g_alloc_calls{0}, g_alloc_us{0};
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
     bool owned = true;              /* false: a view into another buffer (the raw arena of an upload) */
@@ -58,10 +61,16 @@ struct DevBuf {
     int reserve(size_t n) {
         if (!owned) { p = nullptr; cap = 0; owned = true; }
         if (n <= cap && p) return CRUMBLE_OK;
+        struct timespec t0_, t1_;
+        clock_gettime(CLOCK_MONOTONIC, &t0_);
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
         size_t want = n + n / 8 + 256;
-        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; g_last_error = "hipMalloc failed"; return CRUMBLE_ENOMEM; }
+        const bool ok = hipMalloc(&p, want) == hipSuccess;
+        clock_gettime(CLOCK_MONOTONIC, &t1_);
+        g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
+        g_alloc_us.fetch_add((long long)((t1_.tv_sec - t0_.tv_sec) * 1000000ll + (t1_.tv_nsec - t0_.tv_nsec) / 1000), std::memory_order_relaxed);
+        if (!ok) { p = nullptr; g_last_error = "hipMalloc failed"; return CRUMBLE_ENOMEM; }
         cap = want;
         return CRUMBLE_OK;
     }
@@ -1615,6 +1624,12 @@ extern "C" int crumble_hip_transfer_bytes(crumble_hip *h, int64_t *up, int64_t *
     if (up) *up = (int64_t)h->up_bytes;
     if (down) *down = (int64_t)h->down_bytes;
     return CRUMBLE_OK;
+}
+
+extern "C" void crumble_hip_alloc_stats(int64_t *calls, double *ms)
+{
+    if (calls) *calls = g_alloc_calls.load();
+    if (ms) *ms = g_alloc_us.load() / 1e3;
 }
 
 extern "C" void *crumble_hip_host_alloc(size_t bytes)

@@ -494,6 +494,8 @@ int  crumble_stream_times(crumble_stream *s, float ms[5], int64_t *bytes_in, int
  * PCIe at the link's rate without the runtime's staging through its own buffers (pageable memory: about half).  Any host
  * memory works with every entry point; this is an option for callers that keep their buffers.  NULL on failure. */
 void *crumble_hip_host_alloc(size_t bytes);
+/* diagnostic: device allocations (hipFree + hipMalloc of a growing buffer) of this process so far and the host time they took */
+void  crumble_hip_alloc_stats(int64_t *calls, double *ms);
 void  crumble_hip_host_free(void *p);
 
 const char *crumble_hip_strerror(int err);
