@@ -8,8 +8,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-bash $R/tools/fetch_calib.sh $tag > /dev/null 2>&1
+# (the bench line first: twice in three the file -> file legs of a bench that ran right behind the counter calibration's --pmc passes
+# took three times as long -- the engines' stage only --, never in eleven runs without them in front)
 python3 $R/bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+bash $R/tools/fetch_calib.sh $tag > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -- python3 $R/bench.py --steps 5 --warmup 1 --profile > $out/${tag}_prof.log 2>&1
 # PMC passes on their own (no trace domains), one counter per pass
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --profile > /dev/null 2>&1
