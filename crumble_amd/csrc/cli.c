@@ -311,9 +311,8 @@ static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_ba
     if (!rc) { pthread_create(&rt, NULL, dp_reader, &d); pthread_create(&wt, NULL, dp_writer, &d); threads_up = 1; }
     int bed_i = 0, oslot = 0, eof = 0;
     dp_out *inflight = NULL;                                  /* the output buffer of a drain that was begun and not yet collected */
-    /* (opt-in: typically 5 % faster -- 24 contigs 94-97 ms against 99-107 --, but one bench run in ten on the pool's boxes took
-     * 270 ms this way, the engines' kernels queueing behind the deflate's persistent workgroups; the synchronous order never did) */
-    const int async_drain = getenv("CRUMBLE_HIP_ASYNC_DRAIN") && atoi(getenv("CRUMBLE_HIP_ASYNC_DRAIN"));
+    /* (CRUMBLE_HIP_ASYNC_DRAIN=0: the synchronous order -- 24 contigs 99-107 ms against 94-97) */
+    const int async_drain = !(getenv("CRUMBLE_HIP_ASYNC_DRAIN") && !atoi(getenv("CRUMBLE_HIP_ASYNC_DRAIN")));
     for (int slot = 0; !rc && !eof; slot ^= 1) {
         dp_in *c = &d.in[slot];
         pthread_mutex_lock(&d.mu);
