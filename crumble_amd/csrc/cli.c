@@ -297,7 +297,7 @@ static int device_pipeline(const char *in_fn, crumble_bam_reader *rd, crumble_ba
     dp_pre pre[3] = { { &d.in[0].buf, d.in[0].cap, &d.in[0].pinned }, { &d.out[0].buf, d.out[0].cap, &d.out[0].pinned }, { &d.out[1].buf, d.out[1].cap, &d.out[1].pinned } };
     pthread_t pth[3];
     for (int i = 0; i < 3; i++) pthread_create(&pth[i], NULL, dp_prealloc, &pre[i]);
-    (void)crumble_stream_reserve(s, (int64_t)d.in[0].cap, (int64_t)d.in[0].cap * 5);   /* (a hint: what it cannot get now it asks for again later) */
+    (void)crumble_stream_reserve(s, (int64_t)d.in[0].cap, (int64_t)d.in[0].cap * 4);   /* (a hint: what it cannot get now it asks for again later) */
     for (int i = 0; i < 3; i++) pthread_join(pth[i], NULL);
     int rc = (!d.in[0].buf || !d.out[0].buf || !d.out[1].buf || !d.in[0].blk || !d.in[1].blk) ? 1 : 0;
     if (rc) fprintf(stderr, "crumble-hip: out of memory\n");
