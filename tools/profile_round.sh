@@ -8,8 +8,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-# (the bench line first: twice in three the file -> file legs of a bench that ran right behind the counter calibration's --pmc passes
-# took three times as long -- the engines' stage only --, never in eleven runs without them in front)
+# (the bench line first: a driver process that starts right behind other GPU processes' exits -- the calibration's passes here --
+# can wait in its first allocations, profiles/NOTES_r06.md)
 python3 $R/bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 bash $R/tools/fetch_calib.sh $tag > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -- python3 $R/bench.py --steps 5 --warmup 1 --profile > $out/${tag}_prof.log 2>&1
