@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <thread>
 #include <atomic>
+#include <mutex>
 #ifndef CRUMBLE_EMU
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -54,19 +55,42 @@ static inline hipError_t fill_sync(hipStream_t st, void *dst, int v, size_t n)
 /* device allocations of this process: how many, and the host time they took (crumble_hip_alloc_stats: a diagnostic -- a first
  * contig's seventy-odd buffers are allocated inside a driver's timed loop) */
 static std::atomic<long long> g_alloc_calls{0}, g_alloc_us{0};
+/* A buffer that grows does not free its old memory on the spot: hipFree waits for the whole device, i.e. for whatever the other
+ * engines of the process (or a deflate in flight) have running -- milliseconds per growing buffer while a driver's first contigs
+ * size seventy of them.  The old blocks wait here and go when an object is destroyed, or at the start of a contig once more
+ * than a gigabyte of them has piled up. */
+static std::mutex g_defer_mu;
+static std::vector<void *> g_defer_ptr;
+static size_t g_defer_bytes = 0;
+static void dev_free_later(void *p, size_t n)
+{
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    g_defer_ptr.push_back(p); g_defer_bytes += n;
+}
+static void dev_free_deferred(size_t keep_below)
+{
+    std::vector<void *> v;
+    {
+        std::lock_guard<std::mutex> lk(g_defer_mu);
+        if (g_defer_bytes <= keep_below) return;
+        v.swap(g_defer_ptr); g_defer_bytes = 0;
+    }
+    for (void *p : v) (void)hipFree(p);
+}
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
     bool owned = true;              /* false: a view into another buffer (the raw arena of an upload) */
-    void view(void *ptr, size_t n) { if (owned && p) (void)hipFree(p); p = ptr; cap = n; owned = false; }
+    void view(void *ptr, size_t n) { if (owned && p) dev_free_later(p, cap); p = ptr; cap = n; owned = false; }
     int reserve(size_t n) {
         if (!owned) { p = nullptr; cap = 0; owned = true; }
         if (n <= cap && p) return CRUMBLE_OK;
         struct timespec t0_, t1_;
         clock_gettime(CLOCK_MONOTONIC, &t0_);
-        if (p) (void)hipFree(p);
+        if (p) dev_free_later(p, cap);
         p = nullptr; cap = 0;
         size_t want = n + n / 8 + 256;
-        const bool ok = hipMalloc(&p, want) == hipSuccess;
+        bool ok = hipMalloc(&p, want) == hipSuccess;
+        if (!ok) { dev_free_deferred(0); (void)hipGetLastError(); ok = hipMalloc(&p, want) == hipSuccess; }      /* (out of memory with old blocks waiting: they go first) */
         clock_gettime(CLOCK_MONOTONIC, &t1_);
         g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
         g_alloc_us.fetch_add((long long)((t1_.tv_sec - t0_.tv_sec) * 1000000ll + (t1_.tv_nsec - t0_.tv_nsec) / 1000), std::memory_order_relaxed);
@@ -336,6 +360,7 @@ extern "C" void crumble_hip_destroy(crumble_hip *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    dev_free_deferred(0);
     DevBuf *all[] = { &h->d_genlist, &h->d_vrec, &h->d_params, &h->d_tables, &h->d_stats, &h->d_batch_stats, &h->d_misc, &h->d_mqslot,
         &h->d_ufirst, &h->d_tcum, &h->d_tpart, &h->d_pbdirty, &h->d_pbcarry, &h->d_pbchg, &h->d_bases4, &h->d_pbwmm, &h->d_act, &h->d_pbstop, &h->d_pbrs, &h->d_pbruns, &h->d_pbval, &h->d_flag, &h->d_p0cnt, &h->d_p0part, &h->d_sr_ppos, &h->d_sr_pend, &h->d_kpos, &h->d_kend,
         &h->d_slow_g, &h->d_slow_r, &h->d_cix, &h->d_sr, &h->d_stile_lo, &h->d_stile_hi, &h->d_rr, &h->d_pos, &h->d_end, &h->d_mapq, &h->d_inplp, &h->d_seq_off, &h->d_cig_off, &h->d_seg_off,
@@ -438,6 +463,7 @@ struct DevSrc {
 };
 static int copy_raw(crumble_hip *h, const crumble_batch *b, const DevSrc *ds = nullptr)
 {
+    dev_free_deferred((size_t)1 << 30);                      /* (old blocks of grown buffers, once a gigabyte of them waits) */
     hipStream_t st = h->stream;
     const int64_t n = b->n_reads;
     /* the offset tables, or BAM's own per-read lengths (6 bytes per read over PCIe instead of 16; offsets made on the device) */

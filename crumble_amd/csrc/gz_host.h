@@ -93,6 +93,7 @@ extern "C" crumble_gz *crumble_gz_create(int device, int *err)
 extern "C" void crumble_gz_destroy(crumble_gz *g)
 {
     if (!g) return;
+    dev_free_deferred(0);
     (void)hipSetDevice(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     DevBuf *all[] = { &g->d_comp, &g->d_blk, &g->d_tokoff, &g->d_tok, &g->d_ntok, &g->d_status, &g->d_raw, &g->d_slots, &g->d_sizes,

@@ -66,6 +66,7 @@ extern "C" crumble_stream *crumble_stream_create(int device, int32_t n_ref, int6
 extern "C" void crumble_stream_destroy(crumble_stream *s)
 {
     if (!s) return;
+    dev_free_deferred(0);
     (void)hipSetDevice(s->device);
     if (s->gz && s->gz->stream) (void)hipStreamSynchronize(s->gz->stream);
     DevBuf *all[] = { &s->d_rec[0], &s->d_rec[1], &s->d_guess, &s->d_exit, &s->d_count, &s->d_slots, &s->d_coff, &s->d_recoff, &s->d_list,
