@@ -192,6 +192,31 @@ class Stream:
             raise CrumbleError(rc, "crumble_stream_drain", self.L)
         return out[:n.value]
 
+    def drain_begin(self, k, level=6, flush=True, cap=None):
+        """the drain's first half: marks the runs, enqueues the deflate of what a buffer of `cap` bytes takes; -> (record bytes
+        taken, cap); drain_end(cap) collects the members"""
+        gs = self.groups()
+        nbytes = gs[k - 1].byte_end if k else self.pending()
+        if cap is None:
+            cap = int(self.L.crumble_gz_deflate_bound(nbytes)) + 64
+        self.L.crumble_stream_drain_begin.restype = C.c_int
+        self.L.crumble_stream_drain_begin.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int64)]
+        taken = C.c_int64(0)
+        rc = self.L.crumble_stream_drain_begin(self.h, k, level, 1 if flush else 0, cap, C.byref(taken))
+        if rc:
+            raise CrumbleError(rc, "crumble_stream_drain_begin", self.L)
+        return taken.value, cap
+
+    def drain_end(self, cap):
+        self.L.crumble_stream_drain_end.restype = C.c_int
+        self.L.crumble_stream_drain_end.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        out = np.empty(max(cap, 1), np.uint8)
+        n = C.c_int64(0)
+        rc = self.L.crumble_stream_drain_end(self.h, out.ctypes.data, cap, C.byref(n))
+        if rc:
+            raise CrumbleError(rc, "crumble_stream_drain_end", self.L)
+        return out[:n.value]
+
     def peek(self):
         """(buffer bytes, record offsets)"""
         ln, nr = C.c_int64(0), C.c_int64(0)
