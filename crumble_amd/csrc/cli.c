@@ -906,6 +906,12 @@ int main(int argc, char **argv)
          * the device's one level does */
         dev_mode = can && (!strcmp(pm, "device") || (!strcmp(pm, "auto") && PIPELINE_AUTO_DEVICE && level < 7));
     }
+    /* The device pipeline runs a dozen streams (four engines, their field streams, the codec's); the runtime spreads streams
+     * over GPU_MAX_HW_QUEUES hardware queues, four by default, and with four the engines' kernels and the deflate's persistent
+     * workgroups get in each other's way on some boxes and not on others (measured, 24 contigs, a box each: 0.088 s and
+     * 0.118-0.182 s of loop with four queues, 0.092-0.096 s on all of them with two; six and more: slower everywhere).  Two
+     * unless the caller says otherwise; it must be in the environment before the runtime starts. */
+    if (dev_mode && !getenv("GPU_MAX_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "2", 0);
     int engines_one = 0;
     if (ngpu == 1 && !windowed && !getenv("CRUMBLE_HIP_DEVICES")) {      /* (the device pipeline too: its contig runs go to whichever engine is free) */
         const char *ev = getenv("CRUMBLE_HIP_ENGINES");
