@@ -21,6 +21,13 @@ import os
 import sys
 import time
 
+# The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (four by default).  The file -> file legs
+# start crumble-hip, whose device pipeline runs a dozen streams and sets two for itself; with THIS process holding four more
+# beside it the legs were box- and run-dependent (0.09-0.29 s of loop), with two here as well they are 0.089-0.091 s run after
+# run (profiles/NOTES_r06.md).  The timed step, the streamed legs and the other configurations measure the same either way
+# (174.1 / 174.1 Gbases/s, 26.5 / 27.0, 107 / 124).  Must be in the environment before the runtime starts; a caller's value wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
